@@ -1,0 +1,158 @@
+"""The oracle (oracle/) against the golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fir, folds, harness, lanczos, nested_cv, ridge, stats
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_fir_bit_exact(golden_dir):
+    g = load(golden_dir, "fir.npz")
+    for tag in "abcdefg":
+        out = fir.make_delayed(g[f"{tag}_stim"], g[f"{tag}_delays"].tolist(), bool(g[f"{tag}_circpad"]))
+        want = g[f"{tag}_out"]
+        assert out.dtype == want.dtype and out.shape == want.shape, tag
+        assert np.array_equal(out, want), tag
+
+
+def test_lanczos_kat_and_interp(golden_dir):
+    g = load(golden_dir, "downsample.npz")
+    assert np.array_equal(lanczos.lanczos_kernel(0.5, g["kat_t"], 3), g["kat_val"])
+    d, ot, nt = g["data"], g["oldtime"], g["newtime"]
+    np.testing.assert_allclose(lanczos.lanczos_interp(d, ot, nt, 3, 1.0), g["lanczos_w3"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(lanczos.lanczos_interp(d, ot, nt, 2, 0.5), g["lanczos_w2_c05"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(lanczos.lanczos_interp(d, ot, nt, 3, 1.0, True), g["lanczos_w3_rect"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(lanczos.lanczos_interp(g["data_f32"], ot, nt, 3, 1.0), g["lanczos_f32"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(lanczos.sinc_interp(d, ot, nt, 1.0, 3), g["sinc_w3"], rtol=0, atol=1e-13)
+
+
+def test_simple_downsamplers(golden_dir):
+    g = load(golden_dir, "downsample.npz")
+    d, ot, nt = g["data"], g["oldtime"], g["newtime"]
+    np.testing.assert_allclose(lanczos.rect(d, ot, nt), g["rect"], atol=1e-15)
+    for m in ("average", "sum", "last"):
+        np.testing.assert_allclose(lanczos.by_label(d, g["labels"], m), g[m], atol=1e-15)
+        np.testing.assert_allclose(lanczos.by_chunks(d, g["bounds"], m), g["legacy_" + m], atol=1e-15)
+
+
+def test_folds_identical(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "folds.json")))
+    for c in cases:
+        if c["seed"] is not None:
+            random.seed(c["seed"])
+            np.random.seed(c["seed"])
+        groups = np.array(c["groups"]) if "groups" in c else None
+        sp = folds.create_folds(c["n"], c["fold_type"], c["n_folds"], c["chunk_length"], c["trim_size"], groups)
+        got = [[list(map(int, a)), list(map(int, b))] for a, b in sp]
+        assert got == c["splits"], c["fold_type"]
+
+
+def test_fold_known_answers():
+    assert [(len(a), len(b)) for a, b in folds.create_folds(3000, "kfold", 5)] == [(2400, 600)] * 5
+    assert [(len(a), len(b)) for a, b in folds.create_folds(3000, "kfold_trimmed", 5)] == [(2400, 590)] * 5
+    random.seed(0)
+    assert [(len(a), len(b)) for a, b in folds.create_folds(3000, "chunked_trimmed", 5, 20)] == [(2400, 300)] * 5
+    assert [len(a) for a, _ in folds.create_folds(3000, "timeseries", 5)] == [500, 1000, 1500, 2000, 2500]
+    assert max(max(b) for _, b in folds.create_folds(3005, "chunked_contiguous", 5, 20)) == 2999
+    with pytest.raises(ValueError):          # groups landing in trim_size (nested_cv.py:130-132 positional bug)
+        folds.create_folds(300, "kfold_trimmed", 3, 20, np.arange(300))
+    with pytest.raises(ValueError):
+        folds.create_folds(10, "nope", 2)
+
+
+def test_ridge_solvers(golden_dir):
+    g = load(golden_dir, "ridge.npz")
+    alphas = g["alphas"]
+    for tag in ("wide", "tall"):
+        X = torch.tensor(g[f"{tag}_X"], dtype=torch.float32)
+        Y = torch.tensor(g[f"{tag}_Y"], dtype=torch.float32)
+        tr, va = g[f"{tag}_tr"], g[f"{tag}_va"]
+        for uc in (1, 0):
+            for na in (1, 0):
+                got = ridge.alpha_sweep_scores(X[tr], X[va], Y[tr], Y[va], alphas, 1e-10, bool(uc), bool(na)).numpy()
+                np.testing.assert_allclose(got, g[f"{tag}_scores_corr{uc}_norm{na}"], rtol=0, atol=1e-6)
+        val = torch.tensor(g[f"{tag}_valphas"])
+        for na in (1, 0):
+            got = ridge.ridge_weights(X[tr], Y[tr], val, 1e-10, bool(na)).numpy()
+            np.testing.assert_allclose(got, g[f"{tag}_W_norm{na}"], rtol=0, atol=1e-6)
+        got = ridge.ridge_weights(X[tr], Y[tr], 2.5, 1e-10, True).numpy()
+        np.testing.assert_allclose(got, g[f"{tag}_W_scalar"], rtol=0, atol=1e-6)
+
+
+def _check_fit(g, spec, name):
+    s = spec[name]
+    X, Y = g[f"X_{s['data']}"], g[f"Y_{s['data']}"]
+    random.seed(s["random_seed"])
+    np.random.seed(s["random_seed"])
+    kw = dict(s["kwargs"], alphas=g["alphas"])
+    if s["train_test"]:
+        m, W, a = nested_cv.fit_predict(X[:180], Y[:180], X_test=X[180:], y_test=Y[180:], **kw)
+    else:
+        m, W, a = nested_cv.fit_predict(X, Y, **kw)
+    pre = name + "__"
+    assert str(W.dtype) == s["types"]["W"] and str(a.dtype) == s["types"]["alphas"]
+    assert type(m["correlations"][0]).__name__ == s["types"]["corr_elem"]
+    np.testing.assert_allclose(a, g[pre + "alphas"], rtol=1e-6)
+    np.testing.assert_allclose(W, g[pre + "W"], rtol=0, atol=2e-6)
+    keys = sorted(k[len(pre) + 2:] for k in g.files if k.startswith(pre + "m_"))
+    assert keys == sorted(m.keys()), name
+    for k in keys:
+        want = g[pre + "m_" + k]
+        got = np.asarray(m[k])
+        if want.dtype == bool or want.dtype.kind in "iu":
+            assert np.array_equal(got, want), (name, k)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6, err_msg=f"{name}:{k}")
+
+
+def test_full_fits(golden_dir):
+    g = load(golden_dir, "fits.npz")
+    spec = json.load(open(os.path.join(golden_dir, "fits.json")))
+    for name in spec:
+        _check_fit(g, spec, name)
+
+
+def test_harness(golden_dir):
+    g = load(golden_dir, "harness.npz")
+    assert np.array_equal(harness.zs(g["zs_in"]), g["zs_out"])
+    stories = ["s0", "s1", "s2", "s3"]
+    feats = harness.delay_all({s: g[f"feat_{s}"] for s in stories}, [1, 2, 3, 4])
+    brain = {s: g[f"brain_{s}"] for s in stories}
+    trimming = {"train_features_start": 10, "train_features_end": -5, "train_targets_start": 0,
+                "train_targets_end": None, "test_features_start": 50, "test_features_end": -5,
+                "test_targets_start": 40, "test_targets_end": None}
+    d = harness.train_test_matrices(feats, brain, trimming)
+    for k in ("Rstim", "Rresp", "Pstim", "Presp"):
+        assert np.array_equal(d[k], g[k]), k
+    d = harness.concatenated_matrices(feats, brain, stories,
+                                      {"features_start": 10, "features_end": -5, "targets_start": 3, "targets_end": -12})
+    assert np.array_equal(d["X"], g["cat_X"]) and np.array_equal(d["Y"], g["cat_Y"])
+
+
+def test_bh_fdr_known_answers():
+    # hand-checkable: n=5, alpha=0.05 -> thresholds .01 .02 .03 .04 .05
+    p = np.array([0.04, 0.001, 0.03, 0.5, 0.011])
+    rej, adj = stats.bh_fdr(p, 0.05)
+    # sorted: .001 .011 .03 .04 .5 ; p*n/i: .005 .0275 .05 .05 .5 ; largest i with p<=i/n*a: i=4 (.04<=.04)
+    assert rej.tolist() == [True, True, True, False, True]
+    np.testing.assert_allclose(adj, [0.05, 0.005, 0.05, 0.5, 0.0275], atol=1e-15)
+    rej, adj = stats.bh_fdr(np.array([0.9, 0.8, 1.0]), 0.05)
+    assert not rej.any() and np.allclose(adj, [1.0, 1.0, 1.0])
+    rej, adj = stats.bh_fdr(np.array([0.2, 0.2, 0.2, 0.2]), 0.25)   # ties
+    assert rej.all() and np.allclose(adj, 0.2)
+
+
+def test_fisher_known_answers():
+    from scipy.stats import chi2
+    got = stats.fisher_combine([[0.01, 1.0], [0.2, 1.0], [0.5, 1.0]])
+    assert got[1] == 1.0
+    assert abs(got[0] - chi2.sf(-2 * np.log(0.01 * 0.2 * 0.5), 6)) < 1e-15
