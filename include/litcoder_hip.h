@@ -1,0 +1,196 @@
+/*
+ * litcoder_hip.h -- C ABI of liblitcoder_hip.so, the MI355X (gfx950) implementation of
+ * LITcoder's nested-CV ridge hot path (FIR delay stacking, Lanczos downsampling,
+ * the per-alpha ridge solve / prediction contractions, per-voxel correlation scoring).
+ *
+ * Conventions
+ *   - Every pointer named d_* is DEVICE memory owned by the caller (the Python host
+ *     allocates it as torch tensors and passes data_ptr()); h_* is host memory.
+ *     The library never allocates memory that outlives a call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All work is
+ *     enqueued asynchronously on it; nothing here synchronises unless stated.
+ *   - Matrices are row-major; `ld*` is the row stride in ELEMENTS.
+ *   - Return value: 0 = ok, <0 = error (LC_E_*); lc_last_error() gives the message
+ *     of the calling thread's last failure.
+ *   - Row-index lists are int32; an entry of -1 marks a padding row (contributes
+ *     nothing).
+ *
+ * Each entry point cites the reference call site it replaces (paths under
+ * /root/reference/encoding/).
+ */
+#ifndef LITCODER_HIP_H
+#define LITCODER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_OK 0
+#define LC_E_BADARG (-1)   /* null pointer, negative size, unsupported dtype ... */
+#define LC_E_SHAPE (-2)    /* sizes that violate a documented multiple / limit */
+#define LC_E_HIP (-3)      /* a HIP runtime call or kernel launch failed */
+#define LC_E_NOTSPD (-4)   /* Cholesky met a non-positive pivot (alpha == 0 on a singular Gram) */
+#define LC_E_ARCH (-5)     /* device is not gfx950 */
+
+#define LC_F32 0
+#define LC_F64 1
+
+#define LC_SCORE_CORR 0    /* ridge_regression.py:122-125 */
+#define LC_SCORE_R2 1      /* ridge_regression.py:126-130 */
+
+/* Padding granules the batched routines require (see DESIGN.md "Data layout"). */
+#define LC_NB 64           /* Gram/Cholesky block: N (train rows, padded) % LC_NB == 0 */
+#define LC_MB 32           /* score row-block: M (validation rows, padded) % LC_MB == 0 */
+
+typedef void* lc_stream_t;
+
+int lc_version(void);
+const char* lc_last_error(void);
+/* 0 when device `dev` is a gfx950; LC_E_ARCH otherwise. */
+int lc_check_device(int dev);
+
+/* ---------------------------------------------------------------- preprocessing */
+
+/* FIR.make_delayed (features/FIR_expander.py:24-43).  d_stim: (nt, ndim) f32 or f64,
+ * d_out: (nt, ndim*nd) f64, column block k = stim shifted by h_delays[k] rows;
+ * vacated rows zero, or wrapped when circpad.  Bit-exact copies. */
+int lc_fir_delay(const void* d_stim, int dtype, int64_t nt, int64_t ndim, int64_t ld_in,
+                 const int64_t* h_delays, int nd, int circpad,
+                 double* d_out, int64_t ld_out, lc_stream_t stream);
+
+/* lanczosinterp2D (downsample/interpdata.py:87-126) with lanczosfun (:45-63).
+ * d_data (n_old, D) f32|f64; d_oldtime (n_old), d_newtime (n_new) f64;
+ * cutoff = 1/mean(diff(newtime))*cutoff_mult is computed by the host (interpdata.py:107).
+ * d_out (n_new, D) f64, or (n_new, 2*D) = [neg | pos] when rectify. */
+int lc_lanczos_interp(const void* d_data, int dtype, int64_t n_old, int64_t D, int64_t ld_in,
+                      const double* d_oldtime, const double* d_newtime, int64_t n_new,
+                      double cutoff, double window, int rectify,
+                      double* d_out, int64_t ld_out, lc_stream_t stream);
+
+/* ---------------------------------------------------------------- casts / gathers */
+
+/* torch.tensor(x, dtype=float32) (models/nested_cv.py:99-100): f64 -> f32, (rows, cols)
+ * into a (possibly wider, zero-padded by the caller) destination. */
+int lc_cast_f64_f32(const double* d_in, int64_t ld_in, float* d_out, int64_t ld_out,
+                    int64_t rows, int64_t cols, lc_stream_t stream);
+
+/* out[r, j] = in[rows[r], cols ? cols[j] : j]   (nested_cv.py:200-201 row splits, plus the
+ * alpha-sorted voxel order used by the grouped refit).  rows[r] == -1 or cols[j] == -1 -> 0. */
+int lc_gather_f32(const float* d_in, int64_t ld_in, const int32_t* d_rows, int64_t n_rows,
+                  const int32_t* d_cols, int64_t n_cols, float* d_out, int64_t ld_out,
+                  lc_stream_t stream);
+
+/* acc[:, cols[j]] += scale * w[:, j]  (np.mean(fold_weights) accumulated on device,
+ * nested_cv.py:249,296); cols[j] == -1 skipped. */
+int lc_scatter_axpy_f32(const float* d_w, int64_t ld_w, int64_t n_rows, const int32_t* d_cols,
+                        int64_t n_cols, float scale, float* d_acc, int64_t ld_acc,
+                        lc_stream_t stream);
+
+/* ---------------------------------------------------------------- column statistics */
+
+/* DataNormalizer.fit (models/ridge_utils.py:94-125): per-column mean and UNBIASED std of
+ * the rows listed in d_rows (NULL = rows 0..n-1).  d_mean/d_std: (n_cols) f32. */
+int lc_col_mean_std_f32(const float* d_x, int64_t ld, const int32_t* d_rows, int64_t n_rows,
+                        int64_t n_cols, float* d_mean, float* d_std, lc_stream_t stream);
+
+/* DataNormalizer.transform (ridge_utils.py:127-166): x = (x - mean) / (std + eps), in place,
+ * all n_rows rows. */
+int lc_col_normalize_f32(float* d_x, int64_t ld, int64_t n_rows, int64_t n_cols,
+                         const float* d_mean, const float* d_std, float eps, lc_stream_t stream);
+
+/* scipy.stats.pearsonr per voxel (nested_cv.py:418-438): d_a, d_b (n, V) f32 -> d_r (V) f64
+ * Pearson r, NaN (constant column) reported as NaN; the host maps NaN -> 0 like the
+ * reference.  fp64 accumulation. */
+int lc_pearson_cols(const float* d_a, int64_t lda, const float* d_b, int64_t ldb,
+                    int64_t n, int64_t V, double* d_r, lc_stream_t stream);
+
+/* ---------------------------------------------------------------- small dense fp64 */
+
+/* K = X X' with fp64 accumulation; X (T, p) f32, K (T, T) f64.  Replaces the SVD of the
+ * design matrix (ridge_utils.py:52): every fold's train Gram and validation cross-Gram
+ * are row/column subsets of this one matrix. */
+int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_k, int64_t ldk,
+                lc_stream_t stream);
+
+/* Largest eigenvalue of K[rows_f, rows_f] for F row lists (each N entries, -1 padded)
+ * by `steps` Lanczos iterations + bisection: S[0]^2 of the fold's design matrix
+ * (ridge_regression.py:39,97 `norm = S[0].item()`).  d_work: F*(3*N + 2*steps + 8) f64.
+ * d_lmax: (F) f64. */
+int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, int N, int steps,
+                  double* d_work, double* d_lmax, lc_stream_t stream);
+
+/* a2[f*A + a] = (alphas[a] * (normalpha ? sqrt(lmax[f]) : 1))^2
+ * (ridge_regression.py:99-101,117: D = S/(S^2 + nalpha^2)). */
+int lc_penalties(const double* d_lmax, int F, const double* d_alphas, int A, int normalpha,
+                 double* d_a2, lc_stream_t stream);
+
+/* Build B = F*A augmented systems, batch b = f*A + a:
+ *   top    (N x N): K[tr_f, tr_f] + a2[b] I      (padding rows/cols -> identity)
+ *   bottom (M x N): K[va_f, tr_f]                (d_rhs == NULL; padding -> 0)
+ *                   or d_rhs[f] (M x N f64 panel, ld N) when d_rhs != NULL
+ * d_aug: (B, N+M, N) f64.  d_tr: (F, N) int32, d_va: (F, M) int32 (ignored with d_rhs). */
+int lc_batch_assemble(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
+                      const double* d_rhs, const double* d_a2, int F, int A, int N, int M,
+                      double* d_aug, lc_stream_t stream);
+
+/* In place on every (N+M, N) system: Cholesky of the top block, then bottom <- bottom * inv(top)
+ * i.e. the hat matrices  Xva Xtr' (Xtr Xtr' + a^2 I)^-1  (= Pstim Vh' diag(S/(S^2+a^2)) U',
+ * ridge_regression.py:104-105,117-120).  Result written as f32 to d_h (B, M, N).
+ * d_linv: workspace (B, N/LC_NB, LC_NB, LC_NB) f64.  d_info: (B) int32, nonzero = failed pivot. */
+int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
+                        int32_t* d_info, lc_stream_t stream);
+
+/* rhs[f] (p x N) f64 <- X[tr_f]' for the refit systems (rows of X listed in d_tr, -1 -> 0). */
+int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_tr, int N, int64_t p,
+                          double* d_out, lc_stream_t stream);
+
+/* ---------------------------------------------------------------- the V-wide contractions */
+
+/* Column statistics of the validation targets of one inner fold, feeding the fused scorer:
+ * d_ystat (3, V) f32 = [mean, unbiased std, unbiased var] of Y[va_rows] (z_score / .var,
+ * ridge_regression.py:108,111); d_yblk (M/LC_MB, V) f32 = per-32-row-block sums of (y - mean). */
+int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int M, int n_val,
+                 float* d_ystat, float* d_yblk, lc_stream_t stream);
+
+/* Fused alpha sweep of one inner fold (ridge_regression.py:115-133, K4+K5 of SURVEY 2.2):
+ *   pred_a = H_a (M x N) . Y[tr_rows] (N x V)    for a = 0..A-1, never stored;
+ *   score[a, v] = mean(z(Yva) z(pred_a))  or  signed sqrt|R2|,  NaN -> 0,
+ *   d_scores[a, v] (+)= score     (accumulate != 0 adds: the inner-fold mean, nested_cv.py:391).
+ * d_h (A*M, N) f32 hat matrices (row stride N); d_part workspace (A*M/LC_MB, 4, V) f32. */
+int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N,
+                          const float* d_y, int64_t ldy, int64_t V,
+                          const int32_t* d_tr, const int32_t* d_va, int n_val,
+                          const float* d_ystat, const float* d_yblk, int mode,
+                          float* d_part, float* d_scores, int accumulate, lc_stream_t stream);
+
+/* best[v] = first argmax_a scores[a, v] / n_folds (nested_cv.py:391-408); also
+ * d_rowsum[a] = sum_v scores[a, v] (f64) for the single-alpha path (:396-400, all-reduced
+ * across ranks by the host).  Either output may be NULL. */
+int lc_select_alpha(const float* d_scores, int A, int64_t V, int32_t* d_best, double* d_rowsum,
+                    lc_stream_t stream);
+
+/* Counting sort of voxels by alpha index (torch.unique / nonzero grouping,
+ * ridge_regression.py:46-50): d_perm = voxel ids grouped by alpha, stable, each group starting
+ * at a multiple of `pad` columns (slots between groups are left untouched: pre-fill d_perm,
+ * V + A*pad entries, with -1).  d_count (A) = group sizes. */
+int lc_group_by_alpha(const int32_t* d_best, int64_t V, int A, int pad, int32_t* d_perm,
+                      int32_t* d_count, lc_stream_t stream);
+
+/* Grouped plain GEMM, C[:, tile] = A_g(tile) . B[:, tile]   (f32 MFMA, 128-column tiles):
+ *   ridge_torch's  wt[:, sel] = Vh' diag(D) U' Y[:, sel]  (ridge_regression.py:56-61) with
+ *   A_g = X_tr'(K + a_g^2 I)^-1, and  y_pred = X_test @ wt  (nested_cv.py:151,251) with one group.
+ * d_a: (G, Mrows, K) f32, group stride a_group_stride elements; d_b: (K, Ncols) f32;
+ * d_c: (Mrows, Ncols) f32.  Ncols % 128 == 0, K % 32 == 0 (callers pad with zeros).
+ * h_group_tiles: G+1 column-tile offsets (host) -- group g owns tiles [h[g], h[g+1]).
+ * d_brows: optional row-index list for B (K entries, -1 = zero row). */
+int lc_gemm_grouped_f32(const float* d_a, int64_t lda, int64_t a_group_stride,
+                        const float* d_b, int64_t ldb, const int32_t* d_brows,
+                        float* d_c, int64_t ldc, int64_t Mrows, int64_t Ncols, int64_t K,
+                        const int32_t* h_group_tiles, int G, lc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LITCODER_HIP_H */

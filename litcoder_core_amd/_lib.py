@@ -1,0 +1,85 @@
+"""ctypes binding of liblitcoder_hip.so (C ABI declared in include/litcoder_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails this module
+raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``python -m litcoder_core_amd.build``.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblitcoder_hip.so")
+
+LC_F32, LC_F64 = 0, 1
+LC_SCORE_CORR, LC_SCORE_R2 = 0, 1
+LC_NB, LC_MB = 64, 32
+COL_TILE = 128          # voxel-axis padding granule of the MFMA kernels
+K_TILE = 32             # contraction-axis padding granule of the MFMA kernels
+
+_ptr = c_void_p
+# name -> (restype, argtypes); mirrors include/litcoder_hip.h one to one
+SIGNATURES = {
+    "lc_version": (c_int, []),
+    "lc_last_error": (c_char_p, []),
+    "lc_check_device": (c_int, [c_int]),
+    "lc_fir_delay": (c_int, [_ptr, c_int, c_int64, c_int64, c_int64, POINTER(c_int64), c_int, c_int, _ptr, c_int64, _ptr]),
+    "lc_lanczos_interp": (c_int, [_ptr, c_int, c_int64, c_int64, c_int64, _ptr, _ptr, c_int64, c_double, c_double,
+                                  c_int, _ptr, c_int64, _ptr]),
+    "lc_cast_f64_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64, _ptr]),
+    "lc_gather_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr]),
+    "lc_scatter_axpy_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, c_float, _ptr, c_int64, _ptr]),
+    "lc_col_mean_std_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, _ptr, _ptr, _ptr]),
+    "lc_col_normalize_f32": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, c_float, _ptr]),
+    "lc_pearson_cols": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64, _ptr, _ptr]),
+    "lc_gram_f64": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, c_int64, _ptr]),
+    "lc_lambda_max": (c_int, [_ptr, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
+    "lc_penalties": (c_int, [_ptr, c_int, _ptr, c_int, c_int, _ptr, _ptr]),
+    "lc_batch_assemble": (c_int, [_ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
+    "lc_batch_chol_solve": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr]),
+    "lc_transpose_rows_f64": (c_int, [_ptr, c_int64, _ptr, c_int, c_int64, _ptr, _ptr]),
+    "lc_val_stats": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, _ptr, _ptr, _ptr]),
+    "lc_alpha_sweep_scores": (c_int, [_ptr, c_int, c_int, c_int, _ptr, c_int64, c_int64, _ptr, _ptr, c_int, _ptr, _ptr,
+                                      c_int, _ptr, _ptr, c_int, _ptr]),
+    "lc_select_alpha": (c_int, [_ptr, c_int, c_int64, _ptr, _ptr, _ptr]),
+    "lc_group_by_alpha": (c_int, [_ptr, c_int64, c_int, c_int, _ptr, _ptr, _ptr]),
+    "lc_gemm_grouped_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, _ptr, _ptr, c_int64, c_int64, c_int64,
+                                    c_int64, POINTER(c_int32), c_int, _ptr]),
+}
+
+_lib = None
+
+
+class LitcoderHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LitcoderHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()). "
+            "litcoder_core_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().lc_last_error()
+        msg = msg.decode() if msg else ""
+        if rc == -2 or rc == -1:
+            raise ValueError(f"{what}: {msg} (code {rc})")
+        raise LitcoderHipError(f"{what}: {msg} (code {rc})")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,43 @@
+// Shared host-side plumbing for liblitcoder_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/litcoder_hip.h"
+
+namespace lc {
+
+void set_error(const char* fmt, ...);
+
+inline int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    set_error("%s", buf);
+    return code;
+}
+
+inline hipStream_t as_stream(lc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// After a kernel launch: surface launch-configuration errors without synchronising.
+inline int launched(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LC_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    return LC_OK;
+}
+
+template <typename T>
+inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
+
+inline long long imin(long long a, long long b) { return a < b ? a : b; }
+
+}  // namespace lc
+
+#define LC_REQUIRE(cond, code, ...) \
+    do { if (!(cond)) return lc::fail((code), __VA_ARGS__); } while (0)
+#define LC_HIP(call) \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) return lc::fail(LC_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)

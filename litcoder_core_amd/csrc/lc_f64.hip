@@ -1,0 +1,538 @@
+// The V-independent dense algebra of the fit, in fp64:
+//   Gram matrix K = X X', largest eigenvalue of fold sub-Grams (Lanczos + bisection), and the
+//   batched Cholesky / triangular solves that turn K into hat matrices
+//       H_a = Xva Xtr' (Xtr Xtr' + a^2 I)^-1
+//   for every (fold, alpha) at once.  This replaces the 30 thin SVDs of the reference
+//   (ridge_utils.py:52): with U S Vh = svd(Xtr),  Pstim Vh' diag(S/(S^2+a^2)) U' == H_a exactly.
+//
+// Everything that is GEMM-shaped goes through one 64x64x64 register-tiled fp64 product
+// (vector fp64 FMA rate == matrix fp64 rate on gfx950, so VALU tiles are the simple choice).
+#include "lc_common.h"
+
+namespace {
+
+constexpr int NB = LC_NB;   // 64
+
+// ------------------------------------------------------------------ 64x64 tile product
+// acc[4][4] (rows ty*4.., cols tx*4..) += sum_k Aop[m][k] * Bop[k][n] over a 64-deep K.
+// The A operand is always given as global [m][k] (row stride lda); the B operand either as
+// global [n][k] (BT = true: "N x T" product) or as [k][n] (BT = false).  Rows beyond
+// a_rows / b_rows are treated as zero.  256 threads.
+constexpr int TS_LD = 64 + 2;   // LDS row stride (doubles) of the k-major staged tiles
+
+__device__ inline void stage_t(double* s, const double* __restrict__ g, long long ld, int rows_valid, int k0) {
+    // global [idx][k] -> s[k][idx];  thread: idx = tid % 64, k = 8*(tid/64) .. +7
+    const int idx = threadIdx.x & 63, kb = (threadIdx.x >> 6) * 8;
+    if (idx < rows_valid) {
+        const double* src = g + (long long)idx * ld + k0 + kb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[(kb + e) * TS_LD + idx] = src[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[(kb + e) * TS_LD + idx] = 0.0;
+    }
+}
+
+__device__ inline void stage_n(double* s, const double* __restrict__ g, long long ld, int k0) {
+    // global [k][n] -> s[k][n];  thread: n = tid % 64, k = 8*(tid/64) .. +7
+    const int n = threadIdx.x & 63, kb = (threadIdx.x >> 6) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[(kb + e) * TS_LD + n] = g[(long long)(k0 + kb + e) * ld + n];
+}
+
+template <bool BT>
+__device__ inline void tile_product(double (&acc)[4][4], const double* __restrict__ A, long long lda, int a_rows,
+                                    const double* __restrict__ B, long long ldb, int b_rows, double* sA, double* sB) {
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    for (int k0 = 0; k0 < NB; k0 += 32) {
+        __syncthreads();
+        stage_t(sA, A, lda, a_rows, k0);
+        if (BT) stage_t(sB, B, ldb, b_rows, k0);
+        else stage_n(sB, B, ldb, k0);
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sA[k * TS_LD + ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sB[k * TS_LD + tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ Gram matrix
+// K[i][j] = sum_k X[i][k] X[j][k], fp32 inputs, fp64 products and sums.  Lower-triangle tiles are
+// computed and mirrored.
+__global__ void __launch_bounds__(256) k_gram(const float* __restrict__ X, long long ldx, int T, int p,
+                                              double* __restrict__ Kmat, long long ldk) {
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    __shared__ double sA[16 * TS_LD], sB[16 * TS_LD];
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;    // loader: row 0..63, k offset 0,4,8,12
+    const int ra = bi * 64 + lr, rb = bj * 64 + lr;
+    double acc[4][4] = {};
+    for (int k0 = 0; k0 < p; k0 += 16) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + lk + e;
+            sA[(lk + e) * TS_LD + lr] = (ra < T && k < p) ? (double)X[(long long)ra * ldx + k] : 0.0;
+            sB[(lk + e) * TS_LD + lr] = (rb < T && k < p) ? (double)X[(long long)rb * ldx + k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sA[k * TS_LD + ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sB[k * TS_LD + tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = bi * 64 + ty * 4 + i, c = bj * 64 + tx * 4 + j;
+            if (r < T && c < T) {
+                Kmat[(long long)r * ldk + c] = acc[i][j];
+                if (bi != bj) Kmat[(long long)c * ldk + r] = acc[i][j];
+            }
+        }
+}
+
+// ------------------------------------------------------------------ lambda_max (Lanczos)
+// Per fold f the work area holds: v[N], vprev[N], w[N], a[steps], b[steps], meta[8].
+__device__ inline double* lz_base(double* work, int f, int N, int steps) {
+    return work + (long long)f * (3ll * N + 2ll * steps + 8);
+}
+
+__global__ void __launch_bounds__(256) k_lz_init(const int* __restrict__ rows, int N, int steps, double* work) {
+    __shared__ double red[256];
+    const int f = blockIdx.x;
+    double* base = lz_base(work, f, N, steps);
+    double* v = base;
+    double* vp = base + N;
+    const int* rw = rows + (long long)f * N;
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        // fixed pseudo-random start vector (integer hash -> (-1, 1)), zero on padding rows
+        unsigned h = (unsigned)i * 2654435761u + 12345u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const double x = rw[i] >= 0 ? ((double)(h & 0xFFFFFF) / 8388608.0 - 1.0) + 1.5 : 0.0;
+        v[i] = x;
+        vp[i] = 0.0;
+        ss += x * x;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    const double inv = red[0] > 0.0 ? 1.0 / sqrt(red[0]) : 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) v[i] *= inv;
+    if (threadIdx.x < 8) base[3ll * N + 2ll * steps + threadIdx.x] = 0.0;   // meta: [0]=steps done, [1]=stopped, [2]=prev beta
+}
+
+// w = K[rows, rows] v : one wave per row.
+__global__ void __launch_bounds__(256) k_lz_symv(const double* __restrict__ Kmat, long long ldk,
+                                                 const int* __restrict__ rows, int N, int steps, double* work) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= N) return;
+    double* base = lz_base(work, f, N, steps);
+    const double* v = base;
+    double* w = base + 2ll * N;
+    const int* rw = rows + (long long)f * N;
+    const int r = rw[i];
+    double s = 0.0;
+    if (r >= 0) {
+        const double* krow = Kmat + (long long)r * ldk;
+        for (int j = lane; j < N; j += 64) {
+            const int c = rw[j];
+            if (c >= 0) s += krow[c] * v[j];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) w[i] = s;
+}
+
+__device__ inline double block_sum_1024(double x, double* red) {
+    red[threadIdx.x] = x;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    const double t = red[0];
+    __syncthreads();
+    return t;
+}
+
+// One Lanczos recurrence step per fold: a = v.w ; w -= a v + b_prev vprev ; b = |w| ; rotate.
+__global__ void __launch_bounds__(1024) k_lz_step(int N, int steps, int step, double* work) {
+    __shared__ double red[1024];
+    const int f = blockIdx.x;
+    double* base = lz_base(work, f, N, steps);
+    double* v = base;
+    double* vp = base + N;
+    double* w = base + 2ll * N;
+    double* al = base + 3ll * N;
+    double* be = al + steps;
+    double* meta = be + steps;
+    if (meta[1] != 0.0) return;                       // already stopped (invariant subspace found)
+    double d = 0.0;
+    for (int i = threadIdx.x; i < N; i += 1024) d += v[i] * w[i];
+    const double a = block_sum_1024(d, red);
+    const double bprev = meta[2];
+    double nn = 0.0;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const double x = w[i] - a * v[i] - bprev * vp[i];
+        w[i] = x;
+        nn += x * x;
+    }
+    const double b = sqrt(block_sum_1024(nn, red));
+    const bool stop = !(b > 1e-13 * (fabs(a) + bprev));
+    const double inv = stop ? 0.0 : 1.0 / b;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        vp[i] = v[i];
+        v[i] = w[i] * inv;
+    }
+    if (threadIdx.x == 0) {
+        al[step] = a;
+        be[step] = b;
+        meta[0] = (double)(step + 1);
+        meta[2] = b;
+        if (stop) meta[1] = 1.0;
+    }
+}
+
+// Largest eigenvalue of the k x k tridiagonal (a, b) by bisection on the Sturm count.
+__global__ void k_lz_eig(int N, int steps, double* work, double* __restrict__ lmax) {
+    const int f = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double* base = lz_base(work, f, N, steps);
+    const double* al = base + 3ll * N;
+    const double* be = al + steps;
+    const int k = (int)(be + steps)[0];
+    if (k <= 0) { lmax[f] = 0.0; return; }
+    double lo = al[0], hi = al[0];
+    for (int i = 0; i < k; ++i) {
+        const double bl = i > 0 ? fabs(be[i - 1]) : 0.0, br = i + 1 < k ? fabs(be[i]) : 0.0;
+        lo = fmin(lo, al[i] - bl - br);
+        hi = fmax(hi, al[i] + bl + br);
+    }
+    // count(x) = number of eigenvalues < x ; we want the smallest x with count(x) == k
+    for (int it = 0; it < 200 && hi > lo; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        int cnt = 0;
+        double q = al[0] - mid;
+        if (q < 0.0) ++cnt;
+        for (int i = 1; i < k; ++i) {
+            const double den = q != 0.0 ? q : 1e-300;
+            q = al[i] - mid - be[i - 1] * be[i - 1] / den;
+            if (q < 0.0) ++cnt;
+        }
+        if (cnt >= k) hi = mid; else lo = mid;
+    }
+    lmax[f] = hi;
+}
+
+__global__ void k_penalties(const double* __restrict__ lmax, int F, const double* __restrict__ alphas, int A,
+                            int normalpha, double* __restrict__ a2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F * A) return;
+    const int f = i / A, a = i - f * A;
+    const double s0 = normalpha ? sqrt(lmax[f]) : 1.0;
+    const double na = alphas[a] * s0;
+    a2[i] = na * na;
+}
+
+// ------------------------------------------------------------------ batch assembly
+__global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ Kmat, long long ldk,
+                                                  const int* __restrict__ tr, const int* __restrict__ va,
+                                                  const double* __restrict__ rhs, const double* __restrict__ a2, int A,
+                                                  int N, int M, double* __restrict__ aug) {
+    const int i = blockIdx.x;             // row of the (N+M) x N system
+    const int b = blockIdx.y;
+    const int f = b / A;
+    const int* trf = tr + (long long)f * N;
+    double* dst = aug + ((long long)b * (N + M) + i) * N;
+    if (i < N) {
+        const int r = trf[i];
+        const double diag = r >= 0 ? a2[b] : 1.0;
+        for (int j = threadIdx.x; j < N; j += 256) {
+            const int c = trf[j];
+            double v = (r >= 0 && c >= 0) ? Kmat[(long long)r * ldk + c] : 0.0;
+            if (j == i) v = (r >= 0 ? v : 0.0) + diag;
+            dst[j] = v;
+        }
+    } else if (rhs) {
+        const double* src = rhs + ((long long)f * M + (i - N)) * N;
+        for (int j = threadIdx.x; j < N; j += 256) dst[j] = src[j];
+    } else {
+        const int r = va[(long long)f * M + (i - N)];
+        for (int j = threadIdx.x; j < N; j += 256) {
+            const int c = trf[j];
+            dst[j] = (r >= 0 && c >= 0) ? Kmat[(long long)r * ldk + c] : 0.0;
+        }
+    }
+}
+
+// rhs[c][j] = X[tr[j]][c]  (p x N panel for the refit systems), 32x32 LDS transpose.
+__global__ void __launch_bounds__(256) k_transpose_rows(const float* __restrict__ X, long long ldx,
+                                                        const int* __restrict__ tr, int N, long long p,
+                                                        double* __restrict__ out) {
+    __shared__ float t[32][33];
+    const int j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int jj = ty; jj < 32; jj += 8) {
+        const int j = j0 + jj;
+        const int r = j < N ? tr[j] : -1;
+        const long long c = c0 + tx;
+        t[jj][tx] = (r >= 0 && c < p) ? X[(long long)r * ldx + c] : 0.f;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 32; cc += 8) {
+        const long long c = c0 + cc;
+        const int j = j0 + tx;
+        if (c < p && j < N) out[c * N + j] = (double)t[tx][cc];
+    }
+}
+
+// ------------------------------------------------------------------ blocked Cholesky pieces
+// Diagonal block k: L_kk = chol(A_kk) in LDS, then Linv = inv(L_kk).  One block per system.
+__global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ aug, int N, int M, int k,
+                                                    double* __restrict__ linv, int* __restrict__ info) {
+    __shared__ double L[NB][NB];
+    __shared__ double Li[NB][NB];
+    const int b = blockIdx.x;
+    double* a = aug + (long long)b * (N + M) * N + (long long)k * NB * N + k * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) L[e >> 6][e & 63] = a[(long long)(e >> 6) * N + (e & 63)];
+    __syncthreads();
+    for (int j = 0; j < NB; ++j) {
+        const double d = L[j][j];
+        if (threadIdx.x == 0 && !(d > 0.0) && info[b] == 0) info[b] = k * NB + j + 1;
+        const double sd = sqrt(d);
+        __syncthreads();
+        if (threadIdx.x == 0) L[j][j] = sd;
+        for (int i = j + 1 + threadIdx.x; i < NB; i += 256) L[i][j] /= sd;
+        __syncthreads();
+        // trailing update of the lower triangle: L[i][c] -= L[i][j] * L[c][j], j < c <= i
+        const int rem = NB - 1 - j;
+        for (int e = threadIdx.x; e < rem * rem; e += 256) {
+            const int i = j + 1 + e / rem, c = j + 1 + e % rem;
+            if (c <= i) L[i][c] -= L[i][j] * L[c][j];
+        }
+        __syncthreads();
+    }
+    // inverse of the lower-triangular L: column c solved by forward substitution (one thread each)
+    if (threadIdx.x < NB) {
+        const int c = threadIdx.x;
+        for (int i = 0; i < NB; ++i) Li[i][c] = 0.0;
+        Li[c][c] = 1.0 / L[c][c];
+        for (int i = c + 1; i < NB; ++i) {
+            double s = 0.0;
+            for (int t = c; t < i; ++t) s += L[i][t] * Li[t][c];
+            Li[i][c] = -s / L[i][i];
+        }
+    }
+    __syncthreads();
+    double* lo = linv + ((long long)b * (N / NB) + k) * NB * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        a[(long long)i * N + j] = j <= i ? L[i][j] : 0.0;
+        lo[e] = Li[i][j];
+    }
+}
+
+// Panel: rows below the diagonal block (including the M augmented rows):  P <- P * Linv_kk'.
+__global__ void __launch_bounds__(256) k_panel(double* __restrict__ aug, int N, int M, int k,
+                                               const double* __restrict__ linv) {
+    __shared__ double sA[32 * TS_LD], sB[32 * TS_LD];
+    const int b = blockIdx.y;
+    const int R = N + M;
+    const int r0 = (k + 1) * NB + blockIdx.x * NB;
+    double* base = aug + (long long)b * R * N;
+    double* P = base + (long long)r0 * N + k * NB;
+    const double* Li = linv + ((long long)b * (N / NB) + k) * NB * NB;
+    const int rows = min(NB, R - r0);
+    double acc[4][4] = {};
+    tile_product<true>(acc, P, N, rows, Li, NB, NB, sA, sB);     // C[r][c] = sum_j P[r][j] Linv[c][j]
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ty * 4 + i < rows)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) P[(long long)(ty * 4 + i) * N + tx * 4 + j] = acc[i][j];
+}
+
+// Trailing update: A_ij -= L_ik L_jk'  for column tiles j > k and row tiles i >= j (rows to N+M).
+__global__ void __launch_bounds__(256) k_trailing(double* __restrict__ aug, int N, int M, int k) {
+    __shared__ double sA[32 * TS_LD], sB[32 * TS_LD];
+    const int b = blockIdx.z;
+    const int tj = k + 1 + blockIdx.x, ti = k + 1 + blockIdx.y;
+    if (ti < tj) return;
+    const int R = N + M;
+    const int r0 = ti * NB;
+    if (r0 >= R) return;
+    double* base = aug + (long long)b * R * N;
+    const double* Pi = base + (long long)r0 * N + k * NB;
+    const double* Pj = base + (long long)tj * NB * N + k * NB;
+    const int rows = min(NB, R - r0);
+    double acc[4][4] = {};
+    tile_product<true>(acc, Pi, N, rows, Pj, N, NB, sA, sB);
+    double* Cij = base + (long long)r0 * N + tj * NB;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ty * 4 + i < rows)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Cij[(long long)(ty * 4 + i) * N + tx * 4 + j] -= acc[i][j];
+}
+
+// Backward substitution on the augmented rows Z (M x N):  solve H L = Z block column by block column,
+// from the last to the first.  Step k:  H_k = Z_k Linv_kk ;  Z_j -= H_k L_kj  for j < k.
+__global__ void __launch_bounds__(256) k_back_diag(double* __restrict__ aug, int N, int M, int k,
+                                                   const double* __restrict__ linv) {
+    __shared__ double sA[32 * TS_LD], sB[32 * TS_LD];
+    const int b = blockIdx.y;
+    const int r0 = N + blockIdx.x * NB;
+    const int R = N + M;
+    double* Z = aug + (long long)b * R * N + (long long)r0 * N + k * NB;
+    const double* Li = linv + ((long long)b * (N / NB) + k) * NB * NB;
+    const int rows = min(NB, R - r0);
+    double acc[4][4] = {};
+    tile_product<false>(acc, Z, N, rows, Li, NB, NB, sA, sB);    // C[r][c] = sum_j Z[r][j] Linv[j][c]
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ty * 4 + i < rows)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Z[(long long)(ty * 4 + i) * N + tx * 4 + j] = acc[i][j];
+}
+
+__global__ void __launch_bounds__(256) k_back_update(double* __restrict__ aug, int N, int M, int k) {
+    __shared__ double sA[32 * TS_LD], sB[32 * TS_LD];
+    const int b = blockIdx.z;
+    const int tj = blockIdx.x;                      // column tile j < k
+    const int r0 = N + blockIdx.y * NB;
+    const int R = N + M;
+    double* base = aug + (long long)b * R * N;
+    const double* Hk = base + (long long)r0 * N + k * NB;
+    const double* Lkj = base + (long long)k * NB * N + tj * NB;     // [t][c] = L[k*NB+t][tj*NB+c]
+    const int rows = min(NB, R - r0);
+    double acc[4][4] = {};
+    tile_product<false>(acc, Hk, N, rows, Lkj, N, NB, sA, sB);
+    double* Zj = base + (long long)r0 * N + tj * NB;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ty * 4 + i < rows)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Zj[(long long)(ty * 4 + i) * N + tx * 4 + j] -= acc[i][j];
+}
+
+__global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ aug, int N, int M, float* __restrict__ h) {
+    const int i = blockIdx.x, b = blockIdx.y;
+    const double* src = aug + ((long long)b * (N + M) + N + i) * N;
+    float* dst = h + ((long long)b * M + i) * N;
+    for (int j = threadIdx.x; j < N; j += 256) dst[j] = (float)src[j];
+}
+
+}  // namespace
+
+extern "C" int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_k, int64_t ldk,
+                           lc_stream_t stream) {
+    LC_REQUIRE(d_x && d_k, LC_E_BADARG, "lc_gram_f64: null pointer");
+    LC_REQUIRE(T > 0 && p > 0 && ldx >= p && ldk >= T && T < (1 << 30), LC_E_SHAPE, "lc_gram_f64: bad shape");
+    const unsigned nt = (unsigned)lc::ceil_div<long long>(T, 64);
+    hipLaunchKernelGGL(k_gram, dim3(nt, nt), dim3(256), 0, lc::as_stream(stream), d_x, (long long)ldx, (int)T, (int)p,
+                       d_k, (long long)ldk);
+    return lc::launched("k_gram");
+}
+
+extern "C" int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, int N, int steps,
+                             double* d_work, double* d_lmax, lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_rows && d_work && d_lmax, LC_E_BADARG, "lc_lambda_max: null pointer");
+    LC_REQUIRE(F > 0 && N > 0 && steps > 0, LC_E_SHAPE, "lc_lambda_max: bad shape");
+    hipStream_t s = lc::as_stream(stream);
+    hipLaunchKernelGGL(k_lz_init, dim3(F), dim3(256), 0, s, d_rows, N, steps, d_work);
+    if (int rc = lc::launched("k_lz_init")) return rc;
+    for (int it = 0; it < steps; ++it) {
+        hipLaunchKernelGGL(k_lz_symv, dim3((unsigned)lc::ceil_div(N, 4), (unsigned)F), dim3(256), 0, s, d_k,
+                           (long long)ldk, d_rows, N, steps, d_work);
+        hipLaunchKernelGGL(k_lz_step, dim3(F), dim3(1024), 0, s, N, steps, it, d_work);
+    }
+    if (int rc = lc::launched("k_lz_step")) return rc;
+    hipLaunchKernelGGL(k_lz_eig, dim3(F), dim3(64), 0, s, N, steps, d_work, d_lmax);
+    return lc::launched("k_lz_eig");
+}
+
+extern "C" int lc_penalties(const double* d_lmax, int F, const double* d_alphas, int A, int normalpha, double* d_a2,
+                            lc_stream_t stream) {
+    LC_REQUIRE(d_alphas && d_a2 && (d_lmax || !normalpha), LC_E_BADARG, "lc_penalties: null pointer");
+    LC_REQUIRE(F > 0 && A > 0, LC_E_SHAPE, "lc_penalties: bad shape");
+    hipLaunchKernelGGL(k_penalties, dim3((unsigned)lc::ceil_div(F * A, 256)), dim3(256), 0, lc::as_stream(stream),
+                       d_lmax, F, d_alphas, A, normalpha, d_a2);
+    return lc::launched("k_penalties");
+}
+
+extern "C" int lc_batch_assemble(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
+                                 const double* d_rhs, const double* d_a2, int F, int A, int N, int M, double* d_aug,
+                                 lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_tr && d_a2 && d_aug && (d_va || d_rhs), LC_E_BADARG, "lc_batch_assemble: null pointer");
+    LC_REQUIRE(F > 0 && A > 0 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0 && F * A <= 65535, LC_E_SHAPE,
+               "lc_batch_assemble: need N %% %d == 0, M %% %d == 0, F*A <= 65535", LC_NB, LC_MB);
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)(N + M), (unsigned)(F * A)), dim3(256), 0, lc::as_stream(stream), d_k,
+                       (long long)ldk, d_tr, d_va, d_rhs, d_a2, A, N, M, d_aug);
+    return lc::launched("k_assemble");
+}
+
+extern "C" int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_tr, int N, int64_t p,
+                                     double* d_out, lc_stream_t stream) {
+    LC_REQUIRE(d_x && d_tr && d_out, LC_E_BADARG, "lc_transpose_rows_f64: null pointer");
+    LC_REQUIRE(N > 0 && p > 0 && ldx >= p, LC_E_SHAPE, "lc_transpose_rows_f64: bad shape");
+    dim3 grid((unsigned)lc::ceil_div(N, 32), (unsigned)lc::ceil_div<long long>(p, 32));
+    hipLaunchKernelGGL(k_transpose_rows, grid, dim3(256), 0, lc::as_stream(stream), d_x, (long long)ldx, d_tr, N,
+                       (long long)p, d_out);
+    return lc::launched("k_transpose_rows");
+}
+
+extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, int32_t* d_info,
+                                   lc_stream_t stream) {
+    LC_REQUIRE(d_aug && d_linv && d_h && d_info, LC_E_BADARG, "lc_batch_chol_solve: null pointer");
+    LC_REQUIRE(B > 0 && B <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
+               "lc_batch_chol_solve: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
+    hipStream_t s = lc::as_stream(stream);
+    LC_HIP(hipMemsetAsync(d_info, 0, sizeof(int32_t) * B, s));
+    const int nb = N / NB;
+    const int R = N + M;
+    const int mt = lc::ceil_div(M, NB);                      // row tiles of the augmented part
+    for (int k = 0; k < nb; ++k) {
+        hipLaunchKernelGGL(k_potrf_diag, dim3(B), dim3(256), 0, s, d_aug, N, M, k, d_linv, d_info);
+        const int below = lc::ceil_div(R - (k + 1) * NB, NB);   // row tiles under the diagonal block
+        if (below > 0) hipLaunchKernelGGL(k_panel, dim3(below, B), dim3(256), 0, s, d_aug, N, M, k, d_linv);
+        const int ct = nb - 1 - k;                              // trailing column tiles
+        if (ct > 0)
+            hipLaunchKernelGGL(k_trailing, dim3(ct, below, B), dim3(256), 0, s, d_aug, N, M, k);
+    }
+    if (int rc = lc::launched("cholesky sweep")) return rc;
+    for (int k = nb - 1; k >= 0; --k) {
+        hipLaunchKernelGGL(k_back_diag, dim3(mt, B), dim3(256), 0, s, d_aug, N, M, k, d_linv);
+        if (k > 0) hipLaunchKernelGGL(k_back_update, dim3(k, mt, B), dim3(256), 0, s, d_aug, N, M, k);
+    }
+    if (int rc = lc::launched("back substitution")) return rc;
+    hipLaunchKernelGGL(k_extract_h, dim3(M, B), dim3(256), 0, s, d_aug, N, M, d_h);
+    return lc::launched("k_extract_h");
+}

@@ -1,0 +1,147 @@
+// FIR delay stacking and Lanczos downsampling: HBM-bound, coalesced along the feature axis.
+#include "lc_common.h"
+
+namespace {
+
+constexpr int FIR_MAX_DELAYS = 16;
+
+struct FirDelays {
+    long long d[FIR_MAX_DELAYS];
+    int n;
+};
+
+// One thread per output element; grid.x = time row, grid.y covers (delay, feature).
+// out[r, k*ndim + c] = stim[r - d_k, c] when that row exists, else 0 (or wrapped).
+template <typename T>
+__global__ void __launch_bounds__(256) k_fir_delay(const T* __restrict__ stim, long long nt, long long ndim,
+                                                   long long ld_in, FirDelays dl, int circpad,
+                                                   double* __restrict__ out, long long ld_out, long long col0) {
+    const long long r = blockIdx.x;
+    const long long e = (long long)blockIdx.y * blockDim.x + threadIdx.x;   // index into (k, c)
+    if (e >= (long long)dl.n * ndim) return;
+    const int k = (int)(e / ndim);
+    const long long c = e - (long long)k * ndim;
+    const long long d = dl.d[k];
+    long long src = r - d;
+    double v = 0.0;
+    const bool far = (d >= nt) || (-d >= nt);
+    if (far) {
+        // Slice arithmetic of the reference: |d| >= nt copies everything unshifted when
+        // wrapping, and leaves zeros otherwise (oracle/fir.py).
+        if (circpad) v = (double)stim[r * ld_in + c];
+    } else if (src >= 0 && src < nt) {
+        v = (double)stim[src * ld_in + c];
+    } else if (circpad) {
+        src = src < 0 ? src + nt : src - nt;
+        v = (double)stim[src * ld_in + c];
+    }
+    out[r * ld_out + col0 + e] = v;
+}
+
+// One block per output time point and 1024-column slab.  Weights of a chunk of input
+// samples are evaluated once into LDS (fp64 sin), then every thread streams its columns
+// down the chunk, skipping samples outside the window (weight exactly 0).
+constexpr int LZ_THREADS = 256;
+constexpr int LZ_CPT = 4;       // columns per thread, strided by LZ_THREADS -> coalesced rows
+constexpr int LZ_CHUNK = 1024;  // input samples per weight chunk
+
+template <typename T, bool RECTIFY>
+__global__ void __launch_bounds__(LZ_THREADS) k_lanczos(const T* __restrict__ data, long long n_old, long long D,
+                                                        long long ld_in, const double* __restrict__ oldtime,
+                                                        const double* __restrict__ newtime, double cutoff,
+                                                        double window, double* __restrict__ out, long long ld_out) {
+    __shared__ double w[LZ_CHUNK];
+    const long long i = blockIdx.x;
+    const long long cbase = (long long)blockIdx.y * (LZ_THREADS * LZ_CPT) + threadIdx.x;
+    const double tn = newtime[i];
+    double acc[LZ_CPT], accp[LZ_CPT];
+#pragma unroll
+    for (int q = 0; q < LZ_CPT; ++q) { acc[q] = 0.0; accp[q] = 0.0; }
+    constexpr double PI = 3.141592653589793;
+    for (long long j0 = 0; j0 < n_old; j0 += LZ_CHUNK) {
+        const int len = (int)min((long long)LZ_CHUNK, n_old - j0);
+        for (int j = threadIdx.x; j < len; j += LZ_THREADS) {
+            const double t = (tn - oldtime[j0 + j]) * cutoff;
+            double v;
+            if (t == 0.0) v = 1.0;
+            else if (fabs(t) > window) v = 0.0;
+            else v = window * sin(PI * t) * sin(PI * t / window) / ((PI * PI) * (t * t));
+            w[j] = v;
+        }
+        __syncthreads();
+        for (int j = 0; j < len; ++j) {
+            const double wj = w[j];
+            if (wj == 0.0) continue;   // uniform across the block
+            const T* row = data + (j0 + j) * ld_in;
+#pragma unroll
+            for (int q = 0; q < LZ_CPT; ++q) {
+                const long long c = cbase + (long long)q * LZ_THREADS;
+                if (c < D) {
+                    const double x = (double)row[c];
+                    if (RECTIFY) {
+                        acc[q] += wj * fmin(x, 0.0);
+                        accp[q] += wj * fmax(x, 0.0);
+                    } else {
+                        acc[q] += wj * x;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < LZ_CPT; ++q) {
+        const long long c = cbase + (long long)q * LZ_THREADS;
+        if (c < D) {
+            out[i * ld_out + c] = acc[q];
+            if (RECTIFY) out[i * ld_out + D + c] = accp[q];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lc_fir_delay(const void* d_stim, int dtype, int64_t nt, int64_t ndim, int64_t ld_in,
+                            const int64_t* h_delays, int nd, int circpad, double* d_out, int64_t ld_out,
+                            lc_stream_t stream) {
+    LC_REQUIRE(d_stim && d_out && h_delays, LC_E_BADARG, "lc_fir_delay: null pointer");
+    LC_REQUIRE(nt >= 0 && ndim >= 0 && nd >= 0, LC_E_BADARG, "lc_fir_delay: negative size");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, LC_E_BADARG, "lc_fir_delay: dtype %d unsupported", dtype);
+    LC_REQUIRE(ld_in >= ndim && ld_out >= ndim * nd, LC_E_SHAPE, "lc_fir_delay: leading dimension too small");
+    if (nt == 0 || ndim == 0 || nd == 0) return LC_OK;
+    hipStream_t s = lc::as_stream(stream);
+    for (int k0 = 0; k0 < nd; k0 += FIR_MAX_DELAYS) {
+        FirDelays dl;
+        dl.n = nd - k0 < FIR_MAX_DELAYS ? nd - k0 : FIR_MAX_DELAYS;
+        for (int k = 0; k < dl.n; ++k) dl.d[k] = h_delays[k0 + k];
+        dim3 grid((unsigned)nt, (unsigned)lc::ceil_div<long long>((long long)dl.n * ndim, 256));
+        const long long col0 = (long long)k0 * ndim;
+        if (dtype == LC_F32)
+            hipLaunchKernelGGL(k_fir_delay<float>, grid, dim3(256), 0, s, (const float*)d_stim, nt, ndim, ld_in, dl,
+                               circpad, d_out, ld_out, col0);
+        else
+            hipLaunchKernelGGL(k_fir_delay<double>, grid, dim3(256), 0, s, (const double*)d_stim, nt, ndim, ld_in,
+                               dl, circpad, d_out, ld_out, col0);
+        if (int rc = lc::launched("k_fir_delay")) return rc;
+    }
+    return LC_OK;
+}
+
+extern "C" int lc_lanczos_interp(const void* d_data, int dtype, int64_t n_old, int64_t D, int64_t ld_in,
+                                 const double* d_oldtime, const double* d_newtime, int64_t n_new, double cutoff,
+                                 double window, int rectify, double* d_out, int64_t ld_out, lc_stream_t stream) {
+    LC_REQUIRE(d_data && d_oldtime && d_newtime && d_out, LC_E_BADARG, "lc_lanczos_interp: null pointer");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, LC_E_BADARG, "lc_lanczos_interp: dtype %d unsupported", dtype);
+    LC_REQUIRE(n_old >= 0 && D >= 0 && n_new >= 0, LC_E_BADARG, "lc_lanczos_interp: negative size");
+    LC_REQUIRE(ld_in >= D && ld_out >= (rectify ? 2 * D : D), LC_E_SHAPE, "lc_lanczos_interp: leading dimension too small");
+    if (n_new == 0 || D == 0) return LC_OK;
+    hipStream_t s = lc::as_stream(stream);
+    dim3 grid((unsigned)n_new, (unsigned)lc::ceil_div<long long>(D, LZ_THREADS * LZ_CPT));
+#define LC_LZ(T, R)                                                                                             \
+    hipLaunchKernelGGL((k_lanczos<T, R>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, n_old, D, ld_in, d_oldtime, \
+                       d_newtime, cutoff, window, d_out, ld_out)
+    if (dtype == LC_F32) { if (rectify) LC_LZ(float, true); else LC_LZ(float, false); }
+    else                 { if (rectify) LC_LZ(double, true); else LC_LZ(double, false); }
+#undef LC_LZ
+    return lc::launched("k_lanczos");
+}

@@ -1,0 +1,351 @@
+// HBM-bound helpers around the fit: casts, row/column gathers, column statistics,
+// per-voxel Pearson correlation, alpha selection and grouping.  All kernels put the voxel
+// (column) axis on the lanes so every wave-level access is a contiguous row segment.
+#include "lc_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ cast
+__global__ void __launch_bounds__(256) k_cast_f64_f32(const double* __restrict__ in, long long ld_in,
+                                                      float* __restrict__ out, long long ld_out, long long cols) {
+    const long long r = blockIdx.x;
+    const long long stride = (long long)gridDim.y * blockDim.x;
+    const double* src = in + r * ld_in;
+    float* dst = out + r * ld_out;
+    for (long long j = (long long)blockIdx.y * blockDim.x + threadIdx.x; j < cols; j += stride) dst[j] = (float)src[j];
+}
+
+// ------------------------------------------------------------------ gather / scatter
+__global__ void __launch_bounds__(256) k_gather(const float* __restrict__ in, long long ld_in,
+                                                const int* __restrict__ rows, const int* __restrict__ cols,
+                                                long long n_cols, float* __restrict__ out, long long ld_out) {
+    const long long r = blockIdx.x;
+    const long long src = rows ? rows[r] : r;
+    const long long stride = (long long)gridDim.y * blockDim.x;
+    for (long long j = (long long)blockIdx.y * blockDim.x + threadIdx.x; j < n_cols; j += stride) {
+        float v = 0.f;
+        const long long c = cols ? cols[j] : j;
+        if (src >= 0 && c >= 0) v = in[src * ld_in + c];
+        out[r * ld_out + j] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scatter_axpy(const float* __restrict__ w, long long ld_w,
+                                                      const int* __restrict__ cols, long long n_cols, float scale,
+                                                      float* __restrict__ acc, long long ld_acc) {
+    const long long r = blockIdx.x;
+    const long long stride = (long long)gridDim.y * blockDim.x;
+    for (long long j = (long long)blockIdx.y * blockDim.x + threadIdx.x; j < n_cols; j += stride) {
+        const long long c = cols ? cols[j] : j;
+        if (c >= 0) acc[r * ld_acc + c] += scale * w[r * ld_w + j];
+    }
+}
+
+// ------------------------------------------------------------------ column moments
+// Block = 64 columns (x) by RG row groups (y).  Two passes over the listed rows: mean, then
+// centred second moment, both in fp64; the second pass re-reads a panel that is still in L2.
+constexpr int CM_RG = 8;
+
+template <int RG>
+__device__ inline double block_colsum(double v, double (*sm)[64]) {
+    sm[threadIdx.y][threadIdx.x] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) t += sm[g][threadIdx.x];
+    __syncthreads();
+    return t;
+}
+
+__global__ void __launch_bounds__(64 * CM_RG) k_col_mean_std(const float* __restrict__ x, long long ld,
+                                                             const int* __restrict__ rows, long long n_rows,
+                                                             long long n_cols, float* __restrict__ mean_out,
+                                                             float* __restrict__ std_out) {
+    __shared__ double sm[CM_RG][64];
+    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = c < n_cols;
+    double s = 0.0;
+    if (live)
+        for (long long i = threadIdx.y; i < n_rows; i += CM_RG) {
+            const long long r = rows ? rows[i] : i;
+            if (r >= 0) s += (double)x[r * ld + c];
+        }
+    const double mean = block_colsum<CM_RG>(s, sm) / (double)n_rows;
+    double q = 0.0;
+    if (live)
+        for (long long i = threadIdx.y; i < n_rows; i += CM_RG) {
+            const long long r = rows ? rows[i] : i;
+            if (r >= 0) { const double d = (double)x[r * ld + c] - mean; q += d * d; }
+        }
+    const double m2 = block_colsum<CM_RG>(q, sm);
+    if (live && threadIdx.y == 0) {
+        mean_out[c] = (float)mean;
+        std_out[c] = (float)sqrt(m2 / (double)(n_rows - 1));   // n_rows == 1 -> NaN, like torch.std
+    }
+}
+
+__global__ void __launch_bounds__(256) k_col_normalize(float* __restrict__ x, long long ld, long long n_cols,
+                                                       const float* __restrict__ mean, const float* __restrict__ sd,
+                                                       float eps) {
+    const long long r = blockIdx.x;
+    const long long stride = (long long)gridDim.y * blockDim.x;
+    for (long long j = (long long)blockIdx.y * blockDim.x + threadIdx.x; j < n_cols; j += stride)
+        x[r * ld + j] = (x[r * ld + j] - mean[j]) / (sd[j] + eps);
+}
+
+// Validation-target statistics for the fused scorer.  ystat = [mean | std | var] (unbiased),
+// yblk[b, v] = sum over the b-th 32-row block of fl32(y - mean): exactly the centred values
+// the GEMM epilogue multiplies with.
+__global__ void __launch_bounds__(64 * CM_RG) k_val_stats(const float* __restrict__ y, long long ldy, long long V,
+                                                          const int* __restrict__ va, int M, int n_val,
+                                                          float* __restrict__ ystat, float* __restrict__ yblk) {
+    __shared__ double sm[CM_RG][64];
+    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = c < V;
+    double s = 0.0;
+    if (live)
+        for (int i = threadIdx.y; i < n_val; i += CM_RG) s += (double)y[(long long)va[i] * ldy + c];
+    const double mean = block_colsum<CM_RG>(s, sm) / (double)n_val;
+    const float meanf = (float)mean;
+    double q = 0.0;
+    if (live)
+        for (int i = threadIdx.y; i < n_val; i += CM_RG) {
+            const double d = (double)y[(long long)va[i] * ldy + c] - mean;
+            q += d * d;
+        }
+    const double m2 = block_colsum<CM_RG>(q, sm);
+    if (live && threadIdx.y == 0) {
+        const double var = m2 / (double)(n_val - 1);
+        ystat[c] = meanf;
+        ystat[V + c] = (float)sqrt(var);
+        ystat[2 * V + c] = (float)var;
+    }
+    if (live)
+        for (int b = threadIdx.y; b < M / LC_MB; b += CM_RG) {
+            float t = 0.f;
+            for (int i = b * LC_MB; i < (b + 1) * LC_MB && i < n_val; ++i) t += y[(long long)va[i] * ldy + c] - meanf;
+            yblk[(long long)b * V + c] = t;
+        }
+}
+
+// ------------------------------------------------------------------ Pearson r per column
+constexpr int PR_RG = 16;
+
+__global__ void __launch_bounds__(64 * PR_RG) k_pearson_cols(const float* __restrict__ a, long long lda,
+                                                             const float* __restrict__ b, long long ldb,
+                                                             long long n, long long V, double* __restrict__ r_out) {
+    __shared__ double sm[PR_RG][64];
+    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = c < V;
+    double sa = 0.0, sb = 0.0;
+    if (live)
+        for (long long i = threadIdx.y; i < n; i += PR_RG) {
+            sa += (double)a[i * lda + c];
+            sb += (double)b[i * ldb + c];
+        }
+    const double ma = block_colsum<PR_RG>(sa, sm) / (double)n;
+    const double mb = block_colsum<PR_RG>(sb, sm) / (double)n;
+    double qa = 0.0, qb = 0.0, qab = 0.0;
+    if (live)
+        for (long long i = threadIdx.y; i < n; i += PR_RG) {
+            const double da = (double)a[i * lda + c] - ma;
+            const double db = (double)b[i * ldb + c] - mb;
+            qa += da * da;
+            qb += db * db;
+            qab += da * db;
+        }
+    qa = block_colsum<PR_RG>(qa, sm);
+    qb = block_colsum<PR_RG>(qb, sm);
+    qab = block_colsum<PR_RG>(qab, sm);
+    if (live && threadIdx.y == 0) {
+        double r = qab / (sqrt(qa) * sqrt(qb));       // 0/0 -> NaN for a constant column
+        if (r > 1.0) r = 1.0;
+        if (r < -1.0) r = -1.0;
+        r_out[c] = r;
+    }
+}
+
+// ------------------------------------------------------------------ alpha selection
+__global__ void __launch_bounds__(256) k_argmax_alpha(const float* __restrict__ scores, int A, long long V,
+                                                      int* __restrict__ best) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float top = scores[v];
+    int arg = 0;
+    for (int a = 1; a < A; ++a) {
+        const float s = scores[(long long)a * V + v];
+        if (s > top) { top = s; arg = a; }      // strict: the first maximum wins (torch.argmax)
+    }
+    best[v] = arg;
+}
+
+// One block per alpha; fixed-order tree reduction -> deterministic.
+__global__ void __launch_bounds__(1024) k_rowsum(const float* __restrict__ scores, long long V,
+                                                 double* __restrict__ out) {
+    __shared__ double sm[1024];
+    const float* row = scores + (long long)blockIdx.x * V;
+    double s = 0.0;
+    for (long long v = threadIdx.x; v < V; v += 1024) s += (double)row[v];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+
+// Stable counting sort of voxel ids by alpha index, one block.  Thread t owns the contiguous
+// voxel segment [t*L, (t+1)*L); hist[a][t] is scanned alpha-major so that equal alphas keep
+// voxel order.
+constexpr int GB_THREADS = 512;
+constexpr int GB_MAX_A = 64;
+
+__global__ void __launch_bounds__(GB_THREADS) k_group_by_alpha(const int* __restrict__ best, long long V, int A, int pad,
+                                                               int* __restrict__ perm, int* __restrict__ count) {
+    extern __shared__ int hist[];            // A * GB_THREADS
+    __shared__ int carry;
+    const int t = threadIdx.x;
+    const long long L = (V + GB_THREADS - 1) / GB_THREADS;
+    const long long lo = (long long)t * L, hi = min(V, lo + L);
+    for (int a = 0; a < A; ++a) hist[a * GB_THREADS + t] = 0;
+    for (long long v = lo; v < hi; ++v) hist[best[v] * GB_THREADS + t] += 1;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    // exclusive scan over the A*GB_THREADS table in chunks of GB_THREADS (Hillis-Steele per chunk)
+    __shared__ int buf[2][GB_THREADS];
+    for (int a = 0; a < A; ++a) {
+        const int mine = hist[a * GB_THREADS + t];
+        int cur = 0;
+        buf[0][t] = mine;
+        __syncthreads();
+        for (int off = 1; off < GB_THREADS; off <<= 1) {
+            int v = buf[cur][t];
+            if (t >= off) v += buf[cur][t - off];
+            buf[cur ^ 1][t] = v;
+            cur ^= 1;
+            __syncthreads();
+        }
+        const int incl = buf[cur][t];
+        const int base = carry;
+        hist[a * GB_THREADS + t] = base + incl - mine;
+        __syncthreads();
+        if (t == GB_THREADS - 1) {
+            carry = ((base + incl + pad - 1) / pad) * pad;      // next group starts on a pad boundary
+            count[a] = incl;
+        }
+        __syncthreads();
+    }
+    for (long long v = lo; v < hi; ++v) {
+        const int a = best[v];
+        perm[hist[a * GB_THREADS + t]++] = (int)v;
+    }
+}
+
+}  // namespace
+
+extern "C" int lc_cast_f64_f32(const double* d_in, int64_t ld_in, float* d_out, int64_t ld_out, int64_t rows,
+                               int64_t cols, lc_stream_t stream) {
+    LC_REQUIRE(d_in && d_out, LC_E_BADARG, "lc_cast_f64_f32: null pointer");
+    LC_REQUIRE(rows >= 0 && cols >= 0 && ld_in >= cols && ld_out >= cols, LC_E_SHAPE, "lc_cast_f64_f32: bad shape");
+    if (rows == 0 || cols == 0) return LC_OK;
+    dim3 grid((unsigned)rows, (unsigned)lc::imin(lc::ceil_div<long long>(cols, 1024), 1024));
+    hipLaunchKernelGGL(k_cast_f64_f32, grid, dim3(256), 0, lc::as_stream(stream), d_in, (long long)ld_in, d_out,
+                       (long long)ld_out, (long long)cols);
+    return lc::launched("k_cast_f64_f32");
+}
+
+extern "C" int lc_gather_f32(const float* d_in, int64_t ld_in, const int32_t* d_rows, int64_t n_rows,
+                             const int32_t* d_cols, int64_t n_cols, float* d_out, int64_t ld_out,
+                             lc_stream_t stream) {
+    LC_REQUIRE(d_in && d_out, LC_E_BADARG, "lc_gather_f32: null pointer");
+    LC_REQUIRE(n_rows >= 0 && n_cols >= 0 && ld_out >= n_cols, LC_E_SHAPE, "lc_gather_f32: bad shape");
+    if (n_rows == 0 || n_cols == 0) return LC_OK;
+    dim3 grid((unsigned)n_rows, (unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 1024), 1024));
+    hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, lc::as_stream(stream), d_in, ld_in, d_rows, d_cols, n_cols,
+                       d_out, ld_out);
+    return lc::launched("k_gather");
+}
+
+extern "C" int lc_scatter_axpy_f32(const float* d_w, int64_t ld_w, int64_t n_rows, const int32_t* d_cols,
+                                   int64_t n_cols, float scale, float* d_acc, int64_t ld_acc, lc_stream_t stream) {
+    LC_REQUIRE(d_w && d_acc, LC_E_BADARG, "lc_scatter_axpy_f32: null pointer");
+    LC_REQUIRE(n_rows >= 0 && n_cols >= 0, LC_E_SHAPE, "lc_scatter_axpy_f32: bad shape");
+    if (n_rows == 0 || n_cols == 0) return LC_OK;
+    dim3 grid((unsigned)n_rows, (unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 1024), 1024));
+    hipLaunchKernelGGL(k_scatter_axpy, grid, dim3(256), 0, lc::as_stream(stream), d_w, ld_w, d_cols, n_cols, scale,
+                       d_acc, ld_acc);
+    return lc::launched("k_scatter_axpy");
+}
+
+extern "C" int lc_col_mean_std_f32(const float* d_x, int64_t ld, const int32_t* d_rows, int64_t n_rows,
+                                   int64_t n_cols, float* d_mean, float* d_std, lc_stream_t stream) {
+    LC_REQUIRE(d_x && d_mean && d_std, LC_E_BADARG, "lc_col_mean_std_f32: null pointer");
+    LC_REQUIRE(n_rows > 0 && n_cols >= 0, LC_E_SHAPE, "lc_col_mean_std_f32: need at least one row");
+    if (n_cols == 0) return LC_OK;
+    hipLaunchKernelGGL(k_col_mean_std, dim3((unsigned)lc::ceil_div<long long>(n_cols, 64)), dim3(64, CM_RG), 0,
+                       lc::as_stream(stream), d_x, ld, d_rows, n_rows, n_cols, d_mean, d_std);
+    return lc::launched("k_col_mean_std");
+}
+
+extern "C" int lc_col_normalize_f32(float* d_x, int64_t ld, int64_t n_rows, int64_t n_cols, const float* d_mean,
+                                    const float* d_std, float eps, lc_stream_t stream) {
+    LC_REQUIRE(d_x && d_mean && d_std, LC_E_BADARG, "lc_col_normalize_f32: null pointer");
+    if (n_rows <= 0 || n_cols <= 0) return LC_OK;
+    dim3 grid((unsigned)n_rows, (unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 1024), 1024));
+    hipLaunchKernelGGL(k_col_normalize, grid, dim3(256), 0, lc::as_stream(stream), d_x, ld, n_cols, d_mean, d_std,
+                       eps);
+    return lc::launched("k_col_normalize");
+}
+
+extern "C" int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int M, int n_val,
+                            float* d_ystat, float* d_yblk, lc_stream_t stream) {
+    LC_REQUIRE(d_y && d_va && d_ystat && d_yblk, LC_E_BADARG, "lc_val_stats: null pointer");
+    LC_REQUIRE(M % LC_MB == 0 && n_val > 0 && n_val <= M, LC_E_SHAPE, "lc_val_stats: need 0 < n_val <= M, M %% %d == 0",
+               LC_MB);
+    if (V <= 0) return LC_OK;
+    hipLaunchKernelGGL(k_val_stats, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, CM_RG), 0,
+                       lc::as_stream(stream), d_y, ldy, V, d_va, M, n_val, d_ystat, d_yblk);
+    return lc::launched("k_val_stats");
+}
+
+extern "C" int lc_pearson_cols(const float* d_a, int64_t lda, const float* d_b, int64_t ldb, int64_t n, int64_t V,
+                               double* d_r, lc_stream_t stream) {
+    LC_REQUIRE(d_a && d_b && d_r, LC_E_BADARG, "lc_pearson_cols: null pointer");
+    LC_REQUIRE(n > 0 && V >= 0 && lda >= V && ldb >= V, LC_E_SHAPE, "lc_pearson_cols: bad shape");
+    if (V == 0) return LC_OK;
+    hipLaunchKernelGGL(k_pearson_cols, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, PR_RG), 0,
+                       lc::as_stream(stream), d_a, lda, d_b, ldb, n, V, d_r);
+    return lc::launched("k_pearson_cols");
+}
+
+extern "C" int lc_select_alpha(const float* d_scores, int A, int64_t V, int32_t* d_best, double* d_rowsum,
+                               lc_stream_t stream) {
+    LC_REQUIRE(d_scores && A > 0 && V >= 0, LC_E_BADARG, "lc_select_alpha: bad argument");
+    if (V == 0) return LC_OK;
+    hipStream_t s = lc::as_stream(stream);
+    if (d_best) {
+        hipLaunchKernelGGL(k_argmax_alpha, dim3((unsigned)lc::ceil_div<long long>(V, 256)), dim3(256), 0, s, d_scores,
+                           A, V, d_best);
+        if (int rc = lc::launched("k_argmax_alpha")) return rc;
+    }
+    if (d_rowsum) {
+        hipLaunchKernelGGL(k_rowsum, dim3((unsigned)A), dim3(1024), 0, s, d_scores, V, d_rowsum);
+        if (int rc = lc::launched("k_rowsum")) return rc;
+    }
+    return LC_OK;
+}
+
+extern "C" int lc_group_by_alpha(const int32_t* d_best, int64_t V, int A, int pad, int32_t* d_perm,
+                                 int32_t* d_count, lc_stream_t stream) {
+    LC_REQUIRE(d_best && d_perm && d_count, LC_E_BADARG, "lc_group_by_alpha: null pointer");
+    LC_REQUIRE(A > 0 && A <= GB_MAX_A && pad >= 1, LC_E_SHAPE, "lc_group_by_alpha: A must be in 1..%d, pad >= 1", GB_MAX_A);
+    LC_REQUIRE(V >= 0 && V < (1ll << 31), LC_E_SHAPE, "lc_group_by_alpha: V out of range");
+    const size_t lds = (size_t)A * GB_THREADS * sizeof(int);
+    if (lds > 48 * 1024)
+        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_by_alpha),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_group_by_alpha, dim3(1), dim3(GB_THREADS), lds, lc::as_stream(stream), d_best, V, A, pad,
+                       d_perm, d_count);
+    return lc::launched("k_group_by_alpha");
+}

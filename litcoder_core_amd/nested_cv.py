@@ -1,0 +1,330 @@
+"""Nested-CV ridge fit on the MI355X behind the reference's ``NestedCVModel`` interface.
+
+Interface: ``encoding/models/nested_cv.py:14-42`` (``NestedCVModel.fit_predict``) and the README's
+``fit_nested_cv(features=, targets=, ...)`` (``README.md:212-226``; absent from the reference's
+code, provided here as the thin alias the README describes).
+
+How the work is laid out (DESIGN.md has the derivation):
+
+* The reference takes a thin SVD of every inner/outer training block and forms, per alpha,
+  ``pred = Pstim Vh' diag(S/(S^2+a^2)) U' Rresp``.  With ``K = X X'`` this is exactly
+  ``pred = K[va, tr] (K[tr, tr] + a^2 I)^-1 Rresp``: ONE fp64 Gram matrix of all rows serves every
+  fold by row/column selection, ``S[0]^2`` is the top eigenvalue of ``K[tr, tr]`` (Lanczos), and the
+  per-(fold, alpha) hat matrices come from a batched blocked Cholesky.  No SVD is computed.
+* The V-wide work -- hat matrices times the training targets for all alphas of an inner fold,
+  z-scoring and correlating against the validation targets -- is one fused f32-MFMA kernel whose
+  epilogue reduces each 32-row block to three moments; predictions never reach HBM.
+* Refit: voxels are grouped by their selected alpha (counting sort), weights come from a grouped
+  MFMA GEMM ``W[:, group] = X_tr'(K + a_g^2 I)^-1 Y[:, group]``, test predictions from a second
+  GEMM, and Pearson r from a column-reduction kernel.  Mean weights accumulate on the device.
+* The statistics tail (p-values, Fisher, BH-FDR, metrics dict) is vectorised numpy on the host.
+
+Every device operation is a call into liblitcoder_hip.so (``ops.py``); there is no CPU fallback.
+"""
+import logging
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import ops, stats
+from ._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2
+from .dist import ShardContext
+from .folding import create_folds
+
+logger = logging.getLogger(__name__)
+
+LANCZOS_STEPS = 192                 # Lanczos iterations for S[0]^2 (converged far below fp32 eps, see tests)
+AUG_BUDGET_BYTES = 24 << 30         # cap on the batched (fold, alpha) fp64 systems resident at once
+
+
+class BasePredictivityModel:
+    """``encoding/models/base.py:7-41``: the interface AbstractTrainer calls."""
+
+    def __init__(self, model_name: str):
+        self.model_name = model_name
+
+    def fit_predict(self, features, targets, groups=None, **kwargs):  # pragma: no cover - interface
+        raise NotImplementedError
+
+
+class _FoldResult:
+    __slots__ = ("r", "best_idx", "n_test")
+
+    def __init__(self, r, best_idx, n_test):
+        self.r, self.best_idx, self.n_test = r, best_idx, n_test
+
+
+class RidgeCVEngine:
+    """Device-resident state of one fit: fp32 copies of X / Y (zero padded), the Gram matrix, and the
+    per-fold pipeline.  ``Y`` holds only this rank's voxel block."""
+
+    def __init__(self, X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets,
+                 shard: Optional[ShardContext] = None, lanczos_steps: int = LANCZOS_STEPS):
+        self.dev = ops.device()
+        self.shard = shard or ShardContext()
+        X_all = np.asarray(X_all) if not torch.is_tensor(X_all) else X_all
+        self.Ttot, self.p = X_all.shape
+        self.V = Y_all.shape[1]
+        if Y_all.shape[0] != self.Ttot:
+            raise RuntimeError(f"shape mismatch: features have {self.Ttot} rows, targets {Y_all.shape[0]}")
+        self.p_pad = ops.pad_to(self.p, K_TILE)
+        self.Vp = ops.pad_to(max(self.V, 1), COL_TILE)
+        self.alphas = [float(a) for a in alphas]
+        self.A = len(self.alphas)
+        if any(not (a > 0) for a in self.alphas):
+            raise ValueError("alphas must be positive: the Gram/Cholesky route needs a^2 > 0")
+        self.normalpha = bool(normalpha)
+        self.mode = LC_SCORE_CORR if use_corr else LC_SCORE_R2
+        self.norm_x, self.norm_y = bool(normalize_features), bool(normalize_targets)
+        self.steps = int(lanczos_steps)
+        self.dX = self._resident(X_all, self.p_pad)
+        self.dY = self._resident(Y_all, self.Vp)
+        self.d_alphas = torch.tensor(self.alphas, dtype=torch.float64, device=self.dev)
+        self.K = None if self.norm_x else ops.gram(self.dX, self.Ttot, self.p)
+        self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
+
+    def _resident(self, arr, ld):
+        if torch.is_tensor(arr):            # already on the device, already fp32 and padded (bench path)
+            if arr.dtype != torch.float32 or not arr.is_cuda or arr.shape[1] != ld or not arr.is_contiguous():
+                raise ValueError("device inputs must be contiguous fp32 tensors padded to the tile width")
+            return arr
+        return ops.upload_f32(arr, ld, self.dev)
+
+    # -------------------------------------------------------------- per-outer-fold data
+    def _fold_data(self, tr_rows):
+        """Train-statistics z-scoring of X and/or Y for this outer fold (DataNormalizer,
+        ridge_utils.py:70-180; nested_cv.py:111-124,204-213) and the matching Gram matrix."""
+        X, Y, K = self.dX, self.dY, self.K
+        if self.norm_x or self.norm_y:
+            rows = ops.idx_tensor(tr_rows, len(tr_rows), self.dev)
+        if self.norm_x:
+            mean, std = ops.col_mean_std(self.dX, rows, len(tr_rows), self.p)
+            X = self.dX.clone()
+            ops.col_normalize_(X, self.Ttot, self.p, mean, std)
+            K = ops.gram(X, self.Ttot, self.p)
+        if self.norm_y:
+            mean, std = ops.col_mean_std(self.dY, rows, len(tr_rows), self.V)
+            Y = self.dY.clone()
+            ops.col_normalize_(Y, self.Ttot, self.V, mean, std)
+        return X, Y, K
+
+    # -------------------------------------------------------------- inner CV: alpha scores
+    def _alpha_scores(self, K, Y, inner_abs):
+        """Sum over inner folds of the (A, Vp) validation scores (ridge_corr_torch for every fold,
+        nested_cv.py:366-393)."""
+        F, A = len(inner_abs), self.A
+        n_i = [len(t) for t, _ in inner_abs]
+        n_v = [len(v) for _, v in inner_abs]
+        if min(n_i) < 1 or min(n_v) < 1:
+            raise ValueError("every inner fold needs at least one training and one validation row")
+        N = ops.pad_to(max(n_i), LC_NB)
+        M = ops.pad_to(max(n_v), LC_MB)
+        tr = torch.stack([ops.idx_tensor(t, N, self.dev) for t, _ in inner_abs])
+        va = torch.stack([ops.idx_tensor(v, M, self.dev) for _, v in inner_abs])
+        lmax = ops.lambda_max(K, tr, F, N, self.steps) if self.normalpha else None
+        a2 = ops.penalties(lmax, F, self.d_alphas, self.normalpha)
+        scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
+        part = torch.empty((A * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
+        ystat = torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev)
+        yblk = torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
+        per_sys = (N + M) * N * 8
+        chunk = max(1, min(F, AUG_BUDGET_BYTES // max(1, per_sys * A)))
+        infos = []
+        for f0 in range(0, F, chunk):
+            fc = min(chunk, F - f0)
+            aug = torch.empty((fc * A, N + M, N), dtype=torch.float64, device=self.dev)
+            H = torch.empty((fc * A, M, N), dtype=torch.float32, device=self.dev)
+            ops.batch_assemble(K, tr[f0:f0 + fc], va[f0:f0 + fc], None, a2[f0 * A:(f0 + fc) * A], fc, A, N, M, aug)
+            infos.append(ops.batch_chol_solve(aug, fc * A, N, M, H))
+            del aug
+            for j in range(fc):
+                f = f0 + j
+                ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk)
+                ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], va[f], n_v[f], ystat, yblk,
+                                       self.mode, part, scores, accumulate=f > 0)
+        return scores, torch.cat(infos)
+
+    # -------------------------------------------------------------- one outer fold
+    def run_fold(self, tr_rows, te_rows, inner_rel, single_alpha, weight_scale) -> _FoldResult:
+        tr_rows = np.asarray(tr_rows, dtype=np.int64)
+        te_rows = np.asarray(te_rows, dtype=np.int64)
+        X, Y, K = self._fold_data(tr_rows)
+        inner_abs = [(tr_rows[np.asarray(a, dtype=np.int64)], tr_rows[np.asarray(b, dtype=np.int64)])
+                     for a, b in inner_rel]
+        scores, info = self._alpha_scores(K, Y, inner_abs)
+        A, V = self.A, self.V
+        if single_alpha:
+            # nested_cv.py:396-400: one alpha for all voxels = argmax of the across-voxel mean
+            _, rowsum = ops.select_alpha(scores, A, self.Vp, want_best=False, want_rowsum=True)
+            total = self.shard.allreduce_sum(rowsum.cpu().numpy())
+            k = int(np.argmax(total))                      # first maximum, like torch.argmax
+            best = torch.full((self.Vp,), k, dtype=torch.int32, device=self.dev)
+        else:
+            best, _ = ops.select_alpha(scores, A, self.Vp)
+        perm, count = ops.group_by_alpha(best, V, A, COL_TILE)
+        count_h = count.cpu().numpy()
+        if int(info.cpu().numpy().any()):
+            raise RuntimeError("Cholesky failed: Gram matrix + alpha^2 I is not positive definite")
+        used = [a for a in range(A) if count_h[a] > 0]
+        tiles = [0]
+        for a in used:
+            tiles.append(tiles[-1] + (int(count_h[a]) + COL_TILE - 1) // COL_TILE)
+        Vs = tiles[-1] * COL_TILE
+        G = len(used)
+
+        # ---- refit on the whole outer-train block (ridge_torch, ridge_regression.py:9-63)
+        n_o, n_t = len(tr_rows), len(te_rows)
+        N_o = ops.pad_to(n_o, LC_NB)
+        tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
+        lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
+        a2_o = ops.penalties(lmax_o, 1, self.d_alphas[used], self.normalpha)
+        rhs = torch.zeros((self.p_pad, N_o), dtype=torch.float64, device=self.dev)
+        ops.transpose_rows(X, tr_o, N_o, self.p, rhs)
+        aug = torch.empty((G, N_o + self.p_pad, N_o), dtype=torch.float64, device=self.dev)
+        ops.batch_assemble(K, tr_o, None, rhs, a2_o, 1, G, N_o, self.p_pad, aug)
+        Malpha = torch.empty((G, self.p_pad, N_o), dtype=torch.float32, device=self.dev)
+        info_o = ops.batch_chol_solve(aug, G, N_o, self.p_pad, Malpha)
+        del aug, rhs
+
+        rows_s = ops.idx_tensor(np.concatenate([tr_rows, np.full(N_o - n_o, -1), te_rows]), N_o + n_t, self.dev)
+        Ys = torch.empty((N_o + n_t, Vs), dtype=torch.float32, device=self.dev)
+        ops.gather(Y, self.Vp, rows_s, N_o + n_t, perm, Vs, Ys)
+        Ws = torch.empty((self.p_pad, Vs), dtype=torch.float32, device=self.dev)
+        ops.gemm_grouped(Malpha, N_o, self.p_pad * N_o, Ys, Vs, None, Ws, Vs, self.p_pad, Vs, N_o, tiles)
+        # ---- test predictions and per-voxel Pearson r (nested_cv.py:151-155, 251-257)
+        Xte = torch.empty((n_t, self.p_pad), dtype=torch.float32, device=self.dev)
+        ops.gather(X, self.p_pad, ops.idx_tensor(te_rows, n_t, self.dev), n_t, None, self.p_pad, Xte)
+        pred = torch.empty((n_t, Vs), dtype=torch.float32, device=self.dev)
+        ops.gemm_grouped(Xte, self.p_pad, 0, Ws, Vs, None, pred, Vs, n_t, Vs, self.p_pad, [0, Vs // COL_TILE])
+        r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
+        ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
+
+        if int(info_o.cpu().numpy().any()):
+            raise RuntimeError("Cholesky failed in the refit: Gram matrix + alpha^2 I is not positive definite")
+        perm_h = perm[:Vs].cpu().numpy()
+        r_sorted = r_s.cpu().numpy()
+        live = perm_h >= 0
+        r = np.empty(V, dtype=np.float64)
+        r[perm_h[live]] = r_sorted[live]
+        return _FoldResult(r, best[:V].cpu().numpy(), n_t)
+
+    def weights(self) -> np.ndarray:
+        return self.W_acc[:, : self.V].cpu().numpy()
+
+
+def _alpha_vector(alphas, idx, single_alpha):
+    """The tensor the reference builds for the chosen alphas, dtype quirks included
+    (nested_cv.py:401-403: torch default for the element type; :409-411: fp32)."""
+    if single_alpha:
+        return torch.tensor([alphas[int(idx[0])]] * len(idx)).numpy()
+    return torch.tensor([alphas[int(i)] for i in idx], dtype=torch.float32).numpy()
+
+
+def _fold_lists(r32: np.ndarray, n_test: int):
+    """What ``_calculate_correlations_pvalues`` (nested_cv.py:418-438) returns for one fold:
+    list of np.float32 r (NaN -> Python 0.0) and list of float64 p (NaN -> 1.0)."""
+    nan = np.isnan(r32)
+    p = stats.pearson_pvalues(r32.astype(np.float64), n_test)
+    corrs = [0.0 if bad else v for v, bad in zip(r32, nan)]
+    pvals = [1.0 if bad else v for v, bad in zip(p, nan)]
+    return corrs, pvals
+
+
+class NestedCVModel(BasePredictivityModel):
+    """Drop-in for ``encoding.models.nested_cv.NestedCVModel``; same ``fit_predict`` signature,
+    defaults, return triple and metrics keys.  ``shard`` (optional) makes the instance fit only its
+    rank's block of voxel columns and gather the per-voxel results across ranks."""
+
+    def __init__(self, model_name: str, shard: Optional[ShardContext] = None):
+        super().__init__(model_name)
+        self.shard = shard
+
+    def fit_predict(
+        self,
+        features: np.ndarray,
+        targets: np.ndarray,
+        X_test: Optional[np.ndarray] = None,
+        y_test: Optional[np.ndarray] = None,
+        groups: Optional[np.ndarray] = None,
+        folding_type: str = "chunked",
+        n_outer_folds: int = 5,
+        n_inner_folds: int = 5,
+        chunk_length: int = 20,
+        alphas: Optional[List[float]] = None,
+        alpha_fdr: float = 0.05,
+        use_gpu: bool = True,
+        single_alpha: bool = False,
+        normalpha: bool = True,
+        use_corr: bool = True,
+        normalize_features: bool = False,
+        normalize_targets: bool = False,
+        singcutoff: float = 1e-10,
+    ) -> Tuple[Dict[str, Union[float, List[float], List[bool]]], np.ndarray, np.ndarray]:
+        if alphas is None:
+            alphas = np.logspace(-1, 8, 10)
+        if not use_gpu:
+            logger.info("use_gpu=False ignored: this implementation runs on the MI355X only")
+        shard = self.shard or ShardContext()
+        train_test = X_test is not None and y_test is not None
+        T = len(features)
+        V_total = np.shape(targets)[1]
+        lo, hi = shard.bounds(V_total)
+
+        def cols(y):                       # this rank's voxel block (the whole matrix on one GPU)
+            return y if shard.world == 1 else np.asarray(y)[:, lo:hi]
+
+        if train_test:
+            X_all = np.concatenate([np.asarray(features), np.asarray(X_test)], axis=0)
+            Y_all = np.concatenate([cols(targets), cols(y_test)], axis=0)
+            # nested_cv.py:130-132 passes ``groups`` positionally into ``trim_size``
+            inner = create_folds(len(features), folding_type, n_inner_folds, chunk_length, groups)
+            outer = [(np.arange(T), T + np.arange(len(X_test)), inner)]
+        else:
+            X_all, Y_all = features, cols(targets)
+            if groups is not None and folding_type == "group":
+                splits = create_folds(T, "group", n_outer_folds, groups=groups)
+            else:
+                splits = create_folds(T, folding_type, n_outer_folds, chunk_length, groups)
+            outer = []
+            for tr, te in splits:
+                if groups is not None and folding_type == "group":
+                    inner = create_folds(len(tr), "group", n_inner_folds, groups=[groups[i] for i in tr])
+                else:
+                    inner = create_folds(len(tr), folding_type, n_inner_folds, chunk_length)
+                outer.append((tr, te, inner))
+
+        eng = RidgeCVEngine(X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard)
+        scale = 1.0 if train_test else 1.0 / len(outer)
+        folds = [eng.run_fold(tr, te, inner, single_alpha, scale) for tr, te, inner in outer]
+        weights = eng.weights()
+
+        # ---- gather the per-voxel vectors of every fold (the only V-sized exchange)
+        r_all = shard.allgather_cols(np.stack([f.r for f in folds]), V_total)
+        idx_all = shard.allgather_cols(np.stack([f.best_idx for f in folds]).astype(np.int32), V_total)
+
+        fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
+        for f, r, idx in zip(folds, r_all, idx_all):
+            corrs, pvals = _fold_lists(r.astype(np.float32), f.n_test)
+            fold_scores.append(corrs)
+            fold_p.append(pvals)
+            fold_alpha.append(_alpha_vector(alphas, idx, single_alpha))
+            fold_sig.append(stats.fdrcorrection(pvals, alpha=alpha_fdr))
+
+        if train_test:
+            sig, padj = fold_sig[0]
+            metrics = stats.train_test_metrics(fold_scores[0], fold_p[0], padj, sig, fold_alpha[0], np.sum(sig))
+            return metrics, weights, fold_alpha[0]
+
+        scores = np.mean(fold_scores, axis=0)
+        pcomb = stats.fisher_combine(fold_p)
+        sig, padj = stats.fdrcorrection(pcomb, alpha=alpha_fdr)
+        majority = np.sum([s for s, _ in fold_sig], axis=0) >= (n_outer_folds // 2 + 1)
+        mean_alphas = np.mean(fold_alpha, axis=0)
+        metrics = stats.full_cv_metrics(scores, pcomb, padj, sig, majority, mean_alphas, np.sum(sig), np.sum(majority))
+        return metrics, weights, mean_alphas
+
+
+def fit_nested_cv(features: np.ndarray, targets: np.ndarray, **kwargs: Any):
+    """README.md:128,137,212-226: functional entry point, same kwargs as ``fit_predict``."""
+    return NestedCVModel("ridge_regression").fit_predict(features=features, targets=targets, **kwargs)

@@ -1,0 +1,193 @@
+"""Thin typed wrappers over the C ABI (include/litcoder_hip.h).
+
+torch is used here only as the device-memory container (``torch.empty(..., device=...)``,
+``data_ptr()``) and for the current HIP stream; every computation is a call into
+liblitcoder_hip.so.  No function here has a CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import COL_TILE, K_TILE, LC_F32, LC_F64, LC_MB, LC_NB  # noqa: F401
+
+_checked_devices = set()
+
+
+def pad_to(n, g):
+    return ((int(n) + g - 1) // g) * g
+
+
+def device(index=None):
+    """The torch device the path runs on; raises when no gfx950 GPU is usable."""
+    if not torch.cuda.is_available():
+        raise _lib.LitcoderHipError("no HIP device visible: litcoder_core_amd runs on MI355X only (no CPU fallback)")
+    idx = torch.cuda.current_device() if index is None else int(index)
+    if idx not in _checked_devices:
+        _lib.call("lc_check_device", idx)
+        _checked_devices.add(idx)
+    return torch.device("cuda", idx)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t, dtype, what):
+    if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{what}: expected contiguous {dtype} device tensor, got {t.dtype} on {t.device}")
+
+
+def idx_tensor(rows, length, dev, fill=-1):
+    """int32 device index list of ``length`` entries: ``rows`` then ``fill`` padding."""
+    h = np.full(length, fill, dtype=np.int32)
+    r = np.asarray(rows, dtype=np.int64)
+    h[: r.size] = r
+    return torch.from_numpy(h).to(dev)
+
+
+# ------------------------------------------------------------------ preprocessing
+def fir_delay(stim, delays, circpad):
+    """stim: (nt, ndim) f32/f64 device tensor -> (nt, ndim*len(delays)) f64 device tensor."""
+    dt = LC_F32 if stim.dtype == torch.float32 else LC_F64
+    _need(stim, torch.float32 if dt == LC_F32 else torch.float64, "fir_delay")
+    nt, ndim = stim.shape
+    nd = len(delays)
+    out = torch.empty((nt, ndim * nd), dtype=torch.float64, device=stim.device)
+    arr = (ctypes.c_int64 * max(nd, 1))(*[int(d) for d in delays])
+    _lib.call("lc_fir_delay", _p(stim), dt, nt, ndim, ndim, arr, nd, int(bool(circpad)), _p(out), ndim * nd, _s())
+    return out
+
+
+def lanczos_interp(data, oldtime, newtime, cutoff, window, rectify):
+    dt = LC_F32 if data.dtype == torch.float32 else LC_F64
+    _need(data, torch.float32 if dt == LC_F32 else torch.float64, "lanczos_interp")
+    _need(oldtime, torch.float64, "lanczos_interp oldtime")
+    _need(newtime, torch.float64, "lanczos_interp newtime")
+    n_old, D = data.shape
+    n_new = newtime.numel()
+    ld_out = 2 * D if rectify else D
+    out = torch.empty((n_new, ld_out), dtype=torch.float64, device=data.device)
+    _lib.call("lc_lanczos_interp", _p(data), dt, n_old, D, D, _p(oldtime), _p(newtime), n_new, float(cutoff),
+              float(window), int(bool(rectify)), _p(out), ld_out, _s())
+    return out
+
+
+# ------------------------------------------------------------------ casts / gathers
+def upload_f32(host, ld, dev, rows_pad=None, chunk_bytes=1 << 28):
+    """Host (rows, cols) real array -> zero-padded (rows_pad or rows, ld) f32 device buffer.
+    float64 input is cast on the device (lc_cast_f64_f32), mirroring
+    ``torch.tensor(x, dtype=torch.float32)`` (nested_cv.py:99-100)."""
+    host = np.asarray(host)
+    rows, cols = host.shape
+    out = torch.zeros((rows_pad or rows, ld), dtype=torch.float32, device=dev)
+    if host.dtype == np.float32:
+        out[:rows, :cols].copy_(torch.from_numpy(np.ascontiguousarray(host)))
+        return out
+    host = np.ascontiguousarray(host, dtype=np.float64)
+    step = max(1, chunk_bytes // max(1, cols * 8))
+    for r0 in range(0, rows, step):
+        blk = torch.from_numpy(host[r0:r0 + step]).to(dev)
+        dst = out[r0:r0 + blk.shape[0]]
+        _lib.call("lc_cast_f64_f32", _p(blk), cols, _p(dst), ld, blk.shape[0], cols, _s())
+    return out
+
+
+def gather(src, ld_src, rows, n_rows, cols, n_cols, out):
+    _lib.call("lc_gather_f32", _p(src), ld_src, _p(rows), n_rows, _p(cols), n_cols, _p(out), out.stride(0), _s())
+    return out
+
+
+def scatter_axpy(w, n_rows, cols, n_cols, scale, acc):
+    _lib.call("lc_scatter_axpy_f32", _p(w), w.stride(0), n_rows, _p(cols), n_cols, float(scale), _p(acc),
+              acc.stride(0), _s())
+
+
+# ------------------------------------------------------------------ column statistics
+def col_mean_std(x, rows, n_rows, n_cols):
+    mean = torch.empty(n_cols, dtype=torch.float32, device=x.device)
+    std = torch.empty(n_cols, dtype=torch.float32, device=x.device)
+    _lib.call("lc_col_mean_std_f32", _p(x), x.stride(0), _p(rows), n_rows, n_cols, _p(mean), _p(std), _s())
+    return mean, std
+
+
+def col_normalize_(x, n_rows, n_cols, mean, std, eps=1e-8):
+    _lib.call("lc_col_normalize_f32", _p(x), x.stride(0), n_rows, n_cols, _p(mean), _p(std), float(eps), _s())
+
+
+def pearson_cols(a, b, n, V):
+    r = torch.empty(V, dtype=torch.float64, device=a.device)
+    _lib.call("lc_pearson_cols", _p(a), a.stride(0), _p(b), b.stride(0), n, V, _p(r), _s())
+    return r
+
+
+# ------------------------------------------------------------------ small dense fp64
+def gram(x, T, p):
+    k = torch.empty((T, T), dtype=torch.float64, device=x.device)
+    _lib.call("lc_gram_f64", _p(x), x.stride(0), T, p, _p(k), T, _s())
+    return k
+
+
+def lambda_max(k, rows, F, N, steps):
+    work = torch.empty(F * (3 * N + 2 * steps + 8), dtype=torch.float64, device=k.device)
+    out = torch.empty(F, dtype=torch.float64, device=k.device)
+    _lib.call("lc_lambda_max", _p(k), k.stride(0), _p(rows), F, N, steps, _p(work), _p(out), _s())
+    return out
+
+
+def penalties(lmax, F, alphas, normalpha):
+    A = alphas.numel()
+    a2 = torch.empty(F * A, dtype=torch.float64, device=alphas.device)
+    _lib.call("lc_penalties", _p(lmax), F, _p(alphas), A, int(bool(normalpha)), _p(a2), _s())
+    return a2
+
+
+def batch_assemble(k, tr, va, rhs, a2, F, A, N, M, aug):
+    _lib.call("lc_batch_assemble", _p(k), k.stride(0), _p(tr), _p(va), _p(rhs), _p(a2), F, A, N, M, _p(aug), _s())
+
+
+def batch_chol_solve(aug, B, N, M, h):
+    linv = torch.empty((B, N // LC_NB, LC_NB, LC_NB), dtype=torch.float64, device=aug.device)
+    info = torch.empty(B, dtype=torch.int32, device=aug.device)
+    _lib.call("lc_batch_chol_solve", _p(aug), B, N, M, _p(linv), _p(h), _p(info), _s())
+    return info
+
+
+def transpose_rows(x, tr, N, p, out):
+    _lib.call("lc_transpose_rows_f64", _p(x), x.stride(0), _p(tr), N, p, _p(out), _s())
+
+
+# ------------------------------------------------------------------ V-wide contractions
+def val_stats(y, V, va, M, n_val, ystat, yblk):
+    _lib.call("lc_val_stats", _p(y), y.stride(0), V, _p(va), M, n_val, _p(ystat), _p(yblk), _s())
+
+
+def alpha_sweep_scores(h, A, M, N, y, V, tr, va, n_val, ystat, yblk, mode, part, scores, accumulate):
+    _lib.call("lc_alpha_sweep_scores", _p(h), A, M, N, _p(y), y.stride(0), V, _p(tr), _p(va), n_val, _p(ystat),
+              _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), _s())
+
+
+def select_alpha(scores, A, V, want_best=True, want_rowsum=False):
+    best = torch.empty(V, dtype=torch.int32, device=scores.device) if want_best else None
+    rowsum = torch.empty(A, dtype=torch.float64, device=scores.device) if want_rowsum else None
+    _lib.call("lc_select_alpha", _p(scores), A, V, _p(best), _p(rowsum), _s())
+    return best, rowsum
+
+
+def group_by_alpha(best, V, A, pad):
+    perm = torch.full((V + A * pad,), -1, dtype=torch.int32, device=best.device)
+    count = torch.empty(A, dtype=torch.int32, device=best.device)
+    _lib.call("lc_group_by_alpha", _p(best), V, A, pad, _p(perm), _p(count), _s())
+    return perm, count
+
+
+def gemm_grouped(a, lda, a_group_stride, b, ldb, brows, c, ldc, Mrows, Ncols, K, group_tiles):
+    G = len(group_tiles) - 1
+    arr = (ctypes.c_int32 * (G + 1))(*[int(t) for t in group_tiles])
+    _lib.call("lc_gemm_grouped_f32", _p(a), lda, a_group_stride, _p(b), ldb, _p(brows), _p(c), ldc, Mrows, Ncols, K,
+              arr, G, _s())

@@ -1,0 +1,151 @@
+"""Host-side statistics tail of the fit (O(V log V), vectorised numpy).
+
+Replaces the reference's three per-voxel Python loops (``nested_cv.py:433-436`` scipy
+``pearsonr`` p-values, ``:455-475`` Fisher combination) and the statsmodels
+``fdrcorrection`` call sites (``:158,:263,:282``) with closed forms over whole vectors,
+and builds the metrics dictionaries with the reference's keys and container types
+(``:480-616``).  The correlations themselves come from the device.
+"""
+import numpy as np
+
+try:                                     # scipy is a convenience, not a requirement
+    from scipy.special import betainc as _betainc
+except Exception:                        # pragma: no cover
+    _betainc = None
+
+
+def _betainc_cf(a, b, x, iters=300):
+    """Regularised incomplete beta I_x(a, b) by Lentz's continued fraction (numpy only)."""
+    from math import lgamma
+    x = np.asarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    flip = x > (a + 1.0) / (a + b + 2.0)
+    xx = np.where(flip, 1.0 - x, x)
+    aa = np.where(flip, b, a) * np.ones_like(x)
+    bb = np.where(flip, a, b) * np.ones_like(x)
+    tiny = 1e-300
+    with np.errstate(all="ignore"):
+        lbeta = np.vectorize(lambda p, q: lgamma(p) + lgamma(q) - lgamma(p + q))(aa, bb)
+        front = np.exp(aa * np.log(xx) + bb * np.log1p(-xx) - lbeta) / aa
+        c = np.ones_like(xx)
+        d = 1.0 - (aa + bb) * xx / (aa + 1.0)
+        d = np.where(np.abs(d) < tiny, tiny, d)
+        d = 1.0 / d
+        h = d.copy()
+        for m in range(1, iters + 1):
+            m2 = 2 * m
+            num = m * (bb - m) * xx / ((aa + m2 - 1.0) * (aa + m2))
+            d = 1.0 + num * d
+            d = np.where(np.abs(d) < tiny, tiny, d)
+            c = 1.0 + num / c
+            c = np.where(np.abs(c) < tiny, tiny, c)
+            d = 1.0 / d
+            h = h * d * c
+            num = -(aa + m) * (aa + bb + m) * xx / ((aa + m2) * (aa + m2 + 1.0))
+            d = 1.0 + num * d
+            d = np.where(np.abs(d) < tiny, tiny, d)
+            c = 1.0 + num / c
+            c = np.where(np.abs(c) < tiny, tiny, c)
+            d = 1.0 / d
+            delta = d * c
+            h = h * delta
+            if np.all(np.abs(delta - 1.0) < 1e-16):
+                break
+        val = front * h
+    val = np.where(xx <= 0.0, 0.0, val)
+    out = np.where(flip, 1.0 - val, val)
+    return np.clip(out, 0.0, 1.0)
+
+
+def pearson_pvalues(r, n):
+    """Two-sided p-value of Pearson r for sample size n, as scipy.stats.pearsonr computes it:
+    r ~ Beta(n/2-1, n/2-1) on [-1, 1] under H0, p = 2*sf(|r|) = 2*I_{(1-|r|)/2}(n/2-1, n/2-1).
+    NaN r -> p = 1 (nested_cv.py:436).  n == 2 -> p = 1."""
+    r = np.asarray(r, dtype=np.float64)
+    p = np.ones_like(r)
+    if n <= 2:
+        return p
+    ab = n / 2.0 - 1.0
+    ok = ~np.isnan(r)
+    x = (1.0 - np.abs(np.clip(r[ok], -1.0, 1.0))) / 2.0
+    inc = _betainc(ab, ab, x) if _betainc is not None else _betainc_cf(ab, ab, x)
+    p[ok] = np.minimum(2.0 * inc, 1.0)
+    return p
+
+
+def fisher_combine(fold_pvalues):
+    """nested_cv.py:441-477: p = chi2.sf(-2*sum(ln p_k), 2k).  For even degrees of freedom the
+    survival function is the closed form exp(-L) * sum_{i<k} L^i/i!, L = -sum(ln p_k); all-ones
+    rows give exactly 1.0 (the reference's shortcut)."""
+    P = np.asarray(fold_pvalues, dtype=np.float64)        # (k, V)
+    k = P.shape[0]
+    with np.errstate(divide="ignore"):
+        L = -np.sum(np.log(P), axis=0)
+    term = np.ones_like(L)
+    acc = np.ones_like(L)
+    with np.errstate(all="ignore"):
+        for i in range(1, k):
+            term = term * L / i
+            acc = acc + term
+        out = np.exp(-L) * acc
+    out = np.where(np.isinf(L), 0.0, out)
+    out = np.where(np.all(P == 1.0, axis=0), 1.0, out)
+    return np.minimum(out, 1.0)
+
+
+def fdrcorrection(pvals, alpha=0.05):
+    """Benjamini-Hochberg, the ``method='indep'`` branch of statsmodels' ``fdrcorrection``
+    (statsmodels is not a dependency here): returns (reject mask, adjusted p), input order."""
+    p = np.asarray(pvals, dtype=np.float64)
+    n = p.size
+    order = np.argsort(p)
+    ps = p[order]
+    frac = np.arange(1, n + 1) / float(n)
+    rej = ps <= frac * alpha
+    if rej.any():
+        rej[: np.nonzero(rej)[0].max()] = True
+    adj = np.minimum.accumulate((ps / frac)[::-1])[::-1]
+    adj[adj > 1] = 1
+    rej_o = np.empty(n, dtype=bool)
+    adj_o = np.empty(n, dtype=np.float64)
+    rej_o[order] = rej
+    adj_o[order] = adj
+    return rej_o, adj_o
+
+
+def _summary(scores):
+    s = np.asarray(scores)
+    return {"median_score": float(np.median(s)), "mean_score": float(np.mean(s)), "std_score": float(np.std(s)),
+            "min_score": float(np.min(s)), "max_score": float(np.max(s))}
+
+
+def _subset(metrics, scores, mask, n, tag):
+    if n > 0:
+        s = np.asarray(scores)[mask]
+        metrics.update({f"median_{tag}_score": float(np.median(s)), f"mean_{tag}_score": float(np.mean(s)),
+                        f"min_{tag}_score": float(np.min(s)), f"max_{tag}_score": float(np.max(s))})
+
+
+def train_test_metrics(correlations, pvalues, corrected, significant, best_alphas, n_significant):
+    """nested_cv.py:480-530 (keys, order and container types kept)."""
+    m = _summary(correlations)
+    m.update({"best_alphas": best_alphas.tolist(), "correlations": correlations, "p_values": pvalues,
+              "corrected_p_values": corrected.tolist(), "significant_mask": significant.tolist(),
+              "n_significant": int(n_significant),
+              "percent_significant": float(n_significant / len(correlations) * 100)})
+    _subset(m, correlations, significant, n_significant, "significant")
+    return m
+
+
+def full_cv_metrics(scores, pvalues, corrected, significant, majority, mean_alphas, n_significant, n_majority):
+    """nested_cv.py:533-616."""
+    m = _summary(scores)
+    m.update({"best_alphas": mean_alphas.tolist(), "correlations": scores.tolist(), "p_values": pvalues.tolist(),
+              "corrected_p_values": corrected.tolist(), "significant_mask": significant.tolist(),
+              "majority_significant_mask": majority.tolist(), "n_significant": int(n_significant),
+              "n_majority_significant": int(n_majority),
+              "percent_significant": float(n_significant / len(scores) * 100),
+              "percent_majority_significant": float(n_majority / len(scores) * 100)})
+    _subset(m, scores, significant, n_significant, "significant")
+    _subset(m, scores, majority, n_majority, "majority_significant")
+    return m
