@@ -51,6 +51,15 @@ const char* lc_last_error(void);
 /* 0 when device `dev` is a gfx950; LC_E_ARCH otherwise. */
 int lc_check_device(int dev);
 
+/* Optional per-kernel-class timing (bench.py's roofline leg): when enabled, entry points bracket
+ * their launches with HIP events on `stream`.  lc_timing_read synchronises on the recorded events,
+ * returns the summed milliseconds / call count of a slot and clears it.  Slot 0 is the fused
+ * alpha-sweep MFMA kernel alone. */
+int lc_timing_enable(int on);
+int lc_timing_slots(void);
+const char* lc_timing_name(int slot);
+int lc_timing_read(int slot, double* total_ms, int* calls);
+
 /* ---------------------------------------------------------------- preprocessing */
 
 /* FIR.make_delayed (features/FIR_expander.py:24-43).  d_stim: (nt, ndim) f32 or f64,

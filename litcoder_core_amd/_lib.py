@@ -23,6 +23,10 @@ SIGNATURES = {
     "lc_version": (c_int, []),
     "lc_last_error": (c_char_p, []),
     "lc_check_device": (c_int, [c_int]),
+    "lc_timing_enable": (c_int, [c_int]),
+    "lc_timing_slots": (c_int, []),
+    "lc_timing_name": (c_char_p, [c_int]),
+    "lc_timing_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),
     "lc_fir_delay": (c_int, [_ptr, c_int, c_int64, c_int64, c_int64, POINTER(c_int64), c_int, c_int, _ptr, c_int64, _ptr]),
     "lc_lanczos_interp": (c_int, [_ptr, c_int, c_int64, c_int64, c_int64, _ptr, _ptr, c_int64, c_double, c_double,
                                   c_int, _ptr, c_int64, _ptr]),

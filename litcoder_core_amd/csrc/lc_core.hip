@@ -1,6 +1,8 @@
 // Library-level entry points: version, per-thread error string, device check.
 #include "lc_common.h"
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace lc {
 static thread_local char g_err[512] = "";
@@ -13,7 +15,75 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace lc
 
+namespace lc {
+namespace {
+struct EventPair { hipEvent_t a, b; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<EventPair> g_events[T_SLOTS];
+std::vector<hipEvent_t> g_open[T_SLOTS];
+const char* const g_names[T_SLOTS] = {
+    "alpha_sweep_gemm", "alpha_sweep_finalize", "grouped_gemm", "batch_chol_solve", "lambda_max", "gram",
+    "batch_assemble", "val_stats", "pearson_cols", "gather", "scatter_axpy", "select_group", "fir_delay",
+    "lanczos_interp", "cast", "col_stats"};
+}  // namespace
+
+bool timing_on() { return g_on; }
+
+void timing_begin(int slot, hipStream_t s) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_open[slot].push_back(e);
+}
+
+void timing_end(int slot, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_open[slot].empty()) return;
+    EventPair p;
+    p.a = g_open[slot].back();
+    g_open[slot].pop_back();
+    if (hipEventCreate(&p.b) != hipSuccess) { (void)hipEventDestroy(p.a); return; }
+    (void)hipEventRecord(p.b, s);
+    g_events[slot].push_back(p);
+}
+}  // namespace lc
+
 extern "C" int lc_version(void) { return 100; }
+
+extern "C" int lc_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(lc::g_mu);
+    lc::g_on = on != 0;
+    return LC_OK;
+}
+
+extern "C" int lc_timing_slots(void) { return lc::T_SLOTS; }
+
+extern "C" const char* lc_timing_name(int slot) {
+    return (slot >= 0 && slot < lc::T_SLOTS) ? lc::g_names[slot] : "";
+}
+
+extern "C" int lc_timing_read(int slot, double* total_ms, int* calls) {
+    LC_REQUIRE(slot >= 0 && slot < lc::T_SLOTS && total_ms && calls, LC_E_BADARG, "lc_timing_read: bad argument");
+    std::vector<lc::EventPair> ev;
+    {
+        std::lock_guard<std::mutex> lk(lc::g_mu);
+        ev.swap(lc::g_events[slot]);
+    }
+    double sum = 0.0;
+    for (auto& p : ev) {
+        float ms = 0.f;
+        LC_HIP(hipEventSynchronize(p.b));
+        LC_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+        sum += ms;
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    *total_ms = sum;
+    *calls = (int)ev.size();
+    return LC_OK;
+}
 
 extern "C" const char* lc_last_error(void) { return lc::g_err; }
 

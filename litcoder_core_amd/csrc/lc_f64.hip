@@ -457,6 +457,7 @@ extern "C" int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, 
     LC_REQUIRE(d_x && d_k, LC_E_BADARG, "lc_gram_f64: null pointer");
     LC_REQUIRE(T > 0 && p > 0 && ldx >= p && ldk >= T && T < (1 << 30), LC_E_SHAPE, "lc_gram_f64: bad shape");
     const unsigned nt = (unsigned)lc::ceil_div<long long>(T, 64);
+    lc::ScopedTimer timer_(lc::T_GRAM, lc::as_stream(stream));
     hipLaunchKernelGGL(k_gram, dim3(nt, nt), dim3(256), 0, lc::as_stream(stream), d_x, (long long)ldx, (int)T, (int)p,
                        d_k, (long long)ldk);
     return lc::launched("k_gram");
@@ -467,6 +468,7 @@ extern "C" int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_ro
     LC_REQUIRE(d_k && d_rows && d_work && d_lmax, LC_E_BADARG, "lc_lambda_max: null pointer");
     LC_REQUIRE(F > 0 && N > 0 && steps > 0, LC_E_SHAPE, "lc_lambda_max: bad shape");
     hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_LAMBDA_MAX, s);
     hipLaunchKernelGGL(k_lz_init, dim3(F), dim3(256), 0, s, d_rows, N, steps, d_work);
     if (int rc = lc::launched("k_lz_init")) return rc;
     for (int it = 0; it < steps; ++it) {
@@ -494,6 +496,7 @@ extern "C" int lc_batch_assemble(const double* d_k, int64_t ldk, const int32_t* 
     LC_REQUIRE(d_k && d_tr && d_a2 && d_aug && (d_va || d_rhs), LC_E_BADARG, "lc_batch_assemble: null pointer");
     LC_REQUIRE(F > 0 && A > 0 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0 && F * A <= 65535, LC_E_SHAPE,
                "lc_batch_assemble: need N %% %d == 0, M %% %d == 0, F*A <= 65535", LC_NB, LC_MB);
+    lc::ScopedTimer timer_(lc::T_ASSEMBLE, lc::as_stream(stream));
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)(N + M), (unsigned)(F * A)), dim3(256), 0, lc::as_stream(stream), d_k,
                        (long long)ldk, d_tr, d_va, d_rhs, d_a2, A, N, M, d_aug);
     return lc::launched("k_assemble");
@@ -515,6 +518,7 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
     LC_REQUIRE(B > 0 && B <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
                "lc_batch_chol_solve: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
     hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_CHOL_SOLVE, s);
     LC_HIP(hipMemsetAsync(d_info, 0, sizeof(int32_t) * B, s));
     const int nb = N / NB;
     const int R = N + M;

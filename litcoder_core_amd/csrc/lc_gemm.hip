@@ -191,11 +191,12 @@ k_gemm_f32(const float* __restrict__ A, long long lda, long long a_group_stride,
             for (int r = 0; r < 16; ++r) {
                 const int il = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const bool ok = il < sa.n_val;
-                const float yv = ok ? sa.y[(long long)sa.va[il] * sa.ldy + col] - ym : 0.f;
+                const float yraw = ok ? sa.y[(long long)sa.va[il] * sa.ldy + col] : 0.f;
                 const float pv = acc[mi][ni][r];
-                yc[r] = yv;
-                // corr: statistics of pred; R2: statistics of the residual (y - pred)
-                p[r] = ok ? (sa.mode == LC_SCORE_CORR ? pv : yv - pv) : 0.f;
+                yc[r] = ok ? yraw - ym : 0.f;
+                // corr: statistics of pred; R2: statistics of the residual fl32(y - pred), formed from
+                // the raw target exactly as ``(Presp - pred).var()`` does (ridge_regression.py:128)
+                p[r] = ok ? (sa.mode == LC_SCORE_CORR ? pv : yraw - pv) : 0.f;
                 s1 += p[r];
             }
             s1 += __shfl_xor(s1, 32);
@@ -315,10 +316,14 @@ extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, cons
     gt.start[0] = 0;
     gt.start[1] = (int)Ntiles;
     ScoreArgs sa{d_y, (long long)ldy, d_va, d_ystat, d_part, M, n_val, mode};
-    hipLaunchKernelGGL(k_gemm_f32<true>, dim3((unsigned)(Mtiles * Ntiles)), dim3(256), GEMM_LDS_BYTES, s, d_h,
-                       (long long)N, 0ll, Mrows, d_y, (long long)ldy, d_tr, N, Mtiles, gt, (float*)nullptr,
-                       (long long)V, sa);
+    {
+        lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
+        hipLaunchKernelGGL(k_gemm_f32<true>, dim3((unsigned)(Mtiles * Ntiles)), dim3(256), GEMM_LDS_BYTES, s, d_h,
+                           (long long)N, 0ll, Mrows, d_y, (long long)ldy, d_tr, N, Mtiles, gt, (float*)nullptr,
+                           (long long)V, sa);
+    }
     if (int rc = lc::launched("k_gemm_f32<score>")) return rc;
+    lc::ScopedTimer timer_(lc::T_SWEEP_FINALIZE, s);
     hipLaunchKernelGGL(k_score_finalize, dim3((unsigned)lc::ceil_div<long long>(V, 256), (unsigned)A), dim3(256), 0, s,
                        d_part, d_ystat, d_yblk, A, M, n_val, (long long)V, mode, d_scores, accumulate);
     return lc::launched("k_score_finalize");
@@ -345,6 +350,7 @@ extern "C" int lc_gemm_grouped_f32(const float* d_a, int64_t lda, int64_t a_grou
     const int Mtiles = (int)lc::ceil_div<long long>(Mrows, BM);
     LC_REQUIRE((long long)Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_gemm_grouped_f32: grid too large");
     ScoreArgs sa{};
+    lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, lc::as_stream(stream));
     hipLaunchKernelGGL(k_gemm_f32<false>, dim3((unsigned)(Mtiles * Ntiles)), dim3(256), GEMM_LDS_BYTES,
                        lc::as_stream(stream), d_a, (long long)lda, (long long)a_group_stride, (int)Mrows, d_b,
                        (long long)ldb, d_brows, (int)K, Mtiles, gt, d_c, (long long)ldc, sa);

@@ -110,6 +110,7 @@ extern "C" int lc_fir_delay(const void* d_stim, int dtype, int64_t nt, int64_t n
     LC_REQUIRE(ld_in >= ndim && ld_out >= ndim * nd, LC_E_SHAPE, "lc_fir_delay: leading dimension too small");
     if (nt == 0 || ndim == 0 || nd == 0) return LC_OK;
     hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_FIR, s);
     for (int k0 = 0; k0 < nd; k0 += FIR_MAX_DELAYS) {
         FirDelays dl;
         dl.n = nd - k0 < FIR_MAX_DELAYS ? nd - k0 : FIR_MAX_DELAYS;
@@ -136,6 +137,7 @@ extern "C" int lc_lanczos_interp(const void* d_data, int dtype, int64_t n_old, i
     LC_REQUIRE(ld_in >= D && ld_out >= (rectify ? 2 * D : D), LC_E_SHAPE, "lc_lanczos_interp: leading dimension too small");
     if (n_new == 0 || D == 0) return LC_OK;
     hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_LANCZOS, s);
     dim3 grid((unsigned)n_new, (unsigned)lc::ceil_div<long long>(D, LZ_THREADS * LZ_CPT));
 #define LC_LZ(T, R)                                                                                             \
     hipLaunchKernelGGL((k_lanczos<T, R>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, n_old, D, ld_in, d_oldtime, \

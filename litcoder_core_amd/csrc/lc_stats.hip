@@ -250,6 +250,7 @@ extern "C" int lc_cast_f64_f32(const double* d_in, int64_t ld_in, float* d_out, 
     LC_REQUIRE(rows >= 0 && cols >= 0 && ld_in >= cols && ld_out >= cols, LC_E_SHAPE, "lc_cast_f64_f32: bad shape");
     if (rows == 0 || cols == 0) return LC_OK;
     dim3 grid((unsigned)rows, (unsigned)lc::imin(lc::ceil_div<long long>(cols, 1024), 1024));
+    lc::ScopedTimer timer_(lc::T_CAST, lc::as_stream(stream));
     hipLaunchKernelGGL(k_cast_f64_f32, grid, dim3(256), 0, lc::as_stream(stream), d_in, (long long)ld_in, d_out,
                        (long long)ld_out, (long long)cols);
     return lc::launched("k_cast_f64_f32");
@@ -262,6 +263,7 @@ extern "C" int lc_gather_f32(const float* d_in, int64_t ld_in, const int32_t* d_
     LC_REQUIRE(n_rows >= 0 && n_cols >= 0 && ld_out >= n_cols, LC_E_SHAPE, "lc_gather_f32: bad shape");
     if (n_rows == 0 || n_cols == 0) return LC_OK;
     dim3 grid((unsigned)n_rows, (unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 1024), 1024));
+    lc::ScopedTimer timer_(lc::T_GATHER, lc::as_stream(stream));
     hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, lc::as_stream(stream), d_in, ld_in, d_rows, d_cols, n_cols,
                        d_out, ld_out);
     return lc::launched("k_gather");
@@ -273,6 +275,7 @@ extern "C" int lc_scatter_axpy_f32(const float* d_w, int64_t ld_w, int64_t n_row
     LC_REQUIRE(n_rows >= 0 && n_cols >= 0, LC_E_SHAPE, "lc_scatter_axpy_f32: bad shape");
     if (n_rows == 0 || n_cols == 0) return LC_OK;
     dim3 grid((unsigned)n_rows, (unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 1024), 1024));
+    lc::ScopedTimer timer_(lc::T_SCATTER, lc::as_stream(stream));
     hipLaunchKernelGGL(k_scatter_axpy, grid, dim3(256), 0, lc::as_stream(stream), d_w, ld_w, d_cols, n_cols, scale,
                        d_acc, ld_acc);
     return lc::launched("k_scatter_axpy");
@@ -304,6 +307,7 @@ extern "C" int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int3
     LC_REQUIRE(M % LC_MB == 0 && n_val > 0 && n_val <= M, LC_E_SHAPE, "lc_val_stats: need 0 < n_val <= M, M %% %d == 0",
                LC_MB);
     if (V <= 0) return LC_OK;
+    lc::ScopedTimer timer_(lc::T_VAL_STATS, lc::as_stream(stream));
     hipLaunchKernelGGL(k_val_stats, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, CM_RG), 0,
                        lc::as_stream(stream), d_y, ldy, V, d_va, M, n_val, d_ystat, d_yblk);
     return lc::launched("k_val_stats");
@@ -314,6 +318,7 @@ extern "C" int lc_pearson_cols(const float* d_a, int64_t lda, const float* d_b, 
     LC_REQUIRE(d_a && d_b && d_r, LC_E_BADARG, "lc_pearson_cols: null pointer");
     LC_REQUIRE(n > 0 && V >= 0 && lda >= V && ldb >= V, LC_E_SHAPE, "lc_pearson_cols: bad shape");
     if (V == 0) return LC_OK;
+    lc::ScopedTimer timer_(lc::T_PEARSON, lc::as_stream(stream));
     hipLaunchKernelGGL(k_pearson_cols, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, PR_RG), 0,
                        lc::as_stream(stream), d_a, lda, d_b, ldb, n, V, d_r);
     return lc::launched("k_pearson_cols");

@@ -63,7 +63,8 @@ class RidgeCVEngine:
                  shard: Optional[ShardContext] = None, lanczos_steps: int = LANCZOS_STEPS):
         self.dev = ops.device()
         self.shard = shard or ShardContext()
-        X_all = np.asarray(X_all) if not torch.is_tensor(X_all) else X_all
+        if not isinstance(X_all, _DeviceShapes):
+            X_all = np.asarray(X_all)
         self.Ttot, self.p = X_all.shape
         self.V = Y_all.shape[1]
         if Y_all.shape[0] != self.Ttot:
@@ -85,10 +86,11 @@ class RidgeCVEngine:
         self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
 
     def _resident(self, arr, ld):
-        if torch.is_tensor(arr):            # already on the device, already fp32 and padded (bench path)
-            if arr.dtype != torch.float32 or not arr.is_cuda or arr.shape[1] != ld or not arr.is_contiguous():
-                raise ValueError("device inputs must be contiguous fp32 tensors padded to the tile width")
-            return arr
+        if isinstance(arr, _DeviceShapes):  # already resident: fp32, contiguous, zero-padded to the tile width
+            t = arr.tensor
+            if t.dtype != torch.float32 or not t.is_cuda or t.shape[1] != ld or not t.is_contiguous():
+                raise ValueError(f"device inputs must be contiguous fp32 tensors with {ld} (zero-padded) columns")
+            return t
         return ops.upload_f32(arr, ld, self.dev)
 
     # -------------------------------------------------------------- per-outer-fold data
@@ -145,36 +147,33 @@ class RidgeCVEngine:
                                        self.mode, part, scores, accumulate=f > 0)
         return scores, torch.cat(infos)
 
-    # -------------------------------------------------------------- one outer fold
-    def run_fold(self, tr_rows, te_rows, inner_rel, single_alpha, weight_scale) -> _FoldResult:
-        tr_rows = np.asarray(tr_rows, dtype=np.int64)
-        te_rows = np.asarray(te_rows, dtype=np.int64)
-        X, Y, K = self._fold_data(tr_rows)
-        inner_abs = [(tr_rows[np.asarray(a, dtype=np.int64)], tr_rows[np.asarray(b, dtype=np.int64)])
-                     for a, b in inner_rel]
-        scores, info = self._alpha_scores(K, Y, inner_abs)
-        A, V = self.A, self.V
+    # -------------------------------------------------------------- alpha selection
+    def choose(self, scores, single_alpha):
+        """(Vp,) int32 device vector of alpha indices: per-voxel first argmax (nested_cv.py:405-411)
+        or, for ``single_alpha``, the argmax of the across-voxel mean (:396-400; the per-alpha sums
+        are all-reduced over the voxel shards)."""
         if single_alpha:
-            # nested_cv.py:396-400: one alpha for all voxels = argmax of the across-voxel mean
-            _, rowsum = ops.select_alpha(scores, A, self.Vp, want_best=False, want_rowsum=True)
+            _, rowsum = ops.select_alpha(scores, self.A, self.Vp, want_best=False, want_rowsum=True)
             total = self.shard.allreduce_sum(rowsum.cpu().numpy())
             k = int(np.argmax(total))                      # first maximum, like torch.argmax
-            best = torch.full((self.Vp,), k, dtype=torch.int32, device=self.dev)
-        else:
-            best, _ = ops.select_alpha(scores, A, self.Vp)
+            return torch.full((self.Vp,), k, dtype=torch.int32, device=self.dev)
+        return ops.select_alpha(scores, self.A, self.Vp)[0]
+
+    # -------------------------------------------------------------- refit (ridge_torch)
+    def refit(self, X, Y, K, tr_rows, best, extra_rows=()):
+        """Weights of every voxel at its chosen alpha, in alpha-sorted voxel order
+        (ridge_regression.py:9-63).  Returns (Ws (p_pad, Vs), Ys (N_o + len(extra_rows), Vs), perm,
+        N_o): column j of Ws / Ys is voxel perm[j] (-1 = padding).  ``extra_rows`` of Y are gathered
+        below the training rows in the same voxel order (the test targets)."""
+        A, V = self.A, self.V
         perm, count = ops.group_by_alpha(best, V, A, COL_TILE)
         count_h = count.cpu().numpy()
-        if int(info.cpu().numpy().any()):
-            raise RuntimeError("Cholesky failed: Gram matrix + alpha^2 I is not positive definite")
         used = [a for a in range(A) if count_h[a] > 0]
         tiles = [0]
         for a in used:
             tiles.append(tiles[-1] + (int(count_h[a]) + COL_TILE - 1) // COL_TILE)
-        Vs = tiles[-1] * COL_TILE
-        G = len(used)
-
-        # ---- refit on the whole outer-train block (ridge_torch, ridge_regression.py:9-63)
-        n_o, n_t = len(tr_rows), len(te_rows)
+        Vs, G = tiles[-1] * COL_TILE, len(used)
+        n_o = len(tr_rows)
         N_o = ops.pad_to(n_o, LC_NB)
         tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
         lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
@@ -184,14 +183,43 @@ class RidgeCVEngine:
         aug = torch.empty((G, N_o + self.p_pad, N_o), dtype=torch.float64, device=self.dev)
         ops.batch_assemble(K, tr_o, None, rhs, a2_o, 1, G, N_o, self.p_pad, aug)
         Malpha = torch.empty((G, self.p_pad, N_o), dtype=torch.float32, device=self.dev)
-        info_o = ops.batch_chol_solve(aug, G, N_o, self.p_pad, Malpha)
+        info = ops.batch_chol_solve(aug, G, N_o, self.p_pad, Malpha)
         del aug, rhs
-
-        rows_s = ops.idx_tensor(np.concatenate([tr_rows, np.full(N_o - n_o, -1), te_rows]), N_o + n_t, self.dev)
-        Ys = torch.empty((N_o + n_t, Vs), dtype=torch.float32, device=self.dev)
-        ops.gather(Y, self.Vp, rows_s, N_o + n_t, perm, Vs, Ys)
+        n_x = len(extra_rows)
+        rows_s = ops.idx_tensor(np.concatenate([tr_rows, np.full(N_o - n_o, -1), np.asarray(extra_rows, dtype=np.int64)]),
+                                N_o + n_x, self.dev)
+        Ys = torch.empty((N_o + n_x, Vs), dtype=torch.float32, device=self.dev)
+        ops.gather(Y, self.Vp, rows_s, N_o + n_x, perm, Vs, Ys)
         Ws = torch.empty((self.p_pad, Vs), dtype=torch.float32, device=self.dev)
         ops.gemm_grouped(Malpha, N_o, self.p_pad * N_o, Ys, Vs, None, Ws, Vs, self.p_pad, Vs, N_o, tiles)
+        if int(info.cpu().numpy().any()):
+            raise RuntimeError("Cholesky failed in the refit: Gram matrix + alpha^2 I is not positive definite")
+        return Ws, Ys, perm, N_o
+
+    def unsort(self, vec_sorted, perm, Vs):
+        """Sorted-voxel-order host vector -> natural voxel order."""
+        perm_h = perm[:Vs].cpu().numpy()
+        live = perm_h >= 0
+        out = np.empty(self.V, dtype=vec_sorted.dtype)
+        out[perm_h[live]] = vec_sorted[live]
+        return out
+
+    # -------------------------------------------------------------- one outer fold
+    def run_fold(self, tr_rows, te_rows, inner_rel, single_alpha, weight_scale) -> _FoldResult:
+        tr_rows = np.asarray(tr_rows, dtype=np.int64)
+        te_rows = np.asarray(te_rows, dtype=np.int64)
+        n_t = len(te_rows)
+        if n_t < 2:
+            raise ValueError("x and y must have length at least 2.")      # scipy.stats.pearsonr's message
+        X, Y, K = self._fold_data(tr_rows)
+        inner_abs = [(tr_rows[np.asarray(a, dtype=np.int64)], tr_rows[np.asarray(b, dtype=np.int64)])
+                     for a, b in inner_rel]
+        scores, info = self._alpha_scores(K, Y, inner_abs)
+        best = self.choose(scores, single_alpha)
+        Ws, Ys, perm, N_o = self.refit(X, Y, K, tr_rows, best, te_rows)
+        if int(info.cpu().numpy().any()):
+            raise RuntimeError("Cholesky failed: Gram matrix + alpha^2 I is not positive definite")
+        Vs = Ws.shape[1]
         # ---- test predictions and per-voxel Pearson r (nested_cv.py:151-155, 251-257)
         Xte = torch.empty((n_t, self.p_pad), dtype=torch.float32, device=self.dev)
         ops.gather(X, self.p_pad, ops.idx_tensor(te_rows, n_t, self.dev), n_t, None, self.p_pad, Xte)
@@ -199,15 +227,7 @@ class RidgeCVEngine:
         ops.gemm_grouped(Xte, self.p_pad, 0, Ws, Vs, None, pred, Vs, n_t, Vs, self.p_pad, [0, Vs // COL_TILE])
         r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
         ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
-
-        if int(info_o.cpu().numpy().any()):
-            raise RuntimeError("Cholesky failed in the refit: Gram matrix + alpha^2 I is not positive definite")
-        perm_h = perm[:Vs].cpu().numpy()
-        r_sorted = r_s.cpu().numpy()
-        live = perm_h >= 0
-        r = np.empty(V, dtype=np.float64)
-        r[perm_h[live]] = r_sorted[live]
-        return _FoldResult(r, best[:V].cpu().numpy(), n_t)
+        return _FoldResult(self.unsort(r_s.cpu().numpy(), perm, Vs), best[: self.V].cpu().numpy(), n_t)
 
     def weights(self) -> np.ndarray:
         return self.W_acc[:, : self.V].cpu().numpy()
@@ -225,7 +245,7 @@ def _fold_lists(r32: np.ndarray, n_test: int):
     """What ``_calculate_correlations_pvalues`` (nested_cv.py:418-438) returns for one fold:
     list of np.float32 r (NaN -> Python 0.0) and list of float64 p (NaN -> 1.0)."""
     nan = np.isnan(r32)
-    p = stats.pearson_pvalues(r32.astype(np.float64), n_test)
+    p = stats.pearson_pvalues(r32, n_test)
     corrs = [0.0 if bad else v for v, bad in zip(r32, nan)]
     pvals = [1.0 if bad else v for v, bad in zip(p, nan)]
     return corrs, pvals
@@ -267,7 +287,6 @@ class NestedCVModel(BasePredictivityModel):
             logger.info("use_gpu=False ignored: this implementation runs on the MI355X only")
         shard = self.shard or ShardContext()
         train_test = X_test is not None and y_test is not None
-        T = len(features)
         V_total = np.shape(targets)[1]
         lo, hi = shard.bounds(V_total)
 
@@ -277,11 +296,46 @@ class NestedCVModel(BasePredictivityModel):
         if train_test:
             X_all = np.concatenate([np.asarray(features), np.asarray(X_test)], axis=0)
             Y_all = np.concatenate([cols(targets), cols(y_test)], axis=0)
-            # nested_cv.py:130-132 passes ``groups`` positionally into ``trim_size``
-            inner = create_folds(len(features), folding_type, n_inner_folds, chunk_length, groups)
-            outer = [(np.arange(T), T + np.arange(len(X_test)), inner)]
         else:
             X_all, Y_all = features, cols(targets)
+        return self._run(X_all, Y_all, len(features), len(X_test) if train_test else 0, V_total, groups, folding_type,
+                         n_outer_folds, n_inner_folds, chunk_length, alphas, alpha_fdr, single_alpha, normalpha,
+                         use_corr, normalize_features, normalize_targets, weights_on_host=True)
+
+    def fit_predict_device(self, features_dev: torch.Tensor, targets_dev: torch.Tensor, n_features: int,
+                           n_voxels_local: int, n_voxels_total: Optional[int] = None, n_test_rows: int = 0,
+                           weights_on_host: bool = False, **kwargs):
+        """Same fit with the inputs already resident in HBM (extension, not in the reference):
+        ``features_dev`` (T[+T_test], pad32(p)) and ``targets_dev`` (T[+T_test], pad128(V_local)) are
+        zero-padded contiguous fp32 device tensors; ``targets_dev`` holds this rank's voxel block.
+        kwargs as ``fit_predict`` (folding / alphas / flags).  With ``weights_on_host=False`` the
+        (p, V_local) weights come back as a device tensor."""
+        opt = dict(groups=None, folding_type="chunked", n_outer_folds=5, n_inner_folds=5, chunk_length=20, alphas=None,
+                   alpha_fdr=0.05, single_alpha=False, normalpha=True, use_corr=True, normalize_features=False,
+                   normalize_targets=False)
+        unknown = set(kwargs) - set(opt) - {"use_gpu", "singcutoff"}
+        if unknown:
+            raise TypeError(f"unexpected keyword arguments: {sorted(unknown)}")
+        opt.update({k: v for k, v in kwargs.items() if k in opt})
+        if opt["alphas"] is None:
+            opt["alphas"] = np.logspace(-1, 8, 10)
+        T = features_dev.shape[0] - n_test_rows
+        shapes = _DeviceShapes(features_dev, n_features), _DeviceShapes(targets_dev, n_voxels_local)
+        return self._run(shapes[0], shapes[1], T, n_test_rows, n_voxels_total or n_voxels_local, opt["groups"],
+                         opt["folding_type"], opt["n_outer_folds"], opt["n_inner_folds"], opt["chunk_length"],
+                         opt["alphas"], opt["alpha_fdr"], opt["single_alpha"], opt["normalpha"], opt["use_corr"],
+                         opt["normalize_features"], opt["normalize_targets"], weights_on_host=weights_on_host)
+
+    def _run(self, X_all, Y_all, T, n_test_rows, V_total, groups, folding_type, n_outer_folds, n_inner_folds,
+             chunk_length, alphas, alpha_fdr, single_alpha, normalpha, use_corr, normalize_features,
+             normalize_targets, weights_on_host):
+        shard = self.shard or ShardContext()
+        train_test = n_test_rows > 0
+        if train_test:
+            # nested_cv.py:130-132 passes ``groups`` positionally into ``trim_size``
+            inner = create_folds(T, folding_type, n_inner_folds, chunk_length, groups)
+            outer = [(np.arange(T), T + np.arange(n_test_rows), inner)]
+        else:
             if groups is not None and folding_type == "group":
                 splits = create_folds(T, "group", n_outer_folds, groups=groups)
             else:
@@ -297,7 +351,7 @@ class NestedCVModel(BasePredictivityModel):
         eng = RidgeCVEngine(X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard)
         scale = 1.0 if train_test else 1.0 / len(outer)
         folds = [eng.run_fold(tr, te, inner, single_alpha, scale) for tr, te, inner in outer]
-        weights = eng.weights()
+        weights = eng.weights() if weights_on_host else eng.W_acc[:, : eng.V]
 
         # ---- gather the per-voxel vectors of every fold (the only V-sized exchange)
         r_all = shard.allgather_cols(np.stack([f.r for f in folds]), V_total)
@@ -323,6 +377,13 @@ class NestedCVModel(BasePredictivityModel):
         mean_alphas = np.mean(fold_alpha, axis=0)
         metrics = stats.full_cv_metrics(scores, pcomb, padj, sig, majority, mean_alphas, np.sum(sig), np.sum(majority))
         return metrics, weights, mean_alphas
+
+
+class _DeviceShapes:
+    """A resident, zero-padded device matrix together with its logical column count."""
+
+    def __init__(self, tensor: torch.Tensor, n_cols: int):
+        self.tensor, self.shape = tensor, (tensor.shape[0], int(n_cols))
 
 
 def fit_nested_cv(features: np.ndarray, targets: np.ndarray, **kwargs: Any):

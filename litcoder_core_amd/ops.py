@@ -51,6 +51,22 @@ def idx_tensor(rows, length, dev, fill=-1):
     return torch.from_numpy(h).to(dev)
 
 
+def timing_enable(on=True):
+    _lib.call("lc_timing_enable", int(bool(on)))
+
+
+def timing_read():
+    """{kernel class: (total milliseconds, launches)} since the last read (synchronises)."""
+    lib = _lib.load()
+    out = {}
+    for slot in range(lib.lc_timing_slots()):
+        ms, n = ctypes.c_double(0), ctypes.c_int(0)
+        _lib.call("lc_timing_read", slot, ctypes.byref(ms), ctypes.byref(n))
+        if n.value:
+            out[lib.lc_timing_name(slot).decode()] = (ms.value, n.value)
+    return out
+
+
 # ------------------------------------------------------------------ preprocessing
 def fir_delay(stim, delays, circpad):
     """stim: (nt, ndim) f32/f64 device tensor -> (nt, ndim*len(delays)) f64 device tensor."""

@@ -59,16 +59,21 @@ def _betainc_cf(a, b, x, iters=300):
 
 def pearson_pvalues(r, n):
     """Two-sided p-value of Pearson r for sample size n, as scipy.stats.pearsonr computes it:
-    r ~ Beta(n/2-1, n/2-1) on [-1, 1] under H0, p = 2*sf(|r|) = 2*I_{(1-|r|)/2}(n/2-1, n/2-1).
-    NaN r -> p = 1 (nested_cv.py:436).  n == 2 -> p = 1."""
-    r = np.asarray(r, dtype=np.float64)
-    p = np.ones_like(r)
+    r ~ Beta(n/2-1, n/2-1) on [-1, 1] under H0, p = 2*sf(|r|) = 2*(1 - I_x(ab, ab)), x = (|r|+1)/2.
+    ``x`` is formed in r's own dtype (scipy >= 1.14 keeps float32 statistics in float32 there and only
+    then evaluates the incomplete beta in float64); NaN r -> p = 1 (nested_cv.py:436); n == 2 -> 1."""
+    r = np.asarray(r)
+    if r.dtype not in (np.float32, np.float64):
+        r = r.astype(np.float64)
+    p = np.ones(r.shape, dtype=np.float64)
     if n <= 2:
         return p
     ab = n / 2.0 - 1.0
     ok = ~np.isnan(r)
-    x = (1.0 - np.abs(np.clip(r[ok], -1.0, 1.0))) / 2.0
-    inc = _betainc(ab, ab, x) if _betainc is not None else _betainc_cf(ab, ab, x)
+    one = r.dtype.type(1)
+    x = ((np.abs(np.clip(r[ok], -one, one)) + one) / r.dtype.type(2)).astype(np.float64)
+    # 1 - I_x(ab, ab) == I_{1-x}(ab, ab) by symmetry; 1 - x is exact in float64
+    inc = _betainc(ab, ab, 1.0 - x) if _betainc is not None else _betainc_cf(ab, ab, 1.0 - x)
     p[ok] = np.minimum(2.0 * inc, 1.0)
     return p
 

@@ -1,0 +1,169 @@
+"""Host-side logic of litcoder_core_amd that needs no GPU: fold generation, the statistics tail,
+the Downsampler front-end's host methods, the C-ABI library's exported symbols, sharding helpers."""
+import ctypes
+import json
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import litcoder_core_amd as lc
+from litcoder_core_amd import _lib, folding, stats
+from oracle import folds as ofolds
+from oracle import stats as ostats
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports every function include/litcoder_hip.h declares;
+    the ctypes table names exactly the same set."""
+    hdr = open(os.path.join(ROOT, "include", "litcoder_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(lc_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().lc_version() >= 100
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.LitcoderHipError, match="no CPU fallback"):
+        lc.FIR.make_delayed(np.zeros((4, 2)), [1])
+    with pytest.raises(_lib.LitcoderHipError):
+        lc.NestedCVModel("r").fit_predict(np.zeros((40, 3)), np.zeros((40, 2)), folding_type="kfold")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "litcoder_core_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def test_folds_match_reference_golden(golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, "folds.json"))):
+        if c["seed"] is not None:
+            random.seed(c["seed"])
+            np.random.seed(c["seed"])
+        groups = np.array(c["groups"]) if "groups" in c else None
+        sp = folding.create_folds(c["n"], c["fold_type"], c["n_folds"], c["chunk_length"], c["trim_size"], groups)
+        assert [[list(map(int, a)), list(map(int, b))] for a, b in sp] == c["splits"], c["fold_type"]
+
+
+def test_folds_match_oracle_on_more_shapes():
+    rng = np.random.default_rng(3)
+    for n, k in [(10, 2), (11, 3), (97, 5), (100, 7), (2400, 5)]:
+        for ft in ("kfold", "kfold_trimmed", "timeseries", "chunked_contiguous"):
+            a = folding.create_folds(n, ft, k, 7)
+            b = ofolds.create_folds(n, ft, k, 7)
+            assert all(list(x[0]) == list(y[0]) and list(x[1]) == list(y[1]) for x, y in zip(a, b)), (n, k, ft)
+        g = rng.integers(0, k + 3, size=n)
+        a, b = folding.create_folds(n, "group", k, groups=g), ofolds.create_folds(n, "group", k, groups=g)
+        assert all(list(x[0]) == list(y[0]) and list(x[1]) == list(y[1]) for x, y in zip(a, b))
+        for ft in ("chunked", "chunked_trimmed"):
+            random.seed(n); np.random.seed(n)
+            a = folding.create_folds(n, ft, k, 7)
+            random.seed(n); np.random.seed(n)
+            b = ofolds.create_folds(n, ft, k, 7)
+            assert all(list(x[0]) == list(y[0]) and list(x[1]) == list(y[1]) for x, y in zip(a, b)), (n, k, ft)
+    with pytest.raises(ValueError, match="Unknown folding type"):
+        folding.create_folds(10, "nope", 2)
+    with pytest.raises(ValueError, match="Groups must be provided"):
+        folding.create_folds(10, "group", 2)
+    with pytest.raises(ValueError):        # the reference's groups-into-trim_size positional slip
+        folding.create_folds(300, "kfold_trimmed", 3, 20, np.arange(300))
+
+
+def test_pearson_pvalues_match_scipy():
+    from scipy.stats import pearsonr
+    rng = np.random.default_rng(0)
+    for n in (3, 10, 600):
+        x = rng.standard_normal((n, 40)).astype(np.float32)
+        y = (0.3 * x + rng.standard_normal((n, 40))).astype(np.float32)
+        rp = [pearsonr(x[:, i], y[:, i]) for i in range(40)]
+        r = np.array([a for a, _ in rp])                      # float32, like the reference's fold scores
+        p = np.array([float(b) for _, b in rp])
+        assert r.dtype == np.float32
+        np.testing.assert_allclose(stats.pearson_pvalues(r, n), p, rtol=1e-9, atol=1e-300)
+        r64 = np.array([float(pearsonr(x[:, i].astype(np.float64), y[:, i].astype(np.float64))[0]) for i in range(40)])
+        p64 = np.array([float(pearsonr(x[:, i].astype(np.float64), y[:, i].astype(np.float64))[1]) for i in range(40)])
+        np.testing.assert_allclose(stats.pearson_pvalues(r64, n), p64, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(stats.pearson_pvalues(np.array([np.nan, 1.0, -1.0, 0.0]), 50), [1.0, 0.0, 0.0, 1.0], atol=1e-15)
+    assert stats.pearson_pvalues(np.array([0.5]), 2).tolist() == [1.0]
+    # numpy-only continued fraction agrees with scipy's betainc
+    from scipy.special import betainc
+    x = np.linspace(0, 1, 101)
+    for ab in (0.5, 4.0, 299.0):
+        np.testing.assert_allclose(stats._betainc_cf(ab, ab, x), betainc(ab, ab, x), rtol=1e-10, atol=1e-300)
+
+
+def test_fisher_and_fdr_match_oracle():
+    rng = np.random.default_rng(1)
+    P = rng.uniform(0, 1, size=(5, 300)) ** 3
+    P[:, 7] = 1.0
+    P[2, 9] = 0.0
+    np.testing.assert_allclose(stats.fisher_combine(P), ostats.fisher_combine([list(r) for r in P]), rtol=1e-12, atol=0)
+    for alpha in (0.05, 0.2):
+        r1, a1 = stats.fdrcorrection(P[0], alpha)
+        r2, a2 = ostats.bh_fdr(P[0], alpha)
+        assert np.array_equal(r1, r2) and np.array_equal(a1, a2)
+    rej, adj = stats.fdrcorrection(np.array([0.04, 0.001, 0.03, 0.5, 0.011]), 0.05)     # hand-checked KAT
+    assert rej.tolist() == [True, True, True, False, True]
+    np.testing.assert_allclose(adj, [0.05, 0.005, 0.05, 0.5, 0.0275], atol=1e-15)
+
+
+def test_metrics_dicts_have_reference_keys(golden_dir):
+    g = np.load(os.path.join(golden_dir, "fits.npz"))
+    r = np.array([0.5, 0.1, -0.2, 0.9], dtype=np.float32)
+    p = stats.pearson_pvalues(r.astype(np.float64), 60)
+    sig, adj = stats.fdrcorrection(p, 0.05)
+    m = stats.train_test_metrics(list(r), list(p), adj, sig, np.array([1, 2, 3, 4], dtype=np.float32), sig.sum())
+    want = sorted(k.split("__m_")[1] for k in g.files if k.startswith("tt_kfold_p__m_"))
+    assert sorted(m) == want
+    m = stats.full_cv_metrics(r.astype(np.float64), p, adj, sig, sig, np.ones(4), sig.sum(), sig.sum())
+    want = sorted(k.split("__m_")[1] for k in g.files if k.startswith("cv_kfold_p__m_"))
+    assert sorted(m) == want
+    assert isinstance(m["correlations"], list) and isinstance(m["median_score"], float)
+
+
+def test_downsampler_host_methods_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "downsample.npz"))
+    ds = lc.Downsampler()
+    d, ot, nt = g["data"], g["oldtime"], g["newtime"]
+    np.testing.assert_allclose(ds.downsample(d, ot, nt), g["rect"], atol=1e-15)
+    for m in ("average", "sum", "last"):
+        np.testing.assert_allclose(ds.downsample(d, ot, nt, method=m, split_indices=list(g["labels"])), g[m], atol=1e-15)
+        np.testing.assert_allclose(ds.downsample(d, ot, nt, method="legacy_" + m, split_indices=g["bounds"]),
+                                   g["legacy_" + m], atol=1e-15)
+    np.testing.assert_allclose(ds.downsample(d, ot, nt, method="sinc", window=3, cutoff_mult=1.0), g["sinc_w3"],
+                               atol=1e-13)
+    assert set(ds.available_methods) == set(lc.Downsampler.METHOD_PARAMS)
+    assert ds.get_method_params("lanczos") == {"required": ["window", "cutoff_mult"], "optional": ["rectify"]}
+    with pytest.raises(ValueError, match="Required parameter 'split_indices' missing for method 'average'"):
+        ds.downsample(d, ot, nt, method="average")
+    with pytest.raises(ValueError, match="Unsupported downsampling method"):
+        ds.get_method_params("zzz")
+
+
+def test_fir_helpers_without_gpu():
+    f = lc.FIR(delays=[1, 2, 3, 4])
+    assert f.n_delays() == 4 and f.output_dim(10) == 40 and f.valid_length(100) == 96
+    assert lc.FIR(delays=[-3, 2], circpad=True).valid_length(50) == 50
+    assert "FIR(delays=[1, 2, 3, 4], circpad=False)" in f.summary(10, 100)
+    with pytest.raises(ValueError, match="delays must be provided"):
+        lc.FIR().expand(np.zeros((3, 3)))
+
+
+def test_shard_bounds_partition():
+    for n, w in [(80000, 8), (10, 3), (7, 8), (200000, 8)]:
+        b = [lc.shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
