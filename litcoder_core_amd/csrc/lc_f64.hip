@@ -214,36 +214,41 @@ __global__ void __launch_bounds__(1024) k_lz_step(int N, int steps, int step, do
     }
 }
 
-// Largest eigenvalue of the k x k tridiagonal (a, b) by bisection on the Sturm count.
-__global__ void k_lz_eig(int N, int steps, double* work, double* __restrict__ lmax) {
-    const int f = blockIdx.x;
-    if (threadIdx.x != 0) return;
+// Largest eigenvalue of the k x k tridiagonal (a, b): 64-way multisection on the Sturm count, one
+// wave per fold.  count(x) = number of eigenvalues < x; we shrink [lo, hi] around the smallest x
+// with count(x) == k.
+__global__ void __launch_bounds__(64) k_lz_eig(int N, int steps, double* work, double* __restrict__ lmax) {
+    const int f = blockIdx.x, lane = threadIdx.x;
     double* base = lz_base(work, f, N, steps);
     const double* al = base + 3ll * N;
     const double* be = al + steps;
     const int k = (int)(be + steps)[0];
-    if (k <= 0) { lmax[f] = 0.0; return; }
+    if (k <= 0) { if (lane == 0) lmax[f] = 0.0; return; }
     double lo = al[0], hi = al[0];
     for (int i = 0; i < k; ++i) {
         const double bl = i > 0 ? fabs(be[i - 1]) : 0.0, br = i + 1 < k ? fabs(be[i]) : 0.0;
         lo = fmin(lo, al[i] - bl - br);
         hi = fmax(hi, al[i] + bl + br);
     }
-    // count(x) = number of eigenvalues < x ; we want the smallest x with count(x) == k
-    for (int it = 0; it < 200 && hi > lo; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        if (mid == lo || mid == hi) break;
+    for (int round = 0; round < 14 && hi > lo; ++round) {
+        const double w = (hi - lo) / 65.0;
+        const double x = lo + w * (lane + 1);
         int cnt = 0;
-        double q = al[0] - mid;
+        double q = al[0] - x;
         if (q < 0.0) ++cnt;
         for (int i = 1; i < k; ++i) {
             const double den = q != 0.0 ? q : 1e-300;
-            q = al[i] - mid - be[i - 1] * be[i - 1] / den;
+            q = al[i] - x - be[i - 1] * be[i - 1] / den;
             if (q < 0.0) ++cnt;
         }
-        if (cnt >= k) hi = mid; else lo = mid;
+        const unsigned long long full = __ballot(cnt >= k);      // lanes whose x is above every eigenvalue
+        const int first = full ? __ffsll((long long)full) - 1 : 64;
+        const double nlo = first == 0 ? lo : lo + w * first;     // x of lane first-1
+        const double nhi = first == 64 ? hi : lo + w * (first + 1);
+        lo = nlo;
+        hi = nhi;
     }
-    lmax[f] = hi;
+    if (lane == 0) lmax[f] = hi;
 }
 
 __global__ void k_penalties(const double* __restrict__ lmax, int F, const double* __restrict__ alphas, int A,

@@ -7,8 +7,10 @@
 // Operand feeding: the MFMA consumes two k per issue (lane half h = lane>>5 supplies one).  We
 // let half h own k = 4h..4h+3 of every 8-k group, so ONE ds_read_b128 per operand block feeds
 // four MFMAs (component t of the float4 pairs k = t (h=0) with k = 4+t (h=1)).  A is staged
-// row-major with a 36-float row stride (conflict-free b128 reads), B is staged k-interleaved
-// [k/4][n][k%4] via a 4x4 register transpose so its fragment is also one b128.
+// row-major with a 36-float row stride (conflict-free b128 reads).  B is staged as it comes from
+// memory ([k][n], float4 rows, no register shuffles) and its fragment is four conflict-free
+// ds_read_b32 -- the f32 MFMA is slow enough (64 cycles each) that LDS read width is irrelevant,
+// while shuffles in the staging path would force early waits on the prefetched global loads.
 #include "lc_common.h"
 
 namespace {
@@ -18,7 +20,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int AS_LD = BK + 4;                     // floats per staged A row
 constexpr int AS_SZ = BM * AS_LD;                 // floats per A stage
-constexpr int BS_SZ = (BK / 4) * BN * 4;          // floats per B stage
+constexpr int BS_SZ = BK * BN;                    // floats per B stage
 constexpr int GEMM_LDS_BYTES = 2 * (AS_SZ + BS_SZ) * 4;
 constexpr int MAX_GROUPS = 64;
 
@@ -45,14 +47,33 @@ __device__ inline int xcd_tile_id(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <bool SCORE>
+#define READ_FRAG(g, fa0, fa1, fb0, fb1)                                             \
+    fa0 = *reinterpret_cast<const float4*>(as + (g) * 8);                            \
+    fa1 = *reinterpret_cast<const float4*>(as + 32 * AS_LD + (g) * 8);               \
+    fb0 = make_float4(bs[((g) * 8 + 0) * BN], bs[((g) * 8 + 1) * BN], bs[((g) * 8 + 2) * BN], bs[((g) * 8 + 3) * BN]); \
+    fb1 = make_float4(bs[((g) * 8 + 0) * BN + 32], bs[((g) * 8 + 1) * BN + 32], bs[((g) * 8 + 2) * BN + 32],         \
+                      bs[((g) * 8 + 3) * BN + 32])
+
+#define MFMA4(acc_, fa_, fb_)                                                        \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_.x, fb_.x, acc_, 0, 0, 0);        \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_.y, fb_.y, acc_, 0, 0, 0);        \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_.z, fb_.z, acc_, 0, 0, 0);        \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_.w, fb_.w, acc_, 0, 0, 0)
+
+#define MFMA_GROUP(fa0, fa1, fb0, fb1) \
+    MFMA4(acc00, fa0, fb0);            \
+    MFMA4(acc01, fa0, fb1);            \
+    MFMA4(acc10, fa1, fb0);            \
+    MFMA4(acc11, fa1, fb1)
+
+template <bool SCORE, bool HAS_ROWS>
 __global__ void __launch_bounds__(256, 2)
 k_gemm_f32(const float* __restrict__ A, long long lda, long long a_group_stride, int Mrows,
            const float* __restrict__ B, long long ldb, const int* __restrict__ brows, int K, int Mtiles,
            GroupTiles gt, float* __restrict__ C, long long ldc, ScoreArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                    // [2][BM][AS_LD]
-    float* Bs = lds + 2 * AS_SZ;        // [2][BK/4][BN][4]
+    float* Bs = lds + 2 * AS_SZ;        // [2][BK][BN]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -70,94 +91,98 @@ k_gemm_f32(const float* __restrict__ A, long long lda, long long a_group_stride,
         A += (long long)g * a_group_stride;
     }
 
-    // ---- global -> register staging maps
+    // ---- global -> register staging maps (branch-free: out-of-range rows are clamped to a valid
+    // row; their products are either multiplied by zero-padded operand entries or never stored)
     // A: 128 rows x 8 float4 (along k); thread handles (row = idx>>3, kq = idx&7), idx = tid + 256 q
-    const float* a_ptr[4];
-    bool a_ok[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + 256 * q;
-        const int row = m0 + (idx >> 3);
-        a_ok[q] = row < Mrows;
-        a_ptr[q] = A + (long long)(a_ok[q] ? row : 0) * lda + (idx & 7) * 4;
-    }
+    const int a_kq = (tid & 7) * 4;
+    const float* a_p0 = A + (long long)min(m0 + (tid >> 3), Mrows - 1) * lda + a_kq;
+    const float* a_p1 = A + (long long)min(m0 + 32 + (tid >> 3), Mrows - 1) * lda + a_kq;
+    const float* a_p2 = A + (long long)min(m0 + 64 + (tid >> 3), Mrows - 1) * lda + a_kq;
+    const float* a_p3 = A + (long long)min(m0 + 96 + (tid >> 3), Mrows - 1) * lda + a_kq;
     // B: thread handles k = 4*kg .. 4*kg+3 (kg = tid>>5) and columns n = 4*(tid&31) .. +3
     const int b_kg = tid >> 5, b_nq = tid & 31;
     const float* b_col = B + n0 + b_nq * 4;
+    const int* b_rows = HAS_ROWS ? brows + b_kg * 4 : nullptr;
 
-    float4 ra[4], rb[4];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            ra[q] = a_ok[q] ? *reinterpret_cast<const float4*>(a_ptr[q] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = k0 + b_kg * 4 + e;
-            const int r = brows ? brows[k] : k;
-            rb[e] = r >= 0 ? *reinterpret_cast<const float4*>(b_col + (long long)r * ldb)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float* as = As + buf * AS_SZ;
-        float* bs = Bs + buf * BS_SZ;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + 256 * q;
-            *reinterpret_cast<float4*>(as + (idx >> 3) * AS_LD + (idx & 7) * 4) = ra[q];
-        }
-        float* dst = bs + (b_kg * BN + b_nq * 4) * 4;
-        *reinterpret_cast<float4*>(dst + 0) = make_float4(rb[0].x, rb[1].x, rb[2].x, rb[3].x);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(rb[0].y, rb[1].y, rb[2].y, rb[3].y);
-        *reinterpret_cast<float4*>(dst + 8) = make_float4(rb[0].z, rb[1].z, rb[2].z, rb[3].z);
-        *reinterpret_cast<float4*>(dst + 12) = make_float4(rb[0].w, rb[1].w, rb[2].w, rb[3].w);
-    };
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    int4 bidx = make_int4(0, 0, 0, 0);     // raw B row indices of the tile to be loaded next (one tile ahead)
+#define LOAD_IDX(kt_) \
+    if (HAS_ROWS) bidx = *reinterpret_cast<const int4*>(b_rows + (kt_) * BK)
+    // -1 (padding) -> row 0: the matching A column is zero, so the product vanishes
+#define B_ROW(e_, raw_) (HAS_ROWS ? max((raw_), 0) : k0_ + b_kg * 4 + (e_))
+#define LOAD_TILE(kt_)                                                                   \
+    {                                                                                    \
+        const int k0_ = (kt_) * BK;                                                      \
+        ra0 = *reinterpret_cast<const float4*>(a_p0 + k0_);                              \
+        ra1 = *reinterpret_cast<const float4*>(a_p1 + k0_);                              \
+        ra2 = *reinterpret_cast<const float4*>(a_p2 + k0_);                              \
+        ra3 = *reinterpret_cast<const float4*>(a_p3 + k0_);                              \
+        rb0 = *reinterpret_cast<const float4*>(b_col + (long long)B_ROW(0, bidx.x) * ldb); \
+        rb1 = *reinterpret_cast<const float4*>(b_col + (long long)B_ROW(1, bidx.y) * ldb); \
+        rb2 = *reinterpret_cast<const float4*>(b_col + (long long)B_ROW(2, bidx.z) * ldb); \
+        rb3 = *reinterpret_cast<const float4*>(b_col + (long long)B_ROW(3, bidx.w) * ldb); \
+    }
+    const int a_woff = (tid >> 3) * AS_LD + a_kq;
+    const int b_woff = b_kg * 4 * BN + b_nq * 4;
+#define STORE_TILE(buf_)                                              \
+    {                                                                 \
+        float* as_ = As + (buf_) * AS_SZ + a_woff;                    \
+        float* bs_ = Bs + (buf_) * BS_SZ + b_woff;                    \
+        *reinterpret_cast<float4*>(as_) = ra0;                        \
+        *reinterpret_cast<float4*>(as_ + 32 * AS_LD) = ra1;           \
+        *reinterpret_cast<float4*>(as_ + 64 * AS_LD) = ra2;           \
+        *reinterpret_cast<float4*>(as_ + 96 * AS_LD) = ra3;           \
+        *reinterpret_cast<float4*>(bs_) = rb0;                        \
+        *reinterpret_cast<float4*>(bs_ + BN) = rb1;                   \
+        *reinterpret_cast<float4*>(bs_ + 2 * BN) = rb2;               \
+        *reinterpret_cast<float4*>(bs_ + 3 * BN) = rb3;               \
+    }
 
-    f32x16 acc[2][2];
+    f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
     const int KT = K / BK;
-    load_tile(0);
-    store_tile(0);
+    LOAD_IDX(0);
+    LOAD_TILE(0);
+    if (KT > 1) { LOAD_IDX(1); }
+    STORE_TILE(0);
     __syncthreads();
 
     const int a_frag = (wm * 64 + li) * AS_LD + lh * 4;          // + mi*32*AS_LD + g*8
-    const int b_frag = (lh * BN + wn * 64 + li) * 4;             // + g*2*BN*4 + ni*32*4
+    const int b_frag = lh * 4 * BN + wn * 64 + li;               // + (g*8 + t)*BN + ni*32
 
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
+        if (kt + 1 < KT) LOAD_TILE(kt + 1);
+        if (kt + 2 < KT) { LOAD_IDX(kt + 2); }
         const float* as = As + cur * AS_SZ + a_frag;
         const float* bs = Bs + cur * BS_SZ + b_frag;
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            float4 fa[2], fb[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) fa[mi] = *reinterpret_cast<const float4*>(as + mi * 32 * AS_LD + g * 8);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) fb[ni] = *reinterpret_cast<const float4*>(bs + g * 2 * BN * 4 + ni * 32 * 4);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].x, fb[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].y, fb[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].z, fb[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
-                }
-        }
-        if (kt + 1 < KT) store_tile(cur ^ 1);
+        // fragment reads run one 8-k group ahead of the MFMAs that consume them
+        float4 a0, a1, b0, b1, c0, c1, d0, d1;
+        READ_FRAG(0, a0, a1, b0, b1);
+        READ_FRAG(1, c0, c1, d0, d1);
+        MFMA_GROUP(a0, a1, b0, b1);
+        READ_FRAG(2, a0, a1, b0, b1);
+        MFMA_GROUP(c0, c1, d0, d1);
+        READ_FRAG(3, c0, c1, d0, d1);
+        MFMA_GROUP(a0, a1, b0, b1);
+        MFMA_GROUP(c0, c1, d0, d1);
+        // pin the issue order: two groups of fragment reads up front, then {16 MFMA, one group of
+        // reads} x 2, then 32 MFMA (a group = 2 ds_read_b128 + 8 ds_read_b32, possibly paired)
+        __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+        if (kt + 1 < KT) STORE_TILE(cur ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue.  Accumulator map (32x32 block): column = lane & 31,
     // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    const f32x16 acc[2][2] = {{acc00, acc01}, {acc10, acc11}};
     if (!SCORE) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -281,11 +306,11 @@ int check_gemm_shapes(const char* who, const void* a, long long lda, const void*
     return LC_OK;
 }
 
-template <bool SCORE>
+template <bool SCORE, bool HAS_ROWS>
 int set_lds_attr() {
     static thread_local bool done = false;
     if (!done) {
-        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f32<SCORE>),
+        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f32<SCORE, HAS_ROWS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         done = true;
     }
@@ -305,7 +330,7 @@ extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, cons
     LC_REQUIRE(mode == LC_SCORE_CORR || mode == LC_SCORE_R2, LC_E_BADARG, "lc_alpha_sweep_scores: bad mode %d", mode);
     LC_REQUIRE(ldy >= V, LC_E_SHAPE, "lc_alpha_sweep_scores: ldy < V");
     if (int rc = check_gemm_shapes("lc_alpha_sweep_scores", d_h, N, d_y, ldy, V, N)) return rc;
-    if (int rc = set_lds_attr<true>()) return rc;
+    if (int rc = set_lds_attr<true, true>()) return rc;
     hipStream_t s = lc::as_stream(stream);
     const int Mrows = A * M;
     const int Mtiles = lc::ceil_div(Mrows, BM);
@@ -318,7 +343,7 @@ extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, cons
     ScoreArgs sa{d_y, (long long)ldy, d_va, d_ystat, d_part, M, n_val, mode};
     {
         lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
-        hipLaunchKernelGGL(k_gemm_f32<true>, dim3((unsigned)(Mtiles * Ntiles)), dim3(256), GEMM_LDS_BYTES, s, d_h,
+        hipLaunchKernelGGL((k_gemm_f32<true, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(256), GEMM_LDS_BYTES, s, d_h,
                            (long long)N, 0ll, Mrows, d_y, (long long)ldy, d_tr, N, Mtiles, gt, (float*)nullptr,
                            (long long)V, sa);
     }
@@ -346,13 +371,20 @@ extern "C" int lc_gemm_grouped_f32(const float* d_a, int64_t lda, int64_t a_grou
     }
     LC_REQUIRE(gt.start[G] == Ntiles, LC_E_SHAPE, "lc_gemm_grouped_f32: last group offset %d != %lld column tiles",
                gt.start[G], Ntiles);
-    if (int rc = set_lds_attr<false>()) return rc;
     const int Mtiles = (int)lc::ceil_div<long long>(Mrows, BM);
     LC_REQUIRE((long long)Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_gemm_grouped_f32: grid too large");
     ScoreArgs sa{};
     lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, lc::as_stream(stream));
-    hipLaunchKernelGGL(k_gemm_f32<false>, dim3((unsigned)(Mtiles * Ntiles)), dim3(256), GEMM_LDS_BYTES,
-                       lc::as_stream(stream), d_a, (long long)lda, (long long)a_group_stride, (int)Mrows, d_b,
-                       (long long)ldb, d_brows, (int)K, Mtiles, gt, d_c, (long long)ldc, sa);
+    if (d_brows) {
+        if (int rc = set_lds_attr<false, true>()) return rc;
+        hipLaunchKernelGGL((k_gemm_f32<false, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(256), GEMM_LDS_BYTES,
+                           lc::as_stream(stream), d_a, (long long)lda, (long long)a_group_stride, (int)Mrows, d_b,
+                           (long long)ldb, d_brows, (int)K, Mtiles, gt, d_c, (long long)ldc, sa);
+    } else {
+        if (int rc = set_lds_attr<false, false>()) return rc;
+        hipLaunchKernelGGL((k_gemm_f32<false, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(256), GEMM_LDS_BYTES,
+                           lc::as_stream(stream), d_a, (long long)lda, (long long)a_group_stride, (int)Mrows, d_b,
+                           (long long)ldb, d_brows, (int)K, Mtiles, gt, d_c, (long long)ldc, sa);
+    }
     return lc::launched("k_gemm_f32<plain>");
 }

@@ -34,7 +34,7 @@ from .folding import create_folds
 
 logger = logging.getLogger(__name__)
 
-LANCZOS_STEPS = 192                 # Lanczos iterations for S[0]^2 (converged far below fp32 eps, see tests)
+LANCZOS_STEPS = 96                  # Lanczos iterations for S[0]^2: <= 1e-14 relative on the cfg2 Grams (profiles/)
 AUG_BUDGET_BYTES = 24 << 30         # cap on the batched (fold, alpha) fp64 systems resident at once
 
 
@@ -204,20 +204,28 @@ class RidgeCVEngine:
         out[perm_h[live]] = vec_sorted[live]
         return out
 
-    # -------------------------------------------------------------- one outer fold
-    def run_fold(self, tr_rows, te_rows, inner_rel, single_alpha, weight_scale) -> _FoldResult:
+    # -------------------------------------------------------------- one outer fold, in three phases
+    # begin (async: inner-CV sweeps) -> refit (one sync on the alpha histogram, then async refit /
+    # prediction / Pearson / D2H) -> collect (wait for the fold's results).  The caller interleaves
+    # the phases of consecutive folds so that the host statistics of fold f run while the GPU works
+    # on fold f+1.
+    def fold_begin(self, tr_rows, te_rows, inner_rel):
         tr_rows = np.asarray(tr_rows, dtype=np.int64)
         te_rows = np.asarray(te_rows, dtype=np.int64)
-        n_t = len(te_rows)
-        if n_t < 2:
+        if len(te_rows) < 2:
             raise ValueError("x and y must have length at least 2.")      # scipy.stats.pearsonr's message
         X, Y, K = self._fold_data(tr_rows)
         inner_abs = [(tr_rows[np.asarray(a, dtype=np.int64)], tr_rows[np.asarray(b, dtype=np.int64)])
                      for a, b in inner_rel]
         scores, info = self._alpha_scores(K, Y, inner_abs)
-        best = self.choose(scores, single_alpha)
+        return dict(tr=tr_rows, te=te_rows, X=X, Y=Y, K=K, scores=scores, info=info)
+
+    def fold_refit(self, st, single_alpha, weight_scale):
+        tr_rows, te_rows, X, Y, K = st["tr"], st["te"], st["X"], st["Y"], st["K"]
+        n_t = len(te_rows)
+        best = self.choose(st["scores"], single_alpha)
         Ws, Ys, perm, N_o = self.refit(X, Y, K, tr_rows, best, te_rows)
-        if int(info.cpu().numpy().any()):
+        if int(st["info"].cpu().numpy().any()):
             raise RuntimeError("Cholesky failed: Gram matrix + alpha^2 I is not positive definite")
         Vs = Ws.shape[1]
         # ---- test predictions and per-voxel Pearson r (nested_cv.py:151-155, 251-257)
@@ -227,27 +235,51 @@ class RidgeCVEngine:
         ops.gemm_grouped(Xte, self.p_pad, 0, Ws, Vs, None, pred, Vs, n_t, Vs, self.p_pad, [0, Vs // COL_TILE])
         r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
         ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
-        return _FoldResult(self.unsort(r_s.cpu().numpy(), perm, Vs), best[: self.V].cpu().numpy(), n_t)
+        # results leave through pinned buffers so the copies do not stall the host
+        h_r = torch.empty(Vs, dtype=torch.float64, pin_memory=True)
+        h_perm = torch.empty(Vs, dtype=torch.int32, pin_memory=True)
+        h_best = torch.empty(self.V, dtype=torch.int32, pin_memory=True)
+        h_r.copy_(r_s, non_blocking=True)
+        h_perm.copy_(perm[:Vs], non_blocking=True)
+        h_best.copy_(best[: self.V], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return dict(done=done, r=h_r, perm=h_perm, best=h_best, n_t=n_t, keep=(r_s, perm, best))
+
+    def fold_collect(self, pend) -> _FoldResult:
+        pend["done"].synchronize()
+        perm_h = pend["perm"].numpy()
+        live = perm_h >= 0
+        r = np.empty(self.V, dtype=np.float64)
+        r[perm_h[live]] = pend["r"].numpy()[live]
+        return _FoldResult(r, pend["best"].numpy().copy(), pend["n_t"])
+
+    def run_fold(self, tr_rows, te_rows, inner_rel, single_alpha, weight_scale) -> _FoldResult:
+        st = self.fold_begin(tr_rows, te_rows, inner_rel)
+        return self.fold_collect(self.fold_refit(st, single_alpha, weight_scale))
 
     def weights(self) -> np.ndarray:
         return self.W_acc[:, : self.V].cpu().numpy()
 
 
 def _alpha_vector(alphas, idx, single_alpha):
-    """The tensor the reference builds for the chosen alphas, dtype quirks included
-    (nested_cv.py:401-403: torch default for the element type; :409-411: fp32)."""
+    """The array the reference returns for the chosen alphas, dtype quirks included
+    (nested_cv.py:401-403: ``torch.tensor([alpha] * V)`` takes torch's default for the element type --
+    float64 for numpy scalars, float32 for Python floats; :409-411: explicit float32)."""
     if single_alpha:
-        return torch.tensor([alphas[int(idx[0])]] * len(idx)).numpy()
-    return torch.tensor([alphas[int(i)] for i in idx], dtype=torch.float32).numpy()
+        dtype = torch.tensor([alphas[int(idx[0])]]).numpy().dtype
+        return np.full(len(idx), alphas[int(idx[0])], dtype=dtype)
+    return np.asarray(alphas, dtype=np.float64)[np.asarray(idx, dtype=np.int64)].astype(np.float32)
 
 
 def _fold_lists(r32: np.ndarray, n_test: int):
     """What ``_calculate_correlations_pvalues`` (nested_cv.py:418-438) returns for one fold:
     list of np.float32 r (NaN -> Python 0.0) and list of float64 p (NaN -> 1.0)."""
-    nan = np.isnan(r32)
     p = stats.pearson_pvalues(r32, n_test)
-    corrs = [0.0 if bad else v for v, bad in zip(r32, nan)]
-    pvals = [1.0 if bad else v for v, bad in zip(p, nan)]
+    corrs, pvals = list(r32), list(p)
+    for i in np.nonzero(np.isnan(r32))[0]:
+        corrs[i] = 0.0
+        pvals[i] = 1.0
     return corrs, pvals
 
 
@@ -350,20 +382,28 @@ class NestedCVModel(BasePredictivityModel):
 
         eng = RidgeCVEngine(X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard)
         scale = 1.0 if train_test else 1.0 / len(outer)
-        folds = [eng.run_fold(tr, te, inner, single_alpha, scale) for tr, te, inner in outer]
-        weights = eng.weights() if weights_on_host else eng.W_acc[:, : eng.V]
-
-        # ---- gather the per-voxel vectors of every fold (the only V-sized exchange)
-        r_all = shard.allgather_cols(np.stack([f.r for f in folds]), V_total)
-        idx_all = shard.allgather_cols(np.stack([f.best_idx for f in folds]).astype(np.int32), V_total)
-
         fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
-        for f, r, idx in zip(folds, r_all, idx_all):
+
+        def tail(pend):
+            """Host statistics of one finished fold; runs while the GPU works on the next fold.
+            The all-gather over voxel shards is the only V-sized exchange of the fit."""
+            f = eng.fold_collect(pend)
+            r = shard.allgather_cols(f.r[None, :], V_total)[0]
+            idx = shard.allgather_cols(f.best_idx.astype(np.int32)[None, :], V_total)[0]
             corrs, pvals = _fold_lists(r.astype(np.float32), f.n_test)
             fold_scores.append(corrs)
             fold_p.append(pvals)
             fold_alpha.append(_alpha_vector(alphas, idx, single_alpha))
             fold_sig.append(stats.fdrcorrection(pvals, alpha=alpha_fdr))
+
+        pending = None
+        for tr, te, inner in outer:
+            st = eng.fold_begin(tr, te, inner)
+            if pending is not None:
+                tail(pending)
+            pending = eng.fold_refit(st, single_alpha, scale)
+        tail(pending)
+        weights = eng.weights() if weights_on_host else eng.W_acc[:, : eng.V]
 
         if train_test:
             sig, padj = fold_sig[0]

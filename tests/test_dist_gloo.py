@@ -46,6 +46,12 @@ class OracleEngine:
             r = (pc * yc).sum(0) / np.sqrt((pc ** 2).sum(0) * (yc ** 2).sum(0))
         self.W += scale * W.numpy()
         return ncv._FoldResult(r, idx, len(te))
+    def fold_begin(self, tr, te, inner):
+        return (tr, te, inner)
+    def fold_refit(self, st, single_alpha, scale):
+        return self.run_fold(*st, single_alpha, scale)
+    def fold_collect(self, pend):
+        return pend
     def weights(self):
         return self.W
 

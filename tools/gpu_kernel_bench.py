@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of individual kernels at the BASELINE cfg2 shapes (one inner fold).
+    python tools/gpu_kernel_bench.py [sweep] [lanczos] [chol]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from litcoder_core_amd import ops  # noqa: E402
+from litcoder_core_amd._lib import LC_MB, LC_NB, LC_SCORE_CORR  # noqa: E402
+
+dev = ops.device()
+what = set(sys.argv[1:]) or {"sweep", "lanczos", "chol"}
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+if "sweep" in what:
+    A, n_v, n_i, V, T = 20, 480, 1920, 80000, 3000
+    M, N = ops.pad_to(n_v, LC_MB), ops.pad_to(n_i, LC_NB)
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    H = torch.randn((A * M, N), generator=g, device=dev, dtype=torch.float32) * 0.02
+    Y = torch.randn((T, V), generator=g, device=dev, dtype=torch.float32)
+    tr = ops.idx_tensor(np.r_[0:1920], N, dev)
+    va = ops.idx_tensor(np.r_[1920:2400], M, dev)
+    ystat = torch.empty((3, V), dtype=torch.float32, device=dev)
+    yblk = torch.empty((M // LC_MB, V), dtype=torch.float32, device=dev)
+    part = torch.empty((A * M // LC_MB, 4, V), dtype=torch.float32, device=dev)
+    scores = torch.empty((A, V), dtype=torch.float32, device=dev)
+    ops.val_stats(Y, V, va, M, n_v, ystat, yblk)
+    fn = lambda: ops.alpha_sweep_scores(H, A, M, N, Y, V, tr, va, n_v, ystat, yblk, LC_SCORE_CORR, part, scores, False)
+    ms = timeit(fn)
+    fl = 2.0 * A * n_v * n_i * V
+    print(f"alpha_sweep (gemm+finalize): {ms:.2f} ms  -> {fl / ms / 1e9:.1f} TFLOP/s algorithmic")
+    # correctness spot check against torch fp64 on a few columns
+    cols = [0, 17, 40000, 79999]
+    pred = (H.double() @ Y[:1920][:, cols].double()).reshape(A, M, len(cols))[:, :n_v]
+    yv = Y[1920:2400][:, cols].double()
+    zy = (yv - yv.mean(0)) / (yv.std(0) + 1e-8)
+    zp = (pred - pred.mean(1, keepdim=True)) / (pred.std(1, keepdim=True) + 1e-8)
+    ref = (zy.unsqueeze(0) * zp).mean(1)
+    print("   max |score - fp64 ref| on sample columns:", float((scores[:, cols].double() - ref).abs().max()))
+
+if "lanczos" in what:
+    rng = np.random.default_rng(0)
+    for (T, p, ar) in [(2400, 3072, 0.0), (2400, 3072, 0.8), (2400, 768, 0.5)]:
+        x = rng.standard_normal((T, p))
+        if ar:
+            for t in range(1, T):
+                x[t] = ar * x[t - 1] + np.sqrt(1 - ar * ar) * x[t]
+        x = x.astype(np.float32)
+        dx = ops.upload_f32(x, ops.pad_to(p, 32), dev)
+        K = ops.gram(dx, T, p)
+        rows = np.arange(0, 1920)
+        N = ops.pad_to(len(rows), LC_NB)
+        idx = ops.idx_tensor(rows, N, dev).reshape(1, N)
+        ref = float(torch.linalg.eigvalsh(K[:1920, :1920].cpu())[-1])
+        errs = []
+        for steps in (16, 24, 32, 48, 64, 96, 128, 192):
+            lm = float(ops.lambda_max(K, idx, 1, N, steps).cpu()[0])
+            errs.append(f"{steps}:{abs(lm - ref) / ref:.1e}")
+        print(f"lambda_max T{T} p{p} ar{ar}: " + " ".join(errs))
+    idx5 = torch.stack([ops.idx_tensor(np.r_[0:480 * f, 480 * (f + 1):2400], 1920, dev) for f in range(5)])
+    for steps in (64, 192):
+        ms = timeit(lambda: ops.lambda_max(K, idx5, 5, 1920, steps), reps=3, warm=1)
+        print(f"lambda_max F=5 N=1920 steps={steps}: {ms:.2f} ms")
+
+if "chol" in what:
+    rng = np.random.default_rng(1)
+    T, p = 3000, 3072
+    x = rng.standard_normal((T, p)).astype(np.float32)
+    dx = ops.upload_f32(x, p, dev)
+    K = ops.gram(dx, T, p)
+    F, A, N, M = 5, 20, 1920, 480
+    tr = torch.stack([ops.idx_tensor(np.r_[0:480 * f, 480 * (f + 1):2400], N, dev) for f in range(F)])
+    va = torch.stack([ops.idx_tensor(np.r_[480 * f:480 * (f + 1)], M, dev) for f in range(F)])
+    lm = ops.lambda_max(K, tr, F, N, 64)
+    a2 = ops.penalties(lm, F, torch.tensor(np.logspace(-1, 8, A), device=dev), True)
+    aug = torch.empty((F * A, N + M, N), dtype=torch.float64, device=dev)
+    H = torch.empty((F * A, M, N), dtype=torch.float32, device=dev)
+    def run():
+        ops.batch_assemble(K, tr, va, None, a2, F, A, N, M, aug)
+        ops.batch_chol_solve(aug, F * A, N, M, H)
+    ms = timeit(run, reps=2, warm=1)
+    fl = F * A * (N ** 3 / 3 + 2.0 * N * N * M)
+    print(f"assemble + batch_chol_solve B={F * A} N={N} M={M}: {ms:.1f} ms -> {fl / ms / 1e9:.1f} TFLOP/s fp64")
