@@ -174,6 +174,33 @@ int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N,
                           const float* d_ystat, const float* d_yblk, int mode,
                           float* d_part, float* d_scores, int accumulate, lc_stream_t stream);
 
+/* ---- split-precision variant of the sweep (fp16 hi + lo operands, three fp16 MFMAs per product,
+ * fp32 accumulate; fp32-level accuracy at ~5x the f32-MFMA rate).  Same contract and outputs as
+ * lc_alpha_sweep_scores; operands are prepared once per fold by the three helpers below. ---- */
+
+/* H (rows, K) f32 -> tiled fp16 hi/lo image (pad256(rows) * K * 2 halves) with an exact power-of-two
+ * scale per row; d_rowscale_inv (pad256(rows)) receives 2^e undoing it.  K % 32 == 0. */
+int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int64_t K, void* d_tiled,
+                      float* d_rowscale_inv, lc_stream_t stream);
+
+/* Per-voxel power-of-two scale from max|y| over rows 0..T-1: d_cscale[v] = 2^-e, d_cscale[V + v] = 2^e.
+ * *d_flag (caller-zeroed) is OR-ed with 1 when some column is non-finite or has most of its entries more
+ * than 2^9 below its maximum (outliers): the 22-bit split would then not be fp32-equivalent and callers
+ * should use lc_alpha_sweep_scores. */
+int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
+                      int32_t* d_flag, lc_stream_t stream);
+
+/* Y[d_rows] (K rows incl. -1 padding, V columns) * cscale -> tiled fp16 hi/lo image
+ * (pad256(V) * K * 2 halves).  K % 32 == 0. */
+int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_rows, int K,
+                      const float* d_cscale, void* d_tiled, lc_stream_t stream);
+
+int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
+                                const void* d_yt, const float* d_cscale_inv,
+                                const float* d_y, int64_t ldy, int64_t V,
+                                const int32_t* d_va, int n_val, const float* d_ystat, const float* d_yblk,
+                                int mode, float* d_part, float* d_scores, int accumulate, lc_stream_t stream);
+
 /* best[v] = first argmax_a scores[a, v] / n_folds (nested_cv.py:391-408); also
  * d_rowsum[a] = sum_v scores[a, v] (f64) for the single-alpha path (:396-400, all-reduced
  * across ranks by the host).  Either output may be NULL. */

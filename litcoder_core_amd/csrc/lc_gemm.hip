@@ -319,6 +319,15 @@ int set_lds_attr() {
 
 }  // namespace
 
+// shared with the fp16x3 variant (lc_gemm16.hip)
+int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int A, int M, int n_val,
+                             long long V, int mode, float* d_scores, int accumulate, hipStream_t s) {
+    lc::ScopedTimer timer_(lc::T_SWEEP_FINALIZE, s);
+    hipLaunchKernelGGL(k_score_finalize, dim3((unsigned)lc::ceil_div<long long>(V, 256), (unsigned)A), dim3(256), 0, s,
+                       d_part, d_ystat, d_yblk, A, M, n_val, V, mode, d_scores, accumulate);
+    return lc::launched("k_score_finalize");
+}
+
 extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, const float* d_y, int64_t ldy, int64_t V,
                                      const int32_t* d_tr, const int32_t* d_va, int n_val, const float* d_ystat,
                                      const float* d_yblk, int mode, float* d_part, float* d_scores, int accumulate,
@@ -348,10 +357,7 @@ extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, cons
                            (long long)V, sa);
     }
     if (int rc = lc::launched("k_gemm_f32<score>")) return rc;
-    lc::ScopedTimer timer_(lc::T_SWEEP_FINALIZE, s);
-    hipLaunchKernelGGL(k_score_finalize, dim3((unsigned)lc::ceil_div<long long>(V, 256), (unsigned)A), dim3(256), 0, s,
-                       d_part, d_ystat, d_yblk, A, M, n_val, (long long)V, mode, d_scores, accumulate);
-    return lc::launched("k_score_finalize");
+    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, n_val, (long long)V, mode, d_scores, accumulate, s);
 }
 
 extern "C" int lc_gemm_grouped_f32(const float* d_a, int64_t lda, int64_t a_group_stride, const float* d_b, int64_t ldb,

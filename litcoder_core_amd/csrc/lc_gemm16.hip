@@ -1,0 +1,361 @@
+// Split-precision variant of the fused alpha sweep: the same contraction  pred_a = H_a . Y[train rows]
+// and the same epilogue as lc_gemm.hip, but each fp32 operand is carried as TWO fp16 numbers
+// (x*2^e = hi + lo, 22 significant bits after an exact power-of-two pre-scale of every H row and every
+// Y column) and every product as THREE fp16 MFMAs with fp32 accumulation:
+//       h*y  ~=  hi_h*hi_y + hi_h*lo_y + lo_h*hi_y          (dropped lo*lo term <= 2^-22 relative)
+// v_mfma_f32_32x32x16_f16 runs at 16x the rate of the f32-input MFMA, so three of them are ~5x faster
+// than one f32 MFMA step at fp32-level accuracy (measured against fp64: profiles/, tests).
+//
+// Operands are pre-tiled by the split kernels so that a K-tile of either operand is ONE contiguous
+// 32 KB chunk whose order is exactly the LDS image:  [plane hi|lo][k-group of 8][row or column 0..255][8 x f16].
+// A lane's MFMA fragment (8 consecutive k of one row / column) is then one conflict-free ds_read_b128.
+//
+// Tile 256 x 256 x 32, 512 threads = 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA blocks.
+#include "lc_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int TM = 256, TN = 256, TK = 32;
+constexpr int CHUNK16 = 2 * 4 * 256;              // 16-byte units per (tile, K-tile) chunk = 32 KB
+constexpr int STAGE16 = 2 * CHUNK16;              // A chunk + B chunk
+constexpr int LDS16_BYTES = 2 * STAGE16 * 16;     // two stages = 128 KB
+
+__device__ inline int xcd_tile_id16(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// ------------------------------------------------------------------ operand preparation
+// One wave per row of H: exact power-of-two scale to [0.5, 1), split, scatter into the tiled layout.
+__global__ void __launch_bounds__(256) k_split_rows_f16(const float* __restrict__ h, long long ld, int rows, int K,
+                                                        uint4* __restrict__ out, float* __restrict__ rs_inv,
+                                                        int rows_pad) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows_pad) return;
+    const int KT = K / TK;
+    const bool live = r < rows;
+    const float* src = h + (long long)r * ld;
+    float mx = 0.f;
+    if (live)
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(src + k);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) frexpf(mx, &e);         // mx = f * 2^e, f in [0.5, 1)
+    e = max(-120, min(120, e));
+    const float s = ldexpf(1.f, -e);
+    if (lane == 0) rs_inv[r] = ldexpf(1.f, e);
+    const long long tile_base = (long long)(r >> 8) * KT * CHUNK16;
+    const int rr = r & 255;
+    for (int c = lane; c < K / 8; c += 64) {
+        h8 hi, lo;
+        if (live) {
+            const float4 v0 = *reinterpret_cast<const float4*>(src + c * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(src + c * 8 + 4);
+            const float x[8] = {v0.x * s, v0.y * s, v0.z * s, v0.w * s, v1.x * s, v1.y * s, v1.z * s, v1.w * s};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hi[j] = (_Float16)x[j];
+                lo[j] = (_Float16)(x[j] - (float)hi[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; lo[j] = (_Float16)0.f; }
+        }
+        const long long o = tile_base + (long long)(c >> 2) * CHUNK16 + (c & 3) * 256 + rr;
+        out[o] = *reinterpret_cast<uint4*>(&hi);
+        out[o + 4 * 256] = *reinterpret_cast<uint4*>(&lo);
+    }
+}
+
+// Per-column power-of-two scale from max |y| over all T rows: cs[v] = 2^-e, cs[V + v] = 2^e.
+// *flag is OR-ed with 1 when a column is non-finite or when most of its entries lie more than 2^9 below
+// its maximum (outliers: the 22-bit hi+lo split, whose precision is absolute w.r.t. the column maximum,
+// would then resolve the typical entries worse than fp32 does): the host keeps the f32 path in that case.
+__global__ void __launch_bounds__(512) k_col_scales(const float* __restrict__ y, long long ldy, int T, long long V,
+                                                    float* __restrict__ cs, int* __restrict__ flag) {
+    __shared__ float sm[8][64];
+    __shared__ int cnt[8][64];
+    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    float mx = 0.f;
+    bool bad = false;
+    if (c < V)
+        for (int i = threadIdx.y; i < T; i += 8) {
+            const float v = y[(long long)i * ldy + c];
+            bad |= !(fabsf(v) < 3.0e38f);
+            mx = fmaxf(mx, fabsf(v));
+        }
+    sm[threadIdx.y][threadIdx.x] = bad ? 3.4e38f : mx;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) mx = fmaxf(mx, sm[g][threadIdx.x]);
+    const float small = mx * (1.f / 512.f);
+    int n_small = 0;
+    if (c < V)
+        for (int i = threadIdx.y; i < T; i += 8) n_small += fabsf(y[(long long)i * ldy + c]) < small;
+    cnt[threadIdx.y][threadIdx.x] = n_small;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < V) {
+#pragma unroll
+        for (int g = 1; g < 8; ++g) n_small += cnt[g][threadIdx.x];
+        int e = 0;
+        const bool finite = mx < 3.0e38f;
+        if (mx > 0.f && finite) frexpf(mx, &e);
+        e = max(-120, min(120, e));
+        cs[c] = ldexpf(1.f, -e);
+        cs[V + c] = ldexpf(1.f, e);
+        if (!finite || (mx > 0.f && 2 * n_small > T)) atomicOr(flag, 1);
+    }
+}
+
+// Tiled fp16 hi/lo image of Y[rows] (K = padded row count, -1 rows -> 0): thread = (column, 8-row group).
+__global__ void __launch_bounds__(256) k_split_cols_f16(const float* __restrict__ y, long long ldy, long long V,
+                                                        const int* __restrict__ rows, int K, const float* __restrict__ cs,
+                                                        uint4* __restrict__ out) {
+    const int nt = blockIdx.x, g = blockIdx.y;              // g = K-tile * 4 + k-group
+    const int col = threadIdx.x;
+    const long long c = (long long)nt * 256 + col;
+    const int KT = K / TK;
+    h8 hi, lo;
+    if (c < V) {
+        const float s = cs[c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = rows[g * 8 + j];
+            const float x = r >= 0 ? y[(long long)r * ldy + c] * s : 0.f;
+            hi[j] = (_Float16)x;
+            lo[j] = (_Float16)(x - (float)hi[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; lo[j] = (_Float16)0.f; }
+    }
+    const long long o = ((long long)nt * KT + (g >> 2)) * CHUNK16 + (g & 3) * 256 + col;
+    out[o] = *reinterpret_cast<uint4*>(&hi);
+    out[o + 4 * 256] = *reinterpret_cast<uint4*>(&lo);
+}
+
+// ------------------------------------------------------------------ the fused sweep on fp16 x 3
+struct Score16Args {
+    const float* y;        // raw targets (T, ldy) for the validation rows of the epilogue
+    long long ldy;
+    const int* va;
+    const float* ymean;
+    const float* rs_inv;   // per H row: 2^e undoing the row pre-scale
+    const float* cs_inv;   // per voxel: 2^e undoing the column pre-scale
+    float* part;
+    long long V;           // padded voxel count of part / scores (multiple of 128)
+    int M, n_val, mode, Mrows;
+};
+
+#define MFMA16(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
+
+__global__ void __launch_bounds__(512, 2)
+k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT, int Mtiles, Score16Args sa) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds16[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tile = xcd_tile_id16(blockIdx.x, gridDim.x);
+    const int mt = tile % Mtiles, nt = tile / Mtiles;
+    const uint4* a_src = At + (long long)mt * KT * CHUNK16 + tid;
+    const uint4* b_src = Bt + (long long)nt * KT * CHUNK16 + tid;
+
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define LOAD16(kt_)                                                   \
+    {                                                                 \
+        const uint4* pa_ = a_src + (long long)(kt_) * CHUNK16;        \
+        const uint4* pb_ = b_src + (long long)(kt_) * CHUNK16;        \
+        ra0 = pa_[0]; ra1 = pa_[512]; ra2 = pa_[1024]; ra3 = pa_[1536]; \
+        rb0 = pb_[0]; rb1 = pb_[512]; rb2 = pb_[1024]; rb3 = pb_[1536]; \
+    }
+#define STORE16(buf_)                                                 \
+    {                                                                 \
+        uint4* sa_ = lds16 + (buf_) * STAGE16 + tid;                  \
+        uint4* sb_ = sa_ + CHUNK16;                                   \
+        sa_[0] = ra0; sa_[512] = ra1; sa_[1024] = ra2; sa_[1536] = ra3; \
+        sb_[0] = rb0; sb_[512] = rb1; sb_[1024] = rb2; sb_[1536] = rb3; \
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    LOAD16(0);
+    STORE16(0);
+    __syncthreads();
+
+    // fragment addresses (16-byte units) inside a chunk: ((plane*4 + 2*s + lh) * 256 + row)
+    const int a_frag = lh * 256 + wm * 128 + li;
+    const int b_frag = CHUNK16 + lh * 256 + wn * 64 + li;
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) LOAD16(kt + 1);
+        const uint4* st = lds16 + cur * STAGE16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            h8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const uint4 v = st[a_frag + s * 512 + mi * 32];
+                const uint4 w = st[a_frag + 1024 + s * 512 + mi * 32];
+                ah[mi] = *reinterpret_cast<const h8*>(&v);
+                al[mi] = *reinterpret_cast<const h8*>(&w);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const uint4 v = st[b_frag + s * 512 + ni * 32];
+                const uint4 w = st[b_frag + 1024 + s * 512 + ni * 32];
+                bh[ni] = *reinterpret_cast<const h8*>(&v);
+                bl[ni] = *reinterpret_cast<const h8*>(&w);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    MFMA16(acc[mi][ni], al[mi], bh[ni]);      // small terms first
+                    MFMA16(acc[mi][ni], ah[mi], bl[ni]);
+                    MFMA16(acc[mi][ni], ah[mi], bh[ni]);
+                }
+        }
+        if (kt + 1 < KT) STORE16(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: identical statistics to lc_gemm.hip after undoing the power-of-two scales
+    const long long V = sa.V;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int rb0 = mt * TM + wm * 128 + mi * 32;
+        if (rb0 >= sa.Mrows) continue;
+        const int alpha = rb0 / sa.M;
+        const int i0 = rb0 - alpha * sa.M;
+        const int nb = min(32, sa.n_val - i0);
+        float rsc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rsc[r] = sa.rs_inv[rb0 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const long long col = (long long)nt * TN + wn * 64 + ni * 32 + li;
+            if (col >= V) continue;
+            float p[16], yc[16];
+            const float ym = sa.ymean[col];
+            const float csc = sa.cs_inv[col];
+            float s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const bool ok = il < sa.n_val;
+                const float yraw = ok ? sa.y[(long long)sa.va[il] * sa.ldy + col] : 0.f;
+                const float pv = acc[mi][ni][r] * rsc[r] * csc;
+                yc[r] = ok ? yraw - ym : 0.f;
+                p[r] = ok ? (sa.mode == LC_SCORE_CORR ? pv : yraw - pv) : 0.f;
+                s1 += p[r];
+            }
+            s1 += __shfl_xor(s1, 32);
+            const float mean_b = nb > 0 ? s1 / (float)nb : 0.f;
+            float m2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float d = il < sa.n_val ? p[r] - mean_b : 0.f;
+                m2 += d * d;
+                s3 += d * yc[r];
+            }
+            m2 += __shfl_xor(m2, 32);
+            s3 += __shfl_xor(s3, 32);
+            if (lh == 0) {
+                float* out = sa.part + (long long)(rb0 >> 5) * 4 * V + col;
+                out[0] = s1;
+                out[V] = m2;
+                out[2 * V] = s3;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// defined in lc_gemm.hip: combines the per-block partial moments into scores
+int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int A, int M, int n_val,
+                             long long V, int mode, float* d_scores, int accumulate, hipStream_t s);
+
+extern "C" int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int64_t K, void* d_tiled,
+                                 float* d_rowscale_inv, lc_stream_t stream) {
+    LC_REQUIRE(d_h && d_tiled && d_rowscale_inv, LC_E_BADARG, "lc_split_rows_f16: null pointer");
+    LC_REQUIRE(rows > 0 && K > 0 && K % TK == 0 && ld % 4 == 0 && ld >= K, LC_E_SHAPE,
+               "lc_split_rows_f16: need K %% %d == 0 and ld %% 4 == 0", TK);
+    const int rows_pad = (int)(lc::ceil_div<long long>(rows, TM) * TM);
+    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_split_rows_f16, dim3((unsigned)(rows_pad / 4)), dim3(256), 0, lc::as_stream(stream), d_h,
+                       (long long)ld, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, rows_pad);
+    return lc::launched("k_split_rows_f16");
+}
+
+extern "C" int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
+                                 int32_t* d_flag, lc_stream_t stream) {
+    LC_REQUIRE(d_y && d_cscale && d_flag, LC_E_BADARG, "lc_col_scales_f16: null pointer");
+    LC_REQUIRE(T > 0 && V > 0 && ldy >= V, LC_E_SHAPE, "lc_col_scales_f16: bad shape");
+    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_col_scales, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, 8), 0,
+                       lc::as_stream(stream), d_y, (long long)ldy, (int)T, (long long)V, d_cscale, d_flag);
+    return lc::launched("k_col_scales");
+}
+
+extern "C" int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_rows, int K,
+                                 const float* d_cscale, void* d_tiled, lc_stream_t stream) {
+    LC_REQUIRE(d_y && d_rows && d_cscale && d_tiled, LC_E_BADARG, "lc_split_cols_f16: null pointer");
+    LC_REQUIRE(V > 0 && K > 0 && K % TK == 0 && ldy >= V, LC_E_SHAPE, "lc_split_cols_f16: need K %% %d == 0", TK);
+    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
+    dim3 grid((unsigned)lc::ceil_div<long long>(V, TN), (unsigned)(K / 8));
+    hipLaunchKernelGGL(k_split_cols_f16, grid, dim3(256), 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V,
+                       d_rows, K, d_cscale, (uint4*)d_tiled);
+    return lc::launched("k_split_cols_f16");
+}
+
+extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
+                                           const void* d_yt, const float* d_cscale_inv, const float* d_y, int64_t ldy,
+                                           int64_t V, const int32_t* d_va, int n_val, const float* d_ystat,
+                                           const float* d_yblk, int mode, float* d_part, float* d_scores,
+                                           int accumulate, lc_stream_t stream) {
+    LC_REQUIRE(d_ht && d_rowscale_inv && d_yt && d_cscale_inv && d_y && d_va && d_ystat && d_yblk && d_part && d_scores,
+               LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: null pointer");
+    LC_REQUIRE(A > 0 && M > 0 && M % LC_MB == 0 && n_val > 0 && n_val <= M && N > 0 && N % TK == 0, LC_E_SHAPE,
+               "lc_alpha_sweep_scores_f16x3: need M %% %d == 0, N %% %d == 0, 0 < n_val <= M", LC_MB, TK);
+    LC_REQUIRE(V > 0 && V % 128 == 0 && ldy >= V, LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: V must be a multiple of 128");
+    LC_REQUIRE(mode == LC_SCORE_CORR || mode == LC_SCORE_R2, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: bad mode");
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
+        attr_done = true;
+    }
+    hipStream_t s = lc::as_stream(stream);
+    const int Mrows = A * M;
+    const int Mtiles = lc::ceil_div(Mrows, TM);
+    const long long Ntiles = lc::ceil_div<long long>(V, TN);
+    LC_REQUIRE((long long)Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: grid too large");
+    Score16Args sa{d_y, (long long)ldy, d_va, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val,
+                   mode, Mrows};
+    {
+        lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
+        hipLaunchKernelGGL(k_sweep_f16x3, dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
+                           (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa);
+    }
+    if (int rc = lc::launched("k_sweep_f16x3")) return rc;
+    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, n_val, (long long)V, mode, d_scores, accumulate, s);
+}

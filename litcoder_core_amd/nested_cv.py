@@ -36,6 +36,7 @@ logger = logging.getLogger(__name__)
 
 LANCZOS_STEPS = 96                  # Lanczos iterations for S[0]^2: <= 1e-14 relative on the cfg2 Grams (profiles/)
 AUG_BUDGET_BYTES = 24 << 30         # cap on the batched (fold, alpha) fp64 systems resident at once
+LAST_SWEEP = {"precision": None}    # arithmetic the most recent alpha sweep ran in (read by bench.py)
 
 
 class BasePredictivityModel:
@@ -60,7 +61,7 @@ class RidgeCVEngine:
     per-fold pipeline.  ``Y`` holds only this rank's voxel block."""
 
     def __init__(self, X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets,
-                 shard: Optional[ShardContext] = None, lanczos_steps: int = LANCZOS_STEPS):
+                 shard: Optional[ShardContext] = None, lanczos_steps: int = LANCZOS_STEPS, precision: str = "auto"):
         self.dev = ops.device()
         self.shard = shard or ShardContext()
         if not isinstance(X_all, _DeviceShapes):
@@ -79,6 +80,9 @@ class RidgeCVEngine:
         self.mode = LC_SCORE_CORR if use_corr else LC_SCORE_R2
         self.norm_x, self.norm_y = bool(normalize_features), bool(normalize_targets)
         self.steps = int(lanczos_steps)
+        if precision not in ("auto", "f32", "f16x3"):
+            raise ValueError(f"precision must be 'auto', 'f32' or 'f16x3', got {precision!r}")
+        self.precision = precision
         self.dX = self._resident(X_all, self.p_pad)
         self.dY = self._resident(Y_all, self.Vp)
         self.d_alphas = torch.tensor(self.alphas, dtype=torch.float64, device=self.dev)
@@ -109,7 +113,24 @@ class RidgeCVEngine:
             mean, std = ops.col_mean_std(self.dY, rows, len(tr_rows), self.V)
             Y = self.dY.clone()
             ops.col_normalize_(Y, self.Ttot, self.V, mean, std)
+            self._cs_key = None              # new target values: the fp16 column scales must be recomputed
         return X, Y, K
+
+    def _use_split(self, Y):
+        """Arithmetic of the alpha sweep for this target matrix.  "f16x3": fp16 hi + lo operands after an
+        exact power-of-two scale per H row / Y column, three fp16 MFMAs per product, fp32 accumulate
+        (22-bit operands: fp32-level scores, ~3x faster than the f32-input MFMA).  "auto" takes it unless a
+        target column is non-finite or dominated by outliers (most entries > 2^9 below the column maximum)."""
+        if self.precision == "f32":
+            return False
+        key = Y.data_ptr()
+        if getattr(self, "_cs_key", None) != key:
+            self._cs, flag = ops.col_scales_f16(Y, self.Ttot, self.Vp)
+            self._cs_key = key
+            self._cs_wide = bool(int(flag.cpu()[0])) if self.precision == "auto" else False
+            if self._cs_wide:
+                logger.info("target dynamic range too wide for the fp16x3 sweep: using the f32 MFMA path")
+        return not self._cs_wide
 
     # -------------------------------------------------------------- inner CV: alpha scores
     def _alpha_scores(self, K, Y, inner_abs):
@@ -133,6 +154,14 @@ class RidgeCVEngine:
         per_sys = (N + M) * N * 8
         chunk = max(1, min(F, AUG_BUDGET_BYTES // max(1, per_sys * A)))
         infos = []
+        split = self._use_split(Y)
+        LAST_SWEEP["precision"] = "f16x3" if split else "f32"
+        if split:
+            rows_pad = ops.pad_to(A * M, 256)
+            cs = self._cs
+            Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
+            rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
+            Yt = torch.empty(ops.pad_to(self.Vp, 256) * N * 2, dtype=torch.float16, device=self.dev)
         for f0 in range(0, F, chunk):
             fc = min(chunk, F - f0)
             aug = torch.empty((fc * A, N + M, N), dtype=torch.float64, device=self.dev)
@@ -143,8 +172,14 @@ class RidgeCVEngine:
             for j in range(fc):
                 f = f0 + j
                 ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk)
-                ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], va[f], n_v[f], ystat, yblk,
-                                       self.mode, part, scores, accumulate=f > 0)
+                if split:
+                    ops.split_rows_f16(H[j * A:(j + 1) * A].reshape(A * M, N), A * M, N, Ht, rs_inv)
+                    ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt)
+                    ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, N, Yt, cs[self.Vp:], Y, self.Vp, va[f], n_v[f], ystat,
+                                                 yblk, self.mode, part, scores, accumulate=f > 0)
+                else:
+                    ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], va[f], n_v[f], ystat, yblk,
+                                           self.mode, part, scores, accumulate=f > 0)
         return scores, torch.cat(infos)
 
     # -------------------------------------------------------------- alpha selection
@@ -288,9 +323,13 @@ class NestedCVModel(BasePredictivityModel):
     defaults, return triple and metrics keys.  ``shard`` (optional) makes the instance fit only its
     rank's block of voxel columns and gather the per-voxel results across ranks."""
 
-    def __init__(self, model_name: str, shard: Optional[ShardContext] = None):
+    def __init__(self, model_name: str, shard: Optional[ShardContext] = None, precision: str = "auto"):
+        """``precision``: arithmetic of the V-wide alpha sweep -- "f32" (f32-input MFMA), "f16x3" (fp16
+        hi/lo operands, three fp16 MFMAs per product, fp32 accumulate; fp32-level accuracy, ~3x faster) or
+        "auto" (f16x3 unless the targets' dynamic range is too wide for it; see RidgeCVEngine._use_split)."""
         super().__init__(model_name)
         self.shard = shard
+        self.precision = precision
 
     def fit_predict(
         self,
@@ -380,7 +419,8 @@ class NestedCVModel(BasePredictivityModel):
                     inner = create_folds(len(tr), folding_type, n_inner_folds, chunk_length)
                 outer.append((tr, te, inner))
 
-        eng = RidgeCVEngine(X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard)
+        eng = RidgeCVEngine(X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
+                            precision=self.precision)
         scale = 1.0 if train_test else 1.0 / len(outer)
         fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
 

@@ -188,6 +188,29 @@ def alpha_sweep_scores(h, A, M, N, y, V, tr, va, n_val, ystat, yblk, mode, part,
               _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), _s())
 
 
+def split_rows_f16(h, rows, K, tiled, rowscale_inv):
+    _lib.call("lc_split_rows_f16", _p(h), h.stride(0), rows, K, _p(tiled), _p(rowscale_inv), _s())
+
+
+def col_scales_f16(y, T, V):
+    """(cs, flag): cs[:V] = 2^-e, cs[V:] = 2^e per column; flag (device int32) != 0 when some column's
+    dynamic range is too wide for the fp16 hi/lo split."""
+    cs = torch.empty(2 * V, dtype=torch.float32, device=y.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=y.device)
+    _lib.call("lc_col_scales_f16", _p(y), y.stride(0), T, V, _p(cs), _p(flag), _s())
+    return cs, flag
+
+
+def split_cols_f16(y, V, rows, K, cscale, tiled):
+    _lib.call("lc_split_cols_f16", _p(y), y.stride(0), V, _p(rows), K, _p(cscale), _p(tiled), _s())
+
+
+def alpha_sweep_scores_f16x3(ht, rowscale_inv, A, M, N, yt, cscale_inv, y, V, va, n_val, ystat, yblk, mode, part, scores,
+                             accumulate):
+    _lib.call("lc_alpha_sweep_scores_f16x3", _p(ht), _p(rowscale_inv), A, M, N, _p(yt), _p(cscale_inv), _p(y),
+              y.stride(0), V, _p(va), n_val, _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), _s())
+
+
 def select_alpha(scores, A, V, want_best=True, want_rowsum=False):
     best = torch.empty(V, dtype=torch.int32, device=scores.device) if want_best else None
     rowsum = torch.empty(A, dtype=torch.float64, device=scores.device) if want_rowsum else None

@@ -180,6 +180,53 @@ def _():
     return " | ".join(msgs)
 
 
+@stage("alpha_sweep f16x3 vs oracle")
+def _():
+    import oracle.ridge as oridge
+    from litcoder_core_amd.nested_cv import RidgeCVEngine
+    msgs = []
+    for (T, p, V, use_corr) in [(300, 400, 200, True), (300, 400, 200, False), (700, 64, 1000, True), (900, 1100, 700, True)]:
+        X = rng.standard_normal((T, p))
+        Y = X @ (rng.standard_normal((p, V)) / np.sqrt(p)) + rng.standard_normal((T, V))
+        Y[:, 3] = 2.0
+        Y[:, 4] += 100.0
+        Y[:, 5] *= 1e-4
+        Y[:, 6] *= 3e4
+        tr_rows = np.r_[0:T // 2, T // 2 + T // 5:T]
+        va_rows = np.r_[T // 2:T // 2 + T // 5]
+        alphas = np.logspace(-1, 4, 6)
+        Xt, Yt = torch.tensor(X, dtype=torch.float32), torch.tensor(Y, dtype=torch.float32)
+        ref = oridge.alpha_sweep_scores(Xt[tr_rows], Xt[va_rows], Yt[tr_rows], Yt[va_rows], alphas, 1e-10, use_corr,
+                                        True).numpy()
+        eng = RidgeCVEngine(X, Y, alphas, True, use_corr, False, False, precision="f16x3")
+        scores, info = eng._alpha_scores(eng.K, eng.dY, [(tr_rows, va_rows)])
+        got = scores[:, :V].cpu().numpy()
+        eng32 = RidgeCVEngine(X, Y, alphas, True, use_corr, False, False)
+        got32 = eng32._alpha_scores(eng32.K, eng32.dY, [(tr_rows, va_rows)])[0][:, :V].cpu().numpy()
+        d = np.abs(got - ref)
+        d[np.abs(ref) > 1e30] = 0
+        d32 = np.abs(got - got32)
+        d32[np.abs(got32) > 1e30] = 0
+        msgs.append(f"T{T}p{p}V{V}corr{int(use_corr)}:vs_oracle={d.max():.2e} vs_f32path={d32.max():.2e} "
+                    f"argmax_agree={np.mean(got.argmax(0) == ref.argmax(0)):.3f}")
+    return " | ".join(msgs)
+
+
+@stage("full fit f16x3 vs oracle (kfold)")
+def _():
+    from litcoder_core_amd import NestedCVModel
+    import oracle.nested_cv as onc
+    T, p, V = 240, 320, 64
+    X = rng.standard_normal((T, p))
+    Y = X @ (rng.standard_normal((p, V)) * 0.05) + rng.standard_normal((T, V))
+    alphas = np.logspace(-1, 4, 6)
+    kw = dict(folding_type="kfold", n_outer_folds=4, n_inner_folds=3, alphas=alphas)
+    m0, W0, a0 = onc.fit_predict(X, Y, **kw)
+    m1, W1, a1 = NestedCVModel("ridge_regression", precision="f16x3").fit_predict(X, Y, **kw)
+    return (f"corr={np.abs(np.array(m0['correlations']) - np.array(m1['correlations'])).max():.2e} "
+            f"W={np.abs(W0 - W1).max():.2e} alphas_equal={np.mean(a0 == a1):.3f}")
+
+
 @stage("full fit vs oracle (kfold)")
 def _():
     import random

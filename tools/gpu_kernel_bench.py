@@ -57,6 +57,40 @@ if "sweep" in what:
     ref = (zy.unsqueeze(0) * zp).mean(1)
     print("   max |score - fp64 ref| on sample columns:", float((scores[:, cols].double() - ref).abs().max()))
 
+if "sweep16" in what:
+    A, n_v, n_i, V, T = 20, 480, 1920, 80000, 3000
+    M, N = ops.pad_to(n_v, LC_MB), ops.pad_to(n_i, LC_NB)
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    H = torch.randn((A * M, N), generator=g, device=dev, dtype=torch.float32) * 0.02
+    Y = torch.randn((T, V), generator=g, device=dev, dtype=torch.float32)
+    tr = ops.idx_tensor(np.r_[0:1920], N, dev)
+    va = ops.idx_tensor(np.r_[1920:2400], M, dev)
+    ystat = torch.empty((3, V), dtype=torch.float32, device=dev)
+    yblk = torch.empty((M // LC_MB, V), dtype=torch.float32, device=dev)
+    part = torch.empty((A * M // LC_MB, 4, V), dtype=torch.float32, device=dev)
+    scores = torch.empty((A, V), dtype=torch.float32, device=dev)
+    ops.val_stats(Y, V, va, M, n_v, ystat, yblk)
+    rows_pad = ops.pad_to(A * M, 256)
+    Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=dev)
+    rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=dev)
+    Yt = torch.empty(ops.pad_to(V, 256) * N * 2, dtype=torch.float16, device=dev)
+    cs, _flag = ops.col_scales_f16(Y, T, V)
+    prep = lambda: (ops.split_rows_f16(H, A * M, N, Ht, rs_inv), ops.split_cols_f16(Y, V, tr, N, cs, Yt))
+    print(f"f16 operand split (H rows + Y cols): {timeit(prep):.2f} ms")
+    fn = lambda: ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, N, Yt, cs[V:], Y, V, va, n_v, ystat, yblk, LC_SCORE_CORR,
+                                              part, scores, False)
+    ms = timeit(fn)
+    fl = 2.0 * A * n_v * n_i * V
+    print(f"alpha_sweep f16x3 (gemm+finalize): {ms:.2f} ms  -> {fl / ms / 1e9:.1f} TFLOP/s algorithmic, "
+          f"{3 * fl / ms / 1e9:.0f} TFLOP/s of fp16 MFMA")
+    cols = [0, 17, 40000, 79999]
+    pred = (H.double() @ Y[:1920][:, cols].double()).reshape(A, M, len(cols))[:, :n_v]
+    yv = Y[1920:2400][:, cols].double()
+    zy = (yv - yv.mean(0)) / (yv.std(0) + 1e-8)
+    zp = (pred - pred.mean(1, keepdim=True)) / (pred.std(1, keepdim=True) + 1e-8)
+    ref = (zy.unsqueeze(0) * zp).mean(1)
+    print("   max |score - fp64 ref| on sample columns:", float((scores[:, cols].double() - ref).abs().max()))
+
 if "lanczos" in what:
     rng = np.random.default_rng(0)
     for (T, p, ar) in [(2400, 3072, 0.0), (2400, 3072, 0.8), (2400, 768, 0.5)]:
