@@ -147,9 +147,20 @@ int lc_batch_assemble(const double* d_k, int64_t ldk, const int32_t* d_tr, const
 /* In place on every (N+M, N) system: Cholesky of the top block, then bottom <- bottom * inv(top)
  * i.e. the hat matrices  Xva Xtr' (Xtr Xtr' + a^2 I)^-1  (= Pstim Vh' diag(S/(S^2+a^2)) U',
  * ridge_regression.py:104-105,117-120).  Result written as f32 to d_h (B, M, N).
- * d_linv: workspace (B, N/LC_NB, LC_NB, LC_NB) f64.  d_info: (B) int32, nonzero = failed pivot. */
+ * d_linv: workspace (B, N/LC_NB, LC_NB, LC_NB) f64.  d_info: (B) int32, nonzero = failed pivot.
+ * d_slot: optional (B) int32, system b is written to slot d_slot[b] of d_h (NULL = b). */
 int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
-                        int32_t* d_info, lc_stream_t stream);
+                        const int32_t* d_slot, int32_t* d_info, lc_stream_t stream);
+
+/* The same hat matrices for alphas whose penalty dwarfs the spectrum (a^2 >> lambda_max):
+ *   K[va,tr] (K[tr,tr] + a^2 I)^-1 = sum_{j<terms} (-1)^j K[va,tr] K[tr,tr]^j / a^(2j+2)
+ * (truncation error (lambda_max/a^2)^terms, relative).  The matrix powers are shared by the S alphas
+ * of a fold.  a = d_alphas[s] * (normalpha ? sqrt(d_lmax[f]) : 1).  Output goes to slot
+ * f*A + d_aidx[s] of d_h (F*A, M, N) f32.  d_work: F*N*N + terms*F*M*N doubles. */
+int lc_batch_series_hat(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
+                        int F, int N, int M, const double* d_lmax, const double* d_alphas,
+                        const int32_t* d_aidx, int S, int A, int normalpha, int terms,
+                        double* d_work, float* d_h, lc_stream_t stream);
 
 /* rhs[f] (p x N) f64 <- X[tr_f]' for the refit systems (rows of X listed in d_tr, -1 -> 0). */
 int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_tr, int N, int64_t p,

@@ -449,11 +449,68 @@ __global__ void __launch_bounds__(256) k_back_update(double* __restrict__ aug, i
             for (int j = 0; j < 4; ++j) Zj[(long long)(ty * 4 + i) * N + tx * 4 + j] -= acc[i][j];
 }
 
-__global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ aug, int N, int M, float* __restrict__ h) {
+__global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ aug, int N, int M, float* __restrict__ h,
+                                                   const int* __restrict__ slot) {
     const int i = blockIdx.x, b = blockIdx.y;
     const double* src = aug + ((long long)b * (N + M) + N + i) * N;
-    float* dst = h + ((long long)b * M + i) * N;
+    float* dst = h + ((long long)(slot ? slot[b] : b) * M + i) * N;
     for (int j = threadIdx.x; j < N; j += 256) dst[j] = (float)src[j];
+}
+
+// ------------------------------------------------------------------ Neumann-series hat matrices
+// For a^2 >> lambda_max(K):  G (K + a^2 I)^-1 = sum_j (-1)^j G K^j / a^(2j+2), truncated after J+1 terms
+// (relative error (lambda_max/a^2)^(J+1)).  The powers P_j = G K^j are shared by every such alpha of a
+// fold, so a handful of fp64 GEMMs replaces one Cholesky factorisation + two triangular solves per alpha.
+
+// out[f][i][j] = K[rows[f][i], cols[f][j]]   (-1 -> 0)
+__global__ void __launch_bounds__(256) k_gather_sub(const double* __restrict__ Kmat, long long ldk,
+                                                    const int* __restrict__ rows, const int* __restrict__ cols, int R,
+                                                    int C, double* __restrict__ out) {
+    const int i = blockIdx.x, f = blockIdx.y;
+    const int r = rows[(long long)f * R + i];
+    const int* cf = cols + (long long)f * C;
+    double* dst = out + ((long long)f * R + i) * C;
+    for (int j = threadIdx.x; j < C; j += 256) {
+        const int c = cf[j];
+        dst[j] = (r >= 0 && c >= 0) ? Kmat[(long long)r * ldk + c] : 0.0;
+    }
+}
+
+// C[f] (M x N) = A[f] (M x Kd) . B[f] (Kd x N), row-major, 64 x 64 output tiles, Kd % 64 == 0, N % 64 == 0.
+__global__ void __launch_bounds__(256) k_gemm_f64_nn(const double* __restrict__ A, const double* __restrict__ B,
+                                                     double* __restrict__ C, int M, int N, int Kd) {
+    __shared__ double sA[32 * TS_LD], sB[32 * TS_LD];
+    const int f = blockIdx.z;
+    const int c0 = blockIdx.x * NB, r0 = blockIdx.y * NB;
+    const double* a = A + (long long)f * M * Kd + (long long)r0 * Kd;
+    const double* b = B + (long long)f * Kd * N + c0;
+    const int rows = min(NB, M - r0);
+    double acc[4][4] = {};
+    for (int kb = 0; kb < Kd; kb += NB) tile_product<false>(acc, a + kb, Kd, rows, b + (long long)kb * N, N, NB, sA, sB);
+    double* c = C + (long long)f * M * N + (long long)r0 * N + c0;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ty * 4 + i < rows)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[(long long)(ty * 4 + i) * N + tx * 4 + j] = acc[i][j];
+}
+
+// H[f*A + aidx[s]] = sum_j (-1)^j P_j[f] / a2^(j+1),  a2 = (alphas[s] * (normalpha ? sqrt(lmax[f]) : 1))^2
+__global__ void __launch_bounds__(256) k_series_hat(const double* __restrict__ P, long long p_stride, int terms,
+                                                    const double* __restrict__ lmax, const double* __restrict__ alphas,
+                                                    const int* __restrict__ aidx, int normalpha, int A, int M, int N,
+                                                    float* __restrict__ h) {
+    const int i = blockIdx.x, s = blockIdx.y, f = blockIdx.z;
+    const double na = alphas[s] * (normalpha ? sqrt(lmax[f]) : 1.0);
+    const double inv = 1.0 / (na * na);
+    const double* src = P + ((long long)f * M + i) * N;
+    float* dst = h + (((long long)f * A + aidx[s]) * M + i) * N;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        double acc = 0.0;
+        for (int t = terms - 1; t >= 0; --t) acc = src[(long long)t * p_stride + j] - inv * acc;   // Horner, alternating signs
+        dst[j] = (float)(inv * acc);
+    }
 }
 
 }  // namespace
@@ -518,8 +575,8 @@ extern "C" int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_
     return lc::launched("k_transpose_rows");
 }
 
-extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, int32_t* d_info,
-                                   lc_stream_t stream) {
+extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
+                                   const int32_t* d_slot, int32_t* d_info, lc_stream_t stream) {
     LC_REQUIRE(d_aug && d_linv && d_h && d_info, LC_E_BADARG, "lc_batch_chol_solve: null pointer");
     LC_REQUIRE(B > 0 && B <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
                "lc_batch_chol_solve: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
@@ -543,6 +600,30 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
         if (k > 0) hipLaunchKernelGGL(k_back_update, dim3(k, mt, B), dim3(256), 0, s, d_aug, N, M, k);
     }
     if (int rc = lc::launched("back substitution")) return rc;
-    hipLaunchKernelGGL(k_extract_h, dim3(M, B), dim3(256), 0, s, d_aug, N, M, d_h);
+    hipLaunchKernelGGL(k_extract_h, dim3(M, B), dim3(256), 0, s, d_aug, N, M, d_h, d_slot);
     return lc::launched("k_extract_h");
+}
+
+extern "C" int lc_batch_series_hat(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va, int F, int N,
+                                   int M, const double* d_lmax, const double* d_alphas, const int32_t* d_aidx, int S,
+                                   int A, int normalpha, int terms, double* d_work, float* d_h, lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_tr && d_va && d_alphas && d_aidx && d_work && d_h && (d_lmax || !normalpha), LC_E_BADARG,
+               "lc_batch_series_hat: null pointer");
+    LC_REQUIRE(F > 0 && F <= 65535 && S > 0 && S <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0 &&
+                   terms >= 1 && terms <= 16,
+               LC_E_SHAPE, "lc_batch_series_hat: need N %% %d == 0, M %% %d == 0, 1 <= terms <= 16", LC_NB, LC_MB);
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_SERIES, s);
+    // work: Kf (F, N, N) then P_0 .. P_{terms-1}, each (F, M, N)
+    double* Kf = d_work;
+    double* P = d_work + (long long)F * N * N;
+    const long long p_stride = (long long)F * M * N;
+    hipLaunchKernelGGL(k_gather_sub, dim3(N, F), dim3(256), 0, s, d_k, (long long)ldk, d_tr, d_tr, N, N, Kf);
+    hipLaunchKernelGGL(k_gather_sub, dim3(M, F), dim3(256), 0, s, d_k, (long long)ldk, d_va, d_tr, M, N, P);
+    for (int t = 1; t < terms; ++t)
+        hipLaunchKernelGGL(k_gemm_f64_nn, dim3(N / NB, lc::ceil_div(M, NB), F), dim3(256), 0, s, P + (t - 1) * p_stride, Kf,
+                           P + t * p_stride, M, N, N);
+    hipLaunchKernelGGL(k_series_hat, dim3(M, S, F), dim3(256), 0, s, P, p_stride, terms, d_lmax, d_alphas, d_aidx,
+                       normalpha, A, M, N, d_h);
+    return lc::launched("lc_batch_series_hat");
 }

@@ -36,6 +36,8 @@ logger = logging.getLogger(__name__)
 
 LANCZOS_STEPS = 96                  # Lanczos iterations for S[0]^2: <= 1e-14 relative on the cfg2 Grams (profiles/)
 AUG_BUDGET_BYTES = 24 << 30         # cap on the batched (fold, alpha) fp64 systems resident at once
+SERIES_TERMS = 6                    # Neumann terms for the hat matrices of large alphas ...
+SERIES_TOL = 1e-10                  # ... used when (lambda_max / a^2)^SERIES_TERMS <= this (H is stored as fp32)
 LAST_SWEEP = {"precision": None}    # arithmetic the most recent alpha sweep ran in (read by bench.py)
 
 
@@ -162,13 +164,28 @@ class RidgeCVEngine:
             Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
             rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
             Yt = torch.empty(ops.pad_to(self.Vp, 256) * N * 2, dtype=torch.float16, device=self.dev)
+        # alphas whose penalty dwarfs the spectrum take the Neumann series (shared matrix powers), the
+        # rest the batched Cholesky; rho = lambda_max / a^2 = 1 / alpha^2 under normalpha
+        ser = [a for a in range(A) if self.normalpha and self.alphas[a] ** (-2 * SERIES_TERMS) <= SERIES_TOL]
+        cho = [a for a in range(A) if a not in ser]
+        d_ser = torch.tensor(ser, dtype=torch.int32, device=self.dev) if ser else None
+        Ac = len(cho)
+        chunk = max(1, min(F, AUG_BUDGET_BYTES // max(1, per_sys * max(Ac, 1))))
         for f0 in range(0, F, chunk):
             fc = min(chunk, F - f0)
-            aug = torch.empty((fc * A, N + M, N), dtype=torch.float64, device=self.dev)
             H = torch.empty((fc * A, M, N), dtype=torch.float32, device=self.dev)
-            ops.batch_assemble(K, tr[f0:f0 + fc], va[f0:f0 + fc], None, a2[f0 * A:(f0 + fc) * A], fc, A, N, M, aug)
-            infos.append(ops.batch_chol_solve(aug, fc * A, N, M, H))
-            del aug
+            if Ac:
+                aug = torch.empty((fc * Ac, N + M, N), dtype=torch.float64, device=self.dev)
+                a2c = a2[f0 * A:(f0 + fc) * A].reshape(fc, A)[:, cho].reshape(-1).contiguous()
+                slot = (torch.arange(fc, device=self.dev, dtype=torch.int32).reshape(fc, 1) * A
+                        + torch.tensor(cho, dtype=torch.int32, device=self.dev).reshape(1, Ac)).reshape(-1).contiguous()
+                ops.batch_assemble(K, tr[f0:f0 + fc], va[f0:f0 + fc], None, a2c, fc, Ac, N, M, aug)
+                infos.append(ops.batch_chol_solve(aug, fc * Ac, N, M, H, slot))
+                del aug
+            if ser:
+                ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M,
+                                     lmax[f0:f0 + fc] if lmax is not None else None, self.d_alphas[ser], d_ser, A,
+                                     self.normalpha, SERIES_TERMS, H)
             for j in range(fc):
                 f = f0 + j
                 ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk)
@@ -180,7 +197,7 @@ class RidgeCVEngine:
                 else:
                     ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], va[f], n_v[f], ystat, yblk,
                                            self.mode, part, scores, accumulate=f > 0)
-        return scores, torch.cat(infos)
+        return scores, (torch.cat(infos) if infos else torch.zeros(1, dtype=torch.int32, device=self.dev))
 
     # -------------------------------------------------------------- alpha selection
     def choose(self, scores, single_alpha):

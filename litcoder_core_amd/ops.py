@@ -167,11 +167,18 @@ def batch_assemble(k, tr, va, rhs, a2, F, A, N, M, aug):
     _lib.call("lc_batch_assemble", _p(k), k.stride(0), _p(tr), _p(va), _p(rhs), _p(a2), F, A, N, M, _p(aug), _s())
 
 
-def batch_chol_solve(aug, B, N, M, h):
+def batch_chol_solve(aug, B, N, M, h, slot=None):
     linv = torch.empty((B, N // LC_NB, LC_NB, LC_NB), dtype=torch.float64, device=aug.device)
     info = torch.empty(B, dtype=torch.int32, device=aug.device)
-    _lib.call("lc_batch_chol_solve", _p(aug), B, N, M, _p(linv), _p(h), _p(info), _s())
+    _lib.call("lc_batch_chol_solve", _p(aug), B, N, M, _p(linv), _p(h), _p(slot), _p(info), _s())
     return info
+
+
+def batch_series_hat(k, tr, va, F, N, M, lmax, alphas_s, aidx, A, normalpha, terms, h):
+    S = alphas_s.numel()
+    work = torch.empty(F * N * N + terms * F * M * N, dtype=torch.float64, device=k.device)
+    _lib.call("lc_batch_series_hat", _p(k), k.stride(0), _p(tr), _p(va), F, N, M, _p(lmax), _p(alphas_s), _p(aidx), S, A,
+              int(bool(normalpha)), terms, _p(work), _p(h), _s())
 
 
 def transpose_rows(x, tr, N, p, out):
