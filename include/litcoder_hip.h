@@ -115,6 +115,11 @@ int lc_col_normalize_f32(float* d_x, int64_t ld, int64_t n_rows, int64_t n_cols,
 int lc_pearson_cols(const float* d_a, int64_t lda, const float* d_b, int64_t ldb,
                     int64_t n, int64_t V, double* d_r, lc_stream_t stream);
 
+/* The p-value scipy.stats.pearsonr attaches to r for n samples (nested_cv.py:434-436): two-sided, from the
+ * Beta(n/2-1, n/2-1) null distribution, evaluated on the float32-rounded r like scipy does for float32
+ * inputs; NaN r -> 1.  d_r, d_p: (V) f64. */
+int lc_pearson_pvalues(const double* d_r, int64_t V, int64_t n, double* d_p, lc_stream_t stream);
+
 /* ---------------------------------------------------------------- small dense fp64 */
 
 /* K = X X' with fp64 accumulation; X (T, p) f32, K (T, T) f64.  Replaces the SVD of the

@@ -165,6 +165,55 @@ __global__ void __launch_bounds__(64 * PR_RG) k_pearson_cols(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------ Pearson p-values
+// Two-sided p-value of r under H0 as scipy.stats.pearsonr forms it (r ~ Beta(n/2-1, n/2-1) on [-1, 1]):
+// p = 2 * (1 - I_x(ab, ab)), x = (|r| + 1) / 2 evaluated in fp32 like scipy does for float32 inputs, the
+// regularised incomplete beta by Lentz's continued fraction in fp64.  NaN r -> p = 1.
+__device__ inline double betainc_sym(double ab, double x) {        // I_x(ab, ab)
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    const bool flip = x > 0.5;
+    const double xx = flip ? 1.0 - x : x;
+    const double lbeta = 2.0 * lgamma(ab) - lgamma(2.0 * ab);
+    const double front = exp(ab * log(xx) + ab * log1p(-xx) - lbeta) / ab;
+    const double tiny = 1e-300;
+    double c = 1.0, d = 1.0 - 2.0 * ab * xx / (ab + 1.0);
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 400; ++m) {
+        const double m2 = 2.0 * m;
+        double num = m * (ab - m) * xx / ((ab + m2 - 1.0) * (ab + m2));
+        d = 1.0 + num * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + num / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        h *= d * c;
+        num = -(ab + m) * (2.0 * ab + m) * xx / ((ab + m2) * (ab + m2 + 1.0));
+        d = 1.0 + num * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + num / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double delta = d * c;
+        h *= delta;
+        if (fabs(delta - 1.0) < 1e-16) break;
+    }
+    const double val = front * h;
+    return flip ? 1.0 - val : val;
+}
+
+__global__ void __launch_bounds__(256) k_pearson_pvalues(const double* __restrict__ r, long long V, long long n,
+                                                         double* __restrict__ p) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float r32 = (float)r[v];
+    double out = 1.0;
+    if (r32 == r32 && n > 2) {
+        const float a = fminf(fabsf(r32), 1.f);
+        const double x = (double)((a + 1.f) / 2.f);          // fp32, as scipy >= 1.14 does for fp32 statistics
+        out = fmin(2.0 * betainc_sym((double)n / 2.0 - 1.0, 1.0 - x), 1.0);
+    }
+    p[v] = out;
+}
+
 // ------------------------------------------------------------------ alpha selection
 __global__ void __launch_bounds__(256) k_argmax_alpha(const float* __restrict__ scores, int A, long long V,
                                                       int* __restrict__ best) {
@@ -353,4 +402,14 @@ extern "C" int lc_group_by_alpha(const int32_t* d_best, int64_t V, int A, int pa
     hipLaunchKernelGGL(k_group_by_alpha, dim3(1), dim3(GB_THREADS), lds, lc::as_stream(stream), d_best, V, A, pad,
                        d_perm, d_count);
     return lc::launched("k_group_by_alpha");
+}
+
+extern "C" int lc_pearson_pvalues(const double* d_r, int64_t V, int64_t n, double* d_p, lc_stream_t stream) {
+    LC_REQUIRE(d_r && d_p, LC_E_BADARG, "lc_pearson_pvalues: null pointer");
+    LC_REQUIRE(V >= 0 && n >= 0, LC_E_SHAPE, "lc_pearson_pvalues: bad shape");
+    if (V == 0) return LC_OK;
+    lc::ScopedTimer timer_(lc::T_PEARSON, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_pearson_pvalues, dim3((unsigned)lc::ceil_div<long long>(V, 256)), dim3(256), 0,
+                       lc::as_stream(stream), d_r, (long long)V, (long long)n, d_p);
+    return lc::launched("k_pearson_pvalues");
 }

@@ -34,7 +34,8 @@ from .folding import create_folds
 
 logger = logging.getLogger(__name__)
 
-LANCZOS_STEPS = 96                  # Lanczos iterations for S[0]^2: <= 1e-14 relative on the cfg2 Grams (profiles/)
+LANCZOS_STEPS = 64                  # Lanczos iterations for S[0]^2: <= 1e-11 relative on the cfg2 Grams (profiles/);
+                                    # the reference's own S[0] is an fp32 SVD value (~1e-7)
 AUG_BUDGET_BYTES = 24 << 30         # cap on the batched (fold, alpha) fp64 systems resident at once
 SERIES_TERMS = 6                    # Neumann terms for the hat matrices of large alphas ...
 SERIES_TOL = 1e-10                  # ... used when (lambda_max / a^2)^SERIES_TERMS <= this (H is stored as fp32)
@@ -52,10 +53,10 @@ class BasePredictivityModel:
 
 
 class _FoldResult:
-    __slots__ = ("r", "best_idx", "n_test")
+    __slots__ = ("r", "p", "best_idx", "n_test")
 
-    def __init__(self, r, best_idx, n_test):
-        self.r, self.best_idx, self.n_test = r, best_idx, n_test
+    def __init__(self, r, p, best_idx, n_test):
+        self.r, self.p, self.best_idx, self.n_test = r, p, best_idx, n_test
 
 
 class RidgeCVEngine:
@@ -286,9 +287,12 @@ class RidgeCVEngine:
         pred = torch.empty((n_t, Vs), dtype=torch.float32, device=self.dev)
         ops.gemm_grouped(Xte, self.p_pad, 0, Ws, Vs, None, pred, Vs, n_t, Vs, self.p_pad, [0, Vs // COL_TILE])
         r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
+        p_s = ops.pearson_pvalues(r_s, Vs, n_t)
         ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
         # results leave through pinned buffers so the copies do not stall the host
         h_r = torch.empty(Vs, dtype=torch.float64, pin_memory=True)
+        h_p = torch.empty(Vs, dtype=torch.float64, pin_memory=True)
+        h_p.copy_(p_s, non_blocking=True)
         h_perm = torch.empty(Vs, dtype=torch.int32, pin_memory=True)
         h_best = torch.empty(self.V, dtype=torch.int32, pin_memory=True)
         h_r.copy_(r_s, non_blocking=True)
@@ -296,15 +300,17 @@ class RidgeCVEngine:
         h_best.copy_(best[: self.V], non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return dict(done=done, r=h_r, perm=h_perm, best=h_best, n_t=n_t, keep=(r_s, perm, best))
+        return dict(done=done, r=h_r, p=h_p, perm=h_perm, best=h_best, n_t=n_t, keep=(r_s, p_s, perm, best))
 
     def fold_collect(self, pend) -> _FoldResult:
         pend["done"].synchronize()
         perm_h = pend["perm"].numpy()
         live = perm_h >= 0
         r = np.empty(self.V, dtype=np.float64)
+        p = np.empty(self.V, dtype=np.float64)
         r[perm_h[live]] = pend["r"].numpy()[live]
-        return _FoldResult(r, pend["best"].numpy().copy(), pend["n_t"])
+        p[perm_h[live]] = pend["p"].numpy()[live]
+        return _FoldResult(r, p, pend["best"].numpy().copy(), pend["n_t"])
 
     def run_fold(self, tr_rows, te_rows, inner_rel, single_alpha, weight_scale) -> _FoldResult:
         st = self.fold_begin(tr_rows, te_rows, inner_rel)
@@ -324,10 +330,10 @@ def _alpha_vector(alphas, idx, single_alpha):
     return np.asarray(alphas, dtype=np.float64)[np.asarray(idx, dtype=np.int64)].astype(np.float32)
 
 
-def _fold_lists(r32: np.ndarray, n_test: int):
+def _fold_lists(r32: np.ndarray, p: np.ndarray):
     """What ``_calculate_correlations_pvalues`` (nested_cv.py:418-438) returns for one fold:
-    list of np.float32 r (NaN -> Python 0.0) and list of float64 p (NaN -> 1.0)."""
-    p = stats.pearson_pvalues(r32, n_test)
+    list of np.float32 r (NaN -> Python 0.0) and list of float64 p (NaN -> 1.0).  ``p`` comes from the
+    device (``lc_pearson_pvalues``; ``stats.pearson_pvalues`` is the same formula on the host)."""
     corrs, pvals = list(r32), list(p)
     for i in np.nonzero(np.isnan(r32))[0]:
         corrs[i] = 0.0
@@ -440,18 +446,24 @@ class NestedCVModel(BasePredictivityModel):
                             precision=self.precision)
         scale = 1.0 if train_test else 1.0 / len(outer)
         fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
+        score_rows, p_rows, any_nan = [], [], []
 
         def tail(pend):
             """Host statistics of one finished fold; runs while the GPU works on the next fold.
             The all-gather over voxel shards is the only V-sized exchange of the fit."""
             f = eng.fold_collect(pend)
-            r = shard.allgather_cols(f.r[None, :], V_total)[0]
+            rp = shard.allgather_cols(np.stack([f.r, f.p]), V_total)
             idx = shard.allgather_cols(f.best_idx.astype(np.int32)[None, :], V_total)[0]
-            corrs, pvals = _fold_lists(r.astype(np.float32), f.n_test)
+            r32 = rp[0].astype(np.float32)
+            corrs, pvals = _fold_lists(r32, rp[1])
             fold_scores.append(corrs)
             fold_p.append(pvals)
             fold_alpha.append(_alpha_vector(alphas, idx, single_alpha))
-            fold_sig.append(stats.fdrcorrection(pvals, alpha=alpha_fdr))
+            p_arr = np.where(np.isnan(r32), 1.0, rp[1])
+            fold_sig.append(stats.fdrcorrection(p_arr, alpha=alpha_fdr))
+            score_rows.append(np.nan_to_num(r32, nan=0.0))
+            p_rows.append(p_arr)
+            any_nan.append(bool(np.isnan(r32).any()))
 
         pending = None
         for tr, te, inner in outer:
@@ -467,8 +479,10 @@ class NestedCVModel(BasePredictivityModel):
             metrics = stats.train_test_metrics(fold_scores[0], fold_p[0], padj, sig, fold_alpha[0], np.sum(sig))
             return metrics, weights, fold_alpha[0]
 
-        scores = np.mean(fold_scores, axis=0)
-        pcomb = stats.fisher_combine(fold_p)
+        # np.mean(fold_scores, axis=0) of the reference (nested_cv.py:276): the nested lists hold np.float32
+        # scalars, plus Python 0.0 where r was NaN -- numpy then builds a float64 array, else a float32 one
+        scores = np.mean(np.stack(score_rows).astype(np.float64 if any(any_nan) else np.float32), axis=0)
+        pcomb = stats.fisher_combine(np.stack(p_rows))
         sig, padj = stats.fdrcorrection(pcomb, alpha=alpha_fdr)
         majority = np.sum([s for s, _ in fold_sig], axis=0) >= (n_outer_folds // 2 + 1)
         mean_alphas = np.mean(fold_alpha, axis=0)

@@ -142,6 +142,12 @@ def pearson_cols(a, b, n, V):
     return r
 
 
+def pearson_pvalues(r, V, n):
+    p = torch.empty(V, dtype=torch.float64, device=r.device)
+    _lib.call("lc_pearson_pvalues", _p(r), V, n, _p(p), _s())
+    return p
+
+
 # ------------------------------------------------------------------ small dense fp64
 def gram(x, T, p):
     k = torch.empty((T, T), dtype=torch.float64, device=x.device)

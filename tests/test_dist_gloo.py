@@ -23,7 +23,7 @@ import oracle.ridge as oridge
 
 class OracleEngine:
     """Same interface as RidgeCVEngine.run_fold/weights, arithmetic by the CPU oracle."""
-    def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard):
+    def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard, precision="auto"):
         self.X, self.Y = torch.tensor(np.asarray(X), dtype=torch.float32), torch.tensor(np.asarray(Y), dtype=torch.float32)
         self.alphas, self.normalpha, self.use_corr, self.shard = list(alphas), normalpha, use_corr, shard
         self.V = self.Y.shape[1]
@@ -45,7 +45,8 @@ class OracleEngine:
         with np.errstate(all="ignore"):
             r = (pc * yc).sum(0) / np.sqrt((pc ** 2).sum(0) * (yc ** 2).sum(0))
         self.W += scale * W.numpy()
-        return ncv._FoldResult(r, idx, len(te))
+        from litcoder_core_amd import stats
+        return ncv._FoldResult(r, stats.pearson_pvalues(r.astype(np.float32), len(te)), idx, len(te))
     def fold_begin(self, tr, te, inner):
         return (tr, te, inner)
     def fold_refit(self, st, single_alpha, scale):

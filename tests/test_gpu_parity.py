@@ -87,6 +87,33 @@ def test_lanczos_story_size_vs_oracle(lc):
     np.testing.assert_allclose(out_p, out, rtol=0, atol=1e-12)
 
 
+# ------------------------------------------------------------------ per-voxel statistics kernels
+def test_pearson_r_and_pvalues_vs_scipy(lc):
+    from scipy.stats import pearsonr
+    from litcoder_core_amd import ops
+    rng = np.random.default_rng(3)
+    dev = ops.device()
+    for n in (3, 25, 600):
+        V = 300
+        a = rng.standard_normal((n, V)).astype(np.float32)
+        b = (0.4 * a + rng.standard_normal((n, V))).astype(np.float32)
+        b[:, 5] = 1.5                                           # constant column -> NaN r -> p = 1
+        b[:, 6] = a[:, 6]                                       # r = 1 -> p = 0
+        da, db = ops.upload_f32(a, 384, dev), ops.upload_f32(b, 384, dev)
+        r = ops.pearson_cols(da, db, n, V)
+        p = ops.pearson_pvalues(r, V, n).cpu().numpy()
+        r = r.cpu().numpy()
+        ref = [pearsonr(a[:, i].astype(np.float64), b[:, i].astype(np.float64)) for i in range(V) if i != 5]
+        keep = np.array([i for i in range(V) if i != 5])
+        np.testing.assert_allclose(r[keep], [float(x[0]) for x in ref], rtol=0, atol=1e-12)
+        assert np.isnan(r[5]) and p[5] == 1.0
+        # p as scipy computes it for float32 statistics: from the fp32-rounded r
+        want = lc.stats.pearson_pvalues(r.astype(np.float32), n) if hasattr(lc, "stats") else None
+        from litcoder_core_amd import stats
+        want = stats.pearson_pvalues(r.astype(np.float32), n)
+        np.testing.assert_allclose(p, want, rtol=1e-9, atol=1e-300)
+
+
 # ------------------------------------------------------------------ ridge solvers vs the reference
 def test_ridge_solvers_golden(lc, golden_dir):
     from litcoder_core_amd import ridge
