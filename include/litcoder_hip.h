@@ -217,6 +217,15 @@ int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, i
                                 const int32_t* d_va, int n_val, const float* d_ystat, const float* d_yblk,
                                 int mode, float* d_part, float* d_scores, int accumulate, lc_stream_t stream);
 
+/* Grouped GEMM of the refit (lc_gemm_grouped_f32's job) on the same fp16x3 scheme:
+ * C[:, tile] = A_g(tile) . B[:, tile].  d_at: G tiled images made by lc_split_rows_f16 (one per group, each
+ * pad256(Mrows) rows), d_rowscale_inv: (G * pad256(Mrows)); d_bt: tiled image of B (K x Ncols) made by
+ * lc_split_cols_f16, d_cscale_inv: (Ncols).  Ncols % 256 == 0, K % 32 == 0; h_group_tiles: G+1 offsets in
+ * 256-column tiles. */
+int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows,
+                          const void* d_bt, const float* d_cscale_inv, float* d_c, int64_t ldc,
+                          int64_t Ncols, int64_t K, const int32_t* h_group_tiles, int G, lc_stream_t stream);
+
 /* best[v] = first argmax_a scores[a, v] / n_folds (nested_cv.py:391-408); also
  * d_rowsum[a] = sum_v scores[a, v] (f64) for the single-alpha path (:396-400, all-reduced
  * across ranks by the host).  Either output may be NULL. */

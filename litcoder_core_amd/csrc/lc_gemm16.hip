@@ -155,10 +155,24 @@ struct Score16Args {
     int M, n_val, mode, Mrows;
 };
 
+// plain (store) mode: C[:, tile] = A_g(tile) . B[:, tile] with one A matrix per column group
+constexpr int MAX_GROUPS16 = 64;
+struct Plain16Args {
+    float* c;              // (Mrows, ldc) f32 output
+    long long ldc;
+    const float* rs_inv;   // (G * Mtiles * 256)
+    const float* cs_inv;   // (Ncols)
+    int Mrows;             // real rows per group
+    int G;
+    int start[MAX_GROUPS16 + 1];   // first 256-column tile of each group; start[G] = number of column tiles
+};
+
 #define MFMA16(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
 
+template <bool SCORE>
 __global__ void __launch_bounds__(512, 2)
-k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT, int Mtiles, Score16Args sa) {
+k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT, int Mtiles, Score16Args sa,
+              Plain16Args pa) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds16[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -167,7 +181,11 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 
     const int tile = xcd_tile_id16(blockIdx.x, gridDim.x);
     const int mt = tile % Mtiles, nt = tile / Mtiles;
-    const uint4* a_src = At + (long long)mt * KT * CHUNK16 + tid;
+    int grp = 0;
+    if (!SCORE) {
+        while (grp + 1 < pa.G && nt >= pa.start[grp + 1]) ++grp;
+    }
+    const uint4* a_src = At + ((long long)grp * Mtiles + mt) * KT * CHUNK16 + tid;
     const uint4* b_src = Bt + (long long)nt * KT * CHUNK16 + tid;
 
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
@@ -234,6 +252,25 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         }
         if (kt + 1 < KT) STORE16(cur ^ 1);
         __syncthreads();
+    }
+
+    if (!SCORE) {
+        // ---- plain epilogue: undo the power-of-two scales and store
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const long long col = (long long)nt * TN + wn * 64 + ni * 32 + li;
+                const float csc = pa.cs_inv[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * TM + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < pa.Mrows)
+                        pa.c[(long long)row * pa.ldc + col] =
+                            acc[mi][ni][r] * pa.rs_inv[(long long)grp * Mtiles * TM + row] * csc;
+                }
+            }
+        return;
     }
 
     // ---- epilogue: identical statistics to lc_gemm.hip after undoing the power-of-two scales
@@ -340,7 +377,7 @@ extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rows
     LC_REQUIRE(mode == LC_SCORE_CORR || mode == LC_SCORE_R2, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: bad mode");
     static thread_local bool attr_done = false;
     if (!attr_done) {
-        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3),
+        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
         attr_done = true;
     }
@@ -353,9 +390,49 @@ extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rows
                    mode, Mrows};
     {
         lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
-        hipLaunchKernelGGL(k_sweep_f16x3, dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
-                           (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa);
+        Plain16Args pa{};
+        hipLaunchKernelGGL(k_sweep_f16x3<true>, dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
+                           (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa);
     }
     if (int rc = lc::launched("k_sweep_f16x3")) return rc;
     return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, n_val, (long long)V, mode, d_scores, accumulate, s);
+}
+
+extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
+                                     const float* d_cscale_inv, float* d_c, int64_t ldc, int64_t Ncols, int64_t K,
+                                     const int32_t* h_group_tiles, int G, lc_stream_t stream) {
+    LC_REQUIRE(d_at && d_rowscale_inv && d_bt && d_cscale_inv && d_c && h_group_tiles, LC_E_BADARG,
+               "lc_gemm_grouped_f16x3: null pointer");
+    LC_REQUIRE(G >= 1 && G <= MAX_GROUPS16, LC_E_SHAPE, "lc_gemm_grouped_f16x3: G must be in 1..%d", MAX_GROUPS16);
+    LC_REQUIRE(Mrows > 0 && K > 0 && K % TK == 0 && Ncols > 0 && Ncols % TN == 0 && ldc >= Ncols, LC_E_SHAPE,
+               "lc_gemm_grouped_f16x3: need K %% %d == 0 and Ncols %% %d == 0", TK, TN);
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
+        attr_done = true;
+    }
+    const int Mtiles = (int)lc::ceil_div<long long>(Mrows, TM);
+    const long long Ntiles = Ncols / TN;
+    Plain16Args pa{};
+    pa.c = d_c;
+    pa.ldc = ldc;
+    pa.rs_inv = d_rowscale_inv;
+    pa.cs_inv = d_cscale_inv;
+    pa.Mrows = (int)Mrows;
+    pa.G = G;
+    for (int g = 0; g <= G; ++g) {
+        pa.start[g] = h_group_tiles[g];
+        LC_REQUIRE(g == 0 ? pa.start[0] == 0 : pa.start[g] >= pa.start[g - 1], LC_E_SHAPE,
+                   "lc_gemm_grouped_f16x3: group tile offsets must start at 0 and be non-decreasing");
+    }
+    LC_REQUIRE(pa.start[G] == Ntiles, LC_E_SHAPE, "lc_gemm_grouped_f16x3: last group offset %d != %lld column tiles",
+               pa.start[G], Ntiles);
+    LC_REQUIRE((long long)Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_gemm_grouped_f16x3: grid too large");
+    Score16Args sa{};
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
+    hipLaunchKernelGGL(k_sweep_f16x3<false>, dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
+                       (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa);
+    return lc::launched("k_sweep_f16x3<plain>");
 }

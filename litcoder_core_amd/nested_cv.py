@@ -219,13 +219,15 @@ class RidgeCVEngine:
         N_o): column j of Ws / Ys is voxel perm[j] (-1 = padding).  ``extra_rows`` of Y are gathered
         below the training rows in the same voxel order (the test targets)."""
         A, V = self.A, self.V
-        perm, count = ops.group_by_alpha(best, V, A, COL_TILE)
+        split = self._use_split(Y)
+        tile = 256 if split else COL_TILE                 # column-tile width of the GEMM that follows
+        perm, count = ops.group_by_alpha(best, V, A, tile)
         count_h = count.cpu().numpy()
         used = [a for a in range(A) if count_h[a] > 0]
         tiles = [0]
         for a in used:
-            tiles.append(tiles[-1] + (int(count_h[a]) + COL_TILE - 1) // COL_TILE)
-        Vs, G = tiles[-1] * COL_TILE, len(used)
+            tiles.append(tiles[-1] + (int(count_h[a]) + tile - 1) // tile)
+        Vs, G = tiles[-1] * tile, len(used)
         n_o = len(tr_rows)
         N_o = ops.pad_to(n_o, LC_NB)
         tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
@@ -244,7 +246,21 @@ class RidgeCVEngine:
         Ys = torch.empty((N_o + n_x, Vs), dtype=torch.float32, device=self.dev)
         ops.gather(Y, self.Vp, rows_s, N_o + n_x, perm, Vs, Ys)
         Ws = torch.empty((self.p_pad, Vs), dtype=torch.float32, device=self.dev)
-        ops.gemm_grouped(Malpha, N_o, self.p_pad * N_o, Ys, Vs, None, Ws, Vs, self.p_pad, Vs, N_o, tiles)
+        if split:
+            # weights on the fp16x3 MFMA path: split every group's M_alpha by rows, the sorted targets by
+            # columns (their scales follow the voxels through the permutation), one grouped launch
+            rows_pad = ops.pad_to(self.p_pad, 256)
+            At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
+            rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
+            for g in range(G):
+                ops.split_rows_f16(Malpha[g], self.p_pad, N_o, At[g * rows_pad * N_o * 2:], rs_inv[g * rows_pad:])
+            cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)
+            ops.gather(self._cs.reshape(2, self.Vp), self.Vp, None, 2, perm, Vs, cs_s)
+            Yt = torch.empty(Vs * N_o * 2, dtype=torch.float16, device=self.dev)
+            ops.split_cols_f16(Ys, Vs, torch.arange(N_o, dtype=torch.int32, device=self.dev), N_o, cs_s[0], Yt)
+            ops.gemm_grouped_f16x3(At, rs_inv, self.p_pad, Yt, cs_s[1], Ws, Vs, Vs, N_o, tiles)
+        else:
+            ops.gemm_grouped(Malpha, N_o, self.p_pad * N_o, Ys, Vs, None, Ws, Vs, self.p_pad, Vs, N_o, tiles)
         if int(info.cpu().numpy().any()):
             raise RuntimeError("Cholesky failed in the refit: Gram matrix + alpha^2 I is not positive definite")
         return Ws, Ys, perm, N_o

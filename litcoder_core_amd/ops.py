@@ -224,6 +224,13 @@ def alpha_sweep_scores_f16x3(ht, rowscale_inv, A, M, N, yt, cscale_inv, y, V, va
               y.stride(0), V, _p(va), n_val, _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), _s())
 
 
+def gemm_grouped_f16x3(at, rowscale_inv, Mrows, bt, cscale_inv, c, ldc, Ncols, K, group_tiles):
+    G = len(group_tiles) - 1
+    arr = (ctypes.c_int32 * (G + 1))(*[int(t) for t in group_tiles])
+    _lib.call("lc_gemm_grouped_f16x3", _p(at), _p(rowscale_inv), Mrows, _p(bt), _p(cscale_inv), _p(c), ldc, Ncols, K,
+              arr, G, _s())
+
+
 def select_alpha(scores, A, V, want_best=True, want_rowsum=False):
     best = torch.empty(V, dtype=torch.int32, device=scores.device) if want_best else None
     rowsum = torch.empty(A, dtype=torch.float64, device=scores.device) if want_rowsum else None
