@@ -109,6 +109,11 @@ int lc_col_mean_std_f32(const float* d_x, int64_t ld, const int32_t* d_rows, int
 int lc_col_normalize_f32(float* d_x, int64_t ld, int64_t n_rows, int64_t n_cols,
                          const float* d_mean, const float* d_std, float eps, lc_stream_t stream);
 
+/* The trainer's per-story z-score (utils.py:23-29 ``zs``; trainer.py:235-257): float64, population std,
+ * zero-std columns only de-meaned; nan_to_num != 0 also applies np.nan_to_num to the result (features). */
+int lc_zscore_story_f64(const double* d_x, int64_t ld_in, int64_t rows, int64_t cols, int nan_to_num,
+                        double* d_out, int64_t ld_out, lc_stream_t stream);
+
 /* scipy.stats.pearsonr per voxel (nested_cv.py:418-438): d_a, d_b (n, V) f32 -> d_r (V) f64
  * Pearson r, NaN (constant column) reported as NaN; the host maps NaN -> 0 like the
  * reference.  fp64 accumulation. */

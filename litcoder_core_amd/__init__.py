@@ -16,6 +16,7 @@ from .fir import FIR
 from .folding import create_folds
 from .nested_cv import BasePredictivityModel, NestedCVModel, fit_nested_cv
 from .dist import ShardContext, shard_bounds
+from .harness import StoryPipeline
 
 __all__ = ["NestedCVModel", "fit_nested_cv", "FIR", "Downsampler", "create_folds", "BasePredictivityModel",
-           "ShardContext", "shard_bounds"]
+           "ShardContext", "shard_bounds", "StoryPipeline"]

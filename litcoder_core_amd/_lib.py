@@ -35,6 +35,7 @@ SIGNATURES = {
     "lc_scatter_axpy_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, c_float, _ptr, c_int64, _ptr]),
     "lc_col_mean_std_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_col_normalize_f32": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, c_float, _ptr]),
+    "lc_zscore_story_f64": (c_int, [_ptr, c_int64, c_int64, c_int64, c_int, _ptr, c_int64, _ptr]),
     "lc_pearson_cols": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64, _ptr, _ptr]),
     "lc_pearson_pvalues": (c_int, [_ptr, c_int64, c_int64, _ptr, _ptr]),
     "lc_gram_f64": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, c_int64, _ptr]),

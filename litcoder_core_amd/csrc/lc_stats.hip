@@ -93,6 +93,35 @@ __global__ void __launch_bounds__(256) k_col_normalize(float* __restrict__ x, lo
         x[r * ld + j] = (x[r * ld + j] - mean[j]) / (sd[j] + eps);
 }
 
+// Per-story z-scoring of the trainer (utils.py:23-29 ``zs``): float64, POPULATION std, a column whose std is
+// exactly 0 is only de-meaned; optional np.nan_to_num on the result (trainer.py:235,250 applies it to X).
+__global__ void __launch_bounds__(64 * CM_RG) k_zscore_story(const double* __restrict__ x, long long ld_in, long long rows,
+                                                             long long cols, int nan_to_num, double* __restrict__ out,
+                                                             long long ld_out) {
+    __shared__ double sm[CM_RG][64];
+    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = c < cols;
+    double s = 0.0;
+    if (live)
+        for (long long i = threadIdx.y; i < rows; i += CM_RG) s += x[i * ld_in + c];
+    const double mean = block_colsum<CM_RG>(s, sm) / (double)rows;
+    double q = 0.0;
+    if (live)
+        for (long long i = threadIdx.y; i < rows; i += CM_RG) { const double d = x[i * ld_in + c] - mean; q += d * d; }
+    const double sd = sqrt(block_colsum<CM_RG>(q, sm) / (double)rows);
+    if (live)
+        for (long long i = threadIdx.y; i < rows; i += CM_RG) {
+            double v = x[i * ld_in + c] - mean;
+            if (sd != 0.0) v /= sd;
+            if (nan_to_num) {
+                if (v != v) v = 0.0;
+                else if (v > 1.7976931348623157e308) v = 1.7976931348623157e308;
+                else if (v < -1.7976931348623157e308) v = -1.7976931348623157e308;
+            }
+            out[i * ld_out + c] = v;
+        }
+}
+
 // Validation-target statistics for the fused scorer.  ystat = [mean | std | var] (unbiased),
 // yblk[b, v] = sum over the b-th 32-row block of fl32(y - mean): exactly the centred values
 // the GEMM epilogue multiplies with.
@@ -412,4 +441,16 @@ extern "C" int lc_pearson_pvalues(const double* d_r, int64_t V, int64_t n, doubl
     hipLaunchKernelGGL(k_pearson_pvalues, dim3((unsigned)lc::ceil_div<long long>(V, 256)), dim3(256), 0,
                        lc::as_stream(stream), d_r, (long long)V, (long long)n, d_p);
     return lc::launched("k_pearson_pvalues");
+}
+
+extern "C" int lc_zscore_story_f64(const double* d_x, int64_t ld_in, int64_t rows, int64_t cols, int nan_to_num,
+                                   double* d_out, int64_t ld_out, lc_stream_t stream) {
+    LC_REQUIRE(d_x && d_out, LC_E_BADARG, "lc_zscore_story_f64: null pointer");
+    LC_REQUIRE(rows > 0 && cols >= 0 && ld_in >= cols && ld_out >= cols, LC_E_SHAPE, "lc_zscore_story_f64: bad shape");
+    if (cols == 0) return LC_OK;
+    lc::ScopedTimer timer_(lc::T_COLSTATS, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_zscore_story, dim3((unsigned)lc::ceil_div<long long>(cols, 64)), dim3(64, CM_RG), 0,
+                       lc::as_stream(stream), d_x, (long long)ld_in, (long long)rows, (long long)cols, nan_to_num, d_out,
+                       (long long)ld_out);
+    return lc::launched("k_zscore_story");
 }

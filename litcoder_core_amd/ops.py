@@ -114,6 +114,11 @@ def upload_f32(host, ld, dev, rows_pad=None, chunk_bytes=1 << 28):
     return out
 
 
+def cast_f64_f32(src, dst, rows, cols):
+    """(rows, cols) float64 device view -> float32 device view (row strides taken from the tensors)."""
+    _lib.call("lc_cast_f64_f32", _p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, _s())
+
+
 def gather(src, ld_src, rows, n_rows, cols, n_cols, out):
     _lib.call("lc_gather_f32", _p(src), ld_src, _p(rows), n_rows, _p(cols), n_cols, _p(out), out.stride(0), _s())
     return out
@@ -134,6 +139,12 @@ def col_mean_std(x, rows, n_rows, n_cols):
 
 def col_normalize_(x, n_rows, n_cols, mean, std, eps=1e-8):
     _lib.call("lc_col_normalize_f32", _p(x), x.stride(0), n_rows, n_cols, _p(mean), _p(std), float(eps), _s())
+
+
+def zscore_story(x, rows, cols, nan_to_num, out):
+    """x: f64 device view (rows, >=cols); out: f64 device view, same shape; utils.zs semantics."""
+    _lib.call("lc_zscore_story_f64", _p(x), x.stride(0), rows, cols, int(bool(nan_to_num)), _p(out), out.stride(0), _s())
+    return out
 
 
 def pearson_cols(a, b, n, V):

@@ -208,6 +208,39 @@ def test_fit_nested_cv_alias(lc):
     assert m1["correlations"] == m2["correlations"] and np.array_equal(W1, W2) and np.array_equal(a1, a2)
 
 
+# ------------------------------------------------------------------ trainer-side structuring
+def test_story_structuring_matches_reference_trainer(lc, golden_dir):
+    """FIR -> trim -> zs -> stack on the device against captures of the reference's own
+    AbstractTrainer._create_train_test_split / utils.zs (tests/golden/harness.npz)."""
+    from litcoder_core_amd import harness
+    g = load(golden_dir, "harness.npz")
+    np.testing.assert_allclose(harness.zs(g["zs_in"]), g["zs_out"], rtol=0, atol=1e-13)
+    stories = ["s0", "s1", "s2", "s3"]
+    trimming = {"train_features_start": 10, "train_features_end": -5, "train_targets_start": 0,
+                "train_targets_end": None, "test_features_start": 50, "test_features_end": -5,
+                "test_targets_start": 40, "test_targets_end": None}
+    feats = {s: g[f"feat_{s}"] for s in stories}
+    brain = {s: g[f"brain_{s}"] for s in stories}
+    delayed = harness.apply_fir_delays(feats, [1, 2, 3, 4])
+    d = harness.structure_train_test(delayed, brain, trimming)
+    for k in ("Rstim", "Rresp", "Pstim", "Presp"):
+        assert d[k].shape == g[k].shape and d[k].dtype == np.float64
+        # float64; the device sums in a different order than numpy's pairwise mean: a few ulps
+        np.testing.assert_allclose(d[k], g[k], rtol=0, atol=5e-12, err_msg=k)
+    c = harness.structure_concatenated({s: delayed[s].cpu().numpy() for s in stories}, brain, stories,
+                                       {"features_start": 10, "features_end": -5, "targets_start": 3, "targets_end": -12})
+    assert np.array_equal(c["X"], g["cat_X"]) and np.array_equal(c["Y"], g["cat_Y"])
+    # stories in -> metrics out, resident on the device, against the oracle fed with the reference's matrices
+    import oracle.nested_cv as onc
+    kw = dict(folding_type="kfold", n_inner_folds=3, alphas=np.logspace(-1, 3, 5), single_alpha=True)
+    m_o, W_o, a_o = onc.fit_predict(g["Rstim"], g["Rresp"], X_test=g["Pstim"], y_test=g["Presp"], **kw)
+    m, W, a = lc.StoryPipeline([1, 2, 3, 4], trimming).fit(feats, brain, **kw)
+    assert np.array_equal(a, a_o)
+    np.testing.assert_allclose(np.asarray(m["correlations"], dtype=np.float64),
+                               np.asarray(m_o["correlations"], dtype=np.float64), atol=2e-5)
+    np.testing.assert_allclose(W, W_o, rtol=1e-4, atol=2e-6)
+
+
 # ------------------------------------------------------------------ size-independent properties, larger sizes
 def _synthetic(T, p, V, seed):
     rng = np.random.default_rng(seed)
