@@ -91,6 +91,9 @@ class RidgeCVEngine:
         self.d_alphas = torch.tensor(self.alphas, dtype=torch.float64, device=self.dev)
         self.K = None if self.norm_x else ops.gram(self.dX, self.Ttot, self.p)
         self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
+        self.aux = torch.cuda.Stream(device=self.dev)
+        self.ready = torch.cuda.Event()               # X, Y, K resident: the only thing the aux stream waits for
+        self.ready.record()
 
     def _resident(self, arr, ld):
         if isinstance(arr, _DeviceShapes):  # already resident: fp32, contiguous, zero-padded to the tile width
@@ -135,10 +138,11 @@ class RidgeCVEngine:
                 logger.info("target dynamic range too wide for the fp16x3 sweep: using the f32 MFMA path")
         return not self._cs_wide
 
-    # -------------------------------------------------------------- inner CV: alpha scores
-    def _alpha_scores(self, K, Y, inner_abs):
-        """Sum over inner folds of the (A, Vp) validation scores (ridge_corr_torch for every fold,
-        nested_cv.py:366-393)."""
+    # -------------------------------------------------------------- inner CV: hat matrices, then the sweeps
+    def _hat_matrices(self, K, inner_abs):
+        """V-independent part of the inner CV of one outer fold: row lists, S[0]^2 (Lanczos), penalties and the
+        hat matrices H_alpha of every (inner fold, alpha) -- batched Cholesky for the small alphas, the shared
+        Neumann series for the large ones.  Returns a dict the sweeps consume."""
         F, A = len(inner_abs), self.A
         n_i = [len(t) for t, _ in inner_abs]
         n_v = [len(v) for _, v in inner_abs]
@@ -150,28 +154,15 @@ class RidgeCVEngine:
         va = torch.stack([ops.idx_tensor(v, M, self.dev) for _, v in inner_abs])
         lmax = ops.lambda_max(K, tr, F, N, self.steps) if self.normalpha else None
         a2 = ops.penalties(lmax, F, self.d_alphas, self.normalpha)
-        scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
-        part = torch.empty((A * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
-        ystat = torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev)
-        yblk = torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
-        per_sys = (N + M) * N * 8
-        chunk = max(1, min(F, AUG_BUDGET_BYTES // max(1, per_sys * A)))
-        infos = []
-        split = self._use_split(Y)
-        LAST_SWEEP["precision"] = "f16x3" if split else "f32"
-        if split:
-            rows_pad = ops.pad_to(A * M, 256)
-            cs = self._cs
-            Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
-            rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
-            Yt = torch.empty(ops.pad_to(self.Vp, 256) * N * 2, dtype=torch.float16, device=self.dev)
         # alphas whose penalty dwarfs the spectrum take the Neumann series (shared matrix powers), the
         # rest the batched Cholesky; rho = lambda_max / a^2 = 1 / alpha^2 under normalpha
         ser = [a for a in range(A) if self.normalpha and self.alphas[a] ** (-2 * SERIES_TERMS) <= SERIES_TOL]
         cho = [a for a in range(A) if a not in ser]
         d_ser = torch.tensor(ser, dtype=torch.int32, device=self.dev) if ser else None
         Ac = len(cho)
+        per_sys = (N + M) * N * 8
         chunk = max(1, min(F, AUG_BUDGET_BYTES // max(1, per_sys * max(Ac, 1))))
+        infos, Hs = [], []
         for f0 in range(0, F, chunk):
             fc = min(chunk, F - f0)
             H = torch.empty((fc * A, M, N), dtype=torch.float32, device=self.dev)
@@ -187,6 +178,27 @@ class RidgeCVEngine:
                 ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M,
                                      lmax[f0:f0 + fc] if lmax is not None else None, self.d_alphas[ser], d_ser, A,
                                      self.normalpha, SERIES_TERMS, H)
+            Hs.append((f0, fc, H))
+        info = torch.cat(infos) if infos else torch.zeros(1, dtype=torch.int32, device=self.dev)
+        return dict(F=F, N=N, M=M, n_v=n_v, tr=tr, va=va, Hs=Hs, info=info, lmax=lmax, a2=a2)
+
+    def _sweeps(self, hat, Y):
+        """Sum over inner folds of the (A, Vp) validation scores (ridge_corr_torch for every fold,
+        nested_cv.py:366-393): the V-wide fused MFMA sweeps."""
+        A, N, M, tr, va, n_v = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"]
+        scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
+        part = torch.empty((A * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
+        ystat = torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev)
+        yblk = torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
+        split = self._use_split(Y)
+        LAST_SWEEP["precision"] = "f16x3" if split else "f32"
+        if split:
+            rows_pad = ops.pad_to(A * M, 256)
+            cs = self._cs
+            Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
+            rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
+            Yt = torch.empty(ops.pad_to(self.Vp, 256) * N * 2, dtype=torch.float16, device=self.dev)
+        for f0, fc, H in hat["Hs"]:
             for j in range(fc):
                 f = f0 + j
                 ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk)
@@ -198,7 +210,11 @@ class RidgeCVEngine:
                 else:
                     ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], va[f], n_v[f], ystat, yblk,
                                            self.mode, part, scores, accumulate=f > 0)
-        return scores, (torch.cat(infos) if infos else torch.zeros(1, dtype=torch.int32, device=self.dev))
+        return scores
+
+    def _alpha_scores(self, K, Y, inner_abs):
+        hat = self._hat_matrices(K, inner_abs)
+        return self._sweeps(hat, Y), hat["info"]
 
     # -------------------------------------------------------------- alpha selection
     def choose(self, scores, single_alpha):
@@ -278,16 +294,35 @@ class RidgeCVEngine:
     # prediction / Pearson / D2H) -> collect (wait for the fold's results).  The caller interleaves
     # the phases of consecutive folds so that the host statistics of fold f run while the GPU works
     # on fold f+1.
-    def fold_begin(self, tr_rows, te_rows, inner_rel):
+    def fold_prepare(self, tr_rows, te_rows, inner_rel):
+        """Everything of an outer fold that does not touch the voxel axis beyond O(V) copies -- train-statistics
+        normalisation, Lanczos, the batched Cholesky / series hat matrices -- enqueued on the engine's AUXILIARY
+        stream, so that it overlaps the V-wide MFMA sweeps of the previous fold running on the main stream
+        (these fp64 kernels are latency chains with small grids; on their own they leave most CUs idle)."""
         tr_rows = np.asarray(tr_rows, dtype=np.int64)
         te_rows = np.asarray(te_rows, dtype=np.int64)
         if len(te_rows) < 2:
             raise ValueError("x and y must have length at least 2.")      # scipy.stats.pearsonr's message
-        X, Y, K = self._fold_data(tr_rows)
         inner_abs = [(tr_rows[np.asarray(a, dtype=np.int64)], tr_rows[np.asarray(b, dtype=np.int64)])
                      for a, b in inner_rel]
-        scores, info = self._alpha_scores(K, Y, inner_abs)
-        return dict(tr=tr_rows, te=te_rows, X=X, Y=Y, K=K, scores=scores, info=info)
+        main = torch.cuda.current_stream()
+        self.aux.wait_event(self.ready)                # inputs (X, Y, K) were produced on the main stream
+        with torch.cuda.stream(self.aux):
+            X, Y, K = self._fold_data(tr_rows)
+            hat = self._hat_matrices(K, inner_abs)
+            done = torch.cuda.Event()
+            done.record()
+        for t in [X, Y, K, hat["tr"], hat["va"], hat["info"]] + [h for _, _, h in hat["Hs"]]:
+            if t is not None and t.is_cuda:
+                t.record_stream(main)                  # allocated on aux, consumed on main
+        return dict(tr=tr_rows, te=te_rows, X=X, Y=Y, K=K, hat=hat, done=done)
+
+    def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None):
+        st = prepared if prepared is not None else self.fold_prepare(tr_rows, te_rows, inner_rel)
+        torch.cuda.current_stream().wait_event(st["done"])
+        st["scores"] = self._sweeps(st["hat"], st["Y"])
+        st["info"] = st["hat"]["info"]
+        return st
 
     def fold_refit(self, st, single_alpha, weight_scale):
         tr_rows, te_rows, X, Y, K = st["tr"], st["te"], st["X"], st["Y"], st["K"]
@@ -482,8 +517,10 @@ class NestedCVModel(BasePredictivityModel):
             any_nan.append(bool(np.isnan(r32).any()))
 
         pending = None
-        for tr, te, inner in outer:
-            st = eng.fold_begin(tr, te, inner)
+        prepared = eng.fold_prepare(*outer[0])
+        for i in range(len(outer)):
+            st = eng.fold_begin(*outer[i], prepared=prepared)                      # main stream: the sweeps
+            prepared = eng.fold_prepare(*outer[i + 1]) if i + 1 < len(outer) else None   # aux stream, next fold
             if pending is not None:
                 tail(pending)
             pending = eng.fold_refit(st, single_alpha, scale)
