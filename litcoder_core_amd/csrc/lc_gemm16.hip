@@ -6,11 +6,13 @@
 // v_mfma_f32_32x32x16_f16 runs at 16x the rate of the f32-input MFMA, so three of them are ~5x faster
 // than one f32 MFMA step at fp32-level accuracy (measured against fp64: profiles/, tests).
 //
-// Operands are pre-tiled by the split kernels so that a K-tile of either operand is ONE contiguous
-// 32 KB chunk whose order is exactly the LDS image:  [plane hi|lo][k-group of 8][row or column 0..255][8 x f16].
+// Operands are pre-tiled by the split kernels so that a K-tile (16 k) of either operand is ONE contiguous
+// 16 KB chunk whose order is exactly the LDS image:  [plane hi|lo][k-group of 8][row or column 0..255][8 x f16].
 // A lane's MFMA fragment (8 consecutive k of one row / column) is then one conflict-free ds_read_b128.
 //
-// Tile 256 x 256 x 32, 512 threads = 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA blocks.
+// Tile 256 x 256 x 16, 512 threads = 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA blocks, four 32 KB LDS
+// stages filled by LDS-DMA three to four K-tiles ahead, and the two waves of every SIMD run half an iteration
+// apart (one reads fragments / issues DMA while the other issues MFMAs).
 #include "lc_common.h"
 
 namespace {
@@ -18,10 +20,12 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-constexpr int TM = 256, TN = 256, TK = 32;
-constexpr int CHUNK16 = 2 * 4 * 256;              // 16-byte units per (tile, K-tile) chunk = 32 KB
-constexpr int STAGE16 = 2 * CHUNK16;              // A chunk + B chunk
-constexpr int LDS16_BYTES = 2 * STAGE16 * 16;     // two stages = 128 KB
+constexpr int TM = 256, TN = 256, TK = 16;
+constexpr int KG = TK / 8;                        // 8-k groups per K-tile
+constexpr int CHUNK16 = 2 * KG * 256;             // 16-byte units per (tile, K-tile) chunk = 16 KB
+constexpr int STAGE16 = 2 * CHUNK16;              // A chunk + B chunk = 32 KB
+constexpr int NSTAGE = 4;                         // LDS ring
+constexpr int LDS16_BYTES = NSTAGE * STAGE16 * 16;   // 128 KB
 
 __device__ inline int xcd_tile_id16(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -69,9 +73,9 @@ __global__ void __launch_bounds__(256) k_split_rows_f16(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; lo[j] = (_Float16)0.f; }
         }
-        const long long o = tile_base + (long long)(c >> 2) * CHUNK16 + (c & 3) * 256 + rr;
+        const long long o = tile_base + (long long)(c / KG) * CHUNK16 + (c % KG) * 256 + rr;
         out[o] = *reinterpret_cast<uint4*>(&hi);
-        out[o + 4 * 256] = *reinterpret_cast<uint4*>(&lo);
+        out[o + KG * 256] = *reinterpret_cast<uint4*>(&lo);
     }
 }
 
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(512) k_col_scales(const float* __restrict__ y,
 __global__ void __launch_bounds__(256) k_split_cols_f16(const float* __restrict__ y, long long ldy, long long V,
                                                         const int* __restrict__ rows, int K, const float* __restrict__ cs,
                                                         uint4* __restrict__ out) {
-    const int nt = blockIdx.x, g = blockIdx.y;              // g = K-tile * 4 + k-group
+    const int nt = blockIdx.x, g = blockIdx.y;              // g = K-tile * KG + k-group
     const int col = threadIdx.x;
     const long long c = (long long)nt * 256 + col;
     const int KT = K / TK;
@@ -137,9 +141,9 @@ __global__ void __launch_bounds__(256) k_split_cols_f16(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; lo[j] = (_Float16)0.f; }
     }
-    const long long o = ((long long)nt * KT + (g >> 2)) * CHUNK16 + (g & 3) * 256 + col;
+    const long long o = ((long long)nt * KT + g / KG) * CHUNK16 + (g % KG) * 256 + col;
     out[o] = *reinterpret_cast<uint4*>(&hi);
-    out[o + 4 * 256] = *reinterpret_cast<uint4*>(&lo);
+    out[o + KG * 256] = *reinterpret_cast<uint4*>(&lo);
 }
 
 // ------------------------------------------------------------------ the fused sweep on fp16 x 3
@@ -175,7 +179,7 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
               Plain16Args pa) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds16[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform (scalar)
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -188,21 +192,41 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     const uint4* a_src = At + ((long long)grp * Mtiles + mt) * KT * CHUNK16 + tid;
     const uint4* b_src = Bt + (long long)nt * KT * CHUNK16 + tid;
 
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define LOAD16(kt_)                                                   \
-    {                                                                 \
-        const uint4* pa_ = a_src + (long long)(kt_) * CHUNK16;        \
-        const uint4* pb_ = b_src + (long long)(kt_) * CHUNK16;        \
-        ra0 = pa_[0]; ra1 = pa_[512]; ra2 = pa_[1024]; ra3 = pa_[1536]; \
-        rb0 = pb_[0]; rb1 = pb_[512]; rb2 = pb_[1024]; rb3 = pb_[1536]; \
+    // ---- main loop: two phases per K-tile, the two waves of every SIMD one phase apart --------------------
+    //   L_j: read the 12 fragments of tile j from LDS stage j&3, start the LDS-DMA of a later tile
+    //   C_j: 24 MFMAs on registers only
+    // with a block barrier after each phase.  Waves 4-7 (wm = 1, the second wave of each SIMD) take one extra
+    // barrier up front, so while group 0 is in C_j group 1 is in L_j and vice versa: every SIMD always has one
+    // wave issuing MFMAs, and the LDS reads / DMA issue of the other hide behind them.
+    // Operand chunks go global -> LDS directly (global_load_lds_dwordx4 through inline asm, so that hipcc does
+    // not drain the queue in front of every LDS read); thread t moves the 16-byte units t and t + 512 of each
+    // 16 KB chunk, a wave's 64 lanes land contiguously at its wave-uniform LDS base (M0).  Ring discipline:
+    //   tiles 0..3 are loaded in the prologue;
+    //   group 0 starts its share of tile j+3 -> stage (j+3)&3 during C_j (group 1 read that stage two phases
+    //   earlier);  group 1 starts its share of tile j+4 -> stage j&3 during its own C_j (both groups have read
+    //   it).  The DMA pieces are issued BETWEEN the MFMAs of phase C, where their issue cost hides.
+    //   Before the barrier that ends L_j every wave waits (counted vmcnt) until its share of tile j+1 has
+    //   landed: that barrier publishes it to the other group, the next one to itself.
+    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) uint4*)lds16);
+#define DMA16(gptr_, unit_)                                                                                   \
+    {                                                                                                         \
+        const unsigned m0_ = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((unit_) + (wave << 6)) * 16u); \
+        const uint4* gp_ = (gptr_);                                                                           \
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0_), "v"(gp_) : "memory");  \
     }
-#define STORE16(buf_)                                                 \
-    {                                                                 \
-        uint4* sa_ = lds16 + (buf_) * STAGE16 + tid;                  \
-        uint4* sb_ = sa_ + CHUNK16;                                   \
-        sa_[0] = ra0; sa_[512] = ra1; sa_[1024] = ra2; sa_[1536] = ra3; \
-        sb_[0] = rb0; sb_[512] = rb1; sb_[1024] = rb2; sb_[1536] = rb3; \
+#define GLDS16(kt_, stg_)                                                           \
+    {                                                                               \
+        const uint4* pa_ = a_src + (long long)(kt_) * CHUNK16;                      \
+        const uint4* pb_ = b_src + (long long)(kt_) * CHUNK16;                      \
+        DMA16(pa_, (stg_) * STAGE16);                                               \
+        DMA16(pa_ + 512, (stg_) * STAGE16 + 512);                                   \
+        DMA16(pb_, (stg_) * STAGE16 + CHUNK16);                                     \
+        DMA16(pb_ + 512, (stg_) * STAGE16 + CHUNK16 + 512);                         \
     }
+#define PHASE_BARRIER()                        \
+    __builtin_amdgcn_sched_barrier(0);         \
+    __builtin_amdgcn_s_barrier();              \
+    __builtin_amdgcn_sched_barrier(0)
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -212,47 +236,74 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    LOAD16(0);
-    STORE16(0);
-    __syncthreads();
+    for (int t = 0; t < NSTAGE && t < KT; ++t) GLDS16(t, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_BARRIER();
+    if (wm == 1) { PHASE_BARRIER(); }            // stagger: group 1 runs one phase behind group 0
 
-    // fragment addresses (16-byte units) inside a chunk: ((plane*4 + 2*s + lh) * 256 + row)
+    // fragment addresses (16-byte units) inside a stage: ((plane*KG + lh) * 256 + row)
     const int a_frag = lh * 256 + wm * 128 + li;
     const int b_frag = CHUNK16 + lh * 256 + wn * 64 + li;
 
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) LOAD16(kt + 1);
-        const uint4* st = lds16 + cur * STAGE16;
+        const uint4* st = lds16 + (kt & 3) * STAGE16;
+        // ---- phase L
+        h8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            h8 ah[4], al[4], bh[2], bl[2];
+        for (int mi = 0; mi < 4; ++mi) {
+            const uint4 v = st[a_frag + mi * 32];
+            const uint4 w = st[a_frag + KG * 256 + mi * 32];
+            ah[mi] = *reinterpret_cast<const h8*>(&v);
+            al[mi] = *reinterpret_cast<const h8*>(&w);
+        }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const uint4 v = st[a_frag + s * 512 + mi * 32];
-                const uint4 w = st[a_frag + 1024 + s * 512 + mi * 32];
-                ah[mi] = *reinterpret_cast<const h8*>(&v);
-                al[mi] = *reinterpret_cast<const h8*>(&w);
-            }
+        for (int ni = 0; ni < 2; ++ni) {
+            const uint4 v = st[b_frag + ni * 32];
+            const uint4 w = st[b_frag + KG * 256 + ni * 32];
+            bh[ni] = *reinterpret_cast<const h8*>(&v);
+            bl[ni] = *reinterpret_cast<const h8*>(&w);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // fragments are in registers
+        // publish point: this wave's share of tile kt+1 must have landed before the barrier below
+        // (group 0 issued it two C phases ago, group 1 three: one resp. two younger tiles may still fly)
+        const int issue_tile = wm == 0 ? kt + 3 : kt + 4;       // what this wave will start in C_kt
+        if (wm == 0) {
+            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PHASE_BARRIER();
+        // ---- phase C: 24 MFMAs; the four DMA pieces of a later tile are issued between them, where their
+        // issue cost hides behind the matrix pipe.  Target stage: (kt+3)&3 for group 0 (group 1 finished
+        // reading it one phase ago), kt&3 for group 1 (both groups have read it).
+        const bool do_dma = issue_tile < KT && (wm == 1 || kt >= 1);
+        const int stg = (wm == 0 ? kt + 3 : kt) & 3;
+        const uint4* pa_ = a_src + (long long)issue_tile * CHUNK16;
+        const uint4* pb_ = b_src + (long long)issue_tile * CHUNK16;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                const uint4 v = st[b_frag + s * 512 + ni * 32];
-                const uint4 w = st[b_frag + 1024 + s * 512 + ni * 32];
-                bh[ni] = *reinterpret_cast<const h8*>(&v);
-                bl[ni] = *reinterpret_cast<const h8*>(&w);
+                MFMA16(acc[mi][ni], al[mi], bh[ni]);      // small terms first
+                MFMA16(acc[mi][ni], ah[mi], bl[ni]);
+                MFMA16(acc[mi][ni], ah[mi], bh[ni]);
             }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    MFMA16(acc[mi][ni], al[mi], bh[ni]);      // small terms first
-                    MFMA16(acc[mi][ni], ah[mi], bl[ni]);
-                    MFMA16(acc[mi][ni], ah[mi], bh[ni]);
-                }
+            if (do_dma) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (mi == 0) DMA16(pa_, stg * STAGE16);
+                if (mi == 1) DMA16(pa_ + 512, stg * STAGE16 + 512);
+                if (mi == 2) DMA16(pb_, stg * STAGE16 + CHUNK16);
+                if (mi == 3) DMA16(pb_ + 512, stg * STAGE16 + CHUNK16 + 512);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (kt + 1 < KT) STORE16(cur ^ 1);
-        __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+        PHASE_BARRIER();
     }
+    if (wm == 0) { PHASE_BARRIER(); }            // group 0 pays its extra barrier at the end
 
     if (!SCORE) {
         // ---- plain epilogue: undo the power-of-two scales and store
