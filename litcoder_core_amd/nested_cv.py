@@ -229,7 +229,7 @@ class RidgeCVEngine:
         return ops.select_alpha(scores, self.A, self.Vp)[0]
 
     # -------------------------------------------------------------- refit (ridge_torch)
-    def refit(self, X, Y, K, tr_rows, best, extra_rows=()):
+    def refit(self, X, Y, K, tr_rows, best, extra_rows=(), tr_o=None, lmax_o=None):
         """Weights of every voxel at its chosen alpha, in alpha-sorted voxel order
         (ridge_regression.py:9-63).  Returns (Ws (p_pad, Vs), Ys (N_o + len(extra_rows), Vs), perm,
         N_o): column j of Ws / Ys is voxel perm[j] (-1 = padding).  ``extra_rows`` of Y are gathered
@@ -246,8 +246,9 @@ class RidgeCVEngine:
         Vs, G = tiles[-1] * tile, len(used)
         n_o = len(tr_rows)
         N_o = ops.pad_to(n_o, LC_NB)
-        tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
-        lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
+        if tr_o is None:
+            tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
+            lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
         a2_o = ops.penalties(lmax_o, 1, self.d_alphas[used], self.normalpha)
         rhs = torch.zeros((self.p_pad, N_o), dtype=torch.float64, device=self.dev)
         ops.transpose_rows(X, tr_o, N_o, self.p, rhs)
@@ -310,12 +311,16 @@ class RidgeCVEngine:
         with torch.cuda.stream(self.aux):
             X, Y, K = self._fold_data(tr_rows)
             hat = self._hat_matrices(K, inner_abs)
+            # S[0]^2 of the whole outer-train block (refit penalty scale): independent of the alpha choice
+            N_o = ops.pad_to(len(tr_rows), LC_NB)
+            tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
+            lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
             done = torch.cuda.Event()
             done.record()
-        for t in [X, Y, K, hat["tr"], hat["va"], hat["info"]] + [h for _, _, h in hat["Hs"]]:
+        for t in [X, Y, K, hat["tr"], hat["va"], hat["info"], tr_o, lmax_o] + [h for _, _, h in hat["Hs"]]:
             if t is not None and t.is_cuda:
                 t.record_stream(main)                  # allocated on aux, consumed on main
-        return dict(tr=tr_rows, te=te_rows, X=X, Y=Y, K=K, hat=hat, done=done)
+        return dict(tr=tr_rows, te=te_rows, X=X, Y=Y, K=K, hat=hat, done=done, tr_o=tr_o, lmax_o=lmax_o)
 
     def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None):
         st = prepared if prepared is not None else self.fold_prepare(tr_rows, te_rows, inner_rel)
@@ -328,7 +333,7 @@ class RidgeCVEngine:
         tr_rows, te_rows, X, Y, K = st["tr"], st["te"], st["X"], st["Y"], st["K"]
         n_t = len(te_rows)
         best = self.choose(st["scores"], single_alpha)
-        Ws, Ys, perm, N_o = self.refit(X, Y, K, tr_rows, best, te_rows)
+        Ws, Ys, perm, N_o = self.refit(X, Y, K, tr_rows, best, te_rows, st.get("tr_o"), st.get("lmax_o"))
         if int(st["info"].cpu().numpy().any()):
             raise RuntimeError("Cholesky failed: Gram matrix + alpha^2 I is not positive definite")
         Vs = Ws.shape[1]
