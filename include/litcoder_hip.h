@@ -78,6 +78,21 @@ int lc_lanczos_interp(const void* d_data, int dtype, int64_t n_old, int64_t D, i
                       double cutoff, double window, int rectify,
                       double* d_out, int64_t ld_out, lc_stream_t stream);
 
+/* sincinterp2D (downsample/interpdata.py:66-84) with sincfun (:29-42, array branch): same banded
+ * weighted-row-sum kernel as Lanczos with the sinc weight, optional causal mask and per-output-row
+ * renormalisation (weights / sum(weights) unless the sum is exactly 0). */
+int lc_sinc_interp(const void* d_data, int dtype, int64_t n_old, int64_t D, int64_t ld_in,
+                   const double* d_oldtime, const double* d_newtime, int64_t n_new,
+                   double cutoff, double window, int causal, int renorm,
+                   double* d_out, int64_t ld_out, lc_stream_t stream);
+
+/* The per-TR reducers (downsample/downsampling.py:24-136,180-319: rect, average, sum, last and the legacy_*
+ * chunk variants): out[s] = mean (0) | sum (1) | last (2) of rows d_idx[d_seg[s] .. d_seg[s+1]) of d_data,
+ * zero for an empty segment.  The host turns time windows / TR labels / split points into (d_seg, d_idx). */
+int lc_segment_reduce(const void* d_data, int dtype, int64_t D, int64_t ld_in, const int64_t* d_seg,
+                      const int32_t* d_idx, int64_t n_seg, int how, double* d_out, int64_t ld_out,
+                      lc_stream_t stream);
+
 /* ---------------------------------------------------------------- casts / gathers */
 
 /* torch.tensor(x, dtype=float32) (models/nested_cv.py:99-100): f64 -> f32, (rows, cols)

@@ -30,6 +30,9 @@ SIGNATURES = {
     "lc_fir_delay": (c_int, [_ptr, c_int, c_int64, c_int64, c_int64, POINTER(c_int64), c_int, c_int, _ptr, c_int64, _ptr]),
     "lc_lanczos_interp": (c_int, [_ptr, c_int, c_int64, c_int64, c_int64, _ptr, _ptr, c_int64, c_double, c_double,
                                   c_int, _ptr, c_int64, _ptr]),
+    "lc_sinc_interp": (c_int, [_ptr, c_int, c_int64, c_int64, c_int64, _ptr, _ptr, c_int64, c_double, c_double, c_int,
+                               c_int, _ptr, c_int64, _ptr]),
+    "lc_segment_reduce": (c_int, [_ptr, c_int, c_int64, c_int64, _ptr, _ptr, c_int64, c_int, _ptr, c_int64, _ptr]),
     "lc_cast_f64_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64, _ptr]),
     "lc_gather_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr]),
     "lc_scatter_axpy_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, c_float, _ptr, c_int64, _ptr]),

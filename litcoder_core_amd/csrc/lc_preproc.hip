@@ -45,29 +45,58 @@ constexpr int LZ_THREADS = 256;
 constexpr int LZ_CPT = 4;       // columns per thread, strided by LZ_THREADS -> coalesced rows
 constexpr int LZ_CHUNK = 1024;  // input samples per weight chunk
 
-template <typename T, bool RECTIFY>
+enum { WK_LANCZOS = 0, WK_SINC = 1 };
+
+// weight of one (output time, input sample) pair; t is the time difference, c the cutoff frequency
+template <int KIND>
+__device__ inline double interp_weight(double dt, double c, double window, int causal) {
+    constexpr double PI = 3.141592653589793;
+    if (KIND == WK_LANCZOS) {
+        // interpdata.py:59-63
+        const double t = dt * c;
+        if (t == 0.0) return 1.0;
+        if (fabs(t) > window) return 0.0;
+        return window * sin(PI * t) * sin(PI * t / window) / ((PI * PI) * (t * t));
+    } else {
+        // interpdata.py:31-36 (sincfun, array branch): 2B sin(2 pi B t) / (2 pi B t + 1e-20), windowed, causal
+        if (fabs(dt) > window / (2 * c)) return 0.0;
+        if (causal && dt < 0) return 0.0;
+        return 2 * c * sin(2 * PI * c * dt) / (2 * PI * c * dt + 1e-20);
+    }
+}
+
+template <typename T, bool RECTIFY, int KIND>
 __global__ void __launch_bounds__(LZ_THREADS) k_lanczos(const T* __restrict__ data, long long n_old, long long D,
                                                         long long ld_in, const double* __restrict__ oldtime,
                                                         const double* __restrict__ newtime, double cutoff,
-                                                        double window, double* __restrict__ out, long long ld_out) {
+                                                        double window, int causal, int renorm,
+                                                        double* __restrict__ out, long long ld_out) {
     __shared__ double w[LZ_CHUNK];
+    __shared__ double red[LZ_THREADS];
     const long long i = blockIdx.x;
     const long long cbase = (long long)blockIdx.y * (LZ_THREADS * LZ_CPT) + threadIdx.x;
     const double tn = newtime[i];
+    double scale = 1.0;
+    if (KIND == WK_SINC && renorm) {
+        // sincfun's ``val / np.sum(val)`` (skipped when the sum is exactly 0), interpdata.py:37-38
+        double s = 0.0;
+        for (long long j = threadIdx.x; j < n_old; j += LZ_THREADS) s += interp_weight<KIND>(tn - oldtime[j], cutoff, window, causal);
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int h = LZ_THREADS / 2; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (red[0] != 0.0) scale = 1.0 / red[0];
+        __syncthreads();
+    }
     double acc[LZ_CPT], accp[LZ_CPT];
 #pragma unroll
     for (int q = 0; q < LZ_CPT; ++q) { acc[q] = 0.0; accp[q] = 0.0; }
-    constexpr double PI = 3.141592653589793;
     for (long long j0 = 0; j0 < n_old; j0 += LZ_CHUNK) {
         const int len = (int)min((long long)LZ_CHUNK, n_old - j0);
-        for (int j = threadIdx.x; j < len; j += LZ_THREADS) {
-            const double t = (tn - oldtime[j0 + j]) * cutoff;
-            double v;
-            if (t == 0.0) v = 1.0;
-            else if (fabs(t) > window) v = 0.0;
-            else v = window * sin(PI * t) * sin(PI * t / window) / ((PI * PI) * (t * t));
-            w[j] = v;
-        }
+        for (int j = threadIdx.x; j < len; j += LZ_THREADS)
+            w[j] = interp_weight<KIND>(tn - oldtime[j0 + j], cutoff, window, causal) * scale;
         __syncthreads();
         for (int j = 0; j < len; ++j) {
             const double wj = w[j];
@@ -96,6 +125,31 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos(const T* __restrict__ da
             out[i * ld_out + c] = acc[q];
             if (RECTIFY) out[i * ld_out + D + c] = accp[q];
         }
+    }
+}
+
+// Per-TR reducers (downsampling.py:24-136,180-319): out[s] = mean | sum | last of the rows idx[seg[s] .. seg[s+1]),
+// zero for an empty segment.  One block row per segment, lanes across the feature axis.
+enum { SR_MEAN = 0, SR_SUM = 1, SR_LAST = 2 };
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_segment_reduce(const T* __restrict__ data, long long D, long long ld_in,
+                                                        const long long* __restrict__ seg, const int* __restrict__ idx,
+                                                        int how, double* __restrict__ out, long long ld_out) {
+    const long long s = blockIdx.x;
+    const long long lo = seg[s], hi = seg[s + 1];
+    const long long stride = (long long)gridDim.y * blockDim.x;
+    for (long long c = (long long)blockIdx.y * blockDim.x + threadIdx.x; c < D; c += stride) {
+        double acc = 0.0;
+        if (hi > lo) {
+            if (how == SR_LAST) {
+                acc = (double)data[(long long)idx[hi - 1] * ld_in + c];
+            } else {
+                for (long long e = lo; e < hi; ++e) acc += (double)data[(long long)idx[e] * ld_in + c];
+                if (how == SR_MEAN) acc /= (double)(hi - lo);
+            }
+        }
+        out[s * ld_out + c] = acc;
     }
 }
 
@@ -139,11 +193,51 @@ extern "C" int lc_lanczos_interp(const void* d_data, int dtype, int64_t n_old, i
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_LANCZOS, s);
     dim3 grid((unsigned)n_new, (unsigned)lc::ceil_div<long long>(D, LZ_THREADS * LZ_CPT));
-#define LC_LZ(T, R)                                                                                             \
-    hipLaunchKernelGGL((k_lanczos<T, R>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, n_old, D, ld_in, d_oldtime, \
-                       d_newtime, cutoff, window, d_out, ld_out)
+#define LC_LZ(T, R)                                                                                              \
+    hipLaunchKernelGGL((k_lanczos<T, R, WK_LANCZOS>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, n_old, D, ld_in, \
+                       d_oldtime, d_newtime, cutoff, window, 0, 0, d_out, ld_out)
     if (dtype == LC_F32) { if (rectify) LC_LZ(float, true); else LC_LZ(float, false); }
     else                 { if (rectify) LC_LZ(double, true); else LC_LZ(double, false); }
 #undef LC_LZ
     return lc::launched("k_lanczos");
+}
+
+extern "C" int lc_sinc_interp(const void* d_data, int dtype, int64_t n_old, int64_t D, int64_t ld_in,
+                              const double* d_oldtime, const double* d_newtime, int64_t n_new, double cutoff,
+                              double window, int causal, int renorm, double* d_out, int64_t ld_out,
+                              lc_stream_t stream) {
+    LC_REQUIRE(d_data && d_oldtime && d_newtime && d_out, LC_E_BADARG, "lc_sinc_interp: null pointer");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, LC_E_BADARG, "lc_sinc_interp: dtype %d unsupported", dtype);
+    LC_REQUIRE(n_old >= 0 && D >= 0 && n_new >= 0 && ld_in >= D && ld_out >= D, LC_E_SHAPE, "lc_sinc_interp: bad shape");
+    if (n_new == 0 || D == 0) return LC_OK;
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_LANCZOS, s);
+    dim3 grid((unsigned)n_new, (unsigned)lc::ceil_div<long long>(D, LZ_THREADS * LZ_CPT));
+    if (dtype == LC_F32)
+        hipLaunchKernelGGL((k_lanczos<float, false, WK_SINC>), grid, dim3(LZ_THREADS), 0, s, (const float*)d_data, n_old, D,
+                           ld_in, d_oldtime, d_newtime, cutoff, window, causal, renorm, d_out, ld_out);
+    else
+        hipLaunchKernelGGL((k_lanczos<double, false, WK_SINC>), grid, dim3(LZ_THREADS), 0, s, (const double*)d_data, n_old,
+                           D, ld_in, d_oldtime, d_newtime, cutoff, window, causal, renorm, d_out, ld_out);
+    return lc::launched("k_lanczos<sinc>");
+}
+
+extern "C" int lc_segment_reduce(const void* d_data, int dtype, int64_t D, int64_t ld_in, const int64_t* d_seg,
+                                 const int32_t* d_idx, int64_t n_seg, int how, double* d_out, int64_t ld_out,
+                                 lc_stream_t stream) {
+    LC_REQUIRE(d_data && d_seg && d_idx && d_out, LC_E_BADARG, "lc_segment_reduce: null pointer");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, LC_E_BADARG, "lc_segment_reduce: dtype %d unsupported", dtype);
+    LC_REQUIRE(how >= SR_MEAN && how <= SR_LAST, LC_E_BADARG, "lc_segment_reduce: how must be 0 (mean), 1 (sum), 2 (last)");
+    LC_REQUIRE(D >= 0 && n_seg >= 0 && ld_in >= D && ld_out >= D, LC_E_SHAPE, "lc_segment_reduce: bad shape");
+    if (n_seg == 0 || D == 0) return LC_OK;
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_LANCZOS, s);
+    dim3 grid((unsigned)n_seg, (unsigned)lc::imin(lc::ceil_div<long long>(D, 256), 64));
+    if (dtype == LC_F32)
+        hipLaunchKernelGGL(k_segment_reduce<float>, grid, dim3(256), 0, s, (const float*)d_data, (long long)D,
+                           (long long)ld_in, (const long long*)d_seg, d_idx, how, d_out, (long long)ld_out);
+    else
+        hipLaunchKernelGGL(k_segment_reduce<double>, grid, dim3(256), 0, s, (const double*)d_data, (long long)D,
+                           (long long)ld_in, (const long long*)d_seg, d_idx, how, d_out, (long long)ld_out);
+    return lc::launched("k_segment_reduce");
 }

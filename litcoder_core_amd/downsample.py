@@ -1,10 +1,10 @@
 """Downsampler front-end with the reference's interface (``downsampling.py:322-445``).
 
-``lanczos`` -- the method every shipped LITcoder config uses -- runs on the MI355X
-(``lc_lanczos_interp``: weights evaluated on the fly in fp64, banded weighted row sums).
-The per-TR reducers (rect/average/sum/last/legacy_*) and sinc/gabor are not on the hot path
-(SURVEY.md section 2, rows 6-7): they are short numpy routines on the host here, kept so the
-class is a complete drop-in for ``AbstractTrainer(downsampler=...)``.
+``lanczos`` -- the method every shipped LITcoder config uses -- and ``sinc`` run on the MI355X as banded
+weighted row sums with the weights evaluated on the fly in fp64 (``lc_lanczos_interp`` / ``lc_sinc_interp``);
+the per-TR reducers (rect / average / sum / last / legacy_*) are one segment-reduction kernel
+(``lc_segment_reduce``) fed with row-index lists the host derives from time windows, TR labels or split points.
+Only ``gabor`` (never used by a shipped config) stays a short numpy routine.
 """
 from typing import List
 
@@ -14,35 +14,64 @@ import torch
 from . import ops
 
 
-def _lanczos(data, data_times, tr_times, window=3, cutoff_mult=1.0, rectify=False):
-    """interpdata.py:87-126.  cutoff = 1/mean(diff(newtime))*cutoff_mult (:107)."""
+def _to_device(data, dev):
+    """Sample matrix on the device: float32 stays float32, every other real dtype is widened to float64 (the
+    reference's numpy arithmetic promotes to float64 as well)."""
     data = np.asarray(data)
+    if data.dtype == np.float32:
+        return torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+    return torch.from_numpy(np.ascontiguousarray(data, dtype=np.float64)).to(dev)
+
+
+def _times(data, data_times, tr_times):
     newtime = np.ascontiguousarray(tr_times, dtype=np.float64)
     oldtime = np.ascontiguousarray(data_times, dtype=np.float64)
-    if len(oldtime) != data.shape[0]:
-        raise ValueError(f"shapes {(len(newtime), len(oldtime))} and {data.shape} not aligned")
+    if len(oldtime) != np.shape(data)[0]:
+        raise ValueError(f"shapes {(len(newtime), len(oldtime))} and {np.shape(data)} not aligned")
+    return oldtime, newtime
+
+
+def _lanczos(data, data_times, tr_times, window=3, cutoff_mult=1.0, rectify=False):
+    """interpdata.py:87-126.  cutoff = 1/mean(diff(newtime))*cutoff_mult (:107)."""
+    oldtime, newtime = _times(data, data_times, tr_times)
     cutoff = 1 / np.mean(np.diff(newtime)) * cutoff_mult
     dev = ops.device()
-    if data.dtype == np.float32:
-        d = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
-    else:
-        d = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float64)).to(dev)
-    out = ops.lanczos_interp(d, torch.from_numpy(oldtime).to(dev), torch.from_numpy(newtime).to(dev),
+    out = ops.lanczos_interp(_to_device(data, dev), torch.from_numpy(oldtime).to(dev), torch.from_numpy(newtime).to(dev),
                              cutoff, window, rectify)
     return out.cpu().numpy()
 
 
+def _sinc(data, data_times, tr_times, window=1, cutoff_mult=1.0, causal=False, renorm=True):
+    """interpdata.py:29-42,66-84."""
+    oldtime, newtime = _times(data, data_times, tr_times)
+    cutoff = 1 / np.mean(np.diff(newtime)) * cutoff_mult
+    dev = ops.device()
+    out = ops.sinc_interp(_to_device(data, dev), torch.from_numpy(oldtime).to(dev), torch.from_numpy(newtime).to(dev),
+                          cutoff, window, causal, renorm)
+    return out.cpu().numpy()
+
+
+_HOW = {"average": 0, "sum": 1, "last": 2}
+
+
+def _segments(data, groups, how):
+    """``groups`` = list of row-index arrays, one per output row -> device segment reduction."""
+    dev = ops.device()
+    sizes = np.array([len(g) for g in groups], dtype=np.int64)
+    seg = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    idx = (np.concatenate(groups) if len(groups) and seg[-1] else np.zeros(0)).astype(np.int32)
+    if idx.size == 0:
+        idx = np.zeros(1, dtype=np.int32)
+    out = ops.segment_reduce(_to_device(data, dev), torch.from_numpy(seg).to(dev), torch.from_numpy(idx).to(dev), how)
+    return out.cpu().numpy()
+
+
 def _rect(data, data_times, tr_times):
-    out = np.zeros((len(tr_times), data.shape[1]))
+    """downsampling.py:31-39: mean of the samples in [t - TR/2, t + TR/2)."""
+    data_times = np.asarray(data_times)
     half = np.mean(np.diff(tr_times)) / 2
-    for i, t in enumerate(tr_times):
-        sel = (data_times >= t - half) & (data_times < t + half)
-        if np.any(sel):
-            out[i] = np.mean(data[sel], axis=0)
-    return out
-
-
-_REDUCERS = {"average": lambda a: np.mean(a, axis=0), "sum": lambda a: np.sum(a, axis=0), "last": lambda a: a[-1]}
+    groups = [np.nonzero((data_times >= t - half) & (data_times < t + half))[0] for t in tr_times]
+    return _segments(data, groups, _HOW["average"])
 
 
 def _by_label(how, what):
@@ -50,12 +79,11 @@ def _by_label(how, what):
         if split_indices is None:
             raise ValueError(f"split_indices must be provided for {what} downsampling")
         lab = np.asarray(split_indices)
-        out = np.zeros((int(max(split_indices)) + 1, data.shape[1]))
-        for tr in range(out.shape[0]):
-            idx = np.nonzero(lab == tr)[0]
-            if idx.size:
-                out[tr] = _REDUCERS[how](data[idx])
-        return out
+        n_trs = int(max(split_indices)) + 1
+        order = np.argsort(lab, kind="stable")
+        bounds = np.searchsorted(lab[order], np.arange(n_trs + 1))
+        groups = [order[bounds[i]:bounds[i + 1]] for i in range(n_trs)]
+        return _segments(data, groups, _HOW[how])
     return run
 
 
@@ -63,28 +91,9 @@ def _by_chunks(how):
     def run(data, data_times=None, tr_times=None, split_indices=None):
         if split_indices is None:
             raise ValueError("split_indices must be provided for Legacy downsampling")
-        out = np.zeros((len(split_indices) + 1, data.shape[1]))
-        for ci, chunk in enumerate(np.split(data, split_indices)):
-            if len(chunk):
-                out[ci] = _REDUCERS[how](chunk)
-        return out
+        groups = np.split(np.arange(np.shape(data)[0]), split_indices)
+        return _segments(data, groups, _HOW[how])
     return run
-
-
-def _sinc(data, data_times, tr_times, window=1, cutoff_mult=1.0, causal=False, renorm=True):
-    """interpdata.py:29-42,66-84."""
-    B = 1 / np.mean(np.diff(tr_times)) * cutoff_mult
-    rows = []
-    for tn in tr_times:
-        t = tn - np.asarray(data_times, dtype=np.float64)
-        v = 2 * B * np.sin(2 * np.pi * B * t) / (2 * np.pi * B * t + 1e-20)
-        v[np.abs(t) > window / (2 * B)] = 0
-        if causal:
-            v[t < 0] = 0
-        if not np.sum(v) == 0.0 and renorm:
-            v = v / np.sum(v)
-        rows.append(v)
-    return np.dot(np.stack(rows), data)
 
 
 def _gabor(data, data_times, tr_times, freqs, sigma):

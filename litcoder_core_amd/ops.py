@@ -94,6 +94,28 @@ def lanczos_interp(data, oldtime, newtime, cutoff, window, rectify):
     return out
 
 
+def sinc_interp(data, oldtime, newtime, cutoff, window, causal, renorm):
+    dt = LC_F32 if data.dtype == torch.float32 else LC_F64
+    _need(data, torch.float32 if dt == LC_F32 else torch.float64, "sinc_interp")
+    n_old, D = data.shape
+    n_new = newtime.numel()
+    out = torch.empty((n_new, D), dtype=torch.float64, device=data.device)
+    _lib.call("lc_sinc_interp", _p(data), dt, n_old, D, D, _p(oldtime), _p(newtime), n_new, float(cutoff),
+              float(window), int(bool(causal)), int(bool(renorm)), _p(out), D, _s())
+    return out
+
+
+def segment_reduce(data, seg, idx, how):
+    """data (n, D) f32|f64; seg (n_seg+1) int64 offsets into idx (int32 row numbers); how: 0 mean, 1 sum, 2 last."""
+    dt = LC_F32 if data.dtype == torch.float32 else LC_F64
+    _need(data, torch.float32 if dt == LC_F32 else torch.float64, "segment_reduce")
+    n_seg = seg.numel() - 1
+    D = data.shape[1]
+    out = torch.empty((n_seg, D), dtype=torch.float64, device=data.device)
+    _lib.call("lc_segment_reduce", _p(data), dt, D, D, _p(seg), _p(idx), n_seg, int(how), _p(out), D, _s())
+    return out
+
+
 # ------------------------------------------------------------------ casts / gathers
 def upload_f32(host, ld, dev, rows_pad=None, chunk_bytes=1 << 28):
     """Host (rows, cols) real array -> zero-padded (rows_pad or rows, ld) f32 device buffer.

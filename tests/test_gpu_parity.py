@@ -87,6 +87,27 @@ def test_lanczos_story_size_vs_oracle(lc):
     np.testing.assert_allclose(out_p, out, rtol=0, atol=1e-12)
 
 
+def test_other_downsamplers_golden(lc, golden_dir):
+    """rect / average / sum / last / legacy_* (segment-reduction kernel) and sinc against the reference's outputs."""
+    g = load(golden_dir, "downsample.npz")
+    ds = lc.Downsampler()
+    d, ot, nt = g["data"], g["oldtime"], g["newtime"]
+    np.testing.assert_allclose(ds.downsample(d, ot, nt), g["rect"], rtol=0, atol=1e-14)
+    for m in ("average", "sum", "last"):
+        np.testing.assert_allclose(ds.downsample(d, ot, nt, method=m, split_indices=list(g["labels"])), g[m],
+                                   rtol=0, atol=1e-13, err_msg=m)
+        np.testing.assert_allclose(ds.downsample(d, ot, nt, method="legacy_" + m, split_indices=g["bounds"]),
+                                   g["legacy_" + m], rtol=0, atol=1e-13, err_msg="legacy_" + m)
+    np.testing.assert_allclose(ds.downsample(d, ot, nt, method="sinc", window=3, cutoff_mult=1.0), g["sinc_w3"],
+                               rtol=0, atol=1e-12)
+    out32 = ds.downsample(g["data_f32"], ot, nt, method="average", split_indices=list(g["labels"]))
+    assert out32.dtype == np.float64
+    np.testing.assert_allclose(out32, g["average"], rtol=0, atol=1e-6)
+    from oracle.lanczos import sinc_interp
+    np.testing.assert_allclose(ds.downsample(d, ot, nt, method="sinc", window=2, cutoff_mult=0.7, causal=True, renorm=False),
+                               sinc_interp(d, ot, nt, 0.7, 2, True, False), rtol=0, atol=1e-12)
+
+
 # ------------------------------------------------------------------ per-voxel statistics kernels
 def test_pearson_r_and_pvalues_vs_scipy(lc):
     from scipy.stats import pearsonr
