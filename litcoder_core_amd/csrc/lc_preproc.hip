@@ -38,11 +38,7 @@ __global__ void __launch_bounds__(256) k_fir_delay(const T* __restrict__ stim, l
     out[r * ld_out + col0 + e] = v;
 }
 
-// One block per output time point and 1024-column slab.  Weights of a chunk of input
-// samples are evaluated once into LDS (fp64 sin), then every thread streams its columns
-// down the chunk, skipping samples outside the window (weight exactly 0).
 constexpr int LZ_THREADS = 256;
-constexpr int LZ_CPT = 4;       // columns per thread, strided by LZ_THREADS -> coalesced rows
 constexpr int LZ_CHUNK = 1024;  // input samples per weight chunk
 
 enum { WK_LANCZOS = 0, WK_SINC = 1 };
@@ -65,6 +61,10 @@ __device__ inline double interp_weight(double dt, double c, double window, int c
     }
 }
 
+// One block per (output time point, 256-column slab).  Pass 1: every thread evaluates the weights of its
+// input samples (fp64 sin) and the non-zero ones are compacted, in increasing sample order, into an LDS list
+// (ballot + prefix: deterministic).  Pass 2: each thread streams its column down that short list -- for a
+// Lanczos window of 3 lobes only ~60 of the 2500 samples of a story carry weight.
 template <typename T, bool RECTIFY, int KIND>
 __global__ void __launch_bounds__(LZ_THREADS) k_lanczos(const T* __restrict__ data, long long n_old, long long D,
                                                         long long ld_in, const double* __restrict__ oldtime,
@@ -72,9 +72,12 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos(const T* __restrict__ da
                                                         double window, int causal, int renorm,
                                                         double* __restrict__ out, long long ld_out) {
     __shared__ double w[LZ_CHUNK];
+    __shared__ int wj[LZ_CHUNK];
     __shared__ double red[LZ_THREADS];
+    __shared__ int wave_cnt[LZ_THREADS / 64];
     const long long i = blockIdx.x;
-    const long long cbase = (long long)blockIdx.y * (LZ_THREADS * LZ_CPT) + threadIdx.x;
+    const long long c = (long long)blockIdx.y * LZ_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double tn = newtime[i];
     double scale = 1.0;
     if (KIND == WK_SINC && renorm) {
@@ -90,41 +93,50 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos(const T* __restrict__ da
         if (red[0] != 0.0) scale = 1.0 / red[0];
         __syncthreads();
     }
-    double acc[LZ_CPT], accp[LZ_CPT];
-#pragma unroll
-    for (int q = 0; q < LZ_CPT; ++q) { acc[q] = 0.0; accp[q] = 0.0; }
-    for (long long j0 = 0; j0 < n_old; j0 += LZ_CHUNK) {
-        const int len = (int)min((long long)LZ_CHUNK, n_old - j0);
-        for (int j = threadIdx.x; j < len; j += LZ_THREADS)
-            w[j] = interp_weight<KIND>(tn - oldtime[j0 + j], cutoff, window, causal) * scale;
+    double acc = 0.0, accp = 0.0;
+    int fill = 0;                                   // entries in the LDS list (block-uniform)
+    for (long long j0 = 0; j0 < n_old || fill > 0; j0 += LZ_THREADS) {
+        // ---- pass 1 on samples j0 .. j0+255: weight, then ordered compaction
+        const long long j = j0 + threadIdx.x;
+        double wt = 0.0;
+        if (j < n_old) wt = interp_weight<KIND>(tn - oldtime[j], cutoff, window, causal) * scale;
+        const unsigned long long m = __ballot(wt != 0.0);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
         __syncthreads();
-        for (int j = 0; j < len; ++j) {
-            const double wj = w[j];
-            if (wj == 0.0) continue;   // uniform across the block
-            const T* row = data + (j0 + j) * ld_in;
+        int base = fill, total = 0;
 #pragma unroll
-            for (int q = 0; q < LZ_CPT; ++q) {
-                const long long c = cbase + (long long)q * LZ_THREADS;
-                if (c < D) {
-                    const double x = (double)row[c];
+        for (int q = 0; q < LZ_THREADS / 64; ++q) {
+            if (q < wave) base += wave_cnt[q];
+            total += wave_cnt[q];
+        }
+        if (wt != 0.0) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            w[pos] = wt;
+            wj[pos] = (int)j;
+        }
+        fill += total;
+        __syncthreads();
+        // ---- pass 2 whenever the list could overflow on the next round, or at the end
+        const bool last = j0 + LZ_THREADS >= n_old;
+        if (fill > LZ_CHUNK - LZ_THREADS || last) {
+            if (c < D)
+                for (int e = 0; e < fill; ++e) {
+                    const double x = (double)data[(long long)wj[e] * ld_in + c];
                     if (RECTIFY) {
-                        acc[q] += wj * fmin(x, 0.0);
-                        accp[q] += wj * fmax(x, 0.0);
+                        acc += w[e] * fmin(x, 0.0);
+                        accp += w[e] * fmax(x, 0.0);
                     } else {
-                        acc[q] += wj * x;
+                        acc += w[e] * x;
                     }
                 }
-            }
+            fill = 0;
+            __syncthreads();
+            if (last) break;
         }
-        __syncthreads();
     }
-#pragma unroll
-    for (int q = 0; q < LZ_CPT; ++q) {
-        const long long c = cbase + (long long)q * LZ_THREADS;
-        if (c < D) {
-            out[i * ld_out + c] = acc[q];
-            if (RECTIFY) out[i * ld_out + D + c] = accp[q];
-        }
+    if (c < D) {
+        out[i * ld_out + c] = acc;
+        if (RECTIFY) out[i * ld_out + D + c] = accp;
     }
 }
 
@@ -192,7 +204,7 @@ extern "C" int lc_lanczos_interp(const void* d_data, int dtype, int64_t n_old, i
     if (n_new == 0 || D == 0) return LC_OK;
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_LANCZOS, s);
-    dim3 grid((unsigned)n_new, (unsigned)lc::ceil_div<long long>(D, LZ_THREADS * LZ_CPT));
+    dim3 grid((unsigned)n_new, (unsigned)lc::ceil_div<long long>(D, LZ_THREADS));
 #define LC_LZ(T, R)                                                                                              \
     hipLaunchKernelGGL((k_lanczos<T, R, WK_LANCZOS>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, n_old, D, ld_in, \
                        d_oldtime, d_newtime, cutoff, window, 0, 0, d_out, ld_out)
@@ -212,7 +224,7 @@ extern "C" int lc_sinc_interp(const void* d_data, int dtype, int64_t n_old, int6
     if (n_new == 0 || D == 0) return LC_OK;
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_LANCZOS, s);
-    dim3 grid((unsigned)n_new, (unsigned)lc::ceil_div<long long>(D, LZ_THREADS * LZ_CPT));
+    dim3 grid((unsigned)n_new, (unsigned)lc::ceil_div<long long>(D, LZ_THREADS));
     if (dtype == LC_F32)
         hipLaunchKernelGGL((k_lanczos<float, false, WK_SINC>), grid, dim3(LZ_THREADS), 0, s, (const float*)d_data, n_old, D,
                            ld_in, d_oldtime, d_newtime, cutoff, window, causal, renorm, d_out, ld_out);

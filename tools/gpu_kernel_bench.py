@@ -15,7 +15,7 @@ from litcoder_core_amd import ops  # noqa: E402
 from litcoder_core_amd._lib import LC_MB, LC_NB, LC_SCORE_CORR  # noqa: E402
 
 dev = ops.device()
-what = set(sys.argv[1:]) or {"sweep", "lanczos", "chol"}
+what = set(sys.argv[1:]) or {"sweep", "sweep16", "lanczos", "chol", "hbm"}
 
 
 def timeit(fn, reps=5, warm=2):
@@ -134,3 +134,43 @@ if "chol" in what:
     ms = timeit(run, reps=2, warm=1)
     fl = F * A * (N ** 3 / 3 + 2.0 * N * N * M)
     print(f"assemble + batch_chol_solve B={F * A} N={N} M={M}: {ms:.1f} ms -> {fl / ms / 1e9:.1f} TFLOP/s fp64")
+
+if "hbm" in what:
+    # HBM-bound kernels: algorithmic bytes / time against the 8 TB/s datasheet rate (6.3 TB/s achievable copy)
+    rng = np.random.default_rng(3)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    def report(name, nbytes, ms):
+        print(f"{name}: {ms * 1e3:.1f} us, {nbytes / 1e6:.1f} MB algorithmic -> {nbytes / ms / 1e6:.0f} GB/s "
+              f"({nbytes / ms / 1e6 / 8000:.2f} of 8 TB/s)")
+    # FIR: one LeBel story (350 TRs) and the concatenated design (3000 rows), 768 features x 4 delays, f64
+    for nt in (350, 3000):
+        x = torch.randn((nt, 768), generator=g, device=dev, dtype=torch.float64)
+        ms = timeit(lambda: ops.fir_delay(x, [1, 2, 3, 4], False), reps=20)
+        report(f"fir_delay {nt}x768x4 f64", nt * 768 * (8 + 4 * 8), ms)
+    # Lanczos: 2500 words x 768 -> 350 TRs (LeBel story), speech 7000 x 1280 -> 350
+    for (n_old, D) in ((2500, 768), (7000, 1280)):
+        ot = torch.from_numpy(np.sort(rng.uniform(0, 700, n_old))).to(dev)
+        nt_ = torch.from_numpy(1.0 + 2.0 * np.arange(350)).to(dev)
+        d = torch.randn((n_old, D), generator=g, device=dev, dtype=torch.float64)
+        ms = timeit(lambda: ops.lanczos_interp(d, ot, nt_, 0.5, 3, False), reps=20)
+        report(f"lanczos {n_old}x{D}->350 f64", n_old * D * 8 + 350 * D * 8, ms)
+    # Pearson r + p over 80000 voxels, 600 test rows
+    a = torch.randn((600, 80000), generator=g, device=dev, dtype=torch.float32)
+    b = a * 0.3 + torch.randn((600, 80000), generator=g, device=dev, dtype=torch.float32)
+    ms = timeit(lambda: ops.pearson_cols(a, b, 600, 80000), reps=10)
+    report("pearson_cols 600x80000 f32", 2 * 600 * 80000 * 4, ms)
+    r = ops.pearson_cols(a, b, 600, 80000)
+    ms = timeit(lambda: ops.pearson_pvalues(r, 80000, 600), reps=10)
+    print(f"pearson_pvalues 80000 voxels: {ms * 1e3:.1f} us")
+    # validation-target statistics and the alpha-sorted gather
+    Y = torch.randn((3000, 80000), generator=g, device=dev, dtype=torch.float32)
+    va = ops.idx_tensor(np.r_[1920:2400], 480, dev)
+    ystat = torch.empty((3, 80000), dtype=torch.float32, device=dev)
+    yblk = torch.empty((15, 80000), dtype=torch.float32, device=dev)
+    ms = timeit(lambda: ops.val_stats(Y, 80000, va, 480, 480, ystat, yblk), reps=10)
+    report("val_stats 480x80000 f32", 480 * 80000 * 4, ms)
+    perm = torch.randperm(80000, generator=g, device=dev).to(torch.int32)
+    rows = ops.idx_tensor(np.r_[0:3000], 3000, dev)
+    out = torch.empty((3000, 80000), dtype=torch.float32, device=dev)
+    ms = timeit(lambda: ops.gather(Y, 80000, rows, 3000, perm, 80000, out), reps=5)
+    report("gather (alpha-sorted copy) 3000x80000 f32", 2 * 3000 * 80000 * 4, ms)
