@@ -195,9 +195,10 @@ int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_tr, in
 
 /* Column statistics of the validation targets of one inner fold, feeding the fused scorer:
  * d_ystat (3, V) f32 = [mean, unbiased std, unbiased var] of Y[va_rows] (z_score / .var,
- * ridge_regression.py:108,111); d_yblk (M/LC_MB, V) f32 = per-32-row-block sums of (y - mean). */
+ * ridge_regression.py:108,111); d_yblk (M/LC_MB, V) f32 = per-32-row-block sums of (y - mean);
+ * d_yv (M, V) f32 = the validation rows gathered contiguously (zero padding rows) for the sweep epilogue. */
 int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int M, int n_val,
-                 float* d_ystat, float* d_yblk, lc_stream_t stream);
+                 float* d_ystat, float* d_yblk, float* d_yv, lc_stream_t stream);
 
 /* Fused alpha sweep of one inner fold (ridge_regression.py:115-133, K4+K5 of SURVEY 2.2):
  *   pred_a = H_a (M x N) . Y[tr_rows] (N x V)    for a = 0..A-1, never stored;
@@ -206,7 +207,7 @@ int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, 
  * d_h (A*M, N) f32 hat matrices (row stride N); d_part workspace (A*M/LC_MB, 4, V) f32. */
 int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N,
                           const float* d_y, int64_t ldy, int64_t V,
-                          const int32_t* d_tr, const int32_t* d_va, int n_val,
+                          const int32_t* d_tr, const float* d_yv, int n_val,
                           const float* d_ystat, const float* d_yblk, int mode,
                           float* d_part, float* d_scores, int accumulate, lc_stream_t stream);
 
@@ -233,9 +234,17 @@ int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const int32_t* d
 
 int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
                                 const void* d_yt, const float* d_cscale_inv,
-                                const float* d_y, int64_t ldy, int64_t V,
-                                const int32_t* d_va, int n_val, const float* d_ystat, const float* d_yblk,
+                                const float* d_yv, int64_t V, int n_val,
+                                const float* d_ystat, const float* d_yblk,
                                 int mode, float* d_part, float* d_scores, int accumulate, lc_stream_t stream);
+
+/* Diagnostics only (tools/gpu_kernel_bench.py stamps): the fp16x3 sweep with s_memtime stamps at its phase
+ * boundaries; d_stamps (16 x uint64, caller-zeroed) receives per wave-group sums of the five segments of an
+ * iteration.  Not used by the product path. */
+int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
+                            const void* d_yt, const float* d_cscale_inv, const float* d_yv,
+                            int64_t V, int n_val, const float* d_ystat, float* d_part,
+                            unsigned long long* d_stamps, lc_stream_t stream);
 
 /* Grouped GEMM of the refit (lc_gemm_grouped_f32's job) on the same fp16x3 scheme:
  * C[:, tile] = A_g(tile) . B[:, tile].  d_at: G tiled images made by lc_split_rows_f16 (one per group, each

@@ -12,6 +12,7 @@
 // ds_read_b32 -- the f32 MFMA is slow enough (64 cycles each) that LDS read width is irrelevant,
 // while shuffles in the staging path would force early waits on the prefetched global loads.
 #include "lc_common.h"
+#include "lc_epilogue.h"
 
 namespace {
 
@@ -30,9 +31,7 @@ struct GroupTiles {
 };
 
 struct ScoreArgs {
-    const float* y;        // targets (T, ldy)
-    long long ldy;
-    const int* va;         // validation rows (M entries, first n_val valid)
+    const float* yv;       // gathered validation targets (M, V), zero padding rows
     const float* ymean;    // (V)
     float* part;           // (rowblocks, 4, V)
     int M;                 // padded validation rows per alpha
@@ -199,49 +198,26 @@ k_gemm_f32(const float* __restrict__ A, long long lda, long long a_group_stride,
     }
 
     const long long V = ldc;   // score mode: ldc carries the padded voxel count
+    const bool corr = sa.mode == LC_SCORE_CORR;
+    const lc::ep_f32x4 no_scale[4] = {};
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int rb0 = m0 + wm * 64 + mi * 32;          // first row of this 32-row block
         if (rb0 >= Mrows) continue;
-        const int alpha = rb0 / sa.M;
-        const int i0 = rb0 - alpha * sa.M;               // offset inside the alpha's validation rows
-        const int nb = min(32, sa.n_val - i0);           // valid rows in the block (<= 0: padding only)
+        const int i0 = rb0 % sa.M;                       // offset inside the alpha's validation rows
+        lc::EpiTargets t[2];
+        float ym[2];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const long long col = n0 + wn * 64 + ni * 32 + li;
-            float p[16], yc[16];
-            const float ym = sa.ymean[col];
-            float s1 = 0.f;
+            lc::epi_load_targets(sa.yv, V, i0, lh, col, t[ni]);
+            ym[ni] = sa.ymean[col];
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const bool ok = il < sa.n_val;
-                const float yraw = ok ? sa.y[(long long)sa.va[il] * sa.ldy + col] : 0.f;
-                const float pv = acc[mi][ni][r];
-                yc[r] = ok ? yraw - ym : 0.f;
-                // corr: statistics of pred; R2: statistics of the residual fl32(y - pred), formed from
-                // the raw target exactly as ``(Presp - pred).var()`` does (ridge_regression.py:128)
-                p[r] = ok ? (sa.mode == LC_SCORE_CORR ? pv : yraw - pv) : 0.f;
-                s1 += p[r];
-            }
-            s1 += __shfl_xor(s1, 32);
-            const float mean_b = nb > 0 ? s1 / (float)nb : 0.f;
-            float m2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float d = il < sa.n_val ? p[r] - mean_b : 0.f;
-                m2 += d * d;
-                s3 += d * yc[r];
-            }
-            m2 += __shfl_xor(m2, 32);
-            s3 += __shfl_xor(s3, 32);
-            if (lh == 0) {
-                float* out = sa.part + (long long)(rb0 >> 5) * 4 * V + col;
-                out[0] = s1;
-                out[V] = m2;
-                out[2 * V] = s3;
-            }
+        for (int ni = 0; ni < 2; ++ni) {
+            const long long col = n0 + wn * 64 + ni * 32 + li;
+            lc::epi_block_dispatch<false>(corr, acc[mi][ni], t[ni], no_scale, 1.f, ym[ni], i0, sa.n_val, lh,
+                                          sa.part + (long long)(rb0 >> 5) * 4 * V + col, V, true);
         }
     }
 }
@@ -282,8 +258,23 @@ __global__ void __launch_bounds__(256) k_score_finalize(const float* __restrict_
         const double sy = (double)ystat[V + v];
         score = (float)(cov / ((double)n_val * (sy + 1e-8) * (sp + 1e-8)));
     } else {
+        // moments of the raw targets, formed and merged exactly like those of the residual (lc_epilogue.h)
+        double ny = 0.0, meany = 0.0, m2y = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            const int nb = min(LC_MB, n_val - b * LC_MB);
+            if (nb <= 0) break;
+            const double s1 = p0[(long long)b * 4 * V + 2 * V], q = p0[(long long)b * 4 * V + 3 * V];
+            const double mb = s1 / nb, nn = ny + nb, d = mb - meany;
+            m2y += q + d * d * ny * nb / nn;
+            meany += d * nb / nn;
+            ny = nn;
+        }
         const float resvar = (float)(m2 / (double)(n_val - 1));
-        const float rsq = 1.f - resvar / ystat[2 * V + v];
+        const float yvar_same = (float)(m2y / (double)(n_val - 1));
+        // residual statistically identical to the targets under identical arithmetic: the reference's two
+        // torch.var calls agree bit for bit as well and give Rsq = 0 (or 0/0 -> NaN -> 0 for constant targets)
+        const float yvar = ystat[2 * V + v];
+        const float rsq = resvar == yvar_same ? (yvar == 0.f ? __builtin_nanf("") : 0.f) : 1.f - resvar / yvar;
         const float sgn = rsq > 0.f ? 1.f : (rsq < 0.f ? -1.f : rsq);   // sign(NaN) = NaN, sign(0) = 0
         score = sqrtf(fabsf(rsq)) * sgn;
     }
@@ -329,10 +320,10 @@ int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const fl
 }
 
 extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, const float* d_y, int64_t ldy, int64_t V,
-                                     const int32_t* d_tr, const int32_t* d_va, int n_val, const float* d_ystat,
+                                     const int32_t* d_tr, const float* d_yv, int n_val, const float* d_ystat,
                                      const float* d_yblk, int mode, float* d_part, float* d_scores, int accumulate,
                                      lc_stream_t stream) {
-    LC_REQUIRE(d_h && d_y && d_tr && d_va && d_ystat && d_yblk && d_part && d_scores, LC_E_BADARG,
+    LC_REQUIRE(d_h && d_y && d_tr && d_yv && d_ystat && d_yblk && d_part && d_scores, LC_E_BADARG,
                "lc_alpha_sweep_scores: null pointer");
     LC_REQUIRE(A > 0 && M > 0 && M % LC_MB == 0 && n_val > 0 && n_val <= M, LC_E_SHAPE,
                "lc_alpha_sweep_scores: need M %% %d == 0 and 0 < n_val <= M", LC_MB);
@@ -349,7 +340,7 @@ extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, cons
     gt.G = 1;
     gt.start[0] = 0;
     gt.start[1] = (int)Ntiles;
-    ScoreArgs sa{d_y, (long long)ldy, d_va, d_ystat, d_part, M, n_val, mode};
+    ScoreArgs sa{d_yv, d_ystat, d_part, M, n_val, mode};
     {
         lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
         hipLaunchKernelGGL((k_gemm_f32<true, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(256), GEMM_LDS_BYTES, s, d_h,

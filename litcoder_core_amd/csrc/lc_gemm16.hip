@@ -14,6 +14,7 @@
 // stages filled by LDS-DMA three to four K-tiles ahead, and the two waves of every SIMD run half an iteration
 // apart (one reads fragments / issues DMA while the other issues MFMAs).
 #include "lc_common.h"
+#include "lc_epilogue.h"
 
 namespace {
 
@@ -148,9 +149,7 @@ __global__ void __launch_bounds__(256) k_split_cols_f16(const float* __restrict_
 
 // ------------------------------------------------------------------ the fused sweep on fp16 x 3
 struct Score16Args {
-    const float* y;        // raw targets (T, ldy) for the validation rows of the epilogue
-    long long ldy;
-    const int* va;
+    const float* yv;       // gathered validation targets (M, V), zero padding rows
     const float* ymean;
     const float* rs_inv;   // per H row: 2^e undoing the row pre-scale
     const float* cs_inv;   // per voxel: 2^e undoing the column pre-scale
@@ -173,7 +172,16 @@ struct Plain16Args {
 
 #define MFMA16(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
 
-template <bool SCORE>
+// STAMP builds (diagnostics only, lc_debug_sweep16_stamps): s_memtime at the phase boundaries, per-wave sums of
+// the five segments of an iteration added into pa.c (unsigned long long[2 groups][8]) -- results are not used.
+#define STAMP_T(var_)                                                                          \
+    if (STAMP) {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var_)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+
+template <bool SCORE, bool STAMP>
 __global__ void __launch_bounds__(512, 2)
 k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT, int Mtiles, Score16Args sa,
               Plain16Args pa) {
@@ -228,6 +236,8 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     __builtin_amdgcn_s_barrier();              \
     __builtin_amdgcn_sched_barrier(0)
 
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+    STAMP_T(tk0);
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -245,8 +255,12 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     const int a_frag = lh * 256 + wm * 128 + li;
     const int b_frag = CHUNK16 + lh * 256 + wn * 64 + li;
 
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    STAMP_T(tk1);
+    unsigned long long sum_read = 0, sum_wait = 0, sum_bar1 = 0, sum_mma = 0, sum_bar2 = 0;
     for (int kt = 0; kt < KT; ++kt) {
         const uint4* st = lds16 + (kt & 3) * STAGE16;
+        STAMP_T(t0);
         // ---- phase L
         h8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
@@ -264,6 +278,7 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
             bl[ni] = *reinterpret_cast<const h8*>(&w);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // fragments are in registers
+        STAMP_T(t1);
         // publish point: this wave's share of tile kt+1 must have landed before the barrier below
         // (group 0 issued it two C phases ago, group 1 three: one resp. two younger tiles may still fly)
         const int issue_tile = wm == 0 ? kt + 3 : kt + 4;       // what this wave will start in C_kt
@@ -274,7 +289,9 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
             if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        STAMP_T(t2);
         PHASE_BARRIER();
+        STAMP_T(t3);
         // ---- phase C: 24 MFMAs; the four DMA pieces of a later tile are issued between them, where their
         // issue cost hides behind the matrix pipe.  Target stage: (kt+3)&3 for group 0 (group 1 finished
         // reading it one phase ago), kt&3 for group 1 (both groups have read it).
@@ -301,7 +318,21 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        STAMP_T(t4);
         PHASE_BARRIER();
+        STAMP_T(t5);
+        if (STAMP) {
+            sum_read += t1 - t0; sum_wait += t2 - t1; sum_bar1 += t3 - t2; sum_mma += t4 - t3; sum_bar2 += t5 - t4;
+        }
+    }
+    STAMP_T(tk2);
+    if (STAMP) {
+        if (lane == 0) {
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(pa.c) + wm * 8;
+            atomicAdd(dbg + 6, tk1 - tk0);
+            atomicAdd(dbg + 0, sum_read); atomicAdd(dbg + 1, sum_wait); atomicAdd(dbg + 2, sum_bar1);
+            atomicAdd(dbg + 3, sum_mma); atomicAdd(dbg + 4, sum_bar2); atomicAdd(dbg + 5, (unsigned long long)KT);
+        }
     }
     if (wm == 0) { PHASE_BARRIER(); }            // group 0 pays its extra barrier at the end
 
@@ -324,55 +355,59 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         return;
     }
 
-    // ---- epilogue: identical statistics to lc_gemm.hip after undoing the power-of-two scales
+    // ---- epilogue: the statistics of lc_epilogue.h after undoing the power-of-two scales.  The loads of a
+    // 32-row block (row scales, the two column panels of gathered targets) are one batch, and the batch of
+    // block mi+1 is in flight while block mi is reduced.
     const long long V = sa.V;
+    const long long col0 = (long long)nt * TN + wn * 64 + li;
+    const bool cok[2] = {col0 < V, col0 + 32 < V};
+    const long long colc[2] = {cok[0] ? col0 : 0, cok[1] ? col0 + 32 : 0};       // clamped: loads stay in range
+    float ymv[2], cscv[2];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int ni = 0; ni < 2; ++ni) {
+        ymv[ni] = sa.ymean[colc[ni]];
+        cscv[ni] = sa.cs_inv[colc[ni]];
+    }
+    const bool corr = sa.mode == LC_SCORE_CORR;
+    struct RowScales {
+        lc::ep_f32x4 rs[4];
+    };
+    // step s = 2 mi + ni: the targets of step s+1 (and the row scales of block mi+1) are issued before step s
+    // is reduced; rows of the tile lie below rows_pad (rs_inv is that long) and yv rows are i0 < M
+    auto load_rs = [&](int mi, RowScales& r) {
         const int rb0 = mt * TM + wm * 128 + mi * 32;
-        if (rb0 >= sa.Mrows) continue;
-        const int alpha = rb0 / sa.M;
-        const int i0 = rb0 - alpha * sa.M;
-        const int nb = min(32, sa.n_val - i0);
-        float rsc[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rsc[r] = sa.rs_inv[rb0 + (r & 3) + 8 * (r >> 2) + 4 * lh];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const long long col = (long long)nt * TN + wn * 64 + ni * 32 + li;
-            if (col >= V) continue;
-            float p[16], yc[16];
-            const float ym = sa.ymean[col];
-            const float csc = sa.cs_inv[col];
-            float s1 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const bool ok = il < sa.n_val;
-                const float yraw = ok ? sa.y[(long long)sa.va[il] * sa.ldy + col] : 0.f;
-                const float pv = acc[mi][ni][r] * rsc[r] * csc;
-                yc[r] = ok ? yraw - ym : 0.f;
-                p[r] = ok ? (sa.mode == LC_SCORE_CORR ? pv : yraw - pv) : 0.f;
-                s1 += p[r];
-            }
-            s1 += __shfl_xor(s1, 32);
-            const float mean_b = nb > 0 ? s1 / (float)nb : 0.f;
-            float m2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = i0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float d = il < sa.n_val ? p[r] - mean_b : 0.f;
-                m2 += d * d;
-                s3 += d * yc[r];
-            }
-            m2 += __shfl_xor(m2, 32);
-            s3 += __shfl_xor(s3, 32);
-            if (lh == 0) {
-                float* out = sa.part + (long long)(rb0 >> 5) * 4 * V + col;
-                out[0] = s1;
-                out[V] = m2;
-                out[2 * V] = s3;
-            }
-        }
+        for (int q = 0; q < 4; ++q)
+            r.rs[q] = *reinterpret_cast<const lc::ep_f32x4*>(sa.rs_inv + rb0 + 8 * q + 4 * lh);
+    };
+    auto load_t = [&](int step, lc::EpiTargets& t) {
+        const int rb0 = mt * TM + wm * 128 + (step >> 1) * 32;
+        lc::epi_load_targets(sa.yv, V, rb0 % sa.M, lh, colc[step & 1], t);
+    };
+    auto reduce = [&](int step, const lc::EpiTargets& t, const RowScales& r) {
+        const int mi = step >> 1, ni = step & 1;
+        const int rb0 = mt * TM + wm * 128 + mi * 32;
+        if (rb0 >= sa.Mrows) return;
+        lc::epi_block_dispatch<true>(corr, acc[mi][ni], t, r.rs, cscv[ni], ymv[ni], rb0 % sa.M, sa.n_val, lh,
+                                     sa.part + (long long)(rb0 >> 5) * 4 * V + colc[ni], V, cok[ni]);
+    };
+#define EPI_FENCE() __builtin_amdgcn_sched_barrier(0)
+    lc::EpiTargets tA, tB;
+    RowScales rA, rB;
+    load_rs(0, rA); load_t(0, tA);
+    load_t(1, tB);                 EPI_FENCE(); reduce(0, tA, rA); EPI_FENCE();
+    load_rs(1, rB); load_t(2, tA); EPI_FENCE(); reduce(1, tB, rA); EPI_FENCE();
+    load_t(3, tB);                 EPI_FENCE(); reduce(2, tA, rB); EPI_FENCE();
+    load_rs(2, rA); load_t(4, tA); EPI_FENCE(); reduce(3, tB, rB); EPI_FENCE();
+    load_t(5, tB);                 EPI_FENCE(); reduce(4, tA, rA); EPI_FENCE();
+    load_rs(3, rB); load_t(6, tA); EPI_FENCE(); reduce(5, tB, rA); EPI_FENCE();
+    load_t(7, tB);                 EPI_FENCE(); reduce(6, tA, rB); EPI_FENCE();
+    reduce(7, tB, rB);
+#undef EPI_FENCE
+    if (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP_T(tk3);
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(pa.c) + wm * 8 + 7, tk3 - tk2);
     }
 }
 
@@ -416,19 +451,19 @@ extern "C" int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const
 }
 
 extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
-                                           const void* d_yt, const float* d_cscale_inv, const float* d_y, int64_t ldy,
-                                           int64_t V, const int32_t* d_va, int n_val, const float* d_ystat,
+                                           const void* d_yt, const float* d_cscale_inv, const float* d_yv,
+                                           int64_t V, int n_val, const float* d_ystat,
                                            const float* d_yblk, int mode, float* d_part, float* d_scores,
                                            int accumulate, lc_stream_t stream) {
-    LC_REQUIRE(d_ht && d_rowscale_inv && d_yt && d_cscale_inv && d_y && d_va && d_ystat && d_yblk && d_part && d_scores,
+    LC_REQUIRE(d_ht && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_part && d_scores,
                LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: null pointer");
     LC_REQUIRE(A > 0 && M > 0 && M % LC_MB == 0 && n_val > 0 && n_val <= M && N > 0 && N % TK == 0, LC_E_SHAPE,
                "lc_alpha_sweep_scores_f16x3: need M %% %d == 0, N %% %d == 0, 0 < n_val <= M", LC_MB, TK);
-    LC_REQUIRE(V > 0 && V % 128 == 0 && ldy >= V, LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: V must be a multiple of 128");
+    LC_REQUIRE(V > 0 && V % 128 == 0, LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: V must be a multiple of 128");
     LC_REQUIRE(mode == LC_SCORE_CORR || mode == LC_SCORE_R2, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: bad mode");
     static thread_local bool attr_done = false;
     if (!attr_done) {
-        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<true>),
+        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<true, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
         attr_done = true;
     }
@@ -437,12 +472,11 @@ extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rows
     const int Mtiles = lc::ceil_div(Mrows, TM);
     const long long Ntiles = lc::ceil_div<long long>(V, TN);
     LC_REQUIRE((long long)Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: grid too large");
-    Score16Args sa{d_y, (long long)ldy, d_va, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val,
-                   mode, Mrows};
+    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val, mode, Mrows};
     {
         lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
         Plain16Args pa{};
-        hipLaunchKernelGGL(k_sweep_f16x3<true>, dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
+        hipLaunchKernelGGL((k_sweep_f16x3<true, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
                            (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa);
     }
     if (int rc = lc::launched("k_sweep_f16x3")) return rc;
@@ -459,7 +493,7 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
                "lc_gemm_grouped_f16x3: need K %% %d == 0 and Ncols %% %d == 0", TK, TN);
     static thread_local bool attr_done = false;
     if (!attr_done) {
-        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<false>),
+        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<false, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
         attr_done = true;
     }
@@ -483,7 +517,27 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     Score16Args sa{};
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
-    hipLaunchKernelGGL(k_sweep_f16x3<false>, dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
+    hipLaunchKernelGGL((k_sweep_f16x3<false, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
                        (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa);
     return lc::launched("k_sweep_f16x3<plain>");
+}
+
+// Diagnostics: the score kernel with s_memtime stamps (not part of the product path; see tools/gpu_kernel_bench.py).
+// d_stamps: 16 x uint64, zeroed by the caller: [group][read, dma-wait, barrier1, mfma, barrier2, iterations, -, -].
+extern "C" int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N, const void* d_yt,
+                                       const float* d_cscale_inv, const float* d_yv, int64_t V, int n_val,
+                                       const float* d_ystat, float* d_part,
+                                       unsigned long long* d_stamps, lc_stream_t stream) {
+    LC_REQUIRE(d_ht && d_yt && d_stamps, LC_E_BADARG, "lc_debug_sweep16_stamps: null pointer");
+    LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
+    const int Mrows = A * M;
+    const int Mtiles = lc::ceil_div(Mrows, TM);
+    const long long Ntiles = lc::ceil_div<long long>(V, TN);
+    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val, LC_SCORE_CORR, Mrows};
+    Plain16Args pa{};
+    pa.c = reinterpret_cast<float*>(d_stamps);
+    hipLaunchKernelGGL((k_sweep_f16x3<true, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES,
+                       lc::as_stream(stream), (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa);
+    return lc::launched("k_sweep_f16x3<stamp>");
 }

@@ -124,10 +124,12 @@ __global__ void __launch_bounds__(64 * CM_RG) k_zscore_story(const double* __res
 
 // Validation-target statistics for the fused scorer.  ystat = [mean | std | var] (unbiased),
 // yblk[b, v] = sum over the b-th 32-row block of fl32(y - mean): exactly the centred values
-// the GEMM epilogue multiplies with.
+// the GEMM epilogue multiplies with;  yv = the M validation rows gathered (zero padding rows) in the row-quad
+// interleaved layout of lc_epilogue.h, so that the sweep epilogue reads them with 16-byte coalesced loads.
 __global__ void __launch_bounds__(64 * CM_RG) k_val_stats(const float* __restrict__ y, long long ldy, long long V,
                                                           const int* __restrict__ va, int M, int n_val,
-                                                          float* __restrict__ ystat, float* __restrict__ yblk) {
+                                                          float* __restrict__ ystat, float* __restrict__ yblk,
+                                                          float* __restrict__ yv) {
     __shared__ double sm[CM_RG][64];
     const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
     const bool live = c < V;
@@ -152,7 +154,17 @@ __global__ void __launch_bounds__(64 * CM_RG) k_val_stats(const float* __restric
     if (live)
         for (int b = threadIdx.y; b < M / LC_MB; b += CM_RG) {
             float t = 0.f;
-            for (int i = b * LC_MB; i < (b + 1) * LC_MB && i < n_val; ++i) t += y[(long long)va[i] * ldy + c] - meanf;
+            for (int i4 = b * LC_MB; i4 < (b + 1) * LC_MB; i4 += 4) {
+                float4 quad;                                 // row-quad interleaved layout, see lc_epilogue.h
+                float* qv = reinterpret_cast<float*>(&quad);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i4 + j;
+                    qv[j] = i < n_val ? y[(long long)va[i] * ldy + c] : 0.f;   // zero padding rows
+                    if (i < n_val) t += qv[j] - meanf;
+                }
+                reinterpret_cast<float4*>(yv)[(long long)(i4 >> 2) * V + c] = quad;
+            }
             yblk[(long long)b * V + c] = t;
         }
 }
@@ -380,14 +392,14 @@ extern "C" int lc_col_normalize_f32(float* d_x, int64_t ld, int64_t n_rows, int6
 }
 
 extern "C" int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int M, int n_val,
-                            float* d_ystat, float* d_yblk, lc_stream_t stream) {
-    LC_REQUIRE(d_y && d_va && d_ystat && d_yblk, LC_E_BADARG, "lc_val_stats: null pointer");
+                            float* d_ystat, float* d_yblk, float* d_yv, lc_stream_t stream) {
+    LC_REQUIRE(d_y && d_va && d_ystat && d_yblk && d_yv, LC_E_BADARG, "lc_val_stats: null pointer");
     LC_REQUIRE(M % LC_MB == 0 && n_val > 0 && n_val <= M, LC_E_SHAPE, "lc_val_stats: need 0 < n_val <= M, M %% %d == 0",
                LC_MB);
     if (V <= 0) return LC_OK;
     lc::ScopedTimer timer_(lc::T_VAL_STATS, lc::as_stream(stream));
     hipLaunchKernelGGL(k_val_stats, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, CM_RG), 0,
-                       lc::as_stream(stream), d_y, ldy, V, d_va, M, n_val, d_ystat, d_yblk);
+                       lc::as_stream(stream), d_y, ldy, V, d_va, M, n_val, d_ystat, d_yblk, d_yv);
     return lc::launched("k_val_stats");
 }
 

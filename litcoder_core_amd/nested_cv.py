@@ -190,6 +190,7 @@ class RidgeCVEngine:
         part = torch.empty((A * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
         ystat = torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev)
         yblk = torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
+        yv = torch.empty((M, self.Vp), dtype=torch.float32, device=self.dev)
         split = self._use_split(Y)
         LAST_SWEEP["precision"] = "f16x3" if split else "f32"
         if split:
@@ -201,14 +202,14 @@ class RidgeCVEngine:
         for f0, fc, H in hat["Hs"]:
             for j in range(fc):
                 f = f0 + j
-                ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk)
+                ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk, yv)
                 if split:
                     ops.split_rows_f16(H[j * A:(j + 1) * A].reshape(A * M, N), A * M, N, Ht, rs_inv)
                     ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt)
-                    ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, N, Yt, cs[self.Vp:], Y, self.Vp, va[f], n_v[f], ystat,
-                                                 yblk, self.mode, part, scores, accumulate=f > 0)
+                    ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, N, Yt, cs[self.Vp:], yv, self.Vp, n_v[f], ystat, yblk,
+                                                 self.mode, part, scores, accumulate=f > 0)
                 else:
-                    ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], va[f], n_v[f], ystat, yblk,
+                    ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], yv, n_v[f], ystat, yblk,
                                            self.mode, part, scores, accumulate=f > 0)
         return scores
 

@@ -225,12 +225,12 @@ def transpose_rows(x, tr, N, p, out):
 
 
 # ------------------------------------------------------------------ V-wide contractions
-def val_stats(y, V, va, M, n_val, ystat, yblk):
-    _lib.call("lc_val_stats", _p(y), y.stride(0), V, _p(va), M, n_val, _p(ystat), _p(yblk), _s())
+def val_stats(y, V, va, M, n_val, ystat, yblk, yv):
+    _lib.call("lc_val_stats", _p(y), y.stride(0), V, _p(va), M, n_val, _p(ystat), _p(yblk), _p(yv), _s())
 
 
-def alpha_sweep_scores(h, A, M, N, y, V, tr, va, n_val, ystat, yblk, mode, part, scores, accumulate):
-    _lib.call("lc_alpha_sweep_scores", _p(h), A, M, N, _p(y), y.stride(0), V, _p(tr), _p(va), n_val, _p(ystat),
+def alpha_sweep_scores(h, A, M, N, y, V, tr, yv, n_val, ystat, yblk, mode, part, scores, accumulate):
+    _lib.call("lc_alpha_sweep_scores", _p(h), A, M, N, _p(y), y.stride(0), V, _p(tr), _p(yv), n_val, _p(ystat),
               _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), _s())
 
 
@@ -251,10 +251,10 @@ def split_cols_f16(y, V, rows, K, cscale, tiled):
     _lib.call("lc_split_cols_f16", _p(y), y.stride(0), V, _p(rows), K, _p(cscale), _p(tiled), _s())
 
 
-def alpha_sweep_scores_f16x3(ht, rowscale_inv, A, M, N, yt, cscale_inv, y, V, va, n_val, ystat, yblk, mode, part, scores,
+def alpha_sweep_scores_f16x3(ht, rowscale_inv, A, M, N, yt, cscale_inv, yv, V, n_val, ystat, yblk, mode, part, scores,
                              accumulate):
-    _lib.call("lc_alpha_sweep_scores_f16x3", _p(ht), _p(rowscale_inv), A, M, N, _p(yt), _p(cscale_inv), _p(y),
-              y.stride(0), V, _p(va), n_val, _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), _s())
+    _lib.call("lc_alpha_sweep_scores_f16x3", _p(ht), _p(rowscale_inv), A, M, N, _p(yt), _p(cscale_inv), _p(yv), V, n_val,
+              _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), _s())
 
 
 def gemm_grouped_f16x3(at, rowscale_inv, Mrows, bt, cscale_inv, c, ldc, Ncols, K, group_tiles):

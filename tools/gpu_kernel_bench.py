@@ -43,16 +43,17 @@ if "sweep" in what:
     yblk = torch.empty((M // LC_MB, V), dtype=torch.float32, device=dev)
     part = torch.empty((A * M // LC_MB, 4, V), dtype=torch.float32, device=dev)
     scores = torch.empty((A, V), dtype=torch.float32, device=dev)
-    ops.val_stats(Y, V, va, M, n_v, ystat, yblk)
-    fn = lambda: ops.alpha_sweep_scores(H, A, M, N, Y, V, tr, va, n_v, ystat, yblk, LC_SCORE_CORR, part, scores, False)
+    yv = torch.empty((M, V), dtype=torch.float32, device=dev)
+    ops.val_stats(Y, V, va, M, n_v, ystat, yblk, yv)
+    fn = lambda: ops.alpha_sweep_scores(H, A, M, N, Y, V, tr, yv, n_v, ystat, yblk, LC_SCORE_CORR, part, scores, False)
     ms = timeit(fn)
     fl = 2.0 * A * n_v * n_i * V
     print(f"alpha_sweep (gemm+finalize): {ms:.2f} ms  -> {fl / ms / 1e9:.1f} TFLOP/s algorithmic")
     # correctness spot check against torch fp64 on a few columns
     cols = [0, 17, 40000, 79999]
     pred = (H.double() @ Y[:1920][:, cols].double()).reshape(A, M, len(cols))[:, :n_v]
-    yv = Y[1920:2400][:, cols].double()
-    zy = (yv - yv.mean(0)) / (yv.std(0) + 1e-8)
+    yref = Y[1920:2400][:, cols].double()
+    zy = (yref - yref.mean(0)) / (yref.std(0) + 1e-8)
     zp = (pred - pred.mean(1, keepdim=True)) / (pred.std(1, keepdim=True) + 1e-8)
     ref = (zy.unsqueeze(0) * zp).mean(1)
     print("   max |score - fp64 ref| on sample columns:", float((scores[:, cols].double() - ref).abs().max()))
@@ -69,7 +70,8 @@ if "sweep16" in what:
     yblk = torch.empty((M // LC_MB, V), dtype=torch.float32, device=dev)
     part = torch.empty((A * M // LC_MB, 4, V), dtype=torch.float32, device=dev)
     scores = torch.empty((A, V), dtype=torch.float32, device=dev)
-    ops.val_stats(Y, V, va, M, n_v, ystat, yblk)
+    yv = torch.empty((M, V), dtype=torch.float32, device=dev)
+    ops.val_stats(Y, V, va, M, n_v, ystat, yblk, yv)
     rows_pad = ops.pad_to(A * M, 256)
     Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=dev)
     rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=dev)
@@ -77,7 +79,7 @@ if "sweep16" in what:
     cs, _flag = ops.col_scales_f16(Y, T, V)
     prep = lambda: (ops.split_rows_f16(H, A * M, N, Ht, rs_inv), ops.split_cols_f16(Y, V, tr, N, cs, Yt))
     print(f"f16 operand split (H rows + Y cols): {timeit(prep):.2f} ms")
-    fn = lambda: ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, N, Yt, cs[V:], Y, V, va, n_v, ystat, yblk, LC_SCORE_CORR,
+    fn = lambda: ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, N, Yt, cs[V:], yv, V, n_v, ystat, yblk, LC_SCORE_CORR,
                                               part, scores, False)
     ms = timeit(fn)
     fl = 2.0 * A * n_v * n_i * V
@@ -85,11 +87,28 @@ if "sweep16" in what:
           f"{3 * fl / ms / 1e9:.0f} TFLOP/s of fp16 MFMA")
     cols = [0, 17, 40000, 79999]
     pred = (H.double() @ Y[:1920][:, cols].double()).reshape(A, M, len(cols))[:, :n_v]
-    yv = Y[1920:2400][:, cols].double()
-    zy = (yv - yv.mean(0)) / (yv.std(0) + 1e-8)
+    yref = Y[1920:2400][:, cols].double()
+    zy = (yref - yref.mean(0)) / (yref.std(0) + 1e-8)
     zp = (pred - pred.mean(1, keepdim=True)) / (pred.std(1, keepdim=True) + 1e-8)
     ref = (zy.unsqueeze(0) * zp).mean(1)
     print("   max |score - fp64 ref| on sample columns:", float((scores[:, cols].double() - ref).abs().max()))
+    if "stamps" in what:
+        import ctypes
+        from litcoder_core_amd import _lib
+        st = torch.zeros(16, dtype=torch.int64, device=dev)
+        p_ = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.call("lc_debug_sweep16_stamps", p_(Ht), p_(rs_inv), A, M, N, p_(Yt), p_(cs[V:]), p_(yv), V, n_v, p_(ystat),
+                  p_(part), p_(st), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        h = st.cpu().numpy().reshape(2, 8)
+        for g_ in range(2):
+            it = max(int(h[g_, 5]), 1)
+            names = ["frag reads", "dma wait", "barrier L", "mfma+dma issue", "barrier C"]
+            print(f"   group {g_}: cycles per iteration and wave: " + ", ".join(f"{n} {h[g_, i] / it:.0f}" for i, n in enumerate(names))
+                  + f"  | total {sum(h[g_, :5]) / it:.0f}")
+            nw = it / 120                     # waves x tiles that contributed (KT = 120 iterations each)
+            print(f"      per tile and wave: prologue {h[g_, 6] / nw:.0f}, main loop {sum(h[g_, :5]) / nw:.0f}, "
+                  f"epilogue {h[g_, 7] / nw:.0f} cycles")
 
 if "lanczos" in what:
     rng = np.random.default_rng(0)
@@ -167,7 +186,8 @@ if "hbm" in what:
     va = ops.idx_tensor(np.r_[1920:2400], 480, dev)
     ystat = torch.empty((3, 80000), dtype=torch.float32, device=dev)
     yblk = torch.empty((15, 80000), dtype=torch.float32, device=dev)
-    ms = timeit(lambda: ops.val_stats(Y, 80000, va, 480, 480, ystat, yblk), reps=10)
+    yv_ = torch.empty((480, 80000), dtype=torch.float32, device=dev)
+    ms = timeit(lambda: ops.val_stats(Y, 80000, va, 480, 480, ystat, yblk, yv_), reps=10)
     report("val_stats 480x80000 f32", 480 * 80000 * 4, ms)
     perm = torch.randperm(80000, generator=g, device=dev).to(torch.int32)
     rows = ops.idx_tensor(np.r_[0:3000], 3000, dev)
