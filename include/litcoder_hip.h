@@ -155,6 +155,13 @@ int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_k
 int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, int N, int steps,
                   double* d_work, double* d_lmax, lc_stream_t stream);
 
+/* The same for up to 32 row sets of ONE Gram matrix in a single pass over K per iteration: bit f of
+ * d_member[i] (T x uint32) says whether row i belongs to system f.  Every fold of a nested CV (outer
+ * train sets and their inner train sets) is a principal submatrix of K, so one call serves the whole fit.
+ * d_work: F*(3*T + 2*steps + 8) f64.  d_lmax: (F) f64. */
+int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
+                         double* d_work, double* d_lmax, lc_stream_t stream);
+
 /* a2[f*A + a] = (alphas[a] * (normalpha ? sqrt(lmax[f]) : 1))^2
  * (ridge_regression.py:99-101,117: D = S/(S^2 + nalpha^2)). */
 int lc_penalties(const double* d_lmax, int F, const double* d_alphas, int A, int normalpha,
@@ -239,7 +246,7 @@ int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, i
                                 int mode, float* d_part, float* d_scores, int accumulate, lc_stream_t stream);
 
 /* Diagnostics only (tools/gpu_kernel_bench.py stamps): the fp16x3 sweep with s_memtime stamps at its phase
- * boundaries; d_stamps (16 x uint64, caller-zeroed) receives per wave-group sums of the five segments of an
+ * boundaries; d_stamps (32 x uint64, caller-zeroed) receives per wave-group sums of the five segments of an
  * iteration.  Not used by the product path. */
 int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
                             const void* d_yt, const float* d_cscale_inv, const float* d_yv,

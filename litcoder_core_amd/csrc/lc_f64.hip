@@ -251,6 +251,94 @@ __global__ void __launch_bounds__(64) k_lz_eig(int N, int steps, double* work, d
     if (lane == 0) lmax[f] = hi;
 }
 
+// ---- all systems of a fit at once: K[I_f, I_f] for up to 32 row sets I_f of ONE Gram matrix -----------------
+// Every fold's matrix is a principal submatrix of K, so with the Lanczos vectors kept at full length T (zero
+// outside I_f) one pass over K serves all systems:  w_f = mask_f .* (K v_f).  member[i] bit f = (i in I_f).
+// The per-fold gather version above reads K once per system and iteration (5 inner + 1 outer train set per
+// outer fold: ~4x the bytes of K per outer fold); this one reads K once per iteration for the whole fit.
+__global__ void __launch_bounds__(256) k_lz_init_masked(const unsigned* __restrict__ member, int T, int steps,
+                                                        double* work) {
+    __shared__ double red[256];
+    const int f = blockIdx.x;
+    double* base = lz_base(work, f, T, steps);
+    double* v = base;
+    double* vp = base + T;
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < T; i += 256) {
+        unsigned h = (unsigned)i * 2654435761u + 12345u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const double x = (member[i] >> f) & 1u ? ((double)(h & 0xFFFFFF) / 8388608.0 - 1.0) + 1.5 : 0.0;
+        v[i] = x;
+        vp[i] = 0.0;
+        ss += x * x;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    const double inv = red[0] > 0.0 ? 1.0 / sqrt(red[0]) : 0.0;
+    for (int i = threadIdx.x; i < T; i += 256) v[i] *= inv;
+    if (threadIdx.x < 8) base[3ll * T + 2ll * steps + threadIdx.x] = 0.0;
+}
+
+constexpr int LZM_ROWS = 8;      // rows of K per block
+constexpr int LZM_JT = 128;      // columns of K per LDS tile
+
+// block: 8 rows of K x all F <= 32 systems.  thread (f = tid & 31, g = tid >> 5): partial sums over the g-th
+// 16-column slice of every tile for the 8 rows; K and V tiles go through LDS (V transposed to [j][f]), the next
+// tile is fetched into registers while the current one is consumed; fixed-order reduction over g at the end.
+__global__ void __launch_bounds__(256) k_lz_symv_multi(const double* __restrict__ Kmat, long long ldk,
+                                                       const unsigned* __restrict__ member, int T, int F, int steps,
+                                                       double* work) {
+    __shared__ double Ks[LZM_ROWS][LZM_JT];
+    __shared__ double Vs[LZM_JT][33];
+    const int tid = threadIdx.x, f = tid & 31, g = tid >> 5;
+    const int i0 = blockIdx.x * LZM_ROWS;
+    double kreg[4], vreg[16];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + 256 * k, r = e >> 7, j = j0 + (e & 127);
+            kreg[k] = (i0 + r < T && j < T) ? Kmat[(long long)(i0 + r) * ldk + j] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = tid + 256 * k, ff = e >> 7, j = j0 + (e & 127);
+            vreg[k] = (ff < F && j < T) ? lz_base(work, ff, T, steps)[j] : 0.0;
+        }
+    };
+    double acc[LZM_ROWS];
+#pragma unroll
+    for (int r = 0; r < LZM_ROWS; ++r) acc[r] = 0.0;
+    fetch(0);
+    for (int j0 = 0; j0 < T; j0 += LZM_JT) {
+        __syncthreads();                                   // previous tile consumed
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int e = tid + 256 * k; Ks[e >> 7][e & 127] = kreg[k]; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int e = tid + 256 * k; Vs[e & 127][e >> 7] = vreg[k]; }
+        __syncthreads();
+        if (j0 + LZM_JT < T) fetch(j0 + LZM_JT);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const double vj = Vs[g * 16 + jj][f];
+#pragma unroll
+            for (int r = 0; r < LZM_ROWS; ++r) acc[r] += Ks[r][g * 16 + jj] * vj;
+        }
+    }
+    __syncthreads();
+    double* red = &Vs[0][0];                               // [g][r][f]: 8 * 8 * 32 doubles
+#pragma unroll
+    for (int r = 0; r < LZM_ROWS; ++r) red[(g * LZM_ROWS + r) * 32 + f] = acc[r];
+    __syncthreads();
+    const int r = g, i = i0 + r;                           // thread (r, f) finishes one output
+    if (i < T && f < F) {
+        double sum = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) sum += red[(gg * LZM_ROWS + r) * 32 + f];
+        lz_base(work, f, T, steps)[2ll * T + i] = (member[i] >> f) & 1u ? sum : 0.0;
+    }
+}
+
 __global__ void k_penalties(const double* __restrict__ lmax, int F, const double* __restrict__ alphas, int A,
                             int normalpha, double* __restrict__ a2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -541,6 +629,25 @@ extern "C" int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_ro
     }
     if (int rc = lc::launched("k_lz_step")) return rc;
     hipLaunchKernelGGL(k_lz_eig, dim3(F), dim3(64), 0, s, N, steps, d_work, d_lmax);
+    return lc::launched("k_lz_eig");
+}
+
+extern "C" int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
+                                    double* d_work, double* d_lmax, lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_member && d_work && d_lmax, LC_E_BADARG, "lc_lambda_max_masked: null pointer");
+    LC_REQUIRE(F > 0 && F <= 32 && T > 0 && steps > 0 && ldk >= T, LC_E_SHAPE,
+               "lc_lambda_max_masked: need 1 <= F <= 32 systems, T > 0, steps > 0");
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_LAMBDA_MAX, s);
+    hipLaunchKernelGGL(k_lz_init_masked, dim3(F), dim3(256), 0, s, d_member, T, steps, d_work);
+    if (int rc = lc::launched("k_lz_init_masked")) return rc;
+    for (int it = 0; it < steps; ++it) {
+        hipLaunchKernelGGL(k_lz_symv_multi, dim3((unsigned)lc::ceil_div(T, LZM_ROWS)), dim3(256), 0, s, d_k,
+                           (long long)ldk, d_member, T, F, steps, d_work);
+        hipLaunchKernelGGL(k_lz_step, dim3(F), dim3(1024), 0, s, T, steps, it, d_work);
+    }
+    if (int rc = lc::launched("k_lz_step")) return rc;
+    hipLaunchKernelGGL(k_lz_eig, dim3(F), dim3(64), 0, s, T, steps, d_work, d_lmax);
     return lc::launched("k_lz_eig");
 }
 

@@ -13,6 +13,8 @@
 // Tile 256 x 256 x 16, 512 threads = 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA blocks, four 32 KB LDS
 // stages filled by LDS-DMA three to four K-tiles ahead, and the two waves of every SIMD run half an iteration
 // apart (one reads fragments / issues DMA while the other issues MFMAs).
+#include <type_traits>
+
 #include "lc_common.h"
 #include "lc_epilogue.h"
 
@@ -26,7 +28,7 @@ constexpr int KG = TK / 8;                        // 8-k groups per K-tile
 constexpr int CHUNK16 = 2 * KG * 256;             // 16-byte units per (tile, K-tile) chunk = 16 KB
 constexpr int STAGE16 = 2 * CHUNK16;              // A chunk + B chunk = 32 KB
 constexpr int NSTAGE = 4;                         // LDS ring
-constexpr int LDS16_BYTES = NSTAGE * STAGE16 * 16;   // 128 KB
+constexpr int LDS16_BYTES = NSTAGE * STAGE16 * 16 + TM * 4;   // 128 KB ring + the tile's 256 row scales
 
 __device__ inline int xcd_tile_id16(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -173,7 +175,7 @@ struct Plain16Args {
 #define MFMA16(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
 
 // STAMP builds (diagnostics only, lc_debug_sweep16_stamps): s_memtime at the phase boundaries, per-wave sums of
-// the five segments of an iteration added into pa.c (unsigned long long[2 groups][8]) -- results are not used.
+// the segments of an iteration / of the tile added into pa.c (unsigned long long[2 groups][16]) -- results are not used.
 #define STAMP_T(var_)                                                                          \
     if (STAMP) {                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                     \
@@ -246,8 +248,36 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int t = 0; t < NSTAGE && t < KT; ++t) GLDS16(t, t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // prologue: tiles 0..2 for everybody, tile 3 only from group 1 (group 0 starts its share of tile 3 in C_0)
+    for (int t = 0; t < 3 && t < KT; ++t) GLDS16(t, t);
+    if (wm == 1 && 3 < KT) GLDS16(3, 3);
+
+    // score epilogue operands that do not depend on the accumulators are fetched up front: the epilogue has
+    // nothing to hide a global round trip behind (one block per CU).  Row scales of the tile -> LDS behind the
+    // ring, per-column constants -> registers; the first target batches follow in the last K-tiles (below).
+    float* lds_rs = reinterpret_cast<float*>(lds16 + NSTAGE * STAGE16);
+    const long long V = sa.V;
+    const long long col0 = (long long)nt * TN + wn * 64 + li;
+    const bool cok[2] = {col0 < V, col0 + 32 < V};
+    const long long colc[2] = {cok[0] ? col0 : 0, cok[1] ? col0 + 32 : 0};       // clamped: loads stay in range
+    float ymv[2] = {0.f, 0.f}, cscv[2] = {0.f, 0.f};
+    if (SCORE) {
+        if (tid < TM) lds_rs[tid] = sa.rs_inv[mt * TM + tid];                      // rs_inv has rows_pad entries
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            ymv[ni] = sa.ymean[colc[ni]];
+            cscv[ni] = sa.cs_inv[colc[ni]];
+        }
+    }
+    // targets of epilogue step s = 2 mi + ni (32 rows x this lane's column of panel ni)
+    auto load_t = [&](int step, lc::EpiTargets& t) {
+        const int rb0 = mt * TM + wm * 128 + (step >> 1) * 32;                      // yv rows are i0 < M
+        lc::epi_load_targets(sa.yv, V, rb0 % sa.M, lh, colc[step & 1], t);
+    };
+    lc::EpiTargets tb0, tb1, tb2;
+    if (SCORE && KT < 2) { load_t(0, tb0); load_t(1, tb1); }
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     PHASE_BARRIER();
     if (wm == 1) { PHASE_BARRIER(); }            // stagger: group 1 runs one phase behind group 0
 
@@ -258,7 +288,11 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     STAMP_T(tk1);
     unsigned long long sum_read = 0, sum_wait = 0, sum_bar1 = 0, sum_mma = 0, sum_bar2 = 0;
-    for (int kt = 0; kt < KT; ++kt) {
+    // one K-tile.  STEADY (kt + 4 < KT): both groups issue a later tile and wait with fixed counts -- no
+    // branches between the MFMAs, where an instruction-fetch hiccup is a bubble in the matrix pipe;  the last
+    // four K-tiles run the guarded version.
+    auto kstep = [&](const int kt, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
         const uint4* st = lds16 + (kt & 3) * STAGE16;
         STAMP_T(t0);
         // ---- phase L
@@ -283,38 +317,47 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         // (group 0 issued it two C phases ago, group 1 three: one resp. two younger tiles may still fly)
         const int issue_tile = wm == 0 ? kt + 3 : kt + 4;       // what this wave will start in C_kt
         if (wm == 0) {
-            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (STEADY || kt + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (STEADY || kt + 3 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         STAMP_T(t2);
         PHASE_BARRIER();
         STAMP_T(t3);
+        if (!STEADY && SCORE && kt == KT - 2) {   // every later wait is vmcnt(0): the batches land under the last K-tiles
+            load_t(0, tb0); load_t(1, tb1);      // (a third batch would spill: 186 + 48 registers)
+        }
         // ---- phase C: 24 MFMAs; the four DMA pieces of a later tile are issued between them, where their
         // issue cost hides behind the matrix pipe.  Target stage: (kt+3)&3 for group 0 (group 1 finished
         // reading it one phase ago), kt&3 for group 1 (both groups have read it).
-        const bool do_dma = issue_tile < KT && (wm == 1 || kt >= 1);
+        const bool do_dma = STEADY || issue_tile < KT;
         const int stg = (wm == 0 ? kt + 3 : kt) & 3;
         const uint4* pa_ = a_src + (long long)issue_tile * CHUNK16;
         const uint4* pb_ = b_src + (long long)issue_tile * CHUNK16;
         __builtin_amdgcn_s_setprio(1);
+        // term-major order: the eight accumulators take the lo*hi terms, then hi*lo, then hi*hi (small terms
+        // first), so that consecutive MFMAs never wait for each other's result
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int term = 0; term < 3; ++term) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                MFMA16(acc[mi][ni], al[mi], bh[ni]);      // small terms first
-                MFMA16(acc[mi][ni], ah[mi], bl[ni]);
-                MFMA16(acc[mi][ni], ah[mi], bh[ni]);
-            }
-            if (do_dma) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (mi == 0) DMA16(pa_, stg * STAGE16);
-                if (mi == 1) DMA16(pa_ + 512, stg * STAGE16 + 512);
-                if (mi == 2) DMA16(pb_, stg * STAGE16 + CHUNK16);
-                if (mi == 3) DMA16(pb_ + 512, stg * STAGE16 + CHUNK16 + 512);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if (term == 0) MFMA16(acc[mi][ni], al[mi], bh[ni]);
+                    if (term == 1) MFMA16(acc[mi][ni], ah[mi], bl[ni]);
+                    if (term == 2) MFMA16(acc[mi][ni], ah[mi], bh[ni]);
+                }
+                const int piece = term * 4 + mi;         // 12 slots, the four DMA pieces go into slots 1, 4, 7, 10
+                if (piece % 3 == 1 && do_dma) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (piece == 1) DMA16(pa_, stg * STAGE16);
+                    if (piece == 4) DMA16(pa_ + 512, stg * STAGE16 + 512);
+                    if (piece == 7) DMA16(pb_, stg * STAGE16 + CHUNK16);
+                    if (piece == 10) DMA16(pb_ + 512, stg * STAGE16 + CHUNK16 + 512);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -324,17 +367,22 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         if (STAMP) {
             sum_read += t1 - t0; sum_wait += t2 - t1; sum_bar1 += t3 - t2; sum_mma += t4 - t3; sum_bar2 += t5 - t4;
         }
-    }
+    };
+    int kt = 0;
+    for (; kt + 4 < KT; ++kt) kstep(kt, std::true_type{});
+    for (; kt < KT; ++kt) kstep(kt, std::false_type{});
     STAMP_T(tk2);
     if (STAMP) {
         if (lane == 0) {
-            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(pa.c) + wm * 8;
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(pa.c) + wm * 16;
             atomicAdd(dbg + 6, tk1 - tk0);
             atomicAdd(dbg + 0, sum_read); atomicAdd(dbg + 1, sum_wait); atomicAdd(dbg + 2, sum_bar1);
             atomicAdd(dbg + 3, sum_mma); atomicAdd(dbg + 4, sum_bar2); atomicAdd(dbg + 5, (unsigned long long)KT);
         }
     }
     if (wm == 0) { PHASE_BARRIER(); }            // group 0 pays its extra barrier at the end
+    unsigned long long te0 = 0, te1 = 0, te2 = 0, te3 = 0;
+    STAMP_T(te0);
 
     if (!SCORE) {
         // ---- plain epilogue: undo the power-of-two scales and store
@@ -355,59 +403,57 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         return;
     }
 
-    // ---- epilogue: the statistics of lc_epilogue.h after undoing the power-of-two scales.  The loads of a
-    // 32-row block (row scales, the two column panels of gathered targets) are one batch, and the batch of
-    // block mi+1 is in flight while block mi is reduced.
-    const long long V = sa.V;
-    const long long col0 = (long long)nt * TN + wn * 64 + li;
-    const bool cok[2] = {col0 < V, col0 + 32 < V};
-    const long long colc[2] = {cok[0] ? col0 : 0, cok[1] ? col0 + 32 : 0};       // clamped: loads stay in range
-    float ymv[2], cscv[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        ymv[ni] = sa.ymean[colc[ni]];
-        cscv[ni] = sa.cs_inv[colc[ni]];
-    }
+    // ---- epilogue: the statistics of lc_epilogue.h after undoing the power-of-two scales.  Two target
+    // batches are already in registers, the third is issued first thing; batch s+3 follows step s.
     const bool corr = sa.mode == LC_SCORE_CORR;
-    struct RowScales {
-        lc::ep_f32x4 rs[4];
-    };
-    // step s = 2 mi + ni: the targets of step s+1 (and the row scales of block mi+1) are issued before step s
-    // is reduced; rows of the tile lie below rows_pad (rs_inv is that long) and yv rows are i0 < M
-    auto load_rs = [&](int mi, RowScales& r) {
-        const int rb0 = mt * TM + wm * 128 + mi * 32;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            r.rs[q] = *reinterpret_cast<const lc::ep_f32x4*>(sa.rs_inv + rb0 + 8 * q + 4 * lh);
-    };
-    auto load_t = [&](int step, lc::EpiTargets& t) {
-        const int rb0 = mt * TM + wm * 128 + (step >> 1) * 32;
-        lc::epi_load_targets(sa.yv, V, rb0 % sa.M, lh, colc[step & 1], t);
-    };
-    auto reduce = [&](int step, const lc::EpiTargets& t, const RowScales& r) {
+    auto reduce = [&](int step, const lc::EpiTargets& t) {
         const int mi = step >> 1, ni = step & 1;
         const int rb0 = mt * TM + wm * 128 + mi * 32;
         if (rb0 >= sa.Mrows) return;
-        lc::epi_block_dispatch<true>(corr, acc[mi][ni], t, r.rs, cscv[ni], ymv[ni], rb0 % sa.M, sa.n_val, lh,
+        lc::ep_f32x4 rs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            rs[q] = *reinterpret_cast<const lc::ep_f32x4*>(lds_rs + wm * 128 + mi * 32 + 8 * q + 4 * lh);
+        lc::epi_block_dispatch<true>(corr, acc[mi][ni], t, rs, cscv[ni], ymv[ni], rb0 % sa.M, sa.n_val, lh,
                                      sa.part + (long long)(rb0 >> 5) * 4 * V + colc[ni], V, cok[ni]);
     };
 #define EPI_FENCE() __builtin_amdgcn_sched_barrier(0)
-    lc::EpiTargets tA, tB;
-    RowScales rA, rB;
-    load_rs(0, rA); load_t(0, tA);
-    load_t(1, tB);                 EPI_FENCE(); reduce(0, tA, rA); EPI_FENCE();
-    load_rs(1, rB); load_t(2, tA); EPI_FENCE(); reduce(1, tB, rA); EPI_FENCE();
-    load_t(3, tB);                 EPI_FENCE(); reduce(2, tA, rB); EPI_FENCE();
-    load_rs(2, rA); load_t(4, tA); EPI_FENCE(); reduce(3, tB, rB); EPI_FENCE();
-    load_t(5, tB);                 EPI_FENCE(); reduce(4, tA, rA); EPI_FENCE();
-    load_rs(3, rB); load_t(6, tA); EPI_FENCE(); reduce(5, tB, rA); EPI_FENCE();
-    load_t(7, tB);                 EPI_FENCE(); reduce(6, tA, rB); EPI_FENCE();
-    reduce(7, tB, rB);
+    load_t(2, tb2); EPI_FENCE();
+    unsigned long long ter = 0;
+    if (STAMP) {                       // diagnostics: run step 0 twice, the second pass finds code and data warm
+#pragma unroll 1
+        for (int rep = 0; rep < 2; ++rep) {
+            reduce(0, tb0); EPI_FENCE();
+            if (rep == 0) { STAMP_T(ter); }
+        }
+        load_t(3, tb0); EPI_FENCE();
+    } else {
+        reduce(0, tb0); EPI_FENCE(); load_t(3, tb0); EPI_FENCE();
+    }
+    STAMP_T(te1);
+    reduce(1, tb1); EPI_FENCE(); load_t(4, tb1); EPI_FENCE();
+    reduce(2, tb2); EPI_FENCE(); load_t(5, tb2); EPI_FENCE();
+    reduce(3, tb0); EPI_FENCE(); load_t(6, tb0); EPI_FENCE();
+    reduce(4, tb1); EPI_FENCE(); load_t(7, tb1); EPI_FENCE();
+    reduce(5, tb2);
+    reduce(6, tb0);
+    STAMP_T(te2);
+    reduce(7, tb1);
+    STAMP_T(te3);
 #undef EPI_FENCE
     if (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAMP_T(tk3);
-        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(pa.c) + wm * 8 + 7, tk3 - tk2);
+        if (lane == 0) {
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(pa.c) + wm * 16;
+            atomicAdd(dbg + 7, tk3 - tk2);
+            atomicAdd(dbg + 8, te0 - tk2);       // group-0 catch-up barrier
+            atomicAdd(dbg + 9, ter - te0);       // first reduce step (cold)
+            atomicAdd(dbg + 13, te1 - ter);      // the same step again (warm)
+            atomicAdd(dbg + 10, te2 - te1);      // steps 1..6
+            atomicAdd(dbg + 11, te3 - te2);      // step 7
+            atomicAdd(dbg + 12, tk3 - te3);      // store drain
+        }
     }
 }
 
@@ -523,7 +569,8 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
 }
 
 // Diagnostics: the score kernel with s_memtime stamps (not part of the product path; see tools/gpu_kernel_bench.py).
-// d_stamps: 16 x uint64, zeroed by the caller: [group][read, dma-wait, barrier1, mfma, barrier2, iterations, -, -].
+// d_stamps: 32 x uint64, zeroed by the caller: [group][read, dma-wait, barrier1, mfma, barrier2, iterations, prologue,
+// epilogue, catch-up barrier, step 0, steps 1-6, step 7, store drain, -, -, -].
 extern "C" int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N, const void* d_yt,
                                        const float* d_cscale_inv, const float* d_yv, int64_t V, int n_val,
                                        const float* d_ystat, float* d_part,

@@ -138,8 +138,37 @@ class RidgeCVEngine:
                 logger.info("target dynamic range too wide for the fp16x3 sweep: using the f32 MFMA path")
         return not self._cs_wide
 
+    # -------------------------------------------------------------- S[0]^2 of every train set (Lanczos)
+    def lmax_systems(self, K, row_sets):
+        """lambda_max(K[I, I]) for every row set I: all sets are principal submatrices of the one Gram matrix, so
+        they share a single pass over K per Lanczos iteration, 32 systems per launch chain."""
+        out = []
+        for c0 in range(0, len(row_sets), 32):
+            chunk = row_sets[c0:c0 + 32]
+            bits = np.zeros(self.Ttot, dtype=np.uint32)
+            for f, rows in enumerate(chunk):
+                bits[np.asarray(rows, dtype=np.int64)] |= np.uint32(1 << f)
+            member = torch.from_numpy(bits.view(np.int32)).to(self.dev)
+            out.append(ops.lambda_max_masked(K, self.Ttot, member, len(chunk), self.steps))
+        return torch.cat(out)
+
+    def precompute_lmax(self, outer):
+        """(inner-fold lmax (F,), outer-train lmax (1,)) per outer fold from ONE Lanczos run over the shared Gram
+        matrix; [None, ...] when there is nothing to share (no normalpha, or normalize_features gives every
+        outer fold its own Gram matrix -- fold_prepare then runs the fold's systems by itself)."""
+        if not self.normalpha or self.norm_x:
+            return [None] * len(outer)
+        sets, spans = [], []
+        for tr_rows, _, inner_rel in outer:
+            tr_rows = np.asarray(tr_rows, dtype=np.int64)
+            spans.append((len(sets), len(inner_rel)))
+            sets += [tr_rows[np.asarray(a, dtype=np.int64)] for a, _ in inner_rel] + [tr_rows]
+        lm = self.lmax_systems(self.K, sets)
+        self.ready.record()                           # the auxiliary stream consumes these
+        return [(lm[s:s + n], lm[s + n:s + n + 1]) for s, n in spans]
+
     # -------------------------------------------------------------- inner CV: hat matrices, then the sweeps
-    def _hat_matrices(self, K, inner_abs):
+    def _hat_matrices(self, K, inner_abs, lmax=None):
         """V-independent part of the inner CV of one outer fold: row lists, S[0]^2 (Lanczos), penalties and the
         hat matrices H_alpha of every (inner fold, alpha) -- batched Cholesky for the small alphas, the shared
         Neumann series for the large ones.  Returns a dict the sweeps consume."""
@@ -152,7 +181,8 @@ class RidgeCVEngine:
         M = ops.pad_to(max(n_v), LC_MB)
         tr = torch.stack([ops.idx_tensor(t, N, self.dev) for t, _ in inner_abs])
         va = torch.stack([ops.idx_tensor(v, M, self.dev) for _, v in inner_abs])
-        lmax = ops.lambda_max(K, tr, F, N, self.steps) if self.normalpha else None
+        if self.normalpha and lmax is None:
+            lmax = self.lmax_systems(K, [t for t, _ in inner_abs])
         a2 = ops.penalties(lmax, F, self.d_alphas, self.normalpha)
         # alphas whose penalty dwarfs the spectrum take the Neumann series (shared matrix powers), the
         # rest the batched Cholesky; rho = lambda_max / a^2 = 1 / alpha^2 under normalpha
@@ -296,7 +326,7 @@ class RidgeCVEngine:
     # prediction / Pearson / D2H) -> collect (wait for the fold's results).  The caller interleaves
     # the phases of consecutive folds so that the host statistics of fold f run while the GPU works
     # on fold f+1.
-    def fold_prepare(self, tr_rows, te_rows, inner_rel):
+    def fold_prepare(self, tr_rows, te_rows, inner_rel, lmax_pre=None):
         """Everything of an outer fold that does not touch the voxel axis beyond O(V) copies -- train-statistics
         normalisation, Lanczos, the batched Cholesky / series hat matrices -- enqueued on the engine's AUXILIARY
         stream, so that it overlaps the V-wide MFMA sweeps of the previous fold running on the main stream
@@ -311,11 +341,17 @@ class RidgeCVEngine:
         self.aux.wait_event(self.ready)                # inputs (X, Y, K) were produced on the main stream
         with torch.cuda.stream(self.aux):
             X, Y, K = self._fold_data(tr_rows)
-            hat = self._hat_matrices(K, inner_abs)
-            # S[0]^2 of the whole outer-train block (refit penalty scale): independent of the alpha choice
+            # S[0]^2 of the inner train sets and of the whole outer-train block (refit penalty scale,
+            # independent of the alpha choice): precomputed for the whole fit, or one run for this fold
+            lmax_i = lmax_o = None
+            if self.normalpha:
+                if lmax_pre is None:
+                    lm = self.lmax_systems(K, [t for t, _ in inner_abs] + [tr_rows])
+                    lmax_pre = (lm[:len(inner_abs)], lm[len(inner_abs):])
+                lmax_i, lmax_o = lmax_pre
+            hat = self._hat_matrices(K, inner_abs, lmax_i)
             N_o = ops.pad_to(len(tr_rows), LC_NB)
             tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
-            lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
             done = torch.cuda.Event()
             done.record()
         for t in [X, Y, K, hat["tr"], hat["va"], hat["info"], tr_o, lmax_o] + [h for _, _, h in hat["Hs"]]:
@@ -323,8 +359,8 @@ class RidgeCVEngine:
                 t.record_stream(main)                  # allocated on aux, consumed on main
         return dict(tr=tr_rows, te=te_rows, X=X, Y=Y, K=K, hat=hat, done=done, tr_o=tr_o, lmax_o=lmax_o)
 
-    def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None):
-        st = prepared if prepared is not None else self.fold_prepare(tr_rows, te_rows, inner_rel)
+    def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None, lmax_pre=None):
+        st = prepared if prepared is not None else self.fold_prepare(tr_rows, te_rows, inner_rel, lmax_pre)
         torch.cuda.current_stream().wait_event(st["done"])
         st["scores"] = self._sweeps(st["hat"], st["Y"])
         st["info"] = st["hat"]["info"]
@@ -523,10 +559,12 @@ class NestedCVModel(BasePredictivityModel):
             any_nan.append(bool(np.isnan(r32).any()))
 
         pending = None
-        prepared = eng.fold_prepare(*outer[0])
+        lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
+        prepared = eng.fold_prepare(*outer[0], lmax_pre=lmax_pre[0])
         for i in range(len(outer)):
             st = eng.fold_begin(*outer[i], prepared=prepared)                      # main stream: the sweeps
-            prepared = eng.fold_prepare(*outer[i + 1]) if i + 1 < len(outer) else None   # aux stream, next fold
+            prepared = (eng.fold_prepare(*outer[i + 1], lmax_pre=lmax_pre[i + 1])  # aux stream, next fold
+                        if i + 1 < len(outer) else None)
             if pending is not None:
                 tail(pending)
             pending = eng.fold_refit(st, single_alpha, scale)

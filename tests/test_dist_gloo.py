@@ -47,7 +47,9 @@ class OracleEngine:
         self.W += scale * W.numpy()
         from litcoder_core_amd import stats
         return ncv._FoldResult(r, stats.pearson_pvalues(r.astype(np.float32), len(te)), idx, len(te))
-    def fold_prepare(self, tr, te, inner):
+    def precompute_lmax(self, outer):
+        return [None] * len(outer)
+    def fold_prepare(self, tr, te, inner, lmax_pre=None):
         return (tr, te, inner)
     def fold_begin(self, tr, te, inner, prepared=None):
         return (tr, te, inner)

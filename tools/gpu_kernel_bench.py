@@ -95,12 +95,12 @@ if "sweep16" in what:
     if "stamps" in what:
         import ctypes
         from litcoder_core_amd import _lib
-        st = torch.zeros(16, dtype=torch.int64, device=dev)
+        st = torch.zeros(32, dtype=torch.int64, device=dev)
         p_ = lambda t: ctypes.c_void_p(t.data_ptr())
         _lib.call("lc_debug_sweep16_stamps", p_(Ht), p_(rs_inv), A, M, N, p_(Yt), p_(cs[V:]), p_(yv), V, n_v, p_(ystat),
                   p_(part), p_(st), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
-        h = st.cpu().numpy().reshape(2, 8)
+        h = st.cpu().numpy().reshape(2, 16)
         for g_ in range(2):
             it = max(int(h[g_, 5]), 1)
             names = ["frag reads", "dma wait", "barrier L", "mfma+dma issue", "barrier C"]
@@ -108,7 +108,8 @@ if "sweep16" in what:
                   + f"  | total {sum(h[g_, :5]) / it:.0f}")
             nw = it / 120                     # waves x tiles that contributed (KT = 120 iterations each)
             print(f"      per tile and wave: prologue {h[g_, 6] / nw:.0f}, main loop {sum(h[g_, :5]) / nw:.0f}, "
-                  f"epilogue {h[g_, 7] / nw:.0f} cycles")
+                  f"epilogue {h[g_, 7] / nw:.0f} cycles (catch-up barrier {h[g_, 8] / nw:.0f}, step 0 {h[g_, 9] / nw:.0f}, step 0 again {h[g_, 13] / nw:.0f}, "
+                  f"steps 1-6 {h[g_, 10] / nw:.0f}, step 7 {h[g_, 11] / nw:.0f}, drain {h[g_, 12] / nw:.0f})")
 
 if "lanczos" in what:
     rng = np.random.default_rng(0)
@@ -133,6 +134,24 @@ if "lanczos" in what:
     for steps in (64, 192):
         ms = timeit(lambda: ops.lambda_max(K, idx5, 5, 1920, steps), reps=3, warm=1)
         print(f"lambda_max F=5 N=1920 steps={steps}: {ms:.2f} ms")
+    # all 30 systems of a 5x5 nested CV over T=3000 in one masked run
+    T3 = 3000
+    x3 = rng.standard_normal((T3, 3072)).astype(np.float32)
+    K3 = ops.gram(ops.upload_f32(x3, 3072, dev), T3, 3072)
+    sets = []
+    for o in range(5):
+        tr_o = np.r_[0:o * 600, (o + 1) * 600:T3]
+        sets += [np.delete(tr_o, np.s_[i * 480:(i + 1) * 480]) for i in range(5)] + [tr_o]
+    bits = np.zeros(T3, dtype=np.uint32)
+    for f_, rows_ in enumerate(sets):
+        bits[rows_] |= np.uint32(1 << f_)
+    member = torch.from_numpy(bits.view(np.int32)).to(dev)
+    ms = timeit(lambda: ops.lambda_max_masked(K3, T3, member, len(sets), 64), reps=3, warm=1)
+    got = ops.lambda_max_masked(K3, T3, member, len(sets), 64).cpu().numpy()
+    Kh = K3.cpu().numpy()
+    ref = np.array([np.linalg.eigvalsh(Kh[np.ix_(r_, r_)])[-1] for r_ in sets[:6]])
+    print(f"lambda_max_masked 30 systems T=3000 steps=64: {ms:.2f} ms; max rel err vs eigvalsh (first 6): "
+          f"{np.max(np.abs(got[:6] / ref - 1)):.2e}")
 
 if "chol" in what:
     rng = np.random.default_rng(1)
