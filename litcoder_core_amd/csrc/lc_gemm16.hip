@@ -202,21 +202,20 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     const uint4* a_src = At + ((long long)grp * Mtiles + mt) * KT * CHUNK16 + tid;
     const uint4* b_src = Bt + (long long)nt * KT * CHUNK16 + tid;
 
-    // ---- main loop: two phases per K-tile, the two waves of every SIMD one phase apart --------------------
-    //   L_j: read the 12 fragments of tile j from LDS stage j&3, start the LDS-DMA of a later tile
-    //   C_j: 24 MFMAs on registers only
-    // with a block barrier after each phase.  Waves 4-7 (wm = 1, the second wave of each SIMD) take one extra
-    // barrier up front, so while group 0 is in C_j group 1 is in L_j and vice versa: every SIMD always has one
-    // wave issuing MFMAs, and the LDS reads / DMA issue of the other hide behind them.
+    // ---- main loop: software-pipelined fragments, ONE block barrier per K-tile ----------------------------
+    // Every wave keeps two register sets of fragments: while the 24 MFMAs of K-tile j run on one set, the 12
+    // LDS reads of tile j+1 fill the other and the four LDS-DMA pieces of tile j+4 are started, all interleaved
+    // between the MFMAs -- each wave always has independent MFMAs to issue, so the two waves of a SIMD keep the
+    // matrix pipe fed without any phase choreography, and the only bubble left is the barrier crossing.
     // Operand chunks go global -> LDS directly (global_load_lds_dwordx4 through inline asm, so that hipcc does
     // not drain the queue in front of every LDS read); thread t moves the 16-byte units t and t + 512 of each
-    // 16 KB chunk, a wave's 64 lanes land contiguously at its wave-uniform LDS base (M0).  Ring discipline:
-    //   tiles 0..3 are loaded in the prologue;
-    //   group 0 starts its share of tile j+3 -> stage (j+3)&3 during C_j (group 1 read that stage two phases
-    //   earlier);  group 1 starts its share of tile j+4 -> stage j&3 during its own C_j (both groups have read
-    //   it).  The DMA pieces are issued BETWEEN the MFMAs of phase C, where their issue cost hides.
-    //   Before the barrier that ends L_j every wave waits (counted vmcnt) until its share of tile j+1 has
-    //   landed: that barrier publishes it to the other group, the next one to itself.
+    // 16 KB chunk, a wave's 64 lanes land contiguously at its wave-uniform LDS base (M0).  Ring discipline
+    // (tile t lives in stage t & 3):
+    //   prologue: tiles 0..3 -> stages 0..3, fragments of tile 0 -> registers, barrier;
+    //   iteration j: MFMAs of tile j (registers) | read tile j+1 from stage (j+1)&3 | DMA tile j+4 -> stage j&3
+    //   (every wave read tile j out of it during iteration j-1, i.e. before the last barrier);
+    //   end of iteration j: wait (counted vmcnt: tiles j+3, j+4 may still fly) until this wave's share of tile
+    //   j+2 has landed, then the barrier publishes it -- two iterations of latency budget per DMA.
     const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) uint4*)lds16);
 #define DMA16(gptr_, unit_)                                                                                   \
     {                                                                                                         \
@@ -248,9 +247,7 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // prologue: tiles 0..2 for everybody, tile 3 only from group 1 (group 0 starts its share of tile 3 in C_0)
-    for (int t = 0; t < 3 && t < KT; ++t) GLDS16(t, t);
-    if (wm == 1 && 3 < KT) GLDS16(3, 3);
+    for (int t = 0; t < NSTAGE && t < KT; ++t) GLDS16(t, t);
 
     // score epilogue operands that do not depend on the accumulators are fetched up front: the epilogue has
     // nothing to hide a global round trip behind (one block per CU).  Row scales of the tile -> LDS behind the
@@ -275,112 +272,106 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         lc::epi_load_targets(sa.yv, V, rb0 % sa.M, lh, colc[step & 1], t);
     };
     lc::EpiTargets tb0, tb1, tb2;
-    if (SCORE && KT < 2) { load_t(0, tb0); load_t(1, tb1); }
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     PHASE_BARRIER();
-    if (wm == 1) { PHASE_BARRIER(); }            // stagger: group 1 runs one phase behind group 0
 
     // fragment addresses (16-byte units) inside a stage: ((plane*KG + lh) * 256 + row)
     const int a_frag = lh * 256 + wm * 128 + li;
     const int b_frag = CHUNK16 + lh * 256 + wn * 64 + li;
-
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-    STAMP_T(tk1);
-    unsigned long long sum_read = 0, sum_wait = 0, sum_bar1 = 0, sum_mma = 0, sum_bar2 = 0;
-    // one K-tile.  STEADY (kt + 4 < KT): both groups issue a later tile and wait with fixed counts -- no
-    // branches between the MFMAs, where an instruction-fetch hiccup is a bubble in the matrix pipe;  the last
-    // four K-tiles run the guarded version.
-    auto kstep = [&](const int kt, auto steady_tag) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        const uint4* st = lds16 + (kt & 3) * STAGE16;
-        STAMP_T(t0);
-        // ---- phase L
+    struct Frag {
         h8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const uint4 v = st[a_frag + mi * 32];
-            const uint4 w = st[a_frag + KG * 256 + mi * 32];
-            ah[mi] = *reinterpret_cast<const h8*>(&v);
-            al[mi] = *reinterpret_cast<const h8*>(&w);
-        }
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const uint4 v = st[b_frag + ni * 32];
-            const uint4 w = st[b_frag + KG * 256 + ni * 32];
-            bh[ni] = *reinterpret_cast<const h8*>(&v);
-            bl[ni] = *reinterpret_cast<const h8*>(&w);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // fragments are in registers
-        STAMP_T(t1);
-        // publish point: this wave's share of tile kt+1 must have landed before the barrier below
-        // (group 0 issued it two C phases ago, group 1 three: one resp. two younger tiles may still fly)
-        const int issue_tile = wm == 0 ? kt + 3 : kt + 4;       // what this wave will start in C_kt
-        if (wm == 0) {
-            if (STEADY || kt + 2 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // fragment k of the 12 of a stage, in the order the MFMAs consume them (lo*hi terms first)
+    auto read_frag = [&](Frag& f, const uint4* st, const int k) {
+        if (k < 2) {
+            const uint4 v = st[b_frag + k * 32];
+            f.bh[k] = *reinterpret_cast<const h8*>(&v);
+        } else if (k < 6) {
+            const uint4 v = st[a_frag + KG * 256 + (k - 2) * 32];
+            f.al[k - 2] = *reinterpret_cast<const h8*>(&v);
+        } else if (k < 8) {
+            const uint4 v = st[b_frag + KG * 256 + (k - 6) * 32];
+            f.bl[k - 6] = *reinterpret_cast<const h8*>(&v);
         } else {
-            if (STEADY || kt + 3 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        STAMP_T(t2);
-        PHASE_BARRIER();
-        STAMP_T(t3);
-        if (!STEADY && SCORE && kt == KT - 2) {   // every later wait is vmcnt(0): the batches land under the last K-tiles
-            load_t(0, tb0); load_t(1, tb1);      // (a third batch would spill: 186 + 48 registers)
-        }
-        // ---- phase C: 24 MFMAs; the four DMA pieces of a later tile are issued between them, where their
-        // issue cost hides behind the matrix pipe.  Target stage: (kt+3)&3 for group 0 (group 1 finished
-        // reading it one phase ago), kt&3 for group 1 (both groups have read it).
-        const bool do_dma = STEADY || issue_tile < KT;
-        const int stg = (wm == 0 ? kt + 3 : kt) & 3;
-        const uint4* pa_ = a_src + (long long)issue_tile * CHUNK16;
-        const uint4* pb_ = b_src + (long long)issue_tile * CHUNK16;
-        __builtin_amdgcn_s_setprio(1);
-        // term-major order: the eight accumulators take the lo*hi terms, then hi*lo, then hi*hi (small terms
-        // first), so that consecutive MFMAs never wait for each other's result
-#pragma unroll
-        for (int term = 0; term < 3; ++term) {
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    if (term == 0) MFMA16(acc[mi][ni], al[mi], bh[ni]);
-                    if (term == 1) MFMA16(acc[mi][ni], ah[mi], bl[ni]);
-                    if (term == 2) MFMA16(acc[mi][ni], ah[mi], bh[ni]);
-                }
-                const int piece = term * 4 + mi;         // 12 slots, the four DMA pieces go into slots 1, 4, 7, 10
-                if (piece % 3 == 1 && do_dma) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (piece == 1) DMA16(pa_, stg * STAGE16);
-                    if (piece == 4) DMA16(pa_ + 512, stg * STAGE16 + 512);
-                    if (piece == 7) DMA16(pb_, stg * STAGE16 + CHUNK16);
-                    if (piece == 10) DMA16(pb_ + 512, stg * STAGE16 + CHUNK16 + 512);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        STAMP_T(t4);
-        PHASE_BARRIER();
-        STAMP_T(t5);
-        if (STAMP) {
-            sum_read += t1 - t0; sum_wait += t2 - t1; sum_bar1 += t3 - t2; sum_mma += t4 - t3; sum_bar2 += t5 - t4;
+            const uint4 v = st[a_frag + (k - 8) * 32];
+            f.ah[k - 8] = *reinterpret_cast<const h8*>(&v);
         }
     };
+    Frag fa, fb;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) read_frag(fa, lds16, k);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PHASE_BARRIER();                             // everybody holds tile 0: stage 0 may be overwritten
+    STAMP_T(tk1);
+    unsigned long long tr1 = 0, tr2 = 0;         // 100 MHz wall clock around the main loop: in-kernel shader clock
+    if (STAMP) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr1)::"memory");
+
+    // one K-tile.  MODE 0 = steady (kt + 4 < KT): no branches between the MFMAs, where an instruction-fetch
+    // hiccup is a bubble in the matrix pipe;  1 = the guarded version for the last few tiles;  2 = the last
+    // tile (no next fragments, no DMA: its free registers take the first target batches of the epilogue).
+    auto kstep = [&](const int kt, const Frag& cur, Frag& nxt, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool STEADY = MODE == 0, LAST = MODE == 2;
+        const bool has_next = STEADY || (!LAST && kt + 1 < KT);
+        const bool do_dma = STEADY || (!LAST && kt + 4 < KT);
+        const uint4* stn = lds16 + ((kt + 1) & 3) * STAGE16;
+        const int stg = kt & 3;
+        const uint4* pa_ = a_src + (long long)(kt + 4) * CHUNK16;
+        const uint4* pb_ = b_src + (long long)(kt + 4) * CHUNK16;
+        if (LAST && SCORE) { load_t(0, tb0); load_t(1, tb1); }   // land under the MFMAs of the last tile
+        // 12 slots of two MFMAs, term-major (the eight accumulators take the lo*hi terms, then hi*lo, then
+        // hi*hi: small terms first, and consecutive MFMAs never wait for each other's result)
+#pragma unroll
+        for (int sl = 0; sl < 12; ++sl) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * sl + h, term = i >> 3, mi = (i & 7) >> 1, ni = i & 1;
+                if (term == 0) MFMA16(acc[mi][ni], cur.al[mi], cur.bh[ni]);
+                if (term == 1) MFMA16(acc[mi][ni], cur.ah[mi], cur.bl[ni]);
+                if (term == 2) MFMA16(acc[mi][ni], cur.ah[mi], cur.bh[ni]);
+            }
+            if (has_next) read_frag(nxt, stn, sl);
+            if (sl % 3 == 1 && do_dma) {
+                if (sl == 1) DMA16(pa_, stg * STAGE16);
+                if (sl == 4) DMA16(pa_ + 512, stg * STAGE16 + 512);
+                if (sl == 7) DMA16(pb_, stg * STAGE16 + CHUNK16);
+                if (sl == 10) DMA16(pb_ + 512, stg * STAGE16 + CHUNK16 + 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (LAST) return;
+        // publish tile kt+2 (read during iteration kt+1); nothing left to publish in the last two iterations
+        if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
+    };
+    using Steady = std::integral_constant<int, 0>;
+    using Tail = std::integral_constant<int, 1>;
+    using Last = std::integral_constant<int, 2>;
     int kt = 0;
-    for (; kt + 4 < KT; ++kt) kstep(kt, std::true_type{});
-    for (; kt < KT; ++kt) kstep(kt, std::false_type{});
+    for (; kt + 5 < KT; kt += 2) {
+        kstep(kt, fa, fb, Steady{});
+        kstep(kt + 1, fb, fa, Steady{});
+    }
+    for (; kt + 2 < KT; kt += 2) {
+        kstep(kt, fa, fb, Tail{});
+        kstep(kt + 1, fb, fa, Tail{});
+    }
+    kstep(kt, fa, fb, Tail{});                   // KT is even (K % 32 == 0): kt == KT - 2 here
+    kstep(kt + 1, fb, fa, Last{});
     STAMP_T(tk2);
     if (STAMP) {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr2)::"memory");
         if (lane == 0) {
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(pa.c) + wm * 16;
             atomicAdd(dbg + 6, tk1 - tk0);
-            atomicAdd(dbg + 0, sum_read); atomicAdd(dbg + 1, sum_wait); atomicAdd(dbg + 2, sum_bar1);
-            atomicAdd(dbg + 3, sum_mma); atomicAdd(dbg + 4, sum_bar2); atomicAdd(dbg + 5, (unsigned long long)KT);
+            atomicAdd(dbg + 0, tk2 - tk1);                      // main loop, shader cycles
+            atomicAdd(dbg + 14, tr2 - tr1);                     // main loop, 100 MHz ticks
+            atomicAdd(dbg + 5, (unsigned long long)KT);
         }
     }
-    if (wm == 0) { PHASE_BARRIER(); }            // group 0 pays its extra barrier at the end
     unsigned long long te0 = 0, te1 = 0, te2 = 0, te3 = 0;
     STAMP_T(te0);
 
@@ -503,8 +494,8 @@ extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rows
                                            int accumulate, lc_stream_t stream) {
     LC_REQUIRE(d_ht && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_part && d_scores,
                LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: null pointer");
-    LC_REQUIRE(A > 0 && M > 0 && M % LC_MB == 0 && n_val > 0 && n_val <= M && N > 0 && N % TK == 0, LC_E_SHAPE,
-               "lc_alpha_sweep_scores_f16x3: need M %% %d == 0, N %% %d == 0, 0 < n_val <= M", LC_MB, TK);
+    LC_REQUIRE(A > 0 && M > 0 && M % LC_MB == 0 && n_val > 0 && n_val <= M && N > 0 && N % (2 * TK) == 0,
+               LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: need M %% %d == 0, N %% %d == 0, 0 < n_val <= M", LC_MB, 2 * TK);
     LC_REQUIRE(V > 0 && V % 128 == 0, LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: V must be a multiple of 128");
     LC_REQUIRE(mode == LC_SCORE_CORR || mode == LC_SCORE_R2, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: bad mode");
     static thread_local bool attr_done = false;
@@ -535,8 +526,8 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     LC_REQUIRE(d_at && d_rowscale_inv && d_bt && d_cscale_inv && d_c && h_group_tiles, LC_E_BADARG,
                "lc_gemm_grouped_f16x3: null pointer");
     LC_REQUIRE(G >= 1 && G <= MAX_GROUPS16, LC_E_SHAPE, "lc_gemm_grouped_f16x3: G must be in 1..%d", MAX_GROUPS16);
-    LC_REQUIRE(Mrows > 0 && K > 0 && K % TK == 0 && Ncols > 0 && Ncols % TN == 0 && ldc >= Ncols, LC_E_SHAPE,
-               "lc_gemm_grouped_f16x3: need K %% %d == 0 and Ncols %% %d == 0", TK, TN);
+    LC_REQUIRE(Mrows > 0 && K > 0 && K % (2 * TK) == 0 && Ncols > 0 && Ncols % TN == 0 && ldc >= Ncols, LC_E_SHAPE,
+               "lc_gemm_grouped_f16x3: need K %% %d == 0 and Ncols %% %d == 0", 2 * TK, TN);
     static thread_local bool attr_done = false;
     if (!attr_done) {
         LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<false, false>),
@@ -569,8 +560,8 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
 }
 
 // Diagnostics: the score kernel with s_memtime stamps (not part of the product path; see tools/gpu_kernel_bench.py).
-// d_stamps: 32 x uint64, zeroed by the caller: [group][read, dma-wait, barrier1, mfma, barrier2, iterations, prologue,
-// epilogue, catch-up barrier, step 0, steps 1-6, step 7, store drain, -, -, -].
+// d_stamps: 32 x uint64, zeroed by the caller: [wave group][main loop cycles, -, -, -, -, K-tiles, prologue, epilogue,
+// -, epilogue step 0, steps 1-6, step 7, store drain, step 0 repeated, main loop 100 MHz ticks, -].
 extern "C" int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N, const void* d_yt,
                                        const float* d_cscale_inv, const float* d_yv, int64_t V, int n_val,
                                        const float* d_ystat, float* d_part,

@@ -102,14 +102,12 @@ if "sweep16" in what:
         torch.cuda.synchronize()
         h = st.cpu().numpy().reshape(2, 16)
         for g_ in range(2):
-            it = max(int(h[g_, 5]), 1)
-            names = ["frag reads", "dma wait", "barrier L", "mfma+dma issue", "barrier C"]
-            print(f"   group {g_}: cycles per iteration and wave: " + ", ".join(f"{n} {h[g_, i] / it:.0f}" for i, n in enumerate(names))
-                  + f"  | total {sum(h[g_, :5]) / it:.0f}")
-            nw = it / 120                     # waves x tiles that contributed (KT = 120 iterations each)
-            print(f"      per tile and wave: prologue {h[g_, 6] / nw:.0f}, main loop {sum(h[g_, :5]) / nw:.0f}, "
-                  f"epilogue {h[g_, 7] / nw:.0f} cycles (catch-up barrier {h[g_, 8] / nw:.0f}, step 0 {h[g_, 9] / nw:.0f}, step 0 again {h[g_, 13] / nw:.0f}, "
-                  f"steps 1-6 {h[g_, 10] / nw:.0f}, step 7 {h[g_, 11] / nw:.0f}, drain {h[g_, 12] / nw:.0f})")
+            nw = max(int(h[g_, 5]), 1) / 120              # waves x tiles that contributed (KT = 120 each)
+            ghz = h[g_, 0] / max(h[g_, 14], 1) * 0.1
+            print(f"   waves {4 * g_}-{4 * g_ + 3}: per tile and wave: prologue {h[g_, 6] / nw:.0f}, main loop {h[g_, 0] / nw:.0f} "
+                  f"({h[g_, 0] / nw / 120:.0f} per K-tile; in-kernel clock {ghz:.2f} GHz), epilogue {h[g_, 7] / nw:.0f} cycles "
+                  f"(step 0 {h[g_, 9] / nw:.0f}, again {h[g_, 13] / nw:.0f}, steps 1-6 {h[g_, 10] / nw:.0f}, "
+                  f"step 7 {h[g_, 11] / nw:.0f}, drain {h[g_, 12] / nw:.0f})")
 
 if "lanczos" in what:
     rng = np.random.default_rng(0)
