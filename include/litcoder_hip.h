@@ -194,6 +194,14 @@ int lc_batch_series_hat(const double* d_k, int64_t ldk, const int32_t* d_tr, con
                         const int32_t* d_aidx, int S, int A, int normalpha, int terms,
                         double* d_work, float* d_h, lc_stream_t stream);
 
+/* The shared matrix powers of that series themselves, scaled:  P'_j = K[va,tr] K[tr,tr]^j / scale_f^(j+1),
+ * j < terms <= 8, as f32 in d_p (F, terms, M, N).  With T_j = P'_j Y the prediction of every series alpha is
+ * sum_j (-1)^j rho^(j+1) T_j, rho = scale_f / a^2: ONE (terms*M x N x V) contraction serves all those alphas
+ * (lc_series_scores).  d_scale: (F) f64 (lambda_max under normalpha).  d_work: F*N*N + terms*F*M*N doubles. */
+int lc_batch_series_terms(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
+                          int F, int N, int M, const double* d_scale, int terms,
+                          double* d_work, float* d_p, lc_stream_t stream);
+
 /* rhs[f] (p x N) f64 <- X[tr_f]' for the refit systems (rows of X listed in d_tr, -1 -> 0). */
 int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_tr, int N, int64_t p,
                           double* d_out, lc_stream_t stream);
@@ -244,6 +252,16 @@ int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, i
                                 const float* d_yv, int64_t V, int n_val,
                                 const float* d_ystat, const float* d_yblk,
                                 int mode, float* d_part, float* d_scores, int accumulate, lc_stream_t stream);
+
+/* Correlation scores (mode LC_SCORE_CORR, same formula and nan_to_num as lc_alpha_sweep_scores) of S series
+ * alphas of ONE inner fold from d_t (terms*M, ldt) f32 = the stacked T_j = P'_j Y (lc_batch_series_terms +
+ * lc_gemm_grouped_f16x3 / lc_gemm_grouped_f32): per voxel the fp64 moments of the T_j over the n_val
+ * validation rows give mean, variance and covariance with y of every alpha's prediction as linear / quadratic
+ * forms.  d_scale: (1) f64 scale of this fold, d_a2: (A) f64 penalties a^2 of this fold, d_aidx: (S) rows of
+ * d_scores (A, V) f32 that receive (or accumulate) the scores.  d_yv, d_ystat as produced by lc_val_stats. */
+int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val, int64_t V,
+                     const float* d_yv, const float* d_ystat, const double* d_scale, const double* d_a2,
+                     const int32_t* d_aidx, int S, float* d_scores, int accumulate, lc_stream_t stream);
 
 /* Diagnostics only (tools/gpu_kernel_bench.py stamps): the fp16x3 sweep with s_memtime stamps at its phase
  * boundaries; d_stamps (32 x uint64, caller-zeroed) receives per wave-group sums of the five segments of an

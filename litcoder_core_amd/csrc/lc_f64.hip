@@ -601,6 +601,20 @@ __global__ void __launch_bounds__(256) k_series_hat(const double* __restrict__ P
     }
 }
 
+// P'_j[f] = P_j[f] / scale[f]^(j+1) as f32, laid out (F, terms, M, N): the shared matrix powers themselves, for
+// callers that contract them with the targets once and combine the per-alpha predictions afterwards.
+__global__ void __launch_bounds__(256) k_series_terms(const double* __restrict__ P, long long p_stride, int terms,
+                                                      const double* __restrict__ scale, int M, int N,
+                                                      float* __restrict__ out) {
+    const int i = blockIdx.x, t = blockIdx.y, f = blockIdx.z;
+    const double inv = 1.0 / scale[f];
+    double w = inv;
+    for (int k = 0; k < t; ++k) w *= inv;
+    const double* src = P + (long long)t * p_stride + ((long long)f * M + i) * N;
+    float* dst = out + (((long long)f * terms + t) * M + i) * N;
+    for (int j = threadIdx.x; j < N; j += 256) dst[j] = (float)(src[j] * w);
+}
+
 }  // namespace
 
 extern "C" int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_k, int64_t ldk,
@@ -709,6 +723,26 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
     if (int rc = lc::launched("back substitution")) return rc;
     hipLaunchKernelGGL(k_extract_h, dim3(M, B), dim3(256), 0, s, d_aug, N, M, d_h, d_slot);
     return lc::launched("k_extract_h");
+}
+
+extern "C" int lc_batch_series_terms(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va, int F,
+                                     int N, int M, const double* d_scale, int terms, double* d_work, float* d_p,
+                                     lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_tr && d_va && d_scale && d_work && d_p, LC_E_BADARG, "lc_batch_series_terms: null pointer");
+    LC_REQUIRE(F > 0 && F <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0 && terms >= 1 && terms <= 8,
+               LC_E_SHAPE, "lc_batch_series_terms: need N %% %d == 0, M %% %d == 0, 1 <= terms <= 8", LC_NB, LC_MB);
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_SERIES, s);
+    double* Kf = d_work;                                   // (F, N, N), then P_0 .. P_{terms-1}, each (F, M, N)
+    double* P = d_work + (long long)F * N * N;
+    const long long p_stride = (long long)F * M * N;
+    hipLaunchKernelGGL(k_gather_sub, dim3(N, F), dim3(256), 0, s, d_k, (long long)ldk, d_tr, d_tr, N, N, Kf);
+    hipLaunchKernelGGL(k_gather_sub, dim3(M, F), dim3(256), 0, s, d_k, (long long)ldk, d_va, d_tr, M, N, P);
+    for (int t = 1; t < terms; ++t)
+        hipLaunchKernelGGL(k_gemm_f64_nn, dim3(N / NB, lc::ceil_div(M, NB), F), dim3(256), 0, s, P + (t - 1) * p_stride, Kf,
+                           P + t * p_stride, M, N, N);
+    hipLaunchKernelGGL(k_series_terms, dim3(M, terms, F), dim3(256), 0, s, P, p_stride, terms, d_scale, M, N, d_p);
+    return lc::launched("lc_batch_series_terms");
 }
 
 extern "C" int lc_batch_series_hat(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va, int F, int N,

@@ -286,6 +286,98 @@ __global__ void __launch_bounds__(256) k_score_finalize(const float* __restrict_
     *dst = accumulate ? *dst + score : score;
 }
 
+// ---- correlation scores of the series alphas from the moments of the shared terms ------------------------------
+// For the alphas on the Neumann series the prediction is a fixed linear combination of `terms` matrices
+//     pred_s = sum_j c_sj T_j,   T_j = P'_j Y (M x V, one GEMM for all those alphas),   c_sj = (-1)^j rho_s^(j+1),
+// rho_s = scale / a_s^2, so every statistic the score needs is a linear or quadratic form in the moments of the
+// T_j over the validation rows:  mean_s = c.m,  M2_s = c' S c,  cov_s = c.C  (S the terms' scatter matrix, C their
+// co-moments with y).  One pass over T in fp64 (shifted by the first row) gives all of them for every alpha.
+// Block: 64 columns x 4 row groups; same shift in every group, so the groups' raw sums simply add.
+template <int TERMS>
+__global__ void __launch_bounds__(256) k_series_scores(const float* __restrict__ T, long long ldt, int M, int n_val,
+                                                       long long V, const float* __restrict__ yv,
+                                                       const float* __restrict__ ystat, const double* __restrict__ scale,
+                                                       const double* __restrict__ a2, const int* __restrict__ aidx, int S,
+                                                       float* __restrict__ scores, int accumulate) {
+    constexpr int NB2 = TERMS * (TERMS + 1) / 2, NACC = 2 * TERMS + NB2 + 1;
+    __shared__ double red[3][NACC][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long long c = (long long)blockIdx.x * 64 + lane;
+    const bool live = c < V;
+    const long long cc = live ? c : 0;
+    double sh[TERMS], a[TERMS], cy[TERMS], b[NB2], ay = 0.0;
+#pragma unroll
+    for (int j = 0; j < TERMS; ++j) { sh[j] = (double)T[(long long)j * M * ldt + cc]; a[j] = 0.0; cy[j] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < NB2; ++k) b[k] = 0.0;
+    const double shy = (double)yv[lc::yv_index(0, cc, V)];
+    for (int i = g; i < n_val; i += 4) {
+        const double dy = (double)yv[lc::yv_index(i, cc, V)] - shy;
+        double d[TERMS];
+#pragma unroll
+        for (int j = 0; j < TERMS; ++j) d[j] = (double)T[((long long)j * M + i) * ldt + cc] - sh[j];
+        ay += dy;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < TERMS; ++j) {
+            a[j] += d[j];
+            cy[j] += d[j] * dy;
+#pragma unroll
+            for (int l = j; l < TERMS; ++l) b[k++] += d[j] * d[l];
+        }
+    }
+    if (g > 0) {
+#pragma unroll
+        for (int j = 0; j < TERMS; ++j) { red[g - 1][j][lane] = a[j]; red[g - 1][TERMS + j][lane] = cy[j]; }
+#pragma unroll
+        for (int k = 0; k < NB2; ++k) red[g - 1][2 * TERMS + k][lane] = b[k];
+        red[g - 1][NACC - 1][lane] = ay;
+    }
+    __syncthreads();
+    if (g != 0 || !live) return;
+    for (int q = 0; q < 3; ++q) {                        // fixed order: deterministic
+#pragma unroll
+        for (int j = 0; j < TERMS; ++j) { a[j] += red[q][j][lane]; cy[j] += red[q][TERMS + j][lane]; }
+#pragma unroll
+        for (int k = 0; k < NB2; ++k) b[k] += red[q][2 * TERMS + k][lane];
+        ay += red[q][NACC - 1][lane];
+    }
+    // centred moments
+    const double n = (double)n_val;
+    {
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < TERMS; ++j) {
+            cy[j] -= a[j] * ay / n;
+#pragma unroll
+            for (int l = j; l < TERMS; ++l) { b[k] -= a[j] * a[l] / n; ++k; }
+        }
+    }
+    const double sy = (double)ystat[V + c];
+    for (int s = 0; s < S; ++s) {
+        const double rho = scale[0] / a2[aidx[s]];
+        double coef[TERMS];
+        double w = rho;
+#pragma unroll
+        for (int j = 0; j < TERMS; ++j) { coef[j] = (j & 1) ? -w : w; w *= rho; }
+        double m2 = 0.0, cov = 0.0;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < TERMS; ++j) {
+            cov += coef[j] * cy[j];
+#pragma unroll
+            for (int l = j; l < TERMS; ++l) { m2 += (l == j ? 1.0 : 2.0) * coef[j] * coef[l] * b[k]; ++k; }
+        }
+        const double sp = sqrt(fmax(m2, 0.0) / (n - 1.0));
+        float score = (float)(cov / (n * (sy + 1e-8) * (sp + 1e-8)));
+        if (score != score) score = 0.f;
+        else if (score > 3.4028234663852886e38f) score = 3.4028234663852886e38f;
+        else if (score < -3.4028234663852886e38f) score = -3.4028234663852886e38f;
+        float* dst = scores + (long long)aidx[s] * V + c;
+        *dst = accumulate ? *dst + score : score;
+    }
+}
+
 int check_gemm_shapes(const char* who, const void* a, long long lda, const void* b, long long ldb, long long Ncols,
                       long long K) {
     LC_REQUIRE(K > 0 && K % BK == 0, LC_E_SHAPE, "%s: K=%lld must be a positive multiple of %d", who, K, BK);
@@ -349,6 +441,30 @@ extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, cons
     }
     if (int rc = lc::launched("k_gemm_f32<score>")) return rc;
     return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, n_val, (long long)V, mode, d_scores, accumulate, s);
+}
+
+extern "C" int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val, int64_t V, const float* d_yv,
+                                const float* d_ystat, const double* d_scale, const double* d_a2, const int32_t* d_aidx,
+                                int S, float* d_scores, int accumulate, lc_stream_t stream) {
+    LC_REQUIRE(d_t && d_yv && d_ystat && d_scale && d_a2 && d_aidx && d_scores, LC_E_BADARG,
+               "lc_series_scores: null pointer");
+    LC_REQUIRE(terms >= 1 && terms <= 8 && M > 0 && M % LC_MB == 0 && n_val > 1 && n_val <= M && V > 0 && ldt >= V &&
+                   S > 0,
+               LC_E_SHAPE, "lc_series_scores: need 1 <= terms <= 8, M %% %d == 0, 1 < n_val <= M, ldt >= V", LC_MB);
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_SWEEP_FINALIZE, s);
+    const dim3 grid((unsigned)lc::ceil_div<long long>(V, 64)), block(256);
+#define LC_SERIES_CASE(t_)                                                                                             \
+    case t_:                                                                                                           \
+        hipLaunchKernelGGL((k_series_scores<t_>), grid, block, 0, s, d_t, (long long)ldt, M, n_val, (long long)V, d_yv,  \
+                           d_ystat, d_scale, d_a2, d_aidx, S, d_scores, accumulate);                                   \
+        break;
+    switch (terms) {
+        LC_SERIES_CASE(1) LC_SERIES_CASE(2) LC_SERIES_CASE(3) LC_SERIES_CASE(4)
+        LC_SERIES_CASE(5) LC_SERIES_CASE(6) LC_SERIES_CASE(7) LC_SERIES_CASE(8)
+    }
+#undef LC_SERIES_CASE
+    return lc::launched("k_series_scores");
 }
 
 extern "C" int lc_gemm_grouped_f32(const float* d_a, int64_t lda, int64_t a_group_stride, const float* d_b, int64_t ldb,

@@ -89,6 +89,12 @@ class RidgeCVEngine:
         self.dX = self._resident(X_all, self.p_pad)
         self.dY = self._resident(Y_all, self.Vp)
         self.d_alphas = torch.tensor(self.alphas, dtype=torch.float64, device=self.dev)
+        # alphas whose penalty dwarfs the spectrum take the Neumann series (shared matrix powers), the rest the
+        # batched Cholesky; rho = lambda_max / a^2 = 1 / alpha^2 under normalpha
+        self.ser = [a for a in range(self.A) if self.normalpha and self.alphas[a] ** (-2 * SERIES_TERMS) <= SERIES_TOL]
+        self.cho = [a for a in range(self.A) if a not in self.ser]
+        self.d_ser = torch.tensor(self.ser, dtype=torch.int32, device=self.dev) if self.ser else None
+        self.d_cho = torch.tensor(self.cho, dtype=torch.int32, device=self.dev)
         self.K = None if self.norm_x else ops.gram(self.dX, self.Ttot, self.p)
         self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
         self.aux = torch.cuda.Stream(device=self.dev)
@@ -168,10 +174,17 @@ class RidgeCVEngine:
         return [(lm[s:s + n], lm[s + n:s + n + 1]) for s, n in spans]
 
     # -------------------------------------------------------------- inner CV: hat matrices, then the sweeps
-    def _hat_matrices(self, K, inner_abs, lmax=None):
+    def _series_by_moments(self, Y):
+        """Score the series alphas from the moments of the shared terms T_j = P'_j Y (one contraction for all of
+        them, lc_series_scores) instead of one hat matrix per alpha: correlation scoring on the fp16x3 path only
+        (the R2 score needs the elementwise fl32 residual, see lc_epilogue.h)."""
+        return self.normalpha and self.mode == LC_SCORE_CORR and self._use_split(Y)
+
+    def _hat_matrices(self, K, inner_abs, lmax=None, moments=False):
         """V-independent part of the inner CV of one outer fold: row lists, S[0]^2 (Lanczos), penalties and the
         hat matrices H_alpha of every (inner fold, alpha) -- batched Cholesky for the small alphas, the shared
-        Neumann series for the large ones.  Returns a dict the sweeps consume."""
+        Neumann series for the large ones (as hat matrices, or with ``moments`` as the scaled matrix powers
+        themselves).  Returns a dict the sweeps consume."""
         F, A = len(inner_abs), self.A
         n_i = [len(t) for t, _ in inner_abs]
         n_v = [len(v) for _, v in inner_abs]
@@ -184,67 +197,92 @@ class RidgeCVEngine:
         if self.normalpha and lmax is None:
             lmax = self.lmax_systems(K, [t for t, _ in inner_abs])
         a2 = ops.penalties(lmax, F, self.d_alphas, self.normalpha)
-        # alphas whose penalty dwarfs the spectrum take the Neumann series (shared matrix powers), the
-        # rest the batched Cholesky; rho = lambda_max / a^2 = 1 / alpha^2 under normalpha
-        ser = [a for a in range(A) if self.normalpha and self.alphas[a] ** (-2 * SERIES_TERMS) <= SERIES_TOL]
-        cho = [a for a in range(A) if a not in ser]
-        d_ser = torch.tensor(ser, dtype=torch.int32, device=self.dev) if ser else None
+        ser, cho, d_ser = self.ser, self.cho, self.d_ser
+        moments = bool(moments and ser and min(n_v) > 1)
         Ac = len(cho)
+        slots = Ac if moments else A                     # hat matrices kept per inner fold
         per_sys = (N + M) * N * 8
         chunk = max(1, min(F, AUG_BUDGET_BYTES // max(1, per_sys * max(Ac, 1))))
         infos, Hs = [], []
         for f0 in range(0, F, chunk):
             fc = min(chunk, F - f0)
-            H = torch.empty((fc * A, M, N), dtype=torch.float32, device=self.dev)
+            H = torch.empty((fc * slots, M, N), dtype=torch.float32, device=self.dev) if slots else None
+            P = None
             if Ac:
                 aug = torch.empty((fc * Ac, N + M, N), dtype=torch.float64, device=self.dev)
-                a2c = a2[f0 * A:(f0 + fc) * A].reshape(fc, A)[:, cho].reshape(-1).contiguous()
-                slot = (torch.arange(fc, device=self.dev, dtype=torch.int32).reshape(fc, 1) * A
-                        + torch.tensor(cho, dtype=torch.int32, device=self.dev).reshape(1, Ac)).reshape(-1).contiguous()
+                a2c = a2[f0 * A:(f0 + fc) * A].reshape(fc, A).index_select(1, self.d_cho.to(torch.int64)).reshape(-1)
+                slot = None if moments else (
+                    torch.arange(fc, device=self.dev, dtype=torch.int32).reshape(fc, 1) * A
+                    + self.d_cho.reshape(1, Ac)).reshape(-1).contiguous()
                 ops.batch_assemble(K, tr[f0:f0 + fc], va[f0:f0 + fc], None, a2c, fc, Ac, N, M, aug)
                 infos.append(ops.batch_chol_solve(aug, fc * Ac, N, M, H, slot))
                 del aug
-            if ser:
+            if ser and moments:
+                P = torch.empty((fc, SERIES_TERMS * M, N), dtype=torch.float32, device=self.dev)
+                ops.batch_series_terms(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], SERIES_TERMS, P)
+            elif ser:
                 ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M,
                                      lmax[f0:f0 + fc] if lmax is not None else None, self.d_alphas[ser], d_ser, A,
                                      self.normalpha, SERIES_TERMS, H)
-            Hs.append((f0, fc, H))
+            Hs.append((f0, fc, H, P))
         info = torch.cat(infos) if infos else torch.zeros(1, dtype=torch.int32, device=self.dev)
-        return dict(F=F, N=N, M=M, n_v=n_v, tr=tr, va=va, Hs=Hs, info=info, lmax=lmax, a2=a2)
+        return dict(F=F, N=N, M=M, n_v=n_v, tr=tr, va=va, Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
+                    d_ser=d_ser, moments=moments)
 
     def _sweeps(self, hat, Y):
         """Sum over inner folds of the (A, Vp) validation scores (ridge_corr_torch for every fold,
-        nested_cv.py:366-393): the V-wide fused MFMA sweeps."""
+        nested_cv.py:366-393): the V-wide fused MFMA sweeps, plus -- with ``hat["moments"]`` -- one plain
+        contraction of the shared series terms and the moment kernel for the alphas on the series."""
         A, N, M, tr, va, n_v = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"]
+        moments, cho = hat["moments"], hat["cho"]
+        Ad = len(cho) if moments else A                   # alphas that go through the fused sweep
         scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
-        part = torch.empty((A * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
+        scores_d = torch.empty((Ad, self.Vp), dtype=torch.float32, device=self.dev) if moments and Ad else scores
+        part = torch.empty((max(Ad, 1) * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
         ystat = torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev)
         yblk = torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
         yv = torch.empty((M, self.Vp), dtype=torch.float32, device=self.dev)
         split = self._use_split(Y)
-        LAST_SWEEP["precision"] = "f16x3" if split else "f32"
+        LAST_SWEEP.update(precision="f16x3" if split else "f32", fused_alphas=Ad,
+                          series_terms=SERIES_TERMS if moments else 0)
         if split:
-            rows_pad = ops.pad_to(A * M, 256)
+            rows_pad = ops.pad_to(max(Ad, 1) * M, 256)
             cs = self._cs
             Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
             rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
-            Yt = torch.empty(ops.pad_to(self.Vp, 256) * N * 2, dtype=torch.float16, device=self.dev)
-        for f0, fc, H in hat["Hs"]:
+            Vt = ops.pad_to(self.Vp, 256)
+            Yt = torch.empty(Vt * N * 2, dtype=torch.float16, device=self.dev)
+        if moments:
+            Tm = SERIES_TERMS * M
+            Pt = torch.empty(ops.pad_to(Tm, 256) * N * 2, dtype=torch.float16, device=self.dev)
+            rs_p = torch.empty(ops.pad_to(Tm, 256), dtype=torch.float32, device=self.dev)
+            Tbuf = torch.empty((Tm, Vt), dtype=torch.float32, device=self.dev)
+            cs_inv = torch.ones(Vt, dtype=torch.float32, device=self.dev)      # padded to the plain GEMM's tiles
+            cs_inv[: self.Vp] = cs[self.Vp:]
+        for f0, fc, H, P in hat["Hs"]:
             for j in range(fc):
                 f = f0 + j
                 ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk, yv)
                 if split:
-                    ops.split_rows_f16(H[j * A:(j + 1) * A].reshape(A * M, N), A * M, N, Ht, rs_inv)
                     ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt)
-                    ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, N, Yt, cs[self.Vp:], yv, self.Vp, n_v[f], ystat, yblk,
-                                                 self.mode, part, scores, accumulate=f > 0)
+                    if Ad:
+                        ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
+                        ops.alpha_sweep_scores_f16x3(Ht, rs_inv, Ad, M, N, Yt, cs[self.Vp:], yv, self.Vp, n_v[f], ystat,
+                                                     yblk, self.mode, part, scores_d, accumulate=f > 0)
+                    if moments:
+                        ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
+                        ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt, cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256])
+                        ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv, ystat, hat["lmax"][f:f + 1],
+                                          hat["a2"][f * A:(f + 1) * A], hat["d_ser"], scores, accumulate=f > 0)
                 else:
                     ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], yv, n_v[f], ystat, yblk,
                                            self.mode, part, scores, accumulate=f > 0)
+        if moments and Ad:
+            scores.index_copy_(0, self.d_cho.to(torch.int64), scores_d)
         return scores
 
     def _alpha_scores(self, K, Y, inner_abs):
-        hat = self._hat_matrices(K, inner_abs)
+        hat = self._hat_matrices(K, inner_abs, moments=self._series_by_moments(Y))
         return self._sweeps(hat, Y), hat["info"]
 
     # -------------------------------------------------------------- alpha selection
@@ -260,58 +298,85 @@ class RidgeCVEngine:
         return ops.select_alpha(scores, self.A, self.Vp)[0]
 
     # -------------------------------------------------------------- refit (ridge_torch)
-    def refit(self, X, Y, K, tr_rows, best, extra_rows=(), tr_o=None, lmax_o=None):
-        """Weights of every voxel at its chosen alpha, in alpha-sorted voxel order
-        (ridge_regression.py:9-63).  Returns (Ws (p_pad, Vs), Ys (N_o + len(extra_rows), Vs), perm,
-        N_o): column j of Ws / Ys is voxel perm[j] (-1 = padding).  ``extra_rows`` of Y are gathered
-        below the training rows in the same voxel order (the test targets)."""
-        A, V = self.A, self.V
-        split = self._use_split(Y)
+    # three steps, so that the driver can put the fp64 systems on the auxiliary stream beside the next fold's
+    # sweeps: groups (argmax histogram -> host), systems (M_alpha of the alphas in use), apply (V-wide GEMM)
+    def _refit_groups(self, best, split):
+        """Voxels sorted by chosen alpha: (perm, used alphas, column-tile offsets per group, Vs).  The one
+        host synchronisation of a fold: the histogram decides how many systems the refit solves."""
         tile = 256 if split else COL_TILE                 # column-tile width of the GEMM that follows
-        perm, count = ops.group_by_alpha(best, V, A, tile)
+        perm, count = ops.group_by_alpha(best, self.V, self.A, tile)
         count_h = count.cpu().numpy()
-        used = [a for a in range(A) if count_h[a] > 0]
+        used = [a for a in range(self.A) if count_h[a] > 0]
         tiles = [0]
         for a in used:
             tiles.append(tiles[-1] + (int(count_h[a]) + tile - 1) // tile)
-        Vs, G = tiles[-1] * tile, len(used)
-        n_o = len(tr_rows)
+        return perm, used, tiles, tiles[-1] * tile
+
+    def _refit_systems(self, X, K, tr_rows, used, tr_o=None, lmax_o=None, te_rows=()):
+        """Per alpha in use, the rows  [Xtr' ; K[te,tr]] (K[tr,tr] + a^2 I)^-1  as f32 (G, p_pad + pad32(n_te), N_o):
+        M_alpha, whose product with the targets is the weight matrix (the V-independent half of
+        ridge_regression.py:46-61), and below it the hat matrix of the test rows, whose product with the same
+        targets is the test prediction X_te W (nested_cv.py:151,251) -- one V-wide contraction gives both.
+        Augmented batched Cholesky in fp64."""
+        G = len(used)
+        n_o, n_t = len(tr_rows), len(te_rows)
         N_o = ops.pad_to(n_o, LC_NB)
+        rows = self.p_pad + ops.pad_to(n_t, LC_MB)
         if tr_o is None:
             tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
             lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
-        a2_o = ops.penalties(lmax_o, 1, self.d_alphas[used], self.normalpha)
-        rhs = torch.zeros((self.p_pad, N_o), dtype=torch.float64, device=self.dev)
+        a2_o = ops.penalties(lmax_o, 1, self.d_alphas.index_select(0, ops.upload(np.asarray(used, dtype=np.int64), self.dev)),
+                             self.normalpha)
+        rhs = torch.zeros((rows, N_o), dtype=torch.float64, device=self.dev)
         ops.transpose_rows(X, tr_o, N_o, self.p, rhs)
-        aug = torch.empty((G, N_o + self.p_pad, N_o), dtype=torch.float64, device=self.dev)
-        ops.batch_assemble(K, tr_o, None, rhs, a2_o, 1, G, N_o, self.p_pad, aug)
-        Malpha = torch.empty((G, self.p_pad, N_o), dtype=torch.float32, device=self.dev)
-        info = ops.batch_chol_solve(aug, G, N_o, self.p_pad, Malpha)
-        del aug, rhs
+        if n_t:
+            te64 = ops.upload(np.asarray(te_rows, dtype=np.int64), self.dev)
+            tr64 = ops.upload(np.asarray(tr_rows, dtype=np.int64), self.dev)
+            rhs[self.p_pad:self.p_pad + n_t, :n_o] = K.index_select(0, te64).index_select(1, tr64)
+        aug = torch.empty((G, N_o + rows, N_o), dtype=torch.float64, device=self.dev)
+        ops.batch_assemble(K, tr_o, None, rhs, a2_o, 1, G, N_o, rows, aug)
+        Malpha = torch.empty((G, rows, N_o), dtype=torch.float32, device=self.dev)
+        info = ops.batch_chol_solve(aug, G, N_o, rows, Malpha)
+        return Malpha, info
+
+    def _refit_apply(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split):
+        """C (rows, Vs) = [M_alpha ; H_te,alpha](group) . Ys -- the weights in its first p_pad rows, the test
+        predictions below -- and Ys (N_o + len(extra_rows), Vs): the targets gathered in alpha-sorted voxel
+        order (``extra_rows``, the test targets, below the training rows)."""
+        G, rows, n_o = Malpha.shape[0], Malpha.shape[1], len(tr_rows)
+        N_o = ops.pad_to(n_o, LC_NB)
         n_x = len(extra_rows)
         rows_s = ops.idx_tensor(np.concatenate([tr_rows, np.full(N_o - n_o, -1), np.asarray(extra_rows, dtype=np.int64)]),
                                 N_o + n_x, self.dev)
         Ys = torch.empty((N_o + n_x, Vs), dtype=torch.float32, device=self.dev)
         ops.gather(Y, self.Vp, rows_s, N_o + n_x, perm, Vs, Ys)
-        Ws = torch.empty((self.p_pad, Vs), dtype=torch.float32, device=self.dev)
+        C = torch.empty((rows, Vs), dtype=torch.float32, device=self.dev)
         if split:
-            # weights on the fp16x3 MFMA path: split every group's M_alpha by rows, the sorted targets by
-            # columns (their scales follow the voxels through the permutation), one grouped launch
-            rows_pad = ops.pad_to(self.p_pad, 256)
+            # on the fp16x3 MFMA path: split every group's rows, the sorted targets by columns (their scales
+            # follow the voxels through the permutation), one grouped launch
+            rows_pad = ops.pad_to(rows, 256)
             At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
             rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
             for g in range(G):
-                ops.split_rows_f16(Malpha[g], self.p_pad, N_o, At[g * rows_pad * N_o * 2:], rs_inv[g * rows_pad:])
+                ops.split_rows_f16(Malpha[g], rows, N_o, At[g * rows_pad * N_o * 2:], rs_inv[g * rows_pad:])
             cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)
             ops.gather(self._cs.reshape(2, self.Vp), self.Vp, None, 2, perm, Vs, cs_s)
             Yt = torch.empty(Vs * N_o * 2, dtype=torch.float16, device=self.dev)
             ops.split_cols_f16(Ys, Vs, torch.arange(N_o, dtype=torch.int32, device=self.dev), N_o, cs_s[0], Yt)
-            ops.gemm_grouped_f16x3(At, rs_inv, self.p_pad, Yt, cs_s[1], Ws, Vs, Vs, N_o, tiles)
+            ops.gemm_grouped_f16x3(At, rs_inv, rows, Yt, cs_s[1], C, Vs, Vs, N_o, tiles)
         else:
-            ops.gemm_grouped(Malpha, N_o, self.p_pad * N_o, Ys, Vs, None, Ws, Vs, self.p_pad, Vs, N_o, tiles)
-        if int(info.cpu().numpy().any()):
-            raise RuntimeError("Cholesky failed in the refit: Gram matrix + alpha^2 I is not positive definite")
-        return Ws, Ys, perm, N_o
+            ops.gemm_grouped(Malpha, N_o, rows * N_o, Ys, Vs, None, C, Vs, rows, Vs, N_o, tiles)
+        return C, Ys, N_o
+
+    def refit(self, X, Y, K, tr_rows, best, extra_rows=(), tr_o=None, lmax_o=None):
+        """Weights of every voxel at its chosen alpha, in alpha-sorted voxel order
+        (ridge_regression.py:9-63), all on the current stream.  Returns (Ws (p_pad, Vs), Ys, perm, N_o, info):
+        column j of Ws / Ys is voxel perm[j] (-1 = padding)."""
+        split = self._use_split(Y)
+        perm, used, tiles, Vs = self._refit_groups(best, split)
+        Malpha, info = self._refit_systems(X, K, tr_rows, used, tr_o, lmax_o)
+        Ws, Ys, N_o = self._refit_apply(Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split)
+        return Ws[: self.p_pad], Ys, perm, N_o, info
 
     def unsort(self, vec_sorted, perm, Vs):
         """Sorted-voxel-order host vector -> natural voxel order."""
@@ -321,11 +386,11 @@ class RidgeCVEngine:
         out[perm_h[live]] = vec_sorted[live]
         return out
 
-    # -------------------------------------------------------------- one outer fold, in three phases
-    # begin (async: inner-CV sweeps) -> refit (one sync on the alpha histogram, then async refit /
-    # prediction / Pearson / D2H) -> collect (wait for the fold's results).  The caller interleaves
-    # the phases of consecutive folds so that the host statistics of fold f run while the GPU works
-    # on fold f+1.
+    # -------------------------------------------------------------- one outer fold, in phases
+    # prepare (aux stream: fp64, V-independent) -> begin (main: inner-CV sweeps) -> select (one sync on the alpha
+    # histogram; refit systems on aux) -> finish (main: V-wide refit, prediction, Pearson, D2H) -> collect (wait
+    # for the fold's results).  The caller interleaves the phases of consecutive folds so that the main stream
+    # always has MFMA work, the auxiliary stream the fp64 work, and the host statistics of fold f run meanwhile.
     def fold_prepare(self, tr_rows, te_rows, inner_rel, lmax_pre=None):
         """Everything of an outer fold that does not touch the voxel axis beyond O(V) copies -- train-statistics
         normalisation, Lanczos, the batched Cholesky / series hat matrices -- enqueued on the engine's AUXILIARY
@@ -349,12 +414,13 @@ class RidgeCVEngine:
                     lm = self.lmax_systems(K, [t for t, _ in inner_abs] + [tr_rows])
                     lmax_pre = (lm[:len(inner_abs)], lm[len(inner_abs):])
                 lmax_i, lmax_o = lmax_pre
-            hat = self._hat_matrices(K, inner_abs, lmax_i)
+            hat = self._hat_matrices(K, inner_abs, lmax_i, self._series_by_moments(Y))
             N_o = ops.pad_to(len(tr_rows), LC_NB)
             tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
             done = torch.cuda.Event()
             done.record()
-        for t in [X, Y, K, hat["tr"], hat["va"], hat["info"], tr_o, lmax_o] + [h for _, _, h in hat["Hs"]]:
+        for t in ([X, Y, K, hat["tr"], hat["va"], hat["info"], hat["a2"], hat["lmax"], hat["d_ser"], tr_o, lmax_o]
+                  + [h for _, _, h, _ in hat["Hs"]] + [q for _, _, _, q in hat["Hs"]]):
             if t is not None and t.is_cuda:
                 t.record_stream(main)                  # allocated on aux, consumed on main
         return dict(tr=tr_rows, te=te_rows, X=X, Y=Y, K=K, hat=hat, done=done, tr_o=tr_o, lmax_o=lmax_o)
@@ -366,19 +432,35 @@ class RidgeCVEngine:
         st["info"] = st["hat"]["info"]
         return st
 
-    def fold_refit(self, st, single_alpha, weight_scale):
-        tr_rows, te_rows, X, Y, K = st["tr"], st["te"], st["X"], st["Y"], st["K"]
-        n_t = len(te_rows)
+    def fold_select(self, st, single_alpha):
+        """Alpha choice of the fold (waits for its sweeps: the histogram comes to the host) and, on the auxiliary
+        stream, the fp64 systems of the refit -- they run beside whatever the main stream does next."""
         best = self.choose(st["scores"], single_alpha)
-        Ws, Ys, perm, N_o = self.refit(X, Y, K, tr_rows, best, te_rows, st.get("tr_o"), st.get("lmax_o"))
-        if int(st["info"].cpu().numpy().any()):
-            raise RuntimeError("Cholesky failed: Gram matrix + alpha^2 I is not positive definite")
-        Vs = Ws.shape[1]
-        # ---- test predictions and per-voxel Pearson r (nested_cv.py:151-155, 251-257)
-        Xte = torch.empty((n_t, self.p_pad), dtype=torch.float32, device=self.dev)
-        ops.gather(X, self.p_pad, ops.idx_tensor(te_rows, n_t, self.dev), n_t, None, self.p_pad, Xte)
-        pred = torch.empty((n_t, Vs), dtype=torch.float32, device=self.dev)
-        ops.gemm_grouped(Xte, self.p_pad, 0, Ws, Vs, None, pred, Vs, n_t, Vs, self.p_pad, [0, Vs // COL_TILE])
+        split = self._use_split(st["Y"])
+        perm, used, tiles, Vs = self._refit_groups(best, split)
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.aux):                  # inputs: X, K, tr_o, lmax_o -- all made on aux or at start
+            Malpha, info_o = self._refit_systems(st["X"], st["K"], st["tr"], used, st.get("tr_o"), st.get("lmax_o"),
+                                                 st["te"])
+            ready = torch.cuda.Event()
+            ready.record()
+        for x in (Malpha, info_o):
+            x.record_stream(main)
+        st.update(best=best, perm=perm, used=used, tiles=tiles, Vs=Vs, split=split, Malpha=Malpha, info_o=info_o,
+                  systems_ready=ready)
+        return st
+
+    def fold_finish(self, st, weight_scale):
+        """V-wide half of the refit, test predictions, Pearson r / p-values and the D2H of the results."""
+        tr_rows, te_rows, X, Y = st["tr"], st["te"], st["X"], st["Y"]
+        n_t = len(te_rows)
+        best, perm, Vs = st["best"], st["perm"], st["Vs"]
+        torch.cuda.current_stream().wait_event(st["systems_ready"])
+        C, Ys, N_o = self._refit_apply(Y, tr_rows, te_rows, perm, st["tiles"], Vs, st["Malpha"], st["split"])
+        info_o = st["info_o"]
+        # ---- weights, test predictions (nested_cv.py:151,251: X_te W, here as the hat matrix of the test rows
+        # applied to the same targets) and per-voxel Pearson r (:152-155, 252-257)
+        Ws, pred = C[: self.p_pad], C[self.p_pad:self.p_pad + n_t]
         r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
         ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
@@ -391,12 +473,24 @@ class RidgeCVEngine:
         h_r.copy_(r_s, non_blocking=True)
         h_perm.copy_(perm[:Vs], non_blocking=True)
         h_best.copy_(best[: self.V], non_blocking=True)
+        # Cholesky pivot flags of the inner folds and of the refit: checked when the fold is collected
+        bad = torch.stack([st["info"].ne(0).any(), info_o.ne(0).any()]).to(torch.int32)
+        h_bad = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        h_bad.copy_(bad, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return dict(done=done, r=h_r, p=h_p, perm=h_perm, best=h_best, n_t=n_t, keep=(r_s, p_s, perm, best))
+        return dict(done=done, r=h_r, p=h_p, perm=h_perm, best=h_best, n_t=n_t, bad=h_bad,
+                    keep=(r_s, p_s, perm, best, bad))
+
+    def fold_refit(self, st, single_alpha, weight_scale):
+        return self.fold_finish(self.fold_select(st, single_alpha), weight_scale)
 
     def fold_collect(self, pend) -> _FoldResult:
         pend["done"].synchronize()
+        if int(pend["bad"][0]):
+            raise RuntimeError("Cholesky failed: Gram matrix + alpha^2 I is not positive definite")
+        if int(pend["bad"][1]):
+            raise RuntimeError("Cholesky failed in the refit: Gram matrix + alpha^2 I is not positive definite")
         perm_h = pend["perm"].numpy()
         live = perm_h >= 0
         r = np.empty(self.V, dtype=np.float64)
@@ -560,14 +654,19 @@ class NestedCVModel(BasePredictivityModel):
 
         pending = None
         lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
-        prepared = eng.fold_prepare(*outer[0], lmax_pre=lmax_pre[0])
-        for i in range(len(outer)):
-            st = eng.fold_begin(*outer[i], prepared=prepared)                      # main stream: the sweeps
-            prepared = (eng.fold_prepare(*outer[i + 1], lmax_pre=lmax_pre[i + 1])  # aux stream, next fold
-                        if i + 1 < len(outer) else None)
+        n = len(outer)
+        st = eng.fold_begin(*outer[0], prepared=eng.fold_prepare(*outer[0], lmax_pre=lmax_pre[0]))
+        prepared = eng.fold_prepare(*outer[1], lmax_pre=lmax_pre[1]) if n > 1 else None       # aux stream
+        for i in range(n):
+            st = eng.fold_select(st, single_alpha)          # host waits for the sweeps of fold i here
+            st_next = None
+            if i + 1 < n:
+                st_next = eng.fold_begin(*outer[i + 1], prepared=prepared)                    # main: sweeps of i+1
+                prepared = eng.fold_prepare(*outer[i + 2], lmax_pre=lmax_pre[i + 2]) if i + 2 < n else None
             if pending is not None:
                 tail(pending)
-            pending = eng.fold_refit(st, single_alpha, scale)
+            pending = eng.fold_finish(st, scale)            # main: V-wide refit of fold i behind those sweeps
+            st = st_next
         tail(pending)
         weights = eng.weights() if weights_on_host else eng.W_acc[:, : eng.V]
 

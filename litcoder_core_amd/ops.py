@@ -48,7 +48,17 @@ def idx_tensor(rows, length, dev, fill=-1):
     h = np.full(length, fill, dtype=np.int32)
     r = np.asarray(rows, dtype=np.int64)
     h[: r.size] = r
-    return torch.from_numpy(h).to(dev)
+    return upload(h, dev)
+
+
+def upload(arr, dev):
+    """Small host array -> device through pinned memory, asynchronously on the current stream.  (A pageable
+    ``.to(dev)`` / ``torch.tensor(..., device=dev)`` synchronises the stream: with two streams in flight that
+    stalls the host behind all the work already queued.)"""
+    h = torch.from_numpy(np.ascontiguousarray(arr))
+    if dev.type != "cuda":
+        return h.to(dev)
+    return h.pin_memory().to(dev, non_blocking=True)
 
 
 def timing_enable(on=True):
@@ -226,6 +236,17 @@ def batch_series_hat(k, tr, va, F, N, M, lmax, alphas_s, aidx, A, normalpha, ter
     work = torch.empty(F * N * N + terms * F * M * N, dtype=torch.float64, device=k.device)
     _lib.call("lc_batch_series_hat", _p(k), k.stride(0), _p(tr), _p(va), F, N, M, _p(lmax), _p(alphas_s), _p(aidx), S, A,
               int(bool(normalpha)), terms, _p(work), _p(h), _s())
+
+
+def batch_series_terms(k, tr, va, F, N, M, scale, terms, out):
+    work = torch.empty(F * N * N + terms * F * M * N, dtype=torch.float64, device=k.device)
+    _lib.call("lc_batch_series_terms", _p(k), k.stride(0), _p(tr), _p(va), F, N, M, _p(scale), terms, _p(work), _p(out),
+              _s())
+
+
+def series_scores(t, ldt, terms, M, n_val, V, yv, ystat, scale, a2, aidx, scores, accumulate):
+    _lib.call("lc_series_scores", _p(t), ldt, terms, M, n_val, V, _p(yv), _p(ystat), _p(scale), _p(a2), _p(aidx),
+              aidx.numel(), _p(scores), int(bool(accumulate)), _s())
 
 
 def transpose_rows(x, tr, N, p, out):

@@ -39,7 +39,9 @@ def ridge(Rstim, Rresp, alphas: Union[float, Sequence[float]], singcutoff: float
     eng = RidgeCVEngine(Rstim, Rresp, grid, normalpha, True, False, False)
     best = torch.zeros(eng.Vp, dtype=torch.int32, device=eng.dev)
     best[:V] = torch.from_numpy(idx.astype(np.int32)).to(eng.dev)
-    Ws, _, perm, _ = eng.refit(eng.dX, eng.dY, eng.K, np.arange(len(Rstim)), best)
+    Ws, _, perm, _, info = eng.refit(eng.dX, eng.dY, eng.K, np.arange(len(Rstim)), best)
+    if int(info.cpu().numpy().any()):
+        raise RuntimeError("Cholesky failed in the refit: Gram matrix + alpha^2 I is not positive definite")
     Wh = Ws[: eng.p].cpu().numpy()
     perm_h = perm[: Ws.shape[1]].cpu().numpy()
     live = perm_h >= 0

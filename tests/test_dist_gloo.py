@@ -55,6 +55,10 @@ class OracleEngine:
         return (tr, te, inner)
     def fold_refit(self, st, single_alpha, scale):
         return self.run_fold(*st, single_alpha, scale)
+    def fold_select(self, st, single_alpha):
+        return (st, single_alpha)
+    def fold_finish(self, sel, scale):
+        return self.run_fold(*sel[0], sel[1], scale)
     def fold_collect(self, pend):
         return pend
     def weights(self):
