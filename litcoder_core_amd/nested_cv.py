@@ -37,9 +37,11 @@ logger = logging.getLogger(__name__)
 LANCZOS_STEPS = 64                  # Lanczos iterations for S[0]^2: <= 1e-11 relative on the cfg2 Grams (profiles/);
                                     # the reference's own S[0] is an fp32 SVD value (~1e-7)
 AUG_BUDGET_BYTES = 24 << 30         # cap on the batched (fold, alpha) fp64 systems resident at once
-SERIES_TERMS = 6                    # Neumann terms for the hat matrices of large alphas ...
-SERIES_TOL = 1e-10                  # ... used when (lambda_max / a^2)^SERIES_TERMS <= this (H is stored as fp32)
-LAST_SWEEP = {"precision": None}    # arithmetic the most recent alpha sweep ran in (read by bench.py)
+SERIES_TERMS = 5                    # Neumann terms for the hat matrices of large alphas ...
+SERIES_TOL = 2e-9                   # ... used when (lambda_max / a^2)^SERIES_TERMS <= this: the relative truncation
+                                    # error, 30x below the fp32 epsilon of the values it is stored / consumed in
+LAST_SWEEP = {"precision": None,    # arithmetic the most recent alpha sweep ran in (read by bench.py) ...
+              "plain_flops": 0.0, "plain_launches": 0}   # ... and the algorithmic flops of the plain fp16x3 GEMMs
 
 
 class BasePredictivityModel:
@@ -226,7 +228,7 @@ class RidgeCVEngine:
                                      self.normalpha, SERIES_TERMS, H)
             Hs.append((f0, fc, H, P))
         info = torch.cat(infos) if infos else torch.zeros(1, dtype=torch.int32, device=self.dev)
-        return dict(F=F, N=N, M=M, n_v=n_v, tr=tr, va=va, Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
+        return dict(F=F, N=N, M=M, n_v=n_v, n_i=n_i, tr=tr, va=va, Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
                     d_ser=d_ser, moments=moments)
 
     def _sweeps(self, hat, Y):
@@ -272,6 +274,8 @@ class RidgeCVEngine:
                     if moments:
                         ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
                         ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt, cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256])
+                        LAST_SWEEP["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
+                        LAST_SWEEP["plain_launches"] += 1
                         ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv, ystat, hat["lmax"][f:f + 1],
                                           hat["a2"][f * A:(f + 1) * A], hat["d_ser"], scores, accumulate=f > 0)
                 else:
@@ -364,6 +368,8 @@ class RidgeCVEngine:
             Yt = torch.empty(Vs * N_o * 2, dtype=torch.float16, device=self.dev)
             ops.split_cols_f16(Ys, Vs, torch.arange(N_o, dtype=torch.int32, device=self.dev), N_o, cs_s[0], Yt)
             ops.gemm_grouped_f16x3(At, rs_inv, rows, Yt, cs_s[1], C, Vs, Vs, N_o, tiles)
+            LAST_SWEEP["plain_flops"] += 2.0 * (self.p + n_x) * n_o * self.V
+            LAST_SWEEP["plain_launches"] += 1
         else:
             ops.gemm_grouped(Malpha, N_o, rows * N_o, Ys, Vs, None, C, Vs, rows, Vs, N_o, tiles)
         return C, Ys, N_o

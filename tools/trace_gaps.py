@@ -31,3 +31,23 @@ print(f"gaps >= {min_gap:.0f} us: {len(big)}, total {sum(g[0] for g in big) / 1e
       f"smaller gaps: {len(gaps) - len(big)}, total {sum(g[0] for g in gaps if g[0] / 1e3 < min_gap) / 1e6:.1f} ms")
 for g in sorted(big, reverse=True)[:40]:
     print(f"  {g[0] / 1e3:9.0f} us at {g[1] / 1e6:9.2f} ms   after {g[2]}   before {g[3]}")
+
+# per-queue busy time and the top kernels per queue inside a window (last `win` ms of the trace)
+if len(sys.argv) > 3:
+    win = float(sys.argv[3]) * 1e6
+    lo = t1 - win
+    per_q = {}
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            if e < lo:
+                continue
+            q = r.get("Queue_Id", "?")
+            d = per_q.setdefault(q, {})
+            n = r["Kernel_Name"].split("(")[0][-48:]
+            d[n] = d.get(n, 0) + (e - max(s, lo))
+    for q, d in per_q.items():
+        tot = sum(d.values())
+        print(f"queue {q}: kernel time {tot / 1e6:.1f} ms in the last {win / 1e6:.0f} ms")
+        for n, v in sorted(d.items(), key=lambda kv: -kv[1])[:14]:
+            print(f"     {v / 1e6:8.2f} ms  {n}")
