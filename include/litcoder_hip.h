@@ -197,10 +197,12 @@ int lc_batch_series_hat(const double* d_k, int64_t ldk, const int32_t* d_tr, con
 /* The shared matrix powers of that series themselves, scaled:  P'_j = K[va,tr] K[tr,tr]^j / scale_f^(j+1),
  * j < terms <= 8, as f32 in d_p (F, terms, M, N).  With T_j = P'_j Y the prediction of every series alpha is
  * sum_j (-1)^j rho^(j+1) T_j, rho = scale_f / a^2: ONE (terms*M x N x V) contraction serves all those alphas
- * (lc_series_scores).  d_scale: (F) f64 (lambda_max under normalpha).  d_work: F*N*N + terms*F*M*N doubles. */
+ * (lc_series_scores).  d_scale: (F) f64 (lambda_max under normalpha).  d_work: F*N*N + terms*F*M*N doubles.
+ * d_rowmap: optional (terms*M) int32, row of d_p (F, rows_p, N) that receives row i of term j (entry j*M + i);
+ * NULL = j*M + i with rows_p = terms*M.  Rows of d_p that no entry names are left untouched (callers zero them). */
 int lc_batch_series_terms(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
                           int F, int N, int M, const double* d_scale, int terms,
-                          double* d_work, float* d_p, lc_stream_t stream);
+                          double* d_work, float* d_p, const int32_t* d_rowmap, int rows_p, lc_stream_t stream);
 
 /* rhs[f] (p x N) f64 <- X[tr_f]' for the refit systems (rows of X listed in d_tr, -1 -> 0). */
 int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_tr, int N, int64_t p,
@@ -258,10 +260,12 @@ int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, i
  * lc_gemm_grouped_f16x3 / lc_gemm_grouped_f32): per voxel the fp64 moments of the T_j over the n_val
  * validation rows give mean, variance and covariance with y of every alpha's prediction as linear / quadratic
  * forms.  d_scale: (1) f64 scale of this fold, d_a2: (A) f64 penalties a^2 of this fold, d_aidx: (S) rows of
- * d_scores (A, V) f32 that receive (or accumulate) the scores.  d_yv, d_ystat as produced by lc_val_stats. */
+ * d_scores (A, V) f32 that receive (or accumulate) the scores.  d_yv, d_ystat as produced by lc_val_stats.
+ * d_rowmap: optional (terms*M) int32 row of d_t holding row i of term j (as in lc_batch_series_terms). */
 int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val, int64_t V,
                      const float* d_yv, const float* d_ystat, const double* d_scale, const double* d_a2,
-                     const int32_t* d_aidx, int S, float* d_scores, int accumulate, lc_stream_t stream);
+                     const int32_t* d_aidx, int S, const int32_t* d_rowmap, float* d_scores, int accumulate,
+                     lc_stream_t stream);
 
 /* Diagnostics only (tools/gpu_kernel_bench.py stamps): the fp16x3 sweep with s_memtime stamps at its phase
  * boundaries; d_stamps (32 x uint64, caller-zeroed) receives per wave-group sums of the five segments of an
@@ -275,10 +279,14 @@ int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A
  * C[:, tile] = A_g(tile) . B[:, tile].  d_at: G tiled images made by lc_split_rows_f16 (one per group, each
  * pad256(Mrows) rows), d_rowscale_inv: (G * pad256(Mrows)); d_bt: tiled image of B (K x Ncols) made by
  * lc_split_cols_f16, d_cscale_inv: (Ncols).  Ncols % 256 == 0, K % 32 == 0; h_group_tiles: G+1 offsets in
- * 256-column tiles. */
+ * 256-column tiles.  d_slab_light: optional (G * pad256(Mrows) / 128) bytes, one per 128-row slab of the tiled
+ * image: nonzero = that slab's rows are computed from the fp16 hi parts alone (11-bit operands, one MFMA per
+ * product instead of three) -- for rows that enter the caller's result scaled down by 2^-11 or more, such as
+ * the higher terms of lc_batch_series_terms. */
 int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows,
                           const void* d_bt, const float* d_cscale_inv, float* d_c, int64_t ldc,
-                          int64_t Ncols, int64_t K, const int32_t* h_group_tiles, int G, lc_stream_t stream);
+                          int64_t Ncols, int64_t K, const int32_t* h_group_tiles, int G,
+                          const uint8_t* d_slab_light, lc_stream_t stream);
 
 /* best[v] = first argmax_a scores[a, v] / n_folds (nested_cv.py:391-408); also
  * d_rowsum[a] = sum_v scores[a, v] (f64) for the single-alpha path (:396-400, all-reduced

@@ -605,13 +605,15 @@ __global__ void __launch_bounds__(256) k_series_hat(const double* __restrict__ P
 // callers that contract them with the targets once and combine the per-alpha predictions afterwards.
 __global__ void __launch_bounds__(256) k_series_terms(const double* __restrict__ P, long long p_stride, int terms,
                                                       const double* __restrict__ scale, int M, int N,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, const int* __restrict__ rowmap,
+                                                      int rows_p) {
     const int i = blockIdx.x, t = blockIdx.y, f = blockIdx.z;
     const double inv = 1.0 / scale[f];
     double w = inv;
     for (int k = 0; k < t; ++k) w *= inv;
     const double* src = P + (long long)t * p_stride + ((long long)f * M + i) * N;
-    float* dst = out + (((long long)f * terms + t) * M + i) * N;
+    const int row = rowmap ? rowmap[t * M + i] : t * M + i;
+    float* dst = out + ((long long)f * rows_p + row) * N;
     for (int j = threadIdx.x; j < N; j += 256) dst[j] = (float)(src[j] * w);
 }
 
@@ -727,10 +729,11 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
 
 extern "C" int lc_batch_series_terms(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va, int F,
                                      int N, int M, const double* d_scale, int terms, double* d_work, float* d_p,
-                                     lc_stream_t stream) {
+                                     const int32_t* d_rowmap, int rows_p, lc_stream_t stream) {
     LC_REQUIRE(d_k && d_tr && d_va && d_scale && d_work && d_p, LC_E_BADARG, "lc_batch_series_terms: null pointer");
     LC_REQUIRE(F > 0 && F <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0 && terms >= 1 && terms <= 8,
                LC_E_SHAPE, "lc_batch_series_terms: need N %% %d == 0, M %% %d == 0, 1 <= terms <= 8", LC_NB, LC_MB);
+    LC_REQUIRE(rows_p >= terms * M, LC_E_SHAPE, "lc_batch_series_terms: rows_p < terms * M");
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_SERIES, s);
     double* Kf = d_work;                                   // (F, N, N), then P_0 .. P_{terms-1}, each (F, M, N)
@@ -741,7 +744,8 @@ extern "C" int lc_batch_series_terms(const double* d_k, int64_t ldk, const int32
     for (int t = 1; t < terms; ++t)
         hipLaunchKernelGGL(k_gemm_f64_nn, dim3(N / NB, lc::ceil_div(M, NB), F), dim3(256), 0, s, P + (t - 1) * p_stride, Kf,
                            P + t * p_stride, M, N, N);
-    hipLaunchKernelGGL(k_series_terms, dim3(M, terms, F), dim3(256), 0, s, P, p_stride, terms, d_scale, M, N, d_p);
+    hipLaunchKernelGGL(k_series_terms, dim3(M, terms, F), dim3(256), 0, s, P, p_stride, terms, d_scale, M, N, d_p,
+                       d_rowmap, rows_p);
     return lc::launched("lc_batch_series_terms");
 }
 

@@ -298,7 +298,8 @@ __global__ void __launch_bounds__(256) k_series_scores(const float* __restrict__
                                                        long long V, const float* __restrict__ yv,
                                                        const float* __restrict__ ystat, const double* __restrict__ scale,
                                                        const double* __restrict__ a2, const int* __restrict__ aidx, int S,
-                                                       float* __restrict__ scores, int accumulate) {
+                                                       const int* __restrict__ rowmap, float* __restrict__ scores,
+                                                       int accumulate) {
     constexpr int NB2 = TERMS * (TERMS + 1) / 2, NACC = 2 * TERMS + NB2 + 1;
     __shared__ double red[3][NACC][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -307,7 +308,11 @@ __global__ void __launch_bounds__(256) k_series_scores(const float* __restrict__
     const long long cc = live ? c : 0;
     double sh[TERMS], a[TERMS], cy[TERMS], b[NB2], ay = 0.0;
 #pragma unroll
-    for (int j = 0; j < TERMS; ++j) { sh[j] = (double)T[(long long)j * M * ldt + cc]; a[j] = 0.0; cy[j] = 0.0; }
+    for (int j = 0; j < TERMS; ++j) {
+        sh[j] = (double)T[(long long)(rowmap ? rowmap[j * M] : j * M) * ldt + cc];
+        a[j] = 0.0;
+        cy[j] = 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < NB2; ++k) b[k] = 0.0;
     const double shy = (double)yv[lc::yv_index(0, cc, V)];
@@ -315,7 +320,8 @@ __global__ void __launch_bounds__(256) k_series_scores(const float* __restrict__
         const double dy = (double)yv[lc::yv_index(i, cc, V)] - shy;
         double d[TERMS];
 #pragma unroll
-        for (int j = 0; j < TERMS; ++j) d[j] = (double)T[((long long)j * M + i) * ldt + cc] - sh[j];
+        for (int j = 0; j < TERMS; ++j)
+            d[j] = (double)T[(long long)(rowmap ? rowmap[j * M + i] : j * M + i) * ldt + cc] - sh[j];
         ay += dy;
         int k = 0;
 #pragma unroll
@@ -445,7 +451,7 @@ extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, cons
 
 extern "C" int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val, int64_t V, const float* d_yv,
                                 const float* d_ystat, const double* d_scale, const double* d_a2, const int32_t* d_aidx,
-                                int S, float* d_scores, int accumulate, lc_stream_t stream) {
+                                int S, const int32_t* d_rowmap, float* d_scores, int accumulate, lc_stream_t stream) {
     LC_REQUIRE(d_t && d_yv && d_ystat && d_scale && d_a2 && d_aidx && d_scores, LC_E_BADARG,
                "lc_series_scores: null pointer");
     LC_REQUIRE(terms >= 1 && terms <= 8 && M > 0 && M % LC_MB == 0 && n_val > 1 && n_val <= M && V > 0 && ldt >= V &&
@@ -457,7 +463,7 @@ extern "C" int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M,
 #define LC_SERIES_CASE(t_)                                                                                             \
     case t_:                                                                                                           \
         hipLaunchKernelGGL((k_series_scores<t_>), grid, block, 0, s, d_t, (long long)ldt, M, n_val, (long long)V, d_yv,  \
-                           d_ystat, d_scale, d_a2, d_aidx, S, d_scores, accumulate);                                   \
+                           d_ystat, d_scale, d_a2, d_aidx, S, d_rowmap, d_scores, accumulate);                         \
         break;
     switch (terms) {
         LC_SERIES_CASE(1) LC_SERIES_CASE(2) LC_SERIES_CASE(3) LC_SERIES_CASE(4)

@@ -170,6 +170,7 @@ struct Plain16Args {
     int Mrows;             // real rows per group
     int G;
     int start[MAX_GROUPS16 + 1];   // first 256-column tile of each group; start[G] = number of column tiles
+    const unsigned char* slab_light;   // optional, per 128-row slab (G * Mtiles * 2): nonzero = hi*hi term only
 };
 
 #define MFMA16(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
@@ -183,7 +184,7 @@ struct Plain16Args {
         __builtin_amdgcn_sched_barrier(0);                                                     \
     }
 
-template <bool SCORE, bool STAMP>
+template <bool SCORE, bool STAMP, bool LIGHTCAP = false>
 __global__ void __launch_bounds__(512, 2)
 k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT, int Mtiles, Score16Args sa,
               Plain16Args pa) {
@@ -201,6 +202,10 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     }
     const uint4* a_src = At + ((long long)grp * Mtiles + mt) * KT * CHUNK16 + tid;
     const uint4* b_src = Bt + (long long)nt * KT * CHUNK16 + tid;
+    // "light" slabs (plain mode): rows whose product only needs fp16 accuracy (11-bit operands) -- the higher
+    // terms of a series, which enter the caller's result scaled down by >= 2^-11 -- take the hi*hi MFMA alone
+    const bool light = LIGHTCAP && !SCORE && pa.slab_light != nullptr &&
+                       __builtin_amdgcn_readfirstlane((int)pa.slab_light[((long long)grp * Mtiles + mt) * 2 + wm]) != 0;
 
     // ---- main loop: software-pipelined fragments, ONE block barrier per K-tile ----------------------------
     // Every wave keeps two register sets of fragments: while the 24 MFMAs of K-tile j run on one set, the 12
@@ -347,20 +352,65 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
     };
+    // the same K-tile for a light slab: 8 MFMAs (hi*hi), the 6 hi fragments of the next tile, the same DMA share
+    auto kstep_light = [&](const int kt, const Frag& cur, Frag& nxt, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool STEADY = MODE == 0, LAST = MODE == 2;
+        const bool has_next = STEADY || (!LAST && kt + 1 < KT);
+        const bool do_dma = STEADY || (!LAST && kt + 4 < KT);
+        const uint4* stn = lds16 + ((kt + 1) & 3) * STAGE16;
+        const int stg = kt & 3;
+        const uint4* pa_ = a_src + (long long)(kt + 4) * CHUNK16;
+        const uint4* pb_ = b_src + (long long)(kt + 4) * CHUNK16;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) MFMA16(acc[sl][h], cur.ah[sl], cur.bh[h]);
+            if (has_next) {
+                if (sl < 2) read_frag(nxt, stn, sl);              // bh[0], bh[1]
+                read_frag(nxt, stn, 8 + sl);                      // ah[sl]
+            }
+            if (do_dma) {
+                if (sl == 0) DMA16(pa_, stg * STAGE16);
+                if (sl == 1) DMA16(pa_ + 512, stg * STAGE16 + 512);
+                if (sl == 2) DMA16(pb_, stg * STAGE16 + CHUNK16);
+                if (sl == 3) DMA16(pb_ + 512, stg * STAGE16 + CHUNK16 + 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (LAST) return;
+        if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
+    };
     using Steady = std::integral_constant<int, 0>;
     using Tail = std::integral_constant<int, 1>;
     using Last = std::integral_constant<int, 2>;
     int kt = 0;
-    for (; kt + 5 < KT; kt += 2) {
-        kstep(kt, fa, fb, Steady{});
-        kstep(kt + 1, fb, fa, Steady{});
+    if (LIGHTCAP && light) {
+        for (; kt + 5 < KT; kt += 2) {
+            kstep_light(kt, fa, fb, Steady{});
+            kstep_light(kt + 1, fb, fa, Steady{});
+        }
+        for (; kt + 2 < KT; kt += 2) {
+            kstep_light(kt, fa, fb, Tail{});
+            kstep_light(kt + 1, fb, fa, Tail{});
+        }
+        kstep_light(kt, fa, fb, Tail{});
+        kstep_light(kt + 1, fb, fa, Last{});
+    } else {
+        for (; kt + 5 < KT; kt += 2) {
+            kstep(kt, fa, fb, Steady{});
+            kstep(kt + 1, fb, fa, Steady{});
+        }
+        for (; kt + 2 < KT; kt += 2) {
+            kstep(kt, fa, fb, Tail{});
+            kstep(kt + 1, fb, fa, Tail{});
+        }
+        kstep(kt, fa, fb, Tail{});                   // KT is even (K % 32 == 0): kt == KT - 2 here
+        kstep(kt + 1, fb, fa, Last{});
     }
-    for (; kt + 2 < KT; kt += 2) {
-        kstep(kt, fa, fb, Tail{});
-        kstep(kt + 1, fb, fa, Tail{});
-    }
-    kstep(kt, fa, fb, Tail{});                   // KT is even (K % 32 == 0): kt == KT - 2 here
-    kstep(kt + 1, fb, fa, Last{});
     STAMP_T(tk2);
     if (STAMP) {
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr2)::"memory");
@@ -522,7 +572,8 @@ extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rows
 
 extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
                                      const float* d_cscale_inv, float* d_c, int64_t ldc, int64_t Ncols, int64_t K,
-                                     const int32_t* h_group_tiles, int G, lc_stream_t stream) {
+                                     const int32_t* h_group_tiles, int G, const uint8_t* d_slab_light,
+                                     lc_stream_t stream) {
     LC_REQUIRE(d_at && d_rowscale_inv && d_bt && d_cscale_inv && d_c && h_group_tiles, LC_E_BADARG,
                "lc_gemm_grouped_f16x3: null pointer");
     LC_REQUIRE(G >= 1 && G <= MAX_GROUPS16, LC_E_SHAPE, "lc_gemm_grouped_f16x3: G must be in 1..%d", MAX_GROUPS16);
@@ -531,6 +582,8 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     static thread_local bool attr_done = false;
     if (!attr_done) {
         LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<false, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
+        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
         attr_done = true;
     }
@@ -543,6 +596,7 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     pa.cs_inv = d_cscale_inv;
     pa.Mrows = (int)Mrows;
     pa.G = G;
+    pa.slab_light = d_slab_light;
     for (int g = 0; g <= G; ++g) {
         pa.start[g] = h_group_tiles[g];
         LC_REQUIRE(g == 0 ? pa.start[0] == 0 : pa.start[g] >= pa.start[g - 1], LC_E_SHAPE,
@@ -554,8 +608,12 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     Score16Args sa{};
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
-    hipLaunchKernelGGL((k_sweep_f16x3<false, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
-                       (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa);
+    if (d_slab_light)
+        hipLaunchKernelGGL((k_sweep_f16x3<false, false, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES,
+                           s, (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa);
+    else
+        hipLaunchKernelGGL((k_sweep_f16x3<false, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
+                           (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa);
     return lc::launched("k_sweep_f16x3<plain>");
 }
 

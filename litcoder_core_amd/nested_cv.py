@@ -176,6 +176,38 @@ class RidgeCVEngine:
         return [(lm[s:s + n], lm[s + n:s + n + 1]) for s, n in spans]
 
     # -------------------------------------------------------------- inner CV: hat matrices, then the sweeps
+    def _series_layout(self, M):
+        """Row layout of the stacked series terms for the plain fp16x3 GEMM: every term padded to whole 128-row
+        slabs, heavy slabs (terms 0 and 1: full three-MFMA products) paired with light ones (terms >= 2, which
+        enter a prediction scaled by rho^2 <= 2.7e-4 relative to term 0 and only need fp16 operands) inside the
+        256-row tiles, so that the two waves of a SIMD together issue 32 instead of 48 MFMAs per K-tile.
+        Returns (rows, rowmap (terms*M,) int32 device, slab_light uint8 device)."""
+        key = ("series_layout", M)
+        if getattr(self, "_layout_key", None) != key:
+            per = (M + 127) // 128
+            heavy = [(j, s) for j in range(min(2, SERIES_TERMS)) for s in range(per)]
+            light = [(j, s) for j in range(2, SERIES_TERMS) for s in range(per)]
+            order, cls = [], []
+            while heavy or light:                        # one 256-row tile per round: (wm = 0 slab, wm = 1 slab)
+                for _ in range(2):
+                    if heavy and (not cls or len(cls) % 2 == 0 or not light):
+                        order.append(heavy.pop(0)); cls.append(0)
+                    elif light:
+                        order.append(light.pop(0)); cls.append(1)
+                    else:
+                        order.append(None); cls.append(1)
+            rows = 128 * len(order)
+            rowmap = np.full(SERIES_TERMS * M, -1, dtype=np.int32)
+            for slab, js in enumerate(order):
+                if js is None:
+                    continue
+                j, s = js
+                lo, hi = s * 128, min(M, (s + 1) * 128)
+                rowmap[j * M + lo:j * M + hi] = slab * 128 + np.arange(hi - lo)
+            self._layout = (rows, ops.upload(rowmap, self.dev), ops.upload(np.asarray(cls, dtype=np.uint8), self.dev))
+            self._layout_key = key
+        return self._layout
+
     def _series_by_moments(self, Y):
         """Score the series alphas from the moments of the shared terms T_j = P'_j Y (one contraction for all of
         them, lc_series_scores) instead of one hat matrix per alpha: correlation scoring on the fp16x3 path only
@@ -220,8 +252,10 @@ class RidgeCVEngine:
                 infos.append(ops.batch_chol_solve(aug, fc * Ac, N, M, H, slot))
                 del aug
             if ser and moments:
-                P = torch.empty((fc, SERIES_TERMS * M, N), dtype=torch.float32, device=self.dev)
-                ops.batch_series_terms(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], SERIES_TERMS, P)
+                rows_p, rowmap, _ = self._series_layout(M)
+                P = torch.zeros((fc, rows_p, N), dtype=torch.float32, device=self.dev)
+                ops.batch_series_terms(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], SERIES_TERMS, P,
+                                       rowmap)
             elif ser:
                 ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M,
                                      lmax[f0:f0 + fc] if lmax is not None else None, self.d_alphas[ser], d_ser, A,
@@ -255,7 +289,7 @@ class RidgeCVEngine:
             Vt = ops.pad_to(self.Vp, 256)
             Yt = torch.empty(Vt * N * 2, dtype=torch.float16, device=self.dev)
         if moments:
-            Tm = SERIES_TERMS * M
+            Tm, rowmap, slab_light = self._series_layout(M)
             Pt = torch.empty(ops.pad_to(Tm, 256) * N * 2, dtype=torch.float16, device=self.dev)
             rs_p = torch.empty(ops.pad_to(Tm, 256), dtype=torch.float32, device=self.dev)
             Tbuf = torch.empty((Tm, Vt), dtype=torch.float32, device=self.dev)
@@ -273,11 +307,12 @@ class RidgeCVEngine:
                                                      yblk, self.mode, part, scores_d, accumulate=f > 0)
                     if moments:
                         ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
-                        ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt, cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256])
+                        ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt, cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light)
                         LAST_SWEEP["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
                         LAST_SWEEP["plain_launches"] += 1
                         ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv, ystat, hat["lmax"][f:f + 1],
-                                          hat["a2"][f * A:(f + 1) * A], hat["d_ser"], scores, accumulate=f > 0)
+                                          hat["a2"][f * A:(f + 1) * A], hat["d_ser"], scores, accumulate=f > 0,
+                                          rowmap=rowmap)
                 else:
                     ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], yv, n_v[f], ystat, yblk,
                                            self.mode, part, scores, accumulate=f > 0)

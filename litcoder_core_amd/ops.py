@@ -238,15 +238,16 @@ def batch_series_hat(k, tr, va, F, N, M, lmax, alphas_s, aidx, A, normalpha, ter
               int(bool(normalpha)), terms, _p(work), _p(h), _s())
 
 
-def batch_series_terms(k, tr, va, F, N, M, scale, terms, out):
+def batch_series_terms(k, tr, va, F, N, M, scale, terms, out, rowmap=None):
+    """out: (F, rows_p, N) f32; ``rowmap`` (terms*M int32) places row i of term j, default j*M + i."""
     work = torch.empty(F * N * N + terms * F * M * N, dtype=torch.float64, device=k.device)
     _lib.call("lc_batch_series_terms", _p(k), k.stride(0), _p(tr), _p(va), F, N, M, _p(scale), terms, _p(work), _p(out),
-              _s())
+              _p(rowmap), out.shape[1], _s())
 
 
-def series_scores(t, ldt, terms, M, n_val, V, yv, ystat, scale, a2, aidx, scores, accumulate):
+def series_scores(t, ldt, terms, M, n_val, V, yv, ystat, scale, a2, aidx, scores, accumulate, rowmap=None):
     _lib.call("lc_series_scores", _p(t), ldt, terms, M, n_val, V, _p(yv), _p(ystat), _p(scale), _p(a2), _p(aidx),
-              aidx.numel(), _p(scores), int(bool(accumulate)), _s())
+              aidx.numel(), _p(rowmap), _p(scores), int(bool(accumulate)), _s())
 
 
 def transpose_rows(x, tr, N, p, out):
@@ -286,11 +287,11 @@ def alpha_sweep_scores_f16x3(ht, rowscale_inv, A, M, N, yt, cscale_inv, yv, V, n
               _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), _s())
 
 
-def gemm_grouped_f16x3(at, rowscale_inv, Mrows, bt, cscale_inv, c, ldc, Ncols, K, group_tiles):
+def gemm_grouped_f16x3(at, rowscale_inv, Mrows, bt, cscale_inv, c, ldc, Ncols, K, group_tiles, slab_light=None):
     G = len(group_tiles) - 1
     arr = (ctypes.c_int32 * (G + 1))(*[int(t) for t in group_tiles])
     _lib.call("lc_gemm_grouped_f16x3", _p(at), _p(rowscale_inv), Mrows, _p(bt), _p(cscale_inv), _p(c), ldc, Ncols, K,
-              arr, G, _s())
+              arr, G, _p(slab_light), _s())
 
 
 def select_alpha(scores, A, V, want_best=True, want_rowsum=False):

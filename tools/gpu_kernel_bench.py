@@ -109,6 +109,39 @@ if "sweep16" in what:
                   f"(step 0 {h[g_, 9] / nw:.0f}, again {h[g_, 13] / nw:.0f}, steps 1-6 {h[g_, 10] / nw:.0f}, "
                   f"step 7 {h[g_, 11] / nw:.0f}, drain {h[g_, 12] / nw:.0f})")
 
+if "plain16" in what:
+    # the plain (store) launches of k_sweep_f16x3: series terms (2400 x 1920) and refit (3680 x 2400), V = 80000
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    V = 80000
+    Vt = ops.pad_to(V, 256)
+    for rows, K, label in [(2400, 1920, "series terms 5 x 480"), (3680, 2400, "refit p_pad + test rows")]:
+        Amat = torch.randn((rows, K), generator=g, device=dev, dtype=torch.float32) * 0.02
+        Y = torch.randn((K, V), generator=g, device=dev, dtype=torch.float32)
+        rows_pad = ops.pad_to(rows, 256)
+        At = torch.empty(rows_pad * K * 2, dtype=torch.float16, device=dev)
+        rs = torch.empty(rows_pad, dtype=torch.float32, device=dev)
+        Yt = torch.empty(Vt * K * 2, dtype=torch.float16, device=dev)
+        cs, _ = ops.col_scales_f16(Y, K, V)
+        cs_inv = torch.ones(Vt, dtype=torch.float32, device=dev); cs_inv[:V] = cs[V:]
+        ops.split_rows_f16(Amat, rows, K, At, rs)
+        ops.split_cols_f16(Y, V, torch.arange(K, dtype=torch.int32, device=dev), K, cs, Yt)
+        C = torch.empty((rows, Vt), dtype=torch.float32, device=dev)
+        fn = lambda: ops.gemm_grouped_f16x3(At, rs, rows, Yt, cs_inv, C, Vt, Vt, K, [0, Vt // 256])
+        ms = timeit(fn)
+        if rows == 2400:      # the series layout: 8 tiles heavy + light, 2 tiles light + light
+            cls = torch.tensor([0, 1] * 8 + [1] * 4, dtype=torch.uint8, device=dev)
+            fl_ = lambda: ops.gemm_grouped_f16x3(At, rs, rows_pad, Yt, cs_inv, C2, Vt, Vt, K, [0, Vt // 256], cls)
+            C2 = torch.empty((rows_pad, Vt), dtype=torch.float32, device=dev)
+            ms_l = timeit(fl_)
+            ref_l = Amat[128:132].double() @ Y[:, :512].double()
+            err_l = float((C2[128:132, :512].double() - ref_l).abs().max() / ref_l.abs().max())
+            print(f"   with light slabs (12 of 20): {ms_l:.2f} ms; rel err of a light row {err_l:.1e}")
+        fl = 2.0 * rows * K * V
+        ref = Amat[:4].double() @ Y[:, :512].double()
+        err = float((C[:4, :512].double() - ref).abs().max() / ref.abs().max())
+        print(f"plain f16x3 GEMM {label} ({rows} x {K} x {V}): {ms:.2f} ms -> {fl / ms / 1e9:.1f} TFLOP/s algorithmic, "
+              f"{3 * fl / ms / 1e9:.0f} TF of fp16 MFMA; rel err {err:.1e}")
+
 if "lanczos" in what:
     rng = np.random.default_rng(0)
     for (T, p, ar) in [(2400, 3072, 0.0), (2400, 3072, 0.8), (2400, 768, 0.5)]:
