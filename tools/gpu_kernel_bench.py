@@ -203,6 +203,22 @@ if "chol" in what:
     ms = timeit(run, reps=2, warm=1)
     fl = F * A * (N ** 3 / 3 + 2.0 * N * N * M)
     print(f"assemble + batch_chol_solve B={F * A} N={N} M={M}: {ms:.1f} ms -> {fl / ms / 1e9:.1f} TFLOP/s fp64")
+    # the shapes of the fit: inner batch (5 folds x 4 Cholesky alphas) and the refit systems (4 alphas, 3680 rows)
+    for (B_, N_, M_, label) in ((20, 1920, 480, "inner folds"), (4, 2432, 3680, "refit")):
+        aug2 = torch.randn((B_, N_ + M_, N_), dtype=torch.float64, device=dev)
+        aug2[:, :N_] = torch.eye(N_, dtype=torch.float64, device=dev) * (4.0 * N_) + aug2[:, :N_] * 0.0 + 1.0
+        H2 = torch.empty((B_, M_, N_), dtype=torch.float32, device=dev)
+        base = aug2.clone()
+        def run2():
+            aug2.copy_(base)
+            ops.batch_chol_solve(aug2, B_, N_, M_, H2)
+        ops.timing_enable(True); ops.timing_read()
+        ms2 = timeit(run2, reps=3, warm=1)
+        kt = ops.timing_read(); ops.timing_enable(False)
+        fl2 = B_ * (N_ ** 3 / 3 + 2.0 * N_ * N_ * M_)
+        chol_ms = kt.get("batch_chol_solve", (0, 1))
+        print(f"batch_chol_solve {label} B={B_} N={N_} M={M_}: {chol_ms[0] / chol_ms[1]:.2f} ms -> "
+              f"{fl2 / (chol_ms[0] / chol_ms[1]) / 1e9:.1f} TFLOP/s fp64")
 
 if "hbm" in what:
     # HBM-bound kernels: algorithmic bytes / time against the 8 TB/s datasheet rate (6.3 TB/s achievable copy)
