@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256) k_score_finalize(const float* __restrict_
 // T_j over the validation rows:  mean_s = c.m,  M2_s = c' S c,  cov_s = c.C  (S the terms' scatter matrix, C their
 // co-moments with y).  One pass over T in fp64 (shifted by the first row) gives all of them for every alpha.
 // Block: 64 columns x 4 row groups; same shift in every group, so the groups' raw sums simply add.
-template <int TERMS>
+template <int TERMS, bool MAPPED>
 __global__ void __launch_bounds__(256) k_series_scores(const float* __restrict__ T, long long ldt, int M, int n_val,
                                                        long long V, const float* __restrict__ yv,
                                                        const float* __restrict__ ystat, const double* __restrict__ scale,
@@ -302,34 +302,50 @@ __global__ void __launch_bounds__(256) k_series_scores(const float* __restrict__
                                                        int accumulate) {
     constexpr int NB2 = TERMS * (TERMS + 1) / 2, NACC = 2 * TERMS + NB2 + 1;
     __shared__ double red[3][NACC][64];
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const long long c = (long long)blockIdx.x * 64 + lane;
     const bool live = c < V;
     const long long cc = live ? c : 0;
+    const float* tcol = T + cc;
+    const long long tstride = ldt;
     double sh[TERMS], a[TERMS], cy[TERMS], b[NB2], ay = 0.0;
 #pragma unroll
     for (int j = 0; j < TERMS; ++j) {
-        sh[j] = (double)T[(long long)(rowmap ? rowmap[j * M] : j * M) * ldt + cc];
+        sh[j] = (double)tcol[(long long)(MAPPED ? rowmap[j * M] : j * M) * tstride];
         a[j] = 0.0;
         cy[j] = 0.0;
     }
 #pragma unroll
     for (int k = 0; k < NB2; ++k) b[k] = 0.0;
     const double shy = (double)yv[lc::yv_index(0, cc, V)];
-    for (int i = g; i < n_val; i += 4) {
-        const double dy = (double)yv[lc::yv_index(i, cc, V)] - shy;
-        double d[TERMS];
+    // rows g, g+4, ...: four rows per trip with all their loads issued first (the loop is latency bound)
+    constexpr int UR = 4;
+    for (int i0 = g; i0 < n_val; i0 += 4 * UR) {
+        float tv[UR][TERMS], yvv[UR];
 #pragma unroll
-        for (int j = 0; j < TERMS; ++j)
-            d[j] = (double)T[(long long)(rowmap ? rowmap[j * M + i] : j * M + i) * ldt + cc] - sh[j];
-        ay += dy;
-        int k = 0;
+        for (int u = 0; u < UR; ++u) {
+            const int i = min(i0 + 4 * u, n_val - 1);        // clamped: the extra rows are masked below
+            yvv[u] = yv[lc::yv_index(i, cc, V)];
 #pragma unroll
-        for (int j = 0; j < TERMS; ++j) {
-            a[j] += d[j];
-            cy[j] += d[j] * dy;
+            for (int j = 0; j < TERMS; ++j)                  // row index: wave-uniform, a scalar load
+                tv[u][j] = tcol[(long long)(MAPPED ? rowmap[j * M + i] : j * M + i) * tstride];
+        }
 #pragma unroll
-            for (int l = j; l < TERMS; ++l) b[k++] += d[j] * d[l];
+        for (int u = 0; u < UR; ++u) {
+            if (i0 + 4 * u >= n_val) break;
+            const double dy = (double)yvv[u] - shy;
+            double d[TERMS];
+#pragma unroll
+            for (int j = 0; j < TERMS; ++j) d[j] = (double)tv[u][j] - sh[j];
+            ay += dy;
+            int k = 0;
+#pragma unroll
+            for (int j = 0; j < TERMS; ++j) {
+                a[j] += d[j];
+                cy[j] += d[j] * dy;
+#pragma unroll
+                for (int l = j; l < TERMS; ++l) b[k++] += d[j] * d[l];
+            }
         }
     }
     if (g > 0) {
@@ -462,8 +478,12 @@ extern "C" int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M,
     const dim3 grid((unsigned)lc::ceil_div<long long>(V, 64)), block(256);
 #define LC_SERIES_CASE(t_)                                                                                             \
     case t_:                                                                                                           \
-        hipLaunchKernelGGL((k_series_scores<t_>), grid, block, 0, s, d_t, (long long)ldt, M, n_val, (long long)V, d_yv,  \
-                           d_ystat, d_scale, d_a2, d_aidx, S, d_rowmap, d_scores, accumulate);                         \
+        if (d_rowmap)                                                                                                  \
+            hipLaunchKernelGGL((k_series_scores<t_, true>), grid, block, 0, s, d_t, (long long)ldt, M, n_val,          \
+                               (long long)V, d_yv, d_ystat, d_scale, d_a2, d_aidx, S, d_rowmap, d_scores, accumulate); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_series_scores<t_, false>), grid, block, 0, s, d_t, (long long)ldt, M, n_val,         \
+                               (long long)V, d_yv, d_ystat, d_scale, d_a2, d_aidx, S, d_rowmap, d_scores, accumulate); \
         break;
     switch (terms) {
         LC_SERIES_CASE(1) LC_SERIES_CASE(2) LC_SERIES_CASE(3) LC_SERIES_CASE(4)

@@ -427,20 +427,26 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 
     if (!SCORE) {
         // ---- plain epilogue: undo the power-of-two scales and store
+        const int colw = wn * 64 + li;                       // column inside the 256-wide tile (+ 32 ni)
+        float* cbase = pa.c + (long long)nt * TN;
+        const long long rstride = pa.ldc;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi) {
+            const int rb0 = mt * TM + wm * 128 + mi * 32;
+            float rsc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rsc[r] = pa.rs_inv[(long long)grp * Mtiles * TM + rb0 + (r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                const long long col = (long long)nt * TN + wn * 64 + ni * 32 + li;
-                const float csc = pa.cs_inv[col];
+                const float csc = pa.cs_inv[(long long)nt * TN + colw + ni * 32];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = mt * TM + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < pa.Mrows)
-                        pa.c[(long long)row * pa.ldc + col] =
-                            acc[mi][ni][r] * pa.rs_inv[(long long)grp * Mtiles * TM + row] * csc;
+                    const int row = rb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < pa.Mrows) cbase[(long long)row * rstride + colw + ni * 32] = acc[mi][ni][r] * rsc[r] * csc;
                 }
             }
+        }
         return;
     }
 

@@ -131,28 +131,31 @@ __global__ void __launch_bounds__(64 * CM_RG) k_val_stats(const float* __restric
                                                           float* __restrict__ ystat, float* __restrict__ yblk,
                                                           float* __restrict__ yv) {
     __shared__ double sm[CM_RG][64];
+    // row group = wave (blockDim = (64, CM_RG)): a scalar, so that the row indices va[i] are scalar loads and
+    // the strided target loads of consecutive trips can be in flight together
+    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
     const bool live = c < V;
     double s = 0.0;
     if (live)
-        for (int i = threadIdx.y; i < n_val; i += CM_RG) s += (double)y[(long long)va[i] * ldy + c];
+        for (int i = ty; i < n_val; i += CM_RG) s += (double)y[(long long)va[i] * ldy + c];
     const double mean = block_colsum<CM_RG>(s, sm) / (double)n_val;
     const float meanf = (float)mean;
     double q = 0.0;
     if (live)
-        for (int i = threadIdx.y; i < n_val; i += CM_RG) {
+        for (int i = ty; i < n_val; i += CM_RG) {
             const double d = (double)y[(long long)va[i] * ldy + c] - mean;
             q += d * d;
         }
     const double m2 = block_colsum<CM_RG>(q, sm);
-    if (live && threadIdx.y == 0) {
+    if (live && ty == 0) {
         const double var = m2 / (double)(n_val - 1);
         ystat[c] = meanf;
         ystat[V + c] = (float)sqrt(var);
         ystat[2 * V + c] = (float)var;
     }
     if (live)
-        for (int b = threadIdx.y; b < M / LC_MB; b += CM_RG) {
+        for (int b = ty; b < M / LC_MB; b += CM_RG) {
             float t = 0.f;
             for (int i4 = b * LC_MB; i4 < (b + 1) * LC_MB; i4 += 4) {
                 float4 quad;                                 // row-quad interleaved layout, see lc_epilogue.h
@@ -176,11 +179,12 @@ __global__ void __launch_bounds__(64 * PR_RG) k_pearson_cols(const float* __rest
                                                              const float* __restrict__ b, long long ldb,
                                                              long long n, long long V, double* __restrict__ r_out) {
     __shared__ double sm[PR_RG][64];
+    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);      // row group = wave: scalar row offsets
     const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
     const bool live = c < V;
     double sa = 0.0, sb = 0.0;
     if (live)
-        for (long long i = threadIdx.y; i < n; i += PR_RG) {
+        for (long long i = ty; i < n; i += PR_RG) {
             sa += (double)a[i * lda + c];
             sb += (double)b[i * ldb + c];
         }
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(64 * PR_RG) k_pearson_cols(const float* __rest
     const double mb = block_colsum<PR_RG>(sb, sm) / (double)n;
     double qa = 0.0, qb = 0.0, qab = 0.0;
     if (live)
-        for (long long i = threadIdx.y; i < n; i += PR_RG) {
+        for (long long i = ty; i < n; i += PR_RG) {
             const double da = (double)a[i * lda + c] - ma;
             const double db = (double)b[i * ldb + c] - mb;
             qa += da * da;
@@ -198,7 +202,7 @@ __global__ void __launch_bounds__(64 * PR_RG) k_pearson_cols(const float* __rest
     qa = block_colsum<PR_RG>(qa, sm);
     qb = block_colsum<PR_RG>(qb, sm);
     qab = block_colsum<PR_RG>(qab, sm);
-    if (live && threadIdx.y == 0) {
+    if (live && ty == 0) {
         double r = qab / (sqrt(qa) * sqrt(qb));       // 0/0 -> NaN for a constant column
         if (r > 1.0) r = 1.0;
         if (r < -1.0) r = -1.0;
