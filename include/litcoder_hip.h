@@ -204,6 +204,13 @@ int lc_batch_series_terms(const double* d_k, int64_t ldk, const int32_t* d_tr, c
                           int F, int N, int M, const double* d_scale, int terms,
                           double* d_work, float* d_p, const int32_t* d_rowmap, int rows_p, lc_stream_t stream);
 
+/* out[f] (R, C) f32 = K[rows_f, cols_f] / scale[f] (d_scale NULL = 1; index -1 = zero row / column): the
+ * f32 operands of the series terms when their chain  P'_j = P'_(j-1) (K[tr,tr] / scale)  runs on the f32 MFMA
+ * (lc_gemm_grouped_f32) instead of in fp64 -- terms j >= 1 enter a prediction scaled by rho^j <= 1.6e-2 per
+ * step, so fp32 products with fp32 accumulation leave the result at full fp32 accuracy. */
+int lc_gather_sub_f32(const double* d_k, int64_t ldk, const int32_t* d_rows, const int32_t* d_cols,
+                      int F, int R, int C, const double* d_scale, float* d_out, lc_stream_t stream);
+
 /* rhs[f] (p x N) f64 <- X[tr_f]' for the refit systems (rows of X listed in d_tr, -1 -> 0). */
 int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_tr, int N, int64_t p,
                           double* d_out, lc_stream_t stream);

@@ -564,6 +564,21 @@ __global__ void __launch_bounds__(256) k_gather_sub(const double* __restrict__ K
     }
 }
 
+// out[f][i][j] = K[rows_f[i]][cols_f[j]] / scale[f] as f32 (zeros where an index is -1)
+__global__ void __launch_bounds__(256) k_gather_sub_f32(const double* __restrict__ Kmat, long long ldk,
+                                                        const int* __restrict__ rows, const int* __restrict__ cols, int R,
+                                                        int C, const double* __restrict__ scale, float* __restrict__ out) {
+    const int i = blockIdx.x, f = blockIdx.y;
+    const int r = rows[(long long)f * R + i];
+    const int* cf = cols + (long long)f * C;
+    const double w = scale ? 1.0 / scale[f] : 1.0;
+    float* dst = out + ((long long)f * R + i) * C;
+    for (int j = threadIdx.x; j < C; j += 256) {
+        const int c = cf[j];
+        dst[j] = (r >= 0 && c >= 0) ? (float)(Kmat[(long long)r * ldk + c] * w) : 0.f;
+    }
+}
+
 // C[f] (M x N) = A[f] (M x Kd) . B[f] (Kd x N), row-major, 64 x 64 output tiles, Kd % 64 == 0, N % 64 == 0.
 __global__ void __launch_bounds__(256) k_gemm_f64_nn(const double* __restrict__ A, const double* __restrict__ B,
                                                      double* __restrict__ C, int M, int N, int Kd) {
@@ -725,6 +740,17 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
     if (int rc = lc::launched("back substitution")) return rc;
     hipLaunchKernelGGL(k_extract_h, dim3(M, B), dim3(256), 0, s, d_aug, N, M, d_h, d_slot);
     return lc::launched("k_extract_h");
+}
+
+extern "C" int lc_gather_sub_f32(const double* d_k, int64_t ldk, const int32_t* d_rows, const int32_t* d_cols, int F,
+                                 int R, int C, const double* d_scale, float* d_out, lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_rows && d_cols && d_out, LC_E_BADARG, "lc_gather_sub_f32: null pointer");
+    LC_REQUIRE(F > 0 && F <= 65535 && R > 0 && C > 0, LC_E_SHAPE, "lc_gather_sub_f32: bad shape");
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_SERIES, s);
+    hipLaunchKernelGGL(k_gather_sub_f32, dim3(R, F), dim3(256), 0, s, d_k, (long long)ldk, d_rows, d_cols, R, C, d_scale,
+                       d_out);
+    return lc::launched("k_gather_sub_f32");
 }
 
 extern "C" int lc_batch_series_terms(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va, int F,

@@ -254,8 +254,28 @@ class RidgeCVEngine:
             if ser and moments:
                 rows_p, rowmap, _ = self._series_layout(M)
                 P = torch.zeros((fc, rows_p, N), dtype=torch.float32, device=self.dev)
-                ops.batch_series_terms(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], SERIES_TERMS, P,
-                                       rowmap)
+                if N % COL_TILE == 0:
+                    # the chain P'_j = P'_(j-1) (K[tr,tr] / lambda) on the f32 MFMA: its terms enter a prediction
+                    # scaled by rho^j, fp32 products with fp32 accumulation keep them at full fp32 accuracy.
+                    # Run transposed, Q_j = Kn Q_(j-1) with the folds as column groups of one grouped launch.
+                    Mq = ops.pad_to(M, COL_TILE)
+                    Kn = torch.empty((fc, N, N), dtype=torch.float32, device=self.dev)
+                    Q0 = torch.empty((fc, N, M), dtype=torch.float32, device=self.dev)
+                    ops.gather_sub_f32(K, tr[f0:f0 + fc], tr[f0:f0 + fc], fc, N, N, lmax[f0:f0 + fc], Kn)
+                    ops.gather_sub_f32(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], Q0)   # K symmetric
+                    Q = torch.zeros((N, fc, Mq), dtype=torch.float32, device=self.dev)
+                    Q[:, :, :M] = Q0.permute(1, 0, 2)
+                    rm64 = rowmap.to(torch.int64)
+                    tiles = [f * (Mq // COL_TILE) for f in range(fc + 1)]
+                    for j in range(SERIES_TERMS):
+                        if j:
+                            Qn = torch.empty_like(Q)
+                            ops.gemm_grouped(Kn, N, N * N, Q, fc * Mq, None, Qn, fc * Mq, N, fc * Mq, N, tiles)
+                            Q = Qn
+                        P.index_copy_(1, rm64[j * M:(j + 1) * M], Q[:, :, :M].permute(1, 2, 0))
+                else:
+                    ops.batch_series_terms(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], SERIES_TERMS,
+                                           P, rowmap)
             elif ser:
                 ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M,
                                      lmax[f0:f0 + fc] if lmax is not None else None, self.d_alphas[ser], d_ser, A,

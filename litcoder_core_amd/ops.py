@@ -245,6 +245,10 @@ def batch_series_terms(k, tr, va, F, N, M, scale, terms, out, rowmap=None):
               _p(rowmap), out.shape[1], _s())
 
 
+def gather_sub_f32(k, rows, cols, F, R, C, scale, out):
+    _lib.call("lc_gather_sub_f32", _p(k), k.stride(0), _p(rows), _p(cols), F, R, C, _p(scale), _p(out), _s())
+
+
 def series_scores(t, ldt, terms, M, n_val, V, yv, ystat, scale, a2, aidx, scores, accumulate, rowmap=None):
     _lib.call("lc_series_scores", _p(t), ldt, terms, M, n_val, V, _p(yv), _p(ystat), _p(scale), _p(a2), _p(aidx),
               aidx.numel(), _p(rowmap), _p(scores), int(bool(accumulate)), _s())
