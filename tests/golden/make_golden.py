@@ -277,7 +277,30 @@ def gen_harness():
     save("harness.npz", **out)
 
 
+def gen_saver():
+    """The reference's ModelSaver run on a small result: directory-name hash and file contents."""
+    import json
+    import pickle
+    import tempfile
+    hp = {"fir_delays": [1, 2, 3, 4], "downsample_config": {"method": "lanczos", "window": 3, "cutoff_mult": 1.0},
+          "n_outer_folds": 5, "single_alpha": True, "modality": "language_model", "layer_idx": 9, "note": None,
+          "alphas": [0.1, 1.0, 10.0]}
+    metrics = {"median_score": 0.25, "correlations": [np.float32(0.5), 0.0, np.float32(-0.125)],
+               "best_alphas": [1.0, 1.0, 10.0], "significant_mask": [True, False, False]}
+    W = np.arange(12, dtype=np.float32).reshape(4, 3)
+    with tempfile.TemporaryDirectory() as d:
+        sv = ref.utils.ModelSaver(base_dir=d)
+        run = quiet(sv.save_encoding_model, W, np.array([1.0, 1.0, 10.0]), hp, metrics, True)
+        out = {"hyperparams": hp, "dir_suffix": run.name.split("_")[-1], "files": sorted(p.name for p in run.iterdir()),
+               "hyperparams_json_text": (run / "hyperparams.json").read_text(),
+               "metrics_keys": sorted(pickle.load(open(run / "metrics.pkl", "rb")).keys()),
+               "weights_shape": list(np.load(run / "weights.npy").shape)}
+    with open(os.path.join(HERE, "saver.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
+    gen_saver()
     gen_fir()
     gen_downsample()
     gen_folds()

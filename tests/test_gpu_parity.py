@@ -280,6 +280,34 @@ def test_fit_nested_cv_alias(lc):
     assert m1["correlations"] == m2["correlations"] and np.array_equal(W1, W2) and np.array_equal(a1, a2)
 
 
+# ------------------------------------------------------------------ banded ridge (self-defined)
+def test_banded_ridge_against_oracle_on_rescaled_design(lc):
+    """Per-band penalty scale gamma_b == ordinary ridge on X_b / gamma_b with w_b = w'_b / gamma_b: the oracle
+    (the reference algorithm) run on the rescaled design defines the expected result."""
+    import oracle.nested_cv as onc
+    rng = np.random.default_rng(12)
+    T, p, V = 160, 30, 40
+    X = rng.standard_normal((T, p)) * np.r_[np.ones(10), 3.0 * np.ones(20)]
+    Y = X @ (rng.standard_normal((p, V)) * 0.2) + rng.standard_normal((T, V))
+    bands, gam = [(0, 10), (10, 30)], [0.5, 4.0]
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 2, 6), single_alpha=False,
+              normalpha=True, use_corr=True)
+    m, W, a = lc.BandedNestedCVModel("ridge_regression").fit_predict(X, Y, bands=bands, band_scales=gam, **kw)
+    gcol = np.r_[np.full(10, 0.5), np.full(20, 4.0)]
+    mo, Wo, ao = onc.fit_predict(X / gcol, Y, **kw)
+    np.testing.assert_allclose(a, ao, rtol=1e-6)
+    np.testing.assert_allclose(np.asarray(m["correlations"], dtype=np.float64),
+                               np.asarray(mo["correlations"], dtype=np.float64), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(W, Wo / gcol[:, None], rtol=1e-4, atol=2e-5)
+    # without bands it is the plain model
+    m0, W0, a0 = lc.BandedNestedCVModel("ridge_regression").fit_predict(X, Y, **kw)
+    m1, W1, a1 = lc.NestedCVModel("ridge_regression").fit_predict(X, Y, **kw)
+    assert np.array_equal(W0, W1) and np.array_equal(a0, a1)
+    with pytest.raises(ValueError):
+        lc.BandedNestedCVModel("ridge_regression").fit_predict(X, Y, bands=bands, band_scales=gam,
+                                                               normalize_features=True, **kw)
+
+
 # ------------------------------------------------------------------ trainer-side structuring (SURVEY 8f row 1)
 def test_story_structuring_matches_reference_trainer(lc, golden_dir):
     """FIR -> trim -> zs -> stack on the device against captures of the reference's own

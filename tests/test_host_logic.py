@@ -165,3 +165,39 @@ def test_shard_bounds_partition():
         b = [lc.shard_bounds(n, w, r) for r in range(w)]
         assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
         assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+# ------------------------------------------------------------------ result files
+def test_model_saver_matches_reference_format(golden_dir, tmp_path):
+    import pickle
+    from litcoder_core_amd import ModelSaver
+    g = json.load(open(os.path.join(golden_dir, "saver.json")))
+    hp = g["hyperparams"]
+    assert ModelSaver.run_hash(hp) == g["dir_suffix"]
+    metrics = {"median_score": 0.25, "correlations": [np.float32(0.5), 0.0, np.float32(-0.125)],
+               "best_alphas": [1.0, 1.0, 10.0], "significant_mask": [True, False, False]}
+    W = np.arange(12, dtype=np.float32).reshape(4, 3)
+    sv = ModelSaver(base_dir=str(tmp_path / "results"))
+    run = sv.save_encoding_model(W, np.array([1.0, 1.0, 10.0]), hp, metrics, save_weights=True)
+    parts = run.name.split("_")
+    assert parts[0] == "run" and len(parts[1]) == 8 and len(parts[2]) == 6 and parts[3] == g["dir_suffix"]
+    assert sorted(p.name for p in run.iterdir()) == g["files"]
+    assert (run / "hyperparams.json").read_text() == g["hyperparams_json_text"]
+    assert sorted(pickle.load(open(run / "metrics.pkl", "rb")).keys()) == g["metrics_keys"]
+    assert list(np.load(run / "weights.npy").shape) == g["weights_shape"]
+    W2, a2, hp2, m2 = sv.load_encoding_model(run)
+    assert np.array_equal(W2, W) and np.array_equal(a2, [1.0, 1.0, 10.0]) and hp2 == hp and m2["median_score"] == 0.25
+    run_nw = sv.save_encoding_model(W, None, dict(hp, layer_idx=3), metrics)        # default: no weights file
+    assert sorted(p.name for p in run_nw.iterdir()) == ["hyperparams.json", "metrics.pkl"]
+    runs = sv.list_runs()
+    assert len(runs) == 2 and {r["hyperparams"]["layer_idx"] for r in runs} == {3, 9}
+
+
+def test_band_column_scales_validation():
+    from litcoder_core_amd.banded import band_column_scales
+    np.testing.assert_array_equal(band_column_scales(5, [(0, 2), (2, 5)], [1.0, 4.0]), [1, 1, 4, 4, 4])
+    np.testing.assert_array_equal(band_column_scales(4, np.array([1, 0, 1, 0]), [2.0, 3.0]), [3, 2, 3, 2])
+    for bad in (([(0, 2), (1, 5)], [1.0, 2.0]), ([(0, 2)], [1.0]), ([(0, 2), (2, 5)], [1.0, -1.0]),
+                ([(0, 2), (2, 5)], [1.0])):
+        with pytest.raises(ValueError):
+            band_column_scales(5, *bad)
