@@ -242,15 +242,6 @@ class RidgeCVEngine:
             fc = min(chunk, F - f0)
             H = torch.empty((fc * slots, M, N), dtype=torch.float32, device=self.dev) if slots else None
             P = None
-            if Ac:
-                aug = torch.empty((fc * Ac, N + M, N), dtype=torch.float64, device=self.dev)
-                a2c = a2[f0 * A:(f0 + fc) * A].reshape(fc, A).index_select(1, self.d_cho.to(torch.int64)).reshape(-1)
-                slot = None if moments else (
-                    torch.arange(fc, device=self.dev, dtype=torch.int32).reshape(fc, 1) * A
-                    + self.d_cho.reshape(1, Ac)).reshape(-1).contiguous()
-                ops.batch_assemble(K, tr[f0:f0 + fc], va[f0:f0 + fc], None, a2c, fc, Ac, N, M, aug)
-                infos.append(ops.batch_chol_solve(aug, fc * Ac, N, M, H, slot))
-                del aug
             if ser and moments:
                 rows_p, rowmap, _ = self._series_layout(M)
                 P = torch.zeros((fc, rows_p, N), dtype=torch.float32, device=self.dev)
@@ -280,62 +271,88 @@ class RidgeCVEngine:
                 ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M,
                                      lmax[f0:f0 + fc] if lmax is not None else None, self.d_alphas[ser], d_ser, A,
                                      self.normalpha, SERIES_TERMS, H)
+            series_ready = torch.cuda.Event() if self.dev.type == "cuda" else None
+            if series_ready is not None:
+                series_ready.record()           # the series operands of this chunk are complete; Cholesky follows
+            if Ac:
+                aug = torch.empty((fc * Ac, N + M, N), dtype=torch.float64, device=self.dev)
+                a2c = a2[f0 * A:(f0 + fc) * A].reshape(fc, A).index_select(1, self.d_cho.to(torch.int64)).reshape(-1)
+                slot = None if moments else (
+                    torch.arange(fc, device=self.dev, dtype=torch.int32).reshape(fc, 1) * A
+                    + self.d_cho.reshape(1, Ac)).reshape(-1).contiguous()
+                ops.batch_assemble(K, tr[f0:f0 + fc], va[f0:f0 + fc], None, a2c, fc, Ac, N, M, aug)
+                infos.append(ops.batch_chol_solve(aug, fc * Ac, N, M, H, slot))
+                del aug
             Hs.append((f0, fc, H, P))
         info = torch.cat(infos) if infos else torch.zeros(1, dtype=torch.int32, device=self.dev)
         return dict(F=F, N=N, M=M, n_v=n_v, n_i=n_i, tr=tr, va=va, Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
-                    d_ser=d_ser, moments=moments)
+                    d_ser=d_ser, moments=moments, series_ready=series_ready)
 
-    def _sweeps(self, hat, Y):
+    def _sweeps(self, hat, Y, done=None):
         """Sum over inner folds of the (A, Vp) validation scores (ridge_corr_torch for every fold,
         nested_cv.py:366-393): the V-wide fused MFMA sweeps, plus -- with ``hat["moments"]`` -- one plain
-        contraction of the shared series terms and the moment kernel for the alphas on the series."""
+        contraction of the shared series terms and the moment kernel for the alphas on the series.  ``done``: event
+        after which the hat matrices are complete; the series part only waits for ``hat["series_ready"]`` and
+        runs first, so the main stream has work while the auxiliary stream is still in the Cholesky chains."""
         A, N, M, tr, va, n_v = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"]
+        F = hat["F"]
         moments, cho = hat["moments"], hat["cho"]
         Ad = len(cho) if moments else A                   # alphas that go through the fused sweep
+        main = torch.cuda.current_stream()
         scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
         scores_d = torch.empty((Ad, self.Vp), dtype=torch.float32, device=self.dev) if moments and Ad else scores
         part = torch.empty((max(Ad, 1) * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
-        ystat = torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev)
-        yblk = torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
-        yv = torch.empty((M, self.Vp), dtype=torch.float32, device=self.dev)
         split = self._use_split(Y)
         LAST_SWEEP.update(precision="f16x3" if split else "f32", fused_alphas=Ad,
                           series_terms=SERIES_TERMS if moments else 0)
+        nbuf = F if moments else 1                        # two passes over the folds keep every fold's operands
+        ystat = [torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev) for _ in range(nbuf)]
+        yblk = [torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev) for _ in range(nbuf)]
+        yv = [torch.empty((M, self.Vp), dtype=torch.float32, device=self.dev) for _ in range(nbuf)]
         if split:
             rows_pad = ops.pad_to(max(Ad, 1) * M, 256)
             cs = self._cs
             Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
             rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
             Vt = ops.pad_to(self.Vp, 256)
-            Yt = torch.empty(Vt * N * 2, dtype=torch.float16, device=self.dev)
+            Yt = [torch.empty(Vt * N * 2, dtype=torch.float16, device=self.dev) for _ in range(nbuf)]
+        folds = [(f0 + j, j, H, P) for f0, fc, H, P in hat["Hs"] for j in range(fc)]
         if moments:
+            # ---- pass 1: validation statistics, operand split, series contraction + moment kernel
             Tm, rowmap, slab_light = self._series_layout(M)
             Pt = torch.empty(ops.pad_to(Tm, 256) * N * 2, dtype=torch.float16, device=self.dev)
             rs_p = torch.empty(ops.pad_to(Tm, 256), dtype=torch.float32, device=self.dev)
             Tbuf = torch.empty((Tm, Vt), dtype=torch.float32, device=self.dev)
             cs_inv = torch.ones(Vt, dtype=torch.float32, device=self.dev)      # padded to the plain GEMM's tiles
             cs_inv[: self.Vp] = cs[self.Vp:]
-        for f0, fc, H, P in hat["Hs"]:
-            for j in range(fc):
-                f = f0 + j
-                ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk, yv)
-                if split:
-                    ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt)
-                    if Ad:
-                        ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
-                        ops.alpha_sweep_scores_f16x3(Ht, rs_inv, Ad, M, N, Yt, cs[self.Vp:], yv, self.Vp, n_v[f], ystat,
-                                                     yblk, self.mode, part, scores_d, accumulate=f > 0)
-                    if moments:
-                        ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
-                        ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt, cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light)
-                        LAST_SWEEP["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
-                        LAST_SWEEP["plain_launches"] += 1
-                        ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv, ystat, hat["lmax"][f:f + 1],
-                                          hat["a2"][f * A:(f + 1) * A], hat["d_ser"], scores, accumulate=f > 0,
-                                          rowmap=rowmap)
-                else:
-                    ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], yv, n_v[f], ystat, yblk,
-                                           self.mode, part, scores, accumulate=f > 0)
+            if hat.get("series_ready") is not None:
+                main.wait_event(hat["series_ready"])
+            for f, j, H, P in folds:
+                ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat[f], yblk[f], yv[f])
+                ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[f])
+                ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
+                ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light)
+                LAST_SWEEP["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
+                LAST_SWEEP["plain_launches"] += 1
+                ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv[f], ystat[f], hat["lmax"][f:f + 1],
+                                  hat["a2"][f * A:(f + 1) * A], hat["d_ser"], scores, accumulate=f > 0, rowmap=rowmap)
+        if done is not None:
+            main.wait_event(done)
+        # ---- pass 2 (the only one without the moment path): fused sweeps of the alphas that have hat matrices
+        for f, j, H, P in folds:
+            b = f if moments else 0
+            if not moments:
+                ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat[b], yblk[b], yv[b])
+            if split:
+                if not moments:
+                    ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[b])
+                if Ad:
+                    ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
+                    ops.alpha_sweep_scores_f16x3(Ht, rs_inv, Ad, M, N, Yt[b], cs[self.Vp:], yv[b], self.Vp, n_v[f], ystat[b],
+                                                 yblk[b], self.mode, part, scores_d, accumulate=f > 0)
+            else:
+                ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], yv[b], n_v[f], ystat[b], yblk[b],
+                                       self.mode, part, scores, accumulate=f > 0)
         if moments and Ad:
             scores.index_copy_(0, self.d_cho.to(torch.int64), scores_d)
         return scores
@@ -488,8 +505,7 @@ class RidgeCVEngine:
 
     def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None, lmax_pre=None):
         st = prepared if prepared is not None else self.fold_prepare(tr_rows, te_rows, inner_rel, lmax_pre)
-        torch.cuda.current_stream().wait_event(st["done"])
-        st["scores"] = self._sweeps(st["hat"], st["Y"])
+        st["scores"] = self._sweeps(st["hat"], st["Y"], st["done"])
         st["info"] = st["hat"]["info"]
         return st
 
@@ -703,9 +719,10 @@ class NestedCVModel(BasePredictivityModel):
             rp = shard.allgather_cols(np.stack([f.r, f.p]), V_total)
             idx = shard.allgather_cols(f.best_idx.astype(np.int32)[None, :], V_total)[0]
             r32 = rp[0].astype(np.float32)
-            corrs, pvals = _fold_lists(r32, rp[1])
-            fold_scores.append(corrs)
-            fold_p.append(pvals)
+            if train_test:                  # the per-fold Python lists are only returned by the train/test metrics;
+                corrs, pvals = _fold_lists(r32, rp[1])      # the CV summary works on the arrays below
+                fold_scores.append(corrs)
+                fold_p.append(pvals)
             fold_alpha.append(_alpha_vector(alphas, idx, single_alpha))
             p_arr = np.where(np.isnan(r32), 1.0, rp[1])
             fold_sig.append(stats.fdrcorrection(p_arr, alpha=alpha_fdr))
