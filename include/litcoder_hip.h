@@ -184,19 +184,20 @@ int lc_batch_assemble(const double* d_k, int64_t ldk, const int32_t* d_tr, const
 int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
                         const int32_t* d_slot, int32_t* d_info, lc_stream_t stream);
 
-/* The same hat matrices for alphas whose penalty dwarfs the spectrum (a^2 >> lambda_max):
- *   K[va,tr] (K[tr,tr] + a^2 I)^-1 = sum_{j<terms} (-1)^j K[va,tr] K[tr,tr]^j / a^(2j+2)
- * (truncation error (lambda_max/a^2)^terms, relative).  The matrix powers are shared by the S alphas
- * of a fold.  a = d_alphas[s] * (normalpha ? sqrt(d_lmax[f]) : 1).  Output goes to slot
- * f*A + d_aidx[s] of d_h (F*A, M, N) f32.  d_work: F*N*N + terms*F*M*N doubles. */
+/* The same hat matrices for alphas whose penalty dwarfs the spectrum, as a polynomial in K[tr,tr]:
+ *   K[va,tr] (K[tr,tr] + a^2 I)^-1  ~=  sum_{j<terms} c_sj K[va,tr] K[tr,tr]^j / scale_f^(j+1)
+ * with a = alpha_s * sqrt(scale_f) (normalpha: scale_f = lambda_max of the fold) and c_s the coefficients of a
+ * polynomial close to 1 / (x + alpha_s^2) on [0, 1] (d_coef: (S, terms) f64; Neumann/Taylor (-1)^j alpha^-2(j+1), or
+ * the minimax ones of litcoder_core_amd/series.py).  The matrix powers are shared by the S alphas of a fold.
+ * Output goes to slot f*A + d_aidx[s] of d_h (F*A, M, N) f32.  d_work: F*N*N + terms*F*M*N doubles. */
 int lc_batch_series_hat(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
-                        int F, int N, int M, const double* d_lmax, const double* d_alphas,
-                        const int32_t* d_aidx, int S, int A, int normalpha, int terms,
-                        double* d_work, float* d_h, lc_stream_t stream);
+                        int F, int N, int M, const double* d_scale, const double* d_coef,
+                        const int32_t* d_aidx, int S, int A, int terms, double* d_work, float* d_h,
+                        lc_stream_t stream);
 
 /* The shared matrix powers of that series themselves, scaled:  P'_j = K[va,tr] K[tr,tr]^j / scale_f^(j+1),
  * j < terms <= 8, as f32 in d_p (F, terms, M, N).  With T_j = P'_j Y the prediction of every series alpha is
- * sum_j (-1)^j rho^(j+1) T_j, rho = scale_f / a^2: ONE (terms*M x N x V) contraction serves all those alphas
+ * sum_j c_sj T_j (coefficients as in lc_batch_series_hat): ONE (terms*M x N x V) contraction serves all those alphas
  * (lc_series_scores).  d_scale: (F) f64 (lambda_max under normalpha).  d_work: F*N*N + terms*F*M*N doubles.
  * d_rowmap: optional (terms*M) int32, row of d_p (F, rows_p, N) that receives row i of term j (entry j*M + i);
  * NULL = j*M + i with rows_p = terms*M.  Rows of d_p that no entry names are left untouched (callers zero them). */
@@ -266,11 +267,11 @@ int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, i
  * alphas of ONE inner fold from d_t (terms*M, ldt) f32 = the stacked T_j = P'_j Y (lc_batch_series_terms +
  * lc_gemm_grouped_f16x3 / lc_gemm_grouped_f32): per voxel the fp64 moments of the T_j over the n_val
  * validation rows give mean, variance and covariance with y of every alpha's prediction as linear / quadratic
- * forms.  d_scale: (1) f64 scale of this fold, d_a2: (A) f64 penalties a^2 of this fold, d_aidx: (S) rows of
- * d_scores (A, V) f32 that receive (or accumulate) the scores.  d_yv, d_ystat as produced by lc_val_stats.
+ * forms.  d_coef: (S, terms) f64 polynomial coefficients per alpha, d_aidx: (S) rows of d_scores (A, V) f32 that
+ * receive (or accumulate) the scores.  d_yv, d_ystat as produced by lc_val_stats.
  * d_rowmap: optional (terms*M) int32 row of d_t holding row i of term j (as in lc_batch_series_terms). */
 int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val, int64_t V,
-                     const float* d_yv, const float* d_ystat, const double* d_scale, const double* d_a2,
+                     const float* d_yv, const float* d_ystat, const double* d_coef,
                      const int32_t* d_aidx, int S, const int32_t* d_rowmap, float* d_scores, int accumulate,
                      lc_stream_t stream);
 

@@ -48,12 +48,12 @@ SIGNATURES = {
     "lc_batch_assemble": (c_int, [_ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
     "lc_batch_chol_solve": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_batch_series_hat": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int, c_int, c_int,
-                                    c_int, _ptr, _ptr, _ptr]),
+                                    _ptr, _ptr, _ptr]),
     "lc_batch_series_terms": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, c_int, _ptr, _ptr, _ptr, c_int,
                                       _ptr]),
     "lc_gather_sub_f32": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
-    "lc_series_scores": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, c_int, _ptr,
-                                 _ptr, c_int, _ptr]),
+    "lc_series_scores": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr,
+                                 c_int, _ptr]),
     "lc_transpose_rows_f64": (c_int, [_ptr, c_int64, _ptr, c_int, c_int64, _ptr, _ptr]),
     "lc_val_stats": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr]),
     "lc_alpha_sweep_scores": (c_int, [_ptr, c_int, c_int, c_int, _ptr, c_int64, c_int64, _ptr, _ptr, c_int, _ptr, _ptr,

@@ -599,19 +599,19 @@ __global__ void __launch_bounds__(256) k_gemm_f64_nn(const double* __restrict__ 
             for (int j = 0; j < 4; ++j) c[(long long)(ty * 4 + i) * N + tx * 4 + j] = acc[i][j];
 }
 
-// H[f*A + aidx[s]] = sum_j (-1)^j P_j[f] / a2^(j+1),  a2 = (alphas[s] * (normalpha ? sqrt(lmax[f]) : 1))^2
+// H[f*A + aidx[s]] = sum_j coef[s][j] P_j[f] / scale[f]^(j+1)   (Horner in P_j / scale^j)
 __global__ void __launch_bounds__(256) k_series_hat(const double* __restrict__ P, long long p_stride, int terms,
-                                                    const double* __restrict__ lmax, const double* __restrict__ alphas,
-                                                    const int* __restrict__ aidx, int normalpha, int A, int M, int N,
+                                                    const double* __restrict__ scale, const double* __restrict__ coef,
+                                                    const int* __restrict__ aidx, int A, int M, int N,
                                                     float* __restrict__ h) {
     const int i = blockIdx.x, s = blockIdx.y, f = blockIdx.z;
-    const double na = alphas[s] * (normalpha ? sqrt(lmax[f]) : 1.0);
-    const double inv = 1.0 / (na * na);
+    const double inv = 1.0 / scale[f];
+    const double* c = coef + (long long)s * terms;
     const double* src = P + ((long long)f * M + i) * N;
     float* dst = h + (((long long)f * A + aidx[s]) * M + i) * N;
     for (int j = threadIdx.x; j < N; j += 256) {
         double acc = 0.0;
-        for (int t = terms - 1; t >= 0; --t) acc = src[(long long)t * p_stride + j] - inv * acc;   // Horner, alternating signs
+        for (int t = terms - 1; t >= 0; --t) acc = c[t] * src[(long long)t * p_stride + j] + inv * acc;
         dst[j] = (float)(inv * acc);
     }
 }
@@ -776,9 +776,9 @@ extern "C" int lc_batch_series_terms(const double* d_k, int64_t ldk, const int32
 }
 
 extern "C" int lc_batch_series_hat(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va, int F, int N,
-                                   int M, const double* d_lmax, const double* d_alphas, const int32_t* d_aidx, int S,
-                                   int A, int normalpha, int terms, double* d_work, float* d_h, lc_stream_t stream) {
-    LC_REQUIRE(d_k && d_tr && d_va && d_alphas && d_aidx && d_work && d_h && (d_lmax || !normalpha), LC_E_BADARG,
+                                   int M, const double* d_scale, const double* d_coef, const int32_t* d_aidx, int S,
+                                   int A, int terms, double* d_work, float* d_h, lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_tr && d_va && d_scale && d_coef && d_aidx && d_work && d_h, LC_E_BADARG,
                "lc_batch_series_hat: null pointer");
     LC_REQUIRE(F > 0 && F <= 65535 && S > 0 && S <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0 &&
                    terms >= 1 && terms <= 16,
@@ -794,7 +794,7 @@ extern "C" int lc_batch_series_hat(const double* d_k, int64_t ldk, const int32_t
     for (int t = 1; t < terms; ++t)
         hipLaunchKernelGGL(k_gemm_f64_nn, dim3(N / NB, lc::ceil_div(M, NB), F), dim3(256), 0, s, P + (t - 1) * p_stride, Kf,
                            P + t * p_stride, M, N, N);
-    hipLaunchKernelGGL(k_series_hat, dim3(M, S, F), dim3(256), 0, s, P, p_stride, terms, d_lmax, d_alphas, d_aidx,
-                       normalpha, A, M, N, d_h);
+    hipLaunchKernelGGL(k_series_hat, dim3(M, S, F), dim3(256), 0, s, P, p_stride, terms, d_scale, d_coef, d_aidx, A, M,
+                       N, d_h);
     return lc::launched("lc_batch_series_hat");
 }

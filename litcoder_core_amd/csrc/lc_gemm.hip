@@ -288,16 +288,16 @@ __global__ void __launch_bounds__(256) k_score_finalize(const float* __restrict_
 
 // ---- correlation scores of the series alphas from the moments of the shared terms ------------------------------
 // For the alphas on the Neumann series the prediction is a fixed linear combination of `terms` matrices
-//     pred_s = sum_j c_sj T_j,   T_j = P'_j Y (M x V, one GEMM for all those alphas),   c_sj = (-1)^j rho_s^(j+1),
-// rho_s = scale / a_s^2, so every statistic the score needs is a linear or quadratic form in the moments of the
+//     pred_s = sum_j c_sj T_j,   T_j = P'_j Y (M x V, one GEMM for all those alphas),   c_sj given per alpha
+// (minimax polynomial of 1 / (x + alpha^2), series.py), so every statistic the score needs is a linear or quadratic form in the moments of the
 // T_j over the validation rows:  mean_s = c.m,  M2_s = c' S c,  cov_s = c.C  (S the terms' scatter matrix, C their
 // co-moments with y).  One pass over T in fp64 (shifted by the first row) gives all of them for every alpha.
 // Block: 64 columns x 4 row groups; same shift in every group, so the groups' raw sums simply add.
 template <int TERMS, bool MAPPED>
 __global__ void __launch_bounds__(256) k_series_scores(const float* __restrict__ T, long long ldt, int M, int n_val,
                                                        long long V, const float* __restrict__ yv,
-                                                       const float* __restrict__ ystat, const double* __restrict__ scale,
-                                                       const double* __restrict__ a2, const int* __restrict__ aidx, int S,
+                                                       const float* __restrict__ ystat, const double* __restrict__ coefs,
+                                                       const int* __restrict__ aidx, int S,
                                                        const int* __restrict__ rowmap, float* __restrict__ scores,
                                                        int accumulate) {
     constexpr int NB2 = TERMS * (TERMS + 1) / 2, NACC = 2 * TERMS + NB2 + 1;
@@ -377,11 +377,9 @@ __global__ void __launch_bounds__(256) k_series_scores(const float* __restrict__
     }
     const double sy = (double)ystat[V + c];
     for (int s = 0; s < S; ++s) {
-        const double rho = scale[0] / a2[aidx[s]];
         double coef[TERMS];
-        double w = rho;
 #pragma unroll
-        for (int j = 0; j < TERMS; ++j) { coef[j] = (j & 1) ? -w : w; w *= rho; }
+        for (int j = 0; j < TERMS; ++j) coef[j] = coefs[s * TERMS + j];
         double m2 = 0.0, cov = 0.0;
         int k = 0;
 #pragma unroll
@@ -466,9 +464,9 @@ extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, cons
 }
 
 extern "C" int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val, int64_t V, const float* d_yv,
-                                const float* d_ystat, const double* d_scale, const double* d_a2, const int32_t* d_aidx,
+                                const float* d_ystat, const double* d_coef, const int32_t* d_aidx,
                                 int S, const int32_t* d_rowmap, float* d_scores, int accumulate, lc_stream_t stream) {
-    LC_REQUIRE(d_t && d_yv && d_ystat && d_scale && d_a2 && d_aidx && d_scores, LC_E_BADARG,
+    LC_REQUIRE(d_t && d_yv && d_ystat && d_coef && d_aidx && d_scores, LC_E_BADARG,
                "lc_series_scores: null pointer");
     LC_REQUIRE(terms >= 1 && terms <= 8 && M > 0 && M % LC_MB == 0 && n_val > 1 && n_val <= M && V > 0 && ldt >= V &&
                    S > 0,
@@ -480,10 +478,10 @@ extern "C" int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M,
     case t_:                                                                                                           \
         if (d_rowmap)                                                                                                  \
             hipLaunchKernelGGL((k_series_scores<t_, true>), grid, block, 0, s, d_t, (long long)ldt, M, n_val,          \
-                               (long long)V, d_yv, d_ystat, d_scale, d_a2, d_aidx, S, d_rowmap, d_scores, accumulate); \
+                               (long long)V, d_yv, d_ystat, d_coef, d_aidx, S, d_rowmap, d_scores, accumulate);        \
         else                                                                                                           \
             hipLaunchKernelGGL((k_series_scores<t_, false>), grid, block, 0, s, d_t, (long long)ldt, M, n_val,         \
-                               (long long)V, d_yv, d_ystat, d_scale, d_a2, d_aidx, S, d_rowmap, d_scores, accumulate); \
+                               (long long)V, d_yv, d_ystat, d_coef, d_aidx, S, d_rowmap, d_scores, accumulate);        \
         break;
     switch (terms) {
         LC_SERIES_CASE(1) LC_SERIES_CASE(2) LC_SERIES_CASE(3) LC_SERIES_CASE(4)

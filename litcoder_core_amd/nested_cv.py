@@ -27,7 +27,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 import numpy as np
 import torch
 
-from . import ops, stats
+from . import ops, series, stats
 from ._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2
 from .dist import ShardContext
 from .folding import create_folds
@@ -37,9 +37,9 @@ logger = logging.getLogger(__name__)
 LANCZOS_STEPS = 64                  # Lanczos iterations for S[0]^2: <= 1e-11 relative on the cfg2 Grams (profiles/);
                                     # the reference's own S[0] is an fp32 SVD value (~1e-7)
 AUG_BUDGET_BYTES = 24 << 30         # cap on the batched (fold, alpha) fp64 systems resident at once
-SERIES_TERMS = 5                    # Neumann terms for the hat matrices of large alphas ...
-SERIES_TOL = 2e-9                   # ... used when (lambda_max / a^2)^SERIES_TERMS <= this: the relative truncation
-                                    # error, 30x below the fp32 epsilon of the values it is stored / consumed in
+SERIES_TERMS = 4                    # terms of the polynomial form of the hat matrices of large alphas (series.py) ...
+SERIES_TOL = 2e-9                   # ... used when its worst relative error over the spectrum, 1 / T_d(1 + 2 alpha^2),
+                                    # is <= this: 30x below the fp32 epsilon of the values it is stored / consumed in
 LAST_SWEEP = {"precision": None,    # arithmetic the most recent alpha sweep ran in (read by bench.py) ...
               "plain_flops": 0.0, "plain_launches": 0}   # ... and the algorithmic flops of the plain fp16x3 GEMMs
 
@@ -91,11 +91,16 @@ class RidgeCVEngine:
         self.dX = self._resident(X_all, self.p_pad)
         self.dY = self._resident(Y_all, self.Vp)
         self.d_alphas = torch.tensor(self.alphas, dtype=torch.float64, device=self.dev)
-        # alphas whose penalty dwarfs the spectrum take the Neumann series (shared matrix powers), the rest the
-        # batched Cholesky; rho = lambda_max / a^2 = 1 / alpha^2 under normalpha
-        self.ser = [a for a in range(self.A) if self.normalpha and self.alphas[a] ** (-2 * SERIES_TERMS) <= SERIES_TOL]
+        # alphas whose penalty dwarfs the spectrum take the polynomial form of the inverse (shared matrix powers,
+        # minimax coefficients: series.py), the rest the batched Cholesky.  Needs normalpha (a^2 = alpha^2 lambda_max
+        # makes the coefficients a function of alpha alone).
+        self.ser = [a for a in range(self.A)
+                    if self.normalpha and series.residual_bound(self.alphas[a], SERIES_TERMS) <= SERIES_TOL]
         self.cho = [a for a in range(self.A) if a not in self.ser]
         self.d_ser = torch.tensor(self.ser, dtype=torch.int32, device=self.dev) if self.ser else None
+        self.d_coef = (torch.tensor(np.stack([series.minimax_inverse_coefficients(self.alphas[a], SERIES_TERMS)
+                                              for a in self.ser]), dtype=torch.float64, device=self.dev)
+                       if self.ser else None)
         self.d_cho = torch.tensor(self.cho, dtype=torch.int32, device=self.dev)
         self.K = None if self.norm_x else ops.gram(self.dX, self.Ttot, self.p)
         self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
@@ -268,9 +273,8 @@ class RidgeCVEngine:
                     ops.batch_series_terms(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], SERIES_TERMS,
                                            P, rowmap)
             elif ser:
-                ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M,
-                                     lmax[f0:f0 + fc] if lmax is not None else None, self.d_alphas[ser], d_ser, A,
-                                     self.normalpha, SERIES_TERMS, H)
+                ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], self.d_coef, d_ser, A,
+                                     SERIES_TERMS, H)
             series_ready = torch.cuda.Event() if self.dev.type == "cuda" else None
             if series_ready is not None:
                 series_ready.record()           # the series operands of this chunk are complete; Cholesky follows
@@ -334,8 +338,8 @@ class RidgeCVEngine:
                 ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light)
                 LAST_SWEEP["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
                 LAST_SWEEP["plain_launches"] += 1
-                ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv[f], ystat[f], hat["lmax"][f:f + 1],
-                                  hat["a2"][f * A:(f + 1) * A], hat["d_ser"], scores, accumulate=f > 0, rowmap=rowmap)
+                ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv[f], ystat[f], self.d_coef, hat["d_ser"],
+                                  scores, accumulate=f > 0, rowmap=rowmap)
         if done is not None:
             main.wait_event(done)
         # ---- pass 2 (the only one without the moment path): fused sweeps of the alphas that have hat matrices

@@ -231,11 +231,12 @@ def batch_chol_solve(aug, B, N, M, h, slot=None):
     return info
 
 
-def batch_series_hat(k, tr, va, F, N, M, lmax, alphas_s, aidx, A, normalpha, terms, h):
-    S = alphas_s.numel()
+def batch_series_hat(k, tr, va, F, N, M, scale, coef, aidx, A, terms, h):
+    """coef: (S, terms) f64 polynomial coefficients of the S alphas (series.py); scale: (F) f64."""
+    S = aidx.numel()
     work = torch.empty(F * N * N + terms * F * M * N, dtype=torch.float64, device=k.device)
-    _lib.call("lc_batch_series_hat", _p(k), k.stride(0), _p(tr), _p(va), F, N, M, _p(lmax), _p(alphas_s), _p(aidx), S, A,
-              int(bool(normalpha)), terms, _p(work), _p(h), _s())
+    _lib.call("lc_batch_series_hat", _p(k), k.stride(0), _p(tr), _p(va), F, N, M, _p(scale), _p(coef), _p(aidx), S, A,
+              terms, _p(work), _p(h), _s())
 
 
 def batch_series_terms(k, tr, va, F, N, M, scale, terms, out, rowmap=None):
@@ -249,9 +250,9 @@ def gather_sub_f32(k, rows, cols, F, R, C, scale, out):
     _lib.call("lc_gather_sub_f32", _p(k), k.stride(0), _p(rows), _p(cols), F, R, C, _p(scale), _p(out), _s())
 
 
-def series_scores(t, ldt, terms, M, n_val, V, yv, ystat, scale, a2, aidx, scores, accumulate, rowmap=None):
-    _lib.call("lc_series_scores", _p(t), ldt, terms, M, n_val, V, _p(yv), _p(ystat), _p(scale), _p(a2), _p(aidx),
-              aidx.numel(), _p(rowmap), _p(scores), int(bool(accumulate)), _s())
+def series_scores(t, ldt, terms, M, n_val, V, yv, ystat, coef, aidx, scores, accumulate, rowmap=None):
+    _lib.call("lc_series_scores", _p(t), ldt, terms, M, n_val, V, _p(yv), _p(ystat), _p(coef), _p(aidx), aidx.numel(),
+              _p(rowmap), _p(scores), int(bool(accumulate)), _s())
 
 
 def transpose_rows(x, tr, N, p, out):

@@ -201,3 +201,22 @@ def test_band_column_scales_validation():
                 ([(0, 2), (2, 5)], [1.0])):
         with pytest.raises(ValueError):
             band_column_scales(5, *bad)
+
+
+# ------------------------------------------------------------------ polynomial form of the ridge inverse
+def test_minimax_inverse_polynomial():
+    from litcoder_core_amd import series
+    xs = np.linspace(0.0, 1.0, 4001)
+    for alpha in (2.64, 7.85, 23.4, 616.0, 1e8):
+        for terms in (3, 4, 5, 6):
+            c = series.minimax_inverse_coefficients(alpha, terms)
+            res = np.max(np.abs(1.0 - (xs + alpha ** 2) * np.polynomial.polynomial.polyval(xs, c)))
+            bound = series.residual_bound(alpha, terms)
+            assert res <= 1.02 * bound + 5e-16, (alpha, terms, res, bound)
+            taylor = np.array([(-1) ** j * alpha ** (-2.0 * (j + 1)) for j in range(terms)])
+            res_t = np.max(np.abs(1.0 - (xs + alpha ** 2) * np.polynomial.polynomial.polyval(xs, taylor)))
+            assert res <= res_t + 5e-16                      # never worse than the truncated Neumann series
+            np.testing.assert_allclose(c[0], taylor[0], rtol=1e-3)
+    # the engine's membership rule at cfg2: 4 terms serve every alpha >= 7.85 of logspace(-1, 8, 20)
+    al = np.logspace(-1, 8, 20)
+    assert [i for i, a in enumerate(al) if series.residual_bound(a, 4) <= 2e-9] == list(range(4, 20))

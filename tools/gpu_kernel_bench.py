@@ -143,9 +143,9 @@ if "plain16" in what:
               f"{3 * fl / ms / 1e9:.0f} TF of fp16 MFMA; rel err {err:.1e}")
 
 if "series" in what:
-    # lc_series_scores at the cfg2 shape: 5 terms x 480 rows x 80000 voxels, 16 alphas
+    # lc_series_scores at the cfg2 shape: 4 terms x 480 rows x 80000 voxels, 16 alphas
     g = torch.Generator(device=dev); g.manual_seed(2)
-    V, M, n_v, TERMS = 80000, 480, 480, 5
+    V, M, n_v, TERMS = 80000, 480, 480, 4
     Vt = ops.pad_to(V, 256)
     rows = 2560
     Tb = torch.randn((rows, Vt), generator=g, device=dev, dtype=torch.float32)
@@ -155,15 +155,16 @@ if "series" in what:
     yblk = torch.empty((M // LC_MB, V), dtype=torch.float32, device=dev)
     yv = torch.empty((M, V), dtype=torch.float32, device=dev)
     ops.val_stats(Y, V, va, M, n_v, ystat, yblk, yv)
-    scale = torch.tensor([1.0e4], dtype=torch.float64, device=dev)
-    a2 = torch.tensor(np.logspace(-1, 8, 20) ** 2 * 1e4, dtype=torch.float64, device=dev)
+    from litcoder_core_amd import series as lc_series
+    coef = torch.tensor(np.stack([lc_series.minimax_inverse_coefficients(a, TERMS) for a in np.logspace(-1, 8, 20)[4:]]),
+                        dtype=torch.float64, device=dev)
     aidx = torch.arange(4, 20, dtype=torch.int32, device=dev)
     scores = torch.zeros((20, V), dtype=torch.float32, device=dev)
     rowmap_h = np.concatenate([np.arange(480) + 512 * j for j in range(TERMS)]).astype(np.int32)
     rowmap = torch.from_numpy(rowmap_h).to(dev)
     for rm, label in ((None, "contiguous rows"), (rowmap, "row map")):
-        ms = timeit(lambda: ops.series_scores(Tb, Vt, TERMS, M, n_v, V, yv, ystat, scale, a2, aidx, scores, False, rm))
-        print(f"series_scores 5 x 480 x 80000, 16 alphas, {label}: {ms * 1e3:.0f} us "
+        ms = timeit(lambda: ops.series_scores(Tb, Vt, TERMS, M, n_v, V, yv, ystat, coef, aidx, scores, False, rm))
+        print(f"series_scores {TERMS} x 480 x 80000, 16 alphas, {label}: {ms * 1e3:.0f} us "
               f"({TERMS * n_v * V * 4 / ms / 1e6:.0f} GB/s of term reads)")
     ms = timeit(lambda: ops.val_stats(Y, V, va, M, n_v, ystat, yblk, yv))
     print(f"val_stats 480 x 80000: {ms * 1e3:.0f} us")
