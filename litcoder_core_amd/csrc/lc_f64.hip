@@ -407,44 +407,115 @@ __global__ void __launch_bounds__(256) k_transpose_rows(const float* __restrict_
 // registers (L entries are wave-uniform LDS broadcasts).  One block per system.
 constexpr int PD_LD = NB + 1;
 
+// 1 / sqrt(d) for d > 0: hardware estimate + two Newton steps (full fp64 accuracy); sqrt(d) = d * rsqrt(d).
+// The software sqrt and divide of the pivots were the longest dependent chain of the diagonal kernel.
+__device__ inline double rsqrt_nr(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = fma(r, fma(-h * r, r, 0.5), r);
+    r = fma(r, fma(-h * r, r, 0.5), r);
+    return r;
+}
+
 __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ aug, int N, int M, int k,
                                                     double* __restrict__ linv, int* __restrict__ info) {
     __shared__ double L[NB * PD_LD];
+    __shared__ double rdiag[NB];                       // 1 / L[i][i]
     const int b = blockIdx.x;
     const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
     double* a = aug + (long long)b * (N + M) * N + (long long)k * NB * N + k * NB;
     for (int e = t; e < NB * NB; e += 256) L[(e >> 6) * PD_LD + (e & 63)] = a[(long long)(e >> 6) * N + (e & 63)];
     __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        __syncthreads();                              // column j is final up to its scaling
-        const double d = L[j * PD_LD + j];
-        if (t == 0 && !(d > 0.0) && info[b] == 0) info[b] = k * NB + j + 1;
-        const double inv = 1.0 / sqrt(d), inv2 = 1.0 / d;
-        // trailing update with the still unscaled column j:  L[i][c] -= L[i][j] L[c][j] / d,  j < c <= i
-        for (int i = j + 1 + ti; i < NB; i += 16) {
-            const double lij = L[i * PD_LD + j] * inv2;
-            for (int c = j + 1 + tj; c <= i; c += 16) L[i * PD_LD + c] -= lij * L[c * PD_LD + j];
+    // Four columns per step (16 steps, two barriers each): every thread factors the 4 x 4 pivot block redundantly
+    // in registers, transforms the panel rows it needs on the fly (l = a G^-T, six FMAs) and applies the rank-4
+    // update; the scaled panel is written after the second barrier.  Latency, not flops, is what this kernel
+    // costs (one workgroup per system), and the barrier count is its latency.
+    for (int j = 0; j < NB; j += 4) {
+        __syncthreads();                              // columns j..j+3 are final up to their scaling
+        double g00 = L[j * PD_LD + j];
+        const double a10 = L[(j + 1) * PD_LD + j], a11 = L[(j + 1) * PD_LD + j + 1];
+        const double a20 = L[(j + 2) * PD_LD + j], a21 = L[(j + 2) * PD_LD + j + 1], a22 = L[(j + 2) * PD_LD + j + 2];
+        const double a30 = L[(j + 3) * PD_LD + j], a31 = L[(j + 3) * PD_LD + j + 1], a32 = L[(j + 3) * PD_LD + j + 2],
+                     a33 = L[(j + 3) * PD_LD + j + 3];
+        int bad = 0;
+        if (!(g00 > 0.0)) bad = 1;
+        const double r0 = rsqrt_nr(g00);
+        g00 *= r0;
+        const double g10 = a10 * r0, g20 = a20 * r0, g30 = a30 * r0;
+        double g11 = a11 - g10 * g10;
+        if (!bad && !(g11 > 0.0)) bad = 2;
+        const double r1 = rsqrt_nr(g11);
+        g11 *= r1;
+        const double g21 = (a21 - g20 * g10) * r1, g31 = (a31 - g30 * g10) * r1;
+        double g22 = a22 - g20 * g20 - g21 * g21;
+        if (!bad && !(g22 > 0.0)) bad = 3;
+        const double r2 = rsqrt_nr(g22);
+        g22 *= r2;
+        const double g32 = (a32 - g30 * g20 - g31 * g21) * r2;
+        double g33 = a33 - g30 * g30 - g31 * g31 - g32 * g32;
+        if (!bad && !(g33 > 0.0)) bad = 4;
+        const double r3 = rsqrt_nr(g33);
+        g33 *= r3;
+        if (t == 0 && bad && info[b] == 0) info[b] = k * NB + j + bad;
+        // l = a G^-T for a panel row a = (x0..x3)
+#define LC_ROW_TRANSFORM(x0, x1, x2, x3, l0, l1, l2, l3)                 \
+        const double l0 = (x0) * r0;                                      \
+        const double l1 = ((x1) - l0 * g10) * r1;                         \
+        const double l2 = ((x2) - l0 * g20 - l1 * g21) * r2;              \
+        const double l3 = ((x3) - l0 * g30 - l1 * g31 - l2 * g32) * r3;
+        for (int i = j + 4 + ti; i < NB; i += 16) {
+            const double* ai = L + i * PD_LD + j;
+            LC_ROW_TRANSFORM(ai[0], ai[1], ai[2], ai[3], li0, li1, li2, li3)
+            for (int c = j + 4 + tj; c <= i; c += 16) {
+                const double* ac = L + c * PD_LD + j;
+                LC_ROW_TRANSFORM(ac[0], ac[1], ac[2], ac[3], lc0, lc1, lc2, lc3)
+                L[i * PD_LD + c] -= li0 * lc0 + li1 * lc1 + li2 * lc2 + li3 * lc3;
+            }
         }
-        __syncthreads();                              // all reads of the unscaled column are done
-        for (int i = j + t; i < NB; i += 256) L[i * PD_LD + j] *= inv;     // pivot becomes sqrt(d)
+        __syncthreads();                              // all reads of the unscaled panel are done
+        for (int i = j + 4 + t; i < NB; i += 256) {
+            double* ai = L + i * PD_LD + j;
+            LC_ROW_TRANSFORM(ai[0], ai[1], ai[2], ai[3], l0, l1, l2, l3)
+            ai[0] = l0; ai[1] = l1; ai[2] = l2; ai[3] = l3;
+        }
+#undef LC_ROW_TRANSFORM
+        if (t == 255) {                               // the pivot block itself
+            L[j * PD_LD + j] = g00;
+            L[(j + 1) * PD_LD + j] = g10; L[(j + 1) * PD_LD + j + 1] = g11;
+            L[(j + 2) * PD_LD + j] = g20; L[(j + 2) * PD_LD + j + 1] = g21; L[(j + 2) * PD_LD + j + 2] = g22;
+            L[(j + 3) * PD_LD + j] = g30; L[(j + 3) * PD_LD + j + 1] = g31; L[(j + 3) * PD_LD + j + 2] = g32;
+            L[(j + 3) * PD_LD + j + 3] = g33;
+            rdiag[j] = r0; rdiag[j + 1] = r1; rdiag[j + 2] = r2; rdiag[j + 3] = r3;
+        }
     }
     __syncthreads();
     for (int e = t; e < NB * NB; e += 256) {
         const int i = e >> 6, j = e & 63;
         a[(long long)i * N + j] = j <= i ? L[i * PD_LD + j] : 0.0;
     }
-    if (t < NB) {
-        double x[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            double s = (i == t) ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < i; ++q) s -= L[i * PD_LD + q] * x[q];
-            x[i] = s / L[i * PD_LD + i];
-        }
+    // Linv = inv(L): column c by forward substitution, four lanes per column -- lane part r keeps the entries
+    // x_q with q = r (mod 4) and sums their share of every row's dot product, two shuffles combine the shares.
+    {
+        const int c = t >> 2, r = t & 3;
+        double x[NB / 4];
         double* lo = linv + ((long long)b * (N / NB) + k) * NB * NB;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) lo[i * NB + t] = x[i];
+        for (int i = 0; i < NB; ++i) {
+            double sp = 0.0;
+#pragma unroll
+            for (int m = 0; m < NB / 4; ++m)
+                if (4 * m < i) {                             // static bound; the lane's own q = 4m + r may still be >= i
+                    const int q = 4 * m + r;
+                    if (q < i) sp = fma(L[i * PD_LD + q], x[m], sp);
+                }
+            sp += __shfl_xor(sp, 1);
+            sp += __shfl_xor(sp, 2);
+            const double xi = ((i == c ? 1.0 : 0.0) - sp) * rdiag[i];
+            if (r == (i & 3)) {
+                x[i >> 2] = xi;
+                lo[i * NB + c] = xi;
+            }
+        }
     }
 }
 
