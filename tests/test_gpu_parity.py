@@ -268,6 +268,30 @@ def test_randomised_shapes_against_oracle(lc):
                 assert m["n_significant"] == m_o["n_significant"], tag
 
 
+def test_series_moments_match_per_alpha_hat_matrices(lc):
+    """The alphas on the polynomial series are scored from the moments of the shared terms (one contraction, light
+    slabs, f32-MFMA chain or fp64 chain) -- against the same alphas expanded into per-alpha hat matrices and sent
+    through the fused sweep, on shapes that hit the padding of every layout (slabs, quads, odd fold sizes)."""
+    from litcoder_core_amd.nested_cv import RidgeCVEngine
+    rng = np.random.default_rng(77)
+    alphas = np.logspace(-1, 6, 12)
+    for (T, p, V, cuts) in ((300, 90, 333, (200, 260)), (450, 700, 130, (256, 390)), (171, 40, 64, (100, 139))):
+        X = rng.standard_normal((T, p))
+        Y = X @ (rng.standard_normal((p, V)) * (0.4 / np.sqrt(p))) + rng.standard_normal((T, V))
+        a, b = cuts
+        inner = [(np.r_[0:a], np.r_[a:b]), (np.r_[0:a - 37, b:T], np.r_[a - 37:b])]
+        eng = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
+        assert eng.ser and eng.cho, "grid must straddle the series threshold"
+        s_mom, info = eng._alpha_scores(eng.K, eng.dY, inner)
+        eng._series_by_moments = lambda Y_: False
+        s_hat, info2 = eng._alpha_scores(eng.K, eng.dY, inner)
+        assert not int(info.cpu().numpy().any()) and not int(info2.cpu().numpy().any())
+        s_mom, s_hat = s_mom[:, :V].cpu().numpy(), s_hat[:, :V].cpu().numpy()
+        np.testing.assert_array_equal(s_mom[eng.cho], s_hat[eng.cho])           # same kernel, same operands
+        np.testing.assert_allclose(s_mom[eng.ser], s_hat[eng.ser], rtol=0, atol=3e-6)
+        assert (np.argmax(s_mom, axis=0) == np.argmax(s_hat, axis=0)).mean() >= 0.99
+
+
 def test_fit_nested_cv_alias(lc):
     rng = np.random.default_rng(6)
     X = rng.standard_normal((150, 24))
