@@ -165,6 +165,12 @@ class RidgeCVEngine:
             out.append(ops.lambda_max_masked(K, self.Ttot, member, len(chunk), self.steps))
         return torch.cat(out)
 
+    def begin_fit(self):
+        """Decide the arithmetic of the V-wide contractions now (column scales of the targets + the one flag that
+        comes to the host), so that the first fold's set-up is enqueued without waiting on the device."""
+        if not self.norm_y:
+            self._use_split(self.dY)
+
     def precompute_lmax(self, outer):
         """(inner-fold lmax (F,), outer-train lmax (1,)) per outer fold from ONE Lanczos run over the shared Gram
         matrix; [None, ...] when there is nothing to share (no normalpha, or normalize_features gives every
@@ -735,6 +741,7 @@ class NestedCVModel(BasePredictivityModel):
             any_nan.append(bool(np.isnan(r32).any()))
 
         pending = None
+        eng.begin_fit()                                     # the one host sync of the set-up, before anything is queued
         lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
         n = len(outer)
         st = eng.fold_begin(*outer[0], prepared=eng.fold_prepare(*outer[0], lmax_pre=lmax_pre[0]))

@@ -47,6 +47,8 @@ class OracleEngine:
         self.W += scale * W.numpy()
         from litcoder_core_amd import stats
         return ncv._FoldResult(r, stats.pearson_pvalues(r.astype(np.float32), len(te)), idx, len(te))
+    def begin_fit(self):
+        pass
     def precompute_lmax(self, outer):
         return [None] * len(outer)
     def fold_prepare(self, tr, te, inner, lmax_pre=None):
