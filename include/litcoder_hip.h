@@ -257,11 +257,17 @@ int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float
 int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_rows, int K,
                       const float* d_cscale, void* d_tiled, lc_stream_t stream);
 
+/* "B view" (both fp16x3 entry points): d_yt / d_bt may be the tiled image of MORE rows than the product
+ * contracts -- the targets of a whole outer training set, split once -- of which the product skips one aligned gap
+ * (the validation block of an inner fold).  b_rows = rows of the image (0: the image is exactly the K rows),
+ * b_gap_begin / b_gap_rows = first row and length of the skipped block in image rows; all multiples of 16, and
+ * K + b_gap_rows <= b_rows. */
 int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
                                 const void* d_yt, const float* d_cscale_inv,
                                 const float* d_yv, int64_t V, int n_val,
                                 const float* d_ystat, const float* d_yblk,
-                                int mode, float* d_part, float* d_scores, int accumulate, lc_stream_t stream);
+                                int mode, float* d_part, float* d_scores, int accumulate,
+                                int64_t b_rows, int64_t b_gap_begin, int64_t b_gap_rows, lc_stream_t stream);
 
 /* Correlation scores (mode LC_SCORE_CORR, same formula and nan_to_num as lc_alpha_sweep_scores) of S series
  * alphas of ONE inner fold from d_t (terms*M, ldt) f32 = the stacked T_j = P'_j Y (lc_batch_series_terms +
@@ -294,7 +300,8 @@ int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A
 int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows,
                           const void* d_bt, const float* d_cscale_inv, float* d_c, int64_t ldc,
                           int64_t Ncols, int64_t K, const int32_t* h_group_tiles, int G,
-                          const uint8_t* d_slab_light, lc_stream_t stream);
+                          const uint8_t* d_slab_light,
+                          int64_t b_rows, int64_t b_gap_begin, int64_t b_gap_rows, lc_stream_t stream);
 
 /* best[v] = first argmax_a scores[a, v] / n_folds (nested_cv.py:391-408); also
  * d_rowsum[a] = sum_v scores[a, v] (f64) for the single-alpha path (:396-400, all-reduced

@@ -62,11 +62,11 @@ SIGNATURES = {
     "lc_col_scales_f16": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_split_cols_f16": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, _ptr, _ptr, _ptr]),
     "lc_alpha_sweep_scores_f16x3": (c_int, [_ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int, _ptr, _ptr,
-                                            c_int, _ptr, _ptr, c_int, _ptr]),
+                                            c_int, _ptr, _ptr, c_int, c_int64, c_int64, c_int64, _ptr]),
     "lc_debug_sweep16_stamps": (c_int, [_ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int, _ptr, _ptr, _ptr,
                                         _ptr]),
     "lc_gemm_grouped_f16x3": (c_int, [_ptr, _ptr, c_int64, _ptr, _ptr, _ptr, c_int64, c_int64, c_int64,
-                                      POINTER(c_int32), c_int, _ptr, _ptr]),
+                                      POINTER(c_int32), c_int, _ptr, c_int64, c_int64, c_int64, _ptr]),
     "lc_select_alpha": (c_int, [_ptr, c_int, c_int64, _ptr, _ptr, _ptr]),
     "lc_group_by_alpha": (c_int, [_ptr, c_int64, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_gemm_grouped_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, _ptr, _ptr, c_int64, c_int64, c_int64,

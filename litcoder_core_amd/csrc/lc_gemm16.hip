@@ -160,6 +160,14 @@ struct Score16Args {
     int M, n_val, mode, Mrows;
 };
 
+// Which K-tiles of the tiled B image a launch contracts: the image may hold MORE rows than the product uses (the
+// targets of a whole outer training set, split once), and the product skips one aligned gap of it (the validation
+// block of the inner fold):  K-tile kt of the product is tile kt + (kt >= cut ? skip : 0) of the image.
+struct BView {
+    int kt_total;          // K-tiles per column tile of the image
+    int cut, skip;
+};
+
 // plain (store) mode: C[:, tile] = A_g(tile) . B[:, tile] with one A matrix per column group
 constexpr int MAX_GROUPS16 = 64;
 struct Plain16Args {
@@ -187,7 +195,7 @@ struct Plain16Args {
 template <bool SCORE, bool STAMP, bool LIGHTCAP = false>
 __global__ void __launch_bounds__(512, 2)
 k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT, int Mtiles, Score16Args sa,
-              Plain16Args pa) {
+              Plain16Args pa, BView bv) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds16[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform (scalar)
@@ -201,7 +209,8 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         while (grp + 1 < pa.G && nt >= pa.start[grp + 1]) ++grp;
     }
     const uint4* a_src = At + ((long long)grp * Mtiles + mt) * KT * CHUNK16 + tid;
-    const uint4* b_src = Bt + (long long)nt * KT * CHUNK16 + tid;
+    const uint4* b_src = Bt + (long long)nt * bv.kt_total * CHUNK16 + tid;
+#define BKT(kt_) ((kt_) + ((kt_) >= bv.cut ? bv.skip : 0))
     // "light" slabs (plain mode): rows whose product only needs fp16 accuracy (11-bit operands) -- the higher
     // terms of a series, which enter the caller's result scaled down by >= 2^-11 -- take the hi*hi MFMA alone
     const bool light = LIGHTCAP && !SCORE && pa.slab_light != nullptr &&
@@ -231,7 +240,7 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 #define GLDS16(kt_, stg_)                                                           \
     {                                                                               \
         const uint4* pa_ = a_src + (long long)(kt_) * CHUNK16;                      \
-        const uint4* pb_ = b_src + (long long)(kt_) * CHUNK16;                      \
+        const uint4* pb_ = b_src + (long long)BKT(kt_) * CHUNK16;                   \
         DMA16(pa_, (stg_) * STAGE16);                                               \
         DMA16(pa_ + 512, (stg_) * STAGE16 + 512);                                   \
         DMA16(pb_, (stg_) * STAGE16 + CHUNK16);                                     \
@@ -323,7 +332,7 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         const uint4* stn = lds16 + ((kt + 1) & 3) * STAGE16;
         const int stg = kt & 3;
         const uint4* pa_ = a_src + (long long)(kt + 4) * CHUNK16;
-        const uint4* pb_ = b_src + (long long)(kt + 4) * CHUNK16;
+        const uint4* pb_ = b_src + (long long)BKT(kt + 4) * CHUNK16;
         if (LAST && SCORE) { load_t(0, tb0); load_t(1, tb1); }   // land under the MFMAs of the last tile
         // 12 slots of two MFMAs, term-major (the eight accumulators take the lo*hi terms, then hi*lo, then
         // hi*hi: small terms first, and consecutive MFMAs never wait for each other's result)
@@ -361,7 +370,7 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         const uint4* stn = lds16 + ((kt + 1) & 3) * STAGE16;
         const int stg = kt & 3;
         const uint4* pa_ = a_src + (long long)(kt + 4) * CHUNK16;
-        const uint4* pb_ = b_src + (long long)(kt + 4) * CHUNK16;
+        const uint4* pb_ = b_src + (long long)BKT(kt + 4) * CHUNK16;
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
 #pragma unroll
@@ -510,6 +519,19 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int A, int M, int n_val,
                              long long V, int mode, float* d_scores, int accumulate, hipStream_t s);
 
+// B view from the C-ABI triple (rows of the image, first row of the gap, rows of the gap; all multiples of 16)
+static int make_bview(const char* who, int64_t K, int64_t b_rows, int64_t gap_begin, int64_t gap_rows, BView* bv) {
+    if (b_rows <= 0) { b_rows = K; gap_begin = K; gap_rows = 0; }
+    LC_REQUIRE(b_rows % TK == 0 && gap_begin % TK == 0 && gap_rows % TK == 0 && gap_rows >= 0 && gap_begin >= 0 &&
+                   gap_begin <= K && K + gap_rows <= b_rows,
+               LC_E_SHAPE, "%s: B view needs b_rows, gap_begin, gap_rows multiples of %d with K + gap_rows <= b_rows", who,
+               TK);
+    bv->kt_total = (int)(b_rows / TK);
+    bv->cut = (int)(gap_begin / TK);
+    bv->skip = (int)(gap_rows / TK);
+    return LC_OK;
+}
+
 extern "C" int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int64_t K, void* d_tiled,
                                  float* d_rowscale_inv, lc_stream_t stream) {
     LC_REQUIRE(d_h && d_tiled && d_rowscale_inv, LC_E_BADARG, "lc_split_rows_f16: null pointer");
@@ -547,7 +569,8 @@ extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rows
                                            const void* d_yt, const float* d_cscale_inv, const float* d_yv,
                                            int64_t V, int n_val, const float* d_ystat,
                                            const float* d_yblk, int mode, float* d_part, float* d_scores,
-                                           int accumulate, lc_stream_t stream) {
+                                           int accumulate, int64_t b_rows, int64_t b_gap_begin, int64_t b_gap_rows,
+                                           lc_stream_t stream) {
     LC_REQUIRE(d_ht && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_part && d_scores,
                LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: null pointer");
     LC_REQUIRE(A > 0 && M > 0 && M % LC_MB == 0 && n_val > 0 && n_val <= M && N > 0 && N % (2 * TK) == 0,
@@ -561,6 +584,8 @@ extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rows
         attr_done = true;
     }
     hipStream_t s = lc::as_stream(stream);
+    BView bv;
+    if (int rc = make_bview("lc_alpha_sweep_scores_f16x3", N, b_rows, b_gap_begin, b_gap_rows, &bv)) return rc;
     const int Mrows = A * M;
     const int Mtiles = lc::ceil_div(Mrows, TM);
     const long long Ntiles = lc::ceil_div<long long>(V, TN);
@@ -570,7 +595,7 @@ extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rows
         lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
         Plain16Args pa{};
         hipLaunchKernelGGL((k_sweep_f16x3<true, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
-                           (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa);
+                           (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa, bv);
     }
     if (int rc = lc::launched("k_sweep_f16x3")) return rc;
     return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, n_val, (long long)V, mode, d_scores, accumulate, s);
@@ -579,7 +604,7 @@ extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rows
 extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
                                      const float* d_cscale_inv, float* d_c, int64_t ldc, int64_t Ncols, int64_t K,
                                      const int32_t* h_group_tiles, int G, const uint8_t* d_slab_light,
-                                     lc_stream_t stream) {
+                                     int64_t b_rows, int64_t b_gap_begin, int64_t b_gap_rows, lc_stream_t stream) {
     LC_REQUIRE(d_at && d_rowscale_inv && d_bt && d_cscale_inv && d_c && h_group_tiles, LC_E_BADARG,
                "lc_gemm_grouped_f16x3: null pointer");
     LC_REQUIRE(G >= 1 && G <= MAX_GROUPS16, LC_E_SHAPE, "lc_gemm_grouped_f16x3: G must be in 1..%d", MAX_GROUPS16);
@@ -595,6 +620,8 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     }
     const int Mtiles = (int)lc::ceil_div<long long>(Mrows, TM);
     const long long Ntiles = Ncols / TN;
+    BView bv;
+    if (int rc = make_bview("lc_gemm_grouped_f16x3", K, b_rows, b_gap_begin, b_gap_rows, &bv)) return rc;
     Plain16Args pa{};
     pa.c = d_c;
     pa.ldc = ldc;
@@ -616,10 +643,10 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
     if (d_slab_light)
         hipLaunchKernelGGL((k_sweep_f16x3<false, false, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES,
-                           s, (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa);
+                           s, (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa, bv);
     else
         hipLaunchKernelGGL((k_sweep_f16x3<false, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
-                           (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa);
+                           (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa, bv);
     return lc::launched("k_sweep_f16x3<plain>");
 }
 
@@ -640,6 +667,7 @@ extern "C" int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale
     Plain16Args pa{};
     pa.c = reinterpret_cast<float*>(d_stamps);
     hipLaunchKernelGGL((k_sweep_f16x3<true, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES,
-                       lc::as_stream(stream), (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa);
+                       lc::as_stream(stream), (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa,
+                       BView{N / TK, N / TK, 0});
     return lc::launched("k_sweep_f16x3<stamp>");
 }

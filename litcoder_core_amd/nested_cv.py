@@ -219,6 +219,30 @@ class RidgeCVEngine:
             self._layout_key = key
         return self._layout
 
+    def _shared_image(self, inner_abs, N):
+        """One tiled fp16 image of the targets for all inner folds of an outer fold: possible when every inner
+        training set is the same row sequence minus one block whose position and length are multiples of 16 (the
+        K-tile of the MFMA kernels) and no padding rows are needed -- contiguous K-folds of a multiple-of-16 fold
+        length.  Returns (union rows, [(gap_begin, gap_rows) per fold]) or None (one split per inner fold)."""
+        sets = [np.asarray(t_, dtype=np.int64) for t_, _ in inner_abs]
+        if len(sets) < 2 or any(len(s_) != N for s_ in sets):
+            return None
+        union = np.unique(np.concatenate(sets))
+        if len(union) % 16 or (len(union) - N) % 16:
+            return None
+        pos = {int(r): i for i, r in enumerate(union)}
+        gaps = []
+        for s_ in sets:
+            idx = np.fromiter((pos[int(r)] for r in s_), dtype=np.int64, count=N)
+            if np.any(np.diff(idx) <= 0):
+                return None                                  # not in the union's order
+            missing = np.setdiff1d(np.arange(len(union)), idx)
+            if len(missing) != len(union) - N or (len(missing) and
+                                                  (missing[-1] - missing[0] + 1 != len(missing) or missing[0] % 16)):
+                return None
+            gaps.append((int(missing[0]) if len(missing) else N, int(len(missing))))
+        return union, gaps
+
     def _series_by_moments(self, Y):
         """Score the series alphas from the moments of the shared terms T_j = P'_j Y (one contraction for all of
         them, lc_series_scores) instead of one hat matrix per alpha: correlation scoring on the fp16x3 path only
@@ -295,7 +319,7 @@ class RidgeCVEngine:
                 del aug
             Hs.append((f0, fc, H, P))
         info = torch.cat(infos) if infos else torch.zeros(1, dtype=torch.int32, device=self.dev)
-        return dict(F=F, N=N, M=M, n_v=n_v, n_i=n_i, tr=tr, va=va, Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
+        return dict(F=F, N=N, M=M, n_v=n_v, n_i=n_i, tr=tr, va=va, shared=self._shared_image(inner_abs, N), Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
                     d_ser=d_ser, moments=moments, series_ready=series_ready)
 
     def _sweeps(self, hat, Y, done=None):
@@ -319,13 +343,24 @@ class RidgeCVEngine:
         ystat = [torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev) for _ in range(nbuf)]
         yblk = [torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev) for _ in range(nbuf)]
         yv = [torch.empty((M, self.Vp), dtype=torch.float32, device=self.dev) for _ in range(nbuf)]
+        shared = hat.get("shared") if split else None
         if split:
             rows_pad = ops.pad_to(max(Ad, 1) * M, 256)
             cs = self._cs
             Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
             rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
             Vt = ops.pad_to(self.Vp, 256)
-            Yt = [torch.empty(Vt * N * 2, dtype=torch.float16, device=self.dev) for _ in range(nbuf)]
+            if shared is not None:
+                # the targets of the whole outer training set split once; every inner fold contracts it minus one
+                # aligned block (B view): saves F - 1 passes over Y per outer fold
+                union, gaps = shared
+                Yu = torch.empty(Vt * len(union) * 2, dtype=torch.float16, device=self.dev)
+                ops.split_cols_f16(Y, self.Vp, ops.idx_tensor(union, len(union), self.dev), len(union), cs, Yu)
+                Yt = [Yu] * nbuf
+                views = [(len(union), g0, gl) for g0, gl in gaps]
+            else:
+                Yt = [torch.empty(Vt * N * 2, dtype=torch.float16, device=self.dev) for _ in range(nbuf)]
+                views = [(0, 0, 0)] * F
         folds = [(f0 + j, j, H, P) for f0, fc, H, P in hat["Hs"] for j in range(fc)]
         if moments:
             # ---- pass 1: validation statistics, operand split, series contraction + moment kernel
@@ -339,9 +374,11 @@ class RidgeCVEngine:
                 main.wait_event(hat["series_ready"])
             for f, j, H, P in folds:
                 ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat[f], yblk[f], yv[f])
-                ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[f])
+                if shared is None:
+                    ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[f])
                 ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
-                ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light)
+                ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
+                                       bview=views[f])
                 LAST_SWEEP["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
                 LAST_SWEEP["plain_launches"] += 1
                 ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv[f], ystat[f], self.d_coef, hat["d_ser"],
@@ -354,12 +391,12 @@ class RidgeCVEngine:
             if not moments:
                 ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat[b], yblk[b], yv[b])
             if split:
-                if not moments:
+                if not moments and shared is None:
                     ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[b])
                 if Ad:
                     ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
                     ops.alpha_sweep_scores_f16x3(Ht, rs_inv, Ad, M, N, Yt[b], cs[self.Vp:], yv[b], self.Vp, n_v[f], ystat[b],
-                                                 yblk[b], self.mode, part, scores_d, accumulate=f > 0)
+                                                 yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f])
             else:
                 ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], yv[b], n_v[f], ystat[b], yblk[b],
                                        self.mode, part, scores, accumulate=f > 0)

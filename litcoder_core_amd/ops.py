@@ -287,16 +287,19 @@ def split_cols_f16(y, V, rows, K, cscale, tiled):
 
 
 def alpha_sweep_scores_f16x3(ht, rowscale_inv, A, M, N, yt, cscale_inv, yv, V, n_val, ystat, yblk, mode, part, scores,
-                             accumulate):
+                             accumulate, bview=(0, 0, 0)):
+    """``bview`` = (rows of the tiled image yt, first row of the skipped block, its length); (0, 0, 0): yt holds
+    exactly the N contracted rows."""
     _lib.call("lc_alpha_sweep_scores_f16x3", _p(ht), _p(rowscale_inv), A, M, N, _p(yt), _p(cscale_inv), _p(yv), V, n_val,
-              _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), _s())
+              _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), *bview, _s())
 
 
-def gemm_grouped_f16x3(at, rowscale_inv, Mrows, bt, cscale_inv, c, ldc, Ncols, K, group_tiles, slab_light=None):
+def gemm_grouped_f16x3(at, rowscale_inv, Mrows, bt, cscale_inv, c, ldc, Ncols, K, group_tiles, slab_light=None,
+                       bview=(0, 0, 0)):
     G = len(group_tiles) - 1
     arr = (ctypes.c_int32 * (G + 1))(*[int(t) for t in group_tiles])
     _lib.call("lc_gemm_grouped_f16x3", _p(at), _p(rowscale_inv), Mrows, _p(bt), _p(cscale_inv), _p(c), ldc, Ncols, K,
-              arr, G, _p(slab_light), _s())
+              arr, G, _p(slab_light), *bview, _s())
 
 
 def select_alpha(scores, A, V, want_best=True, want_rowsum=False):

@@ -292,6 +292,29 @@ def test_series_moments_match_per_alpha_hat_matrices(lc):
         assert (np.argmax(s_mom, axis=0) == np.argmax(s_hat, axis=0)).mean() >= 0.99
 
 
+def test_shared_target_image_is_bitwise_neutral(lc):
+    """Aligned K-folds contract one tiled fp16 image of the outer training targets through a "B view" (the
+    validation block skipped) instead of one image per inner fold: the operands are the same numbers, so the
+    score table must be identical bit for bit; unaligned folds must fall back by themselves."""
+    from litcoder_core_amd.nested_cv import RidgeCVEngine
+    rng = np.random.default_rng(5)
+    T, p, V = 640, 100, 300
+    X = rng.standard_normal((T, p))
+    Y = X @ (rng.standard_normal((p, V)) * 0.05) + rng.standard_normal((T, V))
+    alphas = np.logspace(-1, 4, 8)
+    tr_o = np.r_[0:128, 256:640]                                       # 512 outer-train rows
+    inner = [(np.delete(tr_o, np.s_[k * 128:(k + 1) * 128]), tr_o[k * 128:(k + 1) * 128]) for k in range(4)]
+    eng = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
+    assert eng._shared_image(inner, 384) is not None
+    s_shared, _ = eng._alpha_scores(eng.K, eng.dY, inner)
+    eng._shared_image = lambda *a: None
+    s_plain, _ = eng._alpha_scores(eng.K, eng.dY, inner)
+    assert torch.equal(s_shared, s_plain)
+    eng2 = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
+    ragged = [(np.delete(tr_o, np.s_[k * 128 + 8:(k + 1) * 128 + 8]), tr_o[k * 128 + 8:(k + 1) * 128 + 8]) for k in range(3)]
+    assert eng2._shared_image(ragged, 384) is None                       # gap not a multiple of 16 rows in
+
+
 def test_fit_nested_cv_alias(lc):
     rng = np.random.default_rng(6)
     X = rng.standard_normal((150, 24))
