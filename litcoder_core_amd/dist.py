@@ -34,6 +34,19 @@ class ShardContext:
         self.device = device
         self.rank = self._dist.get_rank(group) if self._dist else 0
         self.world = self._dist.get_world_size(group) if self._dist else 1
+        self._comm = None
+
+    def _comm_scope(self):
+        """The exchanges carry host data (per-voxel result vectors, score sums): on a GPU they run on a stream of
+        their own, so that neither the staging copies nor the collective queue behind the fit's kernels already
+        enqueued on the compute streams."""
+        import contextlib
+        if self.device is not None and getattr(self.device, "type", None) == "cuda":
+            import torch
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=self.device)
+            return torch.cuda.stream(self._comm)
+        return contextlib.nullcontext()
 
     def bounds(self, n_items: int) -> Tuple[int, int]:
         return shard_bounds(n_items, self.world, self.rank)
@@ -47,9 +60,10 @@ class ShardContext:
         """Element-wise sum over ranks of a small float64 vector."""
         if self.world == 1:
             return np.asarray(arr, dtype=np.float64)
-        t = self._tensor(np.asarray(arr, dtype=np.float64))
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy()
+        with self._comm_scope():
+            t = self._tensor(np.asarray(arr, dtype=np.float64))
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+            return t.cpu().numpy()
 
     def allgather_cols(self, arr: np.ndarray, n_total: int) -> np.ndarray:
         """``arr`` is (k, n_local) for this rank's block; returns (k, n_total) on every rank."""
@@ -62,12 +76,13 @@ class ShardContext:
         wmax = max(hi - lo for lo, hi in widths)
         pad = np.zeros((k, wmax), dtype=arr.dtype)
         pad[:, : arr.shape[1]] = arr
-        mine = self._tensor(pad)
-        parts = [torch.empty_like(mine) for _ in range(self.world)]
-        self._dist.all_gather(parts, mine, group=self.group)
         out = np.empty((k, n_total), dtype=arr.dtype)
-        for (lo, hi), part in zip(widths, parts):
-            out[:, lo:hi] = part.cpu().numpy()[:, : hi - lo]
+        with self._comm_scope():
+            mine = self._tensor(pad)
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            self._dist.all_gather(parts, mine, group=self.group)
+            for (lo, hi), part in zip(widths, parts):
+                out[:, lo:hi] = part.cpu().numpy()[:, : hi - lo]
         return out
 
     def barrier(self):
