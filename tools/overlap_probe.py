@@ -66,6 +66,22 @@ sweeps(2); chols(1)
 t_s = wall(sweeps)
 t_c = wall(chols)
 print(f"12 sweeps alone {t_s:.1f} ms; 6 Cholesky batches (B=20, N=1920, M=480) alone {t_c:.1f} ms; sum {t_s + t_c:.1f} ms")
+# two independent Cholesky chains on two streams (do the serial diagonal steps of one hide behind the other?)
+aug_b = base.clone()
+H2b = torch.empty_like(H2)
+s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+
+def chols_two_streams(n=6):
+    for i in range(n):
+        with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+            tgt, out = (aug, H2) if i % 2 == 0 else (aug_b, H2b)
+            tgt.copy_(base)
+            ops.batch_chol_solve(tgt, B_, N_, M_, out)
+
+
+chols_two_streams(2)
+print(f"6 Cholesky batches alternating between two streams: {wall(chols_two_streams):.1f} ms")
 for prio in (0, -1):
     aux = torch.cuda.Stream(device=dev, priority=prio)
 
