@@ -208,8 +208,8 @@ def main():
                          "kernel": "k_sweep_f16x3 (fused alpha sweep, 3 fp16 MFMAs per product)" if split
                                    else "k_gemm_f32<score> (fused alpha sweep, f32-input MFMA)",
                          "note": "peak = dense fp16 MFMA datasheet figure at 2.4 GHz; under this kernel the chip holds "
-                                 "1.4-1.5 GHz (in-kernel s_memtime/s_memrealtime, profiles/), where the same MFMA stream "
-                                 "tops out at ~1.5 PFLOP/s" if split else None,
+                                 "1.4-1.8 GHz (in-kernel s_memtime/s_memrealtime, profiles/), where the same MFMA stream "
+                                 "tops out at 1.5-1.8 PFLOP/s" if split else None,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic,
                          "algorithmic_tflops": alg_tflops, "mfma_per_product": mfma_per_product,
