@@ -28,6 +28,50 @@ __global__ void __launch_bounds__(512) k_rate(int iters, float* out, unsigned lo
     if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; cyc[256 + blockIdx.x] = r1 - r0; cyc[512 + blockIdx.x] = r0; }
 }
 
+// the same flops per wave with v_mfma_f32_16x16x32_f16 (4 accumulator VGPRs per block, 16 cycles per MFMA)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ void __launch_bounds__(512) k_rate16(int iters, float* out, unsigned long long* cyc) {
+    f32x4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    h8 a, b;
+    for (int r = 0; r < 8; ++r) { a[r] = (_Float16)(threadIdx.x * 0.001f + r); b[r] = (_Float16)(r * 0.5f); }
+    unsigned long long t0, t1, r0, r1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 3; ++rep)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; cyc[256 + blockIdx.x] = r1 - r0; cyc[512 + blockIdx.x] = r0; }
+}
+
+void run16(int threads) {
+    const int blocks = 256, iters = 4000;
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, blocks * 512 * 4); hipMalloc(&cyc, 3 * blocks * 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_rate16<32>, dim3(blocks), dim3(threads), 0, 0, 10, out, cyc);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_rate16<32>, dim3(blocks), dim3(threads), 0, 0, iters, out, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[768]; hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+    double mean = 0, real = 0;
+    for (int i = 0; i < blocks; ++i) { mean += h[i]; real += h[256 + i]; }
+    mean /= blocks; real /= blocks;
+    const double flops = (double)iters * 3 * 32 * 16384.0 * blocks * (threads / 64);
+    printf("16x16x32, %d waves/SIMD, 32 accumulators: %.3f ms  %.0f TFLOP/s | shader clock %.2f GHz (s_memtime / s_memrealtime)\n",
+           threads / 256, ms, flops / ms / 1e9, mean / real * 0.1);
+}
+
 template <int NACC>
 void run(int threads, const char* name) {
     const int blocks = 256, iters = 4000;
@@ -43,7 +87,7 @@ void run(int threads, const char* name) {
     double mean = 0, real = 0; unsigned long long rmin = ~0ull, rmax = 0;
     for (int i = 0; i < blocks; ++i) { mean += h[i]; real += h[256 + i]; rmin = h[512 + i] < rmin ? h[512 + i] : rmin; rmax = h[512 + i] > rmax ? h[512 + i] : rmax; }
     mean /= blocks; real /= blocks;
-    printf("   per-wave s_memrealtime span %.0f ticks (= %.3f ms at 100 MHz); block start times spread over %.3f ms\n", real, real / 1e5, (rmax - rmin) / 1e5);
+    printf("   per-wave s_memrealtime span %.0f ticks (= %.3f ms at 100 MHz); block start times spread over %.3f ms; shader clock %.2f GHz\n", real, real / 1e5, (rmax - rmin) / 1e5, mean / real * 0.1);
     const double mfmas_per_wave = (double)iters * 3 * NACC;
     const double flops = mfmas_per_wave * 32768.0 * blocks * (threads / 64);
     printf("%s: %.3f ms  %.0f TFLOP/s  | s_memtime delta %.0f -> counter %.3f GHz, %.1f counts per MFMA per SIMD-wave-slot\n", name, ms,
@@ -54,5 +98,7 @@ int main() {
     run<8>(256, "1 wave/SIMD, 8 accumulators");
     run<8>(512, "2 waves/SIMD, 8 accumulators");
     run<1>(512, "2 waves/SIMD, 1 accumulator (dependent chain)");
+    run16(256);
+    run16(512);
     return 0;
 }
