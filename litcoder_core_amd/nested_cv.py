@@ -98,9 +98,9 @@ class RidgeCVEngine:
                     if self.normalpha and series.residual_bound(self.alphas[a], SERIES_TERMS) <= SERIES_TOL]
         self.cho = [a for a in range(self.A) if a not in self.ser]
         self.d_ser = torch.tensor(self.ser, dtype=torch.int32, device=self.dev) if self.ser else None
-        self.d_coef = (torch.tensor(np.stack([series.minimax_inverse_coefficients(self.alphas[a], SERIES_TERMS)
-                                              for a in self.ser]), dtype=torch.float64, device=self.dev)
-                       if self.ser else None)
+        self.coef_host = (np.stack([series.minimax_inverse_coefficients(self.alphas[a], SERIES_TERMS)
+                                    for a in self.ser]) if self.ser else None)
+        self.d_coef = torch.tensor(self.coef_host, dtype=torch.float64, device=self.dev) if self.ser else None
         self.d_cho = torch.tensor(self.cho, dtype=torch.int32, device=self.dev)
         self.K = None if self.norm_x else ops.gram(self.dX, self.Ttot, self.p)
         self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
@@ -448,18 +448,45 @@ class RidgeCVEngine:
         if tr_o is None:
             tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
             lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
-        a2_o = ops.penalties(lmax_o, 1, self.d_alphas.index_select(0, ops.upload(np.asarray(used, dtype=np.int64), self.dev)),
-                             self.normalpha)
         rhs = torch.zeros((rows, N_o), dtype=torch.float64, device=self.dev)
         ops.transpose_rows(X, tr_o, N_o, self.p, rhs)
         if n_t:
             te64 = ops.upload(np.asarray(te_rows, dtype=np.int64), self.dev)
             tr64 = ops.upload(np.asarray(tr_rows, dtype=np.int64), self.dev)
             rhs[self.p_pad:self.p_pad + n_t, :n_o] = K.index_select(0, te64).index_select(1, tr64)
-        aug = torch.empty((G, N_o + rows, N_o), dtype=torch.float64, device=self.dev)
-        ops.batch_assemble(K, tr_o, None, rhs, a2_o, 1, G, N_o, rows, aug)
+        # alphas on the polynomial series (large penalties: what real recordings usually select) need no
+        # factorisation:  [Xtr' ; K_te] (K + a^2 I)^-1 = sum_j c_j(alpha) R_j,  R_j = [Xtr' ; K_te] K^j / lambda^(j+1),
+        # with the chain R_j = R_(j-1) (K / lambda) on the f32 MFMA, shared by all such alphas (cf. _hat_matrices)
+        poly = [a for a in used if a in self.ser] if (N_o % COL_TILE == 0 and lmax_o is not None) else []
+        chol = [a for a in used if a not in poly]
         Malpha = torch.empty((G, rows, N_o), dtype=torch.float32, device=self.dev)
-        info = ops.batch_chol_solve(aug, G, N_o, rows, Malpha)
+        info = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        if chol:
+            Gc = len(chol)
+            a2_o = ops.penalties(lmax_o, 1, self.d_alphas.index_select(0, ops.upload(np.asarray(chol, dtype=np.int64),
+                                                                                   self.dev)), self.normalpha)
+            aug = torch.empty((Gc, N_o + rows, N_o), dtype=torch.float64, device=self.dev)
+            ops.batch_assemble(K, tr_o, None, rhs, a2_o, 1, Gc, N_o, rows, aug)
+            Mc = Malpha if Gc == G else torch.empty((Gc, rows, N_o), dtype=torch.float32, device=self.dev)
+            info = ops.batch_chol_solve(aug, Gc, N_o, rows, Mc)
+            if Gc != G:
+                for i, a in enumerate(chol):
+                    Malpha[used.index(a)] = Mc[i]
+        if poly:
+            Kn = torch.empty((1, N_o, N_o), dtype=torch.float32, device=self.dev)
+            ops.gather_sub_f32(K, tr_o, tr_o, 1, N_o, N_o, lmax_o, Kn)
+            R = (rhs / lmax_o).to(torch.float32)
+            terms = [R]
+            for _ in range(1, SERIES_TERMS):
+                Rn = torch.empty_like(R)
+                ops.gemm_grouped(terms[-1], N_o, 0, Kn[0], N_o, None, Rn, N_o, rows, N_o, N_o, [0, N_o // COL_TILE])
+                terms.append(Rn)
+            for a in poly:
+                c = self.coef_host[self.ser.index(a)]
+                M = Malpha[used.index(a)]
+                torch.mul(terms[0], float(c[0]), out=M)
+                for j in range(1, SERIES_TERMS):
+                    M.add_(terms[j], alpha=float(c[j]))
         return Malpha, info
 
     def _refit_apply(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split):

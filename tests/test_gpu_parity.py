@@ -315,6 +315,25 @@ def test_shared_target_image_is_bitwise_neutral(lc):
     assert eng2._shared_image(ragged, 384) is None                       # gap not a multiple of 16 rows in
 
 
+def test_refit_with_large_alphas_polynomial_route(lc):
+    """Weights for voxels whose alpha lies on the polynomial series (no factorisation: shared powers of K on the
+    f32 MFMA) next to voxels that need the Cholesky route, against the oracle's SVD-route ridge."""
+    import oracle.ridge as oridge
+    from litcoder_core_amd import ridge
+    rng = np.random.default_rng(21)
+    T, p, V = 256, 90, 200                                       # N_o = 256: a multiple of the f32 tile width
+    X = rng.standard_normal((T, p))
+    Y = X @ (rng.standard_normal((p, V)) * 0.1) + rng.standard_normal((T, V))
+    valphas = rng.choice([0.5, 2.0, 10.0, 300.0, 1.0e5], size=V)
+    W = ridge.ridge(X, Y, valphas, 1e-10, True)
+    Wo = oridge.ridge_weights(torch.tensor(X, dtype=torch.float32), torch.tensor(Y, dtype=torch.float32),
+                              torch.tensor(valphas, dtype=torch.float32), normalpha=True, singcutoff=1e-10).numpy()
+    for a in (0.5, 10.0, 1.0e5):
+        sel = valphas == a
+        scale = np.abs(Wo[:, sel]).max()
+        np.testing.assert_allclose(W[:, sel], Wo[:, sel], rtol=2e-4, atol=3e-6 * scale, err_msg=f"alpha {a}")
+
+
 def test_fit_nested_cv_alias(lc):
     rng = np.random.default_rng(6)
     X = rng.standard_normal((150, 24))
