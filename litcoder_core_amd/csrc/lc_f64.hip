@@ -616,7 +616,7 @@ __global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ au
     for (int j = threadIdx.x; j < N; j += 256) dst[j] = (float)src[j];
 }
 
-// ------------------------------------------------------------------ Neumann-series hat matrices
+// ------------------------------------------------------------------ polynomial-series hat matrices
 // For a^2 >> lambda_max(K):  G (K + a^2 I)^-1 = sum_j (-1)^j G K^j / a^(2j+2), truncated after J+1 terms
 // (relative error (lambda_max/a^2)^(J+1)).  The powers P_j = G K^j are shared by every such alpha of a
 // fold, so a handful of fp64 GEMMs replaces one Cholesky factorisation + two triangular solves per alpha.

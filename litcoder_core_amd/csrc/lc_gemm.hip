@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256) k_score_finalize(const float* __restrict_
 }
 
 // ---- correlation scores of the series alphas from the moments of the shared terms ------------------------------
-// For the alphas on the Neumann series the prediction is a fixed linear combination of `terms` matrices
+// For the alphas on the polynomial series the prediction is a fixed linear combination of `terms` matrices
 //     pred_s = sum_j c_sj T_j,   T_j = P'_j Y (M x V, one GEMM for all those alphas),   c_sj given per alpha
 // (minimax polynomial of 1 / (x + alpha^2), series.py), so every statistic the score needs is a linear or quadratic form in the moments of the
 // T_j over the validation rows:  mean_s = c.m,  M2_s = c' S c,  cov_s = c.C  (S the terms' scatter matrix, C their

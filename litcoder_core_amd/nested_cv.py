@@ -22,7 +22,7 @@ How the work is laid out (DESIGN.md has the derivation):
 Every device operation is a call into liblitcoder_hip.so (``ops.py``); there is no CPU fallback.
 """
 import logging
-from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+from typing import Any, Dict, List, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -252,7 +252,7 @@ class RidgeCVEngine:
     def _hat_matrices(self, K, inner_abs, lmax=None, moments=False):
         """V-independent part of the inner CV of one outer fold: row lists, S[0]^2 (Lanczos), penalties and the
         hat matrices H_alpha of every (inner fold, alpha) -- batched Cholesky for the small alphas, the shared
-        Neumann series for the large ones (as hat matrices, or with ``moments`` as the scaled matrix powers
+        polynomial series for the large ones (as hat matrices, or with ``moments`` as the scaled matrix powers
         themselves).  Returns a dict the sweeps consume."""
         F, A = len(inner_abs), self.A
         n_i = [len(t) for t, _ in inner_abs]
