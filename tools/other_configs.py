@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""One fit at the shapes of BASELINE.json configs 4 and 5 on a single GPU (synthetic data, device-resident inputs):
+cfg4 = T 2226, p 3072, V 200 000 (the whole volume on one GPU instead of 8 shards), 20 alphas;
+cfg5 = T 3000, p 1280 x 6 delays = 7680, V 80 000, 32 alphas, two feature bands with different penalty scales.
+Prints time, voxels/s and the median score; checks that every result is finite.   python tools/other_configs.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from litcoder_core_amd import NestedCVModel, ops  # noqa: E402
+
+dev = ops.device(0)
+KW = dict(folding_type="kfold", n_outer_folds=5, n_inner_folds=5, single_alpha=False, normalpha=True, use_corr=True)
+
+
+def synth(T, F0, delays, V, band_scale=None, seed=0):
+    rng = np.random.default_rng(seed)
+    Xd = ops.fir_delay(torch.from_numpy(rng.standard_normal((T, F0))).to(dev), delays, False)
+    p = Xd.shape[1]
+    dX = torch.zeros((T, ops.pad_to(p, 32)), dtype=torch.float32, device=dev)
+    dX[:, :p] = Xd.to(torch.float32)
+    if band_scale is not None:                     # banded ridge with fixed scales == ridge on the rescaled design
+        dX[:, :p] /= torch.as_tensor(band_scale, dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    dY = torch.zeros((T, ops.pad_to(V, 128)), dtype=torch.float32, device=dev)
+    W = 0.02 * torch.randn((p, V), generator=g, device=dev, dtype=torch.float32)
+    dY[:, :V] = dX[:, :p] @ W + torch.randn((T, V), generator=g, device=dev, dtype=torch.float32)
+    return dX, dY, p
+
+
+for name, args, alphas in (
+        ("cfg4-like: T 2226, p 3072, V 200000, 20 alphas", dict(T=2226, F0=768, delays=[1, 2, 3, 4], V=200000),
+         np.logspace(-1, 8, 20)),
+        ("cfg5-like: T 3000, p 7680 (1280 x 6), V 80000, 32 alphas, 2 bands",
+         dict(T=3000, F0=1280, delays=[1, 2, 3, 4, 5, 6], V=80000,
+              band_scale=np.r_[np.full(3840, 1.0), np.full(3840, 2.0)]), np.logspace(-1, 8, 32))):
+    V = args["V"]
+    dX, dY, p = synth(**args)
+    model = NestedCVModel("ridge_regression")
+    fit = lambda: model.fit_predict_device(dX, dY, p, V, alphas=alphas, **KW)
+    fit(); torch.cuda.synchronize()
+    t = time.perf_counter(); m, W, a = fit(); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    ok = bool(np.isfinite(np.asarray(m["correlations"])).all() and torch.isfinite(W).all() and np.isfinite(a).all())
+    print(f"{name}: {1e3 * dt:.0f} ms = {V / dt:.0f} voxels/s, median score {m['median_score']:.4f}, all finite: {ok}", flush=True)
+    del dX, dY, W
+    torch.cuda.empty_cache()
