@@ -281,6 +281,20 @@ int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val,
                      const int32_t* d_aidx, int S, const int32_t* d_rowmap, float* d_scores, int accumulate,
                      lc_stream_t stream);
 
+/* ---------------------------------------------------------------- statistics tail */
+
+/* Fisher's combination of k p-values per voxel, nested_cv.py:441-477 (`_combine_pvalues_across_folds`):
+ * chi2.sf(-2 sum ln p, 2k) in closed form for the even degrees of freedom; all-ones rows give exactly 1.
+ * d_p: (k, V) f64 row-major, NaN-free; d_out: (V) f64. */
+int lc_fisher_combine(const double* d_p, int k, int64_t V, double* d_out, lc_stream_t stream);
+
+/* Benjamini-Hochberg step-up (statsmodels `fdrcorrection(pvals, alpha, method="indep")`, call sites
+ * nested_cv.py:158,263,282): d_reject (n) u8 and d_padj (n) f64 in input order.  d_work: at least
+ * lc_bh_fdr_work_bytes(n) bytes (sorted copies + hipCUB radix-sort temporary), caller-owned. */
+int64_t lc_bh_fdr_work_bytes(int64_t n);
+int lc_bh_fdr(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, double* d_padj,
+              void* d_work, int64_t work_bytes, lc_stream_t stream);
+
 /* Diagnostics only (tools/gpu_kernel_bench.py stamps): the fp16x3 sweep with s_memtime stamps at its phase
  * boundaries; d_stamps (32 x uint64, caller-zeroed) receives per wave-group sums of the five segments of an
  * iteration.  Not used by the product path. */

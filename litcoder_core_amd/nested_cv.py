@@ -55,10 +55,11 @@ class BasePredictivityModel:
 
 
 class _FoldResult:
-    __slots__ = ("r", "p", "best_idx", "n_test")
+    __slots__ = ("r", "p", "best_idx", "n_test", "sig")
 
-    def __init__(self, r, p, best_idx, n_test):
+    def __init__(self, r, p, best_idx, n_test, sig=None):
         self.r, self.p, self.best_idx, self.n_test = r, p, best_idx, n_test
+        self.sig = sig             # (reject mask, adjusted p) of the fold when the device made them (one GPU), else None
 
 
 class RidgeCVEngine:
@@ -105,6 +106,11 @@ class RidgeCVEngine:
         self.K = None if self.norm_x else ops.gram(self.dX, self.Ttot, self.p)
         self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
         self.aux = torch.cuda.Stream(device=self.dev)
+        # statistics tail on the device (lc_bh_fdr / lc_fisher_combine): BH-FDR is global over the voxels, so only
+        # when this process holds all of them; the driver sets alpha_fdr
+        self.device_stats = self.shard.world == 1
+        self.alpha_fdr = 0.05
+        self.p_folds = []                              # per outer fold: NaN-free p-values, natural voxel order, device
         self.ready = torch.cuda.Event()               # X, Y, K resident: the only thing the aux stream waits for
         self.ready.record()
 
@@ -624,13 +630,27 @@ class RidgeCVEngine:
         h_r.copy_(r_s, non_blocking=True)
         h_perm.copy_(perm[:Vs], non_blocking=True)
         h_best.copy_(best[: self.V], non_blocking=True)
+        h_rej = h_padj = None
+        if self.device_stats:
+            # p-values back in natural voxel order (NaN r -> p = 1, nested_cv.py:436), BH-FDR of the fold on the device
+            idx = perm[:Vs].to(torch.int64)
+            p_nat = torch.ones(self.V + 1, dtype=torch.float64, device=self.dev)      # slot V swallows the padding
+            p_nat.scatter_(0, torch.where(idx < 0, torch.full_like(idx, self.V), idx),
+                           torch.where(torch.isnan(r_s), torch.ones_like(p_s), p_s))
+            p_nat = p_nat[: self.V]
+            self.p_folds.append(p_nat)
+            rej_d, padj_d = ops.bh_fdr(p_nat, self.alpha_fdr)
+            h_rej = torch.empty(self.V, dtype=torch.uint8, pin_memory=True)
+            h_padj = torch.empty(self.V, dtype=torch.float64, pin_memory=True)
+            h_rej.copy_(rej_d, non_blocking=True)
+            h_padj.copy_(padj_d, non_blocking=True)
         # Cholesky pivot flags of the inner folds and of the refit: checked when the fold is collected
         bad = torch.stack([st["info"].ne(0).any(), info_o.ne(0).any()]).to(torch.int32)
         h_bad = torch.empty(2, dtype=torch.int32, pin_memory=True)
         h_bad.copy_(bad, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return dict(done=done, r=h_r, p=h_p, perm=h_perm, best=h_best, n_t=n_t, bad=h_bad,
+        return dict(done=done, r=h_r, p=h_p, perm=h_perm, best=h_best, n_t=n_t, bad=h_bad, rej=h_rej, padj=h_padj,
                     keep=(r_s, p_s, perm, best, bad))
 
     def fold_refit(self, st, single_alpha, weight_scale):
@@ -648,7 +668,17 @@ class RidgeCVEngine:
         p = np.empty(self.V, dtype=np.float64)
         r[perm_h[live]] = pend["r"].numpy()[live]
         p[perm_h[live]] = pend["p"].numpy()[live]
-        return _FoldResult(r, p, pend["best"].numpy().copy(), pend["n_t"])
+        sig = None
+        if pend.get("rej") is not None:
+            sig = (pend["rej"].numpy().astype(bool), pend["padj"].numpy().copy())
+        return _FoldResult(r, p, pend["best"].numpy().copy(), pend["n_t"], sig)
+
+    def combined_significance(self):
+        """Fisher's combination of the folds' p-values and its BH-FDR on the device (one GPU): (p_comb, reject,
+        adjusted p) as host arrays."""
+        pcomb = ops.fisher_combine(torch.stack(self.p_folds))
+        rej, padj = ops.bh_fdr(pcomb, self.alpha_fdr)
+        return pcomb.cpu().numpy(), rej.cpu().numpy().astype(bool), padj.cpu().numpy()
 
     def run_fold(self, tr_rows, te_rows, inner_rel, single_alpha, weight_scale) -> _FoldResult:
         st = self.fold_begin(tr_rows, te_rows, inner_rel)
@@ -799,12 +829,13 @@ class NestedCVModel(BasePredictivityModel):
                 fold_p.append(pvals)
             fold_alpha.append(_alpha_vector(alphas, idx, single_alpha))
             p_arr = np.where(np.isnan(r32), 1.0, rp[1])
-            fold_sig.append(stats.fdrcorrection(p_arr, alpha=alpha_fdr))
+            fold_sig.append(f.sig if getattr(f, "sig", None) is not None else stats.fdrcorrection(p_arr, alpha=alpha_fdr))
             score_rows.append(np.nan_to_num(r32, nan=0.0))
             p_rows.append(p_arr)
             any_nan.append(bool(np.isnan(r32).any()))
 
         pending = None
+        eng.alpha_fdr = alpha_fdr
         eng.begin_fit()                                     # the one host sync of the set-up, before anything is queued
         lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
         n = len(outer)
@@ -831,8 +862,11 @@ class NestedCVModel(BasePredictivityModel):
         # np.mean(fold_scores, axis=0) of the reference (nested_cv.py:276): the nested lists hold np.float32
         # scalars, plus Python 0.0 where r was NaN -- numpy then builds a float64 array, else a float32 one
         scores = np.mean(np.stack(score_rows).astype(np.float64 if any(any_nan) else np.float32), axis=0)
-        pcomb = stats.fisher_combine(np.stack(p_rows))
-        sig, padj = stats.fdrcorrection(pcomb, alpha=alpha_fdr)
+        if getattr(eng, "device_stats", False) and len(getattr(eng, "p_folds", ())) == len(outer):
+            pcomb, sig, padj = eng.combined_significance()
+        else:
+            pcomb = stats.fisher_combine(np.stack(p_rows))
+            sig, padj = stats.fdrcorrection(pcomb, alpha=alpha_fdr)
         majority = np.sum([s for s, _ in fold_sig], axis=0) >= (n_outer_folds // 2 + 1)
         mean_alphas = np.mean(fold_alpha, axis=0)
         metrics = stats.full_cv_metrics(scores, pcomb, padj, sig, majority, mean_alphas, np.sum(sig), np.sum(majority))

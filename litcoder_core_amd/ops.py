@@ -246,6 +246,27 @@ def batch_series_terms(k, tr, va, F, N, M, scale, terms, out, rowmap=None):
               _p(rowmap), out.shape[1], _s())
 
 
+def fisher_combine(p):
+    """(k, V) f64 device p-values (NaN-free) -> (V,) f64 combined p-values."""
+    k, V = p.shape
+    out = torch.empty(V, dtype=torch.float64, device=p.device)
+    _lib.call("lc_fisher_combine", _p(p), k, V, _p(out), _s())
+    return out
+
+
+def bh_fdr(p, alpha):
+    """Benjamini-Hochberg on a (n,) f64 device vector -> (reject (n,) uint8, adjusted p (n,) f64), input order."""
+    n = p.numel()
+    nbytes = int(_lib.load().lc_bh_fdr_work_bytes(n))
+    if nbytes < 0:
+        raise ValueError("bh_fdr: bad length")
+    work = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
+    reject = torch.empty(n, dtype=torch.uint8, device=p.device)
+    padj = torch.empty(n, dtype=torch.float64, device=p.device)
+    _lib.call("lc_bh_fdr", _p(p), n, float(alpha), _p(reject), _p(padj), _p(work), nbytes, _s())
+    return reject, padj
+
+
 def gather_sub_f32(k, rows, cols, F, R, C, scale, out):
     _lib.call("lc_gather_sub_f32", _p(k), k.stride(0), _p(rows), _p(cols), F, R, C, _p(scale), _p(out), _s())
 

@@ -334,6 +334,31 @@ def test_refit_with_large_alphas_polynomial_route(lc):
         np.testing.assert_allclose(W[:, sel], Wo[:, sel], rtol=2e-4, atol=3e-6 * scale, err_msg=f"alpha {a}")
 
 
+def test_device_statistics_tail_matches_host(lc):
+    """lc_fisher_combine / lc_bh_fdr against their host twins (stats.py, themselves pinned by known-answer vectors):
+    BH-FDR is the same IEEE arithmetic on the same sorted values -> identical; Fisher differs by libm rounding."""
+    from litcoder_core_amd import ops, stats
+    dev = ops.device(0)
+    rng = np.random.default_rng(31)
+    for n in (1, 7, 1000, 80000, 200001):
+        p = rng.uniform(0, 1, n) ** rng.choice([1.0, 4.0, 12.0], size=n)        # many small ones
+        p[rng.integers(0, n, size=max(1, n // 50))] = 1.0
+        p[rng.integers(0, n, size=max(1, n // 97))] = p[0]                         # ties
+        for alpha in (0.05, 0.3):
+            rej_h, adj_h = stats.fdrcorrection(p, alpha=alpha)
+            rej_d, adj_d = ops.bh_fdr(torch.from_numpy(p).to(dev), alpha)
+            np.testing.assert_array_equal(rej_d.cpu().numpy().astype(bool), rej_h, err_msg=f"n={n} alpha={alpha}")
+            np.testing.assert_array_equal(adj_d.cpu().numpy(), adj_h, err_msg=f"n={n} alpha={alpha}")
+    P = rng.uniform(1e-300, 1, (5, 4000))
+    P[:, 10] = 1.0                                                                 # all-ones shortcut
+    P[2, 11] = 0.0                                                                 # ln 0 = -inf -> 0
+    P[:, 12] = 1e-200                                                              # underflow of exp(-L)
+    got = ops.fisher_combine(torch.from_numpy(P).to(dev)).cpu().numpy()
+    want = stats.fisher_combine(P)
+    assert got[10] == 1.0 and got[11] == 0.0 and want[11] == 0.0
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+
+
 def test_fit_nested_cv_alias(lc):
     rng = np.random.default_rng(6)
     X = rng.standard_normal((150, 24))

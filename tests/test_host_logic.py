@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     """The shared library loads without a GPU and exports every function include/litcoder_hip.h declares;
     the ctypes table names exactly the same set."""
     hdr = open(os.path.join(ROOT, "include", "litcoder_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(lc_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(lc_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 25
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
