@@ -48,6 +48,11 @@ typedef void* lc_stream_t;
 
 int lc_version(void);
 const char* lc_last_error(void);
+/* A HIP stream restricted to the compute units whose bits are set in mask (words x 32 bits, bit i = CU i of the
+ * current device; hipExtStreamCreateWithCUMask).  Destroy with lc_stream_destroy. */
+int lc_stream_create_cu_mask(const uint32_t* mask, int words, lc_stream_t* out);
+int lc_stream_destroy(lc_stream_t stream);
+
 /* 0 when device `dev` is a gfx950; LC_E_ARCH otherwise. */
 int lc_check_device(int dev);
 
@@ -183,6 +188,12 @@ int lc_batch_assemble(const double* d_k, int64_t ldk, const int32_t* d_tr, const
  * d_slot: optional (B) int32, system b is written to slot d_slot[b] of d_h (NULL = b). */
 int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
                         const int32_t* d_slot, int32_t* d_info, lc_stream_t stream);
+
+/* Tuning hook of lc_batch_chol_solve: columns per outer block of its two-level blocking (a multiple of LC_NB;
+ * default 256).  columns <= 0 only queries.  Returns the value in force (>= LC_NB), or a negative error code. */
+int lc_chol_outer_block(int columns);
+/* Diagnostic: deep updates of lc_batch_chol_solve on the vector ALU (1, default) or the fp64 MFMA (0); < 0 queries. */
+int lc_debug_chol_big_kernel(int valu);
 
 /* The same hat matrices for alphas whose penalty dwarfs the spectrum, as a polynomial in K[tr,tr]:
  *   K[va,tr] (K[tr,tr] + a^2 I)^-1  ~=  sum_{j<terms} c_sj K[va,tr] K[tr,tr]^j / scale_f^(j+1)

@@ -23,6 +23,8 @@ SIGNATURES = {
     "lc_version": (c_int, []),
     "lc_last_error": (c_char_p, []),
     "lc_check_device": (c_int, [c_int]),
+    "lc_stream_create_cu_mask": (c_int, [_ptr, c_int, _ptr]),
+    "lc_stream_destroy": (c_int, [_ptr]),
     "lc_timing_enable": (c_int, [c_int]),
     "lc_timing_slots": (c_int, []),
     "lc_timing_name": (c_char_p, [c_int]),
@@ -46,6 +48,8 @@ SIGNATURES = {
     "lc_lambda_max_masked": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_penalties": (c_int, [_ptr, c_int, _ptr, c_int, c_int, _ptr, _ptr]),
     "lc_batch_assemble": (c_int, [_ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
+    "lc_chol_outer_block": (c_int, [c_int]),
+    "lc_debug_chol_big_kernel": (c_int, [c_int]),
     "lc_batch_chol_solve": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_batch_series_hat": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int, c_int, c_int,
                                     _ptr, _ptr, _ptr]),

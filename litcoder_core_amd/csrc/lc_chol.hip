@@ -1,0 +1,497 @@
+// Batched Cholesky solve of the augmented ridge systems, fp64 (gfx950).
+//
+// One system is an (N + M) x N row-major block: rows 0..N-1 hold A = K[tr,tr] + a^2 I (lower triangle used), rows
+// N..N+M-1 hold G = K[va,tr] (inner folds) or the stacked [X'; K[te,tr]] rows (refit).  The solve leaves
+// H = G A^-1 in the bottom rows:  A = L L',  Z = G L^-T (the augmented rows ride along with the panel and trailing
+// updates of the factorisation),  H = Z L^-1 (block back substitution).
+//
+// Two-level right-looking blocking.  Columns are factored in NB = 64 wide steps (diagonal tile in LDS by one
+// workgroup per system, its inverse Linv kept, panel = P Linv'), but the rank-64 updates of a step only touch the
+// remaining columns of the current OUTER block (LC_CHOL_OB = 256 columns); everything to the right is updated once
+// per outer block with a depth-256 product.  At NB = 64 depth the trailing update re-reads and re-writes the whole
+// trailing matrix 30 times for N = 1920 -- 10 GB per batch of 20 systems, the largest single cost of the old
+// VALU-tiled version -- at depth 256 it is a quarter of that.  The back substitution is blocked the same way.
+//
+// Every GEMM-shaped piece is one kernel, k_mm64: v_mfma_f64_16x16x4_f64 on LDS-staged operands.  The matrix fp64
+// rate of gfx950 equals the vector fp64 rate, but a 4 x 4 register tile of v_fma_f64 needs 8 LDS reads per 16 FMAs
+// (256 B/clk/CU with four SIMDs busy: twice what the LDS delivers), the MFMA form 8 reads per 16 MFMAs of 64 cycles.
+#include "lc_common.h"
+
+namespace {
+
+constexpr int NB = LC_NB;   // 64
+
+// Diagonal block k: L_kk = chol(A_kk) in LDS (2-D thread map, two barriers per column), then
+// Linv = inv(L_kk): lane c solves L x = e_c by a fully unrolled forward substitution with x in
+// registers (L entries are wave-uniform LDS broadcasts).  One block per system.
+constexpr int PD_LD = NB + 1;
+
+// 1 / sqrt(d) for d > 0: hardware estimate + two Newton steps (full fp64 accuracy); sqrt(d) = d * rsqrt(d).
+// The software sqrt and divide of the pivots were the longest dependent chain of the diagonal kernel.
+__device__ inline double rsqrt_nr(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = fma(r, fma(-h * r, r, 0.5), r);
+    r = fma(r, fma(-h * r, r, 0.5), r);
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ aug, int N, int M, int k,
+                                                    double* __restrict__ linv, int* __restrict__ info) {
+    __shared__ double L[NB * PD_LD];
+    __shared__ double rdiag[NB];                       // 1 / L[i][i]
+    const int b = blockIdx.x;
+    const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
+    double* a = aug + (long long)b * (N + M) * N + (long long)k * NB * N + k * NB;
+    for (int e = t; e < NB * NB; e += 256) L[(e >> 6) * PD_LD + (e & 63)] = a[(long long)(e >> 6) * N + (e & 63)];
+    __syncthreads();
+    // Four columns per step (16 steps, two barriers each): every thread factors the 4 x 4 pivot block redundantly
+    // in registers, transforms the panel rows it needs on the fly (l = a G^-T, six FMAs) and applies the rank-4
+    // update; the scaled panel is written after the second barrier.  Latency, not flops, is what this kernel
+    // costs (one workgroup per system), and the barrier count is its latency.
+    for (int j = 0; j < NB; j += 4) {
+        __syncthreads();                              // columns j..j+3 are final up to their scaling
+        double g00 = L[j * PD_LD + j];
+        const double a10 = L[(j + 1) * PD_LD + j], a11 = L[(j + 1) * PD_LD + j + 1];
+        const double a20 = L[(j + 2) * PD_LD + j], a21 = L[(j + 2) * PD_LD + j + 1], a22 = L[(j + 2) * PD_LD + j + 2];
+        const double a30 = L[(j + 3) * PD_LD + j], a31 = L[(j + 3) * PD_LD + j + 1], a32 = L[(j + 3) * PD_LD + j + 2],
+                     a33 = L[(j + 3) * PD_LD + j + 3];
+        int bad = 0;
+        if (!(g00 > 0.0)) bad = 1;
+        const double r0 = rsqrt_nr(g00);
+        g00 *= r0;
+        const double g10 = a10 * r0, g20 = a20 * r0, g30 = a30 * r0;
+        double g11 = a11 - g10 * g10;
+        if (!bad && !(g11 > 0.0)) bad = 2;
+        const double r1 = rsqrt_nr(g11);
+        g11 *= r1;
+        const double g21 = (a21 - g20 * g10) * r1, g31 = (a31 - g30 * g10) * r1;
+        double g22 = a22 - g20 * g20 - g21 * g21;
+        if (!bad && !(g22 > 0.0)) bad = 3;
+        const double r2 = rsqrt_nr(g22);
+        g22 *= r2;
+        const double g32 = (a32 - g30 * g20 - g31 * g21) * r2;
+        double g33 = a33 - g30 * g30 - g31 * g31 - g32 * g32;
+        if (!bad && !(g33 > 0.0)) bad = 4;
+        const double r3 = rsqrt_nr(g33);
+        g33 *= r3;
+        if (t == 0 && bad && info[b] == 0) info[b] = k * NB + j + bad;
+        // l = a G^-T for a panel row a = (x0..x3)
+#define LC_ROW_TRANSFORM(x0, x1, x2, x3, l0, l1, l2, l3)                 \
+        const double l0 = (x0) * r0;                                      \
+        const double l1 = ((x1) - l0 * g10) * r1;                         \
+        const double l2 = ((x2) - l0 * g20 - l1 * g21) * r2;              \
+        const double l3 = ((x3) - l0 * g30 - l1 * g31 - l2 * g32) * r3;
+        for (int i = j + 4 + ti; i < NB; i += 16) {
+            const double* ai = L + i * PD_LD + j;
+            LC_ROW_TRANSFORM(ai[0], ai[1], ai[2], ai[3], li0, li1, li2, li3)
+            for (int c = j + 4 + tj; c <= i; c += 16) {
+                const double* ac = L + c * PD_LD + j;
+                LC_ROW_TRANSFORM(ac[0], ac[1], ac[2], ac[3], lc0, lc1, lc2, lc3)
+                L[i * PD_LD + c] -= li0 * lc0 + li1 * lc1 + li2 * lc2 + li3 * lc3;
+            }
+        }
+        __syncthreads();                              // all reads of the unscaled panel are done
+        for (int i = j + 4 + t; i < NB; i += 256) {
+            double* ai = L + i * PD_LD + j;
+            LC_ROW_TRANSFORM(ai[0], ai[1], ai[2], ai[3], l0, l1, l2, l3)
+            ai[0] = l0; ai[1] = l1; ai[2] = l2; ai[3] = l3;
+        }
+#undef LC_ROW_TRANSFORM
+        if (t == 255) {                               // the pivot block itself
+            L[j * PD_LD + j] = g00;
+            L[(j + 1) * PD_LD + j] = g10; L[(j + 1) * PD_LD + j + 1] = g11;
+            L[(j + 2) * PD_LD + j] = g20; L[(j + 2) * PD_LD + j + 1] = g21; L[(j + 2) * PD_LD + j + 2] = g22;
+            L[(j + 3) * PD_LD + j] = g30; L[(j + 3) * PD_LD + j + 1] = g31; L[(j + 3) * PD_LD + j + 2] = g32;
+            L[(j + 3) * PD_LD + j + 3] = g33;
+            rdiag[j] = r0; rdiag[j + 1] = r1; rdiag[j + 2] = r2; rdiag[j + 3] = r3;
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < NB * NB; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        a[(long long)i * N + j] = j <= i ? L[i * PD_LD + j] : 0.0;
+    }
+    // Linv = inv(L): column c by forward substitution, four lanes per column -- lane part r keeps the entries
+    // x_q with q = r (mod 4) and sums their share of every row's dot product, two shuffles combine the shares.
+    {
+        const int c = t >> 2, r = t & 3;
+        double x[NB / 4];
+        double* lo = linv + ((long long)b * (N / NB) + k) * NB * NB;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            double sp = 0.0;
+#pragma unroll
+            for (int m = 0; m < NB / 4; ++m)
+                if (4 * m < i) {                             // static bound; the lane's own q = 4m + r may still be >= i
+                    const int q = 4 * m + r;
+                    if (q < i) sp = fma(L[i * PD_LD + q], x[m], sp);
+                }
+            sp += __shfl_xor(sp, 1);
+            sp += __shfl_xor(sp, 2);
+            const double xi = ((i == c ? 1.0 : 0.0) - sp) * rdiag[i];
+            if (r == (i & 3)) {
+                x[i >> 2] = xi;
+                lo[i * NB + c] = xi;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fp64 MFMA tile product
+// C (rows x cols) = or -= A B for every system of a batch.  A is global [m][k] (row stride lda); B is [n][k]
+// (BT: "N x T" product, C[m][n] = sum_k A[m][k] B[n][k]) or [k][n].  A workgroup (4 waves, 2 x 2) owns a
+// TS x TS tile of C, TS = 32 WB, each wave WB x WB MFMA blocks of 16 x 16.  Operands go through LDS in depth-16
+// chunks stored [row][k] with a row stride of 18 doubles: the 32 lanes ds_read_b64 serves per cycle (16 rows x 2
+// k) then fall on 32 distinct 8-byte bank pairs.  The next chunk is fetched into registers while the current
+// one is multiplied.  C may alias A when cols <= TS and depth covers all of A's columns (panel, back_diag): a
+// workgroup has consumed all its A rows before it stores.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int MM_KC = 16;
+constexpr int MM_LD = MM_KC + 2;
+
+struct MMArgs {
+    double* c;
+    const double* a;
+    const double* b;
+    long long c_sys, a_sys, b_sys;   // strides between systems
+    long long lda, ldb, ldc;
+    int rows, cols, depth;           // depth % 16 == 0
+    int row0, col0;                  // matrix coordinates of C[0][0], for the triangle test
+    int tri;                         // skip tiles that lie entirely above the diagonal
+    int subtract;                    // C -= A B, else C = A B
+};
+
+template <int WB, bool BT>
+__global__ void __launch_bounds__(256, 2) k_mm64(const MMArgs g) {
+    constexpr int TS = 32 * WB;
+    __shared__ double sA[TS * MM_LD], sB[TS * MM_LD];
+    const int r0 = blockIdx.y * TS, c0 = blockIdx.x * TS;
+    if (g.tri && g.row0 + r0 + TS - 1 < g.col0 + c0) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1, li = lane & 15, lq = lane >> 4;
+    const double* A = g.a + (long long)blockIdx.z * g.a_sys + (long long)r0 * g.lda;
+    const double* B = g.b + (long long)blockIdx.z * g.b_sys + (BT ? (long long)c0 * g.ldb : (long long)c0);
+    const int a_rows = min(TS, g.rows - r0), b_n = min(TS, g.cols - c0);
+
+    f64x2 ra[WB], rb[WB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < WB; ++q) {
+            const int e = t + 256 * q;
+            const int row = e >> 3, kp = e & 7;
+            ra[q] = row < a_rows ? *reinterpret_cast<const f64x2*>(A + (long long)row * g.lda + k0 + 2 * kp)
+                                 : f64x2{0.0, 0.0};
+            if (BT) {
+                rb[q] = row < b_n ? *reinterpret_cast<const f64x2*>(B + (long long)row * g.ldb + k0 + 2 * kp)
+                                  : f64x2{0.0, 0.0};
+            } else {
+                const int kr = e / (TS / 2), cp = e % (TS / 2);
+                rb[q] = 2 * cp < b_n ? *reinterpret_cast<const f64x2*>(B + (long long)(k0 + kr) * g.ldb + 2 * cp)
+                                     : f64x2{0.0, 0.0};
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int q = 0; q < WB; ++q) {
+            const int e = t + 256 * q;
+            const int row = e >> 3, kp = e & 7;
+            *reinterpret_cast<f64x2*>(sA + row * MM_LD + 2 * kp) = ra[q];
+            if (BT) {
+                *reinterpret_cast<f64x2*>(sB + row * MM_LD + 2 * kp) = rb[q];
+            } else {
+                const int kr = e / (TS / 2), cp = e % (TS / 2);
+                sB[(2 * cp) * MM_LD + kr] = rb[q].x;
+                sB[(2 * cp + 1) * MM_LD + kr] = rb[q].y;
+            }
+        }
+    };
+
+    f64x4 acc[WB][WB];
+#pragma unroll
+    for (int i = 0; i < WB; ++i)
+#pragma unroll
+        for (int j = 0; j < WB; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    fetch(0);
+    stash();
+    __syncthreads();
+    const double* pa = sA + (wm * 16 * WB + li) * MM_LD + lq;
+    const double* pb = sB + (wn * 16 * WB + li) * MM_LD + lq;
+    for (int k0 = 0; k0 < g.depth; k0 += MM_KC) {
+        const bool more = k0 + MM_KC < g.depth;
+        if (more) fetch(k0 + MM_KC);
+#pragma unroll
+        for (int k4 = 0; k4 < MM_KC / 4; ++k4) {
+            double a[WB], b[WB];
+#pragma unroll
+            for (int i = 0; i < WB; ++i) a[i] = pa[i * 16 * MM_LD + 4 * k4];
+#pragma unroll
+            for (int j = 0; j < WB; ++j) b[j] = pb[j * 16 * MM_LD + 4 * k4];
+#pragma unroll
+            for (int i = 0; i < WB; ++i)
+#pragma unroll
+                for (int j = 0; j < WB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
+    }
+
+    double* C = g.c + (long long)blockIdx.z * g.c_sys + (long long)r0 * g.ldc + c0;
+#pragma unroll
+    for (int i = 0; i < WB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wm * 16 * WB + i * 16 + lq + 4 * r;
+            if (row < a_rows)
+#pragma unroll
+                for (int j = 0; j < WB; ++j) {
+                    const int col = wn * 16 * WB + j * 16 + li;
+                    if (col < b_n) {
+                        double* dst = C + (long long)row * g.ldc + col;
+                        *dst = g.subtract ? *dst - acc[i][j][r] : acc[i][j][r];
+                    }
+                }
+        }
+}
+
+template <int WB, bool BT>
+void launch_mm(const MMArgs& g, int B, hipStream_t s) {
+    constexpr int TS = 32 * WB;
+    if (g.rows <= 0 || g.cols <= 0) return;
+    hipLaunchKernelGGL((k_mm64<WB, BT>), dim3((unsigned)lc::ceil_div(g.cols, TS), (unsigned)lc::ceil_div(g.rows, TS), (unsigned)B),
+                       dim3(256), 0, s, g);
+}
+
+// The same product on the vector ALU for the deep (outer-block) updates: 128 x 128 tile, 8 x 8 accumulators per
+// thread, two workgroups per CU.  On gfx950 v_fma_f64 out-runs the fp64 MFMA once a SIMD holds two waves
+// (tools/mfma_f64_rate.hip: 57 vs 45 TFLOP/s at two waves per SIMD, 34 for the MFMA at one), and an 8 x 8 register
+// tile needs only 8 ds_read_b128 per 64 FMAs.  Operands sit k-major in LDS ([k][128 + 2]); a thread owns rows
+// 32 i + 2 ty + {0, 1} and columns 32 j + 2 tx + {0, 1}, so the 16 lanes one LDS cycle serves read 256 contiguous
+// bytes (B) or two broadcast addresses (A).
+constexpr int MV_TS = 128, MV_KC = 16, MV_LD = MV_TS + 2;
+
+template <bool BT>
+__global__ void __launch_bounds__(256, 2) k_mm64v(const MMArgs g) {
+    __shared__ double sA[MV_KC * MV_LD], sB[MV_KC * MV_LD];
+    const int r0 = blockIdx.y * MV_TS, c0 = blockIdx.x * MV_TS;
+    if (g.tri && g.row0 + r0 + MV_TS - 1 < g.col0 + c0) return;
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    const double* A = g.a + (long long)blockIdx.z * g.a_sys + (long long)r0 * g.lda;
+    const double* B = g.b + (long long)blockIdx.z * g.b_sys + (BT ? (long long)c0 * g.ldb : (long long)c0);
+    const int a_rows = min(MV_TS, g.rows - r0), b_n = min(MV_TS, g.cols - c0);
+
+    f64x2 ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = t + 256 * q;
+            const int row = e >> 3, kp = e & 7;
+            ra[q] = row < a_rows ? *reinterpret_cast<const f64x2*>(A + (long long)row * g.lda + k0 + 2 * kp)
+                                 : f64x2{0.0, 0.0};
+            if (BT) {
+                rb[q] = row < b_n ? *reinterpret_cast<const f64x2*>(B + (long long)row * g.ldb + k0 + 2 * kp)
+                                  : f64x2{0.0, 0.0};
+            } else {
+                const int kr = e >> 6, cp = e & 63;
+                rb[q] = 2 * cp < b_n ? *reinterpret_cast<const f64x2*>(B + (long long)(k0 + kr) * g.ldb + 2 * cp)
+                                     : f64x2{0.0, 0.0};
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = t + 256 * q;
+            const int row = e >> 3, kp = e & 7;
+            sA[(2 * kp) * MV_LD + row] = ra[q].x;
+            sA[(2 * kp + 1) * MV_LD + row] = ra[q].y;
+            if (BT) {
+                sB[(2 * kp) * MV_LD + row] = rb[q].x;
+                sB[(2 * kp + 1) * MV_LD + row] = rb[q].y;
+            } else {
+                const int kr = e >> 6, cp = e & 63;
+                *reinterpret_cast<f64x2*>(sB + kr * MV_LD + 2 * cp) = rb[q];
+            }
+        }
+    };
+
+    double acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
+
+    fetch(0);
+    stash();
+    __syncthreads();
+    const double* pa = sA + 2 * ty;
+    const double* pb = sB + 2 * tx;
+    for (int k0 = 0; k0 < g.depth; k0 += MV_KC) {
+        const bool more = k0 + MV_KC < g.depth;
+        if (more) fetch(k0 + MV_KC);
+#pragma unroll 4
+        for (int k = 0; k < MV_KC; ++k) {
+            f64x2 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f64x2*>(pa + k * MV_LD + 32 * i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f64x2*>(pb + k * MV_LD + 32 * j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * i][2 * j] = fma(a[i].x, b[j].x, acc[2 * i][2 * j]);
+                    acc[2 * i][2 * j + 1] = fma(a[i].x, b[j].y, acc[2 * i][2 * j + 1]);
+                    acc[2 * i + 1][2 * j] = fma(a[i].y, b[j].x, acc[2 * i + 1][2 * j]);
+                    acc[2 * i + 1][2 * j + 1] = fma(a[i].y, b[j].y, acc[2 * i + 1][2 * j + 1]);
+                }
+        }
+        if (more) {
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
+    }
+
+    double* C = g.c + (long long)blockIdx.z * g.c_sys + (long long)r0 * g.ldc + c0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 32 * (i >> 1) + 2 * ty + (i & 1);
+        if (row < a_rows)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 32 * j + 2 * tx;
+                if (col < b_n) {
+                    f64x2* dst = reinterpret_cast<f64x2*>(C + (long long)row * g.ldc + col);
+                    f64x2 v = {acc[i][2 * j], acc[i][2 * j + 1]};
+                    if (g.subtract) v = *dst - v;
+                    *dst = v;
+                }
+            }
+    }
+}
+
+static int g_big_valu = 1;       // deep updates on the vector ALU (k_mm64v) or on the MFMA (k_mm64<4>)
+
+template <bool BT>
+void launch_big(const MMArgs& g, int B, hipStream_t s) {
+    if (g.rows <= 0 || g.cols <= 0) return;
+    if (g_big_valu)
+        hipLaunchKernelGGL((k_mm64v<BT>), dim3((unsigned)lc::ceil_div(g.cols, MV_TS), (unsigned)lc::ceil_div(g.rows, MV_TS), (unsigned)B),
+                           dim3(256), 0, s, g);
+    else
+        launch_mm<4, BT>(g, B, s);
+}
+
+__global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ aug, int N, int M, float* __restrict__ h,
+                                                   const int* __restrict__ slot) {
+    const int i = blockIdx.x, b = blockIdx.y;
+    const double* src = aug + ((long long)b * (N + M) + N + i) * N;
+    float* dst = h + ((long long)(slot ? slot[b] : b) * M + i) * N;
+    for (int j = threadIdx.x; j < N; j += 256) dst[j] = (float)src[j];
+}
+
+}  // namespace
+
+static int g_chol_outer = 256;   // columns per outer block (multiple of NB)
+
+extern "C" int lc_chol_outer_block(int columns) {
+    if (columns > 0) {
+        LC_REQUIRE(columns % NB == 0, LC_E_SHAPE, "lc_chol_outer_block: need a multiple of %d", NB);
+        g_chol_outer = columns;
+    }
+    return g_chol_outer;
+}
+
+extern "C" int lc_debug_chol_big_kernel(int valu) {
+    if (valu >= 0) g_big_valu = valu ? 1 : 0;
+    return g_big_valu;
+}
+
+extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
+                                   const int32_t* d_slot, int32_t* d_info, lc_stream_t stream) {
+    LC_REQUIRE(d_aug && d_linv && d_h && d_info, LC_E_BADARG, "lc_batch_chol_solve: null pointer");
+    LC_REQUIRE(B > 0 && B <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
+               "lc_batch_chol_solve: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_CHOL_SOLVE, s);
+    LC_HIP(hipMemsetAsync(d_info, 0, sizeof(int32_t) * B, s));
+    const int nb = N / NB;
+    const int R = N + M;
+    const int ob = g_chol_outer / NB;                        // NB-steps per outer block
+    const long long sys = (long long)R * N;
+    MMArgs g{};
+    g.c_sys = g.a_sys = g.b_sys = sys;
+    g.lda = g.ldb = g.ldc = N;
+    for (int K0 = 0; K0 < nb; K0 += ob) {
+        const int K1 = min(K0 + ob, nb);
+        for (int k = K0; k < K1; ++k) {
+            hipLaunchKernelGGL(k_potrf_diag, dim3(B), dim3(256), 0, s, d_aug, N, M, k, d_linv, d_info);
+            const int below = (k + 1) * NB;                  // first row under the diagonal tile
+            // panel:  P <- P Linv_kk'   (rows below the diagonal tile, including the M augmented rows; in place)
+            g.a = g.c = d_aug + (long long)below * N + k * NB;
+            g.a_sys = g.c_sys = sys;
+            g.b = d_linv + (long long)k * NB * NB;
+            g.b_sys = (long long)nb * NB * NB;
+            g.ldb = NB;
+            g.rows = R - below; g.cols = NB; g.depth = NB;
+            g.row0 = below; g.col0 = k * NB; g.tri = 0; g.subtract = 0;
+            launch_mm<2, true>(g, B, s);
+            // rank-64 update of the rest of the outer block
+            g.b = g.a; g.b_sys = sys; g.ldb = N;
+            g.c = d_aug + (long long)below * N + below;
+            g.cols = K1 * NB - below;
+            g.col0 = below; g.tri = 1; g.subtract = 1;
+            launch_mm<2, true>(g, B, s);
+        }
+        // everything right of the outer block, once, at the block's full depth
+        const int c1 = K1 * NB;
+        g.a = g.b = d_aug + (long long)c1 * N + K0 * NB;
+        g.a_sys = g.b_sys = g.c_sys = sys;
+        g.ldb = N;
+        g.c = d_aug + (long long)c1 * N + c1;
+        g.rows = R - c1; g.cols = N - c1; g.depth = (K1 - K0) * NB;
+        g.row0 = g.col0 = c1; g.tri = 1; g.subtract = 1;
+        launch_big<true>(g, B, s);
+    }
+    if (int rc = lc::launched("cholesky sweep")) return rc;
+    // H L = Z from the last block column to the first:  H_k = Z_k Linv_kk,  Z_j -= H_k L_kj (j < k)
+    const int last_full = ((nb - 1) / ob) * ob;
+    for (int K0 = last_full; K0 >= 0; K0 -= ob) {
+        const int K1 = min(K0 + ob, nb);
+        for (int k = K1 - 1; k >= K0; --k) {
+            g.a = g.c = d_aug + (long long)N * N + k * NB;
+            g.a_sys = g.c_sys = sys;
+            g.b = d_linv + (long long)k * NB * NB;
+            g.b_sys = (long long)nb * NB * NB;
+            g.ldb = NB;
+            g.rows = M; g.cols = NB; g.depth = NB;
+            g.row0 = g.col0 = 0; g.tri = 0; g.subtract = 0;
+            launch_mm<2, false>(g, B, s);
+            g.b = d_aug + (long long)k * NB * N + K0 * NB;   // L[k rows][columns of the outer block left of k]
+            g.b_sys = sys; g.ldb = N;
+            g.c = d_aug + (long long)N * N + K0 * NB;
+            g.cols = (k - K0) * NB;
+            g.subtract = 1;
+            launch_mm<2, false>(g, B, s);
+        }
+        g.a = d_aug + (long long)N * N + K0 * NB;
+        g.b = d_aug + (long long)K0 * NB * N;
+        g.c = d_aug + (long long)N * N;
+        g.a_sys = g.b_sys = g.c_sys = sys;
+        g.ldb = N;
+        g.rows = M; g.cols = K0 * NB; g.depth = (K1 - K0) * NB;
+        g.tri = 0; g.subtract = 1;
+        launch_big<false>(g, B, s);
+    }
+    if (int rc = lc::launched("back substitution")) return rc;
+    hipLaunchKernelGGL(k_extract_h, dim3(M, B), dim3(256), 0, s, d_aug, N, M, d_h, d_slot);
+    return lc::launched("k_extract_h");
+}

@@ -94,3 +94,20 @@ extern "C" int lc_check_device(int dev) {
         return lc::fail(LC_E_ARCH, "device %d is %s; this library carries gfx950 code only", dev, prop.gcnArchName);
     return LC_OK;
 }
+
+// A stream whose kernels may only run on the CUs whose bits are set in `mask` (words x 32 bits, bit i = CU i).
+// The fit's main stream can be created this way to keep a few CUs free for the auxiliary stream's short fp64
+// kernels, which otherwise wait for a whole MFMA-sweep workgroup to retire before they find a free slot.
+extern "C" int lc_stream_create_cu_mask(const uint32_t* mask, int words, lc_stream_t* out) {
+    LC_REQUIRE(mask && out && words > 0, LC_E_BADARG, "lc_stream_create_cu_mask: bad argument");
+    hipStream_t s = nullptr;
+    LC_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+    *out = reinterpret_cast<lc_stream_t>(s);
+    return LC_OK;
+}
+
+extern "C" int lc_stream_destroy(lc_stream_t stream) {
+    LC_REQUIRE(stream, LC_E_BADARG, "lc_stream_destroy: null stream");
+    LC_HIP(hipStreamDestroy(lc::as_stream(stream)));
+    return LC_OK;
+}

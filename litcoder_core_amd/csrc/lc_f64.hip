@@ -1,12 +1,11 @@
 // The V-independent dense algebra of the fit, in fp64:
-//   Gram matrix K = X X', largest eigenvalue of fold sub-Grams (Lanczos + bisection), and the
-//   batched Cholesky / triangular solves that turn K into hat matrices
-//       H_a = Xva Xtr' (Xtr Xtr' + a^2 I)^-1
-//   for every (fold, alpha) at once.  This replaces the 30 thin SVDs of the reference
-//   (ridge_utils.py:52): with U S Vh = svd(Xtr),  Pstim Vh' diag(S/(S^2+a^2)) U' == H_a exactly.
+//   Gram matrix K = X X', largest eigenvalue of fold sub-Grams (Lanczos + bisection), the assembly of the
+//   augmented ridge systems and the polynomial-series operands.  The batched Cholesky solve that turns the
+//   systems into hat matrices  H_a = Xva Xtr' (Xtr Xtr' + a^2 I)^-1  lives in lc_chol.hip.  Together they replace
+//   the 30 thin SVDs of the reference (ridge_utils.py:52): with U S Vh = svd(Xtr),
+//   Pstim Vh' diag(S/(S^2+a^2)) U' == H_a exactly.
 //
-// Everything that is GEMM-shaped goes through one 64x64x64 register-tiled fp64 product
-// (vector fp64 FMA rate == matrix fp64 rate on gfx950, so VALU tiles are the simple choice).
+// The GEMM-shaped pieces of THIS file go through one 64x64x64 register-tiled fp64 product.
 #include "lc_common.h"
 
 namespace {
@@ -401,221 +400,6 @@ __global__ void __launch_bounds__(256) k_transpose_rows(const float* __restrict_
     }
 }
 
-// ------------------------------------------------------------------ blocked Cholesky pieces
-// Diagonal block k: L_kk = chol(A_kk) in LDS (2-D thread map, two barriers per column), then
-// Linv = inv(L_kk): lane c solves L x = e_c by a fully unrolled forward substitution with x in
-// registers (L entries are wave-uniform LDS broadcasts).  One block per system.
-constexpr int PD_LD = NB + 1;
-
-// 1 / sqrt(d) for d > 0: hardware estimate + two Newton steps (full fp64 accuracy); sqrt(d) = d * rsqrt(d).
-// The software sqrt and divide of the pivots were the longest dependent chain of the diagonal kernel.
-__device__ inline double rsqrt_nr(double d) {
-    double r = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;
-    r = fma(r, fma(-h * r, r, 0.5), r);
-    r = fma(r, fma(-h * r, r, 0.5), r);
-    return r;
-}
-
-__global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ aug, int N, int M, int k,
-                                                    double* __restrict__ linv, int* __restrict__ info) {
-    __shared__ double L[NB * PD_LD];
-    __shared__ double rdiag[NB];                       // 1 / L[i][i]
-    const int b = blockIdx.x;
-    const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
-    double* a = aug + (long long)b * (N + M) * N + (long long)k * NB * N + k * NB;
-    for (int e = t; e < NB * NB; e += 256) L[(e >> 6) * PD_LD + (e & 63)] = a[(long long)(e >> 6) * N + (e & 63)];
-    __syncthreads();
-    // Four columns per step (16 steps, two barriers each): every thread factors the 4 x 4 pivot block redundantly
-    // in registers, transforms the panel rows it needs on the fly (l = a G^-T, six FMAs) and applies the rank-4
-    // update; the scaled panel is written after the second barrier.  Latency, not flops, is what this kernel
-    // costs (one workgroup per system), and the barrier count is its latency.
-    for (int j = 0; j < NB; j += 4) {
-        __syncthreads();                              // columns j..j+3 are final up to their scaling
-        double g00 = L[j * PD_LD + j];
-        const double a10 = L[(j + 1) * PD_LD + j], a11 = L[(j + 1) * PD_LD + j + 1];
-        const double a20 = L[(j + 2) * PD_LD + j], a21 = L[(j + 2) * PD_LD + j + 1], a22 = L[(j + 2) * PD_LD + j + 2];
-        const double a30 = L[(j + 3) * PD_LD + j], a31 = L[(j + 3) * PD_LD + j + 1], a32 = L[(j + 3) * PD_LD + j + 2],
-                     a33 = L[(j + 3) * PD_LD + j + 3];
-        int bad = 0;
-        if (!(g00 > 0.0)) bad = 1;
-        const double r0 = rsqrt_nr(g00);
-        g00 *= r0;
-        const double g10 = a10 * r0, g20 = a20 * r0, g30 = a30 * r0;
-        double g11 = a11 - g10 * g10;
-        if (!bad && !(g11 > 0.0)) bad = 2;
-        const double r1 = rsqrt_nr(g11);
-        g11 *= r1;
-        const double g21 = (a21 - g20 * g10) * r1, g31 = (a31 - g30 * g10) * r1;
-        double g22 = a22 - g20 * g20 - g21 * g21;
-        if (!bad && !(g22 > 0.0)) bad = 3;
-        const double r2 = rsqrt_nr(g22);
-        g22 *= r2;
-        const double g32 = (a32 - g30 * g20 - g31 * g21) * r2;
-        double g33 = a33 - g30 * g30 - g31 * g31 - g32 * g32;
-        if (!bad && !(g33 > 0.0)) bad = 4;
-        const double r3 = rsqrt_nr(g33);
-        g33 *= r3;
-        if (t == 0 && bad && info[b] == 0) info[b] = k * NB + j + bad;
-        // l = a G^-T for a panel row a = (x0..x3)
-#define LC_ROW_TRANSFORM(x0, x1, x2, x3, l0, l1, l2, l3)                 \
-        const double l0 = (x0) * r0;                                      \
-        const double l1 = ((x1) - l0 * g10) * r1;                         \
-        const double l2 = ((x2) - l0 * g20 - l1 * g21) * r2;              \
-        const double l3 = ((x3) - l0 * g30 - l1 * g31 - l2 * g32) * r3;
-        for (int i = j + 4 + ti; i < NB; i += 16) {
-            const double* ai = L + i * PD_LD + j;
-            LC_ROW_TRANSFORM(ai[0], ai[1], ai[2], ai[3], li0, li1, li2, li3)
-            for (int c = j + 4 + tj; c <= i; c += 16) {
-                const double* ac = L + c * PD_LD + j;
-                LC_ROW_TRANSFORM(ac[0], ac[1], ac[2], ac[3], lc0, lc1, lc2, lc3)
-                L[i * PD_LD + c] -= li0 * lc0 + li1 * lc1 + li2 * lc2 + li3 * lc3;
-            }
-        }
-        __syncthreads();                              // all reads of the unscaled panel are done
-        for (int i = j + 4 + t; i < NB; i += 256) {
-            double* ai = L + i * PD_LD + j;
-            LC_ROW_TRANSFORM(ai[0], ai[1], ai[2], ai[3], l0, l1, l2, l3)
-            ai[0] = l0; ai[1] = l1; ai[2] = l2; ai[3] = l3;
-        }
-#undef LC_ROW_TRANSFORM
-        if (t == 255) {                               // the pivot block itself
-            L[j * PD_LD + j] = g00;
-            L[(j + 1) * PD_LD + j] = g10; L[(j + 1) * PD_LD + j + 1] = g11;
-            L[(j + 2) * PD_LD + j] = g20; L[(j + 2) * PD_LD + j + 1] = g21; L[(j + 2) * PD_LD + j + 2] = g22;
-            L[(j + 3) * PD_LD + j] = g30; L[(j + 3) * PD_LD + j + 1] = g31; L[(j + 3) * PD_LD + j + 2] = g32;
-            L[(j + 3) * PD_LD + j + 3] = g33;
-            rdiag[j] = r0; rdiag[j + 1] = r1; rdiag[j + 2] = r2; rdiag[j + 3] = r3;
-        }
-    }
-    __syncthreads();
-    for (int e = t; e < NB * NB; e += 256) {
-        const int i = e >> 6, j = e & 63;
-        a[(long long)i * N + j] = j <= i ? L[i * PD_LD + j] : 0.0;
-    }
-    // Linv = inv(L): column c by forward substitution, four lanes per column -- lane part r keeps the entries
-    // x_q with q = r (mod 4) and sums their share of every row's dot product, two shuffles combine the shares.
-    {
-        const int c = t >> 2, r = t & 3;
-        double x[NB / 4];
-        double* lo = linv + ((long long)b * (N / NB) + k) * NB * NB;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            double sp = 0.0;
-#pragma unroll
-            for (int m = 0; m < NB / 4; ++m)
-                if (4 * m < i) {                             // static bound; the lane's own q = 4m + r may still be >= i
-                    const int q = 4 * m + r;
-                    if (q < i) sp = fma(L[i * PD_LD + q], x[m], sp);
-                }
-            sp += __shfl_xor(sp, 1);
-            sp += __shfl_xor(sp, 2);
-            const double xi = ((i == c ? 1.0 : 0.0) - sp) * rdiag[i];
-            if (r == (i & 3)) {
-                x[i >> 2] = xi;
-                lo[i * NB + c] = xi;
-            }
-        }
-    }
-}
-
-// Panel: rows below the diagonal block (including the M augmented rows):  P <- P * Linv_kk'.
-__global__ void __launch_bounds__(256) k_panel(double* __restrict__ aug, int N, int M, int k,
-                                               const double* __restrict__ linv) {
-    __shared__ double sA[32 * TS_LD], sB[32 * TS_LD];
-    const int b = blockIdx.y;
-    const int R = N + M;
-    const int r0 = (k + 1) * NB + blockIdx.x * NB;
-    double* base = aug + (long long)b * R * N;
-    double* P = base + (long long)r0 * N + k * NB;
-    const double* Li = linv + ((long long)b * (N / NB) + k) * NB * NB;
-    const int rows = min(NB, R - r0);
-    double acc[4][4] = {};
-    tile_product<true>(acc, P, N, rows, Li, NB, NB, sA, sB);     // C[r][c] = sum_j P[r][j] Linv[c][j]
-    __syncthreads();
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (ty * 4 + i < rows)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) P[(long long)(ty * 4 + i) * N + tx * 4 + j] = acc[i][j];
-}
-
-// Trailing update: A_ij -= L_ik L_jk'  for column tiles j > k and row tiles i >= j (rows to N+M).
-__global__ void __launch_bounds__(256) k_trailing(double* __restrict__ aug, int N, int M, int k) {
-    __shared__ double sA[32 * TS_LD], sB[32 * TS_LD];
-    const int b = blockIdx.z;
-    const int tj = k + 1 + blockIdx.x, ti = k + 1 + blockIdx.y;
-    if (ti < tj) return;
-    const int R = N + M;
-    const int r0 = ti * NB;
-    if (r0 >= R) return;
-    double* base = aug + (long long)b * R * N;
-    const double* Pi = base + (long long)r0 * N + k * NB;
-    const double* Pj = base + (long long)tj * NB * N + k * NB;
-    const int rows = min(NB, R - r0);
-    double acc[4][4] = {};
-    tile_product<true>(acc, Pi, N, rows, Pj, N, NB, sA, sB);
-    double* Cij = base + (long long)r0 * N + tj * NB;
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (ty * 4 + i < rows)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Cij[(long long)(ty * 4 + i) * N + tx * 4 + j] -= acc[i][j];
-}
-
-// Backward substitution on the augmented rows Z (M x N):  solve H L = Z block column by block column,
-// from the last to the first.  Step k:  H_k = Z_k Linv_kk ;  Z_j -= H_k L_kj  for j < k.
-__global__ void __launch_bounds__(256) k_back_diag(double* __restrict__ aug, int N, int M, int k,
-                                                   const double* __restrict__ linv) {
-    __shared__ double sA[32 * TS_LD], sB[32 * TS_LD];
-    const int b = blockIdx.y;
-    const int r0 = N + blockIdx.x * NB;
-    const int R = N + M;
-    double* Z = aug + (long long)b * R * N + (long long)r0 * N + k * NB;
-    const double* Li = linv + ((long long)b * (N / NB) + k) * NB * NB;
-    const int rows = min(NB, R - r0);
-    double acc[4][4] = {};
-    tile_product<false>(acc, Z, N, rows, Li, NB, NB, sA, sB);    // C[r][c] = sum_j Z[r][j] Linv[j][c]
-    __syncthreads();
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (ty * 4 + i < rows)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Z[(long long)(ty * 4 + i) * N + tx * 4 + j] = acc[i][j];
-}
-
-__global__ void __launch_bounds__(256) k_back_update(double* __restrict__ aug, int N, int M, int k) {
-    __shared__ double sA[32 * TS_LD], sB[32 * TS_LD];
-    const int b = blockIdx.z;
-    const int tj = blockIdx.x;                      // column tile j < k
-    const int r0 = N + blockIdx.y * NB;
-    const int R = N + M;
-    double* base = aug + (long long)b * R * N;
-    const double* Hk = base + (long long)r0 * N + k * NB;
-    const double* Lkj = base + (long long)k * NB * N + tj * NB;     // [t][c] = L[k*NB+t][tj*NB+c]
-    const int rows = min(NB, R - r0);
-    double acc[4][4] = {};
-    tile_product<false>(acc, Hk, N, rows, Lkj, N, NB, sA, sB);
-    double* Zj = base + (long long)r0 * N + tj * NB;
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (ty * 4 + i < rows)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Zj[(long long)(ty * 4 + i) * N + tx * 4 + j] -= acc[i][j];
-}
-
-__global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ aug, int N, int M, float* __restrict__ h,
-                                                   const int* __restrict__ slot) {
-    const int i = blockIdx.x, b = blockIdx.y;
-    const double* src = aug + ((long long)b * (N + M) + N + i) * N;
-    float* dst = h + ((long long)(slot ? slot[b] : b) * M + i) * N;
-    for (int j = threadIdx.x; j < N; j += 256) dst[j] = (float)src[j];
-}
-
 // ------------------------------------------------------------------ polynomial-series hat matrices
 // For a^2 >> lambda_max(K):  G (K + a^2 I)^-1 = sum_j (-1)^j G K^j / a^(2j+2), truncated after J+1 terms
 // (relative error (lambda_max/a^2)^(J+1)).  The powers P_j = G K^j are shared by every such alpha of a
@@ -782,35 +566,6 @@ extern "C" int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_
     hipLaunchKernelGGL(k_transpose_rows, grid, dim3(256), 0, lc::as_stream(stream), d_x, (long long)ldx, d_tr, N,
                        (long long)p, d_out);
     return lc::launched("k_transpose_rows");
-}
-
-extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
-                                   const int32_t* d_slot, int32_t* d_info, lc_stream_t stream) {
-    LC_REQUIRE(d_aug && d_linv && d_h && d_info, LC_E_BADARG, "lc_batch_chol_solve: null pointer");
-    LC_REQUIRE(B > 0 && B <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
-               "lc_batch_chol_solve: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
-    hipStream_t s = lc::as_stream(stream);
-    lc::ScopedTimer timer_(lc::T_CHOL_SOLVE, s);
-    LC_HIP(hipMemsetAsync(d_info, 0, sizeof(int32_t) * B, s));
-    const int nb = N / NB;
-    const int R = N + M;
-    const int mt = lc::ceil_div(M, NB);                      // row tiles of the augmented part
-    for (int k = 0; k < nb; ++k) {
-        hipLaunchKernelGGL(k_potrf_diag, dim3(B), dim3(256), 0, s, d_aug, N, M, k, d_linv, d_info);
-        const int below = lc::ceil_div(R - (k + 1) * NB, NB);   // row tiles under the diagonal block
-        if (below > 0) hipLaunchKernelGGL(k_panel, dim3(below, B), dim3(256), 0, s, d_aug, N, M, k, d_linv);
-        const int ct = nb - 1 - k;                              // trailing column tiles
-        if (ct > 0)
-            hipLaunchKernelGGL(k_trailing, dim3(ct, below, B), dim3(256), 0, s, d_aug, N, M, k);
-    }
-    if (int rc = lc::launched("cholesky sweep")) return rc;
-    for (int k = nb - 1; k >= 0; --k) {
-        hipLaunchKernelGGL(k_back_diag, dim3(mt, B), dim3(256), 0, s, d_aug, N, M, k, d_linv);
-        if (k > 0) hipLaunchKernelGGL(k_back_update, dim3(k, mt, B), dim3(256), 0, s, d_aug, N, M, k);
-    }
-    if (int rc = lc::launched("back substitution")) return rc;
-    hipLaunchKernelGGL(k_extract_h, dim3(M, B), dim3(256), 0, s, d_aug, N, M, d_h, d_slot);
-    return lc::launched("k_extract_h");
 }
 
 extern "C" int lc_gather_sub_f32(const double* d_k, int64_t ldk, const int32_t* d_rows, const int32_t* d_cols, int F,

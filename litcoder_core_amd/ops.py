@@ -224,6 +224,23 @@ def batch_assemble(k, tr, va, rhs, a2, F, A, N, M, aug):
     _lib.call("lc_batch_assemble", _p(k), k.stride(0), _p(tr), _p(va), _p(rhs), _p(a2), F, A, N, M, _p(aug), _s())
 
 
+def masked_stream(mask_words):
+    """torch ExternalStream over a HIP stream limited to the CUs set in mask_words (sequence of uint32)."""
+    import ctypes as ct
+    words = (ct.c_uint32 * len(mask_words))(*[int(w) & 0xFFFFFFFF for w in mask_words])
+    out = ct.c_void_p()
+    _lib.call("lc_stream_create_cu_mask", ct.cast(words, ct.c_void_p), len(mask_words), ct.cast(ct.byref(out), ct.c_void_p))
+    return torch.cuda.ExternalStream(out.value, device=device())
+
+
+def chol_outer_block(columns=0):
+    """Columns per outer block of batch_chol_solve's two-level blocking (0 = query)."""
+    rc = _lib.load().lc_chol_outer_block(int(columns))
+    if rc < 0:
+        _lib.check(rc, "lc_chol_outer_block")
+    return rc
+
+
 def batch_chol_solve(aug, B, N, M, h, slot=None):
     linv = torch.empty((B, N // LC_NB, LC_NB, LC_NB), dtype=torch.float64, device=aug.device)
     info = torch.empty(B, dtype=torch.int32, device=aug.device)

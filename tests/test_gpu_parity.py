@@ -268,6 +268,40 @@ def test_randomised_shapes_against_oracle(lc):
                 assert m["n_significant"] == m_o["n_significant"], tag
 
 
+def test_batch_chol_solve_against_fp64_solves(lc):
+    """The batched augmented Cholesky solve (fp64 MFMA tiles, two-level blocking) against numpy's fp64 solve, on
+    shapes that exercise ragged outer blocks, 128-tile edges and augmented rows that are no multiple of 64."""
+    from litcoder_core_amd import ops
+    dev = ops.device()
+    rng = np.random.default_rng(11)
+    default = ops.chol_outer_block()
+    try:
+        for (B, N, M, ob) in ((3, 64, 32, 256), (2, 192, 96, 128), (2, 448, 160, 256), (2, 576, 416, 256),
+                              (1, 832, 1056, 512), (2, 320, 64, 64)):
+            assert ops.chol_outer_block(ob) == ob
+            aug = np.empty((B, N + M, N))
+            for b in range(B):
+                x = rng.standard_normal((N, N + 8))
+                aug[b, :N] = x @ x.T / N + np.eye(N) * 10.0 ** (-b)
+                aug[b, N:] = rng.standard_normal((M, N))
+            d_aug = torch.from_numpy(aug).to(dev)
+            h = torch.empty((B, M, N), dtype=torch.float32, device=dev)
+            info = ops.batch_chol_solve(d_aug, B, N, M, h)
+            assert not info.cpu().numpy().any()
+            got = h.cpu().numpy().astype(np.float64)
+            for b in range(B):
+                want = np.linalg.solve(aug[b, :N], aug[b, N:].T).T
+                err = np.abs(got[b] - want).max() / np.abs(want).max()
+                assert err < 3e-7, (B, N, M, ob, b, err)
+        # a non-positive pivot is reported, not hidden
+        bad = np.zeros((1, 64 + 32, 64)); bad[0, :64] = -np.eye(64)
+        info = ops.batch_chol_solve(torch.from_numpy(bad).to(dev), 1, 64, 32,
+                                    torch.empty((1, 32, 64), dtype=torch.float32, device=dev))
+        assert info.cpu().numpy()[0] != 0
+    finally:
+        ops.chol_outer_block(default)
+
+
 def test_series_moments_match_per_alpha_hat_matrices(lc):
     """The alphas on the polynomial series are scored from the moments of the shared terms (one contraction, light
     slabs, f32-MFMA chain or fp64 chain) -- against the same alphas expanded into per-alpha hat matrices and sent

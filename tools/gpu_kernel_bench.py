@@ -239,13 +239,24 @@ if "chol" in what:
         def run2():
             aug2.copy_(base)
             ops.batch_chol_solve(aug2, B_, N_, M_, H2)
-        ops.timing_enable(True); ops.timing_read()
-        ms2 = timeit(run2, reps=3, warm=1)
-        kt = ops.timing_read(); ops.timing_enable(False)
         fl2 = B_ * (N_ ** 3 / 3 + 2.0 * N_ * N_ * M_)
-        chol_ms = kt.get("batch_chol_solve", (0, 1))
-        print(f"batch_chol_solve {label} B={B_} N={N_} M={M_}: {chol_ms[0] / chol_ms[1]:.2f} ms -> "
-              f"{fl2 / (chol_ms[0] / chol_ms[1]) / 1e9:.1f} TFLOP/s fp64")
+        default_ob = ops.chol_outer_block()
+        from litcoder_core_amd import _lib
+        for valu, ob in ((1, 128), (1, 256), (1, 512), (0, 256), (0, 512)):
+            _lib.load().lc_debug_chol_big_kernel(valu)
+            ops.chol_outer_block(ob)
+            ops.timing_enable(True); ops.timing_read()
+            ms2 = timeit(run2, reps=3, warm=1)
+            kt = ops.timing_read(); ops.timing_enable(False)
+            chol_ms = kt.get("batch_chol_solve", (0, 1))
+            print(f"batch_chol_solve {label} B={B_} N={N_} M={M_} outer block {ob} deep updates on {'VALU' if valu else 'MFMA'}: {chol_ms[0] / chol_ms[1]:.2f} ms -> "
+                  f"{fl2 / (chol_ms[0] / chol_ms[1]) / 1e9:.1f} TFLOP/s fp64")
+        ops.chol_outer_block(default_ob)
+        _lib.load().lc_debug_chol_big_kernel(1)
+    a64 = torch.randn((4096, 4096), dtype=torch.float64, device=dev)
+    b64 = torch.randn((4096, 4096), dtype=torch.float64, device=dev)
+    ms = timeit(lambda: torch.matmul(a64, b64), reps=5, warm=2)
+    print(f"for reference, torch.matmul fp64 4096^3 (vendor BLAS): {ms:.2f} ms -> {2 * 4096 ** 3 / ms / 1e9:.1f} TFLOP/s")
 
 if "hbm" in what:
     # HBM-bound kernels: algorithmic bytes / time against the 8 TB/s datasheet rate (6.3 TB/s achievable copy)

@@ -91,3 +91,35 @@ for prio in (0, -1):
         sweeps()
     both()
     print(f"both at once, aux priority {prio}: {wall(both):.1f} ms")
+
+
+# main stream restricted to a subset of the CUs (lc_stream_create_cu_mask): do the short fp64 kernels of the
+# auxiliary stream then run beside the sweeps instead of waiting for sweep workgroups to retire?
+masks = {
+    "all but CUs 224-255": [0xFFFFFFFF] * 7 + [0],
+    "all but every 8th CU": [0xFEFEFEFE] * 8,
+    "all but every 16th CU": [0xFFFEFFFE] * 8,
+    "all but CUs 0-15": [0xFFFF0000] + [0xFFFFFFFF] * 7,
+}
+aux = torch.cuda.Stream(device=dev)
+for name, words in masks.items():
+    try:
+        ms = ops.masked_stream(words)
+    except Exception as e:   # noqa: BLE001
+        print(f"masked stream ({name}): {e}")
+        continue
+
+    def masked_sweeps():
+        with torch.cuda.stream(ms):
+            sweeps()
+
+    def both_masked():
+        with torch.cuda.stream(aux):
+            chols()
+        with torch.cuda.stream(ms):
+            sweeps()
+    masked_sweeps()
+    t_m = wall(masked_sweeps)
+    both_masked()
+    print(f"main stream on {name}: 12 sweeps alone {t_m:.1f} ms; with the Cholesky batches on an unrestricted stream "
+          f"{wall(both_masked):.1f} ms")
