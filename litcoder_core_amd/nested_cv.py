@@ -441,43 +441,64 @@ class RidgeCVEngine:
             tiles.append(tiles[-1] + (int(count_h[a]) + tile - 1) // tile)
         return perm, used, tiles, tiles[-1] * tile
 
-    def _refit_systems(self, X, K, tr_rows, used, tr_o=None, lmax_o=None, te_rows=()):
-        """Per alpha in use, the rows  [Xtr' ; K[te,tr]] (K[tr,tr] + a^2 I)^-1  as f32 (G, p_pad + pad32(n_te), N_o):
-        M_alpha, whose product with the targets is the weight matrix (the V-independent half of
-        ridge_regression.py:46-61), and below it the hat matrix of the test rows, whose product with the same
-        targets is the test prediction X_te W (nested_cv.py:151,251) -- one V-wide contraction gives both.
-        Augmented batched Cholesky in fp64."""
-        G = len(used)
+    def _refit_rhs(self, X, K, tr_rows, tr_o, te_rows):
+        """The augmented rows of the refit systems, fp64 (rows, N_o):  Xtr' above K[te,tr]."""
         n_o, n_t = len(tr_rows), len(te_rows)
-        N_o = ops.pad_to(n_o, LC_NB)
+        N_o = tr_o.shape[-1]
         rows = self.p_pad + ops.pad_to(n_t, LC_MB)
-        if tr_o is None:
-            tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
-            lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
         rhs = torch.zeros((rows, N_o), dtype=torch.float64, device=self.dev)
         ops.transpose_rows(X, tr_o, N_o, self.p, rhs)
         if n_t:
             te64 = ops.upload(np.asarray(te_rows, dtype=np.int64), self.dev)
             tr64 = ops.upload(np.asarray(tr_rows, dtype=np.int64), self.dev)
             rhs[self.p_pad:self.p_pad + n_t, :n_o] = K.index_select(0, te64).index_select(1, tr64)
+        return rhs
+
+    def _refit_chol(self, K, tr_o, lmax_o, rhs, alphas_idx):
+        """rhs (K[tr,tr] + a^2 I)^-1 for the listed alphas by the augmented batched Cholesky in fp64:
+        ((len(alphas_idx), rows, N_o) f32, (len(alphas_idx),) int32 pivot flags)."""
+        Gc, (rows, N_o) = len(alphas_idx), rhs.shape
+        a2_o = ops.penalties(lmax_o, 1, self.d_alphas.index_select(0, ops.upload(np.asarray(alphas_idx, dtype=np.int64),
+                                                                               self.dev)), self.normalpha)
+        aug = torch.empty((Gc, N_o + rows, N_o), dtype=torch.float64, device=self.dev)
+        ops.batch_assemble(K, tr_o, None, rhs, a2_o, 1, Gc, N_o, rows, aug)
+        Mc = torch.empty((Gc, rows, N_o), dtype=torch.float32, device=self.dev)
+        return Mc, ops.batch_chol_solve(aug, Gc, N_o, rows, Mc)
+
+    def _refit_systems(self, X, K, tr_rows, used, tr_o=None, lmax_o=None, te_rows=(), spec=None):
+        """Per alpha in use, the rows  [Xtr' ; K[te,tr]] (K[tr,tr] + a^2 I)^-1  as f32 (G, p_pad + pad32(n_te), N_o):
+        M_alpha, whose product with the targets is the weight matrix (the V-independent half of
+        ridge_regression.py:46-61), and below it the hat matrix of the test rows, whose product with the same
+        targets is the test prediction X_te W (nested_cv.py:151,251) -- one V-wide contraction gives both.
+        Augmented batched Cholesky in fp64; ``spec`` (fold_speculate) holds systems solved ahead of the alpha
+        choice, which are taken from there."""
+        G = len(used)
+        n_o = len(tr_rows)
+        N_o = ops.pad_to(n_o, LC_NB)
+        if tr_o is None:
+            tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
+            lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
+        rhs = spec["rhs"] if spec is not None else self._refit_rhs(X, K, tr_rows, tr_o, te_rows)
+        rows = rhs.shape[0]
         # alphas on the polynomial series (large penalties: what real recordings usually select) need no
         # factorisation:  [Xtr' ; K_te] (K + a^2 I)^-1 = sum_j c_j(alpha) R_j,  R_j = [Xtr' ; K_te] K^j / lambda^(j+1),
         # with the chain R_j = R_(j-1) (K / lambda) on the f32 MFMA, shared by all such alphas (cf. _hat_matrices)
         poly = [a for a in used if a in self.ser] if (N_o % COL_TILE == 0 and lmax_o is not None) else []
         chol = [a for a in used if a not in poly]
+        have = list(spec["alphas"]) if spec is not None else []
+        need = [a for a in chol if a not in have]
         Malpha = torch.empty((G, rows, N_o), dtype=torch.float32, device=self.dev)
-        info = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        if chol:
-            Gc = len(chol)
-            a2_o = ops.penalties(lmax_o, 1, self.d_alphas.index_select(0, ops.upload(np.asarray(chol, dtype=np.int64),
-                                                                                   self.dev)), self.normalpha)
-            aug = torch.empty((Gc, N_o + rows, N_o), dtype=torch.float64, device=self.dev)
-            ops.batch_assemble(K, tr_o, None, rhs, a2_o, 1, Gc, N_o, rows, aug)
-            Mc = Malpha if Gc == G else torch.empty((Gc, rows, N_o), dtype=torch.float32, device=self.dev)
-            info = ops.batch_chol_solve(aug, Gc, N_o, rows, Mc)
-            if Gc != G:
-                for i, a in enumerate(chol):
-                    Malpha[used.index(a)] = Mc[i]
+        flags = []
+        for a in chol:
+            if a in have:
+                Malpha[used.index(a)].copy_(spec["M"][have.index(a)])
+                flags.append(spec["info"][have.index(a):have.index(a) + 1])
+        if need:
+            Mc, info_n = self._refit_chol(K, tr_o, lmax_o, rhs, need)
+            for i, a in enumerate(need):
+                Malpha[used.index(a)].copy_(Mc[i])
+            flags.append(info_n)
+        info = torch.cat(flags) if flags else torch.zeros(1, dtype=torch.int32, device=self.dev)
         if poly:
             Kn = torch.empty((1, N_o, N_o), dtype=torch.float32, device=self.dev)
             ops.gather_sub_f32(K, tr_o, tr_o, 1, N_o, N_o, lmax_o, Kn)
@@ -589,6 +610,19 @@ class RidgeCVEngine:
         st["info"] = st["hat"]["info"]
         return st
 
+    def fold_speculate(self, st, alphas_idx):
+        """Solve the refit systems of a prepared fold for the listed alphas BEFORE its alpha choice is known, on the
+        auxiliary stream (the driver passes the alphas the previous fold used: the histogram of the chosen alphas
+        hardly moves between outer folds).  fold_select then only solves what is missing; without this the last
+        fold's systems are a serial 8 ms at the end of the fit, with nothing left to run beside them."""
+        todo = [a for a in alphas_idx if a in self.cho] if st.get("tr_o") is not None else []
+        if not todo:
+            return
+        with torch.cuda.stream(self.aux):
+            rhs = self._refit_rhs(st["X"], st["K"], st["tr"], st["tr_o"], st["te"])
+            Mc, info = self._refit_chol(st["K"], st["tr_o"], st["lmax_o"], rhs, todo)
+        st["spec"] = dict(alphas=todo, M=Mc, info=info, rhs=rhs)
+
     def fold_select(self, st, single_alpha):
         """Alpha choice of the fold (waits for its sweeps: the histogram comes to the host) and, on the auxiliary
         stream, the fp64 systems of the refit -- they run beside whatever the main stream does next."""
@@ -598,7 +632,7 @@ class RidgeCVEngine:
         main = torch.cuda.current_stream()
         with torch.cuda.stream(self.aux):                  # inputs: X, K, tr_o, lmax_o -- all made on aux or at start
             Malpha, info_o = self._refit_systems(st["X"], st["K"], st["tr"], used, st.get("tr_o"), st.get("lmax_o"),
-                                                 st["te"])
+                                                 st["te"], spec=st.get("spec"))
             ready = torch.cuda.Event()
             ready.record()
         for x in (Malpha, info_o):
@@ -847,6 +881,8 @@ class NestedCVModel(BasePredictivityModel):
             if i + 1 < n:
                 st_next = eng.fold_begin(*outer[i + 1], prepared=prepared)                    # main: sweeps of i+1
                 prepared = eng.fold_prepare(*outer[i + 2], lmax_pre=lmax_pre[i + 2]) if i + 2 < n else None
+                if getattr(eng, "fold_speculate", None) is not None:
+                    eng.fold_speculate(st_next, st["used"])                                   # aux: refit systems of i+1
             if pending is not None:
                 tail(pending)
             pending = eng.fold_finish(st, scale)            # main: V-wide refit of fold i behind those sweeps

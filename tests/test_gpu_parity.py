@@ -349,6 +349,42 @@ def test_shared_target_image_is_bitwise_neutral(lc):
     assert eng2._shared_image(ragged, 384) is None                       # gap not a multiple of 16 rows in
 
 
+def test_speculative_refit_systems_are_neutral(lc):
+    """The driver solves a fold's refit systems ahead of its alpha choice for the alphas the previous fold used
+    (fold_speculate); fold_select then only adds what is missing.  Same systems, same arithmetic: weights, scores
+    and chosen alphas must be identical bit for bit with and without it, also when the guess is incomplete."""
+    from litcoder_core_amd import nested_cv as ncv
+    rng = np.random.default_rng(21)
+    T, p, V = 400, 40, 200
+    X = rng.standard_normal((T, p))
+    W = rng.standard_normal((p, V)) * np.r_[np.full(V // 2, 0.5), np.full(V - V // 2, 0.02)]
+    Y = X @ W + rng.standard_normal((T, V))
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-2, 3, 6).tolist(),
+              normalpha=False, use_corr=True, single_alpha=False, normalize_features=False, normalize_targets=False)
+    calls = []
+    real = ncv.RidgeCVEngine.fold_speculate
+
+    def spy(self, st, alphas_idx):
+        calls.append(list(alphas_idx))
+        return real(self, st, alphas_idx)
+
+    def partial(self, st, alphas_idx):
+        return real(self, st, list(alphas_idx)[:1])       # an incomplete guess: the rest is solved after the choice
+
+    out = {}
+    for name, fn in (("spec", spy), ("partial", partial), ("none", None)):
+        ncv.RidgeCVEngine.fold_speculate = fn
+        try:
+            out[name] = lc.NestedCVModel("ridge_regression").fit_predict(features=X, targets=Y, **kw)
+        finally:
+            ncv.RidgeCVEngine.fold_speculate = real
+    assert len(calls) == 2 and all(calls)
+    for name in ("spec", "partial"):
+        (m, w, a), (m0, w0, a0) = out[name], out["none"]
+        assert np.array_equal(w, w0) and np.array_equal(a, a0), name
+        assert m["correlations"] == m0["correlations"] and m["p_values"] == m0["p_values"], name
+
+
 def test_refit_with_large_alphas_polynomial_route(lc):
     """Weights for voxels whose alpha lies on the polynomial series (no factorisation: shared powers of K on the
     f32 MFMA) next to voxels that need the Cholesky route, against the oracle's SVD-route ridge."""
