@@ -190,10 +190,11 @@ int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, floa
                         const int32_t* d_slot, int32_t* d_info, lc_stream_t stream);
 
 /* Tuning hook of lc_batch_chol_solve: columns per outer block of its two-level blocking (a multiple of LC_NB;
- * default 256).  columns <= 0 only queries.  Returns the value in force (>= LC_NB), or a negative error code. */
+ * default 512).  columns <= 0 only queries.  Returns the value in force (>= LC_NB), or a negative error code. */
 int lc_chol_outer_block(int columns);
-/* Diagnostic: deep updates of lc_batch_chol_solve on the vector ALU (1, default) or the fp64 MFMA (0); < 0 queries. */
-int lc_debug_chol_big_kernel(int valu);
+/* Diagnostic: kernel of the deep updates of lc_batch_chol_solve -- 2: 4x4x4 fp64 MFMA (default), 1: vector ALU,
+ * 0: 16x16x4 fp64 MFMA; anything else only queries.  Returns the one in force. */
+int lc_debug_chol_big_kernel(int which);
 
 /* The same hat matrices for alphas whose penalty dwarfs the spectrum, as a polynomial in K[tr,tr]:
  *   K[va,tr] (K[tr,tr] + a^2 I)^-1  ~=  sum_{j<terms} c_sj K[va,tr] K[tr,tr]^j / scale_f^(j+1)

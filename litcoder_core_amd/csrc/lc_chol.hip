@@ -16,6 +16,7 @@
 // rate of gfx950 equals the vector fp64 rate, but a 4 x 4 register tile of v_fma_f64 needs 8 LDS reads per 16 FMAs
 // (256 B/clk/CU with four SIMDs busy: twice what the LDS delivers), the MFMA form 8 reads per 16 MFMAs of 64 cycles.
 #include "lc_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -243,9 +244,21 @@ __global__ void __launch_bounds__(256, 2) k_mm64(const MMArgs g) {
         }
     }
 
+    // C -= acc as batches of loads, then the stores of the batch: written as "*dst = *dst - acc" per element the
+    // compiler must assume that a store aliases the next load and serialises WB * WB * 4 memory round trips
     double* C = g.c + (long long)blockIdx.z * g.c_sys + (long long)r0 * g.ldc + c0;
 #pragma unroll
-    for (int i = 0; i < WB; ++i)
+    for (int i = 0; i < WB; ++i) {
+        double old[4][WB];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wm * 16 * WB + i * 16 + lq + 4 * r;
+#pragma unroll
+            for (int j = 0; j < WB; ++j) {
+                const int col = wn * 16 * WB + j * 16 + li;
+                old[r][j] = (g.subtract && row < a_rows && col < b_n) ? C[(long long)row * g.ldc + col] : 0.0;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = wm * 16 * WB + i * 16 + lq + 4 * r;
@@ -253,12 +266,10 @@ __global__ void __launch_bounds__(256, 2) k_mm64(const MMArgs g) {
 #pragma unroll
                 for (int j = 0; j < WB; ++j) {
                     const int col = wn * 16 * WB + j * 16 + li;
-                    if (col < b_n) {
-                        double* dst = C + (long long)row * g.ldc + col;
-                        *dst = g.subtract ? *dst - acc[i][j][r] : acc[i][j][r];
-                    }
+                    if (col < b_n) C[(long long)row * g.ldc + col] = g.subtract ? old[r][j] - acc[i][j][r] : acc[i][j][r];
                 }
         }
+    }
 }
 
 template <int WB, bool BT>
@@ -360,34 +371,195 @@ __global__ void __launch_bounds__(256, 2) k_mm64v(const MMArgs g) {
         }
     }
 
+    // loads of a batch first, then its stores (see k_mm64: element-wise read-modify-write serialises the round trips)
     double* C = g.c + (long long)blockIdx.z * g.c_sys + (long long)r0 * g.ldc + c0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = 32 * (i >> 1) + 2 * ty + (i & 1);
-        if (row < a_rows)
+    for (int h = 0; h < 2; ++h) {
+        f64x2 old[4][4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * h + ii;
+            const int row = 32 * (i >> 1) + 2 * ty + (i & 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = 32 * j + 2 * tx;
-                if (col < b_n) {
-                    f64x2* dst = reinterpret_cast<f64x2*>(C + (long long)row * g.ldc + col);
-                    f64x2 v = {acc[i][2 * j], acc[i][2 * j + 1]};
-                    if (g.subtract) v = *dst - v;
-                    *dst = v;
-                }
+                old[ii][j] = (g.subtract && row < a_rows && col < b_n)
+                                 ? *reinterpret_cast<const f64x2*>(C + (long long)row * g.ldc + col) : f64x2{0.0, 0.0};
             }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = 4 * h + ii;
+            const int row = 32 * (i >> 1) + 2 * ty + (i & 1);
+            if (row < a_rows)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = 32 * j + 2 * tx;
+                    if (col < b_n) {
+                        f64x2 v = {acc[i][2 * j], acc[i][2 * j + 1]};
+                        if (g.subtract) v = old[ii][j] - v;
+                        *reinterpret_cast<f64x2*>(C + (long long)row * g.ldc + col) = v;
+                    }
+                }
+        }
     }
 }
 
-static int g_big_valu = 1;       // deep updates on the vector ALU (k_mm64v) or on the MFMA (k_mm64<4>)
+// The deep updates on the matrix pipe after all -- with v_mfma_f64_4x4x4_4b_f64.  Measured on this part
+// (tools/mfma_f64_rate.hip): the 16x16x4 fp64 MFMA issues every ~130 cycles from one wave (34 TFLOP/s, 45-50 with two
+// waves per SIMD), the 4x4x4 four-block form every 16-17 cycles (65-70 TFLOP/s from a single wave per SIMD, the
+// datasheet rate).  Its four blocks are independent 4x4x4 products with lanes  A: 16 k + 4 blk + i,  B: 16 k + 4 blk + j,
+// D: 16 i + 4 blk + j  (tools/mfma_f64_4x4_layout.hip; CBSZ / ABID have no effect); with the A block replicated
+// over blk -- an LDS broadcast read -- one instruction is a 4 x 16 x 4 product.  Tile 128 x 128 per workgroup, wave
+// w owns rows 32 w .. 32 w + 31 and all 128 columns (8 row groups x 8 column groups = 64 accumulators in AGPRs).
+// Software pipeline: LDS double buffer (one barrier per depth-16 chunk), B fragments of the next depth-4 step in a
+// second register set, every A fragment reloaded in place right after its eight MFMAs, next chunk in registers.
+// The MFMAs are inline asm with a tied accumulator: left to the register allocator a quarter of them came out as
+// D != C with write-after-read chains between neighbours and the loop ran at 40 cycles per MFMA instead of 16.
+constexpr int MQ_TS = 128, MQ_KC = 16, MQ_LD = MQ_KC + 2;
+constexpr int MQ_BUF = MQ_TS * MQ_LD;          // doubles per operand buffer
+constexpr int MQ_LDS_BYTES = 2 * 2 * MQ_BUF * 8;
+
+template <bool BT>
+__global__ void __launch_bounds__(256, 2) k_mm64q(const MMArgs g) {
+    extern __shared__ double smem[];            // [2 buffers][A, B][MQ_BUF]
+    const int r0 = blockIdx.y * MQ_TS, c0 = blockIdx.x * MQ_TS;
+    if (g.tri && g.row0 + r0 + MQ_TS - 1 < g.col0 + c0) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const double* A = g.a + (long long)blockIdx.z * g.a_sys + (long long)r0 * g.lda;
+    const double* B = g.b + (long long)blockIdx.z * g.b_sys + (BT ? (long long)c0 * g.ldb : (long long)c0);
+    const int a_rows = min(MQ_TS, g.rows - r0), b_n = min(MQ_TS, g.cols - c0);
+
+    // loader: 4 x 16 B per operand and thread (rows (t >> 3) + 32 q, k pair t & 7); rows past the edge are clamped
+    // to the last valid one -- their products are never stored
+    const int lrow = t >> 3, lkp = t & 7;
+    f64x2 ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = lrow + 32 * q;
+            ra[q] = *reinterpret_cast<const f64x2*>(A + (long long)min(row, a_rows - 1) * g.lda + k0 + 2 * lkp);
+            if (BT) {
+                rb[q] = *reinterpret_cast<const f64x2*>(B + (long long)min(row, b_n - 1) * g.ldb + k0 + 2 * lkp);
+            } else {
+                const int e = t + 256 * q, kr = e >> 6, cp = e & 63;
+                rb[q] = *reinterpret_cast<const f64x2*>(B + (long long)(k0 + kr) * g.ldb + min(2 * cp, b_n - 2));
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+        double* sA = smem + buf * 2 * MQ_BUF;
+        double* sB = sA + MQ_BUF;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int so = (lrow + 32 * q) * MQ_LD + 2 * lkp;
+            *reinterpret_cast<f64x2*>(sA + so) = ra[q];
+            if (BT) {
+                *reinterpret_cast<f64x2*>(sB + so) = rb[q];
+            } else {
+                const int e = t + 256 * q, kr = e >> 6, cp = e & 63;
+                sB[(2 * cp) * MQ_LD + kr] = rb[q].x;
+                sB[(2 * cp + 1) * MQ_LD + kr] = rb[q].y;
+            }
+        }
+    };
+
+    // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks; lanes  A: 16 k + 4 blk + i,  B: 16 k + 4 blk + j,
+    // D: 16 i + 4 blk + j.  With the A block replicated over blk (an LDS broadcast) it is a 4 x 16 x 4 product.
+    // Wave w owns rows 32 w .. 32 w + 31 of the tile and all 128 columns: 8 row groups x 8 column groups.
+    double acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
+
+    const int oa = (w * 32 + (lane & 3)) * MQ_LD + lq, ob = MQ_BUF + li * MQ_LD + lq;
+    double fa[8], fb[2][8];
+    // one depth-4 step: the B fragments of the next step go to the other register set up front, every A fragment is
+    // reloaded in place as soon as its eight MFMAs are issued
+    auto step = [&](int cur, bool next, int nbuf, int nk4) {
+        const double* base = smem + nbuf * 2 * MQ_BUF + 4 * nk4;
+        if (next) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fb[cur ^ 1][j] = base[ob + j * 16 * MQ_LD];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[i]), "v"(fb[cur][j]));
+            if (next) fa[i] = base[oa + i * 4 * MQ_LD];
+        }
+    };
+
+    const int nk = g.depth / MQ_KC;
+    fetch(0);
+    stash(0);
+    if (nk > 1) fetch(MQ_KC);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = smem[oa + i * 4 * MQ_LD];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fb[0][j] = smem[ob + j * 16 * MQ_LD];
+    auto chunk = [&](int k, auto last) {
+        constexpr bool LAST = decltype(last)::value;
+        const int buf = k & 1;
+        step(0, true, buf, 1);
+        step(1, true, buf, 2);
+        if (!LAST) stash(buf ^ 1);          // chunk k+1 (in registers since the previous iteration)
+        step(0, true, buf, 3);
+        if (!LAST && k + 2 < nk) fetch((k + 2) * MQ_KC);
+        __syncthreads();                  // chunk k+1 visible; everyone has read all of chunk k
+        step(1, !LAST, buf ^ 1, 0);
+    };
+    for (int k = 0; k + 1 < nk; ++k) chunk(k, std::false_type{});
+    chunk(nk - 1, std::true_type{});
+
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the MFMAs above are opaque to the hazard recogniser
+    double* C = g.c + (long long)blockIdx.z * g.c_sys + (long long)r0 * g.ldc + c0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double old[4][8];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int row = w * 32 + 4 * (4 * h + ii) + lq;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                old[ii][j] = (g.subtract && row < a_rows && 16 * j + li < b_n) ? C[(long long)row * g.ldc + 16 * j + li] : 0.0;
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int row = w * 32 + 4 * (4 * h + ii) + lq;
+            if (row < a_rows)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (16 * j + li < b_n)
+                        C[(long long)row * g.ldc + 16 * j + li] = g.subtract ? old[ii][j] - acc[4 * h + ii][j] : acc[4 * h + ii][j];
+        }
+    }
+}
+
+static int g_big_kernel = 2;    // deep updates: 2 = 4x4x4 MFMA (k_mm64q), 1 = vector ALU (k_mm64v), 0 = 16x16x4 MFMA (k_mm64<4>)
+       // deep updates on the vector ALU (k_mm64v) or on the MFMA (k_mm64<4>)
 
 template <bool BT>
 void launch_big(const MMArgs& g, int B, hipStream_t s) {
     if (g.rows <= 0 || g.cols <= 0) return;
-    if (g_big_valu)
-        hipLaunchKernelGGL((k_mm64v<BT>), dim3((unsigned)lc::ceil_div(g.cols, MV_TS), (unsigned)lc::ceil_div(g.rows, MV_TS), (unsigned)B),
-                           dim3(256), 0, s, g);
-    else
+    const dim3 grid((unsigned)lc::ceil_div(g.cols, 128), (unsigned)lc::ceil_div(g.rows, 128), (unsigned)B);
+    if (g_big_kernel == 2) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm64q<BT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      MQ_LDS_BYTES);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((k_mm64q<BT>), grid, dim3(256), MQ_LDS_BYTES, s, g);
+    } else if (g_big_kernel == 1) {
+        hipLaunchKernelGGL((k_mm64v<BT>), grid, dim3(256), 0, s, g);
+    } else {
         launch_mm<4, BT>(g, B, s);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ aug, int N, int M, float* __restrict__ h,
@@ -400,7 +572,7 @@ __global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ au
 
 }  // namespace
 
-static int g_chol_outer = 256;   // columns per outer block (multiple of NB)
+static int g_chol_outer = 512;   // columns per outer block (multiple of NB)
 
 extern "C" int lc_chol_outer_block(int columns) {
     if (columns > 0) {
@@ -410,9 +582,9 @@ extern "C" int lc_chol_outer_block(int columns) {
     return g_chol_outer;
 }
 
-extern "C" int lc_debug_chol_big_kernel(int valu) {
-    if (valu >= 0) g_big_valu = valu ? 1 : 0;
-    return g_big_valu;
+extern "C" int lc_debug_chol_big_kernel(int which) {
+    if (which >= 0 && which <= 2) g_big_kernel = which;
+    return g_big_kernel;
 }
 
 extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,

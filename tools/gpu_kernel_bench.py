@@ -242,17 +242,17 @@ if "chol" in what:
         fl2 = B_ * (N_ ** 3 / 3 + 2.0 * N_ * N_ * M_)
         default_ob = ops.chol_outer_block()
         from litcoder_core_amd import _lib
-        for valu, ob in ((1, 128), (1, 256), (1, 512), (0, 256), (0, 512)):
+        for valu, ob in ((2, 256), (2, 512), (1, 256), (1, 512), (0, 256)):
             _lib.load().lc_debug_chol_big_kernel(valu)
             ops.chol_outer_block(ob)
             ops.timing_enable(True); ops.timing_read()
             ms2 = timeit(run2, reps=3, warm=1)
             kt = ops.timing_read(); ops.timing_enable(False)
             chol_ms = kt.get("batch_chol_solve", (0, 1))
-            print(f"batch_chol_solve {label} B={B_} N={N_} M={M_} outer block {ob} deep updates on {'VALU' if valu else 'MFMA'}: {chol_ms[0] / chol_ms[1]:.2f} ms -> "
+            print(f"batch_chol_solve {label} B={B_} N={N_} M={M_} outer block {ob} deep updates on {('MFMA 16x16x4', 'VALU', 'MFMA 4x4x4')[valu]}: {chol_ms[0] / chol_ms[1]:.2f} ms -> "
                   f"{fl2 / (chol_ms[0] / chol_ms[1]) / 1e9:.1f} TFLOP/s fp64")
         ops.chol_outer_block(default_ob)
-        _lib.load().lc_debug_chol_big_kernel(1)
+        _lib.load().lc_debug_chol_big_kernel(2)
     a64 = torch.randn((4096, 4096), dtype=torch.float64, device=dev)
     b64 = torch.randn((4096, 4096), dtype=torch.float64, device=dev)
     ms = timeit(lambda: torch.matmul(a64, b64), reps=5, warm=2)

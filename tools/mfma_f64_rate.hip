@@ -65,6 +65,57 @@ __global__ void __launch_bounds__(256) k_fma(int iters, double* out, unsigned lo
 }
 
 
+// variants of the bare MFMA loop: distinct operand registers, fillers between MFMAs, the 4x4x4 (4-block) shape
+template <int MODE>
+__global__ void __launch_bounds__(256) k_mfma_var(int iters, double* out, unsigned long long* cyc) {
+    f64x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = f64x4{0, 0, 0, 0};
+    double a[4], b[4];
+    for (int i = 0; i < 4; ++i) { a[i] = threadIdx.x * 1e-3 + i; b[i] = 0.5 + threadIdx.x * 1e-4 - i; }
+    int filler = threadIdx.x;
+    double acc4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (MODE == 4) {
+                acc4[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i & 3], b[(i >> 1) & 3], acc4[i], 0, 0, 0);
+            } else {
+                acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i & 3], b[(i >> 1) & 3], acc[i], 0, 0, 0);
+                if (MODE == 2) asm volatile("s_nop 1");
+                if (MODE == 3) asm volatile("v_add_u32 %0, %0, 1" : "+v"(filler));
+            }
+        }
+    }
+    double s = filler;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + acc4[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { cyc[blockIdx.x & 2047] = 1; cyc[2048 + (blockIdx.x & 2047)] = 1; }
+}
+
+// 4x4x4 MFMA with a GEMM-like register pattern: 64 accumulators, A fragment shared by 8 consecutive MFMAs
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k_mfma44(int iters, double* out, unsigned long long* cyc) {
+    double acc[8][8];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) acc[i][j] = 0;
+    double a[8], b[8];
+    for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x * 1e-3 + i; b[i] = 0.5 + threadIdx.x * 1e-4 - i; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (MODE == 0) acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[(i + j) & 7], b[j], acc[i][j], 0, 0, 0);
+            }
+        // keep the operands live and changing so that nothing is hoisted
+        for (int i = 0; i < 8; ++i) { a[i] += 1e-9; b[i] -= 1e-9; }
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) s += acc[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { cyc[blockIdx.x & 2047] = 1; cyc[2048 + (blockIdx.x & 2047)] = 1; }
+}
+
 // half of the waves issue MFMAs, the other half vector FMAs: do the two share one fp64 datapath?
 __global__ void __launch_bounds__(256) k_mix(int iters, double* out, unsigned long long* cyc) {
     const bool mf = (threadIdx.x >> 6) & 1;
@@ -149,6 +200,19 @@ int main() {
         snprintf(name, sizeof name, "v_fma_f64, %d wave(s)/SIMD, 16 accumulators", m);
         run(k_fma<16>, name, 256 * m, 16, 128.0);
     }
+    for (int m = 1; m <= 4; m *= 2) {
+        char name[160];
+        snprintf(name, sizeof name, "MFMA 16x16x4, 4 operand pairs, %d wave(s)/SIMD", m);
+        run(k_mfma_var<1>, name, 256 * m, 8, 2048.0);
+        snprintf(name, sizeof name, "MFMA 16x16x4, 4 operand pairs + s_nop, %d wave(s)/SIMD", m);
+        run(k_mfma_var<2>, name, 256 * m, 8, 2048.0);
+        snprintf(name, sizeof name, "MFMA 16x16x4, 4 operand pairs + VALU filler, %d wave(s)/SIMD", m);
+        run(k_mfma_var<3>, name, 256 * m, 8, 2048.0);
+        snprintf(name, sizeof name, "MFMA 4x4x4 (4 blocks), %d wave(s)/SIMD", m);
+        run(k_mfma_var<4>, name, 256 * m, 8, 512.0);
+    }
+    run(k_mfma44<0>, "MFMA 4x4x4, 64 accumulators, A shared by 8 consecutive, 1 wave/SIMD", 256, 64, 512.0);
+    run(k_mfma44<1>, "MFMA 4x4x4, 64 accumulators, A rotating, 1 wave/SIMD", 256, 64, 512.0);
     run_mix(512);
     run_mix(1024);
     run_mix(2048);
