@@ -7,14 +7,15 @@
 //
 // Two-level right-looking blocking.  Columns are factored in NB = 64 wide steps (diagonal tile in LDS by one
 // workgroup per system, its inverse Linv kept, panel = P Linv'), but the rank-64 updates of a step only touch the
-// remaining columns of the current OUTER block (LC_CHOL_OB = 256 columns); everything to the right is updated once
-// per outer block with a depth-256 product.  At NB = 64 depth the trailing update re-reads and re-writes the whole
-// trailing matrix 30 times for N = 1920 -- 10 GB per batch of 20 systems, the largest single cost of the old
-// VALU-tiled version -- at depth 256 it is a quarter of that.  The back substitution is blocked the same way.
+// remaining columns of the current OUTER block (512 columns, lc_chol_outer_block); everything to the right is
+// updated once per outer block with a product of that depth.  At NB = 64 depth the trailing update re-reads and
+// re-writes the whole trailing matrix 30 times for N = 1920 -- 10 GB per batch of 20 systems, the largest single
+// cost of the first version -- at depth 512 an eighth of that.  The back substitution is blocked the same way.
 //
-// Every GEMM-shaped piece is one kernel, k_mm64: v_mfma_f64_16x16x4_f64 on LDS-staged operands.  The matrix fp64
-// rate of gfx950 equals the vector fp64 rate, but a 4 x 4 register tile of v_fma_f64 needs 8 LDS reads per 16 FMAs
-// (256 B/clk/CU with four SIMDs busy: twice what the LDS delivers), the MFMA form 8 reads per 16 MFMAs of 64 cycles.
+// Every GEMM-shaped piece is a tile product on LDS-staged operands: the short step kernels on
+// v_mfma_f64_16x16x4_f64 (k_mm64<2>), the deep updates on v_mfma_f64_4x4x4_4b_f64 (k_mm64q, below), with a
+// v_fma_f64 version (k_mm64v) kept for comparison.  What the three pipes deliver on this part was measured first
+// (tools/mfma_f64_rate.hip); the datasheet's "matrix fp64 = vector fp64 = 78.6 TF" holds only for the 4x4x4 form.
 #include "lc_common.h"
 #include <type_traits>
 
