@@ -429,17 +429,31 @@ class RidgeCVEngine:
     # -------------------------------------------------------------- refit (ridge_torch)
     # three steps, so that the driver can put the fp64 systems on the auxiliary stream beside the next fold's
     # sweeps: groups (argmax histogram -> host), systems (M_alpha of the alphas in use), apply (V-wide GEMM)
-    def _refit_groups(self, best, split):
+    def _refit_groups(self, best, split, pending=None):
         """Voxels sorted by chosen alpha: (perm, used alphas, column-tile offsets per group, Vs).  The one
-        host synchronisation of a fold: the histogram decides how many systems the refit solves."""
+        host synchronisation of a fold: the histogram decides how many systems the refit solves.  ``pending``
+        (from _group_async) holds a grouping whose histogram is already on its way to pinned memory."""
         tile = 256 if split else COL_TILE                 # column-tile width of the GEMM that follows
-        perm, count = ops.group_by_alpha(best, self.V, self.A, tile)
-        count_h = count.cpu().numpy()
+        if pending is None:
+            pending = self._group_async(best, split)
+        perm, count_h, ev = pending
+        ev.synchronize()
+        count_h = count_h.numpy()
         used = [a for a in range(self.A) if count_h[a] > 0]
         tiles = [0]
         for a in used:
             tiles.append(tiles[-1] + (int(count_h[a]) + tile - 1) // tile)
         return perm, used, tiles, tiles[-1] * tile
+
+    def _group_async(self, best, split):
+        """Grouping kernel + asynchronous copy of the alpha histogram to pinned memory: (perm, host counts, event)."""
+        tile = 256 if split else COL_TILE
+        perm, count = ops.group_by_alpha(best, self.V, self.A, tile)
+        count_h = torch.empty(self.A, dtype=torch.int32, pin_memory=True)
+        count_h.copy_(count, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return perm, count_h, ev
 
     def _refit_rhs(self, X, K, tr_rows, tr_o, te_rows):
         """The augmented rows of the refit systems, fp64 (rows, N_o):  Xtr' above K[te,tr]."""
@@ -623,12 +637,22 @@ class RidgeCVEngine:
             Mc, info = self._refit_chol(st["K"], st["tr_o"], st["lmax_o"], rhs, todo)
         st["spec"] = dict(alphas=todo, M=Mc, info=info, rhs=rhs)
 
+    def fold_choose(self, st, single_alpha):
+        """Alpha choice of the fold and the grouping of the voxels by it, enqueued behind the fold's sweeps; the
+        histogram travels to pinned memory asynchronously, so the caller can queue the next fold's sweeps on the
+        main stream BEFORE waiting for it in fold_select (the stream then never idles through the host round trip)."""
+        st["best"] = self.choose(st["scores"], single_alpha)
+        st["split"] = self._use_split(st["Y"])
+        st["grouping"] = self._group_async(st["best"], st["split"])
+        return st
+
     def fold_select(self, st, single_alpha):
-        """Alpha choice of the fold (waits for its sweeps: the histogram comes to the host) and, on the auxiliary
-        stream, the fp64 systems of the refit -- they run beside whatever the main stream does next."""
-        best = self.choose(st["scores"], single_alpha)
-        split = self._use_split(st["Y"])
-        perm, used, tiles, Vs = self._refit_groups(best, split)
+        """Waits for the fold's alpha histogram (fold_choose; the one host synchronisation of a fold) and puts the
+        fp64 systems of the refit on the auxiliary stream -- they run beside whatever the main stream does next."""
+        if "grouping" not in st:
+            self.fold_choose(st, single_alpha)
+        best, split = st["best"], st["split"]
+        perm, used, tiles, Vs = self._refit_groups(best, split, st.pop("grouping"))
         main = torch.cuda.current_stream()
         with torch.cuda.stream(self.aux):                  # inputs: X, K, tr_o, lmax_o -- all made on aux or at start
             Malpha, info_o = self._refit_systems(st["X"], st["K"], st["tr"], used, st.get("tr_o"), st.get("lmax_o"),
@@ -876,10 +900,13 @@ class NestedCVModel(BasePredictivityModel):
         st = eng.fold_begin(*outer[0], prepared=eng.fold_prepare(*outer[0], lmax_pre=lmax_pre[0]))
         prepared = eng.fold_prepare(*outer[1], lmax_pre=lmax_pre[1]) if n > 1 else None       # aux stream
         for i in range(n):
-            st = eng.fold_select(st, single_alpha)          # host waits for the sweeps of fold i here
+            if getattr(eng, "fold_choose", None) is not None:
+                eng.fold_choose(st, single_alpha)           # main: argmax + grouping; the histogram leaves asynchronously
             st_next = None
             if i + 1 < n:
                 st_next = eng.fold_begin(*outer[i + 1], prepared=prepared)                    # main: sweeps of i+1
+            st = eng.fold_select(st, single_alpha)          # host waits for the histogram of fold i here
+            if i + 1 < n:
                 prepared = eng.fold_prepare(*outer[i + 2], lmax_pre=lmax_pre[i + 2]) if i + 2 < n else None
                 if getattr(eng, "fold_speculate", None) is not None:
                     eng.fold_speculate(st_next, st["used"])                                   # aux: refit systems of i+1
