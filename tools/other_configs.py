@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """One fit at the shapes of BASELINE.json configs 4 and 5 on a single GPU (synthetic data, device-resident inputs):
+cfg1 = a word-rate feature (p = 4) over T 9000, V 80 000 (p << n: the dual form still applies);
 cfg4 = T 2226, p 3072, V 200 000 (the whole volume on one GPU instead of 8 shards), 20 alphas;
 cfg5 = T 3000, p 1280 x 6 delays = 7680, V 80 000, 32 alphas, two feature bands with different penalty scales.
 Prints time, voxels/s and the median score; checks that every result is finite.   python tools/other_configs.py"""
@@ -32,12 +33,17 @@ def synth(T, F0, delays, V, band_scale=None, seed=0):
     return dX, dY, p
 
 
+only = sys.argv[1:]
 for name, args, alphas in (
+        ("cfg1-like: wordrate, T 9000, p 4 (1 x 4 delays), V 80000, 20 alphas", dict(T=9000, F0=1, delays=[1, 2, 3, 4], V=80000),
+         np.logspace(-1, 8, 20)),
         ("cfg4-like: T 2226, p 3072, V 200000, 20 alphas", dict(T=2226, F0=768, delays=[1, 2, 3, 4], V=200000),
          np.logspace(-1, 8, 20)),
         ("cfg5-like: T 3000, p 7680 (1280 x 6), V 80000, 32 alphas, 2 bands",
          dict(T=3000, F0=1280, delays=[1, 2, 3, 4, 5, 6], V=80000,
               band_scale=np.r_[np.full(3840, 1.0), np.full(3840, 2.0)]), np.logspace(-1, 8, 32))):
+    if only and not any(o in name for o in only):
+        continue
     V = args["V"]
     dX, dY, p = synth(**args)
     model = NestedCVModel("ridge_regression")
