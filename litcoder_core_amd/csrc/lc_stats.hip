@@ -16,13 +16,16 @@ __global__ void __launch_bounds__(256) k_cast_f64_f32(const double* __restrict__
 }
 
 // ------------------------------------------------------------------ gather / scatter
+// x = column chunk (fastest), y = row: the workgroups that are resident together read (or update) the same row, whose
+// sectors -- each touched for one 4-byte element -- are then shared through L2 instead of being fetched per chunk
+// (2.2x on the alpha-sorted copy of the targets; several rows per workgroup were slower again).
 __global__ void __launch_bounds__(256) k_gather(const float* __restrict__ in, long long ld_in,
                                                 const int* __restrict__ rows, const int* __restrict__ cols,
                                                 long long n_cols, float* __restrict__ out, long long ld_out) {
-    const long long r = blockIdx.x;
+    const long long r = blockIdx.y;
     const long long src = rows ? rows[r] : r;
-    const long long stride = (long long)gridDim.y * blockDim.x;
-    for (long long j = (long long)blockIdx.y * blockDim.x + threadIdx.x; j < n_cols; j += stride) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += stride) {
         float v = 0.f;
         const long long c = cols ? cols[j] : j;
         if (src >= 0 && c >= 0) v = in[src * ld_in + c];
@@ -33,9 +36,9 @@ __global__ void __launch_bounds__(256) k_gather(const float* __restrict__ in, lo
 __global__ void __launch_bounds__(256) k_scatter_axpy(const float* __restrict__ w, long long ld_w,
                                                       const int* __restrict__ cols, long long n_cols, float scale,
                                                       float* __restrict__ acc, long long ld_acc) {
-    const long long r = blockIdx.x;
-    const long long stride = (long long)gridDim.y * blockDim.x;
-    for (long long j = (long long)blockIdx.y * blockDim.x + threadIdx.x; j < n_cols; j += stride) {
+    const long long r = blockIdx.y;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += stride) {
         const long long c = cols ? cols[j] : j;
         if (c >= 0) acc[r * ld_acc + c] += scale * w[r * ld_w + j];
     }
@@ -356,10 +359,14 @@ extern "C" int lc_gather_f32(const float* d_in, int64_t ld_in, const int32_t* d_
     LC_REQUIRE(d_in && d_out, LC_E_BADARG, "lc_gather_f32: null pointer");
     LC_REQUIRE(n_rows >= 0 && n_cols >= 0 && ld_out >= n_cols, LC_E_SHAPE, "lc_gather_f32: bad shape");
     if (n_rows == 0 || n_cols == 0) return LC_OK;
-    dim3 grid((unsigned)n_rows, (unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 1024), 1024));
     lc::ScopedTimer timer_(lc::T_GATHER, lc::as_stream(stream));
-    hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, lc::as_stream(stream), d_in, ld_in, d_rows, d_cols, n_cols,
-                       d_out, ld_out);
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {          // grid.y carries the row
+        const int64_t nr = lc::imin(65535, n_rows - r0);
+        dim3 grid((unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 1024), 1024), (unsigned)nr);
+        hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, lc::as_stream(stream), d_rows ? d_in : d_in + r0 * ld_in,
+                           (long long)ld_in, d_rows ? d_rows + r0 : nullptr, d_cols, (long long)n_cols, d_out + r0 * ld_out,
+                           (long long)ld_out);
+    }
     return lc::launched("k_gather");
 }
 
@@ -368,10 +375,13 @@ extern "C" int lc_scatter_axpy_f32(const float* d_w, int64_t ld_w, int64_t n_row
     LC_REQUIRE(d_w && d_acc, LC_E_BADARG, "lc_scatter_axpy_f32: null pointer");
     LC_REQUIRE(n_rows >= 0 && n_cols >= 0, LC_E_SHAPE, "lc_scatter_axpy_f32: bad shape");
     if (n_rows == 0 || n_cols == 0) return LC_OK;
-    dim3 grid((unsigned)n_rows, (unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 1024), 1024));
     lc::ScopedTimer timer_(lc::T_SCATTER, lc::as_stream(stream));
-    hipLaunchKernelGGL(k_scatter_axpy, grid, dim3(256), 0, lc::as_stream(stream), d_w, ld_w, d_cols, n_cols, scale,
-                       d_acc, ld_acc);
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {          // grid.y carries the row
+        const int64_t nr = lc::imin(65535, n_rows - r0);
+        dim3 grid((unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 1024), 1024), (unsigned)nr);
+        hipLaunchKernelGGL(k_scatter_axpy, grid, dim3(256), 0, lc::as_stream(stream), d_w + r0 * ld_w, (long long)ld_w, d_cols,
+                           (long long)n_cols, scale, d_acc + r0 * ld_acc, (long long)ld_acc);
+    }
     return lc::launched("k_scatter_axpy");
 }
 
