@@ -405,6 +405,79 @@ extern "C" int lc_col_normalize_f32(float* d_x, int64_t ld, int64_t n_rows, int6
     return lc::launched("k_col_normalize");
 }
 
+namespace {
+// The same statistics with the validation rows held in registers: one pass over Y instead of three.  A wave owns
+// whole 32-row blocks (b = ty, ty + CM_RG, ...; at most NBLK of them), so the values it loaded are the ones whose
+// block sums and row-quad copies it writes.  The float arithmetic per element is that of k_val_stats; only the order
+// of the fp64 sums behind mean and variance differs (by rounding of the last bit of a double).
+template <int NBLK>
+__global__ void __launch_bounds__(64 * CM_RG) k_val_stats_regs(const float* __restrict__ y, long long ldy, long long V,
+                                                               const int* __restrict__ va, int M, int n_val,
+                                                               float* __restrict__ ystat, float* __restrict__ yblk,
+                                                               float* __restrict__ yv) {
+    __shared__ double sm[CM_RG][64];
+    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = c < V;
+    const int nblocks = M / LC_MB;
+    float cache[NBLK][LC_MB];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+        const int b = ty + k * CM_RG;
+#pragma unroll
+        for (int r = 0; r < LC_MB; ++r) {
+            const int i = b * LC_MB + r;
+            cache[k][r] = (live && b < nblocks && i < n_val) ? y[(long long)va[i] * ldy + c] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k)
+#pragma unroll
+        for (int r = 0; r < LC_MB; ++r) s += (double)cache[k][r];          // padding entries are exact zeros
+    const double mean = block_colsum<CM_RG>(s, sm) / (double)n_val;
+    const float meanf = (float)mean;
+    double q = 0.0;
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+        const int b = ty + k * CM_RG;
+#pragma unroll
+        for (int r = 0; r < LC_MB; ++r)
+            if (b * LC_MB + r < n_val && b < nblocks) {
+                const double d = (double)cache[k][r] - mean;
+                q += d * d;
+            }
+    }
+    const double m2 = block_colsum<CM_RG>(q, sm);
+    if (live && ty == 0) {
+        const double var = m2 / (double)(n_val - 1);
+        ystat[c] = meanf;
+        ystat[V + c] = (float)sqrt(var);
+        ystat[2 * V + c] = (float)var;
+    }
+    if (live)
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k) {
+            const int b = ty + k * CM_RG;
+            if (b < nblocks) {
+                float t = 0.f;
+#pragma unroll
+                for (int r4 = 0; r4 < LC_MB; r4 += 4) {
+                    float4 quad;                             // row-quad interleaved layout, see lc_epilogue.h
+                    float* qv = reinterpret_cast<float*>(&quad);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        qv[j] = cache[k][r4 + j];
+                        if (b * LC_MB + r4 + j < n_val) t += qv[j] - meanf;
+                    }
+                    reinterpret_cast<float4*>(yv)[(long long)((b * LC_MB + r4) >> 2) * V + c] = quad;
+                }
+                yblk[(long long)b * V + c] = t;
+            }
+        }
+}
+}  // namespace
+
 extern "C" int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int M, int n_val,
                             float* d_ystat, float* d_yblk, float* d_yv, lc_stream_t stream) {
     LC_REQUIRE(d_y && d_va && d_ystat && d_yblk && d_yv, LC_E_BADARG, "lc_val_stats: null pointer");
@@ -412,8 +485,13 @@ extern "C" int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int3
                LC_MB);
     if (V <= 0) return LC_OK;
     lc::ScopedTimer timer_(lc::T_VAL_STATS, lc::as_stream(stream));
-    hipLaunchKernelGGL(k_val_stats, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, CM_RG), 0,
-                       lc::as_stream(stream), d_y, ldy, V, d_va, M, n_val, d_ystat, d_yblk, d_yv);
+    const dim3 grid((unsigned)lc::ceil_div<long long>(V, 64)), block(64, CM_RG);
+    if (M / LC_MB <= 2 * CM_RG)                              // up to 512 validation rows: held in registers, one pass
+        hipLaunchKernelGGL(k_val_stats_regs<2>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V, d_va,
+                           M, n_val, d_ystat, d_yblk, d_yv);
+    else
+        hipLaunchKernelGGL(k_val_stats, grid, block, 0, lc::as_stream(stream), d_y, ldy, V, d_va, M, n_val, d_ystat, d_yblk,
+                           d_yv);
     return lc::launched("k_val_stats");
 }
 
