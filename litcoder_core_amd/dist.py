@@ -17,6 +17,9 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 
+_COMM_STREAMS: dict = {}
+
+
 def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous block [lo, hi) of rank ``rank``; the first ``n % world`` ranks get one more."""
     base, extra = divmod(int(n_items), int(world))
@@ -44,7 +47,10 @@ class ShardContext:
         if self.device is not None and getattr(self.device, "type", None) == "cuda":
             import torch
             if self._comm is None:
-                self._comm = torch.cuda.Stream(device=self.device)
+                key = (self.device.type, self.device.index)
+                if key not in _COMM_STREAMS:        # one per device and process: a stream's first use costs milliseconds
+                    _COMM_STREAMS[key] = torch.cuda.Stream(device=self.device)
+                self._comm = _COMM_STREAMS[key]
             return torch.cuda.stream(self._comm)
         return contextlib.nullcontext()
 

@@ -62,6 +62,20 @@ class _FoldResult:
         self.sig = sig             # (reject mask, adjusted p) of the fold when the device made them (one GPU), else None
 
 
+_AUX_STREAMS: Dict[Any, Any] = {}
+
+
+def _aux_stream(dev):
+    """One auxiliary stream per device for the life of the process.  A fresh ``torch.cuda.Stream()`` per engine walks
+    through torch's pool of 32 streams, and the FIRST cross-stream wait on a stream that has never run anything blocks
+    the host for ~6 ms (its hardware queue is created there): every fit of a series paid that before its first fold
+    was queued."""
+    key = (dev.type, dev.index)
+    if key not in _AUX_STREAMS:
+        _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _AUX_STREAMS[key]
+
+
 class RidgeCVEngine:
     """Device-resident state of one fit: fp32 copies of X / Y (zero padded), the Gram matrix, and the
     per-fold pipeline.  ``Y`` holds only this rank's voxel block."""
@@ -105,7 +119,7 @@ class RidgeCVEngine:
         self.d_cho = torch.tensor(self.cho, dtype=torch.int32, device=self.dev)
         self.K = None if self.norm_x else ops.gram(self.dX, self.Ttot, self.p)
         self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
-        self.aux = torch.cuda.Stream(device=self.dev)
+        self.aux = _aux_stream(self.dev)
         # statistics tail on the device (lc_bh_fdr / lc_fisher_combine): BH-FDR is global over the voxels, so only
         # when this process holds all of them; the driver sets alpha_fdr
         self.device_stats = self.shard.world == 1
@@ -167,7 +181,7 @@ class RidgeCVEngine:
             bits = np.zeros(self.Ttot, dtype=np.uint32)
             for f, rows in enumerate(chunk):
                 bits[np.asarray(rows, dtype=np.int64)] |= np.uint32(1 << f)
-            member = torch.from_numpy(bits.view(np.int32)).to(self.dev)
+            member = ops.upload(bits.view(np.int32), self.dev)
             out.append(ops.lambda_max_masked(K, self.Ttot, member, len(chunk), self.steps))
         return torch.cat(out)
 
@@ -188,8 +202,11 @@ class RidgeCVEngine:
             tr_rows = np.asarray(tr_rows, dtype=np.int64)
             spans.append((len(sets), len(inner_rel)))
             sets += [tr_rows[np.asarray(a, dtype=np.int64)] for a, _ in inner_rel] + [tr_rows]
-        lm = self.lmax_systems(self.K, sets)
-        self.ready.record()                           # the auxiliary stream consumes these
+        # on the AUXILIARY stream, where every consumer of these values runs
+        self.ready.record()                           # X, Y, K resident
+        self.aux.wait_event(self.ready)
+        with torch.cuda.stream(self.aux):
+            lm = self.lmax_systems(self.K, sets)
         return [(lm[s:s + n], lm[s + n:s + n + 1]) for s, n in spans]
 
     # -------------------------------------------------------------- inner CV: hat matrices, then the sweeps

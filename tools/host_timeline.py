@@ -35,7 +35,8 @@ def wrap(obj, name, label=None):
 
 for n in ("fold_prepare", "fold_begin", "fold_select", "fold_finish", "fold_collect", "precompute_lmax", "weights"):
     wrap(ncv.RidgeCVEngine, n)
-for n in ("choose", "_refit_groups", "_refit_systems", "_sweeps", "_hat_matrices", "_refit_apply"):
+for n in ("choose", "_refit_groups", "_refit_systems", "_sweeps", "_hat_matrices", "_refit_apply", "_fold_data",
+          "_series_by_moments", "_shared_image", "begin_fit", "fold_choose", "fold_speculate"):
     wrap(ncv.RidgeCVEngine, n, "    . " + n)
 for n in ("fdrcorrection", "fisher_combine", "full_cv_metrics"):
     wrap(stats, n)
