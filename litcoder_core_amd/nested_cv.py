@@ -105,19 +105,20 @@ class RidgeCVEngine:
         self.precision = precision
         self.dX = self._resident(X_all, self.p_pad)
         self.dY = self._resident(Y_all, self.Vp)
-        self.d_alphas = torch.tensor(self.alphas, dtype=torch.float64, device=self.dev)
+        # the Gram matrix first: the host-side set-up below (polynomial coefficients, index tables) runs beside it
+        self.K = None if self.norm_x else ops.gram(self.dX, self.Ttot, self.p)
+        self.d_alphas = ops.upload(np.asarray(self.alphas, dtype=np.float64), self.dev)
         # alphas whose penalty dwarfs the spectrum take the polynomial form of the inverse (shared matrix powers,
         # minimax coefficients: series.py), the rest the batched Cholesky.  Needs normalpha (a^2 = alpha^2 lambda_max
         # makes the coefficients a function of alpha alone).
         self.ser = [a for a in range(self.A)
                     if self.normalpha and series.residual_bound(self.alphas[a], SERIES_TERMS) <= SERIES_TOL]
         self.cho = [a for a in range(self.A) if a not in self.ser]
-        self.d_ser = torch.tensor(self.ser, dtype=torch.int32, device=self.dev) if self.ser else None
+        self.d_ser = ops.upload(np.asarray(self.ser, dtype=np.int32), self.dev) if self.ser else None
         self.coef_host = (np.stack([series.minimax_inverse_coefficients(self.alphas[a], SERIES_TERMS)
                                     for a in self.ser]) if self.ser else None)
-        self.d_coef = torch.tensor(self.coef_host, dtype=torch.float64, device=self.dev) if self.ser else None
-        self.d_cho = torch.tensor(self.cho, dtype=torch.int32, device=self.dev)
-        self.K = None if self.norm_x else ops.gram(self.dX, self.Ttot, self.p)
+        self.d_coef = ops.upload(np.asarray(self.coef_host, dtype=np.float64), self.dev) if self.ser else None
+        self.d_cho = ops.upload(np.asarray(self.cho, dtype=np.int32), self.dev)
         self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
         self.aux = _aux_stream(self.dev)
         # statistics tail on the device (lc_bh_fdr / lc_fisher_combine): BH-FDR is global over the voxels, so only

@@ -16,6 +16,7 @@ maximum over [0, 1] is the classical Chebyshev one,
 five for 1.1e-9; the coefficients differ from the Taylor ones ((-1)^j alpha^-2(j+1)) only in their last digits.
 The ``P'_j`` do not depend on alpha: they are shared by every alpha of an inner fold.
 """
+import functools
 import math
 
 import numpy as np
@@ -31,6 +32,11 @@ def residual_bound(alpha: float, terms: int) -> float:
 
 def minimax_inverse_coefficients(alpha: float, terms: int) -> np.ndarray:
     """c_0 .. c_{terms-1} (float64) of the polynomial q minimising max_{x in [0,1]} |1 - (x + alpha^2) q(x)|."""
+    return np.array(_minimax_cached(float(alpha), int(terms)))
+
+
+@functools.lru_cache(maxsize=4096)
+def _minimax_cached(alpha: float, terms: int) -> tuple:
     a2 = float(alpha) ** 2
     t_poly = _C.cheb2poly([0.0] * terms + [1.0])            # T_d as a monomial polynomial in t
     px, powk, lin = np.zeros(1), np.ones(1), np.array([-1.0, 2.0])
@@ -43,4 +49,4 @@ def minimax_inverse_coefficients(alpha: float, terms: int) -> np.ndarray:
         raise ArithmeticError("minimax polynomial: (x + alpha^2) does not divide 1 - r(x)")
     out = np.zeros(terms, dtype=np.float64)
     out[: q.size] = q
-    return out
+    return tuple(out.tolist())
