@@ -254,10 +254,9 @@ class RidgeCVEngine:
         union = np.unique(np.concatenate(sets))
         if len(union) % 16 or (len(union) - N) % 16:
             return None
-        pos = {int(r): i for i, r in enumerate(union)}
         gaps = []
         for s_ in sets:
-            idx = np.fromiter((pos[int(r)] for r in s_), dtype=np.int64, count=N)
+            idx = np.searchsorted(union, s_)                 # position of every row in the (sorted) union
             if np.any(np.diff(idx) <= 0):
                 return None                                  # not in the union's order
             missing = np.setdiff1d(np.arange(len(union)), idx)
