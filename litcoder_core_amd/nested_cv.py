@@ -695,7 +695,6 @@ class RidgeCVEngine:
         Ws, pred = C[: self.p_pad], C[self.p_pad:self.p_pad + n_t]
         r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
-        ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
         # results leave through pinned buffers so the copies do not stall the host
         h_r = torch.empty(Vs, dtype=torch.float64, pin_memory=True)
         h_p = torch.empty(Vs, dtype=torch.float64, pin_memory=True)
@@ -725,6 +724,9 @@ class RidgeCVEngine:
         h_bad.copy_(bad, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
+        # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
+        # run beside this pass over the weight matrix)
+        ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
         return dict(done=done, r=h_r, p=h_p, perm=h_perm, best=h_best, n_t=n_t, bad=h_bad, rej=h_rej, padj=h_padj,
                     keep=(r_s, p_s, perm, best, bad))
 
