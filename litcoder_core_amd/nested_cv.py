@@ -547,36 +547,52 @@ class RidgeCVEngine:
                     M.add_(terms[j], alpha=float(c[j]))
         return Malpha, info
 
-    def _refit_apply(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split):
-        """C (rows, Vs) = [M_alpha ; H_te,alpha](group) . Ys -- the weights in its first p_pad rows, the test
-        predictions below -- and Ys (N_o + len(extra_rows), Vs): the targets gathered in alpha-sorted voxel
-        order (``extra_rows``, the test targets, below the training rows)."""
-        G, rows, n_o = Malpha.shape[0], Malpha.shape[1], len(tr_rows)
+    def _refit_operands(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split):
+        """Operands of the V-wide refit contraction: Ys (N_o + len(extra_rows), Vs), the targets gathered in
+        alpha-sorted voxel order (``extra_rows``, the test targets, below the training rows), and on the fp16x3 path
+        their tiled fp16 image with the column scales carried through the permutation."""
+        n_o = len(tr_rows)
         N_o = ops.pad_to(n_o, LC_NB)
         n_x = len(extra_rows)
         rows_s = ops.idx_tensor(np.concatenate([tr_rows, np.full(N_o - n_o, -1), np.asarray(extra_rows, dtype=np.int64)]),
                                 N_o + n_x, self.dev)
         Ys = torch.empty((N_o + n_x, Vs), dtype=torch.float32, device=self.dev)
         ops.gather(Y, self.Vp, rows_s, N_o + n_x, perm, Vs, Ys)
-        C = torch.empty((rows, Vs), dtype=torch.float32, device=self.dev)
+        o = dict(Ys=Ys, N_o=N_o, n_o=n_o, Vs=Vs, tiles=tiles, Malpha=Malpha, split=split)
         if split:
-            # on the fp16x3 MFMA path: split every group's rows, the sorted targets by columns (their scales
-            # follow the voxels through the permutation), one grouped launch
-            rows_pad = ops.pad_to(rows, 256)
-            At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
-            rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
-            for g in range(G):
-                ops.split_rows_f16(Malpha[g], rows, N_o, At[g * rows_pad * N_o * 2:], rs_inv[g * rows_pad:])
             cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)
             ops.gather(self._cs.reshape(2, self.Vp), self.Vp, None, 2, perm, Vs, cs_s)
             Yt = torch.empty(Vs * N_o * 2, dtype=torch.float16, device=self.dev)
             ops.split_cols_f16(Ys, Vs, torch.arange(N_o, dtype=torch.int32, device=self.dev), N_o, cs_s[0], Yt)
-            ops.gemm_grouped_f16x3(At, rs_inv, rows, Yt, cs_s[1], C, Vs, Vs, N_o, tiles)
-            LAST_SWEEP["plain_flops"] += 2.0 * (self.p + n_x) * n_o * self.V
+            o.update(cs_s=cs_s, Yt=Yt)
+        return o
+
+    def _refit_product(self, o, r0, r1, useful_rows):
+        """Rows [r0, r1) of  C = [M_alpha ; H_te,alpha](group) . Ys  as an (r1 - r0, Vs) f32 matrix (fp16x3 path: the
+        rows of every group split to fp16 triples, one grouped launch).  The caller takes the test predictions first
+        -- what the host statistics wait for -- and the weight rows afterwards."""
+        Malpha, Vs, N_o = o["Malpha"], o["Vs"], o["N_o"]
+        G, rows = Malpha.shape[0], r1 - r0
+        C = torch.empty((rows, Vs), dtype=torch.float32, device=self.dev)
+        if o["split"]:
+            rows_pad = ops.pad_to(rows, 256)
+            At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
+            rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
+            for g in range(G):
+                ops.split_rows_f16(Malpha[g, r0:r1], rows, N_o, At[g * rows_pad * N_o * 2:], rs_inv[g * rows_pad:])
+            ops.gemm_grouped_f16x3(At, rs_inv, rows, o["Yt"], o["cs_s"][1], C, Vs, Vs, N_o, o["tiles"])
+            LAST_SWEEP["plain_flops"] += 2.0 * useful_rows * o["n_o"] * self.V
             LAST_SWEEP["plain_launches"] += 1
         else:
-            ops.gemm_grouped(Malpha, N_o, rows * N_o, Ys, Vs, None, C, Vs, rows, Vs, N_o, tiles)
-        return C, Ys, N_o
+            ops.gemm_grouped(Malpha[:, r0:r1], N_o, Malpha.stride(0), o["Ys"], Vs, None, C, Vs, rows, Vs, N_o, o["tiles"])
+        return C
+
+    def _refit_apply(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split):
+        """C (rows, Vs) = [M_alpha ; H_te,alpha](group) . Ys -- the weights in its first p_pad rows, the test
+        predictions below -- together with Ys and N_o (see _refit_operands)."""
+        o = self._refit_operands(Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split)
+        C = self._refit_product(o, 0, Malpha.shape[1], self.p + len(extra_rows))
+        return C, o["Ys"], o["N_o"]
 
     def refit(self, X, Y, K, tr_rows, best, extra_rows=(), tr_o=None, lmax_o=None):
         """Weights of every voxel at its chosen alpha, in alpha-sorted voxel order
@@ -688,11 +704,13 @@ class RidgeCVEngine:
         n_t = len(te_rows)
         best, perm, Vs = st["best"], st["perm"], st["Vs"]
         torch.cuda.current_stream().wait_event(st["systems_ready"])
-        C, Ys, N_o = self._refit_apply(Y, tr_rows, te_rows, perm, st["tiles"], Vs, st["Malpha"], st["split"])
+        o = self._refit_operands(Y, tr_rows, te_rows, perm, st["tiles"], Vs, st["Malpha"], st["split"])
+        Ys, N_o = o["Ys"], o["N_o"]
         info_o = st["info_o"]
-        # ---- weights, test predictions (nested_cv.py:151,251: X_te W, here as the hat matrix of the test rows
-        # applied to the same targets) and per-voxel Pearson r (:152-155, 252-257)
-        Ws, pred = C[: self.p_pad], C[self.p_pad:self.p_pad + n_t]
+        # ---- test predictions first (nested_cv.py:151,251: X_te W, here as the hat matrix of the test rows applied
+        # to the same targets) and per-voxel Pearson r (:152-155, 252-257); the weight rows of the same contraction
+        # follow once the fold's results are on their way to the host
+        pred = self._refit_product(o, self.p_pad, st["Malpha"].shape[1], n_t)[:n_t]
         r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
         # results leave through pinned buffers so the copies do not stall the host
@@ -724,8 +742,10 @@ class RidgeCVEngine:
         h_bad.copy_(bad, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
+        self.results_ready = done
         # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
-        # run beside this pass over the weight matrix)
+        # run beside this part of the contraction)
+        Ws = self._refit_product(o, 0, self.p_pad, self.p)
         ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
         return dict(done=done, r=h_r, p=h_p, perm=h_perm, best=h_best, n_t=n_t, bad=h_bad, rej=h_rej, padj=h_padj,
                     keep=(r_s, p_s, perm, best, bad))
@@ -753,9 +773,14 @@ class RidgeCVEngine:
     def combined_significance(self):
         """Fisher's combination of the folds' p-values and its BH-FDR on the device (one GPU): (p_comb, reject,
         adjusted p) as host arrays."""
-        pcomb = ops.fisher_combine(torch.stack(self.p_folds))
-        rej, padj = ops.bh_fdr(pcomb, self.alpha_fdr)
-        return pcomb.cpu().numpy(), rej.cpu().numpy().astype(bool), padj.cpu().numpy()
+        # on the auxiliary stream (idle by now), behind the last fold's results: the main stream is still busy with
+        # the weight rows of that fold's refit, which nothing here depends on
+        self.aux.wait_event(self.results_ready)
+        with torch.cuda.stream(self.aux):
+            pcomb = ops.fisher_combine(torch.stack(self.p_folds))
+            rej, padj = ops.bh_fdr(pcomb, self.alpha_fdr)
+            out = pcomb.cpu().numpy(), rej.cpu().numpy().astype(bool), padj.cpu().numpy()
+        return out
 
     def run_fold(self, tr_rows, te_rows, inner_rel, single_alpha, weight_scale) -> _FoldResult:
         st = self.fold_begin(tr_rows, te_rows, inner_rel)
