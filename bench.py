@@ -192,6 +192,10 @@ def main():
                 traffic = tj.get(LAST_SWEEP["precision"], tj).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the fit's main stream leaves 32 of the 256 CUs to the auxiliary (fp64) stream: the kernel's launches are
+        # 256/224 longer than on the whole chip, `frac` stays priced against the whole chip
+        from litcoder_core_amd.nested_cv import _main_stream
+        cus_main = 224 if _main_stream() is not None else 256
         out = {
             "metric": "voxels/sec full nested-CV ridge fit (LeBel UTS03, GPT-2 768x4 delays, ~80k voxels)",
             "value": world * V * args.steps / elapsed, "unit": "voxels/sec", "n_gpus": world, "steps": args.steps,
@@ -212,6 +216,8 @@ def main():
                                  "tops out at 1.5-1.8 PFLOP/s" if split else None,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic,
+                         "cus_of_256_the_kernel_runs_on": cus_main,
+                         "frac_of_the_cus_it_runs_on": (achieved / (peak * cus_main / 256.0)) if achieved else None,
                          "algorithmic_tflops": alg_tflops, "mfma_per_product": mfma_per_product,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
                          "fused_alphas_per_launch": A_fused, "plain_launches_same_kernel": plain},

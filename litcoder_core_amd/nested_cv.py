@@ -76,6 +76,32 @@ def _aux_stream(dev):
     return _AUX_STREAMS[key]
 
 
+_MAIN_STREAMS: Dict[Any, Any] = {}
+
+
+def _main_stream():
+    """The stream the V-wide (MFMA) work of a fit runs on: restricted to CUs 0-223 of an MI355X, so that 32 CUs stay
+    free for the auxiliary stream's short fp64 kernels (diagonal tiles, panels: ~70 launches per Cholesky batch), which
+    otherwise each wait for a whole MFMA-sweep workgroup to retire before they find a slot.  Measured on the cfg2 fit
+    (profiles/experiments/README.md): 167-169 ms unrestricted, 162 ms with this mask; holding back 16 or 8 CUs 163 ms,
+    48-64 CUs no gain, and CU masks that cut through a group of 8 can be pathological (250 ms) -- hence one fixed,
+    measured mask, only on a device with 256 CUs.  LITCODER_AMD_CU_MASK=0 turns it off."""
+    import os
+    if os.environ.get("LITCODER_AMD_CU_MASK", "1") == "0":
+        return None
+    dev = ops.device()
+    key = (dev.type, dev.index)
+    if key not in _MAIN_STREAMS:
+        stream = None
+        try:
+            if torch.cuda.get_device_properties(dev).multi_processor_count == 256:
+                stream = ops.masked_stream([0xFFFFFFFF] * 7 + [0])
+        except Exception as exc:  # noqa: BLE001 -- an optimisation only: fall back to the caller's stream
+            logger.info("no CU-masked main stream (%s): the fit runs on the caller's stream", exc)
+        _MAIN_STREAMS[key] = stream
+    return _MAIN_STREAMS[key]
+
+
 class RidgeCVEngine:
     """Device-resident state of one fit: fp32 copies of X / Y (zero padded), the Gram matrix, and the
     per-fold pipeline.  ``Y`` holds only this rank's voxel block."""
@@ -890,9 +916,25 @@ class NestedCVModel(BasePredictivityModel):
                          opt["alphas"], opt["alpha_fdr"], opt["single_alpha"], opt["normalpha"], opt["use_corr"],
                          opt["normalize_features"], opt["normalize_targets"], weights_on_host=weights_on_host)
 
-    def _run(self, X_all, Y_all, T, n_test_rows, V_total, groups, folding_type, n_outer_folds, n_inner_folds,
-             chunk_length, alphas, alpha_fdr, single_alpha, normalpha, use_corr, normalize_features,
-             normalize_targets, weights_on_host):
+    def _run(self, *args, **kwargs):
+        """The fit on the process's MAIN stream of the device (see _main_stream), ordered after the caller's stream
+        at entry and before it at exit."""
+        ms = _main_stream() if torch.cuda.is_available() else None
+        if ms is None:
+            return self._run_on_current_stream(*args, **kwargs)
+        caller = torch.cuda.current_stream()
+        ms.wait_stream(caller)
+        with torch.cuda.stream(ms):
+            out = self._run_on_current_stream(*args, **kwargs)
+        caller.wait_stream(ms)
+        for x in out:
+            if isinstance(x, torch.Tensor) and x.is_cuda:
+                x.record_stream(caller)
+        return out
+
+    def _run_on_current_stream(self, X_all, Y_all, T, n_test_rows, V_total, groups, folding_type, n_outer_folds,
+                               n_inner_folds, chunk_length, alphas, alpha_fdr, single_alpha, normalpha, use_corr,
+                               normalize_features, normalize_targets, weights_on_host):
         shard = self.shard or ShardContext()
         train_test = n_test_rows > 0
         if train_test:
