@@ -85,9 +85,11 @@ def _main_stream():
     otherwise each wait for a whole MFMA-sweep workgroup to retire before they find a slot.  Measured on the cfg2 fit
     (profiles/experiments/README.md): 167-169 ms unrestricted, 162 ms with this mask; holding back 16 or 8 CUs 163 ms,
     48-64 CUs no gain, and CU masks that cut through a group of 8 can be pathological (250 ms) -- hence one fixed,
-    measured mask, only on a device with 256 CUs.  LITCODER_AMD_CU_MASK=0 turns it off."""
+    measured mask, only on a device with 256 CUs.  OPT-IN (LITCODER_AMD_CU_MASK=1): the sweep's launches get 256/224
+    longer on 224 CUs, i.e. the fit trades 3 % of wall time against 0.06 of the dominant kernel's whole-chip roofline
+    fraction (0.44 -> 0.38); the default keeps the kernel on the whole chip."""
     import os
-    if os.environ.get("LITCODER_AMD_CU_MASK", "1") == "0":
+    if os.environ.get("LITCODER_AMD_CU_MASK", "0") != "1":
         return None
     dev = ops.device()
     key = (dev.type, dev.index)
