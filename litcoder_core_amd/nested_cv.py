@@ -65,12 +65,12 @@ class _FoldResult:
 _AUX_STREAMS: Dict[Any, Any] = {}
 
 
-def _aux_stream(dev):
-    """One auxiliary stream per device for the life of the process.  A fresh ``torch.cuda.Stream()`` per engine walks
-    through torch's pool of 32 streams, and the FIRST cross-stream wait on a stream that has never run anything blocks
-    the host for ~6 ms (its hardware queue is created there): every fit of a series paid that before its first fold
-    was queued."""
-    key = (dev.type, dev.index)
+def _aux_stream(dev, which=0):
+    """The auxiliary streams of a device, created once for the life of the process.  A fresh ``torch.cuda.Stream()`` per
+    engine walks through torch's pool of 32 streams, and the FIRST cross-stream wait on a stream that has never run
+    anything blocks the host for ~6 ms (its hardware queue is created there): every fit of a series paid that before
+    its first fold was queued."""
+    key = (dev.type, dev.index, which)
     if key not in _AUX_STREAMS:
         _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _AUX_STREAMS[key]
@@ -149,6 +149,7 @@ class RidgeCVEngine:
         self.d_cho = ops.upload(np.asarray(self.cho, dtype=np.int32), self.dev)
         self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
         self.aux = _aux_stream(self.dev)
+        self.aux2 = _aux_stream(self.dev, 1)            # refit systems (see _refit_stream)
         # statistics tail on the device (lc_bh_fdr / lc_fisher_combine): BH-FDR is global over the voxels, so only
         # when this process holds all of them; the driver sets alpha_fdr
         self.device_stats = self.shard.world == 1
@@ -685,6 +686,19 @@ class RidgeCVEngine:
         st["info"] = st["hat"]["info"]
         return st
 
+    def _refit_stream(self, st):
+        """The refit systems run on a SECOND auxiliary stream, ordered behind the fold's prepare: their chain of short
+        fp64 launches then interleaves with the inner-fold chain of the fold after next on the first one -- each
+        launch waits for workgroup slots the MFMA sweeps own, and two chains wait in parallel (cfg2 fit 166.7 -> 161.2
+        ms, three interleaved pairs on one box)."""
+        s2 = self.aux2
+        if st.get("done") is not None:
+            s2.wait_event(st["done"])
+        for t in (st.get("X"), st.get("K"), st.get("tr_o"), st.get("lmax_o")):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(s2)                    # made on the first auxiliary stream (or at set-up), read here
+        return s2
+
     def fold_speculate(self, st, alphas_idx):
         """Solve the refit systems of a prepared fold for the listed alphas BEFORE its alpha choice is known, on the
         auxiliary stream (the driver passes the alphas the previous fold used: the histogram of the chosen alphas
@@ -693,7 +707,8 @@ class RidgeCVEngine:
         todo = [a for a in alphas_idx if a in self.cho] if st.get("tr_o") is not None else []
         if not todo:
             return
-        with torch.cuda.stream(self.aux):
+        rs = self._refit_stream(st)
+        with torch.cuda.stream(rs):
             rhs = self._refit_rhs(st["X"], st["K"], st["tr"], st["tr_o"], st["te"])
             Mc, info = self._refit_chol(st["K"], st["tr_o"], st["lmax_o"], rhs, todo)
         st["spec"] = dict(alphas=todo, M=Mc, info=info, rhs=rhs)
@@ -715,7 +730,7 @@ class RidgeCVEngine:
         best, split = st["best"], st["split"]
         perm, used, tiles, Vs = self._refit_groups(best, split, st.pop("grouping"))
         main = torch.cuda.current_stream()
-        with torch.cuda.stream(self.aux):                  # inputs: X, K, tr_o, lmax_o -- all made on aux or at start
+        with torch.cuda.stream(self._refit_stream(st)):    # inputs: X, K, tr_o, lmax_o -- all made on aux or at start
             Malpha, info_o = self._refit_systems(st["X"], st["K"], st["tr"], used, st.get("tr_o"), st.get("lmax_o"),
                                                  st["te"], spec=st.get("spec"))
             ready = torch.cuda.Event()
