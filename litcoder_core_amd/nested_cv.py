@@ -301,7 +301,7 @@ class RidgeCVEngine:
         (the R2 score needs the elementwise fl32 residual, see lc_epilogue.h)."""
         return self.normalpha and self.mode == LC_SCORE_CORR and self._use_split(Y)
 
-    def _hat_matrices(self, K, inner_abs, lmax=None, moments=False):
+    def _hat_matrices(self, K, inner_abs, lmax=None, moments=False, chol_after=None):
         """V-independent part of the inner CV of one outer fold: row lists, S[0]^2 (Lanczos), penalties and the
         hat matrices H_alpha of every (inner fold, alpha) -- batched Cholesky for the small alphas, the shared
         polynomial series for the large ones (as hat matrices, or with ``moments`` as the scaled matrix powers
@@ -361,6 +361,8 @@ class RidgeCVEngine:
             if series_ready is not None:
                 series_ready.record()           # the series operands of this chunk are complete; Cholesky follows
             if Ac:
+                if chol_after is not None:
+                    torch.cuda.current_stream().wait_event(chol_after)
                 aug = torch.empty((fc * Ac, N + M, N), dtype=torch.float64, device=self.dev)
                 a2c = a2[f0 * A:(f0 + fc) * A].reshape(fc, A).index_select(1, self.d_cho.to(torch.int64)).reshape(-1)
                 slot = None if moments else (
@@ -454,6 +456,8 @@ class RidgeCVEngine:
                                        self.mode, part, scores, accumulate=f > 0)
         if moments and Ad:
             scores.index_copy_(0, self.d_cho.to(torch.int64), scores_d)
+        self.sweeps_done = torch.cuda.Event()
+        self.sweeps_done.record()
         return scores
 
     def _alpha_scores(self, K, Y, inner_abs):
@@ -646,7 +650,7 @@ class RidgeCVEngine:
     # histogram; refit systems on aux) -> finish (main: V-wide refit, prediction, Pearson, D2H) -> collect (wait
     # for the fold's results).  The caller interleaves the phases of consecutive folds so that the main stream
     # always has MFMA work, the auxiliary stream the fp64 work, and the host statistics of fold f run meanwhile.
-    def fold_prepare(self, tr_rows, te_rows, inner_rel, lmax_pre=None):
+    def fold_prepare(self, tr_rows, te_rows, inner_rel, lmax_pre=None, chol_after=None):
         """Everything of an outer fold that does not touch the voxel axis beyond O(V) copies -- train-statistics
         normalisation, Lanczos, the batched Cholesky / series hat matrices -- enqueued on the engine's AUXILIARY
         stream, so that it overlaps the V-wide MFMA sweeps of the previous fold running on the main stream
@@ -669,7 +673,7 @@ class RidgeCVEngine:
                     lm = self.lmax_systems(K, [t for t, _ in inner_abs] + [tr_rows])
                     lmax_pre = (lm[:len(inner_abs)], lm[len(inner_abs):])
                 lmax_i, lmax_o = lmax_pre
-            hat = self._hat_matrices(K, inner_abs, lmax_i, self._series_by_moments(Y))
+            hat = self._hat_matrices(K, inner_abs, lmax_i, self._series_by_moments(Y), chol_after=chol_after)
             N_o = ops.pad_to(len(tr_rows), LC_NB)
             tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
             done = torch.cuda.Event()
@@ -708,6 +712,8 @@ class RidgeCVEngine:
         if not todo:
             return
         rs = self._refit_stream(st)
+        if getattr(self, "sweeps_done", None) is not None:
+            rs.wait_event(self.sweeps_done)            # like the inner-fold chain: not beside the sweeps just queued
         with torch.cuda.stream(rs):
             rhs = self._refit_rhs(st["X"], st["K"], st["tr"], st["tr_o"], st["te"])
             Mc, info = self._refit_chol(st["K"], st["tr_o"], st["lmax_o"], rhs, todo)
@@ -1010,7 +1016,11 @@ class NestedCVModel(BasePredictivityModel):
                 st_next = eng.fold_begin(*outer[i + 1], prepared=prepared)                    # main: sweeps of i+1
             st = eng.fold_select(st, single_alpha)          # host waits for the histogram of fold i here
             if i + 1 < n:
-                prepared = eng.fold_prepare(*outer[i + 2], lmax_pre=lmax_pre[i + 2]) if i + 2 < n else None
+                # the Cholesky chain of fold i+2 starts when the sweeps of fold i+1 (just queued) are done: it has
+                # until the fused pass of fold i+2, and the fused launches -- the dominant kernel -- of fold i+1
+                # then run without it (1.79 -> 1.62 ms per launch at the same fit time)
+                prepared = (eng.fold_prepare(*outer[i + 2], lmax_pre=lmax_pre[i + 2],
+                                             chol_after=getattr(eng, "sweeps_done", None)) if i + 2 < n else None)
                 if getattr(eng, "fold_speculate", None) is not None:
                     eng.fold_speculate(st_next, st["used"])                                   # aux: refit systems of i+1
             if pending is not None:

@@ -51,7 +51,7 @@ class OracleEngine:
         pass
     def precompute_lmax(self, outer):
         return [None] * len(outer)
-    def fold_prepare(self, tr, te, inner, lmax_pre=None):
+    def fold_prepare(self, tr, te, inner, lmax_pre=None, chol_after=None):
         return (tr, te, inner)
     def fold_begin(self, tr, te, inner, prepared=None):
         return (tr, te, inner)
