@@ -23,9 +23,8 @@ namespace {
 
 constexpr int NB = LC_NB;   // 64
 
-// Diagonal block k: L_kk = chol(A_kk) in LDS (2-D thread map, two barriers per column), then
-// Linv = inv(L_kk): lane c solves L x = e_c by a fully unrolled forward substitution with x in
-// registers (L entries are wave-uniform LDS broadcasts).  One block per system.
+// Diagonal block k: L_kk = chol(A_kk) in LDS, four columns per barrier pair, then Linv = inv(L_kk) by forward
+// substitution with four lanes per column (details at the two loops).  One workgroup per system.
 constexpr int PD_LD = NB + 1;
 
 // 1 / sqrt(d) for d > 0: hardware estimate + two Newton steps (full fp64 accuracy); sqrt(d) = d * rsqrt(d).
@@ -281,12 +280,12 @@ void launch_mm(const MMArgs& g, int B, hipStream_t s) {
                        dim3(256), 0, s, g);
 }
 
-// The same product on the vector ALU for the deep (outer-block) updates: 128 x 128 tile, 8 x 8 accumulators per
-// thread, two workgroups per CU.  On gfx950 v_fma_f64 out-runs the fp64 MFMA once a SIMD holds two waves
-// (tools/mfma_f64_rate.hip: 57 vs 45 TFLOP/s at two waves per SIMD, 34 for the MFMA at one), and an 8 x 8 register
-// tile needs only 8 ds_read_b128 per 64 FMAs.  Operands sit k-major in LDS ([k][128 + 2]); a thread owns rows
-// 32 i + 2 ty + {0, 1} and columns 32 j + 2 tx + {0, 1}, so the 16 lanes one LDS cycle serves read 256 contiguous
-// bytes (B) or two broadcast addresses (A).
+// The same product on the vector ALU (kept for comparison, lc_debug_chol_big_kernel(1); it served the deep updates
+// until the 4x4x4 MFMA below): 128 x 128 tile, 8 x 8 accumulators per thread, two workgroups per CU.  v_fma_f64
+// out-runs the 16x16x4 fp64 MFMA once a SIMD holds two waves (tools/mfma_f64_rate.hip: 57 vs 45 TFLOP/s), and an
+// 8 x 8 register tile needs only 8 ds_read_b128 per 64 FMAs.  Operands sit k-major in LDS ([k][128 + 2]); a thread
+// owns rows 32 i + 2 ty + {0, 1} and columns 32 j + 2 tx + {0, 1}, so the 16 lanes one LDS cycle serves read 256
+// contiguous bytes (B) or two broadcast addresses (A).
 constexpr int MV_TS = 128, MV_KC = 16, MV_LD = MV_TS + 2;
 
 template <bool BT>
