@@ -385,6 +385,27 @@ def test_speculative_refit_systems_are_neutral(lc):
         assert m["correlations"] == m0["correlations"] and m["p_values"] == m0["p_values"], name
 
 
+def test_cu_mask_option_is_neutral(lc, monkeypatch):
+    """LITCODER_AMD_CU_MASK=1 runs the fit on a main stream restricted to a CU subset (nested_cv._main_stream): a
+    scheduling option only -- results identical bit for bit; and the stream plumbing (caller's stream ordered before
+    and after the fit) leaves the weights usable on the caller's stream."""
+    from litcoder_core_amd import nested_cv as ncv
+    rng = np.random.default_rng(33)
+    T, p, V = 360, 24, 150
+    X = rng.standard_normal((T, p))
+    Y = X @ (rng.standard_normal((p, V)) * 0.3) + rng.standard_normal((T, V))
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 3, 5).tolist(),
+              single_alpha=False)
+    base = lc.NestedCVModel("ridge_regression").fit_predict(features=X, targets=Y, **kw)
+    monkeypatch.setenv("LITCODER_AMD_CU_MASK", "1")
+    ncv._MAIN_STREAMS.clear()
+    masked = lc.NestedCVModel("ridge_regression").fit_predict(features=X, targets=Y, **kw)
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert ncv._main_stream() is not None
+    assert np.array_equal(base[1], masked[1]) and np.array_equal(base[2], masked[2])
+    assert base[0]["correlations"] == masked[0]["correlations"]
+
+
 def test_refit_with_large_alphas_polynomial_route(lc):
     """Weights for voxels whose alpha lies on the polynomial series (no factorisation: shared powers of K on the
     f32 MFMA) next to voxels that need the Cholesky route, against the oracle's SVD-route ridge."""
