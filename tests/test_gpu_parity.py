@@ -431,7 +431,7 @@ def test_device_statistics_tail_matches_host(lc):
     from litcoder_core_amd import ops, stats
     dev = ops.device(0)
     rng = np.random.default_rng(31)
-    for n in (1, 7, 1000, 80000, 200001):
+    for n in (1, 7, 1000, 80000, 200001, 640000):
         p = rng.uniform(0, 1, n) ** rng.choice([1.0, 4.0, 12.0], size=n)        # many small ones
         p[rng.integers(0, n, size=max(1, n // 50))] = 1.0
         p[rng.integers(0, n, size=max(1, n // 97))] = p[0]                         # ties
@@ -448,6 +448,24 @@ def test_device_statistics_tail_matches_host(lc):
     want = stats.fisher_combine(P)
     assert got[10] == 1.0 and got[11] == 0.0 and want[11] == 0.0
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+    # the voxel-shard route: per-fold BH-FDR and the final Fisher + BH-FDR on p-values gathered from all ranks
+    from litcoder_core_amd.nested_cv import RidgeCVEngine
+    from litcoder_core_amd import ShardContext
+    eng = RidgeCVEngine(rng.standard_normal((64, 8)), rng.standard_normal((64, 16)), [1.0, 10.0], True, True, False, False,
+                        shard=ShardContext(device=dev))
+    eng.alpha_fdr = 0.05
+    folds = [rng.uniform(0, 1, 30000) ** 6 for _ in range(3)]
+    for pf in folds:
+        rej, adj = eng.gathered_significance(pf)
+        rej_h, adj_h = stats.fdrcorrection(pf, alpha=0.05)
+        np.testing.assert_array_equal(rej, rej_h)
+        np.testing.assert_array_equal(adj, adj_h)
+    pc, rej, adj = eng.gathered_combined()
+    pc_h = stats.fisher_combine(np.stack(folds))
+    np.testing.assert_allclose(pc, pc_h, rtol=1e-12, atol=0)
+    rej_h, adj_h = stats.fdrcorrection(pc, alpha=0.05)
+    np.testing.assert_array_equal(rej, rej_h)
+    np.testing.assert_array_equal(adj, adj_h)
 
 
 def test_fit_nested_cv_alias(lc):
