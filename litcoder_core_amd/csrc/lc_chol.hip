@@ -547,13 +547,7 @@ template <bool BT>
 void launch_big(const MMArgs& g, int B, hipStream_t s) {
     if (g.rows <= 0 || g.cols <= 0) return;
     const dim3 grid((unsigned)lc::ceil_div(g.cols, 128), (unsigned)lc::ceil_div(g.rows, 128), (unsigned)B);
-    if (g_big_kernel == 2) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mm64q<BT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      MQ_LDS_BYTES);
-            attr_done = true;
-        }
+    if (g_big_kernel == 2) {                         // LDS attribute: set (and checked) by lc_batch_chol_solve
         hipLaunchKernelGGL((k_mm64q<BT>), grid, dim3(256), MQ_LDS_BYTES, s, g);
     } else if (g_big_kernel == 1) {
         hipLaunchKernelGGL((k_mm64v<BT>), grid, dim3(256), 0, s, g);
@@ -593,6 +587,8 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
     LC_REQUIRE(B > 0 && B <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
                "lc_batch_chol_solve: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
     hipStream_t s = lc::as_stream(stream);
+    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_mm64q<true>), MQ_LDS_BYTES)) return rc;
+    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_mm64q<false>), MQ_LDS_BYTES)) return rc;
     lc::ScopedTimer timer_(lc::T_CHOL_SOLVE, s);
     LC_HIP(hipMemsetAsync(d_info, 0, sizeof(int32_t) * B, s));
     const int nb = N / NB;

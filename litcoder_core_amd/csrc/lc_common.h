@@ -35,6 +35,10 @@ inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 
 inline long long imin(long long a, long long b) { return a < b ? a : b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that needs more than the default 64 KB of LDS.  The
+// attribute is per DEVICE: set once per (kernel, current device), under a mutex, with the return code checked.
+int ensure_dynamic_lds(const void* kernel, int bytes);
+
 // Optional per-kernel-class timing with HIP events on the launch stream (lc_timing_enable).
 enum TimingSlot {
     T_SWEEP_GEMM = 0, T_SWEEP_FINALIZE, T_GROUPED_GEMM, T_CHOL_SOLVE, T_LAMBDA_MAX, T_GRAM, T_ASSEMBLE,

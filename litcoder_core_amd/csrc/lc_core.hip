@@ -2,6 +2,8 @@
 #include "lc_common.h"
 #include <cstring>
 #include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 namespace lc {
@@ -50,7 +52,21 @@ void timing_end(int slot, hipStream_t s) {
 }
 }  // namespace lc
 
-extern "C" int lc_version(void) { return 100; }
+namespace lc {
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    LC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({kernel, dev})) return LC_OK;
+    LC_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({kernel, dev});
+    return LC_OK;
+}
+}  // namespace lc
+
+extern "C" int lc_version(void) { return 101; }
 
 extern "C" int lc_timing_enable(int on) {
     std::lock_guard<std::mutex> lk(lc::g_mu);

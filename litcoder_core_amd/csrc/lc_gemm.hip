@@ -411,13 +411,7 @@ int check_gemm_shapes(const char* who, const void* a, long long lda, const void*
 
 template <bool SCORE, bool HAS_ROWS>
 int set_lds_attr() {
-    static thread_local bool done = false;
-    if (!done) {
-        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_f32<SCORE, HAS_ROWS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-        done = true;
-    }
-    return LC_OK;
+    return lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_f32<SCORE, HAS_ROWS>), GEMM_LDS_BYTES);
 }
 
 }  // namespace

@@ -577,12 +577,7 @@ extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rows
                LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: need M %% %d == 0, N %% %d == 0, 0 < n_val <= M", LC_MB, 2 * TK);
     LC_REQUIRE(V > 0 && V % 128 == 0, LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: V must be a multiple of 128");
     LC_REQUIRE(mode == LC_SCORE_CORR || mode == LC_SCORE_R2, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: bad mode");
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<true, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
-        attr_done = true;
-    }
+    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<true, false>), LDS16_BYTES)) return rc;
     hipStream_t s = lc::as_stream(stream);
     BView bv;
     if (int rc = make_bview("lc_alpha_sweep_scores_f16x3", N, b_rows, b_gap_begin, b_gap_rows, &bv)) return rc;
@@ -610,14 +605,9 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     LC_REQUIRE(G >= 1 && G <= MAX_GROUPS16, LC_E_SHAPE, "lc_gemm_grouped_f16x3: G must be in 1..%d", MAX_GROUPS16);
     LC_REQUIRE(Mrows > 0 && K > 0 && K % (2 * TK) == 0 && Ncols > 0 && Ncols % TN == 0 && ldc >= Ncols, LC_E_SHAPE,
                "lc_gemm_grouped_f16x3: need K %% %d == 0 and Ncols %% %d == 0", 2 * TK, TN);
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<false, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
-        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
-        attr_done = true;
-    }
+    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<false, false>), LDS16_BYTES)) return rc;
+    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true>), LDS16_BYTES))
+        return rc;
     const int Mtiles = (int)lc::ceil_div<long long>(Mrows, TM);
     const long long Ntiles = Ncols / TN;
     BView bv;

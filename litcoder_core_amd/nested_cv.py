@@ -44,6 +44,46 @@ LAST_SWEEP = {"precision": None,    # arithmetic the most recent alpha sweep ran
               "plain_flops": 0.0, "plain_launches": 0}   # ... and the algorithmic flops of the plain fp16x3 GEMMs
 
 
+SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singcutoff enters a prediction with weight
+                                    # S^2 / (S^2 + a^2) <= (singcutoff / a)^2: below 1e-6 it is invisible in fp32
+MAX_ALPHAS = 64                     # lc_group_by_alpha / the grouped GEMMs carry at most 64 alpha groups per launch
+MAX_INNER_FOLDS = 64                # the series chain runs the inner folds as column groups of one grouped launch
+
+
+def check_penalties(alphas, singcutoff, normalpha, n_inner_folds=None):
+    """Host-side validation of the penalty grid, before anything touches the device.
+
+    Deviation from the reference, stated where a caller meets it: the reference takes a thin SVD, DROPS singular
+    values <= ``singcutoff`` (ridge_utils.py:44-63) and shrinks the rest by S / (S^2 + a^2) (ridge_regression.py:56,
+    117), which is defined for alpha = 0 (pseudo-inverse).  Here (K + a^2 I) is factored by Cholesky: it needs
+    a^2 > 0, and it truncates nothing -- a direction the reference would drop contributes at most
+    (singcutoff / a)^2 to a prediction.  That is < 1e-6 (invisible in fp32) whenever singcutoff <= 1e-3 a_min, which
+    holds for every shipped caller (singcutoff 1e-10 / 1e-30, alphas >= 0.1); outside that range this raises instead
+    of silently returning something else.  With ``normalpha`` a = alpha S[0]: the bound is re-checked against the
+    measured S[0] of every training block (RidgeCVEngine._check_singcutoff)."""
+    al = np.asarray(list(alphas), dtype=np.float64).reshape(-1)
+    if al.size == 0:
+        raise ValueError("alphas is empty")
+    if al.size > MAX_ALPHAS:
+        raise ValueError(f"at most {MAX_ALPHAS} alphas per fit (got {al.size}): the alpha-grouped kernels carry "
+                         f"{MAX_ALPHAS} groups per launch")
+    if n_inner_folds is not None and int(n_inner_folds) > MAX_INNER_FOLDS:
+        raise ValueError(f"at most {MAX_INNER_FOLDS} inner folds per fit (got {n_inner_folds})")
+    if not np.all(np.isfinite(al)) or np.any(al <= 0):
+        raise ValueError(
+            "alphas must be finite and > 0: this implementation factors (X X' + a^2 I) by Cholesky and does not "
+            "reproduce the reference's alpha = 0 case (pseudo-inverse with singular values <= singcutoff dropped, "
+            "encoding/models/ridge_utils.py:44-63, ridge_regression.py:56,117)")
+    sc = float(singcutoff)
+    if not (sc >= 0) or not np.isfinite(sc):
+        raise ValueError("singcutoff must be a finite number >= 0")
+    if not normalpha and sc > SINGCUTOFF_REL * float(al.min()):
+        raise ValueError(
+            f"singcutoff={sc:g} is not negligible against the smallest penalty a={al.min():g} (need singcutoff <= "
+            f"{SINGCUTOFF_REL:g} a): the reference would drop singular values <= singcutoff "
+            "(encoding/models/ridge_utils.py:44-63), this implementation never truncates")
+
+
 class BasePredictivityModel:
     """``encoding/models/base.py:7-41``: the interface AbstractTrainer calls."""
 
@@ -109,7 +149,10 @@ class RidgeCVEngine:
     per-fold pipeline.  ``Y`` holds only this rank's voxel block."""
 
     def __init__(self, X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets,
-                 shard: Optional[ShardContext] = None, lanczos_steps: int = LANCZOS_STEPS, precision: str = "auto"):
+                 shard: Optional[ShardContext] = None, lanczos_steps: int = LANCZOS_STEPS, precision: str = "auto",
+                 singcutoff: float = 0.0):
+        check_penalties(alphas, singcutoff, normalpha)
+        self.singcutoff = float(singcutoff)
         self.dev = ops.device()
         self.shard = shard or ShardContext()
         if not isinstance(X_all, _DeviceShapes):
@@ -122,9 +165,9 @@ class RidgeCVEngine:
         self.Vp = ops.pad_to(max(self.V, 1), COL_TILE)
         self.alphas = [float(a) for a in alphas]
         self.A = len(self.alphas)
-        if any(not (a > 0) for a in self.alphas):
-            raise ValueError("alphas must be positive: the Gram/Cholesky route needs a^2 > 0")
         self.normalpha = bool(normalpha)
+        # normalpha: a = alpha S[0]; the truncation bound needs S[0] when singcutoff is not tiny against alpha alone
+        self._cut_pending = self.normalpha and self.singcutoff > 1e-6 * min(self.alphas)
         self.mode = LC_SCORE_CORR if use_corr else LC_SCORE_R2
         self.norm_x, self.norm_y = bool(normalize_features), bool(normalize_targets)
         self.steps = int(lanczos_steps)
@@ -156,6 +199,7 @@ class RidgeCVEngine:
         self.alpha_fdr = 0.05
         self.p_folds = []                              # per outer fold: NaN-free p-values, natural voxel order, device
         self.p_folds_all = []                          # voxel shards: the same for the gathered p-values of all ranks
+        self._base_scales = None                       # (cs, split) of the resident targets, see _target_scales
         self.ready = torch.cuda.Event()               # X, Y, K resident: the only thing the aux stream waits for
         self.ready.record()
 
@@ -183,24 +227,29 @@ class RidgeCVEngine:
             mean, std = ops.col_mean_std(self.dY, rows, len(tr_rows), self.V)
             Y = self.dY.clone()
             ops.col_normalize_(Y, self.Ttot, self.V, mean, std)
-            self._cs_key = None              # new target values: the fp16 column scales must be recomputed
-        return X, Y, K
+        cs, split = self._target_scales(Y)   # new target values have column scales of their own: per-fold state
+        return X, Y, K, cs, split
 
-    def _use_split(self, Y):
-        """Arithmetic of the alpha sweep for this target matrix.  "f16x3": fp16 hi + lo operands after an
-        exact power-of-two scale per H row / Y column, three fp16 MFMAs per product, fp32 accumulate
-        (22-bit operands: fp32-level scores, ~3x faster than the f32-input MFMA).  "auto" takes it unless a
-        target column is non-finite or dominated by outliers (most entries > 2^9 below the column maximum)."""
+    def _target_scales(self, Y):
+        """(cs, split) for one target matrix: ``split`` = the V-wide contractions run as "f16x3" -- fp16 hi + lo
+        operands after an exact power-of-two scale per H row / Y column, three fp16 MFMAs per product, fp32
+        accumulate (22-bit operands: fp32-level scores, ~3x faster than the f32-input MFMA) -- and ``cs`` the
+        (2 Vp,) column scales that go with it (2^-e, then 2^e).  "auto" takes the split unless a target column is
+        non-finite or dominated by outliers (most entries > 2^9 below the column maximum).  The scales belong to
+        the VALUES of ``Y``: with normalize_targets every outer fold has its own (fold state, never engine state:
+        folds are pipelined over streams); only those of the resident, un-normalised targets are cached."""
         if self.precision == "f32":
-            return False
-        key = Y.data_ptr()
-        if getattr(self, "_cs_key", None) != key:
-            self._cs, flag = ops.col_scales_f16(Y, self.Ttot, self.Vp)
-            self._cs_key = key
-            self._cs_wide = bool(int(flag.cpu()[0])) if self.precision == "auto" else False
-            if self._cs_wide:
-                logger.info("target dynamic range too wide for the fp16x3 sweep: using the f32 MFMA path")
-        return not self._cs_wide
+            return None, False
+        if Y is self.dY and self._base_scales is not None:
+            return self._base_scales
+        cs, flag = ops.col_scales_f16(Y, self.Ttot, self.Vp)
+        wide = bool(int(flag.cpu()[0])) if self.precision == "auto" else False
+        if wide:
+            logger.info("target dynamic range too wide for the fp16x3 sweep: using the f32 MFMA path")
+        out = (cs, not wide)
+        if Y is self.dY:
+            self._base_scales = out
+        return out
 
     # -------------------------------------------------------------- S[0]^2 of every train set (Lanczos)
     def lmax_systems(self, K, row_sets):
@@ -216,11 +265,24 @@ class RidgeCVEngine:
             out.append(ops.lambda_max_masked(K, self.Ttot, member, len(chunk), self.steps))
         return torch.cat(out)
 
+    def _check_singcutoff(self, lmax):
+        """normalpha: singcutoff against a_min = alpha_min S[0] with the measured S[0]^2 = lambda_max of the training
+        blocks (one host sync, only when singcutoff is not already negligible against alpha_min alone)."""
+        if not self._cut_pending or lmax is None:
+            return
+        s0 = float(torch.sqrt(lmax.min()).cpu())
+        a_min = min(self.alphas) * s0
+        if self.singcutoff > SINGCUTOFF_REL * a_min:
+            raise ValueError(
+                f"singcutoff={self.singcutoff:g} is not negligible against the smallest penalty a = alpha S[0] = "
+                f"{a_min:g} (need singcutoff <= {SINGCUTOFF_REL:g} a): the reference would drop singular values <= "
+                "singcutoff (encoding/models/ridge_utils.py:44-63), this implementation never truncates")
+
     def begin_fit(self):
         """Decide the arithmetic of the V-wide contractions now (column scales of the targets + the one flag that
         comes to the host), so that the first fold's set-up is enqueued without waiting on the device."""
         if not self.norm_y:
-            self._use_split(self.dY)
+            self._target_scales(self.dY)
 
     def precompute_lmax(self, outer):
         """(inner-fold lmax (F,), outer-train lmax (1,)) per outer fold from ONE Lanczos run over the shared Gram
@@ -238,6 +300,7 @@ class RidgeCVEngine:
         self.aux.wait_event(self.ready)
         with torch.cuda.stream(self.aux):
             lm = self.lmax_systems(self.K, sets)
+            self._check_singcutoff(lm)
         return [(lm[s:s + n], lm[s + n:s + n + 1]) for s, n in spans]
 
     # -------------------------------------------------------------- inner CV: hat matrices, then the sweeps
@@ -296,11 +359,11 @@ class RidgeCVEngine:
             gaps.append((int(missing[0]) if len(missing) else N, int(len(missing))))
         return union, gaps
 
-    def _series_by_moments(self, Y):
+    def _series_by_moments(self, split):
         """Score the series alphas from the moments of the shared terms T_j = P'_j Y (one contraction for all of
         them, lc_series_scores) instead of one hat matrix per alpha: correlation scoring on the fp16x3 path only
         (the R2 score needs the elementwise fl32 residual, see lc_epilogue.h)."""
-        return self.normalpha and self.mode == LC_SCORE_CORR and self._use_split(Y)
+        return bool(self.normalpha and self.mode == LC_SCORE_CORR and split)
 
     def _hat_matrices(self, K, inner_abs, lmax=None, moments=False, chol_after=None):
         """V-independent part of the inner CV of one outer fold: row lists, S[0]^2 (Lanczos), penalties and the
@@ -318,6 +381,7 @@ class RidgeCVEngine:
         va = torch.stack([ops.idx_tensor(v, M, self.dev) for _, v in inner_abs])
         if self.normalpha and lmax is None:
             lmax = self.lmax_systems(K, [t for t, _ in inner_abs])
+            self._check_singcutoff(lmax)
         a2 = ops.penalties(lmax, F, self.d_alphas, self.normalpha)
         ser, cho, d_ser = self.ser, self.cho, self.d_ser
         moments = bool(moments and ser and min(n_v) > 1)
@@ -391,7 +455,9 @@ class RidgeCVEngine:
         scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
         scores_d = torch.empty((Ad, self.Vp), dtype=torch.float32, device=self.dev) if moments and Ad else scores
         part = torch.empty((max(Ad, 1) * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
-        split = self._use_split(Y)
+        split, cs = hat["split"], hat["cs"]
+        if hat.get("data_ready") is not None:
+            main.wait_event(hat["data_ready"])            # this fold's (normalised) targets and their column scales
         LAST_SWEEP.update(precision="f16x3" if split else "f32", fused_alphas=Ad,
                           series_terms=SERIES_TERMS if moments else 0)
         nbuf = F if moments else 1                        # two passes over the folds keep every fold's operands
@@ -401,7 +467,6 @@ class RidgeCVEngine:
         shared = hat.get("shared") if split else None
         if split:
             rows_pad = ops.pad_to(max(Ad, 1) * M, 256)
-            cs = self._cs
             Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
             rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
             Vt = ops.pad_to(self.Vp, 256)
@@ -462,7 +527,9 @@ class RidgeCVEngine:
         return scores
 
     def _alpha_scores(self, K, Y, inner_abs):
-        hat = self._hat_matrices(K, inner_abs, moments=self._series_by_moments(Y))
+        cs, split = self._target_scales(Y)
+        hat = self._hat_matrices(K, inner_abs, moments=self._series_by_moments(split))
+        hat.update(cs=cs, split=split)
         return self._sweeps(hat, Y), hat["info"]
 
     # -------------------------------------------------------------- alpha selection
@@ -543,6 +610,7 @@ class RidgeCVEngine:
         if tr_o is None:
             tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
             lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
+            self._check_singcutoff(lmax_o)
         rhs = spec["rhs"] if spec is not None else self._refit_rhs(X, K, tr_rows, tr_o, te_rows)
         rows = rhs.shape[0]
         # alphas on the polynomial series (large penalties: what real recordings usually select) need no
@@ -581,7 +649,7 @@ class RidgeCVEngine:
                     M.add_(terms[j], alpha=float(c[j]))
         return Malpha, info
 
-    def _refit_operands(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split):
+    def _refit_operands(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs):
         """Operands of the V-wide refit contraction: Ys (N_o + len(extra_rows), Vs), the targets gathered in
         alpha-sorted voxel order (``extra_rows``, the test targets, below the training rows), and on the fp16x3 path
         their tiled fp16 image with the column scales carried through the permutation."""
@@ -595,7 +663,7 @@ class RidgeCVEngine:
         o = dict(Ys=Ys, N_o=N_o, n_o=n_o, Vs=Vs, tiles=tiles, Malpha=Malpha, split=split)
         if split:
             cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)
-            ops.gather(self._cs.reshape(2, self.Vp), self.Vp, None, 2, perm, Vs, cs_s)
+            ops.gather(cs.reshape(2, self.Vp), self.Vp, None, 2, perm, Vs, cs_s)
             Yt = torch.empty(Vs * N_o * 2, dtype=torch.float16, device=self.dev)
             ops.split_cols_f16(Ys, Vs, torch.arange(N_o, dtype=torch.int32, device=self.dev), N_o, cs_s[0], Yt)
             o.update(cs_s=cs_s, Yt=Yt)
@@ -621,10 +689,10 @@ class RidgeCVEngine:
             ops.gemm_grouped(Malpha[:, r0:r1], N_o, Malpha.stride(0), o["Ys"], Vs, None, C, Vs, rows, Vs, N_o, o["tiles"])
         return C
 
-    def _refit_apply(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split):
+    def _refit_apply(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs):
         """C (rows, Vs) = [M_alpha ; H_te,alpha](group) . Ys -- the weights in its first p_pad rows, the test
         predictions below -- together with Ys and N_o (see _refit_operands)."""
-        o = self._refit_operands(Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split)
+        o = self._refit_operands(Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs)
         C = self._refit_product(o, 0, Malpha.shape[1], self.p + len(extra_rows))
         return C, o["Ys"], o["N_o"]
 
@@ -632,10 +700,10 @@ class RidgeCVEngine:
         """Weights of every voxel at its chosen alpha, in alpha-sorted voxel order
         (ridge_regression.py:9-63), all on the current stream.  Returns (Ws (p_pad, Vs), Ys, perm, N_o, info):
         column j of Ws / Ys is voxel perm[j] (-1 = padding)."""
-        split = self._use_split(Y)
+        cs, split = self._target_scales(Y)
         perm, used, tiles, Vs = self._refit_groups(best, split)
         Malpha, info = self._refit_systems(X, K, tr_rows, used, tr_o, lmax_o)
-        Ws, Ys, N_o = self._refit_apply(Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split)
+        Ws, Ys, N_o = self._refit_apply(Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs)
         return Ws[: self.p_pad], Ys, perm, N_o, info
 
     def unsort(self, vec_sorted, perm, Vs):
@@ -665,25 +733,30 @@ class RidgeCVEngine:
         main = torch.cuda.current_stream()
         self.aux.wait_event(self.ready)                # inputs (X, Y, K) were produced on the main stream
         with torch.cuda.stream(self.aux):
-            X, Y, K = self._fold_data(tr_rows)
+            X, Y, K, cs, split = self._fold_data(tr_rows)
+            data_ready = torch.cuda.Event()
+            data_ready.record()
             # S[0]^2 of the inner train sets and of the whole outer-train block (refit penalty scale,
             # independent of the alpha choice): precomputed for the whole fit, or one run for this fold
             lmax_i = lmax_o = None
             if self.normalpha:
                 if lmax_pre is None:
                     lm = self.lmax_systems(K, [t for t, _ in inner_abs] + [tr_rows])
+                    self._check_singcutoff(lm)
                     lmax_pre = (lm[:len(inner_abs)], lm[len(inner_abs):])
                 lmax_i, lmax_o = lmax_pre
-            hat = self._hat_matrices(K, inner_abs, lmax_i, self._series_by_moments(Y), chol_after=chol_after)
+            hat = self._hat_matrices(K, inner_abs, lmax_i, self._series_by_moments(split), chol_after=chol_after)
+            hat.update(cs=cs, split=split, data_ready=data_ready)
             N_o = ops.pad_to(len(tr_rows), LC_NB)
             tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
             done = torch.cuda.Event()
             done.record()
-        for t in ([X, Y, K, hat["tr"], hat["va"], hat["info"], hat["a2"], hat["lmax"], hat["d_ser"], tr_o, lmax_o]
+        for t in ([X, Y, K, cs, hat["tr"], hat["va"], hat["info"], hat["a2"], hat["lmax"], hat["d_ser"], tr_o, lmax_o]
                   + [h for _, _, h, _ in hat["Hs"]] + [q for _, _, _, q in hat["Hs"]]):
             if t is not None and t.is_cuda:
                 t.record_stream(main)                  # allocated on aux, consumed on main
-        return dict(tr=tr_rows, te=te_rows, X=X, Y=Y, K=K, hat=hat, done=done, tr_o=tr_o, lmax_o=lmax_o)
+        return dict(tr=tr_rows, te=te_rows, X=X, Y=Y, K=K, cs=cs, split=split, hat=hat, done=done, tr_o=tr_o,
+                    lmax_o=lmax_o)
 
     def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None, lmax_pre=None):
         st = prepared if prepared is not None else self.fold_prepare(tr_rows, te_rows, inner_rel, lmax_pre)
@@ -725,7 +798,6 @@ class RidgeCVEngine:
         histogram travels to pinned memory asynchronously, so the caller can queue the next fold's sweeps on the
         main stream BEFORE waiting for it in fold_select (the stream then never idles through the host round trip)."""
         st["best"] = self.choose(st["scores"], single_alpha)
-        st["split"] = self._use_split(st["Y"])
         st["grouping"] = self._group_async(st["best"], st["split"])
         return st
 
@@ -754,7 +826,7 @@ class RidgeCVEngine:
         n_t = len(te_rows)
         best, perm, Vs = st["best"], st["perm"], st["Vs"]
         torch.cuda.current_stream().wait_event(st["systems_ready"])
-        o = self._refit_operands(Y, tr_rows, te_rows, perm, st["tiles"], Vs, st["Malpha"], st["split"])
+        o = self._refit_operands(Y, tr_rows, te_rows, perm, st["tiles"], Vs, st["Malpha"], st["split"], st["cs"])
         Ys, N_o = o["Ys"], o["N_o"]
         info_o = st["info_o"]
         # ---- test predictions first (nested_cv.py:151,251: X_te W, here as the hat matrix of the test rows applied
@@ -888,7 +960,7 @@ class NestedCVModel(BasePredictivityModel):
     def __init__(self, model_name: str, shard: Optional[ShardContext] = None, precision: str = "auto"):
         """``precision``: arithmetic of the V-wide alpha sweep -- "f32" (f32-input MFMA), "f16x3" (fp16
         hi/lo operands, three fp16 MFMAs per product, fp32 accumulate; fp32-level accuracy, ~3x faster) or
-        "auto" (f16x3 unless the targets' dynamic range is too wide for it; see RidgeCVEngine._use_split)."""
+        "auto" (f16x3 unless the targets' dynamic range is too wide for it; see RidgeCVEngine._target_scales)."""
         super().__init__(model_name)
         self.shard = shard
         self.precision = precision
@@ -916,8 +988,12 @@ class NestedCVModel(BasePredictivityModel):
     ) -> Tuple[Dict[str, Union[float, List[float], List[bool]]], np.ndarray, np.ndarray]:
         if alphas is None:
             alphas = np.logspace(-1, 8, 10)
+        check_penalties(alphas, singcutoff, normalpha, n_inner_folds)
         if not use_gpu:
             logger.info("use_gpu=False ignored: this implementation runs on the MI355X only")
+        features, targets = np.asarray(features), np.asarray(targets)   # lists / nested lists, like torch.tensor(...)
+        if X_test is not None and y_test is not None:
+            X_test, y_test = np.asarray(X_test), np.asarray(y_test)
         shard = self.shard or ShardContext()
         train_test = X_test is not None and y_test is not None
         V_total = np.shape(targets)[1]
@@ -933,7 +1009,7 @@ class NestedCVModel(BasePredictivityModel):
             X_all, Y_all = features, cols(targets)
         return self._run(X_all, Y_all, len(features), len(X_test) if train_test else 0, V_total, groups, folding_type,
                          n_outer_folds, n_inner_folds, chunk_length, alphas, alpha_fdr, single_alpha, normalpha,
-                         use_corr, normalize_features, normalize_targets, weights_on_host=True)
+                         use_corr, normalize_features, normalize_targets, weights_on_host=True, singcutoff=singcutoff)
 
     def fit_predict_device(self, features_dev: torch.Tensor, targets_dev: torch.Tensor, n_features: int,
                            n_voxels_local: int, n_voxels_total: Optional[int] = None, n_test_rows: int = 0,
@@ -945,19 +1021,21 @@ class NestedCVModel(BasePredictivityModel):
         (p, V_local) weights come back as a device tensor."""
         opt = dict(groups=None, folding_type="chunked", n_outer_folds=5, n_inner_folds=5, chunk_length=20, alphas=None,
                    alpha_fdr=0.05, single_alpha=False, normalpha=True, use_corr=True, normalize_features=False,
-                   normalize_targets=False)
-        unknown = set(kwargs) - set(opt) - {"use_gpu", "singcutoff"}
+                   normalize_targets=False, singcutoff=1e-10)
+        unknown = set(kwargs) - set(opt) - {"use_gpu"}
         if unknown:
             raise TypeError(f"unexpected keyword arguments: {sorted(unknown)}")
         opt.update({k: v for k, v in kwargs.items() if k in opt})
         if opt["alphas"] is None:
             opt["alphas"] = np.logspace(-1, 8, 10)
+        check_penalties(opt["alphas"], opt["singcutoff"], opt["normalpha"], opt["n_inner_folds"])
         T = features_dev.shape[0] - n_test_rows
         shapes = _DeviceShapes(features_dev, n_features), _DeviceShapes(targets_dev, n_voxels_local)
         return self._run(shapes[0], shapes[1], T, n_test_rows, n_voxels_total or n_voxels_local, opt["groups"],
                          opt["folding_type"], opt["n_outer_folds"], opt["n_inner_folds"], opt["chunk_length"],
                          opt["alphas"], opt["alpha_fdr"], opt["single_alpha"], opt["normalpha"], opt["use_corr"],
-                         opt["normalize_features"], opt["normalize_targets"], weights_on_host=weights_on_host)
+                         opt["normalize_features"], opt["normalize_targets"], weights_on_host=weights_on_host,
+                         singcutoff=opt["singcutoff"])
 
     def _run(self, *args, **kwargs):
         """The fit on the process's MAIN stream of the device (see _main_stream), ordered after the caller's stream
@@ -977,7 +1055,7 @@ class NestedCVModel(BasePredictivityModel):
 
     def _run_on_current_stream(self, X_all, Y_all, T, n_test_rows, V_total, groups, folding_type, n_outer_folds,
                                n_inner_folds, chunk_length, alphas, alpha_fdr, single_alpha, normalpha, use_corr,
-                               normalize_features, normalize_targets, weights_on_host):
+                               normalize_features, normalize_targets, weights_on_host, singcutoff=0.0):
         shard = self.shard or ShardContext()
         train_test = n_test_rows > 0
         if train_test:
@@ -998,7 +1076,7 @@ class NestedCVModel(BasePredictivityModel):
                 outer.append((tr, te, inner))
 
         eng = RidgeCVEngine(X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
-                            precision=self.precision)
+                            precision=self.precision, singcutoff=singcutoff)
         scale = 1.0 if train_test else 1.0 / len(outer)
         fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
         score_rows, p_rows, any_nan = [], [], []

@@ -4,8 +4,9 @@
 score of every alpha for every voxel.  ``ridge`` = ``ridge_torch`` (``:9-63``): weights with a
 per-voxel (or scalar) alpha.  Both take and return host arrays; the arithmetic is the same HIP
 pipeline ``NestedCVModel`` uses (Gram + batched Cholesky instead of the SVD, fused MFMA sweep).
-``singcutoff`` is accepted for signature compatibility: directions with singular value <= cutoff
-contribute at most cutoff/alpha^2 to the hat matrix and are not truncated here.
+``singcutoff``: nothing is truncated here; a direction with singular value <= cutoff enters a prediction
+with weight <= (cutoff / a)^2, and a value that is not negligible against the smallest penalty raises
+(``nested_cv.check_penalties``), as does alpha = 0.
 """
 from typing import Sequence, Union
 
@@ -22,7 +23,7 @@ def ridge_corr(Rstim, Pstim, Rresp, Presp, alphas: Sequence[float], singcutoff: 
     Rstim, Pstim = np.asarray(Rstim), np.asarray(Pstim)
     n_tr, n_va = len(Rstim), len(Pstim)
     eng = RidgeCVEngine(np.concatenate([Rstim, Pstim]), np.concatenate([np.asarray(Rresp), np.asarray(Presp)]),
-                        alphas, normalpha, use_corr, False, False)
+                        alphas, normalpha, use_corr, False, False, singcutoff=singcutoff)
     scores, info = eng._alpha_scores(eng.K, eng.dY, [(np.arange(n_tr), n_tr + np.arange(n_va))])
     if int(info.cpu().numpy().any()):
         raise RuntimeError("Cholesky failed: Gram matrix + alpha^2 I is not positive definite")
@@ -36,7 +37,7 @@ def ridge(Rstim, Rresp, alphas: Union[float, Sequence[float]], singcutoff: float
     V = Rresp.shape[1]
     per_voxel = np.full(V, float(alphas)) if np.isscalar(alphas) else np.asarray(alphas, dtype=np.float64)
     grid, idx = np.unique(per_voxel, return_inverse=True)
-    eng = RidgeCVEngine(Rstim, Rresp, grid, normalpha, True, False, False)
+    eng = RidgeCVEngine(Rstim, Rresp, grid, normalpha, True, False, False, singcutoff=singcutoff)
     best = torch.zeros(eng.Vp, dtype=torch.int32, device=eng.dev)
     best[:V] = torch.from_numpy(idx.astype(np.int32)).to(eng.dev)
     Ws, _, perm, _, info = eng.refit(eng.dX, eng.dY, eng.K, np.arange(len(Rstim)), best)

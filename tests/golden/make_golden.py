@@ -172,6 +172,40 @@ def gen_ridge():
     save("ridge.npz", **out)
 
 
+# ---------------------------------------------------------------- singcutoff on a rank-deficient design
+def gen_singcutoff():
+    """ridge_corr_torch / ridge_torch / a full fit of the reference on a design of rank 25 < p = 40 (so the thin SVD
+    carries 15 noise-level singular values) for singcutoff in {1e-30, 1e-10, 1e-6}: where the truncation
+    (ridge_utils.py:44-63) acts, and how little it moves the result at the penalties the callers use."""
+    import torch
+    rng = np.random.default_rng(51)
+    T, r, p, V = 150, 25, 40, 32
+    X = rng.standard_normal((T, r)) @ rng.standard_normal((r, p)) / np.sqrt(r)
+    Y = X @ (rng.standard_normal((p, V)) * 0.3) + rng.standard_normal((T, V))
+    alphas = np.logspace(-1, 3, 5)
+    Xt, Yt = torch.tensor(X, dtype=torch.float32), torch.tensor(Y, dtype=torch.float32)
+    tr, va = np.r_[0:80, 110:150], np.r_[80:110]
+    out = {"X": X, "Y": Y, "alphas": alphas, "tr": tr, "va": va, "cutoffs": np.array([1e-30, 1e-10, 1e-6])}
+    S = torch.linalg.svd(Xt[tr], full_matrices=False)[1].numpy()
+    out["singular_values"] = S
+    model = ref.nested_cv.NestedCVModel("ridge_regression")
+    for i, sc in enumerate(out["cutoffs"]):
+        sc = float(sc)
+        out[f"kept_{i}"] = np.array(int((S > sc).sum()))
+        for na in (True, False):
+            out[f"scores_{i}_norm{int(na)}"] = ref.ridge_regression.ridge_corr_torch(
+                Xt[tr], Xt[va], Yt[tr], Yt[va], alphas, singcutoff=sc, use_corr=True, normalpha=na).numpy()
+            out[f"W_{i}_norm{int(na)}"] = ref.ridge_regression.ridge_torch(
+                Xt[tr], Yt[tr], 3.0, singcutoff=sc, normalpha=na).numpy()
+        random.seed(7)
+        np.random.seed(7)
+        m, W, best = quiet(model.fit_predict, X, Y, alphas=alphas, use_gpu=False, folding_type="kfold",
+                           n_outer_folds=3, n_inner_folds=3, singcutoff=sc)
+        out[f"fit_{i}_W"], out[f"fit_{i}_alphas"] = W, best
+        out[f"fit_{i}_correlations"] = np.asarray(m["correlations"])
+    save("singcutoff.npz", **out)
+
+
 # ---------------------------------------------------------------- full fits
 def flatten_metrics(m):
     flat = {}
@@ -307,3 +341,4 @@ if __name__ == "__main__":
     gen_ridge()
     gen_fits()
     gen_harness()
+    gen_singcutoff()

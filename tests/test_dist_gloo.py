@@ -23,7 +23,7 @@ import oracle.ridge as oridge
 
 class OracleEngine:
     """Same interface as RidgeCVEngine.run_fold/weights, arithmetic by the CPU oracle."""
-    def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard, precision="auto"):
+    def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard, precision="auto", singcutoff=0.0):
         self.X, self.Y = torch.tensor(np.asarray(X), dtype=torch.float32), torch.tensor(np.asarray(Y), dtype=torch.float32)
         self.alphas, self.normalpha, self.use_corr, self.shard = list(alphas), normalpha, use_corr, shard
         self.V = self.Y.shape[1]

@@ -161,6 +161,30 @@ def test_ridge_solvers_golden(lc, golden_dir):
         np.testing.assert_allclose(got, g[f"{tag}_W_scalar"], rtol=1e-4, atol=2e-5)
 
 
+def test_singcutoff_boundary_on_rank_deficient_design(lc, golden_dir):
+    """Rank-25 design with p = 40 (15 singular values at fp32 noise level, ~1e-6): the reference's results for
+    singcutoff 1e-30 / 1e-10 (nothing dropped) and 1e-6 (7 directions dropped, ridge_utils.py:44-63) against this
+    implementation, which never truncates -- scores, weights and a full fit.  A singcutoff large enough to act
+    (here 1.0 against a_min = 0.1 S[0] ~ 2.6) raises instead of returning something else."""
+    from litcoder_core_amd import ridge
+    g = load(golden_dir, "singcutoff.npz")
+    X, Y, tr, va, alphas = g["X"], g["Y"], g["tr"], g["va"], g["alphas"]
+    for i, sc in enumerate(g["cutoffs"]):
+        for na in (1, 0):
+            got = ridge.ridge_corr(X[tr], X[va], Y[tr], Y[va], alphas, float(sc), True, bool(na))
+            np.testing.assert_allclose(got, g[f"scores_{i}_norm{na}"], rtol=1e-4, atol=2e-5, err_msg=f"cut {sc} norm{na}")
+            got = ridge.ridge(X[tr], Y[tr], 3.0, float(sc), bool(na))
+            np.testing.assert_allclose(got, g[f"W_{i}_norm{na}"], rtol=1e-4, atol=2e-5, err_msg=f"cut {sc} norm{na}")
+        m, W, a = lc.NestedCVModel("r").fit_predict(X, Y, alphas=alphas, folding_type="kfold", n_outer_folds=3,
+                                                    n_inner_folds=3, singcutoff=float(sc))
+        np.testing.assert_allclose(a, g[f"fit_{i}_alphas"], rtol=1e-6)
+        np.testing.assert_allclose(np.asarray(m["correlations"], dtype=np.float64), g[f"fit_{i}_correlations"], atol=2e-5)
+        np.testing.assert_allclose(W, g[f"fit_{i}_W"], rtol=1e-4, atol=2e-5)
+    with pytest.raises(ValueError, match="singcutoff=1 is not negligible against the smallest penalty a = alpha S"):
+        lc.NestedCVModel("r").fit_predict(X, Y, alphas=alphas, folding_type="kfold", n_outer_folds=3, n_inner_folds=3,
+                                          singcutoff=1.0)
+
+
 # ------------------------------------------------------------------ full fits vs the reference
 def _run_case(lc, g, spec, name):
     s = spec[name]

@@ -40,6 +40,29 @@ def test_no_gpu_means_loud_failure():
         lc.NestedCVModel("r").fit_predict(np.zeros((40, 3)), np.zeros((40, 2)), folding_type="kfold")
 
 
+def test_penalty_grid_validation_names_the_deviation():
+    """alpha = 0 and a singcutoff that would act are where this implementation (Cholesky of K + a^2 I, no truncation)
+    leaves the reference (ridge_utils.py:44-63, ridge_regression.py:56,117): both raise before the device is touched,
+    with a message that says so; every shipped caller's values pass."""
+    from litcoder_core_amd.nested_cv import check_penalties
+    check_penalties(np.logspace(-1, 8, 20), 1e-10, True, 5)              # example.py / train_simple.py / unified.py
+    check_penalties([0.1, 1.0], 1e-30, False)                             # ridge_corr_torch's own default
+    check_penalties([1.0], 1e-3, False)                                   # (1e-3 / 1)^2 = 1e-6: still invisible in fp32
+    model = lc.NestedCVModel("r")
+    X, Y = np.zeros((40, 3)), np.zeros((40, 2))
+    for bad in ([0.0, 1.0], [-1.0], [np.nan], [np.inf]):
+        with pytest.raises(ValueError, match=r"alpha = 0 case .*ridge_utils\.py:44-63"):
+            model.fit_predict(X, Y, alphas=bad, folding_type="kfold")
+    with pytest.raises(ValueError, match=r"singcutoff=0\.01 is not negligible .*ridge_utils\.py:44-63"):
+        model.fit_predict(X, Y, alphas=[1.0, 10.0], normalpha=False, singcutoff=1e-2, folding_type="kfold")
+    with pytest.raises(ValueError, match="at most 64 alphas"):
+        model.fit_predict(X, Y, alphas=np.logspace(-1, 8, 65), folding_type="kfold")
+    with pytest.raises(ValueError, match="at most 64 inner folds"):
+        model.fit_predict(X, Y, alphas=[1.0], n_inner_folds=65, folding_type="kfold")
+    with pytest.raises(ValueError):
+        check_penalties([], 1e-10, True)
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "litcoder_core_amd")
     for fn in os.listdir(pkg):

@@ -88,6 +88,28 @@ def test_ridge_solvers(golden_dir):
         np.testing.assert_allclose(got, g[f"{tag}_W_scalar"], rtol=0, atol=1e-6)
 
 
+def test_singcutoff_on_rank_deficient_design(golden_dir):
+    """The oracle truncates like the reference (ridge_utils.py:44-63): scores / weights / a full fit of the reference
+    on a rank-25 design with p = 40 for singcutoff 1e-30, 1e-10 (nothing dropped) and 1e-6 (7 of the 15 noise-level
+    singular values dropped)."""
+    g = load(golden_dir, "singcutoff.npz")
+    X, Y = torch.tensor(g["X"], dtype=torch.float32), torch.tensor(g["Y"], dtype=torch.float32)
+    tr, va, alphas = g["tr"], g["va"], g["alphas"]
+    assert [int(g[f"kept_{i}"]) for i in range(3)] == [40, 40, 33]
+    for i, sc in enumerate(g["cutoffs"]):
+        assert ridge.thin_svd(X[tr], float(sc))[1].numel() == int(g[f"kept_{i}"])
+        for na in (1, 0):
+            got = ridge.alpha_sweep_scores(X[tr], X[va], Y[tr], Y[va], alphas, float(sc), True, bool(na)).numpy()
+            np.testing.assert_allclose(got, g[f"scores_{i}_norm{na}"], rtol=0, atol=1e-6)
+            got = ridge.ridge_weights(X[tr], Y[tr], 3.0, float(sc), bool(na)).numpy()
+            np.testing.assert_allclose(got, g[f"W_{i}_norm{na}"], rtol=0, atol=1e-6)
+        m, W, a = nested_cv.fit_predict(g["X"], g["Y"], alphas=alphas, folding_type="kfold", n_outer_folds=3,
+                                        n_inner_folds=3, singcutoff=float(sc))
+        np.testing.assert_allclose(a, g[f"fit_{i}_alphas"], rtol=1e-6)
+        np.testing.assert_allclose(W, g[f"fit_{i}_W"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(np.asarray(m["correlations"]), g[f"fit_{i}_correlations"], rtol=0, atol=2e-6)
+
+
 def _check_fit(g, spec, name):
     s = spec[name]
     X, Y = g[f"X_{s['data']}"], g[f"Y_{s['data']}"]
