@@ -7,8 +7,16 @@ per-voxel alpha, normalpha, correlation scoring.  One "step" = one complete fit 
 alpha sweeps, 5 refits, test scoring, host statistics) with the fp32 inputs already resident in HBM
 and the weights left resident; `value` = voxels of all ranks x steps / max-over-ranks wall time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--voxels V] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--voxels V] [--scaling weak|strong] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Scaling: "weak" (default) = every rank fits `--voxels` voxels; "strong" = `--voxels` voxels IN TOTAL,
+split over the ranks (north_star's 80 000-voxel job on 1/2/4/8 GPUs).  At N > 1 the line carries both:
+the headline `value` in the chosen mode and the other mode under `other_scaling`.
+
+Extra legs in the same JSON line (N = 1): `host_path` = the SURVEY 8d metric proper, float64 numpy
+arrays in -> metrics + host float32 weights out (H2D / D2H inside the timed region; never `value`);
+`f32_path` = the same device-resident fit with the exact-fp32 MFMA sweep (precision="f32").
 
 Prints ONE JSON line on rank 0.  The `roofline` object is for the dominant kernel, the fp16x3 MFMA
 contraction k_sweep_f16x3, in its fused-score launches (the alphas that go through the batched
@@ -99,13 +107,77 @@ def cpu_baseline(dX, dY, p, V_full, alphas, v_sample=2000):
     }
 
 
+def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, collect_kernels=False):
+    """`warmup` untimed + `steps` timed device-resident fits, barrier + synchronize on both sides, MAX over ranks.
+    Returns (seconds, last metrics, kernel timing dict or None, plain-GEMM flops counted during the timed steps)."""
+    from litcoder_core_amd import ops
+    from litcoder_core_amd.nested_cv import LAST_SWEEP
+
+    def step():
+        return model.fit_predict_device(dX, dY, p, V, n_voxels_total=None if world == 1 else V_total,
+                                        alphas=alphas, **FIT_KW)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    metrics = None
+    for _ in range(warmup):
+        metrics, _, _ = step()
+    if collect_kernels:
+        ops.timing_enable(True)
+        ops.timing_read()
+    flops0 = LAST_SWEEP["plain_flops"]
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        metrics, _, _ = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern = None
+    if collect_kernels:
+        kern = ops.timing_read()
+        ops.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, metrics, kern, LAST_SWEEP["plain_flops"] - flops0
+
+
+def host_path_leg(dX, dY, p, V, alphas, steps=2):
+    """SURVEY 8d's metric as written: float64 numpy arrays in (features 73.7 MB, targets 1.92 GB), metrics dict +
+    float32 host weights + alphas out, through the reference's own entry point NestedCVModel.fit_predict."""
+    from litcoder_core_amd import NestedCVModel
+    X = dX[:, :p].cpu().numpy().astype(np.float64)
+    Y = dY[:, :V].cpu().numpy().astype(np.float64)
+    model = NestedCVModel("ridge_regression")
+    model.fit_predict(X, Y, alphas=alphas, **FIT_KW)                      # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m, W, a = model.fit_predict(X, Y, alphas=alphas, **FIT_KW)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert isinstance(W, np.ndarray) and W.shape == (p, V) and W.dtype == np.float32
+    return {"value": V / dt, "unit": "voxels/sec", "ms_per_step": 1e3 * dt, "steps": steps,
+            "what": "float64 numpy features/targets in (pageable host memory) -> metrics + float32 host weights out; "
+                    "H2D of 1.99 GB, on-device cast to fp32, D2H of 0.98 GB of weights inside the timed region",
+            "median_score": m["median_score"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--voxels", type=int, default=80000, help="voxels per GPU (weak scaling)")
+    ap.add_argument("--voxels", type=int, default=80000,
+                    help="voxels per GPU (weak scaling) / voxels in total (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip host_path / f32_path / other_scaling")
     ap.add_argument("--precision", default="auto", choices=["auto", "f32", "f16x3"],
                     help="arithmetic of the alpha sweep (auto = f16x3 unless the targets' dynamic range forbids it)")
     args = ap.parse_args()
@@ -121,108 +193,112 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from litcoder_core_amd import NestedCVModel, ShardContext, ops
+    from litcoder_core_amd.dist import shard_bounds
     dev = ops.device(local)
-    V = args.voxels
     alphas = np.logspace(-1, 8, A)
-    dX, dY, p = synth_inputs(V, rank, dev)
     shard = ShardContext(device=dev) if world > 1 else None
     model = NestedCVModel("ridge_regression", shard=shard, precision=args.precision)
 
-    def step():
-        # every rank passes its own V-voxel block; the gather at the end of the fit spans V*world voxels
-        return model.fit_predict_device(dX, dY, p, V, n_voxels_total=None if world == 1 else V * world,
-                                        alphas=alphas, **FIT_KW)
+    def inputs(mode):
+        """(dX, dY, p, V_local, V_total) of this rank: weak = `--voxels` each; strong = its block of `--voxels`."""
+        if mode == "weak" or world == 1:
+            dX, dY, p = synth_inputs(args.voxels, rank, dev)
+            return dX, dY, p, args.voxels, args.voxels * world
+        lo, hi = shard_bounds(args.voxels, world, rank)
+        dX, dY, p = synth_inputs(hi - lo, rank, dev)
+        return dX, dY, p, hi - lo, args.voxels
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    metrics = None
-    for _ in range(args.warmup):
-        metrics, _, _ = step()
-    ops.timing_enable(True)
-    ops.timing_read()
-    from litcoder_core_amd.nested_cv import LAST_SWEEP as _ls
-    plain_flops0 = _ls["plain_flops"]
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        metrics, _, _ = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kern = ops.timing_read()
-    ops.timing_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    dX, dY, p, V, V_total = inputs(args.scaling)
+    elapsed, metrics, kern, plain_flops = timed_fits(model, dX, dY, p, V, V_total, alphas, args.steps, args.warmup,
+                                                     world, dev, collect_kernels=True)
+    from litcoder_core_amd.nested_cv import LAST_SWEEP
+    sweep = dict(LAST_SWEEP)
+    other = None
+    if world > 1 and not args.no_extra_legs:
+        mode2 = "strong" if args.scaling == "weak" else "weak"
+        del dX, dY
+        torch.cuda.empty_cache()
+        dX, dY, p, V2, V2_total = inputs(mode2)
+        e2, m2, _, _ = timed_fits(model, dX, dY, p, V2, V2_total, alphas, args.steps, args.warmup, world, dev)
+        other = {"scaling": mode2, "value": V2_total * args.steps / e2, "unit": "voxels/sec",
+                 "ms_per_step": 1e3 * e2 / args.steps, "voxels_total": V2_total, "median_score": m2["median_score"]}
 
     if rank == 0:
         n_o = T - T // N_OUTER
         n_v = n_o // N_INNER
         n_i = n_o - n_v
-        from litcoder_core_amd.nested_cv import LAST_SWEEP
-        split = LAST_SWEEP["precision"] == "f16x3"
-        A_fused = LAST_SWEEP.get("fused_alphas", A)           # alphas scored inside the fused launch
+        split = sweep["precision"] == "f16x3"
+        A_fused = sweep.get("fused_alphas", A)               # alphas scored inside the fused launch
         flops_per_launch = 2.0 * A_fused * n_v * n_i * V      # algorithmic: those alphas of one inner fold
         ms, launches = kern.get("alpha_sweep_gemm", (0.0, 0))
         avg_ms = ms / max(launches, 1)
         alg_tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None
-        # f16x3: every algorithmic product is three fp16 MFMAs (hi*hi + hi*lo + lo*hi); the MFMA roofline
-        # is priced on the MFMA flops the kernel executes, the algorithmic rate is reported beside it.
+        # f16x3: every algorithmic product is three fp16 MFMAs (hi*hi + hi*lo + lo*hi).  `achieved` / `frac` are
+        # ALGORITHMIC (what the caller's GEMM needs); the MFMA flops the kernel issues are reported beside them.
         mfma_per_product = 3 if split else 1
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        achieved = alg_tflops * mfma_per_product if alg_tflops else None
+        issued = alg_tflops * mfma_per_product if alg_tflops else None
         plain_ms, plain_n = kern.get("grouped_gemm", (0.0, 0))
         plain = None
         if split and plain_n:
-            pf = LAST_SWEEP["plain_flops"] - plain_flops0
             plain = {"launches": plain_n, "ms_per_step": plain_ms / args.steps,
-                     "algorithmic_tflops": pf / (plain_ms * 1e-3) / 1e12,
-                     "mfma_tflops": 3 * pf / (plain_ms * 1e-3) / 1e12,
-                     "what": f"{LAST_SWEEP.get('series_terms', 0)} shared series terms x 25 inner folds + 5 refits "
+                     "algorithmic_tflops": plain_flops / (plain_ms * 1e-3) / 1e12,
+                     "mfma_tflops": 3 * plain_flops / (plain_ms * 1e-3) / 1e12,
+                     "what": f"{sweep.get('series_terms', 0)} shared series terms x 25 inner folds + 5 refits "
                              "(weights and test predictions) per step; includes the f32 MFMA launches of that slot"}
-        traffic = None
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "alpha_sweep_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(LAST_SWEEP["precision"], tj).get("hbm_bytes_per_launch")
+                traffic = tj.get(sweep["precision"], tj).get("hbm_bytes_per_launch")
+                traffic_src = ("profiles/alpha_sweep_traffic.json (static: FETCH_SIZE x2 + WRITE_SIZE per launch from "
+                               "separate rocprofv3 --pmc passes of this command; not measured in this run)")
             except Exception:
                 traffic = None
-        # the fit's main stream leaves 32 of the 256 CUs to the auxiliary (fp64) stream: the kernel's launches are
-        # 256/224 longer than on the whole chip, `frac` stays priced against the whole chip
         from litcoder_core_amd.nested_cv import _main_stream
         cus_main = 224 if _main_stream() is not None else 256
         out = {
             "metric": "voxels/sec full nested-CV ridge fit (LeBel UTS03, GPT-2 768x4 delays, ~80k voxels)",
-            "value": world * V * args.steps / elapsed, "unit": "voxels/sec", "n_gpus": world, "steps": args.steps,
+            "value": V_total * args.steps / elapsed, "unit": "voxels/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f16x3+f32acc (fp16 hi+lo operands, fp32 accumulate; Gram/Cholesky in f64)" if split
                      else "f32 (Gram/Cholesky in f64)", "data": "synthetic",
-            "config": {"workload": f"cfg2 synthetic T={T} F={F0}x{len(DELAYS)} delays (p={p}) V={V}/GPU "
-                                   f"A={A} alphas {N_OUTER}x{N_INNER} kfold, per-voxel alpha, normalpha, corr",
-                       "voxels_per_gpu": V, "inputs": "fp32 resident in HBM; weights left resident; "
-                                                      "per-voxel scores/alphas/p-values on host",
+            "config": {"workload": f"cfg2 synthetic T={T} F={F0}x{len(DELAYS)} delays (p={p}) "
+                                   + (f"V={args.voxels}/GPU" if args.scaling == "weak" else f"V={args.voxels} in total")
+                                   + f" A={A} alphas {N_OUTER}x{N_INNER} kfold, per-voxel alpha, normalpha, corr",
+                       "voxels_total": V_total, "voxels_rank0": V,
+                       "inputs": "fp32 resident in HBM; weights left resident; per-voxel scores/alphas/p-values on host",
                        "parallelism": f"voxel-shard x{world}", "median_score": metrics["median_score"]},
             "roofline": {"bound": "mfma",
                          "kernel": "k_sweep_f16x3 (fused alpha sweep, 3 fp16 MFMAs per product)" if split
                                    else "k_gemm_f32<score> (fused alpha sweep, f32-input MFMA)",
-                         "note": "peak = dense fp16 MFMA datasheet figure at 2.4 GHz; under this kernel the chip holds "
-                                 "1.4-1.8 GHz (in-kernel s_memtime/s_memrealtime, profiles/), where the same MFMA stream "
-                                 "tops out at 1.5-1.8 PFLOP/s" if split else None,
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (achieved / peak) if achieved else None, "traffic": traffic,
+                         "note": ("achieved/frac = ALGORITHMIC flops of the caller's contraction; the kernel issues "
+                                  "mfma_per_product fp16 MFMAs per product (mfma_issue_tflops / mfma_issue_frac).  peak = "
+                                  "dense fp16 MFMA datasheet figure at 2.4 GHz; under this kernel the chip holds 1.4-1.8 "
+                                  "GHz (in-kernel s_memtime/s_memrealtime, profiles/)") if split else None,
+                         "achieved": alg_tflops, "peak": peak, "unit": "TFLOP/s",
+                         "frac": (alg_tflops / peak) if alg_tflops else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "mfma_per_product": mfma_per_product, "mfma_issue_tflops": issued,
+                         "mfma_issue_frac": (issued / peak) if issued else None,
+                         "frac_vs_f32_mfma_peak": (alg_tflops / PEAK_F32_MFMA_TFLOPS) if alg_tflops else None,
                          "cus_of_256_the_kernel_runs_on": cus_main,
-                         "frac_of_the_cus_it_runs_on": (achieved / (peak * cus_main / 256.0)) if achieved else None,
-                         "algorithmic_tflops": alg_tflops, "mfma_per_product": mfma_per_product,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
                          "fused_alphas_per_launch": A_fused, "plain_launches_same_kernel": plain},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(kern.items())},
         }
+        if other is not None:
+            out["other_scaling"] = other
+        if world == 1 and not args.no_extra_legs:
+            if args.precision != "f32":
+                m32 = NestedCVModel("ridge_regression", precision="f32")
+                e32, mm, _, _ = timed_fits(m32, dX, dY, p, V, V_total, alphas, 2, 1, 1, dev)
+                out["f32_path"] = {"value": V * 2 / e32, "unit": "voxels/sec", "ms_per_step": 1e3 * e32 / 2, "steps": 2,
+                                   "dtype": "f32 (f32-input MFMA sweep and refit; Gram/Cholesky in f64)",
+                                   "median_score": mm["median_score"]}
+            out["host_path"] = host_path_leg(dX, dY, p, V, alphas)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dX, dY, p, V, alphas)
         print(json.dumps(out), flush=True)

@@ -181,6 +181,13 @@ int lc_batch_assemble(const double* d_k, int64_t ldk, const int32_t* d_tr, const
                       const double* d_rhs, const double* d_a2, int F, int A, int N, int M,
                       double* d_aug, lc_stream_t stream);
 
+/* The same for a SUBSET of that grid (voxel shards: the (fold, alpha) systems are dealt out over the ranks, each
+ * solves its share and the f32 results are all-gathered): system j of the batch is grid system s = d_sys[j]
+ * (int32, B entries), built from fold s / A and penalty d_a2[s].  d_aug: (B, N+M, N). */
+int lc_batch_assemble_sel(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
+                          const double* d_rhs, const double* d_a2, const int32_t* d_sys, int B, int A,
+                          int N, int M, double* d_aug, lc_stream_t stream);
+
 /* In place on every (N+M, N) system: Cholesky of the top block, then bottom <- bottom * inv(top)
  * i.e. the hat matrices  Xva Xtr' (Xtr Xtr' + a^2 I)^-1  (= Pstim Vh' diag(S/(S^2+a^2)) U',
  * ridge_regression.py:104-105,117-120).  Result written as f32 to d_h (B, M, N).
@@ -334,6 +341,27 @@ int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t
  * across ranks by the host).  Either output may be NULL. */
 int lc_select_alpha(const float* d_scores, int A, int64_t V, int32_t* d_best, double* d_rowsum,
                     lc_stream_t stream);
+
+/* single_alpha (nested_cv.py:396-403): best[v] = first argmax_a rowsum[a] for every v -- `rowsum` being the per-alpha
+ * score sums after the all-reduce over the voxel shards, so the choice never visits the host. */
+int lc_fill_argmax(const double* d_rowsum, int A, int32_t* d_best, int64_t V, lc_stream_t stream);
+
+/* One fold's per-voxel results of this rank as ONE (4, ld) f64 block in natural voxel order, the unit of the
+ * all-gather over voxel shards (SURVEY 8e "single gather"; nested_cv.py:152-158, 252-263 are its consumers):
+ *   row 0: Pearson r (alpha-sorted d_r_sorted[j] belongs to voxel d_perm[j]; -1 = padding), NaN kept
+ *   row 1: p-value, raw          row 2: chosen alpha index (d_best, natural order)
+ *   row 3: [any(d_info_a != 0), any(d_info_b != 0), 0 ...]  -- Cholesky pivot flags (inner folds, refit)
+ * Columns >= V are zero. */
+int lc_fold_pack(const double* d_r_sorted, const double* d_p_sorted, const int32_t* d_perm, int64_t Vs,
+                 const int32_t* d_best, int64_t V, const int32_t* d_info_a, int n_a,
+                 const int32_t* d_info_b, int n_b, double* d_out, int64_t ld, lc_stream_t stream);
+
+/* The gathered blocks of all ranks (world, 4, ld) -> V_total-long vectors: rank k's columns [0, lo[k+1]-lo[k])
+ * land at [lo[k], lo[k+1]) (d_lo: world+1 int64 on the device; w_max = widest shard).  d_p_clean = p with
+ * NaN-r voxels set to 1 (nested_cv.py:436), the input of the BH-FDR; d_bad (2 int32) = OR of the ranks' flags. */
+int lc_fold_unpack(const double* d_src, int world, int64_t ld, const int64_t* d_lo, int64_t w_max,
+                   double* d_r, double* d_p, int32_t* d_idx, double* d_p_clean, int32_t* d_bad,
+                   lc_stream_t stream);
 
 /* Counting sort of voxels by alpha index (torch.unique / nonzero grouping,
  * ridge_regression.py:46-50): d_perm = voxel ids grouped by alpha, stable, each group starting

@@ -48,6 +48,10 @@ SIGNATURES = {
     "lc_lambda_max_masked": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_penalties": (c_int, [_ptr, c_int, _ptr, c_int, c_int, _ptr, _ptr]),
     "lc_batch_assemble": (c_int, [_ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
+    "lc_batch_assemble_sel": (c_int, [_ptr, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
+    "lc_fill_argmax": (c_int, [_ptr, c_int, _ptr, c_int64, _ptr]),
+    "lc_fold_pack": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr, c_int, _ptr, c_int, _ptr, c_int64, _ptr]),
+    "lc_fold_unpack": (c_int, [_ptr, c_int, c_int64, _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_chol_outer_block": (c_int, [c_int]),
     "lc_debug_chol_big_kernel": (c_int, [c_int]),
     "lc_batch_chol_solve": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),

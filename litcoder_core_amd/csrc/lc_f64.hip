@@ -351,16 +351,18 @@ __global__ void k_penalties(const double* __restrict__ lmax, int F, const double
 // ------------------------------------------------------------------ batch assembly
 __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ Kmat, long long ldk,
                                                   const int* __restrict__ tr, const int* __restrict__ va,
-                                                  const double* __restrict__ rhs, const double* __restrict__ a2, int A,
+                                                  const double* __restrict__ rhs, const double* __restrict__ a2,
+                                                  const int* __restrict__ sys, int A,
                                                   int N, int M, double* __restrict__ aug) {
     const int i = blockIdx.x;             // row of the (N+M) x N system
-    const int b = blockIdx.y;
-    const int f = b / A;
+    const int b = blockIdx.y;             // system of the batch being built ...
+    const int sg = sys ? sys[b] : b;      // ... which is system sg = f * A + a of the full (fold, alpha) grid
+    const int f = sg / A;
     const int* trf = tr + (long long)f * N;
     double* dst = aug + ((long long)b * (N + M) + i) * N;
     if (i < N) {
         const int r = trf[i];
-        const double diag = r >= 0 ? a2[b] : 1.0;
+        const double diag = r >= 0 ? a2[sg] : 1.0;
         for (int j = threadIdx.x; j < N; j += 256) {
             const int c = trf[j];
             double v = (r >= 0 && c >= 0) ? Kmat[(long long)r * ldk + c] : 0.0;
@@ -554,7 +556,19 @@ extern "C" int lc_batch_assemble(const double* d_k, int64_t ldk, const int32_t* 
                "lc_batch_assemble: need N %% %d == 0, M %% %d == 0, F*A <= 65535", LC_NB, LC_MB);
     lc::ScopedTimer timer_(lc::T_ASSEMBLE, lc::as_stream(stream));
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)(N + M), (unsigned)(F * A)), dim3(256), 0, lc::as_stream(stream), d_k,
-                       (long long)ldk, d_tr, d_va, d_rhs, d_a2, A, N, M, d_aug);
+                       (long long)ldk, d_tr, d_va, d_rhs, d_a2, (const int*)nullptr, A, N, M, d_aug);
+    return lc::launched("k_assemble");
+}
+
+extern "C" int lc_batch_assemble_sel(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
+                                     const double* d_rhs, const double* d_a2, const int32_t* d_sys, int B, int A, int N,
+                                     int M, double* d_aug, lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_tr && d_a2 && d_sys && d_aug && (d_va || d_rhs), LC_E_BADARG, "lc_batch_assemble_sel: null pointer");
+    LC_REQUIRE(B > 0 && B <= 65535 && A > 0 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
+               "lc_batch_assemble_sel: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
+    lc::ScopedTimer timer_(lc::T_ASSEMBLE, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)(N + M), (unsigned)B), dim3(256), 0, lc::as_stream(stream), d_k,
+                       (long long)ldk, d_tr, d_va, d_rhs, d_a2, d_sys, A, N, M, d_aug);
     return lc::launched("k_assemble");
 }
 

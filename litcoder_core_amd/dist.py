@@ -1,23 +1,31 @@
 """Voxel sharding across the GPUs of a node: one process per GPU, torch.distributed.
 
-The fit is independent per voxel (column of ``targets``) given the replicated design-matrix
-algebra, so each rank fits a contiguous block of voxel columns and the data path needs no
-collective.  Two small exchanges remain:
+The fit is independent per voxel (column of ``targets``) given the design-matrix algebra
+(``encoding/models/ridge_regression.py:104-125``, ``nested_cv.py:396-411``), so each rank fits a contiguous block
+of voxel columns and the V-wide data path needs no collective.  What the ranks exchange:
 
-  * ``single_alpha=True`` (nested_cv.py:396-400): the per-alpha score sums over voxels are
-    all-reduced (A doubles, once per outer fold);
-  * the per-voxel result vectors (correlations, chosen alpha index; a few floats per voxel)
-    are all-gathered once at the end so that the global statistics (FDR, medians) see every
-    voxel.
+  * the V-INDEPENDENT fp64 operators.  Every (fold, alpha) Cholesky system -- hat matrices of the inner folds,
+    weight/prediction operators of the refit -- is needed by every rank but depends on no voxel: the systems are dealt
+    out over the ranks (``RidgeCVEngine._sharded_solve``), each rank solves its share, and the f32 results are
+    all-gathered (<= 74 MB per outer fold for the hat matrices at cfg2; one direct hop over xGMI).  Without this
+    every rank repeats ~60 ms of fp64 work per fit and 8 GPUs cannot be more than ~2x faster than one;
+  * ``single_alpha=True`` (nested_cv.py:396-400): the per-alpha score sums over voxels, all-reduced on the device
+    (A doubles, once per outer fold); the histogram of the chosen alphas (A ints) the same way, so that all ranks
+    solve the same refit systems;
+  * one packed (4, V_local) block of per-voxel results per fold (r, p, alpha index, pivot flags;
+    ``lc_fold_pack`` / ``lc_fold_unpack``), all-gathered so that the global statistics (BH-FDR ranks ALL p-values)
+    see every voxel.
 
-Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+All of these take and return DEVICE tensors.  Backend "nccl" is RCCL over xGMI on ROCm and moves them directly;
+under "gloo" (the CPU tests, and the two-ranks-on-one-GPU parity test) the same calls stage through the host.
+``ShardContext.simulated`` runs one rank of a W-rank job alone (collectives become local copies): the results are
+meaningless, the per-rank timeline is what an W-GPU run would see minus the wire time -- used by
+``tools/scaling_model.py`` on the single-GPU box.
 """
-from typing import List, Optional, Tuple
+from typing import Tuple
 
 import numpy as np
 
-
-_COMM_STREAMS: dict = {}
 
 
 def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
@@ -27,70 +35,123 @@ def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def job_share(n_jobs: int, world: int, rank: int) -> Tuple[int, range]:
+    """How ``n_jobs`` independent systems are dealt out: contiguous chunks of n_per = ceil(n_jobs / world); returns
+    (n_per, the jobs of ``rank``).  Slot j of the all-gathered result (world * n_per slots) is job j."""
+    n_per = -(-int(n_jobs) // int(world))
+    return n_per, range(min(n_jobs, rank * n_per), min(n_jobs, (rank + 1) * n_per))
+
+
 class ShardContext:
     """Wraps a torch.distributed process group (or nothing, for a single process)."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, always_collective=False):
+        """``always_collective``: issue the backend's collectives even in a one-rank group (they are no-ops
+        arithmetically) -- lets a single GPU exercise the RCCL calls of the sharded path."""
         import torch.distributed as dist
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.group = group
         self.device = device
         self.rank = self._dist.get_rank(group) if self._dist else 0
         self.world = self._dist.get_world_size(group) if self._dist else 1
-        self._comm = None
+        self.backend = str(self._dist.get_backend(group)) if self._dist else None
+        self.simulate = False
+        self.always = bool(always_collective) and self._dist is not None
 
-    def _comm_scope(self):
-        """The exchanges carry host data (per-voxel result vectors, score sums): on a GPU they run on a stream of
-        their own, so that neither the staging copies nor the collective queue behind the fit's kernels already
-        enqueued on the compute streams."""
-        import contextlib
-        if self.device is not None and getattr(self.device, "type", None) == "cuda":
-            import torch
-            if self._comm is None:
-                key = (self.device.type, self.device.index)
-                if key not in _COMM_STREAMS:        # one per device and process: a stream's first use costs milliseconds
-                    _COMM_STREAMS[key] = torch.cuda.Stream(device=self.device)
-                self._comm = _COMM_STREAMS[key]
-            return torch.cuda.stream(self._comm)
-        return contextlib.nullcontext()
+    @classmethod
+    def simulated(cls, world: int, rank: int, device=None):
+        """One rank of a ``world``-rank job without peers: every collective is a local copy of this rank's own
+        contribution into all slots.  Timing studies only."""
+        ctx = cls(device=device)
+        ctx._dist, ctx.rank, ctx.world, ctx.backend, ctx.simulate = None, int(rank), int(world), "simulated", True
+        return ctx
 
+    @property
+    def active(self) -> bool:
+        """Collectives are issued (more than one rank, or a one-rank group with ``always_collective``)."""
+        return self.world > 1 or self.always
+
+    # ------------------------------------------------------------------ partition
     def bounds(self, n_items: int) -> Tuple[int, int]:
         return shard_bounds(n_items, self.world, self.rank)
 
-    def _tensor(self, arr):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(arr))
-        return t.to(self.device) if self.device is not None else t
+    def all_bounds(self, n_items: int) -> np.ndarray:
+        """(world + 1,) int64 offsets of every rank's block."""
+        return np.asarray([shard_bounds(n_items, self.world, r)[0] for r in range(self.world)] + [int(n_items)],
+                          dtype=np.int64)
 
+    # ------------------------------------------------------------------ device-tensor collectives
+    def _direct(self, t) -> bool:
+        """True when the backend moves ``t`` where it lives (RCCL for device tensors, gloo for host tensors)."""
+        return (self.backend == "nccl") == bool(t.is_cuda)
+
+    def all_gather(self, t):
+        """(world, *t.shape): every rank's ``t`` (same shape and dtype everywhere), on ``t``'s device, ordered on the
+        current stream.  One rank: a view, no copy."""
+        import torch
+        if not self.active:
+            return t.unsqueeze(0)
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if self.simulate:
+            out.copy_(t.unsqueeze(0).expand_as(out))
+            return out
+        t = t.contiguous()
+        if self._direct(t):
+            self._dist.all_gather_into_tensor(out.view(-1), t.view(-1), group=self.group)     # flat: rank-major blocks
+            return out
+        # staging: gloo given device tensors (the tests) or RCCL given host tensors
+        h = t.cpu() if t.is_cuda else t.to(self.device)
+        parts = torch.empty((self.world,) + tuple(h.shape), dtype=h.dtype, device=h.device)
+        self._dist.all_gather_into_tensor(parts.view(-1), h.contiguous().view(-1), group=self.group)
+        out.copy_(parts)
+        return out
+
+    def all_reduce_(self, t, op: str = "sum"):
+        """In-place element-wise sum / max over ranks of a small device tensor, ordered on the current stream."""
+        if not self.active or self.simulate:
+            return t
+        rop = self._dist.ReduceOp.SUM if op == "sum" else self._dist.ReduceOp.MAX
+        if self._direct(t):
+            self._dist.all_reduce(t, op=rop, group=self.group)
+            return t
+        h = t.cpu() if t.is_cuda else t.to(self.device)
+        self._dist.all_reduce(h, op=rop, group=self.group)
+        t.copy_(h)
+        return t
+
+    # ------------------------------------------------------------------ host-array helpers (small vectors)
     def allreduce_sum(self, arr: np.ndarray) -> np.ndarray:
-        """Element-wise sum over ranks of a small float64 vector."""
-        if self.world == 1:
-            return np.asarray(arr, dtype=np.float64)
-        with self._comm_scope():
-            t = self._tensor(np.asarray(arr, dtype=np.float64))
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
-            return t.cpu().numpy()
+        """Element-wise sum over ranks of a small float64 host vector."""
+        import torch
+        arr = np.asarray(arr, dtype=np.float64)
+        if self.world == 1 or self.simulate:
+            return arr
+        t = torch.from_numpy(np.ascontiguousarray(arr).copy())
+        if self.backend == "nccl":
+            t = t.to(self.device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
 
     def allgather_cols(self, arr: np.ndarray, n_total: int) -> np.ndarray:
-        """``arr`` is (k, n_local) for this rank's block; returns (k, n_total) on every rank."""
+        """``arr`` is (k, n_local) for this rank's block; returns (k, n_total) on every rank (host arrays)."""
+        import torch
         arr = np.ascontiguousarray(arr)
         if self.world == 1:
             return arr
-        import torch
         k = arr.shape[0]
-        widths = [shard_bounds(n_total, self.world, r) for r in range(self.world)]
-        wmax = max(hi - lo for lo, hi in widths)
+        lo = self.all_bounds(n_total)
+        wmax = int(np.max(np.diff(lo)))
         pad = np.zeros((k, wmax), dtype=arr.dtype)
         pad[:, : arr.shape[1]] = arr
+        mine = torch.from_numpy(pad)
+        if self.backend == "nccl":
+            mine = mine.to(self.device)
+        parts = self.all_gather(mine).cpu().numpy()
         out = np.empty((k, n_total), dtype=arr.dtype)
-        with self._comm_scope():
-            mine = self._tensor(pad)
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
-            self._dist.all_gather(parts, mine, group=self.group)
-            for (lo, hi), part in zip(widths, parts):
-                out[:, lo:hi] = part.cpu().numpy()[:, : hi - lo]
+        for r in range(self.world):
+            out[:, lo[r]:lo[r + 1]] = parts[r][:, : lo[r + 1] - lo[r]]
         return out
 
     def barrier(self):
-        if self.world > 1:
+        if self.world > 1 and not self.simulate:
             self._dist.barrier(group=self.group)

@@ -29,7 +29,7 @@ import torch
 
 from . import ops, series, stats
 from ._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2
-from .dist import ShardContext
+from .dist import ShardContext, job_share
 from .folding import create_folds
 
 logger = logging.getLogger(__name__)
@@ -150,7 +150,7 @@ class RidgeCVEngine:
 
     def __init__(self, X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets,
                  shard: Optional[ShardContext] = None, lanczos_steps: int = LANCZOS_STEPS, precision: str = "auto",
-                 singcutoff: float = 0.0):
+                 singcutoff: float = 0.0, V_total: Optional[int] = None):
         check_penalties(alphas, singcutoff, normalpha)
         self.singcutoff = float(singcutoff)
         self.dev = ops.device()
@@ -193,13 +193,21 @@ class RidgeCVEngine:
         self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
         self.aux = _aux_stream(self.dev)
         self.aux2 = _aux_stream(self.dev, 1)            # refit systems (see _refit_stream)
-        # statistics tail on the device (lc_bh_fdr / lc_fisher_combine): BH-FDR is global over the voxels, so only
-        # when this process holds all of them; the driver sets alpha_fdr
-        self.device_stats = self.shard.world == 1
+        self.comm = _aux_stream(self.dev, 2)            # per-fold result exchange + global statistics
+        # voxel shards: this rank's block is columns [lo[rank], lo[rank + 1]) of V_total; the statistics tail (BH-FDR
+        # ranks ALL p-values) runs on the gathered vectors, on the device, on every rank; the driver sets alpha_fdr
+        self.V_total = int(V_total) if V_total is not None else self.V
+        lo = self.shard.all_bounds(self.V_total)
+        if int(lo[self.shard.rank + 1] - lo[self.shard.rank]) != self.V:
+            raise ValueError(f"rank {self.shard.rank} of {self.shard.world} holds {self.V} voxel columns, its block of "
+                             f"{self.V_total} has {int(lo[self.shard.rank + 1] - lo[self.shard.rank])}")
+        self.w_max = int(np.max(np.diff(lo)))
+        self.d_lo = ops.upload(lo, self.dev)
         self.alpha_fdr = 0.05
-        self.p_folds = []                              # per outer fold: NaN-free p-values, natural voxel order, device
-        self.p_folds_all = []                          # voxel shards: the same for the gathered p-values of all ranks
+        self.p_folds = None                            # (n_folds, V_total) NaN-free p-values of all voxels, device
+        self.n_folds_done = 0
         self._base_scales = None                       # (cs, split) of the resident targets, see _target_scales
+        self.sweeps_done = None                        # end of the sweeps queued last (chain_gate)
         self.ready = torch.cuda.Event()               # X, Y, K resident: the only thing the aux stream waits for
         self.ready.record()
 
@@ -278,30 +286,60 @@ class RidgeCVEngine:
                 f"{a_min:g} (need singcutoff <= {SINGCUTOFF_REL:g} a): the reference would drop singular values <= "
                 "singcutoff (encoding/models/ridge_utils.py:44-63), this implementation never truncates")
 
-    def begin_fit(self):
+    def begin_fit(self, n_folds=1):
         """Decide the arithmetic of the V-wide contractions now (column scales of the targets + the one flag that
         comes to the host), so that the first fold's set-up is enqueued without waiting on the device."""
         if not self.norm_y:
             self._target_scales(self.dY)
+        self.p_folds = torch.empty((int(n_folds), self.V_total), dtype=torch.float64, device=self.dev)
+        self.n_folds_done = 0
+
+    # -------------------------------------------------------------- V-independent fp64 systems, dealt out over ranks
+    def _sharded_solve(self, n_jobs, N, M, assemble, out=None, slot=None):
+        """``n_jobs`` independent augmented systems (same list, same order on every rank): rank r factors jobs
+        [r n_per, (r + 1) n_per), n_per = ceil(n_jobs / world), and the f32 results are all-gathered -- on return
+        ``H`` (>= n_jobs, M, N) is complete on every rank, job j in slot j.  ``assemble(jobs)`` builds the
+        (len(jobs), N + M, N) fp64 batch of the listed jobs.  Returns (H, pivot flags of THIS rank's jobs).
+        One rank: the whole batch, no copy, no collective -- and with ``out`` / ``slot`` (int32 device vector) job j
+        is written straight to out[slot[j]] (the f32 / R2 paths keep the series alphas' hat matrices in the same
+        buffer); with several ranks the caller places the gathered blocks itself."""
+        G = self.shard.world
+        n_per, mine = job_share(n_jobs, G, self.shard.rank)
+        mine = list(mine)
+        direct = not self.shard.active and out is not None
+        H = out if direct else torch.empty((n_per, M, N), dtype=torch.float32, device=self.dev)
+        if mine:
+            aug = assemble(mine)
+            info = ops.batch_chol_solve(aug, len(mine), N, M, H, slot if direct else None)
+            del aug
+        else:
+            info = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        if self.shard.active:
+            H = self.shard.all_gather(H).view(G * n_per, M, N)
+        return H, info
 
     def precompute_lmax(self, outer):
         """(inner-fold lmax (F,), outer-train lmax (1,)) per outer fold from ONE Lanczos run over the shared Gram
         matrix; [None, ...] when there is nothing to share (no normalpha, or normalize_features gives every
-        outer fold its own Gram matrix -- fold_prepare then runs the fold's systems by itself)."""
+        outer fold its own Gram matrix -- fold_prepare then runs the fold's systems by itself).  The inner-fold
+        values of consecutive outer folds are neighbours in one vector (prepare_folds takes slices spanning folds)."""
         if not self.normalpha or self.norm_x:
             return [None] * len(outer)
-        sets, spans = [], []
+        inner_sets, outer_sets, spans = [], [], []
         for tr_rows, _, inner_rel in outer:
             tr_rows = np.asarray(tr_rows, dtype=np.int64)
-            spans.append((len(sets), len(inner_rel)))
-            sets += [tr_rows[np.asarray(a, dtype=np.int64)] for a, _ in inner_rel] + [tr_rows]
+            spans.append((len(inner_sets), len(inner_rel)))
+            inner_sets += [tr_rows[np.asarray(a, dtype=np.int64)] for a, _ in inner_rel]
+            outer_sets.append(tr_rows)
         # on the AUXILIARY stream, where every consumer of these values runs
         self.ready.record()                           # X, Y, K resident
         self.aux.wait_event(self.ready)
         with torch.cuda.stream(self.aux):
-            lm = self.lmax_systems(self.K, sets)
+            lm = self.lmax_systems(self.K, inner_sets + outer_sets)
             self._check_singcutoff(lm)
-        return [(lm[s:s + n], lm[s + n:s + n + 1]) for s, n in spans]
+        n_in = len(inner_sets)
+        self._lm_inner = lm[:n_in]
+        return [(lm[s:s + n], lm[n_in + i:n_in + i + 1]) for i, (s, n) in enumerate(spans)]
 
     # -------------------------------------------------------------- inner CV: hat matrices, then the sweeps
     def _series_layout(self, M):
@@ -377,8 +415,8 @@ class RidgeCVEngine:
             raise ValueError("every inner fold needs at least one training and one validation row")
         N = ops.pad_to(max(n_i), LC_NB)
         M = ops.pad_to(max(n_v), LC_MB)
-        tr = torch.stack([ops.idx_tensor(t, N, self.dev) for t, _ in inner_abs])
-        va = torch.stack([ops.idx_tensor(v, M, self.dev) for _, v in inner_abs])
+        tr = ops.idx_matrix([t for t, _ in inner_abs], N, self.dev)          # (F, N) / (F, M) int32, -1 padded
+        va = ops.idx_matrix([v for _, v in inner_abs], M, self.dev)
         if self.normalpha and lmax is None:
             lmax = self.lmax_systems(K, [t for t, _ in inner_abs])
             self._check_singcutoff(lmax)
@@ -392,7 +430,7 @@ class RidgeCVEngine:
         infos, Hs = [], []
         for f0 in range(0, F, chunk):
             fc = min(chunk, F - f0)
-            H = torch.empty((fc * slots, M, N), dtype=torch.float32, device=self.dev) if slots else None
+            H = torch.empty((fc * A, M, N), dtype=torch.float32, device=self.dev) if not moments else None
             P = None
             if ser and moments:
                 rows_p, rowmap, _ = self._series_layout(M)
@@ -428,14 +466,25 @@ class RidgeCVEngine:
             if Ac:
                 if chol_after is not None:
                     torch.cuda.current_stream().wait_event(chol_after)
-                aug = torch.empty((fc * Ac, N + M, N), dtype=torch.float64, device=self.dev)
-                a2c = a2[f0 * A:(f0 + fc) * A].reshape(fc, A).index_select(1, self.d_cho.to(torch.int64)).reshape(-1)
-                slot = None if moments else (
-                    torch.arange(fc, device=self.dev, dtype=torch.int32).reshape(fc, 1) * A
-                    + self.d_cho.reshape(1, Ac)).reshape(-1).contiguous()
-                ops.batch_assemble(K, tr[f0:f0 + fc], va[f0:f0 + fc], None, a2c, fc, Ac, N, M, aug)
-                infos.append(ops.batch_chol_solve(aug, fc * Ac, N, M, H, slot))
-                del aug
+                # job j = (inner fold f0 + j // Ac, Cholesky alpha j % Ac) = system (f0 + j // Ac) * A + cho[j % Ac] of
+                # the (fold, alpha) grid that tr / va / a2 are laid out on
+                grid_id = [(f0 + j // Ac) * A + cho[j % Ac] for j in range(fc * Ac)]
+
+                def assemble(jobs, grid_id=grid_id):
+                    aug = torch.empty((len(jobs), N + M, N), dtype=torch.float64, device=self.dev)
+                    sysv = ops.upload(np.asarray([grid_id[j] for j in jobs], dtype=np.int32), self.dev)
+                    ops.batch_assemble_sel(K, tr, va, None, a2, sysv, len(jobs), A, N, M, aug)
+                    return aug
+
+                slot = None if moments else ops.upload(np.asarray(
+                    [(j // Ac) * A + cho[j % Ac] for j in range(fc * Ac)], dtype=np.int32), self.dev)
+                Hc, info_c = self._sharded_solve(fc * Ac, N, M, assemble, out=H, slot=slot)
+                infos.append(info_c)
+                if moments:
+                    H = Hc                                   # (>= fc * Ac, M, N): fold j's alphas at [j * Ac, (j + 1) * Ac)
+                elif Hc is not H:
+                    for j in range(fc * Ac):                 # voxel shards: beside the series alphas' hat matrices
+                        H[(j // Ac) * A + cho[j % Ac]].copy_(Hc[j])          # (D2D copies)
             Hs.append((f0, fc, H, P))
         info = torch.cat(infos) if infos else torch.zeros(1, dtype=torch.int32, device=self.dev)
         return dict(F=F, N=N, M=M, n_v=n_v, n_i=n_i, tr=tr, va=va, shared=self._shared_image(inner_abs, N), Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
@@ -539,9 +588,9 @@ class RidgeCVEngine:
         are all-reduced over the voxel shards)."""
         if single_alpha:
             _, rowsum = ops.select_alpha(scores, self.A, self.Vp, want_best=False, want_rowsum=True)
-            total = self.shard.allreduce_sum(rowsum.cpu().numpy())
-            k = int(np.argmax(total))                      # first maximum, like torch.argmax
-            return torch.full((self.Vp,), k, dtype=torch.int32, device=self.dev)
+            self.shard.all_reduce_(rowsum, "sum")          # A doubles, on the device: the choice never visits the host
+            best = torch.empty(self.Vp, dtype=torch.int32, device=self.dev)
+            return ops.fill_argmax(rowsum, self.A, best, self.Vp)     # first maximum, like torch.argmax
         return ops.select_alpha(scores, self.A, self.Vp)[0]
 
     # -------------------------------------------------------------- refit (ridge_torch)
@@ -557,27 +606,40 @@ class RidgeCVEngine:
         perm, count_h, ev = pending
         ev.synchronize()
         count_h = count_h.numpy()
-        used = [a for a in range(self.A) if count_h[a] > 0]
+        used = [a for a in range(self.A) if count_h[0, a] > 0]
+        used_all = [a for a in range(self.A) if count_h[1, a] > 0]       # over all voxel shards
+        if self.shard.simulate:     # one rank run alone for timing: its peers' choices are unknown -- assume they
+            used_all = sorted(set(used_all) | set(self.cho))             # need every factorised alpha (worst case)
+        LAST_SWEEP["used_all"] = list(used_all)
         tiles = [0]
         for a in used:
-            tiles.append(tiles[-1] + (int(count_h[a]) + tile - 1) // tile)
-        return perm, used, tiles, tiles[-1] * tile
+            tiles.append(tiles[-1] + (int(count_h[0, a]) + tile - 1) // tile)
+        return perm, used, tiles, tiles[-1] * tile, used_all
 
     def _group_async(self, best, split):
         """Grouping kernel + asynchronous copy of the alpha histogram to pinned memory: (perm, host counts, event)."""
         tile = 256 if split else COL_TILE
-        perm, count = ops.group_by_alpha(best, self.V, self.A, tile)
-        count_h = torch.empty(self.A, dtype=torch.int32, pin_memory=True)
-        count_h.copy_(count, non_blocking=True)
+        perm, count2 = ops.group_by_alpha(best, self.V, self.A, tile)    # count2: (2, A), both rows = this rank's counts
+        self.shard.all_reduce_(count2[1], "sum")                         # row 1 -> the histogram over all voxel shards
+        count_h = torch.empty((2, self.A), dtype=torch.int32, pin_memory=True)
+        count_h.copy_(count2, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         return perm, count_h, ev
+
+    def _refit_row_granule(self):
+        """The augmented rows of a refit system can be cut into up to ``world`` slices (a power of two) that different
+        ranks transform; every slice must be a multiple of LC_MB rows."""
+        g = 1
+        while 2 * g <= self.shard.world:
+            g *= 2
+        return LC_MB * g
 
     def _refit_rhs(self, X, K, tr_rows, tr_o, te_rows):
         """The augmented rows of the refit systems, fp64 (rows, N_o):  Xtr' above K[te,tr]."""
         n_o, n_t = len(tr_rows), len(te_rows)
         N_o = tr_o.shape[-1]
-        rows = self.p_pad + ops.pad_to(n_t, LC_MB)
+        rows = ops.pad_to(self.p_pad + ops.pad_to(n_t, LC_MB), self._refit_row_granule())
         rhs = torch.zeros((rows, N_o), dtype=torch.float64, device=self.dev)
         ops.transpose_rows(X, tr_o, N_o, self.p, rhs)
         if n_t:
@@ -588,23 +650,47 @@ class RidgeCVEngine:
 
     def _refit_chol(self, K, tr_o, lmax_o, rhs, alphas_idx):
         """rhs (K[tr,tr] + a^2 I)^-1 for the listed alphas by the augmented batched Cholesky in fp64:
-        ((len(alphas_idx), rows, N_o) f32, (len(alphas_idx),) int32 pivot flags)."""
+        ((len(alphas_idx), rows, N_o) f32, pivot flags of this rank's share).  Voxel shards: the batch is dealt out
+        over the ranks as (alpha, row slice) jobs -- with fewer alphas than ranks every system's augmented rows are
+        cut into S slices (each job then factors K + a^2 I again, N^3/3 of the system's N^3/3 + 2 N^2 rows flops) --
+        and all-gathered; every rank must be called with the same ``alphas_idx``."""
         Gc, (rows, N_o) = len(alphas_idx), rhs.shape
-        a2_o = ops.penalties(lmax_o, 1, self.d_alphas.index_select(0, ops.upload(np.asarray(alphas_idx, dtype=np.int64),
-                                                                               self.dev)), self.normalpha)
-        aug = torch.empty((Gc, N_o + rows, N_o), dtype=torch.float64, device=self.dev)
-        ops.batch_assemble(K, tr_o, None, rhs, a2_o, 1, Gc, N_o, rows, aug)
-        Mc = torch.empty((Gc, rows, N_o), dtype=torch.float32, device=self.dev)
-        return Mc, ops.batch_chol_solve(aug, Gc, N_o, rows, Mc)
+        a2_o = ops.penalties(lmax_o, 1, self.d_alphas, self.normalpha)              # (A,): grid F = 1
+        S = 1
+        while 2 * S * Gc <= self.shard.world and rows % (2 * S * LC_MB) == 0:
+            S *= 2
+        rs = rows // S                                                              # rows per job
 
-    def _refit_systems(self, X, K, tr_rows, used, tr_o=None, lmax_o=None, te_rows=(), spec=None):
+        def assemble(jobs):
+            # job j = (alpha j // S, row slice j % S): slices of one system are neighbours, so the gathered blocks are
+            # already the (Gc, rows, N_o) result; one assemble launch per run of jobs that share a row slice
+            aug = torch.empty((len(jobs), N_o + rs, N_o), dtype=torch.float64, device=self.dev)
+            for k, j in enumerate(jobs):
+                q = j % S
+                sysv = ops.upload(np.asarray([alphas_idx[j // S]], dtype=np.int32), self.dev)
+                ops.batch_assemble_sel(K, tr_o, None, rhs[q * rs:(q + 1) * rs], a2_o, sysv, 1, self.A, N_o, rs, aug[k:k + 1])
+            return aug
+
+        def assemble_whole(jobs):
+            aug = torch.empty((len(jobs), N_o + rows, N_o), dtype=torch.float64, device=self.dev)
+            sysv = ops.upload(np.asarray([alphas_idx[j] for j in jobs], dtype=np.int32), self.dev)
+            ops.batch_assemble_sel(K, tr_o, None, rhs, a2_o, sysv, len(jobs), self.A, N_o, rows, aug)
+            return aug
+
+        Hj, info = self._sharded_solve(Gc * S, N_o, rs, assemble if S > 1 else assemble_whole)
+        return Hj[: Gc * S].view(Gc, rows, N_o), info
+
+    def _refit_systems(self, X, K, tr_rows, used, tr_o=None, lmax_o=None, te_rows=(), spec=None, used_all=None):
         """Per alpha in use, the rows  [Xtr' ; K[te,tr]] (K[tr,tr] + a^2 I)^-1  as f32 (G, p_pad + pad32(n_te), N_o):
         M_alpha, whose product with the targets is the weight matrix (the V-independent half of
         ridge_regression.py:46-61), and below it the hat matrix of the test rows, whose product with the same
         targets is the test prediction X_te W (nested_cv.py:151,251) -- one V-wide contraction gives both.
         Augmented batched Cholesky in fp64; ``spec`` (fold_speculate) holds systems solved ahead of the alpha
-        choice, which are taken from there."""
+        choice, which are taken from there.  ``used`` = the alphas THIS rank's voxels chose (the groups of its refit
+        contraction), ``used_all`` = those of all ranks: the Cholesky systems are solved collectively
+        (_sharded_solve), so every rank must ask for the same ones."""
         G = len(used)
+        used_all = list(used) if used_all is None else list(used_all)
         n_o = len(tr_rows)
         N_o = ops.pad_to(n_o, LC_NB)
         if tr_o is None:
@@ -616,20 +702,21 @@ class RidgeCVEngine:
         # alphas on the polynomial series (large penalties: what real recordings usually select) need no
         # factorisation:  [Xtr' ; K_te] (K + a^2 I)^-1 = sum_j c_j(alpha) R_j,  R_j = [Xtr' ; K_te] K^j / lambda^(j+1),
         # with the chain R_j = R_(j-1) (K / lambda) on the f32 MFMA, shared by all such alphas (cf. _hat_matrices)
-        poly = [a for a in used if a in self.ser] if (N_o % COL_TILE == 0 and lmax_o is not None) else []
-        chol = [a for a in used if a not in poly]
+        on_series = set(self.ser) if (N_o % COL_TILE == 0 and lmax_o is not None) else set()
+        poly = [a for a in used if a in on_series]
+        chol = [a for a in used if a not in on_series]
         have = list(spec["alphas"]) if spec is not None else []
-        need = [a for a in chol if a not in have]
+        need = [a for a in used_all if a not in on_series and a not in have]
         Malpha = torch.empty((G, rows, N_o), dtype=torch.float32, device=self.dev)
-        flags = []
+        flags = [spec["info"]] if have else []          # pivot flags: of every system solved for this fold
         for a in chol:
             if a in have:
                 Malpha[used.index(a)].copy_(spec["M"][have.index(a)])
-                flags.append(spec["info"][have.index(a):have.index(a) + 1])
         if need:
             Mc, info_n = self._refit_chol(K, tr_o, lmax_o, rhs, need)
             for i, a in enumerate(need):
-                Malpha[used.index(a)].copy_(Mc[i])
+                if a in used:
+                    Malpha[used.index(a)].copy_(Mc[i])
             flags.append(info_n)
         info = torch.cat(flags) if flags else torch.zeros(1, dtype=torch.int32, device=self.dev)
         if poly:
@@ -701,8 +788,8 @@ class RidgeCVEngine:
         (ridge_regression.py:9-63), all on the current stream.  Returns (Ws (p_pad, Vs), Ys, perm, N_o, info):
         column j of Ws / Ys is voxel perm[j] (-1 = padding)."""
         cs, split = self._target_scales(Y)
-        perm, used, tiles, Vs = self._refit_groups(best, split)
-        Malpha, info = self._refit_systems(X, K, tr_rows, used, tr_o, lmax_o)
+        perm, used, tiles, Vs, used_all = self._refit_groups(best, split)
+        Malpha, info = self._refit_systems(X, K, tr_rows, used, tr_o, lmax_o, used_all=used_all)
         Ws, Ys, N_o = self._refit_apply(Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs)
         return Ws[: self.p_pad], Ys, perm, N_o, info
 
@@ -720,43 +807,110 @@ class RidgeCVEngine:
     # for the fold's results).  The caller interleaves the phases of consecutive folds so that the main stream
     # always has MFMA work, the auxiliary stream the fp64 work, and the host statistics of fold f run meanwhile.
     def fold_prepare(self, tr_rows, te_rows, inner_rel, lmax_pre=None, chol_after=None):
-        """Everything of an outer fold that does not touch the voxel axis beyond O(V) copies -- train-statistics
+        """prepare_folds for a single outer fold."""
+        return self.prepare_folds([(tr_rows, te_rows, inner_rel)], [lmax_pre], chol_after)[0]
+
+    def _hat_slice(self, hat, s, Fo, inner_abs):
+        """The hat-matrix set of the inner folds [s, s + Fo) of a batch prepared together (one chunk): views."""
+        (f0, fc, H, P), = hat["Hs"]
+        per = len(hat["cho"]) if hat["moments"] else self.A          # hat matrices kept per inner fold
+        sub = dict(hat)
+        sub.update(F=Fo, n_v=hat["n_v"][s:s + Fo], n_i=hat["n_i"][s:s + Fo], tr=hat["tr"][s:s + Fo], va=hat["va"][s:s + Fo],
+                   lmax=None if hat["lmax"] is None else hat["lmax"][s:s + Fo], a2=hat["a2"][s * self.A:(s + Fo) * self.A],
+                   shared=self._shared_image(inner_abs, hat["N"]),
+                   Hs=[(0, Fo, None if H is None else H[s * per:(s + Fo) * per], None if P is None else P[s:s + Fo])])
+        return sub
+
+    def prepare_folds(self, folds, lmax_pre, chol_after=None):
+        """Everything of the given outer folds that does not touch the voxel axis beyond O(V) copies -- train-statistics
         normalisation, Lanczos, the batched Cholesky / series hat matrices -- enqueued on the engine's AUXILIARY
-        stream, so that it overlaps the V-wide MFMA sweeps of the previous fold running on the main stream
-        (these fp64 kernels are latency chains with small grids; on their own they leave most CUs idle)."""
-        tr_rows = np.asarray(tr_rows, dtype=np.int64)
-        te_rows = np.asarray(te_rows, dtype=np.int64)
-        if len(te_rows) < 2:
-            raise ValueError("x and y must have length at least 2.")      # scipy.stats.pearsonr's message
-        inner_abs = [(tr_rows[np.asarray(a, dtype=np.int64)], tr_rows[np.asarray(b, dtype=np.int64)])
-                     for a, b in inner_rel]
+        stream, so that it overlaps the V-wide MFMA sweeps running on the main stream (these fp64 kernels are latency
+        chains with small grids; on their own they leave most CUs idle).  ``folds``: [(tr_rows, te_rows, inner_rel)];
+        ``lmax_pre``: precompute_lmax's entries for them.  Folds that share the Gram matrix and the padded system
+        size go through ONE batch (a chain of ~N/64 dependent steps costs the same for 3 systems as for 30; with
+        voxel shards the batch is what gets dealt out over the ranks).  Returns one state dict per fold."""
         main = torch.cuda.current_stream()
+        metas = []
+        for tr_rows, te_rows, inner_rel in folds:
+            tr_rows = np.asarray(tr_rows, dtype=np.int64)
+            te_rows = np.asarray(te_rows, dtype=np.int64)
+            if len(te_rows) < 2:
+                raise ValueError("x and y must have length at least 2.")      # scipy.stats.pearsonr's message
+            inner_abs = [(tr_rows[np.asarray(a, dtype=np.int64)], tr_rows[np.asarray(b, dtype=np.int64)])
+                         for a, b in inner_rel]
+            if not inner_abs or min(len(t) for t, _ in inner_abs) < 1 or min(len(v) for _, v in inner_abs) < 1:
+                raise ValueError("every inner fold needs at least one training and one validation row")
+            N = ops.pad_to(max(len(t) for t, _ in inner_abs), LC_NB)
+            M = ops.pad_to(max(len(v) for _, v in inner_abs), LC_MB)
+            metas.append(dict(tr=tr_rows, te=te_rows, inner_abs=inner_abs, N=N, M=M))
+        # groups of consecutive folds prepared as one batch: shared data (no per-fold normalisation), equal padded
+        # sizes, neighbouring precomputed lmax, and the whole group's fp64 systems within the memory budget
+        groups, batchable = [], not (self.norm_x or self.norm_y) and (not self.normalpha or all(l is not None for l in lmax_pre))
+        for i, m in enumerate(metas):
+            g = groups[-1] if groups else None
+            per_fold = (m["N"] + m["M"]) * m["N"] * 8 * max(len(self.cho), 1) * len(m["inner_abs"])
+            if (g is not None and batchable and (metas[g[0]]["N"], metas[g[0]]["M"]) == (m["N"], m["M"])
+                    and per_fold * (len(g) + 1) <= AUG_BUDGET_BYTES and self._lmax_adjacent(lmax_pre, g[-1], i)
+                    and sum(len(metas[k]["inner_abs"]) for k in g) + len(m["inner_abs"]) <= MAX_INNER_FOLDS):
+                g.append(i)
+            else:
+                groups.append([i])
         self.aux.wait_event(self.ready)                # inputs (X, Y, K) were produced on the main stream
+        out = [None] * len(folds)
         with torch.cuda.stream(self.aux):
-            X, Y, K, cs, split = self._fold_data(tr_rows)
-            data_ready = torch.cuda.Event()
-            data_ready.record()
-            # S[0]^2 of the inner train sets and of the whole outer-train block (refit penalty scale,
-            # independent of the alpha choice): precomputed for the whole fit, or one run for this fold
-            lmax_i = lmax_o = None
-            if self.normalpha:
-                if lmax_pre is None:
-                    lm = self.lmax_systems(K, [t for t, _ in inner_abs] + [tr_rows])
-                    self._check_singcutoff(lm)
-                    lmax_pre = (lm[:len(inner_abs)], lm[len(inner_abs):])
-                lmax_i, lmax_o = lmax_pre
-            hat = self._hat_matrices(K, inner_abs, lmax_i, self._series_by_moments(split), chol_after=chol_after)
-            hat.update(cs=cs, split=split, data_ready=data_ready)
-            N_o = ops.pad_to(len(tr_rows), LC_NB)
-            tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
-            done = torch.cuda.Event()
-            done.record()
-        for t in ([X, Y, K, cs, hat["tr"], hat["va"], hat["info"], hat["a2"], hat["lmax"], hat["d_ser"], tr_o, lmax_o]
-                  + [h for _, _, h, _ in hat["Hs"]] + [q for _, _, _, q in hat["Hs"]]):
-            if t is not None and t.is_cuda:
-                t.record_stream(main)                  # allocated on aux, consumed on main
-        return dict(tr=tr_rows, te=te_rows, X=X, Y=Y, K=K, cs=cs, split=split, hat=hat, done=done, tr_o=tr_o,
-                    lmax_o=lmax_o)
+            for g in groups:
+                X, Y, K, cs, split = self._fold_data(metas[g[0]]["tr"])      # per-fold data only when len(g) == 1
+                data_ready = torch.cuda.Event()
+                data_ready.record()
+                # S[0]^2 of the inner train sets and of the whole outer-train block (refit penalty scale,
+                # independent of the alpha choice): precomputed for the whole fit, or one run for this fold
+                lmax_i, lmax_os = None, [None] * len(g)
+                if self.normalpha:
+                    if lmax_pre[g[0]] is None:
+                        m = metas[g[0]]
+                        lm = self.lmax_systems(K, [t for t, _ in m["inner_abs"]] + [m["tr"]])
+                        self._check_singcutoff(lm)
+                        lmax_i, lmax_os = lm[:len(m["inner_abs"])], [lm[len(m["inner_abs"]):]]
+                    else:
+                        lmax_os = [lmax_pre[i][1] for i in g]
+                        lmax_i = lmax_pre[g[0]][0] if len(g) == 1 else self._lmax_span(lmax_pre, g)
+                inner_all = [ia for i in g for ia in metas[i]["inner_abs"]]
+                hat = self._hat_matrices(K, inner_all, lmax_i, self._series_by_moments(split), chol_after=chol_after)
+                hat.update(cs=cs, split=split, data_ready=data_ready)
+                done = torch.cuda.Event()
+                s = 0
+                for k, i in enumerate(g):
+                    m = metas[i]
+                    Fo = len(m["inner_abs"])
+                    sub = hat if len(g) == 1 else self._hat_slice(hat, s, Fo, m["inner_abs"])
+                    s += Fo
+                    N_o = ops.pad_to(len(m["tr"]), LC_NB)
+                    tr_o = ops.idx_tensor(m["tr"], N_o, self.dev).reshape(1, N_o)
+                    out[i] = dict(tr=m["tr"], te=m["te"], X=X, Y=Y, K=K, cs=cs, split=split, hat=sub, done=done, tr_o=tr_o,
+                                  lmax_o=lmax_os[k])
+                done.record()
+                for t in ([X, Y, K, cs, hat["tr"], hat["va"], hat["info"], hat["a2"], hat["lmax"], hat["d_ser"]]
+                          + [out[i]["tr_o"] for i in g] + lmax_os
+                          + [h for _, _, h, _ in hat["Hs"]] + [q for _, _, _, q in hat["Hs"]]):
+                    if t is not None and t.is_cuda:
+                        t.record_stream(main)              # allocated on aux, consumed on main
+        return out
+
+    @staticmethod
+    def _lmax_adjacent(lmax_pre, i, j):
+        """The precomputed inner-fold lmax of folds i and j are neighbouring slices of one vector."""
+        if lmax_pre[i] is None or lmax_pre[j] is None:
+            return lmax_pre[i] is None and lmax_pre[j] is None
+        a, b = lmax_pre[i][0], lmax_pre[j][0]
+        return (a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+                and a.storage_offset() + a.numel() == b.storage_offset())
+
+    @staticmethod
+    def _lmax_span(lmax_pre, g):
+        """One view over the neighbouring inner-fold lmax slices of the folds in ``g``."""
+        first, last = lmax_pre[g[0]][0], lmax_pre[g[-1]][0]
+        n = last.storage_offset() + last.numel() - first.storage_offset()
+        return torch.as_strided(first, (n,), (1,), first.storage_offset())
 
     def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None, lmax_pre=None):
         st = prepared if prepared is not None else self.fold_prepare(tr_rows, te_rows, inner_rel, lmax_pre)
@@ -777,6 +931,13 @@ class RidgeCVEngine:
                 t.record_stream(s2)                    # made on the first auxiliary stream (or at set-up), read here
         return s2
 
+    def chain_gate(self):
+        """Event the NEXT fold_prepare's Cholesky chain waits for (see the driver loop): the end of the sweeps queued
+        last -- on one GPU, where the fp64 chains would otherwise take CUs from the dominant MFMA kernel at no gain
+        in fit time.  With voxel shards the V-wide work per rank is a fraction and the chains are the critical path:
+        no gate."""
+        return self.sweeps_done if self.shard.world == 1 else None
+
     def fold_speculate(self, st, alphas_idx):
         """Solve the refit systems of a prepared fold for the listed alphas BEFORE its alpha choice is known, on the
         auxiliary stream (the driver passes the alphas the previous fold used: the histogram of the chosen alphas
@@ -786,8 +947,8 @@ class RidgeCVEngine:
         if not todo:
             return
         rs = self._refit_stream(st)
-        if getattr(self, "sweeps_done", None) is not None:
-            rs.wait_event(self.sweeps_done)            # like the inner-fold chain: not beside the sweeps just queued
+        if self.chain_gate() is not None:
+            rs.wait_event(self.chain_gate())           # like the inner-fold chain: not beside the sweeps just queued
         with torch.cuda.stream(rs):
             rhs = self._refit_rhs(st["X"], st["K"], st["tr"], st["tr_o"], st["te"])
             Mc, info = self._refit_chol(st["K"], st["tr_o"], st["lmax_o"], rhs, todo)
@@ -807,17 +968,17 @@ class RidgeCVEngine:
         if "grouping" not in st:
             self.fold_choose(st, single_alpha)
         best, split = st["best"], st["split"]
-        perm, used, tiles, Vs = self._refit_groups(best, split, st.pop("grouping"))
+        perm, used, tiles, Vs, used_all = self._refit_groups(best, split, st.pop("grouping"))
         main = torch.cuda.current_stream()
         with torch.cuda.stream(self._refit_stream(st)):    # inputs: X, K, tr_o, lmax_o -- all made on aux or at start
             Malpha, info_o = self._refit_systems(st["X"], st["K"], st["tr"], used, st.get("tr_o"), st.get("lmax_o"),
-                                                 st["te"], spec=st.get("spec"))
+                                                 st["te"], spec=st.get("spec"), used_all=used_all)
             ready = torch.cuda.Event()
             ready.record()
         for x in (Malpha, info_o):
             x.record_stream(main)
-        st.update(best=best, perm=perm, used=used, tiles=tiles, Vs=Vs, split=split, Malpha=Malpha, info_o=info_o,
-                  systems_ready=ready)
+        st.update(best=best, perm=perm, used=used, used_all=used_all, tiles=tiles, Vs=Vs, split=split, Malpha=Malpha,
+                  info_o=info_o, systems_ready=ready)
         return st
 
     def fold_finish(self, st, weight_scale):
@@ -835,93 +996,70 @@ class RidgeCVEngine:
         pred = self._refit_product(o, self.p_pad, st["Malpha"].shape[1], n_t)[:n_t]
         r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
-        # results leave through pinned buffers so the copies do not stall the host
-        h_r = torch.empty(Vs, dtype=torch.float64, pin_memory=True)
-        h_p = torch.empty(Vs, dtype=torch.float64, pin_memory=True)
-        h_p.copy_(p_s, non_blocking=True)
-        h_perm = torch.empty(Vs, dtype=torch.int32, pin_memory=True)
-        h_best = torch.empty(self.V, dtype=torch.int32, pin_memory=True)
-        h_r.copy_(r_s, non_blocking=True)
-        h_perm.copy_(perm[:Vs], non_blocking=True)
-        h_best.copy_(best[: self.V], non_blocking=True)
-        h_rej = h_padj = None
-        if self.device_stats:
-            # p-values back in natural voxel order (NaN r -> p = 1, nested_cv.py:436), BH-FDR of the fold on the device
-            idx = perm[:Vs].to(torch.int64)
-            p_nat = torch.ones(self.V + 1, dtype=torch.float64, device=self.dev)      # slot V swallows the padding
-            p_nat.scatter_(0, torch.where(idx < 0, torch.full_like(idx, self.V), idx),
-                           torch.where(torch.isnan(r_s), torch.ones_like(p_s), p_s))
-            p_nat = p_nat[: self.V]
-            self.p_folds.append(p_nat)
-            rej_d, padj_d = ops.bh_fdr(p_nat, self.alpha_fdr)
-            h_rej = torch.empty(self.V, dtype=torch.uint8, pin_memory=True)
-            h_padj = torch.empty(self.V, dtype=torch.float64, pin_memory=True)
-            h_rej.copy_(rej_d, non_blocking=True)
-            h_padj.copy_(padj_d, non_blocking=True)
-        # Cholesky pivot flags of the inner folds and of the refit: checked when the fold is collected
-        bad = torch.stack([st["info"].ne(0).any(), info_o.ne(0).any()]).to(torch.int32)
-        h_bad = torch.empty(2, dtype=torch.int32, pin_memory=True)
-        h_bad.copy_(bad, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record()
+        # ---- the fold's per-voxel results: one packed block in natural voxel order (r, p, alpha index, pivot flags),
+        # all-gathered over the voxel shards, unpacked to V_total-long vectors, BH-FDR of the fold on ALL p-values --
+        # on the communication stream, so that neither the collective nor the sort hold up the main stream
+        blk = torch.empty((4, max(self.w_max, 2)), dtype=torch.float64, device=self.dev)
+        ops.fold_pack(r_s, p_s, perm, Vs, best, self.V, st["info"], info_o, blk)
+        packed = torch.cuda.Event()
+        packed.record()
+        self.comm.wait_event(packed)
+        fold_no = self.n_folds_done
+        self.n_folds_done += 1
+        Vt = self.V_total
+        with torch.cuda.stream(self.comm):
+            gathered = self.shard.all_gather(blk)                                  # (world, 4, ld)
+            dres = torch.empty((2, Vt), dtype=torch.float64, device=self.dev)      # r, p of all voxels
+            didx = torch.empty(Vt, dtype=torch.int32, device=self.dev)
+            dbad = torch.empty(2, dtype=torch.int32, device=self.dev)
+            ops.fold_unpack(gathered, self.shard.world, blk.shape[1], self.d_lo, self.w_max, dres[0], dres[1], didx,
+                            self.p_folds[fold_no], dbad)
+            rej_d, padj_d = ops.bh_fdr(self.p_folds[fold_no], self.alpha_fdr)
+            # results leave through pinned buffers so the copies do not stall the host
+            h_res = torch.empty((2, Vt), dtype=torch.float64, pin_memory=True)
+            h_idx = torch.empty(Vt, dtype=torch.int32, pin_memory=True)
+            h_rej = torch.empty(Vt, dtype=torch.uint8, pin_memory=True)
+            h_padj = torch.empty(Vt, dtype=torch.float64, pin_memory=True)
+            h_bad = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            for h, d in ((h_res, dres), (h_idx, didx), (h_rej, rej_d), (h_padj, padj_d), (h_bad, dbad)):
+                h.copy_(d, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        for t in (blk, r_s, p_s, perm, best, st["info"], info_o):
+            t.record_stream(self.comm)
         self.results_ready = done
         # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
         # run beside this part of the contraction)
         Ws = self._refit_product(o, 0, self.p_pad, self.p)
         ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
-        return dict(done=done, r=h_r, p=h_p, perm=h_perm, best=h_best, n_t=n_t, bad=h_bad, rej=h_rej, padj=h_padj,
-                    keep=(r_s, p_s, perm, best, bad))
+        return dict(done=done, res=h_res, idx=h_idx, n_t=n_t, bad=h_bad, rej=h_rej, padj=h_padj,
+                    keep=(dres, didx, dbad, rej_d, padj_d, gathered))
 
     def fold_refit(self, st, single_alpha, weight_scale):
         return self.fold_finish(self.fold_select(st, single_alpha), weight_scale)
 
     def fold_collect(self, pend) -> _FoldResult:
+        """Waits for a fold's results: r / p / alpha index of ALL voxels (every shard), and the fold's BH-FDR.  The
+        pivot flags are OR-ed over the ranks, so a failed factorisation raises on every rank together."""
         pend["done"].synchronize()
         if int(pend["bad"][0]):
             raise RuntimeError("Cholesky failed: Gram matrix + alpha^2 I is not positive definite")
         if int(pend["bad"][1]):
             raise RuntimeError("Cholesky failed in the refit: Gram matrix + alpha^2 I is not positive definite")
-        perm_h = pend["perm"].numpy()
-        live = perm_h >= 0
-        r = np.empty(self.V, dtype=np.float64)
-        p = np.empty(self.V, dtype=np.float64)
-        r[perm_h[live]] = pend["r"].numpy()[live]
-        p[perm_h[live]] = pend["p"].numpy()[live]
-        sig = None
-        if pend.get("rej") is not None:
-            sig = (pend["rej"].numpy().astype(bool), pend["padj"].numpy().copy())
-        return _FoldResult(r, p, pend["best"].numpy().copy(), pend["n_t"], sig)
+        res = pend["res"].numpy()
+        sig = (pend["rej"].numpy().astype(bool), pend["padj"].numpy().copy())
+        return _FoldResult(res[0].copy(), res[1].copy(), pend["idx"].numpy().copy(), pend["n_t"], sig)
 
     def combined_significance(self):
-        """Fisher's combination of the folds' p-values and its BH-FDR on the device (one GPU): (p_comb, reject,
-        adjusted p) as host arrays."""
-        # on the auxiliary stream (idle by now), behind the last fold's results: the main stream is still busy with
-        # the weight rows of that fold's refit, which nothing here depends on
-        self.aux.wait_event(self.results_ready)
-        with torch.cuda.stream(self.aux):
-            pcomb = ops.fisher_combine(torch.stack(self.p_folds))
+        """Fisher's combination of the folds' p-values and its BH-FDR on the device, over the voxels of all shards
+        (every rank, redundantly): (p_comb, reject, adjusted p) as host arrays."""
+        # on the communication stream, behind the last fold's results: the main stream is still busy with the weight
+        # rows of that fold's refit, which nothing here depends on
+        with torch.cuda.stream(self.comm):
+            pcomb = ops.fisher_combine(self.p_folds[: self.n_folds_done])
             rej, padj = ops.bh_fdr(pcomb, self.alpha_fdr)
             out = pcomb.cpu().numpy(), rej.cpu().numpy().astype(bool), padj.cpu().numpy()
         return out
-
-    # voxel shards: BH-FDR is global over the voxels, so it runs on the p-values gathered from all ranks -- on the
-    # device all the same (every rank, redundantly: 5 MB up, a sort, 6 MB down at 8 x 80 000 voxels), on the
-    # communication stream.  The host twin costs ~100 ms per call at that size, six calls per fit: more than the fit.
-    def gathered_significance(self, p_all: np.ndarray):
-        """(reject, adjusted p) of the NaN-free p-values of ALL voxels of one fold; the device copy is kept for
-        gathered_combined."""
-        with self.shard._comm_scope():
-            p_dev = ops.upload(np.ascontiguousarray(p_all, dtype=np.float64), self.dev)
-            rej, padj = ops.bh_fdr(p_dev, self.alpha_fdr)
-            self.p_folds_all.append(p_dev)
-            return rej.cpu().numpy().astype(bool), padj.cpu().numpy()
-
-    def gathered_combined(self):
-        """Fisher's combination over the folds and its BH-FDR for the gathered p-values: (p_comb, reject, adjusted p)."""
-        with self.shard._comm_scope():
-            pcomb = ops.fisher_combine(torch.stack(self.p_folds_all))
-            rej, padj = ops.bh_fdr(pcomb, self.alpha_fdr)
-            return pcomb.cpu().numpy(), rej.cpu().numpy().astype(bool), padj.cpu().numpy()
 
     def run_fold(self, tr_rows, te_rows, inner_rel, single_alpha, weight_scale) -> _FoldResult:
         st = self.fold_begin(tr_rows, te_rows, inner_rel)
@@ -1076,56 +1214,43 @@ class NestedCVModel(BasePredictivityModel):
                 outer.append((tr, te, inner))
 
         eng = RidgeCVEngine(X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
-                            precision=self.precision, singcutoff=singcutoff)
+                            precision=self.precision, singcutoff=singcutoff, V_total=V_total)
         scale = 1.0 if train_test else 1.0 / len(outer)
         fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
-        score_rows, p_rows, any_nan = [], [], []
+        score_rows, any_nan = [], []
 
         def tail(pend):
-            """Host statistics of one finished fold; runs while the GPU works on the next fold.
-            The all-gather over voxel shards is the only V-sized exchange of the fit."""
+            """Host statistics of one finished fold; runs while the GPU works on the next fold.  The engine hands
+            over the vectors of ALL voxels: the one exchange of per-voxel results over the voxel shards (and the
+            fold's BH-FDR on them) happened on the device (RidgeCVEngine.fold_finish)."""
             f = eng.fold_collect(pend)
-            rp = shard.allgather_cols(np.stack([f.r, f.p]), V_total)
-            idx = shard.allgather_cols(f.best_idx.astype(np.int32)[None, :], V_total)[0]
-            r32 = rp[0].astype(np.float32)
+            r32 = f.r.astype(np.float32)
             if train_test:                  # the per-fold Python lists are only returned by the train/test metrics;
-                corrs, pvals = _fold_lists(r32, rp[1])      # the CV summary works on the arrays below
+                corrs, pvals = _fold_lists(r32, f.p)        # the CV summary works on the arrays below
                 fold_scores.append(corrs)
                 fold_p.append(pvals)
-            fold_alpha.append(_alpha_vector(alphas, idx, single_alpha))
-            p_arr = np.where(np.isnan(r32), 1.0, rp[1])
-            if getattr(f, "sig", None) is not None:
-                fold_sig.append(f.sig)                                    # one GPU: made on the device with the fold
-            elif shard.world > 1 and getattr(eng, "gathered_significance", None) is not None and torch.cuda.is_available():
-                fold_sig.append(eng.gathered_significance(p_arr))        # voxel shards: device, on the gathered vector
-            else:
-                fold_sig.append(stats.fdrcorrection(p_arr, alpha=alpha_fdr))
+            fold_alpha.append(_alpha_vector(alphas, f.best_idx, single_alpha))
+            fold_sig.append(f.sig)
             score_rows.append(np.nan_to_num(r32, nan=0.0))
-            p_rows.append(p_arr)
             any_nan.append(bool(np.isnan(r32).any()))
 
         pending = None
         eng.alpha_fdr = alpha_fdr
-        eng.begin_fit()                                     # the one host sync of the set-up, before anything is queued
-        lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
         n = len(outer)
-        st = eng.fold_begin(*outer[0], prepared=eng.fold_prepare(*outer[0], lmax_pre=lmax_pre[0]))
-        prepared = eng.fold_prepare(*outer[1], lmax_pre=lmax_pre[1]) if n > 1 else None       # aux stream
+        eng.begin_fit(n)                                    # the one host sync of the set-up, before anything is queued
+        lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
+        # V-independent part of every fold, ahead of everything on the auxiliary stream: fold 0 by itself (its sweeps
+        # start as soon as its own systems are done), then ALL other folds as one batch
+        st = eng.fold_begin(*outer[0], prepared=eng.prepare_folds(outer[:1], lmax_pre[:1])[0])
+        prepared = eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else []
         for i in range(n):
-            if getattr(eng, "fold_choose", None) is not None:
-                eng.fold_choose(st, single_alpha)           # main: argmax + grouping; the histogram leaves asynchronously
+            eng.fold_choose(st, single_alpha)               # main: argmax + grouping; the histogram leaves asynchronously
             st_next = None
             if i + 1 < n:
-                st_next = eng.fold_begin(*outer[i + 1], prepared=prepared)                    # main: sweeps of i+1
+                st_next = eng.fold_begin(*outer[i + 1], prepared=prepared[i])                 # main: sweeps of i+1
             st = eng.fold_select(st, single_alpha)          # host waits for the histogram of fold i here
             if i + 1 < n:
-                # the Cholesky chain of fold i+2 starts when the sweeps of fold i+1 (just queued) are done: it has
-                # until the fused pass of fold i+2, and the fused launches -- the dominant kernel -- of fold i+1
-                # then run without it (1.79 -> 1.62 ms per launch at the same fit time)
-                prepared = (eng.fold_prepare(*outer[i + 2], lmax_pre=lmax_pre[i + 2],
-                                             chol_after=getattr(eng, "sweeps_done", None)) if i + 2 < n else None)
-                if getattr(eng, "fold_speculate", None) is not None:
-                    eng.fold_speculate(st_next, st["used"])                                   # aux: refit systems of i+1
+                eng.fold_speculate(st_next, st["used_all"])                                   # aux: refit systems of i+1
             if pending is not None:
                 tail(pending)
             pending = eng.fold_finish(st, scale)            # main: V-wide refit of fold i behind those sweeps
@@ -1141,13 +1266,7 @@ class NestedCVModel(BasePredictivityModel):
         # np.mean(fold_scores, axis=0) of the reference (nested_cv.py:276): the nested lists hold np.float32
         # scalars, plus Python 0.0 where r was NaN -- numpy then builds a float64 array, else a float32 one
         scores = np.mean(np.stack(score_rows).astype(np.float64 if any(any_nan) else np.float32), axis=0)
-        if getattr(eng, "device_stats", False) and len(getattr(eng, "p_folds", ())) == len(outer):
-            pcomb, sig, padj = eng.combined_significance()
-        elif len(getattr(eng, "p_folds_all", ())) == len(outer) and len(outer) > 0:
-            pcomb, sig, padj = eng.gathered_combined()
-        else:
-            pcomb = stats.fisher_combine(np.stack(p_rows))
-            sig, padj = stats.fdrcorrection(pcomb, alpha=alpha_fdr)
+        pcomb, sig, padj = eng.combined_significance()
         majority = np.sum([s for s, _ in fold_sig], axis=0) >= (n_outer_folds // 2 + 1)
         mean_alphas = np.mean(fold_alpha, axis=0)
         metrics = stats.full_cv_metrics(scores, pcomb, padj, sig, majority, mean_alphas, np.sum(sig), np.sum(majority))

@@ -51,6 +51,15 @@ def idx_tensor(rows, length, dev, fill=-1):
     return upload(h, dev)
 
 
+def idx_matrix(row_sets, length, dev, fill=-1):
+    """(len(row_sets), length) int32 device matrix of index lists, one upload."""
+    h = np.full((len(row_sets), length), fill, dtype=np.int32)
+    for i, rows in enumerate(row_sets):
+        r = np.asarray(rows, dtype=np.int64)
+        h[i, : r.size] = r
+    return upload(h, dev)
+
+
 def upload(arr, dev):
     """Small host array -> device through pinned memory, asynchronously on the current stream.  (A pageable
     ``.to(dev)`` / ``torch.tensor(..., device=dev)`` synchronises the stream: with two streams in flight that
@@ -224,6 +233,12 @@ def batch_assemble(k, tr, va, rhs, a2, F, A, N, M, aug):
     _lib.call("lc_batch_assemble", _p(k), k.stride(0), _p(tr), _p(va), _p(rhs), _p(a2), F, A, N, M, _p(aug), _s())
 
 
+def batch_assemble_sel(k, tr, va, rhs, a2, sys, B, A, N, M, aug):
+    """System j of the batch = grid system sys[j] = fold * A + alpha (see lc_batch_assemble_sel)."""
+    _lib.call("lc_batch_assemble_sel", _p(k), k.stride(0), _p(tr), _p(va), _p(rhs), _p(a2), _p(sys), B, A, N, M, _p(aug),
+              _s())
+
+
 def masked_stream(mask_words):
     """torch ExternalStream over a HIP stream limited to the CUs set in mask_words (sequence of uint32)."""
     import ctypes as ct
@@ -347,10 +362,27 @@ def select_alpha(scores, A, V, want_best=True, want_rowsum=False):
     return best, rowsum
 
 
+def fill_argmax(rowsum, A, best, V):
+    _lib.call("lc_fill_argmax", _p(rowsum), A, _p(best), V, _s())
+    return best
+
+
+def fold_pack(r_s, p_s, perm, Vs, best, V, info_a, info_b, out):
+    """out: (4, ld) f64 device block (see lc_fold_pack)."""
+    _lib.call("lc_fold_pack", _p(r_s), _p(p_s), _p(perm), Vs, _p(best), V, _p(info_a), info_a.numel(), _p(info_b),
+              info_b.numel(), _p(out), out.stride(0), _s())
+    return out
+
+
+def fold_unpack(src, world, ld, lo, w_max, r, p, idx, p_clean, bad):
+    _lib.call("lc_fold_unpack", _p(src), world, ld, _p(lo), w_max, _p(r), _p(p), _p(idx), _p(p_clean), _p(bad), _s())
+
+
 def group_by_alpha(best, V, A, pad):
     perm = torch.full((V + A * pad,), -1, dtype=torch.int32, device=best.device)
-    count = torch.empty(A, dtype=torch.int32, device=best.device)
-    _lib.call("lc_group_by_alpha", _p(best), V, A, pad, _p(perm), _p(count), _s())
+    count = torch.empty((2, A), dtype=torch.int32, device=best.device)       # row 0: counts; row 1: a copy (callers
+    _lib.call("lc_group_by_alpha", _p(best), V, A, pad, _p(perm), _p(count), _s())      # all-reduce it over shards)
+    count[1].copy_(count[0])
     return perm, count
 
 

@@ -1,7 +1,12 @@
-"""The voxel-sharded orchestration (gather of per-voxel vectors, single-alpha all-reduce) on CPU:
-two processes, gloo backend.  The device engine is replaced by an oracle-backed stand-in so that
-only the host-side sharding logic of litcoder_core_amd.nested_cv is under test; the result must
-equal the unsharded run on every rank."""
+"""The voxel-sharded path on CPU: two processes, gloo backend.
+
+Three layers (the real engine needs a GPU: its two-rank run is tests/test_gpu_shards.py, ``-m gpu``):
+  * ShardContext's collectives themselves (all_gather / all_reduce_ / allgather_cols / bounds / job_share) on host
+    tensors;
+  * the driver loop of litcoder_core_amd.nested_cv (fold phases, the order of the collectives, the host tail) with
+    the device engine replaced by an oracle-backed stand-in that implements the engine's phase interface -- the
+    result must equal the unsharded run on every rank, per-voxel alpha and single_alpha, CV and train/test.
+"""
 import os
 import pickle
 import subprocess
@@ -18,51 +23,72 @@ import numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 import torch.distributed as dist
 import litcoder_core_amd.nested_cv as ncv
-from litcoder_core_amd.dist import ShardContext
+from litcoder_core_amd import stats
+from litcoder_core_amd.dist import ShardContext, job_share, shard_bounds
 import oracle.ridge as oridge
 
 class OracleEngine:
-    """Same interface as RidgeCVEngine.run_fold/weights, arithmetic by the CPU oracle."""
-    def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard, precision="auto", singcutoff=0.0):
+    """The phase interface of RidgeCVEngine (what NestedCVModel's driver loop calls), arithmetic by the CPU oracle,
+    exchanges through the same ShardContext."""
+    def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard, precision="auto", singcutoff=0.0, V_total=None):
         self.X, self.Y = torch.tensor(np.asarray(X), dtype=torch.float32), torch.tensor(np.asarray(Y), dtype=torch.float32)
         self.alphas, self.normalpha, self.use_corr, self.shard = list(alphas), normalpha, use_corr, shard
         self.V = self.Y.shape[1]
+        self.V_total = V_total or self.V
         self.W = np.zeros((self.X.shape[1], self.V), dtype=np.float32)
-    def run_fold(self, tr, te, inner, single_alpha, scale):
-        tr, te = np.asarray(tr), np.asarray(te)
-        Xtr, Ytr = self.X[tr], self.Y[tr]
+        self.W_acc = self.W
+        self.alpha_fdr = 0.05
+        self.p_rows = []
+    def begin_fit(self, n_folds=1):
+        self.p_rows = []
+    def precompute_lmax(self, outer):
+        return [None] * len(outer)
+    def prepare_folds(self, folds, lmax_pre, chol_after=None):
+        return [dict(tr=np.asarray(tr), te=np.asarray(te), inner=inner) for tr, te, inner in folds]
+    def fold_begin(self, tr, te, inner, prepared=None, lmax_pre=None):
+        return prepared
+    def chain_gate(self):
+        return None
+    def fold_choose(self, st, single_alpha):
+        Xtr, Ytr = self.X[st["tr"]], self.Y[st["tr"]]
         tot = 0
-        for a, b in inner:
+        for a, b in st["inner"]:
             tot = tot + oridge.alpha_sweep_scores(Xtr[a], Xtr[b], Ytr[a], Ytr[b], self.alphas, 1e-10, self.use_corr, self.normalpha)
         if single_alpha:
-            total = self.shard.allreduce_sum(tot.double().sum(dim=1).numpy())
-            idx = np.full(self.V, int(np.argmax(total)), dtype=np.int32)
+            total = self.shard.all_reduce_(tot.double().sum(dim=1), "sum")          # host tensor under gloo
+            st["idx"] = np.full(self.V, int(torch.argmax(total)), dtype=np.int32)
         else:
-            idx = tot.argmax(dim=0).numpy().astype(np.int32)
+            st["idx"] = tot.argmax(dim=0).numpy().astype(np.int32)
+        return st
+    def fold_select(self, st, single_alpha):
+        count = torch.from_numpy(np.bincount(st["idx"], minlength=len(self.alphas)).astype(np.int32))
+        st["used"] = [a for a in range(len(self.alphas)) if count[a] > 0]
+        st["used_all"] = [a for a, c in enumerate(self.shard.all_reduce_(count.clone(), "sum").tolist()) if c > 0]
+        assert set(st["used"]) <= set(st["used_all"])
+        return st
+    def fold_speculate(self, st, alphas_idx):
+        pass
+    def fold_finish(self, st, scale):
+        tr, te, idx = st["tr"], st["te"], st["idx"]
+        Xtr, Ytr = self.X[tr], self.Y[tr]
         W = oridge.ridge_weights(Xtr, Ytr, torch.tensor([self.alphas[i] for i in idx], dtype=torch.float32), 1e-10, self.normalpha)
         pred = (self.X[te] @ W).numpy().astype(np.float64); yt = self.Y[te].numpy().astype(np.float64)
         pc, yc = pred - pred.mean(0), yt - yt.mean(0)
         with np.errstate(all="ignore"):
             r = (pc * yc).sum(0) / np.sqrt((pc ** 2).sum(0) * (yc ** 2).sum(0))
         self.W += scale * W.numpy()
-        from litcoder_core_amd import stats
-        return ncv._FoldResult(r, stats.pearson_pvalues(r.astype(np.float32), len(te)), idx, len(te))
-    def begin_fit(self):
-        pass
-    def precompute_lmax(self, outer):
-        return [None] * len(outer)
-    def fold_prepare(self, tr, te, inner, lmax_pre=None, chol_after=None):
-        return (tr, te, inner)
-    def fold_begin(self, tr, te, inner, prepared=None):
-        return (tr, te, inner)
-    def fold_refit(self, st, single_alpha, scale):
-        return self.run_fold(*st, single_alpha, scale)
-    def fold_select(self, st, single_alpha):
-        return (st, single_alpha)
-    def fold_finish(self, sel, scale):
-        return self.run_fold(*sel[0], sel[1], scale)
+        p = stats.pearson_pvalues(r.astype(np.float32), len(te))
+        rp = self.shard.allgather_cols(np.stack([r, p]), self.V_total)
+        gi = self.shard.allgather_cols(idx[None, :], self.V_total)[0]
+        p_clean = np.where(np.isnan(rp[0].astype(np.float32)), 1.0, rp[1])
+        self.p_rows.append(p_clean)
+        return ncv._FoldResult(rp[0], rp[1], gi, len(te), stats.fdrcorrection(p_clean, alpha=self.alpha_fdr))
     def fold_collect(self, pend):
         return pend
+    def combined_significance(self):
+        pc = stats.fisher_combine(np.stack(self.p_rows))
+        sig, padj = stats.fdrcorrection(pc, alpha=self.alpha_fdr)
+        return pc, sig, padj
     def weights(self):
         return self.W
 
@@ -75,9 +101,19 @@ kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=np.logs
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     dist.init_process_group("gloo")
     shard = ShardContext()
-    assert shard.world == 2
-    m, W, a = ncv.NestedCVModel("r", shard=shard).fit_predict(X, Y, **kw)
+    assert shard.world == 2 and shard.backend == "gloo"
+    # ---- the collectives themselves, on host tensors
+    r = shard.rank
+    g = shard.all_gather(torch.full((2, 3), float(r)))
+    assert g.shape == (2, 2, 3) and torch.equal(g[0], torch.zeros(2, 3)) and torch.equal(g[1], torch.ones(2, 3))
+    t = torch.tensor([1.0 + r, 10.0 * (r + 1)], dtype=torch.float64)
+    assert shard.all_reduce_(t.clone(), "sum").tolist() == [3.0, 30.0] and shard.all_reduce_(t.clone(), "max").tolist() == [2.0, 20.0]
     lo, hi = shard.bounds(37)
+    cols = shard.allgather_cols(np.arange(lo, hi, dtype=np.float64)[None, :] * 2.0, 37)
+    assert np.array_equal(cols[0], 2.0 * np.arange(37)) and list(shard.all_bounds(37)) == [0, 19, 37]
+    assert shard.allreduce_sum(np.array([r + 1.0, 0.5])).tolist() == [3.0, 1.0]
+    # ---- the driver loop
+    m, W, a = ncv.NestedCVModel("r", shard=shard).fit_predict(X, Y, **kw)
     assert W.shape == (12, hi - lo)
     # train/test mode through the same sharded path
     m2, W2, a2 = ncv.NestedCVModel("r", shard=shard).fit_predict(X[:90], Y[:90], X_test=X[90:], y_test=Y[90:], **kw)
@@ -89,6 +125,25 @@ else:
     m2, W2, a2 = ncv.NestedCVModel("r").fit_predict(X[:90], Y[:90], X_test=X[90:], y_test=Y[90:], **kw)
     pickle.dump(dict(m=m, W=W, a=a, m2=m2, a2=a2), open(os.path.join(sys.argv[3], f"single_{mode}.pkl"), "wb"))
 '''
+
+
+def test_job_share_and_bounds_partition():
+    """Every job / voxel belongs to exactly one rank, slots of the gathered buffer are the job numbers."""
+    from litcoder_core_amd.dist import ShardContext, job_share, shard_bounds
+    for n in (0, 1, 4, 7, 20, 24, 100):
+        for world in (1, 2, 3, 8):
+            n_per = job_share(n, world, 0)[0]
+            jobs = [j for r in range(world) for j in job_share(n, world, r)[1]]
+            assert jobs == list(range(n)) and world * n_per >= n
+            assert all(len(job_share(n, world, r)[1]) <= n_per for r in range(world))
+            for r in range(world):
+                assert all(j // n_per == r for j in job_share(n, world, r)[1])      # slot j = job j
+            assert [shard_bounds(n, world, r)[1] for r in range(world)][-1] == n
+    sim = ShardContext.simulated(8, 3)
+    assert (sim.world, sim.rank, sim.simulate) == (8, 3, True) and sim.bounds(80000) == (30000, 40000)
+    import torch
+    g = sim.all_gather(torch.arange(4.0))
+    assert g.shape == (8, 4) and torch.equal(g[5], torch.arange(4.0))                 # local copies, timing studies only
 
 
 @pytest.mark.parametrize("mode", ["pervoxel", "single"])

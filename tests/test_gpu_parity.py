@@ -396,7 +396,7 @@ def test_speculative_refit_systems_are_neutral(lc):
         return real(self, st, list(alphas_idx)[:1])       # an incomplete guess: the rest is solved after the choice
 
     out = {}
-    for name, fn in (("spec", spy), ("partial", partial), ("none", None)):
+    for name, fn in (("spec", spy), ("partial", partial), ("none", lambda self, st, alphas_idx: None)):
         ncv.RidgeCVEngine.fold_speculate = fn
         try:
             out[name] = lc.NestedCVModel("ridge_regression").fit_predict(features=X, targets=Y, **kw)
@@ -449,7 +449,7 @@ def test_refit_with_large_alphas_polynomial_route(lc):
         np.testing.assert_allclose(W[:, sel], Wo[:, sel], rtol=2e-4, atol=3e-6 * scale, err_msg=f"alpha {a}")
 
 
-def test_device_statistics_tail_matches_host(lc):
+def test_device_statistics_tail_matches_host(lc):  # noqa: C901
     """lc_fisher_combine / lc_bh_fdr against their host twins (stats.py, themselves pinned by known-answer vectors):
     BH-FDR is the same IEEE arithmetic on the same sorted values -> identical; Fisher differs by libm rounding."""
     from litcoder_core_amd import ops, stats
@@ -472,24 +472,48 @@ def test_device_statistics_tail_matches_host(lc):
     want = stats.fisher_combine(P)
     assert got[10] == 1.0 and got[11] == 0.0 and want[11] == 0.0
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
-    # the voxel-shard route: per-fold BH-FDR and the final Fisher + BH-FDR on p-values gathered from all ranks
-    from litcoder_core_amd.nested_cv import RidgeCVEngine
-    from litcoder_core_amd import ShardContext
-    eng = RidgeCVEngine(rng.standard_normal((64, 8)), rng.standard_normal((64, 16)), [1.0, 10.0], True, True, False, False,
-                        shard=ShardContext(device=dev))
-    eng.alpha_fdr = 0.05
-    folds = [rng.uniform(0, 1, 30000) ** 6 for _ in range(3)]
-    for pf in folds:
-        rej, adj = eng.gathered_significance(pf)
-        rej_h, adj_h = stats.fdrcorrection(pf, alpha=0.05)
-        np.testing.assert_array_equal(rej, rej_h)
-        np.testing.assert_array_equal(adj, adj_h)
-    pc, rej, adj = eng.gathered_combined()
-    pc_h = stats.fisher_combine(np.stack(folds))
-    np.testing.assert_allclose(pc, pc_h, rtol=1e-12, atol=0)
-    rej_h, adj_h = stats.fdrcorrection(pc, alpha=0.05)
-    np.testing.assert_array_equal(rej, rej_h)
-    np.testing.assert_array_equal(adj, adj_h)
+    # the voxel-shard route: every rank packs its fold results (lc_fold_pack: alpha-sorted r / p -> natural order, alpha
+    # index, pivot flags), the blocks are all-gathered, lc_fold_unpack rebuilds the V_total-long vectors (ragged shard
+    # widths, NaN r -> p = 1, OR of the flags) that the global BH-FDR / Fisher kernels above then consume
+    from litcoder_core_amd.dist import shard_bounds
+    V_total, world = 1003, 3
+    lo = np.asarray([shard_bounds(V_total, world, r)[0] for r in range(world)] + [V_total], dtype=np.int64)
+    w_max = int(np.diff(lo).max())
+    r_all = rng.uniform(-1, 1, V_total)
+    r_all[[3, 400, 1002]] = np.nan
+    p_all = rng.uniform(0, 1, V_total) ** 5
+    idx_all = rng.integers(0, 7, V_total).astype(np.int32)
+    blocks = []
+    for rk in range(world):
+        V = int(lo[rk + 1] - lo[rk])
+        perm = np.full(V + 40, -1, dtype=np.int32)                     # alpha-sorted order with padding slots
+        slots = np.sort(rng.choice(V + 40, size=V, replace=False))
+        perm[slots] = rng.permutation(V)
+        live = perm >= 0
+        r_s, p_s = np.zeros(V + 40), np.zeros(V + 40)
+        r_s[live], p_s[live] = r_all[lo[rk] + perm[live]], p_all[lo[rk] + perm[live]]
+        blk = torch.empty((4, w_max), dtype=torch.float64, device=dev)
+        info_a = torch.zeros(5, dtype=torch.int32, device=dev)
+        info_b = torch.tensor([0, 7 if rk == 1 else 0], dtype=torch.int32, device=dev)    # rank 1: a refit pivot failed
+        ops.fold_pack(torch.from_numpy(r_s).to(dev), torch.from_numpy(p_s).to(dev), torch.from_numpy(perm).to(dev), V + 40,
+                      torch.from_numpy(idx_all[lo[rk]:lo[rk + 1]].copy()).to(dev), V, info_a, info_b, blk)
+        blocks.append(blk)
+    d_r, d_p, d_pc = (torch.empty(V_total, dtype=torch.float64, device=dev) for _ in range(3))
+    d_idx = torch.empty(V_total, dtype=torch.int32, device=dev)
+    d_bad = torch.empty(2, dtype=torch.int32, device=dev)
+    ops.fold_unpack(torch.stack(blocks), world, w_max, torch.from_numpy(lo).to(dev), w_max, d_r, d_p, d_idx, d_pc, d_bad)
+    np.testing.assert_array_equal(d_r.cpu().numpy(), r_all)
+    np.testing.assert_array_equal(d_p.cpu().numpy(), p_all)
+    np.testing.assert_array_equal(d_idx.cpu().numpy(), idx_all)
+    np.testing.assert_array_equal(d_pc.cpu().numpy(), np.where(np.isnan(r_all), 1.0, p_all))
+    assert d_bad.cpu().tolist() == [0, 1]
+    rej, adj = ops.bh_fdr(d_pc, 0.05)
+    rej_h, adj_h = stats.fdrcorrection(np.where(np.isnan(r_all), 1.0, p_all), alpha=0.05)
+    np.testing.assert_array_equal(rej.cpu().numpy().astype(bool), rej_h)
+    np.testing.assert_array_equal(adj.cpu().numpy(), adj_h)
+    best = torch.empty(77, dtype=torch.int32, device=dev)                # single_alpha: argmax of the all-reduced sums
+    ops.fill_argmax(torch.tensor([0.5, np.nan, 2.0, 2.0, -1.0], dtype=torch.float64, device=dev), 5, best, 77)
+    assert best.cpu().unique().tolist() == [2]                           # first maximum, NaN never wins
 
 
 def test_fit_nested_cv_alias(lc):

@@ -1,0 +1,117 @@
+"""The sharded fit with the REAL engine (``-m gpu``).
+
+* Two ranks on the one GPU of the box: two fresh processes (torch.distributed.run, gloo backend for the exchanges --
+  RCCL refuses two ranks on one device), each with its own RidgeCVEngine on cuda:0 fitting its block of voxel
+  columns, the (fold, alpha) Cholesky systems dealt out over the two (``RidgeCVEngine._sharded_solve``) and
+  all-gathered.  Every rank must return the unsharded fit BIT FOR BIT: metrics of all voxels, chosen alphas, and its
+  own block of the weights -- per-voxel alpha and single_alpha, full CV and train/test, the moments path and the
+  per-alpha hat-matrix paths (R2 scoring, raw alphas, f32 sweep).
+* One rank through RCCL: a one-rank "nccl" group with ``always_collective`` runs the same code with every collective
+  issued as a real RCCL call on device tensors (all_gather_into_tensor of f32 / f64 blocks, all_reduce of f64 and int32
+  vectors, on the engine's auxiliary / communication streams): the calls the 8-GPU run makes, checked for API /
+  dtype / stream-ordering mistakes on the hardware we have; results identical to the plain fit.
+"""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, pickle, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from litcoder_core_amd import NestedCVModel, ShardContext
+backend, out_dir = sys.argv[2], sys.argv[3]
+torch.cuda.set_device(0)
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rng = np.random.default_rng(3)
+T, p, V = 420, 96, 777
+X = rng.standard_normal((T, p))
+Y = X @ (rng.standard_normal((p, V)) * (0.3 / np.sqrt(p)) * rng.uniform(0.0, 3.0, V)) + rng.standard_normal((T, V))
+Y[:, 5] = 1.5                                     # constant voxel: NaN r -> (0, p = 1)
+cases = {
+    "pervoxel": dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 5, 8)),
+    "single": dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 5, 8), single_alpha=True),
+    "rawalpha_r2": dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=np.logspace(0, 3, 5), normalpha=False,
+                        use_corr=False),
+    "one_alpha": dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=[0.5]),   # one refit system: row slices
+    "normalised": dict(folding_type="chunked_contiguous", n_outer_folds=3, n_inner_folds=2, chunk_length=10,
+                       alphas=np.logspace(-1, 4, 6), normalize_features=True, normalize_targets=True),
+}
+shard = None
+if backend != "none":
+    dist.init_process_group(backend, rank=int(os.environ.get("RANK", "0")), world_size=world,
+                            **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
+    shard = ShardContext(device=torch.device("cuda", 0), always_collective=(world == 1))
+    assert shard.active
+lo, hi = (shard.bounds(V) if shard else (0, V))
+out = {"lo": lo, "hi": hi}
+for name, kw in cases.items():
+    for prec in (("auto", "f32") if name == "pervoxel" else ("auto",)):
+        model = NestedCVModel("r", shard=shard, precision=prec)
+        out[name, prec, "cv"] = model.fit_predict(X, Y, **kw)
+        kw_tt = {k: v for k, v in kw.items() if k != "n_outer_folds"}
+        out[name, prec, "tt"] = model.fit_predict(X[:330], Y[:330], X_test=X[330:], y_test=Y[330:], **kw_tt)
+tag = "single" if backend == "none" else f"{backend}{world}_rank{shard.rank}"
+pickle.dump(out, open(os.path.join(out_dir, tag + ".pkl"), "wb"))
+if shard is not None:
+    dist.destroy_process_group()
+'''
+
+
+def _same(got, want, lo, hi, what):
+    (m, W, al), (m0, W0, al0) = got, want
+    assert sorted(m) == sorted(m0), what
+    for k, v in m0.items():
+        if isinstance(v, list):
+            assert np.array_equal(np.asarray(m[k]), np.asarray(v), equal_nan=True), (what, k)
+        else:
+            assert m[k] == v or (v != v and m[k] != m[k]), (what, k)
+    assert np.array_equal(al, al0), what
+    assert W.shape == (W0.shape[0], hi - lo) and np.array_equal(W, W0[:, lo:hi]), what
+
+
+@pytest.fixture(scope="module")
+def runs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("shards")
+    script = d / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500), OMP_NUM_THREADS="4",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.run([sys.executable, str(script), ROOT, "none", str(d)], check=True, env=env, timeout=900)
+    return d, script, env, pickle.load(open(d / "single.pkl", "rb"))
+
+
+def test_two_real_engine_ranks_on_one_gpu_equal_the_unsharded_fit(runs):
+    d, script, env, ref = runs
+    port = 29900 + os.getpid() % 500
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                    "127.0.0.1", "--master-port", str(port), str(script), ROOT, "gloo", str(d)], check=True, env=env,
+                   timeout=1500)
+    ranks = [pickle.load(open(d / f"gloo2_rank{r}.pkl", "rb")) for r in range(2)]
+    assert (ranks[0]["lo"], ranks[0]["hi"], ranks[1]["lo"], ranks[1]["hi"]) == (0, 389, 389, 777)
+    n = 0
+    for key, want in ref.items():
+        if not isinstance(key, tuple):
+            continue
+        for r, out in enumerate(ranks):
+            _same(out[key], want, out["lo"], out["hi"], (key, r))
+            n += 1
+    assert n == 2 * 2 * 6
+
+
+def test_one_rank_through_rccl_collectives(runs):
+    d, script, env, ref = runs
+    env = dict(env, RANK="0", WORLD_SIZE="1", MASTER_PORT=str(29950 + os.getpid() % 40))
+    subprocess.run([sys.executable, str(script), ROOT, "nccl", str(d)], check=True, env=env, timeout=900)
+    out = pickle.load(open(d / "nccl1_rank0.pkl", "rb"))
+    for key, want in ref.items():
+        if isinstance(key, tuple):
+            _same(out[key], want, 0, out["hi"], key)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Host-side timeline of one cfg2 fit: wall time the Python thread spends in each engine phase (enqueue cost and
-sync waits, no added synchronisation).  python tools/host_timeline.py [V]"""
+sync waits, no added synchronisation).  python tools/host_timeline.py [V_total [world rank]]  -- with world > 1 one
+rank of a simulated world-rank job (ShardContext.simulated: collectives are local copies) on its block of V_total."""
 import os
 import sys
 import time
@@ -13,11 +14,16 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from litcoder_core_amd import NestedCVModel, nested_cv as ncv, ops, stats  # noqa: E402
 
-V = int(sys.argv[1]) if len(sys.argv) > 1 else 80000
+from litcoder_core_amd import ShardContext  # noqa: E402
+from litcoder_core_amd.dist import shard_bounds  # noqa: E402
+V_total = int(sys.argv[1]) if len(sys.argv) > 1 else 80000
+world, rank = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1, 0)
 dev = ops.device(0)
-dX, dY, p = bench.synth_inputs(V, 0, dev)
+lo, hi = shard_bounds(V_total, world, rank)
+V = hi - lo
+dX, dY, p = bench.synth_inputs(V, rank, dev)
 alphas = np.logspace(-1, 8, bench.A)
-model = NestedCVModel("ridge_regression")
+model = NestedCVModel("ridge_regression", shard=ShardContext.simulated(world, rank, device=dev) if world > 1 else None)
 log = []
 
 
@@ -33,10 +39,11 @@ def wrap(obj, name, label=None):
     setattr(obj, name, inner)
 
 
-for n in ("fold_prepare", "fold_begin", "fold_select", "fold_finish", "fold_collect", "precompute_lmax", "weights"):
+for n in ("prepare_folds", "fold_begin", "fold_select", "fold_finish", "fold_collect", "precompute_lmax", "weights"):
     wrap(ncv.RidgeCVEngine, n)
 for n in ("choose", "_refit_groups", "_refit_systems", "_sweeps", "_hat_matrices", "_refit_apply", "_fold_data",
-          "_series_by_moments", "_shared_image", "begin_fit", "fold_choose", "fold_speculate"):
+          "_shared_image", "begin_fit", "fold_choose", "fold_speculate", "_sharded_solve", "_refit_chol",
+          "combined_significance"):
     wrap(ncv.RidgeCVEngine, n, "    . " + n)
 for n in ("fdrcorrection", "fisher_combine", "full_cv_metrics"):
     wrap(stats, n)
@@ -44,7 +51,7 @@ wrap(ncv, "_fold_lists")
 
 
 def run():
-    return model.fit_predict_device(dX, dY, p, V, alphas=alphas, **bench.FIT_KW)
+    return model.fit_predict_device(dX, dY, p, V, n_voxels_total=V_total, alphas=alphas, **bench.FIT_KW)
 
 
 run()
