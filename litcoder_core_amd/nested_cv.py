@@ -1102,6 +1102,7 @@ class NestedCVModel(BasePredictivityModel):
         super().__init__(model_name)
         self.shard = shard
         self.precision = precision
+        self.last_fold_alphas = None
 
     def fit_predict(
         self,
@@ -1257,6 +1258,9 @@ class NestedCVModel(BasePredictivityModel):
             st = st_next
         tail(pending)
         weights = eng.weights() if weights_on_host else eng.W_acc[:, : eng.V]
+        # diagnostics (not in the reference's return value): the alpha vector of every outer fold, all voxels --
+        # the returned best_alphas is their mean (nested_cv.py:293-296)
+        self.last_fold_alphas = [np.asarray(a) for a in fold_alpha]
 
         if train_test:
             sig, padj = fold_sig[0]

@@ -1,0 +1,195 @@
+"""The configurations BASELINE.json names, at their own shapes (``-m gpu``).
+
+cfg2 (the bench workload) at full size through size-independent properties; cfg3 (LeBel UTS03-like: Lanczos
+downsampling of word-level GPT-2 features -> 4 FIR delays -> per-story z-scoring -> train/test fit, p = 3072), cfg4
+(Narratives-like: T = 2226, V = 200 000 voxels) and cfg5 (Whisper-like: 1280-d x 6 delays = 7680 features, 32 alphas,
+two feature bands) against the CPU oracle on a voxel sample -- with every alpha that differs from the oracle's proven
+to be a near-tie of the oracle's own score table (tests/_oracle_check.py).  The oracle (SVD route on the CPU) costs
+seconds per SVD at these sizes, so it sees 48 voxels and, where the config leaves the fold counts open, 3 x 3 folds.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _oracle_check import assert_matches_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lc():
+    import litcoder_core_amd as pkg
+    from litcoder_core_amd import ops
+    ops.device()
+    return pkg
+
+
+def _device_problem(lc, T, F0, delays, V, seed, band_scale=None, noise=1.0, wscale=0.02):
+    """bench.py's generator on the device: X0 ~ N(0,1) -> FIR delays (HIP) -> X; Y = X W + noise, fp32, padded."""
+    from litcoder_core_amd import ops
+    dev = ops.device(0)
+    rng = np.random.default_rng(seed)
+    Xd = ops.fir_delay(torch.from_numpy(rng.standard_normal((T, F0))).to(dev), delays, False)
+    p = Xd.shape[1]
+    dX = torch.zeros((T, ops.pad_to(p, 32)), dtype=torch.float32, device=dev)
+    dX[:, :p] = Xd.to(torch.float32)
+    if band_scale is not None:
+        dX[:, :p] /= torch.as_tensor(band_scale, dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed + 1)
+    dY = torch.zeros((T, ops.pad_to(V, 128)), dtype=torch.float32, device=dev)
+    W = wscale * torch.randn((p, V), generator=g, device=dev, dtype=torch.float32)
+    dY[:, :V] = dX[:, :p] @ W + noise * torch.randn((T, V), generator=g, device=dev, dtype=torch.float32)
+    return dX, dY, p
+
+
+def test_cfg2_full_size_properties(lc):
+    """The bench workload itself (T 3000, p 3072, V 80 000, 20 alphas, 5 x 5 K-folds): every result finite, planted
+    known answers in place (a constant voxel -> r 0 / p 1 / alphas[0] in every fold; a noiseless voxel on top), the
+    metrics consistent with each other, and a 10 000-voxel block fitted alone equal to its slice of the big fit bit for
+    bit (what makes an 8-GPU shard of this job return the 1-GPU numbers)."""
+    V = 80000
+    alphas = np.logspace(-1, 8, 20)
+    kw = dict(folding_type="kfold", n_outer_folds=5, n_inner_folds=5, alphas=alphas)
+    dX, dY, p = _device_problem(lc, 3000, 768, [1, 2, 3, 4], V, seed=0)
+    dY[:, 123] = 0.75                                                     # constant voxels (one inside the block
+    dY[:, 30007] = -2.0                                                   # fitted alone below: the reference's
+    # np.mean(fold_scores) is float64 when some r was NaN and float32 otherwise, nested_cv.py:276 -- keep both alike)
+    g = torch.Generator(device=dY.device)
+    g.manual_seed(5)
+    dY[:, 456] = dX[:, :p] @ (0.05 * torch.randn(p, generator=g, device=dY.device))   # noiseless voxel
+    model = lc.NestedCVModel("r")
+    m, W, a = model.fit_predict_device(dX, dY, p, V, weights_on_host=True, **kw)
+    r = np.asarray(m["correlations"])
+    assert r.shape == (V,) and np.isfinite(r).all() and np.isfinite(W).all() and np.isfinite(a).all()
+    assert np.isfinite(np.asarray(m["p_values"])).all() and np.isfinite(np.asarray(m["corrected_p_values"])).all()
+    assert r[123] == 0.0 and m["p_values"][123] == 1.0 and a[123] == np.float32(alphas[0]) and not m["significant_mask"][123]
+    # noiseless, but p = 3072 > n = 2400 and the smallest penalty is 0.1 S[0]: far above every noisy voxel, not 1
+    assert r[456] > 0.7 and r[456] >= np.quantile(r, 0.999) and m["significant_mask"][456]
+    assert 0.3 < m["median_score"] < 0.55 and abs(m["median_score"] - float(np.median(r))) < 1e-6    # ~0.43
+    assert m["n_significant"] == int(np.sum(m["significant_mask"])) and m["n_significant"] > 0.9 * V
+    assert set(np.unique(np.concatenate(model.last_fold_alphas))) <= set(alphas.astype(np.float32))
+    lo, hi = 30000, 40000
+    blk = torch.zeros((3000, 10112), dtype=torch.float32, device=dY.device)
+    blk[:, : hi - lo] = dY[:, lo:hi]
+    m_b, W_b, a_b = lc.NestedCVModel("r").fit_predict_device(dX, blk, p, hi - lo, weights_on_host=True, **kw)
+    assert np.array_equal(np.asarray(m_b["correlations"]), r[lo:hi]) and np.array_equal(a_b, a[lo:hi])
+    assert np.array_equal(W_b, W[:, lo:hi])
+
+
+def test_cfg3_story_pipeline_train_test(lc):
+    """LeBel-UTS03-like end to end: per story, word-level 768-d features at irregular word times -> Lanczos resampling
+    to the TR grid (lc_lanczos_interp) -> 4 FIR delays (p = 3072) -> trim + per-story z-scoring -> stories[:-1] train
+    / last story tests -> nested-CV fit in train/test mode with single_alpha (example.py:104-117), V = 8192, resident on
+    the device from the FIR kernel on (StoryPipeline).  Against the oracle's own pipeline (oracle.lanczos / fir /
+    harness / nested_cv) on the first 48 voxels."""
+    import oracle.harness as oh
+    import oracle.lanczos as olz
+    import oracle.nested_cv as onc
+    rng = np.random.default_rng(17)
+    V, D = 8192, 768
+    stories = {"s%d" % i: n for i, n in enumerate((330, 290, 360, 310, 345, 300, 325, 240))}      # TRs per story
+    feats_ds, feats_ds_o, brain = {}, {}, {}
+    Wtrue = rng.standard_normal((D * 4, V)) * 0.02
+    for name, n_tr in stories.items():
+        n_words = int(7.2 * n_tr)
+        wt = np.sort(rng.uniform(0, 2.0 * n_tr, n_words))
+        tr_times = 1.0 + 2.0 * np.arange(n_tr + 15)                                            # features 15 TRs longer
+        emb = rng.standard_normal((n_words, D))
+        emb[1:] = 0.6 * emb[:-1] + 0.8 * emb[1:]                                                # smooth like LM states
+        ds = lc.Downsampler().downsample(emb, wt, tr_times, method="lanczos", window=3, cutoff_mult=1.0)
+        ds_o = olz.lanczos_interp(emb, wt, tr_times, window=3, cutoff_mult=1.0)
+        np.testing.assert_allclose(ds, ds_o, rtol=0, atol=1e-10)
+        feats_ds[name], feats_ds_o[name] = ds, ds_o
+    trimming = {"train_features_start": 10, "train_features_end": -5, "train_targets_start": 0, "train_targets_end": None,
+                "test_features_start": 10, "test_features_end": -5, "test_targets_start": 0, "test_targets_end": None}
+    delayed_o = oh.delay_all(feats_ds_o, [1, 2, 3, 4])
+    for name, n_tr in stories.items():
+        brain[name] = delayed_o[name][10:-5] @ Wtrue + rng.standard_normal((n_tr, V))
+    kw = dict(folding_type="chunked", n_inner_folds=5, chunk_length=20, alphas=np.logspace(1, 4, 10), single_alpha=True)
+    import random
+    random.seed(3)
+    model = lc.NestedCVModel("r")
+    ours = lc.StoryPipeline([1, 2, 3, 4], trimming, model=model).fit(feats_ds, brain, **kw)
+    mats = oh.train_test_matrices(delayed_o, {k: v[:, :48] for k, v in brain.items()}, trimming)
+    assert mats["Rstim"].shape == (sum(stories.values()) - 240, 3072) and mats["Pstim"].shape == (240, 3072)
+    # single_alpha couples the voxels (argmax of the across-voxel mean): the oracle on 48 voxels would choose from
+    # another mean, so it is GIVEN the alpha the full fit chose and must reproduce weights / correlations at it ...
+    chosen = float(ours[2][0])
+    assert np.all(ours[2] == ours[2][0]) and ours[2].dtype == np.float64
+    random.seed(3)
+    oracle = onc.fit_predict(mats["Rstim"], mats["Rresp"], X_test=mats["Pstim"], y_test=mats["Presp"],
+                             **dict(kw, alphas=[chosen]))
+    np.testing.assert_allclose(np.asarray(ours[0]["correlations"])[:48], np.asarray(oracle[0]["correlations"]), atol=1e-4)
+    np.testing.assert_allclose(ours[1][:, :48], oracle[1], rtol=1e-3, atol=2e-5)
+    assert ours[0]["median_score"] > 0.15
+    # ... and per-voxel alpha on the same data is compared in full, ties proven
+    kw2 = dict(kw, single_alpha=False)
+    random.seed(3)
+    ours2 = lc.StoryPipeline([1, 2, 3, 4], trimming, model=model).fit(feats_ds, brain, **kw2)
+    detail = {}
+    random.seed(3)
+    oracle2 = onc.fit_predict(mats["Rstim"], mats["Rresp"], X_test=mats["Pstim"], y_test=mats["Presp"], detail=detail, **kw2)
+    assert_matches_oracle(lc, model, ours2, oracle2, detail, mats["Rstim"], np.hstack([mats["Rresp"]]), kw2, "cfg3",
+                          corr_atol=1e-4, w_rtol=1e-3, w_atol=1e-4, X_test=mats["Pstim"], y_test=mats["Presp"],
+                          cols=np.arange(48))
+
+
+def test_cfg4_narratives_shape_full_volume(lc):
+    """Narratives-like: T = 2226, p = 3072, V = 200 000 voxels on one GPU (the 8-GPU job's whole volume): finite
+    everywhere; a 25 000-voxel shard fitted alone equals its slice bit for bit, and so does a column-permuted copy
+    (which other voxels share a launch never matters); the first 48 voxels against the oracle (3 x 3 K-folds)."""
+    import oracle.nested_cv as onc
+    V, T = 200000, 2226
+    alphas = np.logspace(-1, 8, 20)
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=alphas)
+    dX, dY, p = _device_problem(lc, T, 768, [1, 2, 3, 4], V, seed=4)
+    model = lc.NestedCVModel("r")
+    m, W, a = model.fit_predict_device(dX, dY, p, V, weights_on_host=False, **kw)
+    r = np.asarray(m["correlations"])
+    assert r.shape == (V,) and np.isfinite(r).all() and bool(torch.isfinite(W).all()) and np.isfinite(a).all()
+    from litcoder_core_amd.dist import shard_bounds
+    lo, hi = shard_bounds(V, 8, 5)
+    blk = torch.zeros((T, 25088), dtype=torch.float32, device=dY.device)
+    blk[:, : hi - lo] = dY[:, lo:hi]
+    m_b, W_b, a_b = lc.NestedCVModel("r").fit_predict_device(dX, blk, p, hi - lo, weights_on_host=False, **kw)
+    assert np.array_equal(np.asarray(m_b["correlations"]), r[lo:hi]) and np.array_equal(a_b, a[lo:hi])
+    assert torch.equal(W_b, W[:, lo:hi])
+    perm = torch.randperm(hi - lo, device=dY.device, generator=torch.Generator(device=dY.device).manual_seed(1))
+    blk[:, : hi - lo] = dY[:, lo:hi][:, perm]
+    m_p, W_p, a_p = lc.NestedCVModel("r").fit_predict_device(dX, blk, p, hi - lo, weights_on_host=False, **kw)
+    ph = perm.cpu().numpy()
+    assert np.array_equal(np.asarray(m_p["correlations"]), r[lo:hi][ph]) and np.array_equal(a_p, a[lo:hi][ph])
+    assert torch.equal(W_p, W[:, lo:hi][:, perm])
+    X, Y = dX[:, :p].cpu().numpy().astype(np.float64), dY[:, :48].cpu().numpy().astype(np.float64)
+    detail = {}
+    oracle = onc.fit_predict(X, Y, detail=detail, **kw)
+    assert_matches_oracle(lc, model, (m, W[:, :48].cpu().numpy(), a), oracle, detail, X, Y, kw, "cfg4", corr_atol=1e-4,
+                          w_rtol=1e-3, w_atol=1e-4, cols=np.arange(48))
+    assert abs(np.median(r[:48]) - np.median(oracle[0]["correlations"])) < 1e-3
+
+
+def test_cfg5_whisper_shape_banded(lc):
+    """Whisper-like: 1280-d speech features x 6 FIR delays = 7680 columns (p > n), 32 alphas logspace(-1, 8), two feature
+    bands with penalty scales (1, 2) (BandedNestedCVModel: ridge on the rescaled design), T = 3000,
+    V = 2048: against the oracle run on the rescaled design, 48 voxels, 3 x 3 K-folds."""
+    import oracle.fir as ofir
+    import oracle.nested_cv as onc
+    rng = np.random.default_rng(23)
+    T, V = 3000, 2048
+    X = ofir.make_delayed(rng.standard_normal((T, 1280)), [1, 2, 3, 4, 5, 6])
+    assert X.shape == (T, 7680)
+    gamma = np.r_[np.full(3840, 1.0), np.full(3840, 2.0)]
+    Y = (X / gamma) @ (0.015 * rng.standard_normal((7680, V))) + rng.standard_normal((T, V))
+    alphas = np.logspace(-1, 8, 32)
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=alphas)
+    model = lc.BandedNestedCVModel("r")
+    m, W, a = model.fit_predict(X, Y, bands=[(0, 3840), (3840, 7680)], band_scales=[1.0, 2.0], **kw)
+    assert W.shape == (7680, V) and np.isfinite(W).all() and np.isfinite(np.asarray(m["correlations"])).all()
+    detail = {}
+    Xs = X / gamma
+    m_o, W_o, a_o = onc.fit_predict(Xs, Y[:, :48], detail=detail, **kw)
+    # weights come back on the ORIGINAL feature scale: w_b = w'_b / gamma_b
+    assert_matches_oracle(lc, model, (m, W * gamma[:, None].astype(np.float32), a), (m_o, W_o, a_o), detail, Xs, Y, kw,
+                          "cfg5", corr_atol=1e-4, w_rtol=1e-3, w_atol=1e-4, cols=np.arange(48))
+    assert m["median_score"] > 0.2

@@ -244,8 +244,10 @@ def test_constant_and_degenerate_voxels(lc):
 def test_randomised_shapes_against_oracle(lc):
     """Odd sizes on every axis (rows not multiples of 32/64, voxels not multiples of 128/256, p below and above
     n, a single voxel, a single alpha, uneven chunked folds, groups, time-series splits): padding and masking
-    must never leak into the results.  Compared with the oracle on the same seeded inputs."""
+    must never leak into the results.  Compared with the oracle on the same seeded inputs; a voxel whose alpha
+    differs from the oracle's must be a proven near-tie of the oracle's own score table (tests/_oracle_check.py)."""
     import oracle.nested_cv as onc
+    from _oracle_check import assert_matches_oracle
     rng = np.random.default_rng(123)
     cases = [
         dict(T=97, p=5, V=1, kw=dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=[0.5, 5.0, 50.0])),
@@ -271,22 +273,20 @@ def test_randomised_shapes_against_oracle(lc):
         kw = dict(c["kw"])
         if kw.pop("groups", False):
             kw["groups"] = rng.integers(0, 9, size=T)
+        random.seed(5 + i); np.random.seed(5 + i)
+        detail = {}
+        oracle = onc.fit_predict(X, Y, detail=detail, **kw)
+        m_o = oracle[0]
         for precision in ("auto", "f32"):
             random.seed(5 + i); np.random.seed(5 + i)
-            m_o, W_o, a_o = onc.fit_predict(X, Y, **kw)
-            random.seed(5 + i); np.random.seed(5 + i)
-            m, W, a = lc.NestedCVModel("r", precision=precision).fit_predict(X, Y, **kw)
+            model = lc.NestedCVModel("r", precision=precision)
+            m, W, a = model.fit_predict(X, Y, **kw)
             tag = f"case {i} {precision}"
-            assert W.shape == W_o.shape and a.shape == a_o.shape and sorted(m) == sorted(m_o), tag
-            same = np.isclose(a, a_o, rtol=1e-6)
-            assert same.mean() >= 0.97, tag
-            atol = 1e-3 if not kw.get("use_corr", True) else 3e-5     # R2 scores: sqrt amplification near 0
-            np.testing.assert_allclose(np.asarray(m["correlations"], dtype=np.float64)[same],
-                                       np.asarray(m_o["correlations"], dtype=np.float64)[same], rtol=0, atol=atol,
-                                       err_msg=tag)
-            np.testing.assert_allclose(W[:, same], W_o[:, same], rtol=2e-4, atol=3e-6 * max(1.0, np.abs(W_o).max()),
-                                       err_msg=tag)
-            if same.all():
+            assert W.shape == oracle[1].shape and a.shape == oracle[2].shape and sorted(m) == sorted(m_o), tag
+            r2 = not kw.get("use_corr", True)               # R2 scores: sqrt amplification of fp32 noise near 0
+            flips = assert_matches_oracle(lc, model, (m, W, a), oracle, detail, X, Y, kw, tag,
+                                          corr_atol=1e-3 if r2 else 3e-5, gap_tol=2e-3 if r2 else 2e-6, min_same=0.97)
+            if flips == 0:
                 np.testing.assert_allclose(np.asarray(m["p_values"]), np.asarray(m_o["p_values"]), rtol=5e-3, atol=1e-12,
                                            err_msg=tag)
                 assert m["n_significant"] == m_o["n_significant"], tag
@@ -624,14 +624,15 @@ def test_wide_target_scales_and_planted_signal(lc):
     X, Y = _synthetic(500, 64, 256, 8)
     Y = Y * (2.0 ** (np.arange(256) % 25 - 12)).astype(np.float32)
     kw = dict(folding_type="kfold", n_outer_folds=4, n_inner_folds=3, alphas=np.array([0.3, 1.0, 3.0, 10.0, 30.0, 100.0]))
-    m_o, W_o, a_o = onc.fit_predict(X, Y, **kw)
+    from _oracle_check import assert_matches_oracle
+    detail = {}
+    oracle = onc.fit_predict(X, Y, detail=detail, **kw)
     for precision in ("auto", "f32"):
-        m, W, a = lc.NestedCVModel("r", precision=precision).fit_predict(X, Y, **kw)
-        same = a == a_o
-        assert same.mean() >= 0.97, precision            # plateau near-ties (gaps ~1e-6) may flip
-        np.testing.assert_allclose(np.asarray(m["correlations"])[same], np.asarray(m_o["correlations"])[same],
-                                   rtol=0, atol=2e-5, err_msg=precision)
-        np.testing.assert_allclose(W[:, same], W_o[:, same], rtol=2e-4, atol=1e-6 * np.abs(W_o).max(), err_msg=precision)
+        model = lc.NestedCVModel("r", precision=precision)
+        ours = model.fit_predict(X, Y, **kw)
+        # plateau near-ties (oracle score gaps <= 2e-6, proven per voxel) may flip
+        assert_matches_oracle(lc, model, ours, oracle, detail, X, Y, kw, precision, corr_atol=2e-5, w_rtol=2e-4, w_atol=1e-6,
+                              min_same=0.97)
     X, Y = _synthetic(500, 64, 256, 8)
     Wtrue = np.random.default_rng(9).standard_normal((64,)).astype(np.float32)
     Y[:, 0] = X @ Wtrue
@@ -672,10 +673,17 @@ def test_baseline_shape_against_oracle_sample(lc):
     V = 1024
     Y = X @ (0.02 * rng.standard_normal((3072, V))) + rng.standard_normal((3000, V))
     kw = dict(folding_type="kfold", n_outer_folds=5, n_inner_folds=5, alphas=np.logspace(-1, 8, 20))
-    m, W, a = lc.NestedCVModel("r").fit_predict(X, Y, **kw)
-    m_o, W_o, a_o = onc.fit_predict(X, Y[:, :48], **kw)
+    from _oracle_check import assert_matches_oracle
+    model = lc.NestedCVModel("r")
+    m, W, a = model.fit_predict(X, Y, **kw)
+    detail = {}
+    oracle = onc.fit_predict(X, Y[:, :48], detail=detail, **kw)
+    m_o = oracle[0]
+    # north_star's fp32 bound is 1e-3; the voxels whose alpha agrees in every fold are held to 1e-4 here, and every
+    # voxel whose alpha differs must be a proven near-tie (<= 2e-6) of the oracle's own score table
+    assert_matches_oracle(lc, model, (m, W, a), oracle, detail, X, Y, kw, "cfg2 shape", corr_atol=1e-4, w_rtol=1e-3,
+                          w_atol=1e-4, min_same=0.9, cols=np.arange(48))
     got = np.asarray(m["correlations"])[:48]
-    np.testing.assert_allclose(got, np.asarray(m_o["correlations"]), rtol=0, atol=1e-3)   # north_star fp32 bound
-    assert np.mean(a[:48] == a_o) >= 0.95           # alpha picks may flip only at fp32 near-ties
+    np.testing.assert_allclose(got, np.asarray(m_o["correlations"]), rtol=0, atol=1e-3)   # all 48, flipped or not
     assert abs(np.median(got) - np.median(m_o["correlations"])) < 1e-3
     assert 0.3 < m["median_score"] < 0.55           # reference median ~0.43 on this generator
