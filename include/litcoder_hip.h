@@ -184,9 +184,29 @@ int lc_batch_assemble(const double* d_k, int64_t ldk, const int32_t* d_tr, const
 /* The same for a SUBSET of that grid (voxel shards: the (fold, alpha) systems are dealt out over the ranks, each
  * solves its share and the f32 results are all-gathered): system j of the batch is grid system s = d_sys[j]
  * (int32, B entries), built from fold s / A and penalty d_a2[s].  d_aug: (B, N+M, N). */
-int lc_batch_assemble_sel(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
-                          const double* d_rhs, const double* d_a2, const int32_t* d_sys, int B, int A,
-                          int N, int M, double* d_aug, lc_stream_t stream);
+int lc_batch_assemble_sel(const double* d_k, int64_t ldk, int64_t k_fold_stride, const int32_t* d_tr,
+                          const int32_t* d_va, const double* d_rhs, const double* d_a2, const int32_t* d_sys,
+                          int B, int A, int N, int M, double* d_aug, lc_stream_t stream);
+
+/* Primal form of the same ridge systems, for p < n/2 (SURVEY 8d "for p<n use the primal form"; what the reference's
+ * thin SVD of a tall Rstim, ridge_utils.py:52, is by construction):  pred = Pstim (Rstim'Rstim + a^2 I)^-1 Rstim'Rresp.
+ *   lc_gather_transpose_f32: d_out (F * p_pad, N) f32, block f = the rows d_rows[f][0..N) (int32, -1 = zero column)
+ *                            of X (ldx, p columns), transposed and zero-padded to p_pad rows: Rstim' of training set f;
+ *   lc_gram_blocks_f64:      d_g (n_blocks, rows_per, rows_per) f64, block b = Xt_b Xt_b' with Xt_b rows
+ *                            [b rows_per, (b+1) rows_per) of d_xt (ld ldx, `depth` columns): Rstim'Rstim of every set;
+ *   lc_gather_rows_f64:      d_out (F, M, N) f64, row i of block f = row d_rows[f][i] of X (p columns, zero padded to
+ *                            N); -1 -> zero row; -(2 + c) -> unit row e_c: the augmented rows Pstim (inner folds) /
+ *                            [I ; X_test] (refit: weights operator above the test-row hat matrix);
+ *   lc_batch_assemble_sel with k_fold_stride = rows_per^2 then takes the top block of fold f from ITS Gram matrix
+ *   (0 = one shared matrix, the dual form), and lc_lambda_max_strided does the same for S[0]^2. */
+int lc_gather_transpose_f32(const float* d_x, int64_t ldx, const int32_t* d_rows, int F, int N, int p,
+                            int p_pad, float* d_out, lc_stream_t stream);
+int lc_gram_blocks_f64(const float* d_xt, int64_t ldx, int n_blocks, int rows_per, int depth, double* d_g,
+                       lc_stream_t stream);
+int lc_gather_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_rows, int F, int M, int p, int N,
+                       double* d_out, lc_stream_t stream);
+int lc_lambda_max_strided(const double* d_k, int64_t ldk, int64_t k_stride, const int32_t* d_rows, int F, int N,
+                          int steps, double* d_work, double* d_lmax, lc_stream_t stream);
 
 /* In place on every (N+M, N) system: Cholesky of the top block, then bottom <- bottom * inv(top)
  * i.e. the hat matrices  Xva Xtr' (Xtr Xtr' + a^2 I)^-1  (= Pstim Vh' diag(S/(S^2+a^2)) U',

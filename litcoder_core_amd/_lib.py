@@ -48,7 +48,12 @@ SIGNATURES = {
     "lc_lambda_max_masked": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_penalties": (c_int, [_ptr, c_int, _ptr, c_int, c_int, _ptr, _ptr]),
     "lc_batch_assemble": (c_int, [_ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
-    "lc_batch_assemble_sel": (c_int, [_ptr, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
+    "lc_batch_assemble_sel": (c_int, [_ptr, c_int64, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, c_int, c_int, c_int, c_int, _ptr,
+                                      _ptr]),
+    "lc_gather_transpose_f32": (c_int, [_ptr, c_int64, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
+    "lc_gram_blocks_f64": (c_int, [_ptr, c_int64, c_int, c_int, c_int, _ptr, _ptr]),
+    "lc_gather_rows_f64": (c_int, [_ptr, c_int64, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
+    "lc_lambda_max_strided": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_fill_argmax": (c_int, [_ptr, c_int, _ptr, c_int64, _ptr]),
     "lc_fold_pack": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr, c_int, _ptr, c_int, _ptr, c_int64, _ptr]),
     "lc_fold_unpack": (c_int, [_ptr, c_int, c_int64, _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),

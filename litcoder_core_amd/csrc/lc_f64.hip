@@ -142,9 +142,10 @@ __global__ void __launch_bounds__(256) k_lz_init(const int* __restrict__ rows, i
 }
 
 // w = K[rows, rows] v : one wave per row.
-__global__ void __launch_bounds__(256) k_lz_symv(const double* __restrict__ Kmat, long long ldk,
+__global__ void __launch_bounds__(256) k_lz_symv(const double* __restrict__ Kmat, long long ldk, long long k_stride,
                                                  const int* __restrict__ rows, int N, int steps, double* work) {
     const int f = blockIdx.y;
+    Kmat += (long long)f * k_stride;                  // 0: every system indexes the same matrix
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= N) return;
@@ -352,12 +353,13 @@ __global__ void k_penalties(const double* __restrict__ lmax, int F, const double
 __global__ void __launch_bounds__(256) k_assemble(const double* __restrict__ Kmat, long long ldk,
                                                   const int* __restrict__ tr, const int* __restrict__ va,
                                                   const double* __restrict__ rhs, const double* __restrict__ a2,
-                                                  const int* __restrict__ sys, int A,
+                                                  const int* __restrict__ sys, long long k_fold_stride, int A,
                                                   int N, int M, double* __restrict__ aug) {
     const int i = blockIdx.x;             // row of the (N+M) x N system
     const int b = blockIdx.y;             // system of the batch being built ...
     const int sg = sys ? sys[b] : b;      // ... which is system sg = f * A + a of the full (fold, alpha) grid
     const int f = sg / A;
+    Kmat += (long long)f * k_fold_stride; // 0: one matrix for all folds (dual form); else fold f's own (primal form)
     const int* trf = tr + (long long)f * N;
     double* dst = aug + ((long long)b * (N + M) + i) * N;
     if (i < N) {
@@ -489,6 +491,91 @@ __global__ void __launch_bounds__(256) k_series_terms(const double* __restrict__
     for (int j = threadIdx.x; j < N; j += 256) dst[j] = (float)(src[j] * w);
 }
 
+
+// ---- primal form (p << n): Gram matrices of the FEATURE axis, one per training set --------------------------
+// G_s = X_s' X_s for row set s.  The sets are gathered and transposed once into a stack Xt (n_sets * p_pad rows,
+// set s = rows [s p_pad, (s+1) p_pad), column j = row rows[s][j] of X, -1 -> zero column); every set's Gram matrix
+// is then the diagonal block of Xt Xt', computed by the tile kernel below with one grid plane per set.
+__global__ void __launch_bounds__(256) k_gather_transpose_f32(const float* __restrict__ X, long long ldx,
+                                                              const int* __restrict__ rows, int N, int p, int p_pad,
+                                                              float* __restrict__ out) {
+    __shared__ float t[32][33];
+    const int f = blockIdx.z;
+    const int j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int* rw = rows + (long long)f * N;
+    for (int jj = ty; jj < 32; jj += 8) {
+        const int j = j0 + jj;
+        const int r = j < N ? rw[j] : -1;
+        const int c = c0 + tx;
+        t[jj][tx] = (r >= 0 && c < p) ? X[(long long)r * ldx + c] : 0.f;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 32; cc += 8) {
+        const int c = c0 + cc, j = j0 + tx;
+        if (c < p_pad && j < N) out[((long long)f * p_pad + c) * N + j] = t[tx][cc];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gram_blocks(const float* __restrict__ X, long long ldx, int rows_per, int depth,
+                                                     double* __restrict__ G) {
+    const int bi = blockIdx.y, bj = blockIdx.x, b = blockIdx.z;
+    if (bj > bi) return;
+    X += (long long)b * rows_per * ldx;
+    G += (long long)b * rows_per * rows_per;
+    __shared__ double sA[16 * TS_LD], sB[16 * TS_LD];
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 4;
+    const int ra = bi * 64 + lr, rb = bj * 64 + lr;
+    double acc[4][4] = {};
+    for (int k0 = 0; k0 < depth; k0 += 16) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + lk + e;
+            sA[(lk + e) * TS_LD + lr] = (ra < rows_per && k < depth) ? (double)X[(long long)ra * ldx + k] : 0.0;
+            sB[(lk + e) * TS_LD + lr] = (rb < rows_per && k < depth) ? (double)X[(long long)rb * ldx + k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            double a[4], bb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sA[k * TS_LD + ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bb[j] = sB[k * TS_LD + tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], bb[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = bi * 64 + ty * 4 + i, c = bj * 64 + tx * 4 + j;
+            if (r < rows_per && c < rows_per) {
+                G[(long long)r * rows_per + c] = acc[i][j];
+                if (bi != bj) G[(long long)c * rows_per + r] = acc[i][j];
+            }
+        }
+}
+
+// out[f][i][:] (N doubles) = row rows[f][i] of X (p columns, then zeros);  -1 -> zero row;  -(2 + c) -> unit row e_c
+__global__ void __launch_bounds__(256) k_gather_rows_f64(const float* __restrict__ X, long long ldx,
+                                                         const int* __restrict__ rows, int M, int p, int N,
+                                                         double* __restrict__ out) {
+    const int i = blockIdx.x, f = blockIdx.y;
+    const int r = rows[(long long)f * M + i];
+    double* dst = out + ((long long)f * M + i) * N;
+    for (int c = threadIdx.x; c < N; c += 256) {
+        double v = 0.0;
+        if (r >= 0) v = c < p ? (double)X[(long long)r * ldx + c] : 0.0;
+        else if (r <= -2) v = (c == -(r + 2)) ? 1.0 : 0.0;
+        dst[c] = v;
+    }
+}
 }  // namespace
 
 extern "C" int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_k, int64_t ldk,
@@ -502,22 +589,59 @@ extern "C" int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, 
     return lc::launched("k_gram");
 }
 
-extern "C" int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, int N, int steps,
-                             double* d_work, double* d_lmax, lc_stream_t stream) {
+
+extern "C" int lc_gather_transpose_f32(const float* d_x, int64_t ldx, const int32_t* d_rows, int F, int N, int p,
+                                       int p_pad, float* d_out, lc_stream_t stream) {
+    LC_REQUIRE(d_x && d_rows && d_out, LC_E_BADARG, "lc_gather_transpose_f32: null pointer");
+    LC_REQUIRE(F > 0 && F <= 65535 && N > 0 && p > 0 && p_pad >= p && ldx >= p, LC_E_SHAPE, "lc_gather_transpose_f32: bad shape");
+    dim3 grid((unsigned)lc::ceil_div(N, 32), (unsigned)lc::ceil_div(p_pad, 32), (unsigned)F);
+    hipLaunchKernelGGL(k_gather_transpose_f32, grid, dim3(256), 0, lc::as_stream(stream), d_x, (long long)ldx, d_rows, N, p,
+                       p_pad, d_out);
+    return lc::launched("k_gather_transpose_f32");
+}
+
+extern "C" int lc_gram_blocks_f64(const float* d_xt, int64_t ldx, int n_blocks, int rows_per, int depth, double* d_g,
+                                  lc_stream_t stream) {
+    LC_REQUIRE(d_xt && d_g, LC_E_BADARG, "lc_gram_blocks_f64: null pointer");
+    LC_REQUIRE(n_blocks > 0 && n_blocks <= 65535 && rows_per > 0 && depth > 0 && ldx >= depth, LC_E_SHAPE,
+               "lc_gram_blocks_f64: bad shape");
+    const unsigned nt = (unsigned)lc::ceil_div(rows_per, 64);
+    lc::ScopedTimer timer_(lc::T_GRAM, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_gram_blocks, dim3(nt, nt, (unsigned)n_blocks), dim3(256), 0, lc::as_stream(stream), d_xt,
+                       (long long)ldx, rows_per, depth, d_g);
+    return lc::launched("k_gram_blocks");
+}
+
+extern "C" int lc_gather_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_rows, int F, int M, int p, int N,
+                                  double* d_out, lc_stream_t stream) {
+    LC_REQUIRE(d_x && d_rows && d_out, LC_E_BADARG, "lc_gather_rows_f64: null pointer");
+    LC_REQUIRE(F > 0 && F <= 65535 && M > 0 && p > 0 && N >= p && ldx >= p, LC_E_SHAPE, "lc_gather_rows_f64: bad shape");
+    hipLaunchKernelGGL(k_gather_rows_f64, dim3((unsigned)M, (unsigned)F), dim3(256), 0, lc::as_stream(stream), d_x,
+                       (long long)ldx, d_rows, M, p, N, d_out);
+    return lc::launched("k_gather_rows_f64");
+}
+
+extern "C" int lc_lambda_max_strided(const double* d_k, int64_t ldk, int64_t k_stride, const int32_t* d_rows, int F,
+                                     int N, int steps, double* d_work, double* d_lmax, lc_stream_t stream) {
     LC_REQUIRE(d_k && d_rows && d_work && d_lmax, LC_E_BADARG, "lc_lambda_max: null pointer");
-    LC_REQUIRE(F > 0 && N > 0 && steps > 0, LC_E_SHAPE, "lc_lambda_max: bad shape");
+    LC_REQUIRE(F > 0 && F <= 65535 && N > 0 && steps > 0 && k_stride >= 0, LC_E_SHAPE, "lc_lambda_max: bad shape");
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_LAMBDA_MAX, s);
     hipLaunchKernelGGL(k_lz_init, dim3(F), dim3(256), 0, s, d_rows, N, steps, d_work);
     if (int rc = lc::launched("k_lz_init")) return rc;
     for (int it = 0; it < steps; ++it) {
         hipLaunchKernelGGL(k_lz_symv, dim3((unsigned)lc::ceil_div(N, 4), (unsigned)F), dim3(256), 0, s, d_k,
-                           (long long)ldk, d_rows, N, steps, d_work);
+                           (long long)ldk, (long long)k_stride, d_rows, N, steps, d_work);
         hipLaunchKernelGGL(k_lz_step, dim3(F), dim3(1024), 0, s, N, steps, it, d_work);
     }
     if (int rc = lc::launched("k_lz_step")) return rc;
     hipLaunchKernelGGL(k_lz_eig, dim3(F), dim3(64), 0, s, N, steps, d_work, d_lmax);
     return lc::launched("k_lz_eig");
+}
+
+extern "C" int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, int N, int steps,
+                             double* d_work, double* d_lmax, lc_stream_t stream) {
+    return lc_lambda_max_strided(d_k, ldk, 0, d_rows, F, N, steps, d_work, d_lmax, stream);
 }
 
 extern "C" int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
@@ -556,19 +680,19 @@ extern "C" int lc_batch_assemble(const double* d_k, int64_t ldk, const int32_t* 
                "lc_batch_assemble: need N %% %d == 0, M %% %d == 0, F*A <= 65535", LC_NB, LC_MB);
     lc::ScopedTimer timer_(lc::T_ASSEMBLE, lc::as_stream(stream));
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)(N + M), (unsigned)(F * A)), dim3(256), 0, lc::as_stream(stream), d_k,
-                       (long long)ldk, d_tr, d_va, d_rhs, d_a2, (const int*)nullptr, A, N, M, d_aug);
+                       (long long)ldk, d_tr, d_va, d_rhs, d_a2, (const int*)nullptr, 0ll, A, N, M, d_aug);
     return lc::launched("k_assemble");
 }
 
-extern "C" int lc_batch_assemble_sel(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
-                                     const double* d_rhs, const double* d_a2, const int32_t* d_sys, int B, int A, int N,
-                                     int M, double* d_aug, lc_stream_t stream) {
+extern "C" int lc_batch_assemble_sel(const double* d_k, int64_t ldk, int64_t k_fold_stride, const int32_t* d_tr,
+                                     const int32_t* d_va, const double* d_rhs, const double* d_a2, const int32_t* d_sys,
+                                     int B, int A, int N, int M, double* d_aug, lc_stream_t stream) {
     LC_REQUIRE(d_k && d_tr && d_a2 && d_sys && d_aug && (d_va || d_rhs), LC_E_BADARG, "lc_batch_assemble_sel: null pointer");
     LC_REQUIRE(B > 0 && B <= 65535 && A > 0 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
                "lc_batch_assemble_sel: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
     lc::ScopedTimer timer_(lc::T_ASSEMBLE, lc::as_stream(stream));
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)(N + M), (unsigned)B), dim3(256), 0, lc::as_stream(stream), d_k,
-                       (long long)ldk, d_tr, d_va, d_rhs, d_a2, d_sys, A, N, M, d_aug);
+                       (long long)ldk, d_tr, d_va, d_rhs, d_a2, d_sys, (long long)k_fold_stride, A, N, M, d_aug);
     return lc::launched("k_assemble");
 }
 

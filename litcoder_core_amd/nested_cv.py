@@ -46,6 +46,8 @@ LAST_SWEEP = {"precision": None,    # arithmetic the most recent alpha sweep ran
 
 SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singcutoff enters a prediction with weight
                                     # S^2 / (S^2 + a^2) <= (singcutoff / a)^2: below 1e-6 it is invisible in fp32
+PRIMAL_MAX_SCALE_RATIO = 64.0       # ... and whose feature column norms lie within this factor of each other (fp16x3)
+PRIMAL_MAX_P = 512                  # the primal (p x p) form is taken for tall designs up to this many features
 MAX_ALPHAS = 64                     # lc_group_by_alpha / the grouped GEMMs carry at most 64 alpha groups per launch
 MAX_INNER_FOLDS = 64                # the series chain runs the inner folds as column groups of one grouped launch
 
@@ -82,6 +84,10 @@ def check_penalties(alphas, singcutoff, normalpha, n_inner_folds=None):
             f"singcutoff={sc:g} is not negligible against the smallest penalty a={al.min():g} (need singcutoff <= "
             f"{SINGCUTOFF_REL:g} a): the reference would drop singular values <= singcutoff "
             "(encoding/models/ridge_utils.py:44-63), this implementation never truncates")
+
+
+class _PrimalUnsuitable(Exception):
+    """Raised while preparing a fit in the primal form when the data rule it out; the driver falls back to the dual."""
 
 
 class BasePredictivityModel:
@@ -150,7 +156,11 @@ class RidgeCVEngine:
 
     def __init__(self, X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets,
                  shard: Optional[ShardContext] = None, lanczos_steps: int = LANCZOS_STEPS, precision: str = "auto",
-                 singcutoff: float = 0.0, V_total: Optional[int] = None):
+                 singcutoff: float = 0.0, V_total: Optional[int] = None, min_train_rows: Optional[int] = None,
+                 form: str = "dual"):
+        """``form``: "dual" (n x n Gram / hat matrices: every shape), "primal" (p x p systems, see _prepare_primal) or
+        "auto" = primal when the design is tall, 2 p <= ``min_train_rows`` (the smallest inner training set) and
+        p <= PRIMAL_MAX_P."""
         check_penalties(alphas, singcutoff, normalpha)
         self.singcutoff = float(singcutoff)
         self.dev = ops.device()
@@ -174,16 +184,21 @@ class RidgeCVEngine:
         if precision not in ("auto", "f32", "f16x3"):
             raise ValueError(f"precision must be 'auto', 'f32' or 'f16x3', got {precision!r}")
         self.precision = precision
+        if form not in ("dual", "primal", "auto"):
+            raise ValueError(f"form must be 'dual', 'primal' or 'auto', got {form!r}")
+        self.primal = form == "primal" or (form == "auto" and min_train_rows is not None
+                                           and 2 * self.p <= int(min_train_rows) and self.p <= PRIMAL_MAX_P)
+        self.PP = ops.pad_to(self.p, LC_NB)            # primal: padded system size
         self.dX = self._resident(X_all, self.p_pad)
         self.dY = self._resident(Y_all, self.Vp)
         # the Gram matrix first: the host-side set-up below (polynomial coefficients, index tables) runs beside it
-        self.K = None if self.norm_x else ops.gram(self.dX, self.Ttot, self.p)
+        self.K = None if (self.norm_x or self.primal) else ops.gram(self.dX, self.Ttot, self.p)
         self.d_alphas = ops.upload(np.asarray(self.alphas, dtype=np.float64), self.dev)
         # alphas whose penalty dwarfs the spectrum take the polynomial form of the inverse (shared matrix powers,
         # minimax coefficients: series.py), the rest the batched Cholesky.  Needs normalpha (a^2 = alpha^2 lambda_max
         # makes the coefficients a function of alpha alone).
-        self.ser = [a for a in range(self.A)
-                    if self.normalpha and series.residual_bound(self.alphas[a], SERIES_TERMS) <= SERIES_TOL]
+        self.ser = [a for a in range(self.A) if not self.primal       # primal: every alpha is a tiny p x p factorisation
+                    and self.normalpha and series.residual_bound(self.alphas[a], SERIES_TERMS) <= SERIES_TOL]
         self.cho = [a for a in range(self.A) if a not in self.ser]
         self.d_ser = ops.upload(np.asarray(self.ser, dtype=np.int32), self.dev) if self.ser else None
         self.coef_host = (np.stack([series.minimax_inverse_coefficients(self.alphas[a], SERIES_TERMS)
@@ -323,7 +338,7 @@ class RidgeCVEngine:
         matrix; [None, ...] when there is nothing to share (no normalpha, or normalize_features gives every
         outer fold its own Gram matrix -- fold_prepare then runs the fold's systems by itself).  The inner-fold
         values of consecutive outer folds are neighbours in one vector (prepare_folds takes slices spanning folds)."""
-        if not self.normalpha or self.norm_x:
+        if not self.normalpha or self.norm_x or self.primal:
             return [None] * len(outer)
         inner_sets, outer_sets, spans = [], [], []
         for tr_rows, _, inner_rel in outer:
@@ -496,6 +511,8 @@ class RidgeCVEngine:
         contraction of the shared series terms and the moment kernel for the alphas on the series.  ``done``: event
         after which the hat matrices are complete; the series part only waits for ``hat["series_ready"]`` and
         runs first, so the main stream has work while the auxiliary stream is still in the Cholesky chains."""
+        if self.primal:
+            return self._sweeps_primal(hat, Y, done)
         A, N, M, tr, va, n_v = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"]
         F = hat["F"]
         moments, cho = hat["moments"], hat["cho"]
@@ -636,9 +653,16 @@ class RidgeCVEngine:
         return LC_MB * g
 
     def _refit_rhs(self, X, K, tr_rows, tr_o, te_rows):
-        """The augmented rows of the refit systems, fp64 (rows, N_o):  Xtr' above K[te,tr]."""
+        """The augmented rows of the refit systems, fp64 (rows, N_o):  Xtr' above K[te,tr]  (primal form: the identity
+        above X_te -- the weights ARE (G + a^2 I)^-1 B)."""
         n_o, n_t = len(tr_rows), len(te_rows)
         N_o = tr_o.shape[-1]
+        if self.primal:
+            rows = ops.pad_to(self.PP + ops.pad_to(n_t, LC_MB), self._refit_row_granule())
+            idx = np.full(rows, -1, dtype=np.int64)
+            idx[: self.p] = -(2 + np.arange(self.p))                      # unit rows e_c
+            idx[self.PP:self.PP + n_t] = np.asarray(te_rows, dtype=np.int64)
+            return ops.gather_rows_f64(X, ops.idx_tensor(idx, rows, self.dev), 1, rows, self.p, self.PP)[0]
         rows = ops.pad_to(self.p_pad + ops.pad_to(n_t, LC_MB), self._refit_row_granule())
         rhs = torch.zeros((rows, N_o), dtype=torch.float64, device=self.dev)
         ops.transpose_rows(X, tr_o, N_o, self.p, rhs)
@@ -692,7 +716,7 @@ class RidgeCVEngine:
         G = len(used)
         used_all = list(used) if used_all is None else list(used_all)
         n_o = len(tr_rows)
-        N_o = ops.pad_to(n_o, LC_NB)
+        N_o = ops.pad_to(n_o, LC_NB) if tr_o is None else tr_o.shape[-1]
         if tr_o is None:
             tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
             lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
@@ -746,7 +770,7 @@ class RidgeCVEngine:
         rows_s = ops.idx_tensor(np.concatenate([tr_rows, np.full(N_o - n_o, -1), np.asarray(extra_rows, dtype=np.int64)]),
                                 N_o + n_x, self.dev)
         Ys = torch.empty((N_o + n_x, Vs), dtype=torch.float32, device=self.dev)
-        ops.gather(Y, self.Vp, rows_s, N_o + n_x, perm, Vs, Ys)
+        ops.gather(Y, Y.stride(0), rows_s, N_o + n_x, perm, Vs, Ys)
         o = dict(Ys=Ys, N_o=N_o, n_o=n_o, Vs=Vs, tiles=tiles, Malpha=Malpha, split=split)
         if split:
             cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)
@@ -817,7 +841,7 @@ class RidgeCVEngine:
         sub = dict(hat)
         sub.update(F=Fo, n_v=hat["n_v"][s:s + Fo], n_i=hat["n_i"][s:s + Fo], tr=hat["tr"][s:s + Fo], va=hat["va"][s:s + Fo],
                    lmax=None if hat["lmax"] is None else hat["lmax"][s:s + Fo], a2=hat["a2"][s * self.A:(s + Fo) * self.A],
-                   shared=self._shared_image(inner_abs, hat["N"]),
+                   shared=self._shared_image(inner_abs, hat["N"]), xt_off=hat.get("xt_off", 0) + s,
                    Hs=[(0, Fo, None if H is None else H[s * per:(s + Fo) * per], None if P is None else P[s:s + Fo])])
         return sub
 
@@ -845,7 +869,9 @@ class RidgeCVEngine:
             metas.append(dict(tr=tr_rows, te=te_rows, inner_abs=inner_abs, N=N, M=M))
         # groups of consecutive folds prepared as one batch: shared data (no per-fold normalisation), equal padded
         # sizes, neighbouring precomputed lmax, and the whole group's fp64 systems within the memory budget
-        groups, batchable = [], not (self.norm_x or self.norm_y) and (not self.normalpha or all(l is not None for l in lmax_pre))
+        groups = []
+        batchable = not (self.norm_x or self.norm_y) and (self.primal or not self.normalpha
+                                                           or all(l is not None for l in lmax_pre))
         for i, m in enumerate(metas):
             g = groups[-1] if groups else None
             per_fold = (m["N"] + m["M"]) * m["N"] * 8 * max(len(self.cho), 1) * len(m["inner_abs"])
@@ -865,6 +891,9 @@ class RidgeCVEngine:
                 # S[0]^2 of the inner train sets and of the whole outer-train block (refit penalty scale,
                 # independent of the alpha choice): precomputed for the whole fit, or one run for this fold
                 lmax_i, lmax_os = None, [None] * len(g)
+                if self.primal:
+                    self._prepare_primal(g, metas, X, Y, cs, split, data_ready, out, main)
+                    continue
                 if self.normalpha:
                     if lmax_pre[g[0]] is None:
                         m = metas[g[0]]
@@ -895,6 +924,153 @@ class RidgeCVEngine:
                     if t is not None and t.is_cuda:
                         t.record_stream(main)              # allocated on aux, consumed on main
         return out
+
+    # -------------------------------------------------------------- primal form (tall designs, p << n)
+    def _prepare_primal(self, g, metas, X, Y, cs, split, data_ready, out, main):
+        """prepare_folds for a group of outer folds in the PRIMAL form: with G = Rstim'Rstim (p x p),
+            pred_alpha = Pstim (G + a^2 I)^-1 Rstim'Rresp  =:  A_alpha B ,   B = Rstim'Rresp  (p x V),
+        the same quantity the reference forms through its thin SVD of a tall Rstim (rank p, ridge_utils.py:52;
+        ridge_regression.py:104-120) and the dual route forms through n x n systems.  Per training set one p x p Gram
+        matrix (lc_gram_blocks_f64 on the gathered, transposed design), S[0]^2 by Lanczos on it, and per (fold, alpha)
+        an augmented p x p Cholesky system whose augmented rows are Pstim -- the same batched solver, the same sharding.
+        The V-wide part (B by one contraction over the training rows, then the fused sweep of depth p) is
+        _sweeps_primal."""
+        PP, p, A = self.PP, self.p, self.A
+        inner_all = [ia for i in g for ia in metas[i]["inner_abs"]]
+        F = len(inner_all)
+        n_i = [len(t) for t, _ in inner_all]
+        n_v = [len(v) for _, v in inner_all]
+        M = ops.pad_to(max(n_v), LC_MB)
+        sets = [t for t, _ in inner_all] + [metas[i]["tr"] for i in g]       # inner training sets, then the outer ones
+        Nmax = ops.pad_to(max(len(t) for t in sets), LC_NB)
+        rows_all = ops.idx_matrix(sets, Nmax, self.dev)                      # (S, Nmax)
+        S = len(sets)
+        Xt = ops.gather_transpose_f32(X, rows_all, S, Nmax, p, PP)           # (S * PP, Nmax): Rstim' of every set
+        G = ops.gram_blocks(Xt, S, PP, Nmax)                                 # (S, PP, PP) f64
+        ident = ops.idx_matrix([np.arange(p)] * S, PP, self.dev)             # rows / columns of a system: 0..p-1
+        lmax = ops.lambda_max_strided(G, PP, PP * PP, ident, S, PP, self.steps) if self.normalpha else None
+        self._check_singcutoff(lmax)
+        self._check_feature_scales(G[F])
+        a2 = ops.penalties(None if lmax is None else lmax[:F], F, self.d_alphas, self.normalpha)
+        va = ops.idx_matrix([v for _, v in inner_all], M, self.dev)
+        rhs = ops.gather_rows_f64(X, va, F, M, p, PP)                        # (F, M, PP): Pstim of every inner fold
+
+        def assemble(jobs):                                                  # job = system f * A + a of the grid
+            aug = torch.empty((len(jobs), PP + M, PP), dtype=torch.float64, device=self.dev)
+            sysv = ops.upload(np.asarray(jobs, dtype=np.int32), self.dev)
+            ops.batch_assemble_sel(G, ident, None, rhs, a2, sysv, len(jobs), A, PP, M, aug, k_fold_stride=PP * PP)
+            return aug
+
+        H, info = self._sharded_solve(F * A, PP, M, assemble)                # (>= F * A, M, PP) f32: A_alpha
+        hat = dict(F=F, N=PP, M=M, n_v=n_v, n_i=n_i, tr=rows_all[:F], va=va, shared=None, Hs=[(0, F, H, None)],
+                   info=info, lmax=None if lmax is None else lmax[:F], a2=a2, cho=list(range(A)), ser=[], d_ser=None,
+                   moments=False, series_ready=None, cs=cs, split=split, data_ready=data_ready, Xt=Xt, Nmax=Nmax,
+                   xt_off=0)
+        done = torch.cuda.Event()
+        s = 0
+        for k, i in enumerate(g):
+            m = metas[i]
+            Fo = len(m["inner_abs"])
+            sub = hat if len(g) == 1 else self._hat_slice(hat, s, Fo, m["inner_abs"])
+            sub["shared"] = None
+            s += Fo
+            out[i] = dict(tr=m["tr"], te=m["te"], X=X, Y=Y, K=G[F + k], cs=cs, split=split, hat=sub, done=done,
+                          tr_o=ident[:1], lmax_o=None if lmax is None else lmax[F + k:F + k + 1],
+                          Xt_o=Xt[(F + k) * PP:(F + k + 1) * PP], tr_o_rows=rows_all[F + k], Nmax=Nmax)
+        done.record()
+        for t in (X, Y, cs, Xt, G, ident, lmax, a2, va, rows_all, rhs, H, info):
+            if t is not None and t.is_cuda:
+                t.record_stream(main)                      # allocated on aux, consumed on main
+
+    def _check_feature_scales(self, G_o):
+        """The primal V-wide contraction sums over FEATURES: with the fp16 hi/lo operands (22 bits relative to a
+        row's / column's largest entry) a feature whose scale is orders of magnitude below another's would lose
+        its digits.  One look at the column norms (the Gram diagonal; a p-long copy to the host)."""
+        if self.precision == "f32":
+            return
+        d = torch.sqrt(G_o.diagonal()[: self.p]).cpu().numpy()
+        d = d[d > 0]
+        if d.size and float(d.max() / d.min()) > PRIMAL_MAX_SCALE_RATIO:
+            raise _PrimalUnsuitable(f"feature column norms span a factor {float(d.max() / d.min()):.3g}")
+
+    def _sweeps_primal(self, hat, Y, done=None):
+        """_sweeps in the primal form: per inner fold  B = Rstim'Rresp  (one plain contraction over the training rows,
+        p_pad x V), then the fused sweep of all alphas at depth p_pad:  pred_alpha = A_alpha B, scored in the epilogue
+        exactly as in the dual form (same kernel, same validation statistics)."""
+        A, PP, M, tr, va, n_v, n_i = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"], hat["n_i"]
+        F, Xt, Nmax, off = hat["F"], hat["Xt"], hat["Nmax"], hat["xt_off"]
+        (_, _, H, _), = hat["Hs"]
+        main = torch.cuda.current_stream()
+        split, cs = hat["split"], hat["cs"]
+        if hat.get("data_ready") is not None:
+            main.wait_event(hat["data_ready"])
+        if done is not None:
+            main.wait_event(done)
+        LAST_SWEEP.update(precision="f16x3" if split else "f32", fused_alphas=A, series_terms=0)
+        scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
+        part = torch.empty((A * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
+        ystat = torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev)
+        yblk = torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
+        yv = torch.empty((M, self.Vp), dtype=torch.float32, device=self.dev)
+        Vt = ops.pad_to(self.Vp, 256)
+        B = torch.zeros((PP, Vt), dtype=torch.float32, device=self.dev)
+        ident = ops.idx_tensor(np.arange(self.p), PP, self.dev)
+        if split:
+            At = torch.empty(256 * Nmax * 2, dtype=torch.float16, device=self.dev)
+            rs_a = torch.empty(256, dtype=torch.float32, device=self.dev)
+            Yt = torch.empty(Vt * Nmax * 2, dtype=torch.float16, device=self.dev)
+            cs_inv = torch.ones(Vt, dtype=torch.float32, device=self.dev)
+            cs_inv[: self.Vp] = cs[self.Vp:]
+            Bt = torch.empty(Vt * PP * 2, dtype=torch.float16, device=self.dev)
+            rows_pad = ops.pad_to(A * M, 256)
+            Ht = torch.empty(rows_pad * PP * 2, dtype=torch.float16, device=self.dev)
+            rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
+        for f in range(F):
+            Ni = ops.pad_to(n_i[f], 2 * K_TILE)                                   # contraction depth, padded rows are -1
+            Xt_f = Xt[(off + f) * PP:(off + f + 1) * PP]
+            ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk, yv)
+            if split:
+                ops.split_cols_f16(Y, self.Vp, tr[f], Ni, cs, Yt)
+                ops.split_rows_f16(Xt_f, PP, Ni, At, rs_a)
+                ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, B, Vt, Vt, Ni, [0, Vt // 256])
+                csB, _ = ops.col_scales_f16(B, self.p, self.Vp)
+                ops.split_cols_f16(B, self.Vp, ident, PP, csB, Bt)
+                ops.split_rows_f16(H[f * A:(f + 1) * A].reshape(A * M, PP), A * M, PP, Ht, rs_inv)
+                ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, PP, Bt, csB[self.Vp:], yv, self.Vp, n_v[f], ystat, yblk,
+                                             self.mode, part, scores, accumulate=f > 0)
+            else:
+                ops.gemm_grouped(Xt_f, Nmax, 0, Y, self.Vp, tr[f], B, Vt, PP, self.Vp, Ni, [0, self.Vp // COL_TILE])
+                ops.alpha_sweep_scores(H[f * A:(f + 1) * A], A, M, PP, B, self.Vp, ident, yv, n_v[f], ystat, yblk,
+                                       self.mode, part, scores, accumulate=f > 0)
+        self.sweeps_done = torch.cuda.Event()
+        self.sweeps_done.record()
+        return scores
+
+    def _primal_refit_inputs(self, st):
+        """The primal refit contracts over features:  [ (G + a^2 I)^-1 ; X_te (G + a^2 I)^-1 ] . B_o  with
+        B_o = Rstim'Rresp of the outer training block.  Returns the stand-ins for (Y, training rows, test rows, column
+        scales) that _refit_operands takes in the dual form: the (p_pad + n_t) x V matrix [B_o ; Y_te]."""
+        PP, Y, te = self.PP, st["Y"], st["te"]
+        n_t = len(te)
+        Vt = ops.pad_to(self.Vp, 256)
+        No = ops.pad_to(len(st["tr"]), 2 * K_TILE)
+        ext = torch.zeros((PP + n_t, Vt), dtype=torch.float32, device=self.dev)
+        if st["split"]:
+            At = torch.empty(256 * st["Nmax"] * 2, dtype=torch.float16, device=self.dev)
+            rs_a = torch.empty(256, dtype=torch.float32, device=self.dev)
+            Yt = torch.empty(Vt * No * 2, dtype=torch.float16, device=self.dev)
+            cs_inv = torch.ones(Vt, dtype=torch.float32, device=self.dev)
+            cs_inv[: self.Vp] = st["cs"][self.Vp:]
+            ops.split_cols_f16(Y, self.Vp, st["tr_o_rows"], No, st["cs"], Yt)
+            ops.split_rows_f16(st["Xt_o"], PP, No, At, rs_a)
+            ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, ext, Vt, Vt, No, [0, Vt // 256])
+            csB, _ = ops.col_scales_f16(ext, self.p, self.Vp)
+        else:
+            ops.gemm_grouped(st["Xt_o"], st["Nmax"], 0, Y, self.Vp, st["tr_o_rows"], ext, Vt, PP, self.Vp, No,
+                             [0, self.Vp // COL_TILE])
+            csB = None
+        ops.gather(Y, self.Vp, ops.idx_tensor(te, n_t, self.dev), n_t, None, self.Vp, ext[PP:])
+        return ext, np.arange(PP), PP + np.arange(n_t), csB
 
     @staticmethod
     def _lmax_adjacent(lmax_pre, i, j):
@@ -987,13 +1163,19 @@ class RidgeCVEngine:
         n_t = len(te_rows)
         best, perm, Vs = st["best"], st["perm"], st["Vs"]
         torch.cuda.current_stream().wait_event(st["systems_ready"])
-        o = self._refit_operands(Y, tr_rows, te_rows, perm, st["tiles"], Vs, st["Malpha"], st["split"], st["cs"])
+        row0 = self.p_pad                              # first row of the test-row hat matrix inside M_alpha
+        if self.primal:
+            row0 = self.PP
+            ext, rows_b, rows_t, csB = self._primal_refit_inputs(st)
+            o = self._refit_operands(ext, rows_b, rows_t, perm, st["tiles"], Vs, st["Malpha"], st["split"], csB)
+        else:
+            o = self._refit_operands(Y, tr_rows, te_rows, perm, st["tiles"], Vs, st["Malpha"], st["split"], st["cs"])
         Ys, N_o = o["Ys"], o["N_o"]
         info_o = st["info_o"]
         # ---- test predictions first (nested_cv.py:151,251: X_te W, here as the hat matrix of the test rows applied
         # to the same targets) and per-voxel Pearson r (:152-155, 252-257); the weight rows of the same contraction
         # follow once the fold's results are on their way to the host
-        pred = self._refit_product(o, self.p_pad, st["Malpha"].shape[1], n_t)[:n_t]
+        pred = self._refit_product(o, row0, st["Malpha"].shape[1], n_t)[:n_t]
         r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
         # ---- the fold's per-voxel results: one packed block in natural voxel order (r, p, alpha index, pivot flags),
@@ -1095,13 +1277,18 @@ class NestedCVModel(BasePredictivityModel):
     defaults, return triple and metrics keys.  ``shard`` (optional) makes the instance fit only its
     rank's block of voxel columns and gather the per-voxel results across ranks."""
 
-    def __init__(self, model_name: str, shard: Optional[ShardContext] = None, precision: str = "auto"):
+    def __init__(self, model_name: str, shard: Optional[ShardContext] = None, precision: str = "auto",
+                 form: str = "auto"):
         """``precision``: arithmetic of the V-wide alpha sweep -- "f32" (f32-input MFMA), "f16x3" (fp16
         hi/lo operands, three fp16 MFMAs per product, fp32 accumulate; fp32-level accuracy, ~3x faster) or
-        "auto" (f16x3 unless the targets' dynamic range is too wide for it; see RidgeCVEngine._target_scales)."""
+        "auto" (f16x3 unless the targets' dynamic range is too wide for it; see RidgeCVEngine._target_scales).
+        ``form``: "dual" (n x n systems), "primal" (p x p systems) or "auto" (primal for tall designs, 2 p <= the
+        smallest inner training set; see RidgeCVEngine)."""
         super().__init__(model_name)
         self.shard = shard
         self.precision = precision
+        self.form = form
+        self.last_form = None
         self.last_fold_alphas = None
 
     def fit_predict(
@@ -1214,49 +1401,63 @@ class NestedCVModel(BasePredictivityModel):
                     inner = create_folds(len(tr), folding_type, n_inner_folds, chunk_length)
                 outer.append((tr, te, inner))
 
-        eng = RidgeCVEngine(X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
-                            precision=self.precision, singcutoff=singcutoff, V_total=V_total)
-        scale = 1.0 if train_test else 1.0 / len(outer)
-        fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
-        score_rows, any_nan = [], []
+        min_train = min(len(tr_i) for _, _, inner in outer for tr_i, _ in inner)
 
-        def tail(pend):
-            """Host statistics of one finished fold; runs while the GPU works on the next fold.  The engine hands
-            over the vectors of ALL voxels: the one exchange of per-voxel results over the voxel shards (and the
-            fold's BH-FDR on them) happened on the device (RidgeCVEngine.fold_finish)."""
-            f = eng.fold_collect(pend)
-            r32 = f.r.astype(np.float32)
-            if train_test:                  # the per-fold Python lists are only returned by the train/test metrics;
-                corrs, pvals = _fold_lists(r32, f.p)        # the CV summary works on the arrays below
-                fold_scores.append(corrs)
-                fold_p.append(pvals)
-            fold_alpha.append(_alpha_vector(alphas, f.best_idx, single_alpha))
-            fold_sig.append(f.sig)
-            score_rows.append(np.nan_to_num(r32, nan=0.0))
-            any_nan.append(bool(np.isnan(r32).any()))
+        def attempt(form):
+            eng = RidgeCVEngine(X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
+                                precision=self.precision, singcutoff=singcutoff, V_total=V_total,
+                                min_train_rows=min_train, form=form)
+            scale = 1.0 if train_test else 1.0 / len(outer)
+            fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
+            score_rows, any_nan = [], []
 
-        pending = None
-        eng.alpha_fdr = alpha_fdr
-        n = len(outer)
-        eng.begin_fit(n)                                    # the one host sync of the set-up, before anything is queued
-        lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
-        # V-independent part of every fold, ahead of everything on the auxiliary stream: fold 0 by itself (its sweeps
-        # start as soon as its own systems are done), then ALL other folds as one batch
-        st = eng.fold_begin(*outer[0], prepared=eng.prepare_folds(outer[:1], lmax_pre[:1])[0])
-        prepared = eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else []
-        for i in range(n):
-            eng.fold_choose(st, single_alpha)               # main: argmax + grouping; the histogram leaves asynchronously
-            st_next = None
-            if i + 1 < n:
-                st_next = eng.fold_begin(*outer[i + 1], prepared=prepared[i])                 # main: sweeps of i+1
-            st = eng.fold_select(st, single_alpha)          # host waits for the histogram of fold i here
-            if i + 1 < n:
-                eng.fold_speculate(st_next, st["used_all"])                                   # aux: refit systems of i+1
-            if pending is not None:
-                tail(pending)
-            pending = eng.fold_finish(st, scale)            # main: V-wide refit of fold i behind those sweeps
-            st = st_next
-        tail(pending)
+            def tail(pend):
+                """Host statistics of one finished fold; runs while the GPU works on the next fold.  The engine hands
+                over the vectors of ALL voxels: the one exchange of per-voxel results over the voxel shards (and the
+                fold's BH-FDR on them) happened on the device (RidgeCVEngine.fold_finish)."""
+                f = eng.fold_collect(pend)
+                r32 = f.r.astype(np.float32)
+                if train_test:                  # the per-fold Python lists are only returned by the train/test metrics;
+                    corrs, pvals = _fold_lists(r32, f.p)        # the CV summary works on the arrays below
+                    fold_scores.append(corrs)
+                    fold_p.append(pvals)
+                fold_alpha.append(_alpha_vector(alphas, f.best_idx, single_alpha))
+                fold_sig.append(f.sig)
+                score_rows.append(np.nan_to_num(r32, nan=0.0))
+                any_nan.append(bool(np.isnan(r32).any()))
+
+            pending = None
+            eng.alpha_fdr = alpha_fdr
+            n = len(outer)
+            eng.begin_fit(n)                                    # the one host sync of the set-up, before anything is queued
+            lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
+            # V-independent part of every fold, ahead of everything on the auxiliary stream: fold 0 by itself (its sweeps
+            # start as soon as its own systems are done), then ALL other folds as one batch
+            st = eng.fold_begin(*outer[0], prepared=eng.prepare_folds(outer[:1], lmax_pre[:1])[0])
+            prepared = eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else []
+            for i in range(n):
+                eng.fold_choose(st, single_alpha)               # main: argmax + grouping; the histogram leaves asynchronously
+                st_next = None
+                if i + 1 < n:
+                    st_next = eng.fold_begin(*outer[i + 1], prepared=prepared[i])                 # main: sweeps of i+1
+                st = eng.fold_select(st, single_alpha)          # host waits for the histogram of fold i here
+                if i + 1 < n:
+                    eng.fold_speculate(st_next, st["used_all"])                                   # aux: refit systems of i+1
+                if pending is not None:
+                    tail(pending)
+                pending = eng.fold_finish(st, scale)            # main: V-wide refit of fold i behind those sweeps
+                st = st_next
+            tail(pending)
+            return eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan
+
+        try:
+            eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = attempt(self.form)
+        except _PrimalUnsuitable as why:
+            if self.form == "primal":
+                raise ValueError(f"form='primal' is not usable for these features: {why}") from None
+            logger.info("primal form not used (%s): dual form", why)
+            eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = attempt("dual")
+        self.last_form = "primal" if eng.primal else "dual"
         weights = eng.weights() if weights_on_host else eng.W_acc[:, : eng.V]
         # diagnostics (not in the reference's return value): the alpha vector of every outer fold, all voxels --
         # the returned best_alphas is their mean (nested_cv.py:293-296)

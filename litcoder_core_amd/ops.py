@@ -233,10 +233,39 @@ def batch_assemble(k, tr, va, rhs, a2, F, A, N, M, aug):
     _lib.call("lc_batch_assemble", _p(k), k.stride(0), _p(tr), _p(va), _p(rhs), _p(a2), F, A, N, M, _p(aug), _s())
 
 
-def batch_assemble_sel(k, tr, va, rhs, a2, sys, B, A, N, M, aug):
-    """System j of the batch = grid system sys[j] = fold * A + alpha (see lc_batch_assemble_sel)."""
-    _lib.call("lc_batch_assemble_sel", _p(k), k.stride(0), _p(tr), _p(va), _p(rhs), _p(a2), _p(sys), B, A, N, M, _p(aug),
-              _s())
+def batch_assemble_sel(k, tr, va, rhs, a2, sys, B, A, N, M, aug, k_fold_stride=0, ldk=None):
+    """System j of the batch = grid system sys[j] = fold * A + alpha (see lc_batch_assemble_sel); ``k_fold_stride``
+    (elements) > 0: fold f's top block comes from the matrix at k + f * stride (primal form)."""
+    _lib.call("lc_batch_assemble_sel", _p(k), k.stride(-2) if ldk is None else ldk, int(k_fold_stride), _p(tr), _p(va),
+              _p(rhs), _p(a2), _p(sys), B, A, N, M, _p(aug), _s())
+
+
+def gather_transpose_f32(x, rows, F, N, p, p_pad):
+    """(F * p_pad, N) f32: block f = X[rows[f]]' zero-padded (rows: (F, N) int32 device, -1 = zero column)."""
+    out = torch.empty((F * p_pad, N), dtype=torch.float32, device=x.device)
+    _lib.call("lc_gather_transpose_f32", _p(x), x.stride(0), _p(rows), F, N, p, p_pad, _p(out), _s())
+    return out
+
+
+def gram_blocks(xt, n_blocks, rows_per, depth):
+    """(n_blocks, rows_per, rows_per) f64: block b = Xt_b Xt_b' for the row blocks of xt (f32, ld = xt.stride(0))."""
+    g = torch.empty((n_blocks, rows_per, rows_per), dtype=torch.float64, device=xt.device)
+    _lib.call("lc_gram_blocks_f64", _p(xt), xt.stride(0), n_blocks, rows_per, depth, _p(g), _s())
+    return g
+
+
+def gather_rows_f64(x, rows, F, M, p, N):
+    """(F, M, N) f64 rows of X by index list (-1 zero row, -(2 + c) unit row e_c)."""
+    out = torch.empty((F, M, N), dtype=torch.float64, device=x.device)
+    _lib.call("lc_gather_rows_f64", _p(x), x.stride(0), _p(rows), F, M, p, N, _p(out), _s())
+    return out
+
+
+def lambda_max_strided(k, ldk, k_stride, rows, F, N, steps):
+    work = torch.empty(F * (3 * N + 2 * steps + 8), dtype=torch.float64, device=k.device)
+    out = torch.empty(F, dtype=torch.float64, device=k.device)
+    _lib.call("lc_lambda_max_strided", _p(k), ldk, k_stride, _p(rows), F, N, steps, _p(work), _p(out), _s())
+    return out
 
 
 def masked_stream(mask_words):

@@ -30,7 +30,9 @@ import oracle.ridge as oridge
 class OracleEngine:
     """The phase interface of RidgeCVEngine (what NestedCVModel's driver loop calls), arithmetic by the CPU oracle,
     exchanges through the same ShardContext."""
-    def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard, precision="auto", singcutoff=0.0, V_total=None):
+    primal = False
+    def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard, precision="auto", singcutoff=0.0, V_total=None,
+                 min_train_rows=None, form="dual"):
         self.X, self.Y = torch.tensor(np.asarray(X), dtype=torch.float32), torch.tensor(np.asarray(Y), dtype=torch.float32)
         self.alphas, self.normalpha, self.use_corr, self.shard = list(alphas), normalpha, use_corr, shard
         self.V = self.Y.shape[1]

@@ -193,3 +193,68 @@ def test_cfg5_whisper_shape_banded(lc):
     assert_matches_oracle(lc, model, (m, W * gamma[:, None].astype(np.float32), a), (m_o, W_o, a_o), detail, Xs, Y, kw,
                           "cfg5", corr_atol=1e-4, w_rtol=1e-3, w_atol=1e-4, cols=np.arange(48))
     assert m["median_score"] > 0.2
+
+
+def test_primal_form_for_tall_designs(lc):
+    """cfg1-like designs (train_simple.py:21-31: a word-rate feature x 4 delays, p = 4; example.py:104-117 with
+    single_alpha) and other tall ones, T >= 2000: ``form="auto"`` takes the primal (p x p) route, which must give the
+    oracle's answer (ties proven) and the dual route's -- full CV and train/test, per-voxel and single alpha, both
+    arithmetic paths; a design whose feature scales are too far apart for the fp16 split falls back to the dual form by
+    itself."""
+    import oracle.nested_cv as onc
+    rng = np.random.default_rng(41)
+    for p0, delays, T, V, kw in (
+            (1, [1, 2, 3, 4], 2400, 1500, dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 4, 8))),
+            (3, [1, 2, 3, 4], 2000, 700, dict(folding_type="chunked", n_outer_folds=3, n_inner_folds=2, chunk_length=25,
+                                              alphas=np.logspace(-1, 3, 6), single_alpha=True)),
+            (16, [1, 2, 3, 4], 2100, 600, dict(folding_type="kfold_trimmed", n_outer_folds=2, n_inner_folds=3,
+                                               alphas=np.logspace(0, 5, 7), normalpha=False)),
+            (64, [0], 2050, 333, dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=np.logspace(-1, 2, 5),
+                                      use_corr=False)),
+    ):
+        from oracle.fir import make_delayed
+        X = make_delayed(rng.standard_normal((T, p0)), delays)
+        p = X.shape[1]
+        Y = X @ (rng.standard_normal((p, V)) * (0.5 / np.sqrt(p))) + rng.standard_normal((T, V))
+        Y[:, 2] = -1.0
+        r2 = not kw.get("use_corr", True)
+        tol = dict(corr_atol=1e-3 if r2 else 3e-5, gap_tol=2e-3 if r2 else 2e-6)
+        import random
+        for tt in (False, True):
+            kw_run = {k: v for k, v in kw.items() if not (tt and k == "n_outer_folds")}
+            args = (X[:-300], Y[:-300]) if tt else (X, Y)
+            extra = dict(X_test=X[-300:], y_test=Y[-300:]) if tt else {}
+            detail = {}
+            random.seed(11)
+            oracle = onc.fit_predict(*args, detail=detail, **extra, **kw_run)
+            for precision in ("auto", "f32"):
+                tag = f"p={p} tt={tt} {precision}"
+                model = lc.NestedCVModel("r", precision=precision)
+                random.seed(11)
+                ours = model.fit_predict(*args, **extra, **kw_run)
+                assert model.last_form == "primal", tag
+                assert_matches_oracle(lc, model, ours, oracle, detail, args[0], args[1], kw_run, tag, min_same=0.97, **tol,
+                                      **({k: extra[k] for k in extra} if tt else {}))
+            dual = lc.NestedCVModel("r", form="dual")
+            random.seed(11)
+            m_d, W_d, a_d = dual.fit_predict(*args, **extra, **kw_run)
+            assert dual.last_form == "dual"
+            same = np.isclose(a_d, ours[2], rtol=1e-6)
+            assert same.mean() >= 0.97
+            np.testing.assert_allclose(np.asarray(m_d["correlations"])[same], np.asarray(ours[0]["correlations"])[same],
+                                       atol=1e-3 if r2 else 3e-5)
+            np.testing.assert_allclose(W_d[:, same], ours[1][:, same], rtol=2e-4, atol=1e-5)
+    # feature scales 1 : 2^-12 : the fp16 split cannot carry both through a contraction over features -> dual by itself
+    X = rng.standard_normal((2000, 6))
+    X[:, 3] *= 2.0 ** -12
+    Y = X @ rng.standard_normal((6, 50)) + rng.standard_normal((2000, 50))
+    kw = dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=[0.1, 1.0])
+    model = lc.NestedCVModel("r")
+    ours = model.fit_predict(X, Y, **kw)
+    assert model.last_form == "dual"
+    with pytest.raises(ValueError, match="form='primal' is not usable"):
+        lc.NestedCVModel("r", form="primal").fit_predict(X, Y, **kw)
+    model32 = lc.NestedCVModel("r", precision="f32")                       # exact-fp32 arithmetic: primal is fine
+    ours32 = model32.fit_predict(X, Y, **kw)
+    assert model32.last_form == "primal"
+    np.testing.assert_allclose(np.asarray(ours32[0]["correlations"]), np.asarray(ours[0]["correlations"]), atol=3e-5)

@@ -48,8 +48,9 @@ for name, args, alphas in (
     dX, dY, p = synth(**args)
     model = NestedCVModel("ridge_regression")
     fit = lambda: model.fit_predict_device(dX, dY, p, V, alphas=alphas, **KW)
-    fit(); torch.cuda.synchronize()
+    fit(); fit(); torch.cuda.synchronize()
     t = time.perf_counter(); m, W, a = fit(); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    name += f" [{model.last_form} form]"
     ok = bool(np.isfinite(np.asarray(m["correlations"])).all() and torch.isfinite(W).all() and np.isfinite(a).all())
     print(f"{name}: {1e3 * dt:.0f} ms = {V / dt:.0f} voxels/s, median score {m['median_score']:.4f}, all finite: {ok}", flush=True)
     del dX, dY, W
