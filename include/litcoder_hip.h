@@ -222,6 +222,9 @@ int lc_chol_outer_block(int columns);
 /* Diagnostic: kernel of the deep updates of lc_batch_chol_solve -- 2: 4x4x4 fp64 MFMA (default), 1: vector ALU,
  * 0: 16x16x4 fp64 MFMA; anything else only queries.  Returns the one in force. */
 int lc_debug_chol_big_kernel(int which);
+/* Diagnostics: 1 (default) = fused left-looking 64-column steps (one launch per step besides the diagonal tile),
+ * 0 = the first version's panel + in-block update launches; returns the setting. */
+int lc_debug_chol_fused_steps(int on);
 
 /* The same hat matrices for alphas whose penalty dwarfs the spectrum, as a polynomial in K[tr,tr]:
  *   K[va,tr] (K[tr,tr] + a^2 I)^-1  ~=  sum_{j<terms} c_sj K[va,tr] K[tr,tr]^j / scale_f^(j+1)

@@ -540,6 +540,279 @@ __global__ void __launch_bounds__(256, 2) k_mm64q(const MMArgs g) {
     }
 }
 
+
+// ------------------------------------------------------------------ fused 64-column steps (left-looking inside an outer block)
+// The first version ran three launches per 64-column step -- diagonal tile, panel P = A Linv', and a rank-64 update of
+// the rest of the outer block in which every 64 x 64 tile was its own workgroup doing one depth-64 product and a
+// read-modify-write of C: ~170 workgroups per system and step, ~10 us each for 0.5 MFLOP.  Here a step is the diagonal
+// tile plus ONE launch with one workgroup per 64-row tile i > k, which
+//   (1) applies the one contribution its tile of column k still lacks,  C = A[i,k] - L[i,k-1] L[k,k-1]'  (see (3)),
+//   (2) forms  L[i,k] = C Linv_kk'  (C goes through LDS as the A operand) and stores it, and
+//   (3) PRE-UPDATES its tile of the next column with everything that is already final:
+//           A[i,k+1] -= sum_{j = K0 .. k-1} L[i,j] L[k+1,j]'      (one product of depth 64 (k - K0), no RMW per 64),
+//       the j = k term being the one step (1) of the next launch adds -- except in row tile k+1 itself, whose own
+//       L[k+1,k] is at hand, so that the next diagonal tile is final when this launch ends.
+// Same flops, one read-modify-write per tile and block column instead of one per 64 columns of depth, 38 instead of
+// ~170 workgroups per system and step.  The back substitution is restructured the same way (k_bstep: one launch per
+// step,  H[i,k] = (Z[i,k] - sum_{j > k} H[i,j] L[j,k]) Linv_kk ).
+constexpr int ST_LDC = NB + 2;     // row stride of the C tile in LDS
+
+// acc += A B' (BT: B stored [n][k]) or A B (B stored [k][n]) for one 64 x 64 tile, depth % 16 == 0, operands staged
+// through LDS in depth-16 chunks exactly like k_mm64 (4 waves, 2 x 2, each 32 x 32).  A_LDS: A is a 64 x 64 tile
+// already in LDS (row stride ST_LDC) and depth == 64.
+template <bool BT, bool A_LDS>
+__device__ inline void tile_mac(f64x4 (&acc)[2][2], const double* __restrict__ A, long long lda, int a_rows,
+                                const double* __restrict__ B, long long ldb, int depth, double* sA, double* sB) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1, li = lane & 15, lq = lane >> 4;
+    f64x2 ra[2], rb[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = t + 256 * q;
+            const int row = e >> 3, kp = e & 7;
+            if (!A_LDS)
+                ra[q] = row < a_rows ? *reinterpret_cast<const f64x2*>(A + (long long)row * lda + k0 + 2 * kp) : f64x2{0.0, 0.0};
+            if (BT) {
+                rb[q] = *reinterpret_cast<const f64x2*>(B + (long long)row * ldb + k0 + 2 * kp);
+            } else {
+                const int kr = e >> 5, cp = e & 31;
+                rb[q] = *reinterpret_cast<const f64x2*>(B + (long long)(k0 + kr) * ldb + 2 * cp);
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = t + 256 * q;
+            const int row = e >> 3, kp = e & 7;
+            if (!A_LDS) *reinterpret_cast<f64x2*>(sA + row * MM_LD + 2 * kp) = ra[q];
+            if (BT) {
+                *reinterpret_cast<f64x2*>(sB + row * MM_LD + 2 * kp) = rb[q];
+            } else {
+                const int kr = e >> 5, cp = e & 31;
+                sB[(2 * cp) * MM_LD + kr] = rb[q].x;
+                sB[(2 * cp + 1) * MM_LD + kr] = rb[q].y;
+            }
+        }
+    };
+    fetch(0);
+    __syncthreads();                                   // the previous user of sA / sB is done
+    stash();
+    __syncthreads();
+    const double* pb = sB + (wn * 32 + li) * MM_LD + lq;
+    for (int k0 = 0; k0 < depth; k0 += MM_KC) {
+        const bool more = k0 + MM_KC < depth;
+        if (more) fetch(k0 + MM_KC);
+        const double* pa = A_LDS ? A + (wm * 32 + li) * ST_LDC + k0 + lq : sA + (wm * 32 + li) * MM_LD + lq;
+        constexpr int LDA = A_LDS ? ST_LDC : MM_LD;
+#pragma unroll
+        for (int k4 = 0; k4 < MM_KC / 4; ++k4) {
+            double a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = pa[i * 16 * LDA + 4 * k4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = pb[j * 16 * MM_LD + 4 * k4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
+    }
+}
+
+// element (row, col) of the 64 x 64 tile that accumulator acc[i][j][r] of this lane holds
+#define LC_TILE_ROW(i, r) (wm * 32 + (i) * 16 + lq + 4 * (r))
+#define LC_TILE_COL(j) (wn * 32 + (j) * 16 + li)
+
+__global__ void __launch_bounds__(256, 2) k_lstep(double* __restrict__ aug, int N, int M, int k, int K0, int K1,
+                                                  const double* __restrict__ linv) {
+    __shared__ double sA[NB * MM_LD], sB[NB * MM_LD], sC[NB * ST_LDC];
+    const int R = N + M, nb = N / NB;
+    const int i = k + 1 + blockIdx.x, b = blockIdx.y;
+    const int r0 = i * NB, a_rows = min(NB, R - r0);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1, li = lane & 15, lq = lane >> 4;
+    double* Ab = aug + (long long)b * R * N;
+    double* Arow = Ab + (long long)r0 * N;
+    const double* Lk = linv + ((long long)b * nb + k) * NB * NB;
+    f64x4 acc[2][2];
+    auto zero = [&]() {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = f64x4{0.0, 0.0, 0.0, 0.0};
+    };
+    // (1) C = A[i,k] - L[i,k-1] L[k,k-1]'  -> LDS
+    zero();
+    if (k > K0) tile_mac<true, false>(acc, Arow + (k - 1) * NB, N, a_rows, Ab + (long long)k * NB * N + (k - 1) * NB, N, NB, sA, sB);
+    {
+        const double* src = Arow + k * NB;
+        double old[2][2][4];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = LC_TILE_ROW(ii, r);
+                    old[ii][jj][r] = row < a_rows ? src[(long long)row * N + LC_TILE_COL(jj)] : 0.0;
+                }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sC[LC_TILE_ROW(ii, r) * ST_LDC + LC_TILE_COL(jj)] = old[ii][jj][r] - acc[ii][jj][r];
+    }
+    // (2) L[i,k] = C Linv_kk'   (tile_mac's first barrier makes sC visible)
+    zero();
+    tile_mac<true, true>(acc, sC, 0, a_rows, Lk, NB, NB, sA, sB);
+    {
+        double* dst = Arow + k * NB;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = LC_TILE_ROW(ii, r);
+                if (row < a_rows)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) dst[(long long)row * N + LC_TILE_COL(jj)] = acc[ii][jj][r];
+            }
+    }
+    if (k + 1 >= K1) return;
+    // (3) pre-update of the tile in column k+1
+    const bool own = i == k + 1;                       // row tile k+1: its L[k+1,k] is the tile just formed
+    if (own) {
+        __syncthreads();                               // everyone has read sC as the A operand
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sC[LC_TILE_ROW(ii, r) * ST_LDC + LC_TILE_COL(jj)] = acc[ii][jj][r];
+    }
+    if (!own && k == K0) return;                       // nothing final to apply yet
+    zero();
+    if (k > K0)
+        tile_mac<true, false>(acc, Arow + K0 * NB, N, a_rows, Ab + (long long)(k + 1) * NB * N + K0 * NB, N, (k - K0) * NB, sA, sB);
+    if (own) {
+        // + L[k+1,k] L[k+1,k]' with both operands = the tile in sC: stage it as B ([n][k]) through the chunk loop
+        __syncthreads();
+        for (int k0 = 0; k0 < NB; k0 += MM_KC) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = t + 256 * q, row = e >> 3, kp = e & 7;
+                *reinterpret_cast<f64x2*>(sB + row * MM_LD + 2 * kp) =
+                    f64x2{sC[row * ST_LDC + k0 + 2 * kp], sC[row * ST_LDC + k0 + 2 * kp + 1]};
+            }
+            __syncthreads();
+            const double* pa = sC + (wm * 32 + li) * ST_LDC + k0 + lq;
+            const double* pb = sB + (wn * 32 + li) * MM_LD + lq;
+#pragma unroll
+            for (int k4 = 0; k4 < MM_KC / 4; ++k4) {
+                double a[2], bb[2];
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) a[ii] = pa[ii * 16 * ST_LDC + 4 * k4];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) bb[jj] = pb[jj * 16 * MM_LD + 4 * k4];
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        acc[ii][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ii], bb[jj], acc[ii][jj], 0, 0, 0);
+            }
+        }
+    }
+    {
+        double* dst = Arow + (k + 1) * NB;
+        double old[2][2][4];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = LC_TILE_ROW(ii, r);
+                    old[ii][jj][r] = row < a_rows ? dst[(long long)row * N + LC_TILE_COL(jj)] : 0.0;
+                }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = LC_TILE_ROW(ii, r);
+                if (row < a_rows)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) dst[(long long)row * N + LC_TILE_COL(jj)] = old[ii][jj][r] - acc[ii][jj][r];
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_bstep(double* __restrict__ aug, int N, int M, int k, int K1,
+                                                  const double* __restrict__ linv) {
+    __shared__ double sA[NB * MM_LD], sB[NB * MM_LD], sC[NB * ST_LDC];
+    const int R = N + M, nb = N / NB;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * NB, a_rows = min(NB, M - r0);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1, li = lane & 15, lq = lane >> 4;
+    double* Ab = aug + (long long)b * R * N;
+    double* Zrow = Ab + (long long)(N + r0) * N;
+    const double* Lk = linv + ((long long)b * nb + k) * NB * NB;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // C = Z[i,k] - sum_{j = k+1 .. K1-1} H[i,j] L[j,k]  -> LDS
+    const int depth = (K1 - 1 - k) * NB;
+    if (depth > 0)
+        tile_mac<false, false>(acc, Zrow + (k + 1) * NB, N, a_rows, Ab + (long long)(k + 1) * NB * N + k * NB, N, depth, sA, sB);
+    {
+        const double* src = Zrow + k * NB;
+        double old[2][2][4];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = LC_TILE_ROW(ii, r);
+                    old[ii][jj][r] = row < a_rows ? src[(long long)row * N + LC_TILE_COL(jj)] : 0.0;
+                }
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sC[LC_TILE_ROW(ii, r) * ST_LDC + LC_TILE_COL(jj)] = old[ii][jj][r] - acc[ii][jj][r];
+    }
+    // H[i,k] = C Linv_kk
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = f64x4{0.0, 0.0, 0.0, 0.0};
+    tile_mac<false, true>(acc, sC, 0, a_rows, Lk, NB, NB, sA, sB);
+    double* dst = Zrow + k * NB;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = LC_TILE_ROW(ii, r);
+            if (row < a_rows)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) dst[(long long)row * N + LC_TILE_COL(jj)] = acc[ii][jj][r];
+        }
+}
+#undef LC_TILE_ROW
+#undef LC_TILE_COL
+
 static int g_big_kernel = 2;    // deep updates: 2 = 4x4x4 MFMA (k_mm64q), 1 = vector ALU (k_mm64v), 0 = 16x16x4 MFMA (k_mm64<4>)
        // deep updates on the vector ALU (k_mm64v) or on the MFMA (k_mm64<4>)
 
@@ -567,6 +840,12 @@ __global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ au
 }  // namespace
 
 static int g_chol_outer = 512;   // columns per outer block (multiple of NB)
+static int g_chol_fused = 1;     // 1: fused left-looking steps (k_lstep / k_bstep); 0: the first version's three launches per step
+
+extern "C" int lc_debug_chol_fused_steps(int on) {
+    if (on == 0 || on == 1) g_chol_fused = on;
+    return g_chol_fused;
+}
 
 extern "C" int lc_chol_outer_block(int columns) {
     if (columns > 0) {
@@ -603,6 +882,13 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
         for (int k = K0; k < K1; ++k) {
             hipLaunchKernelGGL(k_potrf_diag, dim3(B), dim3(256), 0, s, d_aug, N, M, k, d_linv, d_info);
             const int below = (k + 1) * NB;                  // first row under the diagonal tile
+            if (g_chol_fused) {
+                const int tiles = lc::ceil_div(R - below, NB);
+                if (tiles > 0)
+                    hipLaunchKernelGGL(k_lstep, dim3((unsigned)tiles, (unsigned)B), dim3(256), 0, s, d_aug, N, M, k, K0, K1,
+                                       d_linv);
+                continue;
+            }
             // panel:  P <- P Linv_kk'   (rows below the diagonal tile, including the M augmented rows; in place)
             g.a = g.c = d_aug + (long long)below * N + k * NB;
             g.a_sys = g.c_sys = sys;
@@ -635,6 +921,11 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
     for (int K0 = last_full; K0 >= 0; K0 -= ob) {
         const int K1 = min(K0 + ob, nb);
         for (int k = K1 - 1; k >= K0; --k) {
+            if (g_chol_fused) {
+                hipLaunchKernelGGL(k_bstep, dim3((unsigned)lc::ceil_div(M, NB), (unsigned)B), dim3(256), 0, s, d_aug, N, M,
+                                   k, K1, d_linv);
+                continue;
+            }
             g.a = g.c = d_aug + (long long)N * N + k * NB;
             g.a_sys = g.c_sys = sys;
             g.b = d_linv + (long long)k * NB * NB;

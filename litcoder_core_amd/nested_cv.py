@@ -971,8 +971,11 @@ class RidgeCVEngine:
         for k, i in enumerate(g):
             m = metas[i]
             Fo = len(m["inner_abs"])
-            sub = hat if len(g) == 1 else self._hat_slice(hat, s, Fo, m["inner_abs"])
-            sub["shared"] = None
+            sub = dict(hat) if len(g) == 1 else self._hat_slice(hat, s, Fo, m["inner_abs"])
+            # one tiled image of the outer training targets for all inner folds (see _shared_image): possible when the
+            # inner training sets need no padding rows
+            n_in = len(m["inner_abs"][0][0])
+            sub["shared"] = self._shared_image(m["inner_abs"], n_in) if n_in % (2 * K_TILE) == 0 else None
             s += Fo
             out[i] = dict(tr=m["tr"], te=m["te"], X=X, Y=Y, K=G[F + k], cs=cs, split=split, hat=sub, done=done,
                           tr_o=ident[:1], lmax_o=None if lmax is None else lmax[F + k:F + k + 1],
@@ -1015,10 +1018,18 @@ class RidgeCVEngine:
         Vt = ops.pad_to(self.Vp, 256)
         B = torch.zeros((PP, Vt), dtype=torch.float32, device=self.dev)
         ident = ops.idx_tensor(np.arange(self.p), PP, self.dev)
+        shared = hat.get("shared") if split else None
+        views = [(0, 0, 0)] * F
         if split:
             At = torch.empty(256 * Nmax * 2, dtype=torch.float16, device=self.dev)
             rs_a = torch.empty(256, dtype=torch.float32, device=self.dev)
-            Yt = torch.empty(Vt * Nmax * 2, dtype=torch.float16, device=self.dev)
+            if shared is not None:
+                union, gaps = shared
+                Yt = torch.empty(Vt * len(union) * 2, dtype=torch.float16, device=self.dev)
+                ops.split_cols_f16(Y, self.Vp, ops.idx_tensor(union, len(union), self.dev), len(union), cs, Yt)
+                views = [(len(union), g0, gl) for g0, gl in gaps]
+            else:
+                Yt = torch.empty(Vt * Nmax * 2, dtype=torch.float16, device=self.dev)
             cs_inv = torch.ones(Vt, dtype=torch.float32, device=self.dev)
             cs_inv[: self.Vp] = cs[self.Vp:]
             Bt = torch.empty(Vt * PP * 2, dtype=torch.float16, device=self.dev)
@@ -1030,9 +1041,10 @@ class RidgeCVEngine:
             Xt_f = Xt[(off + f) * PP:(off + f + 1) * PP]
             ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk, yv)
             if split:
-                ops.split_cols_f16(Y, self.Vp, tr[f], Ni, cs, Yt)
+                if shared is None:
+                    ops.split_cols_f16(Y, self.Vp, tr[f], Ni, cs, Yt)
                 ops.split_rows_f16(Xt_f, PP, Ni, At, rs_a)
-                ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, B, Vt, Vt, Ni, [0, Vt // 256])
+                ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, B, Vt, Vt, Ni, [0, Vt // 256], bview=views[f])
                 csB, _ = ops.col_scales_f16(B, self.p, self.Vp)
                 ops.split_cols_f16(B, self.Vp, ident, PP, csB, Bt)
                 ops.split_rows_f16(H[f * A:(f + 1) * A].reshape(A * M, PP), A * M, PP, Ht, rs_inv)
