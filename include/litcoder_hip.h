@@ -247,6 +247,11 @@ int lc_batch_series_terms(const double* d_k, int64_t ldk, const int32_t* d_tr, c
                           int F, int N, int M, const double* d_scale, int terms,
                           double* d_work, float* d_p, const int32_t* d_rowmap, int rows_p, lc_stream_t stream);
 
+/* out[f][i][j] = K[rows[f][i], cols[f][j]] in fp64 (index -1 -> 0): d_out (F, R, C) contiguous.  The test-row block
+ * K[te, tr] of the refit's augmented rows (the hat matrix of the test rows, nested_cv.py:151,251). */
+int lc_gather_sub_f64(const double* d_k, int64_t ldk, const int32_t* d_rows, const int32_t* d_cols, int F,
+                      int R, int C, double* d_out, lc_stream_t stream);
+
 /* out[f] (R, C) f32 = K[rows_f, cols_f] / scale[f] (d_scale NULL = 1; index -1 = zero row / column): the
  * f32 operands of the series terms when their chain  P'_j = P'_(j-1) (K[tr,tr] / scale)  runs on the f32 MFMA
  * (lc_gemm_grouped_f32) instead of in fp64 -- terms j >= 1 enter a prediction scaled by rho^j <= 1.6e-2 per

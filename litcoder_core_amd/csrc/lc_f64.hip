@@ -706,6 +706,15 @@ extern "C" int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_
     return lc::launched("k_transpose_rows");
 }
 
+extern "C" int lc_gather_sub_f64(const double* d_k, int64_t ldk, const int32_t* d_rows, const int32_t* d_cols, int F,
+                                 int R, int C, double* d_out, lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_rows && d_cols && d_out, LC_E_BADARG, "lc_gather_sub_f64: null pointer");
+    LC_REQUIRE(F > 0 && F <= 65535 && R > 0 && C > 0, LC_E_SHAPE, "lc_gather_sub_f64: bad shape");
+    hipLaunchKernelGGL(k_gather_sub, dim3(R, F), dim3(256), 0, lc::as_stream(stream), d_k, (long long)ldk, d_rows, d_cols, R, C,
+                       d_out);
+    return lc::launched("k_gather_sub");
+}
+
 extern "C" int lc_gather_sub_f32(const double* d_k, int64_t ldk, const int32_t* d_rows, const int32_t* d_cols, int F,
                                  int R, int C, const double* d_scale, float* d_out, lc_stream_t stream) {
     LC_REQUIRE(d_k && d_rows && d_cols && d_out, LC_E_BADARG, "lc_gather_sub_f32: null pointer");

@@ -666,10 +666,8 @@ class RidgeCVEngine:
         rows = ops.pad_to(self.p_pad + ops.pad_to(n_t, LC_MB), self._refit_row_granule())
         rhs = torch.zeros((rows, N_o), dtype=torch.float64, device=self.dev)
         ops.transpose_rows(X, tr_o, N_o, self.p, rhs)
-        if n_t:
-            te64 = ops.upload(np.asarray(te_rows, dtype=np.int64), self.dev)
-            tr64 = ops.upload(np.asarray(tr_rows, dtype=np.int64), self.dev)
-            rhs[self.p_pad:self.p_pad + n_t, :n_o] = K.index_select(0, te64).index_select(1, tr64)
+        if n_t:                                        # K[te, tr] below X', padded columns (index -1) zero
+            ops.gather_sub_f64(K, ops.idx_tensor(te_rows, n_t, self.dev), tr_o, 1, n_t, N_o, rhs[self.p_pad:self.p_pad + n_t])
         return rhs
 
     def _refit_chol(self, K, tr_o, lmax_o, rhs, alphas_idx):
@@ -904,6 +902,10 @@ class RidgeCVEngine:
                         lmax_os = [lmax_pre[i][1] for i in g]
                         lmax_i = lmax_pre[g[0]][0] if len(g) == 1 else self._lmax_span(lmax_pre, g)
                 inner_all = [ia for i in g for ia in metas[i]["inner_abs"]]
+                tr_os = [ops.idx_tensor(metas[i]["tr"], ops.pad_to(len(metas[i]["tr"]), LC_NB), self.dev).reshape(1, -1)
+                         for i in g]
+                ids_ready = torch.cuda.Event()         # what the refit systems need (row lists, lmax) exists from here on
+                ids_ready.record()
                 hat = self._hat_matrices(K, inner_all, lmax_i, self._series_by_moments(split), chol_after=chol_after)
                 hat.update(cs=cs, split=split, data_ready=data_ready)
                 done = torch.cuda.Event()
@@ -913,10 +915,8 @@ class RidgeCVEngine:
                     Fo = len(m["inner_abs"])
                     sub = hat if len(g) == 1 else self._hat_slice(hat, s, Fo, m["inner_abs"])
                     s += Fo
-                    N_o = ops.pad_to(len(m["tr"]), LC_NB)
-                    tr_o = ops.idx_tensor(m["tr"], N_o, self.dev).reshape(1, N_o)
-                    out[i] = dict(tr=m["tr"], te=m["te"], X=X, Y=Y, K=K, cs=cs, split=split, hat=sub, done=done, tr_o=tr_o,
-                                  lmax_o=lmax_os[k])
+                    out[i] = dict(tr=m["tr"], te=m["te"], X=X, Y=Y, K=K, cs=cs, split=split, hat=sub, done=done,
+                                  tr_o=tr_os[k], lmax_o=lmax_os[k], ids_ready=ids_ready)
                 done.record()
                 for t in ([X, Y, K, cs, hat["tr"], hat["va"], hat["info"], hat["a2"], hat["lmax"], hat["d_ser"]]
                           + [out[i]["tr_o"] for i in g] + lmax_os
@@ -1126,13 +1126,59 @@ class RidgeCVEngine:
         no gate."""
         return self.sweeps_done if self.shard.world == 1 else None
 
+    def refit_ahead(self, states):
+        """Voxel shards: the refit systems of ALL the given (prepared) folds for ALL factorised alphas in one
+        collective batch, before any alpha is chosen.  With W ranks a rank's share of a fold's handful of systems is a
+        chain of ~N/64 dependent steps either way (latency, not flops), and solving them fold by fold after each
+        choice puts that chain -- and its all-gather -- on the critical path of every fold; one batch over the folds
+        costs one chain for the whole fit, hidden behind the first folds' sweeps.  (On one GPU the systems of alphas
+        nobody chooses would be wasted fp64 work, so there the driver keeps fold_speculate.)  Folds whose systems
+        differ in size fall back to fold_speculate / fold_select."""
+        cho = [a for a in self.cho]
+        sts = [st for st in states if st.get("tr_o") is not None and "spec" not in st]
+        if not cho or not sts or self.primal:
+            return
+        N_o = sts[0]["tr_o"].shape[-1]
+        rs_stream = self.aux2
+        for st in sts:                                 # not behind the folds' hat-matrix batches: beside them
+            rs_stream.wait_event(st.get("ids_ready") or st["done"])
+        with torch.cuda.stream(rs_stream):
+            rhss = [self._refit_rhs(st["X"], st["K"], st["tr"], st["tr_o"], st["te"]) for st in sts]
+            rows = rhss[0].shape[0]
+            if any(st["tr_o"].shape[-1] != N_o for st in sts) or any(r.shape[0] != rows for r in rhss):
+                return
+            Gc, nF = len(cho), len(sts)
+            S = 1
+            while S * Gc * nF < self.shard.world and rows % (2 * S * LC_MB) == 0:
+                S *= 2
+            rsz = rows // S
+            a2s = [ops.penalties(st["lmax_o"], 1, self.d_alphas, self.normalpha) for st in sts]
+
+            def assemble(jobs):                        # job = (fold * Gc + alpha) * S + row slice
+                aug = torch.empty((len(jobs), N_o + rsz, N_o), dtype=torch.float64, device=self.dev)
+                for k, j in enumerate(jobs):
+                    fo, a, q = j // (Gc * S), (j // S) % Gc, j % S
+                    sysv = ops.upload(np.asarray([cho[a]], dtype=np.int32), self.dev)
+                    ops.batch_assemble_sel(sts[fo]["K"], sts[fo]["tr_o"], None, rhss[fo][q * rsz:(q + 1) * rsz], a2s[fo], sysv,
+                                           1, self.A, N_o, rsz, aug[k:k + 1])
+                return aug
+
+            Hj, info = self._sharded_solve(nF * Gc * S, N_o, rsz, assemble)
+            Mall = Hj[: nF * Gc * S].view(nF, Gc, rows, N_o)
+            main = torch.cuda.current_stream()
+        for fo, st in enumerate(sts):
+            st["spec"] = dict(alphas=list(cho), M=Mall[fo], info=info, rhs=rhss[fo])
+            for t in (st.get("X"), st.get("K"), st.get("tr_o"), st.get("lmax_o")):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(rs_stream)
+
     def fold_speculate(self, st, alphas_idx):
         """Solve the refit systems of a prepared fold for the listed alphas BEFORE its alpha choice is known, on the
         auxiliary stream (the driver passes the alphas the previous fold used: the histogram of the chosen alphas
         hardly moves between outer folds).  fold_select then only solves what is missing; without this the last
         fold's systems are a serial 8 ms at the end of the fit, with nothing left to run beside them."""
         todo = [a for a in alphas_idx if a in self.cho] if st.get("tr_o") is not None else []
-        if not todo:
+        if not todo or "spec" in st:                   # nothing to factor, or refit_ahead has covered the fold
             return
         rs = self._refit_stream(st)
         if self.chain_gate() is not None:
@@ -1445,8 +1491,11 @@ class NestedCVModel(BasePredictivityModel):
             lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
             # V-independent part of every fold, ahead of everything on the auxiliary stream: fold 0 by itself (its sweeps
             # start as soon as its own systems are done), then ALL other folds as one batch
-            st = eng.fold_begin(*outer[0], prepared=eng.prepare_folds(outer[:1], lmax_pre[:1])[0])
+            first = eng.prepare_folds(outer[:1], lmax_pre[:1])[0]
+            st = eng.fold_begin(*outer[0], prepared=first)
             prepared = eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else []
+            if shard.world > 1:
+                eng.refit_ahead([first] + prepared)         # aux2: every fold's refit systems, one collective batch
             for i in range(n):
                 eng.fold_choose(st, single_alpha)               # main: argmax + grouping; the histogram leaves asynchronously
                 st_next = None

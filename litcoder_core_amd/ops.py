@@ -60,14 +60,35 @@ def idx_matrix(row_sets, length, dev, fill=-1):
     return upload(h, dev)
 
 
+_STAGE = {"buf": None, "off": 0}
+_STAGE_BYTES = 32 << 20
+
+
 def upload(arr, dev):
     """Small host array -> device through pinned memory, asynchronously on the current stream.  (A pageable
     ``.to(dev)`` / ``torch.tensor(..., device=dev)`` synchronises the stream: with two streams in flight that
-    stalls the host behind all the work already queued.)"""
-    h = torch.from_numpy(np.ascontiguousarray(arr))
+    stalls the host behind all the work already queued.)  The pinned bytes come from ONE staging ring of the process,
+    bump-allocated: ``tensor.pin_memory()`` takes a block from torch's caching host allocator, which cannot reuse a
+    block whose last copy is still queued behind a busy GPU and then calls hipHostMalloc -- measured: an 11 ms host
+    stall in the middle of a fit while five 19 KB index lists were uploaded."""
+    a = np.ascontiguousarray(arr)
     if dev.type != "cuda":
-        return h.to(dev)
-    return h.pin_memory().to(dev, non_blocking=True)
+        return torch.from_numpy(a).to(dev)
+    n = a.nbytes
+    if n == 0 or n > _STAGE_BYTES // 4:
+        return torch.from_numpy(a).pin_memory().to(dev, non_blocking=True)
+    if _STAGE["buf"] is None:
+        _STAGE["buf"] = torch.empty(_STAGE_BYTES, dtype=torch.uint8, pin_memory=True)
+    off = (_STAGE["off"] + 255) & ~255
+    if off + n > _STAGE_BYTES:                      # wrapped: everything staged so far must have left the ring
+        torch.cuda.synchronize()
+        off = 0
+    _STAGE["off"] = off + n
+    stage = _STAGE["buf"][off:off + n]
+    stage.numpy()[:] = a.reshape(-1).view(np.uint8)
+    out = torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype if a.size else torch.float32, device=dev)
+    out.view(torch.uint8).reshape(-1).copy_(stage, non_blocking=True)
+    return out
 
 
 def timing_enable(on=True):
@@ -326,6 +347,11 @@ def bh_fdr(p, alpha):
     padj = torch.empty(n, dtype=torch.float64, device=p.device)
     _lib.call("lc_bh_fdr", _p(p), n, float(alpha), _p(reject), _p(padj), _p(work), nbytes, _s())
     return reject, padj
+
+
+def gather_sub_f64(k, rows, cols, F, R, C, out):
+    """out (F, R, C) f64 contiguous view = K[rows[f][i], cols[f][j]] (-1 -> 0)."""
+    _lib.call("lc_gather_sub_f64", _p(k), k.stride(0), _p(rows), _p(cols), F, R, C, _p(out), _s())
 
 
 def gather_sub_f32(k, rows, cols, F, R, C, scale, out):

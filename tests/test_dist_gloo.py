@@ -70,6 +70,8 @@ class OracleEngine:
         return st
     def fold_speculate(self, st, alphas_idx):
         pass
+    def refit_ahead(self, states):
+        pass
     def fold_finish(self, st, scale):
         tr, te, idx = st["tr"], st["te"], st["idx"]
         Xtr, Ytr = self.X[tr], self.Y[tr]

@@ -43,10 +43,14 @@ for n in ("prepare_folds", "fold_begin", "fold_select", "fold_finish", "fold_col
     wrap(ncv.RidgeCVEngine, n)
 for n in ("choose", "_refit_groups", "_refit_systems", "_sweeps", "_hat_matrices", "_refit_apply", "_fold_data",
           "_shared_image", "begin_fit", "fold_choose", "fold_speculate", "_sharded_solve", "_refit_chol",
-          "combined_significance"):
+          "combined_significance", "refit_ahead", "_refit_rhs"):
     wrap(ncv.RidgeCVEngine, n, "    . " + n)
 for n in ("fdrcorrection", "fisher_combine", "full_cv_metrics"):
     wrap(stats, n)
+from litcoder_core_amd import dist as _dist  # noqa: E402
+wrap(_dist.ShardContext, "all_gather", "        . all_gather")
+for n in ("batch_chol_solve", "batch_assemble_sel", "penalties", "transpose_rows"):
+    wrap(ops, n, "        . ops." + n)
 wrap(ncv, "_fold_lists")
 
 
