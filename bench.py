@@ -164,7 +164,8 @@ def host_path_leg(dX, dY, p, V, alphas, steps=2):
     assert isinstance(W, np.ndarray) and W.shape == (p, V) and W.dtype == np.float32
     return {"value": V / dt, "unit": "voxels/sec", "ms_per_step": 1e3 * dt, "steps": steps,
             "what": "float64 numpy features/targets in (pageable host memory) -> metrics + float32 host weights out; "
-                    "H2D of 1.99 GB, on-device cast to fp32, D2H of 0.98 GB of weights inside the timed region",
+                    "H2D of 1.99 GB through a ring of pinned chunks filled by copy threads, on-device cast to fp32, D2H of "
+                    "0.98 GB of weights into page-locked memory, all inside the timed region",
             "median_score": m["median_score"]}
 
 

@@ -163,7 +163,8 @@ int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, 
 /* The same for up to 32 row sets of ONE Gram matrix in a single pass over K per iteration: bit f of
  * d_member[i] (T x uint32) says whether row i belongs to system f.  Every fold of a nested CV (outer
  * train sets and their inner train sets) is a principal submatrix of K, so one call serves the whole fit.
- * d_work: F*(3*T + 2*steps + 8) f64.  d_lmax: (F) f64. */
+ * d_work: F*(3*T + 2*steps + 8) + 4*32*T f64 (the matvec is split over four column ranges whose partial sums
+ * are added in fixed order).  d_lmax: (F) f64. */
 int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
                          double* d_work, double* d_lmax, lc_stream_t stream);
 
@@ -246,6 +247,26 @@ int lc_batch_series_hat(const double* d_k, int64_t ldk, const int32_t* d_tr, con
 int lc_batch_series_terms(const double* d_k, int64_t ldk, const int32_t* d_tr, const int32_t* d_va,
                           int F, int N, int M, const double* d_scale, int terms,
                           double* d_work, float* d_p, const int32_t* d_rowmap, int rows_p, lc_stream_t stream);
+
+/* Small data movers, so that a fit launches no framework kernels (everything on the caller's stream):
+ *   lc_fill_bytes             hipMemsetAsync (zero-initialised buffers; 0xFF = the -1 padding of index lists);
+ *   lc_gather_sub_f32_strided lc_gather_sub_f32 with explicit output strides (elements): the series chain keeps its
+ *                             operand as (N, folds, M) so that all folds are column groups of one grouped GEMM;
+ *   lc_series_place           P[f][rowmap[i]][n] = Q[n][f][i]: term j of that chain into the stacked, slab-padded
+ *                             operand of the plain fp16x3 contraction (d_rowmap: M entries of term j, -1 = skip);
+ *   lc_scale_cast_f64_f32     dst = (float)(src / divisor[0])  (refit rows over lambda_max for the polynomial route);
+ *   lc_combine_terms_f32      out = c0 T0 + c1 T1 + ... (<= 4 terms, left to right in fp32, no contraction): the
+ *                             polynomial form of  [Xtr' ; K_te](K + a^2 I)^-1  for one alpha from the shared powers. */
+int lc_fill_bytes(void* d_ptr, int byte, int64_t nbytes, lc_stream_t stream);
+int lc_gather_sub_f32_strided(const double* d_k, int64_t ldk, const int32_t* d_rows, const int32_t* d_cols,
+                              int F, int R, int C, const double* d_scale, float* d_out, int64_t s_f,
+                              int64_t s_r, int64_t s_c, lc_stream_t stream);
+int lc_series_place(const float* d_q, int N, int F, int ldq, int M, const int32_t* d_rowmap, float* d_p,
+                    int rows_p, lc_stream_t stream);
+int lc_scale_cast_f64_f32(const double* d_src, const double* d_divisor, float* d_dst, int64_t n,
+                          lc_stream_t stream);
+int lc_combine_terms_f32(const float* const* h_terms, const float* h_coef, int terms, float* d_out, int64_t n,
+                         lc_stream_t stream);
 
 /* out[f][i][j] = K[rows[f][i], cols[f][j]] in fp64 (index -1 -> 0): d_out (F, R, C) contiguous.  The test-row block
  * K[te, tr] of the refit's augmented rows (the hat matrix of the test rows, nested_cv.py:151,251). */

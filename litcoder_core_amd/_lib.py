@@ -68,6 +68,12 @@ SIGNATURES = {
     "lc_fisher_combine": (c_int, [_ptr, c_int, c_int64, _ptr, _ptr]),
     "lc_bh_fdr_work_bytes": (c_int64, [c_int64]),
     "lc_bh_fdr": (c_int, [_ptr, c_int64, c_double, _ptr, _ptr, _ptr, c_int64, _ptr]),
+    "lc_fill_bytes": (c_int, [_ptr, c_int, c_int64, _ptr]),
+    "lc_gather_sub_f32_strided": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, c_int64, c_int64, c_int64,
+                                          _ptr]),
+    "lc_series_place": (c_int, [_ptr, c_int, c_int, c_int, c_int, _ptr, _ptr, c_int, _ptr]),
+    "lc_scale_cast_f64_f32": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr]),
+    "lc_combine_terms_f32": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, _ptr, c_int64, _ptr]),
     "lc_gather_sub_f64": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr]),
     "lc_gather_sub_f32": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_series_scores": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr,

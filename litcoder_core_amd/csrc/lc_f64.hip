@@ -177,7 +177,9 @@ __device__ inline double block_sum_1024(double x, double* red) {
 }
 
 // One Lanczos recurrence step per fold: a = v.w ; w -= a v + b_prev vprev ; b = |w| ; rotate.
-__global__ void __launch_bounds__(1024) k_lz_step(int N, int steps, int step, double* work) {
+__global__ void __launch_bounds__(1024) k_lz_step(int N, int steps, int step, double* work,
+                                                  const double* __restrict__ part = nullptr, int nsplit = 0,
+                                                  const unsigned* __restrict__ member = nullptr) {
     __shared__ double red[1024];
     const int f = blockIdx.x;
     double* base = lz_base(work, f, N, steps);
@@ -188,6 +190,12 @@ __global__ void __launch_bounds__(1024) k_lz_step(int N, int steps, int step, do
     double* be = al + steps;
     double* meta = be + steps;
     if (meta[1] != 0.0) return;                       // already stopped (invariant subspace found)
+    if (part)                                         // masked multi-system matvec: column-split partial sums, fixed order
+        for (int i = threadIdx.x; i < N; i += 1024) {
+            double sum = 0.0;
+            for (int sp = 0; sp < nsplit; ++sp) sum += part[((long long)sp * 32 + f) * N + i];
+            w[i] = (member[i] >> f) & 1u ? sum : 0.0;
+        }
     double d = 0.0;
     for (int i = threadIdx.x; i < N; i += 1024) d += v[i] * w[i];
     const double a = block_sum_1024(d, red);
@@ -282,13 +290,14 @@ __global__ void __launch_bounds__(256) k_lz_init_masked(const unsigned* __restri
 
 constexpr int LZM_ROWS = 8;      // rows of K per block
 constexpr int LZM_JT = 128;      // columns of K per LDS tile
+constexpr int LZM_SPLIT = 4;     // column splits of the matvec (work buffer: + LZM_SPLIT * 32 * T doubles)
 
 // block: 8 rows of K x all F <= 32 systems.  thread (f = tid & 31, g = tid >> 5): partial sums over the g-th
 // 16-column slice of every tile for the 8 rows; K and V tiles go through LDS (V transposed to [j][f]), the next
 // tile is fetched into registers while the current one is consumed; fixed-order reduction over g at the end.
 __global__ void __launch_bounds__(256) k_lz_symv_multi(const double* __restrict__ Kmat, long long ldk,
                                                        const unsigned* __restrict__ member, int T, int F, int steps,
-                                                       double* work) {
+                                                       double* work, double* __restrict__ part, int jspan) {
     __shared__ double Ks[LZM_ROWS][LZM_JT];
     __shared__ double Vs[LZM_JT][33];
     const int tid = threadIdx.x, f = tid & 31, g = tid >> 5;
@@ -309,15 +318,18 @@ __global__ void __launch_bounds__(256) k_lz_symv_multi(const double* __restrict_
     double acc[LZM_ROWS];
 #pragma unroll
     for (int r = 0; r < LZM_ROWS; ++r) acc[r] = 0.0;
-    fetch(0);
-    for (int j0 = 0; j0 < T; j0 += LZM_JT) {
+    // blockIdx.y = column split: this block sums over columns [jb, je) only; the splits are added in k_lz_step (each block
+    // is a chain of load latencies, one per 128-column tile: 4 splits = a quarter of the chain and 4x the blocks in flight)
+    const int jb = blockIdx.y * jspan, je = min(T, jb + jspan);
+    fetch(jb);
+    for (int j0 = jb; j0 < je; j0 += LZM_JT) {
         __syncthreads();                                   // previous tile consumed
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int e = tid + 256 * k; Ks[e >> 7][e & 127] = kreg[k]; }
 #pragma unroll
         for (int k = 0; k < 16; ++k) { const int e = tid + 256 * k; Vs[e & 127][e >> 7] = vreg[k]; }
         __syncthreads();
-        if (j0 + LZM_JT < T) fetch(j0 + LZM_JT);
+        if (j0 + LZM_JT < je) fetch(j0 + LZM_JT);
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) {
             const double vj = Vs[g * 16 + jj][f];
@@ -335,7 +347,7 @@ __global__ void __launch_bounds__(256) k_lz_symv_multi(const double* __restrict_
         double sum = 0.0;
 #pragma unroll
         for (int gg = 0; gg < 8; ++gg) sum += red[(gg * LZM_ROWS + r) * 32 + f];
-        lz_base(work, f, T, steps)[2ll * T + i] = (member[i] >> f) & 1u ? sum : 0.0;
+        part[((long long)blockIdx.y * 32 + f) * T + i] = sum;
     }
 }
 
@@ -576,6 +588,67 @@ __global__ void __launch_bounds__(256) k_gather_rows_f64(const float* __restrict
         dst[c] = v;
     }
 }
+
+// ---- small data movers that keep the fit free of framework kernels ------------------------------------------
+// out[i * s_r + f * s_f + j * s_c] = (float)(K[rows[f][i], cols[f][j]] / scale[f])  (generalised k_gather_sub_f32: the
+// series chain wants its operand as (N, folds, M) so that all folds are column groups of one grouped GEMM)
+__global__ void __launch_bounds__(256) k_gather_sub_f32_strided(const double* __restrict__ Kmat, long long ldk,
+                                                                const int* __restrict__ rows, const int* __restrict__ cols,
+                                                                int R, int C, const double* __restrict__ scale,
+                                                                float* __restrict__ out, long long s_f, long long s_r,
+                                                                long long s_c) {
+    const int i = blockIdx.x, f = blockIdx.y;
+    const int r = rows[(long long)f * R + i];
+    const int* cf = cols + (long long)f * C;
+    const double w = scale ? 1.0 / scale[f] : 1.0;
+    float* dst = out + (long long)f * s_f + (long long)i * s_r;
+    for (int j = threadIdx.x; j < C; j += 256) {
+        const int c = cf[j];
+        dst[(long long)j * s_c] = (r >= 0 && c >= 0) ? (float)(Kmat[(long long)r * ldk + c] * w) : 0.f;
+    }
+}
+
+// P[f][rowmap[i]][n] = Q[n][f][i]   (Q: (N, F, ldq) f32 -- term j of the series chain, transposed; P: (F, rows_p, N)):
+// 32 x 32 LDS transpose per (fold, tile)
+__global__ void __launch_bounds__(256) k_series_place(const float* __restrict__ Q, int N, int F, int ldq, int M,
+                                                      const int* __restrict__ rowmap, float* __restrict__ P, int rows_p) {
+    __shared__ float t[32][33];
+    const int f = blockIdx.z, n0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int nn = ty; nn < 32; nn += 8) {
+        const int n = n0 + nn, i = i0 + tx;
+        t[nn][tx] = (n < N && i < M) ? Q[((long long)n * F + f) * ldq + i] : 0.f;
+    }
+    __syncthreads();
+    for (int ii = ty; ii < 32; ii += 8) {
+        const int i = i0 + ii, n = n0 + tx;
+        if (i < M && n < N) {
+            const int row = rowmap[i];
+            if (row >= 0) P[((long long)f * rows_p + row) * N + n] = t[tx][ii];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scale_cast(const double* __restrict__ src, const double* __restrict__ divisor,
+                                                    float* __restrict__ dst, long long n) {
+    const double w = 1.0 / divisor[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dst[i] = (float)(src[i] * w);
+}
+
+__global__ void __launch_bounds__(256) k_combine_terms(const float* __restrict__ t0, const float* __restrict__ t1,
+                                                       const float* __restrict__ t2, const float* __restrict__ t3,
+                                                       float c0, float c1, float c2, float c3, int terms,
+                                                       float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        // the order and arithmetic of  M = c0 T0; M += c1 T1; ...  (fl32 product, fl32 sum: no fma contraction)
+        float m = __fmul_rn(t0[i], c0);
+        if (terms > 1) m = __fadd_rn(m, __fmul_rn(t1[i], c1));
+        if (terms > 2) m = __fadd_rn(m, __fmul_rn(t2[i], c2));
+        if (terms > 3) m = __fadd_rn(m, __fmul_rn(t3[i], c3));
+        out[i] = m;
+    }
+}
 }  // namespace
 
 extern "C" int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_k, int64_t ldk,
@@ -653,10 +726,14 @@ extern "C" int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const
     lc::ScopedTimer timer_(lc::T_LAMBDA_MAX, s);
     hipLaunchKernelGGL(k_lz_init_masked, dim3(F), dim3(256), 0, s, d_member, T, steps, d_work);
     if (int rc = lc::launched("k_lz_init_masked")) return rc;
+    double* part = d_work + (long long)F * (3ll * T + 2ll * steps + 8);      // (LZM_SPLIT, 32, T) partial matvecs
+    const int jspan = lc::ceil_div(lc::ceil_div(T, LZM_SPLIT), LZM_JT) * LZM_JT;
+    const int nsplit = lc::ceil_div(T, jspan);
     for (int it = 0; it < steps; ++it) {
-        hipLaunchKernelGGL(k_lz_symv_multi, dim3((unsigned)lc::ceil_div(T, LZM_ROWS)), dim3(256), 0, s, d_k,
-                           (long long)ldk, d_member, T, F, steps, d_work);
-        hipLaunchKernelGGL(k_lz_step, dim3(F), dim3(1024), 0, s, T, steps, it, d_work);
+        hipLaunchKernelGGL(k_lz_symv_multi, dim3((unsigned)lc::ceil_div(T, LZM_ROWS), (unsigned)nsplit), dim3(256), 0, s, d_k,
+                           (long long)ldk, d_member, T, F, steps, d_work, part, jspan);
+        hipLaunchKernelGGL(k_lz_step, dim3(F), dim3(1024), 0, s, T, steps, it, d_work, (const double*)part, nsplit,
+                           (const unsigned*)d_member);
     }
     if (int rc = lc::launched("k_lz_step")) return rc;
     hipLaunchKernelGGL(k_lz_eig, dim3(F), dim3(64), 0, s, T, steps, d_work, d_lmax);
@@ -704,6 +781,60 @@ extern "C" int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_
     hipLaunchKernelGGL(k_transpose_rows, grid, dim3(256), 0, lc::as_stream(stream), d_x, (long long)ldx, d_tr, N,
                        (long long)p, d_out);
     return lc::launched("k_transpose_rows");
+}
+
+
+extern "C" int lc_fill_bytes(void* d_ptr, int byte, int64_t nbytes, lc_stream_t stream) {
+    LC_REQUIRE(d_ptr || nbytes == 0, LC_E_BADARG, "lc_fill_bytes: null pointer");
+    LC_REQUIRE(nbytes >= 0 && byte >= 0 && byte <= 255, LC_E_SHAPE, "lc_fill_bytes: bad argument");
+    if (nbytes) LC_HIP(hipMemsetAsync(d_ptr, byte, (size_t)nbytes, lc::as_stream(stream)));
+    return LC_OK;
+}
+
+extern "C" int lc_gather_sub_f32_strided(const double* d_k, int64_t ldk, const int32_t* d_rows, const int32_t* d_cols,
+                                         int F, int R, int C, const double* d_scale, float* d_out, int64_t s_f,
+                                         int64_t s_r, int64_t s_c, lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_rows && d_cols && d_out, LC_E_BADARG, "lc_gather_sub_f32_strided: null pointer");
+    LC_REQUIRE(F > 0 && F <= 65535 && R > 0 && C > 0, LC_E_SHAPE, "lc_gather_sub_f32_strided: bad shape");
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_SERIES, s);
+    hipLaunchKernelGGL(k_gather_sub_f32_strided, dim3(R, F), dim3(256), 0, s, d_k, (long long)ldk, d_rows, d_cols, R, C,
+                       d_scale, d_out, (long long)s_f, (long long)s_r, (long long)s_c);
+    return lc::launched("k_gather_sub_f32_strided");
+}
+
+extern "C" int lc_series_place(const float* d_q, int N, int F, int ldq, int M, const int32_t* d_rowmap, float* d_p,
+                               int rows_p, lc_stream_t stream) {
+    LC_REQUIRE(d_q && d_rowmap && d_p, LC_E_BADARG, "lc_series_place: null pointer");
+    LC_REQUIRE(N > 0 && F > 0 && F <= 65535 && M > 0 && ldq >= M && rows_p > 0, LC_E_SHAPE, "lc_series_place: bad shape");
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_SERIES, s);
+    hipLaunchKernelGGL(k_series_place, dim3((unsigned)lc::ceil_div(N, 32), (unsigned)lc::ceil_div(M, 32), (unsigned)F),
+                       dim3(256), 0, s, d_q, N, F, ldq, M, d_rowmap, d_p, rows_p);
+    return lc::launched("k_series_place");
+}
+
+extern "C" int lc_scale_cast_f64_f32(const double* d_src, const double* d_divisor, float* d_dst, int64_t n,
+                                     lc_stream_t stream) {
+    LC_REQUIRE(d_src && d_divisor && d_dst && n >= 0, LC_E_BADARG, "lc_scale_cast_f64_f32: bad argument");
+    if (n == 0) return LC_OK;
+    hipLaunchKernelGGL(k_scale_cast, dim3((unsigned)lc::imin(lc::ceil_div<long long>(n, 256), 65535)), dim3(256), 0,
+                       lc::as_stream(stream), d_src, d_divisor, d_dst, (long long)n);
+    return lc::launched("k_scale_cast");
+}
+
+extern "C" int lc_combine_terms_f32(const float* const* h_terms, const float* h_coef, int terms, float* d_out, int64_t n,
+                                    lc_stream_t stream) {
+    LC_REQUIRE(h_terms && h_coef && d_out && terms >= 1 && terms <= 4 && n >= 0, LC_E_BADARG,
+               "lc_combine_terms_f32: need 1..4 terms");
+    for (int j = 0; j < terms; ++j) LC_REQUIRE(h_terms[j], LC_E_BADARG, "lc_combine_terms_f32: null term");
+    if (n == 0) return LC_OK;
+    const float* t[4] = {h_terms[0], terms > 1 ? h_terms[1] : nullptr, terms > 2 ? h_terms[2] : nullptr,
+                         terms > 3 ? h_terms[3] : nullptr};
+    float c[4] = {h_coef[0], terms > 1 ? h_coef[1] : 0.f, terms > 2 ? h_coef[2] : 0.f, terms > 3 ? h_coef[3] : 0.f};
+    hipLaunchKernelGGL(k_combine_terms, dim3((unsigned)lc::imin(lc::ceil_div<long long>(n, 256), 65535)), dim3(256), 0,
+                       lc::as_stream(stream), t[0], t[1], t[2], t[3], c[0], c[1], c[2], c[3], terms, d_out, (long long)n);
+    return lc::launched("k_combine_terms");
 }
 
 extern "C" int lc_gather_sub_f64(const double* d_k, int64_t ldk, const int32_t* d_rows, const int32_t* d_cols, int F,

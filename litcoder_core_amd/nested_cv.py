@@ -205,7 +205,7 @@ class RidgeCVEngine:
                                     for a in self.ser]) if self.ser else None)
         self.d_coef = ops.upload(np.asarray(self.coef_host, dtype=np.float64), self.dev) if self.ser else None
         self.d_cho = ops.upload(np.asarray(self.cho, dtype=np.int32), self.dev)
-        self.W_acc = torch.zeros((self.p, self.Vp), dtype=torch.float32, device=self.dev)
+        self.W_acc = ops.zeros((self.p, self.Vp), torch.float32, self.dev)
         self.aux = _aux_stream(self.dev)
         self.aux2 = _aux_stream(self.dev, 1)            # refit systems (see _refit_stream)
         self.comm = _aux_stream(self.dev, 2)            # per-fold result exchange + global statistics
@@ -278,15 +278,15 @@ class RidgeCVEngine:
     def lmax_systems(self, K, row_sets):
         """lambda_max(K[I, I]) for every row set I: all sets are principal submatrices of the one Gram matrix, so
         they share a single pass over K per Lanczos iteration, 32 systems per launch chain."""
-        out = []
+        res = torch.empty(len(row_sets), dtype=torch.float64, device=self.dev)
         for c0 in range(0, len(row_sets), 32):
             chunk = row_sets[c0:c0 + 32]
             bits = np.zeros(self.Ttot, dtype=np.uint32)
             for f, rows in enumerate(chunk):
                 bits[np.asarray(rows, dtype=np.int64)] |= np.uint32(1 << f)
             member = ops.upload(bits.view(np.int32), self.dev)
-            out.append(ops.lambda_max_masked(K, self.Ttot, member, len(chunk), self.steps))
-        return torch.cat(out)
+            ops.lambda_max_masked(K, self.Ttot, member, len(chunk), self.steps, out=res[c0:c0 + len(chunk)])
+        return res
 
     def _check_singcutoff(self, lmax):
         """normalpha: singcutoff against a_min = alpha_min S[0] with the measured S[0]^2 = lambda_max of the training
@@ -309,6 +309,25 @@ class RidgeCVEngine:
         self.p_folds = torch.empty((int(n_folds), self.V_total), dtype=torch.float64, device=self.dev)
         self.n_folds_done = 0
 
+    def _join_flags(self, parts):
+        """One int32 vector from the pivot-flag vectors of several batches (D2D copies, no framework kernel)."""
+        if not parts:
+            return ops.zeros(1, torch.int32, self.dev)
+        if len(parts) == 1:
+            return parts[0]
+        out = torch.empty(sum(int(p.numel()) for p in parts), dtype=torch.int32, device=self.dev)
+        o = 0
+        for p in parts:
+            out[o:o + p.numel()].copy_(p)
+            o += p.numel()
+        return out
+
+    def _cs_inv_padded(self, cs, Vt):
+        """The 2^e column scales padded to the plain GEMM's 256-column tiles (padding columns are never read back)."""
+        out = ops.zeros(Vt, torch.float32, self.dev)
+        out[: self.Vp].copy_(cs[self.Vp:])
+        return out
+
     # -------------------------------------------------------------- V-independent fp64 systems, dealt out over ranks
     def _sharded_solve(self, n_jobs, N, M, assemble, out=None, slot=None):
         """``n_jobs`` independent augmented systems (same list, same order on every rank): rank r factors jobs
@@ -328,7 +347,7 @@ class RidgeCVEngine:
             info = ops.batch_chol_solve(aug, len(mine), N, M, H, slot if direct else None)
             del aug
         else:
-            info = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            info = ops.zeros(1, torch.int32, self.dev)
         if self.shard.active:
             H = self.shard.all_gather(H).view(G * n_per, M, N)
         return H, info
@@ -449,26 +468,25 @@ class RidgeCVEngine:
             P = None
             if ser and moments:
                 rows_p, rowmap, _ = self._series_layout(M)
-                P = torch.zeros((fc, rows_p, N), dtype=torch.float32, device=self.dev)
+                P = ops.zeros((fc, rows_p, N), torch.float32, self.dev)
                 if N % COL_TILE == 0:
                     # the chain P'_j = P'_(j-1) (K[tr,tr] / lambda) on the f32 MFMA: its terms enter a prediction
                     # scaled by rho^j, fp32 products with fp32 accumulation keep them at full fp32 accuracy.
                     # Run transposed, Q_j = Kn Q_(j-1) with the folds as column groups of one grouped launch.
                     Mq = ops.pad_to(M, COL_TILE)
                     Kn = torch.empty((fc, N, N), dtype=torch.float32, device=self.dev)
-                    Q0 = torch.empty((fc, N, M), dtype=torch.float32, device=self.dev)
                     ops.gather_sub_f32(K, tr[f0:f0 + fc], tr[f0:f0 + fc], fc, N, N, lmax[f0:f0 + fc], Kn)
-                    ops.gather_sub_f32(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], Q0)   # K symmetric
-                    Q = torch.zeros((N, fc, Mq), dtype=torch.float32, device=self.dev)
-                    Q[:, :, :M] = Q0.permute(1, 0, 2)
-                    rm64 = rowmap.to(torch.int64)
+                    # Q_0[n][f][i] = K[tr_f[n], va_f[i]] / lambda_f  (K symmetric), zero in the padding columns
+                    Q = ops.zeros((N, fc, Mq), torch.float32, self.dev)
+                    ops.gather_sub_f32_strided(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], Q, Mq,
+                                               fc * Mq, 1)
                     tiles = [f * (Mq // COL_TILE) for f in range(fc + 1)]
                     for j in range(SERIES_TERMS):
                         if j:
                             Qn = torch.empty_like(Q)
                             ops.gemm_grouped(Kn, N, N * N, Q, fc * Mq, None, Qn, fc * Mq, N, fc * Mq, N, tiles)
                             Q = Qn
-                        P.index_copy_(1, rm64[j * M:(j + 1) * M], Q[:, :, :M].permute(1, 2, 0))
+                        ops.series_place(Q, N, fc, Mq, M, rowmap[j * M:(j + 1) * M], P, rows_p)
                 else:
                     ops.batch_series_terms(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], SERIES_TERMS,
                                            P, rowmap)
@@ -501,7 +519,7 @@ class RidgeCVEngine:
                     for j in range(fc * Ac):                 # voxel shards: beside the series alphas' hat matrices
                         H[(j // Ac) * A + cho[j % Ac]].copy_(Hc[j])          # (D2D copies)
             Hs.append((f0, fc, H, P))
-        info = torch.cat(infos) if infos else torch.zeros(1, dtype=torch.int32, device=self.dev)
+        info = self._join_flags(infos)
         return dict(F=F, N=N, M=M, n_v=n_v, n_i=n_i, tr=tr, va=va, shared=self._shared_image(inner_abs, N), Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
                     d_ser=d_ser, moments=moments, series_ready=series_ready)
 
@@ -519,7 +537,10 @@ class RidgeCVEngine:
         Ad = len(cho) if moments else A                   # alphas that go through the fused sweep
         main = torch.cuda.current_stream()
         scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
-        scores_d = torch.empty((Ad, self.Vp), dtype=torch.float32, device=self.dev) if moments and Ad else scores
+        cho_first = list(cho) == list(range(len(cho)))     # ascending grids: the factorised alphas are rows 0 .. Ad-1
+        scores_d = scores
+        if moments and Ad:
+            scores_d = scores[:Ad] if cho_first else torch.empty((Ad, self.Vp), dtype=torch.float32, device=self.dev)
         part = torch.empty((max(Ad, 1) * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
         split, cs = hat["split"], hat["cs"]
         if hat.get("data_ready") is not None:
@@ -554,8 +575,7 @@ class RidgeCVEngine:
             Pt = torch.empty(ops.pad_to(Tm, 256) * N * 2, dtype=torch.float16, device=self.dev)
             rs_p = torch.empty(ops.pad_to(Tm, 256), dtype=torch.float32, device=self.dev)
             Tbuf = torch.empty((Tm, Vt), dtype=torch.float32, device=self.dev)
-            cs_inv = torch.ones(Vt, dtype=torch.float32, device=self.dev)      # padded to the plain GEMM's tiles
-            cs_inv[: self.Vp] = cs[self.Vp:]
+            cs_inv = self._cs_inv_padded(cs, Vt)                               # padded to the plain GEMM's tiles
             if hat.get("series_ready") is not None:
                 main.wait_event(hat["series_ready"])
             for f, j, H, P in folds:
@@ -586,8 +606,9 @@ class RidgeCVEngine:
             else:
                 ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], yv[b], n_v[f], ystat[b], yblk[b],
                                        self.mode, part, scores, accumulate=f > 0)
-        if moments and Ad:
-            scores.index_copy_(0, self.d_cho.to(torch.int64), scores_d)
+        if moments and Ad and not cho_first:
+            for i, a in enumerate(cho):
+                scores[a].copy_(scores_d[i])
         self.sweeps_done = torch.cuda.Event()
         self.sweeps_done.record()
         return scores
@@ -664,7 +685,7 @@ class RidgeCVEngine:
             idx[self.PP:self.PP + n_t] = np.asarray(te_rows, dtype=np.int64)
             return ops.gather_rows_f64(X, ops.idx_tensor(idx, rows, self.dev), 1, rows, self.p, self.PP)[0]
         rows = ops.pad_to(self.p_pad + ops.pad_to(n_t, LC_MB), self._refit_row_granule())
-        rhs = torch.zeros((rows, N_o), dtype=torch.float64, device=self.dev)
+        rhs = ops.zeros((rows, N_o), torch.float64, self.dev)
         ops.transpose_rows(X, tr_o, N_o, self.p, rhs)
         if n_t:                                        # K[te, tr] below X', padded columns (index -1) zero
             ops.gather_sub_f64(K, ops.idx_tensor(te_rows, n_t, self.dev), tr_o, 1, n_t, N_o, rhs[self.p_pad:self.p_pad + n_t])
@@ -740,22 +761,18 @@ class RidgeCVEngine:
                 if a in used:
                     Malpha[used.index(a)].copy_(Mc[i])
             flags.append(info_n)
-        info = torch.cat(flags) if flags else torch.zeros(1, dtype=torch.int32, device=self.dev)
+        info = self._join_flags(flags)
         if poly:
             Kn = torch.empty((1, N_o, N_o), dtype=torch.float32, device=self.dev)
             ops.gather_sub_f32(K, tr_o, tr_o, 1, N_o, N_o, lmax_o, Kn)
-            R = (rhs / lmax_o).to(torch.float32)
+            R = ops.scale_cast_f64_f32(rhs, lmax_o, torch.empty(rhs.shape, dtype=torch.float32, device=self.dev))
             terms = [R]
             for _ in range(1, SERIES_TERMS):
                 Rn = torch.empty_like(R)
                 ops.gemm_grouped(terms[-1], N_o, 0, Kn[0], N_o, None, Rn, N_o, rows, N_o, N_o, [0, N_o // COL_TILE])
                 terms.append(Rn)
             for a in poly:
-                c = self.coef_host[self.ser.index(a)]
-                M = Malpha[used.index(a)]
-                torch.mul(terms[0], float(c[0]), out=M)
-                for j in range(1, SERIES_TERMS):
-                    M.add_(terms[j], alpha=float(c[j]))
+                ops.combine_terms(terms, self.coef_host[self.ser.index(a)], Malpha[used.index(a)])
         return Malpha, info
 
     def _refit_operands(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs):
@@ -774,7 +791,7 @@ class RidgeCVEngine:
             cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)
             ops.gather(cs.reshape(2, self.Vp), self.Vp, None, 2, perm, Vs, cs_s)
             Yt = torch.empty(Vs * N_o * 2, dtype=torch.float16, device=self.dev)
-            ops.split_cols_f16(Ys, Vs, torch.arange(N_o, dtype=torch.int32, device=self.dev), N_o, cs_s[0], Yt)
+            ops.split_cols_f16(Ys, Vs, ops.idx_tensor(np.arange(N_o), N_o, self.dev), N_o, cs_s[0], Yt)
             o.update(cs_s=cs_s, Yt=Yt)
         return o
 
@@ -1016,7 +1033,7 @@ class RidgeCVEngine:
         yblk = torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
         yv = torch.empty((M, self.Vp), dtype=torch.float32, device=self.dev)
         Vt = ops.pad_to(self.Vp, 256)
-        B = torch.zeros((PP, Vt), dtype=torch.float32, device=self.dev)
+        B = ops.zeros((PP, Vt), torch.float32, self.dev)
         ident = ops.idx_tensor(np.arange(self.p), PP, self.dev)
         shared = hat.get("shared") if split else None
         views = [(0, 0, 0)] * F
@@ -1030,8 +1047,7 @@ class RidgeCVEngine:
                 views = [(len(union), g0, gl) for g0, gl in gaps]
             else:
                 Yt = torch.empty(Vt * Nmax * 2, dtype=torch.float16, device=self.dev)
-            cs_inv = torch.ones(Vt, dtype=torch.float32, device=self.dev)
-            cs_inv[: self.Vp] = cs[self.Vp:]
+            cs_inv = self._cs_inv_padded(cs, Vt)
             Bt = torch.empty(Vt * PP * 2, dtype=torch.float16, device=self.dev)
             rows_pad = ops.pad_to(A * M, 256)
             Ht = torch.empty(rows_pad * PP * 2, dtype=torch.float16, device=self.dev)
@@ -1066,13 +1082,12 @@ class RidgeCVEngine:
         n_t = len(te)
         Vt = ops.pad_to(self.Vp, 256)
         No = ops.pad_to(len(st["tr"]), 2 * K_TILE)
-        ext = torch.zeros((PP + n_t, Vt), dtype=torch.float32, device=self.dev)
+        ext = ops.zeros((PP + n_t, Vt), torch.float32, self.dev)
         if st["split"]:
             At = torch.empty(256 * st["Nmax"] * 2, dtype=torch.float16, device=self.dev)
             rs_a = torch.empty(256, dtype=torch.float32, device=self.dev)
             Yt = torch.empty(Vt * No * 2, dtype=torch.float16, device=self.dev)
-            cs_inv = torch.ones(Vt, dtype=torch.float32, device=self.dev)
-            cs_inv[: self.Vp] = st["cs"][self.Vp:]
+            cs_inv = self._cs_inv_padded(st["cs"], Vt)
             ops.split_cols_f16(Y, self.Vp, st["tr_o_rows"], No, st["cs"], Yt)
             ops.split_rows_f16(st["Xt_o"], PP, No, At, rs_a)
             ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, ext, Vt, Vt, No, [0, Vt // 256])
@@ -1306,7 +1321,13 @@ class RidgeCVEngine:
         return self.fold_collect(self.fold_refit(st, single_alpha, weight_scale))
 
     def weights(self) -> np.ndarray:
-        return self.W_acc[:, : self.V].cpu().numpy()
+        """The (p, V) float32 weights as a host array.  The array lives in page-locked memory (the D2H copy is then one
+        DMA at link rate instead of a staged copy through the driver: 0.98 GB at cfg2); it is an ordinary numpy array
+        that owns its buffer through torch's caching host allocator."""
+        h = torch.empty((self.p, self.V), dtype=torch.float32, pin_memory=True)
+        h.copy_(self.W_acc[:, : self.V], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return h.numpy()
 
 
 def _alpha_vector(alphas, idx, single_alpha):

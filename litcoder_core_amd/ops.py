@@ -51,6 +51,17 @@ def idx_tensor(rows, length, dev, fill=-1):
     return upload(h, dev)
 
 
+def filled(shape, dtype, dev, byte=0):
+    """torch.empty + hipMemsetAsync on the current stream (0 = zeros, 0xFF = -1 for int32): no framework fill kernel."""
+    t = torch.empty(shape, dtype=dtype, device=dev)
+    _lib.call("lc_fill_bytes", _p(t), int(byte), t.numel() * t.element_size(), _s())
+    return t
+
+
+def zeros(shape, dtype, dev):
+    return filled(shape, dtype, dev, 0)
+
+
 def idx_matrix(row_sets, length, dev, fill=-1):
     """(len(row_sets), length) int32 device matrix of index lists, one upload."""
     h = np.full((len(row_sets), length), fill, dtype=np.int32)
@@ -157,22 +168,83 @@ def segment_reduce(data, seg, idx, how):
 
 
 # ------------------------------------------------------------------ casts / gathers
-def upload_f32(host, ld, dev, rows_pad=None, chunk_bytes=1 << 28):
-    """Host (rows, cols) real array -> zero-padded (rows_pad or rows, ld) f32 device buffer.
-    float64 input is cast on the device (lc_cast_f64_f32), mirroring
-    ``torch.tensor(x, dtype=torch.float32)`` (nested_cv.py:99-100)."""
+_UPLOAD = {"pinned": None, "pool": None}
+_UPLOAD_CHUNK = 32 << 20            # bytes per pinned staging chunk
+_UPLOAD_DEPTH = 6                   # chunks in flight
+
+
+def _upload_ring():
+    """Pinned staging chunks + copy threads of the process (created on first use)."""
+    if _UPLOAD["pinned"] is None:
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        _UPLOAD["pinned"] = [torch.empty(_UPLOAD_CHUNK, dtype=torch.uint8, pin_memory=True) for _ in range(_UPLOAD_DEPTH)]
+        _UPLOAD["pool"] = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 4) // 2)))
+    return _UPLOAD["pinned"], _UPLOAD["pool"]
+
+
+def upload_f32(host, ld, dev, rows_pad=None):
+    """Host (rows, cols) real array -> zero-padded (rows_pad or rows, ld) f32 device buffer.  float64 input is cast on
+    the device (lc_cast_f64_f32), mirroring ``torch.tensor(x, dtype=torch.float32)`` (nested_cv.py:99-100).
+
+    The caller's array is pageable: a plain copy stages it through the driver at ~10 GB/s (170 ms for cfg2's 1.92 GB
+    of targets, more than the whole fit).  Here row chunks are copied into a ring of pinned buffers by a few threads
+    (numpy's copy releases the GIL), each chunk leaves by an asynchronous H2D copy as soon as it is staged, and the
+    cast to fp32 follows it on the stream; a pinned chunk is refilled once its copy has completed."""
     host = np.asarray(host)
+    if host.ndim != 2:
+        raise ValueError("expected a 2-D array")
     rows, cols = host.shape
-    out = torch.zeros((rows_pad or rows, ld), dtype=torch.float32, device=dev)
-    if host.dtype == np.float32:
-        out[:rows, :cols].copy_(torch.from_numpy(np.ascontiguousarray(host)))
+    out = zeros((rows_pad or rows, ld), torch.float32, dev)
+    if rows == 0 or cols == 0:
         return out
-    host = np.ascontiguousarray(host, dtype=np.float64)
-    step = max(1, chunk_bytes // max(1, cols * 8))
-    for r0 in range(0, rows, step):
-        blk = torch.from_numpy(host[r0:r0 + step]).to(dev)
-        dst = out[r0:r0 + blk.shape[0]]
-        _lib.call("lc_cast_f64_f32", _p(blk), cols, _p(dst), ld, blk.shape[0], cols, _s())
+    if host.dtype not in (np.float32, np.float64):
+        host = host.astype(np.float64)
+    host = np.ascontiguousarray(host)
+    item = host.dtype.itemsize
+    step = max(1, _UPLOAD_CHUNK // (cols * item))
+    if cols * item > _UPLOAD_CHUNK:                     # absurdly wide rows: the plain path
+        blk = torch.from_numpy(host).to(dev)
+        if host.dtype == np.float32:
+            out[:rows, :cols].copy_(blk)
+        else:
+            _lib.call("lc_cast_f64_f32", _p(blk), cols, _p(out), ld, rows, cols, _s())
+        return out
+    pinned, pool = _upload_ring()
+    tdt = torch.float32 if item == 4 else torch.float64
+    chunks = [(r0, min(rows, r0 + step)) for r0 in range(0, rows, step)]
+    free_at = [None] * len(pinned)                      # event after which a pinned chunk may be refilled
+
+    def stage(k, r0, r1):
+        if free_at[k] is not None:
+            free_at[k].synchronize()
+        view = pinned[k][: (r1 - r0) * cols * item].view(tdt).view(r1 - r0, cols)
+        view.numpy()[:] = host[r0:r1]
+        return view
+
+    futs = {}
+    for j in range(min(len(pinned), len(chunks))):
+        futs[j] = pool.submit(stage, j % len(pinned), *chunks[j])
+    dev_stage = [torch.empty(step * cols, dtype=tdt, device=dev) for _ in range(2)] if item == 8 else None
+    for j, (r0, r1) in enumerate(chunks):
+        k = j % len(pinned)
+        view = futs.pop(j).result()
+        n = r1 - r0
+        if item == 4:
+            out[r0:r1, :cols].copy_(view, non_blocking=True)
+        else:
+            d = dev_stage[j & 1][: n * cols].view(n, cols)
+            d.copy_(view, non_blocking=True)
+            _lib.call("lc_cast_f64_f32", _p(d), cols, _p(out[r0:r1]), ld, n, cols, _s())
+        ev = torch.cuda.Event()
+        ev.record()
+        free_at[k] = ev
+        nxt = j + len(pinned)
+        if nxt < len(chunks):
+            futs[nxt] = pool.submit(stage, k, *chunks[nxt])
+    for ev in free_at:                                  # the ring belongs to the process: leave it idle
+        if ev is not None:
+            ev.synchronize()
     return out
 
 
@@ -235,10 +307,11 @@ def lambda_max(k, rows, F, N, steps):
     return out
 
 
-def lambda_max_masked(k, T, member, F, steps):
+def lambda_max_masked(k, T, member, F, steps, out=None):
     """lambda_max of K[I_f, I_f] for F <= 32 row sets given as bit f of member[i] (int32 tensor of T words)."""
-    work = torch.empty(F * (3 * T + 2 * steps + 8), dtype=torch.float64, device=k.device)
-    out = torch.empty(F, dtype=torch.float64, device=k.device)
+    work = torch.empty(F * (3 * T + 2 * steps + 8) + 4 * 32 * T, dtype=torch.float64, device=k.device)
+    if out is None:
+        out = torch.empty(F, dtype=torch.float64, device=k.device)
     _lib.call("lc_lambda_max_masked", _p(k), k.stride(0), T, _p(member), F, steps, _p(work), _p(out), _s())
     return out
 
@@ -354,6 +427,30 @@ def gather_sub_f64(k, rows, cols, F, R, C, out):
     _lib.call("lc_gather_sub_f64", _p(k), k.stride(0), _p(rows), _p(cols), F, R, C, _p(out), _s())
 
 
+def gather_sub_f32_strided(k, rows, cols, F, R, C, scale, out, s_f, s_r, s_c):
+    """out[f * s_f + i * s_r + j * s_c] = K[rows[f][i], cols[f][j]] / scale[f] as f32."""
+    _lib.call("lc_gather_sub_f32_strided", _p(k), k.stride(0), _p(rows), _p(cols), F, R, C, _p(scale), _p(out), s_f, s_r, s_c,
+              _s())
+
+
+def series_place(q, N, F, ldq, M, rowmap, P, rows_p):
+    _lib.call("lc_series_place", _p(q), N, F, ldq, M, _p(rowmap), _p(P), rows_p, _s())
+
+
+def scale_cast_f64_f32(src, divisor, dst):
+    _lib.call("lc_scale_cast_f64_f32", _p(src), _p(divisor), _p(dst), src.numel(), _s())
+    return dst
+
+
+def combine_terms(terms, coef, out):
+    """out = sum_j coef[j] * terms[j] (<= 4 contiguous f32 tensors of out's size), left to right in fp32."""
+    n = len(terms)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+    cf = (ctypes.c_float * n)(*[float(c) for c in coef])
+    _lib.call("lc_combine_terms_f32", ptrs, cf, n, _p(out), out.numel(), _s())
+    return out
+
+
 def gather_sub_f32(k, rows, cols, F, R, C, scale, out):
     _lib.call("lc_gather_sub_f32", _p(k), k.stride(0), _p(rows), _p(cols), F, R, C, _p(scale), _p(out), _s())
 
@@ -385,7 +482,7 @@ def col_scales_f16(y, T, V):
     """(cs, flag): cs[:V] = 2^-e, cs[V:] = 2^e per column; flag (device int32) != 0 when some column's
     dynamic range is too wide for the fp16 hi/lo split."""
     cs = torch.empty(2 * V, dtype=torch.float32, device=y.device)
-    flag = torch.zeros(1, dtype=torch.int32, device=y.device)
+    flag = zeros(1, torch.int32, y.device)
     _lib.call("lc_col_scales_f16", _p(y), y.stride(0), T, V, _p(cs), _p(flag), _s())
     return cs, flag
 
@@ -434,7 +531,7 @@ def fold_unpack(src, world, ld, lo, w_max, r, p, idx, p_clean, bad):
 
 
 def group_by_alpha(best, V, A, pad):
-    perm = torch.full((V + A * pad,), -1, dtype=torch.int32, device=best.device)
+    perm = filled((V + A * pad,), torch.int32, best.device, 0xFF)             # -1 everywhere
     count = torch.empty((2, A), dtype=torch.int32, device=best.device)       # row 0: counts; row 1: a copy (callers
     _lib.call("lc_group_by_alpha", _p(best), V, A, pad, _p(perm), _p(count), _s())      # all-reduce it over shards)
     count[1].copy_(count[0])
