@@ -209,6 +209,7 @@ class RidgeCVEngine:
         self.aux = _aux_stream(self.dev)
         self.aux2 = _aux_stream(self.dev, 1)            # refit systems (see _refit_stream)
         self.comm = _aux_stream(self.dev, 2)            # per-fold result exchange + global statistics
+        self.aux3 = _aux_stream(self.dev, 3)            # voxel shards: what a fold's refit still needs after refit_ahead
         # voxel shards: this rank's block is columns [lo[rank], lo[rank + 1]) of V_total; the statistics tail (BH-FDR
         # ranks ALL p-values) runs on the gathered vectors, on the device, on every rank; the driver sets alpha_fdr
         self.V_total = int(V_total) if V_total is not None else self.V
@@ -1180,9 +1181,10 @@ class RidgeCVEngine:
 
             Hj, info = self._sharded_solve(nF * Gc * S, N_o, rsz, assemble)
             Mall = Hj[: nF * Gc * S].view(nF, Gc, rows, N_o)
-            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record()
         for fo, st in enumerate(sts):
-            st["spec"] = dict(alphas=list(cho), M=Mall[fo], info=info, rhs=rhss[fo])
+            st["spec"] = dict(alphas=list(cho), M=Mall[fo], info=info, rhs=rhss[fo], ready=ready)
             for t in (st.get("X"), st.get("K"), st.get("tr_o"), st.get("lmax_o")):
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(rs_stream)
@@ -1219,7 +1221,19 @@ class RidgeCVEngine:
         best, split = st["best"], st["split"]
         perm, used, tiles, Vs, used_all = self._refit_groups(best, split, st.pop("grouping"))
         main = torch.cuda.current_stream()
-        with torch.cuda.stream(self._refit_stream(st)):    # inputs: X, K, tr_o, lmax_o -- all made on aux or at start
+        spec = st.get("spec")
+        if spec is not None and spec.get("ready") is not None:
+            # voxel shards: the fold's factorised systems came from refit_ahead; what is left (the shared powers of the
+            # polynomial alphas, copies) must not queue behind the later folds' batches on the refit stream
+            rs = self.aux3
+            rs.wait_event(spec["ready"])
+            rs.wait_event(st["done"])
+            for t in (st.get("X"), st.get("K"), st.get("tr_o"), st.get("lmax_o"), spec["M"], spec["rhs"], spec["info"]):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(rs)
+        else:
+            rs = self._refit_stream(st)                    # inputs: X, K, tr_o, lmax_o -- all made on aux or at start
+        with torch.cuda.stream(rs):
             Malpha, info_o = self._refit_systems(st["X"], st["K"], st["tr"], used, st.get("tr_o"), st.get("lmax_o"),
                                                  st["te"], spec=st.get("spec"), used_all=used_all)
             ready = torch.cuda.Event()
@@ -1514,9 +1528,34 @@ class NestedCVModel(BasePredictivityModel):
             # start as soon as its own systems are done), then ALL other folds as one batch
             first = eng.prepare_folds(outer[:1], lmax_pre[:1])[0]
             st = eng.fold_begin(*outer[0], prepared=first)
-            prepared = eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else []
             if shard.world > 1:
-                eng.refit_ahead([first] + prepared)         # aux2: every fold's refit systems, one collective batch
+                # voxel shards: a rank's V-wide work per fold is a few ms, the same order as one latency chain of its
+                # share of a fold's systems -- so the folds are prepared one by one (all queued now, nothing gated), each
+                # ready when its sweeps come up; and every fold's refit systems for every factorised alpha are solved
+                # collectively ahead of the choices (aux2), fold 0's first
+                import os
+                plan = os.environ.get("LITCODER_SHARD_PLAN", "h:1-;r:0|1-")   # experiment knob: fold groups of the batches
+
+                def groups(spec, lo):
+                    out = []
+                    for part in spec.split("|"):
+                        a, _, b = part.partition("-")
+                        a = int(a)
+                        b = (n - 1 if b == "" else int(b)) if "-" in part else a
+                        out.append([i for i in range(max(a, lo), min(b, n - 1) + 1)])
+                    return [g for g in out if g]
+
+                hp, rp = (x.split(":")[1] for x in plan.split(";"))
+                prepared = [None] * n
+                prepared[0] = first
+                for g in groups(hp, 1):
+                    for i, st_g in zip(g, eng.prepare_folds([outer[i] for i in g], [lmax_pre[i] for i in g])):
+                        prepared[i] = st_g
+                for g in groups(rp, 0):
+                    eng.refit_ahead([prepared[i] for i in g])
+                prepared = prepared[1:]
+            else:
+                prepared = eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else []
             for i in range(n):
                 eng.fold_choose(st, single_alpha)               # main: argmax + grouping; the histogram leaves asynchronously
                 st_next = None
