@@ -111,7 +111,6 @@ def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, 
     """`warmup` untimed + `steps` timed device-resident fits, barrier + synchronize on both sides, MAX over ranks.
     Returns (seconds, last metrics, kernel timing dict or None, plain-GEMM flops counted during the timed steps)."""
     from litcoder_core_amd import ops
-    from litcoder_core_amd.nested_cv import LAST_SWEEP
 
     def step():
         return model.fit_predict_device(dX, dY, p, V, n_voxels_total=None if world == 1 else V_total,
@@ -129,11 +128,12 @@ def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, 
     if collect_kernels:
         ops.timing_enable(True)
         ops.timing_read()
-    flops0 = LAST_SWEEP["plain_flops"]
+    plain_flops = 0.0
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         metrics, _, _ = step()
+        plain_flops += model.last_fit.get("plain_flops", 0.0)
     fence()
     elapsed = time.perf_counter() - t0
     kern = None
@@ -144,7 +144,7 @@ def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, 
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, metrics, kern, LAST_SWEEP["plain_flops"] - flops0
+    return elapsed, metrics, kern, plain_flops
 
 
 def host_path_leg(dX, dY, p, V, alphas, steps=2):
@@ -212,8 +212,7 @@ def main():
     dX, dY, p, V, V_total = inputs(args.scaling)
     elapsed, metrics, kern, plain_flops = timed_fits(model, dX, dY, p, V, V_total, alphas, args.steps, args.warmup,
                                                      world, dev, collect_kernels=True)
-    from litcoder_core_amd.nested_cv import LAST_SWEEP
-    sweep = dict(LAST_SWEEP)
+    sweep = dict(model.last_fit)
     other = None
     if world > 1 and not args.no_extra_legs:
         mode2 = "strong" if args.scaling == "weak" else "weak"

@@ -558,13 +558,16 @@ __global__ void __launch_bounds__(256, 2) k_mm64q(const MMArgs g) {
 constexpr int ST_LDC = NB + 2;     // row stride of the C tile in LDS
 
 // acc += A B' (BT: B stored [n][k]) or A B (B stored [k][n]) for one 64 x 64 tile, depth % 16 == 0, operands staged
-// through LDS in depth-16 chunks exactly like k_mm64 (4 waves, 2 x 2, each 32 x 32).  A_LDS: A is a 64 x 64 tile
+// through LDS in depth-16 chunks like k_mm64.  The products run on v_mfma_f64_4x4x4_4b_f64 (see k_mm64q: the only
+// fp64 MFMA form that issues at the datasheet rate on this part): wave w owns rows 16 w .. 16 w + 15 and all 64
+// columns, acc[i][j] = rows 4 i + (lane >> 4) of its strip x columns 16 j + (lane & 15); one depth-4 step is 4 A
+// fragments (LDS broadcast reads), 4 B fragments and 16 MFMAs with tied AGPR accumulators.  A_LDS: A is a 64 x 64 tile
 // already in LDS (row stride ST_LDC) and depth == 64.
 template <bool BT, bool A_LDS>
-__device__ inline void tile_mac(f64x4 (&acc)[2][2], const double* __restrict__ A, long long lda, int a_rows,
+__device__ inline void tile_mac(double (&acc)[4][4], const double* __restrict__ A, long long lda, int a_rows,
                                 const double* __restrict__ B, long long ldb, int depth, double* sA, double* sB) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wm = w >> 1, wn = w & 1, li = lane & 15, lq = lane >> 4;
+    const int li = lane & 15, lq = lane >> 4;
     f64x2 ra[2], rb[2];
     auto fetch = [&](int k0) {
 #pragma unroll
@@ -600,23 +603,24 @@ __device__ inline void tile_mac(f64x4 (&acc)[2][2], const double* __restrict__ A
     __syncthreads();                                   // the previous user of sA / sB is done
     stash();
     __syncthreads();
-    const double* pb = sB + (wn * 32 + li) * MM_LD + lq;
+    const double* pb = sB + li * MM_LD + lq;
     for (int k0 = 0; k0 < depth; k0 += MM_KC) {
         const bool more = k0 + MM_KC < depth;
         if (more) fetch(k0 + MM_KC);
-        const double* pa = A_LDS ? A + (wm * 32 + li) * ST_LDC + k0 + lq : sA + (wm * 32 + li) * MM_LD + lq;
+        const double* pa = A_LDS ? A + (w * 16 + (lane & 3)) * ST_LDC + k0 + lq : sA + (w * 16 + (lane & 3)) * MM_LD + lq;
         constexpr int LDA = A_LDS ? ST_LDC : MM_LD;
 #pragma unroll
         for (int k4 = 0; k4 < MM_KC / 4; ++k4) {
-            double a[2], b[2];
+            double fa[4], fb[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = pa[i * 16 * LDA + 4 * k4];
+            for (int i = 0; i < 4; ++i) fa[i] = pa[i * 4 * LDA + 4 * k4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = pb[j * 16 * MM_LD + 4 * k4];
+            for (int j = 0; j < 4; ++j) fb[j] = pb[j * 16 * MM_LD + 4 * k4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[i]), "v"(fb[j]));
         }
         if (more) {
             __syncthreads();
@@ -624,133 +628,62 @@ __device__ inline void tile_mac(f64x4 (&acc)[2][2], const double* __restrict__ A
             __syncthreads();
         }
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the MFMAs above are opaque to the hazard recogniser
 }
 
-// element (row, col) of the 64 x 64 tile that accumulator acc[i][j][r] of this lane holds
-#define LC_TILE_ROW(i, r) (wm * 32 + (i) * 16 + lq + 4 * (r))
-#define LC_TILE_COL(j) (wn * 32 + (j) * 16 + li)
+// element (row, col) of the 64 x 64 tile that accumulator acc[i][j] of this lane holds
+#define LC_TILE_ROW(i) (w * 16 + (i) * 4 + lq)
+#define LC_TILE_COL(j) ((j) * 16 + li)
+#define LC_FOR_TILE(i, j) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)
 
 __global__ void __launch_bounds__(256, 2) k_lstep(double* __restrict__ aug, int N, int M, int k, int K0, int K1,
                                                   const double* __restrict__ linv) {
     __shared__ double sA[NB * MM_LD], sB[NB * MM_LD], sC[NB * ST_LDC];
     const int R = N + M, nb = N / NB;
-    const int i = k + 1 + blockIdx.x, b = blockIdx.y;
-    const int r0 = i * NB, a_rows = min(NB, R - r0);
+    const int i_t = k + 1 + blockIdx.x, b = blockIdx.y;
+    const int r0 = i_t * NB, a_rows = min(NB, R - r0);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wm = w >> 1, wn = w & 1, li = lane & 15, lq = lane >> 4;
+    const int li = lane & 15, lq = lane >> 4;
     double* Ab = aug + (long long)b * R * N;
     double* Arow = Ab + (long long)r0 * N;
     const double* Lk = linv + ((long long)b * nb + k) * NB * NB;
-    f64x4 acc[2][2];
-    auto zero = [&]() {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = f64x4{0.0, 0.0, 0.0, 0.0};
-    };
+    double acc[4][4];
     // (1) C = A[i,k] - L[i,k-1] L[k,k-1]'  -> LDS
-    zero();
+    LC_FOR_TILE(i, j) acc[i][j] = 0.0;
     if (k > K0) tile_mac<true, false>(acc, Arow + (k - 1) * NB, N, a_rows, Ab + (long long)k * NB * N + (k - 1) * NB, N, NB, sA, sB);
     {
         const double* src = Arow + k * NB;
-        double old[2][2][4];
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = LC_TILE_ROW(ii, r);
-                    old[ii][jj][r] = row < a_rows ? src[(long long)row * N + LC_TILE_COL(jj)] : 0.0;
-                }
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sC[LC_TILE_ROW(ii, r) * ST_LDC + LC_TILE_COL(jj)] = old[ii][jj][r] - acc[ii][jj][r];
+        double old[4][4];
+        LC_FOR_TILE(i, j) old[i][j] = LC_TILE_ROW(i) < a_rows ? src[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] : 0.0;
+        LC_FOR_TILE(i, j) sC[LC_TILE_ROW(i) * ST_LDC + LC_TILE_COL(j)] = old[i][j] - acc[i][j];
     }
     // (2) L[i,k] = C Linv_kk'   (tile_mac's first barrier makes sC visible)
-    zero();
+    LC_FOR_TILE(i, j) acc[i][j] = 0.0;
     tile_mac<true, true>(acc, sC, 0, a_rows, Lk, NB, NB, sA, sB);
     {
         double* dst = Arow + k * NB;
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = LC_TILE_ROW(ii, r);
-                if (row < a_rows)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) dst[(long long)row * N + LC_TILE_COL(jj)] = acc[ii][jj][r];
-            }
+        LC_FOR_TILE(i, j) if (LC_TILE_ROW(i) < a_rows) dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] = acc[i][j];
     }
     if (k + 1 >= K1) return;
     // (3) pre-update of the tile in column k+1
-    const bool own = i == k + 1;                       // row tile k+1: its L[k+1,k] is the tile just formed
+    const bool own = i_t == k + 1;                     // row tile k+1: its L[k+1,k] is the tile just formed
     if (own) {
         __syncthreads();                               // everyone has read sC as the A operand
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sC[LC_TILE_ROW(ii, r) * ST_LDC + LC_TILE_COL(jj)] = acc[ii][jj][r];
+        LC_FOR_TILE(i, j) sC[LC_TILE_ROW(i) * ST_LDC + LC_TILE_COL(j)] = acc[i][j];
     }
     if (!own && k == K0) return;                       // nothing final to apply yet
-    zero();
+    LC_FOR_TILE(i, j) acc[i][j] = 0.0;
     if (k > K0)
         tile_mac<true, false>(acc, Arow + K0 * NB, N, a_rows, Ab + (long long)(k + 1) * NB * N + K0 * NB, N, (k - K0) * NB, sA, sB);
-    if (own) {
-        // + L[k+1,k] L[k+1,k]' with both operands = the tile in sC: stage it as B ([n][k]) through the chunk loop
-        __syncthreads();
-        for (int k0 = 0; k0 < NB; k0 += MM_KC) {
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int e = t + 256 * q, row = e >> 3, kp = e & 7;
-                *reinterpret_cast<f64x2*>(sB + row * MM_LD + 2 * kp) =
-                    f64x2{sC[row * ST_LDC + k0 + 2 * kp], sC[row * ST_LDC + k0 + 2 * kp + 1]};
-            }
-            __syncthreads();
-            const double* pa = sC + (wm * 32 + li) * ST_LDC + k0 + lq;
-            const double* pb = sB + (wn * 32 + li) * MM_LD + lq;
-#pragma unroll
-            for (int k4 = 0; k4 < MM_KC / 4; ++k4) {
-                double a[2], bb[2];
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii) a[ii] = pa[ii * 16 * ST_LDC + 4 * k4];
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) bb[jj] = pb[jj * 16 * MM_LD + 4 * k4];
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-                        acc[ii][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ii], bb[jj], acc[ii][jj], 0, 0, 0);
-            }
-        }
+    if (own) {                                         // + L[k+1,k] L[k+1,k]': both operands are the tile in sC
+        __syncthreads();                               // tile_mac fetches B (= sC here) before its first barrier
+        tile_mac<true, true>(acc, sC, 0, a_rows, sC, ST_LDC, NB, sA, sB);
     }
     {
         double* dst = Arow + (k + 1) * NB;
-        double old[2][2][4];
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = LC_TILE_ROW(ii, r);
-                    old[ii][jj][r] = row < a_rows ? dst[(long long)row * N + LC_TILE_COL(jj)] : 0.0;
-                }
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = LC_TILE_ROW(ii, r);
-                if (row < a_rows)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) dst[(long long)row * N + LC_TILE_COL(jj)] = old[ii][jj][r] - acc[ii][jj][r];
-            }
+        double old[4][4];
+        LC_FOR_TILE(i, j) old[i][j] = LC_TILE_ROW(i) < a_rows ? dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] : 0.0;
+        LC_FOR_TILE(i, j) if (LC_TILE_ROW(i) < a_rows) dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] = old[i][j] - acc[i][j];
     }
 }
 
@@ -761,57 +694,31 @@ __global__ void __launch_bounds__(256, 2) k_bstep(double* __restrict__ aug, int 
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * NB, a_rows = min(NB, M - r0);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wm = w >> 1, wn = w & 1, li = lane & 15, lq = lane >> 4;
+    const int li = lane & 15, lq = lane >> 4;
     double* Ab = aug + (long long)b * R * N;
     double* Zrow = Ab + (long long)(N + r0) * N;
     const double* Lk = linv + ((long long)b * nb + k) * NB * NB;
-    f64x4 acc[2][2];
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = f64x4{0.0, 0.0, 0.0, 0.0};
+    double acc[4][4];
+    LC_FOR_TILE(i, j) acc[i][j] = 0.0;
     // C = Z[i,k] - sum_{j = k+1 .. K1-1} H[i,j] L[j,k]  -> LDS
     const int depth = (K1 - 1 - k) * NB;
     if (depth > 0)
         tile_mac<false, false>(acc, Zrow + (k + 1) * NB, N, a_rows, Ab + (long long)(k + 1) * NB * N + k * NB, N, depth, sA, sB);
     {
         const double* src = Zrow + k * NB;
-        double old[2][2][4];
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = LC_TILE_ROW(ii, r);
-                    old[ii][jj][r] = row < a_rows ? src[(long long)row * N + LC_TILE_COL(jj)] : 0.0;
-                }
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sC[LC_TILE_ROW(ii, r) * ST_LDC + LC_TILE_COL(jj)] = old[ii][jj][r] - acc[ii][jj][r];
+        double old[4][4];
+        LC_FOR_TILE(i, j) old[i][j] = LC_TILE_ROW(i) < a_rows ? src[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] : 0.0;
+        LC_FOR_TILE(i, j) sC[LC_TILE_ROW(i) * ST_LDC + LC_TILE_COL(j)] = old[i][j] - acc[i][j];
     }
     // H[i,k] = C Linv_kk
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) acc[ii][jj] = f64x4{0.0, 0.0, 0.0, 0.0};
+    LC_FOR_TILE(i, j) acc[i][j] = 0.0;
     tile_mac<false, true>(acc, sC, 0, a_rows, Lk, NB, NB, sA, sB);
     double* dst = Zrow + k * NB;
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = LC_TILE_ROW(ii, r);
-            if (row < a_rows)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) dst[(long long)row * N + LC_TILE_COL(jj)] = acc[ii][jj][r];
-        }
+    LC_FOR_TILE(i, j) if (LC_TILE_ROW(i) < a_rows) dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] = acc[i][j];
 }
 #undef LC_TILE_ROW
 #undef LC_TILE_COL
+#undef LC_FOR_TILE
 
 static int g_big_kernel = 2;    // deep updates: 2 = 4x4x4 MFMA (k_mm64q), 1 = vector ALU (k_mm64v), 0 = 16x16x4 MFMA (k_mm64<4>)
        // deep updates on the vector ALU (k_mm64v) or on the MFMA (k_mm64<4>)

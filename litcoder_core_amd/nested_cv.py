@@ -40,8 +40,6 @@ AUG_BUDGET_BYTES = 24 << 30         # cap on the batched (fold, alpha) fp64 syst
 SERIES_TERMS = 4                    # terms of the polynomial form of the hat matrices of large alphas (series.py) ...
 SERIES_TOL = 2e-9                   # ... used when its worst relative error over the spectrum, 1 / T_d(1 + 2 alpha^2),
                                     # is <= this: 30x below the fp32 epsilon of the values it is stored / consumed in
-LAST_SWEEP = {"precision": None,    # arithmetic the most recent alpha sweep ran in (read by bench.py) ...
-              "plain_flops": 0.0, "plain_launches": 0}   # ... and the algorithmic flops of the plain fp16x3 GEMMs
 
 
 SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singcutoff enters a prediction with weight
@@ -224,6 +222,11 @@ class RidgeCVEngine:
         self.n_folds_done = 0
         self._base_scales = None                       # (cs, split) of the resident targets, see _target_scales
         self.sweeps_done = None                        # end of the sweeps queued last (chain_gate)
+        # what this fit ran, for the caller (NestedCVModel.last_fit; bench.py prices the roofline with it): arithmetic
+        # of the sweeps, alphas scored inside the fused launch, algorithmic flops of the plain fp16x3 GEMMs.  Per
+        # engine: two fits in one process do not share it.
+        self.info = {"precision": None, "fused_alphas": self.A, "series_terms": 0, "plain_flops": 0.0,
+                     "plain_launches": 0, "used_all": None}
         self.ready = torch.cuda.Event()               # X, Y, K resident: the only thing the aux stream waits for
         self.ready.record()
 
@@ -546,7 +549,7 @@ class RidgeCVEngine:
         split, cs = hat["split"], hat["cs"]
         if hat.get("data_ready") is not None:
             main.wait_event(hat["data_ready"])            # this fold's (normalised) targets and their column scales
-        LAST_SWEEP.update(precision="f16x3" if split else "f32", fused_alphas=Ad,
+        self.info.update(precision="f16x3" if split else "f32", fused_alphas=Ad,
                           series_terms=SERIES_TERMS if moments else 0)
         nbuf = F if moments else 1                        # two passes over the folds keep every fold's operands
         ystat = [torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev) for _ in range(nbuf)]
@@ -586,8 +589,8 @@ class RidgeCVEngine:
                 ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
                 ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
                                        bview=views[f])
-                LAST_SWEEP["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
-                LAST_SWEEP["plain_launches"] += 1
+                self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
+                self.info["plain_launches"] += 1
                 ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv[f], ystat[f], self.d_coef, hat["d_ser"],
                                   scores, accumulate=f > 0, rowmap=rowmap)
         if done is not None:
@@ -649,7 +652,7 @@ class RidgeCVEngine:
         used_all = [a for a in range(self.A) if count_h[1, a] > 0]       # over all voxel shards
         if self.shard.simulate:     # one rank run alone for timing: its peers' choices are unknown -- assume they
             used_all = sorted(set(used_all) | set(self.cho))             # need every factorised alpha (worst case)
-        LAST_SWEEP["used_all"] = list(used_all)
+        self.info["used_all"] = list(used_all)
         tiles = [0]
         for a in used:
             tiles.append(tiles[-1] + (int(count_h[0, a]) + tile - 1) // tile)
@@ -810,8 +813,8 @@ class RidgeCVEngine:
             for g in range(G):
                 ops.split_rows_f16(Malpha[g, r0:r1], rows, N_o, At[g * rows_pad * N_o * 2:], rs_inv[g * rows_pad:])
             ops.gemm_grouped_f16x3(At, rs_inv, rows, o["Yt"], o["cs_s"][1], C, Vs, Vs, N_o, o["tiles"])
-            LAST_SWEEP["plain_flops"] += 2.0 * useful_rows * o["n_o"] * self.V
-            LAST_SWEEP["plain_launches"] += 1
+            self.info["plain_flops"] += 2.0 * useful_rows * o["n_o"] * self.V
+            self.info["plain_launches"] += 1
         else:
             ops.gemm_grouped(Malpha[:, r0:r1], N_o, Malpha.stride(0), o["Ys"], Vs, None, C, Vs, rows, Vs, N_o, o["tiles"])
         return C
@@ -1027,7 +1030,7 @@ class RidgeCVEngine:
             main.wait_event(hat["data_ready"])
         if done is not None:
             main.wait_event(done)
-        LAST_SWEEP.update(precision="f16x3" if split else "f32", fused_alphas=A, series_terms=0)
+        self.info.update(precision="f16x3" if split else "f32", fused_alphas=A, series_terms=0)
         scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
         part = torch.empty((A * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
         ystat = torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev)
@@ -1382,6 +1385,7 @@ class NestedCVModel(BasePredictivityModel):
         self.precision = precision
         self.form = form
         self.last_form = None
+        self.last_fit = {}                             # RidgeCVEngine.info of the most recent fit (+ "form")
         self.last_fold_alphas = None
 
     def fit_predict(
@@ -1579,6 +1583,7 @@ class NestedCVModel(BasePredictivityModel):
             logger.info("primal form not used (%s): dual form", why)
             eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = attempt("dual")
         self.last_form = "primal" if eng.primal else "dual"
+        self.last_fit = dict(getattr(eng, "info", {}), form=self.last_form)
         weights = eng.weights() if weights_on_host else eng.W_acc[:, : eng.V]
         # diagnostics (not in the reference's return value): the alpha vector of every outer fold, all voxels --
         # the returned best_alphas is their mean (nested_cv.py:293-296)

@@ -648,17 +648,19 @@ def test_precision_policy(lc):
     from litcoder_core_amd import nested_cv as ncv
     X, Y = _synthetic(300, 80, 300, 11)
     kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 3, 5))
-    m32, W32, a32 = lc.NestedCVModel("r", precision="f32").fit_predict(X, Y, **kw)
-    assert ncv.LAST_SWEEP["precision"] == "f32"
-    m16, W16, a16 = lc.NestedCVModel("r", precision="auto").fit_predict(X, Y, **kw)
-    assert ncv.LAST_SWEEP["precision"] == "f16x3"
+    model32 = lc.NestedCVModel("r", precision="f32")
+    m32, W32, a32 = model32.fit_predict(X, Y, **kw)
+    assert model32.last_fit["precision"] == "f32"
+    model16 = lc.NestedCVModel("r", precision="auto")
+    m16, W16, a16 = model16.fit_predict(X, Y, **kw)
+    assert model16.last_fit["precision"] == "f16x3"
     assert np.mean(a16 == a32) >= 0.99
     same = a16 == a32
     np.testing.assert_allclose(np.asarray(m16["correlations"])[same], np.asarray(m32["correlations"])[same], atol=2e-6)
     Y2 = Y.copy()
     Y2[7, 5] = 1e6                      # one spike 10^6 x the rms of its column
-    lc.NestedCVModel("r", precision="auto").fit_predict(X, Y2, **kw)
-    assert ncv.LAST_SWEEP["precision"] == "f32"
+    model16.fit_predict(X, Y2, **kw)
+    assert model16.last_fit["precision"] == "f32"
     with pytest.raises(ValueError):
         lc.NestedCVModel("r", precision="fp8").fit_predict(X, Y, **kw)
 

@@ -59,8 +59,7 @@ for G in (1, 2, 4, 8):
     t = max(per_rank.values())
     if G == 1:
         t1 = t
-        from litcoder_core_amd.nested_cv import LAST_SWEEP
-        out["alphas_in_use_last_fold_1gpu"] = LAST_SWEEP.get("used_all")
+        out["alphas_in_use_last_fold_1gpu"] = model.last_fit.get("used_all")
     out["per_world"][G] = {"ms_per_rank_alone": {str(k): round(v, 2) for k, v in per_rank.items()}, "max_ms": round(t, 2),
                            "allgather_bytes_received": int((hat + refit) * (G - 1) / G), "wire_ms_if_not_hidden": round(wire_ms, 2),
                            "predicted_ms": round(t + wire_ms, 2), "predicted_speedup": round(t1 / (t + wire_ms), 2),
