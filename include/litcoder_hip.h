@@ -226,6 +226,9 @@ int lc_debug_chol_big_kernel(int which);
 /* Diagnostics: 1 (default) = fused left-looking 64-column steps (one launch per step besides the diagonal tile),
  * 0 = the first version's panel + in-block update launches; returns the setting. */
 int lc_debug_chol_fused_steps(int on);
+/* Diagnostics: 1 = the deep updates of the two-level blocking are left-looking (a block column takes all earlier
+ * block columns in one product of full depth; measured: no gain), 0 (default) = right-looking; returns the setting. */
+int lc_debug_chol_left_deep(int on);
 
 /* The same hat matrices for alphas whose penalty dwarfs the spectrum, as a polynomial in K[tr,tr]:
  *   K[va,tr] (K[tr,tr] + a^2 I)^-1  ~=  sum_{j<terms} c_sj K[va,tr] K[tr,tr]^j / scale_f^(j+1)

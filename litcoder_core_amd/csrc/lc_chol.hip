@@ -636,7 +636,7 @@ __device__ inline void tile_mac(double (&acc)[4][4], const double* __restrict__ 
 #define LC_TILE_COL(j) ((j) * 16 + li)
 #define LC_FOR_TILE(i, j) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)
 
-__global__ void __launch_bounds__(256, 2) k_lstep(double* __restrict__ aug, int N, int M, int k, int K0, int K1,
+__global__ void __launch_bounds__(256, 3) k_lstep(double* __restrict__ aug, int N, int M, int k, int K0, int K1,
                                                   const double* __restrict__ linv) {
     __shared__ double sA[NB * MM_LD], sB[NB * MM_LD], sC[NB * ST_LDC];
     const int R = N + M, nb = N / NB;
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(256, 2) k_lstep(double* __restrict__ aug, int 
     }
 }
 
-__global__ void __launch_bounds__(256, 2) k_bstep(double* __restrict__ aug, int N, int M, int k, int K1,
+__global__ void __launch_bounds__(256, 3) k_bstep(double* __restrict__ aug, int N, int M, int k, int K1,
                                                   const double* __restrict__ linv) {
     __shared__ double sA[NB * MM_LD], sB[NB * MM_LD], sC[NB * ST_LDC];
     const int R = N + M, nb = N / NB;
@@ -748,6 +748,12 @@ __global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ au
 
 static int g_chol_outer = 512;   // columns per outer block (multiple of NB)
 static int g_chol_fused = 1;     // 1: fused left-looking steps (k_lstep / k_bstep); 0: the first version's three launches per step
+static int g_chol_left_deep = 0; // 1: the deep updates left-looking too (one product of the full depth per block column: measured, no gain -- the deep-update kernel is not bound by its C read-modify-write -- and less parallel for small batches); 0: right-looking
+
+extern "C" int lc_debug_chol_left_deep(int on) {
+    if (on == 0 || on == 1) g_chol_left_deep = on;
+    return g_chol_left_deep;
+}
 
 extern "C" int lc_debug_chol_fused_steps(int on) {
     if (on == 0 || on == 1) g_chol_fused = on;
@@ -786,6 +792,19 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
     g.lda = g.ldb = g.ldc = N;
     for (int K0 = 0; K0 < nb; K0 += ob) {
         const int K1 = min(K0 + ob, nb);
+        if (g_chol_left_deep && K0 > 0) {
+            // block column [K0, K1) takes the contributions of ALL earlier block columns in one product of depth 64 K0:
+            // every C tile is read and written once per factorisation instead of once per outer block to its left
+            const int c0 = K0 * NB;
+            g.a = d_aug + (long long)c0 * N;                 // L[rows >= c0][0 .. c0)
+            g.b = d_aug + (long long)c0 * N;                 // L[c0 .. c1 rows][0 .. c0)   ([n][k])
+            g.a_sys = g.b_sys = g.c_sys = sys;
+            g.ldb = N;
+            g.c = d_aug + (long long)c0 * N + c0;
+            g.rows = R - c0; g.cols = (K1 - K0) * NB; g.depth = c0;
+            g.row0 = g.col0 = c0; g.tri = 1; g.subtract = 1;
+            launch_big<true>(g, B, s);
+        }
         for (int k = K0; k < K1; ++k) {
             hipLaunchKernelGGL(k_potrf_diag, dim3(B), dim3(256), 0, s, d_aug, N, M, k, d_linv, d_info);
             const int below = (k + 1) * NB;                  // first row under the diagonal tile
@@ -812,6 +831,7 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
             g.col0 = below; g.tri = 1; g.subtract = 1;
             launch_mm<2, true>(g, B, s);
         }
+        if (g_chol_left_deep) continue;
         // everything right of the outer block, once, at the block's full depth
         const int c1 = K1 * NB;
         g.a = g.b = d_aug + (long long)c1 * N + K0 * NB;
@@ -827,6 +847,17 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
     const int last_full = ((nb - 1) / ob) * ob;
     for (int K0 = last_full; K0 >= 0; K0 -= ob) {
         const int K1 = min(K0 + ob, nb);
+        if (g_chol_left_deep && K1 < nb) {
+            // Z[:, K0 .. K1) -= H[:, K1 .. nb) L[K1 .. nb rows, K0 .. K1 cols]: all finished block columns to the right at once
+            g.a = d_aug + (long long)N * N + K1 * NB;
+            g.b = d_aug + (long long)K1 * NB * N + K0 * NB;
+            g.c = d_aug + (long long)N * N + K0 * NB;
+            g.a_sys = g.b_sys = g.c_sys = sys;
+            g.ldb = N;
+            g.rows = M; g.cols = (K1 - K0) * NB; g.depth = (nb - K1) * NB;
+            g.row0 = g.col0 = 0; g.tri = 0; g.subtract = 1;
+            launch_big<false>(g, B, s);
+        }
         for (int k = K1 - 1; k >= K0; --k) {
             if (g_chol_fused) {
                 hipLaunchKernelGGL(k_bstep, dim3((unsigned)lc::ceil_div(M, NB), (unsigned)B), dim3(256), 0, s, d_aug, N, M,
@@ -848,6 +879,7 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
             g.subtract = 1;
             launch_mm<2, false>(g, B, s);
         }
+        if (g_chol_left_deep) continue;
         g.a = d_aug + (long long)N * N + K0 * NB;
         g.b = d_aug + (long long)K0 * NB * N;
         g.c = d_aug + (long long)N * N;

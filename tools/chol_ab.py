@@ -17,8 +17,9 @@ for (B, N, M, label) in ((3, 1920, 480, "inner, one rank of 8"), (20, 1920, 480,
     del X
     fl = B * (N ** 3 / 3 + 2.0 * N * N * M)
     out = {}
-    for fused in (0, 1):
-        lib.lc_debug_chol_fused_steps(fused)
+    for fused in (0, 1, 2):                     # 0 = round 1, 1 = fused steps + right-looking deep updates, 2 = + left-looking deep
+        lib.lc_debug_chol_fused_steps(1 if fused else 0)
+        lib.lc_debug_chol_left_deep(1 if fused == 2 else 0)
         aug = base.clone()
         H = torch.empty((B, M, N), dtype=torch.float32, device=dev)
         ops.batch_chol_solve(aug, B, N, M, H)
@@ -33,8 +34,11 @@ for (B, N, M, label) in ((3, 1920, 480, "inner, one rank of 8"), (20, 1920, 480,
             ts.append(time.perf_counter() - t)
         out[fused] = (min(ts), H.clone(), int(info.abs().max()))
     lib.lc_debug_chol_fused_steps(1)
+    lib.lc_debug_chol_left_deep(0)
     ref = torch.linalg.solve(base[:1, :N].transpose(1, 2), base[:1, N:].transpose(1, 2)).transpose(1, 2)   # H A = G, A symmetric
-    err_new = float((out[1][1][:1].double() - ref).abs().max() / ref.abs().max())
-    diff = float((out[0][1].double() - out[1][1].double()).abs().max() / out[0][1].double().abs().max())
-    print(f"{label}: B={B} N={N} M={M}: old {1e3 * out[0][0]:.2f} ms ({fl / out[0][0] / 1e12:.1f} TF), fused {1e3 * out[1][0]:.2f} ms "
-          f"({fl / out[1][0] / 1e12:.1f} TF); fused vs fp64 solve {err_new:.1e}, fused vs old {diff:.1e}, info {out[0][2]}/{out[1][2]}", flush=True)
+    err_new = float((out[2][1][:1].double() - ref).abs().max() / ref.abs().max())
+    diff = float((out[0][1].double() - out[2][1].double()).abs().max() / out[0][1].double().abs().max())
+    print(f"{label}: B={B} N={N} M={M}: round 1 {1e3 * out[0][0]:.2f} ms ({fl / out[0][0] / 1e12:.1f} TF), fused steps "
+          f"{1e3 * out[1][0]:.2f} ms ({fl / out[1][0] / 1e12:.1f} TF), + left-looking deep updates {1e3 * out[2][0]:.2f} ms "
+          f"({fl / out[2][0] / 1e12:.1f} TF); new vs fp64 solve {err_new:.1e}, new vs round 1 {diff:.1e}, "
+          f"info {out[0][2]}/{out[2][2]}", flush=True)
