@@ -141,7 +141,8 @@ def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, 
         kern = ops.timing_read()
         ops.timing_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, metrics, kern, plain_flops
@@ -188,10 +189,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # LITCODER_BENCH_ONE_GPU=1 (smoke test of the N > 1 code path on a single-GPU box): every rank on device 0, gloo
+    # instead of RCCL (which refuses two ranks on one device); the numbers of such a run mean nothing
+    one_gpu = os.environ.get("LITCODER_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from litcoder_core_amd import NestedCVModel, ShardContext, ops
     from litcoder_core_amd.dist import shard_bounds

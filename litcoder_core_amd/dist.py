@@ -57,13 +57,28 @@ class ShardContext:
         self.backend = str(self._dist.get_backend(group)) if self._dist else None
         self.simulate = False
         self.always = bool(always_collective) and self._dist is not None
+        # Collectives of one communicator execute in issue order on its one internal stream.  The operator all-gathers
+        # are issued far ahead (whole batches of later folds) and wait for their fp64 chains; a 20-int all-reduce that
+        # fold 0 needs NOW must not sit behind them -- so the bulk traffic gets communicators ("lanes") of its own.
+        self._lanes = {}
+        if self._dist is not None and (self.world > 1 or self.always):
+            for lane in ("hat", "refit"):
+                self._lanes[lane] = self._dist.new_group(backend=self.backend)     # all ranks, same order everywhere
+
+    @classmethod
+    def single(cls, device=None):
+        """A one-rank context that ignores any initialised process group (what a model without ``shard=`` runs in)."""
+        ctx = cls.__new__(cls)
+        ctx._dist, ctx.group, ctx.device, ctx.rank, ctx.world, ctx.backend = None, None, device, 0, 1, None
+        ctx.simulate, ctx.always, ctx._lanes = False, False, {}
+        return ctx
 
     @classmethod
     def simulated(cls, world: int, rank: int, device=None):
         """One rank of a ``world``-rank job without peers: every collective is a local copy of this rank's own
         contribution into all slots.  Timing studies only."""
-        ctx = cls(device=device)
-        ctx._dist, ctx.rank, ctx.world, ctx.backend, ctx.simulate = None, int(rank), int(world), "simulated", True
+        ctx = cls.single(device=device)
+        ctx.rank, ctx.world, ctx.backend, ctx.simulate = int(rank), int(world), "simulated", True
         return ctx
 
     @property
@@ -85,9 +100,10 @@ class ShardContext:
         """True when the backend moves ``t`` where it lives (RCCL for device tensors, gloo for host tensors)."""
         return (self.backend == "nccl") == bool(t.is_cuda)
 
-    def all_gather(self, t):
+    def all_gather(self, t, lane=None):
         """(world, *t.shape): every rank's ``t`` (same shape and dtype everywhere), on ``t``'s device, ordered on the
-        current stream.  One rank: a view, no copy."""
+        current stream.  One rank: a view, no copy.  ``lane``: "hat" / "refit" = the communicator of that bulk traffic
+        (default: the group's own, for the small latency-critical exchanges)."""
         import torch
         if not self.active:
             return t.unsqueeze(0)
@@ -96,13 +112,14 @@ class ShardContext:
             out.copy_(t.unsqueeze(0).expand_as(out))
             return out
         t = t.contiguous()
+        group = self._lanes.get(lane, self.group)
         if self._direct(t):
-            self._dist.all_gather_into_tensor(out.view(-1), t.view(-1), group=self.group)     # flat: rank-major blocks
+            self._dist.all_gather_into_tensor(out.view(-1), t.view(-1), group=group)         # flat: rank-major blocks
             return out
         # staging: gloo given device tensors (the tests) or RCCL given host tensors
         h = t.cpu() if t.is_cuda else t.to(self.device)
         parts = torch.empty((self.world,) + tuple(h.shape), dtype=h.dtype, device=h.device)
-        self._dist.all_gather_into_tensor(parts.view(-1), h.contiguous().view(-1), group=self.group)
+        self._dist.all_gather_into_tensor(parts.view(-1), h.contiguous().view(-1), group=group)
         out.copy_(parts)
         return out
 

@@ -162,7 +162,7 @@ class RidgeCVEngine:
         check_penalties(alphas, singcutoff, normalpha)
         self.singcutoff = float(singcutoff)
         self.dev = ops.device()
-        self.shard = shard or ShardContext()
+        self.shard = shard or ShardContext.single()
         if not isinstance(X_all, _DeviceShapes):
             X_all = np.asarray(X_all)
         self.Ttot, self.p = X_all.shape
@@ -333,7 +333,7 @@ class RidgeCVEngine:
         return out
 
     # -------------------------------------------------------------- V-independent fp64 systems, dealt out over ranks
-    def _sharded_solve(self, n_jobs, N, M, assemble, out=None, slot=None):
+    def _sharded_solve(self, n_jobs, N, M, assemble, out=None, slot=None, lane="hat"):
         """``n_jobs`` independent augmented systems (same list, same order on every rank): rank r factors jobs
         [r n_per, (r + 1) n_per), n_per = ceil(n_jobs / world), and the f32 results are all-gathered -- on return
         ``H`` (>= n_jobs, M, N) is complete on every rank, job j in slot j.  ``assemble(jobs)`` builds the
@@ -353,7 +353,7 @@ class RidgeCVEngine:
         else:
             info = ops.zeros(1, torch.int32, self.dev)
         if self.shard.active:
-            H = self.shard.all_gather(H).view(G * n_per, M, N)
+            H = self.shard.all_gather(H, lane=lane).view(G * n_per, M, N)
         return H, info
 
     def precompute_lmax(self, outer):
@@ -724,7 +724,7 @@ class RidgeCVEngine:
             ops.batch_assemble_sel(K, tr_o, None, rhs, a2_o, sysv, len(jobs), self.A, N_o, rows, aug)
             return aug
 
-        Hj, info = self._sharded_solve(Gc * S, N_o, rs, assemble if S > 1 else assemble_whole)
+        Hj, info = self._sharded_solve(Gc * S, N_o, rs, assemble if S > 1 else assemble_whole, lane="refit")
         return Hj[: Gc * S].view(Gc, rows, N_o), info
 
     def _refit_systems(self, X, K, tr_rows, used, tr_o=None, lmax_o=None, te_rows=(), spec=None, used_all=None):
@@ -1182,7 +1182,7 @@ class RidgeCVEngine:
                                            1, self.A, N_o, rsz, aug[k:k + 1])
                 return aug
 
-            Hj, info = self._sharded_solve(nF * Gc * S, N_o, rsz, assemble)
+            Hj, info = self._sharded_solve(nF * Gc * S, N_o, rsz, assemble, lane="refit")
             Mall = Hj[: nF * Gc * S].view(nF, Gc, rows, N_o)
             ready = torch.cuda.Event()
             ready.record()
@@ -1417,7 +1417,7 @@ class NestedCVModel(BasePredictivityModel):
         features, targets = np.asarray(features), np.asarray(targets)   # lists / nested lists, like torch.tensor(...)
         if X_test is not None and y_test is not None:
             X_test, y_test = np.asarray(X_test), np.asarray(y_test)
-        shard = self.shard or ShardContext()
+        shard = self.shard or ShardContext.single()
         train_test = X_test is not None and y_test is not None
         V_total = np.shape(targets)[1]
         lo, hi = shard.bounds(V_total)
@@ -1479,7 +1479,7 @@ class NestedCVModel(BasePredictivityModel):
     def _run_on_current_stream(self, X_all, Y_all, T, n_test_rows, V_total, groups, folding_type, n_outer_folds,
                                n_inner_folds, chunk_length, alphas, alpha_fdr, single_alpha, normalpha, use_corr,
                                normalize_features, normalize_targets, weights_on_host, singcutoff=0.0):
-        shard = self.shard or ShardContext()
+        shard = self.shard or ShardContext.single()
         train_test = n_test_rows > 0
         if train_test:
             # nested_cv.py:130-132 passes ``groups`` positionally into ``trim_size``

@@ -5,7 +5,7 @@
   columns, the (fold, alpha) Cholesky systems dealt out over the two (``RidgeCVEngine._sharded_solve``) and
   all-gathered.  Every rank must return the unsharded fit BIT FOR BIT: metrics of all voxels, chosen alphas, and its
   own block of the weights -- per-voxel alpha and single_alpha, full CV and train/test, the moments path and the
-  per-alpha hat-matrix paths (R2 scoring, raw alphas, f32 sweep).
+  per-alpha hat-matrix paths (R2 scoring, raw alphas, f32 sweep), and the primal form of a tall design.
 * One rank through RCCL: a one-rank "nccl" group with ``always_collective`` runs the same code with every collective
   issued as a real RCCL call on device tensors (all_gather_into_tensor of f32 / f64 blocks, all_reduce of f64 and int32
   vectors, on the engine's auxiliary / communication streams): the calls the 8-GPU run makes, checked for API /
@@ -44,6 +44,7 @@ cases = {
     "one_alpha": dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=[0.5]),   # one refit system: row slices
     "normalised": dict(folding_type="chunked_contiguous", n_outer_folds=3, n_inner_folds=2, chunk_length=10,
                        alphas=np.logspace(-1, 4, 6), normalize_features=True, normalize_targets=True),
+    "tall": dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=np.logspace(-1, 3, 5), _p=8),   # primal form
 }
 shard = None
 if backend != "none":
@@ -54,11 +55,14 @@ if backend != "none":
 lo, hi = (shard.bounds(V) if shard else (0, V))
 out = {"lo": lo, "hi": hi}
 for name, kw in cases.items():
+    kw = dict(kw)
+    Xc = X[:, : kw.pop("_p", p)]
     for prec in (("auto", "f32") if name == "pervoxel" else ("auto",)):
         model = NestedCVModel("r", shard=shard, precision=prec)
-        out[name, prec, "cv"] = model.fit_predict(X, Y, **kw)
+        out[name, prec, "cv"] = model.fit_predict(Xc, Y, **kw)
+        assert model.last_form == ("primal" if name == "tall" else "dual")
         kw_tt = {k: v for k, v in kw.items() if k != "n_outer_folds"}
-        out[name, prec, "tt"] = model.fit_predict(X[:330], Y[:330], X_test=X[330:], y_test=Y[330:], **kw_tt)
+        out[name, prec, "tt"] = model.fit_predict(Xc[:330], Y[:330], X_test=Xc[330:], y_test=Y[330:], **kw_tt)
 tag = "single" if backend == "none" else f"{backend}{world}_rank{shard.rank}"
 pickle.dump(out, open(os.path.join(out_dir, tag + ".pkl"), "wb"))
 if shard is not None:
@@ -104,7 +108,7 @@ def test_two_real_engine_ranks_on_one_gpu_equal_the_unsharded_fit(runs):
         for r, out in enumerate(ranks):
             _same(out[key], want, out["lo"], out["hi"], (key, r))
             n += 1
-    assert n == 2 * 2 * 6
+    assert n == 2 * 2 * 7
 
 
 def test_one_rank_through_rccl_collectives(runs):
