@@ -45,9 +45,14 @@ def job_share(n_jobs: int, world: int, rank: int) -> Tuple[int, range]:
 class ShardContext:
     """Wraps a torch.distributed process group (or nothing, for a single process)."""
 
-    def __init__(self, group=None, device=None, always_collective=False):
+    def __init__(self, group=None, device=None, always_collective=False, global_lists=True):
         """``always_collective``: issue the backend's collectives even in a one-rank group (they are no-ops
-        arithmetically) -- lets a single GPU exercise the RCCL calls of the sharded path."""
+        arithmetically) -- lets a single GPU exercise the RCCL calls of the sharded path.
+        ``global_lists``: the per-voxel containers of the metrics dictionary (correlations, p-values, masks, alphas)
+        cover ALL voxels on every rank (True, default) or only the rank's own block (False).  The scalar summaries and
+        the statistics behind them (BH-FDR ranks all p-values) are global either way; the lists are V_total Python
+        objects each -- ~70 ms of interpreter time per rank at 8 x 80 000 voxels, on every rank -- so a job that only
+        needs each rank's own voxels (like its block of the weights) turns them off."""
         import torch.distributed as dist
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.group = group
@@ -56,6 +61,7 @@ class ShardContext:
         self.world = self._dist.get_world_size(group) if self._dist else 1
         self.backend = str(self._dist.get_backend(group)) if self._dist else None
         self.simulate = False
+        self.global_lists = bool(global_lists)
         self.always = bool(always_collective) and self._dist is not None
         # Collectives of one communicator execute in issue order on its one internal stream.  The operator all-gathers
         # are issued far ahead (whole batches of later folds) and wait for their fp64 chains; a 20-int all-reduce that
@@ -70,15 +76,16 @@ class ShardContext:
         """A one-rank context that ignores any initialised process group (what a model without ``shard=`` runs in)."""
         ctx = cls.__new__(cls)
         ctx._dist, ctx.group, ctx.device, ctx.rank, ctx.world, ctx.backend = None, None, device, 0, 1, None
-        ctx.simulate, ctx.always, ctx._lanes = False, False, {}
+        ctx.simulate, ctx.always, ctx._lanes, ctx.global_lists = False, False, {}, True
         return ctx
 
     @classmethod
-    def simulated(cls, world: int, rank: int, device=None):
+    def simulated(cls, world: int, rank: int, device=None, global_lists=True):
         """One rank of a ``world``-rank job without peers: every collective is a local copy of this rank's own
         contribution into all slots.  Timing studies only."""
         ctx = cls.single(device=device)
         ctx.rank, ctx.world, ctx.backend, ctx.simulate = int(rank), int(world), "simulated", True
+        ctx.global_lists = bool(global_lists)
         return ctx
 
     @property

@@ -1515,7 +1515,8 @@ class NestedCVModel(BasePredictivityModel):
                 f = eng.fold_collect(pend)
                 r32 = f.r.astype(np.float32)
                 if train_test:                  # the per-fold Python lists are only returned by the train/test metrics;
-                    corrs, pvals = _fold_lists(r32, f.p)        # the CV summary works on the arrays below
+                    own = slice(None) if (shard.world == 1 or shard.global_lists) else slice(*shard.bounds(V_total))
+                    corrs, pvals = _fold_lists(r32[own], f.p[own])      # the CV summary works on the arrays below
                     fold_scores.append(corrs)
                     fold_p.append(pvals)
                 fold_alpha.append(_alpha_vector(alphas, f.best_idx, single_alpha))
@@ -1592,10 +1593,16 @@ class NestedCVModel(BasePredictivityModel):
         # the returned best_alphas is their mean (nested_cv.py:293-296)
         self.last_fold_alphas = [np.asarray(a) for a in fold_alpha]
 
+        # voxel shards with local lists: the V-long containers cover this rank's block only (ShardContext.global_lists)
+        part = None
+        if shard.world > 1 and not shard.global_lists:
+            part = slice(*shard.bounds(V_total))
         if train_test:
             sig, padj = fold_sig[0]
-            metrics = stats.train_test_metrics(fold_scores[0], fold_p[0], padj, sig, fold_alpha[0], np.sum(sig))
-            return metrics, weights, fold_alpha[0]
+            metrics = stats.train_test_metrics(fold_scores[0], fold_p[0], padj, sig, fold_alpha[0], np.sum(sig), part=part,
+                                               all_scores=None if part is None else
+                                               score_rows[0].astype(np.float64 if any_nan[0] else np.float32))
+            return metrics, weights, fold_alpha[0] if part is None else fold_alpha[0][part]
 
         # np.mean(fold_scores, axis=0) of the reference (nested_cv.py:276): the nested lists hold np.float32
         # scalars, plus Python 0.0 where r was NaN -- numpy then builds a float64 array, else a float32 one
@@ -1603,8 +1610,9 @@ class NestedCVModel(BasePredictivityModel):
         pcomb, sig, padj = eng.combined_significance()
         majority = np.sum([s for s, _ in fold_sig], axis=0) >= (n_outer_folds // 2 + 1)
         mean_alphas = np.mean(fold_alpha, axis=0)
-        metrics = stats.full_cv_metrics(scores, pcomb, padj, sig, majority, mean_alphas, np.sum(sig), np.sum(majority))
-        return metrics, weights, mean_alphas
+        metrics = stats.full_cv_metrics(scores, pcomb, padj, sig, majority, mean_alphas, np.sum(sig), np.sum(majority),
+                                        part=part)
+        return metrics, weights, mean_alphas if part is None else mean_alphas[part]
 
 
 class _DeviceShapes:

@@ -131,24 +131,31 @@ def _subset(metrics, scores, mask, n, tag):
                         f"min_{tag}_score": float(np.min(s)), f"max_{tag}_score": float(np.max(s))})
 
 
-def train_test_metrics(correlations, pvalues, corrected, significant, best_alphas, n_significant):
-    """nested_cv.py:480-530 (keys, order and container types kept)."""
-    m = _summary(correlations)
-    m.update({"best_alphas": best_alphas.tolist(), "correlations": correlations, "p_values": pvalues,
-              "corrected_p_values": corrected.tolist(), "significant_mask": significant.tolist(),
+def train_test_metrics(correlations, pvalues, corrected, significant, best_alphas, n_significant, part=None,
+                       all_scores=None):
+    """nested_cv.py:480-530 (keys, order and container types kept).  ``part`` (a slice; voxel shards with local
+    lists): the per-voxel containers passed in cover only that part of the voxels, while ``all_scores`` /
+    ``significant`` / ``n_significant`` are those of all voxels and feed the scalar summaries."""
+    scores_all = correlations if all_scores is None else all_scores
+    sl = slice(None) if part is None else part
+    m = _summary(scores_all)
+    m.update({"best_alphas": best_alphas[sl].tolist(), "correlations": correlations, "p_values": pvalues,
+              "corrected_p_values": corrected[sl].tolist(), "significant_mask": significant[sl].tolist(),
               "n_significant": int(n_significant),
-              "percent_significant": float(n_significant / len(correlations) * 100)})
-    _subset(m, correlations, significant, n_significant, "significant")
+              "percent_significant": float(n_significant / len(scores_all) * 100)})
+    _subset(m, scores_all, significant, n_significant, "significant")
     return m
 
 
-def full_cv_metrics(scores, pvalues, corrected, significant, majority, mean_alphas, n_significant, n_majority):
-    """nested_cv.py:533-616."""
+def full_cv_metrics(scores, pvalues, corrected, significant, majority, mean_alphas, n_significant, n_majority, part=None):
+    """nested_cv.py:533-616.  ``part`` (a slice; voxel shards with local lists): the scalar summaries are those of all
+    voxels, the per-voxel lists cover only ``part``."""
+    sl = slice(None) if part is None else part
     m = _summary(scores)
-    m.update({"best_alphas": mean_alphas.tolist(), "correlations": scores.tolist(), "p_values": pvalues.tolist(),
-              "corrected_p_values": corrected.tolist(), "significant_mask": significant.tolist(),
-              "majority_significant_mask": majority.tolist(), "n_significant": int(n_significant),
-              "n_majority_significant": int(n_majority),
+    m.update({"best_alphas": mean_alphas[sl].tolist(), "correlations": scores[sl].tolist(),
+              "p_values": pvalues[sl].tolist(), "corrected_p_values": corrected[sl].tolist(),
+              "significant_mask": significant[sl].tolist(), "majority_significant_mask": majority[sl].tolist(),
+              "n_significant": int(n_significant), "n_majority_significant": int(n_majority),
               "percent_significant": float(n_significant / len(scores) * 100),
               "percent_majority_significant": float(n_majority / len(scores) * 100)})
     _subset(m, scores, significant, n_significant, "significant")

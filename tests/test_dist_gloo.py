@@ -121,7 +121,11 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     assert W.shape == (12, hi - lo)
     # train/test mode through the same sharded path
     m2, W2, a2 = ncv.NestedCVModel("r", shard=shard).fit_predict(X[:90], Y[:90], X_test=X[90:], y_test=Y[90:], **kw)
-    out = dict(m=m, W=W, a=a, lo=lo, hi=hi, m2=m2, a2=a2)
+    # local lists: the V-long containers cover the rank's own voxels only, the scalars stay global
+    shard_l = ShardContext(global_lists=False)
+    m3, W3, a3 = ncv.NestedCVModel("r", shard=shard_l).fit_predict(X, Y, **kw)
+    m4, W4, a4 = ncv.NestedCVModel("r", shard=shard_l).fit_predict(X[:90], Y[:90], X_test=X[90:], y_test=Y[90:], **kw)
+    out = dict(m=m, W=W, a=a, lo=lo, hi=hi, m2=m2, a2=a2, m3=m3, a3=a3, m4=m4, a4=a4)
     pickle.dump(out, open(os.path.join(sys.argv[3], f"rank{shard.rank}_{mode}.pkl"), "wb"))
     dist.destroy_process_group()
 else:
@@ -173,4 +177,13 @@ def test_two_rank_shard_equals_unsharded(tmp_path, mode):
                     assert got == v, (key, k)
         assert np.array_equal(out["a"], ref["a"]) and np.array_equal(out["a2"], ref["a2"])
         assert np.array_equal(out["W"], ref["W"][:, out["lo"]:out["hi"]])
+        lo, hi = out["lo"], out["hi"]
+        for key, rkey, akey in (("m3", "m", "a3"), ("m4", "m2", "a4")):          # ShardContext(global_lists=False)
+            for k, v in ref[rkey].items():
+                got = out[key][k]
+                if isinstance(v, list):
+                    assert np.array_equal(np.asarray(got), np.asarray(v)[lo:hi]), (key, k)
+                else:
+                    assert got == v, (key, k)
+            assert np.array_equal(out[akey], ref["a" if key == "m3" else "a2"][lo:hi])
     assert ranks[0]["hi"] == ranks[1]["lo"] and ranks[1]["hi"] == 37

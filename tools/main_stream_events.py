@@ -22,7 +22,8 @@ lo, hi = shard_bounds(V_total, world, rank)
 V = hi - lo
 dX, dY, p = bench.synth_inputs(V, rank, dev)
 alphas = np.logspace(-1, 8, bench.A)
-model = NestedCVModel("ridge_regression", shard=ShardContext.simulated(world, rank, device=dev) if world > 1 else None)
+model = NestedCVModel("ridge_regression", shard=ShardContext.simulated(world, rank, device=dev, global_lists="--global-lists" in sys.argv)
+                      if world > 1 else None)
 marks = []
 
 

@@ -1,21 +1,28 @@
-# Regenerates the round artifacts kept under profiles/ (run on the GPU box: gpurun -- bash tools/refresh_profiles.sh);
-# outputs land in gpurun_out/r01_final/ and are copied into profiles/ by hand.
+# Regenerates the round artefacts kept under profiles/ (run on the GPU box: gpurun -- bash tools/refresh_profiles.sh);
+# outputs land in gpurun_out/r02_final/ and are copied into profiles/ by hand.
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01_final
+O=$R/gpurun_out/r02_final
 mkdir -p $O
-python3 $R/bench.py --steps 3 --warmup 1 > $O/bench_v13.json 2> $O/bench_v13.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof_v13.json 2> /dev/null
-cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats_v13.csv
+python3 $R/bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs > $O/bench_under_rocprof.json 2> /dev/null
+cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   D=/tmp/pmc_$(echo $C | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-legs > /dev/null 2>&1
 done
 python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "k_sweep_f16x3<true" $O/sweep_fused_pmc.json > /dev/null
 python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "k_sweep_f16x3<false" $O/sweep_plain_pmc.json > /dev/null
-python3 $R/tools/gpu_kernel_bench.py sweep sweep16 stamps plain16 series lanczos chol hbm > $O/kernel_microbench_v13.txt 2>&1
-python3 $R/tools/overlap_probe.py >> $O/kernel_microbench_v13.txt 2>&1
-python3 $R/tools/vendor_dgemm_probe.py > $O/fp64_rate_probe.txt 2>&1
-$R/tools/bin/mfma_f64_rate >> $O/fp64_rate_probe.txt 2>&1
+for K in k_mm64q k_lstep k_bstep k_potrf_diag; do
+  python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "$K" $O/chol_${K}_pmc.json > /dev/null
+done
+python3 $R/tools/gpu_kernel_bench.py sweep sweep16 stamps plain16 series lanczos chol hbm > $O/kernel_microbench.txt 2>&1
+python3 $R/tools/chol_ab.py > $O/chol_fused_ab.txt 2>&1
+python3 $R/tools/scaling_model.py 80000 > $O/scaling_model.json 2> $O/scaling_model.err
+python3 $R/tools/main_stream_events.py 80000 8 0 > $O/device_timeline_rank0_of_8.txt 2>&1
+python3 $R/tools/main_stream_events.py 640000 8 0 > $O/device_timeline_weak_rank0_of_8.txt 2>&1
+python3 $R/tools/main_stream_events.py 80000 > $O/device_timeline_1gpu.txt 2>&1
+python3 $R/tools/host_timeline.py 80000 8 0 > $O/host_timeline_rank0_of_8.txt 2>&1
+python3 $R/tools/other_configs.py > $O/other_configs.txt 2>&1
 ls -la $O
