@@ -39,7 +39,7 @@ for G in (1, 2, 4, 8):
     for r in ranks:
         lo, hi = shard_bounds(V_total, G, r)
         dX, dY, p = bench.synth_inputs(hi - lo, r, dev)
-        shard = ShardContext.simulated(G, r, device=dev) if G > 1 else None
+        shard = ShardContext.simulated(G, r, device=dev, global_lists=False) if G > 1 else None
         model = NestedCVModel("ridge_regression", shard=shard)
         fit = lambda: model.fit_predict_device(dX, dY, p, hi - lo, n_voxels_total=V_total, alphas=alphas, **bench.FIT_KW)
         fit(); fit()
@@ -65,4 +65,22 @@ for G in (1, 2, 4, 8):
                            "predicted_ms": round(t + wire_ms, 2), "predicted_speedup": round(t1 / (t + wire_ms), 2),
                            "voxels_per_sec": round(V_total / (1e-3 * (t + wire_ms)))}
     print(f"G={G}: {out['per_world'][G]}", file=sys.stderr, flush=True)
+# weak scaling: every rank 80 000 voxels (bench.py's default mode): rank 0 of G alone on its 80 000 of 80 000 G voxels
+out["weak"] = {}
+for G in (2, 4, 8):
+    dX, dY, p = bench.synth_inputs(80000, 0, dev)
+    model = NestedCVModel("ridge_regression", shard=ShardContext.simulated(G, 0, device=dev, global_lists=False))
+    fit = lambda: model.fit_predict_device(dX, dY, p, 80000, n_voxels_total=80000 * G, alphas=alphas, **bench.FIT_KW)
+    fit(); fit()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        fit()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / 4
+    out["weak"][G] = {"ms_rank0_alone": round(ms, 1), "voxels_per_sec": round(80000 * G / (1e-3 * ms)),
+                      "speedup_vs_1gpu": round(80000 * G / (1e-3 * ms) / (V_total / (1e-3 * t1)), 2)}
+    print(f"weak G={G}: {out['weak'][G]}", file=sys.stderr, flush=True)
+    del dX, dY
+    torch.cuda.empty_cache()
 print(json.dumps(out))
