@@ -472,28 +472,35 @@ class RidgeCVEngine:
             P = None
             if ser and moments:
                 rows_p, rowmap, _ = self._series_layout(M)
-                P = ops.zeros((fc, rows_p, N), torch.float32, self.dev)
-                if N % COL_TILE == 0:
+                # voxel shards: the chains of the folds are independent and V-independent -- dealt out like the Cholesky
+                # systems (contiguous shares, all-gathered into fold order); one rank: all of them
+                n_per, mine = job_share(fc, self.shard.world, self.shard.rank) if self.shard.active else (fc, range(fc))
+                m0, fcl = (mine[0], len(mine)) if len(mine) else (0, 0)
+                P = ops.zeros((n_per, rows_p, N), torch.float32, self.dev)
+                g0 = f0 + m0
+                if fcl and N % COL_TILE == 0:
                     # the chain P'_j = P'_(j-1) (K[tr,tr] / lambda) on the f32 MFMA: its terms enter a prediction
                     # scaled by rho^j, fp32 products with fp32 accumulation keep them at full fp32 accuracy.
                     # Run transposed, Q_j = Kn Q_(j-1) with the folds as column groups of one grouped launch.
                     Mq = ops.pad_to(M, COL_TILE)
-                    Kn = torch.empty((fc, N, N), dtype=torch.float32, device=self.dev)
-                    ops.gather_sub_f32(K, tr[f0:f0 + fc], tr[f0:f0 + fc], fc, N, N, lmax[f0:f0 + fc], Kn)
+                    Kn = torch.empty((fcl, N, N), dtype=torch.float32, device=self.dev)
+                    ops.gather_sub_f32(K, tr[g0:g0 + fcl], tr[g0:g0 + fcl], fcl, N, N, lmax[g0:g0 + fcl], Kn)
                     # Q_0[n][f][i] = K[tr_f[n], va_f[i]] / lambda_f  (K symmetric), zero in the padding columns
-                    Q = ops.zeros((N, fc, Mq), torch.float32, self.dev)
-                    ops.gather_sub_f32_strided(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], Q, Mq,
-                                               fc * Mq, 1)
-                    tiles = [f * (Mq // COL_TILE) for f in range(fc + 1)]
+                    Q = ops.zeros((N, fcl, Mq), torch.float32, self.dev)
+                    ops.gather_sub_f32_strided(K, tr[g0:g0 + fcl], va[g0:g0 + fcl], fcl, N, M, lmax[g0:g0 + fcl], Q, Mq,
+                                               fcl * Mq, 1)
+                    tiles = [f * (Mq // COL_TILE) for f in range(fcl + 1)]
                     for j in range(SERIES_TERMS):
                         if j:
                             Qn = torch.empty_like(Q)
-                            ops.gemm_grouped(Kn, N, N * N, Q, fc * Mq, None, Qn, fc * Mq, N, fc * Mq, N, tiles)
+                            ops.gemm_grouped(Kn, N, N * N, Q, fcl * Mq, None, Qn, fcl * Mq, N, fcl * Mq, N, tiles)
                             Q = Qn
-                        ops.series_place(Q, N, fc, Mq, M, rowmap[j * M:(j + 1) * M], P, rows_p)
-                else:
-                    ops.batch_series_terms(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], SERIES_TERMS,
+                        ops.series_place(Q, N, fcl, Mq, M, rowmap[j * M:(j + 1) * M], P, rows_p)
+                elif fcl:
+                    ops.batch_series_terms(K, tr[g0:g0 + fcl], va[g0:g0 + fcl], fcl, N, M, lmax[g0:g0 + fcl], SERIES_TERMS,
                                            P, rowmap)
+                if self.shard.active:
+                    P = self.shard.all_gather(P, lane="hat").view(self.shard.world * n_per, rows_p, N)
             elif ser:
                 ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], self.d_coef, d_ser, A,
                                      SERIES_TERMS, H)
@@ -1538,27 +1545,12 @@ class NestedCVModel(BasePredictivityModel):
                 # share of a fold's systems -- so the folds are prepared one by one (all queued now, nothing gated), each
                 # ready when its sweeps come up; and every fold's refit systems for every factorised alpha are solved
                 # collectively ahead of the choices (aux2), fold 0's first
-                import os
-                plan = os.environ.get("LITCODER_SHARD_PLAN", "h:1-;r:0|1-")   # experiment knob: fold groups of the batches
-
-                def groups(spec, lo):
-                    out = []
-                    for part in spec.split("|"):
-                        a, _, b = part.partition("-")
-                        a = int(a)
-                        b = (n - 1 if b == "" else int(b)) if "-" in part else a
-                        out.append([i for i in range(max(a, lo), min(b, n - 1) + 1)])
-                    return [g for g in out if g]
-
-                hp, rp = (x.split(":")[1] for x in plan.split(";"))
-                prepared = [None] * n
-                prepared[0] = first
-                for g in groups(hp, 1):
-                    for i, st_g in zip(g, eng.prepare_folds([outer[i] for i in g], [lmax_pre[i] for i in g])):
-                        prepared[i] = st_g
-                for g in groups(rp, 0):
-                    eng.refit_ahead([prepared[i] for i in g])
-                prepared = prepared[1:]
+                # (one batch over folds 1..n-1 for the hat matrices; fold 0's refit systems by themselves, then the other
+                # folds' in one batch: per-fold batches and other mixtures measured the same, 54-57 ms per simulated rank
+                # of 8 -- the rank is bound by its total work, not by the batching)
+                prepared = eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else []
+                eng.refit_ahead([first])
+                eng.refit_ahead(prepared)
             else:
                 # one GPU: the batch's series operands now, its Cholesky chains once fold 0's sweeps (just queued) are
                 # done -- same fit time, and fold 0's fused launches, the dominant kernel, run without 80 systems of fp64
