@@ -71,7 +71,9 @@ def idx_matrix(row_sets, length, dev, fill=-1):
     return upload(h, dev)
 
 
-_STAGE = {"buf": None, "off": 0}
+import threading
+
+_STAGE = {"buf": None, "off": 0, "lock": threading.Lock()}
 _STAGE_BYTES = 32 << 20
 
 
@@ -88,13 +90,14 @@ def upload(arr, dev):
     n = a.nbytes
     if n == 0 or n > _STAGE_BYTES // 4:
         return torch.from_numpy(a).pin_memory().to(dev, non_blocking=True)
-    if _STAGE["buf"] is None:
-        _STAGE["buf"] = torch.empty(_STAGE_BYTES, dtype=torch.uint8, pin_memory=True)
-    off = (_STAGE["off"] + 255) & ~255
-    if off + n > _STAGE_BYTES:                      # wrapped: everything staged so far must have left the ring
-        torch.cuda.synchronize()
-        off = 0
-    _STAGE["off"] = off + n
+    with _STAGE["lock"]:                            # the ring is the process's: fits in several threads share it
+        if _STAGE["buf"] is None:
+            _STAGE["buf"] = torch.empty(_STAGE_BYTES, dtype=torch.uint8, pin_memory=True)
+        off = (_STAGE["off"] + 255) & ~255
+        if off + n > _STAGE_BYTES:                  # wrapped: everything staged so far must have left the ring
+            torch.cuda.synchronize()
+            off = 0
+        _STAGE["off"] = off + n
     stage = _STAGE["buf"][off:off + n]
     stage.numpy()[:] = a.reshape(-1).view(np.uint8)
     out = torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype if a.size else torch.float32, device=dev)
