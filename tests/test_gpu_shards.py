@@ -111,6 +111,22 @@ def test_two_real_engine_ranks_on_one_gpu_equal_the_unsharded_fit(runs):
     assert n == 2 * 2 * 7
 
 
+def test_three_ranks_uneven_shares(runs):
+    """Three ranks: 777 voxels split 259 / 259 / 259, job counts that do not divide by three (ranks with one job fewer
+    or none at all, row-sliced refit systems with an idle rank) -- still the unsharded fit bit for bit on every rank."""
+    d, script, env, ref = runs
+    port = 29700 + os.getpid() % 200
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr",
+                    "127.0.0.1", "--master-port", str(port), str(script), ROOT, "gloo", str(d)], check=True, env=env,
+                   timeout=1500)
+    ranks = [pickle.load(open(d / f"gloo3_rank{r}.pkl", "rb")) for r in range(3)]
+    assert [(o["lo"], o["hi"]) for o in ranks] == [(0, 259), (259, 518), (518, 777)]
+    for key, want in ref.items():
+        if isinstance(key, tuple):
+            for r, out in enumerate(ranks):
+                _same(out[key], want, out["lo"], out["hi"], (key, r))
+
+
 def test_one_rank_through_rccl_collectives(runs):
     d, script, env, ref = runs
     env = dict(env, RANK="0", WORLD_SIZE="1", MASTER_PORT=str(29950 + os.getpid() % 40))
