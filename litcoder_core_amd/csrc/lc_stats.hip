@@ -299,14 +299,26 @@ constexpr int GB_THREADS = 512;
 constexpr int GB_MAX_A = 64;
 
 __global__ void __launch_bounds__(GB_THREADS) k_group_by_alpha(const int* __restrict__ best, long long V, int A, int pad,
-                                                               int* __restrict__ perm, int* __restrict__ count) {
-    extern __shared__ int hist[];            // A * GB_THREADS
+                                                               int* __restrict__ perm, int* __restrict__ count, int staged) {
+    extern __shared__ int hist[];            // A * GB_THREADS, then (staged) V bytes of alpha indices
     __shared__ int carry;
     const int t = threadIdx.x;
     const long long L = (V + GB_THREADS - 1) / GB_THREADS;
     const long long lo = (long long)t * L, hi = min(V, lo + L);
+    // every thread walks its own contiguous segment twice: straight from global memory that is one dependent ~1 us
+    // load per voxel and thread (2 x 157 at V = 80 000: the whole kernel).  With `staged` the indices (< 64: one byte)
+    // are first copied into LDS with coalesced loads and the segments are walked there.
+    unsigned char* stage = reinterpret_cast<unsigned char*>(hist + A * GB_THREADS);
+    if (staged) {
+        for (long long v = t; v < V; v += GB_THREADS) stage[v] = (unsigned char)best[v];
+        __syncthreads();
+    }
     for (int a = 0; a < A; ++a) hist[a * GB_THREADS + t] = 0;
-    for (long long v = lo; v < hi; ++v) hist[best[v] * GB_THREADS + t] += 1;
+    if (staged) {
+        for (long long v = lo; v < hi; ++v) hist[stage[v] * GB_THREADS + t] += 1;
+    } else {
+        for (long long v = lo; v < hi; ++v) hist[best[v] * GB_THREADS + t] += 1;
+    }
     if (t == 0) carry = 0;
     __syncthreads();
     // exclusive scan over the A*GB_THREADS table in chunks of GB_THREADS (Hillis-Steele per chunk)
@@ -334,7 +346,7 @@ __global__ void __launch_bounds__(GB_THREADS) k_group_by_alpha(const int* __rest
         __syncthreads();
     }
     for (long long v = lo; v < hi; ++v) {
-        const int a = best[v];
+        const int a = staged ? (int)stage[v] : best[v];
         perm[hist[a * GB_THREADS + t]++] = (int)v;
     }
 }
@@ -528,12 +540,12 @@ extern "C" int lc_group_by_alpha(const int32_t* d_best, int64_t V, int A, int pa
     LC_REQUIRE(d_best && d_perm && d_count, LC_E_BADARG, "lc_group_by_alpha: null pointer");
     LC_REQUIRE(A > 0 && A <= GB_MAX_A && pad >= 1, LC_E_SHAPE, "lc_group_by_alpha: A must be in 1..%d, pad >= 1", GB_MAX_A);
     LC_REQUIRE(V >= 0 && V < (1ll << 31), LC_E_SHAPE, "lc_group_by_alpha: V out of range");
-    const size_t lds = (size_t)A * GB_THREADS * sizeof(int);
-    if (lds > 48 * 1024)
-        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_group_by_alpha),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    size_t lds = (size_t)A * GB_THREADS * sizeof(int);
+    const int staged = lds + (size_t)V + 16 <= 150 * 1024 ? 1 : 0;      // the indices as bytes behind the histogram table
+    if (staged) lds += ((size_t)V + 15) / 16 * 16;
+    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_group_by_alpha), 150 * 1024)) return rc;
     hipLaunchKernelGGL(k_group_by_alpha, dim3(1), dim3(GB_THREADS), lds, lc::as_stream(stream), d_best, V, A, pad,
-                       d_perm, d_count);
+                       d_perm, d_count, staged);
     return lc::launched("k_group_by_alpha");
 }
 
