@@ -564,8 +564,8 @@ constexpr int ST_LDC = NB + 2;     // row stride of the C tile in LDS
 // fragments (LDS broadcast reads), 4 B fragments and 16 MFMAs with tied AGPR accumulators.  A_LDS: A is a 64 x 64 tile
 // already in LDS (row stride ST_LDC) and depth == 64.
 template <bool BT, bool A_LDS>
-__device__ inline void tile_mac(double (&acc)[4][4], const double* __restrict__ A, long long lda, int a_rows,
-                                const double* __restrict__ B, long long ldb, int depth, double* sA, double* sB) {
+__device__ inline void tile_mac(double (&acc)[4][4], const double* A, long long lda, int a_rows,
+                                const double* B, long long ldb, int depth, double* sA, double* sB) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
     f64x2 ra[2], rb[2];
