@@ -209,6 +209,43 @@ int lc_gather_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_rows, int
 int lc_lambda_max_strided(const double* d_k, int64_t ldk, int64_t k_stride, const int32_t* d_rows, int F, int N,
                           int steps, double* d_work, double* d_lmax, lc_stream_t stream);
 
+/* Primal form for a handful of features, p <= 16 (csrc/lc_primal.hip): every statistic the nested CV takes from a
+ * prediction X w is a linear / quadratic form in w = (G + a^2 I)^-1 Rstim'y, so the V-wide work of an outer fold is one
+ * pass over the targets (what ridge_regression.py:104-133 and nested_cv.py:150-155 compute through V-wide products).
+ * Row sets: d_rows (n_sets, ldr) int32, the first d_nrows[s] entries of row s valid; d_shrow[s] = the row of Y whose
+ * values are subtracted from the targets of set s (all sets of one outer fold share it).  p_pad = lc_primal_pad(p) in
+ * {4, 8, 16}.
+ *   lc_xty_f64          d_part ((n_sets, RS, p_pad + 2, V) f64): per chunk of `chunk` rows  X'(Y - shift), the sum of
+ *                       the shifted targets and of their squares; slots beyond a set's rows are left untouched;
+ *   lc_primal_set_stats d_xstat ((n_sets, p_pad + 2 p_pad^2) f64) = [column sums | X'X | centred scatter] per set;
+ *   lc_primal_gsys      d_gsys ((n_sys, p_pad, p_pad) f64) = X'X[plus] - X'X[minus], d_sysdef (n_sys, 2) int32 =
+ *                       (plus, minus or -1): the Gram matrix of a training set given as a block minus a sub-block;
+ *   lc_primal_inverse   d_pinv ((n_sys * A, p_pad, p_pad) f64) = (G_sys + d_a2[sys * A + a] I)^-1 by Cholesky (padding
+ *                       rows: identity); d_info (n_sys * A) nonzero = failed pivot;
+ *   lc_primal_scores    d_scores (A, lds) f32 = sum over the F inner folds of the correlation score of every alpha
+ *                       (fp32 sum in fold order; columns >= V zeroed); d_src (F, 3) int32 = (plus, minus or -1,
+ *                       validation) set numbers; d_pinv: system f * A + a;
+ *   lc_primal_refit     W[:, c] += scale * fl32(pinv[best[c]] Rstim'y) over set_train (d_pinv: the A systems of the
+ *                       outer training set) and d_r[c] = Pearson r of the prediction with the targets over set_test. */
+int lc_primal_pad(int p);
+int lc_xty_f64(const float* d_x, int64_t ldx, int p, const float* d_y, int64_t ldy, int64_t V,
+               const int32_t* d_rows, int ldr, const int32_t* d_nrows, const int32_t* d_shrow, int n_sets,
+               int chunk, int RS, double* d_part, lc_stream_t stream);
+int lc_primal_set_stats(const float* d_x, int64_t ldx, int p, const int32_t* d_rows, int ldr,
+                        const int32_t* d_nrows, int n_sets, double* d_xstat, lc_stream_t stream);
+int lc_primal_gsys(const double* d_xstat, const int32_t* d_sysdef, int n_sys, int p, double* d_gsys,
+                   lc_stream_t stream);
+int lc_primal_inverse(const double* d_gsys, const double* d_a2, int n_sys, int A, int p, double* d_pinv,
+                      int32_t* d_info, lc_stream_t stream);
+int lc_primal_scores(const double* d_part, int RS, int chunk, const int32_t* d_nrows, const int32_t* d_shrow,
+                     const float* d_y, int64_t ldy, int64_t V, const int32_t* d_src, const double* d_xstat,
+                     const double* d_pinv, int F, int A, int p, float* d_scores, int64_t lds,
+                     lc_stream_t stream);
+int lc_primal_refit(const double* d_part, int RS, int chunk, const int32_t* d_nrows, const int32_t* d_shrow,
+                    const float* d_y, int64_t ldy, int64_t V, int set_train, int set_test,
+                    const double* d_xstat, const double* d_pinv, const int32_t* d_best, int p, float scale,
+                    float* d_w, int64_t ldw, double* d_r, lc_stream_t stream);
+
 /* In place on every (N+M, N) system: Cholesky of the top block, then bottom <- bottom * inv(top)
  * i.e. the hat matrices  Xva Xtr' (Xtr Xtr' + a^2 I)^-1  (= Pstim Vh' diag(S/(S^2+a^2)) U',
  * ridge_regression.py:104-105,117-120).  Result written as f32 to d_h (B, M, N).

@@ -53,6 +53,16 @@ SIGNATURES = {
     "lc_gather_transpose_f32": (c_int, [_ptr, c_int64, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
     "lc_gram_blocks_f64": (c_int, [_ptr, c_int64, c_int, c_int, c_int, _ptr, _ptr]),
     "lc_gather_rows_f64": (c_int, [_ptr, c_int64, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
+    "lc_primal_pad": (c_int, [c_int]),
+    "lc_xty_f64": (c_int, [_ptr, c_int64, c_int, _ptr, c_int64, c_int64, _ptr, c_int, _ptr, _ptr, c_int, c_int, c_int, _ptr,
+                           _ptr]),
+    "lc_primal_set_stats": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, _ptr, c_int, _ptr, _ptr]),
+    "lc_primal_gsys": (c_int, [_ptr, _ptr, c_int, c_int, _ptr, _ptr]),
+    "lc_primal_inverse": (c_int, [_ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
+    "lc_primal_scores": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int64, _ptr, _ptr, _ptr, c_int, c_int,
+                                 c_int, _ptr, c_int64, _ptr]),
+    "lc_primal_refit": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int64, c_int, c_int, _ptr, _ptr, _ptr,
+                                c_int, c_float, _ptr, c_int64, _ptr, _ptr]),
     "lc_lambda_max_strided": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_fill_argmax": (c_int, [_ptr, c_int, _ptr, c_int64, _ptr]),
     "lc_fold_pack": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr, c_int, _ptr, c_int, _ptr, c_int64, _ptr]),

@@ -1,6 +1,6 @@
 // Statistics tail on the device: Fisher's combination of the per-fold p-values and the
 // Benjamini-Hochberg step-up procedure.  O(V) work on vectors that are already in HBM; the sort is hipCUB's radix
-// sort (rocPRIM), everything else is a single workgroup.
+// sort (rocPRIM).
 //   reference: nested_cv.py:441-477 (_combine_pvalues_across_folds), statsmodels fdrcorrection(method="indep")
 //   at nested_cv.py:158,263,282 -- host twins with the same arithmetic: litcoder_core_amd/stats.py.
 #include <hipcub/hipcub.hpp>
@@ -38,39 +38,93 @@ __global__ void k_iota(int* __restrict__ idx, long long n) {
     if (i < n) idx[i] = (int)i;
 }
 
-// Sorted p-values -> adjusted p-values and rejections, scattered back to input order.  One workgroup: thread t owns
-// the contiguous chunk [t*c, (t+1)*c) of the sorted vector; the suffix minimum and the largest passing rank are
-// combined across threads through LDS.
+// Sorted p-values -> adjusted p-values and rejections, scattered back to input order, in two launches over blocks of
+// BH_THREADS consecutive ranks (coalesced; a fold's 80 000 - 640 000 p-values are 79 - 625 blocks):
+//   k_bh_block_min  per block: min of q_i = p_(i) / frac_i and the largest i with p_(i) <= frac_i alpha;
+//   k_bh_apply      per block: the minimum over the blocks to its right and the largest passing rank of all blocks,
+//                   an inclusive suffix-minimum scan of its own q_i in LDS, then the scatter.
+// Same expressions per element as the one-workgroup version it replaces (0.56 ms for 80 000 values, 4.5 ms for 640 000).
 constexpr int BH_THREADS = 1024;
-__global__ void __launch_bounds__(BH_THREADS) k_bh_sorted(const double* __restrict__ ps, const int* __restrict__ order,
-                                                          long long n, double alpha, unsigned char* __restrict__ reject,
-                                                          double* __restrict__ padj) {
-    __shared__ double smin[BH_THREADS];
-    __shared__ long long smax[BH_THREADS];
-    const int t = threadIdx.x;
-    const long long c = (n + BH_THREADS - 1) / BH_THREADS;
-    const long long lo = (long long)t * c, hi = lo + c < n ? lo + c : n;
-    const double dn = (double)n;
-    // chunk minimum of p_(i) / frac_i and the largest i in the chunk with p_(i) <= frac_i * alpha
-    double m = INFINITY;
-    long long last = -1;
-    for (long long i = hi - 1; i >= lo; --i) {
-        const double frac = (double)(i + 1) / dn;
-        m = fmin(m, ps[i] / frac);
-        if (last < 0 && ps[i] <= frac * alpha) last = i;
+
+__device__ inline void bh_element(const double* __restrict__ ps, long long i, long long n, double alpha, double& q,
+                                  long long& pass) {
+    q = INFINITY;
+    pass = -1;
+    if (i < n) {
+        const double frac = (double)(i + 1) / (double)n;
+        q = ps[i] / frac;
+        if (ps[i] <= frac * alpha) pass = i;
     }
-    smin[t] = m;
-    smax[t] = last;
+}
+
+__global__ void __launch_bounds__(BH_THREADS) k_bh_block_min(const double* __restrict__ ps, long long n, double alpha,
+                                                             double* __restrict__ bmin, long long* __restrict__ blast) {
+    __shared__ double smin[BH_THREADS / 64];
+    __shared__ long long smax[BH_THREADS / 64];
+    const int t = threadIdx.x;
+    double q;
+    long long pass;
+    bh_element(ps, (long long)blockIdx.x * BH_THREADS + t, n, alpha, q, pass);
+    for (int o = 32; o > 0; o >>= 1) {
+        q = fmin(q, __shfl_xor(q, o));
+        const long long other = __shfl_xor(pass, o);
+        pass = other > pass ? other : pass;
+    }
+    if ((t & 63) == 0) { smin[t >> 6] = q; smax[t >> 6] = pass; }
     __syncthreads();
-    // exclusive suffix minimum over the chunks to the right, global maximum passing rank (serial: 1024 entries)
+    if (t == 0) {
+        for (int w = 1; w < BH_THREADS / 64; ++w) {
+            q = fmin(q, smin[w]);
+            pass = smax[w] > pass ? smax[w] : pass;
+        }
+        bmin[blockIdx.x] = q;
+        blast[blockIdx.x] = pass;
+    }
+}
+
+__global__ void __launch_bounds__(BH_THREADS) k_bh_apply(const double* __restrict__ ps, const int* __restrict__ order,
+                                                         long long n, double alpha, const double* __restrict__ bmin,
+                                                         const long long* __restrict__ blast, int nb,
+                                                         unsigned char* __restrict__ reject, double* __restrict__ padj) {
+    __shared__ double scan[2][BH_THREADS];
+    __shared__ double smin[BH_THREADS / 64];
+    __shared__ long long smax[BH_THREADS / 64];
+    const int t = threadIdx.x, b = blockIdx.x;
+    // minimum of the blocks to the right, largest passing rank anywhere
     double right = INFINITY;
-    for (int u = BH_THREADS - 1; u > t; --u) right = fmin(right, smin[u]);
     long long kmax = -1;
-    for (int u = 0; u < BH_THREADS; ++u) kmax = smax[u] > kmax ? smax[u] : kmax;
-    double run = right;
-    for (long long i = hi - 1; i >= lo; --i) {
-        const double frac = (double)(i + 1) / dn;
-        run = fmin(run, ps[i] / frac);
+    for (int u = t; u < nb; u += BH_THREADS) {
+        if (u > b) right = fmin(right, bmin[u]);
+        kmax = blast[u] > kmax ? blast[u] : kmax;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        right = fmin(right, __shfl_xor(right, o));
+        const long long other = __shfl_xor(kmax, o);
+        kmax = other > kmax ? other : kmax;
+    }
+    if ((t & 63) == 0) { smin[t >> 6] = right; smax[t >> 6] = kmax; }
+    __syncthreads();
+    for (int w = 0; w < BH_THREADS / 64; ++w) {
+        right = fmin(right, smin[w]);
+        kmax = smax[w] > kmax ? smax[w] : kmax;
+    }
+    // inclusive suffix minimum of this block's q_i (Hillis-Steele, double buffered)
+    const long long i = (long long)b * BH_THREADS + t;
+    double q;
+    long long pass;
+    bh_element(ps, i, n, alpha, q, pass);
+    int cur = 0;
+    scan[0][t] = q;
+    __syncthreads();
+    for (int o = 1; o < BH_THREADS; o <<= 1) {
+        double v = scan[cur][t];
+        if (t + o < BH_THREADS) v = fmin(v, scan[cur][t + o]);
+        scan[cur ^ 1][t] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (i < n) {
+        const double run = fmin(right, scan[cur][t]);
         const int o = order[i];
         padj[o] = run > 1.0 ? 1.0 : run;
         reject[o] = i <= kmax ? 1 : 0;
@@ -87,14 +141,15 @@ extern "C" int lc_fisher_combine(const double* d_p, int k, int64_t V, double* d_
     return lc::launched("k_fisher");
 }
 
-// workspace layout: sorted keys (n doubles) | sorted indices (n ints) | input indices (n ints) | hipCUB temporary
+// workspace layout: sorted keys (n doubles) | sorted indices (n ints) | input indices (n ints) | per-block minimum and
+// last passing rank (nb doubles, nb int64) | hipCUB temporary
 extern "C" int64_t lc_bh_fdr_work_bytes(int64_t n) {
     if (n <= 0 || n >= (1ll << 31)) return -1;
     size_t tmp = 0;
     if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const double*)nullptr, (double*)nullptr, (const int*)nullptr,
                                            (int*)nullptr, (int)n) != hipSuccess)
         return -1;
-    return (int64_t)(n * 8 + ((n * 4 + 7) / 8) * 8 * 2 + tmp + 64);
+    return (int64_t)(n * 8 + ((n * 4 + 7) / 8) * 8 * 2 + lc::ceil_div<int64_t>(n, BH_THREADS) * 16 + tmp + 64);
 }
 
 extern "C" int lc_bh_fdr(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, double* d_padj, void* d_work,
@@ -108,10 +163,15 @@ extern "C" int lc_bh_fdr(const double* d_p, int64_t n, double alpha, uint8_t* d_
     double* keys = reinterpret_cast<double*>(w);
     int* order = reinterpret_cast<int*>(w + n * 8);
     int* iota = reinterpret_cast<int*>(w + n * 8 + ints);
-    void* tmp = w + n * 8 + 2 * ints;
-    size_t tmp_bytes = (size_t)work_bytes - (n * 8 + 2 * ints);
+    const int nb = (int)lc::ceil_div<int64_t>(n, BH_THREADS);
+    double* bmin = reinterpret_cast<double*>(w + n * 8 + 2 * ints);
+    long long* blast = reinterpret_cast<long long*>(w + n * 8 + 2 * ints + (size_t)nb * 8);
+    void* tmp = w + n * 8 + 2 * ints + (size_t)nb * 16;
+    size_t tmp_bytes = (size_t)work_bytes - (n * 8 + 2 * ints + (size_t)nb * 16);
     hipLaunchKernelGGL(k_iota, dim3((unsigned)lc::ceil_div<long long>(n, 256)), dim3(256), 0, s, iota, (long long)n);
     LC_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, d_p, keys, iota, order, (int)n, 0, 64, s));
-    hipLaunchKernelGGL(k_bh_sorted, dim3(1), dim3(BH_THREADS), 0, s, keys, order, (long long)n, alpha, d_reject, d_padj);
-    return lc::launched("k_bh_sorted");
+    hipLaunchKernelGGL(k_bh_block_min, dim3((unsigned)nb), dim3(BH_THREADS), 0, s, keys, (long long)n, alpha, bmin, blast);
+    hipLaunchKernelGGL(k_bh_apply, dim3((unsigned)nb), dim3(BH_THREADS), 0, s, keys, order, (long long)n, alpha, bmin, blast, nb,
+                       d_reject, d_padj);
+    return lc::launched("k_bh_apply");
 }

@@ -45,6 +45,7 @@ SERIES_TOL = 2e-9                   # ... used when its worst relative error ove
 SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singcutoff enters a prediction with weight
                                     # S^2 / (S^2 + a^2) <= (singcutoff / a)^2: below 1e-6 it is invisible in fp32
 PRIMAL_MAX_SCALE_RATIO = 64.0       # ... and whose feature column norms lie within this factor of each other (fp16x3)
+PRIMAL_MOMENTS_MAX_P = 16           # ... and, up to this many features, scored from block products X'Y alone (_prepare_moments)
 PRIMAL_MAX_P = 512                  # the primal (p x p) form is taken for tall designs up to this many features
 MAX_ALPHAS = 64                     # lc_group_by_alpha / the grouped GEMMs carry at most 64 alpha groups per launch
 MAX_INNER_FOLDS = 64                # the series chain runs the inner folds as column groups of one grouped launch
@@ -187,6 +188,8 @@ class RidgeCVEngine:
         self.primal = form == "primal" or (form == "auto" and min_train_rows is not None
                                            and 2 * self.p <= int(min_train_rows) and self.p <= PRIMAL_MAX_P)
         self.PP = ops.pad_to(self.p, LC_NB)            # primal: padded system size
+        # a handful of features + correlation scoring: the whole nested CV from block products X'Y (_prepare_moments)
+        self.moments = self.primal and self.p <= PRIMAL_MOMENTS_MAX_P and bool(use_corr)
         self.dX = self._resident(X_all, self.p_pad)
         self.dY = self._resident(Y_all, self.Vp)
         # the Gram matrix first: the host-side set-up below (polynomial coefficients, index tables) runs beside it
@@ -222,6 +225,7 @@ class RidgeCVEngine:
         self.n_folds_done = 0
         self._base_scales = None                       # (cs, split) of the resident targets, see _target_scales
         self.sweeps_done = None                        # end of the sweeps queued last (chain_gate)
+        self._natural = None                           # 0 .. V-1 on the device (moments form: results in voxel order)
         # what this fit ran, for the caller (NestedCVModel.last_fit; bench.py prices the roofline with it): arithmetic
         # of the sweeps, alphas scored inside the fused launch, algorithmic flops of the plain fp16x3 GEMMs.  Per
         # engine: two fits in one process do not share it.
@@ -249,11 +253,13 @@ class RidgeCVEngine:
             mean, std = ops.col_mean_std(self.dX, rows, len(tr_rows), self.p)
             X = self.dX.clone()
             ops.col_normalize_(X, self.Ttot, self.p, mean, std)
-            K = ops.gram(X, self.Ttot, self.p)
+            K = None if self.primal else ops.gram(X, self.Ttot, self.p)
         if self.norm_y:
             mean, std = ops.col_mean_std(self.dY, rows, len(tr_rows), self.V)
             Y = self.dY.clone()
             ops.col_normalize_(Y, self.Ttot, self.V, mean, std)
+        if self.moments:
+            return X, Y, K, None, False      # fp64 block products: no fp16 operands, no column scales
         cs, split = self._target_scales(Y)   # new target values have column scales of their own: per-fold state
         return X, Y, K, cs, split
 
@@ -308,7 +314,7 @@ class RidgeCVEngine:
     def begin_fit(self, n_folds=1):
         """Decide the arithmetic of the V-wide contractions now (column scales of the targets + the one flag that
         comes to the host), so that the first fold's set-up is enqueued without waiting on the device."""
-        if not self.norm_y:
+        if not self.norm_y and not self.moments:
             self._target_scales(self.dY)
         self.p_folds = torch.empty((int(n_folds), self.V_total), dtype=torch.float64, device=self.dev)
         self.n_folds_done = 0
@@ -901,6 +907,8 @@ class RidgeCVEngine:
         for i, m in enumerate(metas):
             g = groups[-1] if groups else None
             per_fold = (m["N"] + m["M"]) * m["N"] * 8 * max(len(self.cho), 1) * len(m["inner_abs"])
+            if self.moments:
+                per_fold = 0                           # p x p systems only
             if (g is not None and batchable and (metas[g[0]]["N"], metas[g[0]]["M"]) == (m["N"], m["M"])
                     and per_fold * (len(g) + 1) <= AUG_BUDGET_BYTES and self._lmax_adjacent(lmax_pre, g[-1], i)
                     and sum(len(metas[k]["inner_abs"]) for k in g) + len(m["inner_abs"]) <= MAX_INNER_FOLDS):
@@ -963,6 +971,8 @@ class RidgeCVEngine:
         an augmented p x p Cholesky system whose augmented rows are Pstim -- the same batched solver, the same sharding.
         The V-wide part (B by one contraction over the training rows, then the fused sweep of depth p) is
         _sweeps_primal."""
+        if self.moments:
+            return self._prepare_moments(g, metas, X, Y, data_ready, out, main)
         PP, p, A = self.PP, self.p, self.A
         inner_all = [ia for i in g for ia in metas[i]["inner_abs"]]
         F = len(inner_all)
@@ -1013,6 +1023,86 @@ class RidgeCVEngine:
             if t is not None and t.is_cuda:
                 t.record_stream(main)                      # allocated on aux, consumed on main
 
+    def _prepare_moments(self, g, metas, X, Y, data_ready, out, main):
+        """prepare_folds for a group of outer folds when p <= PRIMAL_MOMENTS_MAX_P and the scores are correlations
+        (csrc/lc_primal.hip): every statistic of a prediction X w is a p-dimensional form in w = (G + a^2 I)^-1 Rstim'y,
+        so all the V-wide work of a fold is ONE pass over the targets that forms X'y per row set (_sweeps_moments) --
+        here, on the auxiliary stream, only the p x p side: per row set the column sums / second moments of the
+        features, per training set its Gram matrix (an inner training set that is the outer block minus its validation
+        block is taken as that difference, of the block products too), S[0]^2, and (G + a^2 I)^-1 for every alpha.
+        Row sets of a fold: 0 = outer training rows, 1 = test rows, then the validation sets (and the inner training
+        sets that are not such differences).  Systems of a fold: its inner folds, then the outer training set."""
+        p, A = self.p, self.A
+        PT = ops.primal_pad(p)
+        sets, shrow, sysdef, per_fold = [], [], [], []
+        for i in g:
+            m = metas[i]
+            s0, y0 = len(sets), len(sysdef)
+            sets += [m["tr"], m["te"]]
+            tr_sorted = np.sort(m["tr"])
+            src = []
+            for t, v in m["inner_abs"]:
+                va = len(sets) - s0
+                sets.append(v)
+                if len(t) + len(v) == len(tr_sorted) and np.array_equal(np.sort(np.concatenate([t, v])), tr_sorted):
+                    src.append((0, va, va))                         # training rows = outer block minus validation rows
+                else:
+                    src.append((len(sets) - s0, -1, va))
+                    sets.append(t)
+                sysdef.append((s0 + src[-1][0], -1 if src[-1][1] < 0 else s0 + src[-1][1]))
+            sysdef.append((s0, -1))
+            shrow += [int(m["tr"][0])] * (len(sets) - s0)
+            per_fold.append((s0, len(sets) - s0, y0, len(src), np.asarray(src, dtype=np.int32)))
+        S, n_sys = len(sets), len(sysdef)
+        Nmax = ops.pad_to(max(len(r) for r in sets), 4)
+        rows = ops.idx_matrix(sets, Nmax, self.dev)
+        meta = ops.upload(np.concatenate([np.asarray([len(r) for r in sets], dtype=np.int32),
+                                          np.asarray(shrow, dtype=np.int32),
+                                          np.asarray(sysdef, dtype=np.int32).reshape(-1)]
+                                         + [pf[4].reshape(-1) for pf in per_fold]), self.dev)
+        nrows, shr, sysd = meta[:S], meta[S:2 * S], meta[2 * S:2 * S + 2 * n_sys]
+        xstat = ops.primal_set_stats(X, p, rows, nrows, S)
+        gsys = ops.primal_gsys(xstat, sysd, n_sys, p)
+        lmax = None
+        if self.normalpha:
+            ident = ops.idx_matrix([np.arange(p)] * n_sys, PT, self.dev)
+            lmax = ops.lambda_max_strided(gsys, PT, PT * PT, ident, n_sys, PT, self.steps)
+            self._check_singcutoff(lmax)
+        a2 = ops.penalties(lmax, n_sys, self.d_alphas, self.normalpha)
+        pinv, info = ops.primal_inverse(gsys, a2, n_sys, A, p)
+        done = torch.cuda.Event()
+        off = 2 * S + 2 * n_sys
+        for k, i in enumerate(g):
+            m = metas[i]
+            s0, ns, y0, F, src = per_fold[k]
+            hat = dict(moments_p=True, F=F, X=X, rows=rows[s0:s0 + ns], nrows=nrows[s0:s0 + ns], shrow=shr[s0:s0 + ns],
+                       n_sets=ns, src=meta[off:off + 3 * F], xstat=xstat[s0:s0 + ns], pinv=pinv[y0 * A:(y0 + F) * A],
+                       pinv_o=pinv[(y0 + F) * A:(y0 + F + 1) * A], info=info[y0 * A:(y0 + F) * A],
+                       info_o=info[(y0 + F) * A:(y0 + F + 1) * A], data_ready=data_ready, cs=None, split=False)
+            off += 3 * F
+            out[i] = dict(tr=m["tr"], te=m["te"], X=X, Y=Y, K=None, cs=None, split=False, hat=hat, done=done)
+        done.record()
+        for t in (X, Y, rows, meta, xstat, gsys, lmax, a2, pinv, info):
+            if t is not None and t.is_cuda:
+                t.record_stream(main)                      # allocated on aux, consumed on main
+
+    def _sweeps_moments(self, hat, Y, done=None):
+        """_sweeps of the moments form: one pass over the fold's targets (block products of every row set), then the
+        per-voxel scores of all inner folds and alphas from them."""
+        main = torch.cuda.current_stream()
+        if hat.get("data_ready") is not None:
+            main.wait_event(hat["data_ready"])
+        if done is not None:
+            main.wait_event(done)
+        self.info.update(precision="f64 block products", fused_alphas=self.A, series_terms=0)
+        hat["part"] = ops.xty(hat["X"], self.p, Y, self.V, hat["rows"], hat["nrows"], hat["shrow"], hat["n_sets"])
+        scores = torch.empty((self.A, self.Vp), dtype=torch.float32, device=self.dev)
+        ops.primal_scores(hat["part"], hat["nrows"], hat["shrow"], Y, self.V, hat["src"], hat["xstat"], hat["pinv"],
+                          hat["F"], self.A, self.p, scores)
+        self.sweeps_done = torch.cuda.Event()
+        self.sweeps_done.record()
+        return scores
+
     def _check_feature_scales(self, G_o):
         """The primal V-wide contraction sums over FEATURES: with the fp16 hi/lo operands (22 bits relative to a
         row's / column's largest entry) a feature whose scale is orders of magnitude below another's would lose
@@ -1028,6 +1118,8 @@ class RidgeCVEngine:
         """_sweeps in the primal form: per inner fold  B = Rstim'Rresp  (one plain contraction over the training rows,
         p_pad x V), then the fused sweep of all alphas at depth p_pad:  pred_alpha = A_alpha B, scored in the epilogue
         exactly as in the dual form (same kernel, same validation statistics)."""
+        if hat.get("moments_p"):
+            return self._sweeps_moments(hat, Y, done)
         A, PP, M, tr, va, n_v, n_i = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"], hat["n_i"]
         F, Xt, Nmax, off = hat["F"], hat["Xt"], hat["Nmax"], hat["xt_off"]
         (_, _, H, _), = hat["Hs"]
@@ -1220,12 +1312,18 @@ class RidgeCVEngine:
         histogram travels to pinned memory asynchronously, so the caller can queue the next fold's sweeps on the
         main stream BEFORE waiting for it in fold_select (the stream then never idles through the host round trip)."""
         st["best"] = self.choose(st["scores"], single_alpha)
-        st["grouping"] = self._group_async(st["best"], st["split"])
+        if not self.moments:                           # the moments form refits voxel by voxel: no grouping by alpha
+            st["grouping"] = self._group_async(st["best"], st["split"])
         return st
 
     def fold_select(self, st, single_alpha):
         """Waits for the fold's alpha histogram (fold_choose; the one host synchronisation of a fold) and puts the
         fp64 systems of the refit on the auxiliary stream -- they run beside whatever the main stream does next."""
+        if self.moments:                               # nothing to factor after the choice, and no host sync
+            if "best" not in st:
+                self.fold_choose(st, single_alpha)
+            st.update(used=[], used_all=[])
+            return st
         if "grouping" not in st:
             self.fold_choose(st, single_alpha)
         best, split = st["best"], st["split"]
@@ -1258,6 +1356,17 @@ class RidgeCVEngine:
         """V-wide half of the refit, test predictions, Pearson r / p-values and the D2H of the results."""
         tr_rows, te_rows, X, Y = st["tr"], st["te"], st["X"], st["Y"]
         n_t = len(te_rows)
+        if self.moments:
+            # per voxel: weights at its alpha from the outer block product, accumulated into W; Pearson r of the test
+            # rows from the test block product (lc_primal_refit) -- natural voxel order, no sorted copy, no scatter
+            hat, best = st["hat"], st["best"]
+            r_d = torch.empty(max(self.V, 1), dtype=torch.float64, device=self.dev)
+            ops.primal_refit(hat["part"], hat["nrows"], hat["shrow"], Y, self.V, 0, 1, hat["xstat"], hat["pinv_o"], best,
+                             self.p, weight_scale, self.W_acc, r_d)
+            p_d = ops.pearson_pvalues(r_d, self.V, n_t)
+            if self._natural is None:
+                self._natural = ops.upload(np.arange(max(self.V, 1), dtype=np.int32), self.dev)
+            return self._publish(r_d, p_d, self._natural, self.V, best, st["info"], hat["info_o"], n_t)
         best, perm, Vs = st["best"], st["perm"], st["Vs"]
         torch.cuda.current_stream().wait_event(st["systems_ready"])
         row0 = self.p_pad                              # first row of the test-row hat matrix inside M_alpha
@@ -1268,18 +1377,25 @@ class RidgeCVEngine:
         else:
             o = self._refit_operands(Y, tr_rows, te_rows, perm, st["tiles"], Vs, st["Malpha"], st["split"], st["cs"])
         Ys, N_o = o["Ys"], o["N_o"]
-        info_o = st["info_o"]
         # ---- test predictions first (nested_cv.py:151,251: X_te W, here as the hat matrix of the test rows applied
         # to the same targets) and per-voxel Pearson r (:152-155, 252-257); the weight rows of the same contraction
         # follow once the fold's results are on their way to the host
         pred = self._refit_product(o, row0, st["Malpha"].shape[1], n_t)[:n_t]
         r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
-        # ---- the fold's per-voxel results: one packed block in natural voxel order (r, p, alpha index, pivot flags),
-        # all-gathered over the voxel shards, unpacked to V_total-long vectors, BH-FDR of the fold on ALL p-values --
-        # on the communication stream, so that neither the collective nor the sort hold up the main stream
+        pend = self._publish(r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t)
+        # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
+        # run beside this part of the contraction)
+        Ws = self._refit_product(o, 0, self.p_pad, self.p)
+        ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
+        return pend
+
+    def _publish(self, r_s, p_s, perm, Vs, best, info, info_o, n_t):
+        """The fold's per-voxel results: one packed block in natural voxel order (r, p, alpha index, pivot flags),
+        all-gathered over the voxel shards, unpacked to V_total-long vectors, BH-FDR of the fold on ALL p-values -- on
+        the communication stream, so that neither the collective nor the sort hold up the main stream."""
         blk = torch.empty((4, max(self.w_max, 2)), dtype=torch.float64, device=self.dev)
-        ops.fold_pack(r_s, p_s, perm, Vs, best, self.V, st["info"], info_o, blk)
+        ops.fold_pack(r_s, p_s, perm, Vs, best, self.V, info, info_o, blk)
         packed = torch.cuda.Event()
         packed.record()
         self.comm.wait_event(packed)
@@ -1304,13 +1420,9 @@ class RidgeCVEngine:
                 h.copy_(d, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
-        for t in (blk, r_s, p_s, perm, best, st["info"], info_o):
+        for t in (blk, r_s, p_s, perm, best, info, info_o):
             t.record_stream(self.comm)
         self.results_ready = done
-        # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
-        # run beside this part of the contraction)
-        Ws = self._refit_product(o, 0, self.p_pad, self.p)
-        ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
         return dict(done=done, res=h_res, idx=h_idx, n_t=n_t, bad=h_bad, rej=h_rej, padj=h_padj,
                     keep=(dres, didx, dbad, rej_d, padj_d, gathered))
 

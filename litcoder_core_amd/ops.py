@@ -358,6 +358,59 @@ def gather_rows_f64(x, rows, F, M, p, N):
     return out
 
 
+# ---- primal form for a handful of features (csrc/lc_primal.hip)
+PRIMAL_CHUNK = 2048                # rows per partial block product
+
+
+def primal_pad(p):
+    return int(_lib.load().lc_primal_pad(int(p)))
+
+
+def xty(x, p, y, V, rows, nrows, shrow, n_sets, part=None):
+    """(n_sets, RS, p_pad + 2, V) f64 partial block products X'(Y - shift) of the row sets (see lc_xty_f64)."""
+    ldr = rows.shape[-1]
+    RS = -(-ldr // PRIMAL_CHUNK)
+    if part is None:
+        part = torch.empty((n_sets, RS, primal_pad(p) + 2, V), dtype=torch.float64, device=y.device)
+    _lib.call("lc_xty_f64", _p(x), x.stride(0), p, _p(y), y.stride(0), V, _p(rows), ldr, _p(nrows), _p(shrow), n_sets,
+              PRIMAL_CHUNK, RS, _p(part), _s())
+    return part
+
+
+def primal_set_stats(x, p, rows, nrows, n_sets):
+    PT = primal_pad(p)
+    out = torch.empty((n_sets, PT + 2 * PT * PT), dtype=torch.float64, device=x.device)
+    _lib.call("lc_primal_set_stats", _p(x), x.stride(0), p, _p(rows), rows.shape[-1], _p(nrows), n_sets, _p(out), _s())
+    return out
+
+
+def primal_gsys(xstat, sysdef, n_sys, p):
+    PT = primal_pad(p)
+    out = torch.empty((n_sys, PT, PT), dtype=torch.float64, device=xstat.device)
+    _lib.call("lc_primal_gsys", _p(xstat), _p(sysdef), n_sys, p, _p(out), _s())
+    return out
+
+
+def primal_inverse(gsys, a2, n_sys, A, p):
+    PT = primal_pad(p)
+    pinv = torch.empty((n_sys * A, PT, PT), dtype=torch.float64, device=gsys.device)
+    info = torch.empty(n_sys * A, dtype=torch.int32, device=gsys.device)
+    _lib.call("lc_primal_inverse", _p(gsys), _p(a2), n_sys, A, p, _p(pinv), _p(info), _s())
+    return pinv, info
+
+
+def primal_scores(part, nrows, shrow, y, V, src, xstat, pinv, F, A, p, scores):
+    _lib.call("lc_primal_scores", _p(part), part.shape[1], PRIMAL_CHUNK, _p(nrows), _p(shrow), _p(y), y.stride(0), V,
+              _p(src), _p(xstat), _p(pinv), F, A, p, _p(scores), scores.stride(0), _s())
+    return scores
+
+
+def primal_refit(part, nrows, shrow, y, V, set_train, set_test, xstat, pinv, best, p, scale, W, r):
+    _lib.call("lc_primal_refit", _p(part), part.shape[1], PRIMAL_CHUNK, _p(nrows), _p(shrow), _p(y), y.stride(0), V,
+              set_train, set_test, _p(xstat), _p(pinv), _p(best), p, float(scale), _p(W), W.stride(0), _p(r), _s())
+    return r
+
+
 def lambda_max_strided(k, ldk, k_stride, rows, F, N, steps):
     work = torch.empty(F * (3 * N + 2 * steps + 8), dtype=torch.float64, device=k.device)
     out = torch.empty(F, dtype=torch.float64, device=k.device)

@@ -199,14 +199,20 @@ def test_primal_form_for_tall_designs(lc):
     """cfg1-like designs (train_simple.py:21-31: a word-rate feature x 4 delays, p = 4; example.py:104-117 with
     single_alpha) and other tall ones, T >= 2000: ``form="auto"`` takes the primal (p x p) route, which must give the
     oracle's answer (ties proven) and the dual route's -- full CV and train/test, per-voxel and single alpha, both
-    arithmetic paths; a design whose feature scales are too far apart for the fp16 split falls back to the dual form by
-    itself."""
+    arithmetic paths.  Up to 16 features with correlation scores the primal route is the moments form (block products
+    X'y, csrc/lc_primal.hip): p = 4, 8 (trimmed folds: inner training sets that are NOT the outer block minus the
+    validation rows), 12; the same small designs also go through the V-wide primal contraction (moments form switched
+    off), as p = 64 and R^2 scoring always do.  A design whose feature scales are too far apart for the fp16 split
+    falls back to the dual form by itself where fp16 operands would be used."""
     import oracle.nested_cv as onc
+    import litcoder_core_amd.nested_cv as ncv
     rng = np.random.default_rng(41)
     for p0, delays, T, V, kw in (
             (1, [1, 2, 3, 4], 2400, 1500, dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 4, 8))),
             (3, [1, 2, 3, 4], 2000, 700, dict(folding_type="chunked", n_outer_folds=3, n_inner_folds=2, chunk_length=25,
                                               alphas=np.logspace(-1, 3, 6), single_alpha=True)),
+            (2, [1, 2, 3, 4], 2100, 450, dict(folding_type="kfold_trimmed", n_outer_folds=2, n_inner_folds=3,
+                                              alphas=np.logspace(0, 5, 7), normalpha=False)),
             (16, [1, 2, 3, 4], 2100, 600, dict(folding_type="kfold_trimmed", n_outer_folds=2, n_inner_folds=3,
                                                alphas=np.logspace(0, 5, 7), normalpha=False)),
             (64, [0], 2050, 333, dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=np.logspace(-1, 2, 5),
@@ -227,12 +233,20 @@ def test_primal_form_for_tall_designs(lc):
             detail = {}
             random.seed(11)
             oracle = onc.fit_predict(*args, detail=detail, **extra, **kw_run)
-            for precision in ("auto", "f32"):
-                tag = f"p={p} tt={tt} {precision}"
+            moments = p <= ncv.PRIMAL_MOMENTS_MAX_P and not r2
+            for precision, gemm in (("auto", False), ("f32", False)) + ((("auto", True),) if moments else ()):
+                tag = f"p={p} tt={tt} {precision} gemm={gemm}"
                 model = lc.NestedCVModel("r", precision=precision)
                 random.seed(11)
-                ours = model.fit_predict(*args, **extra, **kw_run)
+                keep = ncv.PRIMAL_MOMENTS_MAX_P
+                try:
+                    if gemm:
+                        ncv.PRIMAL_MOMENTS_MAX_P = 0
+                    ours = model.fit_predict(*args, **extra, **kw_run)
+                finally:
+                    ncv.PRIMAL_MOMENTS_MAX_P = keep
                 assert model.last_form == "primal", tag
+                assert (model.last_fit["precision"] == "f64 block products") == (moments and not gemm), tag
                 assert_matches_oracle(lc, model, ours, oracle, detail, args[0], args[1], kw_run, tag, min_same=0.97, **tol,
                                       **({k: extra[k] for k in extra} if tt else {}))
             dual = lc.NestedCVModel("r", form="dual")
@@ -249,12 +263,22 @@ def test_primal_form_for_tall_designs(lc):
     X[:, 3] *= 2.0 ** -12
     Y = X @ rng.standard_normal((6, 50)) + rng.standard_normal((2000, 50))
     kw = dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=[0.1, 1.0])
-    model = lc.NestedCVModel("r")
-    ours = model.fit_predict(X, Y, **kw)
-    assert model.last_form == "dual"
-    with pytest.raises(ValueError, match="form='primal' is not usable"):
-        lc.NestedCVModel("r", form="primal").fit_predict(X, Y, **kw)
-    model32 = lc.NestedCVModel("r", precision="f32")                       # exact-fp32 arithmetic: primal is fine
-    ours32 = model32.fit_predict(X, Y, **kw)
-    assert model32.last_form == "primal"
+    keep = ncv.PRIMAL_MOMENTS_MAX_P
+    try:
+        ncv.PRIMAL_MOMENTS_MAX_P = 0                                       # the V-wide primal contraction (fp16 operands)
+        model = lc.NestedCVModel("r")
+        ours = model.fit_predict(X, Y, **kw)
+        assert model.last_form == "dual"
+        with pytest.raises(ValueError, match="form='primal' is not usable"):
+            lc.NestedCVModel("r", form="primal").fit_predict(X, Y, **kw)
+        model32 = lc.NestedCVModel("r", precision="f32")                   # exact-fp32 arithmetic: primal is fine
+        ours32 = model32.fit_predict(X, Y, **kw)
+        assert model32.last_form == "primal"
+    finally:
+        ncv.PRIMAL_MOMENTS_MAX_P = keep
     np.testing.assert_allclose(np.asarray(ours32[0]["correlations"]), np.asarray(ours[0]["correlations"]), atol=3e-5)
+    model64 = lc.NestedCVModel("r")                                        # fp64 block products: any feature scales
+    ours64 = model64.fit_predict(X, Y, **kw)
+    assert model64.last_form == "primal" and model64.last_fit["precision"] == "f64 block products"
+    np.testing.assert_allclose(np.asarray(ours64[0]["correlations"]), np.asarray(ours[0]["correlations"]), atol=3e-5)
+    np.testing.assert_allclose(ours64[1], ours[1], rtol=2e-4, atol=1e-5)

@@ -516,6 +516,88 @@ def test_device_statistics_tail_matches_host(lc):  # noqa: C901
     assert best.cpu().unique().tolist() == [2]                           # first maximum, NaN never wins
 
 
+def test_block_product_kernels_against_numpy(lc):
+    """csrc/lc_primal.hip, kernel by kernel, against float64 numpy: partial block products X'(Y - shift) with the
+    targets' own moments (sets that span several chunks, a ragged last column block), the per-set feature statistics,
+    (G + a^2 I)^-1 with G given as a block minus a sub-block, the scores of every alpha (the reference's
+    mean(z(y) z(pred)) with unbiased std + 1e-8, ridge_regression.py:124-133, summed over the inner folds in fp32)
+    and the refit (weights, Pearson r of the test rows incl. a constant voxel -> NaN)."""
+    from litcoder_core_amd import ops
+    dev = ops.device(0)
+    rng = np.random.default_rng(77)
+    T, V, A = 5200, 333, 5
+    for p in (3, 7, 13):
+        PT = ops.primal_pad(p)
+        X = rng.standard_normal((T, p)).astype(np.float32) + np.float32(0.3)
+        Y = (X @ rng.standard_normal((p, V)) * 0.3 + rng.standard_normal((T, V)) + 40.0).astype(np.float32)
+        Y[:, 5] = 2.5                                                        # constant voxel
+        dX = ops.upload_f32(X, ops.pad_to(p, 16), dev)
+        dY = ops.upload_f32(Y, ops.pad_to(V, 256), dev)
+        tr = rng.permutation(T)[:4700]                                       # > 2 chunks of 2048 rows
+        te = np.setdiff1d(np.arange(T), tr)[:400]
+        va1, va2 = tr[:900], tr[900:2100]
+        t2 = tr[np.r_[0:850, 2150:4700]]                                     # not the complement of va2: own set
+        sets = [tr, te, va1, va2, t2]
+        Nmax = ops.pad_to(max(len(r) for r in sets), 4)
+        rows = ops.idx_matrix(sets, Nmax, dev)
+        nrows = ops.upload(np.asarray([len(r) for r in sets], dtype=np.int32), dev)
+        shrow = ops.upload(np.full(len(sets), tr[0], dtype=np.int32), dev)
+        part = ops.xty(dX, p, dY, V, rows, nrows, shrow, len(sets))
+        X64, D64 = X.astype(np.float64), Y.astype(np.float64) - Y[tr[0]].astype(np.float64)
+        got = part.cpu().numpy()
+        for s_i, r in enumerate(sets):
+            nch = -(-len(r) // ops.PRIMAL_CHUNK)
+            tot = got[s_i, :nch].sum(axis=0)
+            np.testing.assert_allclose(tot[:p], X64[r].T @ D64[r], rtol=1e-11, atol=1e-9)
+            np.testing.assert_allclose(tot[PT], D64[r].sum(0), rtol=1e-11, atol=1e-9)
+            np.testing.assert_allclose(tot[PT + 1], (D64[r] ** 2).sum(0), rtol=1e-11)
+            assert not tot[p:PT].any()
+        xstat = ops.primal_set_stats(dX, p, rows, nrows, len(sets))
+        xs = xstat.cpu().numpy()
+        for s_i, r in enumerate(sets):
+            np.testing.assert_allclose(xs[s_i, :p], X64[r].sum(0), rtol=1e-12)
+            G = xs[s_i, PT:PT + PT * PT].reshape(PT, PT)[:p, :p]
+            np.testing.assert_allclose(G, X64[r].T @ X64[r], rtol=1e-12)
+            Sc = xs[s_i, PT + PT * PT:].reshape(PT, PT)[:p, :p]
+            Xc = X64[r] - X64[r].mean(0)
+            np.testing.assert_allclose(Sc, Xc.T @ Xc, rtol=1e-9, atol=1e-9)
+        # systems: inner fold 1 = tr \ va1 (a difference), inner fold 2 = t2 (its own set), outer = tr
+        sysdef = ops.upload(np.asarray([[0, 2], [4, -1], [0, -1]], dtype=np.int32).reshape(-1), dev)
+        gsys = ops.primal_gsys(xstat, sysdef, 3, p)
+        a2 = ops.upload(rng.uniform(0.5, 50.0, 3 * A), dev)
+        pinv, info = ops.primal_inverse(gsys, a2, 3, A, p)
+        assert not info.cpu().numpy().any()
+        a2h, Pn = a2.cpu().numpy(), pinv.cpu().numpy()
+        tr1 = tr[900:]
+        Gs = [X64[tr1].T @ X64[tr1], X64[t2].T @ X64[t2], X64[tr].T @ X64[tr]]
+        for b in range(3 * A):
+            np.testing.assert_allclose(Pn[b, :p, :p], np.linalg.inv(Gs[b // A] + a2h[b] * np.eye(p)), rtol=1e-9, atol=1e-14)
+        src = ops.upload(np.asarray([[0, 2, 2], [4, -1, 3]], dtype=np.int32).reshape(-1), dev)
+        scores = torch.full((A, dY.shape[1]), 7.0, dtype=torch.float32, device=dev)
+        ops.primal_scores(part, nrows, shrow, dY, V, src, xstat, pinv[:2 * A], 2, A, p, scores)
+        Y64 = Y.astype(np.float64)
+        want = np.zeros((A, V), dtype=np.float32)
+        for f, (trn, van) in enumerate(((tr1, va1), (t2, va2))):
+            for a in range(A):
+                Wf = Pn[f * A + a, :p, :p] @ (X64[trn].T @ Y64[trn])
+                pred, yv = X64[van] @ Wf, Y64[van]
+                zp = (pred - pred.mean(0)) / (pred.std(0, ddof=1) + 1e-8)
+                zy = (yv - yv.mean(0)) / (yv.std(0, ddof=1) + 1e-8)
+                want[a] = want[a] + (zp * zy).mean(0).astype(np.float32)
+        sc = scores.cpu().numpy()
+        np.testing.assert_allclose(np.delete(sc[:, :V], 5, axis=1), np.delete(want, 5, axis=1), atol=2e-6)
+        assert not sc[:, V:].any() and (sc[:, 5] == 0).all()
+        best = rng.integers(0, A, V).astype(np.int32)
+        W = torch.full((p, dY.shape[1]), 1.0, dtype=torch.float32, device=dev)
+        r_d = torch.empty(V, dtype=torch.float64, device=dev)
+        ops.primal_refit(part, nrows, shrow, dY, V, 0, 1, xstat, pinv[2 * A:], ops.upload(best, dev), p, 0.5, W, r_d)
+        Wn = np.stack([Pn[2 * A + best[v], :p, :p] @ (X64[tr].T @ Y64[tr, v]) for v in range(V)], axis=1)
+        np.testing.assert_allclose(W.cpu().numpy()[:, :V], 1.0 + 0.5 * Wn.astype(np.float32), rtol=2e-6, atol=1e-6)
+        pred = X64[te] @ Wn
+        r_want = np.asarray([np.corrcoef(pred[:, v], Y64[te, v])[0, 1] if v != 5 else np.nan for v in range(V)])
+        np.testing.assert_allclose(r_d.cpu().numpy(), r_want, atol=1e-9, equal_nan=True)
+
+
 def test_fit_nested_cv_alias(lc):
     rng = np.random.default_rng(6)
     X = rng.standard_normal((150, 24))
