@@ -332,6 +332,11 @@ int lc_transpose_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_tr, in
  * d_yv (M, V) f32 = the validation rows gathered contiguously (zero padding rows) for the sweep epilogue. */
 int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int M, int n_val,
                  float* d_ystat, float* d_yblk, float* d_yv, lc_stream_t stream);
+/* The same for F (<= 64) inner folds in ONE launch: d_va (F, M), h_n_val (F, host), outputs (F, 3, V) / (F, M/32, V) /
+ * (F, M, V).  The five validation blocks of an outer fold are independent; one launch instead of five. */
+int lc_val_stats_folds(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int F, int M,
+                       const int32_t* h_n_val, float* d_ystat, float* d_yblk, float* d_yv,
+                       lc_stream_t stream);
 
 /* Fused alpha sweep of one inner fold (ridge_regression.py:115-133, K4+K5 of SURVEY 2.2):
  *   pred_a = H_a (M x N) . Y[tr_rows] (N x V)    for a = 0..A-1, never stored;

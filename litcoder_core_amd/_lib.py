@@ -90,6 +90,7 @@ SIGNATURES = {
     "lc_series_scores": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr,
                                  c_int, _ptr]),
     "lc_transpose_rows_f64": (c_int, [_ptr, c_int64, _ptr, c_int, c_int64, _ptr, _ptr]),
+    "lc_val_stats_folds": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, POINTER(c_int32), _ptr, _ptr, _ptr, _ptr]),
     "lc_val_stats": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr]),
     "lc_alpha_sweep_scores": (c_int, [_ptr, c_int, c_int, c_int, _ptr, c_int64, c_int64, _ptr, _ptr, c_int, _ptr, _ptr,
                                       c_int, _ptr, _ptr, c_int, _ptr]),

@@ -129,11 +129,21 @@ __global__ void __launch_bounds__(64 * CM_RG) k_zscore_story(const double* __res
 // yblk[b, v] = sum over the b-th 32-row block of fl32(y - mean): exactly the centred values
 // the GEMM epilogue multiplies with;  yv = the M validation rows gathered (zero padding rows) in the row-quad
 // interleaved layout of lc_epilogue.h, so that the sweep epilogue reads them with 16-byte coalesced loads.
+// blockIdx.y = inner fold: fold f reads the row list va + f M and writes slice f of (F, 3, V) / (F, M/32, V) / (F, M, V)
+struct FoldRows {
+    int n_val[64];
+};
+
 __global__ void __launch_bounds__(64 * CM_RG) k_val_stats(const float* __restrict__ y, long long ldy, long long V,
-                                                          const int* __restrict__ va, int M, int n_val,
+                                                          const int* __restrict__ va, int M, FoldRows fr,
                                                           float* __restrict__ ystat, float* __restrict__ yblk,
                                                           float* __restrict__ yv) {
     __shared__ double sm[CM_RG][64];
+    const int fold = blockIdx.y, n_val = fr.n_val[fold];
+    va += (long long)fold * M;
+    ystat += (long long)fold * 3 * V;
+    yblk += (long long)fold * (M / LC_MB) * V;
+    yv += (long long)fold * M * V;
     // row group = wave (blockDim = (64, CM_RG)): a scalar, so that the row indices va[i] are scalar loads and
     // the strided target loads of consecutive trips can be in flight together
     const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -424,10 +434,15 @@ namespace {
 // of the fp64 sums behind mean and variance differs (by rounding of the last bit of a double).
 template <int NBLK>
 __global__ void __launch_bounds__(64 * CM_RG) k_val_stats_regs(const float* __restrict__ y, long long ldy, long long V,
-                                                               const int* __restrict__ va, int M, int n_val,
+                                                               const int* __restrict__ va, int M, FoldRows fr,
                                                                float* __restrict__ ystat, float* __restrict__ yblk,
                                                                float* __restrict__ yv) {
     __shared__ double sm[CM_RG][64];
+    const int fold = blockIdx.y, n_val = fr.n_val[fold];
+    va += (long long)fold * M;
+    ystat += (long long)fold * 3 * V;
+    yblk += (long long)fold * (M / LC_MB) * V;
+    yv += (long long)fold * M * V;
     const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
     const bool live = c < V;
@@ -490,21 +505,33 @@ __global__ void __launch_bounds__(64 * CM_RG) k_val_stats_regs(const float* __re
 }
 }  // namespace
 
-extern "C" int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int M, int n_val,
-                            float* d_ystat, float* d_yblk, float* d_yv, lc_stream_t stream) {
-    LC_REQUIRE(d_y && d_va && d_ystat && d_yblk && d_yv, LC_E_BADARG, "lc_val_stats: null pointer");
-    LC_REQUIRE(M % LC_MB == 0 && n_val > 0 && n_val <= M, LC_E_SHAPE, "lc_val_stats: need 0 < n_val <= M, M %% %d == 0",
+extern "C" int lc_val_stats_folds(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int F, int M,
+                                  const int32_t* h_n_val, float* d_ystat, float* d_yblk, float* d_yv,
+                                  lc_stream_t stream) {
+    LC_REQUIRE(d_y && d_va && h_n_val && d_ystat && d_yblk && d_yv, LC_E_BADARG, "lc_val_stats: null pointer");
+    LC_REQUIRE(F >= 1 && F <= 64 && M > 0 && M % LC_MB == 0, LC_E_SHAPE, "lc_val_stats: need 1 <= F <= 64, M %% %d == 0",
                LC_MB);
+    FoldRows fr{};
+    for (int f = 0; f < F; ++f) {
+        LC_REQUIRE(h_n_val[f] > 0 && h_n_val[f] <= M, LC_E_SHAPE, "lc_val_stats: need 0 < n_val <= M");
+        fr.n_val[f] = h_n_val[f];
+    }
     if (V <= 0) return LC_OK;
     lc::ScopedTimer timer_(lc::T_VAL_STATS, lc::as_stream(stream));
-    const dim3 grid((unsigned)lc::ceil_div<long long>(V, 64)), block(64, CM_RG);
+    const dim3 grid((unsigned)lc::ceil_div<long long>(V, 64), (unsigned)F), block(64, CM_RG);
     if (M / LC_MB <= 2 * CM_RG)                              // up to 512 validation rows: held in registers, one pass
         hipLaunchKernelGGL(k_val_stats_regs<2>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V, d_va,
-                           M, n_val, d_ystat, d_yblk, d_yv);
+                           M, fr, d_ystat, d_yblk, d_yv);
     else
-        hipLaunchKernelGGL(k_val_stats, grid, block, 0, lc::as_stream(stream), d_y, ldy, V, d_va, M, n_val, d_ystat, d_yblk,
+        hipLaunchKernelGGL(k_val_stats, grid, block, 0, lc::as_stream(stream), d_y, ldy, V, d_va, M, fr, d_ystat, d_yblk,
                            d_yv);
     return lc::launched("k_val_stats");
+}
+
+extern "C" int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int M, int n_val,
+                            float* d_ystat, float* d_yblk, float* d_yv, lc_stream_t stream) {
+    const int32_t n = n_val;
+    return lc_val_stats_folds(d_y, ldy, V, d_va, 1, M, &n, d_ystat, d_yblk, d_yv, stream);
 }
 
 extern "C" int lc_pearson_cols(const float* d_a, int64_t lda, const float* d_b, int64_t ldb, int64_t n, int64_t V,

@@ -565,9 +565,9 @@ class RidgeCVEngine:
         self.info.update(precision="f16x3" if split else "f32", fused_alphas=Ad,
                           series_terms=SERIES_TERMS if moments else 0)
         nbuf = F if moments else 1                        # two passes over the folds keep every fold's operands
-        ystat = [torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev) for _ in range(nbuf)]
-        yblk = [torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev) for _ in range(nbuf)]
-        yv = [torch.empty((M, self.Vp), dtype=torch.float32, device=self.dev) for _ in range(nbuf)]
+        ystat = torch.empty((nbuf, 3, self.Vp), dtype=torch.float32, device=self.dev)
+        yblk = torch.empty((nbuf, M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
+        yv = torch.empty((nbuf, M, self.Vp), dtype=torch.float32, device=self.dev)
         shared = hat.get("shared") if split else None
         if split:
             rows_pad = ops.pad_to(max(Ad, 1) * M, 256)
@@ -595,8 +595,11 @@ class RidgeCVEngine:
             cs_inv = self._cs_inv_padded(cs, Vt)                               # padded to the plain GEMM's tiles
             if hat.get("series_ready") is not None:
                 main.wait_event(hat["series_ready"])
+            # validation statistics of all inner folds in one launch (the blocks are independent)
+            for f0 in range(0, F, 64):
+                f1 = min(F, f0 + 64)
+                ops.val_stats_folds(Y, self.Vp, va[f0:f1], f1 - f0, M, n_v[f0:f1], ystat[f0:f1], yblk[f0:f1], yv[f0:f1])
             for f, j, H, P in folds:
-                ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat[f], yblk[f], yv[f])
                 if shared is None:
                     ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[f])
                 ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)

@@ -525,6 +525,13 @@ def val_stats(y, V, va, M, n_val, ystat, yblk, yv):
     _lib.call("lc_val_stats", _p(y), y.stride(0), V, _p(va), M, n_val, _p(ystat), _p(yblk), _p(yv), _s())
 
 
+def val_stats_folds(y, V, va, F, M, n_vals, ystat, yblk, yv):
+    """All F inner folds of an outer fold in one launch: va (F, M), outputs (F, 3, V) / (F, M/32, V) / (F, M, V)."""
+    import ctypes as ct
+    nv = (ct.c_int32 * F)(*[int(n) for n in n_vals])
+    _lib.call("lc_val_stats_folds", _p(y), y.stride(0), V, _p(va), F, M, nv, _p(ystat), _p(yblk), _p(yv), _s())
+
+
 def alpha_sweep_scores(h, A, M, N, y, V, tr, yv, n_val, ystat, yblk, mode, part, scores, accumulate):
     _lib.call("lc_alpha_sweep_scores", _p(h), A, M, N, _p(y), y.stride(0), V, _p(tr), _p(yv), n_val, _p(ystat),
               _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), _s())
