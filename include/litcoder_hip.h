@@ -394,6 +394,21 @@ int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val,
                      const int32_t* d_aidx, int S, const int32_t* d_rowmap, float* d_scores, int accumulate,
                      lc_stream_t stream);
 
+/* The two steps above in ONE contraction that never stores the terms (four series terms): d_pt = the tiled fp16 image
+ * (lc_split_rows_f16) of the stacked terms in the layout  row = 256 t + 128 (j >> 1) + 32 (2 (j & 1) + (b & 1)) + i % 32
+ * for term j, validation row i, b = i / 32, t = b / 2 -- every 256-row tile holds all four terms of two 32-row
+ * validation blocks, terms 0, 1 in the wave row that issues three MFMAs per product, terms 2, 3 in the one that
+ * issues hi * hi alone -- and the epilogue reduces the accumulators to the blocks' partial moments (d_part: (M / 32,
+ * 18, V) f32 workspace), from which the scores of the S series alphas follow as in lc_series_scores (same formula:
+ * ridge_regression.py:124-133 for pred = sum_j c_j T_j).  d_yt / d_cscale_inv / Ncols / b_*: the tiled target image as
+ * in lc_gemm_grouped_f16x3;  d_yv, d_ystat, d_yblk: lc_val_stats of the fold;  d_scores: (A, V) f32, V %% 128 == 0. */
+int lc_series_sweep_scores_f16x3(const void* d_pt, const float* d_rowscale_inv, int M, int n_val, int64_t K,
+                                 const void* d_yt, const float* d_cscale_inv, int64_t Ncols,
+                                 const float* d_yv, int64_t V, const float* d_ystat, const float* d_yblk,
+                                 const double* d_coef, const int32_t* d_aidx, int S, float* d_part,
+                                 float* d_scores, int accumulate, int64_t b_rows, int64_t b_gap_begin,
+                                 int64_t b_gap_rows, lc_stream_t stream);
+
 /* ---------------------------------------------------------------- statistics tail */
 
 /* Fisher's combination of k p-values per voxel, nested_cv.py:441-477 (`_combine_pvalues_across_folds`):

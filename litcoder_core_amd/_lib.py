@@ -87,6 +87,9 @@ SIGNATURES = {
     "lc_combine_terms_f32": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, _ptr, c_int64, _ptr]),
     "lc_gather_sub_f64": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr]),
     "lc_gather_sub_f32": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
+    "lc_series_sweep_scores_f16x3": (c_int, [_ptr, _ptr, c_int, c_int, c_int64, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr,
+                                             _ptr, _ptr, _ptr, c_int, _ptr, _ptr, c_int, c_int64, c_int64, c_int64,
+                                             _ptr]),
     "lc_series_scores": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr,
                                  c_int, _ptr]),
     "lc_transpose_rows_f64": (c_int, [_ptr, c_int64, _ptr, c_int, c_int64, _ptr, _ptr]),

@@ -128,6 +128,64 @@ __device__ inline void epi_block(const ep_f32x16& acc, const EpiTargets& t, cons
     }
 }
 
+// Series terms: one 32-row block x this lane's column of the FOUR shared terms T_j = P'_j Y (true values, scales
+// undone) -> the block's partial moments, from which lc_series_sweep's finalisation forms the score of every alpha on
+// the polynomial series (prediction = sum_j c_j T_j):
+//     part[j]              = sum T_j                                   j = 0..3
+//     part[4 + j]          = sum (T_j - mean_j,block) (y - mean_y)
+//     part[8 + idx(j, l)]  = sum (T_j - mean_j,block) (T_l - mean_l,block)   j <= l, row-major upper triangle (10)
+// written from the lanes with lh == 0 and `store`.  MASK: rows >= n_val are padding.
+constexpr int EPI_SERIES_PARTS = 18;
+
+template <bool MASK>
+__device__ inline void epi_series_block(const float (&T)[4][16], const EpiTargets& t, float ymean, int i0, int n_val,
+                                        int lh, float* __restrict__ part, long long V, bool store) {
+    const int nb = MASK ? min(32, n_val - i0) : 32;
+    float s1[4], mean[4];
+    bool live[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) live[r] = !MASK || (i0 + 8 * (r >> 2) + 4 * lh + (r & 3)) < n_val;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += live[r] ? T[j][r] : 0.f;
+        a += __shfl_xor(a, 32);
+        s1[j] = a;
+        mean[j] = nb > 0 ? a / (float)nb : 0.f;
+    }
+    float cy[4] = {0.f, 0.f, 0.f, 0.f}, sc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sc[k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float yc = live[r] ? t.y[r >> 2][r & 3] - ymean : 0.f;
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = live[r] ? T[j][r] - mean[j] : 0.f;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cy[j] += d[j] * yc;
+#pragma unroll
+            for (int l = j; l < 4; ++l) sc[k++] += d[j] * d[l];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cy[j] += __shfl_xor(cy[j], 32);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sc[k] += __shfl_xor(sc[k], 32);
+    if (lh == 0 && store) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            part[(long long)j * V] = s1[j];
+            part[(long long)(4 + j) * V] = cy[j];
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) part[(long long)(8 + k) * V] = sc[k];
+    }
+}
+
 // dispatch on the two wave-uniform run-time switches (score mode, padding rows in the block)
 template <bool SCALED>
 __device__ inline void epi_block_dispatch(bool corr, const ep_f32x16& acc, const EpiTargets& t,

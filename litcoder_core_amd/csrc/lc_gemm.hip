@@ -398,6 +398,73 @@ __global__ void __launch_bounds__(256) k_series_scores(const float* __restrict__
     }
 }
 
+// The same scores from the per-32-row-block partial moments the series-moments epilogue of the fp16x3 kernel writes
+// (lc::epi_series_block; part: (M / 32, 18, V) f32): blocks merged in fixed order in fp64 (Chan), then the forms.
+__global__ void __launch_bounds__(256) k_series_scores_part(const float* __restrict__ part, const float* __restrict__ ystat,
+                                                            const float* __restrict__ yblk, int M, int n_val,
+                                                            long long V, const double* __restrict__ coefs,
+                                                            const int* __restrict__ aidx, int S,
+                                                            float* __restrict__ scores, int accumulate) {
+    constexpr int NP = lc::EPI_SERIES_PARTS;
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= V) return;
+    const int nblk = M / LC_MB;
+    double n = 0.0, mean[4] = {0.0, 0.0, 0.0, 0.0}, sc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sc[k] = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const int nb = min(LC_MB, n_val - b * LC_MB);
+        if (nb <= 0) break;
+        const float* p0 = part + (long long)b * NP * V + c;
+        const double nn = n + nb, w = n * nb / nn;
+        double d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = (double)p0[(long long)j * V] / nb - mean[j];
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int l = j; l < 4; ++l) {
+                sc[k] += (double)p0[(long long)(8 + k) * V] + d[j] * d[l] * w;
+                ++k;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mean[j] += d[j] * nb / nn;
+        n = nn;
+    }
+    double cy[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < nblk; ++b) {
+        const int nb = min(LC_MB, n_val - b * LC_MB);
+        if (nb <= 0) break;
+        const float* p0 = part + (long long)b * NP * V + c;
+        const double yb = (double)yblk[(long long)b * V + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            cy[j] += (double)p0[(long long)(4 + j) * V] + ((double)p0[(long long)j * V] / nb - mean[j]) * yb;
+    }
+    const double nv = (double)n_val, sy = (double)ystat[V + c];
+    for (int s = 0; s < S; ++s) {
+        double coef[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) coef[j] = coefs[s * 4 + j];
+        double m2 = 0.0, cov = 0.0;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cov += coef[j] * cy[j];
+#pragma unroll
+            for (int l = j; l < 4; ++l) { m2 += (l == j ? 1.0 : 2.0) * coef[j] * coef[l] * sc[k]; ++k; }
+        }
+        const double sp = sqrt(fmax(m2, 0.0) / (nv - 1.0));
+        float score = (float)(cov / (nv * (sy + 1e-8) * (sp + 1e-8)));
+        if (score != score) score = 0.f;
+        else if (score > 3.4028234663852886e38f) score = 3.4028234663852886e38f;
+        else if (score < -3.4028234663852886e38f) score = -3.4028234663852886e38f;
+        float* dst = scores + (long long)aidx[s] * V + c;
+        *dst = accumulate ? *dst + score : score;
+    }
+}
+
 int check_gemm_shapes(const char* who, const void* a, long long lda, const void* b, long long ldb, long long Ncols,
                       long long K) {
     LC_REQUIRE(K > 0 && K % BK == 0, LC_E_SHAPE, "%s: K=%lld must be a positive multiple of %d", who, K, BK);
@@ -423,6 +490,15 @@ int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const fl
     hipLaunchKernelGGL(k_score_finalize, dim3((unsigned)lc::ceil_div<long long>(V, 256), (unsigned)A), dim3(256), 0, s,
                        d_part, d_ystat, d_yblk, A, M, n_val, V, mode, d_scores, accumulate);
     return lc::launched("k_score_finalize");
+}
+
+int lc_series_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int M, int n_val,
+                              long long V, const double* d_coef, const int* d_aidx, int S, float* d_scores,
+                              int accumulate, hipStream_t s) {
+    lc::ScopedTimer timer_(lc::T_SWEEP_FINALIZE, s);
+    hipLaunchKernelGGL(k_series_scores_part, dim3((unsigned)lc::ceil_div<long long>(V, 256)), dim3(256), 0, s, d_part,
+                       d_ystat, d_yblk, M, n_val, V, d_coef, d_aidx, S, d_scores, accumulate);
+    return lc::launched("k_series_scores_part");
 }
 
 extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, const float* d_y, int64_t ldy, int64_t V,

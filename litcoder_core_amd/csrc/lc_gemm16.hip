@@ -192,7 +192,12 @@ struct Plain16Args {
         __builtin_amdgcn_sched_barrier(0);                                                     \
     }
 
-template <bool SCORE, bool STAMP, bool LIGHTCAP = false>
+// SERMOM (with LIGHTCAP, plain operands): the A rows are the four shared series terms of TWO 32-row validation blocks
+// per tile -- wave row wm = 0: [T0 b0, T0 b1, T1 b0, T1 b1] (heavy), wm = 1: [T2 b0, T2 b1, T3 b0, T3 b1] (light) --
+// and the epilogue reduces them to the blocks' partial moments (lc::epi_series_block) instead of storing them: the two
+// waves that share a column panel swap halves through the (then idle) LDS ring, so that each holds all four terms of
+// ONE 32-column block for both validation blocks.
+template <bool SCORE, bool STAMP, bool LIGHTCAP = false, bool SERMOM = false>
 __global__ void __launch_bounds__(512, 2)
 k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT, int Mtiles, Score16Args sa,
               Plain16Args pa, BView bv) {
@@ -213,8 +218,9 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 #define BKT(kt_) ((kt_) + ((kt_) >= bv.cut ? bv.skip : 0))
     // "light" slabs (plain mode): rows whose product only needs fp16 accuracy (11-bit operands) -- the higher
     // terms of a series, which enter the caller's result scaled down by >= 2^-11 -- take the hi*hi MFMA alone
-    const bool light = LIGHTCAP && !SCORE && pa.slab_light != nullptr &&
-                       __builtin_amdgcn_readfirstlane((int)pa.slab_light[((long long)grp * Mtiles + mt) * 2 + wm]) != 0;
+    const bool light = SERMOM ? wm != 0
+                              : (LIGHTCAP && !SCORE && pa.slab_light != nullptr &&
+                                 __builtin_amdgcn_readfirstlane((int)pa.slab_light[((long long)grp * Mtiles + mt) * 2 + wm]) != 0);
 
     // ---- main loop: software-pipelined fragments, ONE block barrier per K-tile ----------------------------
     // Every wave keeps two register sets of fragments: while the 24 MFMAs of K-tile j run on one set, the 12
@@ -272,6 +278,11 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     const bool cok[2] = {col0 < V, col0 + 32 < V};
     const long long colc[2] = {cok[0] ? col0 : 0, cok[1] ? col0 + 32 : 0};       // clamped: loads stay in range
     float ymv[2] = {0.f, 0.f}, cscv[2] = {0.f, 0.f};
+    if (SERMOM) {                                    // this wave's column block after the swap: ni = wm
+        if (tid < TM) lds_rs[tid] = pa.rs_inv[((long long)grp * Mtiles + mt) * TM + tid];
+        ymv[0] = sa.ymean[colc[wm]];
+        cscv[0] = pa.cs_inv[(long long)nt * TN + wn * 64 + wm * 32 + li];
+    }
     if (SCORE) {
         if (tid < TM) lds_rs[tid] = sa.rs_inv[mt * TM + tid];                      // rs_inv has rows_pad entries
 #pragma unroll
@@ -433,6 +444,67 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     }
     unsigned long long te0 = 0, te1 = 0, te2 = 0, te3 = 0;
     STAMP_T(te0);
+
+    if (SERMOM) {
+        // ---- series-moments epilogue
+        const long long colm = colc[wm];
+        const int blk0 = 2 * mt;
+        lc::EpiTargets tg[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if ((blk0 + b) * 32 < sa.M) lc::epi_load_targets(sa.yv, V, (blk0 + b) * 32, lh, colm, tg[b]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PHASE_BARRIER();                             // every wave is done with the ring: it becomes the swap buffer
+        lc::ep_f32x4* xch = reinterpret_cast<lc::ep_f32x4*>(lds16);
+        {
+            lc::ep_f32x4* dst = xch + (wn * 2 + wm) * 16 * 64 + lane;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const lc::ep_f32x4 rs = *reinterpret_cast<const lc::ep_f32x4*>(lds_rs + wm * 128 + mi * 32 + 8 * q + 4 * lh);
+                    lc::ep_f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (wm ? acc[mi][0][4 * q + j] : acc[mi][1][4 * q + j]) * rs[j];
+                    dst[(mi * 4 + q) * 64] = v;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PHASE_BARRIER();
+        const lc::ep_f32x4* src = xch + (wn * 2 + (1 - wm)) * 16 * 64 + lane;
+        const float cs = cscv[0], ym = ymv[0];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int i0 = (blk0 + b) * 32;
+            if (i0 >= sa.n_val) continue;
+            float own[2][16], oth[2][16];            // [term of the pair][row]
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mi = 2 * h + b;
+                    const lc::ep_f32x4 rs = *reinterpret_cast<const lc::ep_f32x4*>(lds_rs + wm * 128 + mi * 32 + 8 * q + 4 * lh);
+                    const lc::ep_f32x4 o = src[(mi * 4 + q) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        own[h][4 * q + j] = (wm ? acc[mi][1][4 * q + j] : acc[mi][0][4 * q + j]) * rs[j] * cs;
+                        oth[h][4 * q + j] = o[j] * cs;
+                    }
+                }
+            float T[4][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                T[0][r] = wm ? oth[0][r] : own[0][r];
+                T[1][r] = wm ? oth[1][r] : own[1][r];
+                T[2][r] = wm ? own[0][r] : oth[0][r];
+                T[3][r] = wm ? own[1][r] : oth[1][r];
+            }
+            float* dstp = sa.part + (long long)(blk0 + b) * lc::EPI_SERIES_PARTS * V + colm;
+            if (i0 + 32 <= sa.n_val) lc::epi_series_block<false>(T, tg[b], ym, i0, sa.n_val, lh, dstp, V, cok[wm]);
+            else lc::epi_series_block<true>(T, tg[b], ym, i0, sa.n_val, lh, dstp, V, cok[wm]);
+        }
+        return;
+    }
 
     if (!SCORE) {
         // ---- plain epilogue: undo the power-of-two scales and store
@@ -638,6 +710,52 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
         hipLaunchKernelGGL((k_sweep_f16x3<false, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
                            (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa, bv);
     return lc::launched("k_sweep_f16x3<plain>");
+}
+
+// defined in lc_gemm.hip
+int lc_series_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int M, int n_val,
+                              long long V, const double* d_coef, const int* d_aidx, int S, float* d_scores,
+                              int accumulate, hipStream_t s);
+
+extern "C" int lc_series_sweep_scores_f16x3(const void* d_pt, const float* d_rowscale_inv, int M, int n_val, int64_t K,
+                                            const void* d_yt, const float* d_cscale_inv, int64_t Ncols,
+                                            const float* d_yv, int64_t V, const float* d_ystat, const float* d_yblk,
+                                            const double* d_coef, const int32_t* d_aidx, int S, float* d_part,
+                                            float* d_scores, int accumulate, int64_t b_rows, int64_t b_gap_begin,
+                                            int64_t b_gap_rows, lc_stream_t stream) {
+    LC_REQUIRE(d_pt && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_coef && d_aidx &&
+                   d_part && d_scores, LC_E_BADARG, "lc_series_sweep_scores_f16x3: null pointer");
+    LC_REQUIRE(M > 0 && M % LC_MB == 0 && n_val > 1 && n_val <= M && K > 0 && K % (2 * TK) == 0 && S > 0, LC_E_SHAPE,
+               "lc_series_sweep_scores_f16x3: need M %% %d == 0, 1 < n_val <= M, K %% %d == 0", LC_MB, 2 * TK);
+    LC_REQUIRE(V > 0 && V % 128 == 0 && Ncols >= V && Ncols % TN == 0, LC_E_SHAPE,
+               "lc_series_sweep_scores_f16x3: V must be a multiple of 128, Ncols >= V a multiple of %d", TN);
+    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true, true>), LDS16_BYTES))
+        return rc;
+    hipStream_t s = lc::as_stream(stream);
+    BView bv;
+    if (int rc = make_bview("lc_series_sweep_scores_f16x3", K, b_rows, b_gap_begin, b_gap_rows, &bv)) return rc;
+    const int nblk = M / LC_MB;
+    const int Mtiles = (nblk + 1) / 2;                     // two 32-row validation blocks x four terms per tile
+    const long long Ntiles = Ncols / TN;
+    LC_REQUIRE((long long)Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_series_sweep_scores_f16x3: grid too large");
+    // per 128-row slab: wave row 0 = terms 0, 1 (three MFMAs per product), wave row 1 = terms 2, 3 (hi * hi only)
+    Score16Args sa{d_yv, d_ystat, nullptr, nullptr, d_part, (long long)V, M, n_val, LC_SCORE_CORR, Mtiles * TM};
+    Plain16Args pa{};
+    pa.rs_inv = d_rowscale_inv;
+    pa.cs_inv = d_cscale_inv;
+    pa.Mrows = Mtiles * TM;
+    pa.G = 1;
+    pa.start[0] = 0;
+    pa.start[1] = (int)Ntiles;
+    pa.slab_light = nullptr;
+    {
+        lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
+        hipLaunchKernelGGL((k_sweep_f16x3<false, false, true, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512),
+                           LDS16_BYTES, s, (const uint4*)d_pt, (const uint4*)d_yt, (int)(K / TK), Mtiles, sa, pa, bv);
+    }
+    if (int rc = lc::launched("k_sweep_f16x3<series moments>")) return rc;
+    return lc_series_finalize_launch(d_part, d_ystat, d_yblk, M, n_val, (long long)V, d_coef, d_aidx, S, d_scores,
+                                     accumulate, s);
 }
 
 // Diagnostics: the score kernel with s_memtime stamps (not part of the product path; see tools/gpu_kernel_bench.py).

@@ -45,6 +45,7 @@ SERIES_TOL = 2e-9                   # ... used when its worst relative error ove
 SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singcutoff enters a prediction with weight
                                     # S^2 / (S^2 + a^2) <= (singcutoff / a)^2: below 1e-6 it is invisible in fp32
 PRIMAL_MAX_SCALE_RATIO = 64.0       # ... and whose feature column norms lie within this factor of each other (fp16x3)
+SERIES_FUSED_MOMENTS = True         # series terms reduced to moments in the contraction's epilogue (never stored)
 PRIMAL_MOMENTS_MAX_P = 16           # ... and, up to this many features, scored from block products X'Y alone (_prepare_moments)
 PRIMAL_MAX_P = 512                  # the primal (p x p) form is taken for tall designs up to this many features
 MAX_ALPHAS = 64                     # lc_group_by_alpha / the grouped GEMMs carry at most 64 alpha groups per launch
@@ -392,7 +393,19 @@ class RidgeCVEngine:
         enter a prediction scaled by rho^2 <= 2.7e-4 relative to term 0 and only need fp16 operands) inside the
         256-row tiles, so that the two waves of a SIMD together issue 32 instead of 48 MFMAs per K-tile.
         Returns (rows, rowmap (terms*M,) int32 device, slab_light uint8 device)."""
-        key = ("series_layout", M)
+        key = ("series_layout", M, SERIES_FUSED_MOMENTS)
+        if getattr(self, "_layout_key", None) != key and SERIES_FUSED_MOMENTS and SERIES_TERMS == 4:
+            # the moments epilogue (lc_series_sweep_scores_f16x3): every 256-row tile holds all four terms of two
+            # 32-row validation blocks -- wave row 0: [T0 b0, T0 b1, T1 b0, T1 b1], wave row 1: the same of T2, T3
+            nblk = M // LC_MB
+            rows = 256 * ((nblk + 1) // 2)
+            rowmap = np.empty(SERIES_TERMS * M, dtype=np.int32)
+            i = np.arange(M)
+            b = i // LC_MB
+            for j in range(SERIES_TERMS):
+                rowmap[j * M:(j + 1) * M] = 256 * (b // 2) + 128 * (j >> 1) + 32 * (2 * (j & 1) + (b & 1)) + i % LC_MB
+            self._layout = (rows, ops.upload(rowmap, self.dev), None)
+            self._layout_key = key
         if getattr(self, "_layout_key", None) != key:
             per = (M + 127) // 128
             heavy = [(j, s) for j in range(min(2, SERIES_TERMS)) for s in range(per)]
@@ -589,9 +602,13 @@ class RidgeCVEngine:
         if moments:
             # ---- pass 1: validation statistics, operand split, series contraction + moment kernel
             Tm, rowmap, slab_light = self._series_layout(M)
+            fused = slab_light is None                   # layout of the moments epilogue: the terms are never stored
             Pt = torch.empty(ops.pad_to(Tm, 256) * N * 2, dtype=torch.float16, device=self.dev)
             rs_p = torch.empty(ops.pad_to(Tm, 256), dtype=torch.float32, device=self.dev)
-            Tbuf = torch.empty((Tm, Vt), dtype=torch.float32, device=self.dev)
+            if fused:
+                part_s = torch.empty((M // LC_MB, 18, self.Vp), dtype=torch.float32, device=self.dev)
+            else:
+                Tbuf = torch.empty((Tm, Vt), dtype=torch.float32, device=self.dev)
             cs_inv = self._cs_inv_padded(cs, Vt)                               # padded to the plain GEMM's tiles
             if hat.get("series_ready") is not None:
                 main.wait_event(hat["series_ready"])
@@ -603,10 +620,15 @@ class RidgeCVEngine:
                 if shared is None:
                     ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[f])
                 ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
-                ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
-                                       bview=views[f])
                 self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
                 self.info["plain_launches"] += 1
+                if fused:
+                    ops.series_sweep_scores_f16x3(Pt, rs_p, M, n_v[f], N, Yt[f], cs_inv, Vt, yv[f], self.Vp, ystat[f], yblk[f],
+                                                  self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0,
+                                                  bview=views[f])
+                    continue
+                ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
+                                       bview=views[f])
                 ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv[f], ystat[f], self.d_coef, hat["d_ser"],
                                   scores, accumulate=f > 0, rowmap=rowmap)
         if done is not None:

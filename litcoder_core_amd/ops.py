@@ -570,6 +570,14 @@ def gemm_grouped_f16x3(at, rowscale_inv, Mrows, bt, cscale_inv, c, ldc, Ncols, K
               arr, G, _p(slab_light), *bview, _s())
 
 
+def series_sweep_scores_f16x3(pt, rowscale_inv, M, n_val, K, yt, cscale_inv, Ncols, yv, V, ystat, yblk, coef, aidx, part,
+                              scores, accumulate, bview=(0, 0, 0)):
+    """Series contraction with the moments epilogue + the scores of the series alphas (lc_series_sweep_scores_f16x3)."""
+    _lib.call("lc_series_sweep_scores_f16x3", _p(pt), _p(rowscale_inv), M, n_val, K, _p(yt), _p(cscale_inv), Ncols, _p(yv),
+              V, _p(ystat), _p(yblk), _p(coef), _p(aidx), aidx.numel(), _p(part), _p(scores), int(bool(accumulate)), *bview,
+              _s())
+
+
 def select_alpha(scores, A, V, want_best=True, want_rowsum=False):
     best = torch.empty(V, dtype=torch.int32, device=scores.device) if want_best else None
     rowsum = torch.empty(A, dtype=torch.float64, device=scores.device) if want_rowsum else None

@@ -340,7 +340,16 @@ def test_series_moments_match_per_alpha_hat_matrices(lc):
         inner = [(np.r_[0:a], np.r_[a:b]), (np.r_[0:a - 37, b:T], np.r_[a - 37:b])]
         eng = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
         assert eng.ser and eng.cho, "grid must straddle the series threshold"
+        import litcoder_core_amd.nested_cv as ncv
+        assert ncv.SERIES_FUSED_MOMENTS                    # default: the terms are reduced in the contraction's epilogue
         s_mom, info = eng._alpha_scores(eng.K, eng.dY, inner)
+        try:                                                # the same with the terms stored and lc_series_scores
+            ncv.SERIES_FUSED_MOMENTS = False
+            s_sto, _ = eng._alpha_scores(eng.K, eng.dY, inner)
+        finally:
+            ncv.SERIES_FUSED_MOMENTS = True
+        np.testing.assert_array_equal(s_mom[eng.cho].cpu().numpy(), s_sto[eng.cho].cpu().numpy())
+        np.testing.assert_allclose(s_mom[eng.ser, :V].cpu().numpy(), s_sto[eng.ser, :V].cpu().numpy(), rtol=0, atol=2e-6)
         eng._series_by_moments = lambda Y_: False
         s_hat, info2 = eng._alpha_scores(eng.K, eng.dY, inner)
         assert not int(info.cpu().numpy().any()) and not int(info2.cpu().numpy().any())
