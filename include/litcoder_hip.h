@@ -254,6 +254,15 @@ int lc_primal_refit(const double* d_part, int RS, int chunk, const int32_t* d_nr
 int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
                         const int32_t* d_slot, int32_t* d_info, lc_stream_t stream);
 
+/* The explicit inverse of the same top blocks: d_aug (B, 2N, N) f64 with the N x N IDENTITY as bottom block (the
+ * caller assembles it like any other right-hand side); d_p (B, N, N) f32 <- (top)^-1.  Same kernels; the rows of
+ * I L^-T L^-1 are independent, row tile r is zero left of block column r after the first pass and only needed from block
+ * column r on after the second (symmetry), so both passes skip the other tiles: N^3 flops in all instead of
+ * N^3/3 + 2 N^3.  The refit applies  [Xtr' ; K[te,tr]] (K + a^2 I)^-1  (ridge_regression.py:56-61, nested_cv.py:151) as a
+ * product with this inverse on the fp16x3 MFMA where its accuracy allows. */
+int lc_batch_chol_inverse(double* d_aug, int B, int N, double* d_linv, float* d_p, const int32_t* d_slot,
+                          int32_t* d_info, lc_stream_t stream);
+
 /* Tuning hook of lc_batch_chol_solve: columns per outer block of its two-level blocking (a multiple of LC_NB;
  * default 512).  columns <= 0 only queries.  Returns the value in force (>= LC_NB), or a negative error code. */
 int lc_chol_outer_block(int columns);

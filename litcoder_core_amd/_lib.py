@@ -72,6 +72,7 @@ SIGNATURES = {
     "lc_debug_chol_fused_steps": (c_int, [c_int]),
     "lc_debug_chol_left_deep": (c_int, [c_int]),
     "lc_batch_chol_solve": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "lc_batch_chol_inverse": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_batch_series_hat": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int, c_int, c_int,
                                     _ptr, _ptr, _ptr]),
     "lc_batch_series_terms": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, c_int, _ptr, _ptr, _ptr, c_int,

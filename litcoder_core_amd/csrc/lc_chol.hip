@@ -744,6 +744,17 @@ __global__ void __launch_bounds__(256) k_extract_h(const double* __restrict__ au
     for (int j = threadIdx.x; j < N; j += 256) dst[j] = (float)src[j];
 }
 
+// inverse mode: the bottom block holds the inverse's block-upper triangle (row tile <= column tile); mirror the rest
+__global__ void __launch_bounds__(256) k_extract_sym(const double* __restrict__ aug, int N, float* __restrict__ h,
+                                                     const int* __restrict__ slot) {
+    const int i = blockIdx.x, b = blockIdx.y;
+    const double* bot = aug + ((long long)b * 2 * N + N) * N;
+    float* dst = h + ((long long)(slot ? slot[b] : b) * N + i) * N;
+    const int bi = i / NB;
+    for (int j = threadIdx.x; j < N; j += 256)
+        dst[j] = (float)(j / NB >= bi ? bot[(long long)i * N + j] : bot[(long long)j * N + i]);
+}
+
 }  // namespace
 
 static int g_chol_outer = 512;   // columns per outer block (multiple of NB)
@@ -773,8 +784,25 @@ extern "C" int lc_debug_chol_big_kernel(int which) {
     return g_big_kernel;
 }
 
+// inverse: the bottom block is the N x N identity and only the block-upper triangle of  I (top)^-1  is formed -- the
+// rows of the product are independent, row tile r of Z = I L^-T is zero left of block column r, and row tile r of the
+// result is only needed from block column r on (the rest by symmetry): in every step the bottom row tiles beyond the
+// current block column are skipped, N^3 / 3 flops per pass instead of N^3.
+static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,
+                           int32_t* d_info, lc_stream_t stream, bool inverse);
+
 extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
                                    const int32_t* d_slot, int32_t* d_info, lc_stream_t stream) {
+    return chol_solve_impl(d_aug, B, N, M, d_linv, d_h, d_slot, d_info, stream, false);
+}
+
+extern "C" int lc_batch_chol_inverse(double* d_aug, int B, int N, double* d_linv, float* d_p, const int32_t* d_slot,
+                                     int32_t* d_info, lc_stream_t stream) {
+    return chol_solve_impl(d_aug, B, N, N, d_linv, d_p, d_slot, d_info, stream, true);
+}
+
+static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,
+                           int32_t* d_info, lc_stream_t stream, bool inverse) {
     LC_REQUIRE(d_aug && d_linv && d_h && d_info, LC_E_BADARG, "lc_batch_chol_solve: null pointer");
     LC_REQUIRE(B > 0 && B <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
                "lc_batch_chol_solve: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
@@ -787,12 +815,14 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
     const int R = N + M;
     const int ob = g_chol_outer / NB;                        // NB-steps per outer block
     const long long sys = (long long)R * N;
+    const bool fused = g_chol_fused || inverse;              // the triangular limits exist for the default kernels only
+    const bool left_deep = g_chol_left_deep && !inverse;
     MMArgs g{};
     g.c_sys = g.a_sys = g.b_sys = sys;
     g.lda = g.ldb = g.ldc = N;
     for (int K0 = 0; K0 < nb; K0 += ob) {
         const int K1 = min(K0 + ob, nb);
-        if (g_chol_left_deep && K0 > 0) {
+        if (left_deep && K0 > 0) {
             // block column [K0, K1) takes the contributions of ALL earlier block columns in one product of depth 64 K0:
             // every C tile is read and written once per factorisation instead of once per outer block to its left
             const int c0 = K0 * NB;
@@ -808,8 +838,9 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
         for (int k = K0; k < K1; ++k) {
             hipLaunchKernelGGL(k_potrf_diag, dim3(B), dim3(256), 0, s, d_aug, N, M, k, d_linv, d_info);
             const int below = (k + 1) * NB;                  // first row under the diagonal tile
-            if (g_chol_fused) {
-                const int tiles = lc::ceil_div(R - below, NB);
+            if (fused) {
+                // inverse: bottom row tiles 0 .. k only (tile r is zero left of block column r)
+                const int tiles = inverse ? (nb - k - 1) + min(M / NB, k + 1) : lc::ceil_div(R - below, NB);
                 if (tiles > 0)
                     hipLaunchKernelGGL(k_lstep, dim3((unsigned)tiles, (unsigned)B), dim3(256), 0, s, d_aug, N, M, k, K0, K1,
                                        d_linv);
@@ -831,14 +862,15 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
             g.col0 = below; g.tri = 1; g.subtract = 1;
             launch_mm<2, true>(g, B, s);
         }
-        if (g_chol_left_deep) continue;
+        if (left_deep) continue;
         // everything right of the outer block, once, at the block's full depth
         const int c1 = K1 * NB;
         g.a = g.b = d_aug + (long long)c1 * N + K0 * NB;
         g.a_sys = g.b_sys = g.c_sys = sys;
         g.ldb = N;
         g.c = d_aug + (long long)c1 * N + c1;
-        g.rows = R - c1; g.cols = N - c1; g.depth = (K1 - K0) * NB;
+        g.rows = inverse ? (N - c1) + min(M, c1) : R - c1;   // inverse: bottom rows beyond c1 are still zero in this block
+        g.cols = N - c1; g.depth = (K1 - K0) * NB;
         g.row0 = g.col0 = c1; g.tri = 1; g.subtract = 1;
         launch_big<true>(g, B, s);
     }
@@ -847,7 +879,7 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
     const int last_full = ((nb - 1) / ob) * ob;
     for (int K0 = last_full; K0 >= 0; K0 -= ob) {
         const int K1 = min(K0 + ob, nb);
-        if (g_chol_left_deep && K1 < nb) {
+        if (left_deep && K1 < nb) {
             // Z[:, K0 .. K1) -= H[:, K1 .. nb) L[K1 .. nb rows, K0 .. K1 cols]: all finished block columns to the right at once
             g.a = d_aug + (long long)N * N + K1 * NB;
             g.b = d_aug + (long long)K1 * NB * N + K0 * NB;
@@ -859,9 +891,10 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
             launch_big<false>(g, B, s);
         }
         for (int k = K1 - 1; k >= K0; --k) {
-            if (g_chol_fused) {
-                hipLaunchKernelGGL(k_bstep, dim3((unsigned)lc::ceil_div(M, NB), (unsigned)B), dim3(256), 0, s, d_aug, N, M,
-                                   k, K1, d_linv);
+            if (fused) {
+                // inverse: only row tiles 0 .. k of block column k (the block-upper triangle)
+                const int rt = inverse ? min(M / NB, k + 1) : lc::ceil_div(M, NB);
+                hipLaunchKernelGGL(k_bstep, dim3((unsigned)rt, (unsigned)B), dim3(256), 0, s, d_aug, N, M, k, K1, d_linv);
                 continue;
             }
             g.a = g.c = d_aug + (long long)N * N + k * NB;
@@ -879,17 +912,19 @@ extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d
             g.subtract = 1;
             launch_mm<2, false>(g, B, s);
         }
-        if (g_chol_left_deep) continue;
+        if (left_deep) continue;
         g.a = d_aug + (long long)N * N + K0 * NB;
         g.b = d_aug + (long long)K0 * NB * N;
         g.c = d_aug + (long long)N * N;
         g.a_sys = g.b_sys = g.c_sys = sys;
         g.ldb = N;
-        g.rows = M; g.cols = K0 * NB; g.depth = (K1 - K0) * NB;
+        g.rows = inverse ? min(M, K0 * NB) : M;              // inverse: block columns < K0 need row tiles < K0 only
+        g.cols = K0 * NB; g.depth = (K1 - K0) * NB;
         g.tri = 0; g.subtract = 1;
         launch_big<false>(g, B, s);
     }
     if (int rc = lc::launched("back substitution")) return rc;
-    hipLaunchKernelGGL(k_extract_h, dim3(M, B), dim3(256), 0, s, d_aug, N, M, d_h, d_slot);
+    if (inverse) hipLaunchKernelGGL(k_extract_sym, dim3(N, B), dim3(256), 0, s, d_aug, N, d_h, d_slot);
+    else hipLaunchKernelGGL(k_extract_h, dim3(M, B), dim3(256), 0, s, d_aug, N, M, d_h, d_slot);
     return lc::launched("k_extract_h");
 }

@@ -179,6 +179,7 @@ struct Plain16Args {
     int G;
     int start[MAX_GROUPS16 + 1];   // first 256-column tile of each group; start[G] = number of column tiles
     const unsigned char* slab_light;   // optional, per 128-row slab (G * Mtiles * 2): nonzero = hi*hi term only
+    long long col_limit;   // columns >= col_limit are not stored (ldc may then be smaller than the padded column count)
 };
 
 #define MFMA16(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
@@ -521,10 +522,11 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const float csc = pa.cs_inv[(long long)nt * TN + colw + ni * 32];
+                const bool col_ok = (long long)nt * TN + colw + ni * 32 < pa.col_limit;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < pa.Mrows) cbase[(long long)row * rstride + colw + ni * 32] = acc[mi][ni][r] * rsc[r] * csc;
+                    if (row < pa.Mrows && col_ok) cbase[(long long)row * rstride + colw + ni * 32] = acc[mi][ni][r] * rsc[r] * csc;
                 }
             }
         }
@@ -675,8 +677,9 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     LC_REQUIRE(d_at && d_rowscale_inv && d_bt && d_cscale_inv && d_c && h_group_tiles, LC_E_BADARG,
                "lc_gemm_grouped_f16x3: null pointer");
     LC_REQUIRE(G >= 1 && G <= MAX_GROUPS16, LC_E_SHAPE, "lc_gemm_grouped_f16x3: G must be in 1..%d", MAX_GROUPS16);
-    LC_REQUIRE(Mrows > 0 && K > 0 && K % (2 * TK) == 0 && Ncols > 0 && Ncols % TN == 0 && ldc >= Ncols, LC_E_SHAPE,
-               "lc_gemm_grouped_f16x3: need K %% %d == 0 and Ncols %% %d == 0", 2 * TK, TN);
+    // ldc < Ncols: only the first ldc columns are stored (an output whose width is not a multiple of the column tile)
+    LC_REQUIRE(Mrows > 0 && K > 0 && K % (2 * TK) == 0 && Ncols > 0 && Ncols % TN == 0 && ldc > Ncols - TN, LC_E_SHAPE,
+               "lc_gemm_grouped_f16x3: need K %% %d == 0, Ncols %% %d == 0, ldc > Ncols - %d", 2 * TK, TN, TN);
     if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<false, false>), LDS16_BYTES)) return rc;
     if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true>), LDS16_BYTES))
         return rc;
@@ -692,6 +695,7 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     pa.Mrows = (int)Mrows;
     pa.G = G;
     pa.slab_light = d_slab_light;
+    pa.col_limit = ldc < Ncols ? ldc : Ncols;
     for (int g = 0; g <= G; ++g) {
         pa.start[g] = h_group_tiles[g];
         LC_REQUIRE(g == 0 ? pa.start[0] == 0 : pa.start[g] >= pa.start[g - 1], LC_E_SHAPE,

@@ -24,6 +24,8 @@ Every device operation is a call into liblitcoder_hip.so (``ops.py``); there is 
 import logging
 from typing import Any, Dict, List, Optional, Tuple, Union
 
+import os
+
 import numpy as np
 import torch
 
@@ -45,6 +47,8 @@ SERIES_TOL = 2e-9                   # ... used when its worst relative error ove
 SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singcutoff enters a prediction with weight
                                     # S^2 / (S^2 + a^2) <= (singcutoff / a)^2: below 1e-6 it is invisible in fp32
 PRIMAL_MAX_SCALE_RATIO = 64.0       # ... and whose feature column norms lie within this factor of each other (fp16x3)
+REFIT_BY_INVERSE = True             # refit operators through the explicit inverse + one fp16x3 product (_refit_by_inverse)
+REFIT_INVERSE_MIN_ALPHA = 0.05      # ... for alphas (in units of S[0]) from here on
 SERIES_FUSED_MOMENTS = True         # series terms reduced to moments in the contraction's epilogue (never stored)
 PRIMAL_MOMENTS_MAX_P = 16           # ... and, up to this many features, scored from block products X'Y alone (_prepare_moments)
 PRIMAL_MAX_P = 512                  # the primal (p x p) form is taken for tall designs up to this many features
@@ -333,14 +337,15 @@ class RidgeCVEngine:
             o += p.numel()
         return out
 
-    def _cs_inv_padded(self, cs, Vt):
+    def _cs_inv_padded(self, cs, Vt, V=None):
         """The 2^e column scales padded to the plain GEMM's 256-column tiles (padding columns are never read back)."""
+        V = self.Vp if V is None else V
         out = ops.zeros(Vt, torch.float32, self.dev)
-        out[: self.Vp].copy_(cs[self.Vp:])
+        out[:V].copy_(cs[V:])
         return out
 
     # -------------------------------------------------------------- V-independent fp64 systems, dealt out over ranks
-    def _sharded_solve(self, n_jobs, N, M, assemble, out=None, slot=None, lane="hat"):
+    def _sharded_solve(self, n_jobs, N, M, assemble, out=None, slot=None, lane="hat", inverse=False):
         """``n_jobs`` independent augmented systems (same list, same order on every rank): rank r factors jobs
         [r n_per, (r + 1) n_per), n_per = ceil(n_jobs / world), and the f32 results are all-gathered -- on return
         ``H`` (>= n_jobs, M, N) is complete on every rank, job j in slot j.  ``assemble(jobs)`` builds the
@@ -355,7 +360,10 @@ class RidgeCVEngine:
         H = out if direct else torch.empty((n_per, M, N), dtype=torch.float32, device=self.dev)
         if mine:
             aug = assemble(mine)
-            info = ops.batch_chol_solve(aug, len(mine), N, M, H, slot if direct else None)
+            if inverse:                                 # bottom block = identity, M == N: the explicit inverse
+                info = ops.batch_chol_inverse(aug, len(mine), N, H, slot if direct else None)
+            else:
+                info = ops.batch_chol_solve(aug, len(mine), N, M, H, slot if direct else None)
             del aug
         else:
             info = ops.zeros(1, torch.int32, self.dev)
@@ -741,6 +749,17 @@ class RidgeCVEngine:
         and all-gathered; every rank must be called with the same ``alphas_idx``."""
         Gc, (rows, N_o) = len(alphas_idx), rhs.shape
         a2_o = ops.penalties(lmax_o, 1, self.d_alphas, self.normalpha)              # (A,): grid F = 1
+        if self._refit_by_inverse(alphas_idx):
+            eye = self._identity_rows(N_o)
+
+            def assemble_inv(jobs):
+                aug = torch.empty((len(jobs), 2 * N_o, N_o), dtype=torch.float64, device=self.dev)
+                sysv = ops.upload(np.asarray([alphas_idx[j] for j in jobs], dtype=np.int32), self.dev)
+                ops.batch_assemble_sel(K, tr_o, None, eye, a2_o, sysv, len(jobs), self.A, N_o, N_o, aug)
+                return aug
+
+            Pj, info = self._sharded_solve(Gc, N_o, N_o, assemble_inv, lane="refit", inverse=True)
+            return self._apply_inverses(rhs, Pj[:Gc]), info
         S = 1
         while 2 * S * Gc <= self.shard.world and rows % (2 * S * LC_MB) == 0:
             S *= 2
@@ -764,6 +783,47 @@ class RidgeCVEngine:
 
         Hj, info = self._sharded_solve(Gc * S, N_o, rs, assemble if S > 1 else assemble_whole, lane="refit")
         return Hj[: Gc * S].view(Gc, rows, N_o), info
+
+    def _refit_by_inverse(self, alphas_idx):
+        """The refit operator  R (K + a^2 I)^-1,  R = [Xtr' ; K[te,tr]]  (3072 + 600 rows at cfg2), through the explicit
+        inverse (N^3 fp64 flops, lc_batch_chol_inverse) and ONE product R P on the fp16x3 MFMA instead of triangular
+        solves with every row of R (N^3/3 + 2 N^2 rows: 3.4x the fp64 work).  The operator goes through 22-bit fp16
+        triples afterwards anyway (the V-wide contraction), but in the product R P the entries of P ~ 1/a^2 cancel
+        down to ~ 1/(2 a S0): the relative error is ~ 2^-22 x 2 S0 / a = 2^-21 / alpha for alpha S[0] scaling -- taken
+        for alpha >= 0.05 (< 1e-5), on the fp16x3 path, with normalpha (S[0] known); the solves otherwise."""
+        return (REFIT_BY_INVERSE and self.normalpha and not self.primal and self.precision != "f32"
+                and len(alphas_idx) > 0 and min(self.alphas[a] for a in alphas_idx) >= REFIT_INVERSE_MIN_ALPHA)
+
+    def _identity_rows(self, N_o):
+        if getattr(self, "_eye_key", None) != N_o:
+            idx = ops.upload((-(2 + np.arange(N_o))).astype(np.int32).reshape(1, N_o), self.dev)
+            self._eye = ops.gather_rows_f64(self.dX, idx, 1, N_o, 1, N_o)[0]       # (N_o, N_o) f64 identity (unit rows only)
+            self._eye_key = N_o
+        return self._eye
+
+    def _apply_inverses(self, rhs, P):
+        """(G, rows, N_o) f32 = rhs . P[g] for the (G, N_o, N_o) f32 inverses, on the fp16x3 MFMA (plain contraction:
+        A = the rows of rhs as fp16 triples, B = P with per-column power-of-two scales)."""
+        G, (rows, N_o) = P.shape[0], rhs.shape
+        R = ops.scale_cast_f64_f32(rhs, self._one(), torch.empty(rhs.shape, dtype=torch.float32, device=self.dev))
+        rows_pad, Nc = ops.pad_to(rows, 256), ops.pad_to(N_o, 256)
+        At = torch.empty(rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
+        rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
+        ops.split_rows_f16(R, rows, N_o, At, rs_inv)
+        Bt = torch.empty(Nc * N_o * 2, dtype=torch.float16, device=self.dev)
+        cs_inv = torch.empty(Nc, dtype=torch.float32, device=self.dev)
+        out = torch.empty((G, rows, N_o), dtype=torch.float32, device=self.dev)
+        for g in range(G):
+            # P is symmetric: column n of the B operand is row n of P, and the tiled images of the two operands have the
+            # same layout -- the row split (coalesced reads, per-row power-of-two scales) IS the column split
+            ops.split_rows_f16(P[g], N_o, N_o, Bt, cs_inv)
+            ops.gemm_grouped_f16x3(At, rs_inv, rows, Bt, cs_inv, out[g], N_o, Nc, N_o, [0, Nc // 256])
+        return out
+
+    def _one(self):
+        if getattr(self, "_d_one", None) is None:
+            self._d_one = ops.upload(np.ones(1, dtype=np.float64), self.dev)
+        return self._d_one
 
     def _refit_systems(self, X, K, tr_rows, used, tr_o=None, lmax_o=None, te_rows=(), spec=None, used_all=None):
         """Per alpha in use, the rows  [Xtr' ; K[te,tr]] (K[tr,tr] + a^2 I)^-1  as f32 (G, p_pad + pad32(n_te), N_o):
@@ -794,8 +854,14 @@ class RidgeCVEngine:
         need = [a for a in used_all if a not in on_series and a not in have]
         Malpha = torch.empty((G, rows, N_o), dtype=torch.float32, device=self.dev)
         flags = [spec["info"]] if have else []          # pivot flags: of every system solved for this fold
-        for a in chol:
-            if a in have:
+        ahead = [a for a in chol if a in have]
+        if ahead and spec.get("P") is not None:          # refit_ahead left the inverses: apply them to the rows now
+            Pa = spec["P"] if len(ahead) == len(have) and ahead == have else torch.stack([spec["P"][have.index(a)] for a in ahead])
+            Ma = self._apply_inverses(rhs, Pa)
+            for i, a in enumerate(ahead):
+                Malpha[used.index(a)].copy_(Ma[i])
+        else:
+            for a in ahead:
                 Malpha[used.index(a)].copy_(spec["M"][have.index(a)])
         if need:
             Mc, info_n = self._refit_chol(K, tr_o, lmax_o, rhs, need)
@@ -1291,11 +1357,34 @@ class RidgeCVEngine:
             if any(st["tr_o"].shape[-1] != N_o for st in sts) or any(r.shape[0] != rows for r in rhss):
                 return
             Gc, nF = len(cho), len(sts)
+            a2s = [ops.penalties(st["lmax_o"], 1, self.d_alphas, self.normalpha) for st in sts]
+            if self._refit_by_inverse(cho):
+                # one explicit inverse per (fold, alpha) -- N^3 flops each, no row slices -- all-gathered; a fold applies
+                # the inverses of the alphas its voxels chose to its rows on the MFMA (_refit_systems)
+                eye = self._identity_rows(N_o)
+
+                def assemble_inv(jobs):                # job = fold * Gc + alpha
+                    aug = torch.empty((len(jobs), 2 * N_o, N_o), dtype=torch.float64, device=self.dev)
+                    for k, j in enumerate(jobs):
+                        sysv = ops.upload(np.asarray([cho[j % Gc]], dtype=np.int32), self.dev)
+                        ops.batch_assemble_sel(sts[j // Gc]["K"], sts[j // Gc]["tr_o"], None, eye, a2s[j // Gc], sysv, 1,
+                                               self.A, N_o, N_o, aug[k:k + 1])
+                    return aug
+
+                Pj, info = self._sharded_solve(nF * Gc, N_o, N_o, assemble_inv, lane="refit", inverse=True)
+                Pall = Pj[: nF * Gc].view(nF, Gc, N_o, N_o)
+                ready = torch.cuda.Event()
+                ready.record()
+                for fo, st in enumerate(sts):
+                    st["spec"] = dict(alphas=list(cho), M=None, P=Pall[fo], info=info, rhs=rhss[fo], ready=ready)
+                    for t in (st.get("X"), st.get("K"), st.get("tr_o"), st.get("lmax_o")):
+                        if isinstance(t, torch.Tensor) and t.is_cuda:
+                            t.record_stream(rs_stream)
+                return
             S = 1
             while S * Gc * nF < self.shard.world and rows % (2 * S * LC_MB) == 0:
                 S *= 2
             rsz = rows // S
-            a2s = [ops.penalties(st["lmax_o"], 1, self.d_alphas, self.normalpha) for st in sts]
 
             def assemble(jobs):                        # job = (fold * Gc + alpha) * S + row slice
                 aug = torch.empty((len(jobs), N_o + rsz, N_o), dtype=torch.float64, device=self.dev)
@@ -1361,7 +1450,8 @@ class RidgeCVEngine:
             rs = self.aux3
             rs.wait_event(spec["ready"])
             rs.wait_event(st["done"])
-            for t in (st.get("X"), st.get("K"), st.get("tr_o"), st.get("lmax_o"), spec["M"], spec["rhs"], spec["info"]):
+            for t in (st.get("X"), st.get("K"), st.get("tr_o"), st.get("lmax_o"), spec["M"], spec.get("P"), spec["rhs"],
+                      spec["info"]):
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(rs)
         else:
@@ -1692,7 +1782,18 @@ class NestedCVModel(BasePredictivityModel):
                 # one GPU: the batch's series operands now, its Cholesky chains once fold 0's sweeps (just queued) are
                 # done -- same fit time, and fold 0's fused launches, the dominant kernel, run without 80 systems of fp64
                 # work beside them (1.66 -> 1.45 ms per launch over the fit)
-                prepared = eng.prepare_folds(outer[1:], lmax_pre[1:], chol_after=eng.chain_gate()) if n > 1 else []
+                ahead = os.environ.get("LITCODER_AMD_REFIT_AHEAD", "0")
+                plan = os.environ.get("LITCODER_AMD_PREP_PLAN", "1+rest")
+                cuts = {"all": [1, n], "1+rest": [1, 2, n], "per": list(range(1, n + 1)), "2+rest": [1, 3, n]}[plan]
+                prepared = []
+                for c0, c1 in zip(cuts[:-1], cuts[1:]):
+                    if c0 < min(c1, n):
+                        prepared += eng.prepare_folds(outer[c0:c1], lmax_pre[c0:c1], chol_after=eng.chain_gate())
+                if ahead == "1":
+                    eng.refit_ahead([first] + prepared)
+                elif ahead == "2":
+                    eng.refit_ahead([first])
+                    eng.refit_ahead(prepared)
             for i in range(n):
                 eng.fold_choose(st, single_alpha)               # main: argmax + grouping; the histogram leaves asynchronously
                 st_next = None

@@ -442,6 +442,14 @@ def batch_chol_solve(aug, B, N, M, h, slot=None):
     return info
 
 
+def batch_chol_inverse(aug, B, N, p, slot=None):
+    """aug: (B, 2N, N) f64 systems with the identity as bottom block; p (B, N, N) f32 <- inverse of the top blocks."""
+    linv = torch.empty((B, N // LC_NB, LC_NB, LC_NB), dtype=torch.float64, device=aug.device)
+    info = torch.empty(B, dtype=torch.int32, device=aug.device)
+    _lib.call("lc_batch_chol_inverse", _p(aug), B, N, _p(linv), _p(p), _p(slot), _p(info), _s())
+    return info
+
+
 def batch_series_hat(k, tr, va, F, N, M, scale, coef, aidx, A, terms, h):
     """coef: (S, terms) f64 polynomial coefficients of the S alphas (series.py); scale: (F) f64."""
     S = aidx.numel()

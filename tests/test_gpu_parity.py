@@ -317,6 +317,22 @@ def test_batch_chol_solve_against_fp64_solves(lc):
                 want = np.linalg.solve(aug[b, :N], aug[b, N:].T).T
                 err = np.abs(got[b] - want).max() / np.abs(want).max()
                 assert err < 3e-7, (B, N, M, ob, b, err)
+        # the explicit inverse: identity below, only the block-upper triangle formed (rows skipped per step), mirrored
+        for (B, N, ob) in ((2, 64, 256), (3, 320, 128), (2, 576, 256), (1, 1216, 512), (2, 832, 64)):
+            assert ops.chol_outer_block(ob) == ob
+            aug = np.empty((B, 2 * N, N))
+            for b in range(B):
+                x = rng.standard_normal((N, N + 8))
+                aug[b, :N] = x @ x.T / N + np.eye(N) * 10.0 ** (-b)
+                aug[b, N:] = np.eye(N)
+            P = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+            info = ops.batch_chol_inverse(torch.from_numpy(aug).to(dev), B, N, P)
+            assert not info.cpu().numpy().any()
+            got = P.cpu().numpy().astype(np.float64)
+            for b in range(B):
+                want = np.linalg.inv(aug[b, :N])
+                err = np.abs(got[b] - want).max() / np.abs(want).max()
+                assert err < 3e-7, ("inverse", B, N, ob, b, err)
         # a non-positive pivot is reported, not hidden
         bad = np.zeros((1, 64 + 32, 64)); bad[0, :64] = -np.eye(64)
         info = ops.batch_chol_solve(torch.from_numpy(bad).to(dev), 1, 64, 32,
