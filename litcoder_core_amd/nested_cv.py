@@ -1782,18 +1782,11 @@ class NestedCVModel(BasePredictivityModel):
                 # one GPU: the batch's series operands now, its Cholesky chains once fold 0's sweeps (just queued) are
                 # done -- same fit time, and fold 0's fused launches, the dominant kernel, run without 80 systems of fp64
                 # work beside them (1.66 -> 1.45 ms per launch over the fit)
-                ahead = os.environ.get("LITCODER_AMD_REFIT_AHEAD", "0")
-                plan = os.environ.get("LITCODER_AMD_PREP_PLAN", "1+rest")
-                cuts = {"all": [1, n], "1+rest": [1, 2, n], "per": list(range(1, n + 1)), "2+rest": [1, 3, n]}[plan]
-                prepared = []
-                for c0, c1 in zip(cuts[:-1], cuts[1:]):
-                    if c0 < min(c1, n):
-                        prepared += eng.prepare_folds(outer[c0:c1], lmax_pre[c0:c1], chol_after=eng.chain_gate())
-                if ahead == "1":
-                    eng.refit_ahead([first] + prepared)
-                elif ahead == "2":
-                    eng.refit_ahead([first])
-                    eng.refit_ahead(prepared)
+                # (fold 1 first / one batch per fold instead of one batch measured the same within the box-to-box spread,
+                # 145.8-147.6 ms: the fit is bound by the total work of the streams, not by which batch the main stream
+                # waits for; all refit inverses ahead in one batch, as with voxel shards, costs 4 ms here: work for
+                # alphas nobody chooses, beside the fused launches)
+                prepared = eng.prepare_folds(outer[1:], lmax_pre[1:], chol_after=eng.chain_gate()) if n > 1 else []
             for i in range(n):
                 eng.fold_choose(st, single_alpha)               # main: argmax + grouping; the histogram leaves asynchronously
                 st_next = None
