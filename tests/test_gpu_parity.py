@@ -434,6 +434,51 @@ def test_speculative_refit_systems_are_neutral(lc):
         assert m["correlations"] == m0["correlations"] and m["p_values"] == m0["p_values"], name
 
 
+def test_refit_operators_by_inverse_match_the_solves(lc):
+    """The refit operators  [Xtr' ; K[te,tr]] (K + a^2 I)^-1  through the explicit inverse and one fp16x3 product
+    (lc_batch_chol_inverse, RidgeCVEngine._refit_by_inverse) against the augmented fp64 solves they replace: relative
+    error within the stated bound 2^-21 / alpha (alpha in units of S[0]) plus the fp32 rounding of either route, down
+    to the smallest alpha the route is taken for; below it, raw alphas and the exact-f32 path keep the solves; whole
+    fits agree in alphas / scores / weights."""
+    from litcoder_core_amd import nested_cv as ncv
+    from litcoder_core_amd.nested_cv import RidgeCVEngine
+    rng = np.random.default_rng(5)
+    T, p, V = 700, 900, 96
+    X = rng.standard_normal((T, p)) * np.linspace(1.0, 0.05, p)
+    Y = X @ (rng.standard_normal((p, V)) * 0.05) + rng.standard_normal((T, V))
+    alphas = [0.02, 0.05, 0.1, 0.5, 2.0]
+    tr, te = np.r_[0:520], np.r_[520:700]
+    eng = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
+    assert not eng._refit_by_inverse([0, 1]) and eng._refit_by_inverse([1, 2, 3, 4])
+    assert not RidgeCVEngine(X, Y, alphas, False, True, False, False)._refit_by_inverse([2])       # raw alphas
+    assert not RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f32")._refit_by_inverse([2])
+    N_o = ncv.ops.pad_to(len(tr), ncv.LC_NB)
+    tr_o = ncv.ops.idx_tensor(tr, N_o, eng.dev).reshape(1, N_o)
+    lmax_o = ncv.ops.lambda_max(eng.K, tr_o, 1, N_o, eng.steps)
+    rhs = eng._refit_rhs(eng.dX, eng.K, tr, tr_o, te)
+    M_inv, info = eng._refit_chol(eng.K, tr_o, lmax_o, rhs, [1, 2, 3, 4])
+    try:
+        ncv.REFIT_BY_INVERSE = False
+        M_sol, info2 = eng._refit_chol(eng.K, tr_o, lmax_o, rhs, [1, 2, 3, 4])
+    finally:
+        ncv.REFIT_BY_INVERSE = True
+    assert not info.cpu().numpy().any() and not info2.cpu().numpy().any()
+    a, b = M_inv.cpu().numpy().astype(np.float64), M_sol.cpu().numpy().astype(np.float64)
+    for i, al in enumerate(alphas[1:]):
+        err = np.abs(a[i] - b[i]).max() / np.abs(b[i]).max()
+        assert err < 2.0 ** -21 / al + 1e-6, (al, err)       # + the floor of a depth-N product of 22-bit operands
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=alphas[1:], normalpha=True)
+    got = lc.NestedCVModel("r").fit_predict(X, Y, **kw)
+    try:
+        ncv.REFIT_BY_INVERSE = False
+        ref = lc.NestedCVModel("r").fit_predict(X, Y, **kw)
+    finally:
+        ncv.REFIT_BY_INVERSE = True
+    assert np.array_equal(got[2], ref[2])
+    np.testing.assert_allclose(got[0]["correlations"], ref[0]["correlations"], atol=3e-6)
+    np.testing.assert_allclose(got[1], ref[1], rtol=2e-5, atol=2e-5 * float(np.abs(ref[1]).max()))
+
+
 def test_cu_mask_option_is_neutral(lc, monkeypatch):
     """LITCODER_AMD_CU_MASK=1 runs the fit on a main stream restricted to a CU subset (nested_cv._main_stream): a
     scheduling option only -- results identical bit for bit; and the stream plumbing (caller's stream ordered before
