@@ -240,7 +240,8 @@ def main():
         n_i = n_o - n_v
         split = sweep["precision"] == "f16x3"
         A_fused = sweep.get("fused_alphas", A)               # alphas scored inside the fused launch
-        flops_per_launch = 2.0 * A_fused * n_v * n_i * V      # algorithmic: those alphas of one inner fold
+        folds_fused = sweep.get("folds_per_launch", 1)       # inner folds that share the launch
+        flops_per_launch = 2.0 * A_fused * n_v * n_i * V * folds_fused   # algorithmic: those alphas of those inner folds
         ms, launches = kern.get("alpha_sweep_gemm", (0.0, 0))
         avg_ms = ms / max(launches, 1)
         alg_tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None
@@ -262,7 +263,10 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(sweep["precision"], tj).get("hbm_bytes_per_launch")
+                entry = tj.get(sweep["precision"], tj)
+                traffic = entry.get("hbm_bytes_per_launch")
+                if traffic is not None:                  # the stored figure covers `inner_folds_per_launch` folds
+                    traffic *= folds_fused / float(entry.get("inner_folds_per_launch", 1))
                 traffic_src = ("profiles/alpha_sweep_traffic.json (static: FETCH_SIZE x2 + WRITE_SIZE per launch from "
                                "separate rocprofv3 --pmc passes of this command; not measured in this run)")
             except Exception:
@@ -297,7 +301,8 @@ def main():
                          "frac_vs_f32_mfma_peak": (alg_tflops / PEAK_F32_MFMA_TFLOPS) if alg_tflops else None,
                          "cus_of_256_the_kernel_runs_on": cus_main,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
-                         "fused_alphas_per_launch": A_fused, "plain_launches_same_kernel": plain},
+                         "fused_alphas_per_launch": A_fused, "inner_folds_per_launch": folds_fused,
+                         "plain_launches_same_kernel": plain},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(kern.items())},
         }
         if other is not None:

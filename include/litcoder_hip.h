@@ -366,6 +366,10 @@ int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N,
  * scale per row; d_rowscale_inv (pad256(rows)) receives 2^e undoing it.  K % 32 == 0. */
 int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int64_t K, void* d_tiled,
                       float* d_rowscale_inv, lc_stream_t stream);
+/* The same for `groups` row blocks of `rows` rows each that follow one another in d_h (the inner folds' hat matrices /
+ * series terms): every group is padded to whole 256-row tiles in the image and in d_rowscale_inv, one launch. */
+int lc_split_rows_f16_groups(const float* d_h, int64_t ld, int groups, int64_t rows, int64_t K, void* d_tiled,
+                             float* d_rowscale_inv, lc_stream_t stream);
 
 /* Per-voxel power-of-two scale from max|y| over rows 0..T-1: d_cscale[v] = 2^-e, d_cscale[V + v] = 2^e.
  * *d_flag (caller-zeroed) is OR-ed with 1 when some column is non-finite or has most of its entries more
@@ -417,6 +421,26 @@ int lc_series_sweep_scores_f16x3(const void* d_pt, const float* d_rowscale_inv, 
                                  const double* d_coef, const int32_t* d_aidx, int S, float* d_part,
                                  float* d_scores, int accumulate, int64_t b_rows, int64_t b_gap_begin,
                                  int64_t b_gap_rows, lc_stream_t stream);
+
+/* Both contractions for F (<= 64) inner folds of an outer fold in ONE launch each: the folds' tiled A images (and row
+ * scales) are stacked, every fold padded to whole 256-row tiles; d_yv / d_ystat / d_yblk / d_part are (F, ...) stacks
+ * (lc_val_stats_folds); all folds contract the same tiled target image d_yt, fold f skipping its own gap
+ * (h_gap_begin[f], h_gap_rows[f]; b_rows = 0: no gap).  Scores of the folds are added in fp32, fold order
+ * (nested_cv.py:373-380).  The folds are independent: one launch fills the chip where F small ones each end in a
+ * partial round of workgroups (a rank of an 8-GPU job holds 10 000 voxels: 1.25 rounds per fold). */
+int lc_alpha_sweep_scores_f16x3_folds(const void* d_ht, const float* d_rowscale_inv, int F, int A, int M, int N,
+                                      const void* d_yt, const float* d_cscale_inv, const float* d_yv,
+                                      int64_t V, const int32_t* h_n_val, const float* d_ystat,
+                                      const float* d_yblk, int mode, float* d_part, float* d_scores,
+                                      int accumulate, int64_t b_rows, const int64_t* h_gap_begin,
+                                      const int64_t* h_gap_rows, lc_stream_t stream);
+int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float* d_rowscale_inv, int F, int M,
+                                       const int32_t* h_n_val, int64_t K, const void* d_yt,
+                                       const float* d_cscale_inv, int64_t Ncols, const float* d_yv, int64_t V,
+                                       const float* d_ystat, const float* d_yblk, const double* d_coef,
+                                       const int32_t* d_aidx, int S, float* d_part, float* d_scores,
+                                       int accumulate, int64_t b_rows, const int64_t* h_gap_begin,
+                                       const int64_t* h_gap_rows, lc_stream_t stream);
 
 /* ---------------------------------------------------------------- statistics tail */
 

@@ -91,6 +91,12 @@ SIGNATURES = {
     "lc_series_sweep_scores_f16x3": (c_int, [_ptr, _ptr, c_int, c_int, c_int64, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr,
                                              _ptr, _ptr, _ptr, c_int, _ptr, _ptr, c_int, c_int64, c_int64, c_int64,
                                              _ptr]),
+    "lc_alpha_sweep_scores_f16x3_folds": (c_int, [_ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64,
+                                                  POINTER(c_int32), _ptr, _ptr, c_int, _ptr, _ptr, c_int, c_int64,
+                                                  POINTER(c_int64), POINTER(c_int64), _ptr]),
+    "lc_series_sweep_scores_f16x3_folds": (c_int, [_ptr, _ptr, c_int, c_int, POINTER(c_int32), c_int64, _ptr, _ptr, c_int64,
+                                                   _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr, c_int,
+                                                   c_int64, POINTER(c_int64), POINTER(c_int64), _ptr]),
     "lc_series_scores": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr,
                                  c_int, _ptr]),
     "lc_transpose_rows_f64": (c_int, [_ptr, c_int64, _ptr, c_int, c_int64, _ptr, _ptr]),
@@ -99,6 +105,7 @@ SIGNATURES = {
     "lc_alpha_sweep_scores": (c_int, [_ptr, c_int, c_int, c_int, _ptr, c_int64, c_int64, _ptr, _ptr, c_int, _ptr, _ptr,
                                       c_int, _ptr, _ptr, c_int, _ptr]),
     "lc_split_rows_f16": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr]),
+    "lc_split_rows_f16_groups": (c_int, [_ptr, c_int64, c_int, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_col_scales_f16": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_split_cols_f16": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, _ptr, _ptr, _ptr]),
     "lc_alpha_sweep_scores_f16x3": (c_int, [_ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int, _ptr, _ptr,

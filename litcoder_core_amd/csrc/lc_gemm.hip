@@ -226,14 +226,24 @@ k_gemm_f32(const float* __restrict__ A, long long lda, long long a_group_stride,
 // turn them into the reference's score:  corr = mean(z(y) z(pred)) with unbiased stds and the
 // +1e-8 in both denominators (ridge_utils.py:6-15, ridge_regression.py:124-125), or signed
 // sqrt|R2| (:126-130); then nan_to_num (:133) and accumulate over inner folds.
-__global__ void __launch_bounds__(256) k_score_finalize(const float* __restrict__ part, const float* __restrict__ ystat,
-                                                        const float* __restrict__ yblk, int A, int M, int n_val,
-                                                        long long V, int mode, float* __restrict__ scores,
+struct FoldCounts {
+    int n_val[64];
+};
+
+// One thread per column walks the folds itself (the form for many columns; k_score_finalize_fw below for few).
+__global__ void __launch_bounds__(256) k_score_finalize(const float* __restrict__ part_all, const float* __restrict__ ystat_all,
+                                                        const float* __restrict__ yblk_all, int A, int M, FoldCounts fc,
+                                                        int F, long long V, int mode, float* __restrict__ scores,
                                                         int accumulate) {
     const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int a = blockIdx.y;
     if (v >= V) return;
     const int nblk = M / LC_MB;
+  for (int fold = 0; fold < F; ++fold) {
+    const int n_val = fc.n_val[fold];
+    const float* part = part_all + (long long)fold * A * nblk * 4 * V;
+    const float* ystat = ystat_all + (long long)fold * 3 * V;
+    const float* yblk = yblk_all + (long long)fold * nblk * V;
     const float* p0 = part + (long long)a * nblk * 4 * V + v;
     double n = 0.0, mean = 0.0, m2 = 0.0;
     for (int b = 0; b < nblk; ++b) {
@@ -283,7 +293,101 @@ __global__ void __launch_bounds__(256) k_score_finalize(const float* __restrict_
     else if (score > 3.4028234663852886e38f) score = 3.4028234663852886e38f;
     else if (score < -3.4028234663852886e38f) score = -3.4028234663852886e38f;
     float* dst = scores + (long long)a * V + v;
-    *dst = accumulate ? *dst + score : score;
+    *dst = (accumulate || fold > 0) ? *dst + score : score;
+  }
+}
+
+
+// F folds (slices f of part / ystat / yblk): the folds' scores are added in fp32, fold order (nested_cv.py:373-380).
+// Block = 64 columns x FIN_FW fold workers: a worker merges the blocks of ITS fold (a latency chain of ~45 strided
+// loads), the scores meet in LDS and are summed in fold order -- one thread per column doing all folds one after the
+// other left most of the chip idle at 10 000 voxels per rank.
+constexpr int FIN_FW = 8;
+constexpr long long FIN_WIDE_V = 32768;
+// <FW, COLS>: <8, 64> below ~32 000 columns (the fold workers fill the chip), <1, 256> above (one thread per column
+// walks the folds itself: with enough columns that is the cheaper form -- no idle workers when F < 8, no barriers)
+template <int FW, int COLS>
+__global__ void __launch_bounds__(COLS * FW) k_score_finalize_fw(const float* __restrict__ part_all, const float* __restrict__ ystat_all,
+                                                        const float* __restrict__ yblk_all, int A, int M, FoldCounts fc,
+                                                        int F, long long V, int mode, float* __restrict__ scores,
+                                                        int accumulate) {
+    __shared__ float sc_lds[FW][COLS];
+    const long long v = (long long)blockIdx.x * COLS + threadIdx.x;
+    const int a = blockIdx.y, fy = threadIdx.y;
+    const int nblk = M / LC_MB;
+  for (int fc0 = 0; fc0 < F; fc0 += FW) {
+    const int fold = fc0 + fy;
+    float score = 0.f;
+    if (fold < F && v < V) {
+    const int n_val = fc.n_val[fold];
+    const float* part = part_all + (long long)fold * A * nblk * 4 * V;
+    const float* ystat = ystat_all + (long long)fold * 3 * V;
+    const float* yblk = yblk_all + (long long)fold * nblk * V;
+    const float* p0 = part + (long long)a * nblk * 4 * V + v;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const int nb = min(LC_MB, n_val - b * LC_MB);
+        if (nb <= 0) break;
+        const double s1 = p0[(long long)b * 4 * V], q = p0[(long long)b * 4 * V + V];
+        const double mb = s1 / nb, nn = n + nb, d = mb - mean;
+        m2 += q + d * d * n * nb / nn;
+        mean += d * nb / nn;
+        n = nn;
+    }
+    if (mode == LC_SCORE_CORR) {
+        double cov = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            const int nb = min(LC_MB, n_val - b * LC_MB);
+            if (nb <= 0) break;
+            const double s1 = p0[(long long)b * 4 * V], s3 = p0[(long long)b * 4 * V + 2 * V];
+            cov += s3 + (s1 / nb - mean) * (double)yblk[(long long)b * V + v];
+        }
+        const double sp = sqrt(m2 / (double)(n_val - 1));
+        const double sy = (double)ystat[V + v];
+        score = (float)(cov / ((double)n_val * (sy + 1e-8) * (sp + 1e-8)));
+    } else {
+        // moments of the raw targets, formed and merged exactly like those of the residual (lc_epilogue.h)
+        double ny = 0.0, meany = 0.0, m2y = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            const int nb = min(LC_MB, n_val - b * LC_MB);
+            if (nb <= 0) break;
+            const double s1 = p0[(long long)b * 4 * V + 2 * V], q = p0[(long long)b * 4 * V + 3 * V];
+            const double mb = s1 / nb, nn = ny + nb, d = mb - meany;
+            m2y += q + d * d * ny * nb / nn;
+            meany += d * nb / nn;
+            ny = nn;
+        }
+        const float resvar = (float)(m2 / (double)(n_val - 1));
+        const float yvar_same = (float)(m2y / (double)(n_val - 1));
+        // residual statistically identical to the targets under identical arithmetic: the reference's two
+        // torch.var calls agree bit for bit as well and give Rsq = 0 (or 0/0 -> NaN -> 0 for constant targets)
+        const float yvar = ystat[2 * V + v];
+        const float rsq = resvar == yvar_same ? (yvar == 0.f ? __builtin_nanf("") : 0.f) : 1.f - resvar / yvar;
+        const float sgn = rsq > 0.f ? 1.f : (rsq < 0.f ? -1.f : rsq);   // sign(NaN) = NaN, sign(0) = 0
+        score = sqrtf(fabsf(rsq)) * sgn;
+    }
+    // torch.nan_to_num defaults: NaN -> 0, +-inf -> +-FLT_MAX
+    if (score != score) score = 0.f;
+    else if (score > 3.4028234663852886e38f) score = 3.4028234663852886e38f;
+    else if (score < -3.4028234663852886e38f) score = -3.4028234663852886e38f;
+    }
+    if (FW == 1) {                                       // one thread per column: add the fold's score directly
+        if (v < V) {
+            float* dst = scores + (long long)a * V + v;
+            *dst = (accumulate || fc0 > 0) ? *dst + score : score;
+        }
+        continue;
+    }
+    sc_lds[fy][threadIdx.x] = score;
+    __syncthreads();
+    if (fy == 0 && v < V) {
+        float* dst = scores + (long long)a * V + v;
+        float acc = (accumulate || fc0 > 0) ? *dst : 0.f;            // 0 + x = x: the first fold's score as it is
+        for (int f = 0; f < FW && fc0 + f < F; ++f) acc += sc_lds[f][threadIdx.x];
+        *dst = acc;
+    }
+    __syncthreads();
+  }
 }
 
 // ---- correlation scores of the series alphas from the moments of the shared terms ------------------------------
@@ -400,8 +504,8 @@ __global__ void __launch_bounds__(256) k_series_scores(const float* __restrict__
 
 // The same scores from the per-32-row-block partial moments the series-moments epilogue of the fp16x3 kernel writes
 // (lc::epi_series_block; part: (M / 32, 18, V) f32): blocks merged in fixed order in fp64 (Chan), then the forms.
-__global__ void __launch_bounds__(256) k_series_scores_part(const float* __restrict__ part, const float* __restrict__ ystat,
-                                                            const float* __restrict__ yblk, int M, int n_val,
+__global__ void __launch_bounds__(256) k_series_scores_part(const float* __restrict__ part_all, const float* __restrict__ ystat_all,
+                                                            const float* __restrict__ yblk_all, int M, FoldCounts fc, int F,
                                                             long long V, const double* __restrict__ coefs,
                                                             const int* __restrict__ aidx, int S,
                                                             float* __restrict__ scores, int accumulate) {
@@ -409,6 +513,11 @@ __global__ void __launch_bounds__(256) k_series_scores_part(const float* __restr
     const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
     if (c >= V) return;
     const int nblk = M / LC_MB;
+  for (int fold = 0; fold < F; ++fold) {
+    const int n_val = fc.n_val[fold];
+    const float* part = part_all + (long long)fold * nblk * NP * V;
+    const float* ystat = ystat_all + (long long)fold * 3 * V;
+    const float* yblk = yblk_all + (long long)fold * nblk * V;
     double n = 0.0, mean[4] = {0.0, 0.0, 0.0, 0.0}, sc[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) sc[k] = 0.0;
@@ -461,8 +570,113 @@ __global__ void __launch_bounds__(256) k_series_scores_part(const float* __restr
         else if (score > 3.4028234663852886e38f) score = 3.4028234663852886e38f;
         else if (score < -3.4028234663852886e38f) score = -3.4028234663852886e38f;
         float* dst = scores + (long long)aidx[s] * V + c;
-        *dst = accumulate ? *dst + score : score;
+        *dst = (accumulate || fold > 0) ? *dst + score : score;
     }
+  }
+}
+
+
+template <int FW, int COLS>
+__global__ void __launch_bounds__(COLS * FW) k_series_scores_part_fw(const float* __restrict__ part_all, const float* __restrict__ ystat_all,
+                                                            const float* __restrict__ yblk_all, int M, FoldCounts fc, int F,
+                                                            long long V, const double* __restrict__ coefs,
+                                                            const int* __restrict__ aidx, int S,
+                                                            float* __restrict__ scores, int accumulate) {
+    constexpr int NP = lc::EPI_SERIES_PARTS;
+    __shared__ float sc_lds[FW][FIN_FW][COLS];             // [fold worker][alpha of the chunk][column]
+    const long long c = (long long)blockIdx.x * COLS + threadIdx.x;
+    const int fy = threadIdx.y;
+    const int nblk = M / LC_MB;
+  for (int fc0 = 0; fc0 < F; fc0 += FW) {
+    const int fold = fc0 + fy;
+    const bool live = fold < F && c < V;
+    double mean[4] = {0.0, 0.0, 0.0, 0.0}, sc[10], cy[4] = {0.0, 0.0, 0.0, 0.0}, nv = 1.0, sy = 0.0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sc[k] = 0.0;
+    if (live) {
+        const int n_val = fc.n_val[fold];
+        const float* part = part_all + (long long)fold * nblk * NP * V;
+        const float* ystat = ystat_all + (long long)fold * 3 * V;
+        const float* yblk = yblk_all + (long long)fold * nblk * V;
+        double n = 0.0;
+        for (int b = 0; b < nblk; ++b) {
+            const int nb = min(LC_MB, n_val - b * LC_MB);
+            if (nb <= 0) break;
+            const float* p0 = part + (long long)b * NP * V + c;
+            const double nn = n + nb, w = n * nb / nn;
+            double d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = (double)p0[(long long)j * V] / nb - mean[j];
+            int k = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int l = j; l < 4; ++l) {
+                    sc[k] += (double)p0[(long long)(8 + k) * V] + d[j] * d[l] * w;
+                    ++k;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mean[j] += d[j] * nb / nn;
+            n = nn;
+        }
+        for (int b = 0; b < nblk; ++b) {
+            const int nb = min(LC_MB, n_val - b * LC_MB);
+            if (nb <= 0) break;
+            const float* p0 = part + (long long)b * NP * V + c;
+            const double yb = (double)yblk[(long long)b * V + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                cy[j] += (double)p0[(long long)(4 + j) * V] + ((double)p0[(long long)j * V] / nb - mean[j]) * yb;
+        }
+        nv = (double)n_val;
+        sy = (double)ystat[V + c];
+    }
+    for (int s0 = 0; s0 < S; s0 += FIN_FW) {
+#pragma unroll
+        for (int q = 0; q < FIN_FW; ++q) {
+            const int s = s0 + q;
+            float score = 0.f;
+            if (live && s < S) {
+                double coef[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) coef[j] = coefs[s * 4 + j];
+                double m2 = 0.0, cov = 0.0;
+                int k = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cov += coef[j] * cy[j];
+#pragma unroll
+                    for (int l = j; l < 4; ++l) { m2 += (l == j ? 1.0 : 2.0) * coef[j] * coef[l] * sc[k]; ++k; }
+                }
+                const double sp = sqrt(fmax(m2, 0.0) / (nv - 1.0));
+                score = (float)(cov / (nv * (sy + 1e-8) * (sp + 1e-8)));
+                if (score != score) score = 0.f;
+                else if (score > 3.4028234663852886e38f) score = 3.4028234663852886e38f;
+                else if (score < -3.4028234663852886e38f) score = -3.4028234663852886e38f;
+            }
+            if (FW == 1) {
+                if (live && s < S) {
+                    float* dst = scores + (long long)aidx[s] * V + c;
+                    *dst = (accumulate || fc0 > 0) ? *dst + score : score;
+                }
+            } else {
+                sc_lds[fy][q][threadIdx.x] = score;
+            }
+        }
+        if (FW == 1) continue;
+        __syncthreads();
+        for (int q = fy; q < FIN_FW; q += FW) {             // worker fy sums alphas s0 + fy, + FW, ... over the chunk's folds
+            const int s = s0 + q;
+            if (s < S && c < V) {
+                float* dst = scores + (long long)aidx[s] * V + c;
+                float acc = (accumulate || fc0 > 0) ? *dst : 0.f;
+                for (int f = 0; f < FW && fc0 + f < F; ++f) acc += sc_lds[f][q][threadIdx.x];
+                *dst = acc;
+            }
+        }
+        __syncthreads();
+    }
+  }
 }
 
 int check_gemm_shapes(const char* who, const void* a, long long lda, const void* b, long long ldb, long long Ncols,
@@ -484,20 +698,33 @@ int set_lds_attr() {
 }  // namespace
 
 // shared with the fp16x3 variant (lc_gemm16.hip)
-int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int A, int M, int n_val,
-                             long long V, int mode, float* d_scores, int accumulate, hipStream_t s) {
+int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int A, int M,
+                             const int* h_n_val, int F, long long V, int mode, float* d_scores, int accumulate,
+                             hipStream_t s) {
+    FoldCounts fc{};
+    for (int f = 0; f < F && f < 64; ++f) fc.n_val[f] = h_n_val[f];
     lc::ScopedTimer timer_(lc::T_SWEEP_FINALIZE, s);
-    hipLaunchKernelGGL(k_score_finalize, dim3((unsigned)lc::ceil_div<long long>(V, 256), (unsigned)A), dim3(256), 0, s,
-                       d_part, d_ystat, d_yblk, A, M, n_val, V, mode, d_scores, accumulate);
+    if (V < FIN_WIDE_V && F > 1)
+        hipLaunchKernelGGL((k_score_finalize_fw<FIN_FW, 64>), dim3((unsigned)lc::ceil_div<long long>(V, 64), (unsigned)A),
+                           dim3(64, FIN_FW), 0, s, d_part, d_ystat, d_yblk, A, M, fc, F, V, mode, d_scores, accumulate);
+    else
+        hipLaunchKernelGGL(k_score_finalize, dim3((unsigned)lc::ceil_div<long long>(V, 256), (unsigned)A), dim3(256), 0, s,
+                           d_part, d_ystat, d_yblk, A, M, fc, F, V, mode, d_scores, accumulate);
     return lc::launched("k_score_finalize");
 }
 
-int lc_series_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int M, int n_val,
-                              long long V, const double* d_coef, const int* d_aidx, int S, float* d_scores,
+int lc_series_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int M, const int* h_n_val,
+                              int F, long long V, const double* d_coef, const int* d_aidx, int S, float* d_scores,
                               int accumulate, hipStream_t s) {
+    FoldCounts fc{};
+    for (int f = 0; f < F && f < 64; ++f) fc.n_val[f] = h_n_val[f];
     lc::ScopedTimer timer_(lc::T_SWEEP_FINALIZE, s);
-    hipLaunchKernelGGL(k_series_scores_part, dim3((unsigned)lc::ceil_div<long long>(V, 256)), dim3(256), 0, s, d_part,
-                       d_ystat, d_yblk, M, n_val, V, d_coef, d_aidx, S, d_scores, accumulate);
+    if (V < FIN_WIDE_V && F > 1)
+        hipLaunchKernelGGL((k_series_scores_part_fw<FIN_FW, 64>), dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, FIN_FW),
+                           0, s, d_part, d_ystat, d_yblk, M, fc, F, V, d_coef, d_aidx, S, d_scores, accumulate);
+    else
+        hipLaunchKernelGGL(k_series_scores_part, dim3((unsigned)lc::ceil_div<long long>(V, 256)), dim3(256), 0, s, d_part,
+                           d_ystat, d_yblk, M, fc, F, V, d_coef, d_aidx, S, d_scores, accumulate);
     return lc::launched("k_series_scores_part");
 }
 
@@ -530,7 +757,7 @@ extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, cons
                            (long long)V, sa);
     }
     if (int rc = lc::launched("k_gemm_f32<score>")) return rc;
-    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, n_val, (long long)V, mode, d_scores, accumulate, s);
+    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, &n_val, 1, (long long)V, mode, d_scores, accumulate, s);
 }
 
 extern "C" int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val, int64_t V, const float* d_yv,

@@ -37,15 +37,18 @@ __device__ inline int xcd_tile_id16(int bid, int nwg) {
 
 // ------------------------------------------------------------------ operand preparation
 // One wave per row of H: exact power-of-two scale to [0.5, 1), split, scatter into the tiled layout.
+// Groups (the inner folds of an outer fold): group g = source rows [g rows, (g + 1) rows), padded to rows_pad (whole
+// 256-row tiles) in the image and in rs_inv, so that the groups' images are stacked tile-aligned.
 __global__ void __launch_bounds__(256) k_split_rows_f16(const float* __restrict__ h, long long ld, int rows, int K,
                                                         uint4* __restrict__ out, float* __restrict__ rs_inv,
-                                                        int rows_pad) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                        int rows_pad, int groups) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);          // row of the stacked, padded image
     const int lane = threadIdx.x & 63;
-    if (r >= rows_pad) return;
+    if (r >= rows_pad * groups) return;
     const int KT = K / TK;
-    const bool live = r < rows;
-    const float* src = h + (long long)r * ld;
+    const int g = r / rows_pad, rg = r - g * rows_pad;
+    const bool live = rg < rows;
+    const float* src = h + ((long long)g * rows + rg) * ld;
     float mx = 0.f;
     if (live)
         for (int k = lane * 4; k < K; k += 256) {
@@ -168,6 +171,18 @@ struct BView {
     int cut, skip;
 };
 
+// Score and series-moments modes: several inner folds in ONE launch, stacked along the M-tiles -- fold f owns tiles
+// [f mt_per_fold, (f + 1) mt_per_fold) of the A image and of the row scales, slice f of the targets / statistics /
+// partials, and its own gap of the shared B image.  (The folds of an outer fold are independent; one launch fills the
+// chip where five small ones each end in a partial round of workgroups.)
+constexpr int MAX_FOLDS16 = 64;
+struct FoldViews {
+    int mt_per_fold;
+    long long part_stride;             // floats per fold in sa.part
+    int n_val[MAX_FOLDS16];
+    int cut[MAX_FOLDS16], skip[MAX_FOLDS16];
+};
+
 // plain (store) mode: C[:, tile] = A_g(tile) . B[:, tile] with one A matrix per column group
 constexpr int MAX_GROUPS16 = 64;
 struct Plain16Args {
@@ -201,7 +216,7 @@ struct Plain16Args {
 template <bool SCORE, bool STAMP, bool LIGHTCAP = false, bool SERMOM = false>
 __global__ void __launch_bounds__(512, 2)
 k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT, int Mtiles, Score16Args sa,
-              Plain16Args pa, BView bv) {
+              Plain16Args pa, BView bv, FoldViews fv) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds16[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform (scalar)
@@ -209,19 +224,29 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     const int li = lane & 31, lh = lane >> 5;
 
     const int tile = xcd_tile_id16(blockIdx.x, gridDim.x);
-    const int mt = tile % Mtiles, nt = tile / Mtiles;
+    const int mt_all = tile % Mtiles, nt = tile / Mtiles;
+    constexpr bool FOLDS = SCORE || SERMOM;
+    const int fold = FOLDS ? mt_all / fv.mt_per_fold : 0;
+    const int mt = FOLDS ? mt_all - fold * fv.mt_per_fold : mt_all;          // M-tile inside the fold
+    if (FOLDS) {
+        sa.yv += (long long)fold * sa.M * sa.V;
+        sa.ymean += (long long)fold * 3 * sa.V;
+        sa.part += (long long)fold * fv.part_stride;
+        sa.n_val = fv.n_val[fold];
+    }
+    const int b_cut = FOLDS ? fv.cut[fold] : bv.cut, b_skip = FOLDS ? fv.skip[fold] : bv.skip;
     int grp = 0;
     if (!SCORE) {
         while (grp + 1 < pa.G && nt >= pa.start[grp + 1]) ++grp;
     }
-    const uint4* a_src = At + ((long long)grp * Mtiles + mt) * KT * CHUNK16 + tid;
+    const uint4* a_src = At + ((long long)grp * Mtiles + mt_all) * KT * CHUNK16 + tid;
     const uint4* b_src = Bt + (long long)nt * bv.kt_total * CHUNK16 + tid;
-#define BKT(kt_) ((kt_) + ((kt_) >= bv.cut ? bv.skip : 0))
+#define BKT(kt_) ((kt_) + ((kt_) >= b_cut ? b_skip : 0))
     // "light" slabs (plain mode): rows whose product only needs fp16 accuracy (11-bit operands) -- the higher
     // terms of a series, which enter the caller's result scaled down by >= 2^-11 -- take the hi*hi MFMA alone
     const bool light = SERMOM ? wm != 0
                               : (LIGHTCAP && !SCORE && pa.slab_light != nullptr &&
-                                 __builtin_amdgcn_readfirstlane((int)pa.slab_light[((long long)grp * Mtiles + mt) * 2 + wm]) != 0);
+                                 __builtin_amdgcn_readfirstlane((int)pa.slab_light[((long long)grp * Mtiles + mt_all) * 2 + wm]) != 0);
 
     // ---- main loop: software-pipelined fragments, ONE block barrier per K-tile ----------------------------
     // Every wave keeps two register sets of fragments: while the 24 MFMAs of K-tile j run on one set, the 12
@@ -280,12 +305,12 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     const long long colc[2] = {cok[0] ? col0 : 0, cok[1] ? col0 + 32 : 0};       // clamped: loads stay in range
     float ymv[2] = {0.f, 0.f}, cscv[2] = {0.f, 0.f};
     if (SERMOM) {                                    // this wave's column block after the swap: ni = wm
-        if (tid < TM) lds_rs[tid] = pa.rs_inv[((long long)grp * Mtiles + mt) * TM + tid];
+        if (tid < TM) lds_rs[tid] = pa.rs_inv[((long long)grp * Mtiles + mt_all) * TM + tid];
         ymv[0] = sa.ymean[colc[wm]];
         cscv[0] = pa.cs_inv[(long long)nt * TN + wn * 64 + wm * 32 + li];
     }
     if (SCORE) {
-        if (tid < TM) lds_rs[tid] = sa.rs_inv[mt * TM + tid];                      // rs_inv has rows_pad entries
+        if (tid < TM) lds_rs[tid] = sa.rs_inv[mt_all * TM + tid];                  // rs_inv has rows_pad entries per fold
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             ymv[ni] = sa.ymean[colc[ni]];
@@ -589,9 +614,10 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 
 }  // namespace
 
-// defined in lc_gemm.hip: combines the per-block partial moments into scores
-int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int A, int M, int n_val,
-                             long long V, int mode, float* d_scores, int accumulate, hipStream_t s);
+// defined in lc_gemm.hip: combines the per-block partial moments into scores (F folds: fp32 sum in fold order)
+int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int A, int M,
+                             const int* h_n_val, int F, long long V, int mode, float* d_scores, int accumulate,
+                             hipStream_t s);
 
 // B view from the C-ABI triple (rows of the image, first row of the gap, rows of the gap; all multiples of 16)
 static int make_bview(const char* who, int64_t K, int64_t b_rows, int64_t gap_begin, int64_t gap_rows, BView* bv) {
@@ -606,16 +632,22 @@ static int make_bview(const char* who, int64_t K, int64_t b_rows, int64_t gap_be
     return LC_OK;
 }
 
+extern "C" int lc_split_rows_f16_groups(const float* d_h, int64_t ld, int groups, int64_t rows, int64_t K, void* d_tiled,
+                                        float* d_rowscale_inv, lc_stream_t stream) {
+    LC_REQUIRE(d_h && d_tiled && d_rowscale_inv, LC_E_BADARG, "lc_split_rows_f16: null pointer");
+    LC_REQUIRE(groups > 0 && rows > 0 && K > 0 && K % TK == 0 && ld % 4 == 0 && ld >= K, LC_E_SHAPE,
+               "lc_split_rows_f16: need K %% %d == 0 and ld %% 4 == 0", TK);
+    const long long rows_pad = lc::ceil_div<long long>(rows, TM) * TM;
+    LC_REQUIRE(rows_pad * groups < (1ll << 31), LC_E_SHAPE, "lc_split_rows_f16: too many rows");
+    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_split_rows_f16, dim3((unsigned)(rows_pad * groups / 4)), dim3(256), 0, lc::as_stream(stream), d_h,
+                       (long long)ld, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad, groups);
+    return lc::launched("k_split_rows_f16");
+}
+
 extern "C" int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int64_t K, void* d_tiled,
                                  float* d_rowscale_inv, lc_stream_t stream) {
-    LC_REQUIRE(d_h && d_tiled && d_rowscale_inv, LC_E_BADARG, "lc_split_rows_f16: null pointer");
-    LC_REQUIRE(rows > 0 && K > 0 && K % TK == 0 && ld % 4 == 0 && ld >= K, LC_E_SHAPE,
-               "lc_split_rows_f16: need K %% %d == 0 and ld %% 4 == 0", TK);
-    const int rows_pad = (int)(lc::ceil_div<long long>(rows, TM) * TM);
-    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
-    hipLaunchKernelGGL(k_split_rows_f16, dim3((unsigned)(rows_pad / 4)), dim3(256), 0, lc::as_stream(stream), d_h,
-                       (long long)ld, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, rows_pad);
-    return lc::launched("k_split_rows_f16");
+    return lc_split_rows_f16_groups(d_h, ld, 1, rows, K, d_tiled, d_rowscale_inv, stream);
 }
 
 extern "C" int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
@@ -639,35 +671,67 @@ extern "C" int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const
     return lc::launched("k_split_cols_f16");
 }
 
+static int fill_fold_views(const char* who, int F, int64_t K, int64_t b_rows, const int64_t* h_gap_begin,
+                           const int64_t* h_gap_rows, const int32_t* h_n_val, int M, BView* bv, FoldViews* fv) {
+    LC_REQUIRE(F >= 1 && F <= MAX_FOLDS16, LC_E_SHAPE, "%s: 1 <= F <= %d inner folds per launch", who, MAX_FOLDS16);
+    for (int f = 0; f < F; ++f) {
+        BView one;
+        if (int rc = make_bview(who, K, b_rows, h_gap_begin ? h_gap_begin[f] : 0, h_gap_rows ? h_gap_rows[f] : 0, &one))
+            return rc;
+        LC_REQUIRE(h_n_val[f] > 0 && h_n_val[f] <= M, LC_E_SHAPE, "%s: need 0 < n_val <= M", who);
+        *bv = one;
+        fv->cut[f] = one.cut;
+        fv->skip[f] = one.skip;
+        fv->n_val[f] = h_n_val[f];
+    }
+    return LC_OK;
+}
+
+extern "C" int lc_alpha_sweep_scores_f16x3_folds(const void* d_ht, const float* d_rowscale_inv, int F, int A, int M, int N,
+                                                 const void* d_yt, const float* d_cscale_inv, const float* d_yv,
+                                                 int64_t V, const int32_t* h_n_val, const float* d_ystat,
+                                                 const float* d_yblk, int mode, float* d_part, float* d_scores,
+                                                 int accumulate, int64_t b_rows, const int64_t* h_gap_begin,
+                                                 const int64_t* h_gap_rows, lc_stream_t stream) {
+    LC_REQUIRE(d_ht && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_part && d_scores &&
+                   h_n_val, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: null pointer");
+    LC_REQUIRE(A > 0 && M > 0 && M % LC_MB == 0 && N > 0 && N % (2 * TK) == 0, LC_E_SHAPE,
+               "lc_alpha_sweep_scores_f16x3: need M %% %d == 0, N %% %d == 0", LC_MB, 2 * TK);
+    LC_REQUIRE(V > 0 && V % 128 == 0, LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: V must be a multiple of 128");
+    LC_REQUIRE(mode == LC_SCORE_CORR || mode == LC_SCORE_R2, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: bad mode");
+    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<true, false>), LDS16_BYTES)) return rc;
+    hipStream_t s = lc::as_stream(stream);
+    BView bv;
+    FoldViews fv{};
+    if (int rc = fill_fold_views("lc_alpha_sweep_scores_f16x3", F, N, b_rows, h_gap_begin, h_gap_rows, h_n_val, M, &bv, &fv))
+        return rc;
+    const int Mrows = A * M;
+    const int Mtiles = lc::ceil_div(Mrows, TM);            // per fold: the folds' images are stacked tile-aligned
+    const long long Ntiles = lc::ceil_div<long long>(V, TN);
+    LC_REQUIRE((long long)F * Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: grid too large");
+    fv.mt_per_fold = Mtiles;
+    fv.part_stride = (long long)(Mrows / LC_MB) * 4 * V;
+    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, 0, mode, Mrows};
+    {
+        lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
+        Plain16Args pa{};
+        hipLaunchKernelGGL((k_sweep_f16x3<true, false>), dim3((unsigned)(F * Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
+                           (const uint4*)d_ht, (const uint4*)d_yt, N / TK, F * Mtiles, sa, pa, bv, fv);
+    }
+    if (int rc = lc::launched("k_sweep_f16x3")) return rc;
+    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, h_n_val, F, (long long)V, mode, d_scores, accumulate, s);
+}
+
 extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
                                            const void* d_yt, const float* d_cscale_inv, const float* d_yv,
                                            int64_t V, int n_val, const float* d_ystat,
                                            const float* d_yblk, int mode, float* d_part, float* d_scores,
                                            int accumulate, int64_t b_rows, int64_t b_gap_begin, int64_t b_gap_rows,
                                            lc_stream_t stream) {
-    LC_REQUIRE(d_ht && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_part && d_scores,
-               LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: null pointer");
-    LC_REQUIRE(A > 0 && M > 0 && M % LC_MB == 0 && n_val > 0 && n_val <= M && N > 0 && N % (2 * TK) == 0,
-               LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: need M %% %d == 0, N %% %d == 0, 0 < n_val <= M", LC_MB, 2 * TK);
-    LC_REQUIRE(V > 0 && V % 128 == 0, LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: V must be a multiple of 128");
-    LC_REQUIRE(mode == LC_SCORE_CORR || mode == LC_SCORE_R2, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: bad mode");
-    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<true, false>), LDS16_BYTES)) return rc;
-    hipStream_t s = lc::as_stream(stream);
-    BView bv;
-    if (int rc = make_bview("lc_alpha_sweep_scores_f16x3", N, b_rows, b_gap_begin, b_gap_rows, &bv)) return rc;
-    const int Mrows = A * M;
-    const int Mtiles = lc::ceil_div(Mrows, TM);
-    const long long Ntiles = lc::ceil_div<long long>(V, TN);
-    LC_REQUIRE((long long)Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: grid too large");
-    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val, mode, Mrows};
-    {
-        lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
-        Plain16Args pa{};
-        hipLaunchKernelGGL((k_sweep_f16x3<true, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
-                           (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa, bv);
-    }
-    if (int rc = lc::launched("k_sweep_f16x3")) return rc;
-    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, n_val, (long long)V, mode, d_scores, accumulate, s);
+    const int32_t nv = n_val;
+    return lc_alpha_sweep_scores_f16x3_folds(d_ht, d_rowscale_inv, 1, A, M, N, d_yt, d_cscale_inv, d_yv, V, &nv, d_ystat,
+                                             d_yblk, mode, d_part, d_scores, accumulate, b_rows, &b_gap_begin, &b_gap_rows,
+                                             stream);
 }
 
 extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
@@ -709,41 +773,46 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
     lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
     if (d_slab_light)
         hipLaunchKernelGGL((k_sweep_f16x3<false, false, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES,
-                           s, (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa, bv);
+                           s, (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa, bv, FoldViews{});
     else
         hipLaunchKernelGGL((k_sweep_f16x3<false, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
-                           (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa, bv);
+                           (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa, bv, FoldViews{});
     return lc::launched("k_sweep_f16x3<plain>");
 }
 
 // defined in lc_gemm.hip
-int lc_series_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int M, int n_val,
-                              long long V, const double* d_coef, const int* d_aidx, int S, float* d_scores,
+int lc_series_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int M, const int* h_n_val,
+                              int F, long long V, const double* d_coef, const int* d_aidx, int S, float* d_scores,
                               int accumulate, hipStream_t s);
 
-extern "C" int lc_series_sweep_scores_f16x3(const void* d_pt, const float* d_rowscale_inv, int M, int n_val, int64_t K,
-                                            const void* d_yt, const float* d_cscale_inv, int64_t Ncols,
-                                            const float* d_yv, int64_t V, const float* d_ystat, const float* d_yblk,
-                                            const double* d_coef, const int32_t* d_aidx, int S, float* d_part,
-                                            float* d_scores, int accumulate, int64_t b_rows, int64_t b_gap_begin,
-                                            int64_t b_gap_rows, lc_stream_t stream) {
+extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float* d_rowscale_inv, int F, int M,
+                                                  const int32_t* h_n_val, int64_t K, const void* d_yt,
+                                                  const float* d_cscale_inv, int64_t Ncols, const float* d_yv, int64_t V,
+                                                  const float* d_ystat, const float* d_yblk, const double* d_coef,
+                                                  const int32_t* d_aidx, int S, float* d_part, float* d_scores,
+                                                  int accumulate, int64_t b_rows, const int64_t* h_gap_begin,
+                                                  const int64_t* h_gap_rows, lc_stream_t stream) {
     LC_REQUIRE(d_pt && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_coef && d_aidx &&
-                   d_part && d_scores, LC_E_BADARG, "lc_series_sweep_scores_f16x3: null pointer");
-    LC_REQUIRE(M > 0 && M % LC_MB == 0 && n_val > 1 && n_val <= M && K > 0 && K % (2 * TK) == 0 && S > 0, LC_E_SHAPE,
-               "lc_series_sweep_scores_f16x3: need M %% %d == 0, 1 < n_val <= M, K %% %d == 0", LC_MB, 2 * TK);
+                   d_part && d_scores && h_n_val, LC_E_BADARG, "lc_series_sweep_scores_f16x3: null pointer");
+    LC_REQUIRE(M > 0 && M % LC_MB == 0 && K > 0 && K % (2 * TK) == 0 && S > 0, LC_E_SHAPE,
+               "lc_series_sweep_scores_f16x3: need M %% %d == 0, K %% %d == 0", LC_MB, 2 * TK);
     LC_REQUIRE(V > 0 && V % 128 == 0 && Ncols >= V && Ncols % TN == 0, LC_E_SHAPE,
                "lc_series_sweep_scores_f16x3: V must be a multiple of 128, Ncols >= V a multiple of %d", TN);
     if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true, true>), LDS16_BYTES))
         return rc;
     hipStream_t s = lc::as_stream(stream);
     BView bv;
-    if (int rc = make_bview("lc_series_sweep_scores_f16x3", K, b_rows, b_gap_begin, b_gap_rows, &bv)) return rc;
+    FoldViews fv{};
+    if (int rc = fill_fold_views("lc_series_sweep_scores_f16x3", F, K, b_rows, h_gap_begin, h_gap_rows, h_n_val, M, &bv, &fv))
+        return rc;
+    for (int f = 0; f < F; ++f) LC_REQUIRE(h_n_val[f] > 1, LC_E_SHAPE, "lc_series_sweep_scores_f16x3: need n_val > 1");
     const int nblk = M / LC_MB;
     const int Mtiles = (nblk + 1) / 2;                     // two 32-row validation blocks x four terms per tile
     const long long Ntiles = Ncols / TN;
-    LC_REQUIRE((long long)Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_series_sweep_scores_f16x3: grid too large");
-    // per 128-row slab: wave row 0 = terms 0, 1 (three MFMAs per product), wave row 1 = terms 2, 3 (hi * hi only)
-    Score16Args sa{d_yv, d_ystat, nullptr, nullptr, d_part, (long long)V, M, n_val, LC_SCORE_CORR, Mtiles * TM};
+    LC_REQUIRE((long long)F * Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_series_sweep_scores_f16x3: grid too large");
+    fv.mt_per_fold = Mtiles;
+    fv.part_stride = (long long)nblk * lc::EPI_SERIES_PARTS * V;
+    Score16Args sa{d_yv, d_ystat, nullptr, nullptr, d_part, (long long)V, M, 0, LC_SCORE_CORR, Mtiles * TM};
     Plain16Args pa{};
     pa.rs_inv = d_rowscale_inv;
     pa.cs_inv = d_cscale_inv;
@@ -754,12 +823,24 @@ extern "C" int lc_series_sweep_scores_f16x3(const void* d_pt, const float* d_row
     pa.slab_light = nullptr;
     {
         lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
-        hipLaunchKernelGGL((k_sweep_f16x3<false, false, true, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512),
-                           LDS16_BYTES, s, (const uint4*)d_pt, (const uint4*)d_yt, (int)(K / TK), Mtiles, sa, pa, bv);
+        hipLaunchKernelGGL((k_sweep_f16x3<false, false, true, true>), dim3((unsigned)(F * Mtiles * Ntiles)), dim3(512),
+                           LDS16_BYTES, s, (const uint4*)d_pt, (const uint4*)d_yt, (int)(K / TK), F * Mtiles, sa, pa, bv, fv);
     }
     if (int rc = lc::launched("k_sweep_f16x3<series moments>")) return rc;
-    return lc_series_finalize_launch(d_part, d_ystat, d_yblk, M, n_val, (long long)V, d_coef, d_aidx, S, d_scores,
+    return lc_series_finalize_launch(d_part, d_ystat, d_yblk, M, h_n_val, F, (long long)V, d_coef, d_aidx, S, d_scores,
                                      accumulate, s);
+}
+
+extern "C" int lc_series_sweep_scores_f16x3(const void* d_pt, const float* d_rowscale_inv, int M, int n_val, int64_t K,
+                                            const void* d_yt, const float* d_cscale_inv, int64_t Ncols,
+                                            const float* d_yv, int64_t V, const float* d_ystat, const float* d_yblk,
+                                            const double* d_coef, const int32_t* d_aidx, int S, float* d_part,
+                                            float* d_scores, int accumulate, int64_t b_rows, int64_t b_gap_begin,
+                                            int64_t b_gap_rows, lc_stream_t stream) {
+    const int32_t nv = n_val;
+    return lc_series_sweep_scores_f16x3_folds(d_pt, d_rowscale_inv, 1, M, &nv, K, d_yt, d_cscale_inv, Ncols, d_yv, V,
+                                              d_ystat, d_yblk, d_coef, d_aidx, S, d_part, d_scores, accumulate, b_rows,
+                                              &b_gap_begin, &b_gap_rows, stream);
 }
 
 // Diagnostics: the score kernel with s_memtime stamps (not part of the product path; see tools/gpu_kernel_bench.py).
@@ -777,9 +858,13 @@ extern "C" int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale
     const long long Ntiles = lc::ceil_div<long long>(V, TN);
     Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val, LC_SCORE_CORR, Mrows};
     Plain16Args pa{};
+    FoldViews fv{};
+    fv.mt_per_fold = Mtiles;
+    fv.n_val[0] = n_val;
+    fv.cut[0] = N / TK;
     pa.c = reinterpret_cast<float*>(d_stamps);
     hipLaunchKernelGGL((k_sweep_f16x3<true, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES,
                        lc::as_stream(stream), (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa,
-                       BView{N / TK, N / TK, 0});
+                       BView{N / TK, N / TK, 0}, fv);
     return lc::launched("k_sweep_f16x3<stamp>");
 }

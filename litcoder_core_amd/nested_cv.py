@@ -49,6 +49,8 @@ SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singc
 PRIMAL_MAX_SCALE_RATIO = 64.0       # ... and whose feature column norms lie within this factor of each other (fp16x3)
 REFIT_BY_INVERSE = True             # refit operators through the explicit inverse + one fp16x3 product (_refit_by_inverse)
 REFIT_INVERSE_MIN_ALPHA = 0.05      # ... for alphas (in units of S[0]) from here on
+FOLDS_IN_ONE_LAUNCH = False         # one launch per pass for all inner folds of an outer fold (_sweeps): measured neutral at
+                                    # 10 000 voxels per rank and 2 ms slower at 80 000 -- off; kept (and tested) as an option
 SERIES_FUSED_MOMENTS = True         # series terms reduced to moments in the contraction's epilogue (never stored)
 PRIMAL_MOMENTS_MAX_P = 16           # ... and, up to this many features, scored from block products X'Y alone (_prepare_moments)
 PRIMAL_MAX_P = 512                  # the primal (p x p) form is taken for tall designs up to this many features
@@ -584,7 +586,7 @@ class RidgeCVEngine:
         if hat.get("data_ready") is not None:
             main.wait_event(hat["data_ready"])            # this fold's (normalised) targets and their column scales
         self.info.update(precision="f16x3" if split else "f32", fused_alphas=Ad,
-                          series_terms=SERIES_TERMS if moments else 0)
+                          series_terms=SERIES_TERMS if moments else 0, folds_per_launch=1)
         nbuf = F if moments else 1                        # two passes over the folds keep every fold's operands
         ystat = torch.empty((nbuf, 3, self.Vp), dtype=torch.float32, device=self.dev)
         yblk = torch.empty((nbuf, M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
@@ -611,10 +613,16 @@ class RidgeCVEngine:
             # ---- pass 1: validation statistics, operand split, series contraction + moment kernel
             Tm, rowmap, slab_light = self._series_layout(M)
             fused = slab_light is None                   # layout of the moments epilogue: the terms are never stored
-            Pt = torch.empty(ops.pad_to(Tm, 256) * N * 2, dtype=torch.float16, device=self.dev)
-            rs_p = torch.empty(ops.pad_to(Tm, 256), dtype=torch.float32, device=self.dev)
+            # all inner folds in ONE launch per pass (stacked A images, one shared target image with a gap per fold):
+            # the folds are independent, and one launch fills the chip where F small ones each end in a partial round
+            # of workgroups -- at 10 000 voxels per rank (8 GPUs) a fold's launch is 1.25 rounds
+            merged = fused and shared is not None and F <= 64 and FOLDS_IN_ONE_LAUNCH
+            nst = F if merged else 1
+            tp = ops.pad_to(Tm, 256)
+            Pt = torch.empty(nst * tp * N * 2, dtype=torch.float16, device=self.dev)
+            rs_p = torch.empty(nst * tp, dtype=torch.float32, device=self.dev)
             if fused:
-                part_s = torch.empty((M // LC_MB, 18, self.Vp), dtype=torch.float32, device=self.dev)
+                part_s = torch.empty((nst, M // LC_MB, 18, self.Vp), dtype=torch.float32, device=self.dev)
             else:
                 Tbuf = torch.empty((Tm, Vt), dtype=torch.float32, device=self.dev)
             cs_inv = self._cs_inv_padded(cs, Vt)                               # padded to the plain GEMM's tiles
@@ -624,7 +632,15 @@ class RidgeCVEngine:
             for f0 in range(0, F, 64):
                 f1 = min(F, f0 + 64)
                 ops.val_stats_folds(Y, self.Vp, va[f0:f1], f1 - f0, M, n_v[f0:f1], ystat[f0:f1], yblk[f0:f1], yv[f0:f1])
-            for f, j, H, P in folds:
+            if merged:
+                for f0, fc, H, P in hat["Hs"]:           # the folds' terms follow one another in P: one split per chunk
+                    ops.split_rows_f16_groups(P.view(-1, N), fc, Tm, N, Pt[f0 * tp * N * 2:], rs_p[f0 * tp:])
+                for f in range(F):
+                    self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
+                self.info["plain_launches"] += 1
+                ops.series_sweep_scores_f16x3_folds(Pt, rs_p, M, n_v, N, Yu, cs_inv, Vt, yv, self.Vp, ystat, yblk,
+                                                    self.d_coef, hat["d_ser"], part_s, scores, False, views)
+            for f, j, H, P in (() if merged else folds):
                 if shared is None:
                     ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[f])
                 ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
@@ -642,7 +658,16 @@ class RidgeCVEngine:
         if done is not None:
             main.wait_event(done)
         # ---- pass 2 (the only one without the moment path): fused sweeps of the alphas that have hat matrices
-        for f, j, H, P in folds:
+        if moments and merged and Ad:
+            Ht = torch.empty(F * rows_pad * N * 2, dtype=torch.float16, device=self.dev)
+            rs_inv = torch.empty(F * rows_pad, dtype=torch.float32, device=self.dev)
+            part = torch.empty((F, Ad * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
+            for f0, fc, H, P in hat["Hs"]:
+                ops.split_rows_f16_groups(H.view(-1, N), fc, Ad * M, N, Ht[f0 * rows_pad * N * 2:], rs_inv[f0 * rows_pad:])
+            ops.alpha_sweep_scores_f16x3_folds(Ht, rs_inv, Ad, M, N, Yu, cs[self.Vp:], yv, self.Vp, n_v, ystat, yblk, self.mode,
+                                               part, scores_d, False, views)
+            self.info["folds_per_launch"] = F
+        for f, j, H, P in (() if (moments and merged) else folds):
             b = f if moments else 0
             if not moments:
                 ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat[b], yblk[b], yv[b])
@@ -802,22 +827,26 @@ class RidgeCVEngine:
         return self._eye
 
     def _apply_inverses(self, rhs, P):
-        """(G, rows, N_o) f32 = rhs . P[g] for the (G, N_o, N_o) f32 inverses, on the fp16x3 MFMA (plain contraction:
-        A = the rows of rhs as fp16 triples, B = P with per-column power-of-two scales)."""
-        G, (rows, N_o) = P.shape[0], rhs.shape
+        """(G, rows, N_o) f32 = rhs . P[g] for the (G, N_o, N_o) f32 inverses, on the fp16x3 MFMA."""
         R = ops.scale_cast_f64_f32(rhs, self._one(), torch.empty(rhs.shape, dtype=torch.float32, device=self.dev))
-        rows_pad, Nc = ops.pad_to(rows, 256), ops.pad_to(N_o, 256)
-        At = torch.empty(rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
+        return self._times_symmetric(R, P)
+
+    def _times_symmetric(self, R, mats):
+        """(G, rows, N) f32 = R . mats[g] for SYMMETRIC (N, N) f32 matrices, as plain fp16x3 contractions: A = the rows
+        of R as fp16 triples; column n of the B operand is row n of the matrix, and the tiled images of the two
+        operands have the same layout -- so the row split (coalesced reads, per-row power-of-two scales) of the matrix
+        IS its column split."""
+        G, (rows, N) = mats.shape[0], R.shape
+        rows_pad, Nc = ops.pad_to(rows, 256), ops.pad_to(N, 256)
+        At = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
         rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
-        ops.split_rows_f16(R, rows, N_o, At, rs_inv)
-        Bt = torch.empty(Nc * N_o * 2, dtype=torch.float16, device=self.dev)
+        ops.split_rows_f16(R, rows, N, At, rs_inv)
+        Bt = torch.empty(Nc * N * 2, dtype=torch.float16, device=self.dev)
         cs_inv = torch.empty(Nc, dtype=torch.float32, device=self.dev)
-        out = torch.empty((G, rows, N_o), dtype=torch.float32, device=self.dev)
+        out = torch.empty((G, rows, N), dtype=torch.float32, device=self.dev)
         for g in range(G):
-            # P is symmetric: column n of the B operand is row n of P, and the tiled images of the two operands have the
-            # same layout -- the row split (coalesced reads, per-row power-of-two scales) IS the column split
-            ops.split_rows_f16(P[g], N_o, N_o, Bt, cs_inv)
-            ops.gemm_grouped_f16x3(At, rs_inv, rows, Bt, cs_inv, out[g], N_o, Nc, N_o, [0, Nc // 256])
+            ops.split_rows_f16(mats[g], N, N, Bt, cs_inv)
+            ops.gemm_grouped_f16x3(At, rs_inv, rows, Bt, cs_inv, out[g], N, Nc, N, [0, Nc // 256])
         return out
 
     def _one(self):
@@ -876,6 +905,9 @@ class RidgeCVEngine:
             R = ops.scale_cast_f64_f32(rhs, lmax_o, torch.empty(rhs.shape, dtype=torch.float32, device=self.dev))
             terms = [R]
             for _ in range(1, SERIES_TERMS):
+                if self.precision != "f32":              # 43 GFLOP per step: 0.13 ms on the fp16x3 MFMA, 0.5 ms in f32
+                    terms.append(self._times_symmetric(terms[-1], Kn)[0])
+                    continue
                 Rn = torch.empty_like(R)
                 ops.gemm_grouped(terms[-1], N_o, 0, Kn[0], N_o, None, Rn, N_o, rows, N_o, N_o, [0, N_o // COL_TILE])
                 terms.append(Rn)

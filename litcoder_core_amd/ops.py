@@ -549,6 +549,11 @@ def split_rows_f16(h, rows, K, tiled, rowscale_inv):
     _lib.call("lc_split_rows_f16", _p(h), h.stride(0), rows, K, _p(tiled), _p(rowscale_inv), _s())
 
 
+def split_rows_f16_groups(h, groups, rows, K, tiled, rowscale_inv):
+    """``groups`` consecutive row blocks of ``rows`` rows of h, each padded to whole 256-row tiles in the image."""
+    _lib.call("lc_split_rows_f16_groups", _p(h), h.stride(0), groups, rows, K, _p(tiled), _p(rowscale_inv), _s())
+
+
 def col_scales_f16(y, T, V):
     """(cs, flag): cs[:V] = 2^-e, cs[V:] = 2^e per column; flag (device int32) != 0 when some column's
     dynamic range is too wide for the fp16 hi/lo split."""
@@ -584,6 +589,31 @@ def series_sweep_scores_f16x3(pt, rowscale_inv, M, n_val, K, yt, cscale_inv, Nco
     _lib.call("lc_series_sweep_scores_f16x3", _p(pt), _p(rowscale_inv), M, n_val, K, _p(yt), _p(cscale_inv), Ncols, _p(yv),
               V, _p(ystat), _p(yblk), _p(coef), _p(aidx), aidx.numel(), _p(part), _p(scores), int(bool(accumulate)), *bview,
               _s())
+
+
+def _fold_arrays(n_vals, views):
+    F = len(n_vals)
+    nv = (ctypes.c_int32 * F)(*[int(n) for n in n_vals])
+    b_rows = int(views[0][0]) if views else 0
+    g0 = (ctypes.c_int64 * F)(*[int(v[1]) for v in views])
+    gl = (ctypes.c_int64 * F)(*[int(v[2]) for v in views])
+    return F, nv, b_rows, g0, gl
+
+
+def alpha_sweep_scores_f16x3_folds(ht, rowscale_inv, A, M, N, yt, cscale_inv, yv, V, n_vals, ystat, yblk, mode, part, scores,
+                                   accumulate, views):
+    """All inner folds in one launch (see lc_alpha_sweep_scores_f16x3_folds); views: per fold (b_rows, gap0, gap rows)."""
+    F, nv, b_rows, g0, gl = _fold_arrays(n_vals, views)
+    _lib.call("lc_alpha_sweep_scores_f16x3_folds", _p(ht), _p(rowscale_inv), F, A, M, N, _p(yt), _p(cscale_inv), _p(yv), V,
+              nv, _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), b_rows, g0, gl, _s())
+
+
+def series_sweep_scores_f16x3_folds(pt, rowscale_inv, M, n_vals, K, yt, cscale_inv, Ncols, yv, V, ystat, yblk, coef, aidx,
+                                    part, scores, accumulate, views):
+    F, nv, b_rows, g0, gl = _fold_arrays(n_vals, views)
+    _lib.call("lc_series_sweep_scores_f16x3_folds", _p(pt), _p(rowscale_inv), F, M, nv, K, _p(yt), _p(cscale_inv), Ncols,
+              _p(yv), V, _p(ystat), _p(yblk), _p(coef), _p(aidx), aidx.numel(), _p(part), _p(scores),
+              int(bool(accumulate)), b_rows, g0, gl, _s())
 
 
 def select_alpha(scores, A, V, want_best=True, want_rowsum=False):

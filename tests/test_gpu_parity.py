@@ -390,6 +390,16 @@ def test_shared_target_image_is_bitwise_neutral(lc):
     eng = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
     assert eng._shared_image(inner, 384) is not None
     s_shared, _ = eng._alpha_scores(eng.K, eng.dY, inner)
+    # all inner folds in one launch per pass (lc_*_f16x3_folds: stacked A images, a gap per fold, fold-parallel
+    # finalisation): the same tiles, the same fp32 fold sums -- bit for bit
+    import litcoder_core_amd.nested_cv as ncv
+    keep = ncv.FOLDS_IN_ONE_LAUNCH
+    try:
+        ncv.FOLDS_IN_ONE_LAUNCH = not keep
+        s_other, _ = eng._alpha_scores(eng.K, eng.dY, inner)
+    finally:
+        ncv.FOLDS_IN_ONE_LAUNCH = keep
+    assert torch.equal(s_shared, s_other)
     eng._shared_image = lambda *a: None
     s_plain, _ = eng._alpha_scores(eng.K, eng.dY, inner)
     assert torch.equal(s_shared, s_plain)
