@@ -25,4 +25,7 @@ python3 $R/tools/main_stream_events.py 640000 8 0 > $O/device_timeline_weak_rank
 python3 $R/tools/main_stream_events.py 80000 > $O/device_timeline_1gpu.txt 2>&1
 python3 $R/tools/host_timeline.py 80000 8 0 > $O/host_timeline_rank0_of_8.txt 2>&1
 python3 $R/tools/other_configs.py > $O/other_configs.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cfg1 -o cfg1 -- python3 $R/tools/other_configs.py cfg1 > /dev/null 2>&1 < /dev/null
+python3 $R/tools/kstats.py /tmp/prof_cfg1 40 > $O/cfg1_kernel_stats.txt 2>&1 < /dev/null
+python3 $R/tools/kstats.py /tmp/prof_stats 60 > $O/bench_kernel_stats.txt 2>&1 < /dev/null
 ls -la $O
