@@ -7,6 +7,8 @@ two feature bands) against the CPU oracle on a voxel sample -- with every alpha 
 to be a near-tie of the oracle's own score table (tests/_oracle_check.py).  The oracle (SVD route on the CPU) costs
 seconds per SVD at these sizes, so it sees 48 voxels and, where the config leaves the fold counts open, 3 x 3 folds.
 """
+import random
+
 import numpy as np
 import pytest
 import torch
@@ -282,3 +284,47 @@ def test_primal_form_for_tall_designs(lc):
     assert model64.last_form == "primal" and model64.last_fit["precision"] == "f64 block products"
     np.testing.assert_allclose(np.asarray(ours64[0]["correlations"]), np.asarray(ours[0]["correlations"]), atol=3e-5)
     np.testing.assert_allclose(ours64[1], ours[1], rtol=2e-4, atol=1e-5)
+
+
+def test_block_product_form_on_odd_folds_against_oracle(lc):
+    """The moments form of the primal route (p <= 16, correlation scores: csrc/lc_primal.hip) where its bookkeeping
+    differs from the plain K-fold case: time-series and trimmed folds (inner training sets that are NOT the outer
+    block minus the validation rows -> row sets of their own), group folds (ragged), train-statistics normalisation
+    of features and targets (per-fold data), a single alpha for all voxels, train/test mode, one voxel, raw alphas --
+    against the oracle with the near-tie proof."""
+    import oracle.nested_cv as onc
+    from _oracle_check import assert_matches_oracle
+    rng = np.random.default_rng(2024)
+    cases = [
+        dict(T=310, p=3, V=37, kw=dict(folding_type="timeseries", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 3, 6))),
+        dict(T=402, p=6, V=131, kw=dict(folding_type="chunked_trimmed", n_outer_folds=3, n_inner_folds=2, chunk_length=12,
+                                        alphas=np.logspace(0, 4, 5), single_alpha=True)),
+        dict(T=277, p=5, V=64, kw=dict(folding_type="group", n_outer_folds=3, n_inner_folds=2, alphas=[0.3, 3.0, 30.0],
+                                       groups=True)),
+        dict(T=350, p=9, V=90, kw=dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 2, 4),
+                                       normalize_features=True, normalize_targets=True)),
+        dict(T=300, p=2, V=1, kw=dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=np.logspace(-2, 4, 7),
+                                      normalpha=False)),
+        dict(T=420, p=16, V=203, tt=120, kw=dict(folding_type="chunked", n_inner_folds=3, chunk_length=20,
+                                                 alphas=np.logspace(-1, 3, 5))),
+    ]
+    for i, c in enumerate(cases):
+        T, p, V = c["T"], c["p"], c["V"]
+        X = rng.standard_normal((T, p)) * rng.uniform(0.2, 3.0, p) + rng.uniform(-1, 1, p)
+        Y = X @ (rng.standard_normal((p, V)) * (0.4 / np.sqrt(p))) + rng.standard_normal((T, V)) + 5.0
+        kw = dict(c["kw"])
+        if kw.pop("groups", False):
+            kw["groups"] = rng.integers(0, 11, size=T - c.get("tt", 0))
+        tt = c.get("tt", 0)
+        args = (X[:T - tt], Y[:T - tt])
+        extra = dict(X_test=X[T - tt:], y_test=Y[T - tt:]) if tt else {}
+        random.seed(50 + i); np.random.seed(50 + i)
+        detail = {}
+        oracle = onc.fit_predict(*args, detail=detail, **extra, **kw)
+        random.seed(50 + i); np.random.seed(50 + i)
+        model = lc.NestedCVModel("r")
+        ours = model.fit_predict(*args, **extra, **kw)
+        tag = f"moments case {i}"
+        assert model.last_form == "primal" and model.last_fit["precision"] == "f64 block products", tag
+        assert_matches_oracle(lc, model, ours, oracle, detail, args[0], args[1], kw, tag, corr_atol=3e-5, gap_tol=2e-6,
+                              min_same=0.97, **extra)
