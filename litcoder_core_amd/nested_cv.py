@@ -491,7 +491,6 @@ class RidgeCVEngine:
         ser, cho, d_ser = self.ser, self.cho, self.d_ser
         moments = bool(moments and ser and min(n_v) > 1)
         Ac = len(cho)
-        slots = Ac if moments else A                     # hat matrices kept per inner fold
         per_sys = (N + M) * N * 8
         chunk = max(1, min(F, AUG_BUDGET_BYTES // max(1, per_sys * max(Ac, 1))))
         infos, Hs = [], []
@@ -751,7 +750,7 @@ class RidgeCVEngine:
     def _refit_rhs(self, X, K, tr_rows, tr_o, te_rows):
         """The augmented rows of the refit systems, fp64 (rows, N_o):  Xtr' above K[te,tr]  (primal form: the identity
         above X_te -- the weights ARE (G + a^2 I)^-1 B)."""
-        n_o, n_t = len(tr_rows), len(te_rows)
+        n_t = len(te_rows)
         N_o = tr_o.shape[-1]
         if self.primal:
             rows = ops.pad_to(self.PP + ops.pad_to(n_t, LC_MB), self._refit_row_granule())
@@ -1501,7 +1500,7 @@ class RidgeCVEngine:
 
     def fold_finish(self, st, weight_scale):
         """V-wide half of the refit, test predictions, Pearson r / p-values and the D2H of the results."""
-        tr_rows, te_rows, X, Y = st["tr"], st["te"], st["X"], st["Y"]
+        tr_rows, te_rows, Y = st["tr"], st["te"], st["Y"]
         n_t = len(te_rows)
         if self.moments:
             # per voxel: weights at its alpha from the outer block product, accumulated into W; Pearson r of the test
