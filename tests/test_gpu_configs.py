@@ -328,3 +328,30 @@ def test_block_product_form_on_odd_folds_against_oracle(lc):
         assert model.last_form == "primal" and model.last_fit["precision"] == "f64 block products", tag
         assert_matches_oracle(lc, model, ours, oracle, detail, args[0], args[1], kw, tag, corr_atol=3e-5, gap_tol=2e-6,
                               min_same=0.97, **extra)
+
+
+def test_block_product_form_degenerate_voxels(lc):
+    """NaN, inf and constant target voxels through the moments form: alpha, correlation 0 / p 1, NaN weight columns exactly
+    where the oracle has them; the other voxels unaffected."""
+    import oracle.nested_cv as onc
+    rng = np.random.default_rng(3)
+    T, p, V = 320, 4, 12
+    X = rng.standard_normal((T, p))
+    Y = X @ rng.standard_normal((p, V)) * 0.4 + rng.standard_normal((T, V))
+    Y[5, 3] = np.nan
+    Y[7, 6] = np.inf
+    Y[:, 9] = 0.0
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=[0.1, 1.0, 10.0])
+    random.seed(1)
+    mo, Wo, ao = onc.fit_predict(X, Y, **kw)
+    random.seed(1)
+    model = lc.NestedCVModel("r")
+    m, W, a = model.fit_predict(X, Y, **kw)
+    assert model.last_fit["precision"] == "f64 block products"
+    assert np.array_equal(a, ao)
+    c, co = np.asarray(m["correlations"]), np.asarray(mo["correlations"])
+    assert (c[[3, 6, 9]] == 0).all() and (np.asarray(m["p_values"])[[3, 6, 9]] == 1).all()
+    assert np.array_equal(np.isnan(W).any(0), np.isnan(Wo).any(0)) and np.isnan(W).any(0).nonzero()[0].tolist() == [3, 6]
+    ok = ~np.isnan(W).any(0)
+    np.testing.assert_allclose(c[ok], co[ok], atol=3e-6)
+    np.testing.assert_allclose(W[:, ok], Wo[:, ok], rtol=1e-5, atol=1e-6)
