@@ -430,11 +430,44 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
     };
+    // a 128-row slab with no valid rows (the last M-tile of A x 480 = 1920 score rows is half padding): its waves only
+    // keep up their share of the DMA ring and the barriers; the other wave of each SIMD then has the matrix pipe to
+    // itself and the tile takes half the time -- 1/16 of a fused launch
+    auto kstep_empty = [&](const int kt, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool STEADY = MODE == 0, LAST = MODE == 2;
+        if (STEADY || (!LAST && kt + 4 < KT)) {
+            const int stg = kt & 3;
+            const uint4* pa_ = a_src + (long long)(kt + 4) * CHUNK16;
+            const uint4* pb_ = b_src + (long long)BKT(kt + 4) * CHUNK16;
+            DMA16(pa_, stg * STAGE16);
+            DMA16(pa_ + 512, stg * STAGE16 + 512);
+            DMA16(pb_, stg * STAGE16 + CHUNK16);
+            DMA16(pb_ + 512, stg * STAGE16 + CHUNK16 + 512);
+        }
+        if (LAST) return;
+        if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
+    };
     using Steady = std::integral_constant<int, 0>;
     using Tail = std::integral_constant<int, 1>;
     using Last = std::integral_constant<int, 2>;
+    const bool slab_empty = !SERMOM && !STAMP && mt * TM + wm * 128 >= (SCORE ? sa.Mrows : pa.Mrows);
     int kt = 0;
-    if (LIGHTCAP && light) {
+    if (slab_empty) {
+        for (; kt + 5 < KT; kt += 2) {
+            kstep_empty(kt, Steady{});
+            kstep_empty(kt + 1, Steady{});
+        }
+        for (; kt + 2 < KT; kt += 2) {
+            kstep_empty(kt, Tail{});
+            kstep_empty(kt + 1, Tail{});
+        }
+        kstep_empty(kt, Tail{});
+        kstep_empty(kt + 1, Last{});
+    } else if (LIGHTCAP && light) {
         for (; kt + 5 < KT; kt += 2) {
             kstep_light(kt, fa, fb, Steady{});
             kstep_light(kt + 1, fb, fa, Steady{});
