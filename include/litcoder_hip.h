@@ -471,7 +471,10 @@ int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A
  * 256-column tiles.  d_slab_light: optional (G * pad256(Mrows) / 128) bytes, one per 128-row slab of the tiled
  * image: nonzero = that slab's rows are computed from the fp16 hi parts alone (11-bit operands, one MFMA per
  * product instead of three) -- for rows that enter the caller's result scaled down by 2^-11 or more, such as
- * the higher terms of lc_batch_series_terms. */
+ * the higher terms of lc_batch_series_terms.  ldc may be smaller than Ncols (by less than one 256-column tile): only
+ * the first ldc columns are then stored -- an output whose width is no multiple of the tile, such as the refit
+ * operator  [Xtr' ; K[te,tr]] . (K + a^2 I)^-1  with the inverse from lc_batch_chol_inverse as the B operand (a symmetric
+ * B's lc_split_rows_f16 image IS its column image).  128-row slabs without valid rows skip their MFMAs. */
 int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows,
                           const void* d_bt, const float* d_cscale_inv, float* d_c, int64_t ldc,
                           int64_t Ncols, int64_t K, const int32_t* h_group_tiles, int G,
