@@ -1016,8 +1016,17 @@ class RidgeCVEngine:
                 raise ValueError("x and y must have length at least 2.")      # scipy.stats.pearsonr's message
             inner_abs = [(tr_rows[np.asarray(a, dtype=np.int64)], tr_rows[np.asarray(b, dtype=np.int64)])
                          for a, b in inner_rel]
+            # an inner fold WITHOUT validation rows scores NaN -> 0 for every alpha in the reference (z_score of an
+            # empty block, nan_to_num: ridge_regression.py:124-133) and so adds nothing to the sum the alpha is chosen
+            # from: dropped here, same result.  With no validation rows in ANY inner fold the reference silently takes
+            # alphas[0] for every voxel (the trimmed fold types in train/test mode, where nested_cv.py:130-132 passes
+            # ``groups`` as the trim size, can do that) -- refused here instead.
+            if any(len(v) == 0 for _, v in inner_abs) and any(len(v) > 0 for _, v in inner_abs):
+                logger.warning("inner folds without validation rows contribute nothing to the alpha choice: skipped")
+                inner_abs = [(t, v) for t, v in inner_abs if len(v) > 0]
             if not inner_abs or min(len(t) for t, _ in inner_abs) < 1 or min(len(v) for _, v in inner_abs) < 1:
-                raise ValueError("every inner fold needs at least one training and one validation row")
+                raise ValueError("every inner fold needs at least one training and one validation row (the reference "
+                                 "would score every alpha 0 and take alphas[0] for all voxels)")
             N = ops.pad_to(max(len(t) for t, _ in inner_abs), LC_NB)
             M = ops.pad_to(max(len(v) for _, v in inner_abs), LC_MB)
             metas.append(dict(tr=tr_rows, te=te_rows, inner_abs=inner_abs, N=N, M=M))

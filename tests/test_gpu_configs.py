@@ -355,3 +355,29 @@ def test_block_product_form_degenerate_voxels(lc):
     ok = ~np.isnan(W).any(0)
     np.testing.assert_allclose(c[ok], co[ok], atol=3e-6)
     np.testing.assert_allclose(W[:, ok], Wo[:, ok], rtol=1e-5, atol=1e-6)
+
+
+def test_inner_fold_without_validation_rows_is_skipped(lc):
+    """The reference scores every alpha NaN -> 0 on an empty validation block (ridge_regression.py:124-133), which adds
+    nothing to the sum the alpha is chosen from: the engine drops such a fold -- identical scores -- and refuses the
+    case where no inner fold has validation rows (the reference would take alphas[0] everywhere)."""
+    from litcoder_core_amd.nested_cv import RidgeCVEngine
+    rng = np.random.default_rng(9)
+    T, p, V = 260, 30, 70
+    X = rng.standard_normal((T, p))
+    Y = X @ (rng.standard_normal((p, V)) * 0.1) + rng.standard_normal((T, V))
+    tr, te = np.r_[0:200], np.r_[200:260]
+    good = [(np.r_[0:100], np.r_[100:200]), (np.r_[100:200], np.r_[0:100])]
+    empty = (np.r_[0:200], np.r_[0:0])
+    alphas = np.logspace(-1, 3, 5)
+    scores = []
+    for inner in (good, good + [empty], [empty] + good):
+        eng = RidgeCVEngine(X, Y, alphas, True, True, False, False)
+        eng.begin_fit(1)
+        st = eng.fold_begin(tr, te, inner)
+        scores.append(st["scores"][:, :V].cpu().numpy())
+    assert np.array_equal(scores[0], scores[1]) and np.array_equal(scores[0], scores[2])
+    eng = RidgeCVEngine(X, Y, alphas, True, True, False, False)
+    eng.begin_fit(1)
+    with pytest.raises(ValueError, match="at least one training and one validation row"):
+        eng.fold_begin(tr, te, [empty])

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Random small problems through NestedCVModel.fit_predict against the CPU oracle (tests/_oracle_check.py: every alpha
+that differs must be a proven near-tie of the oracle's own score table).  A bug hunt, not a test: shapes, fold types,
+normalisers, scoring, single / per-voxel alpha, CV / train-test, precisions and all three forms (dual, primal, block
+products) are drawn at random.     python tools/fuzz_vs_oracle.py [n_cases [seed]]"""
+import os
+import random
+import sys
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import litcoder_core_amd as lc  # noqa: E402
+import oracle.nested_cv as onc  # noqa: E402
+from _oracle_check import assert_matches_oracle  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+fails = skipped = 0
+forms = {}
+for case in range(n_cases):
+    T = int(rng.integers(90, 420))
+    p = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 40, 70, 130, 300]))
+    V = int(rng.choice([1, 3, 17, 64, 100, 129, 257, 300]))
+    fold = str(rng.choice(["kfold", "chunked", "kfold_trimmed", "chunked_trimmed", "timeseries", "group"]))
+    use_corr = bool(rng.random() < 0.8)
+    kw = dict(folding_type=fold, n_outer_folds=int(rng.integers(2, 4)), n_inner_folds=int(rng.integers(2, 4)),
+              alphas=np.logspace(rng.uniform(-2, 0), rng.uniform(1, 5), int(rng.integers(1, 9))),
+              normalpha=bool(rng.random() < 0.7), use_corr=use_corr, single_alpha=bool(rng.random() < 0.25),
+              normalize_features=bool(rng.random() < 0.2), normalize_targets=bool(rng.random() < 0.2))
+    if "chunked" in fold:
+        kw["chunk_length"] = int(rng.integers(5, 30))
+    tt = int(rng.integers(30, 90)) if rng.random() < 0.3 else 0
+    if fold == "group":
+        kw["groups"] = rng.integers(0, 8, size=T - tt)
+    signal = 1.0 if not use_corr else float(rng.choice([0.3, 1.0]))
+    X = rng.standard_normal((T, p)) * rng.uniform(0.5, 2.0, p)
+    Y = X @ (rng.standard_normal((p, V)) * (signal / np.sqrt(p))) + rng.standard_normal((T, V)) + rng.uniform(-3, 3)
+    args = (X[:T - tt], Y[:T - tt])
+    extra = dict(X_test=X[T - tt:], y_test=Y[T - tt:]) if tt else {}
+    kw_run = {k: v for k, v in kw.items() if not (tt and k == "n_outer_folds")}
+    precision = str(rng.choice(["auto", "auto", "f32"]))
+    tag = f"case {case}: T{T} p{p} V{V} {fold} tt{tt} {precision} " + " ".join(
+        f"{k}={v}" for k, v in kw.items() if k not in ("alphas", "groups", "folding_type")) + f" A={len(kw['alphas'])}"
+    try:
+        random.seed(case); np.random.seed(case)
+        detail = {}
+        try:
+            oracle = onc.fit_predict(*args, detail=detail, **extra, **kw_run)
+        except ValueError as e:                              # a configuration the reference itself rejects
+            random.seed(case); np.random.seed(case)
+            try:
+                lc.NestedCVModel("r", precision=precision).fit_predict(*args, **extra, **kw_run)
+                raise AssertionError(f"the oracle raises ({e}) but the fit went through")
+            except ValueError:
+                print("skip", tag, "-> both raise ValueError", flush=True)
+                skipped += 1
+                continue
+        random.seed(case); np.random.seed(case)
+        model = lc.NestedCVModel("r", precision=precision)
+        ours = model.fit_predict(*args, **extra, **kw_run)
+        r2 = not use_corr
+        # one alpha for all voxels flips for all of them at once; with one feature and correlation scores the prediction
+        # is the same vector up to scale for every alpha: every alpha ties (the near-tie proof still runs)
+        free = kw["single_alpha"] or (p == 1 and use_corr)
+        assert_matches_oracle(lc, model, ours, oracle, detail, args[0], args[1], kw_run, tag, min_same=0.0 if free else 0.9,
+                              corr_atol=2e-3 if r2 else 5e-5, gap_tol=4e-3 if r2 else 4e-6, **extra)
+        key = model.last_form + ("/blocks" if model.last_fit.get("precision") == "f64 block products" else "")
+        forms[key] = forms.get(key, 0) + 1
+        print("ok  ", tag, "->", key, flush=True)
+    except Exception as e:                                   # noqa: BLE001
+        fails += 1
+        print("FAIL", tag, "\n     ", type(e).__name__, str(e)[:400], flush=True)
+        if not isinstance(e, (AssertionError, ValueError)):
+            traceback.print_exc()
+print(f"{n_cases - fails - skipped} of {n_cases - skipped} valid cases agree with the oracle ({skipped} rejected by both); forms: {forms}")
+sys.exit(1 if fails else 0)
