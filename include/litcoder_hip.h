@@ -163,10 +163,12 @@ int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, 
 /* The same for up to 32 row sets of ONE Gram matrix in a single pass over K per iteration: bit f of
  * d_member[i] (T x uint32) says whether row i belongs to system f.  Every fold of a nested CV (outer
  * train sets and their inner train sets) is a principal submatrix of K, so one call serves the whole fit.
- * d_work: F*(3*T + 2*steps + 8) + 4*32*T f64 (the matvec is split over four column ranges whose partial sums
- * are added in fixed order).  d_lmax: (F) f64. */
+ * d_work: F*(3*T + 2*steps + 8) + 16*32*T f64 (the matvec -- K times the 32 systems' vectors on the fp64 MFMA -- is
+ * split over up to 16 column ranges whose partial sums are added in fixed order).  d_lmax: (F) f64.
+ * lc_debug_lanczos_mfma(0 / 1): diagnostics, 0 = the vector-ALU matvec of round 1; returns the setting. */
 int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
                          double* d_work, double* d_lmax, lc_stream_t stream);
+int lc_debug_lanczos_mfma(int on);
 
 /* a2[f*A + a] = (alphas[a] * (normalpha ? sqrt(lmax[f]) : 1))^2
  * (ridge_regression.py:99-101,117: D = S/(S^2 + nalpha^2)). */

@@ -63,6 +63,7 @@ SIGNATURES = {
                                  c_int, _ptr, c_int64, _ptr]),
     "lc_primal_refit": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int64, c_int, c_int, _ptr, _ptr, _ptr,
                                 c_int, c_float, _ptr, c_int64, _ptr, _ptr]),
+    "lc_debug_lanczos_mfma": (c_int, [c_int]),
     "lc_lambda_max_strided": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_fill_argmax": (c_int, [_ptr, c_int, _ptr, c_int64, _ptr]),
     "lc_fold_pack": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr, c_int, _ptr, c_int, _ptr, c_int64, _ptr]),

@@ -351,6 +351,63 @@ __global__ void __launch_bounds__(256) k_lz_symv_multi(const double* __restrict_
     }
 }
 
+// The same product on the fp64 MFMA (v_mfma_f64_16x16x4): as a vector-ALU kernel the matvec above is bound by its LDS
+// reads -- one broadcast read of K per FMA, 2.6 GB of LDS traffic per iteration, 48 us -- while K itself is 72 MB.
+// Here a block holds 64 rows (a wave 16) and a 32-column tile of K plus the 32 systems' vector slices in LDS, a lane
+// reads ONE K element and two V elements per pair of MFMAs (16 rows x 4 k x 32 systems), and 16 column splits put
+// ~750 blocks in flight, so that the iteration is bound by streaming K.  Output: the same column-split partial sums.
+constexpr int LZQ_ROWS = 64, LZQ_JT = 32, LZQ_SPLIT = 8, LZQ_LD = LZQ_JT + 2;
+typedef double lzq_f64x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_lz_symv_mfma(const double* __restrict__ Kmat, long long ldk, int T, int F,
+                                                      int steps, double* work, double* __restrict__ part, int jspan) {
+    __shared__ double Ks[LZQ_ROWS][LZQ_LD];            // [row][k]
+    __shared__ double Vs[32][LZQ_LD];                  // [system][k]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+    const int i0 = blockIdx.x * LZQ_ROWS;
+    const int jb = blockIdx.y * jspan, je = min(T, jb + jspan);
+    if (jb >= je) return;
+    double kreg[8], vreg[4];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q, r = e >> 5, j = j0 + (e & 31);
+            kreg[q] = (i0 + r < T && j < je) ? Kmat[(long long)(i0 + r) * ldk + j] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, n = e >> 5, j = j0 + (e & 31);
+            vreg[q] = (n < F && j < je) ? lz_base(work, n, T, steps)[j] : 0.0;
+        }
+    };
+    lzq_f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    fetch(jb);
+    for (int j0 = jb; j0 < je; j0 += LZQ_JT) {
+        __syncthreads();                               // previous tile consumed
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int e = tid + 256 * q; Ks[e >> 5][e & 31] = kreg[q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int e = tid + 256 * q; Vs[e >> 5][e & 31] = vreg[q]; }
+        __syncthreads();
+        if (j0 + LZQ_JT < je) fetch(j0 + LZQ_JT);
+#pragma unroll
+        for (int k4 = 0; k4 < LZQ_JT / 4; ++k4) {
+            const double a = Ks[w * 16 + li][4 * k4 + lq];
+            const double b0 = Vs[li][4 * k4 + lq], b1 = Vs[16 + li][4 * k4 + lq];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+        }
+    }
+    // accumulator r of a lane: row lq + 4 r of the wave's 16, system li (acc0) / 16 + li (acc1)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + w * 16 + lq + 4 * r;
+        if (i < T) {
+            if (li < F) part[((long long)blockIdx.y * 32 + li) * T + i] = acc0[r];
+            if (16 + li < F) part[((long long)blockIdx.y * 32 + 16 + li) * T + i] = acc1[r];
+        }
+    }
+}
+
 __global__ void k_penalties(const double* __restrict__ lmax, int F, const double* __restrict__ alphas, int A,
                             int normalpha, double* __restrict__ a2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -717,6 +774,12 @@ extern "C" int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_ro
     return lc_lambda_max_strided(d_k, ldk, 0, d_rows, F, N, steps, d_work, d_lmax, stream);
 }
 
+static int g_lz_mfma = 1;       // masked multi-system matvec: 1 = fp64 MFMA (k_lz_symv_mfma), 0 = vector ALU (k_lz_symv_multi)
+extern "C" int lc_debug_lanczos_mfma(int on) {
+    if (on == 0 || on == 1) g_lz_mfma = on;
+    return g_lz_mfma;
+}
+
 extern "C" int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
                                     double* d_work, double* d_lmax, lc_stream_t stream) {
     LC_REQUIRE(d_k && d_member && d_work && d_lmax, LC_E_BADARG, "lc_lambda_max_masked: null pointer");
@@ -726,12 +789,18 @@ extern "C" int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const
     lc::ScopedTimer timer_(lc::T_LAMBDA_MAX, s);
     hipLaunchKernelGGL(k_lz_init_masked, dim3(F), dim3(256), 0, s, d_member, T, steps, d_work);
     if (int rc = lc::launched("k_lz_init_masked")) return rc;
-    double* part = d_work + (long long)F * (3ll * T + 2ll * steps + 8);      // (LZM_SPLIT, 32, T) partial matvecs
-    const int jspan = lc::ceil_div(lc::ceil_div(T, LZM_SPLIT), LZM_JT) * LZM_JT;
+    double* part = d_work + (long long)F * (3ll * T + 2ll * steps + 8);      // (LZQ_SPLIT, 32, T) partial matvecs
+    const bool mfma = g_lz_mfma != 0;
+    const int jspan = mfma ? lc::ceil_div(lc::ceil_div(T, LZQ_SPLIT), LZQ_JT) * LZQ_JT
+                           : lc::ceil_div(lc::ceil_div(T, LZM_SPLIT), LZM_JT) * LZM_JT;
     const int nsplit = lc::ceil_div(T, jspan);
     for (int it = 0; it < steps; ++it) {
-        hipLaunchKernelGGL(k_lz_symv_multi, dim3((unsigned)lc::ceil_div(T, LZM_ROWS), (unsigned)nsplit), dim3(256), 0, s, d_k,
-                           (long long)ldk, d_member, T, F, steps, d_work, part, jspan);
+        if (mfma)
+            hipLaunchKernelGGL(k_lz_symv_mfma, dim3((unsigned)lc::ceil_div(T, LZQ_ROWS), (unsigned)nsplit), dim3(256), 0, s, d_k,
+                               (long long)ldk, T, F, steps, d_work, part, jspan);
+        else
+            hipLaunchKernelGGL(k_lz_symv_multi, dim3((unsigned)lc::ceil_div(T, LZM_ROWS), (unsigned)nsplit), dim3(256), 0, s, d_k,
+                               (long long)ldk, d_member, T, F, steps, d_work, part, jspan);
         hipLaunchKernelGGL(k_lz_step, dim3(F), dim3(1024), 0, s, T, steps, it, d_work, (const double*)part, nsplit,
                            (const unsigned*)d_member);
     }

@@ -312,7 +312,7 @@ def lambda_max(k, rows, F, N, steps):
 
 def lambda_max_masked(k, T, member, F, steps, out=None):
     """lambda_max of K[I_f, I_f] for F <= 32 row sets given as bit f of member[i] (int32 tensor of T words)."""
-    work = torch.empty(F * (3 * T + 2 * steps + 8) + 4 * 32 * T, dtype=torch.float64, device=k.device)
+    work = torch.empty(F * (3 * T + 2 * steps + 8) + 16 * 32 * T, dtype=torch.float64, device=k.device)
     if out is None:
         out = torch.empty(F, dtype=torch.float64, device=k.device)
     _lib.call("lc_lambda_max_masked", _p(k), k.stride(0), T, _p(member), F, steps, _p(work), _p(out), _s())

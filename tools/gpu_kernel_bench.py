@@ -208,8 +208,15 @@ if "lanczos" in what:
     got = ops.lambda_max_masked(K3, T3, member, len(sets), 64).cpu().numpy()
     Kh = K3.cpu().numpy()
     ref = np.array([np.linalg.eigvalsh(Kh[np.ix_(r_, r_)])[-1] for r_ in sets[:6]])
-    print(f"lambda_max_masked 30 systems T=3000 steps=64: {ms:.2f} ms; max rel err vs eigvalsh (first 6): "
-          f"{np.max(np.abs(got[:6] / ref - 1)):.2e}")
+    print(f"lambda_max_masked 30 systems T=3000 steps=64 (fp64 MFMA matvec): {ms:.2f} ms; max rel err vs eigvalsh "
+          f"(first 6): {np.max(np.abs(got[:6] / ref - 1)):.2e}")
+    from litcoder_core_amd import _lib
+    _lib.load().lc_debug_lanczos_mfma(0)
+    ms0 = timeit(lambda: ops.lambda_max_masked(K3, T3, member, len(sets), 64), reps=3, warm=1)
+    got0 = ops.lambda_max_masked(K3, T3, member, len(sets), 64).cpu().numpy()
+    _lib.load().lc_debug_lanczos_mfma(1)
+    print(f"   vector-ALU matvec (round 1): {ms0:.2f} ms; max rel difference of the 30 values: "
+          f"{np.max(np.abs(got / got0 - 1)):.2e}")
 
 if "chol" in what:
     rng = np.random.default_rng(1)
