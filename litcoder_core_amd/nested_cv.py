@@ -233,6 +233,7 @@ class RidgeCVEngine:
         self._base_scales = None                       # (cs, split) of the resident targets, see _target_scales
         self.sweeps_done = None                        # end of the sweeps queued last (chain_gate)
         self._natural = None                           # 0 .. V-1 on the device (moments form: results in voxel order)
+        self._host_weights = None                      # future of the page-locked result buffer (reserve_host_weights)
         # what this fit ran, for the caller (NestedCVModel.last_fit; bench.py prices the roofline with it): arithmetic
         # of the sweeps, alphas scored inside the fused launch, algorithmic flops of the plain fp16x3 GEMMs.  Per
         # engine: two fits in one process do not share it.
@@ -1615,10 +1616,21 @@ class RidgeCVEngine:
         """The (p, V) float32 weights as a host array.  The array lives in page-locked memory (the D2H copy is then one
         DMA at link rate instead of a staged copy through the driver: 0.98 GB at cfg2); it is an ordinary numpy array
         that owns its buffer through torch's caching host allocator."""
-        h = torch.empty((self.p, self.V), dtype=torch.float32, pin_memory=True)
+        h = self._host_weights.result() if self._host_weights is not None else \
+            torch.empty((self.p, self.V), dtype=torch.float32, pin_memory=True)
+        self._host_weights = None
         h.copy_(self.W_acc[:, : self.V], non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return h.numpy()
+
+    def reserve_host_weights(self):
+        """Page-lock the result buffer NOW, on a worker thread: when the caller still holds the previous fit's weights
+        the caching host allocator has no free block of that size and hipHostMalloc of 0.98 GB takes ~50 ms -- beside
+        the fit's GPU work instead of after it."""
+        if self._host_weights is None and self.dev.type == "cuda":
+            _, pool = ops._upload_ring()
+            shape = (self.p, self.V)
+            self._host_weights = pool.submit(lambda: torch.empty(shape, dtype=torch.float32, pin_memory=True))
 
 
 def _alpha_vector(alphas, idx, single_alpha):
@@ -1799,6 +1811,8 @@ class NestedCVModel(BasePredictivityModel):
                 any_nan.append(bool(np.isnan(r32).any()))
 
             pending = None
+            if weights_on_host:
+                eng.reserve_host_weights()
             eng.alpha_fdr = alpha_fdr
             n = len(outer)
             eng.begin_fit(n)                                    # the one host sync of the set-up, before anything is queued

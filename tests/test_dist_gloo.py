@@ -93,6 +93,8 @@ class OracleEngine:
         pc = stats.fisher_combine(np.stack(self.p_rows))
         sig, padj = stats.fdrcorrection(pc, alpha=self.alpha_fdr)
         return pc, sig, padj
+    def reserve_host_weights(self):
+        pass
     def weights(self):
         return self.W
 
