@@ -466,6 +466,12 @@ int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A
                             int64_t V, int n_val, const float* d_ystat, float* d_part,
                             unsigned long long* d_stamps, lc_stream_t stream);
 
+/* Diagnostics only (tools/gpu_kernel_bench.py plain16): the single-group plain contraction of lc_gemm_grouped_f16x3 on
+ * v_mfma_f32_16x16x32_f16 instead of 32x32x16 (an experiment kernel; not used by the product path). */
+int lc_debug_gemm_f16x3_wide(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
+                             const float* d_cscale_inv, float* d_c, int64_t ldc, int64_t Ncols, int64_t K,
+                             lc_stream_t stream);
+
 /* Grouped GEMM of the refit (lc_gemm_grouped_f32's job) on the same fp16x3 scheme:
  * C[:, tile] = A_g(tile) . B[:, tile].  d_at: G tiled images made by lc_split_rows_f16 (one per group, each
  * pad256(Mrows) rows), d_rowscale_inv: (G * pad256(Mrows)); d_bt: tiled image of B (K x Ncols) made by

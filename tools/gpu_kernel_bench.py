@@ -137,6 +137,14 @@ if "plain16" in what:
             err_l = float((C2[128:132, :512].double() - ref_l).abs().max() / ref_l.abs().max())
             print(f"   with light slabs (8 of 16): {ms_l:.2f} ms; rel err of a light row {err_l:.1e}")
         fl = 2.0 * rows * K * V
+        from litcoder_core_amd import _lib
+        Cw = torch.zeros((rows, Vt), dtype=torch.float32, device=dev)
+        fw = lambda: _lib.call("lc_debug_gemm_f16x3_wide", ops._p(At), ops._p(rs), rows, ops._p(Yt), ops._p(cs_inv), ops._p(Cw),
+                               Vt, Vt, K, ops._s())
+        ms_w = timeit(fw)
+        dw = float((Cw[:, :V] - C[:, :V]).abs().max() / C[:, :V].abs().max())
+        print(f"   the same on v_mfma_f32_16x16x32_f16 (experiment kernel): {ms_w:.2f} ms; max difference to the 32x32x16 "
+              f"result {dw:.1e} of the largest entry")
         ref = Amat[:4].double() @ Y[:, :512].double()
         err = float((C[:4, :512].double() - ref).abs().max() / ref.abs().max())
         print(f"plain f16x3 GEMM {label} ({rows} x {K} x {V}): {ms:.2f} ms -> {fl / ms / 1e9:.1f} TFLOP/s algorithmic, "
