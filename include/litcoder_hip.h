@@ -152,6 +152,11 @@ int lc_pearson_pvalues(const double* d_r, int64_t V, int64_t n, double* d_p, lc_
  * are row/column subsets of this one matrix. */
 int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_k, int64_t ldk,
                 lc_stream_t stream);
+/* The same matrix through the fp64 MFMA (the deep-update kernel of lc_batch_chol_solve as one "N x T" product of the
+ * widened design, lower-triangle tiles computed and mirrored): 3x the rate of the vector-ALU kernel, equal to it to
+ * the rounding of the fp64 sums.  d_work: T * pad16(p) doubles. */
+int lc_gram_f64_mfma(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_work, double* d_k,
+                     int64_t ldk, lc_stream_t stream);
 
 /* Largest eigenvalue of K[rows_f, rows_f] for F row lists (each N entries, -1 padded)
  * by `steps` Lanczos iterations + bisection: S[0]^2 of the fold's design matrix

@@ -44,6 +44,7 @@ SIGNATURES = {
     "lc_pearson_cols": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64, _ptr, _ptr]),
     "lc_pearson_pvalues": (c_int, [_ptr, c_int64, c_int64, _ptr, _ptr]),
     "lc_gram_f64": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, c_int64, _ptr]),
+    "lc_gram_f64_mfma": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, c_int64, _ptr]),
     "lc_lambda_max": (c_int, [_ptr, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_lambda_max_masked": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_penalties": (c_int, [_ptr, c_int, _ptr, c_int, c_int, _ptr, _ptr]),

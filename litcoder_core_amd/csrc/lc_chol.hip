@@ -928,3 +928,46 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
     else hipLaunchKernelGGL(k_extract_h, dim3(M, B), dim3(256), 0, s, d_aug, N, M, d_h, d_slot);
     return lc::launched("k_extract_h");
 }
+
+// ------------------------------------------------------------------ Gram matrix on the fp64 MFMA
+// K = X X' (fp32 inputs, fp64 products and sums) as one "N x T" product of the deep-update kernel: the vector-ALU
+// kernel of lc_gram_f64 is bound by its LDS reads (one 8-byte read per two FMAs: 20 TFLOP/s), k_mm64q runs the same
+// flops at the matrix pipe's rate.  X is widened to fp64 once (zero-padded to 16 columns), the lower-triangle tiles
+// are computed, the rest mirrored.  d_work: T * pad16(p) doubles.
+namespace {
+__global__ void __launch_bounds__(256) k_widen_f32_f64(const float* __restrict__ x, long long ldx, int p, int p16,
+                                                       double* __restrict__ out) {
+    const long long r = blockIdx.x;
+    for (int c = threadIdx.x; c < p16; c += 256) out[r * p16 + c] = c < p ? (double)x[r * ldx + c] : 0.0;
+}
+__global__ void __launch_bounds__(256) k_mirror_upper(double* __restrict__ K, long long ldk, int T) {
+    const int i = blockIdx.x;                              // row i takes K[i][j] = K[j][i] for the tiles right of its own
+    for (int j = (i / MQ_TS + 1) * MQ_TS + threadIdx.x; j < T; j += 256) K[(long long)i * ldk + j] = K[(long long)j * ldk + i];
+}
+}  // namespace
+
+extern "C" int lc_gram_f64_mfma(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_work, double* d_k,
+                                int64_t ldk, lc_stream_t stream) {
+    LC_REQUIRE(d_x && d_work && d_k, LC_E_BADARG, "lc_gram_f64_mfma: null pointer");
+    LC_REQUIRE(T > 0 && p > 0 && ldx >= p && ldk >= T && T < (1 << 30) && p < (1 << 30), LC_E_SHAPE,
+               "lc_gram_f64_mfma: bad shape");
+    hipStream_t s = lc::as_stream(stream);
+    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_mm64q<true>), MQ_LDS_BYTES)) return rc;
+    const int p16 = (int)((p + 15) / 16 * 16);
+    lc::ScopedTimer timer_(lc::T_GRAM, s);
+    hipLaunchKernelGGL(k_widen_f32_f64, dim3((unsigned)T), dim3(256), 0, s, d_x, (long long)ldx, (int)p, p16, d_work);
+    MMArgs g{};
+    g.a = g.b = d_work;
+    g.c = d_k;
+    g.lda = g.ldb = p16;
+    g.ldc = ldk;
+    g.rows = g.cols = (int)T;
+    g.depth = p16;
+    g.row0 = g.col0 = 0;
+    g.tri = 1;
+    g.subtract = 0;
+    const dim3 grid((unsigned)lc::ceil_div<long long>(T, MQ_TS), (unsigned)lc::ceil_div<long long>(T, MQ_TS), 1);
+    hipLaunchKernelGGL((k_mm64q<true>), grid, dim3(256), MQ_LDS_BYTES, s, g);
+    hipLaunchKernelGGL(k_mirror_upper, dim3((unsigned)T), dim3(256), 0, s, d_k, (long long)ldk, (int)T);
+    return lc::launched("lc_gram_f64_mfma");
+}
