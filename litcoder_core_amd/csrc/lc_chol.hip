@@ -37,14 +37,15 @@ __device__ inline double rsqrt_nr(double d) {
     return r;
 }
 
-__global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ aug, int N, int M, int k,
-                                                    double* __restrict__ linv, int* __restrict__ info) {
-    __shared__ double L[NB * PD_LD];
-    __shared__ double rdiag[NB];                       // 1 / L[i][i]
-    const int b = blockIdx.x;
+// The body, for the workgroup of system b (256 threads): L = NB x PD_LD doubles and rdiag = NB doubles of LDS.
+// PRELOADED: the caller has put the tile into L already (a barrier follows here either way).
+template <bool PRELOADED>
+__device__ inline void potrf_diag_tile(double* __restrict__ aug, int N, int M, int k, int b, double* __restrict__ linv,
+                                       int* __restrict__ info, double* L, double* rdiag) {
     const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
     double* a = aug + (long long)b * (N + M) * N + (long long)k * NB * N + k * NB;
-    for (int e = t; e < NB * NB; e += 256) L[(e >> 6) * PD_LD + (e & 63)] = a[(long long)(e >> 6) * N + (e & 63)];
+    if (!PRELOADED)
+        for (int e = t; e < NB * NB; e += 256) L[(e >> 6) * PD_LD + (e & 63)] = a[(long long)(e >> 6) * N + (e & 63)];
     __syncthreads();
     // Four columns per step (16 steps, two barriers each): every thread factors the 4 x 4 pivot block redundantly
     // in registers, transforms the panel rows it needs on the fly (l = a G^-T, six FMAs) and applies the rank-4
@@ -137,6 +138,13 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ aug, in
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ aug, int N, int M, int k,
+                                                    double* __restrict__ linv, int* __restrict__ info) {
+    __shared__ double L[NB * PD_LD];
+    __shared__ double rdiag[NB];                       // 1 / L[i][i]
+    potrf_diag_tile<false>(aug, N, M, k, blockIdx.x, linv, info, L, rdiag);
 }
 
 // ------------------------------------------------------------------ fp64 MFMA tile product
@@ -637,7 +645,7 @@ __device__ inline void tile_mac(double (&acc)[4][4], const double* A, long long 
 #define LC_FOR_TILE(i, j) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)
 
 __global__ void __launch_bounds__(256, 3) k_lstep(double* __restrict__ aug, int N, int M, int k, int K0, int K1,
-                                                  const double* __restrict__ linv) {
+                                                  double* __restrict__ linv, int* __restrict__ info) {
     __shared__ double sA[NB * MM_LD], sB[NB * MM_LD], sC[NB * ST_LDC];
     const int R = N + M, nb = N / NB;
     const int i_t = k + 1 + blockIdx.x, b = blockIdx.y;
@@ -679,11 +687,18 @@ __global__ void __launch_bounds__(256, 3) k_lstep(double* __restrict__ aug, int 
         __syncthreads();                               // tile_mac fetches B (= sC here) before its first barrier
         tile_mac<true, true>(acc, sC, 0, a_rows, sC, ST_LDC, NB, sA, sB);
     }
-    {
-        double* dst = Arow + (k + 1) * NB;
-        double old[4][4];
-        LC_FOR_TILE(i, j) old[i][j] = LC_TILE_ROW(i) < a_rows ? dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] : 0.0;
-        LC_FOR_TILE(i, j) if (LC_TILE_ROW(i) < a_rows) dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] = old[i][j] - acc[i][j];
+    double* dst = Arow + (k + 1) * NB;
+    double old[4][4];
+    LC_FOR_TILE(i, j) old[i][j] = LC_TILE_ROW(i) < a_rows ? dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] : 0.0;
+    LC_FOR_TILE(i, j) old[i][j] -= acc[i][j];
+    LC_FOR_TILE(i, j) if (LC_TILE_ROW(i) < a_rows) dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] = old[i][j];
+    // (4) the workgroup of row tile k+1 has just completed the NEXT diagonal tile: it factors it right away (L, Linv:
+    // potrf_diag_tile on the values at hand, in the LDS of sC / sA) -- one launch per step instead of two, and the
+    // diagonal factorisation runs beside the other workgroups' tiles instead of after them
+    if (own) {
+        __syncthreads();                               // sC was an operand of the product above
+        LC_FOR_TILE(i, j) sC[LC_TILE_ROW(i) * PD_LD + LC_TILE_COL(j)] = old[i][j];
+        potrf_diag_tile<true>(aug, N, M, k + 1, b, linv, info, sC, sA);
     }
 }
 
@@ -836,14 +851,17 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
             launch_big<true>(g, B, s);
         }
         for (int k = K0; k < K1; ++k) {
-            hipLaunchKernelGGL(k_potrf_diag, dim3(B), dim3(256), 0, s, d_aug, N, M, k, d_linv, d_info);
+            // fused steps: only the first diagonal tile of an outer block (completed by the deep update) needs a launch
+            // of its own -- the others are factored by the previous step's workgroup of that row tile (k_lstep (4))
+            if (!fused || k == K0)
+                hipLaunchKernelGGL(k_potrf_diag, dim3(B), dim3(256), 0, s, d_aug, N, M, k, d_linv, d_info);
             const int below = (k + 1) * NB;                  // first row under the diagonal tile
             if (fused) {
                 // inverse: bottom row tiles 0 .. k only (tile r is zero left of block column r)
                 const int tiles = inverse ? (nb - k - 1) + min(M / NB, k + 1) : lc::ceil_div(R - below, NB);
                 if (tiles > 0)
                     hipLaunchKernelGGL(k_lstep, dim3((unsigned)tiles, (unsigned)B), dim3(256), 0, s, d_aug, N, M, k, K0, K1,
-                                       d_linv);
+                                       d_linv, d_info);
                 continue;
             }
             // panel:  P <- P Linv_kk'   (rows below the diagonal tile, including the M augmented rows; in place)

@@ -49,6 +49,7 @@ SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singc
 PRIMAL_MAX_SCALE_RATIO = 64.0       # ... and whose feature column norms lie within this factor of each other (fp16x3)
 REFIT_BY_INVERSE = True             # refit operators through the explicit inverse + one fp16x3 product (_refit_by_inverse)
 REFIT_INVERSE_MIN_ALPHA = 0.05      # ... for alphas (in units of S[0]) from here on
+REFIT_INVERSE_MAX_WORLD = 4         # ... and up to this many voxel-shard ranks
 FOLDS_IN_ONE_LAUNCH = False         # one launch per pass for all inner folds of an outer fold (_sweeps): measured neutral at
                                     # 10 000 voxels per rank and 2 ms slower at 80 000 -- off; kept (and tested) as an option
 SERIES_FUSED_MOMENTS = True         # series terms reduced to moments in the contraction's epilogue (never stored)
@@ -816,7 +817,11 @@ class RidgeCVEngine:
         triples afterwards anyway (the V-wide contraction), but in the product R P the entries of P ~ 1/a^2 cancel
         down to ~ 1/(2 a S0): the relative error is ~ 2^-22 x 2 S0 / a = 2^-21 / alpha for alpha S[0] scaling -- taken
         for alpha >= 0.05 (< 1e-5), on the fp16x3 path, with normalpha (S[0] known); the solves otherwise."""
+        # (voxel shards: every rank applies every inverse it needs itself -- the same products on every rank -- while
+        # the row-sliced solves shrink with the ranks: measured per simulated rank 81.8 vs 84.2 ms at 2, 53.6 vs 53.8
+        # at 4, 40.2 vs 39.0 ms at 8 ranks; so the solves from 8 ranks on)
         return (REFIT_BY_INVERSE and self.normalpha and not self.primal and self.precision != "f32"
+                and self.shard.world <= REFIT_INVERSE_MAX_WORLD
                 and len(alphas_idx) > 0 and min(self.alphas[a] for a in alphas_idx) >= REFIT_INVERSE_MIN_ALPHA)
 
     def _identity_rows(self, N_o):
