@@ -84,20 +84,22 @@ __device__ inline void potrf_diag_tile(double* __restrict__ aug, int N, int M, i
         const double l1 = ((x1) - l0 * g10) * r1;                         \
         const double l2 = ((x2) - l0 * g20 - l1 * g21) * r2;              \
         const double l3 = ((x3) - l0 * g30 - l1 * g31 - l2 * g32) * r3;
-        for (int i = j + 4 + ti; i < NB; i += 16) {
-            const double* ai = L + i * PD_LD + j;
-            LC_ROW_TRANSFORM(ai[0], ai[1], ai[2], ai[3], li0, li1, li2, li3)
-            for (int c = j + 4 + tj; c <= i; c += 16) {
-                const double* ac = L + c * PD_LD + j;
-                LC_ROW_TRANSFORM(ac[0], ac[1], ac[2], ac[3], lc0, lc1, lc2, lc3)
-                L[i * PD_LD + c] -= li0 * lc0 + li1 * lc1 + li2 * lc2 + li3 * lc3;
-            }
-        }
-        __syncthreads();                              // all reads of the unscaled panel are done
-        for (int i = j + 4 + t; i < NB; i += 256) {
-            double* ai = L + i * PD_LD + j;
+        // the panel rows are transformed ONCE (one thread per row, in place), then the rank-4 update reads them: the
+        // first version transformed the rows it needed on the fly inside the update -- 16 x the arithmetic of this
+        // phase for one barrier's worth of latency that the pivot block above hides anyway
+        if (j + 4 + t < NB) {
+            double* ai = L + (j + 4 + t) * PD_LD + j;
             LC_ROW_TRANSFORM(ai[0], ai[1], ai[2], ai[3], l0, l1, l2, l3)
             ai[0] = l0; ai[1] = l1; ai[2] = l2; ai[3] = l3;
+        }
+        __syncthreads();                              // the scaled panel is complete
+        for (int i = j + 4 + ti; i < NB; i += 16) {
+            const double* ai = L + i * PD_LD + j;
+            const double li0 = ai[0], li1 = ai[1], li2 = ai[2], li3 = ai[3];
+            for (int c = j + 4 + tj; c <= i; c += 16) {
+                const double* ac = L + c * PD_LD + j;
+                L[i * PD_LD + c] -= li0 * ac[0] + li1 * ac[1] + li2 * ac[2] + li3 * ac[3];
+            }
         }
 #undef LC_ROW_TRANSFORM
         if (t == 255) {                               // the pivot block itself
