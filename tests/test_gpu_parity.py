@@ -338,6 +338,14 @@ def test_batch_chol_solve_against_fp64_solves(lc):
         info = ops.batch_chol_solve(torch.from_numpy(bad).to(dev), 1, 64, 32,
                                     torch.empty((1, 32, 64), dtype=torch.float32, device=dev))
         assert info.cpu().numpy()[0] != 0
+        # ... also when the tile is factored inside the step kernel (block columns 1, 2 of an outer block)
+        for blk in (1, 2):
+            bad = np.zeros((2, 192 + 32, 192))
+            bad[:, :192] = np.eye(192)
+            bad[1, 64 * blk:64 * blk + 64, 64 * blk:64 * blk + 64] = -np.eye(64)
+            info = ops.batch_chol_solve(torch.from_numpy(bad).to(dev), 2, 192, 32,
+                                        torch.empty((2, 32, 192), dtype=torch.float32, device=dev))
+            assert info.cpu().numpy()[0] == 0 and info.cpu().numpy()[1] != 0, blk
     finally:
         ops.chol_outer_block(default)
 
