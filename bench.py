@@ -3,9 +3,12 @@
 
 Workload (BASELINE.json configs[1], SURVEY.md 8d "cfg2"): synthetic T=3000, F=768 x 4 FIR delays
 (p=3072), V=80000 voxels PER GPU, 20 alphas logspace(-1, 8), 5 outer x 5 inner contiguous K-folds,
-per-voxel alpha, normalpha, correlation scoring.  One "step" = one complete fit (Gram, 25 inner
-alpha sweeps, 5 refits, test scoring, host statistics) with the fp32 inputs already resident in HBM
-and the weights left resident; `value` = voxels of all ranks x steps / max-over-ranks wall time.
+per-voxel alpha, normalpha, correlation scoring.  One "step" = one complete call of the reference's
+entry point, SURVEY.md 8d's metric as written: NestedCVModel.fit_predict(features, targets) with float64
+numpy arrays in pageable host memory in -> metrics dict + float32 host weights + alphas out (Gram, 25
+inner alpha sweeps, 5 refits, test scoring, statistics; H2D of the inputs and D2H of the weights
+INSIDE the timed region, every step fenced by a device synchronisation, so `ms_per_step` is one call's
+latency).  `value` = voxels of all ranks x steps / max-over-ranks wall time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--voxels V] [--scaling weak|strong] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -14,9 +17,10 @@ Scaling: "weak" (default) = every rank fits `--voxels` voxels; "strong" = `--vox
 split over the ranks (north_star's 80 000-voxel job on 1/2/4/8 GPUs).  At N > 1 the line carries both:
 the headline `value` in the chosen mode and the other mode under `other_scaling`.
 
-Extra legs in the same JSON line (N = 1): `host_path` = the SURVEY 8d metric proper, float64 numpy
-arrays in -> metrics + host float32 weights out (H2D / D2H inside the timed region; never `value`);
-`f32_path` = the same device-resident fit with the exact-fp32 MFMA sweep (precision="f32").
+Extra legs in the same JSON line (N = 1): `resident_path` = the same fit with the fp32 inputs already in
+HBM and the weights left there (what `value` was in rounds 1-2); `f32_path` = the resident fit with the
+exact-fp32 MFMA sweep (precision="f32"), with a roofline of its own, and `parity_vs_f32_path` = how far
+the headline's f16x3 results are from it over ALL voxels of the bench data.
 
 Prints ONE JSON line on rank 0.  The `roofline` object is for the dominant kernel, the fp16x3 MFMA
 contraction k_sweep_f16x3, in its fused-score launches (the alphas that go through the batched
@@ -107,12 +111,18 @@ def cpu_baseline(dX, dY, p, V_full, alphas, v_sample=2000):
     }
 
 
-def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, collect_kernels=False):
-    """`warmup` untimed + `steps` timed device-resident fits, barrier + synchronize on both sides, MAX over ranks.
-    Returns (seconds, last metrics, kernel timing dict or None, plain-GEMM flops counted during the timed steps)."""
+def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, collect_kernels=False, host=None):
+    """`warmup` untimed + `steps` timed fits, barrier + synchronize on both sides, MAX over ranks.  ``host`` = (X, Y)
+    float64 numpy arrays: the host-to-host call (the headline), every step followed by a device synchronisation;
+    None: device-resident inputs, weights left resident.  Returns (seconds, last (metrics, W, alphas), kernel timing
+    dict or None, {plain, fused} flops counted during the timed steps)."""
     from litcoder_core_amd import ops
 
     def step():
+        if host is not None:
+            out = model.fit_predict(host[0], host[1], alphas=alphas, **FIT_KW)
+            torch.cuda.synchronize()
+            return out
         return model.fit_predict_device(dX, dY, p, V, n_voxels_total=None if world == 1 else V_total,
                                         alphas=alphas, **FIT_KW)
 
@@ -122,18 +132,21 @@ def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, 
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    metrics = None
+    out = None
     for _ in range(warmup):
-        metrics, _, _ = step()
+        out = step()
     if collect_kernels:
         ops.timing_enable(True)
         ops.timing_read()
-    plain_flops = 0.0
+    flops = {"plain": 0.0, "fused": 0.0, "fused_launches": 0}
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        metrics, _, _ = step()
-        plain_flops += model.last_fit.get("plain_flops", 0.0)
+        out = None                                           # the previous step's weights are released first
+        out = step()
+        flops["plain"] += model.last_fit.get("plain_flops", 0.0)
+        flops["fused"] += model.last_fit.get("fused_flops", 0.0)
+        flops["fused_launches"] += model.last_fit.get("fused_launches", 0)
     fence()
     elapsed = time.perf_counter() - t0
     kern = None
@@ -145,29 +158,57 @@ def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, 
                          device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, metrics, kern, plain_flops
+    return elapsed, out, kern, flops
 
 
-def host_path_leg(dX, dY, p, V, alphas, steps=2):
-    """SURVEY 8d's metric as written: float64 numpy arrays in (features 73.7 MB, targets 1.92 GB), metrics dict +
-    float32 host weights + alphas out, through the reference's own entry point NestedCVModel.fit_predict."""
-    from litcoder_core_amd import NestedCVModel
+def host_arrays(dX, dY, p, V):
+    """The bench inputs as the reference's caller holds them: float64 numpy arrays in pageable host memory."""
     X = dX[:, :p].cpu().numpy().astype(np.float64)
-    Y = dY[:, :V].cpu().numpy().astype(np.float64)
-    model = NestedCVModel("ridge_regression")
-    model.fit_predict(X, Y, alphas=alphas, **FIT_KW)                      # warm-up
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        m, W, a = model.fit_predict(X, Y, alphas=alphas, **FIT_KW)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    assert isinstance(W, np.ndarray) and W.shape == (p, V) and W.dtype == np.float32
-    return {"value": V / dt, "unit": "voxels/sec", "ms_per_step": 1e3 * dt, "steps": steps,
-            "what": "float64 numpy features/targets in (pageable host memory) -> metrics + float32 host weights out; "
-                    "H2D of 1.99 GB through a ring of pinned chunks filled by copy threads, on-device cast to fp32, D2H of "
-                    "0.98 GB of weights into page-locked memory, all inside the timed region",
-            "median_score": m["median_score"]}
+    Y = np.empty((dY.shape[0], V), dtype=np.float64)
+    step = 8192
+    for c in range(0, V, step):                              # column blocks: no second 2 GB temporary
+        Y[:, c:c + step] = dY[:, c:min(V, c + step)].cpu().numpy()
+    return X, Y
+
+
+def parity_of(res16, res32, dev):
+    """How far the headline's results (f16x3 arithmetic) are from the same fit on exact-fp32 MFMA arithmetic, over all
+    voxels: per-voxel correlations, chosen alphas (mean over folds), weights."""
+    (m16, W16, a16), (m32, W32, a32) = res16, res32
+    c16, c32 = np.asarray(m16["correlations"], dtype=np.float64), np.asarray(m32["correlations"], dtype=np.float64)
+    dc = np.abs(c16 - c32)
+    w16 = torch.as_tensor(W16).to(dev) if not isinstance(W16, torch.Tensor) else W16
+    w32 = torch.as_tensor(W32).to(dev) if not isinstance(W32, torch.Tensor) else W32
+    same = np.asarray(a16) == np.asarray(a32)
+    cols = torch.as_tensor(np.nonzero(same)[0], device=dev)
+    dW = float((w16[:, cols] - w32[:, cols]).abs().max() / w32.abs().max()) if len(cols) else None
+    return {"max_abs_dcorr": float(dc.max()), "median_abs_dcorr": float(np.median(dc)),
+            "max_abs_dcorr_where_alphas_agree": float(dc[same].max()) if same.any() else None,
+            "alpha_agreement": float(np.mean(same)), "max_rel_dW_where_alphas_agree": dW,
+            "median_score": [m16["median_score"], m32["median_score"]], "voxels": int(len(c16)),
+            "note": "alpha_agreement = voxels whose MEAN alpha over the 5 outer folds is identical; a voxel whose two best "
+                    "alphas score within fp32 rounding may flip in either arithmetic (tests/_oracle_check.py proves such "
+                    "ties against the oracle)"}
+
+
+def sweep_roofline(sweep, kern, flops, steps, split):
+    """roofline object of the fused alpha-sweep kernel from the library's HIP events around its launches (on the launch
+    stream) and the algorithmic flops the engine counted for them."""
+    ms, launches = kern.get("alpha_sweep_gemm", (0.0, 0))
+    alg_tflops = flops["fused"] / (ms * 1e-3) / 1e12 if launches and ms > 0 else None
+    mfma_per_product = 3 if split else 1
+    peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    issued = alg_tflops * mfma_per_product if alg_tflops else None
+    return {"bound": "mfma",
+            "kernel": "k_sweep_f16x3 (fused alpha sweep, 3 fp16 MFMAs per product)" if split
+                      else "k_gemm_f32<score> (fused alpha sweep, f32-input MFMA)",
+            "achieved": alg_tflops, "peak": peak, "unit": "TFLOP/s", "frac": (alg_tflops / peak) if alg_tflops else None,
+            "mfma_per_product": mfma_per_product, "mfma_issue_tflops": issued,
+            "mfma_issue_frac": (issued / peak) if issued else None,
+            "frac_vs_f32_mfma_peak": (alg_tflops / PEAK_F32_MFMA_TFLOPS) if alg_tflops else None,
+            "flops_per_step": flops["fused"] / max(steps, 1), "launches_per_step": launches / max(steps, 1),
+            "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+            "fused_alphas_per_launch": sweep.get("fused_alphas"), "inner_folds_per_launch": sweep.get("folds_per_launch", 1)}
 
 
 def main():
@@ -209,7 +250,7 @@ def main():
     # every rank keeps the per-voxel lists of its OWN voxels (like its block of the weights); the statistics behind them
     # are global.  With global lists every rank would spend ~70 ms of interpreter time on 640 000-entry Python lists.
     shard = ShardContext(device=dev, global_lists=False) if world > 1 else None
-    model = NestedCVModel("ridge_regression", shard=shard, precision=args.precision)
+    model = NestedCVModel("ridge_regression", shard=shard, precision=args.precision, local_targets=world > 1)
 
     def inputs(mode):
         """(dX, dY, p, V_local, V_total) of this rank: weak = `--voxels` each; strong = its block of `--voxels`."""
@@ -221,41 +262,31 @@ def main():
         return dX, dY, p, hi - lo, args.voxels
 
     dX, dY, p, V, V_total = inputs(args.scaling)
-    elapsed, metrics, kern, plain_flops = timed_fits(model, dX, dY, p, V, V_total, alphas, args.steps, args.warmup,
-                                                     world, dev, collect_kernels=True)
+    host = host_arrays(dX, dY, p, V)                         # what the reference's caller holds: float64, pageable
+    elapsed, res, kern, flops = timed_fits(model, dX, dY, p, V, V_total, alphas, args.steps, args.warmup, world, dev,
+                                           collect_kernels=True, host=host)
+    metrics = res[0]
     sweep = dict(model.last_fit)
     other = None
     if world > 1 and not args.no_extra_legs:
         mode2 = "strong" if args.scaling == "weak" else "weak"
-        del dX, dY
+        del dX, dY, host
         torch.cuda.empty_cache()
         dX, dY, p, V2, V2_total = inputs(mode2)
-        e2, m2, _, _ = timed_fits(model, dX, dY, p, V2, V2_total, alphas, args.steps, args.warmup, world, dev)
+        host = host_arrays(dX, dY, p, V2)
+        e2, r2, _, _ = timed_fits(model, dX, dY, p, V2, V2_total, alphas, args.steps, args.warmup, world, dev, host=host)
         other = {"scaling": mode2, "value": V2_total * args.steps / e2, "unit": "voxels/sec",
-                 "ms_per_step": 1e3 * e2 / args.steps, "voxels_total": V2_total, "median_score": m2["median_score"]}
+                 "ms_per_step": 1e3 * e2 / args.steps, "voxels_total": V2_total, "median_score": r2[0]["median_score"]}
 
     if rank == 0:
-        n_o = T - T // N_OUTER
-        n_v = n_o // N_INNER
-        n_i = n_o - n_v
         split = sweep["precision"] == "f16x3"
-        A_fused = sweep.get("fused_alphas", A)               # alphas scored inside the fused launch
-        folds_fused = sweep.get("folds_per_launch", 1)       # inner folds that share the launch
-        flops_per_launch = 2.0 * A_fused * n_v * n_i * V * folds_fused   # algorithmic: those alphas of those inner folds
-        ms, launches = kern.get("alpha_sweep_gemm", (0.0, 0))
-        avg_ms = ms / max(launches, 1)
-        alg_tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None
-        # f16x3: every algorithmic product is three fp16 MFMAs (hi*hi + hi*lo + lo*hi).  `achieved` / `frac` are
-        # ALGORITHMIC (what the caller's GEMM needs); the MFMA flops the kernel issues are reported beside them.
-        mfma_per_product = 3 if split else 1
-        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        issued = alg_tflops * mfma_per_product if alg_tflops else None
+        roof = sweep_roofline(sweep, kern, flops, args.steps, split)
         plain_ms, plain_n = kern.get("grouped_gemm", (0.0, 0))
         plain = None
         if split and plain_n:
             plain = {"launches": plain_n, "ms_per_step": plain_ms / args.steps,
-                     "algorithmic_tflops": plain_flops / (plain_ms * 1e-3) / 1e12,
-                     "mfma_tflops": 3 * plain_flops / (plain_ms * 1e-3) / 1e12,
+                     "algorithmic_tflops": flops["plain"] / (plain_ms * 1e-3) / 1e12,
+                     "mfma_tflops": 3 * flops["plain"] / (plain_ms * 1e-3) / 1e12,
                      "what": f"{sweep.get('series_terms', 0)} shared series terms x 25 inner folds + 5 refits "
                              "(weights and test predictions) per step; includes the f32 MFMA launches of that slot"}
         traffic = traffic_src = None
@@ -265,14 +296,22 @@ def main():
                 tj = json.load(open(tpath))
                 entry = tj.get(sweep["precision"], tj)
                 traffic = entry.get("hbm_bytes_per_launch")
-                if traffic is not None:                  # the stored figure covers `inner_folds_per_launch` folds
-                    traffic *= folds_fused / float(entry.get("inner_folds_per_launch", 1))
-                traffic_src = ("profiles/alpha_sweep_traffic.json (static: FETCH_SIZE x2 + WRITE_SIZE per launch from "
-                               "separate rocprofv3 --pmc passes of this command; not measured in this run)")
+                traffic_src = ("profiles/alpha_sweep_traffic.json (static: FETCH_SIZE x2 + WRITE_SIZE per full-width fused "
+                               "launch from separate rocprofv3 --pmc passes of this command; not measured in this run)")
             except Exception:
                 traffic = None
         from litcoder_core_amd.nested_cv import _main_stream
-        cus_main = 224 if _main_stream() is not None else 256
+        roof.update({
+            "note": ("achieved/frac = ALGORITHMIC flops of the caller's contraction (2 x A_fused x n_val x n_train x V per "
+                     "inner fold, summed over the launches of the timed steps) / the launches' HIP-event time; the kernel "
+                     "issues mfma_per_product fp16 MFMAs per product (mfma_issue_tflops / mfma_issue_frac).  peak = dense "
+                     "fp16 MFMA datasheet figure at 2.4 GHz; under this kernel the chip holds 1.4-1.8 GHz (in-kernel "
+                     "s_memtime/s_memrealtime, profiles/).  The first fold's launches are panel-wide (the targets are still "
+                     "arriving), the others full width") if split else None,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "cus_of_256_the_kernel_runs_on": 224 if _main_stream() is not None else 256,
+            "plain_launches_same_kernel": plain})
+        renamed = {"batch_chol_solve": "batch_chol_solve_stream_ms_incl_waits_for_cus"}
         out = {
             "metric": "voxels/sec full nested-CV ridge fit (LeBel UTS03, GPT-2 768x4 delays, ~80k voxels)",
             "value": V_total * args.steps / elapsed, "unit": "voxels/sec", "n_gpus": world, "steps": args.steps,
@@ -284,37 +323,30 @@ def main():
                                    + (f"V={args.voxels}/GPU" if args.scaling == "weak" else f"V={args.voxels} in total")
                                    + f" A={A} alphas {N_OUTER}x{N_INNER} kfold, per-voxel alpha, normalpha, corr",
                        "voxels_total": V_total, "voxels_rank0": V,
-                       "inputs": "fp32 resident in HBM; weights left resident; per-voxel scores/alphas/p-values on host",
+                       "inputs": "float64 numpy features/targets in pageable host memory -> metrics dict + float32 host "
+                                 "weights + alphas (NestedCVModel.fit_predict, SURVEY 8d); H2D (float32 after a host-side "
+                                 "cast in the staging threads) and D2H inside the timed region, every step fenced",
+                       "panels": [list(c) for c in (sweep.get("panels") or [])],
                        "parallelism": f"voxel-shard x{world}", "median_score": metrics["median_score"]},
-            "roofline": {"bound": "mfma",
-                         "kernel": "k_sweep_f16x3 (fused alpha sweep, 3 fp16 MFMAs per product)" if split
-                                   else "k_gemm_f32<score> (fused alpha sweep, f32-input MFMA)",
-                         "note": ("achieved/frac = ALGORITHMIC flops of the caller's contraction; the kernel issues "
-                                  "mfma_per_product fp16 MFMAs per product (mfma_issue_tflops / mfma_issue_frac).  peak = "
-                                  "dense fp16 MFMA datasheet figure at 2.4 GHz; under this kernel the chip holds 1.4-1.8 "
-                                  "GHz (in-kernel s_memtime/s_memrealtime, profiles/)") if split else None,
-                         "achieved": alg_tflops, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (alg_tflops / peak) if alg_tflops else None,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "mfma_per_product": mfma_per_product, "mfma_issue_tflops": issued,
-                         "mfma_issue_frac": (issued / peak) if issued else None,
-                         "frac_vs_f32_mfma_peak": (alg_tflops / PEAK_F32_MFMA_TFLOPS) if alg_tflops else None,
-                         "cus_of_256_the_kernel_runs_on": cus_main,
-                         "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
-                         "fused_alphas_per_launch": A_fused, "inner_folds_per_launch": folds_fused,
-                         "plain_launches_same_kernel": plain},
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(kern.items())},
+            "roofline": roof,
+            "kernel_ms_per_step": {renamed.get(k, k): round(v[0] / args.steps, 3) for k, v in sorted(kern.items())},
         }
         if other is not None:
             out["other_scaling"] = other
         if world == 1 and not args.no_extra_legs:
+            del host
+            e_res, r_res, _, _ = timed_fits(model, dX, dY, p, V, V_total, alphas, 3, 1, 1, dev)
+            out["resident_path"] = {"value": V * 3 / e_res, "unit": "voxels/sec", "ms_per_step": 1e3 * e_res / 3, "steps": 3,
+                                    "what": "fp32 inputs resident in HBM, weights left resident (the headline of rounds 1-2)",
+                                    "median_score": r_res[0]["median_score"]}
             if args.precision != "f32":
                 m32 = NestedCVModel("ridge_regression", precision="f32")
-                e32, mm, _, _ = timed_fits(m32, dX, dY, p, V, V_total, alphas, 2, 1, 1, dev)
+                e32, r32, k32, f32 = timed_fits(m32, dX, dY, p, V, V_total, alphas, 2, 1, 1, dev, collect_kernels=True)
                 out["f32_path"] = {"value": V * 2 / e32, "unit": "voxels/sec", "ms_per_step": 1e3 * e32 / 2, "steps": 2,
                                    "dtype": "f32 (f32-input MFMA sweep and refit; Gram/Cholesky in f64)",
-                                   "median_score": mm["median_score"]}
-            out["host_path"] = host_path_leg(dX, dY, p, V, alphas)
+                                   "median_score": r32[0]["median_score"],
+                                   "roofline": sweep_roofline(dict(m32.last_fit), k32, f32, 2, False)}
+                out["parity_vs_f32_path"] = parity_of(res, r32, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dX, dY, p, V, alphas)
         print(json.dumps(out), flush=True)

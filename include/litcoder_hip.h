@@ -98,7 +98,66 @@ int lc_segment_reduce(const void* d_data, int dtype, int64_t D, int64_t ld_in, c
                       const int32_t* d_idx, int64_t n_seg, int how, double* d_out, int64_t ld_out,
                       lc_stream_t stream);
 
+/* ---------------------------------------------------------------- the reference's SVD semantics (slow fp64 route)
+ * ridge_utils.py:34-67 drops singular values <= singcutoff of the thin SVD of a training block; ridge_regression.py:
+ * 56,117 shrink the kept ones by S / (S^2 + a^2), which is defined at a = 0.  In terms of K = X X' (eigenpairs
+ * lambda = S^2, U) the operators are  R U_k diag(1 / (lambda_k + a^2)) U_k'  with R = K[va,tr] (hat matrix) or
+ * R = [Xtr' ; K[te,tr]] (refit).  Taken only for penalty grids the Cholesky route cannot serve (alpha = 0, or a
+ * singcutoff that is not negligible against the smallest penalty).
+ * lc_batch_eigh_jacobi: F symmetric (n, n) fp64 systems d_a (n even: pad an odd system with a zero row and column;
+ * destroyed) -> d_lam (F, n) eigenvalues, d_vt (F, n, n) eigenvectors AS ROWS, d_lmax (F, optional) the largest;
+ * cyclic Jacobi, parallel ordering, at most max_sweeps sweeps to the relative off-diagonal tolerance tol (host
+ * synchronisation once per sweep; *h_sweeps = sweeps done).
+ * lc_batch_spectral_apply: d_h[h_slot ? h_slot[f A + a] : f A + a] (M, n) f32 = R_f V_kept diag(1/(lambda + a2[f A +
+ * a])) V_kept', an eigenpair being kept when sqrt(lambda) > cutoff AND it is among the d_rank_cap[f] largest (the thin
+ * SVD of an (n x p) block has min(n, p) values; NULL: no cap); d_kept (F, optional) = how many were. */
+int64_t lc_batch_eigh_work_bytes(int F, int n);
+int lc_batch_eigh_jacobi(double* d_a, int F, int n, double* d_vt, double* d_lam, double* d_lmax, void* d_work,
+                         int64_t work_bytes, int max_sweeps, double tol, int32_t* h_sweeps, lc_stream_t stream);
+int64_t lc_batch_spectral_work_bytes(int F, int A, int n, int M);
+int lc_batch_spectral_apply(const double* d_lam, const double* d_vt, int F, int n, const double* d_r, int M,
+                            const double* d_a2, int A, double cutoff, const int32_t* d_rank_cap, void* d_work,
+                            int64_t work_bytes, float* d_h, const int32_t* h_slot, int32_t* d_kept, lc_stream_t stream);
+
 /* ---------------------------------------------------------------- casts / gathers */
+
+/* ---- host <-> device boundary of a fit (nested_cv.py:99-100: `torch.tensor(features / targets, dtype=float32)`;
+ * :293-296: the float32 weights returned as a host array).  Targets and weights move as column panels of voxels.
+ * lc_memcpy2d_async: `rows` rows of `width_bytes` with byte pitches, kind 0 = H2D, 1 = D2H, 2 = D2D, asynchronous on
+ * `stream` when the host side is page-locked.  lc_fill2d_bytes: the same shape set to a byte value (zero padding).
+ * lc_host_cast_f64_f32 / lc_host_copy_f32: HOST-side staging of a (rows, cols) block of the caller's pageable array
+ * into page-locked memory, float64 -> float32 (round to nearest even, the cast the reference performs on the host) or
+ * a plain copy; no device work, callable from any thread. */
+int lc_memcpy2d_async(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width_bytes,
+                      int64_t rows, int kind, lc_stream_t stream);
+int lc_fill2d_bytes(void* d_ptr, int64_t pitch, int byte, int64_t width_bytes, int64_t rows, lc_stream_t stream);
+int lc_host_cast_f64_f32(const double* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t cols);
+int lc_host_copy_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t cols);
+
+/* The whole upload of a fit's inputs on native threads (nested_cv.py:99-100 for features AND targets): a list of jobs,
+ * each a column range [c0, c1) of a row block of a host matrix (float32 or float64, pageable) going to the same
+ * columns of rows [dst_row0, dst_row0 + rows) of a float32 device matrix.  lc_upload_start returns at once; worker
+ * threads stage row chunks into the caller's page-locked slots (n_slots buffers of slot_bytes; float64 is cast to
+ * float32 there) and issue the copies on `stream` in job order.  lc_upload_wait blocks the calling host thread until
+ * every copy of `job` has been issued and makes `consumer` wait for them on the device.
+ * lc_upload_finish joins the threads and leaves the slots idle (the job sources, the slots and the destinations must
+ * stay alive until it returns); lc_upload_free releases the handle once no thread waits on it any more. */
+typedef struct lc_upload_job {
+    const void* src;   /* host matrix block, row-major */
+    int64_t ld_src;    /* elements between its rows */
+    int dtype;         /* LC_F32 | LC_F64 */
+    int64_t rows;      /* rows of the block */
+    int64_t c0, c1;    /* columns copied */
+    void* dst;         /* device float32 matrix (row 0, column 0) */
+    int64_t ld_dst;    /* elements between its rows */
+    int64_t dst_row0;  /* destination row of the block's first row */
+} lc_upload_job;
+typedef struct lc_upload lc_upload_t;
+int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* const* pinned_slots, int n_slots, int64_t slot_bytes,
+                    int n_threads, int device, lc_stream_t stream, lc_upload_t** out);
+int lc_upload_wait(lc_upload_t* upload, int job, lc_stream_t consumer);
+int lc_upload_finish(lc_upload_t* upload);
+int lc_upload_free(lc_upload_t* upload);
 
 /* torch.tensor(x, dtype=float32) (models/nested_cv.py:99-100): f64 -> f32, (rows, cols)
  * into a (possibly wider, zero-padded by the caller) destination. */
@@ -390,6 +449,13 @@ int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float
 int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_rows, int K,
                       const float* d_cscale, void* d_tiled, lc_stream_t stream);
 
+/* The tiled image of the same K rows with the voxel columns permuted: column j of the output image is column
+ * d_perm[j] of d_tiled (-1: a zero column), j < Vs (a multiple of 256).  The alpha-sorted operand of the refit
+ * (ridge_regression.py:46-61 groups the voxels by alpha) from the image the inner CV already made of the outer training
+ * rows, without a sorted fp32 copy of the targets.  Column scales are per column and travel with it. */
+int lc_permute_cols_f16(const void* d_tiled, const int32_t* d_perm, int64_t Vs, int K, void* d_out,
+                        lc_stream_t stream);
+
 /* "B view" (both fp16x3 entry points): d_yt / d_bt may be the tiled image of MORE rows than the product
  * contracts -- the targets of a whole outer training set, split once -- of which the product skips one aligned gap
  * (the validation block of an inner fold).  b_rows = rows of the image (0: the image is exactly the K rows),
@@ -513,6 +579,14 @@ int lc_fill_argmax(const double* d_rowsum, int A, int32_t* d_best, int64_t V, lc
 int lc_fold_pack(const double* d_r_sorted, const double* d_p_sorted, const int32_t* d_perm, int64_t Vs,
                  const int32_t* d_best, int64_t V, const int32_t* d_info_a, int n_a,
                  const int32_t* d_info_b, int n_b, double* d_out, int64_t ld, lc_stream_t stream);
+
+/* The same block filled panel by panel (voxel panels of one rank processed one after the other share the rank's
+ * block): this panel's V voxels land in columns [col0, col0 + V); `clear` != 0 zeroes the whole block first (the first
+ * panel of a fold); the flags of row 3 are OR-ed over the panels. */
+int lc_fold_pack_at(const double* d_r_sorted, const double* d_p_sorted, const int32_t* d_perm, int64_t Vs,
+                    const int32_t* d_best, int64_t V, const int32_t* d_info_a, int n_a,
+                    const int32_t* d_info_b, int n_b, double* d_out, int64_t ld, int64_t col0, int clear,
+                    lc_stream_t stream);
 
 /* The gathered blocks of all ranks (world, 4, ld) -> V_total-long vectors: rank k's columns [0, lo[k+1]-lo[k])
  * land at [lo[k], lo[k+1]) (d_lo: world+1 int64 on the device; w_max = widest shard).  d_p_clean = p with

@@ -68,6 +68,21 @@ SIGNATURES = {
     "lc_lambda_max_strided": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_fill_argmax": (c_int, [_ptr, c_int, _ptr, c_int64, _ptr]),
     "lc_fold_pack": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr, c_int, _ptr, c_int, _ptr, c_int64, _ptr]),
+    "lc_fold_pack_at": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr, c_int, _ptr, c_int, _ptr, c_int64, c_int64, c_int,
+                                _ptr]),
+    "lc_memcpy2d_async": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64, c_int, _ptr]),
+    "lc_fill2d_bytes": (c_int, [_ptr, c_int64, c_int, c_int64, c_int64, _ptr]),
+    "lc_host_cast_f64_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64]),
+    "lc_host_copy_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64]),
+    "lc_upload_start": (c_int, [_ptr, c_int, _ptr, c_int, c_int64, c_int, c_int, _ptr, _ptr]),
+    "lc_upload_wait": (c_int, [_ptr, c_int, _ptr]),
+    "lc_upload_finish": (c_int, [_ptr]),
+    "lc_upload_free": (c_int, [_ptr]),
+    "lc_batch_eigh_work_bytes": (c_int64, [c_int, c_int]),
+    "lc_batch_eigh_jacobi": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr, c_int64, c_int, c_double, POINTER(c_int32), _ptr]),
+    "lc_batch_spectral_work_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "lc_batch_spectral_apply": (c_int, [_ptr, _ptr, c_int, c_int, _ptr, c_int, _ptr, c_int, c_double, _ptr, _ptr, c_int64, _ptr,
+                                        POINTER(c_int32), _ptr, _ptr]),
     "lc_fold_unpack": (c_int, [_ptr, c_int, c_int64, _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_chol_outer_block": (c_int, [c_int]),
     "lc_debug_chol_big_kernel": (c_int, [c_int]),
@@ -111,6 +126,7 @@ SIGNATURES = {
     "lc_split_rows_f16_groups": (c_int, [_ptr, c_int64, c_int, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_col_scales_f16": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_split_cols_f16": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, _ptr, _ptr, _ptr]),
+    "lc_permute_cols_f16": (c_int, [_ptr, _ptr, c_int64, c_int, _ptr, _ptr]),
     "lc_alpha_sweep_scores_f16x3": (c_int, [_ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int, _ptr, _ptr,
                                             c_int, _ptr, _ptr, c_int, c_int64, c_int64, c_int64, _ptr]),
     "lc_debug_sweep16_stamps": (c_int, [_ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int, _ptr, _ptr, _ptr,

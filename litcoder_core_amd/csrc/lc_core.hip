@@ -127,3 +127,56 @@ extern "C" int lc_stream_destroy(lc_stream_t stream) {
     LC_HIP(hipStreamDestroy(lc::as_stream(stream)));
     return LC_OK;
 }
+
+// ------------------------------------------------------------------ host <-> device movement of voxel panels
+// Strided 2-D copy on a stream: `rows` rows of `width_bytes`, row pitches in bytes.  kind: 0 = host -> device,
+// 1 = device -> host, 2 = device -> device.  The host side should be page-locked (the copy is then one DMA at link
+// rate and really asynchronous).  Used for the column panels of the targets / weights (nested_cv.py:99-100, 293-296
+// are the reference's host <-> device boundary).
+extern "C" int lc_memcpy2d_async(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width_bytes,
+                                 int64_t rows, int kind, lc_stream_t stream) {
+    LC_REQUIRE(dst && src, LC_E_BADARG, "lc_memcpy2d_async: null pointer");
+    LC_REQUIRE(width_bytes >= 0 && rows >= 0 && dst_pitch >= width_bytes && src_pitch >= width_bytes && kind >= 0 && kind <= 2,
+               LC_E_SHAPE, "lc_memcpy2d_async: pitches must cover the row width, kind in 0..2");
+    if (width_bytes == 0 || rows == 0) return LC_OK;
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (dst_pitch == width_bytes && src_pitch == width_bytes)
+        LC_HIP(hipMemcpyAsync(dst, src, (size_t)(width_bytes * rows), k, lc::as_stream(stream)));
+    else
+        LC_HIP(hipMemcpy2DAsync(dst, (size_t)dst_pitch, src, (size_t)src_pitch, (size_t)width_bytes, (size_t)rows, k,
+                                lc::as_stream(stream)));
+    return LC_OK;
+}
+
+// HOST code (no device involved): rows x cols block of a float64 host matrix -> float32, round to nearest even -- the
+// cast of `torch.tensor(x, dtype=torch.float32)` (nested_cv.py:99-100) done while a block is staged into page-locked
+// memory, so that 4 instead of 8 bytes per value cross PCIe.  Called from the staging threads through ctypes (which
+// releases the interpreter lock for the duration of the call).
+extern "C" int lc_host_cast_f64_f32(const double* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows,
+                                    int64_t cols) {
+    LC_REQUIRE(src && dst, LC_E_BADARG, "lc_host_cast_f64_f32: null pointer");
+    LC_REQUIRE(rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= cols, LC_E_SHAPE, "lc_host_cast_f64_f32: bad shape");
+    for (int64_t r = 0; r < rows; ++r) {
+        const double* __restrict__ s = src + r * ld_src;
+        float* __restrict__ d = dst + r * ld_dst;
+        for (int64_t c = 0; c < cols; ++c) d[c] = (float)s[c];
+    }
+    return LC_OK;
+}
+
+// HOST code: plain strided row copy of 4-byte values (float32 inputs staged into page-locked memory).
+extern "C" int lc_host_copy_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t cols) {
+    LC_REQUIRE(src && dst, LC_E_BADARG, "lc_host_copy_f32: null pointer");
+    LC_REQUIRE(rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= cols, LC_E_SHAPE, "lc_host_copy_f32: bad shape");
+    for (int64_t r = 0; r < rows; ++r) memcpy(dst + r * ld_dst, src + r * ld_src, (size_t)cols * sizeof(float));
+    return LC_OK;
+}
+
+// hipMemset2DAsync: `rows` rows of `width_bytes` at byte pitch `pitch` (the zero padding columns of a matrix whose
+// body arrives by copies).
+extern "C" int lc_fill2d_bytes(void* d_ptr, int64_t pitch, int byte, int64_t width_bytes, int64_t rows, lc_stream_t stream) {
+    LC_REQUIRE(d_ptr && pitch >= width_bytes && width_bytes >= 0 && rows >= 0, LC_E_BADARG, "lc_fill2d_bytes: bad argument");
+    if (width_bytes == 0 || rows == 0) return LC_OK;
+    LC_HIP(hipMemset2DAsync(d_ptr, (size_t)pitch, byte, (size_t)width_bytes, (size_t)rows, lc::as_stream(stream)));
+    return LC_OK;
+}

@@ -152,6 +152,26 @@ __global__ void __launch_bounds__(256) k_split_cols_f16(const float* __restrict_
     out[o + KG * 256] = *reinterpret_cast<uint4*>(&lo);
 }
 
+// The tiled image of the SAME rows with the columns permuted (and -1 entries of the permutation as zero columns): the
+// refit contracts the outer training rows of the alpha-SORTED voxels, and the inner CV has already split exactly those
+// rows in natural voxel order (one image per outer fold) -- so the sorted operand is a gather of 16-byte units from that
+// image (column scales travel with their columns) instead of a 4-byte gather of the fp32 targets, a sorted fp32 copy in
+// HBM and a second split pass over it.  Thread = output column, block = R unit rows ((K-tile, plane, k-group)) of a tile.
+__global__ void __launch_bounds__(256) k_permute_cols_f16(const uint4* __restrict__ in, const int* __restrict__ perm,
+                                                          long long Vs, int rows16, uint4* __restrict__ out) {
+    const long long cp = (long long)blockIdx.x * 256 + threadIdx.x;     // output column
+    const int c = cp < Vs ? perm[cp] : -1;
+    const uint4* src = in + ((long long)(c >> 8) * rows16) * 256 + (c & 255);
+    uint4* dst = out + ((long long)blockIdx.x * rows16) * 256 + threadIdx.x;
+    const int g0 = blockIdx.y * 8;
+    uint4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (c >= 0 && g0 + j < rows16) ? src[(long long)(g0 + j) * 256] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (g0 + j < rows16) dst[(long long)(g0 + j) * 256] = v[j];
+}
+
 // ------------------------------------------------------------------ the fused sweep on fp16 x 3
 struct Score16Args {
     const float* yv;       // gathered validation targets (M, V), zero padding rows
@@ -254,7 +274,11 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     // between the MFMAs -- each wave always has independent MFMAs to issue, so the two waves of a SIMD keep the
     // matrix pipe fed without any phase choreography, and the only bubble left is the barrier crossing.
     // Operand chunks go global -> LDS directly (global_load_lds_dwordx4 through inline asm, so that hipcc does
-    // not drain the queue in front of every LDS read); thread t moves the 16-byte units t and t + 512 of each
+    // not drain the queue in front of every LDS read; M0 = the wave's LDS base, written in the same statement with the
+    // ONE WAIT STATE the hardware needs between an SALU write of M0 and an LDS-DMA reading it -- hipcc pads nothing
+    // inside an asm string; without the s_nop a piece now and then landed at the PREVIOUS piece's address whenever
+    // another stream's waves shared the SIMD: one stale 64-column slice of one K-tile in ~1 fit of 10, round 3 --
+    // and with the compiler's own M0 saved and restored around it); thread t moves the 16-byte units t and t + 512 of each
     // 16 KB chunk, a wave's 64 lanes land contiguously at its wave-uniform LDS base (M0).  Ring discipline
     // (tile t lives in stage t & 3):
     //   prologue: tiles 0..3 -> stages 0..3, fragments of tile 0 -> registers, barrier;
@@ -267,7 +291,9 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     {                                                                                                         \
         const unsigned m0_ = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((unit_) + (wave << 6)) * 16u); \
         const uint4* gp_ = (gptr_);                                                                           \
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0_), "v"(gp_) : "memory");  \
+        unsigned keep_;                                                                                       \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(gp_), "s"(m0_) : "memory");                                          \
     }
 #define GLDS16(kt_, stg_)                                                           \
     {                                                                               \
@@ -392,10 +418,15 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
             __builtin_amdgcn_sched_barrier(0);
         }
         if (LAST) return;
-        // publish tile kt+2 (read during iteration kt+1); nothing left to publish in the last two iterations
-        if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // publish tile kt+2 (read during iteration kt+1); nothing left to publish in the last two iterations.
+        // lgkmcnt(0): this wave's fragment reads of tile kt+1 have RETURNED before it reports at the barrier -- the
+        // first DMA piece of the next iteration goes into the stage they came from, and "issued before the barrier" is not
+        // "done": the protocol used to lean on a DMA taking longer to land (>= 250 cycles) than a queued ds_read to return,
+        // which a second workgroup on the CU (any small LDS-using kernel of another stream fits beside this one) breaks
+        // now and then -- one wave then multiplied 32 rows of one K-tile with the NEXT ring turn's bytes (round 3)
+        if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
     };
     // the same K-tile for a light slab: 8 MFMAs (hi*hi), the 6 hi fragments of the next tile, the same DMA share
@@ -425,9 +456,9 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
             __builtin_amdgcn_sched_barrier(0);
         }
         if (LAST) return;
-        if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
     };
     // a 128-row slab with no valid rows (the last M-tile of A x 480 = 1920 score rows is half padding): its waves only
@@ -675,7 +706,9 @@ k_sweep16w_plain(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int
     {                                                                                                         \
         const unsigned m0_ = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((unit_) + (wave << 6)) * 16u); \
         const uint4* gp_ = (gptr_);                                                                           \
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0_), "v"(gp_) : "memory");  \
+        unsigned keep_;                                                                                       \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(gp_), "s"(m0_) : "memory");                                          \
     }
 #define GLDS16W(kt_, stg_)                                                          \
     {                                                                               \
@@ -835,6 +868,19 @@ extern "C" int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const
     hipLaunchKernelGGL(k_split_cols_f16, grid, dim3(256), 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V,
                        d_rows, K, d_cscale, (uint4*)d_tiled);
     return lc::launched("k_split_cols_f16");
+}
+
+extern "C" int lc_permute_cols_f16(const void* d_tiled, const int32_t* d_perm, int64_t Vs, int K, void* d_out,
+                                   lc_stream_t stream) {
+    LC_REQUIRE(d_tiled && d_perm && d_out, LC_E_BADARG, "lc_permute_cols_f16: null pointer");
+    LC_REQUIRE(Vs > 0 && Vs % TN == 0 && K > 0 && K % TK == 0, LC_E_SHAPE,
+               "lc_permute_cols_f16: need Vs %% %d == 0, K %% %d == 0", TN, TK);
+    const int rows16 = (K / TK) * 2 * KG;                 // 16-byte unit rows per column tile
+    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
+    dim3 grid((unsigned)(Vs / TN), (unsigned)lc::ceil_div(rows16, 8));
+    hipLaunchKernelGGL(k_permute_cols_f16, grid, dim3(256), 0, lc::as_stream(stream), (const uint4*)d_tiled, d_perm,
+                       (long long)Vs, rows16, (uint4*)d_out);
+    return lc::launched("k_permute_cols_f16");
 }
 
 static int fill_fold_views(const char* who, int F, int64_t K, int64_t b_rows, const int64_t* h_gap_begin,

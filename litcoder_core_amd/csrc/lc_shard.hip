@@ -13,7 +13,8 @@ __global__ void __launch_bounds__(256) k_fold_pack(const double* __restrict__ r_
                                                    const int* __restrict__ best, long long V,
                                                    const int* __restrict__ info_a, int n_a,
                                                    const int* __restrict__ info_b, int n_b,
-                                                   double* __restrict__ out, long long ld) {
+                                                   double* __restrict__ out, long long ld, long long col0) {
+    // out points at column col0 of the block (this panel's voxels); the flags live in columns 0, 1 of row 3
     const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
     if (j < Vs) {
         const int v = perm[j];
@@ -29,9 +30,9 @@ __global__ void __launch_bounds__(256) k_fold_pack(const double* __restrict__ r_
         for (int i = threadIdx.x; i < n_a; i += 64) bad_a |= info_a[i] != 0;
         for (int i = threadIdx.x; i < n_b; i += 64) bad_b |= info_b[i] != 0;
         const unsigned long long ma = __ballot(bad_a), mb = __ballot(bad_b);
-        if (threadIdx.x == 0) {
-            out[3 * ld + 0] = ma ? 1.0 : 0.0;
-            out[3 * ld + 1] = mb ? 1.0 : 0.0;
+        if (threadIdx.x == 0) {                       // OR into the block's flags (cleared by the first panel's memset)
+            if (ma) out[3 * ld - col0 + 0] = 1.0;
+            if (mb) out[3 * ld - col0 + 1] = 1.0;
         }
     }
 }
@@ -69,19 +70,25 @@ __global__ void __launch_bounds__(256) k_fill_argmax(const double* __restrict__ 
 
 }  // namespace
 
+extern "C" int lc_fold_pack_at(const double* d_r_sorted, const double* d_p_sorted, const int32_t* d_perm, int64_t Vs,
+                               const int32_t* d_best, int64_t V, const int32_t* d_info_a, int n_a, const int32_t* d_info_b,
+                               int n_b, double* d_out, int64_t ld, int64_t col0, int clear, lc_stream_t stream) {
+    LC_REQUIRE(d_r_sorted && d_p_sorted && d_perm && d_best && d_out, LC_E_BADARG, "lc_fold_pack: null pointer");
+    LC_REQUIRE(Vs >= 0 && V >= 0 && col0 >= 0 && ld >= col0 + V && ld >= 2 && (n_a == 0 || d_info_a) && (n_b == 0 || d_info_b),
+               LC_E_SHAPE, "lc_fold_pack: need ld >= max(col0 + V, 2)");
+    hipStream_t s = lc::as_stream(stream);
+    if (clear) LC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * 4 * ld, s));
+    const long long n = Vs > V ? Vs : V;
+    hipLaunchKernelGGL(k_fold_pack, dim3((unsigned)lc::ceil_div<long long>(n > 0 ? n : 1, 256)), dim3(256), 0, s, d_r_sorted,
+                       d_p_sorted, d_perm, (long long)Vs, d_best, (long long)V, d_info_a, n_a, d_info_b, n_b, d_out + col0,
+                       (long long)ld, (long long)col0);
+    return lc::launched("k_fold_pack");
+}
+
 extern "C" int lc_fold_pack(const double* d_r_sorted, const double* d_p_sorted, const int32_t* d_perm, int64_t Vs,
                             const int32_t* d_best, int64_t V, const int32_t* d_info_a, int n_a, const int32_t* d_info_b,
                             int n_b, double* d_out, int64_t ld, lc_stream_t stream) {
-    LC_REQUIRE(d_r_sorted && d_p_sorted && d_perm && d_best && d_out, LC_E_BADARG, "lc_fold_pack: null pointer");
-    LC_REQUIRE(Vs >= 0 && V >= 0 && ld >= V && ld >= 2 && (n_a == 0 || d_info_a) && (n_b == 0 || d_info_b), LC_E_SHAPE,
-               "lc_fold_pack: need ld >= max(V, 2)");
-    hipStream_t s = lc::as_stream(stream);
-    LC_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * 4 * ld, s));
-    const long long n = Vs > V ? Vs : V;
-    hipLaunchKernelGGL(k_fold_pack, dim3((unsigned)lc::ceil_div<long long>(n > 0 ? n : 1, 256)), dim3(256), 0, s, d_r_sorted,
-                       d_p_sorted, d_perm, (long long)Vs, d_best, (long long)V, d_info_a, n_a, d_info_b, n_b, d_out,
-                       (long long)ld);
-    return lc::launched("k_fold_pack");
+    return lc_fold_pack_at(d_r_sorted, d_p_sorted, d_perm, Vs, d_best, V, d_info_a, n_a, d_info_b, n_b, d_out, ld, 0, 1, stream);
 }
 
 extern "C" int lc_fold_unpack(const double* d_src, int world, int64_t ld, const int64_t* d_lo, int64_t w_max, double* d_r,

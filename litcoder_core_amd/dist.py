@@ -42,8 +42,14 @@ def job_share(n_jobs: int, world: int, rank: int) -> Tuple[int, range]:
     return n_per, range(min(n_jobs, rank * n_per), min(n_jobs, (rank + 1) * n_per))
 
 
+_LANES = {}     # (group ranks, backend) -> {"hat": group, "refit": group}: communicators are created once per process
+
+
 class ShardContext:
-    """Wraps a torch.distributed process group (or nothing, for a single process)."""
+    """Wraps a torch.distributed process group (or nothing, for a single process).  Constructing a context whose
+    collectives are active is itself COLLECTIVE over the whole default group the first time a (group, backend) pair is
+    seen (torch.distributed.new_group must be entered by every process, members or not): build it on every rank, in
+    the same order."""
 
     def __init__(self, group=None, device=None, always_collective=False, global_lists=True):
         """``always_collective``: issue the backend's collectives even in a one-rank group (they are no-ops
@@ -59,7 +65,12 @@ class ShardContext:
         self.device = device
         self.rank = self._dist.get_rank(group) if self._dist else 0
         self.world = self._dist.get_world_size(group) if self._dist else 1
-        self.backend = str(self._dist.get_backend(group)) if self._dist else None
+        # the transport per device type: "nccl" (RCCL) moves device tensors where they live, "gloo" host tensors; a
+        # default group initialised without a backend reports e.g. "cpu:gloo,cuda:nccl" and moves both directly
+        raw = str(self._dist.get_backend(group)).lower() if self._dist else ""
+        self._cuda_direct = "nccl" in raw
+        self._cpu_direct = "gloo" in raw or "mpi" in raw
+        self.backend = ("nccl" if raw == "nccl" else "gloo" if raw == "gloo" else raw) if self._dist else None
         self.simulate = False
         self.global_lists = bool(global_lists)
         self.always = bool(always_collective) and self._dist is not None
@@ -68,8 +79,13 @@ class ShardContext:
         # fold 0 needs NOW must not sit behind them -- so the bulk traffic gets communicators ("lanes") of its own.
         self._lanes = {}
         if self._dist is not None and (self.world > 1 or self.always):
-            for lane in ("hat", "refit"):
-                self._lanes[lane] = self._dist.new_group(backend=self.backend)     # all ranks, same order everywhere
+            ranks = tuple(self._dist.get_process_group_ranks(group)) if group is not None else None
+            key = (ranks, raw)
+            if key not in _LANES:                       # the lanes span exactly the ranks of ``group``
+                be = None if raw in ("", "undefined") else raw
+                _LANES[key] = {lane: self._dist.new_group(ranks=list(ranks) if ranks is not None else None, backend=be)
+                               for lane in ("hat", "refit")}               # same order on every process
+            self._lanes = _LANES[key]
 
     @classmethod
     def single(cls, device=None):
@@ -77,6 +93,7 @@ class ShardContext:
         ctx = cls.__new__(cls)
         ctx._dist, ctx.group, ctx.device, ctx.rank, ctx.world, ctx.backend = None, None, device, 0, 1, None
         ctx.simulate, ctx.always, ctx._lanes, ctx.global_lists = False, False, {}, True
+        ctx._cuda_direct, ctx._cpu_direct = False, False
         return ctx
 
     @classmethod
@@ -105,7 +122,7 @@ class ShardContext:
     # ------------------------------------------------------------------ device-tensor collectives
     def _direct(self, t) -> bool:
         """True when the backend moves ``t`` where it lives (RCCL for device tensors, gloo for host tensors)."""
-        return (self.backend == "nccl") == bool(t.is_cuda)
+        return self._cuda_direct if t.is_cuda else self._cpu_direct
 
     def all_gather(self, t, lane=None):
         """(world, *t.shape): every rank's ``t`` (same shape and dtype everywhere), on ``t``'s device, ordered on the
@@ -151,7 +168,7 @@ class ShardContext:
         if self.world == 1 or self.simulate:
             return arr
         t = torch.from_numpy(np.ascontiguousarray(arr).copy())
-        if self.backend == "nccl":
+        if not self._cpu_direct:
             t = t.to(self.device)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
@@ -168,7 +185,7 @@ class ShardContext:
         pad = np.zeros((k, wmax), dtype=arr.dtype)
         pad[:, : arr.shape[1]] = arr
         mine = torch.from_numpy(pad)
-        if self.backend == "nccl":
+        if not self._cpu_direct:
             mine = mine.to(self.device)
         parts = self.all_gather(mine).cpu().numpy()
         out = np.empty((k, n_total), dtype=arr.dtype)

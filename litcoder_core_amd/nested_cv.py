@@ -55,21 +55,27 @@ FOLDS_IN_ONE_LAUNCH = False         # one launch per pass for all inner folds of
 SERIES_FUSED_MOMENTS = True         # series terms reduced to moments in the contraction's epilogue (never stored)
 PRIMAL_MOMENTS_MAX_P = 16           # ... and, up to this many features, scored from block products X'Y alone (_prepare_moments)
 PRIMAL_MAX_P = 512                  # the primal (p x p) form is taken for tall designs up to this many features
+SPECULATE_FIRST_FOLD = True         # the first fold's refit systems for every factorised alpha, beside its hat-matrix chain
+REFIT_FROM_IMAGE = True             # the refit's alpha-sorted fp16 operand as a column gather out of the inner CV's image
+PANEL_COLS = 24576                  # voxel columns per panel of a host-to-host fit (_column_panels): 96 column tiles x 8
+                                    # M-tiles of the sweeps = exactly 3 rounds of workgroups on 256 CUs
+PANEL_MIN_COLS = 16384              # below twice this many voxels a fit is not cut into panels
 MAX_ALPHAS = 64                     # lc_group_by_alpha / the grouped GEMMs carry at most 64 alpha groups per launch
 MAX_INNER_FOLDS = 64                # the series chain runs the inner folds as column groups of one grouped launch
 
 
 def check_penalties(alphas, singcutoff, normalpha, n_inner_folds=None):
-    """Host-side validation of the penalty grid, before anything touches the device.
+    """Host-side validation of the penalty grid, before anything touches the device.  Returns True when the fit has to
+    take the SPECTRAL route (csrc/lc_eig.hip) instead of the Cholesky one.
 
-    Deviation from the reference, stated where a caller meets it: the reference takes a thin SVD, DROPS singular
-    values <= ``singcutoff`` (ridge_utils.py:44-63) and shrinks the rest by S / (S^2 + a^2) (ridge_regression.py:56,
-    117), which is defined for alpha = 0 (pseudo-inverse).  Here (K + a^2 I) is factored by Cholesky: it needs
-    a^2 > 0, and it truncates nothing -- a direction the reference would drop contributes at most
-    (singcutoff / a)^2 to a prediction.  That is < 1e-6 (invisible in fp32) whenever singcutoff <= 1e-3 a_min, which
-    holds for every shipped caller (singcutoff 1e-10 / 1e-30, alphas >= 0.1); outside that range this raises instead
-    of silently returning something else.  With ``normalpha`` a = alpha S[0]: the bound is re-checked against the
-    measured S[0] of every training block (RidgeCVEngine._check_singcutoff)."""
+    The reference takes a thin SVD, DROPS singular values <= ``singcutoff`` (ridge_utils.py:44-63) and shrinks the
+    rest by S / (S^2 + a^2) (ridge_regression.py:56,117), which is defined for alpha = 0 (pseudo-inverse).  The fast
+    route factors (K + a^2 I) by Cholesky: it needs a^2 > 0, and it truncates nothing -- a direction the reference
+    would drop contributes at most (singcutoff / a)^2 to a prediction, < 1e-6 (invisible in fp32) whenever
+    singcutoff <= 1e-3 a_min, which holds for every shipped caller (singcutoff 1e-10 / 1e-30, alphas >= 0.1).
+    Outside that range -- alpha = 0 in the grid, or a singcutoff that is not negligible against the smallest penalty
+    (with ``normalpha`` a = alpha S[0] and S[0] is not known yet: not negligible against alpha_min itself) -- the
+    operators come from the eigendecomposition of K[tr, tr] with exactly the reference's truncation, in fp64, slower."""
     al = np.asarray(list(alphas), dtype=np.float64).reshape(-1)
     if al.size == 0:
         raise ValueError("alphas is empty")
@@ -78,19 +84,15 @@ def check_penalties(alphas, singcutoff, normalpha, n_inner_folds=None):
                          f"{MAX_ALPHAS} groups per launch")
     if n_inner_folds is not None and int(n_inner_folds) > MAX_INNER_FOLDS:
         raise ValueError(f"at most {MAX_INNER_FOLDS} inner folds per fit (got {n_inner_folds})")
-    if not np.all(np.isfinite(al)) or np.any(al <= 0):
-        raise ValueError(
-            "alphas must be finite and > 0: this implementation factors (X X' + a^2 I) by Cholesky and does not "
-            "reproduce the reference's alpha = 0 case (pseudo-inverse with singular values <= singcutoff dropped, "
-            "encoding/models/ridge_utils.py:44-63, ridge_regression.py:56,117)")
+    if not np.all(np.isfinite(al)) or np.any(al < 0):
+        raise ValueError("alphas must be finite and >= 0 (the penalty is alpha^2: ridge_regression.py:56,117)")
     sc = float(singcutoff)
     if not (sc >= 0) or not np.isfinite(sc):
         raise ValueError("singcutoff must be a finite number >= 0")
-    if not normalpha and sc > SINGCUTOFF_REL * float(al.min()):
-        raise ValueError(
-            f"singcutoff={sc:g} is not negligible against the smallest penalty a={al.min():g} (need singcutoff <= "
-            f"{SINGCUTOFF_REL:g} a): the reference would drop singular values <= singcutoff "
-            "(encoding/models/ridge_utils.py:44-63), this implementation never truncates")
+    pos = al[al > 0]
+    if pos.size < al.size:
+        return True                                    # alpha = 0: the pseudo-inverse of the kept directions
+    return bool(sc > (1e-6 if normalpha else SINGCUTOFF_REL) * float(pos.min()))
 
 
 class _PrimalUnsuitable(Exception):
@@ -157,6 +159,62 @@ def _main_stream():
     return _MAIN_STREAMS[key]
 
 
+class _WideTargets(Exception):
+    """precision="auto" met a target column whose dynamic range the fp16 hi/lo split cannot carry AFTER the fit was set up
+    for it (host inputs arrive panel by panel, so the decision cannot be taken up front): the driver repeats the fit on
+    the f32 MFMA path with the targets that are resident by then."""
+
+
+class _Range:
+    """A contiguous range [c0, c0 + V) of this rank's voxel columns: the unit a V-wide phase of a fold works on.  The
+    targets and the mean weights of the rank live in ONE (T, Vp) / (p, Vp) buffer each; a range sees column views of
+    them (row stride = the buffer's), so a fold can be processed full width or panel by panel -- panels while the
+    targets are still arriving from the host (first fold) and while the finished weights leave for it (last fold).
+    Interior boundaries are multiples of 256 columns (the widest column tile), so only the last range carries padding."""
+    __slots__ = ("c0", "V", "Vp", "Y", "W", "scales", "natural", "key")
+
+    def __init__(self, c0, V, Vp, Y, W):
+        self.c0, self.V, self.Vp, self.Y, self.W = int(c0), int(V), int(Vp), Y, W
+        self.scales = None             # (cs, split) of the un-normalised targets of the range (_target_scales)
+        self.natural = None            # 0 .. V-1 on the device (moments form)
+        self.key = (self.c0, self.V)
+
+
+def _column_panels(V, cols=None, min_cols=None, v_ref=None):
+    """[c0, c1) panels of V voxel columns for a host-to-host fit, boundaries on multiples of 256: ``cols`` wide in the
+    middle, ramping up from cols / 3 at the front (the first fold starts on the first panel while the others still
+    cross PCIe: a narrow one is there early) and down to <= cols / 3 at the end (the last panel's weights are the only
+    download nothing overlaps).  With the default width the panels of the sweeps' 8 M-tiles are whole rounds of
+    workgroups on 256 CUs (8192 columns = one round).  ``v_ref``: the column count the PLAN is derived from (voxel
+    shards: the narrowest rank's, so that every rank cuts its block into the same number of panels -- the ranks'
+    collectives pair up range by range); the last panel absorbs the difference."""
+    cols = PANEL_COLS if cols is None else int(cols)
+    min_cols = PANEL_MIN_COLS if min_cols is None else int(min_cols)
+    v_ref = int(V) if v_ref is None else min(int(v_ref), int(V))
+    if cols % 256:
+        raise ValueError("panel width must be a multiple of 256 columns")
+    if v_ref < 2 * min_cols or v_ref <= cols:
+        return [(0, int(V))]
+    third = max(256, (cols // 3) // 256 * 256)
+    widths, left = [], v_ref
+    for w in (third, 2 * third):                           # ramp up
+        if left > w + third:
+            widths.append(w)
+            left -= w
+    while left > cols + third:                             # full panels
+        widths.append(cols)
+        left -= cols
+    if left > 2 * 256:                                     # ramp down: what is left, minus a narrow last panel
+        tail = min(third, (left // 2) // 256 * 256)
+        body = (left - tail) // 256 * 256
+        widths += [body, left - body]
+    else:
+        widths.append(left)
+    edges = np.concatenate([[0], np.cumsum(widths)]).astype(np.int64)
+    edges[-1] = int(V)
+    return [(int(edges[i]), int(edges[i + 1])) for i in range(len(widths))]
+
+
 class RidgeCVEngine:
     """Device-resident state of one fit: fp32 copies of X / Y (zero padded), the Gram matrix, and the
     per-fold pipeline.  ``Y`` holds only this rank's voxel block."""
@@ -164,27 +222,28 @@ class RidgeCVEngine:
     def __init__(self, X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets,
                  shard: Optional[ShardContext] = None, lanczos_steps: int = LANCZOS_STEPS, precision: str = "auto",
                  singcutoff: float = 0.0, V_total: Optional[int] = None, min_train_rows: Optional[int] = None,
-                 form: str = "dual"):
+                 form: str = "dual", panels=None):
         """``form``: "dual" (n x n Gram / hat matrices: every shape), "primal" (p x p systems, see _prepare_primal) or
         "auto" = primal when the design is tall, 2 p <= ``min_train_rows`` (the smallest inner training set) and
-        p <= PRIMAL_MAX_P."""
-        check_penalties(alphas, singcutoff, normalpha)
+        p <= PRIMAL_MAX_P.  ``Y_all``: a host array / ops.HostRows (uploaded in the column ``panels`` [(c0, c1), ...] on a
+        background thread while the fit is being set up) or resident targets (_DeviceShapes)."""
+        self.spectral = check_penalties(alphas, singcutoff, normalpha)
         self.singcutoff = float(singcutoff)
         self.dev = ops.device()
         self.shard = shard or ShardContext.single()
         if not isinstance(X_all, _DeviceShapes):
             X_all = np.asarray(X_all)
+        if not isinstance(Y_all, (_DeviceShapes, ops.HostRows)):
+            Y_all = ops.HostRows([Y_all])
         self.Ttot, self.p = X_all.shape
-        self.V = Y_all.shape[1]
+        self.V_rank = Y_all.shape[1]                   # voxel columns of this rank (all its ranges together)
         if Y_all.shape[0] != self.Ttot:
             raise RuntimeError(f"shape mismatch: features have {self.Ttot} rows, targets {Y_all.shape[0]}")
         self.p_pad = ops.pad_to(self.p, K_TILE)
-        self.Vp = ops.pad_to(max(self.V, 1), COL_TILE)
+        self.Vp_rank = ops.pad_to(max(self.V_rank, 1), COL_TILE)
         self.alphas = [float(a) for a in alphas]
         self.A = len(self.alphas)
         self.normalpha = bool(normalpha)
-        # normalpha: a = alpha S[0]; the truncation bound needs S[0] when singcutoff is not tiny against alpha alone
-        self._cut_pending = self.normalpha and self.singcutoff > 1e-6 * min(self.alphas)
         self.mode = LC_SCORE_CORR if use_corr else LC_SCORE_R2
         self.norm_x, self.norm_y = bool(normalize_features), bool(normalize_targets)
         self.steps = int(lanczos_steps)
@@ -195,18 +254,51 @@ class RidgeCVEngine:
             raise ValueError(f"form must be 'dual', 'primal' or 'auto', got {form!r}")
         self.primal = form == "primal" or (form == "auto" and min_train_rows is not None
                                            and 2 * self.p <= int(min_train_rows) and self.p <= PRIMAL_MAX_P)
+        if self.spectral:
+            # alpha = 0 / a biting singcutoff: the reference's truncated SVD, reproduced from the eigendecomposition of
+            # the n x n Gram blocks (dual form for every shape; see check_penalties and _spectral_operators)
+            logger.info("penalty grid outside the Cholesky route (alpha = 0 or singcutoff not negligible): spectral route")
+            self.primal = False
+        self.moments = self.primal and self.p <= PRIMAL_MOMENTS_MAX_P and bool(use_corr)
         self.PP = ops.pad_to(self.p, LC_NB)            # primal: padded system size
         # a handful of features + correlation scoring: the whole nested CV from block products X'Y (_prepare_moments)
-        self.moments = self.primal and self.p <= PRIMAL_MOMENTS_MAX_P and bool(use_corr)
-        self.dX = self._resident(X_all, self.p_pad)
-        self.dY = self._resident(Y_all, self.Vp)
-        # the Gram matrix first: the host-side set-up below (polynomial coefficients, index tables) runs beside it
-        self.K = None if (self.norm_x or self.primal) else ops.gram(self.dX, self.Ttot, self.p)
+        self.moments = False                           # set below, once the form is known
+        # ---- the targets: resident already, or arriving from the host panel by panel on a background thread (started
+        # FIRST: everything below -- the design, its Gram matrix, the first fold's operators -- runs beside it)
+        self.uploader = None
+        self.upload_panels = [(0, self.V_rank)]
+        jobs = []
+        if isinstance(X_all, _DeviceShapes):
+            self.dX = self._resident(X_all, self.p_pad)
+        else:
+            self.dX = ops.zeros((self.Ttot, self.p_pad), torch.float32, self.dev)
+            if self.Ttot and self.p:
+                jobs.append((X_all, self.dX, 0, self.p))
+        self._x_job = 0 if jobs else None
+        if isinstance(Y_all, _DeviceShapes):
+            self.dY_full = self._resident(Y_all, self.Vp_rank)
+        else:
+            self.dY_full = torch.empty((self.Ttot, self.Vp_rank), dtype=torch.float32, device=self.dev)
+            ops.zero_cols(self.dY_full, self.V_rank, self.Vp_rank)
+            if self.V_rank and self.Ttot:
+                self.upload_panels = [(int(a), int(b)) for a, b in (panels or [(0, self.V_rank)])]
+                self._y_job0 = len(jobs)
+                jobs += [(Y_all, self.dY_full, a, b) for a, b in self.upload_panels]
+        if jobs:
+            zeroed = torch.cuda.Event()
+            zeroed.record()
+            self.uploader = ops.PanelUploader(jobs, self.dev, after=zeroed)
+        self.W_full = ops.zeros((self.p, self.Vp_rank), torch.float32, self.dev)
+        self.full = _Range(0, self.V_rank, self.Vp_rank, self.dY_full, self.W_full)
+        self.cur = self.full                           # the range the V-wide phase being queued works on (_enter)
+        self._ranges = {self.full.key: self.full}
+        # (the host-side set-up below -- polynomial coefficients, index tables -- runs while the design is crossing PCIe)
         self.d_alphas = ops.upload(np.asarray(self.alphas, dtype=np.float64), self.dev)
         # alphas whose penalty dwarfs the spectrum take the polynomial form of the inverse (shared matrix powers,
         # minimax coefficients: series.py), the rest the batched Cholesky.  Needs normalpha (a^2 = alpha^2 lambda_max
         # makes the coefficients a function of alpha alone).
         self.ser = [a for a in range(self.A) if not self.primal       # primal: every alpha is a tiny p x p factorisation
+                    and not self.spectral                             # spectral: every alpha from the eigenpairs
                     and self.normalpha and series.residual_bound(self.alphas[a], SERIES_TERMS) <= SERIES_TOL]
         self.cho = [a for a in range(self.A) if a not in self.ser]
         self.d_ser = ops.upload(np.asarray(self.ser, dtype=np.int32), self.dev) if self.ser else None
@@ -214,34 +306,56 @@ class RidgeCVEngine:
                                     for a in self.ser]) if self.ser else None)
         self.d_coef = ops.upload(np.asarray(self.coef_host, dtype=np.float64), self.dev) if self.ser else None
         self.d_cho = ops.upload(np.asarray(self.cho, dtype=np.int32), self.dev)
-        self.W_acc = ops.zeros((self.p, self.Vp), torch.float32, self.dev)
         self.aux = _aux_stream(self.dev)
         self.aux2 = _aux_stream(self.dev, 1)            # refit systems (see _refit_stream)
         self.comm = _aux_stream(self.dev, 2)            # per-fold result exchange + global statistics
         self.aux3 = _aux_stream(self.dev, 3)            # voxel shards: what a fold's refit still needs after refit_ahead
+        self.dl = _aux_stream(self.dev, 4)              # finished weight panels on their way to the host
         # voxel shards: this rank's block is columns [lo[rank], lo[rank + 1]) of V_total; the statistics tail (BH-FDR
         # ranks ALL p-values) runs on the gathered vectors, on the device, on every rank; the driver sets alpha_fdr
-        self.V_total = int(V_total) if V_total is not None else self.V
+        self.V_total = int(V_total) if V_total is not None else self.V_rank
         lo = self.shard.all_bounds(self.V_total)
-        if int(lo[self.shard.rank + 1] - lo[self.shard.rank]) != self.V:
-            raise ValueError(f"rank {self.shard.rank} of {self.shard.world} holds {self.V} voxel columns, its block of "
+        if int(lo[self.shard.rank + 1] - lo[self.shard.rank]) != self.V_rank:
+            raise ValueError(f"rank {self.shard.rank} of {self.shard.world} holds {self.V_rank} voxel columns, its block of "
                              f"{self.V_total} has {int(lo[self.shard.rank + 1] - lo[self.shard.rank])}")
         self.w_max = int(np.max(np.diff(lo)))
         self.d_lo = ops.upload(lo, self.dev)
         self.alpha_fdr = 0.05
         self.p_folds = None                            # (n_folds, V_total) NaN-free p-values of all voxels, device
-        self.n_folds_done = 0
-        self._base_scales = None                       # (cs, split) of the resident targets, see _target_scales
+        self.n_folds = 1
+        self._fold_blk = {}                            # fold -> the rank's packed (4, ld) result block being filled
         self.sweeps_done = None                        # end of the sweeps queued last (chain_gate)
-        self._natural = None                           # 0 .. V-1 on the device (moments form: results in voxel order)
         self._host_weights = None                      # future of the page-locked result buffer (reserve_host_weights)
+        self._host_w = None                            # ... the buffer itself once panels are leaving for it
+        self._sent = 0                                 # voxel columns of the weights already on their way to the host
+        self._assume_split = None                      # the arithmetic the operators are prepared for (_split_assumed)
+        self._decided = False                          # ... decided from ALL resident target columns (begin_fit)
+        # constants of the fit that every stream reads: made here, before ``ready``
+        self._d_one = ops.upload(np.ones(1, dtype=np.float64), self.dev)
+        self._eye, self._eye_key = None, None
+        self._eig_cache, self._n_real = {}, {}         # spectral route: eigenpairs of a fold's outer block; list lengths
         # what this fit ran, for the caller (NestedCVModel.last_fit; bench.py prices the roofline with it): arithmetic
         # of the sweeps, alphas scored inside the fused launch, algorithmic flops of the plain fp16x3 GEMMs.  Per
         # engine: two fits in one process do not share it.
         self.info = {"precision": None, "fused_alphas": self.A, "series_terms": 0, "plain_flops": 0.0,
-                     "plain_launches": 0, "used_all": None}
-        self.ready = torch.cuda.Event()               # X, Y, K resident: the only thing the aux stream waits for
+                     "plain_launches": 0, "used_all": None, "fused_flops": 0.0, "fused_launches": 0}
+        if self.uploader is not None:
+            if self._x_job is not None:
+                self.uploader.wait(self._x_job)        # the design is needed now (Gram matrix)
+            if len(jobs) == (1 if self._x_job is not None else 0):
+                self.uploader.join()                   # resident targets: nothing arrives later
+                self.uploader = None
+            elif panels is None:
+                self.finish_uploads()                  # no panel plan: the caller (tests, ridge.py) uses the targets at once
+        self.K = None if (self.norm_x or self.primal) else ops.gram(self.dX, self.Ttot, self.p)
+        self.ready = torch.cuda.Event()               # X, K resident: the only thing the aux stream waits for
         self.ready.record()
+
+    # the V-wide phases read the voxel range they work on through these (see _enter)
+    V = property(lambda self: self.cur.V)
+    Vp = property(lambda self: self.cur.Vp)
+    dY = property(lambda self: self.cur.Y)
+    W_acc = property(lambda self: self.cur.W)
 
     def _resident(self, arr, ld):
         if isinstance(arr, _DeviceShapes):  # already resident: fp32, contiguous, zero-padded to the tile width
@@ -251,46 +365,108 @@ class RidgeCVEngine:
             return t
         return ops.upload_f32(arr, ld, self.dev)
 
+    # -------------------------------------------------------------- voxel ranges
+    def range_of(self, c0, c1):
+        """The _Range of columns [c0, c1) of this rank's block (cached: its column scales are computed once)."""
+        c0, c1 = int(c0), int(c1)
+        key = (c0, c1 - c0)
+        if key not in self._ranges:
+            if not (0 <= c0 < c1 <= self.V_rank) or c0 % 256 or (c1 % 256 and c1 != self.V_rank):
+                raise ValueError("voxel ranges must start and end on multiples of 256 columns (the last one at V)")
+            vp = (c1 - c0) if c1 != self.V_rank else self.Vp_rank - c0
+            self._ranges[key] = _Range(c0, c1 - c0, vp, self.dY_full[:, c0:c0 + vp], self.W_full[:, c0:c0 + vp])
+        return self._ranges[key]
+
+    def _enter(self, st):
+        """Make the range of a fold state the one the engine's V-wide methods see (V, Vp, dY, W_acc)."""
+        self.cur = st["rg"]
+        return st
+
+    def _wait_targets(self, rg):
+        """Host inputs: the upload panels that cover the range have been issued (host) and the current stream waits for
+        their copies (device)."""
+        if self.uploader is None:
+            return
+        for b, (c0, c1) in enumerate(self.upload_panels):
+            if c0 < rg.c0 + rg.V and rg.c0 < c1:
+                self.uploader.wait(self._y_job0 + b)
+
+    def plan_steps(self, n_folds, single_alpha=False):
+        """The (fold, range) steps of the fit in execution order.  Folds are processed full width, except: while the
+        targets arrive from the host the first fold works panel by panel (a panel's sweeps start when ITS columns are
+        resident), and when the weights go back to the host the last fold does (a panel's weights leave while the
+        next panel's are computed).  ``single_alpha`` needs the scores of all voxels before any refit: full width."""
+        full = [(0, self.V_rank)]
+        cut = self.upload_panels if (len(self.upload_panels) > 1 and not single_alpha) else full
+        plan = []
+        for f in range(n_folds):
+            first = f == 0 and self.uploader is not None
+            last = f == n_folds - 1 and self._host_weights is not None
+            for c0, c1 in (cut if (first or last) else full):
+                plan.append((f, (c0, c1)))
+        return plan
+
     # -------------------------------------------------------------- per-outer-fold data
-    def _fold_data(self, tr_rows):
-        """Train-statistics z-scoring of X and/or Y for this outer fold (DataNormalizer,
-        ridge_utils.py:70-180; nested_cv.py:111-124,204-213) and the matching Gram matrix."""
-        X, Y, K = self.dX, self.dY, self.K
-        if self.norm_x or self.norm_y:
-            rows = ops.idx_tensor(tr_rows, len(tr_rows), self.dev)
+    def _fold_design(self, tr_rows):
+        """Train-statistics z-scoring of X for this outer fold (DataNormalizer, ridge_utils.py:70-180;
+        nested_cv.py:111-124,204-213) and the matching Gram matrix: the V-independent half of the fold's data."""
+        X, K = self.dX, self.K
         if self.norm_x:
+            rows = ops.idx_tensor(tr_rows, len(tr_rows), self.dev)
             mean, std = ops.col_mean_std(self.dX, rows, len(tr_rows), self.p)
             X = self.dX.clone()
             ops.col_normalize_(X, self.Ttot, self.p, mean, std)
             K = None if self.primal else ops.gram(X, self.Ttot, self.p)
-        if self.norm_y:
-            mean, std = ops.col_mean_std(self.dY, rows, len(tr_rows), self.V)
-            Y = self.dY.clone()
-            ops.col_normalize_(Y, self.Ttot, self.V, mean, std)
-        if self.moments:
-            return X, Y, K, None, False      # fp64 block products: no fp16 operands, no column scales
-        cs, split = self._target_scales(Y)   # new target values have column scales of their own: per-fold state
-        return X, Y, K, cs, split
+        return X, K
 
-    def _target_scales(self, Y):
+    def _fold_targets(self, rg, tr_rows):
+        """(Y, cs, split) of a voxel range for one outer fold: the resident targets, or -- normalize_targets -- their
+        train-statistics z-scored copy with column scales of its own (per-fold state: folds are pipelined)."""
+        Y = rg.Y
+        if self.norm_y:
+            rows = ops.idx_tensor(tr_rows, len(tr_rows), self.dev)
+            mean, std = ops.col_mean_std(rg.Y, rows, len(tr_rows), rg.V)
+            Y = rg.Y.clone()
+            ops.col_normalize_(Y, self.Ttot, rg.V, mean, std)
+        if self.moments:
+            return Y, None, False            # fp64 block products: no fp16 operands, no column scales
+        cs, split = self._target_scales(Y, rg)
+        return Y, cs, split
+
+    def _split_assumed(self):
+        """The arithmetic the V-independent operators are prepared for before any target value has been looked at:
+        f16x3 unless the caller asked for f32 (a range of "auto" that turns out too wide raises _WideTargets)."""
+        if self._assume_split is None:
+            self._assume_split = self.precision != "f32"
+        return self._assume_split
+
+    def _target_scales(self, Y, rg=None):
         """(cs, split) for one target matrix: ``split`` = the V-wide contractions run as "f16x3" -- fp16 hi + lo
         operands after an exact power-of-two scale per H row / Y column, three fp16 MFMAs per product, fp32
         accumulate (22-bit operands: fp32-level scores, ~3x faster than the f32-input MFMA) -- and ``cs`` the
         (2 Vp,) column scales that go with it (2^-e, then 2^e).  "auto" takes the split unless a target column is
         non-finite or dominated by outliers (most entries > 2^9 below the column maximum).  The scales belong to
         the VALUES of ``Y``: with normalize_targets every outer fold has its own (fold state, never engine state:
-        folds are pipelined over streams); only those of the resident, un-normalised targets are cached."""
+        folds are pipelined over streams); only those of the resident, un-normalised targets are cached (per range).
+        The flag is agreed over the voxel shards (MAX all-reduce on the device) BEFORE the host looks at it: the
+        arithmetic decides which collectives _hat_matrices issues, and every rank must issue the same ones."""
+        rg = rg or self.cur
         if self.precision == "f32":
             return None, False
-        if Y is self.dY and self._base_scales is not None:
-            return self._base_scales
-        cs, flag = ops.col_scales_f16(Y, self.Ttot, self.Vp)
-        wide = bool(int(flag.cpu()[0])) if self.precision == "auto" else False
+        if Y is rg.Y and rg.scales is not None:
+            return rg.scales
+        cs, flag = ops.col_scales_f16(Y, self.Ttot, rg.Vp)
+        wide = False
+        if self.precision == "auto" and not (self._decided and Y is rg.Y):
+            self.shard.all_reduce_(flag, "max")
+            wide = bool(int(flag.cpu()[0]))
         if wide:
+            if self._assume_split:
+                raise _WideTargets("target dynamic range too wide for the fp16x3 sweep")
             logger.info("target dynamic range too wide for the fp16x3 sweep: using the f32 MFMA path")
         out = (cs, not wide)
-        if Y is self.dY:
-            self._base_scales = out
+        if Y is rg.Y:
+            rg.scales = out
         return out
 
     # -------------------------------------------------------------- S[0]^2 of every train set (Lanczos)
@@ -308,25 +484,22 @@ class RidgeCVEngine:
         return res
 
     def _check_singcutoff(self, lmax):
-        """normalpha: singcutoff against a_min = alpha_min S[0] with the measured S[0]^2 = lambda_max of the training
-        blocks (one host sync, only when singcutoff is not already negligible against alpha_min alone)."""
-        if not self._cut_pending or lmax is None:
-            return
-        s0 = float(torch.sqrt(lmax.min()).cpu())
-        a_min = min(self.alphas) * s0
-        if self.singcutoff > SINGCUTOFF_REL * a_min:
-            raise ValueError(
-                f"singcutoff={self.singcutoff:g} is not negligible against the smallest penalty a = alpha S[0] = "
-                f"{a_min:g} (need singcutoff <= {SINGCUTOFF_REL:g} a): the reference would drop singular values <= "
-                "singcutoff (encoding/models/ridge_utils.py:44-63), this implementation never truncates")
+        """(Round 3: a singcutoff that could bite takes the spectral route from the start -- check_penalties -- so there
+        is nothing left to verify against the measured S[0]; kept as the hook the callers have.)"""
+        return
 
     def begin_fit(self, n_folds=1):
         """Decide the arithmetic of the V-wide contractions now (column scales of the targets + the one flag that
         comes to the host), so that the first fold's set-up is enqueued without waiting on the device."""
-        if not self.norm_y and not self.moments:
-            self._target_scales(self.dY)
+        if not self.norm_y and not self.moments and self.uploader is None and self.precision == "auto":
+            # resident targets: one look at all columns decides the arithmetic of the whole fit, ranges included
+            _, split = self._target_scales(self.dY_full, self.full)
+            self._assume_split, self._decided = split, True
+            if not split:
+                self.precision = "f32"
         self.p_folds = torch.empty((int(n_folds), self.V_total), dtype=torch.float64, device=self.dev)
-        self.n_folds_done = 0
+        self.n_folds = int(n_folds)
+        self._fold_blk = {}
 
     def _join_flags(self, parts):
         """One int32 vector from the pivot-flag vectors of several batches (D2D copies, no framework kernel)."""
@@ -537,7 +710,17 @@ class RidgeCVEngine:
             series_ready = torch.cuda.Event() if self.dev.type == "cuda" else None
             if series_ready is not None:
                 series_ready.record()           # the series operands of this chunk are complete; Cholesky follows
-            if Ac:
+            if Ac and self.spectral:
+                if chol_after is not None:
+                    torch.cuda.current_stream().wait_event(chol_after)
+                # every alpha of every inner fold of the chunk from ONE eigendecomposition per fold (replicated on every
+                # rank of a sharded fit: no collective)
+                rows_f = tr[f0:f0 + fc]
+                Hs_ = self._spectral_operators(K, rows_f, va[f0:f0 + fc], None, fc, N, M, a2[f0 * A:(f0 + fc) * A], A,
+                                               [min(n_i[f0 + j], self.p) for j in range(fc)], out=H)
+                infos.append(ops.zeros(fc * A, torch.int32, self.dev))
+                assert Hs_ is H
+            elif Ac:
                 if chol_after is not None:
                     torch.cuda.current_stream().wait_event(chol_after)
                 # job j = (inner fold f0 + j // Ac, Cholesky alpha j % Ac) = system (f0 + j // Ac) * A + cho[j % Ac] of
@@ -606,6 +789,7 @@ class RidgeCVEngine:
                 ops.split_cols_f16(Y, self.Vp, ops.idx_tensor(union, len(union), self.dev), len(union), cs, Yu)
                 Yt = [Yu] * nbuf
                 views = [(len(union), g0, gl) for g0, gl in gaps]
+                hat["image"] = (Yu, union)                # the refit permutes its operand out of it (_refit_operands)
             else:
                 Yt = [torch.empty(Vt * N * 2, dtype=torch.float16, device=self.dev) for _ in range(nbuf)]
                 views = [(0, 0, 0)] * F
@@ -667,6 +851,8 @@ class RidgeCVEngine:
                 ops.split_rows_f16_groups(H.view(-1, N), fc, Ad * M, N, Ht[f0 * rows_pad * N * 2:], rs_inv[f0 * rows_pad:])
             ops.alpha_sweep_scores_f16x3_folds(Ht, rs_inv, Ad, M, N, Yu, cs[self.Vp:], yv, self.Vp, n_v, ystat, yblk, self.mode,
                                                part, scores_d, False, views)
+            self.info["fused_flops"] += sum(2.0 * Ad * n_v[f] * hat["n_i"][f] * self.V for f in range(F))
+            self.info["fused_launches"] += 1
             self.info["folds_per_launch"] = F
         for f, j, H, P in (() if (moments and merged) else folds):
             b = f if moments else 0
@@ -676,10 +862,14 @@ class RidgeCVEngine:
                 if not moments and shared is None:
                     ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[b])
                 if Ad:
+                    self.info["fused_flops"] += 2.0 * Ad * n_v[f] * hat["n_i"][f] * self.V
+                    self.info["fused_launches"] += 1
                     ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
                     ops.alpha_sweep_scores_f16x3(Ht, rs_inv, Ad, M, N, Yt[b], cs[self.Vp:], yv[b], self.Vp, n_v[f], ystat[b],
                                                  yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f])
             else:
+                self.info["fused_flops"] += 2.0 * A * n_v[f] * hat["n_i"][f] * self.V
+                self.info["fused_launches"] += 1
                 ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], yv[b], n_v[f], ystat[b], yblk[b],
                                        self.mode, part, scores, accumulate=f > 0)
         if moments and Ad and not cho_first:
@@ -767,6 +957,33 @@ class RidgeCVEngine:
             ops.gather_sub_f64(K, ops.idx_tensor(te_rows, n_t, self.dev), tr_o, 1, n_t, N_o, rhs[self.p_pad:self.p_pad + n_t])
         return rhs
 
+    def _spectral_operators(self, K, rows, rows_r, rhs, F, N, M, a2, A, caps, out=None, cache_key=None):
+        """The reference's operators where the Cholesky route cannot follow it (alpha = 0, biting singcutoff):
+            out[f A + a] (M, N) f32 = R_f U_k diag(1 / (lambda_k + a2[f A + a])) U_k',
+        U, lambda the eigenpairs of K[rows_f, rows_f] (fp64 cyclic Jacobi, lc_batch_eigh_jacobi), kept when
+        sqrt(lambda) > singcutoff and among the ``caps[f]`` = min(n, p) largest -- exactly svd_wrapper's truncation
+        (ridge_utils.py:44-63) followed by D = S / (S^2 + a^2) (ridge_regression.py:56,117).  R_f = K[rows_r[f], rows_f]
+        (hat matrices) or the given ``rhs`` (F, M, N) f64 (refit rows).  ``cache_key``: keep the eigenpairs of the
+        (single) system for later calls of the same fold."""
+        eig = self._eig_cache.get(cache_key) if cache_key is not None else None
+        if eig is None:
+            Ksub = torch.empty((F, N, N), dtype=torch.float64, device=self.dev)
+            ops.gather_sub_f64(K, rows, rows, F, N, N, Ksub)
+            lam, vt, _, sweeps = ops.batch_eigh(Ksub)
+            logger.info("spectral route: %d system(s) of %d rows diagonalised in %d Jacobi sweeps", F, N, sweeps)
+            eig = (lam, vt)
+            if cache_key is not None:
+                self._eig_cache[cache_key] = eig
+        lam, vt = eig
+        if rhs is None:
+            rhs = torch.empty((F, M, N), dtype=torch.float64, device=self.dev)
+            ops.gather_sub_f64(K, rows_r, rows, F, M, N, rhs)
+        if out is None:
+            out = torch.empty((F * A, M, N), dtype=torch.float32, device=self.dev)
+        cap = ops.upload(np.asarray(caps, dtype=np.int32), self.dev)
+        ops.batch_spectral_apply(lam, vt, rhs, a2, A, self.singcutoff, cap, out)
+        return out
+
     def _refit_chol(self, K, tr_o, lmax_o, rhs, alphas_idx):
         """rhs (K[tr,tr] + a^2 I)^-1 for the listed alphas by the augmented batched Cholesky in fp64:
         ((len(alphas_idx), rows, N_o) f32, pivot flags of this rank's share).  Voxel shards: the batch is dealt out
@@ -774,6 +991,12 @@ class RidgeCVEngine:
         cut into S slices (each job then factors K + a^2 I again, N^3/3 of the system's N^3/3 + 2 N^2 rows flops) --
         and all-gathered; every rank must be called with the same ``alphas_idx``."""
         Gc, (rows, N_o) = len(alphas_idx), rhs.shape
+        if self.spectral:
+            d_al = ops.upload(np.asarray([self.alphas[a] for a in alphas_idx], dtype=np.float64), self.dev)
+            a2_sel = ops.penalties(lmax_o, 1, d_al, self.normalpha)
+            H = self._spectral_operators(K, tr_o, None, rhs.reshape(1, rows, N_o), 1, N_o, rows, a2_sel, Gc,
+                                         [min(self._real_rows(tr_o), self.p)], cache_key=("refit", tr_o.data_ptr()))
+            return H.view(Gc, rows, N_o), ops.zeros(max(Gc, 1), torch.int32, self.dev)
         a2_o = ops.penalties(lmax_o, 1, self.d_alphas, self.normalpha)              # (A,): grid F = 1
         if self._refit_by_inverse(alphas_idx):
             eye = self._identity_rows(N_o)
@@ -810,6 +1033,13 @@ class RidgeCVEngine:
         Hj, info = self._sharded_solve(Gc * S, N_o, rs, assemble if S > 1 else assemble_whole, lane="refit")
         return Hj[: Gc * S].view(Gc, rows, N_o), info
 
+    def _real_rows(self, idx):
+        """Number of real (non-padding) entries of an int32 device index list (one small D2H: spectral route only)."""
+        key = idx.data_ptr()
+        if key not in self._n_real:
+            self._n_real[key] = int((idx.cpu() >= 0).sum())
+        return self._n_real[key]
+
     def _refit_by_inverse(self, alphas_idx):
         """The refit operator  R (K + a^2 I)^-1,  R = [Xtr' ; K[te,tr]]  (3072 + 600 rows at cfg2), through the explicit
         inverse (N^3 fp64 flops, lc_batch_chol_inverse) and ONE product R P on the fp16x3 MFMA instead of triangular
@@ -820,15 +1050,22 @@ class RidgeCVEngine:
         # (voxel shards: every rank applies every inverse it needs itself -- the same products on every rank -- while
         # the row-sliced solves shrink with the ranks: measured per simulated rank 81.8 vs 84.2 ms at 2, 53.6 vs 53.8
         # at 4, 40.2 vs 39.0 ms at 8 ranks; so the solves from 8 ranks on)
-        return (REFIT_BY_INVERSE and self.normalpha and not self.primal and self.precision != "f32"
+        return (REFIT_BY_INVERSE and self.normalpha and not self.primal and not self.spectral and self.precision != "f32"
                 and self.shard.world <= REFIT_INVERSE_MAX_WORLD
                 and len(alphas_idx) > 0 and min(self.alphas[a] for a in alphas_idx) >= REFIT_INVERSE_MIN_ALPHA)
 
     def _identity_rows(self, N_o):
-        if getattr(self, "_eye_key", None) != N_o:
+        """(N_o, N_o) f64 identity, cached.  It is made on whichever stream asks first and read from others later: the
+        event recorded behind its creation is waited for at every later use."""
+        if self._eye_key != N_o:
             idx = ops.upload((-(2 + np.arange(N_o))).astype(np.int32).reshape(1, N_o), self.dev)
-            self._eye = ops.gather_rows_f64(self.dX, idx, 1, N_o, 1, N_o)[0]       # (N_o, N_o) f64 identity (unit rows only)
+            self._eye = ops.gather_rows_f64(self.dX, idx, 1, N_o, 1, N_o)[0]       # unit rows only
             self._eye_key = N_o
+            self._eye_ev = torch.cuda.Event()
+            self._eye_ev.record()
+        else:
+            torch.cuda.current_stream().wait_event(self._eye_ev)
+            self._eye.record_stream(torch.cuda.current_stream())
         return self._eye
 
     def _apply_inverses(self, rhs, P):
@@ -855,11 +1092,9 @@ class RidgeCVEngine:
         return out
 
     def _one(self):
-        if getattr(self, "_d_one", None) is None:
-            self._d_one = ops.upload(np.ones(1, dtype=np.float64), self.dev)
-        return self._d_one
+        return self._d_one                             # made in __init__, before ``ready``: every stream may read it
 
-    def _refit_systems(self, X, K, tr_rows, used, tr_o=None, lmax_o=None, te_rows=(), spec=None, used_all=None):
+    def _refit_systems(self, X, K, tr_rows, used, tr_o=None, lmax_o=None, te_rows=(), spec=None, used_all=None, cache=None):
         """Per alpha in use, the rows  [Xtr' ; K[te,tr]] (K[tr,tr] + a^2 I)^-1  as f32 (G, p_pad + pad32(n_te), N_o):
         M_alpha, whose product with the targets is the weight matrix (the V-independent half of
         ridge_regression.py:46-61), and below it the hat matrix of the test rows, whose product with the same
@@ -867,71 +1102,107 @@ class RidgeCVEngine:
         Augmented batched Cholesky in fp64; ``spec`` (fold_speculate) holds systems solved ahead of the alpha
         choice, which are taken from there.  ``used`` = the alphas THIS rank's voxels chose (the groups of its refit
         contraction), ``used_all`` = those of all ranks: the Cholesky systems are solved collectively
-        (_sharded_solve), so every rank must ask for the same ones."""
+        (_sharded_solve), so every rank must ask for the same ones.  ``cache``: the fold's dict of operators already
+        built (alpha -> (rows, N_o) f32), shared by the voxel ranges of the fold -- a later range only solves what an
+        alpha nobody chose before needs."""
         G = len(used)
         used_all = list(used) if used_all is None else list(used_all)
+        cache = {} if cache is None else cache
+        done_M = cache.setdefault("M", {})               # alpha -> operator rows
+        flag_parts = cache.setdefault("flags", [])       # pivot flags of every system solved for this fold
         n_o = len(tr_rows)
         N_o = ops.pad_to(n_o, LC_NB) if tr_o is None else tr_o.shape[-1]
         if tr_o is None:
             tr_o = ops.idx_tensor(tr_rows, N_o, self.dev).reshape(1, N_o)
             lmax_o = ops.lambda_max(K, tr_o, 1, N_o, self.steps) if self.normalpha else None
             self._check_singcutoff(lmax_o)
-        rhs = spec["rhs"] if spec is not None else self._refit_rhs(X, K, tr_rows, tr_o, te_rows)
+        if "rhs" not in cache:
+            cache["rhs"] = spec["rhs"] if spec is not None else self._refit_rhs(X, K, tr_rows, tr_o, te_rows)
+        rhs = cache["rhs"]
         rows = rhs.shape[0]
         # alphas on the polynomial series (large penalties: what real recordings usually select) need no
         # factorisation:  [Xtr' ; K_te] (K + a^2 I)^-1 = sum_j c_j(alpha) R_j,  R_j = [Xtr' ; K_te] K^j / lambda^(j+1),
         # with the chain R_j = R_(j-1) (K / lambda) on the f32 MFMA, shared by all such alphas (cf. _hat_matrices)
         on_series = set(self.ser) if (N_o % COL_TILE == 0 and lmax_o is not None) else set()
         poly = [a for a in used if a in on_series]
-        chol = [a for a in used if a not in on_series]
         have = list(spec["alphas"]) if spec is not None else []
-        need = [a for a in used_all if a not in on_series and a not in have]
-        Malpha = torch.empty((G, rows, N_o), dtype=torch.float32, device=self.dev)
-        flags = [spec["info"]] if have else []          # pivot flags: of every system solved for this fold
-        ahead = [a for a in chol if a in have]
+        if have and not cache.get("spec_flags"):
+            # the flags of the systems solved ahead: those of the alphas somebody chose only (a failed pivot in a system
+            # nobody uses must not fail the fit: the one-GPU path never solves it -- ADVICE r2)
+            cache["spec_flags"] = True
+            by_alpha = spec.get("info_by_alpha")
+            if by_alpha is None:
+                flag_parts.append(spec["info"])
+            else:
+                cache["spec_by_alpha"] = by_alpha
+        if cache.get("spec_by_alpha"):
+            for a in list(cache["spec_by_alpha"]):
+                if a in used_all:
+                    flag_parts += cache["spec_by_alpha"].pop(a)
+        # systems solved ahead of the choice enter the fold's cache when an alpha that has one is first used
+        ahead = [a for a in used_all if a in have and a not in done_M and a not in on_series]
         if ahead and spec.get("P") is not None:          # refit_ahead left the inverses: apply them to the rows now
-            Pa = spec["P"] if len(ahead) == len(have) and ahead == have else torch.stack([spec["P"][have.index(a)] for a in ahead])
+            Pa = spec["P"] if ahead == have else torch.stack([spec["P"][have.index(a)] for a in ahead])
             Ma = self._apply_inverses(rhs, Pa)
             for i, a in enumerate(ahead):
-                Malpha[used.index(a)].copy_(Ma[i])
+                done_M[a] = Ma[i]
         else:
             for a in ahead:
-                Malpha[used.index(a)].copy_(spec["M"][have.index(a)])
+                done_M[a] = spec["M"][have.index(a)]
+        need = [a for a in used_all if a not in on_series and a not in done_M]
         if need:
             Mc, info_n = self._refit_chol(K, tr_o, lmax_o, rhs, need)
             for i, a in enumerate(need):
-                if a in used:
-                    Malpha[used.index(a)].copy_(Mc[i])
-            flags.append(info_n)
-        info = self._join_flags(flags)
-        if poly:
-            Kn = torch.empty((1, N_o, N_o), dtype=torch.float32, device=self.dev)
-            ops.gather_sub_f32(K, tr_o, tr_o, 1, N_o, N_o, lmax_o, Kn)
-            R = ops.scale_cast_f64_f32(rhs, lmax_o, torch.empty(rhs.shape, dtype=torch.float32, device=self.dev))
-            terms = [R]
-            for _ in range(1, SERIES_TERMS):
-                if self.precision != "f32":              # 43 GFLOP per step: 0.13 ms on the fp16x3 MFMA, 0.5 ms in f32
-                    terms.append(self._times_symmetric(terms[-1], Kn)[0])
-                    continue
-                Rn = torch.empty_like(R)
-                ops.gemm_grouped(terms[-1], N_o, 0, Kn[0], N_o, None, Rn, N_o, rows, N_o, N_o, [0, N_o // COL_TILE])
-                terms.append(Rn)
-            for a in poly:
-                ops.combine_terms(terms, self.coef_host[self.ser.index(a)], Malpha[used.index(a)])
-        return Malpha, info
+                done_M[a] = Mc[i]
+            flag_parts.append(info_n)
+        info = self._join_flags(flag_parts)
+        new_poly = [a for a in poly if a not in done_M]
+        if new_poly:
+            if "terms" not in cache:
+                Kn = torch.empty((1, N_o, N_o), dtype=torch.float32, device=self.dev)
+                ops.gather_sub_f32(K, tr_o, tr_o, 1, N_o, N_o, lmax_o, Kn)
+                R = ops.scale_cast_f64_f32(rhs, lmax_o, torch.empty(rhs.shape, dtype=torch.float32, device=self.dev))
+                terms = [R]
+                for _ in range(1, SERIES_TERMS):
+                    if self.precision != "f32":          # 43 GFLOP per step: 0.13 ms on the fp16x3 MFMA, 0.5 ms in f32
+                        terms.append(self._times_symmetric(terms[-1], Kn)[0])
+                        continue
+                    Rn = torch.empty_like(R)
+                    ops.gemm_grouped(terms[-1], N_o, 0, Kn[0], N_o, None, Rn, N_o, rows, N_o, N_o, [0, N_o // COL_TILE])
+                    terms.append(Rn)
+                cache["terms"] = terms
+            for a in new_poly:
+                done_M[a] = ops.combine_terms(cache["terms"], self.coef_host[self.ser.index(a)],
+                                              torch.empty((rows, N_o), dtype=torch.float32, device=self.dev))
+        return [done_M[a] for a in used], info
 
-    def _refit_operands(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs):
+    def _refit_operands(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs, image=None):
         """Operands of the V-wide refit contraction: Ys (N_o + len(extra_rows), Vs), the targets gathered in
         alpha-sorted voxel order (``extra_rows``, the test targets, below the training rows), and on the fp16x3 path
-        their tiled fp16 image with the column scales carried through the permutation."""
+        their tiled fp16 image with the column scales carried through the permutation.  ``image`` = (tiled fp16 image,
+        its rows) the inner CV made of the same targets in natural voxel order: when its rows ARE the training rows the
+        sorted image is a 16-byte-unit column gather out of it (lc_permute_cols_f16) and only the test rows are gathered
+        from the fp32 targets -- no sorted fp32 copy of the training rows, no second split pass."""
         n_o = len(tr_rows)
         N_o = ops.pad_to(n_o, LC_NB)
         n_x = len(extra_rows)
+        from_image = (split and image is not None and REFIT_FROM_IMAGE and n_o % K_TILE == 0
+                      and len(image[1]) == n_o and np.array_equal(np.asarray(image[1]), np.asarray(tr_rows)))
+        if from_image:
+            rows_x = ops.idx_tensor(np.asarray(extra_rows, dtype=np.int64), n_x, self.dev)
+            Ys_te = torch.empty((n_x, Vs), dtype=torch.float32, device=self.dev)
+            ops.gather(Y, Y.stride(0), rows_x, n_x, perm, Vs, Ys_te)
+            cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)
+            ops.gather(cs.reshape(2, self.Vp), self.Vp, None, 2, perm, Vs, cs_s)
+            Yt = torch.empty(Vs * n_o * 2, dtype=torch.float16, device=self.dev)
+            ops.permute_cols_f16(image[0], perm, Vs, n_o, Yt)
+            return dict(Ys=None, Ys_te=Ys_te, N_o=N_o, K=n_o, n_o=n_o, Vs=Vs, tiles=tiles, Malpha=Malpha, split=split,
+                        cs_s=cs_s, Yt=Yt)
         rows_s = ops.idx_tensor(np.concatenate([tr_rows, np.full(N_o - n_o, -1), np.asarray(extra_rows, dtype=np.int64)]),
                                 N_o + n_x, self.dev)
         Ys = torch.empty((N_o + n_x, Vs), dtype=torch.float32, device=self.dev)
         ops.gather(Y, Y.stride(0), rows_s, N_o + n_x, perm, Vs, Ys)
-        o = dict(Ys=Ys, N_o=N_o, n_o=n_o, Vs=Vs, tiles=tiles, Malpha=Malpha, split=split)
+        o = dict(Ys=Ys, Ys_te=Ys[N_o:], N_o=N_o, K=N_o, n_o=n_o, Vs=Vs, tiles=tiles, Malpha=Malpha, split=split)
         if split:
             cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)
             ops.gather(cs.reshape(2, self.Vp), self.Vp, None, 2, perm, Vs, cs_s)
@@ -944,27 +1215,31 @@ class RidgeCVEngine:
         """Rows [r0, r1) of  C = [M_alpha ; H_te,alpha](group) . Ys  as an (r1 - r0, Vs) f32 matrix (fp16x3 path: the
         rows of every group split to fp16 triples, one grouped launch).  The caller takes the test predictions first
         -- what the host statistics wait for -- and the weight rows afterwards."""
-        Malpha, Vs, N_o = o["Malpha"], o["Vs"], o["N_o"]
-        G, rows = Malpha.shape[0], r1 - r0
+        Malpha, Vs, N_o = o["Malpha"], o["Vs"], o["N_o"]          # one (rows, N_o) operator per alpha group
+        G, rows = len(Malpha), r1 - r0
         C = torch.empty((rows, Vs), dtype=torch.float32, device=self.dev)
         if o["split"]:
             rows_pad = ops.pad_to(rows, 256)
             At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
             rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
-            for g in range(G):
-                ops.split_rows_f16(Malpha[g, r0:r1], rows, N_o, At[g * rows_pad * N_o * 2:], rs_inv[g * rows_pad:])
-            ops.gemm_grouped_f16x3(At, rs_inv, rows, o["Yt"], o["cs_s"][1], C, Vs, Vs, N_o, o["tiles"])
+            Kc = o["K"]                                  # contraction depth: the training rows (the operators' padding
+            for g in range(G):                           # columns beyond them are zero)
+                ops.split_rows_f16(Malpha[g][r0:r1], rows, Kc, At[g * rows_pad * Kc * 2:], rs_inv[g * rows_pad:])
+            ops.gemm_grouped_f16x3(At, rs_inv, rows, o["Yt"], o["cs_s"][1], C, Vs, Vs, Kc, o["tiles"])
             self.info["plain_flops"] += 2.0 * useful_rows * o["n_o"] * self.V
             self.info["plain_launches"] += 1
         else:
-            ops.gemm_grouped(Malpha[:, r0:r1], N_o, Malpha.stride(0), o["Ys"], Vs, None, C, Vs, rows, Vs, N_o, o["tiles"])
+            Ms = torch.empty((G, rows, N_o), dtype=torch.float32, device=self.dev)
+            for g in range(G):
+                Ms[g].copy_(Malpha[g][r0:r1])                       # (D2D copies: the groups' operators side by side)
+            ops.gemm_grouped(Ms, N_o, Ms.stride(0), o["Ys"], Vs, None, C, Vs, rows, Vs, N_o, o["tiles"])
         return C
 
     def _refit_apply(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs):
         """C (rows, Vs) = [M_alpha ; H_te,alpha](group) . Ys -- the weights in its first p_pad rows, the test
         predictions below -- together with Ys and N_o (see _refit_operands)."""
         o = self._refit_operands(Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs)
-        C = self._refit_product(o, 0, Malpha.shape[1], self.p + len(extra_rows))
+        C = self._refit_product(o, 0, Malpha[0].shape[0], self.p + len(extra_rows))
         return C, o["Ys"], o["N_o"]
 
     def refit(self, X, Y, K, tr_rows, best, extra_rows=(), tr_o=None, lmax_o=None):
@@ -1039,7 +1314,7 @@ class RidgeCVEngine:
         # groups of consecutive folds prepared as one batch: shared data (no per-fold normalisation), equal padded
         # sizes, neighbouring precomputed lmax, and the whole group's fp64 systems within the memory budget
         groups = []
-        batchable = not (self.norm_x or self.norm_y) and (self.primal or not self.normalpha
+        batchable = not self.norm_x and (self.primal or not self.normalpha
                                                            or all(l is not None for l in lmax_pre))
         for i, m in enumerate(metas):
             g = groups[-1] if groups else None
@@ -1056,14 +1331,15 @@ class RidgeCVEngine:
         out = [None] * len(folds)
         with torch.cuda.stream(self.aux):
             for g in groups:
-                X, Y, K, cs, split = self._fold_data(metas[g[0]]["tr"])      # per-fold data only when len(g) == 1
+                X, K = self._fold_design(metas[g[0]]["tr"])                  # per-fold design only when len(g) == 1
+                split = False if self.moments else self._split_assumed()     # the targets' side belongs to the ranges
                 data_ready = torch.cuda.Event()
                 data_ready.record()
                 # S[0]^2 of the inner train sets and of the whole outer-train block (refit penalty scale,
                 # independent of the alpha choice): precomputed for the whole fit, or one run for this fold
                 lmax_i, lmax_os = None, [None] * len(g)
                 if self.primal:
-                    self._prepare_primal(g, metas, X, Y, cs, split, data_ready, out, main)
+                    self._prepare_primal(g, metas, X, split, data_ready, out, main)
                     continue
                 if self.normalpha:
                     if lmax_pre[g[0]] is None:
@@ -1080,7 +1356,7 @@ class RidgeCVEngine:
                 ids_ready = torch.cuda.Event()         # what the refit systems need (row lists, lmax) exists from here on
                 ids_ready.record()
                 hat = self._hat_matrices(K, inner_all, lmax_i, self._series_by_moments(split), chol_after=chol_after)
-                hat.update(cs=cs, split=split, data_ready=data_ready)
+                hat.update(split=split, data_ready=data_ready)
                 done = torch.cuda.Event()
                 s = 0
                 for k, i in enumerate(g):
@@ -1088,10 +1364,10 @@ class RidgeCVEngine:
                     Fo = len(m["inner_abs"])
                     sub = hat if len(g) == 1 else self._hat_slice(hat, s, Fo, m["inner_abs"])
                     s += Fo
-                    out[i] = dict(tr=m["tr"], te=m["te"], X=X, Y=Y, K=K, cs=cs, split=split, hat=sub, done=done,
+                    out[i] = dict(tr=m["tr"], te=m["te"], X=X, K=K, split=split, hat=sub, done=done,
                                   tr_o=tr_os[k], lmax_o=lmax_os[k], ids_ready=ids_ready)
                 done.record()
-                for t in ([X, Y, K, cs, hat["tr"], hat["va"], hat["info"], hat["a2"], hat["lmax"], hat["d_ser"]]
+                for t in ([X, K, hat["tr"], hat["va"], hat["info"], hat["a2"], hat["lmax"], hat["d_ser"]]
                           + [out[i]["tr_o"] for i in g] + lmax_os
                           + [h for _, _, h, _ in hat["Hs"]] + [q for _, _, _, q in hat["Hs"]]):
                     if t is not None and t.is_cuda:
@@ -1099,7 +1375,7 @@ class RidgeCVEngine:
         return out
 
     # -------------------------------------------------------------- primal form (tall designs, p << n)
-    def _prepare_primal(self, g, metas, X, Y, cs, split, data_ready, out, main):
+    def _prepare_primal(self, g, metas, X, split, data_ready, out, main):
         """prepare_folds for a group of outer folds in the PRIMAL form: with G = Rstim'Rstim (p x p),
             pred_alpha = Pstim (G + a^2 I)^-1 Rstim'Rresp  =:  A_alpha B ,   B = Rstim'Rresp  (p x V),
         the same quantity the reference forms through its thin SVD of a tall Rstim (rank p, ridge_utils.py:52;
@@ -1109,7 +1385,7 @@ class RidgeCVEngine:
         The V-wide part (B by one contraction over the training rows, then the fused sweep of depth p) is
         _sweeps_primal."""
         if self.moments:
-            return self._prepare_moments(g, metas, X, Y, data_ready, out, main)
+            return self._prepare_moments(g, metas, X, data_ready, out, main)
         PP, p, A = self.PP, self.p, self.A
         inner_all = [ia for i in g for ia in metas[i]["inner_abs"]]
         F = len(inner_all)
@@ -1139,7 +1415,7 @@ class RidgeCVEngine:
         H, info = self._sharded_solve(F * A, PP, M, assemble)                # (>= F * A, M, PP) f32: A_alpha
         hat = dict(F=F, N=PP, M=M, n_v=n_v, n_i=n_i, tr=rows_all[:F], va=va, shared=None, Hs=[(0, F, H, None)],
                    info=info, lmax=None if lmax is None else lmax[:F], a2=a2, cho=list(range(A)), ser=[], d_ser=None,
-                   moments=False, series_ready=None, cs=cs, split=split, data_ready=data_ready, Xt=Xt, Nmax=Nmax,
+                   moments=False, series_ready=None, split=split, data_ready=data_ready, Xt=Xt, Nmax=Nmax,
                    xt_off=0)
         done = torch.cuda.Event()
         s = 0
@@ -1152,15 +1428,15 @@ class RidgeCVEngine:
             n_in = len(m["inner_abs"][0][0])
             sub["shared"] = self._shared_image(m["inner_abs"], n_in) if n_in % (2 * K_TILE) == 0 else None
             s += Fo
-            out[i] = dict(tr=m["tr"], te=m["te"], X=X, Y=Y, K=G[F + k], cs=cs, split=split, hat=sub, done=done,
+            out[i] = dict(tr=m["tr"], te=m["te"], X=X, K=G[F + k], split=split, hat=sub, done=done,
                           tr_o=ident[:1], lmax_o=None if lmax is None else lmax[F + k:F + k + 1],
                           Xt_o=Xt[(F + k) * PP:(F + k + 1) * PP], tr_o_rows=rows_all[F + k], Nmax=Nmax)
         done.record()
-        for t in (X, Y, cs, Xt, G, ident, lmax, a2, va, rows_all, rhs, H, info):
+        for t in (X, Xt, G, ident, lmax, a2, va, rows_all, rhs, H, info):
             if t is not None and t.is_cuda:
                 t.record_stream(main)                      # allocated on aux, consumed on main
 
-    def _prepare_moments(self, g, metas, X, Y, data_ready, out, main):
+    def _prepare_moments(self, g, metas, X, data_ready, out, main):
         """prepare_folds for a group of outer folds when p <= PRIMAL_MOMENTS_MAX_P and the scores are correlations
         (csrc/lc_primal.hip): every statistic of a prediction X w is a p-dimensional form in w = (G + a^2 I)^-1 Rstim'y,
         so all the V-wide work of a fold is ONE pass over the targets that forms X'y per row set (_sweeps_moments) --
@@ -1217,9 +1493,9 @@ class RidgeCVEngine:
                        pinv_o=pinv[(y0 + F) * A:(y0 + F + 1) * A], info=info[y0 * A:(y0 + F) * A],
                        info_o=info[(y0 + F) * A:(y0 + F + 1) * A], data_ready=data_ready, cs=None, split=False)
             off += 3 * F
-            out[i] = dict(tr=m["tr"], te=m["te"], X=X, Y=Y, K=None, cs=None, split=False, hat=hat, done=done)
+            out[i] = dict(tr=m["tr"], te=m["te"], X=X, K=None, split=False, hat=hat, done=done)
         done.record()
-        for t in (X, Y, rows, meta, xstat, gsys, lmax, a2, pinv, info):
+        for t in (X, rows, meta, xstat, gsys, lmax, a2, pinv, info):
             if t is not None and t.is_cuda:
                 t.record_stream(main)                      # allocated on aux, consumed on main
 
@@ -1307,7 +1583,7 @@ class RidgeCVEngine:
                 ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, PP, Bt, csB[self.Vp:], yv, self.Vp, n_v[f], ystat, yblk,
                                              self.mode, part, scores, accumulate=f > 0)
             else:
-                ops.gemm_grouped(Xt_f, Nmax, 0, Y, self.Vp, tr[f], B, Vt, PP, self.Vp, Ni, [0, self.Vp // COL_TILE])
+                ops.gemm_grouped(Xt_f, Nmax, 0, Y, Y.stride(0), tr[f], B, Vt, PP, self.Vp, Ni, [0, self.Vp // COL_TILE])
                 ops.alpha_sweep_scores(H[f * A:(f + 1) * A], A, M, PP, B, self.Vp, ident, yv, n_v[f], ystat, yblk,
                                        self.mode, part, scores, accumulate=f > 0)
         self.sweeps_done = torch.cuda.Event()
@@ -1333,10 +1609,10 @@ class RidgeCVEngine:
             ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, ext, Vt, Vt, No, [0, Vt // 256])
             csB, _ = ops.col_scales_f16(ext, self.p, self.Vp)
         else:
-            ops.gemm_grouped(st["Xt_o"], st["Nmax"], 0, Y, self.Vp, st["tr_o_rows"], ext, Vt, PP, self.Vp, No,
+            ops.gemm_grouped(st["Xt_o"], st["Nmax"], 0, Y, Y.stride(0), st["tr_o_rows"], ext, Vt, PP, self.Vp, No,
                              [0, self.Vp // COL_TILE])
             csB = None
-        ops.gather(Y, self.Vp, ops.idx_tensor(te, n_t, self.dev), n_t, None, self.Vp, ext[PP:])
+        ops.gather(Y, Y.stride(0), ops.idx_tensor(te, n_t, self.dev), n_t, None, self.Vp, ext[PP:])
         return ext, np.arange(PP), PP + np.arange(n_t), csB
 
     @staticmethod
@@ -1355,10 +1631,26 @@ class RidgeCVEngine:
         n = last.storage_offset() + last.numel() - first.storage_offset()
         return torch.as_strided(first, (n,), (1,), first.storage_offset())
 
-    def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None, lmax_pre=None):
-        st = prepared if prepared is not None else self.fold_prepare(tr_rows, te_rows, inner_rel, lmax_pre)
-        st["scores"] = self._sweeps(st["hat"], st["Y"], st["done"])
-        st["info"] = st["hat"]["info"]
+    def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None, lmax_pre=None, step=None):
+        """The V-wide inner CV of one (fold, voxel range) step.  ``prepared``: the fold's V-independent state
+        (prepare_folds), shared by all ranges of the fold; ``step`` = (fold number, (c0, c1)) from plan_steps, default:
+        fold 0, all columns.  Returns the step's own state: the fold's entries plus the range's targets, column scales
+        and scores."""
+        base = prepared if prepared is not None else self.fold_prepare(tr_rows, te_rows, inner_rel, lmax_pre)
+        fold_no, cols = step if step is not None else (0, None)
+        rg = self.full if cols is None else self.range_of(*cols)
+        st = dict(base)
+        st.update(base=base, rg=rg, fold=int(fold_no))
+        self._enter(st)
+        self._wait_targets(rg)
+        Y, cs, split = self._fold_targets(rg, base["tr"])
+        if bool(split) != bool(base["split"]) and not self.moments:
+            raise _WideTargets("the fold's operators were prepared for the other arithmetic")
+        hat = dict(base["hat"])
+        hat.update(cs=cs, split=split)
+        st.update(Y=Y, cs=cs, split=split, hat=hat)
+        st["scores"] = self._sweeps(hat, Y, st["done"])
+        st["info"] = hat["info"]
         return st
 
     def _refit_stream(self, st):
@@ -1381,6 +1673,11 @@ class RidgeCVEngine:
         no gate."""
         return self.sweeps_done if self.shard.world == 1 else None
 
+    def refit_ahead_pays(self):
+        """Forming the refit operators of EVERY factorised alpha of every fold before any alpha is chosen is cheap enough
+        on one GPU when they come from explicit inverses (N^3 flops each) and the grid has only a few such alphas."""
+        return bool(self.cho) and len(self.cho) <= 8 and not self.primal and self._refit_by_inverse(self.cho)
+
     def refit_ahead(self, states):
         """Voxel shards: the refit systems of ALL the given (prepared) folds for ALL factorised alphas in one
         collective batch, before any alpha is chosen.  With W ranks a rank's share of a fold's handful of systems is a
@@ -1391,7 +1688,7 @@ class RidgeCVEngine:
         differ in size fall back to fold_speculate / fold_select."""
         cho = [a for a in self.cho]
         sts = [st for st in states if st.get("tr_o") is not None and "spec" not in st]
-        if not cho or not sts or self.primal:
+        if not cho or not sts or self.primal or self.spectral:
             return
         N_o = sts[0]["tr_o"].shape[-1]
         rs_stream = self.aux2
@@ -1421,8 +1718,10 @@ class RidgeCVEngine:
                 Pall = Pj[: nF * Gc].view(nF, Gc, N_o, N_o)
                 ready = torch.cuda.Event()
                 ready.record()
+                by_alpha = self._flags_by_alpha(info, nF * Gc, lambda j: (j // Gc, cho[j % Gc]), nF)
                 for fo, st in enumerate(sts):
-                    st["spec"] = dict(alphas=list(cho), M=None, P=Pall[fo], info=info, rhs=rhss[fo], ready=ready)
+                    st["spec"] = dict(alphas=list(cho), M=None, P=Pall[fo], info=info, rhs=rhss[fo], ready=ready,
+                                      info_by_alpha=by_alpha[fo])
                     for t in (st.get("X"), st.get("K"), st.get("tr_o"), st.get("lmax_o")):
                         if isinstance(t, torch.Tensor) and t.is_cuda:
                             t.record_stream(rs_stream)
@@ -1445,32 +1744,57 @@ class RidgeCVEngine:
             Mall = Hj[: nF * Gc * S].view(nF, Gc, rows, N_o)
             ready = torch.cuda.Event()
             ready.record()
+            by_alpha = self._flags_by_alpha(info, nF * Gc * S, lambda j: (j // (Gc * S), cho[(j // S) % Gc]), nF)
         for fo, st in enumerate(sts):
-            st["spec"] = dict(alphas=list(cho), M=Mall[fo], info=info, rhs=rhss[fo], ready=ready)
+            st["spec"] = dict(alphas=list(cho), M=Mall[fo], info=info, rhs=rhss[fo], ready=ready, info_by_alpha=by_alpha[fo])
             for t in (st.get("X"), st.get("K"), st.get("tr_o"), st.get("lmax_o")):
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(rs_stream)
 
-    def fold_speculate(self, st, alphas_idx):
+    def _flags_by_alpha(self, info, n_jobs, job_fold_alpha, n_folds):
+        """Pivot flags of THIS rank's share of a batch of jobs, sorted per (fold, alpha): [{alpha: [one-entry views]}] --
+        a fold later joins only those of alphas somebody chose."""
+        _, mine = job_share(n_jobs, self.shard.world, self.shard.rank)
+        out = [dict() for _ in range(n_folds)]
+        for k, j in enumerate(mine):
+            fo, a = job_fold_alpha(j)
+            out[fo].setdefault(a, []).append(info[k:k + 1])
+        return out
+
+    def fold_speculate(self, st, alphas_idx, early=False):
         """Solve the refit systems of a prepared fold for the listed alphas BEFORE its alpha choice is known, on the
         auxiliary stream (the driver passes the alphas the previous fold used: the histogram of the chosen alphas
         hardly moves between outer folds).  fold_select then only solves what is missing; without this the last
-        fold's systems are a serial 8 ms at the end of the fit, with nothing left to run beside them."""
+        fold's systems are a serial 8 ms at the end of the fit, with nothing left to run beside them.  ``early`` (the
+        FIRST fold, whose systems nothing can predict: all factorised alphas): beside the fold's own hat-matrix chain
+        instead of behind it -- the chip is idle then, and the fold's refit otherwise waits for a chain that can only
+        start once its first histogram is on the host."""
+        st = st.get("base", st)                        # the fold's V-independent state (shared by its voxel ranges)
         todo = [a for a in alphas_idx if a in self.cho] if st.get("tr_o") is not None else []
         if not todo or "spec" in st:                   # nothing to factor, or refit_ahead has covered the fold
             return
-        rs = self._refit_stream(st)
-        if self.chain_gate() is not None:
-            rs.wait_event(self.chain_gate())           # like the inner-fold chain: not beside the sweeps just queued
+        if early and st.get("ids_ready") is not None:
+            rs = self.aux2
+            rs.wait_event(st["ids_ready"])
+            for t in (st.get("X"), st.get("K"), st.get("tr_o"), st.get("lmax_o")):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(rs)
+        else:
+            rs = self._refit_stream(st)
+            if self.chain_gate() is not None:
+                rs.wait_event(self.chain_gate())       # like the inner-fold chain: not beside the sweeps just queued
         with torch.cuda.stream(rs):
             rhs = self._refit_rhs(st["X"], st["K"], st["tr"], st["tr_o"], st["te"])
             Mc, info = self._refit_chol(st["K"], st["tr_o"], st["lmax_o"], rhs, todo)
-        st["spec"] = dict(alphas=todo, M=Mc, info=info, rhs=rhs)
+        # flags per alpha (one rank: job k = alpha todo[k]): a fold joins only those of alphas somebody chose
+        by_alpha = {a: [info[k:k + 1]] for k, a in enumerate(todo)} if self.shard.world == 1 else None
+        st["spec"] = dict(alphas=todo, M=Mc, info=info, rhs=rhs, info_by_alpha=by_alpha)
 
     def fold_choose(self, st, single_alpha):
         """Alpha choice of the fold and the grouping of the voxels by it, enqueued behind the fold's sweeps; the
         histogram travels to pinned memory asynchronously, so the caller can queue the next fold's sweeps on the
         main stream BEFORE waiting for it in fold_select (the stream then never idles through the host round trip)."""
+        self._enter(st)
         st["best"] = self.choose(st["scores"], single_alpha)
         if not self.moments:                           # the moments form refits voxel by voxel: no grouping by alpha
             st["grouping"] = self._group_async(st["best"], st["split"])
@@ -1479,6 +1803,7 @@ class RidgeCVEngine:
     def fold_select(self, st, single_alpha):
         """Waits for the fold's alpha histogram (fold_choose; the one host synchronisation of a fold) and puts the
         fp64 systems of the refit on the auxiliary stream -- they run beside whatever the main stream does next."""
+        self._enter(st)
         if self.moments:                               # nothing to factor after the choice, and no host sync
             if "best" not in st:
                 self.fold_choose(st, single_alpha)
@@ -1489,7 +1814,9 @@ class RidgeCVEngine:
         best, split = st["best"], st["split"]
         perm, used, tiles, Vs, used_all = self._refit_groups(best, split, st.pop("grouping"))
         main = torch.cuda.current_stream()
-        spec = st.get("spec")
+        base = st.get("base", st)
+        spec = base.get("spec")
+        cache = base.setdefault("refit_cache", {})
         if spec is not None and spec.get("ready") is not None:
             # voxel shards: the fold's factorised systems came from refit_ahead; what is left (the shared powers of the
             # polynomial alphas, copies) must not queue behind the later folds' batches on the refit stream
@@ -1504,17 +1831,20 @@ class RidgeCVEngine:
             rs = self._refit_stream(st)                    # inputs: X, K, tr_o, lmax_o -- all made on aux or at start
         with torch.cuda.stream(rs):
             Malpha, info_o = self._refit_systems(st["X"], st["K"], st["tr"], used, st.get("tr_o"), st.get("lmax_o"),
-                                                 st["te"], spec=st.get("spec"), used_all=used_all)
+                                                 st["te"], spec=spec, used_all=used_all, cache=cache)
             ready = torch.cuda.Event()
             ready.record()
-        for x in (Malpha, info_o):
+        for x in list(Malpha) + [info_o]:
             x.record_stream(main)
         st.update(best=best, perm=perm, used=used, used_all=used_all, tiles=tiles, Vs=Vs, split=split, Malpha=Malpha,
                   info_o=info_o, systems_ready=ready)
         return st
 
     def fold_finish(self, st, weight_scale):
-        """V-wide half of the refit, test predictions, Pearson r / p-values and the D2H of the results."""
+        """V-wide half of the refit of one (fold, voxel range) step, test predictions, Pearson r / p-values.  Returns the
+        pending results of the FOLD (see _publish) when this was the last range of the fold to finish, else None."""
+        self._enter(st)
+        rg = st["rg"]
         tr_rows, te_rows, Y = st["tr"], st["te"], st["Y"]
         n_t = len(te_rows)
         if self.moments:
@@ -1525,9 +1855,11 @@ class RidgeCVEngine:
             ops.primal_refit(hat["part"], hat["nrows"], hat["shrow"], Y, self.V, 0, 1, hat["xstat"], hat["pinv_o"], best,
                              self.p, weight_scale, self.W_acc, r_d)
             p_d = ops.pearson_pvalues(r_d, self.V, n_t)
-            if self._natural is None:
-                self._natural = ops.upload(np.arange(max(self.V, 1), dtype=np.int32), self.dev)
-            return self._publish(r_d, p_d, self._natural, self.V, best, st["info"], hat["info_o"], n_t)
+            if rg.natural is None:
+                rg.natural = ops.upload(np.arange(max(self.V, 1), dtype=np.int32), self.dev)
+            pend = self._publish(st, r_d, p_d, rg.natural, self.V, best, st["info"], hat["info_o"], n_t)
+            self._range_finished(st)
+            return pend
         best, perm, Vs = st["best"], st["perm"], st["Vs"]
         torch.cuda.current_stream().wait_event(st["systems_ready"])
         row0 = self.p_pad                              # first row of the test-row hat matrix inside M_alpha
@@ -1536,32 +1868,56 @@ class RidgeCVEngine:
             ext, rows_b, rows_t, csB = self._primal_refit_inputs(st)
             o = self._refit_operands(ext, rows_b, rows_t, perm, st["tiles"], Vs, st["Malpha"], st["split"], csB)
         else:
-            o = self._refit_operands(Y, tr_rows, te_rows, perm, st["tiles"], Vs, st["Malpha"], st["split"], st["cs"])
-        Ys, N_o = o["Ys"], o["N_o"]
+            o = self._refit_operands(Y, tr_rows, te_rows, perm, st["tiles"], Vs, st["Malpha"], st["split"], st["cs"],
+                                     image=st["hat"].get("image"))
         # ---- test predictions first (nested_cv.py:151,251: X_te W, here as the hat matrix of the test rows applied
         # to the same targets) and per-voxel Pearson r (:152-155, 252-257); the weight rows of the same contraction
         # follow once the fold's results are on their way to the host
-        pred = self._refit_product(o, row0, st["Malpha"].shape[1], n_t)[:n_t]
-        r_s = ops.pearson_cols(Ys[N_o:], pred, n_t, Vs)
+        pred = self._refit_product(o, row0, st["Malpha"][0].shape[0], n_t)[:n_t]
+        r_s = ops.pearson_cols(o["Ys_te"], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
-        pend = self._publish(r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t)
+        pend = self._publish(st, r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t)
         # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
         # run beside this part of the contraction)
         Ws = self._refit_product(o, 0, self.p_pad, self.p)
         ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
+        self._range_finished(st)
         return pend
 
-    def _publish(self, r_s, p_s, perm, Vs, best, info, info_o, n_t):
-        """The fold's per-voxel results: one packed block in natural voxel order (r, p, alpha index, pivot flags),
-        all-gathered over the voxel shards, unpacked to V_total-long vectors, BH-FDR of the fold on ALL p-values -- on
-        the communication stream, so that neither the collective nor the sort hold up the main stream."""
-        blk = torch.empty((4, max(self.w_max, 2)), dtype=torch.float64, device=self.dev)
-        ops.fold_pack(r_s, p_s, perm, Vs, best, self.V, info, info_o, blk)
+    def _range_finished(self, st):
+        """After the last fold's refit of a voxel range its block of the mean weights is final: with the weights wanted
+        on the host (reserve_host_weights) it leaves NOW, on the download stream, beside the next range's refit."""
+        if st["fold"] != self.n_folds - 1 or self._host_weights is None:
+            return
+        if self._host_w is None:
+            self._host_w = self._host_weights.result()
+        rg = st["rg"]
+        final = torch.cuda.Event()
+        final.record()
+        self.dl.wait_event(final)
+        ops.download_cols(rg.W, self._host_w, rg.c0, rg.V, self.dl)
+        self._sent += rg.V
+
+    def _publish(self, st, r_s, p_s, perm, Vs, best, info, info_o, n_t):
+        """The per-voxel results of one (fold, range) step go into the rank's packed block of the fold, natural voxel
+        order (r, p, alpha index, pivot flags).  Once every range of the fold is in, the block is all-gathered over the
+        voxel shards, unpacked to V_total-long vectors, and the fold's BH-FDR runs on ALL p-values -- on the
+        communication stream, so that neither the collective nor the sort hold up the main stream.  Returns the pending
+        host copies of the fold then, None before."""
+        fold_no, rg = st["fold"], st["rg"]
+        ent = self._fold_blk.get(fold_no)
+        if ent is None:
+            ent = self._fold_blk[fold_no] = dict(
+                blk=torch.empty((4, max(self.w_max, 2)), dtype=torch.float64, device=self.dev), cols=0, keep=[])
+        ops.fold_pack(r_s, p_s, perm, Vs, best, rg.V, info, info_o, ent["blk"], col0=rg.c0, clear=ent["cols"] == 0)
+        ent["cols"] += rg.V
+        ent["keep"] += [r_s, p_s, perm, best, info, info_o]
+        if ent["cols"] < self.V_rank:
+            return None
+        blk = ent["blk"]
         packed = torch.cuda.Event()
         packed.record()
         self.comm.wait_event(packed)
-        fold_no = self.n_folds_done
-        self.n_folds_done += 1
         Vt = self.V_total
         with torch.cuda.stream(self.comm):
             gathered = self.shard.all_gather(blk)                                  # (world, 4, ld)
@@ -1581,8 +1937,10 @@ class RidgeCVEngine:
                 h.copy_(d, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
-        for t in (blk, r_s, p_s, perm, best, info, info_o):
-            t.record_stream(self.comm)
+        for t in [blk] + ent["keep"]:
+            if t is not None:
+                t.record_stream(self.comm)
+        del self._fold_blk[fold_no]
         self.results_ready = done
         return dict(done=done, res=h_res, idx=h_idx, n_t=n_t, bad=h_bad, rej=h_rej, padj=h_padj,
                     keep=(dres, didx, dbad, rej_d, padj_d, gathered))
@@ -1608,7 +1966,7 @@ class RidgeCVEngine:
         # on the communication stream, behind the last fold's results: the main stream is still busy with the weight
         # rows of that fold's refit, which nothing here depends on
         with torch.cuda.stream(self.comm):
-            pcomb = ops.fisher_combine(self.p_folds[: self.n_folds_done])
+            pcomb = ops.fisher_combine(self.p_folds[: self.n_folds])
             rej, padj = ops.bh_fdr(pcomb, self.alpha_fdr)
             out = pcomb.cpu().numpy(), rej.cpu().numpy().astype(bool), padj.cpu().numpy()
         return out
@@ -1620,12 +1978,20 @@ class RidgeCVEngine:
     def weights(self) -> np.ndarray:
         """The (p, V) float32 weights as a host array.  The array lives in page-locked memory (the D2H copy is then one
         DMA at link rate instead of a staged copy through the driver: 0.98 GB at cfg2); it is an ordinary numpy array
-        that owns its buffer through torch's caching host allocator."""
-        h = self._host_weights.result() if self._host_weights is not None else \
-            torch.empty((self.p, self.V), dtype=torch.float32, pin_memory=True)
-        self._host_weights = None
-        h.copy_(self.W_acc[:, : self.V], non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        that owns its buffer through torch's caching host allocator.  Voxel ranges whose last fold finished earlier are
+        already there or on their way (_range_finished)."""
+        if self._host_w is None:
+            self._host_w = self._host_weights.result() if self._host_weights is not None else \
+                torch.empty((self.p, self.V_rank), dtype=torch.float32, pin_memory=True)
+        h = self._host_w
+        if self._sent < self.V_rank:                   # nothing left early (weights() without reserve_host_weights)
+            done = torch.cuda.Event()
+            done.record()
+            self.dl.wait_event(done)
+            ops.download_cols(self.W_full, h, 0, self.V_rank, self.dl)
+            self._sent = self.V_rank
+        self.dl.synchronize()
+        self._host_weights = self._host_w = None
         return h.numpy()
 
     def reserve_host_weights(self):
@@ -1633,9 +1999,16 @@ class RidgeCVEngine:
         the caching host allocator has no free block of that size and hipHostMalloc of 0.98 GB takes ~50 ms -- beside
         the fit's GPU work instead of after it."""
         if self._host_weights is None and self.dev.type == "cuda":
-            _, pool = ops._upload_ring()
-            shape = (self.p, self.V)
-            self._host_weights = pool.submit(lambda: torch.empty(shape, dtype=torch.float32, pin_memory=True))
+            shape = (self.p, self.V_rank)
+            self._host_weights = ops.misc_pool().submit(lambda: torch.empty(shape, dtype=torch.float32, pin_memory=True))
+
+    def finish_uploads(self):
+        """Host inputs: wait until every panel of the targets is resident (the fit is being abandoned or repeated)."""
+        if self.uploader is not None:
+            for b in range(len(self.upload_panels)):
+                self.uploader.wait(self._y_job0 + b)
+            self.uploader.join()
+            self.uploader = None
 
 
 def _alpha_vector(alphas, idx, single_alpha):
@@ -1665,16 +2038,25 @@ class NestedCVModel(BasePredictivityModel):
     rank's block of voxel columns and gather the per-voxel results across ranks."""
 
     def __init__(self, model_name: str, shard: Optional[ShardContext] = None, precision: str = "auto",
-                 form: str = "auto"):
+                 form: str = "auto", panel_cols: Optional[int] = None, local_targets: bool = False):
         """``precision``: arithmetic of the V-wide alpha sweep -- "f32" (f32-input MFMA), "f16x3" (fp16
         hi/lo operands, three fp16 MFMAs per product, fp32 accumulate; fp32-level accuracy, ~3x faster) or
         "auto" (f16x3 unless the targets' dynamic range is too wide for it; see RidgeCVEngine._target_scales).
         ``form``: "dual" (n x n systems), "primal" (p x p systems) or "auto" (primal for tall designs, 2 p <= the
-        smallest inner training set; see RidgeCVEngine)."""
+        smallest inner training set; see RidgeCVEngine).
+        ``panel_cols``: width (a multiple of 256 voxel columns) of the panels a host-to-host fit moves its targets
+        and weights in -- the first fold starts on a panel while the others are still crossing PCIe, the last fold's
+        weights leave panel by panel (None: PANEL_COLS for fits of >= 2 PANEL_MIN_COLS voxels; 0: no panels).  The
+        results do not depend on it, bit for bit.
+        ``local_targets`` (voxel shards): ``targets`` / ``y_test`` hold only this rank's block of voxel columns (the
+        blocks of ShardContext.bounds, in rank order) instead of all of them -- a rank then never touches the other
+        ranks' 1.7 GB of host memory."""
         super().__init__(model_name)
+        self.local_targets = bool(local_targets)
         self.shard = shard
         self.precision = precision
         self.form = form
+        self.panel_cols = panel_cols
         self.last_form = None
         self.last_fit = {}                             # RidgeCVEngine.info of the most recent fit (+ "form")
         self.last_fold_alphas = None
@@ -1711,16 +2093,20 @@ class NestedCVModel(BasePredictivityModel):
         shard = self.shard or ShardContext.single()
         train_test = X_test is not None and y_test is not None
         V_total = np.shape(targets)[1]
+        if self.local_targets and shard.world > 1:
+            mine = np.zeros(shard.world)
+            mine[shard.rank] = V_total
+            V_total = int(round(shard.allreduce_sum(mine).sum()))
         lo, hi = shard.bounds(V_total)
 
-        def cols(y):                       # this rank's voxel block (the whole matrix on one GPU)
-            return y if shard.world == 1 else np.asarray(y)[:, lo:hi]
+        def cols(y):                       # this rank's voxel block (the whole matrix on one GPU): a view, no copy
+            return y if (shard.world == 1 or self.local_targets) else np.asarray(y)[:, lo:hi]
 
-        if train_test:
+        if train_test:                      # row blocks side by side: no host-side concatenation of 2 GB of targets
             X_all = np.concatenate([np.asarray(features), np.asarray(X_test)], axis=0)
-            Y_all = np.concatenate([cols(targets), cols(y_test)], axis=0)
+            Y_all = ops.HostRows([cols(targets), cols(y_test)])
         else:
-            X_all, Y_all = features, cols(targets)
+            X_all, Y_all = features, ops.HostRows([cols(targets)])
         return self._run(X_all, Y_all, len(features), len(X_test) if train_test else 0, V_total, groups, folding_type,
                          n_outer_folds, n_inner_folds, chunk_length, alphas, alpha_fdr, single_alpha, normalpha,
                          use_corr, normalize_features, normalize_targets, weights_on_host=True, singcutoff=singcutoff)
@@ -1791,10 +2177,18 @@ class NestedCVModel(BasePredictivityModel):
 
         min_train = min(len(tr_i) for _, _, inner in outer for tr_i, _ in inner)
 
-        def attempt(form):
-            eng = RidgeCVEngine(X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
-                                precision=self.precision, singcutoff=singcutoff, V_total=V_total,
-                                min_train_rows=min_train, form=form)
+        V_rank = Y_all.shape[1]
+        panels = None
+        if not isinstance(Y_all, _DeviceShapes):
+            # the same NUMBER of panels on every rank of a sharded fit (narrowest rank decides)
+            panels = [(0, V_rank)] if self.panel_cols == 0 else _column_panels(
+                V_rank, self.panel_cols, None if self.panel_cols is None else 256, v_ref=V_total // max(shard.world, 1))
+
+        def attempt(form, precision, X_in, Y_in):
+            eng = RidgeCVEngine(X_in, Y_in, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
+                                precision=precision, singcutoff=singcutoff, V_total=V_total,
+                                min_train_rows=min_train, form=form, panels=panels)
+            self._engine = eng
             scale = 1.0 if train_test else 1.0 / len(outer)
             fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
             score_rows, any_nan = [], []
@@ -1820,13 +2214,23 @@ class NestedCVModel(BasePredictivityModel):
                 eng.reserve_host_weights()
             eng.alpha_fdr = alpha_fdr
             n = len(outer)
-            eng.begin_fit(n)                                    # the one host sync of the set-up, before anything is queued
+            eng.begin_fit(n)                                    # resident targets: the one host sync of the set-up
             lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
+            # the (fold, voxel range) steps in execution order: folds full width, the first / last one panel by panel
+            # while the targets arrive from / the weights leave for the host
+            plan = eng.plan_steps(n, single_alpha)
+            self._plan = sorted({c for _, c in plan})
             # V-independent part of every fold, ahead of everything on the auxiliary stream: fold 0 by itself (its sweeps
             # start as soon as its own systems are done), then ALL other folds as one batch
             first = eng.prepare_folds(outer[:1], lmax_pre[:1])[0]
-            st = eng.fold_begin(*outer[0], prepared=first)
-            if shard.world > 1:
+            # host inputs: the targets need ~30 ms to cross PCIe, and until they are there the chip has little V-wide
+            # work -- so EVERYTHING that does not depend on a voxel is queued now and runs in that window, nothing gated:
+            # the hat matrices of all folds (aux) and the refit operators of every fold for every factorised alpha (aux2,
+            # refit_ahead: explicit inverses, cheap enough to form for alphas nobody will choose); the V-wide phases then
+            # find the chip to themselves (fp64 chains beside the MFMA sweeps cost a resident fit ~20 of 137 ms)
+            hosted = getattr(eng, "uploader", None) is not None and shard.world == 1
+            ahead = shard.world > 1 or (hosted and eng.refit_ahead_pays())
+            if shard.world > 1 or hosted:
                 # voxel shards: a rank's V-wide work per fold is a few ms, the same order as one latency chain of its
                 # share of a fold's systems -- so the folds are prepared one by one (all queued now, nothing gated), each
                 # ready when its sweeps come up; and every fold's refit systems for every factorised alpha are solved
@@ -1834,43 +2238,79 @@ class NestedCVModel(BasePredictivityModel):
                 # (one batch over folds 1..n-1 for the hat matrices; fold 0's refit systems by themselves, then the other
                 # folds' in one batch: per-fold batches and other mixtures measured the same, 54-57 ms per simulated rank
                 # of 8 -- the rank is bound by its total work, not by the batching)
-                prepared = eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else []
-                eng.refit_ahead([first])
-                eng.refit_ahead(prepared)
+                if ahead:
+                    eng.refit_ahead([first])
+                prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else [])
+                if ahead:
+                    eng.refit_ahead(prepared[1:])
+                st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
             else:
-                # one GPU: the batch's series operands now, its Cholesky chains once fold 0's sweeps (just queued) are
-                # done -- same fit time, and fold 0's fused launches, the dominant kernel, run without 80 systems of fp64
-                # work beside them (1.66 -> 1.45 ms per launch over the fit)
+                # one GPU, resident targets: the batch's series operands now, its Cholesky chains once fold 0's sweeps
+                # (just queued) are done -- same fit time, and fold 0's fused launches, the dominant kernel, run without 80
+                # systems of fp64 work beside them (1.66 -> 1.45 ms per launch over the fit)
                 # (fold 1 first / one batch per fold instead of one batch measured the same within the box-to-box spread,
                 # 145.8-147.6 ms: the fit is bound by the total work of the streams, not by which batch the main stream
                 # waits for; all refit inverses ahead in one batch, as with voxel shards, costs 4 ms here: work for
                 # alphas nobody chooses, beside the fused launches)
-                prepared = eng.prepare_folds(outer[1:], lmax_pre[1:], chol_after=eng.chain_gate()) if n > 1 else []
-            for i in range(n):
+                if SPECULATE_FIRST_FOLD and getattr(eng, "cho", None):
+                    eng.fold_speculate(first, list(eng.cho), early=True)      # aux2: fold 0's refit systems, all of them
+                st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
+                prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:], chol_after=eng.chain_gate())
+                                      if n > 1 else [])
+            # the weights leave panel by panel during the last fold (0.98 GB at cfg2: ~18 ms of PCIe): its first panel is
+            # taken through refit BEFORE the next panel's sweeps are queued (no look-ahead at that step and at the one
+            # before it), so that the link starts at the head of the fold and the rest of the fold hides the transfer
+            early_out = hosted and weights_on_host and n > 1 and sum(1 for f_, _ in plan if f_ == n - 1) > 1
+            first_last = next((k for k, (f_, _) in enumerate(plan) if f_ == n - 1), None)
+            for k, (f, _) in enumerate(plan):
                 eng.fold_choose(st, single_alpha)               # main: argmax + grouping; the histogram leaves asynchronously
+                look = k + 1 < len(plan) and not (early_out and k in (first_last - 1, first_last))
                 st_next = None
-                if i + 1 < n:
-                    st_next = eng.fold_begin(*outer[i + 1], prepared=prepared[i])                 # main: sweeps of i+1
-                st = eng.fold_select(st, single_alpha)          # host waits for the histogram of fold i here
-                if i + 1 < n:
-                    eng.fold_speculate(st_next, st["used_all"])                                   # aux: refit systems of i+1
+                if look:                                        # main: sweeps of the next (fold, range)
+                    f2 = plan[k + 1][0]
+                    st_next = eng.fold_begin(*outer[f2], prepared=prepared[f2], step=plan[k + 1])
+                st = eng.fold_select(st, single_alpha)          # host waits for the histogram of this step here
+                if f + 1 < n and (k == 0 or plan[k - 1][0] != f):
+                    eng.fold_speculate(prepared[f + 1], st["used_all"])         # aux: refit systems of the next fold
                 if pending is not None:
                     tail(pending)
-                pending = eng.fold_finish(st, scale)            # main: V-wide refit of fold i behind those sweeps
+                    pending = None
+                pending = eng.fold_finish(st, scale)            # main: V-wide refit of this step behind those sweeps
+                if not look and k + 1 < len(plan):
+                    f2 = plan[k + 1][0]
+                    st_next = eng.fold_begin(*outer[f2], prepared=prepared[f2], step=plan[k + 1])
                 st = st_next
             tail(pending)
             return eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan
 
+        def run(form):
+            try:
+                return attempt(form, self.precision, X_all, Y_all)
+            except _WideTargets as why:
+                # host inputs + precision "auto": a panel that arrived later is too wide for the fp16 split -- once, on
+                # the f32 MFMA path, with everything that is resident by now
+                eng = self._engine
+                logger.info("%s: the fit is repeated on the f32 MFMA path", why)
+                eng.finish_uploads()
+                torch.cuda.synchronize()
+                return attempt(form, "f32", _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
+
         try:
-            eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = attempt(self.form)
+            eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = run(self.form)
         except _PrimalUnsuitable as why:
             if self.form == "primal":
                 raise ValueError(f"form='primal' is not usable for these features: {why}") from None
             logger.info("primal form not used (%s): dual form", why)
-            eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = attempt("dual")
+            prev = self._engine
+            prev.finish_uploads()
+            eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = attempt(
+                "dual", self.precision, _DeviceShapes(prev.dX, prev.p), _DeviceShapes(prev.dY_full, prev.V_rank))
+        self._engine = None
         self.last_form = "primal" if eng.primal else "dual"
-        self.last_fit = dict(getattr(eng, "info", {}), form=self.last_form)
-        weights = eng.weights() if weights_on_host else eng.W_acc[:, : eng.V]
+        self.last_fit = dict(getattr(eng, "info", {}), form=self.last_form, panels=self._plan)
+        # the weights last: their final panels are still crossing PCIe while the host statistics below are computed
+        def weights_now():
+            return eng.weights() if weights_on_host else eng.W_full[:, : eng.V_rank]
         # diagnostics (not in the reference's return value): the alpha vector of every outer fold, all voxels --
         # the returned best_alphas is their mean (nested_cv.py:293-296)
         self.last_fold_alphas = [np.asarray(a) for a in fold_alpha]
@@ -1884,7 +2324,7 @@ class NestedCVModel(BasePredictivityModel):
             metrics = stats.train_test_metrics(fold_scores[0], fold_p[0], padj, sig, fold_alpha[0], np.sum(sig), part=part,
                                                all_scores=None if part is None else
                                                score_rows[0].astype(np.float64 if any_nan[0] else np.float32))
-            return metrics, weights, fold_alpha[0] if part is None else fold_alpha[0][part]
+            return metrics, weights_now(), fold_alpha[0] if part is None else fold_alpha[0][part]
 
         # np.mean(fold_scores, axis=0) of the reference (nested_cv.py:276): the nested lists hold np.float32
         # scalars, plus Python 0.0 where r was NaN -- numpy then builds a float64 array, else a float32 one
@@ -1894,7 +2334,7 @@ class NestedCVModel(BasePredictivityModel):
         mean_alphas = np.mean(fold_alpha, axis=0)
         metrics = stats.full_cv_metrics(scores, pcomb, padj, sig, majority, mean_alphas, np.sum(sig), np.sum(majority),
                                         part=part)
-        return metrics, weights, mean_alphas if part is None else mean_alphas[part]
+        return metrics, weights_now(), mean_alphas if part is None else mean_alphas[part]
 
 
 class _DeviceShapes:

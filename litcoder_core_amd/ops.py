@@ -171,84 +171,186 @@ def segment_reduce(data, seg, idx, how):
 
 
 # ------------------------------------------------------------------ casts / gathers
-_UPLOAD = {"pinned": None, "pool": None}
-_UPLOAD_CHUNK = 32 << 20            # bytes per pinned staging chunk
-_UPLOAD_DEPTH = 6                   # chunks in flight
+_UPLOAD = {"pinned": None, "pool": None, "stream": {}}
+_UPLOAD_CHUNK = 16 << 20            # bytes per pinned staging chunk
+_UPLOAD_DEPTH = 12                  # chunks in flight
+_UPLOAD_LOCK = threading.Lock()     # the ring is the process's: one upload job at a time owns it
 
 
 def _upload_ring():
-    """Pinned staging chunks + copy threads of the process (created on first use)."""
+    """Pinned staging chunks + staging threads of the process (created on first use)."""
     if _UPLOAD["pinned"] is None:
         from concurrent.futures import ThreadPoolExecutor
         import os
         _UPLOAD["pinned"] = [torch.empty(_UPLOAD_CHUNK, dtype=torch.uint8, pin_memory=True) for _ in range(_UPLOAD_DEPTH)]
-        _UPLOAD["pool"] = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 4) // 2)))
+        _UPLOAD["pool"] = ThreadPoolExecutor(max_workers=max(2, min(_UPLOAD_DEPTH, (os.cpu_count() or 4) // 2)))
     return _UPLOAD["pinned"], _UPLOAD["pool"]
 
 
-def upload_f32(host, ld, dev, rows_pad=None):
-    """Host (rows, cols) real array -> zero-padded (rows_pad or rows, ld) f32 device buffer.  float64 input is cast on
-    the device (lc_cast_f64_f32), mirroring ``torch.tensor(x, dtype=torch.float32)`` (nested_cv.py:99-100).
+def misc_pool():
+    """One worker thread for slow host-side chores that must not queue behind the staging threads (hipHostMalloc of a
+    result buffer)."""
+    if _UPLOAD.get("misc") is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _UPLOAD["misc"] = ThreadPoolExecutor(max_workers=1)
+    return _UPLOAD["misc"]
 
-    The caller's array is pageable: a plain copy stages it through the driver at ~10 GB/s (170 ms for cfg2's 1.92 GB
-    of targets, more than the whole fit).  Here row chunks are copied into a ring of pinned buffers by a few threads
-    (numpy's copy releases the GIL), each chunk leaves by an asynchronous H2D copy as soon as it is staged, and the
-    cast to fp32 follows it on the stream; a pinned chunk is refilled once its copy has completed."""
-    host = np.asarray(host)
-    if host.ndim != 2:
-        raise ValueError("expected a 2-D array")
+
+def upload_stream(dev):
+    """The stream host-to-device panel copies run on (one per device, for the life of the process)."""
+    key = (dev.type, dev.index)
+    if key not in _UPLOAD["stream"]:
+        _UPLOAD["stream"][key] = torch.cuda.Stream(device=dev)
+    return _UPLOAD["stream"][key]
+
+
+class HostRows:
+    """Row blocks of host matrices with the same column count, seen as one (rows, cols) matrix without concatenating
+    them (train/test mode hands over the training and the test targets as two arrays)."""
+
+    def __init__(self, blocks):
+        self.blocks = []
+        r = 0
+        for b in blocks:
+            b = np.asarray(b)
+            if b.ndim != 2:
+                raise ValueError("expected 2-D arrays")
+            if b.dtype not in (np.float32, np.float64):
+                b = b.astype(np.float64)
+            if b.shape[1] and b.strides[1] != b.dtype.itemsize:
+                b = np.ascontiguousarray(b)
+            self.blocks.append((r, b))
+            r += b.shape[0]
+        cols = {b.shape[1] for _, b in self.blocks}
+        if len(cols) != 1:
+            raise RuntimeError(f"shape mismatch: row blocks with {sorted(cols)} columns")
+        self.shape = (r, cols.pop())
+
+
+class _UploadJob(ctypes.Structure):
+    """lc_upload_job of include/litcoder_hip.h."""
+    _fields_ = [("src", ctypes.c_void_p), ("ld_src", ctypes.c_int64), ("dtype", ctypes.c_int), ("rows", ctypes.c_int64),
+                ("c0", ctypes.c_int64), ("c1", ctypes.c_int64), ("dst", ctypes.c_void_p), ("ld_dst", ctypes.c_int64),
+                ("dst_row0", ctypes.c_int64)]
+
+
+class PanelUploader:
+    """Host matrices -> zero-padded f32 device matrices, in column panels, on native background threads
+    (lc_upload_start, csrc/lc_upload.hip).
+
+    The caller's arrays are pageable: a plain copy stages them through the driver at ~10 GB/s.  Here a panel (a column
+    range of one host matrix) is cut into row chunks; native staging threads cast each chunk to float32 straight into
+    page-locked memory (the cast of ``torch.tensor(x, dtype=torch.float32)``, nested_cv.py:99-100, done on the host so
+    that 4 bytes per value cross PCIe) and issue its 2-D copy into the panel's columns of the destination on the upload
+    stream.  ``jobs``: [(host matrix | HostRows, destination (rows, ld) f32 device matrix, c0, c1)] in upload order --
+    e.g. the design matrix, then the panels of the targets.  ``wait(j, stream)`` blocks the HOST until every copy of job j
+    has been issued and makes ``stream`` wait for them on the device.  (Python threads staged the chunks until round 3:
+    beside a main thread that queues a thousand launches the interpreter lock made both crawl.)"""
+
+    def __init__(self, jobs, dev, after=None):
+        self.jobs = [(h if isinstance(h, HostRows) else HostRows([h]), d, int(c0), int(c1)) for h, d, c0, c1 in jobs]
+        self.dev = dev
+        self.stream = upload_stream(dev)
+        if after is not None:
+            self.stream.wait_event(after)               # e.g. the zero fill of the destination's padding
+        native, self._natives = [], []
+        for host, dst, c0, c1 in self.jobs:
+            if dst.dtype != torch.float32 or not dst.is_cuda or dst.stride(1) != 1:
+                raise ValueError("upload destination must be a row-major f32 device matrix")
+            if not (0 <= c0 < c1 <= host.shape[1] and c1 <= dst.shape[1] and host.shape[0] <= dst.shape[0]):
+                raise ValueError("upload panel outside the source / destination matrix")
+            first = len(native)
+            for row0, blk in host.blocks:
+                item = blk.dtype.itemsize
+                native.append(_UploadJob(blk.ctypes.data, blk.strides[0] // item if blk.shape[0] > 1 else max(blk.shape[1], 1),
+                                         LC_F64 if blk.dtype == np.float64 else LC_F32, blk.shape[0], c0, c1,
+                                         dst.data_ptr(), dst.stride(0), row0))
+            self._natives.append(list(range(first, len(native))))     # the panel = its row blocks' native jobs
+        self._native = (_UploadJob * len(native))(*native)
+        pinned, _ = _upload_ring()
+        self._slots = (ctypes.c_void_p * len(pinned))(*[p.data_ptr() for p in pinned])
+        self._handle = ctypes.c_void_p()
+        self._done = False
+        import os
+        n_threads = max(2, min(len(pinned), (os.cpu_count() or 4) // 2))
+        _UPLOAD_LOCK.acquire()                          # the staging ring is the process's: one upload at a time owns it
+        try:
+            _lib.call("lc_upload_start", ctypes.cast(self._native, ctypes.c_void_p), len(native),
+                      ctypes.cast(self._slots, ctypes.c_void_p), len(pinned), _UPLOAD_CHUNK, n_threads,
+                      dev.index if dev.index is not None else torch.cuda.current_device(),
+                      ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(self._handle))
+        except BaseException:
+            _UPLOAD_LOCK.release()
+            raise
+        self.error = None
+        self.thread = threading.Thread(target=self._finish, name="lc-upload-finish", daemon=True)
+        self.thread.start()
+
+    def _finish(self):
+        """Joins the native threads (blocked in C, interpreter lock released) and hands the staging ring back."""
+        try:
+            _lib.call("lc_upload_finish", self._handle)
+        except BaseException as exc:  # noqa: BLE001 -- handed to whoever joins
+            self.error = exc
+        finally:
+            self._done = True
+            _UPLOAD_LOCK.release()
+
+    def wait(self, j, stream=None):
+        """Host: until job j's copies are all issued; device: ``stream`` (default: current) waits for them."""
+        stream = stream or torch.cuda.current_stream()
+        if self._done and self.error is not None:
+            raise self.error
+        for k in self._natives[j]:
+            _lib.call("lc_upload_wait", self._handle, k, ctypes.c_void_p(stream.cuda_stream))
+
+    def join(self):
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+
+    def __del__(self):
+        try:
+            if self._handle:
+                self.thread.join()
+                _lib.load().lc_upload_free(self._handle)
+                self._handle = ctypes.c_void_p()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def upload_f32(host, ld, dev, rows_pad=None):
+    """Host (rows, cols) real array -> zero-padded (rows_pad or rows, ld) f32 device buffer, ordered on the current
+    stream.  float64 input is cast to float32 on the host while it is staged (PanelUploader), mirroring
+    ``torch.tensor(x, dtype=torch.float32)`` (nested_cv.py:99-100)."""
+    host = host if isinstance(host, HostRows) else HostRows([host])
     rows, cols = host.shape
     out = zeros((rows_pad or rows, ld), torch.float32, dev)
     if rows == 0 or cols == 0:
         return out
-    if host.dtype not in (np.float32, np.float64):
-        host = host.astype(np.float64)
-    host = np.ascontiguousarray(host)
-    item = host.dtype.itemsize
-    step = max(1, _UPLOAD_CHUNK // (cols * item))
-    if cols * item > _UPLOAD_CHUNK:                     # absurdly wide rows: the plain path
-        blk = torch.from_numpy(host).to(dev)
-        if host.dtype == np.float32:
-            out[:rows, :cols].copy_(blk)
-        else:
-            _lib.call("lc_cast_f64_f32", _p(blk), cols, _p(out), ld, rows, cols, _s())
+    if cols * 4 > _UPLOAD_CHUNK:                        # absurdly wide rows: the plain path
+        for row0, blk in host.blocks:
+            out[row0:row0 + blk.shape[0], :cols].copy_(torch.from_numpy(np.ascontiguousarray(blk, dtype=np.float32)))
         return out
-    pinned, pool = _upload_ring()
-    tdt = torch.float32 if item == 4 else torch.float64
-    chunks = [(r0, min(rows, r0 + step)) for r0 in range(0, rows, step)]
-    free_at = [None] * len(pinned)                      # event after which a pinned chunk may be refilled
-
-    def stage(k, r0, r1):
-        if free_at[k] is not None:
-            free_at[k].synchronize()
-        view = pinned[k][: (r1 - r0) * cols * item].view(tdt).view(r1 - r0, cols)
-        view.numpy()[:] = host[r0:r1]
-        return view
-
-    futs = {}
-    for j in range(min(len(pinned), len(chunks))):
-        futs[j] = pool.submit(stage, j % len(pinned), *chunks[j])
-    dev_stage = [torch.empty(step * cols, dtype=tdt, device=dev) for _ in range(2)] if item == 8 else None
-    for j, (r0, r1) in enumerate(chunks):
-        k = j % len(pinned)
-        view = futs.pop(j).result()
-        n = r1 - r0
-        if item == 4:
-            out[r0:r1, :cols].copy_(view, non_blocking=True)
-        else:
-            d = dev_stage[j & 1][: n * cols].view(n, cols)
-            d.copy_(view, non_blocking=True)
-            _lib.call("lc_cast_f64_f32", _p(d), cols, _p(out[r0:r1]), ld, n, cols, _s())
-        ev = torch.cuda.Event()
-        ev.record()
-        free_at[k] = ev
-        nxt = j + len(pinned)
-        if nxt < len(chunks):
-            futs[nxt] = pool.submit(stage, k, *chunks[nxt])
-    for ev in free_at:                                  # the ring belongs to the process: leave it idle
-        if ev is not None:
-            ev.synchronize()
+    zeroed = torch.cuda.Event()
+    zeroed.record()
+    up = PanelUploader([(host, out, 0, cols)], dev, after=zeroed)
+    up.wait(0)
+    up.join()
     return out
+
+
+def download_cols(src, host, c0, V, stream):
+    """Columns [0, V) of the device matrix view ``src`` (rows, >= V) -> columns [c0, c0 + V) of the page-locked host
+    matrix ``host``, as one 2-D copy on ``stream``."""
+    _lib.call("lc_memcpy2d_async", ctypes.c_void_p(host.data_ptr() + c0 * 4), host.stride(0) * 4, _p(src), src.stride(0) * 4,
+              V * 4, src.shape[0], 1, ctypes.c_void_p(stream.cuda_stream))
+
+
+def zero_cols(t, c0, c1):
+    """Zero columns [c0, c1) of a 2-D f32 device matrix on the current stream (hipMemset2DAsync, no framework kernel)."""
+    if c1 > c0:
+        _lib.call("lc_fill2d_bytes", ctypes.c_void_p(t.data_ptr() + c0 * 4), t.stride(0) * 4, 0, (c1 - c0) * 4, t.shape[0], _s())
 
 
 def cast_f64_f32(src, dst, rows, cols):
@@ -457,6 +559,36 @@ def batch_chol_inverse(aug, B, N, p, slot=None):
     return info
 
 
+def batch_eigh(a, max_sweeps=30, tol=1e-14):
+    """Symmetric eigendecomposition of the (F, n, n) f64 systems ``a`` (n even; destroyed) by cyclic Jacobi:
+    (eigenvalues (F, n), eigenvectors as ROWS (F, n, n), largest eigenvalue (F,), sweeps done)."""
+    F, n, _ = a.shape
+    _need(a, torch.float64, "batch_eigh")
+    vt = torch.empty((F, n, n), dtype=torch.float64, device=a.device)
+    lam = torch.empty((F, n), dtype=torch.float64, device=a.device)
+    lmax = torch.empty(F, dtype=torch.float64, device=a.device)
+    nbytes = int(_lib.load().lc_batch_eigh_work_bytes(F, n))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
+    sweeps = ctypes.c_int32(0)
+    _lib.call("lc_batch_eigh_jacobi", _p(a), F, n, _p(vt), _p(lam), _p(lmax), _p(work), nbytes, int(max_sweeps), float(tol),
+              ctypes.byref(sweeps), _s())
+    return lam, vt, lmax, int(sweeps.value)
+
+
+def batch_spectral_apply(lam, vt, r, a2, A, cutoff, rank_cap, h, slot=None):
+    """h[slot[f A + a]] (M, n) f32 = r[f] V_kept diag(1 / (lam + a2[f A + a])) V_kept' (see lc_batch_spectral_apply);
+    returns the number of eigenpairs kept per system (device int32)."""
+    F, n = lam.shape
+    M = r.shape[1]
+    nbytes = int(_lib.load().lc_batch_spectral_work_bytes(F, A, n, M))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=lam.device)
+    kept = torch.empty(F, dtype=torch.int32, device=lam.device)
+    sl = None if slot is None else (ctypes.c_int32 * (F * A))(*[int(x) for x in slot])
+    _lib.call("lc_batch_spectral_apply", _p(lam), _p(vt), F, n, _p(r), M, _p(a2), A, float(cutoff), _p(rank_cap), _p(work),
+              nbytes, _p(h), sl, _p(kept), _s())
+    return kept
+
+
 def batch_series_hat(k, tr, va, F, N, M, scale, coef, aidx, A, terms, h):
     """coef: (S, terms) f64 polynomial coefficients of the S alphas (series.py); scale: (F) f64."""
     S = aidx.numel()
@@ -574,6 +706,12 @@ def split_cols_f16(y, V, rows, K, cscale, tiled):
     _lib.call("lc_split_cols_f16", _p(y), y.stride(0), V, _p(rows), K, _p(cscale), _p(tiled), _s())
 
 
+def permute_cols_f16(tiled, perm, Vs, K, out):
+    """out = the tiled fp16 image ``tiled`` (K rows) with column j taken from column perm[j] (-1: zeros), j < Vs."""
+    _lib.call("lc_permute_cols_f16", _p(tiled), _p(perm), Vs, K, _p(out), _s())
+    return out
+
+
 def alpha_sweep_scores_f16x3(ht, rowscale_inv, A, M, N, yt, cscale_inv, yv, V, n_val, ystat, yblk, mode, part, scores,
                              accumulate, bview=(0, 0, 0)):
     """``bview`` = (rows of the tiled image yt, first row of the skipped block, its length); (0, 0, 0): yt holds
@@ -635,10 +773,10 @@ def fill_argmax(rowsum, A, best, V):
     return best
 
 
-def fold_pack(r_s, p_s, perm, Vs, best, V, info_a, info_b, out):
-    """out: (4, ld) f64 device block (see lc_fold_pack)."""
-    _lib.call("lc_fold_pack", _p(r_s), _p(p_s), _p(perm), Vs, _p(best), V, _p(info_a), info_a.numel(), _p(info_b),
-              info_b.numel(), _p(out), out.stride(0), _s())
+def fold_pack(r_s, p_s, perm, Vs, best, V, info_a, info_b, out, col0=0, clear=True):
+    """out: (4, ld) f64 device block (see lc_fold_pack_at): this range's V voxels land in columns [col0, col0 + V)."""
+    _lib.call("lc_fold_pack_at", _p(r_s), _p(p_s), _p(perm), Vs, _p(best), V, _p(info_a), info_a.numel(), _p(info_b),
+              info_b.numel(), _p(out), out.stride(0), int(col0), int(bool(clear)), _s())
     return out
 
 

@@ -333,6 +333,84 @@ def gen_saver():
         json.dump(out, f, indent=1)
 
 
+# ---------------------------------------------------------------- alpha = 0 and a singcutoff that bites
+def gen_spectral():
+    """The reference where the Cholesky route of the HIP path cannot follow it: alpha = 0 in the grid (ridge_regression.py:
+    56,117: D = S / (S^2 + a^2) at a = 0, the pseudo-inverse of the kept directions) and a singcutoff that really drops
+    singular values (ridge_utils.py:44-63).  Three designs: rank-deficient (rank 25 < p = 40; cutoffs chosen clear of
+    every singular value), wide full rank (p = 320 > n: alpha = 0 interpolates the training rows), tall (p = 16 < n:
+    alpha = 0 is ordinary least squares).  ridge_corr_torch / ridge_torch outputs and full fits."""
+    import torch
+    rng = np.random.default_rng(77)
+    out = {}
+    model = ref.nested_cv.NestedCVModel("ridge_regression")
+
+    def clear_cutoff(S, rel):
+        """rel * S[0], moved off any singular value by at least 2 %."""
+        c = rel * S[0]
+        for _ in range(50):
+            if np.all(np.abs(S - c) > 0.02 * c):
+                return float(c)
+            c *= 1.03
+        raise RuntimeError("no clear cutoff")
+
+    # rank-deficient
+    T, r, p, V = 150, 25, 40, 32
+    X = rng.standard_normal((T, r)) @ rng.standard_normal((r, p)) / np.sqrt(r)
+    Y = X @ (rng.standard_normal((p, V)) * 0.3) + rng.standard_normal((T, V))
+    tr, va = np.r_[0:80, 110:150], np.r_[80:110]
+    Xt, Yt = torch.tensor(X, dtype=torch.float32), torch.tensor(Y, dtype=torch.float32)
+    S = torch.linalg.svd(Xt[tr], full_matrices=False)[1].numpy().astype(np.float64)
+    cut = [clear_cutoff(S, 1e-3), clear_cutoff(S, 0.3)]
+    al = np.array([0.0, 0.1, 1.0, 10.0, 100.0])
+    out.update(rd_X=X, rd_Y=Y, rd_tr=tr, rd_va=va, rd_alphas=al, rd_cutoffs=np.array(cut), rd_singular_values=S)
+    for i, sc in enumerate(cut):
+        out[f"rd_kept_{i}"] = np.array(int((S > sc).sum()))
+        for na in (True, False):
+            out[f"rd_scores_{i}_norm{int(na)}"] = ref.ridge_regression.ridge_corr_torch(
+                Xt[tr], Xt[va], Yt[tr], Yt[va], al, singcutoff=sc, use_corr=True, normalpha=na).numpy()
+            for a_ in (0.0, 3.0):
+                out[f"rd_W_{i}_norm{int(na)}_a{int(a_)}"] = ref.ridge_regression.ridge_torch(
+                    Xt[tr], Yt[tr], a_, singcutoff=sc, normalpha=na).numpy()
+        for single in (False, True):
+            random.seed(7)
+            np.random.seed(7)
+            m, W, best = quiet(model.fit_predict, X, Y, alphas=al, use_gpu=False, folding_type="kfold", n_outer_folds=3,
+                               n_inner_folds=3, singcutoff=sc, single_alpha=single)
+            tag = f"rd_fit_{i}_s{int(single)}"
+            out[tag + "_W"], out[tag + "_alphas"], out[tag + "_correlations"] = W, best, np.asarray(m["correlations"])
+    # wide, full rank: alpha = 0 with the default cutoff
+    Xw = rng.standard_normal((200, 320))
+    Yw = Xw @ (rng.standard_normal((320, 24)) * 0.05) + rng.standard_normal((200, 24))
+    # tall: alpha = 0 is OLS
+    Xs = rng.standard_normal((240, 16))
+    Ys = Xs @ (rng.standard_normal((16, 24)) * 0.3) + rng.standard_normal((240, 24))
+    al0 = np.array([0.0, 0.5, 5.0, 50.0])
+    for tag, (Xc, Yc) in (("wide", (Xw, Yw)), ("tall", (Xs, Ys))):
+        out.update({f"{tag}_X": Xc, f"{tag}_Y": Yc, f"{tag}_alphas": al0})
+        n = len(Xc)
+        tr_, va_ = np.arange(0, n - 40), np.arange(n - 40, n)
+        Xt_, Yt_ = torch.tensor(Xc, dtype=torch.float32), torch.tensor(Yc, dtype=torch.float32)
+        out[f"{tag}_tr"], out[f"{tag}_va"] = tr_, va_
+        for na in (True, False):
+            out[f"{tag}_scores_norm{int(na)}"] = ref.ridge_regression.ridge_corr_torch(
+                Xt_[tr_], Xt_[va_], Yt_[tr_], Yt_[va_], al0, singcutoff=1e-10, use_corr=True, normalpha=na).numpy()
+            out[f"{tag}_scores_r2_norm{int(na)}"] = ref.ridge_regression.ridge_corr_torch(
+                Xt_[tr_], Xt_[va_], Yt_[tr_], Yt_[va_], al0, singcutoff=1e-10, use_corr=False, normalpha=na).numpy()
+        out[f"{tag}_W_a0"] = ref.ridge_regression.ridge_torch(Xt_[tr_], Yt_[tr_], 0.0, singcutoff=1e-10, normalpha=True).numpy()
+        random.seed(7)
+        np.random.seed(7)
+        m, W, best = quiet(model.fit_predict, Xc, Yc, alphas=al0, use_gpu=False, folding_type="kfold", n_outer_folds=3,
+                           n_inner_folds=3, singcutoff=1e-10)
+        out[f"{tag}_fit_W"], out[f"{tag}_fit_alphas"] = W, best
+        out[f"{tag}_fit_correlations"] = np.asarray(m["correlations"])
+        m, W, best = quiet(model.fit_predict, Xc[:160], Yc[:160], X_test=Xc[160:], y_test=Yc[160:], alphas=al0,
+                           use_gpu=False, folding_type="kfold", n_inner_folds=3, singcutoff=1e-10)
+        out[f"{tag}_tt_W"], out[f"{tag}_tt_alphas"] = W, best
+        out[f"{tag}_tt_correlations"] = np.asarray(m["correlations"])
+    save("spectral.npz", **out)
+
+
 if __name__ == "__main__":
     gen_saver()
     gen_fir()
@@ -342,3 +420,4 @@ if __name__ == "__main__":
     gen_fits()
     gen_harness()
     gen_singcutoff()
+    gen_spectral()

@@ -32,7 +32,8 @@ class OracleEngine:
     exchanges through the same ShardContext."""
     primal = False
     def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard, precision="auto", singcutoff=0.0, V_total=None,
-                 min_train_rows=None, form="dual"):
+                 min_train_rows=None, form="dual", panels=None):
+        Y = np.concatenate([b for _, b in Y.blocks], axis=0)              # ops.HostRows: the targets' row blocks
         self.X, self.Y = torch.tensor(np.asarray(X), dtype=torch.float32), torch.tensor(np.asarray(Y), dtype=torch.float32)
         self.alphas, self.normalpha, self.use_corr, self.shard = list(alphas), normalpha, use_corr, shard
         self.V = self.Y.shape[1]
@@ -47,7 +48,9 @@ class OracleEngine:
         return [None] * len(outer)
     def prepare_folds(self, folds, lmax_pre, chol_after=None):
         return [dict(tr=np.asarray(tr), te=np.asarray(te), inner=inner) for tr, te, inner in folds]
-    def fold_begin(self, tr, te, inner, prepared=None, lmax_pre=None):
+    def plan_steps(self, n_folds, single_alpha=False):
+        return [(f, (0, self.V)) for f in range(n_folds)]
+    def fold_begin(self, tr, te, inner, prepared=None, lmax_pre=None, step=None):
         return prepared
     def chain_gate(self):
         return None
@@ -68,7 +71,7 @@ class OracleEngine:
         st["used_all"] = [a for a, c in enumerate(self.shard.all_reduce_(count.clone(), "sum").tolist()) if c > 0]
         assert set(st["used"]) <= set(st["used_all"])
         return st
-    def fold_speculate(self, st, alphas_idx):
+    def fold_speculate(self, st, alphas_idx, early=False):
         pass
     def refit_ahead(self, states):
         pass

@@ -381,3 +381,51 @@ def test_inner_fold_without_validation_rows_is_skipped(lc):
     eng.begin_fit(1)
     with pytest.raises(ValueError, match="at least one training and one validation row"):
         eng.fold_begin(tr, te, [empty])
+
+
+def test_sweeps_are_bit_reproducible_beside_a_coresident_workgroup(lc):
+    """The fp16x3 sweep kernel fills its LDS ring by LDS-DMA behind counted waits and one barrier per K-tile.  A small
+    LDS-using kernel of ANOTHER stream fits on the same CU beside its workgroup (31 KB of LDS and a few VGPRs are left);
+    rounds 1-2 leaned on a DMA landing later than a queued ds_read returns, which such a neighbour broke in ~1 sweep of
+    5: one wave multiplied 32 rows of one K-tile with the next ring turn's bytes, a handful of voxels of the first outer
+    fold chose another alpha (found by the full-size bit-identity test below turning flaky; fixed by waiting for the
+    fragment reads before the barrier).  Fold 0's sweeps at cfg2 size, repeated with the auxiliary stream doing what it
+    does beside them in a real fit (fold 0's own Cholesky chain, then the series chain of folds 1-4): every repetition
+    equals the undisturbed one bit for bit."""
+    from litcoder_core_amd import nested_cv as ncv, ops
+    from litcoder_core_amd.folding import create_folds
+    V, T = 80000, 3000
+    dX, dY, p = _device_problem(lc, T, 768, [1, 2, 3, 4], V, seed=0)
+    alphas = np.logspace(-1, 8, 20)
+    eng = ncv.RidgeCVEngine(ncv._DeviceShapes(dX, p), ncv._DeviceShapes(dY, V), alphas, True, True, False, False)
+    eng.begin_fit(5)
+    outer = [(tr, te, create_folds(len(tr), "kfold", 5)) for tr, te in create_folds(T, "kfold", 5)]
+    lmax_pre = eng.precompute_lmax(outer)
+    base = eng.prepare_folds(outer[:1], lmax_pre[:1])[0]
+    torch.cuda.synchronize()
+
+    def sweep(done=None):
+        hat = dict(base["hat"])
+        cs, split = eng._target_scales(eng.dY_full, eng.full)
+        hat.update(cs=cs, split=split)
+        return eng._sweeps(hat, eng.dY_full, done)
+
+    ref = sweep()
+    torch.cuda.synchronize()
+    ref = ref.clone()
+    N, M, B = 1920, 480, 20
+    aug0 = torch.randn((B, N + M, N), dtype=torch.float64, device=dX.device) * 0.01
+    aug0[:, :N] += torch.eye(N, dtype=torch.float64, device=dX.device) * 50.0
+    for it in range(10):
+        gate = torch.cuda.Event()
+        with torch.cuda.stream(eng.aux):
+            aug = aug0.clone()
+            H = torch.empty((B, M, N), dtype=torch.float32, device=dX.device)
+            ops.batch_chol_solve(aug, B, N, M, H)
+            done = torch.cuda.Event()
+            done.record()
+        eng.prepare_folds(outer[1:], lmax_pre[1:], chol_after=gate)
+        s = sweep(done)
+        gate.record()
+        torch.cuda.synchronize()
+        assert torch.equal(s[:, :V], ref[:, :V]), f"repetition {it}: {int((s[:, :V] != ref[:, :V]).sum())} scores differ"

@@ -164,8 +164,8 @@ def test_ridge_solvers_golden(lc, golden_dir):
 def test_singcutoff_boundary_on_rank_deficient_design(lc, golden_dir):
     """Rank-25 design with p = 40 (15 singular values at fp32 noise level, ~1e-6): the reference's results for
     singcutoff 1e-30 / 1e-10 (nothing dropped) and 1e-6 (7 directions dropped, ridge_utils.py:44-63) against this
-    implementation, which never truncates -- scores, weights and a full fit.  A singcutoff large enough to act
-    (here 1.0 against a_min = 0.1 S[0] ~ 2.6) raises instead of returning something else."""
+    implementation -- scores, weights and a full fit (Cholesky route where the cutoff is negligible against the smallest
+    penalty, the spectral route of test_spectral_route_... where it might not be)."""
     from litcoder_core_amd import ridge
     g = load(golden_dir, "singcutoff.npz")
     X, Y, tr, va, alphas = g["X"], g["Y"], g["tr"], g["va"], g["alphas"]
@@ -180,9 +180,59 @@ def test_singcutoff_boundary_on_rank_deficient_design(lc, golden_dir):
         np.testing.assert_allclose(a, g[f"fit_{i}_alphas"], rtol=1e-6)
         np.testing.assert_allclose(np.asarray(m["correlations"], dtype=np.float64), g[f"fit_{i}_correlations"], atol=2e-5)
         np.testing.assert_allclose(W, g[f"fit_{i}_W"], rtol=1e-4, atol=2e-5)
-    with pytest.raises(ValueError, match="singcutoff=1 is not negligible against the smallest penalty a = alpha S"):
-        lc.NestedCVModel("r").fit_predict(X, Y, alphas=alphas, folding_type="kfold", n_outer_folds=3, n_inner_folds=3,
-                                          singcutoff=1.0)
+
+
+def test_spectral_route_alpha_zero_and_biting_singcutoff(lc, golden_dir):
+    """Where the Cholesky route cannot follow the reference -- alpha = 0 (pseudo-inverse of the kept directions,
+    ridge_regression.py:56,117) and a singcutoff that drops real directions (ridge_utils.py:44-63) -- the operators come
+    from the fp64 eigendecomposition of K[tr, tr] (lc_batch_eigh_jacobi + lc_batch_spectral_apply) with exactly the
+    reference's truncation.  Reference outputs (tests/golden/spectral.npz): scores, weights and full fits on a
+    rank-deficient design (25 / 18 of the 25 real directions kept), a wide full-rank one (alpha = 0 interpolates) and a
+    tall one (alpha = 0 = least squares: the dual route caps the rank at p)."""
+    from litcoder_core_amd import ridge
+    from litcoder_core_amd.nested_cv import check_penalties
+    g = load(golden_dir, "spectral.npz")
+    X, Y, tr, va, alphas = g["rd_X"], g["rd_Y"], g["rd_tr"], g["rd_va"], g["rd_alphas"]
+    assert check_penalties(alphas, 1e-10, True) and check_penalties([0.1, 1.0], 2.5, True) and not check_penalties([0.1], 1e-10, True)
+    for i, sc in enumerate(g["rd_cutoffs"]):
+        for na in (1, 0):
+            got = ridge.ridge_corr(X[tr], X[va], Y[tr], Y[va], alphas, float(sc), True, bool(na))
+            np.testing.assert_allclose(got, g[f"rd_scores_{i}_norm{na}"], rtol=1e-4, atol=2e-5, err_msg=f"cut {sc} norm{na}")
+            for a_ in (0, 3):
+                got = ridge.ridge(X[tr], Y[tr], float(a_), float(sc), bool(na))
+                np.testing.assert_allclose(got, g[f"rd_W_{i}_norm{na}_a{a_}"], rtol=1e-4, atol=2e-5,
+                                           err_msg=f"cut {sc} norm{na} alpha {a_}")
+        for single in (0, 1):
+            m, W, a = lc.NestedCVModel("r").fit_predict(X, Y, alphas=alphas, folding_type="kfold", n_outer_folds=3,
+                                                        n_inner_folds=3, singcutoff=float(sc), single_alpha=bool(single))
+            tag = f"rd_fit_{i}_s{single}"
+            same = np.isclose(a, g[tag + "_alphas"], rtol=1e-6)
+            assert same.mean() >= 0.9, (tag, same.mean())
+            np.testing.assert_allclose(np.asarray(m["correlations"], dtype=np.float64)[same], g[tag + "_correlations"][same],
+                                       atol=2e-5, err_msg=tag)
+            np.testing.assert_allclose(W[:, same], g[tag + "_W"][:, same], rtol=1e-4, atol=2e-5, err_msg=tag)
+    for tag in ("wide", "tall"):
+        Xc, Yc, al = g[f"{tag}_X"], g[f"{tag}_Y"], g[f"{tag}_alphas"]
+        tr, va = g[f"{tag}_tr"], g[f"{tag}_va"]
+        for na in (1, 0):
+            got = ridge.ridge_corr(Xc[tr], Xc[va], Yc[tr], Yc[va], al, 1e-10, True, bool(na))
+            np.testing.assert_allclose(got, g[f"{tag}_scores_norm{na}"], rtol=1e-4, atol=2e-5, err_msg=f"{tag} norm{na}")
+            got = ridge.ridge_corr(Xc[tr], Xc[va], Yc[tr], Yc[va], al, 1e-10, False, bool(na))
+            np.testing.assert_allclose(got, g[f"{tag}_scores_r2_norm{na}"], rtol=1e-4, atol=5e-5, err_msg=f"{tag} r2 norm{na}")
+        got = ridge.ridge(Xc[tr], Yc[tr], 0.0, 1e-10, True)
+        np.testing.assert_allclose(got, g[f"{tag}_W_a0"], rtol=1e-4, atol=2e-5, err_msg=tag)
+        m, W, a = lc.NestedCVModel("r").fit_predict(Xc, Yc, alphas=al, folding_type="kfold", n_outer_folds=3,
+                                                    n_inner_folds=3, singcutoff=1e-10)
+        same = np.isclose(a, g[f"{tag}_fit_alphas"], rtol=1e-6)
+        assert same.mean() >= 0.9, (tag, same.mean())
+        np.testing.assert_allclose(np.asarray(m["correlations"], dtype=np.float64)[same], g[f"{tag}_fit_correlations"][same],
+                                   atol=2e-5, err_msg=tag)
+        np.testing.assert_allclose(W[:, same], g[f"{tag}_fit_W"][:, same], rtol=1e-4, atol=2e-5, err_msg=tag)
+        m, W, a = lc.NestedCVModel("r").fit_predict(Xc[:160], Yc[:160], X_test=Xc[160:], y_test=Yc[160:], alphas=al,
+                                                    folding_type="kfold", n_inner_folds=3, singcutoff=1e-10)
+        same = np.isclose(a, g[f"{tag}_tt_alphas"], rtol=1e-6)
+        assert same.mean() >= 0.9, (tag, same.mean())
+        np.testing.assert_allclose(W[:, same], g[f"{tag}_tt_W"][:, same], rtol=1e-4, atol=2e-5, err_msg=tag)
 
 
 # ------------------------------------------------------------------ full fits vs the reference
@@ -431,21 +481,23 @@ def test_speculative_refit_systems_are_neutral(lc):
     calls = []
     real = ncv.RidgeCVEngine.fold_speculate
 
-    def spy(self, st, alphas_idx):
-        calls.append(list(alphas_idx))
-        return real(self, st, alphas_idx)
+    def spy(self, st, alphas_idx, early=False):
+        calls.append((list(alphas_idx), early))
+        return real(self, st, alphas_idx, early=early)
 
-    def partial(self, st, alphas_idx):
-        return real(self, st, list(alphas_idx)[:1])       # an incomplete guess: the rest is solved after the choice
+    def partial(self, st, alphas_idx, early=False):
+        return real(self, st, list(alphas_idx)[:1], early=early)   # an incomplete guess: the rest is solved after the choice
 
     out = {}
-    for name, fn in (("spec", spy), ("partial", partial), ("none", lambda self, st, alphas_idx: None)):
+    for name, fn in (("spec", spy), ("partial", partial), ("none", lambda self, st, alphas_idx, early=False: None)):
         ncv.RidgeCVEngine.fold_speculate = fn
         try:
             out[name] = lc.NestedCVModel("ridge_regression").fit_predict(features=X, targets=Y, **kw)
         finally:
             ncv.RidgeCVEngine.fold_speculate = real
-    assert len(calls) == 2 and all(calls)
+    # folds 1, 2: what the fold before used (host inputs with raw alphas: nothing is solved ahead for fold 0 -- every
+    # operator is a full augmented solve, too dear to form for alphas nobody may choose)
+    assert [e for _, e in calls] == [False, False] and all(a for a, _ in calls)
     for name in ("spec", "partial"):
         (m, w, a), (m0, w0, a0) = out[name], out["none"]
         assert np.array_equal(w, w0) and np.array_equal(a, a0), name
@@ -782,6 +834,81 @@ def test_voxel_shard_invariance_and_permutation(lc):
     m_p, W_p, a_p = model.fit_predict(X, Y[:, perm], **kw)
     assert np.array_equal(np.asarray(m["correlations"])[perm], np.asarray(m_p["correlations"]))
     assert np.array_equal(a[perm], a_p) and np.array_equal(W[:, perm], W_p)
+
+
+def test_refit_operand_from_the_inner_cv_image_is_bitwise_neutral(lc):
+    """The refit's alpha-sorted fp16 operand is gathered column-wise out of the tiled image the inner CV made of the outer
+    training rows (lc_permute_cols_f16) instead of gathering the fp32 targets, storing a sorted copy and splitting it
+    again: same hi/lo values, same contraction order -- identical weights, correlations and alphas."""
+    from litcoder_core_amd import nested_cv as ncv
+    X, Y = _synthetic(480, 96, 1300, 31)                      # 3 x 160-row folds: inner training sets of 213/214 rows pad
+    X2, Y2 = _synthetic(640, 96, 1300, 32)                    # 5 x 128: aligned K-folds -> one shared image per outer fold
+    for (Xc, Yc, kw) in ((X2, Y2, dict(folding_type="kfold", n_outer_folds=5, n_inner_folds=4, alphas=np.logspace(-1, 5, 8))),
+                         (X, Y, dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=np.logspace(-1, 5, 8)))):
+        assert ncv.REFIT_FROM_IMAGE
+        got = lc.NestedCVModel("r", precision="f16x3").fit_predict(Xc, Yc, **kw)
+        try:
+            ncv.REFIT_FROM_IMAGE = False
+            ref = lc.NestedCVModel("r", precision="f16x3").fit_predict(Xc, Yc, **kw)
+        finally:
+            ncv.REFIT_FROM_IMAGE = True
+        for k in ref[0]:
+            assert np.array_equal(np.asarray(got[0][k]), np.asarray(ref[0][k]), equal_nan=True), k
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+
+
+def test_voxel_panels_are_bitwise_neutral(lc):
+    """A host-to-host fit moves its targets / weights in column panels (first fold on a panel while the others still
+    cross PCIe, last fold's weights leaving panel by panel: VERDICT r2 item 1).  Per-voxel results do not depend on
+    the panel plan, bit for bit: metrics, alphas, weights -- CV and train/test, both scorings, per-voxel and single
+    alpha, train-statistics normalisation, float32 inputs, the primal and the block-product forms."""
+    X, Y = _synthetic(420, 96, 1100, 21)
+    Y[:, 17] = 1.5                                        # a constant voxel
+    cases = [
+        dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 5, 8)),
+        dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 5, 8), use_corr=False,
+             normalpha=False),
+        dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=3, alphas=np.logspace(-1, 4, 6), single_alpha=True),
+        dict(folding_type="chunked_contiguous", n_outer_folds=3, n_inner_folds=2, alphas=np.logspace(0, 4, 5),
+             normalize_targets=True, normalize_features=True),
+    ]
+    for kw in cases:
+        ref = lc.NestedCVModel("r", panel_cols=0).fit_predict(X.astype(np.float64), Y.astype(np.float64), **kw)
+        for cols, dt in ((256, np.float64), (512, np.float32)):
+            got = lc.NestedCVModel("r", panel_cols=cols).fit_predict(X.astype(dt), Y.astype(dt), **kw)
+            assert got[0].keys() == ref[0].keys()
+            for k in ref[0]:
+                assert np.array_equal(np.asarray(got[0][k]), np.asarray(ref[0][k]), equal_nan=True), (kw, cols, k)
+            assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), (kw, cols)
+    # train / test mode: one fold that is first (panels arrive) and last (panels leave) at once
+    kw = dict(folding_type="kfold", n_inner_folds=3, alphas=np.logspace(-1, 5, 8))
+    ref = lc.NestedCVModel("r", panel_cols=0).fit_predict(X[:330], Y[:330], X_test=X[330:], y_test=Y[330:], **kw)
+    got = lc.NestedCVModel("r", panel_cols=256).fit_predict(X[:330], Y[:330], X_test=X[330:], y_test=Y[330:], **kw)
+    for k in ref[0]:
+        assert np.array_equal(np.asarray(got[0][k]), np.asarray(ref[0][k]), equal_nan=True), k
+    assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    # tall designs: the primal form (p = 24) and the block-product form (p = 6)
+    for p in (24, 6):
+        Xt, Yt = _synthetic(900, p, 800, 22 + p)
+        kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 4, 6))
+        m0 = lc.NestedCVModel("r", panel_cols=0)
+        ref = m0.fit_predict(Xt, Yt, **kw)
+        m1 = lc.NestedCVModel("r", panel_cols=256)
+        got = m1.fit_predict(Xt, Yt, **kw)
+        assert m0.last_form == m1.last_form == "primal"
+        for k in ref[0]:
+            assert np.array_equal(np.asarray(got[0][k]), np.asarray(ref[0][k]), equal_nan=True), (p, k)
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), p
+    # precision "auto" meets a too-wide column in a LATE panel: the fit is repeated on the f32 path and equals it
+    Y2 = Y.copy()
+    Y2[7, 1000] = 1e6
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 5, 8))
+    m_auto = lc.NestedCVModel("r", panel_cols=256)
+    got = m_auto.fit_predict(X, Y2, **kw)
+    assert m_auto.last_fit["precision"] == "f32"
+    ref = lc.NestedCVModel("r", precision="f32", panel_cols=0).fit_predict(X, Y2, **kw)
+    assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    assert np.array_equal(np.asarray(got[0]["correlations"]), np.asarray(ref[0]["correlations"]))
 
 
 def test_wide_target_scales_and_planted_signal(lc):

@@ -45,6 +45,9 @@ cases = {
     "normalised": dict(folding_type="chunked_contiguous", n_outer_folds=3, n_inner_folds=2, chunk_length=10,
                        alphas=np.logspace(-1, 4, 6), normalize_features=True, normalize_targets=True),
     "tall": dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=np.logspace(-1, 3, 5), _p=8),   # primal form
+    # a column too wide for the fp16 split in the LAST rank's block only: precision "auto" must take the same arithmetic
+    # (hence the same collectives) on every rank -- the flag is all-reduced before anybody acts on it
+    "outlier": dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 5, 8), _spike=(7, 700)),
 }
 shard = None
 if backend != "none":
@@ -57,12 +60,19 @@ out = {"lo": lo, "hi": hi}
 for name, kw in cases.items():
     kw = dict(kw)
     Xc = X[:, : kw.pop("_p", p)]
+    spike = kw.pop("_spike", None)
+    Yc = Y
+    if spike is not None:
+        Yc = Y.copy()
+        Yc[spike] = 1e6
     for prec in (("auto", "f32") if name == "pervoxel" else ("auto",)):
         model = NestedCVModel("r", shard=shard, precision=prec)
-        out[name, prec, "cv"] = model.fit_predict(Xc, Y, **kw)
+        out[name, prec, "cv"] = model.fit_predict(Xc, Yc, **kw)
         assert model.last_form == ("primal" if name == "tall" else "dual")
+        if spike is not None:
+            assert model.last_fit["precision"] == "f32", "every rank falls back together"
         kw_tt = {k: v for k, v in kw.items() if k != "n_outer_folds"}
-        out[name, prec, "tt"] = model.fit_predict(Xc[:330], Y[:330], X_test=Xc[330:], y_test=Y[330:], **kw_tt)
+        out[name, prec, "tt"] = model.fit_predict(Xc[:330], Yc[:330], X_test=Xc[330:], y_test=Yc[330:], **kw_tt)
 tag = "single" if backend == "none" else f"{backend}{world}_rank{shard.rank}"
 pickle.dump(out, open(os.path.join(out_dir, tag + ".pkl"), "wb"))
 if shard is not None:
@@ -108,7 +118,7 @@ def test_two_real_engine_ranks_on_one_gpu_equal_the_unsharded_fit(runs):
         for r, out in enumerate(ranks):
             _same(out[key], want, out["lo"], out["hi"], (key, r))
             n += 1
-    assert n == 2 * 2 * 7
+    assert n == 2 * 2 * 8
 
 
 def test_three_ranks_uneven_shares(runs):

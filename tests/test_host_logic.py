@@ -40,21 +40,24 @@ def test_no_gpu_means_loud_failure():
         lc.NestedCVModel("r").fit_predict(np.zeros((40, 3)), np.zeros((40, 2)), folding_type="kfold")
 
 
-def test_penalty_grid_validation_names_the_deviation():
-    """alpha = 0 and a singcutoff that would act are where this implementation (Cholesky of K + a^2 I, no truncation)
-    leaves the reference (ridge_utils.py:44-63, ridge_regression.py:56,117): both raise before the device is touched,
-    with a message that says so; every shipped caller's values pass."""
+def test_penalty_grid_validation_and_route():
+    """check_penalties validates the grid before the device is touched and says which route the fit takes: Cholesky
+    (every shipped caller's values) or the spectral one -- alpha = 0 in the grid, or a singcutoff that is not negligible
+    against the smallest penalty, where the reference's truncated SVD has to be reproduced as such
+    (ridge_utils.py:44-63, ridge_regression.py:56,117)."""
     from litcoder_core_amd.nested_cv import check_penalties
-    check_penalties(np.logspace(-1, 8, 20), 1e-10, True, 5)              # example.py / train_simple.py / unified.py
-    check_penalties([0.1, 1.0], 1e-30, False)                             # ridge_corr_torch's own default
-    check_penalties([1.0], 1e-3, False)                                   # (1e-3 / 1)^2 = 1e-6: still invisible in fp32
+    assert not check_penalties(np.logspace(-1, 8, 20), 1e-10, True, 5)   # example.py / train_simple.py / unified.py
+    assert not check_penalties([0.1, 1.0], 1e-30, False)                 # ridge_corr_torch's own default
+    assert not check_penalties([1.0], 1e-3, False)                       # (1e-3 / 1)^2 = 1e-6: invisible in fp32
+    assert check_penalties([0.0, 1.0], 1e-10, True) and check_penalties([1.0, 10.0], 1e-2, False)
+    assert check_penalties([0.1], 1e-6, True)                            # normalpha: S[0] unknown yet -> the safe route
     model = lc.NestedCVModel("r")
     X, Y = np.zeros((40, 3)), np.zeros((40, 2))
-    for bad in ([0.0, 1.0], [-1.0], [np.nan], [np.inf]):
-        with pytest.raises(ValueError, match=r"alpha = 0 case .*ridge_utils\.py:44-63"):
+    for bad in ([-1.0], [np.nan], [np.inf]):
+        with pytest.raises(ValueError, match="alphas must be finite and >= 0"):
             model.fit_predict(X, Y, alphas=bad, folding_type="kfold")
-    with pytest.raises(ValueError, match=r"singcutoff=0\.01 is not negligible .*ridge_utils\.py:44-63"):
-        model.fit_predict(X, Y, alphas=[1.0, 10.0], normalpha=False, singcutoff=1e-2, folding_type="kfold")
+    with pytest.raises(ValueError, match="singcutoff must be a finite number"):
+        model.fit_predict(X, Y, alphas=[1.0], singcutoff=-1.0, folding_type="kfold")
     with pytest.raises(ValueError, match="at most 64 alphas"):
         model.fit_predict(X, Y, alphas=np.logspace(-1, 8, 65), folding_type="kfold")
     with pytest.raises(ValueError, match="at most 64 inner folds"):

@@ -110,6 +110,51 @@ def test_singcutoff_on_rank_deficient_design(golden_dir):
         np.testing.assert_allclose(np.asarray(m["correlations"]), g[f"fit_{i}_correlations"], rtol=0, atol=2e-6)
 
 
+def test_alpha_zero_and_biting_singcutoff(golden_dir):
+    """alpha = 0 (D = 1 / S on the kept directions, ridge_regression.py:56,117) and cutoffs that really drop singular
+    values (ridge_utils.py:44-63), as the reference computes them: rank-deficient design (18 of 25 real directions kept
+    at the larger cutoff), wide full-rank design (alpha = 0 interpolates), tall design (alpha = 0 = least squares)."""
+    g = load(golden_dir, "spectral.npz")
+    X, Y = torch.tensor(g["rd_X"], dtype=torch.float32), torch.tensor(g["rd_Y"], dtype=torch.float32)
+    tr, va, alphas = g["rd_tr"], g["rd_va"], g["rd_alphas"]
+    assert alphas[0] == 0.0 and [int(g["rd_kept_0"]), int(g["rd_kept_1"])] == [25, 18]
+    for i, sc in enumerate(g["rd_cutoffs"]):
+        assert ridge.thin_svd(X[tr], float(sc))[1].numel() == int(g[f"rd_kept_{i}"])
+        for na in (1, 0):
+            got = ridge.alpha_sweep_scores(X[tr], X[va], Y[tr], Y[va], alphas, float(sc), True, bool(na)).numpy()
+            np.testing.assert_allclose(got, g[f"rd_scores_{i}_norm{na}"], rtol=0, atol=2e-6)
+            for a_ in (0, 3):
+                got = ridge.ridge_weights(X[tr], Y[tr], float(a_), float(sc), bool(na)).numpy()
+                np.testing.assert_allclose(got, g[f"rd_W_{i}_norm{na}_a{a_}"], rtol=0, atol=2e-6)
+        for single in (0, 1):
+            m, W, a = nested_cv.fit_predict(g["rd_X"], g["rd_Y"], alphas=alphas, folding_type="kfold", n_outer_folds=3,
+                                            n_inner_folds=3, singcutoff=float(sc), single_alpha=bool(single))
+            tag = f"rd_fit_{i}_s{single}"
+            np.testing.assert_allclose(a, g[tag + "_alphas"], rtol=1e-6)
+            np.testing.assert_allclose(W, g[tag + "_W"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(np.asarray(m["correlations"]), g[tag + "_correlations"], rtol=0, atol=2e-6)
+    for tag in ("wide", "tall"):
+        Xc, Yc, al = g[f"{tag}_X"], g[f"{tag}_Y"], g[f"{tag}_alphas"]
+        Xt, Yt = torch.tensor(Xc, dtype=torch.float32), torch.tensor(Yc, dtype=torch.float32)
+        tr, va = g[f"{tag}_tr"], g[f"{tag}_va"]
+        for na in (1, 0):
+            got = ridge.alpha_sweep_scores(Xt[tr], Xt[va], Yt[tr], Yt[va], al, 1e-10, True, bool(na)).numpy()
+            np.testing.assert_allclose(got, g[f"{tag}_scores_norm{na}"], rtol=0, atol=2e-6)
+            got = ridge.alpha_sweep_scores(Xt[tr], Xt[va], Yt[tr], Yt[va], al, 1e-10, False, bool(na)).numpy()
+            np.testing.assert_allclose(got, g[f"{tag}_scores_r2_norm{na}"], rtol=0, atol=2e-6)
+        got = ridge.ridge_weights(Xt[tr], Yt[tr], 0.0, 1e-10, True).numpy()
+        np.testing.assert_allclose(got, g[f"{tag}_W_a0"], rtol=0, atol=2e-6)
+        m, W, a = nested_cv.fit_predict(Xc, Yc, alphas=al, folding_type="kfold", n_outer_folds=3, n_inner_folds=3,
+                                        singcutoff=1e-10)
+        np.testing.assert_allclose(a, g[f"{tag}_fit_alphas"], rtol=1e-6)
+        np.testing.assert_allclose(W, g[f"{tag}_fit_W"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(np.asarray(m["correlations"]), g[f"{tag}_fit_correlations"], rtol=0, atol=2e-6)
+        m, W, a = nested_cv.fit_predict(Xc[:160], Yc[:160], X_test=Xc[160:], y_test=Yc[160:], alphas=al,
+                                        folding_type="kfold", n_inner_folds=3, singcutoff=1e-10)
+        np.testing.assert_allclose(a, g[f"{tag}_tt_alphas"], rtol=1e-6)
+        np.testing.assert_allclose(W, g[f"{tag}_tt_W"], rtol=0, atol=5e-6)
+
+
 def _check_fit(g, spec, name):
     s = spec[name]
     X, Y = g[f"X_{s['data']}"], g[f"Y_{s['data']}"]

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Timeline of one HOST-TO-HOST cfg2 fit (float64 numpy in -> metrics + host float32 weights out): host wall time of
+the engine phases, when each upload panel had been staged / had landed in HBM, when the V-wide phases ran on the
+device, when each weight panel had reached the host.   python tools/host_path_timeline.py [V]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from litcoder_core_amd import NestedCVModel, nested_cv as ncv, ops  # noqa: E402
+
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 80000
+dev = ops.device(0)
+dX, dY, p = bench.synth_inputs(V, 0, dev)
+X, Y = bench.host_arrays(dX, dY, p, V)
+alphas = np.logspace(-1, 8, bench.A)
+model = NestedCVModel("ridge_regression")
+host_log, dev_marks = [], []
+T0 = [0.0]
+
+
+def wrap_host(obj, name, label=None):
+    fn = getattr(obj, name)
+
+    def inner(*a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            host_log.append((label or name, t, time.perf_counter()))
+    setattr(obj, name, inner)
+
+
+def wrap_dev(name, label):
+    fn = getattr(ncv.RidgeCVEngine, name)
+
+    def inner(self, *a, **k):
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+        out = fn(self, *a, **k)
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        dev_marks.append((label, e0, e1))
+        return out
+    setattr(ncv.RidgeCVEngine, name, inner)
+
+
+for n, lab in (("_sweeps", "MAIN sweeps"), ("fold_finish", "MAIN refit + statistics"), ("fold_choose", "MAIN choose + group")):
+    wrap_dev(n, lab)
+for n in ("__init__", "begin_fit", "precompute_lmax", "prepare_folds", "fold_begin", "fold_choose", "fold_select", "fold_speculate",
+          "fold_finish", "fold_collect", "_wait_targets", "_range_finished", "combined_significance", "weights"):
+    wrap_host(ncv.RidgeCVEngine, n)
+
+real_close = ops.PanelUploader._close
+
+
+def close(self, j, futs):
+    real_close(self, j, futs)
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(self.stream)
+    dev_marks.append((f"UPLOAD job {j} cols {self.jobs[j][2]}:{self.jobs[j][3]} landed", e, e))
+    host_log.append((f"upload job {j} staged+issued", time.perf_counter(), time.perf_counter()))
+
+
+ops.PanelUploader._close = close
+real_dl = ops.download_cols
+
+
+def dl(src, host, c0, Vc, stream):
+    real_dl(src, host, c0, Vc, stream)
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(stream)
+    dev_marks.append((f"DOWNLOAD cols {c0}:{c0 + Vc} on the host", e, e))
+
+
+ops.download_cols = dl
+
+
+def run():
+    out = model.fit_predict(X, Y, alphas=alphas, **bench.FIT_KW)
+    torch.cuda.synchronize()
+    return out
+
+
+for _ in range(2):
+    run()
+host_log.clear(); dev_marks.clear()
+torch.cuda.synchronize()
+start = torch.cuda.Event(enable_timing=True); start.record()
+t0 = time.perf_counter()
+run()
+t1 = time.perf_counter()
+print(f"host-to-host fit: {1e3 * (t1 - t0):.1f} ms   panels {model.last_fit.get('panels')}")
+print("---- host thread(s)")
+for name, a, b in sorted(host_log, key=lambda x: x[1]):
+    print(f"  {1e3 * (a - t0):8.2f} -> {1e3 * (b - t0):8.2f}  ({1e3 * (b - a):7.2f} ms)  {name}")
+print("---- device")
+rows = sorted(((start.elapsed_time(e0), start.elapsed_time(e1), lab) for lab, e0, e1 in dev_marks))
+for a, b, lab in rows:
+    print(f"  {a:8.2f} -> {b:8.2f}  ({b - a:7.2f} ms)  {lab}")

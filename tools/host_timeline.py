@@ -41,7 +41,7 @@ def wrap(obj, name, label=None):
 
 for n in ("prepare_folds", "fold_begin", "fold_select", "fold_finish", "fold_collect", "precompute_lmax", "weights"):
     wrap(ncv.RidgeCVEngine, n)
-for n in ("choose", "_refit_groups", "_refit_systems", "_sweeps", "_hat_matrices", "_refit_apply", "_fold_data",
+for n in ("choose", "_refit_groups", "_refit_systems", "_sweeps", "_hat_matrices", "_refit_apply", "_fold_targets",
           "_shared_image", "begin_fit", "fold_choose", "fold_speculate", "_sharded_solve", "_refit_chol",
           "combined_significance", "refit_ahead", "_refit_rhs"):
     wrap(ncv.RidgeCVEngine, n, "    . " + n)
