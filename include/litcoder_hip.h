@@ -229,10 +229,12 @@ int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, 
  * train sets and their inner train sets) is a principal submatrix of K, so one call serves the whole fit.
  * d_work: F*(3*T + 2*steps + 8) + 16*32*T f64 (the matvec -- K times the 32 systems' vectors on the fp64 MFMA -- is
  * split over up to 16 column ranges whose partial sums are added in fixed order).  d_lmax: (F) f64.
- * lc_debug_lanczos_mfma(0 / 1): diagnostics, 0 = the vector-ALU matvec of round 1; returns the setting. */
+ * lc_lambda_max_masked_opt: use_mfma = 0 takes the vector-ALU matvec of round 1 (a per-call choice: the library has no
+ * process-wide switches). */
 int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
                          double* d_work, double* d_lmax, lc_stream_t stream);
-int lc_debug_lanczos_mfma(int on);
+int lc_lambda_max_masked_opt(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
+                             double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream);
 
 /* a2[f*A + a] = (alphas[a] * (normalpha ? sqrt(lmax[f]) : 1))^2
  * (ridge_regression.py:99-101,117: D = S/(S^2 + nalpha^2)). */
@@ -329,18 +331,19 @@ int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, floa
 int lc_batch_chol_inverse(double* d_aug, int B, int N, double* d_linv, float* d_p, const int32_t* d_slot,
                           int32_t* d_info, lc_stream_t stream);
 
-/* Tuning hook of lc_batch_chol_solve: columns per outer block of its two-level blocking (a multiple of LC_NB;
- * default 512).  columns <= 0 only queries.  Returns the value in force (>= LC_NB), or a negative error code. */
-int lc_chol_outer_block(int columns);
-/* Diagnostic: kernel of the deep updates of lc_batch_chol_solve -- 2: 4x4x4 fp64 MFMA (default), 1: vector ALU,
- * 0: 16x16x4 fp64 MFMA; anything else only queries.  Returns the one in force. */
-int lc_debug_chol_big_kernel(int which);
-/* Diagnostics: 1 (default) = fused left-looking 64-column steps (one launch per step besides the diagonal tile),
- * 0 = the first version's panel + in-block update launches; returns the setting. */
-int lc_debug_chol_fused_steps(int on);
-/* Diagnostics: 1 = the deep updates of the two-level blocking are left-looking (a block column takes all earlier
- * block columns in one product of full depth; measured: no gain), 0 (default) = right-looking; returns the setting. */
-int lc_debug_chol_left_deep(int on);
+/* The variants of lc_batch_chol_solve / lc_batch_chol_inverse as PER-CALL options (NULL = the defaults); the library
+ * keeps no process-wide switches, so fits with different settings coexist in one process:
+ *   outer_block  columns per outer block of the two-level blocking (a multiple of LC_NB; default 512)
+ *   big_kernel   kernel of the deep updates: 2 = 4x4x4 fp64 MFMA (default), 1 = vector ALU, 0 = 16x16x4 fp64 MFMA
+ *   fused_steps  1 (default) = fused left-looking 64-column steps, 0 = the first version's panel + update launches
+ *   left_deep    1 = the deep updates left-looking too (measured: no gain), 0 (default) = right-looking */
+typedef struct lc_chol_options {
+    int outer_block, big_kernel, fused_steps, left_deep;
+} lc_chol_options;
+int lc_batch_chol_solve_opt(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,
+                            int32_t* d_info, const lc_chol_options* opt, lc_stream_t stream);
+int lc_batch_chol_inverse_opt(double* d_aug, int B, int N, double* d_linv, float* d_p, const int32_t* d_slot,
+                              int32_t* d_info, const lc_chol_options* opt, lc_stream_t stream);
 
 /* The same hat matrices for alphas whose penalty dwarfs the spectrum, as a polynomial in K[tr,tr]:
  *   K[va,tr] (K[tr,tr] + a^2 I)^-1  ~=  sum_{j<terms} c_sj K[va,tr] K[tr,tr]^j / scale_f^(j+1)

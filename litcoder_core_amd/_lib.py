@@ -64,7 +64,6 @@ SIGNATURES = {
                                  c_int, _ptr, c_int64, _ptr]),
     "lc_primal_refit": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int64, c_int, c_int, _ptr, _ptr, _ptr,
                                 c_int, c_float, _ptr, c_int64, _ptr, _ptr]),
-    "lc_debug_lanczos_mfma": (c_int, [c_int]),
     "lc_lambda_max_strided": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_fill_argmax": (c_int, [_ptr, c_int, _ptr, c_int64, _ptr]),
     "lc_fold_pack": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr, c_int, _ptr, c_int, _ptr, c_int64, _ptr]),
@@ -84,12 +83,11 @@ SIGNATURES = {
     "lc_batch_spectral_apply": (c_int, [_ptr, _ptr, c_int, c_int, _ptr, c_int, _ptr, c_int, c_double, _ptr, _ptr, c_int64, _ptr,
                                         POINTER(c_int32), _ptr, _ptr]),
     "lc_fold_unpack": (c_int, [_ptr, c_int, c_int64, _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    "lc_chol_outer_block": (c_int, [c_int]),
-    "lc_debug_chol_big_kernel": (c_int, [c_int]),
-    "lc_debug_chol_fused_steps": (c_int, [c_int]),
-    "lc_debug_chol_left_deep": (c_int, [c_int]),
     "lc_batch_chol_solve": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_batch_chol_inverse": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "lc_batch_chol_solve_opt": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "lc_batch_chol_inverse_opt": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "lc_lambda_max_masked_opt": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, _ptr, _ptr, c_int, _ptr]),
     "lc_batch_series_hat": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int, c_int, c_int,
                                     _ptr, _ptr, _ptr]),
     "lc_batch_series_terms": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, c_int, _ptr, _ptr, _ptr, c_int,

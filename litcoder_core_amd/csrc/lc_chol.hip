@@ -737,16 +737,14 @@ __global__ void __launch_bounds__(256, 3) k_bstep(double* __restrict__ aug, int 
 #undef LC_TILE_COL
 #undef LC_FOR_TILE
 
-static int g_big_kernel = 2;    // deep updates: 2 = 4x4x4 MFMA (k_mm64q), 1 = vector ALU (k_mm64v), 0 = 16x16x4 MFMA (k_mm64<4>)
-       // deep updates on the vector ALU (k_mm64v) or on the MFMA (k_mm64<4>)
-
+// deep updates: big_kernel 2 = 4x4x4 MFMA (k_mm64q, the default), 1 = vector ALU (k_mm64v), 0 = 16x16x4 MFMA (k_mm64<4>)
 template <bool BT>
-void launch_big(const MMArgs& g, int B, hipStream_t s) {
+void launch_big(const MMArgs& g, int B, hipStream_t s, int big_kernel) {
     if (g.rows <= 0 || g.cols <= 0) return;
     const dim3 grid((unsigned)lc::ceil_div(g.cols, 128), (unsigned)lc::ceil_div(g.rows, 128), (unsigned)B);
-    if (g_big_kernel == 2) {                         // LDS attribute: set (and checked) by lc_batch_chol_solve
+    if (big_kernel == 2) {                           // LDS attribute: set (and checked) by lc_batch_chol_solve
         hipLaunchKernelGGL((k_mm64q<BT>), grid, dim3(256), MQ_LDS_BYTES, s, g);
-    } else if (g_big_kernel == 1) {
+    } else if (big_kernel == 1) {
         hipLaunchKernelGGL((k_mm64v<BT>), grid, dim3(256), 0, s, g);
     } else {
         launch_mm<4, BT>(g, B, s);
@@ -774,52 +772,46 @@ __global__ void __launch_bounds__(256) k_extract_sym(const double* __restrict__ 
 
 }  // namespace
 
-static int g_chol_outer = 512;   // columns per outer block (multiple of NB)
-static int g_chol_fused = 1;     // 1: fused left-looking steps (k_lstep / k_bstep); 0: the first version's three launches per step
-static int g_chol_left_deep = 0; // 1: the deep updates left-looking too (one product of the full depth per block column: measured, no gain -- the deep-update kernel is not bound by its C read-modify-write -- and less parallel for small batches); 0: right-looking
-
-extern "C" int lc_debug_chol_left_deep(int on) {
-    if (on == 0 || on == 1) g_chol_left_deep = on;
-    return g_chol_left_deep;
-}
-
-extern "C" int lc_debug_chol_fused_steps(int on) {
-    if (on == 0 || on == 1) g_chol_fused = on;
-    return g_chol_fused;
-}
-
-extern "C" int lc_chol_outer_block(int columns) {
-    if (columns > 0) {
-        LC_REQUIRE(columns % NB == 0, LC_E_SHAPE, "lc_chol_outer_block: need a multiple of %d", NB);
-        g_chol_outer = columns;
-    }
-    return g_chol_outer;
-}
-
-extern "C" int lc_debug_chol_big_kernel(int which) {
-    if (which >= 0 && which <= 2) g_big_kernel = which;
-    return g_big_kernel;
-}
+// The variants of the blocking are PER-CALL options (lc_chol_options, NULL = the defaults): columns per outer block
+// (multiple of NB, default 512); the deep-update kernel; fused left-looking 64-column steps (k_lstep / k_bstep, default)
+// or the first version's three launches per step; the deep updates left-looking too (one product of the full depth per
+// block column: measured, no gain -- the deep-update kernel is not bound by its C read-modify-write -- and less parallel
+// for small batches).  No process-wide switches: two fits with different settings coexist in one process.
+static lc_chol_options chol_defaults() { return lc_chol_options{512, 2, 1, 0}; }
 
 // inverse: the bottom block is the N x N identity and only the block-upper triangle of  I (top)^-1  is formed -- the
 // rows of the product are independent, row tile r of Z = I L^-T is zero left of block column r, and row tile r of the
 // result is only needed from block column r on (the rest by symmetry): in every step the bottom row tiles beyond the
 // current block column are skipped, N^3 / 3 flops per pass instead of N^3.
 static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,
-                           int32_t* d_info, lc_stream_t stream, bool inverse);
+                           int32_t* d_info, lc_stream_t stream, bool inverse, const lc_chol_options* opt);
+
+extern "C" int lc_batch_chol_solve_opt(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
+                                       const int32_t* d_slot, int32_t* d_info, const lc_chol_options* opt,
+                                       lc_stream_t stream) {
+    return chol_solve_impl(d_aug, B, N, M, d_linv, d_h, d_slot, d_info, stream, false, opt);
+}
+
+extern "C" int lc_batch_chol_inverse_opt(double* d_aug, int B, int N, double* d_linv, float* d_p, const int32_t* d_slot,
+                                         int32_t* d_info, const lc_chol_options* opt, lc_stream_t stream) {
+    return chol_solve_impl(d_aug, B, N, N, d_linv, d_p, d_slot, d_info, stream, true, opt);
+}
 
 extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
                                    const int32_t* d_slot, int32_t* d_info, lc_stream_t stream) {
-    return chol_solve_impl(d_aug, B, N, M, d_linv, d_h, d_slot, d_info, stream, false);
+    return chol_solve_impl(d_aug, B, N, M, d_linv, d_h, d_slot, d_info, stream, false, nullptr);
 }
 
 extern "C" int lc_batch_chol_inverse(double* d_aug, int B, int N, double* d_linv, float* d_p, const int32_t* d_slot,
                                      int32_t* d_info, lc_stream_t stream) {
-    return chol_solve_impl(d_aug, B, N, N, d_linv, d_p, d_slot, d_info, stream, true);
+    return chol_solve_impl(d_aug, B, N, N, d_linv, d_p, d_slot, d_info, stream, true, nullptr);
 }
 
 static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,
-                           int32_t* d_info, lc_stream_t stream, bool inverse) {
+                           int32_t* d_info, lc_stream_t stream, bool inverse, const lc_chol_options* opt) {
+    const lc_chol_options o = opt ? *opt : chol_defaults();
+    LC_REQUIRE(o.outer_block > 0 && o.outer_block % NB == 0 && o.big_kernel >= 0 && o.big_kernel <= 2, LC_E_SHAPE,
+               "lc_batch_chol_solve: options: outer_block must be a multiple of %d, big_kernel in 0..2", NB);
     LC_REQUIRE(d_aug && d_linv && d_h && d_info, LC_E_BADARG, "lc_batch_chol_solve: null pointer");
     LC_REQUIRE(B > 0 && B <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
                "lc_batch_chol_solve: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
@@ -830,10 +822,10 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
     LC_HIP(hipMemsetAsync(d_info, 0, sizeof(int32_t) * B, s));
     const int nb = N / NB;
     const int R = N + M;
-    const int ob = g_chol_outer / NB;                        // NB-steps per outer block
+    const int ob = o.outer_block / NB;                       // NB-steps per outer block
     const long long sys = (long long)R * N;
-    const bool fused = g_chol_fused || inverse;              // the triangular limits exist for the default kernels only
-    const bool left_deep = g_chol_left_deep && !inverse;
+    const bool fused = o.fused_steps || inverse;             // the triangular limits exist for the default kernels only
+    const bool left_deep = o.left_deep && !inverse;
     MMArgs g{};
     g.c_sys = g.a_sys = g.b_sys = sys;
     g.lda = g.ldb = g.ldc = N;
@@ -850,7 +842,7 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
             g.c = d_aug + (long long)c0 * N + c0;
             g.rows = R - c0; g.cols = (K1 - K0) * NB; g.depth = c0;
             g.row0 = g.col0 = c0; g.tri = 1; g.subtract = 1;
-            launch_big<true>(g, B, s);
+            launch_big<true>(g, B, s, o.big_kernel);
         }
         for (int k = K0; k < K1; ++k) {
             // fused steps: only the first diagonal tile of an outer block (completed by the deep update) needs a launch
@@ -892,7 +884,7 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
         g.rows = inverse ? (N - c1) + min(M, c1) : R - c1;   // inverse: bottom rows beyond c1 are still zero in this block
         g.cols = N - c1; g.depth = (K1 - K0) * NB;
         g.row0 = g.col0 = c1; g.tri = 1; g.subtract = 1;
-        launch_big<true>(g, B, s);
+        launch_big<true>(g, B, s, o.big_kernel);
     }
     if (int rc = lc::launched("cholesky sweep")) return rc;
     // H L = Z from the last block column to the first:  H_k = Z_k Linv_kk,  Z_j -= H_k L_kj (j < k)
@@ -908,7 +900,7 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
             g.ldb = N;
             g.rows = M; g.cols = (K1 - K0) * NB; g.depth = (nb - K1) * NB;
             g.row0 = g.col0 = 0; g.tri = 0; g.subtract = 1;
-            launch_big<false>(g, B, s);
+            launch_big<false>(g, B, s, o.big_kernel);
         }
         for (int k = K1 - 1; k >= K0; --k) {
             if (fused) {
@@ -941,7 +933,7 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
         g.rows = inverse ? min(M, K0 * NB) : M;              // inverse: block columns < K0 need row tiles < K0 only
         g.cols = K0 * NB; g.depth = (K1 - K0) * NB;
         g.tri = 0; g.subtract = 1;
-        launch_big<false>(g, B, s);
+        launch_big<false>(g, B, s, o.big_kernel);
     }
     if (int rc = lc::launched("back substitution")) return rc;
     if (inverse) hipLaunchKernelGGL(k_extract_sym, dim3(N, B), dim3(256), 0, s, d_aug, N, d_h, d_slot);

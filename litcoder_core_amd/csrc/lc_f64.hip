@@ -774,14 +774,18 @@ extern "C" int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_ro
     return lc_lambda_max_strided(d_k, ldk, 0, d_rows, F, N, steps, d_work, d_lmax, stream);
 }
 
-static int g_lz_mfma = 1;       // masked multi-system matvec: 1 = fp64 MFMA (k_lz_symv_mfma), 0 = vector ALU (k_lz_symv_multi)
-extern "C" int lc_debug_lanczos_mfma(int on) {
-    if (on == 0 || on == 1) g_lz_mfma = on;
-    return g_lz_mfma;
-}
+// use_mfma: the masked multi-system matvec on the fp64 MFMA (k_lz_symv_mfma, the default) or on the vector ALU
+// (k_lz_symv_multi) -- a per-call choice, no process-wide switch
+extern "C" int lc_lambda_max_masked_opt(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
+                                        double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream);
 
 extern "C" int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
                                     double* d_work, double* d_lmax, lc_stream_t stream) {
+    return lc_lambda_max_masked_opt(d_k, ldk, T, d_member, F, steps, d_work, d_lmax, 1, stream);
+}
+
+extern "C" int lc_lambda_max_masked_opt(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
+                                        double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream) {
     LC_REQUIRE(d_k && d_member && d_work && d_lmax, LC_E_BADARG, "lc_lambda_max_masked: null pointer");
     LC_REQUIRE(F > 0 && F <= 32 && T > 0 && steps > 0 && ldk >= T, LC_E_SHAPE,
                "lc_lambda_max_masked: need 1 <= F <= 32 systems, T > 0, steps > 0");
@@ -790,7 +794,7 @@ extern "C" int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const
     hipLaunchKernelGGL(k_lz_init_masked, dim3(F), dim3(256), 0, s, d_member, T, steps, d_work);
     if (int rc = lc::launched("k_lz_init_masked")) return rc;
     double* part = d_work + (long long)F * (3ll * T + 2ll * steps + 8);      // (LZQ_SPLIT, 32, T) partial matvecs
-    const bool mfma = g_lz_mfma != 0;
+    const bool mfma = use_mfma != 0;
     const int jspan = mfma ? lc::ceil_div(lc::ceil_div(T, LZQ_SPLIT), LZQ_JT) * LZQ_JT
                            : lc::ceil_div(lc::ceil_div(T, LZM_SPLIT), LZM_JT) * LZM_JT;
     const int nsplit = lc::ceil_div(T, jspan);

@@ -21,6 +21,7 @@ How the work is laid out (DESIGN.md has the derivation):
 
 Every device operation is a call into liblitcoder_hip.so (``ops.py``); there is no CPU fallback.
 """
+import dataclasses
 import logging
 from typing import Any, Dict, List, Optional, Tuple, Union
 
@@ -36,32 +37,46 @@ from .folding import create_folds
 
 logger = logging.getLogger(__name__)
 
-LANCZOS_STEPS = 64                  # Lanczos iterations for S[0]^2: <= 1e-11 relative on the cfg2 Grams (profiles/);
-                                    # the reference's own S[0] is an fp32 SVD value (~1e-7)
-AUG_BUDGET_BYTES = 24 << 30         # cap on the batched (fold, alpha) fp64 systems resident at once
-SERIES_TERMS = 4                    # terms of the polynomial form of the hat matrices of large alphas (series.py) ...
-SERIES_TOL = 2e-9                   # ... used when its worst relative error over the spectrum, 1 / T_d(1 + 2 alpha^2),
-                                    # is <= this: 30x below the fp32 epsilon of the values it is stored / consumed in
-
-
+SERIES_TERMS = 4                    # terms of the polynomial form of the hat matrices of large alphas (series.py): the
+                                    # moments epilogue of the sweep kernel is laid out for exactly four
 SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singcutoff enters a prediction with weight
                                     # S^2 / (S^2 + a^2) <= (singcutoff / a)^2: below 1e-6 it is invisible in fp32
-PRIMAL_MAX_SCALE_RATIO = 64.0       # ... and whose feature column norms lie within this factor of each other (fp16x3)
-REFIT_BY_INVERSE = True             # refit operators through the explicit inverse + one fp16x3 product (_refit_by_inverse)
-REFIT_INVERSE_MIN_ALPHA = 0.05      # ... for alphas (in units of S[0]) from here on
-REFIT_INVERSE_MAX_WORLD = 4         # ... and up to this many voxel-shard ranks
-FOLDS_IN_ONE_LAUNCH = False         # one launch per pass for all inner folds of an outer fold (_sweeps): measured neutral at
-                                    # 10 000 voxels per rank and 2 ms slower at 80 000 -- off; kept (and tested) as an option
-SERIES_FUSED_MOMENTS = True         # series terms reduced to moments in the contraction's epilogue (never stored)
-PRIMAL_MOMENTS_MAX_P = 16           # ... and, up to this many features, scored from block products X'Y alone (_prepare_moments)
-PRIMAL_MAX_P = 512                  # the primal (p x p) form is taken for tall designs up to this many features
-SPECULATE_FIRST_FOLD = True         # the first fold's refit systems for every factorised alpha, beside its hat-matrix chain
-REFIT_FROM_IMAGE = True             # the refit's alpha-sorted fp16 operand as a column gather out of the inner CV's image
-PANEL_COLS = 24576                  # voxel columns per panel of a host-to-host fit (_column_panels): 96 column tiles x 8
-                                    # M-tiles of the sweeps = exactly 3 rounds of workgroups on 256 CUs
-PANEL_MIN_COLS = 16384              # below twice this many voxels a fit is not cut into panels
 MAX_ALPHAS = 64                     # lc_group_by_alpha / the grouped GEMMs carry at most 64 alpha groups per launch
-MAX_INNER_FOLDS = 64                # the series chain runs the inner folds as column groups of one grouped launch
+MAX_INNER_FOLDS = 64                # inner folds per grouped launch of the series chain / per batch of outer folds prepared together
+                                    # (more inner folds than this are taken in chunks: no limit on n_inner_folds)
+
+
+@dataclasses.dataclass
+class FitOptions:
+    """Policy switches and tuning values of ONE fit.  Every engine carries its own copy (``NestedCVModel(options=...)``,
+    ``RidgeCVEngine(options=...)``): two fits in one process with different settings do not see each other's (until round
+    3 these were module-level constants that tests and tools assigned).  The defaults are the measured choices."""
+    lanczos_steps: int = 64                 # Lanczos iterations for S[0]^2: <= 1e-11 relative on the cfg2 Grams (profiles/);
+                                            # the reference's own S[0] is an fp32 SVD value (~1e-7)
+    aug_budget_bytes: int = 24 << 30        # cap on the batched (fold, alpha) fp64 systems resident at once
+    series_tol: float = 2e-9                # an alpha takes the polynomial form when its worst relative error over the
+                                            # spectrum, 1 / T_d(1 + 2 alpha^2), is <= this: 30x below the fp32 epsilon
+    primal_max_scale_ratio: float = 64.0    # primal V-wide route: feature column norms within this factor (fp16x3)
+    refit_by_inverse: bool = True           # refit operators through the explicit inverse + one fp16x3 product
+    refit_inverse_min_alpha: float = 0.05   # ... for alphas (in units of S[0]) from here on
+    refit_inverse_max_world: int = 4        # ... and up to this many voxel-shard ranks
+    folds_in_one_launch: bool = False       # one launch per pass for all inner folds of an outer fold (_sweeps): measured
+                                            # neutral at 10 000 voxels per rank, 2 ms slower at 80 000 -- off; tested
+    series_fused_moments: bool = True       # series terms reduced to moments in the contraction's epilogue (never stored)
+    primal_moments_max_p: int = 16          # up to this many features the tall form scores from block products X'Y alone
+    primal_max_p: int = 512                 # the primal (p x p) form is taken for tall designs up to this many features
+    speculate_first_fold: bool = True       # the first fold's refit systems for every factorised alpha, beside its chain
+    refit_from_image: bool = True           # the refit's alpha-sorted fp16 operand gathered out of the inner CV's image
+    panel_cols: int = 24576                 # voxel columns per panel of a host-to-host fit (_column_panels): 96 column tiles
+                                            # x 8 M-tiles of the sweeps = exactly 3 rounds of workgroups on 256 CUs
+    panel_min_cols: int = 16384             # below twice this many voxels a fit is not cut into panels
+    alpha_progress_log: bool = dataclasses.field(       # per-alpha progress lines (ridge_regression.py:136-139): a device
+        default_factory=lambda: os.environ.get("LITCODER_AMD_ALPHA_LOG", "0") == "1")   # round trip per fold, opt-in
+    chol_outer_block: int = 512             # lc_batch_chol_solve: columns per outer block of the two-level blocking
+    chol_big_kernel: int = 2                # ... deep updates: 2 = 4x4x4 fp64 MFMA, 1 = vector ALU, 0 = 16x16x4 MFMA
+    chol_fused_steps: bool = True           # ... fused left-looking 64-column steps
+    chol_left_deep: bool = False            # ... deep updates left-looking too (measured: no gain)
+    lanczos_mfma: bool = True               # lc_lambda_max_masked: the matvec on the fp64 MFMA
 
 
 def check_penalties(alphas, singcutoff, normalpha, n_inner_folds=None):
@@ -82,8 +97,8 @@ def check_penalties(alphas, singcutoff, normalpha, n_inner_folds=None):
     if al.size > MAX_ALPHAS:
         raise ValueError(f"at most {MAX_ALPHAS} alphas per fit (got {al.size}): the alpha-grouped kernels carry "
                          f"{MAX_ALPHAS} groups per launch")
-    if n_inner_folds is not None and int(n_inner_folds) > MAX_INNER_FOLDS:
-        raise ValueError(f"at most {MAX_INNER_FOLDS} inner folds per fit (got {n_inner_folds})")
+    if n_inner_folds is not None and int(n_inner_folds) < 1:
+        raise ValueError("n_inner_folds must be >= 1")
     if not np.all(np.isfinite(al)) or np.any(al < 0):
         raise ValueError("alphas must be finite and >= 0 (the penalty is alpha^2: ridge_regression.py:56,117)")
     sc = float(singcutoff)
@@ -188,8 +203,8 @@ def _column_panels(V, cols=None, min_cols=None, v_ref=None):
     workgroups on 256 CUs (8192 columns = one round).  ``v_ref``: the column count the PLAN is derived from (voxel
     shards: the narrowest rank's, so that every rank cuts its block into the same number of panels -- the ranks'
     collectives pair up range by range); the last panel absorbs the difference."""
-    cols = PANEL_COLS if cols is None else int(cols)
-    min_cols = PANEL_MIN_COLS if min_cols is None else int(min_cols)
+    cols = FitOptions.panel_cols if cols is None else int(cols)
+    min_cols = FitOptions.panel_min_cols if min_cols is None else int(min_cols)
     v_ref = int(V) if v_ref is None else min(int(v_ref), int(V))
     if cols % 256:
         raise ValueError("panel width must be a multiple of 256 columns")
@@ -220,13 +235,16 @@ class RidgeCVEngine:
     per-fold pipeline.  ``Y`` holds only this rank's voxel block."""
 
     def __init__(self, X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets,
-                 shard: Optional[ShardContext] = None, lanczos_steps: int = LANCZOS_STEPS, precision: str = "auto",
+                 shard: Optional[ShardContext] = None, lanczos_steps: Optional[int] = None, precision: str = "auto",
                  singcutoff: float = 0.0, V_total: Optional[int] = None, min_train_rows: Optional[int] = None,
-                 form: str = "dual", panels=None):
+                 form: str = "dual", panels=None, options: Optional[FitOptions] = None):
         """``form``: "dual" (n x n Gram / hat matrices: every shape), "primal" (p x p systems, see _prepare_primal) or
         "auto" = primal when the design is tall, 2 p <= ``min_train_rows`` (the smallest inner training set) and
-        p <= PRIMAL_MAX_P.  ``Y_all``: a host array / ops.HostRows (uploaded in the column ``panels`` [(c0, c1), ...] on a
+        p <= FitOptions.primal_max_p.  ``Y_all``: a host array / ops.HostRows (uploaded in the column ``panels`` [(c0, c1), ...] on a
         background thread while the fit is being set up) or resident targets (_DeviceShapes)."""
+        self.opt = dataclasses.replace(options) if options is not None else FitOptions()    # this engine's own copy
+        self._chol_opt = ops.chol_options(self.opt.chol_outer_block, self.opt.chol_big_kernel, self.opt.chol_fused_steps,
+                                          self.opt.chol_left_deep)
         self.spectral = check_penalties(alphas, singcutoff, normalpha)
         self.singcutoff = float(singcutoff)
         self.dev = ops.device()
@@ -246,27 +264,27 @@ class RidgeCVEngine:
         self.normalpha = bool(normalpha)
         self.mode = LC_SCORE_CORR if use_corr else LC_SCORE_R2
         self.norm_x, self.norm_y = bool(normalize_features), bool(normalize_targets)
-        self.steps = int(lanczos_steps)
+        self.steps = int(lanczos_steps if lanczos_steps is not None else self.opt.lanczos_steps)
         if precision not in ("auto", "f32", "f16x3"):
             raise ValueError(f"precision must be 'auto', 'f32' or 'f16x3', got {precision!r}")
         self.precision = precision
         if form not in ("dual", "primal", "auto"):
             raise ValueError(f"form must be 'dual', 'primal' or 'auto', got {form!r}")
         self.primal = form == "primal" or (form == "auto" and min_train_rows is not None
-                                           and 2 * self.p <= int(min_train_rows) and self.p <= PRIMAL_MAX_P)
+                                           and 2 * self.p <= int(min_train_rows) and self.p <= self.opt.primal_max_p)
         if self.spectral:
             # alpha = 0 / a biting singcutoff: the reference's truncated SVD, reproduced from the eigendecomposition of
             # the n x n Gram blocks (dual form for every shape; see check_penalties and _spectral_operators)
             logger.info("penalty grid outside the Cholesky route (alpha = 0 or singcutoff not negligible): spectral route")
             self.primal = False
-        self.moments = self.primal and self.p <= PRIMAL_MOMENTS_MAX_P and bool(use_corr)
         self.PP = ops.pad_to(self.p, LC_NB)            # primal: padded system size
         # a handful of features + correlation scoring: the whole nested CV from block products X'Y (_prepare_moments)
-        self.moments = False                           # set below, once the form is known
+        self.moments = self.primal and self.p <= self.opt.primal_moments_max_p and bool(use_corr)
         # ---- the targets: resident already, or arriving from the host panel by panel on a background thread (started
         # FIRST: everything below -- the design, its Gram matrix, the first fold's operators -- runs beside it)
         self.uploader = None
         self.upload_panels = [(0, self.V_rank)]
+        self.download_panels = [(0, self.V_rank)]      # ranges the end of the fit works in when the weights go to the host
         jobs = []
         if isinstance(X_all, _DeviceShapes):
             self.dX = self._resident(X_all, self.p_pad)
@@ -282,6 +300,7 @@ class RidgeCVEngine:
             ops.zero_cols(self.dY_full, self.V_rank, self.Vp_rank)
             if self.V_rank and self.Ttot:
                 self.upload_panels = [(int(a), int(b)) for a, b in (panels or [(0, self.V_rank)])]
+                self.download_panels = list(self.upload_panels)
                 self._y_job0 = len(jobs)
                 jobs += [(Y_all, self.dY_full, a, b) for a, b in self.upload_panels]
         if jobs:
@@ -299,7 +318,7 @@ class RidgeCVEngine:
         # makes the coefficients a function of alpha alone).
         self.ser = [a for a in range(self.A) if not self.primal       # primal: every alpha is a tiny p x p factorisation
                     and not self.spectral                             # spectral: every alpha from the eigenpairs
-                    and self.normalpha and series.residual_bound(self.alphas[a], SERIES_TERMS) <= SERIES_TOL]
+                    and self.normalpha and series.residual_bound(self.alphas[a], SERIES_TERMS) <= self.opt.series_tol]
         self.cho = [a for a in range(self.A) if a not in self.ser]
         self.d_ser = ops.upload(np.asarray(self.ser, dtype=np.int32), self.dev) if self.ser else None
         self.coef_host = (np.stack([series.minimax_inverse_coefficients(self.alphas[a], SERIES_TERMS)
@@ -311,6 +330,7 @@ class RidgeCVEngine:
         self.comm = _aux_stream(self.dev, 2)            # per-fold result exchange + global statistics
         self.aux3 = _aux_stream(self.dev, 3)            # voxel shards: what a fold's refit still needs after refit_ahead
         self.dl = _aux_stream(self.dev, 4)              # finished weight panels on their way to the host
+        self.scales_stream = _aux_stream(self.dev, 5)   # column scales of target panels as they arrive (_target_scales)
         # voxel shards: this rank's block is columns [lo[rank], lo[rank + 1]) of V_total; the statistics tail (BH-FDR
         # ranks ALL p-values) runs on the gathered vectors, on the device, on every rank; the driver sets alpha_fdr
         self.V_total = int(V_total) if V_total is not None else self.V_rank
@@ -382,28 +402,39 @@ class RidgeCVEngine:
         self.cur = st["rg"]
         return st
 
-    def _wait_targets(self, rg):
-        """Host inputs: the upload panels that cover the range have been issued (host) and the current stream waits for
-        their copies (device)."""
+    def _wait_targets(self, rg, stream=None):
+        """Host inputs: the upload panels that cover the range have been issued (host) and the given (default: current)
+        stream waits for their copies (device)."""
         if self.uploader is None:
             return
         for b, (c0, c1) in enumerate(self.upload_panels):
             if c0 < rg.c0 + rg.V and rg.c0 < c1:
-                self.uploader.wait(self._y_job0 + b)
+                self.uploader.wait(self._y_job0 + b, stream)
 
-    def plan_steps(self, n_folds, single_alpha=False):
-        """The (fold, range) steps of the fit in execution order.  Folds are processed full width, except: while the
-        targets arrive from the host the first fold works panel by panel (a panel's sweeps start when ITS columns are
-        resident), and when the weights go back to the host the last fold does (a panel's weights leave while the
-        next panel's are computed).  ``single_alpha`` needs the scores of all voxels before any refit: full width."""
+    def plan_steps(self, n_folds, single_alpha=False, ahead=False):
+        """The (fold, range) steps of the fit in execution order.  Folds are processed full width, except:
+          * while the targets arrive from the host the first fold works panel by panel (a panel's sweeps start when ITS
+            columns are resident);
+          * when the weights go back to the host (0.98 GB at cfg2: ~18 ms of PCIe) the END of the fit runs panel by
+            panel, so that a panel's finished weights leave while the next panel is computed: the last TWO folds
+            voxel-major -- (n-2, panel), (n-1, panel), next panel -- when every fold's operators exist ahead of the
+            choices (``ahead``: the panels then finish spread over two folds of work, which hides the transfer behind
+            a few wide panels), else the last fold alone.
+        ``single_alpha`` needs the scores of all voxels before any refit: full width throughout."""
         full = [(0, self.V_rank)]
-        cut = self.upload_panels if (len(self.upload_panels) > 1 and not single_alpha) else full
+        paneled = len(self.upload_panels) > 1 and not single_alpha
+        up = self.upload_panels if paneled else full
+        down = self.download_panels if (paneled and self._host_weights is not None) else full
+        tail = 2 if (ahead and n_folds >= 3 and len(down) > 1) else 1
         plan = []
-        for f in range(n_folds):
-            first = f == 0 and self.uploader is not None
-            last = f == n_folds - 1 and self._host_weights is not None
-            for c0, c1 in (cut if (first or last) else full):
-                plan.append((f, (c0, c1)))
+        for f in range(n_folds - (tail if len(down) > 1 else 0)):
+            for c in (up if (f == 0 and self.uploader is not None) else full):
+                plan.append((f, c))
+        if len(down) > 1:
+            first_tail = n_folds - tail
+            for c in down:
+                for f in range(first_tail, n_folds):
+                    plan.append((f, c))
         return plan
 
     # -------------------------------------------------------------- per-outer-fold data
@@ -455,11 +486,31 @@ class RidgeCVEngine:
             return None, False
         if Y is rg.Y and rg.scales is not None:
             return rg.scales
-        cs, flag = ops.col_scales_f16(Y, self.Ttot, rg.Vp)
-        wide = False
-        if self.precision == "auto" and not (self._decided and Y is rg.Y):
-            self.shard.all_reduce_(flag, "max")
-            wide = bool(int(flag.cpu()[0]))
+        check = self.precision == "auto" and not (self._decided and Y is rg.Y)
+        if check and self.uploader is not None and Y is rg.Y:
+            # targets still arriving from the host: the scales and the flag of a range on a stream of their own, which
+            # waits for the range's upload panels only -- looking at the flag on the main stream would make the host
+            # wait for everything queued there (the previous panel's sweeps), once per panel of the first fold
+            main = torch.cuda.current_stream()
+            side = self.scales_stream
+            self._wait_targets(rg, side)
+            with torch.cuda.stream(side):
+                cs, flag = ops.col_scales_f16(Y, self.Ttot, rg.Vp)
+                self.shard.all_reduce_(flag, "max")
+                flag_h = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                flag_h.copy_(flag, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            cs.record_stream(main)
+            ev.synchronize()
+            main.wait_event(ev)
+            wide = bool(int(flag_h[0]))
+        else:
+            cs, flag = ops.col_scales_f16(Y, self.Ttot, rg.Vp)
+            wide = False
+            if check:
+                self.shard.all_reduce_(flag, "max")
+                wide = bool(int(flag.cpu()[0]))
         if wide:
             if self._assume_split:
                 raise _WideTargets("target dynamic range too wide for the fp16x3 sweep")
@@ -480,7 +531,8 @@ class RidgeCVEngine:
             for f, rows in enumerate(chunk):
                 bits[np.asarray(rows, dtype=np.int64)] |= np.uint32(1 << f)
             member = ops.upload(bits.view(np.int32), self.dev)
-            ops.lambda_max_masked(K, self.Ttot, member, len(chunk), self.steps, out=res[c0:c0 + len(chunk)])
+            ops.lambda_max_masked(K, self.Ttot, member, len(chunk), self.steps, out=res[c0:c0 + len(chunk)],
+                                  use_mfma=self.opt.lanczos_mfma)
         return res
 
     def _check_singcutoff(self, lmax):
@@ -538,9 +590,9 @@ class RidgeCVEngine:
         if mine:
             aug = assemble(mine)
             if inverse:                                 # bottom block = identity, M == N: the explicit inverse
-                info = ops.batch_chol_inverse(aug, len(mine), N, H, slot if direct else None)
+                info = ops.batch_chol_inverse(aug, len(mine), N, H, slot if direct else None, options=self._chol_opt)
             else:
-                info = ops.batch_chol_solve(aug, len(mine), N, M, H, slot if direct else None)
+                info = ops.batch_chol_solve(aug, len(mine), N, M, H, slot if direct else None, options=self._chol_opt)
             del aug
         else:
             info = ops.zeros(1, torch.int32, self.dev)
@@ -578,8 +630,8 @@ class RidgeCVEngine:
         enter a prediction scaled by rho^2 <= 2.7e-4 relative to term 0 and only need fp16 operands) inside the
         256-row tiles, so that the two waves of a SIMD together issue 32 instead of 48 MFMAs per K-tile.
         Returns (rows, rowmap (terms*M,) int32 device, slab_light uint8 device)."""
-        key = ("series_layout", M, SERIES_FUSED_MOMENTS)
-        if getattr(self, "_layout_key", None) != key and SERIES_FUSED_MOMENTS and SERIES_TERMS == 4:
+        key = ("series_layout", M, self.opt.series_fused_moments)
+        if getattr(self, "_layout_key", None) != key and self.opt.series_fused_moments and SERIES_TERMS == 4:
             # the moments epilogue (lc_series_sweep_scores_f16x3): every 256-row tile holds all four terms of two
             # 32-row validation blocks -- wave row 0: [T0 b0, T0 b1, T1 b0, T1 b1], wave row 1: the same of T2, T3
             nblk = M // LC_MB
@@ -667,7 +719,7 @@ class RidgeCVEngine:
         moments = bool(moments and ser and min(n_v) > 1)
         Ac = len(cho)
         per_sys = (N + M) * N * 8
-        chunk = max(1, min(F, AUG_BUDGET_BYTES // max(1, per_sys * max(Ac, 1))))
+        chunk = max(1, min(F, MAX_INNER_FOLDS, self.opt.aug_budget_bytes // max(1, per_sys * max(Ac, 1))))
         infos, Hs = [], []
         for f0 in range(0, F, chunk):
             fc = min(chunk, F - f0)
@@ -753,6 +805,15 @@ class RidgeCVEngine:
         contraction of the shared series terms and the moment kernel for the alphas on the series.  ``done``: event
         after which the hat matrices are complete; the series part only waits for ``hat["series_ready"]`` and
         runs first, so the main stream has work while the auxiliary stream is still in the Cholesky chains."""
+        if hat.get("no_inner"):
+            # no inner fold of this outer fold has validation rows: the reference scores every alpha 0 for every voxel
+            # (z_score of an empty block -> NaN -> nan_to_num, ridge_regression.py:124-133) and its first-maximum
+            # argmax takes alphas[0]
+            scores = ops.zeros((self.A, self.Vp), torch.float32, self.dev)
+            self.info.update(precision="f16x3" if hat["split"] else "f32", fused_alphas=0, series_terms=0)
+            self.sweeps_done = torch.cuda.Event()
+            self.sweeps_done.record()
+            return scores
         if self.primal:
             return self._sweeps_primal(hat, Y, done)
         A, N, M, tr, va, n_v = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"]
@@ -801,7 +862,7 @@ class RidgeCVEngine:
             # all inner folds in ONE launch per pass (stacked A images, one shared target image with a gap per fold):
             # the folds are independent, and one launch fills the chip where F small ones each end in a partial round
             # of workgroups -- at 10 000 voxels per rank (8 GPUs) a fold's launch is 1.25 rounds
-            merged = fused and shared is not None and F <= 64 and FOLDS_IN_ONE_LAUNCH
+            merged = fused and shared is not None and F <= 64 and self.opt.folds_in_one_launch
             nst = F if merged else 1
             tp = ops.pad_to(Tm, 256)
             Pt = torch.empty(nst * tp * N * 2, dtype=torch.float16, device=self.dev)
@@ -1050,9 +1111,9 @@ class RidgeCVEngine:
         # (voxel shards: every rank applies every inverse it needs itself -- the same products on every rank -- while
         # the row-sliced solves shrink with the ranks: measured per simulated rank 81.8 vs 84.2 ms at 2, 53.6 vs 53.8
         # at 4, 40.2 vs 39.0 ms at 8 ranks; so the solves from 8 ranks on)
-        return (REFIT_BY_INVERSE and self.normalpha and not self.primal and not self.spectral and self.precision != "f32"
-                and self.shard.world <= REFIT_INVERSE_MAX_WORLD
-                and len(alphas_idx) > 0 and min(self.alphas[a] for a in alphas_idx) >= REFIT_INVERSE_MIN_ALPHA)
+        return (self.opt.refit_by_inverse and self.normalpha and not self.primal and not self.spectral and self.precision != "f32"
+                and self.shard.world <= self.opt.refit_inverse_max_world
+                and len(alphas_idx) > 0 and min(self.alphas[a] for a in alphas_idx) >= self.opt.refit_inverse_min_alpha)
 
     def _identity_rows(self, N_o):
         """(N_o, N_o) f64 identity, cached.  It is made on whichever stream asks first and read from others later: the
@@ -1186,7 +1247,7 @@ class RidgeCVEngine:
         n_o = len(tr_rows)
         N_o = ops.pad_to(n_o, LC_NB)
         n_x = len(extra_rows)
-        from_image = (split and image is not None and REFIT_FROM_IMAGE and n_o % K_TILE == 0
+        from_image = (split and image is not None and self.opt.refit_from_image and n_o % K_TILE == 0
                       and len(image[1]) == n_o and np.array_equal(np.asarray(image[1]), np.asarray(tr_rows)))
         if from_image:
             rows_x = ops.idx_tensor(np.asarray(extra_rows, dtype=np.int64), n_x, self.dev)
@@ -1299,15 +1360,20 @@ class RidgeCVEngine:
                          for a, b in inner_rel]
             # an inner fold WITHOUT validation rows scores NaN -> 0 for every alpha in the reference (z_score of an
             # empty block, nan_to_num: ridge_regression.py:124-133) and so adds nothing to the sum the alpha is chosen
-            # from: dropped here, same result.  With no validation rows in ANY inner fold the reference silently takes
-            # alphas[0] for every voxel (the trimmed fold types in train/test mode, where nested_cv.py:130-132 passes
-            # ``groups`` as the trim size, can do that) -- refused here instead.
-            if any(len(v) == 0 for _, v in inner_abs) and any(len(v) > 0 for _, v in inner_abs):
+            # from: dropped here, same result.  With no validation rows in ANY inner fold every alpha scores 0 for every
+            # voxel and the reference's first-maximum argmax takes alphas[0] (the trimmed fold types in train/test mode,
+            # where nested_cv.py:130-132 passes ``groups`` as the trim size, can do that): the fold then has no inner
+            # CV at all -- zero scores, same choice (_sweeps).
+            if not inner_abs or min(len(t) for t, _ in inner_abs) < 1:
+                raise ValueError("every inner fold needs at least one training row")
+            if any(len(v) == 0 for _, v in inner_abs):
                 logger.warning("inner folds without validation rows contribute nothing to the alpha choice: skipped")
                 inner_abs = [(t, v) for t, v in inner_abs if len(v) > 0]
-            if not inner_abs or min(len(t) for t, _ in inner_abs) < 1 or min(len(v) for _, v in inner_abs) < 1:
-                raise ValueError("every inner fold needs at least one training and one validation row (the reference "
-                                 "would score every alpha 0 and take alphas[0] for all voxels)")
+            if not inner_abs:
+                if self.primal:
+                    raise _PrimalUnsuitable("an outer fold without validation rows in any inner fold")
+                metas.append(dict(tr=tr_rows, te=te_rows, inner_abs=[], N=0, M=0, no_inner=True))
+                continue
             N = ops.pad_to(max(len(t) for t, _ in inner_abs), LC_NB)
             M = ops.pad_to(max(len(v) for _, v in inner_abs), LC_MB)
             metas.append(dict(tr=tr_rows, te=te_rows, inner_abs=inner_abs, N=N, M=M))
@@ -1321,8 +1387,9 @@ class RidgeCVEngine:
             per_fold = (m["N"] + m["M"]) * m["N"] * 8 * max(len(self.cho), 1) * len(m["inner_abs"])
             if self.moments:
                 per_fold = 0                           # p x p systems only
-            if (g is not None and batchable and (metas[g[0]]["N"], metas[g[0]]["M"]) == (m["N"], m["M"])
-                    and per_fold * (len(g) + 1) <= AUG_BUDGET_BYTES and self._lmax_adjacent(lmax_pre, g[-1], i)
+            if (g is not None and batchable and not m.get("no_inner") and not metas[g[0]].get("no_inner")
+                    and (metas[g[0]]["N"], metas[g[0]]["M"]) == (m["N"], m["M"])
+                    and per_fold * (len(g) + 1) <= self.opt.aug_budget_bytes and self._lmax_adjacent(lmax_pre, g[-1], i)
                     and sum(len(metas[k]["inner_abs"]) for k in g) + len(m["inner_abs"]) <= MAX_INNER_FOLDS):
                 g.append(i)
             else:
@@ -1342,7 +1409,9 @@ class RidgeCVEngine:
                     self._prepare_primal(g, metas, X, split, data_ready, out, main)
                     continue
                 if self.normalpha:
-                    if lmax_pre[g[0]] is None:
+                    if lmax_pre[g[0]] is None and metas[g[0]].get("no_inner"):
+                        lmax_i, lmax_os = None, [None]
+                    elif lmax_pre[g[0]] is None:
                         m = metas[g[0]]
                         lm = self.lmax_systems(K, [t for t, _ in m["inner_abs"]] + [m["tr"]])
                         self._check_singcutoff(lm)
@@ -1353,8 +1422,21 @@ class RidgeCVEngine:
                 inner_all = [ia for i in g for ia in metas[i]["inner_abs"]]
                 tr_os = [ops.idx_tensor(metas[i]["tr"], ops.pad_to(len(metas[i]["tr"]), LC_NB), self.dev).reshape(1, -1)
                          for i in g]
+                if self.normalpha and lmax_os[0] is None:      # (a fold without inner CV and no precomputed values)
+                    lmax_os = [ops.lambda_max(K, tr_os[0], 1, tr_os[0].shape[-1], self.steps)]
                 ids_ready = torch.cuda.Event()         # what the refit systems need (row lists, lmax) exists from here on
                 ids_ready.record()
+                if metas[g[0]].get("no_inner"):
+                    i, m = g[0], metas[g[0]]
+                    done = torch.cuda.Event()
+                    hat = dict(no_inner=True, info=ops.zeros(1, torch.int32, self.dev), split=split, data_ready=data_ready)
+                    out[i] = dict(tr=m["tr"], te=m["te"], X=X, K=K, split=split, hat=hat, done=done, tr_o=tr_os[0],
+                                  lmax_o=lmax_os[0], ids_ready=ids_ready)
+                    done.record()
+                    for t in (X, K, tr_os[0], lmax_os[0], hat["info"]):
+                        if t is not None and t.is_cuda:
+                            t.record_stream(main)
+                    continue
                 hat = self._hat_matrices(K, inner_all, lmax_i, self._series_by_moments(split), chol_after=chol_after)
                 hat.update(split=split, data_ready=data_ready)
                 done = torch.cuda.Event()
@@ -1437,7 +1519,7 @@ class RidgeCVEngine:
                 t.record_stream(main)                      # allocated on aux, consumed on main
 
     def _prepare_moments(self, g, metas, X, data_ready, out, main):
-        """prepare_folds for a group of outer folds when p <= PRIMAL_MOMENTS_MAX_P and the scores are correlations
+        """prepare_folds for a group of outer folds when p <= FitOptions.primal_moments_max_p and the scores are correlations
         (csrc/lc_primal.hip): every statistic of a prediction X w is a p-dimensional form in w = (G + a^2 I)^-1 Rstim'y,
         so all the V-wide work of a fold is ONE pass over the targets that forms X'y per row set (_sweeps_moments) --
         here, on the auxiliary stream, only the p x p side: per row set the column sums / second moments of the
@@ -1524,7 +1606,7 @@ class RidgeCVEngine:
             return
         d = torch.sqrt(G_o.diagonal()[: self.p]).cpu().numpy()
         d = d[d > 0]
-        if d.size and float(d.max() / d.min()) > PRIMAL_MAX_SCALE_RATIO:
+        if d.size and float(d.max() / d.min()) > self.opt.primal_max_scale_ratio:
             raise _PrimalUnsuitable(f"feature column norms span a factor {float(d.max() / d.min()):.3g}")
 
     def _sweeps_primal(self, hat, Y, done=None):
@@ -1796,6 +1878,14 @@ class RidgeCVEngine:
         main stream BEFORE waiting for it in fold_select (the stream then never idles through the host round trip)."""
         self._enter(st)
         st["best"] = self.choose(st["scores"], single_alpha)
+        if self.opt.alpha_progress_log and logger.isEnabledFor(logging.INFO):
+            # ridge_regression.py:136-139 logs "Alpha=..., mean corr=..." per alpha and inner fold; here the scores exist
+            # as the sum over the inner folds, so one line per alpha and outer fold (a device round trip: opt-in)
+            _, rowsum = ops.select_alpha(st["scores"], self.A, self.Vp, want_best=False, want_rowsum=True)
+            nf = max(1, int(st["hat"].get("F", 1)))
+            for a_, tot in zip(self.alphas, rowsum.cpu().tolist()):
+                logger.info("Alpha=%.3f, mean corr=%.5f (mean over %d inner folds and %d voxels)", a_,
+                            tot / (nf * max(self.V, 1)), nf, self.V)
         if not self.moments:                           # the moments form refits voxel by voxel: no grouping by alpha
             st["grouping"] = self._group_async(st["best"], st["split"])
         return st
@@ -2038,7 +2128,8 @@ class NestedCVModel(BasePredictivityModel):
     rank's block of voxel columns and gather the per-voxel results across ranks."""
 
     def __init__(self, model_name: str, shard: Optional[ShardContext] = None, precision: str = "auto",
-                 form: str = "auto", panel_cols: Optional[int] = None, local_targets: bool = False):
+                 form: str = "auto", panel_cols: Optional[int] = None, local_targets: bool = False,
+                 options: Optional[FitOptions] = None):
         """``precision``: arithmetic of the V-wide alpha sweep -- "f32" (f32-input MFMA), "f16x3" (fp16
         hi/lo operands, three fp16 MFMAs per product, fp32 accumulate; fp32-level accuracy, ~3x faster) or
         "auto" (f16x3 unless the targets' dynamic range is too wide for it; see RidgeCVEngine._target_scales).
@@ -2046,13 +2137,14 @@ class NestedCVModel(BasePredictivityModel):
         smallest inner training set; see RidgeCVEngine).
         ``panel_cols``: width (a multiple of 256 voxel columns) of the panels a host-to-host fit moves its targets
         and weights in -- the first fold starts on a panel while the others are still crossing PCIe, the last fold's
-        weights leave panel by panel (None: PANEL_COLS for fits of >= 2 PANEL_MIN_COLS voxels; 0: no panels).  The
+        weights leave panel by panel (None: FitOptions.panel_cols for fits of >= 2 x panel_min_cols voxels; 0: no panels).  The
         results do not depend on it, bit for bit.
         ``local_targets`` (voxel shards): ``targets`` / ``y_test`` hold only this rank's block of voxel columns (the
         blocks of ShardContext.bounds, in rank order) instead of all of them -- a rank then never touches the other
         ranks' 1.7 GB of host memory."""
         super().__init__(model_name)
         self.local_targets = bool(local_targets)
+        self.options = options                         # FitOptions of this model's fits (None: the defaults)
         self.shard = shard
         self.precision = precision
         self.form = form
@@ -2086,7 +2178,7 @@ class NestedCVModel(BasePredictivityModel):
             alphas = np.logspace(-1, 8, 10)
         check_penalties(alphas, singcutoff, normalpha, n_inner_folds)
         if not use_gpu:
-            logger.info("use_gpu=False ignored: this implementation runs on the MI355X only")
+            logger.warning("use_gpu=False ignored: this implementation has no CPU path, the fit runs on the MI355X")
         features, targets = np.asarray(features), np.asarray(targets)   # lists / nested lists, like torch.tensor(...)
         if X_test is not None and y_test is not None:
             X_test, y_test = np.asarray(X_test), np.asarray(y_test)
@@ -2181,13 +2273,15 @@ class NestedCVModel(BasePredictivityModel):
         panels = None
         if not isinstance(Y_all, _DeviceShapes):
             # the same NUMBER of panels on every rank of a sharded fit (narrowest rank decides)
+            o = self.options or FitOptions()
             panels = [(0, V_rank)] if self.panel_cols == 0 else _column_panels(
-                V_rank, self.panel_cols, None if self.panel_cols is None else 256, v_ref=V_total // max(shard.world, 1))
+                V_rank, o.panel_cols if self.panel_cols is None else self.panel_cols,
+                o.panel_min_cols if self.panel_cols is None else 256, v_ref=V_total // max(shard.world, 1))
 
         def attempt(form, precision, X_in, Y_in):
             eng = RidgeCVEngine(X_in, Y_in, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
                                 precision=precision, singcutoff=singcutoff, V_total=V_total,
-                                min_train_rows=min_train, form=form, panels=panels)
+                                min_train_rows=min_train, form=form, panels=panels, options=self.options)
             self._engine = eng
             scale = 1.0 if train_test else 1.0 / len(outer)
             fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
@@ -2218,11 +2312,6 @@ class NestedCVModel(BasePredictivityModel):
             lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
             # the (fold, voxel range) steps in execution order: folds full width, the first / last one panel by panel
             # while the targets arrive from / the weights leave for the host
-            plan = eng.plan_steps(n, single_alpha)
-            self._plan = sorted({c for _, c in plan})
-            # V-independent part of every fold, ahead of everything on the auxiliary stream: fold 0 by itself (its sweeps
-            # start as soon as its own systems are done), then ALL other folds as one batch
-            first = eng.prepare_folds(outer[:1], lmax_pre[:1])[0]
             # host inputs: the targets need ~30 ms to cross PCIe, and until they are there the chip has little V-wide
             # work -- so EVERYTHING that does not depend on a voxel is queued now and runs in that window, nothing gated:
             # the hat matrices of all folds (aux) and the refit operators of every fold for every factorised alpha (aux2,
@@ -2230,6 +2319,11 @@ class NestedCVModel(BasePredictivityModel):
             # find the chip to themselves (fp64 chains beside the MFMA sweeps cost a resident fit ~20 of 137 ms)
             hosted = getattr(eng, "uploader", None) is not None and shard.world == 1
             ahead = shard.world > 1 or (hosted and eng.refit_ahead_pays())
+            plan = eng.plan_steps(n, single_alpha, ahead=hosted and ahead)
+            self._plan = sorted({c for _, c in plan})
+            # V-independent part of every fold, ahead of everything on the auxiliary stream: fold 0 by itself (its sweeps
+            # start as soon as its own systems are done), then ALL other folds as one batch
+            first = eng.prepare_folds(outer[:1], lmax_pre[:1])[0]
             if shard.world > 1 or hosted:
                 # voxel shards: a rank's V-wide work per fold is a few ms, the same order as one latency chain of its
                 # share of a fold's systems -- so the folds are prepared one by one (all queued now, nothing gated), each
@@ -2240,10 +2334,13 @@ class NestedCVModel(BasePredictivityModel):
                 # of 8 -- the rank is bound by its total work, not by the batching)
                 if ahead:
                     eng.refit_ahead([first])
+                if hosted:      # the first panel is there within a few ms: its sweeps are queued before the big batch is
+                    st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
                 prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else [])
                 if ahead:
                     eng.refit_ahead(prepared[1:])
-                st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
+                if not hosted:
+                    st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
             else:
                 # one GPU, resident targets: the batch's series operands now, its Cholesky chains once fold 0's sweeps
                 # (just queued) are done -- same fit time, and fold 0's fused launches, the dominant kernel, run without 80
@@ -2252,7 +2349,7 @@ class NestedCVModel(BasePredictivityModel):
                 # 145.8-147.6 ms: the fit is bound by the total work of the streams, not by which batch the main stream
                 # waits for; all refit inverses ahead in one batch, as with voxel shards, costs 4 ms here: work for
                 # alphas nobody chooses, beside the fused launches)
-                if SPECULATE_FIRST_FOLD and getattr(eng, "cho", None):
+                if getattr(eng, "cho", None) and eng.opt.speculate_first_fold:
                     eng.fold_speculate(first, list(eng.cho), early=True)      # aux2: fold 0's refit systems, all of them
                 st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
                 prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:], chol_after=eng.chain_gate())
@@ -2260,8 +2357,10 @@ class NestedCVModel(BasePredictivityModel):
             # the weights leave panel by panel during the last fold (0.98 GB at cfg2: ~18 ms of PCIe): its first panel is
             # taken through refit BEFORE the next panel's sweeps are queued (no look-ahead at that step and at the one
             # before it), so that the link starts at the head of the fold and the rest of the fold hides the transfer
-            early_out = hosted and weights_on_host and n > 1 and sum(1 for f_, _ in plan if f_ == n - 1) > 1
             first_last = next((k for k, (f_, _) in enumerate(plan) if f_ == n - 1), None)
+            interleaved = any(f_ < n - 1 for f_, _ in plan[first_last:])           # last two folds voxel-major: spread anyway
+            early_out = (hosted and weights_on_host and n > 1 and not interleaved
+                         and sum(1 for f_, _ in plan if f_ == n - 1) > 1)
             for k, (f, _) in enumerate(plan):
                 eng.fold_choose(st, single_alpha)               # main: argmax + grouping; the histogram leaves asynchronously
                 look = k + 1 < len(plan) and not (early_out and k in (first_last - 1, first_last))

@@ -73,8 +73,9 @@ def idx_matrix(row_sets, length, dev, fill=-1):
 
 import threading
 
-_STAGE = {"buf": None, "off": 0, "lock": threading.Lock()}
+_STAGE = {"buf": None, "off": 0, "lock": threading.Lock(), "events": None}
 _STAGE_BYTES = 32 << 20
+_STAGE_SEGMENTS = 8                 # the ring is recycled segment by segment
 
 
 def upload(arr, dev):
@@ -83,25 +84,39 @@ def upload(arr, dev):
     stalls the host behind all the work already queued.)  The pinned bytes come from ONE staging ring of the process,
     bump-allocated: ``tensor.pin_memory()`` takes a block from torch's caching host allocator, which cannot reuse a
     block whose last copy is still queued behind a busy GPU and then calls hipHostMalloc -- measured: an 11 ms host
-    stall in the middle of a fit while five 19 KB index lists were uploaded."""
+    stall in the middle of a fit while five 19 KB index lists were uploaded.  The ring is recycled in segments: before a
+    segment is written again the copies issued from it on the previous lap are waited for, one event each (round 2
+    synchronised the whole DEVICE at every wrap: a hidden stall in a long-lived process)."""
     a = np.ascontiguousarray(arr)
     if dev.type != "cuda":
         return torch.from_numpy(a).to(dev)
     n = a.nbytes
-    if n == 0 or n > _STAGE_BYTES // 4:
+    seg_bytes = _STAGE_BYTES // _STAGE_SEGMENTS
+    if n == 0 or n > seg_bytes:
         return torch.from_numpy(a).pin_memory().to(dev, non_blocking=True)
+    out = torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype if a.size else torch.float32, device=dev)
     with _STAGE["lock"]:                            # the ring is the process's: fits in several threads share it
         if _STAGE["buf"] is None:
             _STAGE["buf"] = torch.empty(_STAGE_BYTES, dtype=torch.uint8, pin_memory=True)
+            _STAGE["events"] = [[] for _ in range(_STAGE_SEGMENTS)]
         off = (_STAGE["off"] + 255) & ~255
-        if off + n > _STAGE_BYTES:                  # wrapped: everything staged so far must have left the ring
-            torch.cuda.synchronize()
+        if off >= _STAGE_BYTES:
             off = 0
+        seg = off // seg_bytes
+        if off + n > (seg + 1) * seg_bytes:         # does not fit the rest of the segment: on to the next one
+            seg = (seg + 1) % _STAGE_SEGMENTS
+            off = seg * seg_bytes
+        if off == seg * seg_bytes:                  # entering the segment: its copies of the previous lap must be done
+            for ev in _STAGE["events"][seg]:
+                ev.synchronize()
+            _STAGE["events"][seg] = []
         _STAGE["off"] = off + n
-    stage = _STAGE["buf"][off:off + n]
-    stage.numpy()[:] = a.reshape(-1).view(np.uint8)
-    out = torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype if a.size else torch.float32, device=dev)
-    out.view(torch.uint8).reshape(-1).copy_(stage, non_blocking=True)
+        stage = _STAGE["buf"][off:off + n]
+        stage.numpy()[:] = a.reshape(-1).view(np.uint8)
+        out.view(torch.uint8).reshape(-1).copy_(stage, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _STAGE["events"][seg].append(ev)
     return out
 
 
@@ -419,12 +434,13 @@ def lambda_max(k, rows, F, N, steps):
     return out
 
 
-def lambda_max_masked(k, T, member, F, steps, out=None):
+def lambda_max_masked(k, T, member, F, steps, out=None, use_mfma=True):
     """lambda_max of K[I_f, I_f] for F <= 32 row sets given as bit f of member[i] (int32 tensor of T words)."""
     work = torch.empty(F * (3 * T + 2 * steps + 8) + 16 * 32 * T, dtype=torch.float64, device=k.device)
     if out is None:
         out = torch.empty(F, dtype=torch.float64, device=k.device)
-    _lib.call("lc_lambda_max_masked", _p(k), k.stride(0), T, _p(member), F, steps, _p(work), _p(out), _s())
+    _lib.call("lc_lambda_max_masked_opt", _p(k), k.stride(0), T, _p(member), F, steps, _p(work), _p(out),
+              int(bool(use_mfma)), _s())
     return out
 
 
@@ -536,26 +552,30 @@ def masked_stream(mask_words):
     return torch.cuda.ExternalStream(out.value, device=device())
 
 
-def chol_outer_block(columns=0):
-    """Columns per outer block of batch_chol_solve's two-level blocking (0 = query)."""
-    rc = _lib.load().lc_chol_outer_block(int(columns))
-    if rc < 0:
-        _lib.check(rc, "lc_chol_outer_block")
-    return rc
+class CholOptions(ctypes.Structure):
+    """lc_chol_options of include/litcoder_hip.h: per-call variants of the batched Cholesky (defaults: 512, 2, 1, 0)."""
+    _fields_ = [("outer_block", ctypes.c_int), ("big_kernel", ctypes.c_int), ("fused_steps", ctypes.c_int),
+                ("left_deep", ctypes.c_int)]
 
 
-def batch_chol_solve(aug, B, N, M, h, slot=None):
+def chol_options(outer_block=512, big_kernel=2, fused_steps=True, left_deep=False):
+    return CholOptions(int(outer_block), int(big_kernel), int(bool(fused_steps)), int(bool(left_deep)))
+
+
+def batch_chol_solve(aug, B, N, M, h, slot=None, options=None):
     linv = torch.empty((B, N // LC_NB, LC_NB, LC_NB), dtype=torch.float64, device=aug.device)
     info = torch.empty(B, dtype=torch.int32, device=aug.device)
-    _lib.call("lc_batch_chol_solve", _p(aug), B, N, M, _p(linv), _p(h), _p(slot), _p(info), _s())
+    _lib.call("lc_batch_chol_solve_opt", _p(aug), B, N, M, _p(linv), _p(h), _p(slot), _p(info),
+              ctypes.byref(options) if options is not None else None, _s())
     return info
 
 
-def batch_chol_inverse(aug, B, N, p, slot=None):
+def batch_chol_inverse(aug, B, N, p, slot=None, options=None):
     """aug: (B, 2N, N) f64 systems with the identity as bottom block; p (B, N, N) f32 <- inverse of the top blocks."""
     linv = torch.empty((B, N // LC_NB, LC_NB, LC_NB), dtype=torch.float64, device=aug.device)
     info = torch.empty(B, dtype=torch.int32, device=aug.device)
-    _lib.call("lc_batch_chol_inverse", _p(aug), B, N, _p(linv), _p(p), _p(slot), _p(info), _s())
+    _lib.call("lc_batch_chol_inverse_opt", _p(aug), B, N, _p(linv), _p(p), _p(slot), _p(info),
+              ctypes.byref(options) if options is not None else None, _s())
     return info
 
 

@@ -32,7 +32,7 @@ class OracleEngine:
     exchanges through the same ShardContext."""
     primal = False
     def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard, precision="auto", singcutoff=0.0, V_total=None,
-                 min_train_rows=None, form="dual", panels=None):
+                 min_train_rows=None, form="dual", panels=None, options=None):
         Y = np.concatenate([b for _, b in Y.blocks], axis=0)              # ops.HostRows: the targets' row blocks
         self.X, self.Y = torch.tensor(np.asarray(X), dtype=torch.float32), torch.tensor(np.asarray(Y), dtype=torch.float32)
         self.alphas, self.normalpha, self.use_corr, self.shard = list(alphas), normalpha, use_corr, shard
@@ -48,7 +48,7 @@ class OracleEngine:
         return [None] * len(outer)
     def prepare_folds(self, folds, lmax_pre, chol_after=None):
         return [dict(tr=np.asarray(tr), te=np.asarray(te), inner=inner) for tr, te, inner in folds]
-    def plan_steps(self, n_folds, single_alpha=False):
+    def plan_steps(self, n_folds, single_alpha=False, ahead=False):
         return [(f, (0, self.V)) for f in range(n_folds)]
     def fold_begin(self, tr, te, inner, prepared=None, lmax_pre=None, step=None):
         return prepared

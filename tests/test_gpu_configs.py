@@ -137,14 +137,56 @@ def test_cfg3_story_pipeline_train_test(lc):
                           cols=np.arange(48))
 
 
+def test_cfg1_full_size_properties(lc):
+    """BASELINE cfg1 at its full shape -- train_simple.py's word-rate model: one feature x 4 FIR delays (p = 4), T = 9000
+    training + 600 test TRs, V = 80 000 voxels, train/test mode, 10 alphas: the block-product form (csrc/lc_primal.hip).
+    Size-independent properties: everything finite, constant voxel -> (r 0, p 1, alpha[0]), a planted noiseless voxel
+    recovered with its weights, a 10 000-voxel block fitted alone equals its slice bit for bit, host-to-host call in
+    panels equals the resident fit bit for bit; the first 256 voxels against the oracle (ties proven)."""
+    import oracle.nested_cv as onc
+    V, T, Tt = 80000, 9000, 600
+    dX, dY, p = _device_problem(lc, T + Tt, 1, [1, 2, 3, 4], V, seed=9, wscale=0.15)
+    assert p == 4
+    dY[:, 77] = 0.5
+    wtrue = torch.tensor([0.3, -0.2, 0.1, 0.05], device=dY.device)
+    dY[:, 4242] = dX[:, :p] @ wtrue
+    alphas = np.logspace(-1, 8, 10)
+    kw = dict(folding_type="chunked_contiguous", n_inner_folds=5, chunk_length=20, alphas=alphas)
+    model = lc.NestedCVModel("r")
+    m, W, a = model.fit_predict_device(dX, dY, p, V, n_test_rows=Tt, weights_on_host=True, **kw)
+    assert model.last_form == "primal"
+    r = np.asarray(m["correlations"])
+    assert r.shape == (V,) and np.isfinite(r).all() and np.isfinite(W).all() and W.shape == (4, V)
+    assert r[77] == 0.0 and m["p_values"][77] == 1.0 and a[77] == np.float32(alphas[0])
+    assert r[4242] > 0.999 and np.allclose(W[:, 4242], wtrue.cpu().numpy(), atol=6e-3)
+    assert abs(m["median_score"] - float(np.median(r))) < 1e-6 and m["median_score"] > 0.05
+    lo, hi = 30000, 40000
+    blk = torch.zeros((T + Tt, 10112), dtype=torch.float32, device=dY.device)
+    blk[:, : hi - lo] = dY[:, lo:hi]
+    m_b, W_b, a_b = lc.NestedCVModel("r").fit_predict_device(dX, blk, p, hi - lo, n_test_rows=Tt, weights_on_host=True, **kw)
+    assert np.array_equal(np.asarray(m_b["correlations"]), r[lo:hi]) and np.array_equal(a_b, a[lo:hi])
+    assert np.array_equal(W_b, W[:, lo:hi])
+    # the reference's own call: float64 host arrays in, host weights out (moved in voxel panels)
+    X = dX[:, :p].cpu().numpy().astype(np.float64)
+    Y = dY[:, :V].cpu().numpy().astype(np.float64)
+    m_h, W_h, a_h = lc.NestedCVModel("r").fit_predict(X[:T], Y[:T], X_test=X[T:], y_test=Y[T:], **kw)
+    assert np.array_equal(np.asarray(m_h["correlations"]), r) and np.array_equal(a_h, a) and np.array_equal(W_h, W)
+    nv = 256
+    detail = {}
+    oracle = onc.fit_predict(X[:T], Y[:T, :nv], X_test=X[T:], y_test=Y[T:, :nv], detail=detail, **kw)
+    assert_matches_oracle(lc, model, (m, W[:, :nv], a), oracle, detail, X[:T], Y[:T], kw, "cfg1", corr_atol=1e-4,
+                          w_rtol=1e-3, w_atol=1e-4, X_test=X[T:], y_test=Y[T:], cols=np.arange(nv), min_same=0.95)
+
+
 def test_cfg4_narratives_shape_full_volume(lc):
     """Narratives-like: T = 2226, p = 3072, V = 200 000 voxels on one GPU (the 8-GPU job's whole volume): finite
     everywhere; a 25 000-voxel shard fitted alone equals its slice bit for bit, and so does a column-permuted copy
-    (which other voxels share a launch never matters); the first 48 voxels against the oracle (3 x 3 K-folds)."""
+    (which other voxels share a launch never matters); the first 256 voxels against the oracle, 5 x 5 K-folds as the
+    config implies (the oracle's cost is its 30 V-independent SVDs, not the voxels)."""
     import oracle.nested_cv as onc
     V, T = 200000, 2226
     alphas = np.logspace(-1, 8, 20)
-    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=alphas)
+    kw = dict(folding_type="kfold", n_outer_folds=5, n_inner_folds=5, alphas=alphas)
     dX, dY, p = _device_problem(lc, T, 768, [1, 2, 3, 4], V, seed=4)
     model = lc.NestedCVModel("r")
     m, W, a = model.fit_predict_device(dX, dY, p, V, weights_on_host=False, **kw)
@@ -163,18 +205,19 @@ def test_cfg4_narratives_shape_full_volume(lc):
     ph = perm.cpu().numpy()
     assert np.array_equal(np.asarray(m_p["correlations"]), r[lo:hi][ph]) and np.array_equal(a_p, a[lo:hi][ph])
     assert torch.equal(W_p, W[:, lo:hi][:, perm])
-    X, Y = dX[:, :p].cpu().numpy().astype(np.float64), dY[:, :48].cpu().numpy().astype(np.float64)
+    nv = 256
+    X, Y = dX[:, :p].cpu().numpy().astype(np.float64), dY[:, :nv].cpu().numpy().astype(np.float64)
     detail = {}
     oracle = onc.fit_predict(X, Y, detail=detail, **kw)
-    assert_matches_oracle(lc, model, (m, W[:, :48].cpu().numpy(), a), oracle, detail, X, Y, kw, "cfg4", corr_atol=1e-4,
-                          w_rtol=1e-3, w_atol=1e-4, cols=np.arange(48))
-    assert abs(np.median(r[:48]) - np.median(oracle[0]["correlations"])) < 1e-3
+    assert_matches_oracle(lc, model, (m, W[:, :nv].cpu().numpy(), a), oracle, detail, X, Y, kw, "cfg4", corr_atol=1e-4,
+                          w_rtol=1e-3, w_atol=1e-4, cols=np.arange(nv), min_same=0.95)
+    assert abs(np.median(r[:nv]) - np.median(oracle[0]["correlations"])) < 1e-3
 
 
 def test_cfg5_whisper_shape_banded(lc):
     """Whisper-like: 1280-d speech features x 6 FIR delays = 7680 columns (p > n), 32 alphas logspace(-1, 8), two feature
     bands with penalty scales (1, 2) (BandedNestedCVModel: ridge on the rescaled design), T = 3000,
-    V = 2048: against the oracle run on the rescaled design, 48 voxels, 3 x 3 K-folds."""
+    V = 2048: against the oracle run on the rescaled design, 256 voxels, 5 x 5 K-folds."""
     import oracle.fir as ofir
     import oracle.nested_cv as onc
     rng = np.random.default_rng(23)
@@ -184,16 +227,17 @@ def test_cfg5_whisper_shape_banded(lc):
     gamma = np.r_[np.full(3840, 1.0), np.full(3840, 2.0)]
     Y = (X / gamma) @ (0.015 * rng.standard_normal((7680, V))) + rng.standard_normal((T, V))
     alphas = np.logspace(-1, 8, 32)
-    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=alphas)
+    kw = dict(folding_type="kfold", n_outer_folds=5, n_inner_folds=5, alphas=alphas)
     model = lc.BandedNestedCVModel("r")
     m, W, a = model.fit_predict(X, Y, bands=[(0, 3840), (3840, 7680)], band_scales=[1.0, 2.0], **kw)
     assert W.shape == (7680, V) and np.isfinite(W).all() and np.isfinite(np.asarray(m["correlations"])).all()
     detail = {}
     Xs = X / gamma
-    m_o, W_o, a_o = onc.fit_predict(Xs, Y[:, :48], detail=detail, **kw)
+    nv = 256
+    m_o, W_o, a_o = onc.fit_predict(Xs, Y[:, :nv], detail=detail, **kw)
     # weights come back on the ORIGINAL feature scale: w_b = w'_b / gamma_b
     assert_matches_oracle(lc, model, (m, W * gamma[:, None].astype(np.float32), a), (m_o, W_o, a_o), detail, Xs, Y, kw,
-                          "cfg5", corr_atol=1e-4, w_rtol=1e-3, w_atol=1e-4, cols=np.arange(48))
+                          "cfg5", corr_atol=1e-4, w_rtol=1e-3, w_atol=1e-4, cols=np.arange(nv), min_same=0.95)
     assert m["median_score"] > 0.2
 
 
@@ -235,18 +279,13 @@ def test_primal_form_for_tall_designs(lc):
             detail = {}
             random.seed(11)
             oracle = onc.fit_predict(*args, detail=detail, **extra, **kw_run)
-            moments = p <= ncv.PRIMAL_MOMENTS_MAX_P and not r2
+            moments = p <= ncv.FitOptions().primal_moments_max_p and not r2
             for precision, gemm in (("auto", False), ("f32", False)) + ((("auto", True),) if moments else ()):
                 tag = f"p={p} tt={tt} {precision} gemm={gemm}"
-                model = lc.NestedCVModel("r", precision=precision)
+                model = lc.NestedCVModel("r", precision=precision,
+                                         options=ncv.FitOptions(primal_moments_max_p=0) if gemm else None)
                 random.seed(11)
-                keep = ncv.PRIMAL_MOMENTS_MAX_P
-                try:
-                    if gemm:
-                        ncv.PRIMAL_MOMENTS_MAX_P = 0
-                    ours = model.fit_predict(*args, **extra, **kw_run)
-                finally:
-                    ncv.PRIMAL_MOMENTS_MAX_P = keep
+                ours = model.fit_predict(*args, **extra, **kw_run)
                 assert model.last_form == "primal", tag
                 assert (model.last_fit["precision"] == "f64 block products") == (moments and not gemm), tag
                 assert_matches_oracle(lc, model, ours, oracle, detail, args[0], args[1], kw_run, tag, min_same=0.97, **tol,
@@ -265,19 +304,15 @@ def test_primal_form_for_tall_designs(lc):
     X[:, 3] *= 2.0 ** -12
     Y = X @ rng.standard_normal((6, 50)) + rng.standard_normal((2000, 50))
     kw = dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=[0.1, 1.0])
-    keep = ncv.PRIMAL_MOMENTS_MAX_P
-    try:
-        ncv.PRIMAL_MOMENTS_MAX_P = 0                                       # the V-wide primal contraction (fp16 operands)
-        model = lc.NestedCVModel("r")
-        ours = model.fit_predict(X, Y, **kw)
-        assert model.last_form == "dual"
-        with pytest.raises(ValueError, match="form='primal' is not usable"):
-            lc.NestedCVModel("r", form="primal").fit_predict(X, Y, **kw)
-        model32 = lc.NestedCVModel("r", precision="f32")                   # exact-fp32 arithmetic: primal is fine
-        ours32 = model32.fit_predict(X, Y, **kw)
-        assert model32.last_form == "primal"
-    finally:
-        ncv.PRIMAL_MOMENTS_MAX_P = keep
+    gemm_only = ncv.FitOptions(primal_moments_max_p=0)                     # the V-wide primal contraction (fp16 operands)
+    model = lc.NestedCVModel("r", options=gemm_only)
+    ours = model.fit_predict(X, Y, **kw)
+    assert model.last_form == "dual"
+    with pytest.raises(ValueError, match="form='primal' is not usable"):
+        lc.NestedCVModel("r", form="primal", options=gemm_only).fit_predict(X, Y, **kw)
+    model32 = lc.NestedCVModel("r", precision="f32", options=gemm_only)    # exact-fp32 arithmetic: primal is fine
+    ours32 = model32.fit_predict(X, Y, **kw)
+    assert model32.last_form == "primal"
     np.testing.assert_allclose(np.asarray(ours32[0]["correlations"]), np.asarray(ours[0]["correlations"]), atol=3e-5)
     model64 = lc.NestedCVModel("r")                                        # fp64 block products: any feature scales
     ours64 = model64.fit_predict(X, Y, **kw)
@@ -359,8 +394,8 @@ def test_block_product_form_degenerate_voxels(lc):
 
 def test_inner_fold_without_validation_rows_is_skipped(lc):
     """The reference scores every alpha NaN -> 0 on an empty validation block (ridge_regression.py:124-133), which adds
-    nothing to the sum the alpha is chosen from: the engine drops such a fold -- identical scores -- and refuses the
-    case where no inner fold has validation rows (the reference would take alphas[0] everywhere)."""
+    nothing to the sum the alpha is chosen from: the engine drops such a fold -- identical scores; when NO inner fold has
+    validation rows the reference takes alphas[0] for every voxel, and so does the engine."""
     from litcoder_core_amd.nested_cv import RidgeCVEngine
     rng = np.random.default_rng(9)
     T, p, V = 260, 30, 70
@@ -377,10 +412,39 @@ def test_inner_fold_without_validation_rows_is_skipped(lc):
         st = eng.fold_begin(tr, te, inner)
         scores.append(st["scores"][:, :V].cpu().numpy())
     assert np.array_equal(scores[0], scores[1]) and np.array_equal(scores[0], scores[2])
+    # no validation rows in ANY inner fold: every alpha scores 0, the first-maximum argmax takes alphas[0] for every
+    # voxel (ridge_regression.py:124-133, nested_cv.py:405-411) -- a whole fit equals the oracle's, which follows the
+    # reference there
     eng = RidgeCVEngine(X, Y, alphas, True, True, False, False)
     eng.begin_fit(1)
-    with pytest.raises(ValueError, match="at least one training and one validation row"):
-        eng.fold_begin(tr, te, [empty])
+    st = eng.fold_begin(tr, te, [empty])
+    assert not st["scores"][:, :V].any()
+    import oracle.nested_cv as onc
+    import litcoder_core_amd.folding as folding
+    real = folding.create_folds
+
+    def all_empty(n, kind, k, *a, **kw_):                      # every inner split: all rows train, none validate
+        out = real(n, kind, k, *a, **kw_)
+        return [(np.arange(n), np.arange(0)) for _ in out] if n == 200 else out
+
+    import oracle.folds as ofolds
+    real_o = ofolds.create_folds
+    kw = dict(folding_type="kfold", n_inner_folds=3, alphas=alphas)
+    try:
+        folding.create_folds = all_empty
+        ofolds.create_folds = all_empty
+        import litcoder_core_amd.nested_cv as ncv
+        keep = ncv.create_folds
+        ncv.create_folds = all_empty
+        m, W, a = lc.NestedCVModel("r").fit_predict(X[:200], Y[:200], X_test=X[200:], y_test=Y[200:], **kw)
+        m_o, W_o, a_o = onc.fit_predict(X[:200], Y[:200], X_test=X[200:], y_test=Y[200:], **kw)
+    finally:
+        folding.create_folds = real
+        ofolds.create_folds = real_o
+        ncv.create_folds = keep
+    assert np.all(a == np.float32(alphas[0])) and np.array_equal(a, a_o)
+    np.testing.assert_allclose(np.asarray(m["correlations"]), np.asarray(m_o["correlations"]), atol=3e-5)
+    np.testing.assert_allclose(W, W_o, rtol=2e-4, atol=3e-6)
 
 
 def test_sweeps_are_bit_reproducible_beside_a_coresident_workgroup(lc):

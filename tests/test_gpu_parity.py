@@ -286,7 +286,7 @@ def test_constant_and_degenerate_voxels(lc):
     with pytest.raises(ValueError):
         lc.NestedCVModel("r").fit_predict(X, Y, folding_type="nope")
     with pytest.raises(ValueError):
-        lc.NestedCVModel("r").fit_predict(X, Y, folding_type="kfold", alphas=[0.0, 1.0])
+        lc.NestedCVModel("r").fit_predict(X, Y, folding_type="kfold", alphas=[-1.0, 1.0])
     with pytest.raises(RuntimeError):
         lc.NestedCVModel("r").fit_predict(X, Y[:100], folding_type="kfold")
 
@@ -348,11 +348,9 @@ def test_batch_chol_solve_against_fp64_solves(lc):
     from litcoder_core_amd import ops
     dev = ops.device()
     rng = np.random.default_rng(11)
-    default = ops.chol_outer_block()
-    try:
+    if True:                                     # (the blocking variants are per-call options: no state to restore)
         for (B, N, M, ob) in ((3, 64, 32, 256), (2, 192, 96, 128), (2, 448, 160, 256), (2, 576, 416, 256),
                               (1, 832, 1056, 512), (2, 320, 64, 64)):
-            assert ops.chol_outer_block(ob) == ob
             aug = np.empty((B, N + M, N))
             for b in range(B):
                 x = rng.standard_normal((N, N + 8))
@@ -360,7 +358,7 @@ def test_batch_chol_solve_against_fp64_solves(lc):
                 aug[b, N:] = rng.standard_normal((M, N))
             d_aug = torch.from_numpy(aug).to(dev)
             h = torch.empty((B, M, N), dtype=torch.float32, device=dev)
-            info = ops.batch_chol_solve(d_aug, B, N, M, h)
+            info = ops.batch_chol_solve(d_aug, B, N, M, h, options=ops.chol_options(outer_block=ob))
             assert not info.cpu().numpy().any()
             got = h.cpu().numpy().astype(np.float64)
             for b in range(B):
@@ -369,14 +367,13 @@ def test_batch_chol_solve_against_fp64_solves(lc):
                 assert err < 3e-7, (B, N, M, ob, b, err)
         # the explicit inverse: identity below, only the block-upper triangle formed (rows skipped per step), mirrored
         for (B, N, ob) in ((2, 64, 256), (3, 320, 128), (2, 576, 256), (1, 1216, 512), (2, 832, 64)):
-            assert ops.chol_outer_block(ob) == ob
             aug = np.empty((B, 2 * N, N))
             for b in range(B):
                 x = rng.standard_normal((N, N + 8))
                 aug[b, :N] = x @ x.T / N + np.eye(N) * 10.0 ** (-b)
                 aug[b, N:] = np.eye(N)
             P = torch.empty((B, N, N), dtype=torch.float32, device=dev)
-            info = ops.batch_chol_inverse(torch.from_numpy(aug).to(dev), B, N, P)
+            info = ops.batch_chol_inverse(torch.from_numpy(aug).to(dev), B, N, P, options=ops.chol_options(outer_block=ob))
             assert not info.cpu().numpy().any()
             got = P.cpu().numpy().astype(np.float64)
             for b in range(B):
@@ -396,8 +393,20 @@ def test_batch_chol_solve_against_fp64_solves(lc):
             info = ops.batch_chol_solve(torch.from_numpy(bad).to(dev), 2, 192, 32,
                                         torch.empty((2, 32, 192), dtype=torch.float32, device=dev))
             assert info.cpu().numpy()[0] == 0 and info.cpu().numpy()[1] != 0, blk
-    finally:
-        ops.chol_outer_block(default)
+        # the first version's step kernels and the vector-ALU deep updates stay selectable, per call
+        B, N, M = 2, 448, 160
+        aug = np.empty((B, N + M, N))
+        for b in range(B):
+            x = rng.standard_normal((N, N + 8))
+            aug[b, :N] = x @ x.T / N + np.eye(N)
+            aug[b, N:] = rng.standard_normal((M, N))
+        outs = []
+        for opt in (None, ops.chol_options(fused_steps=False), ops.chol_options(big_kernel=1), ops.chol_options(left_deep=True)):
+            h = torch.empty((B, M, N), dtype=torch.float32, device=dev)
+            assert not ops.batch_chol_solve(torch.from_numpy(aug).to(dev), B, N, M, h, options=opt).cpu().numpy().any()
+            outs.append(h.cpu().numpy())
+        for o_ in outs[1:]:
+            np.testing.assert_allclose(o_, outs[0], rtol=0, atol=1e-6 * np.abs(outs[0]).max())
 
 
 def test_series_moments_match_per_alpha_hat_matrices(lc):
@@ -415,13 +424,13 @@ def test_series_moments_match_per_alpha_hat_matrices(lc):
         eng = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
         assert eng.ser and eng.cho, "grid must straddle the series threshold"
         import litcoder_core_amd.nested_cv as ncv
-        assert ncv.SERIES_FUSED_MOMENTS                    # default: the terms are reduced in the contraction's epilogue
+        assert eng.opt.series_fused_moments                # default: the terms are reduced in the contraction's epilogue
         s_mom, info = eng._alpha_scores(eng.K, eng.dY, inner)
         try:                                                # the same with the terms stored and lc_series_scores
-            ncv.SERIES_FUSED_MOMENTS = False
+            eng.opt.series_fused_moments = False          # this engine's own options: nothing process-wide
             s_sto, _ = eng._alpha_scores(eng.K, eng.dY, inner)
         finally:
-            ncv.SERIES_FUSED_MOMENTS = True
+            eng.opt.series_fused_moments = True
         np.testing.assert_array_equal(s_mom[eng.cho].cpu().numpy(), s_sto[eng.cho].cpu().numpy())
         np.testing.assert_allclose(s_mom[eng.ser, :V].cpu().numpy(), s_sto[eng.ser, :V].cpu().numpy(), rtol=0, atol=2e-6)
         eng._series_by_moments = lambda Y_: False
@@ -451,12 +460,12 @@ def test_shared_target_image_is_bitwise_neutral(lc):
     # all inner folds in one launch per pass (lc_*_f16x3_folds: stacked A images, a gap per fold, fold-parallel
     # finalisation): the same tiles, the same fp32 fold sums -- bit for bit
     import litcoder_core_amd.nested_cv as ncv
-    keep = ncv.FOLDS_IN_ONE_LAUNCH
+    keep = eng.opt.folds_in_one_launch
     try:
-        ncv.FOLDS_IN_ONE_LAUNCH = not keep
+        eng.opt.folds_in_one_launch = not keep
         s_other, _ = eng._alpha_scores(eng.K, eng.dY, inner)
     finally:
-        ncv.FOLDS_IN_ONE_LAUNCH = keep
+        eng.opt.folds_in_one_launch = keep
     assert torch.equal(s_shared, s_other)
     eng._shared_image = lambda *a: None
     s_plain, _ = eng._alpha_scores(eng.K, eng.dY, inner)
@@ -528,10 +537,10 @@ def test_refit_operators_by_inverse_match_the_solves(lc):
     rhs = eng._refit_rhs(eng.dX, eng.K, tr, tr_o, te)
     M_inv, info = eng._refit_chol(eng.K, tr_o, lmax_o, rhs, [1, 2, 3, 4])
     try:
-        ncv.REFIT_BY_INVERSE = False
+        eng.opt.refit_by_inverse = False                    # this engine's own options
         M_sol, info2 = eng._refit_chol(eng.K, tr_o, lmax_o, rhs, [1, 2, 3, 4])
     finally:
-        ncv.REFIT_BY_INVERSE = True
+        eng.opt.refit_by_inverse = True
     assert not info.cpu().numpy().any() and not info2.cpu().numpy().any()
     a, b = M_inv.cpu().numpy().astype(np.float64), M_sol.cpu().numpy().astype(np.float64)
     for i, al in enumerate(alphas[1:]):
@@ -539,11 +548,7 @@ def test_refit_operators_by_inverse_match_the_solves(lc):
         assert err < 2.0 ** -21 / al + 1e-6, (al, err)       # + the floor of a depth-N product of 22-bit operands
     kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=alphas[1:], normalpha=True)
     got = lc.NestedCVModel("r").fit_predict(X, Y, **kw)
-    try:
-        ncv.REFIT_BY_INVERSE = False
-        ref = lc.NestedCVModel("r").fit_predict(X, Y, **kw)
-    finally:
-        ncv.REFIT_BY_INVERSE = True
+    ref = lc.NestedCVModel("r", options=ncv.FitOptions(refit_by_inverse=False)).fit_predict(X, Y, **kw)
     assert np.array_equal(got[2], ref[2])
     np.testing.assert_allclose(got[0]["correlations"], ref[0]["correlations"], atol=3e-6)
     np.testing.assert_allclose(got[1], ref[1], rtol=2e-5, atol=2e-5 * float(np.abs(ref[1]).max()))
@@ -845,16 +850,39 @@ def test_refit_operand_from_the_inner_cv_image_is_bitwise_neutral(lc):
     X2, Y2 = _synthetic(640, 96, 1300, 32)                    # 5 x 128: aligned K-folds -> one shared image per outer fold
     for (Xc, Yc, kw) in ((X2, Y2, dict(folding_type="kfold", n_outer_folds=5, n_inner_folds=4, alphas=np.logspace(-1, 5, 8))),
                          (X, Y, dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=np.logspace(-1, 5, 8)))):
-        assert ncv.REFIT_FROM_IMAGE
+        assert ncv.FitOptions().refit_from_image
         got = lc.NestedCVModel("r", precision="f16x3").fit_predict(Xc, Yc, **kw)
-        try:
-            ncv.REFIT_FROM_IMAGE = False
-            ref = lc.NestedCVModel("r", precision="f16x3").fit_predict(Xc, Yc, **kw)
-        finally:
-            ncv.REFIT_FROM_IMAGE = True
+        ref = lc.NestedCVModel("r", precision="f16x3", options=ncv.FitOptions(refit_from_image=False)).fit_predict(Xc, Yc, **kw)
         for k in ref[0]:
             assert np.array_equal(np.asarray(got[0][k]), np.asarray(ref[0][k]), equal_nan=True), k
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+
+
+def test_many_inner_folds_and_per_fit_options(lc):
+    """The reference puts no limit on the number of inner folds (nested_cv.py:366): more than 64 are taken in chunks of
+    the batched operators -- against the oracle.  And the policy switches belong to a fit (FitOptions), not to the
+    process: fits with different options interleaved in one process do not see each other's."""
+    import oracle.nested_cv as onc
+    from litcoder_core_amd import nested_cv as ncv
+    from _oracle_check import assert_matches_oracle
+    X, Y = _synthetic(300, 40, 200, 41)
+    kw = dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=70, alphas=np.logspace(-1, 4, 6))
+    model = lc.NestedCVModel("r")
+    ours = model.fit_predict(X, Y, **kw)
+    detail = {}
+    oracle = onc.fit_predict(X, Y, detail=detail, **kw)
+    assert_matches_oracle(lc, model, ours, oracle, detail, X, Y, kw, "70 inner folds", corr_atol=5e-5, w_rtol=5e-4, w_atol=1e-5)
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 5, 8))
+    a_opts, b_opts = ncv.FitOptions(), ncv.FitOptions(refit_by_inverse=False, series_fused_moments=False, refit_from_image=False,
+                                                      chol_outer_block=128, lanczos_mfma=False)
+    ma, mb = lc.NestedCVModel("r", options=a_opts), lc.NestedCVModel("r", options=b_opts)
+    ra1, rb1, ra2, rb2 = (m.fit_predict(X, Y, **kw) for m in (ma, mb, ma, mb))
+    for (x, y) in ((ra1, ra2), (rb1, rb2)):
+        assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+        assert np.array_equal(np.asarray(x[0]["correlations"]), np.asarray(y[0]["correlations"]))
+    assert np.array_equal(ra1[2], rb1[2])                                  # same alphas, results equal to rounding
+    np.testing.assert_allclose(ra1[1], rb1[1], rtol=2e-5, atol=2e-5 * float(np.abs(rb1[1]).max()))
+    assert a_opts.refit_by_inverse and not b_opts.refit_by_inverse        # the callers' objects are never written to
 
 
 def test_voxel_panels_are_bitwise_neutral(lc):

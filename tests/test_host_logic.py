@@ -60,8 +60,8 @@ def test_penalty_grid_validation_and_route():
         model.fit_predict(X, Y, alphas=[1.0], singcutoff=-1.0, folding_type="kfold")
     with pytest.raises(ValueError, match="at most 64 alphas"):
         model.fit_predict(X, Y, alphas=np.logspace(-1, 8, 65), folding_type="kfold")
-    with pytest.raises(ValueError, match="at most 64 inner folds"):
-        model.fit_predict(X, Y, alphas=[1.0], n_inner_folds=65, folding_type="kfold")
+    with pytest.raises(ValueError, match="n_inner_folds must be >= 1"):
+        model.fit_predict(X, Y, alphas=[1.0], n_inner_folds=0, folding_type="kfold")
     with pytest.raises(ValueError):
         check_penalties([], 1e-10, True)
 

@@ -18,23 +18,20 @@ for (B, N, M, label) in ((3, 1920, 480, "inner, one rank of 8"), (20, 1920, 480,
     fl = B * (N ** 3 / 3 + 2.0 * N * N * M)
     out = {}
     for fused in (0, 1, 2):                     # 0 = round 1, 1 = fused steps + right-looking deep updates, 2 = + left-looking deep
-        lib.lc_debug_chol_fused_steps(1 if fused else 0)
-        lib.lc_debug_chol_left_deep(1 if fused == 2 else 0)
+        copt = ops.chol_options(fused_steps=bool(fused), left_deep=fused == 2)
         aug = base.clone()
         H = torch.empty((B, M, N), dtype=torch.float32, device=dev)
-        ops.batch_chol_solve(aug, B, N, M, H)
+        ops.batch_chol_solve(aug, B, N, M, H, options=copt)
         torch.cuda.synchronize()
         ts = []
         for _ in range(4):
             aug.copy_(base)
             torch.cuda.synchronize()
             t = time.perf_counter()
-            info = ops.batch_chol_solve(aug, B, N, M, H)
+            info = ops.batch_chol_solve(aug, B, N, M, H, options=copt)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t)
         out[fused] = (min(ts), H.clone(), int(info.abs().max()))
-    lib.lc_debug_chol_fused_steps(1)
-    lib.lc_debug_chol_left_deep(0)
     ref = torch.linalg.solve(base[:1, :N].transpose(1, 2), base[:1, N:].transpose(1, 2)).transpose(1, 2)   # H A = G, A symmetric
     err_new = float((out[2][1][:1].double() - ref).abs().max() / ref.abs().max())
     diff = float((out[0][1].double() - out[2][1].double()).abs().max() / out[0][1].double().abs().max())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""cfg2 fit time with a module switch of litcoder_core_amd.nested_cv on / off, interleaved on one box.
-    python tools/flag_ab.py FLAG [V [world rank]]      e.g. FOLDS_IN_ONE_LAUNCH, REFIT_BY_INVERSE, SERIES_FUSED_MOMENTS
+"""cfg2 fit time with a boolean FitOptions field on / off, interleaved on one box.
+    python tools/flag_ab.py FIELD [V [world rank]]      e.g. folds_in_one_launch, refit_by_inverse, series_fused_moments
 (world > 1: one rank of a simulated sharded job, ShardContext.simulated)"""
 import os
 import sys
@@ -22,16 +22,13 @@ lo, hi = shard_bounds(V_total, world, rank)
 V = hi - lo
 dX, dY, p = bench.synth_inputs(V, rank, dev)
 alphas = np.logspace(-1, 8, bench.A)
-model = NestedCVModel("ridge_regression", shard=ShardContext.simulated(world, rank, device=dev, global_lists=False)
-                      if world > 1 else None)
-fit = lambda: model.fit_predict_device(dX, dY, p, V, n_voxels_total=V_total, alphas=alphas, **bench.FIT_KW)  # noqa: E731
-keep = getattr(ncv, flag)
+shard = ShardContext.simulated(world, rank, device=dev, global_lists=False) if world > 1 else None
 for setting in (True, False, True, False):
-    setattr(ncv, flag, setting)
+    model = NestedCVModel("ridge_regression", shard=shard, options=ncv.FitOptions(**{flag: setting}))
+    fit = lambda: model.fit_predict_device(dX, dY, p, V, n_voxels_total=V_total, alphas=alphas, **bench.FIT_KW)  # noqa: E731
     fit(); fit(); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(6):
         fit()
     torch.cuda.synchronize()
     print(f"{flag}={setting}: {1e3 * (time.perf_counter() - t) / 6:.1f} ms per fit", flush=True)
-setattr(ncv, flag, keep)

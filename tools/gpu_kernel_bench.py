@@ -218,11 +218,8 @@ if "lanczos" in what:
     ref = np.array([np.linalg.eigvalsh(Kh[np.ix_(r_, r_)])[-1] for r_ in sets[:6]])
     print(f"lambda_max_masked 30 systems T=3000 steps=64 (fp64 MFMA matvec): {ms:.2f} ms; max rel err vs eigvalsh "
           f"(first 6): {np.max(np.abs(got[:6] / ref - 1)):.2e}")
-    from litcoder_core_amd import _lib
-    _lib.load().lc_debug_lanczos_mfma(0)
-    ms0 = timeit(lambda: ops.lambda_max_masked(K3, T3, member, len(sets), 64), reps=3, warm=1)
-    got0 = ops.lambda_max_masked(K3, T3, member, len(sets), 64).cpu().numpy()
-    _lib.load().lc_debug_lanczos_mfma(1)
+    ms0 = timeit(lambda: ops.lambda_max_masked(K3, T3, member, len(sets), 64, use_mfma=False), reps=3, warm=1)
+    got0 = ops.lambda_max_masked(K3, T3, member, len(sets), 64, use_mfma=False).cpu().numpy()
     print(f"   vector-ALU matvec (round 1): {ms0:.2f} ms; max rel difference of the 30 values: "
           f"{np.max(np.abs(got / got0 - 1)):.2e}")
 
@@ -251,23 +248,19 @@ if "chol" in what:
         aug2[:, :N_] = torch.eye(N_, dtype=torch.float64, device=dev) * (4.0 * N_) + aug2[:, :N_] * 0.0 + 1.0
         H2 = torch.empty((B_, M_, N_), dtype=torch.float32, device=dev)
         base = aug2.clone()
+        copt = [None]
         def run2():
             aug2.copy_(base)
-            ops.batch_chol_solve(aug2, B_, N_, M_, H2)
+            ops.batch_chol_solve(aug2, B_, N_, M_, H2, options=copt[0])
         fl2 = B_ * (N_ ** 3 / 3 + 2.0 * N_ * N_ * M_)
-        default_ob = ops.chol_outer_block()
-        from litcoder_core_amd import _lib
         for valu, ob in ((2, 256), (2, 512), (1, 256), (1, 512), (0, 256)):
-            _lib.load().lc_debug_chol_big_kernel(valu)
-            ops.chol_outer_block(ob)
+            copt[0] = ops.chol_options(outer_block=ob, big_kernel=valu)
             ops.timing_enable(True); ops.timing_read()
             ms2 = timeit(run2, reps=3, warm=1)
             kt = ops.timing_read(); ops.timing_enable(False)
             chol_ms = kt.get("batch_chol_solve", (0, 1))
             print(f"batch_chol_solve {label} B={B_} N={N_} M={M_} outer block {ob} deep updates on {('MFMA 16x16x4', 'VALU', 'MFMA 4x4x4')[valu]}: {chol_ms[0] / chol_ms[1]:.2f} ms -> "
                   f"{fl2 / (chol_ms[0] / chol_ms[1]) / 1e9:.1f} TFLOP/s fp64")
-        ops.chol_outer_block(default_ob)
-        _lib.load().lc_debug_chol_big_kernel(2)
     a64 = torch.randn((4096, 4096), dtype=torch.float64, device=dev)
     b64 = torch.randn((4096, 4096), dtype=torch.float64, device=dev)
     ms = timeit(lambda: torch.matmul(a64, b64), reps=5, warm=2)

@@ -50,22 +50,34 @@ def wrap_dev(name, label):
 
 for n, lab in (("_sweeps", "MAIN sweeps"), ("fold_finish", "MAIN refit + statistics"), ("fold_choose", "MAIN choose + group")):
     wrap_dev(n, lab)
-for n in ("__init__", "begin_fit", "precompute_lmax", "prepare_folds", "fold_begin", "fold_choose", "fold_select", "fold_speculate",
+for n in ("begin_fit", "precompute_lmax", "prepare_folds", "fold_begin", "fold_choose", "fold_select", "fold_speculate",
           "fold_finish", "fold_collect", "_wait_targets", "_range_finished", "combined_significance", "weights"):
     wrap_host(ncv.RidgeCVEngine, n)
 
-real_close = ops.PanelUploader._close
+import threading
+real_init = ncv.RidgeCVEngine.__init__
+watch_stream = torch.cuda.Stream()
 
 
-def close(self, j, futs):
-    real_close(self, j, futs)
-    e = torch.cuda.Event(enable_timing=True)
-    e.record(self.stream)
-    dev_marks.append((f"UPLOAD job {j} cols {self.jobs[j][2]}:{self.jobs[j][3]} landed", e, e))
-    host_log.append((f"upload job {j} staged+issued", time.perf_counter(), time.perf_counter()))
+def init_and_watch(self, *a, **k):
+    real_init(self, *a, **k)
+    up = self.uploader
+    if up is None:
+        return
+
+    def watch():
+        torch.cuda.set_device(0)
+        for j in range(len(up.jobs)):
+            up.wait(j, watch_stream)                       # host: issued; device: watch_stream behind the panel's copies
+            host_log.append((f"upload job {j} staged+issued", time.perf_counter(), time.perf_counter()))
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(watch_stream)
+            dev_marks.append((f"UPLOAD job {j} cols {up.jobs[j][2]}:{up.jobs[j][3]} landed", e, e))
+
+    threading.Thread(target=watch, daemon=True).start()
 
 
-ops.PanelUploader._close = close
+ncv.RidgeCVEngine.__init__ = init_and_watch
 real_dl = ops.download_cols
 
 

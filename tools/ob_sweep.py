@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
-"""cfg2 fit time against the outer-block width of the batched Cholesky (lc_chol_outer_block).  python tools/ob_sweep.py"""
+"""cfg2 fit time against the outer-block width of the batched Cholesky (FitOptions.chol_outer_block).  python tools/ob_sweep.py"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from litcoder_core_amd import NestedCVModel, ops
+from litcoder_core_amd.nested_cv import FitOptions
 dev = ops.device(0)
 dX, dY, p = bench.synth_inputs(80000, 0, dev)
 alphas = np.logspace(-1, 8, bench.A)
-model = NestedCVModel("ridge_regression")
-fit = lambda: model.fit_predict_device(dX, dY, p, 80000, alphas=alphas, **bench.FIT_KW)
 for ob in [int(a) for a in sys.argv[1:]] or [512, 256, 128, 1024, 512]:
-    ops.chol_outer_block(ob)
+    model = NestedCVModel("ridge_regression", options=FitOptions(chol_outer_block=ob))
+    fit = lambda: model.fit_predict_device(dX, dY, p, 80000, alphas=alphas, **bench.FIT_KW)
     fit(); fit(); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(6):
