@@ -176,6 +176,17 @@ int lc_scatter_axpy_f32(const float* d_w, int64_t ld_w, int64_t n_rows, const in
                         int64_t n_cols, float scale, float* d_acc, int64_t ld_acc,
                         lc_stream_t stream);
 
+/* The same mean over folds (nested_cv.py:249,293-296) without a read-modify-write of the accumulator per fold: each
+ * fold keeps its alpha-sorted weight matrix, lc_invert_perm notes where every voxel's column went
+ * (d_pos[d_cols[j]] = base + j for d_cols[j] >= 0), and lc_combine_folds_f32 forms, for one voxel range,
+ *     d_out[r, v] = sum_f scale[f] * w[f][r * ld_w[f] + pos[f][v]]      (folds in order; pos < 0 skipped)
+ * with the same per-term expression as lc_scatter_axpy_f32 (bit-identical to accumulating fold by fold from zero).
+ * w / ld_w / pos / scale are HOST arrays of n_folds entries (device pointers inside). */
+int lc_invert_perm(const int32_t* d_cols, int64_t n_cols, int32_t base, int32_t* d_pos, lc_stream_t stream);
+int lc_combine_folds_f32(const float* const* w, const int64_t* ld_w, const int32_t* const* pos, const float* scale,
+                         int n_folds, int64_t n_rows, int64_t n_cols, float* d_out, int64_t ld_out,
+                         lc_stream_t stream);
+
 /* ---------------------------------------------------------------- column statistics */
 
 /* DataNormalizer.fit (models/ridge_utils.py:94-125): per-column mean and UNBIASED std of

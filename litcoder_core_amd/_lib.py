@@ -38,6 +38,9 @@ SIGNATURES = {
     "lc_cast_f64_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64, _ptr]),
     "lc_gather_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr]),
     "lc_scatter_axpy_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, c_float, _ptr, c_int64, _ptr]),
+    "lc_invert_perm": (c_int, [_ptr, c_int64, c_int32, _ptr, _ptr]),
+    "lc_combine_folds_f32": (c_int, [POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), POINTER(c_float), c_int, c_int64,
+                                     c_int64, _ptr, c_int64, _ptr]),
     "lc_col_mean_std_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_col_normalize_f32": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, c_float, _ptr]),
     "lc_zscore_story_f64": (c_int, [_ptr, c_int64, c_int64, c_int64, c_int, _ptr, c_int64, _ptr]),

@@ -44,6 +44,50 @@ __global__ void __launch_bounds__(256) k_scatter_axpy(const float* __restrict__ 
     }
 }
 
+// Mean of the folds' weights without a read-modify-write per fold: every fold leaves its alpha-SORTED weight matrix where
+// the refit contraction wrote it, k_invert_perm notes where each voxel's column went, and ONE pass per voxel range forms
+//     out[r, v] = sum_f scale_f * w_f[r, pos_f[v]]          (folds in order, the same expression per term as
+// k_scatter_axpy's  acc += scale * w,  starting from 0: bit-identical to the accumulate it replaces)
+// -- per fold one 4-byte gather per element (the sorted neighbours of a group are neighbours in natural order too, so
+// the sectors are shared) instead of a gather, a read and a write of the accumulator.
+constexpr int CF_MAX = 8, CF_ROWS = 4;
+struct CombineArgs {
+    const float* w[CF_MAX];
+    const int* pos[CF_MAX];
+    long long ld[CF_MAX];
+    float scale[CF_MAX];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) k_invert_perm(const int* __restrict__ cols, long long n_cols, int base,
+                                                     int* __restrict__ pos) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cols) return;
+    const int c = cols[j];
+    if (c >= 0) pos[c] = base + (int)j;
+}
+
+__global__ void __launch_bounds__(256) k_combine_folds(const CombineArgs a, long long n_rows, long long n_cols,
+                                                       float* __restrict__ out, long long ld_out, int accumulate) {
+    const long long r0 = (long long)blockIdx.y * CF_ROWS;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n_cols; v += stride) {
+        int p[CF_MAX];
+#pragma unroll
+        for (int f = 0; f < CF_MAX; ++f) p[f] = f < a.n ? a.pos[f][v] : -1;
+#pragma unroll
+        for (int rr = 0; rr < CF_ROWS; ++rr) {
+            const long long r = r0 + rr;
+            if (r >= n_rows) break;
+            float acc = accumulate ? out[r * ld_out + v] : 0.f;
+#pragma unroll
+            for (int f = 0; f < CF_MAX; ++f)
+                if (f < a.n && p[f] >= 0) acc += a.scale[f] * a.w[f][r * a.ld[f] + p[f]];
+            out[r * ld_out + v] = acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ column moments
 // Block = 64 columns (x) by RG row groups (y).  Two passes over the listed rows: mean, then
 // centred second moment, both in fp64; the second pass re-reads a panel that is still in L2.
@@ -405,6 +449,41 @@ extern "C" int lc_scatter_axpy_f32(const float* d_w, int64_t ld_w, int64_t n_row
                            (long long)n_cols, scale, d_acc + r0 * ld_acc, (long long)ld_acc);
     }
     return lc::launched("k_scatter_axpy");
+}
+
+extern "C" int lc_invert_perm(const int32_t* d_cols, int64_t n_cols, int32_t base, int32_t* d_pos, lc_stream_t stream) {
+    LC_REQUIRE(d_cols && d_pos, LC_E_BADARG, "lc_invert_perm: null pointer");
+    LC_REQUIRE(n_cols >= 0 && n_cols < (1ll << 31) && base >= 0, LC_E_SHAPE, "lc_invert_perm: bad shape");
+    if (n_cols == 0) return LC_OK;
+    hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)lc::ceil_div<long long>(n_cols, 256)), dim3(256), 0,
+                       lc::as_stream(stream), d_cols, (long long)n_cols, (int)base, d_pos);
+    return lc::launched("k_invert_perm");
+}
+
+extern "C" int lc_combine_folds_f32(const float* const* w, const int64_t* ld_w, const int32_t* const* pos,
+                                    const float* scale, int n_folds, int64_t n_rows, int64_t n_cols, float* d_out,
+                                    int64_t ld_out, lc_stream_t stream) {
+    LC_REQUIRE(w && ld_w && pos && scale && d_out, LC_E_BADARG, "lc_combine_folds_f32: null pointer");
+    LC_REQUIRE(n_folds > 0 && n_rows >= 0 && n_cols >= 0 && ld_out >= n_cols, LC_E_SHAPE, "lc_combine_folds_f32: bad shape");
+    if (n_rows == 0 || n_cols == 0) return LC_OK;
+    lc::ScopedTimer timer_(lc::T_SCATTER, lc::as_stream(stream));
+    const dim3 grid((unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 256), 4096),
+                    (unsigned)lc::ceil_div<long long>(n_rows, CF_ROWS));
+    LC_REQUIRE(grid.y <= 65535, LC_E_SHAPE, "lc_combine_folds_f32: too many rows");
+    for (int f0 = 0; f0 < n_folds; f0 += CF_MAX) {               // folds in order, CF_MAX per pass
+        CombineArgs a{};
+        a.n = (int)lc::imin(CF_MAX, n_folds - f0);
+        for (int f = 0; f < a.n; ++f) {
+            LC_REQUIRE(w[f0 + f] && pos[f0 + f], LC_E_BADARG, "lc_combine_folds_f32: null fold pointer");
+            a.w[f] = w[f0 + f];
+            a.pos[f] = pos[f0 + f];
+            a.ld[f] = ld_w[f0 + f];
+            a.scale[f] = scale[f0 + f];
+        }
+        hipLaunchKernelGGL(k_combine_folds, grid, dim3(256), 0, lc::as_stream(stream), a, (long long)n_rows, (long long)n_cols,
+                           d_out, (long long)ld_out, f0 > 0 ? 1 : 0);
+    }
+    return lc::launched("k_combine_folds");
 }
 
 extern "C" int lc_col_mean_std_f32(const float* d_x, int64_t ld, const int32_t* d_rows, int64_t n_rows,

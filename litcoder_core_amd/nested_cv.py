@@ -348,6 +348,8 @@ class RidgeCVEngine:
         self._host_weights = None                      # future of the page-locked result buffer (reserve_host_weights)
         self._host_w = None                            # ... the buffer itself once panels are leaving for it
         self._sent = 0                                 # voxel columns of the weights already on their way to the host
+        self._ws = {}                                  # fold -> its alpha-sorted weight matrix + where each voxel went (_ws_slot)
+        self._combined = 0                             # voxel columns whose mean weights are final (_combine_weights)
         self._assume_split = None                      # the arithmetic the operators are prepared for (_split_assumed)
         self._decided = False                          # ... decided from ALL resident target columns (begin_fit)
         # constants of the fit that every stream reads: made here, before ``ready``
@@ -720,7 +722,7 @@ class RidgeCVEngine:
         Ac = len(cho)
         per_sys = (N + M) * N * 8
         chunk = max(1, min(F, MAX_INNER_FOLDS, self.opt.aug_budget_bytes // max(1, per_sys * max(Ac, 1))))
-        infos, Hs = [], []
+        infos, Hs, imgs = [], [], []
         for f0 in range(0, F, chunk):
             fc = min(chunk, F - f0)
             H = torch.empty((fc * A, M, N), dtype=torch.float32, device=self.dev) if not moments else None
@@ -759,6 +761,15 @@ class RidgeCVEngine:
             elif ser:
                 ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], self.d_coef, d_ser, A,
                                      SERIES_TERMS, H)
+            # the fp16 hi/lo images of the operators (the A operands of the V-wide contractions) are V-independent too:
+            # made HERE, once per outer fold, and shared by every voxel range of the fold -- a host-to-host fit works
+            # through the first and the last folds panel by panel, and each panel used to split the same matrices again
+            img = None
+            if moments and P is not None and self._split_assumed():
+                tp = ops.pad_to(P.shape[1], 256)
+                img = dict(tp=tp, Pt=torch.empty(fc * tp * N * 2, dtype=torch.float16, device=self.dev),
+                           rs_p=torch.empty(fc * tp, dtype=torch.float32, device=self.dev), Ht=None, rs_h=None, hp=0)
+                ops.split_rows_f16_groups(P.view(-1, N), fc, P.shape[1], N, img["Pt"], img["rs_p"])
             series_ready = torch.cuda.Event() if self.dev.type == "cuda" else None
             if series_ready is not None:
                 series_ready.record()           # the series operands of this chunk are complete; Cholesky follows
@@ -794,10 +805,16 @@ class RidgeCVEngine:
                 elif Hc is not H:
                     for j in range(fc * Ac):                 # voxel shards: beside the series alphas' hat matrices
                         H[(j // Ac) * A + cho[j % Ac]].copy_(Hc[j])          # (D2D copies)
+            if img is not None and Ac and H is not None:
+                hp = ops.pad_to(Ac * M, 256)
+                img.update(hp=hp, Ht=torch.empty(fc * hp * N * 2, dtype=torch.float16, device=self.dev),
+                           rs_h=torch.empty(fc * hp, dtype=torch.float32, device=self.dev))
+                ops.split_rows_f16_groups(H.view(-1, N), fc, Ac * M, N, img["Ht"], img["rs_h"])
             Hs.append((f0, fc, H, P))
+            imgs.append(img)
         info = self._join_flags(infos)
         return dict(F=F, N=N, M=M, n_v=n_v, n_i=n_i, tr=tr, va=va, shared=self._shared_image(inner_abs, N), Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
-                    d_ser=d_ser, moments=moments, series_ready=series_ready)
+                    d_ser=d_ser, moments=moments, series_ready=series_ready, imgs=imgs)
 
     def _sweeps(self, hat, Y, done=None):
         """Sum over inner folds of the (A, Vp) validation scores (ridge_corr_torch for every fold,
@@ -855,6 +872,9 @@ class RidgeCVEngine:
                 Yt = [torch.empty(Vt * N * 2, dtype=torch.float16, device=self.dev) for _ in range(nbuf)]
                 views = [(0, 0, 0)] * F
         folds = [(f0 + j, j, H, P) for f0, fc, H, P in hat["Hs"] for j in range(fc)]
+        # the operators' fp16 images made with the hat matrices (_hat_matrices), per chunk: fold f0 + j is group j
+        imgs = hat.get("imgs") or [None] * len(hat["Hs"])
+        img_of = {f0 + j: (im, j) for (f0, fc, _, _), im in zip(hat["Hs"], imgs) if im is not None for j in range(fc)}
         if moments:
             # ---- pass 1: validation statistics, operand split, series contraction + moment kernel
             Tm, rowmap, slab_light = self._series_layout(M)
@@ -889,15 +909,20 @@ class RidgeCVEngine:
             for f, j, H, P in (() if merged else folds):
                 if shared is None:
                     ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[f])
-                ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
+                Pt_f, rs_p_f = Pt, rs_p
+                if f in img_of:
+                    im, g = img_of[f]
+                    Pt_f, rs_p_f = im["Pt"][g * im["tp"] * N * 2:], im["rs_p"][g * im["tp"]:]
+                else:
+                    ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
                 self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
                 self.info["plain_launches"] += 1
                 if fused:
-                    ops.series_sweep_scores_f16x3(Pt, rs_p, M, n_v[f], N, Yt[f], cs_inv, Vt, yv[f], self.Vp, ystat[f], yblk[f],
+                    ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], N, Yt[f], cs_inv, Vt, yv[f], self.Vp, ystat[f], yblk[f],
                                                   self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0,
                                                   bview=views[f])
                     continue
-                ops.gemm_grouped_f16x3(Pt, rs_p, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
+                ops.gemm_grouped_f16x3(Pt_f, rs_p_f, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
                                        bview=views[f])
                 ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv[f], ystat[f], self.d_coef, hat["d_ser"],
                                   scores, accumulate=f > 0, rowmap=rowmap)
@@ -925,8 +950,13 @@ class RidgeCVEngine:
                 if Ad:
                     self.info["fused_flops"] += 2.0 * Ad * n_v[f] * hat["n_i"][f] * self.V
                     self.info["fused_launches"] += 1
-                    ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
-                    ops.alpha_sweep_scores_f16x3(Ht, rs_inv, Ad, M, N, Yt[b], cs[self.Vp:], yv[b], self.Vp, n_v[f], ystat[b],
+                    Ht_f, rs_h_f = Ht, rs_inv
+                    if moments and f in img_of and img_of[f][0]["Ht"] is not None:
+                        im, g = img_of[f]
+                        Ht_f, rs_h_f = im["Ht"][g * im["hp"] * N * 2:], im["rs_h"][g * im["hp"]:]
+                    else:
+                        ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
+                    ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, N, Yt[b], cs[self.Vp:], yv[b], self.Vp, n_v[f], ystat[b],
                                                  yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f])
             else:
                 self.info["fused_flops"] += 2.0 * A * n_v[f] * hat["n_i"][f] * self.V
@@ -1272,28 +1302,38 @@ class RidgeCVEngine:
             o.update(cs_s=cs_s, Yt=Yt)
         return o
 
-    def _refit_product(self, o, r0, r1, useful_rows):
+    def _refit_product(self, o, r0, r1, useful_rows, out=None):
         """Rows [r0, r1) of  C = [M_alpha ; H_te,alpha](group) . Ys  as an (r1 - r0, Vs) f32 matrix (fp16x3 path: the
         rows of every group split to fp16 triples, one grouped launch).  The caller takes the test predictions first
-        -- what the host statistics wait for -- and the weight rows afterwards."""
+        -- what the host statistics wait for -- and the weight rows afterwards.  ``out``: a (r1 - r0, Vs) view (any row
+        stride) the product is written to."""
         Malpha, Vs, N_o = o["Malpha"], o["Vs"], o["N_o"]          # one (rows, N_o) operator per alpha group
         G, rows = len(Malpha), r1 - r0
-        C = torch.empty((rows, Vs), dtype=torch.float32, device=self.dev)
+        C = out if out is not None else torch.empty((rows, Vs), dtype=torch.float32, device=self.dev)
         if o["split"]:
             rows_pad = ops.pad_to(rows, 256)
-            At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
-            rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
             Kc = o["K"]                                  # contraction depth: the training rows (the operators' padding
-            for g in range(G):                           # columns beyond them are zero)
-                ops.split_rows_f16(Malpha[g][r0:r1], rows, Kc, At[g * rows_pad * Kc * 2:], rs_inv[g * rows_pad:])
-            ops.gemm_grouped_f16x3(At, rs_inv, rows, o["Yt"], o["cs_s"][1], C, Vs, Vs, Kc, o["tiles"])
+            # columns beyond them are zero).  The operators' images are the same for every voxel range of the fold
+            # whose voxels chose the same alphas: kept in the fold's cache
+            key = (o.get("used"), r0, r1, Kc)
+            cache = o.get("img_cache")
+            if cache is not None and key in cache:
+                At, rs_inv = cache[key]
+            else:
+                At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
+                rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
+                for g in range(G):
+                    ops.split_rows_f16(Malpha[g][r0:r1], rows, Kc, At[g * rows_pad * Kc * 2:], rs_inv[g * rows_pad:])
+                if cache is not None and o.get("used") is not None:
+                    cache[key] = (At, rs_inv)
+            ops.gemm_grouped_f16x3(At, rs_inv, rows, o["Yt"], o["cs_s"][1], C, C.stride(0), Vs, Kc, o["tiles"])
             self.info["plain_flops"] += 2.0 * useful_rows * o["n_o"] * self.V
             self.info["plain_launches"] += 1
         else:
             Ms = torch.empty((G, rows, N_o), dtype=torch.float32, device=self.dev)
             for g in range(G):
                 Ms[g].copy_(Malpha[g][r0:r1])                       # (D2D copies: the groups' operators side by side)
-            ops.gemm_grouped(Ms, N_o, Ms.stride(0), o["Ys"], Vs, None, C, Vs, rows, Vs, N_o, o["tiles"])
+            ops.gemm_grouped(Ms, N_o, Ms.stride(0), o["Ys"], Vs, None, C, C.stride(0), rows, Vs, N_o, o["tiles"])
         return C
 
     def _refit_apply(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs):
@@ -1339,6 +1379,12 @@ class RidgeCVEngine:
                    lmax=None if hat["lmax"] is None else hat["lmax"][s:s + Fo], a2=hat["a2"][s * self.A:(s + Fo) * self.A],
                    shared=self._shared_image(inner_abs, hat["N"]), xt_off=hat.get("xt_off", 0) + s,
                    Hs=[(0, Fo, None if H is None else H[s * per:(s + Fo) * per], None if P is None else P[s:s + Fo])])
+        img = (hat.get("imgs") or [None])[0]
+        if img is not None:
+            N, tp, hp = hat["N"], img["tp"], img["hp"]
+            sub["imgs"] = [dict(tp=tp, hp=hp, Pt=img["Pt"][s * tp * N * 2:(s + Fo) * tp * N * 2], rs_p=img["rs_p"][s * tp:(s + Fo) * tp],
+                                Ht=None if img["Ht"] is None else img["Ht"][s * hp * N * 2:(s + Fo) * hp * N * 2],
+                                rs_h=None if img["rs_h"] is None else img["rs_h"][s * hp:(s + Fo) * hp])]
         return sub
 
     def prepare_folds(self, folds, lmax_pre, chol_after=None):
@@ -1451,7 +1497,8 @@ class RidgeCVEngine:
                 done.record()
                 for t in ([X, K, hat["tr"], hat["va"], hat["info"], hat["a2"], hat["lmax"], hat["d_ser"]]
                           + [out[i]["tr_o"] for i in g] + lmax_os
-                          + [h for _, _, h, _ in hat["Hs"]] + [q for _, _, _, q in hat["Hs"]]):
+                          + [h for _, _, h, _ in hat["Hs"]] + [q for _, _, _, q in hat["Hs"]]
+                          + [im[k] for im in (hat.get("imgs") or []) if im is not None for k in ("Pt", "rs_p", "Ht", "rs_h")]):
                     if t is not None and t.is_cuda:
                         t.record_stream(main)              # allocated on aux, consumed on main
         return out
@@ -1963,21 +2010,57 @@ class RidgeCVEngine:
         # ---- test predictions first (nested_cv.py:151,251: X_te W, here as the hat matrix of the test rows applied
         # to the same targets) and per-voxel Pearson r (:152-155, 252-257); the weight rows of the same contraction
         # follow once the fold's results are on their way to the host
+        o.update(used=tuple(st["used"]), img_cache=st.get("base", st).setdefault("refit_cache", {}).setdefault("imgs", {}))
         pred = self._refit_product(o, row0, st["Malpha"][0].shape[0], n_t)[:n_t]
         r_s = ops.pearson_cols(o["Ys_te"], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
         pend = self._publish(st, r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t)
         # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
         # run beside this part of the contraction)
-        Ws = self._refit_product(o, 0, self.p_pad, self.p)
-        ops.scatter_axpy(Ws, self.p, perm, Vs, weight_scale, self.W_acc)
+        # the weight rows stay in alpha-sorted order where the contraction writes them; the mean over the folds is taken
+        # in one pass per voxel range once its last fold is in (_combine_weights), not accumulated fold by fold
+        ent, off = self._ws_slot(st["fold"], rg, Vs, weight_scale)
+        self._refit_product(o, 0, self.p_pad, self.p, out=ent["buf"][:, off:off + Vs])
+        ops.invert_perm(perm, Vs, off, ent["pos"][rg.c0:])
         self._range_finished(st)
         return pend
+
+    def _ws_slot(self, fold, rg, Vs, scale):
+        """Where the alpha-sorted weight columns of a (fold, voxel range) step go: one (p_pad, cap) matrix per fold, the
+        ranges of the fold side by side (cap covers every range's padding to whole column tiles per alpha group), plus
+        the fold's position list  pos[voxel] = its column  (lc_invert_perm)."""
+        ent = self._ws.get(fold)
+        if ent is None or ent["cols"] >= self.V_rank:          # (a fold number coming round again: a new fit of the engine)
+            cap = ops.pad_to(max(self.V_rank, 1), 256) + 256 * self.A * max(1, len(self.upload_panels))
+            ent = self._ws[fold] = dict(buf=torch.empty((self.p_pad, cap), dtype=torch.float32, device=self.dev),
+                                        pos=ops.filled((max(self.V_rank, 1),), torch.int32, self.dev, 0xFF),
+                                        used=0, cols=0, scale=float(scale))
+        off = ent["used"]
+        if off + Vs > ent["buf"].shape[1]:
+            raise RuntimeError("alpha-sorted weight buffer of the fold is full (more voxel ranges than planned)")
+        ent["used"] += Vs
+        ent["cols"] += rg.V
+        return ent, off
+
+    def _combine_weights(self, rg):
+        """The mean weights of a voxel range, once its last fold is in:  W[:, v] = sum_f scale_f Ws_f[:, pos_f[v]]  in
+        fold order (lc_combine_folds_f32: one gather per fold and element, one write -- the accumulate it replaces
+        read and re-wrote the whole accumulator once per fold; same expression per term, same bits)."""
+        parts = [(self._ws[f]["buf"], self._ws[f]["pos"][rg.c0:], self._ws[f]["scale"]) for f in sorted(self._ws)]
+        ops.combine_folds(parts, self.p, rg.V, rg.W)
+        self._combined += rg.V
+        if self._combined >= self.V_rank:
+            self._ws = {}
+            self._combined = 0
 
     def _range_finished(self, st):
         """After the last fold's refit of a voxel range its block of the mean weights is final: with the weights wanted
         on the host (reserve_host_weights) it leaves NOW, on the download stream, beside the next range's refit."""
-        if st["fold"] != self.n_folds - 1 or self._host_weights is None:
+        if st["fold"] != self.n_folds - 1:
+            return
+        if not self.moments:                           # (the moments form accumulates voxel by voxel: lc_primal_refit)
+            self._combine_weights(st["rg"])
+        if self._host_weights is None:
             return
         if self._host_w is None:
             self._host_w = self._host_weights.result()

@@ -383,6 +383,23 @@ def scatter_axpy(w, n_rows, cols, n_cols, scale, acc):
               acc.stride(0), _s())
 
 
+def invert_perm(cols, n_cols, base, pos):
+    """pos[cols[j]] = base + j for the live entries of the alpha-sorted column list (lc_invert_perm)."""
+    _lib.call("lc_invert_perm", _p(cols), n_cols, int(base), _p(pos), _s())
+
+
+def combine_folds(parts, n_rows, n_cols, out):
+    """out[r, v] = sum_f scale_f * w_f[r, pos_f[v]] over ``parts`` = [(w_f (rows, ld_f) f32, pos_f (>= n_cols,) int32,
+    scale_f)], folds in order (lc_combine_folds_f32); out: (rows, >= n_cols) f32 device view."""
+    n = len(parts)
+    w = (ctypes.c_void_p * n)(*[p_[0].data_ptr() for p_ in parts])
+    ld = (ctypes.c_int64 * n)(*[int(p_[0].stride(0)) for p_ in parts])
+    pos = (ctypes.c_void_p * n)(*[p_[1].data_ptr() for p_ in parts])
+    sc = (ctypes.c_float * n)(*[float(p_[2]) for p_ in parts])
+    _lib.call("lc_combine_folds_f32", w, ld, pos, sc, n, n_rows, n_cols, _p(out), out.stride(0), _s())
+    return out
+
+
 # ------------------------------------------------------------------ column statistics
 def col_mean_std(x, rows, n_rows, n_cols):
     mean = torch.empty(n_cols, dtype=torch.float32, device=x.device)
