@@ -210,6 +210,12 @@ int lc_zscore_story_f64(const double* d_x, int64_t ld_in, int64_t rows, int64_t 
 int lc_pearson_cols(const float* d_a, int64_t lda, const float* d_b, int64_t ldb,
                     int64_t n, int64_t V, double* d_r, lc_stream_t stream);
 
+/* The same r with operand a read THROUGH a row list and a column list: a[i][c] = d_y[d_rows[i] * ld_y + d_cols[c]]
+ * (d_cols NULL: c; an entry < 0: a zero column) -- the test rows of the alpha-sorted voxels straight from the resident
+ * targets, no gathered copy (nested_cv.py:152-155 on y_test[:, i]).  n <= 640 rows (held in registers). */
+int lc_pearson_cols_gather(const float* d_y, int64_t ld_y, const int32_t* d_rows, const int32_t* d_cols,
+                           const float* d_b, int64_t ldb, int64_t n, int64_t V, double* d_r, lc_stream_t stream);
+
 /* The p-value scipy.stats.pearsonr attaches to r for n samples (nested_cv.py:434-436): two-sided, from the
  * Beta(n/2-1, n/2-1) null distribution, evaluated on the float32-rounded r like scipy does for float32
  * inputs; NaN r -> 1.  d_r, d_p: (V) f64. */
@@ -542,6 +548,12 @@ int lc_fisher_combine(const double* d_p, int k, int64_t V, double* d_out, lc_str
 int64_t lc_bh_fdr_work_bytes(int64_t n);
 int lc_bh_fdr(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, double* d_padj,
               void* d_work, int64_t work_bytes, lc_stream_t stream);
+
+/* The rejection mask of the same procedure WITHOUT the adjusted p-values and without a sort (the per-fold masks of a
+ * cross-validated fit, nested_cv.py:263-290: only they enter the majority vote): kmax = max{i : p_(i) <= (i/n) alpha} is the
+ * largest fixed point of c -> #{p <= (c/n) alpha}, reached from c = n by a few counting passes; d_reject[i] =
+ * p[i] <= (kmax / n) alpha.  Element for element the mask lc_bh_fdr returns. */
+int lc_bh_reject(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, lc_stream_t stream);
 
 /* Diagnostics only (tools/gpu_kernel_bench.py stamps): the fp16x3 sweep with s_memtime stamps at its phase
  * boundaries; d_stamps (32 x uint64, caller-zeroed) receives per wave-group sums of the five segments of an

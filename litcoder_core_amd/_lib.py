@@ -45,6 +45,7 @@ SIGNATURES = {
     "lc_col_normalize_f32": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, c_float, _ptr]),
     "lc_zscore_story_f64": (c_int, [_ptr, c_int64, c_int64, c_int64, c_int, _ptr, c_int64, _ptr]),
     "lc_pearson_cols": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64, _ptr, _ptr]),
+    "lc_pearson_cols_gather": (c_int, [_ptr, c_int64, _ptr, _ptr, _ptr, c_int64, c_int64, c_int64, _ptr, _ptr]),
     "lc_pearson_pvalues": (c_int, [_ptr, c_int64, c_int64, _ptr, _ptr]),
     "lc_gram_f64": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, c_int64, _ptr]),
     "lc_gram_f64_mfma": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, c_int64, _ptr]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "lc_fisher_combine": (c_int, [_ptr, c_int, c_int64, _ptr, _ptr]),
     "lc_bh_fdr_work_bytes": (c_int64, [c_int64]),
     "lc_bh_fdr": (c_int, [_ptr, c_int64, c_double, _ptr, _ptr, _ptr, c_int64, _ptr]),
+    "lc_bh_reject": (c_int, [_ptr, c_int64, c_double, _ptr, _ptr]),
     "lc_fill_bytes": (c_int, [_ptr, c_int, c_int64, _ptr]),
     "lc_gather_sub_f32_strided": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, c_int64, c_int64, c_int64,
                                           _ptr]),

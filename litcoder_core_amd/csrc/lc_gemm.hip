@@ -510,9 +510,9 @@ __global__ void __launch_bounds__(256) k_series_scores_part(const float* __restr
                                                             const int* __restrict__ aidx, int S,
                                                             float* __restrict__ scores, int accumulate) {
     constexpr int NP = lc::EPI_SERIES_PARTS;
-    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (c >= V) return;
-    const int nblk = M / LC_MB;
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;    // 64 columns per workgroup: one thread per
+    if (c >= V) return;                                                      // column is a dependent chain over the blocks,
+    const int nblk = M / LC_MB;                                              // so the chip is filled with MANY small workgroups
   for (int fold = 0; fold < F; ++fold) {
     const int n_val = fc.n_val[fold];
     const float* part = part_all + (long long)fold * nblk * NP * V;
@@ -723,7 +723,7 @@ int lc_series_finalize_launch(const float* d_part, const float* d_ystat, const f
         hipLaunchKernelGGL((k_series_scores_part_fw<FIN_FW, 64>), dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, FIN_FW),
                            0, s, d_part, d_ystat, d_yblk, M, fc, F, V, d_coef, d_aidx, S, d_scores, accumulate);
     else
-        hipLaunchKernelGGL(k_series_scores_part, dim3((unsigned)lc::ceil_div<long long>(V, 256)), dim3(256), 0, s, d_part,
+        hipLaunchKernelGGL(k_series_scores_part, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64), 0, s, d_part,
                            d_ystat, d_yblk, M, fc, F, V, d_coef, d_aidx, S, d_scores, accumulate);
     return lc::launched("k_series_scores_part");
 }

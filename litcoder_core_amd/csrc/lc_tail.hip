@@ -249,7 +249,49 @@ __global__ void __launch_bounds__(BH_THREADS) k_bh_apply(const double* __restric
     }
 }
 
+// The rejections ALONE need no sort.  With T(c) = (c / n) alpha, Benjamini-Hochberg rejects the k* smallest p-values,
+// k* = max{i : p_(i) <= T(i)}, and k* is the largest fixed point of  c -> #{p <= T(c)}:  from c = n the iteration falls
+// monotonically and stops exactly at k* (T is monotone, so c >= k* is kept, and a fixed point c has p_(c) <= T(c), i.e.
+// c <= k*); no tie straddles the boundary (p_(k*+1) = p_(k*) would pass at k* + 1), so {p <= T(k*)} is the sorted
+// routine's set, element for element -- same T(c) expression as bh_element.  One workgroup, a handful of counting passes
+// over values that sit in L2: the per-fold masks of a cross-validated fit (only they enter its majority vote) cost
+// ~30 us instead of a 16-pass radix sort each.
+__global__ void __launch_bounds__(1024) k_bh_reject(const double* __restrict__ p, long long n, double alpha,
+                                                    unsigned char* __restrict__ reject) {
+    __shared__ long long wsum[16];
+    __shared__ long long total;
+    const int t = threadIdx.x;
+    long long c = n;
+    double thr = 0.0;
+    for (;;) {
+        thr = ((double)c / (double)n) * alpha;
+        long long mine = 0;
+        for (long long i = t; i < n; i += 1024) mine += p[i] <= thr ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        if ((t & 63) == 0) wsum[t >> 6] = mine;
+        __syncthreads();
+        if (t == 0) {
+            long long s = 0;
+            for (int w = 0; w < 16; ++w) s += wsum[w];
+            total = s;
+        }
+        __syncthreads();
+        const long long cn = total;
+        __syncthreads();
+        if (cn == c) break;
+        c = cn;
+    }
+    for (long long i = t; i < n; i += 1024) reject[i] = (c > 0 && p[i] <= thr) ? 1 : 0;
+}
+
 }  // namespace
+
+extern "C" int lc_bh_reject(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, lc_stream_t stream) {
+    LC_REQUIRE(d_p && d_reject, LC_E_BADARG, "lc_bh_reject: null pointer");
+    LC_REQUIRE(n > 0 && n < (1ll << 31), LC_E_SHAPE, "lc_bh_reject: bad length");
+    hipLaunchKernelGGL(k_bh_reject, dim3(1), dim3(1024), 0, lc::as_stream(stream), d_p, (long long)n, alpha, d_reject);
+    return lc::launched("k_bh_reject");
+}
 
 extern "C" int lc_fisher_combine(const double* d_p, int k, int64_t V, double* d_out, lc_stream_t stream) {
     LC_REQUIRE(d_p && d_out, LC_E_BADARG, "lc_fisher_combine: null pointer");

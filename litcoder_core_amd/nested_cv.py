@@ -70,6 +70,9 @@ class FitOptions:
     panel_cols: int = 24576                 # voxel columns per panel of a host-to-host fit (_column_panels): 96 column tiles
                                             # x 8 M-tiles of the sweeps = exactly 3 rounds of workgroups on 256 CUs
     panel_min_cols: int = 16384             # below twice this many voxels a fit is not cut into panels
+    tail_panels_geometric: bool = True      # the end of a host-to-host fit in few panels of falling width (_download_panels)
+    tail_folds: int = 2                     # ... spread over this many folds, voxel-major (plan_steps)
+XX
     alpha_progress_log: bool = dataclasses.field(       # per-alpha progress lines (ridge_regression.py:136-139): a device
         default_factory=lambda: os.environ.get("LITCODER_AMD_ALPHA_LOG", "0") == "1")   # round trip per fold, opt-in
     chol_outer_block: int = 512             # lc_batch_chol_solve: columns per outer block of the two-level blocking
@@ -230,6 +233,33 @@ def _column_panels(V, cols=None, min_cols=None, v_ref=None):
     return [(int(edges[i]), int(edges[i + 1])) for i in range(len(widths))]
 
 
+def _download_panels(V, first=8.0 / 15.0, ratio=0.5, min_cols=None, v_ref=None, last_min=4096):
+    """[c0, c1) panels the END of a host-to-host fit works in (the last two folds voxel-major, plan_steps): a panel's
+    finished weights cross PCIe while the next panel is computed, so what is not hidden is the LAST panel's transfer --
+    and wide panels run the V-wide kernels more efficiently than narrow ones.  Widths fall geometrically: two folds of
+    V-wide work on a panel take ~2.2x its transfer time (cfg2: 40 ms of work, 18 ms of PCIe for all voxels), so with
+    ``ratio`` = 1/2 every transfer ends before the next panel's work does, and the tail is the transfer of 1/15 of the
+    voxels (~1.2 ms) with four panels instead of five equal ones.  Boundaries on multiples of 256; ``v_ref`` as in
+    _column_panels (the same number of panels on every rank of a sharded fit)."""
+    min_cols = FitOptions.panel_min_cols if min_cols is None else int(min_cols)
+    v_ref = int(V) if v_ref is None else min(int(v_ref), int(V))
+    if v_ref < 2 * min_cols:
+        return [(0, int(V))]
+    last_min = max(256, min(int(last_min), min_cols // 4))
+    widths, left, w = [], v_ref, v_ref * first
+    while left > 0:
+        wi = max(256, int(round(w / 256.0)) * 256)
+        if left - wi < last_min or wi < last_min:
+            widths.append(left)
+            break
+        widths.append(wi)
+        left -= wi
+        w *= ratio
+    edges = np.concatenate([[0], np.cumsum(widths)]).astype(np.int64)
+    edges[-1] = int(V)
+    return [(int(edges[i]), int(edges[i + 1])) for i in range(len(widths))]
+
+
 class RidgeCVEngine:
     """Device-resident state of one fit: fp32 copies of X / Y (zero padded), the Gram matrix, and the
     per-fold pipeline.  ``Y`` holds only this rank's voxel block."""
@@ -237,7 +267,7 @@ class RidgeCVEngine:
     def __init__(self, X_all, Y_all, alphas, normalpha, use_corr, normalize_features, normalize_targets,
                  shard: Optional[ShardContext] = None, lanczos_steps: Optional[int] = None, precision: str = "auto",
                  singcutoff: float = 0.0, V_total: Optional[int] = None, min_train_rows: Optional[int] = None,
-                 form: str = "dual", panels=None, options: Optional[FitOptions] = None):
+                 form: str = "dual", panels=None, options: Optional[FitOptions] = None, down_panels=None):
         """``form``: "dual" (n x n Gram / hat matrices: every shape), "primal" (p x p systems, see _prepare_primal) or
         "auto" = primal when the design is tall, 2 p <= ``min_train_rows`` (the smallest inner training set) and
         p <= FitOptions.primal_max_p.  ``Y_all``: a host array / ops.HostRows (uploaded in the column ``panels`` [(c0, c1), ...] on a
@@ -300,7 +330,8 @@ class RidgeCVEngine:
             ops.zero_cols(self.dY_full, self.V_rank, self.Vp_rank)
             if self.V_rank and self.Ttot:
                 self.upload_panels = [(int(a), int(b)) for a, b in (panels or [(0, self.V_rank)])]
-                self.download_panels = list(self.upload_panels)
+                self.download_panels = ([(int(a), int(b)) for a, b in down_panels] if down_panels
+                                        else list(self.upload_panels))
                 self._y_job0 = len(jobs)
                 jobs += [(Y_all, self.dY_full, a, b) for a, b in self.upload_panels]
         if jobs:
@@ -348,6 +379,7 @@ class RidgeCVEngine:
         self._host_weights = None                      # future of the page-locked result buffer (reserve_host_weights)
         self._host_w = None                            # ... the buffer itself once panels are leaving for it
         self._sent = 0                                 # voxel columns of the weights already on their way to the host
+        self._cs_all, self._cs_known = None, None      # column scales of the target panels that have arrived (_target_scales)
         self._ws = {}                                  # fold -> its alpha-sorted weight matrix + where each voxel went (_ws_slot)
         self._combined = 0                             # voxel columns whose mean weights are final (_combine_weights)
         self._assume_split = None                      # the arithmetic the operators are prepared for (_split_assumed)
@@ -426,8 +458,9 @@ class RidgeCVEngine:
         full = [(0, self.V_rank)]
         paneled = len(self.upload_panels) > 1 and not single_alpha
         up = self.upload_panels if paneled else full
-        down = self.download_panels if (paneled and self._host_weights is not None) else full
-        tail = 2 if (ahead and n_folds >= 3 and len(down) > 1) else 1
+        down = self.download_panels if (len(self.download_panels) > 1 and not single_alpha
+                                        and self._host_weights is not None) else full
+        tail = max(1, min(int(self.opt.tail_folds), 2)) if (ahead and n_folds >= 3 and len(down) > 1) else 1
         plan = []
         for f in range(n_folds - (tail if len(down) > 1 else 0)):
             for c in (up if (f == 0 and self.uploader is not None) else full):
@@ -488,6 +521,14 @@ class RidgeCVEngine:
             return None, False
         if Y is rg.Y and rg.scales is not None:
             return rg.scales
+        if Y is rg.Y and self._cs_known is not None and bool(self._cs_known[rg.c0 // 256:(rg.c0 + rg.Vp + 255) // 256].all()):
+            # every column of the range belongs to a range whose scales exist (the end of a host-to-host fit works in
+            # other panels than its beginning): the values are per column -- two slices of the engine-wide table
+            cs = torch.empty(2 * rg.Vp, dtype=torch.float32, device=self.dev)
+            cs[:rg.Vp].copy_(self._cs_all[0, rg.c0:rg.c0 + rg.Vp])
+            cs[rg.Vp:].copy_(self._cs_all[1, rg.c0:rg.c0 + rg.Vp])
+            rg.scales = (cs, True)
+            return rg.scales
         check = self.precision == "auto" and not (self._decided and Y is rg.Y)
         if check and self.uploader is not None and Y is rg.Y:
             # targets still arriving from the host: the scales and the flag of a range on a stream of their own, which
@@ -520,6 +561,13 @@ class RidgeCVEngine:
         out = (cs, not wide)
         if Y is rg.Y:
             rg.scales = out
+            if not wide and self.uploader is not None:       # (current stream = the one every V-wide phase is queued on)
+                if self._cs_all is None:
+                    self._cs_all = torch.empty((2, self.Vp_rank), dtype=torch.float32, device=self.dev)
+                    self._cs_known = np.zeros((self.Vp_rank + 255) // 256, dtype=bool)
+                self._cs_all[0, rg.c0:rg.c0 + rg.Vp].copy_(cs[:rg.Vp])
+                self._cs_all[1, rg.c0:rg.c0 + rg.Vp].copy_(cs[rg.Vp:])
+                self._cs_known[rg.c0 // 256:(rg.c0 + rg.Vp + 255) // 256] = True
         return out
 
     # -------------------------------------------------------------- S[0]^2 of every train set (Lanczos)
@@ -1281,14 +1329,18 @@ class RidgeCVEngine:
                       and len(image[1]) == n_o and np.array_equal(np.asarray(image[1]), np.asarray(tr_rows)))
         if from_image:
             rows_x = ops.idx_tensor(np.asarray(extra_rows, dtype=np.int64), n_x, self.dev)
-            Ys_te = torch.empty((n_x, Vs), dtype=torch.float32, device=self.dev)
-            ops.gather(Y, Y.stride(0), rows_x, n_x, perm, Vs, Ys_te)
+            Ys_te, te_src = None, None
+            if 0 < n_x <= 640:                           # Pearson r reads the test rows through (rows, perm) in place
+                te_src = (Y, rows_x, perm)
+            else:
+                Ys_te = torch.empty((n_x, Vs), dtype=torch.float32, device=self.dev)
+                ops.gather(Y, Y.stride(0), rows_x, n_x, perm, Vs, Ys_te)
             cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)
             ops.gather(cs.reshape(2, self.Vp), self.Vp, None, 2, perm, Vs, cs_s)
             Yt = torch.empty(Vs * n_o * 2, dtype=torch.float16, device=self.dev)
             ops.permute_cols_f16(image[0], perm, Vs, n_o, Yt)
-            return dict(Ys=None, Ys_te=Ys_te, N_o=N_o, K=n_o, n_o=n_o, Vs=Vs, tiles=tiles, Malpha=Malpha, split=split,
-                        cs_s=cs_s, Yt=Yt)
+            return dict(Ys=None, Ys_te=Ys_te, te_src=te_src, N_o=N_o, K=n_o, n_o=n_o, Vs=Vs, tiles=tiles, Malpha=Malpha,
+                        split=split, cs_s=cs_s, Yt=Yt)
         rows_s = ops.idx_tensor(np.concatenate([tr_rows, np.full(N_o - n_o, -1), np.asarray(extra_rows, dtype=np.int64)]),
                                 N_o + n_x, self.dev)
         Ys = torch.empty((N_o + n_x, Vs), dtype=torch.float32, device=self.dev)
@@ -1807,7 +1859,7 @@ class RidgeCVEngine:
         on one GPU when they come from explicit inverses (N^3 flops each) and the grid has only a few such alphas."""
         return bool(self.cho) and len(self.cho) <= 8 and not self.primal and self._refit_by_inverse(self.cho)
 
-    def refit_ahead(self, states):
+    def refit_ahead(self, states, alphas=None):
         """Voxel shards: the refit systems of ALL the given (prepared) folds for ALL factorised alphas in one
         collective batch, before any alpha is chosen.  With W ranks a rank's share of a fold's handful of systems is a
         chain of ~N/64 dependent steps either way (latency, not flops), and solving them fold by fold after each
@@ -1815,7 +1867,7 @@ class RidgeCVEngine:
         costs one chain for the whole fit, hidden behind the first folds' sweeps.  (On one GPU the systems of alphas
         nobody chooses would be wasted fp64 work, so there the driver keeps fold_speculate.)  Folds whose systems
         differ in size fall back to fold_speculate / fold_select."""
-        cho = [a for a in self.cho]
+        cho = [a for a in self.cho if alphas is None or a in alphas]     # ``alphas``: only these (a first choice is known)
         sts = [st for st in states if st.get("tr_o") is not None and "spec" not in st]
         if not cho or not sts or self.primal or self.spectral:
             return
@@ -2012,7 +2064,10 @@ class RidgeCVEngine:
         # follow once the fold's results are on their way to the host
         o.update(used=tuple(st["used"]), img_cache=st.get("base", st).setdefault("refit_cache", {}).setdefault("imgs", {}))
         pred = self._refit_product(o, row0, st["Malpha"][0].shape[0], n_t)[:n_t]
-        r_s = ops.pearson_cols(o["Ys_te"], pred, n_t, Vs)
+        if o.get("te_src") is not None:
+            r_s = ops.pearson_cols_gather(*o["te_src"], pred, n_t, Vs)
+        else:
+            r_s = ops.pearson_cols(o["Ys_te"], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
         pend = self._publish(st, r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t)
         # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
@@ -2031,7 +2086,7 @@ class RidgeCVEngine:
         the fold's position list  pos[voxel] = its column  (lc_invert_perm)."""
         ent = self._ws.get(fold)
         if ent is None or ent["cols"] >= self.V_rank:          # (a fold number coming round again: a new fit of the engine)
-            cap = ops.pad_to(max(self.V_rank, 1), 256) + 256 * self.A * max(1, len(self.upload_panels))
+            cap = ops.pad_to(max(self.V_rank, 1), 256) + 256 * self.A * max(1, len(self.upload_panels), len(self.download_panels))
             ent = self._ws[fold] = dict(buf=torch.empty((self.p_pad, cap), dtype=torch.float32, device=self.dev),
                                         pos=ops.filled((max(self.V_rank, 1),), torch.int32, self.dev, 0xFF),
                                         used=0, cols=0, scale=float(scale))
@@ -2099,15 +2154,21 @@ class RidgeCVEngine:
             dbad = torch.empty(2, dtype=torch.int32, device=self.dev)
             ops.fold_unpack(gathered, self.shard.world, blk.shape[1], self.d_lo, self.w_max, dres[0], dres[1], didx,
                             self.p_folds[fold_no], dbad)
-            rej_d, padj_d = ops.bh_fdr(self.p_folds[fold_no], self.alpha_fdr)
+            # the fold's BH-FDR: a cross-validated fit only takes the rejection MASKS of its folds (their majority vote,
+            # nested_cv.py:283-290) -- no sort, no adjusted p-values (lc_bh_reject); a train/test fit returns both
+            if self.n_folds > 1:
+                rej_d, padj_d = ops.bh_reject(self.p_folds[fold_no], self.alpha_fdr), None
+            else:
+                rej_d, padj_d = ops.bh_fdr(self.p_folds[fold_no], self.alpha_fdr)
             # results leave through pinned buffers so the copies do not stall the host
             h_res = torch.empty((2, Vt), dtype=torch.float64, pin_memory=True)
             h_idx = torch.empty(Vt, dtype=torch.int32, pin_memory=True)
             h_rej = torch.empty(Vt, dtype=torch.uint8, pin_memory=True)
-            h_padj = torch.empty(Vt, dtype=torch.float64, pin_memory=True)
+            h_padj = torch.empty(Vt, dtype=torch.float64, pin_memory=True) if padj_d is not None else None
             h_bad = torch.empty(2, dtype=torch.int32, pin_memory=True)
             for h, d in ((h_res, dres), (h_idx, didx), (h_rej, rej_d), (h_padj, padj_d), (h_bad, dbad)):
-                h.copy_(d, non_blocking=True)
+                if h is not None:
+                    h.copy_(d, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
         for t in [blk] + ent["keep"]:
@@ -2130,7 +2191,7 @@ class RidgeCVEngine:
         if int(pend["bad"][1]):
             raise RuntimeError("Cholesky failed in the refit: Gram matrix + alpha^2 I is not positive definite")
         res = pend["res"].numpy()
-        sig = (pend["rej"].numpy().astype(bool), pend["padj"].numpy().copy())
+        sig = (pend["rej"].numpy().astype(bool), None if pend["padj"] is None else pend["padj"].numpy().copy())
         return _FoldResult(res[0].copy(), res[1].copy(), pend["idx"].numpy().copy(), pend["n_t"], sig)
 
     def combined_significance(self):
@@ -2353,18 +2414,23 @@ class NestedCVModel(BasePredictivityModel):
         min_train = min(len(tr_i) for _, _, inner in outer for tr_i, _ in inner)
 
         V_rank = Y_all.shape[1]
-        panels = None
+        panels = down_panels = None
         if not isinstance(Y_all, _DeviceShapes):
             # the same NUMBER of panels on every rank of a sharded fit (narrowest rank decides)
             o = self.options or FitOptions()
             panels = [(0, V_rank)] if self.panel_cols == 0 else _column_panels(
                 V_rank, o.panel_cols if self.panel_cols is None else self.panel_cols,
                 o.panel_min_cols if self.panel_cols is None else 256, v_ref=V_total // max(shard.world, 1))
+            # the end of the fit: fewer, wider panels of geometrically falling width (explicit panel_cols: the same panels
+            # at both ends, what the tests of the panel logic ask for)
+            if self.panel_cols is None and o.tail_panels_geometric:
+                down_panels = _download_panels(V_rank, min_cols=o.panel_min_cols, v_ref=V_total // max(shard.world, 1))
 
         def attempt(form, precision, X_in, Y_in):
             eng = RidgeCVEngine(X_in, Y_in, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
                                 precision=precision, singcutoff=singcutoff, V_total=V_total,
-                                min_train_rows=min_train, form=form, panels=panels, options=self.options)
+                                min_train_rows=min_train, form=form, panels=panels, options=self.options,
+                                down_panels=down_panels)
             self._engine = eng
             scale = 1.0 if train_test else 1.0 / len(outer)
             fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
@@ -2420,11 +2486,16 @@ class NestedCVModel(BasePredictivityModel):
                 if hosted:      # the first panel is there within a few ms: its sweeps are queued before the big batch is
                     st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
                 prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else [])
-                if ahead:
+                # one GPU, host inputs: the other folds' refit operators wait for the FIRST choice (fold 0's first panel, a
+                # few ms from now) and are formed for the alphas it used only -- an alpha nobody chooses (the smallest
+                # of a grid, typically) costs an N^3 inverse per fold; one that turns up later is solved then
+                defer_ahead = ahead and hosted and shard.world == 1 and n > 1 and eng.opt.refit_ahead_after_first_choice
+                if ahead and not defer_ahead:
                     eng.refit_ahead(prepared[1:])
                 if not hosted:
                     st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
             else:
+                defer_ahead = False
                 # one GPU, resident targets: the batch's series operands now, its Cholesky chains once fold 0's sweeps
                 # (just queued) are done -- same fit time, and fold 0's fused launches, the dominant kernel, run without 80
                 # systems of fp64 work beside them (1.66 -> 1.45 ms per launch over the fit)
@@ -2452,6 +2523,8 @@ class NestedCVModel(BasePredictivityModel):
                     f2 = plan[k + 1][0]
                     st_next = eng.fold_begin(*outer[f2], prepared=prepared[f2], step=plan[k + 1])
                 st = eng.fold_select(st, single_alpha)          # host waits for the histogram of this step here
+                if k == 0 and defer_ahead:
+                    eng.refit_ahead(prepared[1:], alphas=st["used_all"])
                 if f + 1 < n and (k == 0 or plan[k - 1][0] != f):
                     eng.fold_speculate(prepared[f + 1], st["used_all"])         # aux: refit systems of the next fold
                 if pending is not None:

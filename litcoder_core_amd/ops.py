@@ -424,6 +424,13 @@ def pearson_cols(a, b, n, V):
     return r
 
 
+def pearson_cols_gather(y, rows, cols, b, n, V):
+    """Pearson r of y[rows][:, cols] against b (n, V) per column, y read in place (lc_pearson_cols_gather)."""
+    r = torch.empty(V, dtype=torch.float64, device=y.device)
+    _lib.call("lc_pearson_cols_gather", _p(y), y.stride(0), _p(rows), _p(cols), _p(b), b.stride(0), n, V, _p(r), _s())
+    return r
+
+
 def pearson_pvalues(r, V, n):
     p = torch.empty(V, dtype=torch.float64, device=r.device)
     _lib.call("lc_pearson_pvalues", _p(r), V, n, _p(p), _s())
@@ -660,6 +667,14 @@ def bh_fdr(p, alpha):
     padj = torch.empty(n, dtype=torch.float64, device=p.device)
     _lib.call("lc_bh_fdr", _p(p), n, float(alpha), _p(reject), _p(padj), _p(work), nbytes, _s())
     return reject, padj
+
+
+def bh_reject(p, alpha):
+    """The Benjamini-Hochberg rejection mask alone ((n,) uint8, input order): no sort, no adjusted p-values."""
+    n = p.numel()
+    reject = torch.empty(n, dtype=torch.uint8, device=p.device)
+    _lib.call("lc_bh_reject", _p(p), n, float(alpha), _p(reject), _s())
+    return reject
 
 
 def gather_sub_f64(k, rows, cols, F, R, C, out):

@@ -32,7 +32,7 @@ class OracleEngine:
     exchanges through the same ShardContext."""
     primal = False
     def __init__(self, X, Y, alphas, normalpha, use_corr, nf, nt, shard, precision="auto", singcutoff=0.0, V_total=None,
-                 min_train_rows=None, form="dual", panels=None, options=None):
+                 min_train_rows=None, form="dual", panels=None, options=None, down_panels=None):
         Y = np.concatenate([b for _, b in Y.blocks], axis=0)              # ops.HostRows: the targets' row blocks
         self.X, self.Y = torch.tensor(np.asarray(X), dtype=torch.float32), torch.tensor(np.asarray(Y), dtype=torch.float32)
         self.alphas, self.normalpha, self.use_corr, self.shard = list(alphas), normalpha, use_corr, shard

@@ -609,6 +609,14 @@ def test_device_statistics_tail_matches_host(lc):  # noqa: C901
             rej_d, adj_d = ops.bh_fdr(torch.from_numpy(p).to(dev), alpha)
             np.testing.assert_array_equal(rej_d.cpu().numpy().astype(bool), rej_h, err_msg=f"n={n} alpha={alpha}")
             np.testing.assert_array_equal(adj_d.cpu().numpy(), adj_h, err_msg=f"n={n} alpha={alpha}")
+            # the sort-free rejection mask (the per-fold masks of a cross-validated fit): element for element the same
+            only = ops.bh_reject(torch.from_numpy(p).to(dev), alpha)
+            np.testing.assert_array_equal(only.cpu().numpy().astype(bool), rej_h, err_msg=f"mask only, n={n} alpha={alpha}")
+    for p in (np.full(50, 0.9), np.zeros(9), np.array([0.01, 0.02, 0.03, 0.5]), np.array([1.0])):   # nothing / everything passes
+        for alpha in (0.05, 0.04):
+            rej_h, _ = stats.fdrcorrection(p, alpha=alpha)
+            only = ops.bh_reject(torch.from_numpy(p).to(dev), alpha)
+            np.testing.assert_array_equal(only.cpu().numpy().astype(bool), rej_h)
     P = rng.uniform(1e-300, 1, (5, 4000))
     P[:, 10] = 1.0                                                                 # all-ones shortcut
     P[2, 11] = 0.0                                                                 # ln 0 = -inf -> 0
@@ -908,6 +916,20 @@ def test_voxel_panels_are_bitwise_neutral(lc):
             for k in ref[0]:
                 assert np.array_equal(np.asarray(got[0][k]), np.asarray(ref[0][k]), equal_nan=True), (kw, cols, k)
             assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), (kw, cols)
+    # the default plan: panels of rising width at the start, FEWER panels of geometrically falling width at the end (the
+    # last two folds voxel-major over them) -- other ranges at the two ends of one fit; and the end over one fold only
+    from litcoder_core_amd.nested_cv import FitOptions, _download_panels
+    assert _download_panels(80000) == [(0, 42752), (42752, 64000), (64000, 74752), (74752, 80000)]
+    assert _download_panels(1100, min_cols=256) == [(0, 512), (512, 768), (768, 1100)]
+    kw = dict(folding_type="kfold", n_outer_folds=4, n_inner_folds=3, alphas=np.logspace(-1, 5, 8))
+    ref = lc.NestedCVModel("r", panel_cols=0).fit_predict(X, Y, **kw)
+    for tail_folds in (2, 1):
+        m = lc.NestedCVModel("r", options=FitOptions(panel_cols=256, panel_min_cols=256, tail_folds=tail_folds))
+        got = m.fit_predict(X, Y, **kw)
+        assert len(m.last_fit["panels"]) > 5, m.last_fit["panels"]        # both plans were in use
+        for k in ref[0]:
+            assert np.array_equal(np.asarray(got[0][k]), np.asarray(ref[0][k]), equal_nan=True), (tail_folds, k)
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), tail_folds
     # train / test mode: one fold that is first (panels arrive) and last (panels leave) at once
     kw = dict(folding_type="kfold", n_inner_folds=3, alphas=np.logspace(-1, 5, 8))
     ref = lc.NestedCVModel("r", panel_cols=0).fit_predict(X[:330], Y[:330], X_test=X[330:], y_test=Y[330:], **kw)
