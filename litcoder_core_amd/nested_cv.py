@@ -72,7 +72,9 @@ class FitOptions:
     panel_min_cols: int = 16384             # below twice this many voxels a fit is not cut into panels
     tail_panels_geometric: bool = True      # the end of a host-to-host fit in few panels of falling width (_download_panels)
     tail_folds: int = 2                     # ... spread over this many folds, voxel-major (plan_steps)
-XX
+    refit_ahead_after_first_choice: bool = False  # host inputs: the later folds' refit inverses only for the alphas the first
+                                            # panel chose -- measured 2.4 ms SLOWER at cfg2 (148.4 vs 150.8 ms: the batch then
+                                            # starts at 18 ms beside full-width sweeps instead of in the upload window): off
     alpha_progress_log: bool = dataclasses.field(       # per-alpha progress lines (ridge_regression.py:136-139): a device
         default_factory=lambda: os.environ.get("LITCODER_AMD_ALPHA_LOG", "0") == "1")   # round trip per fold, opt-in
     chol_outer_block: int = 512             # lc_batch_chol_solve: columns per outer block of the two-level blocking
