@@ -72,6 +72,11 @@ class FitOptions:
     panel_min_cols: int = 16384             # below twice this many voxels a fit is not cut into panels
     tail_panels_geometric: bool = True      # the end of a host-to-host fit in few panels of falling width (_download_panels)
     tail_folds: int = 2                     # ... spread over this many folds, voxel-major (plan_steps)
+    resident_refit_batch: bool = True       # resident inputs: refit inverses of folds 1.. as one batch after fold 0's choice
+    shard_first_sweeps_before_batch: bool = False  # voxel shards: fold 0's sweeps queued before the other folds' batch
+                                            # (measured: 38.7 vs 38.5 ms per rank of 8 -- no gain): off
+    second_fold_own_batch: bool = False     # voxel shards: fold 1's hat matrices as a batch of their own -- measured SLOWER
+                                            # (rank 0 of 8: 39.5 vs 37.7 ms, of 4: 54.6 vs 52.6: one more chain latency): off
     refit_ahead_after_first_choice: bool = False  # host inputs: the later folds' refit inverses only for the alphas the first
                                             # panel chose -- measured 2.4 ms SLOWER at cfg2 (148.4 vs 150.8 ms: the batch then
                                             # starts at 18 ms beside full-width sweeps instead of in the upload window): off
@@ -2434,6 +2439,7 @@ class NestedCVModel(BasePredictivityModel):
                                 min_train_rows=min_train, form=form, panels=panels, options=self.options,
                                 down_panels=down_panels)
             self._engine = eng
+            drv_opt = getattr(eng, "opt", None) or FitOptions()     # (the tests' oracle-backed engine has none)
             scale = 1.0 if train_test else 1.0 / len(outer)
             fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
             score_rows, any_nan = [], []
@@ -2485,19 +2491,28 @@ class NestedCVModel(BasePredictivityModel):
                 # of 8 -- the rank is bound by its total work, not by the batching)
                 if ahead:
                     eng.refit_ahead([first])
-                if hosted:      # the first panel is there within a few ms: its sweeps are queued before the big batch is
-                    st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
-                prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else [])
+                early_begin = hosted or (shard.world > 1 and drv_opt.shard_first_sweeps_before_batch)
+                if early_begin:  # the first panel is there within a few ms: its sweeps are queued before the big batch is
+                    st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])     # (shards: ~3 ms of host enqueue time)
+                if shard.world > 1 and n > 2 and drv_opt.second_fold_own_batch:
+                    # voxel shards: fold 1's systems as a batch of their own, so that its sweeps start one (short) chain
+                    # after fold 0's instead of behind the chain of all the other folds' systems
+                    prepared = ([first] + eng.prepare_folds(outer[1:2], lmax_pre[1:2])
+                                + eng.prepare_folds(outer[2:], lmax_pre[2:]))
+                else:
+                    prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else [])
                 # one GPU, host inputs: the other folds' refit operators wait for the FIRST choice (fold 0's first panel, a
                 # few ms from now) and are formed for the alphas it used only -- an alpha nobody chooses (the smallest
                 # of a grid, typically) costs an N^3 inverse per fold; one that turns up later is solved then
-                defer_ahead = ahead and hosted and shard.world == 1 and n > 1 and eng.opt.refit_ahead_after_first_choice
+                defer_ahead = ahead and hosted and shard.world == 1 and n > 1 and drv_opt.refit_ahead_after_first_choice
                 if ahead and not defer_ahead:
                     eng.refit_ahead(prepared[1:])
-                if not hosted:
+                if not early_begin:
                     st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
             else:
-                defer_ahead = False
+                # resident targets: the later folds' refit inverses as ONE batch once fold 0 has chosen (for the alphas it
+                # used), instead of one short chain per fold beside that fold's sweeps
+                defer_ahead = bool(n > 1 and drv_opt.resident_refit_batch and getattr(eng, "refit_ahead_pays", lambda: False)())
                 # one GPU, resident targets: the batch's series operands now, its Cholesky chains once fold 0's sweeps
                 # (just queued) are done -- same fit time, and fold 0's fused launches, the dominant kernel, run without 80
                 # systems of fp64 work beside them (1.66 -> 1.45 ms per launch over the fit)
