@@ -624,7 +624,8 @@ int lc_fold_unpack(const double* d_src, int world, int64_t ld, const int64_t* d_
 /* Counting sort of voxels by alpha index (torch.unique / nonzero grouping,
  * ridge_regression.py:46-50): d_perm = voxel ids grouped by alpha, stable, each group starting
  * at a multiple of `pad` columns (slots between groups are left untouched: pre-fill d_perm,
- * V + A*pad entries, with -1).  d_count (A) = group sizes. */
+ * V + A*pad entries, with -1).  d_count (A) = group sizes.  A voxel whose index is outside 0 .. A-1 (-1) is in
+ * no group (banded ridge with a search over band scales: the voxels another candidate's refit takes). */
 int lc_group_by_alpha(const int32_t* d_best, int64_t V, int A, int pad, int32_t* d_perm,
                       int32_t* d_count, lc_stream_t stream);
 

@@ -422,10 +422,13 @@ __global__ void __launch_bounds__(GB_THREADS) k_group_by_alpha(const int* __rest
         __syncthreads();
     }
     for (int a = 0; a < A; ++a) hist[a * GB_THREADS + t] = 0;
+    // an index outside 0 .. A-1 (-1: the voxel belongs to another candidate's refit, banded.py) is in no group
     if (staged) {
-        for (long long v = lo; v < hi; ++v) hist[stage[v] * GB_THREADS + t] += 1;
+        for (long long v = lo; v < hi; ++v)
+            if ((int)stage[v] < A) hist[stage[v] * GB_THREADS + t] += 1;
     } else {
-        for (long long v = lo; v < hi; ++v) hist[best[v] * GB_THREADS + t] += 1;
+        for (long long v = lo; v < hi; ++v)
+            if ((unsigned)best[v] < (unsigned)A) hist[best[v] * GB_THREADS + t] += 1;
     }
     if (t == 0) carry = 0;
     __syncthreads();
@@ -455,7 +458,7 @@ __global__ void __launch_bounds__(GB_THREADS) k_group_by_alpha(const int* __rest
     }
     for (long long v = lo; v < hi; ++v) {
         const int a = staged ? (int)stage[v] : best[v];
-        perm[hist[a * GB_THREADS + t]++] = (int)v;
+        if ((unsigned)a < (unsigned)A) perm[hist[a * GB_THREADS + t]++] = (int)v;
     }
 }
 

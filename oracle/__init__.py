@@ -22,4 +22,4 @@ Benjamini-Hochberg step (``stats.bh_fdr``) is pinned only by hand-checkable
 known-answer vectors ("parity unpinned" for that step).
 """
 
-from . import fir, folds, lanczos, ridge, stats, nested_cv, harness  # noqa: F401
+from . import fir, folds, lanczos, ridge, stats, nested_cv, harness, banded  # noqa: F401

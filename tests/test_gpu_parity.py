@@ -791,6 +791,53 @@ def test_banded_ridge_against_oracle_on_rescaled_design(lc):
                                                                normalize_features=True, **kw)
 
 
+def test_banded_ridge_search_over_band_scales_against_oracle(lc):
+    """Banded ridge with the band scales chosen per voxel among candidates by the inner-CV score (self-defined, see
+    litcoder_core_amd/banded.py): the oracle builds the definition from the reference's score table / ridge_torch on
+    each rescaled design.  A voxel whose (candidate, alpha) differs from the oracle's in some fold must be a proven near
+    tie of the oracle's own table; the others agree in r and weights."""
+    import oracle.banded as oband
+    rng = np.random.default_rng(44)
+    T, p, V = 200, 36, 70
+    X = rng.standard_normal((T, p)) * np.r_[np.ones(12), 2.5 * np.ones(24)]
+    Wt = rng.standard_normal((p, V)) * 0.25
+    Wt[:12, : V // 2] = 0.0                                 # half of the voxels only listen to the second band
+    Wt[12:, V // 2:] *= 0.1
+    Y = X @ Wt + rng.standard_normal((T, V))
+    bands = [(0, 12), (12, 36)]
+    cands = [[1.0, 1.0], [0.3, 3.0], [3.0, 0.3], [1.0, 30.0]]     # distinct RATIOS: a common factor is absorbed by normalpha
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 2, 5))
+    model = lc.BandedNestedCVModel("ridge_regression")
+    m, W, a = model.fit_predict_search(X, Y, bands, cands, **kw)
+    det = {}
+    mo, Wo, ao = oband.fit_predict_search(X, Y, bands, cands, detail=det, **kw)
+    A = len(kw["alphas"])
+    got_idx = model.last_fold_candidates * A + np.stack([np.searchsorted(kw["alphas"].astype(np.float32), fa)
+                                                         for fa in model.last_fold_alphas])
+    want_idx = det["fold_candidates"] * A + np.stack([np.searchsorted(kw["alphas"].astype(np.float32), fa)
+                                                      for fa in det["fold_alphas"]])
+    same = np.all(got_idx == want_idx, axis=0)
+    for f, v in zip(*np.nonzero(got_idx != want_idx)):     # a flip must be a near tie of the oracle's own table
+        tab = det["fold_tables"][f][:, v]
+        assert abs(tab[got_idx[f, v]] - tab[want_idx[f, v]]) <= 2e-6, (f, v, tab[got_idx[f, v]], tab[want_idx[f, v]])
+    assert same.mean() >= 0.9, f"only {same.mean():.3f} of the voxels chose like the oracle"
+    assert len(np.unique(model.last_fold_candidates)) >= 3            # the search did choose among the candidates
+    np.testing.assert_allclose(np.asarray(m["correlations"], dtype=np.float64)[same],
+                               np.asarray(mo["correlations"], dtype=np.float64)[same], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(W[:, same], Wo[:, same], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(a[same], ao[same], rtol=1e-6)
+    assert m.keys() == mo.keys()
+    # one candidate = the fixed-scale model
+    m1, W1, a1 = model.fit_predict_search(X, Y, bands, [cands[1]], **kw)
+    # (form="dual" like the search: "auto" would take the p x p form for this tall design -- exact solves, while the
+    # dual refit goes through explicit inverses with their stated 2^-21 / alpha error, 1e-5 in W at alpha = 0.1)
+    m2, W2, a2 = lc.BandedNestedCVModel("ridge_regression", form="dual").fit_predict(X, Y, bands=bands, band_scales=cands[1],
+                                                                                      **kw)
+    np.testing.assert_allclose(np.asarray(m1["correlations"]), np.asarray(m2["correlations"]), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(W1, W2, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(a1, a2)
+
+
 # ------------------------------------------------------------------ trainer-side structuring (SURVEY 8f row 1)
 def test_story_structuring_matches_reference_trainer(lc, golden_dir):
     """FIR -> trim -> zs -> stack on the device against captures of the reference's own

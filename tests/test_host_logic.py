@@ -246,3 +246,29 @@ def test_minimax_inverse_polynomial():
     # the engine's membership rule at cfg2: 4 terms serve every alpha >= 7.85 of logspace(-1, 8, 20)
     al = np.logspace(-1, 8, 20)
     assert [i for i, a in enumerate(al) if series.residual_bound(a, 4) <= 2e-9] == list(range(4, 20))
+
+
+def test_oracle_banded_search_reduces_to_the_plain_fit():
+    """oracle/banded.py (the self-defined search over band scales) with ONE candidate of unit scales is the reference
+    algorithm's full nested CV; with one non-trivial candidate it is the fit on the rescaled design with the weights
+    mapped back to the original features."""
+    import oracle.banded as oband
+    import oracle.nested_cv as onc
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((90, 12))
+    Y = X @ (rng.standard_normal((12, 9)) * 0.3) + rng.standard_normal((90, 9))
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 2, 4))
+    bands = [(0, 5), (5, 12)]
+    m0, W0, a0 = onc.fit_predict(X, Y, **kw)
+    m1, W1, a1 = oband.fit_predict_search(X, Y, bands, [[1.0, 1.0]], **kw)
+    np.testing.assert_allclose(W1, W0, rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(a1, a0)
+    np.testing.assert_allclose(m1["correlations"], m0["correlations"], rtol=0, atol=1e-7)
+    g = np.r_[np.full(5, 0.5), np.full(7, 3.0)]
+    m2, W2, a2 = onc.fit_predict(X / g, Y, **kw)
+    m3, W3, a3 = oband.fit_predict_search(X, Y, bands, [[0.5, 3.0]], **kw)
+    np.testing.assert_allclose(W3, W2 / g[:, None], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(a3, a2)
+    det = {}
+    oband.fit_predict_search(X, Y, bands, [[1.0, 1.0], [0.5, 3.0]], detail=det, **kw)
+    assert det["fold_candidates"].shape == (3, 9) and det["fold_tables"].shape == (3, 8, 9)

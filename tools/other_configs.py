@@ -55,3 +55,26 @@ for name, args, alphas in (
     print(f"{name}: {1e3 * dt:.0f} ms = {V / dt:.0f} voxels/s, median score {m['median_score']:.4f}, all finite: {ok}", flush=True)
     del dX, dY, W
     torch.cuda.empty_cache()
+
+if not only or any("search" in o for o in only):
+    # cfg5's shape with a SEARCH over band scales (three candidates): every candidate is a pass of the inner CV
+    import time as _t
+    from litcoder_core_amd import BandedNestedCVModel
+    rng = np.random.default_rng(3)
+    T, F0, V = 3000, 1280, 80000
+    Xh = ops.fir_delay(torch.from_numpy(rng.standard_normal((T, F0))).to(dev), [1, 2, 3, 4, 5, 6], False).cpu().numpy()
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    Wd = 0.02 * torch.randn((Xh.shape[1], V), generator=g, device=dev, dtype=torch.float32)
+    Wd[3840:, : V // 2] = 0
+    Yh = (torch.from_numpy(Xh).to(dev, torch.float32) @ Wd + torch.randn((T, V), generator=g, device=dev)).cpu().numpy()
+    del Wd
+    bm = BandedNestedCVModel("ridge_regression")
+    args = (Xh, Yh, [(0, 3840), (3840, 7680)], [[1.0, 1.0], [1.0, 4.0], [4.0, 1.0]])
+    skw = dict(folding_type="kfold", n_outer_folds=5, n_inner_folds=5, alphas=np.logspace(-1, 8, 32))
+    bm.fit_predict_search(*args, **skw)
+    torch.cuda.synchronize(); t = _t.perf_counter()
+    m, W, a = bm.fit_predict_search(*args, **skw)
+    torch.cuda.synchronize(); dt = _t.perf_counter() - t
+    share = [float((bm.last_fold_candidates == c).mean()) for c in range(3)]
+    print(f"cfg5-like with a search over 3 band-scale candidates (host arrays in, host weights out): {1e3 * dt:.0f} ms = "
+          f"{V / dt:.0f} voxels/s, median score {m['median_score']:.4f}, candidate shares {share}", flush=True)

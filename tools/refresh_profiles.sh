@@ -1,31 +1,34 @@
-# Regenerates the round artefacts kept under profiles/ (run on the GPU box: gpurun -- bash tools/refresh_profiles.sh);
-# outputs land in gpurun_out/r02_final/ and are copied into profiles/ by hand.
+# Regenerates the round artefacts kept under profiles/ (run on the GPU box: gpurun -- bash tools/refresh_profiles.sh [tag]);
+# outputs land in gpurun_out/<tag>_final/ and are copied into profiles/ by hand (see profiles/README.md).
 set -x
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02_final
+O=$R/gpurun_out/${TAG}_final
 mkdir -p $O
 python3 $R/bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs > $O/bench_under_rocprof.json 2> /dev/null
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   D=/tmp/pmc_$(echo $C | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-legs > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -- python3 $R/tools/resident_fit_loop.py 2 > /dev/null 2>&1
 done
 python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "k_sweep_f16x3<true" $O/sweep_fused_pmc.json > /dev/null
-python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "k_sweep_f16x3<false" $O/sweep_plain_pmc.json > /dev/null
+python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "k_sweep_f16x3<false, false, true, true" $O/sweep_series_pmc.json > /dev/null
+python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "k_sweep_f16x3<false, false, false, false" $O/sweep_plain_pmc.json > /dev/null
 for K in k_mm64q k_lstep k_bstep k_potrf_diag; do
   python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "$K" $O/chol_${K}_pmc.json > /dev/null
 done
+rocprofv3 --kernel-trace --output-format csv -d /tmp/p_res -- python3 $R/tools/resident_fit_loop.py 3 > $O/resident_fits.txt 2>&1
+python3 $R/tools/queue_timeline.py $(find /tmp/p_res -name "*kernel_trace.csv" | head -1) 30 > $O/resident_queue_timeline.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/p_host -- python3 $R/tools/host_fit_loop.py 3 > $O/host_fits.txt 2>&1
+python3 $R/tools/queue_timeline.py $(find /tmp/p_host -name "*kernel_trace.csv" | head -1) 30 > $O/host_queue_timeline.txt 2>&1
 python3 $R/tools/gpu_kernel_bench.py sweep sweep16 stamps plain16 series lanczos chol hbm > $O/kernel_microbench.txt 2>&1
 python3 $R/tools/chol_ab.py > $O/chol_fused_ab.txt 2>&1
 python3 $R/tools/scaling_model.py 80000 > $O/scaling_model.json 2> $O/scaling_model.err
 python3 $R/tools/main_stream_events.py 80000 8 0 > $O/device_timeline_rank0_of_8.txt 2>&1
-python3 $R/tools/main_stream_events.py 640000 8 0 > $O/device_timeline_weak_rank0_of_8.txt 2>&1
 python3 $R/tools/main_stream_events.py 80000 > $O/device_timeline_1gpu.txt 2>&1
-python3 $R/tools/host_timeline.py 80000 8 0 > $O/host_timeline_rank0_of_8.txt 2>&1
+python3 $R/tools/host_path_timeline.py > $O/host_path_timeline.txt 2>&1
 python3 $R/tools/other_configs.py > $O/other_configs.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cfg1 -o cfg1 -- python3 $R/tools/other_configs.py cfg1 > /dev/null 2>&1 < /dev/null
-python3 $R/tools/kstats.py /tmp/prof_cfg1 40 > $O/cfg1_kernel_stats.txt 2>&1 < /dev/null
 python3 $R/tools/kstats.py /tmp/prof_stats 60 > $O/bench_kernel_stats.txt 2>&1 < /dev/null
 ls -la $O
