@@ -353,9 +353,11 @@ int lc_batch_chol_inverse(double* d_aug, int B, int N, double* d_linv, float* d_
  *   outer_block  columns per outer block of the two-level blocking (a multiple of LC_NB; default 512)
  *   big_kernel   kernel of the deep updates: 2 = 4x4x4 fp64 MFMA (default), 1 = vector ALU, 0 = 16x16x4 fp64 MFMA
  *   fused_steps  1 (default) = fused left-looking 64-column steps, 0 = the first version's panel + update launches
- *   left_deep    1 = the deep updates left-looking too (measured: no gain), 0 (default) = right-looking */
+ *   left_deep    1 = the deep updates left-looking too (measured: no gain), 0 (default) = right-looking
+ *   persistent   bit 0 (default on): the steps of the back substitution inside an outer block as ONE launch (a row tile's
+ *                steps depend on no other workgroup); 0 = one launch per step */
 typedef struct lc_chol_options {
-    int outer_block, big_kernel, fused_steps, left_deep;
+    int outer_block, big_kernel, fused_steps, left_deep, persistent;
 } lc_chol_options;
 int lc_batch_chol_solve_opt(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,
                             int32_t* d_info, const lc_chol_options* opt, lc_stream_t stream);

@@ -704,12 +704,11 @@ __global__ void __launch_bounds__(256, 3) k_lstep(double* __restrict__ aug, int 
     }
 }
 
-__global__ void __launch_bounds__(256, 3) k_bstep(double* __restrict__ aug, int N, int M, int k, int K1,
-                                                  const double* __restrict__ linv) {
-    __shared__ double sA[NB * MM_LD], sB[NB * MM_LD], sC[NB * ST_LDC];
+// one 64-row tile of the bottom block, one step of the back substitution (see k_lstep's header)
+__device__ inline void bstep_tile(double* __restrict__ aug, int N, int M, int k, int K1, const double* __restrict__ linv,
+                                  int tile, int b, double* sA, double* sB, double* sC) {
     const int R = N + M, nb = N / NB;
-    const int b = blockIdx.y;
-    const int r0 = blockIdx.x * NB, a_rows = min(NB, M - r0);
+    const int r0 = tile * NB, a_rows = min(NB, M - r0);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
     double* Ab = aug + (long long)b * R * N;
@@ -732,6 +731,37 @@ __global__ void __launch_bounds__(256, 3) k_bstep(double* __restrict__ aug, int 
     tile_mac<false, true>(acc, sC, 0, a_rows, Lk, NB, NB, sA, sB);
     double* dst = Zrow + k * NB;
     LC_FOR_TILE(i, j) if (LC_TILE_ROW(i) < a_rows) dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] = acc[i][j];
+}
+
+__global__ void __launch_bounds__(256, 3) k_bstep(double* __restrict__ aug, int N, int M, int k, int K1,
+                                                  const double* __restrict__ linv) {
+    __shared__ double sA[NB * MM_LD], sB[NB * MM_LD], sC[NB * ST_LDC];
+    bstep_tile(aug, N, M, k, K1, linv, blockIdx.x, blockIdx.y, sA, sB, sC);
+}
+
+// All the steps of an outer block in ONE launch (round 3): a row tile's steps only read what the SAME workgroup wrote
+// in its earlier steps (its own rows of H) besides L and Linv, which are final -- no dependency between workgroups, so
+// the chain of K1 - K0 dependent launches (each waiting its turn beside the sweeps' workgroups in a busy fit) becomes a
+// loop.  Between steps: every wave's stores have reached L2 (vmcnt), then ONE wave invalidates the CU's L1 -- the
+// line of block column k+1 was read (old value) before this workgroup overwrote it -- and a barrier releases the rest.
+// inverse: row tile r works on block columns k >= r only (the block-upper triangle).
+__global__ void __launch_bounds__(256, 3) k_bsteps(double* __restrict__ aug, int N, int M, int K0, int K1,
+                                                   const double* __restrict__ linv, int inverse) {
+    __shared__ double sA[NB * MM_LD], sB[NB * MM_LD], sC[NB * ST_LDC];
+    const int tile = blockIdx.x;
+    for (int k = K1 - 1; k >= K0; --k) {
+        if (inverse && tile > k) break;
+        bstep_tile(aug, N, M, k, K1, linv, tile, blockIdx.y, sA, sB, sC);
+        if (k > K0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+    }
 }
 #undef LC_TILE_ROW
 #undef LC_TILE_COL
@@ -777,7 +807,7 @@ __global__ void __launch_bounds__(256) k_extract_sym(const double* __restrict__ 
 // or the first version's three launches per step; the deep updates left-looking too (one product of the full depth per
 // block column: measured, no gain -- the deep-update kernel is not bound by its C read-modify-write -- and less parallel
 // for small batches).  No process-wide switches: two fits with different settings coexist in one process.
-static lc_chol_options chol_defaults() { return lc_chol_options{512, 2, 1, 0}; }
+static lc_chol_options chol_defaults() { return lc_chol_options{512, 2, 1, 0, 1}; }
 
 // inverse: the bottom block is the N x N identity and only the block-upper triangle of  I (top)^-1  is formed -- the
 // rows of the product are independent, row tile r of Z = I L^-T is zero left of block column r, and row tile r of the
@@ -902,7 +932,13 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
             g.row0 = g.col0 = 0; g.tri = 0; g.subtract = 1;
             launch_big<false>(g, B, s, o.big_kernel);
         }
-        for (int k = K1 - 1; k >= K0; --k) {
+        if (fused && (o.persistent & 1)) {
+            // every step of the outer block in one launch (k_bsteps); inverse: row tiles 0 .. K1-1 at most
+            const int rt = inverse ? min(M / NB, K1) : lc::ceil_div(M, NB);
+            hipLaunchKernelGGL(k_bsteps, dim3((unsigned)rt, (unsigned)B), dim3(256), 0, s, d_aug, N, M, K0, K1, d_linv,
+                               inverse ? 1 : 0);
+        }
+        for (int k = K1 - 1; k >= K0 && !(fused && (o.persistent & 1)); --k) {
             if (fused) {
                 // inverse: only row tiles 0 .. k of block column k (the block-upper triangle)
                 const int rt = inverse ? min(M / NB, k + 1) : lc::ceil_div(M, NB);

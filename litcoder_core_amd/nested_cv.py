@@ -86,6 +86,7 @@ class FitOptions:
     chol_big_kernel: int = 2                # ... deep updates: 2 = 4x4x4 fp64 MFMA, 1 = vector ALU, 0 = 16x16x4 MFMA
     chol_fused_steps: bool = True           # ... fused left-looking 64-column steps
     chol_left_deep: bool = False            # ... deep updates left-looking too (measured: no gain)
+    chol_persistent: int = 1                # ... bit 0: the back substitution's steps of an outer block in one launch
     lanczos_mfma: bool = True               # lc_lambda_max_masked: the matvec on the fp64 MFMA
 
 
@@ -281,7 +282,7 @@ class RidgeCVEngine:
         background thread while the fit is being set up) or resident targets (_DeviceShapes)."""
         self.opt = dataclasses.replace(options) if options is not None else FitOptions()    # this engine's own copy
         self._chol_opt = ops.chol_options(self.opt.chol_outer_block, self.opt.chol_big_kernel, self.opt.chol_fused_steps,
-                                          self.opt.chol_left_deep)
+                                          self.opt.chol_left_deep, self.opt.chol_persistent)
         self.spectral = check_penalties(alphas, singcutoff, normalpha)
         self.singcutoff = float(singcutoff)
         self.dev = ops.device()

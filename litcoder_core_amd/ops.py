@@ -579,11 +579,11 @@ def masked_stream(mask_words):
 class CholOptions(ctypes.Structure):
     """lc_chol_options of include/litcoder_hip.h: per-call variants of the batched Cholesky (defaults: 512, 2, 1, 0)."""
     _fields_ = [("outer_block", ctypes.c_int), ("big_kernel", ctypes.c_int), ("fused_steps", ctypes.c_int),
-                ("left_deep", ctypes.c_int)]
+                ("left_deep", ctypes.c_int), ("persistent", ctypes.c_int)]
 
 
-def chol_options(outer_block=512, big_kernel=2, fused_steps=True, left_deep=False):
-    return CholOptions(int(outer_block), int(big_kernel), int(bool(fused_steps)), int(bool(left_deep)))
+def chol_options(outer_block=512, big_kernel=2, fused_steps=True, left_deep=False, persistent=1):
+    return CholOptions(int(outer_block), int(big_kernel), int(bool(fused_steps)), int(bool(left_deep)), int(persistent))
 
 
 def batch_chol_solve(aug, B, N, M, h, slot=None, options=None):

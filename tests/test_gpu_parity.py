@@ -407,6 +407,26 @@ def test_batch_chol_solve_against_fp64_solves(lc):
             outs.append(h.cpu().numpy())
         for o_ in outs[1:]:
             np.testing.assert_allclose(o_, outs[0], rtol=0, atol=1e-6 * np.abs(outs[0]).max())
+        # the back substitution's steps as one launch per outer block (default) or one launch per step: the same bits,
+        # solve and inverse, several outer blocks, many repetitions (a stale L1 line between the steps would show here)
+        for B, N, M, inv in ((3, 1216, 224, False), (2, 1216, 1216, True), (5, 640, 96, False)):
+            rng2 = np.random.default_rng(N + M)
+            aug = np.empty((B, N + M, N))
+            for b in range(B):
+                x = rng2.standard_normal((N, N + 8))
+                aug[b, :N] = x @ x.T / N + 0.1 * np.eye(N)
+                aug[b, N:] = np.eye(N) if inv else rng2.standard_normal((M, N))
+            res = []
+            for pers in (0, 1, 1, 1):
+                h = torch.empty((B, M, N), dtype=torch.float32, device=dev)
+                opt = ops.chol_options(outer_block=256, persistent=pers)
+                d = torch.from_numpy(aug).to(dev)
+                info = (ops.batch_chol_inverse(d, B, N, h, options=opt) if inv else
+                        ops.batch_chol_solve(d, B, N, M, h, options=opt))
+                assert not info.cpu().numpy().any()
+                res.append(h.cpu().numpy())
+            for r_ in res[1:]:
+                assert np.array_equal(r_, res[0]), (B, N, M, inv)
 
 
 def test_series_moments_match_per_alpha_hat_matrices(lc):
