@@ -574,7 +574,7 @@ constexpr int ST_LDC = NB + 2;     // row stride of the C tile in LDS
 // fragments (LDS broadcast reads), 4 B fragments and 16 MFMAs with tied AGPR accumulators.  A_LDS: A is a 64 x 64 tile
 // already in LDS (row stride ST_LDC) and depth == 64.
 template <bool BT, bool A_LDS>
-__device__ inline void tile_mac(double (&acc)[4][4], const double* A, long long lda, int a_rows,
+__device__ __forceinline__ void tile_mac(double (&acc)[4][4], const double* A, long long lda, int a_rows,
                                 const double* B, long long ldb, int depth, double* sA, double* sB) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -705,7 +705,7 @@ __global__ void __launch_bounds__(256, 3) k_lstep(double* __restrict__ aug, int 
 }
 
 // one 64-row tile of the bottom block, one step of the back substitution (see k_lstep's header)
-__device__ inline void bstep_tile(double* __restrict__ aug, int N, int M, int k, int K1, const double* __restrict__ linv,
+__device__ __forceinline__ void bstep_tile(double* __restrict__ aug, int N, int M, int k, int K1, const double* __restrict__ linv,
                                   int tile, int b, double* sA, double* sB, double* sC) {
     const int R = N + M, nb = N / NB;
     const int r0 = tile * NB, a_rows = min(NB, M - r0);

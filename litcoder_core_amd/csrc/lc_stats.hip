@@ -267,25 +267,38 @@ __global__ void __launch_bounds__(64 * PR_RG) k_pearson_cols(const float* __rest
     }
 }
 
-// The same sums with the column's rows held in REGISTERS (n <= PR_RG * RPT rows: one pass over the operands instead of
+// The same sums with the column's rows held in REGISTERS (n <= PQ_RG * RPT rows: one pass over the operands instead of
 // two -- the second pass of the kernel above misses L2: 64 columns x 600 rows x 2 operands per workgroup, 1250
 // workgroups), and with operand a optionally read THROUGH a row list and a column list (the test rows of the
-// alpha-sorted voxels straight from the resident targets: no gathered copy).  Same summation order per thread, same
-// block reduction: the same bits as k_pearson_cols on the gathered copy.
+// alpha-sorted voxels straight from the resident targets: no gathered copy).  Block = 32 columns x 32 row groups: a
+// thread keeps at most 20 rows of each operand (40 rows per thread at 16 row groups spilled 128 VGPRs to scratch and ran
+// no faster than the two-pass kernel).  fp64 sums, two-pass formula on the registers, fixed reduction order.
+constexpr int PQ_C = 32, PQ_RG = 32;
+
+__device__ inline double block_colsum32(double v, double (*sm)[PQ_C]) {
+    sm[threadIdx.y][threadIdx.x] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll 4
+    for (int g = 0; g < PQ_RG; ++g) t += sm[g][threadIdx.x];
+    __syncthreads();
+    return t;
+}
+
 template <int RPT>
-__global__ void __launch_bounds__(64 * PR_RG) k_pearson_cols_regs(const float* __restrict__ a, long long lda,
-                                                                  const int* __restrict__ a_rows, const int* __restrict__ a_cols,
-                                                                  const float* __restrict__ b, long long ldb, long long n,
-                                                                  long long V, double* __restrict__ r_out) {
-    __shared__ double sm[PR_RG][64];
-    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(PQ_C * PQ_RG) k_pearson_cols_regs(const float* __restrict__ a, long long lda,
+                                                                    const int* __restrict__ a_rows, const int* __restrict__ a_cols,
+                                                                    const float* __restrict__ b, long long ldb, long long n,
+                                                                    long long V, double* __restrict__ r_out) {
+    __shared__ double sm[PQ_RG][PQ_C];
+    const int ty = threadIdx.y;
+    const long long c = (long long)blockIdx.x * PQ_C + threadIdx.x;
     const bool live = c < V;
     const long long ca = live ? (a_cols ? (long long)a_cols[c] : c) : -1;
     float va[RPT], vb[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const long long i = ty + (long long)k * PR_RG;
+        const long long i = ty + (long long)k * PQ_RG;
         va[k] = 0.f;
         vb[k] = 0.f;
         if (live && i < n) {
@@ -297,28 +310,35 @@ __global__ void __launch_bounds__(64 * PR_RG) k_pearson_cols_regs(const float* _
     double sa = 0.0, sb = 0.0;
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
-        if (ty + (long long)k * PR_RG < n) { sa += (double)va[k]; sb += (double)vb[k]; }
-    const double ma = block_colsum<PR_RG>(sa, sm) / (double)n;
-    const double mb = block_colsum<PR_RG>(sb, sm) / (double)n;
+        if (ty + (long long)k * PQ_RG < n) { sa += (double)va[k]; sb += (double)vb[k]; }
+    const double ma = block_colsum32(sa, sm) / (double)n;
+    const double mb = block_colsum32(sb, sm) / (double)n;
     double qa = 0.0, qb = 0.0, qab = 0.0;
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
-        if (ty + (long long)k * PR_RG < n) {
+        if (ty + (long long)k * PQ_RG < n) {
             const double da = (double)va[k] - ma;
             const double db = (double)vb[k] - mb;
             qa += da * da;
             qb += db * db;
             qab += da * db;
         }
-    qa = block_colsum<PR_RG>(qa, sm);
-    qb = block_colsum<PR_RG>(qb, sm);
-    qab = block_colsum<PR_RG>(qab, sm);
+    qa = block_colsum32(qa, sm);
+    qb = block_colsum32(qb, sm);
+    qab = block_colsum32(qab, sm);
     if (live && ty == 0) {
         double r = qab / (sqrt(qa) * sqrt(qb));
         if (r > 1.0) r = 1.0;
         if (r < -1.0) r = -1.0;
         r_out[c] = r;
     }
+}
+
+template <int RPT>
+void launch_pearson_regs(const float* a, long long lda, const int* rows, const int* cols, const float* b, long long ldb,
+                         long long n, long long V, double* r, hipStream_t s) {
+    hipLaunchKernelGGL(k_pearson_cols_regs<RPT>, dim3((unsigned)lc::ceil_div<long long>(V, PQ_C)), dim3(PQ_C, PQ_RG), 0, s, a,
+                       lda, rows, cols, b, ldb, n, V, r);
 }
 
 // ------------------------------------------------------------------ Pearson p-values
@@ -676,15 +696,13 @@ extern "C" int lc_pearson_cols(const float* d_a, int64_t lda, const float* d_b, 
     LC_REQUIRE(n > 0 && V >= 0 && lda >= V && ldb >= V, LC_E_SHAPE, "lc_pearson_cols: bad shape");
     if (V == 0) return LC_OK;
     lc::ScopedTimer timer_(lc::T_PEARSON, lc::as_stream(stream));
-    const dim3 grid((unsigned)lc::ceil_div<long long>(V, 64)), block(64, PR_RG);
-    if (n <= PR_RG * 16)
-        hipLaunchKernelGGL(k_pearson_cols_regs<16>, grid, block, 0, lc::as_stream(stream), d_a, (long long)lda, nullptr, nullptr,
-                           d_b, (long long)ldb, (long long)n, (long long)V, d_r);
-    else if (n <= PR_RG * 40)
-        hipLaunchKernelGGL(k_pearson_cols_regs<40>, grid, block, 0, lc::as_stream(stream), d_a, (long long)lda, nullptr, nullptr,
-                           d_b, (long long)ldb, (long long)n, (long long)V, d_r);
+    if (n <= PQ_RG * 8)
+        launch_pearson_regs<8>(d_a, lda, nullptr, nullptr, d_b, ldb, n, V, d_r, lc::as_stream(stream));
+    else if (n <= PQ_RG * 20)
+        launch_pearson_regs<20>(d_a, lda, nullptr, nullptr, d_b, ldb, n, V, d_r, lc::as_stream(stream));
     else
-        hipLaunchKernelGGL(k_pearson_cols, grid, block, 0, lc::as_stream(stream), d_a, lda, d_b, ldb, n, V, d_r);
+        hipLaunchKernelGGL(k_pearson_cols, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, PR_RG), 0,
+                           lc::as_stream(stream), d_a, lda, d_b, ldb, n, V, d_r);
     return lc::launched("k_pearson_cols");
 }
 
@@ -692,17 +710,14 @@ extern "C" int lc_pearson_cols_gather(const float* d_y, int64_t ld_y, const int3
                                       const float* d_b, int64_t ldb, int64_t n, int64_t V, double* d_r,
                                       lc_stream_t stream) {
     LC_REQUIRE(d_y && d_b && d_r && d_rows, LC_E_BADARG, "lc_pearson_cols_gather: null pointer");
-    LC_REQUIRE(n > 0 && n <= PR_RG * 40 && V >= 0 && ldb >= V, LC_E_SHAPE,
-               "lc_pearson_cols_gather: 1 <= n <= %d rows", PR_RG * 40);
+    LC_REQUIRE(n > 0 && n <= PQ_RG * 20 && V >= 0 && ldb >= V, LC_E_SHAPE,
+               "lc_pearson_cols_gather: 1 <= n <= %d rows", PQ_RG * 20);
     if (V == 0) return LC_OK;
     lc::ScopedTimer timer_(lc::T_PEARSON, lc::as_stream(stream));
-    const dim3 grid((unsigned)lc::ceil_div<long long>(V, 64)), block(64, PR_RG);
-    if (n <= PR_RG * 16)
-        hipLaunchKernelGGL(k_pearson_cols_regs<16>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ld_y, d_rows, d_cols,
-                           d_b, (long long)ldb, (long long)n, (long long)V, d_r);
+    if (n <= PQ_RG * 8)
+        launch_pearson_regs<8>(d_y, ld_y, d_rows, d_cols, d_b, ldb, n, V, d_r, lc::as_stream(stream));
     else
-        hipLaunchKernelGGL(k_pearson_cols_regs<40>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ld_y, d_rows, d_cols,
-                           d_b, (long long)ldb, (long long)n, (long long)V, d_r);
+        launch_pearson_regs<20>(d_y, ld_y, d_rows, d_cols, d_b, ldb, n, V, d_r, lc::as_stream(stream));
     return lc::launched("k_pearson_cols_regs");
 }
 
