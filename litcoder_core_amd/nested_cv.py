@@ -67,8 +67,9 @@ class FitOptions:
     primal_max_p: int = 512                 # the primal (p x p) form is taken for tall designs up to this many features
     speculate_first_fold: bool = True       # the first fold's refit systems for every factorised alpha, beside its chain
     refit_from_image: bool = True           # the refit's alpha-sorted fp16 operand gathered out of the inner CV's image
-    panel_cols: int = 24576                 # voxel columns per panel of a host-to-host fit (_column_panels): 96 column tiles
-                                            # x 8 M-tiles of the sweeps = exactly 3 rounds of workgroups on 256 CUs
+    panel_cols: int = 36864                 # voxel columns per panel of a host-to-host fit (_column_panels): 12 288 / 24 576 /
+                                            # 30 720 / 12 416 at cfg2 (measured 144.1 ms against 145.2 for 24 576-wide panels,
+                                            # 145.2 for 73 728, 151.6 without panels)
     panel_min_cols: int = 16384             # below twice this many voxels a fit is not cut into panels
     tail_panels_geometric: bool = True      # the end of a host-to-host fit in few panels of falling width (_download_panels)
     tail_folds: int = 2                     # ... spread over this many folds, voxel-major (plan_steps)
