@@ -47,32 +47,35 @@ class ModelSaver:
             pickle.dump(metrics, f)
         return run_dir
 
+    # ---- readers (own structure; the WRITTEN layout above is what SURVEY 8f-4 asks for, these are conveniences with the
+    # reference's names and return shapes: utils.py:352-414)
+    @staticmethod
+    def _read_run(run_dir: Path, want_weights: bool):
+        """(hyperparams, metrics, weights or None) of one run directory."""
+        hyper = json.loads((run_dir / "hyperparams.json").read_text())
+        metrics = pickle.loads((run_dir / "metrics.pkl").read_bytes())
+        weights = np.load(run_dir / "weights.npy") if want_weights else None
+        return hyper, metrics, weights
+
     def load_encoding_model(self, run_dir: Union[str, Path]) -> Tuple[np.ndarray, np.ndarray, Dict[str, Any],
                                                                      Dict[str, Any]]:
+        """(weights, best_alphas, hyperparams, metrics) of a run saved with ``save_weights=True``."""
         run_dir = Path(run_dir)
-        weights = np.load(run_dir / "weights.npy")
-        with open(run_dir / "hyperparams.json", "r") as f:
-            hyperparams = json.load(f)
-        with open(run_dir / "metrics.pkl", "rb") as f:
-            metrics = pickle.load(f)
-        alphas_file = run_dir / "best_alphas.npy"
-        best_alphas = np.load(alphas_file) if alphas_file.exists() else np.asarray(metrics["best_alphas"])
-        return weights, best_alphas, hyperparams, metrics
+        hyper, metrics, weights = self._read_run(run_dir, want_weights=True)
+        stored = run_dir / "best_alphas.npy"           # the reference reads this file but never writes it (see above)
+        alphas = np.load(stored) if stored.exists() else np.asarray(metrics["best_alphas"])
+        return weights, alphas, hyper, metrics
 
     def list_runs(self) -> List[Dict[str, Any]]:
-        runs = []
-        for run_dir in self.base_dir.glob("run_*"):
-            if not run_dir.is_dir():
-                continue
+        """One record per readable ``run_*`` directory, newest first; an unreadable run is reported and left out."""
+        records = []
+        for run_dir in sorted((d for d in self.base_dir.glob("run_*") if d.is_dir()),
+                              key=lambda d: d.name.split("_")[1], reverse=True):
             try:
-                with open(run_dir / "hyperparams.json", "r") as f:
-                    hyperparams = json.load(f)
-                with open(run_dir / "metrics.pkl", "rb") as f:
-                    metrics = pickle.load(f)
-                runs.append({"run_dir": str(run_dir), "timestamp": run_dir.name.split("_")[1],
-                             "hyperparams": hyperparams, "metrics": metrics})
-            except Exception as e:  # the reference prints and skips unreadable runs (utils.py:405-407)
-                print(f"Error loading run {run_dir}: {e}")
+                hyper, metrics, _ = self._read_run(run_dir, want_weights=False)
+            except Exception as exc:  # noqa: BLE001 -- utils.py:405-407 prints and goes on
+                print(f"Error loading run {run_dir}: {exc}")
                 continue
-        runs.sort(key=lambda x: x["timestamp"], reverse=True)
-        return runs
+            records.append(dict(run_dir=str(run_dir), timestamp=run_dir.name.split("_")[1], hyperparams=hyper,
+                                metrics=metrics))
+        return records

@@ -79,7 +79,7 @@ def test_cfg2_full_size_properties(lc):
     assert np.array_equal(W_b, W[:, lo:hi])
 
 
-def test_cfg3_story_pipeline_train_test(lc):
+def test_cfg3_synthetic_lebel_like_story_pipeline_train_test(lc):
     """LeBel-UTS03-like end to end: per story, word-level 768-d features at irregular word times -> Lanczos resampling
     to the TR grid (lc_lanczos_interp) -> 4 FIR delays (p = 3072) -> trim + per-story z-scoring -> stories[:-1] train
     / last story tests -> nested-CV fit in train/test mode with single_alpha (example.py:104-117), V = 8192, resident on
