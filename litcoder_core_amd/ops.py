@@ -672,8 +672,12 @@ def bh_fdr(p, alpha):
 def bh_reject(p, alpha):
     """The Benjamini-Hochberg rejection mask alone ((n,) uint8, input order): no sort, no adjusted p-values."""
     n = p.numel()
+    nbytes = int(_lib.load().lc_bh_reject_work_bytes(n))
+    if nbytes < 0:
+        raise ValueError("bh_reject: bad length")
+    work = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
     reject = torch.empty(n, dtype=torch.uint8, device=p.device)
-    _lib.call("lc_bh_reject", _p(p), n, float(alpha), _p(reject), _s())
+    _lib.call("lc_bh_reject", _p(p), n, float(alpha), _p(reject), _p(work), nbytes, _s())
     return reject
 
 

@@ -632,6 +632,17 @@ def test_device_statistics_tail_matches_host(lc):  # noqa: C901
             # the sort-free rejection mask (the per-fold masks of a cross-validated fit): element for element the same
             only = ops.bh_reject(torch.from_numpy(p).to(dev), alpha)
             np.testing.assert_array_equal(only.cpu().numpy().astype(bool), rej_h, err_msg=f"mask only, n={n} alpha={alpha}")
+    # p-values that hug the BH line from above: the counting iteration falls one step at a time, the capped kernel hands
+    # over to the sort-based path -- same mask
+    for n, k in ((5000, 0), (5000, 37), (70000, 1200)):
+        alpha = 0.05
+        p = (np.arange(1, n + 1) + 0.5) * alpha / n
+        p[:k] = 1e-9 * np.arange(1, k + 1)
+        p = rng.permutation(np.minimum(p, 1.0))
+        rej_h, _ = stats.fdrcorrection(p, alpha=alpha)
+        assert rej_h.sum() == k
+        only = ops.bh_reject(torch.from_numpy(p).to(dev), alpha)
+        np.testing.assert_array_equal(only.cpu().numpy().astype(bool), rej_h, err_msg=f"hugging the line, n={n} k={k}")
     for p in (np.full(50, 0.9), np.zeros(9), np.array([0.01, 0.02, 0.03, 0.5]), np.array([1.0])):   # nothing / everything passes
         for alpha in (0.05, 0.04):
             rej_h, _ = stats.fdrcorrection(p, alpha=alpha)
