@@ -170,7 +170,13 @@ extern "C" int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* cons
             rc = lc::fail(LC_E_SHAPE, "lc_upload_start: job %d: bad shape, or a row of the panel does not fit a staging slot", j);
             break;
         }
-        const int64_t step = slot_bytes / (w * 4);
+        // rows per chunk: what fits a staging slot, but no more than the job's share per thread -- the design (3000 x 3072)
+        // fitted three 16 MB slots, so only three threads cast it (2.4 ms at the head of every fit); chunks stay >= 1 MB
+        int64_t step = slot_bytes / (w * 4);
+        const int64_t share = (b.rows + u->n_threads - 1) / (u->n_threads > 0 ? u->n_threads : 1);
+        const int64_t floor_rows = ((1 << 20) + w * 4 - 1) / (w * 4);
+        if (share < step) step = share > floor_rows ? share : (floor_rows < step ? floor_rows : step);
+        if (step < 1) step = 1;
         for (int64_t r0 = 0; r0 < b.rows; r0 += step) {
             u->chunks.push_back({j, r0, r0 + step < b.rows ? r0 + step : b.rows});
             ++u->chunks_left[j];
