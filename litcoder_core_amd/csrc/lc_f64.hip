@@ -167,11 +167,16 @@ __global__ void __launch_bounds__(256) k_lz_symv(const double* __restrict__ Kmat
     if (lane == 0) w[i] = s;
 }
 
+// Sum over the 1024 threads of a block, every thread gets it: butterfly inside the waves, the 16 wave sums through LDS
+// in fixed order (two barriers; the tree through LDS it replaces had eleven -- this kernel is 128 dependent launches of a
+// Lanczos run and nothing but latency).
 __device__ inline double block_sum_1024(double x, double* red) {
-    red[threadIdx.x] = x;
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-    const double t = red[0];
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
     __syncthreads();
     return t;
 }

@@ -73,6 +73,7 @@ class FitOptions:
     panel_min_cols: int = 16384             # below twice this many voxels a fit is not cut into panels
     tail_panels_geometric: bool = True      # the end of a host-to-host fit in few panels of falling width (_download_panels)
     tail_folds: int = 2                     # ... spread over this many folds, voxel-major (plan_steps)
+    refit_ahead_behind_hat_batch: bool = False     # host inputs: the later folds' refit inverses behind their hat-matrix batch
     resident_refit_batch: bool = True       # resident inputs: refit inverses of folds 1.. as one batch after fold 0's choice
     shard_first_sweeps_before_batch: bool = False  # voxel shards: fold 0's sweeps queued before the other folds' batch
                                             # (measured: 38.7 vs 38.5 ms per rank of 8 -- no gain): off
@@ -1868,7 +1869,7 @@ class RidgeCVEngine:
         on one GPU when they come from explicit inverses (N^3 flops each) and the grid has only a few such alphas."""
         return bool(self.cho) and len(self.cho) <= 8 and not self.primal and self._refit_by_inverse(self.cho)
 
-    def refit_ahead(self, states, alphas=None):
+    def refit_ahead(self, states, alphas=None, after_hat=False):
         """Voxel shards: the refit systems of ALL the given (prepared) folds for ALL factorised alphas in one
         collective batch, before any alpha is chosen.  With W ranks a rank's share of a fold's handful of systems is a
         chain of ~N/64 dependent steps either way (latency, not flops), and solving them fold by fold after each
@@ -1882,8 +1883,9 @@ class RidgeCVEngine:
             return
         N_o = sts[0]["tr_o"].shape[-1]
         rs_stream = self.aux2
-        for st in sts:                                 # not behind the folds' hat-matrix batches: beside them
-            rs_stream.wait_event(st.get("ids_ready") or st["done"])
+        for st in sts:                                 # not behind the folds' hat-matrix batches: beside them (default)
+            rs_stream.wait_event(st["done"] if (after_hat and st.get("done") is not None)
+                                 else (st.get("ids_ready") or st["done"]))
         with torch.cuda.stream(rs_stream):
             rhss = [self._refit_rhs(st["X"], st["K"], st["tr"], st["tr_o"], st["te"]) for st in sts]
             rows = rhss[0].shape[0]
@@ -2508,7 +2510,7 @@ class NestedCVModel(BasePredictivityModel):
                 # of a grid, typically) costs an N^3 inverse per fold; one that turns up later is solved then
                 defer_ahead = ahead and hosted and shard.world == 1 and n > 1 and drv_opt.refit_ahead_after_first_choice
                 if ahead and not defer_ahead:
-                    eng.refit_ahead(prepared[1:])
+                    eng.refit_ahead(prepared[1:], after_hat=hosted and drv_opt.refit_ahead_behind_hat_batch)
                 if not early_begin:
                     st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
             else:
