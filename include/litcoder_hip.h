@@ -555,11 +555,9 @@ int lc_bh_fdr(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, dou
  * cross-validated fit, nested_cv.py:263-290: only they enter the majority vote): kmax = max{i : p_(i) <= (i/n) alpha} is the
  * largest fixed point of c -> #{p <= (c/n) alpha}, reached from c = n by a few counting passes; d_reject[i] =
  * p[i] <= (kmax / n) alpha.  Element for element the mask lc_bh_fdr returns.  The iteration is capped (48 passes:
- * p-values that hug the BH line from above make it fall one step at a time); past the cap the sort-based path runs in
- * d_work (lc_bh_reject_work_bytes), its kernels returning at once otherwise. */
-int64_t lc_bh_reject_work_bytes(int64_t n);
-int lc_bh_reject(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, void* d_work, int64_t work_bytes,
-                 lc_stream_t stream);
+ * p-values that hug the BH line from above make it fall one step at a time): *d_status = 0 and the mask is written, or
+ * *d_status = 1 and it is not -- the caller then runs lc_bh_fdr on that vector. */
+int lc_bh_reject(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, int32_t* d_status, lc_stream_t stream);
 
 /* Diagnostics only (tools/gpu_kernel_bench.py stamps): the fp16x3 sweep with s_memtime stamps at its phase
  * boundaries; d_stamps (32 x uint64, caller-zeroed) receives per wave-group sums of the five segments of an

@@ -99,8 +99,7 @@ SIGNATURES = {
     "lc_fisher_combine": (c_int, [_ptr, c_int, c_int64, _ptr, _ptr]),
     "lc_bh_fdr_work_bytes": (c_int64, [c_int64]),
     "lc_bh_fdr": (c_int, [_ptr, c_int64, c_double, _ptr, _ptr, _ptr, c_int64, _ptr]),
-    "lc_bh_reject_work_bytes": (c_int64, [c_int64]),
-    "lc_bh_reject": (c_int, [_ptr, c_int64, c_double, _ptr, _ptr, c_int64, _ptr]),
+    "lc_bh_reject": (c_int, [_ptr, c_int64, c_double, _ptr, _ptr, _ptr]),
     "lc_fill_bytes": (c_int, [_ptr, c_int, c_int64, _ptr]),
     "lc_gather_sub_f32_strided": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, c_int64, c_int64, c_int64,
                                           _ptr]),

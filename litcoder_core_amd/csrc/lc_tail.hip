@@ -44,11 +44,9 @@ __device__ inline unsigned long long rs_key(const double* __restrict__ keys, lon
     return (unsigned long long)__double_as_longlong(keys[i]);
 }
 
-// (`enable`: optional device flag; 0 = the whole sort is skipped -- lc_bh_reject's fallback, see below)
 __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const double* __restrict__ keys, long long n, int shift,
-                                                        int* __restrict__ hist, int nblk, const int* __restrict__ enable) {
+                                                        int* __restrict__ hist, int nblk) {
     __shared__ int h[RS_BINS];
-    if (enable && !*enable) return;
     if (threadIdx.x < RS_BINS) h[threadIdx.x] = 0;
     __syncthreads();
     const long long base = (long long)blockIdx.x * RS_TILE + (long long)threadIdx.x * RS_ITEMS;
@@ -64,11 +62,9 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const double* __restrict
 }
 
 // exclusive scan of hist (RS_BINS x nblk, digit-major) in place; *trivial = 1 when one digit holds all n keys
-__global__ void __launch_bounds__(1024) k_rs_scan(int* __restrict__ hist, int nblk, long long n, int* __restrict__ trivial,
-                                                  const int* __restrict__ enable) {
+__global__ void __launch_bounds__(1024) k_rs_scan(int* __restrict__ hist, int nblk, long long n, int* __restrict__ trivial) {
     __shared__ int part[1024];
     __shared__ int carry, triv;
-    if (enable && !*enable) return;
     const int t = threadIdx.x, total = RS_BINS * nblk;
     if (t == 0) { carry = 0; triv = 0; }
     __syncthreads();
@@ -101,9 +97,8 @@ __global__ void __launch_bounds__(1024) k_rs_scan(int* __restrict__ hist, int nb
 __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const double* __restrict__ keys_in, const int* __restrict__ vals_in,
                                                            long long n, int shift, const int* __restrict__ offs, int nblk,
                                                            const int* __restrict__ trivial, double* __restrict__ keys_out,
-                                                           int* __restrict__ vals_out, const int* __restrict__ enable) {
-    __shared__ int cnt[RS_BINS * RS_THREADS];
-    if (enable && !*enable) return;        // [digit][thread]: keys of that digit the thread holds
+                                                           int* __restrict__ vals_out) {
+    __shared__ int cnt[RS_BINS * RS_THREADS];        // [digit][thread]: keys of that digit the thread holds
     __shared__ int tot[RS_THREADS];
     const int t = threadIdx.x;
     const long long base = (long long)blockIdx.x * RS_TILE + (long long)t * RS_ITEMS;
@@ -181,10 +176,8 @@ __device__ inline void bh_element(const double* __restrict__ ps, long long i, lo
 }
 
 __global__ void __launch_bounds__(BH_THREADS) k_bh_block_min(const double* __restrict__ ps, long long n, double alpha,
-                                                             double* __restrict__ bmin, long long* __restrict__ blast,
-                                                             const int* __restrict__ enable) {
+                                                             double* __restrict__ bmin, long long* __restrict__ blast) {
     __shared__ double smin[BH_THREADS / 64];
-    if (enable && !*enable) return;
     __shared__ long long smax[BH_THREADS / 64];
     const int t = threadIdx.x;
     double q;
@@ -210,10 +203,8 @@ __global__ void __launch_bounds__(BH_THREADS) k_bh_block_min(const double* __res
 __global__ void __launch_bounds__(BH_THREADS) k_bh_apply(const double* __restrict__ ps, const int* __restrict__ order,
                                                          long long n, double alpha, const double* __restrict__ bmin,
                                                          const long long* __restrict__ blast, int nb,
-                                                         unsigned char* __restrict__ reject, double* __restrict__ padj,
-                                                         const int* __restrict__ enable) {
+                                                         unsigned char* __restrict__ reject, double* __restrict__ padj) {
     __shared__ double scan[2][BH_THREADS];
-    if (enable && !*enable) return;
     __shared__ double smin[BH_THREADS / 64];
     __shared__ long long smax[BH_THREADS / 64];
     const int t = threadIdx.x, b = blockIdx.x;
@@ -266,8 +257,9 @@ __global__ void __launch_bounds__(BH_THREADS) k_bh_apply(const double* __restric
 // over values that sit in L2: the per-fold masks of a cross-validated fit (only they enter its majority vote) cost
 // ~0.1 ms instead of a 16-pass radix sort each.  The iteration is geometric on real p-values, but p-values that hug the
 // BH line from above (p_(i) ~ (i + 1/2) alpha / n) make it fall one step at a time: after BH_REJECT_MAX_PASSES passes
-// without a fixed point *status is set and the caller's sort-based path runs instead (its kernels return at once when
-// *status is 0), so the worst case is the sort's ~2 ms, not n passes.
+// without a fixed point *status is set to 1 and the mask is left unwritten: the caller then takes the sort-based path
+// (lc_bh_fdr) for that vector, so the worst case is the sort's ~2 ms, not n passes.  (Queueing the sort's 50 launches
+// behind every call with an early exit was measured: each still waits ~35 us for a CU beside the sweeps.)
 constexpr int BH_REJECT_MAX_PASSES = 48;
 __global__ void __launch_bounds__(1024) k_bh_reject(const double* __restrict__ p, long long n, double alpha,
                                                     unsigned char* __restrict__ reject, int* __restrict__ status) {
@@ -321,8 +313,12 @@ extern "C" int64_t lc_bh_fdr_work_bytes(int64_t n) {
                      lc::ceil_div<int64_t>(n, BH_THREADS) * 16 + 64);
 }
 
-static int bh_fdr_impl(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, double* d_padj, void* d_work,
-                       const int* d_enable, hipStream_t s) {
+extern "C" int lc_bh_fdr(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, double* d_padj, void* d_work,
+                         int64_t work_bytes, lc_stream_t stream) {
+    LC_REQUIRE(d_p && d_reject && d_padj && d_work, LC_E_BADARG, "lc_bh_fdr: null pointer");
+    LC_REQUIRE(n > 0 && n < (1ll << 31), LC_E_SHAPE, "lc_bh_fdr: bad length");
+    LC_REQUIRE(work_bytes >= lc_bh_fdr_work_bytes(n), LC_E_SHAPE, "lc_bh_fdr: workspace too small (lc_bh_fdr_work_bytes)");
+    hipStream_t s = lc::as_stream(stream);
     char* w = static_cast<char*>(d_work);
     const size_t ints = bh_ints(n);
     const int nblk = (int)lc::ceil_div<int64_t>(n, RS_TILE);
@@ -340,49 +336,26 @@ static int bh_fdr_impl(const double* d_p, int64_t n, double alpha, uint8_t* d_re
     const int* vin = nullptr;
     for (int pass = 0; pass < 16; ++pass) {
         const int out = (pass + 1) & 1;
-        hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nblk), dim3(RS_THREADS), 0, s, kin, (long long)n, 4 * pass, hist, nblk,
-                           d_enable);
-        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, s, hist, nblk, (long long)n, trivial, d_enable);
+        hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nblk), dim3(RS_THREADS), 0, s, kin, (long long)n, 4 * pass, hist, nblk);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, s, hist, nblk, (long long)n, trivial);
         hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nblk), dim3(RS_THREADS), 0, s, kin, vin, (long long)n, 4 * pass, hist,
-                           nblk, trivial, kbuf[out], vbuf[out], d_enable);
+                           nblk, trivial, kbuf[out], vbuf[out]);
         kin = kbuf[out];
         vin = vbuf[out];
     }
     if (int rc = lc::launched("radix sort")) return rc;
     const double* keys = kbuf[0];
     const int* order = vbuf[0];
-    hipLaunchKernelGGL(k_bh_block_min, dim3((unsigned)nb), dim3(BH_THREADS), 0, s, keys, (long long)n, alpha, bmin, blast,
-                       d_enable);
+    hipLaunchKernelGGL(k_bh_block_min, dim3((unsigned)nb), dim3(BH_THREADS), 0, s, keys, (long long)n, alpha, bmin, blast);
     hipLaunchKernelGGL(k_bh_apply, dim3((unsigned)nb), dim3(BH_THREADS), 0, s, keys, order, (long long)n, alpha, bmin, blast, nb,
-                       d_reject, d_padj, d_enable);
+                       d_reject, d_padj);
     return lc::launched("k_bh_apply");
 }
 
-extern "C" int lc_bh_fdr(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, double* d_padj, void* d_work,
-                         int64_t work_bytes, lc_stream_t stream) {
-    LC_REQUIRE(d_p && d_reject && d_padj && d_work, LC_E_BADARG, "lc_bh_fdr: null pointer");
-    LC_REQUIRE(n > 0 && n < (1ll << 31), LC_E_SHAPE, "lc_bh_fdr: bad length");
-    LC_REQUIRE(work_bytes >= lc_bh_fdr_work_bytes(n), LC_E_SHAPE, "lc_bh_fdr: workspace too small (lc_bh_fdr_work_bytes)");
-    return bh_fdr_impl(d_p, n, alpha, d_reject, d_padj, d_work, nullptr, lc::as_stream(stream));
-}
-
-// workspace of lc_bh_reject: the sort's + n doubles (adjusted p-values of the fallback, discarded) + the status word
-extern "C" int64_t lc_bh_reject_work_bytes(int64_t n) {
-    const int64_t base = lc_bh_fdr_work_bytes(n);
-    return base < 0 ? -1 : base + n * 8 + 64;
-}
-
-extern "C" int lc_bh_reject(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, void* d_work, int64_t work_bytes,
+extern "C" int lc_bh_reject(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, int32_t* d_status,
                             lc_stream_t stream) {
-    LC_REQUIRE(d_p && d_reject && d_work, LC_E_BADARG, "lc_bh_reject: null pointer");
+    LC_REQUIRE(d_p && d_reject && d_status, LC_E_BADARG, "lc_bh_reject: null pointer");
     LC_REQUIRE(n > 0 && n < (1ll << 31), LC_E_SHAPE, "lc_bh_reject: bad length");
-    LC_REQUIRE(work_bytes >= lc_bh_reject_work_bytes(n), LC_E_SHAPE, "lc_bh_reject: workspace too small (lc_bh_reject_work_bytes)");
-    hipStream_t s = lc::as_stream(stream);
-    char* w = static_cast<char*>(d_work);
-    const int64_t base = lc_bh_fdr_work_bytes(n);
-    double* padj = reinterpret_cast<double*>(w + base);
-    int* status = reinterpret_cast<int*>(w + base + n * 8);
-    hipLaunchKernelGGL(k_bh_reject, dim3(1), dim3(1024), 0, s, d_p, (long long)n, alpha, d_reject, status);
-    if (int rc = lc::launched("k_bh_reject")) return rc;
-    return bh_fdr_impl(d_p, n, alpha, d_reject, padj, d_work, status, s);      // runs only when *status != 0
+    hipLaunchKernelGGL(k_bh_reject, dim3(1), dim3(1024), 0, lc::as_stream(stream), d_p, (long long)n, alpha, d_reject, d_status);
+    return lc::launched("k_bh_reject");
 }

@@ -2167,8 +2167,9 @@ class RidgeCVEngine:
                             self.p_folds[fold_no], dbad)
             # the fold's BH-FDR: a cross-validated fit only takes the rejection MASKS of its folds (their majority vote,
             # nested_cv.py:283-290) -- no sort, no adjusted p-values (lc_bh_reject); a train/test fit returns both
+            stat_d = None
             if self.n_folds > 1:
-                rej_d, padj_d = ops.bh_reject(self.p_folds[fold_no], self.alpha_fdr), None
+                (rej_d, stat_d), padj_d = ops.bh_reject(self.p_folds[fold_no], self.alpha_fdr, want_status=True), None
             else:
                 rej_d, padj_d = ops.bh_fdr(self.p_folds[fold_no], self.alpha_fdr)
             # results leave through pinned buffers so the copies do not stall the host
@@ -2177,7 +2178,8 @@ class RidgeCVEngine:
             h_rej = torch.empty(Vt, dtype=torch.uint8, pin_memory=True)
             h_padj = torch.empty(Vt, dtype=torch.float64, pin_memory=True) if padj_d is not None else None
             h_bad = torch.empty(2, dtype=torch.int32, pin_memory=True)
-            for h, d in ((h_res, dres), (h_idx, didx), (h_rej, rej_d), (h_padj, padj_d), (h_bad, dbad)):
+            h_stat = torch.empty(1, dtype=torch.int32, pin_memory=True) if stat_d is not None else None
+            for h, d in ((h_res, dres), (h_idx, didx), (h_rej, rej_d), (h_padj, padj_d), (h_bad, dbad), (h_stat, stat_d)):
                 if h is not None:
                     h.copy_(d, non_blocking=True)
             done = torch.cuda.Event()
@@ -2187,8 +2189,8 @@ class RidgeCVEngine:
                 t.record_stream(self.comm)
         del self._fold_blk[fold_no]
         self.results_ready = done
-        return dict(done=done, res=h_res, idx=h_idx, n_t=n_t, bad=h_bad, rej=h_rej, padj=h_padj,
-                    keep=(dres, didx, dbad, rej_d, padj_d, gathered))
+        return dict(done=done, res=h_res, idx=h_idx, n_t=n_t, bad=h_bad, rej=h_rej, padj=h_padj, stat=h_stat, fold=fold_no,
+                    keep=(dres, didx, dbad, rej_d, padj_d, gathered, stat_d))
 
     def fold_refit(self, st, single_alpha, weight_scale):
         return self.fold_finish(self.fold_select(st, single_alpha), weight_scale)
@@ -2202,7 +2204,12 @@ class RidgeCVEngine:
         if int(pend["bad"][1]):
             raise RuntimeError("Cholesky failed in the refit: Gram matrix + alpha^2 I is not positive definite")
         res = pend["res"].numpy()
-        sig = (pend["rej"].numpy().astype(bool), None if pend["padj"] is None else pend["padj"].numpy().copy())
+        rej = pend["rej"].numpy().astype(bool)
+        if pend.get("stat") is not None and int(pend["stat"][0]):
+            # the counting iteration of lc_bh_reject hit its cap (p-values hugging the BH line): the sort-based routine, now
+            with torch.cuda.stream(self.comm):
+                rej = ops.bh_fdr(self.p_folds[pend["fold"]], self.alpha_fdr)[0].cpu().numpy().astype(bool)
+        sig = (rej, None if pend["padj"] is None else pend["padj"].numpy().copy())
         return _FoldResult(res[0].copy(), res[1].copy(), pend["idx"].numpy().copy(), pend["n_t"], sig)
 
     def combined_significance(self):
@@ -2510,7 +2517,8 @@ class NestedCVModel(BasePredictivityModel):
                 # of a grid, typically) costs an N^3 inverse per fold; one that turns up later is solved then
                 defer_ahead = ahead and hosted and shard.world == 1 and n > 1 and drv_opt.refit_ahead_after_first_choice
                 if ahead and not defer_ahead:
-                    eng.refit_ahead(prepared[1:], after_hat=hosted and drv_opt.refit_ahead_behind_hat_batch)
+                    eng.refit_ahead(prepared[1:], **({"after_hat": True} if (hosted and drv_opt.refit_ahead_behind_hat_batch)
+                                                      else {}))
                 if not early_begin:
                     st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
             else:

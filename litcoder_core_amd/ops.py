@@ -669,15 +669,19 @@ def bh_fdr(p, alpha):
     return reject, padj
 
 
-def bh_reject(p, alpha):
-    """The Benjamini-Hochberg rejection mask alone ((n,) uint8, input order): no sort, no adjusted p-values."""
+def bh_reject(p, alpha, want_status=False):
+    """The Benjamini-Hochberg rejection mask alone ((n,) uint8, input order): no sort, no adjusted p-values.  The
+    counting iteration is capped; ``want_status``: return (mask, status (1,) int32 device) without a host round trip --
+    status != 0 means the mask was NOT written and the caller must take ``bh_fdr`` for this vector.  Otherwise the
+    status is read here (a synchronisation) and the sort-based path is taken when needed."""
     n = p.numel()
-    nbytes = int(_lib.load().lc_bh_reject_work_bytes(n))
-    if nbytes < 0:
-        raise ValueError("bh_reject: bad length")
-    work = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
     reject = torch.empty(n, dtype=torch.uint8, device=p.device)
-    _lib.call("lc_bh_reject", _p(p), n, float(alpha), _p(reject), _p(work), nbytes, _s())
+    status = torch.empty(1, dtype=torch.int32, device=p.device)
+    _lib.call("lc_bh_reject", _p(p), n, float(alpha), _p(reject), _p(status), _s())
+    if want_status:
+        return reject, status
+    if int(status.cpu()[0]):
+        reject = bh_fdr(p, alpha)[0]
     return reject
 
 
