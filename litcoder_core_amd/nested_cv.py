@@ -74,6 +74,7 @@ class FitOptions:
     tail_panels_geometric: bool = True      # the end of a host-to-host fit in few panels of falling width (_download_panels)
     tail_folds: int = 2                     # ... spread over this many folds, voxel-major (plan_steps)
     refit_ahead_behind_hat_batch: bool = False     # host inputs: the later folds' refit inverses behind their hat-matrix batch
+    series_lookahead: bool = True           # the next step's first sweep part queued before a step's fused sweeps (driver)
     resident_refit_batch: bool = True       # resident inputs: refit inverses of folds 1.. as one batch after fold 0's choice
     shard_first_sweeps_before_batch: bool = False  # voxel shards: fold 0's sweeps queued before the other folds' batch
                                             # (measured: 38.7 vs 38.5 ms per rank of 8 -- no gain): off
@@ -874,55 +875,61 @@ class RidgeCVEngine:
         return dict(F=F, N=N, M=M, n_v=n_v, n_i=n_i, tr=tr, va=va, shared=self._shared_image(inner_abs, N), Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
                     d_ser=d_ser, moments=moments, series_ready=series_ready, imgs=imgs)
 
-    def _sweeps(self, hat, Y, done=None):
+    def _sweeps(self, hat, Y, done=None, split_phase=False):
         """Sum over inner folds of the (A, Vp) validation scores (ridge_corr_torch for every fold,
         nested_cv.py:366-393): the V-wide fused MFMA sweeps, plus -- with ``hat["moments"]`` -- one plain
         contraction of the shared series terms and the moment kernel for the alphas on the series.  ``done``: event
         after which the hat matrices are complete; the series part only waits for ``hat["series_ready"]`` and
-        runs first, so the main stream has work while the auxiliary stream is still in the Cholesky chains."""
+        runs first, so the main stream has work while the auxiliary stream is still in the Cholesky chains.
+        ``split_phase``: queue only that first part now and return a callable that queues the rest (the fused sweeps
+        behind ``done``) and returns the scores -- the driver puts the NEXT step's first part in between, so that the
+        main stream has V-wide work while it waits for a fold's Cholesky chains (the range the phases work on is
+        captured here: the engine's current range may have moved on when the callable runs)."""
+        Vp_, V_ = self.Vp, self.V
         if hat.get("no_inner"):
             # no inner fold of this outer fold has validation rows: the reference scores every alpha 0 for every voxel
             # (z_score of an empty block -> NaN -> nan_to_num, ridge_regression.py:124-133) and its first-maximum
             # argmax takes alphas[0]
-            scores = ops.zeros((self.A, self.Vp), torch.float32, self.dev)
+            scores = ops.zeros((self.A, Vp_), torch.float32, self.dev)
             self.info.update(precision="f16x3" if hat["split"] else "f32", fused_alphas=0, series_terms=0)
             self.sweeps_done = torch.cuda.Event()
             self.sweeps_done.record()
-            return scores
+            return (lambda: scores) if split_phase else scores
         if self.primal:
-            return self._sweeps_primal(hat, Y, done)
+            out = self._sweeps_primal(hat, Y, done)
+            return (lambda: out) if split_phase else out
         A, N, M, tr, va, n_v = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"]
         F = hat["F"]
         moments, cho = hat["moments"], hat["cho"]
         Ad = len(cho) if moments else A                   # alphas that go through the fused sweep
         main = torch.cuda.current_stream()
-        scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
+        scores = torch.empty((A, Vp_), dtype=torch.float32, device=self.dev)
         cho_first = list(cho) == list(range(len(cho)))     # ascending grids: the factorised alphas are rows 0 .. Ad-1
         scores_d = scores
         if moments and Ad:
-            scores_d = scores[:Ad] if cho_first else torch.empty((Ad, self.Vp), dtype=torch.float32, device=self.dev)
-        part = torch.empty((max(Ad, 1) * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
+            scores_d = scores[:Ad] if cho_first else torch.empty((Ad, Vp_), dtype=torch.float32, device=self.dev)
+        part = torch.empty((max(Ad, 1) * M // LC_MB, 4, Vp_), dtype=torch.float32, device=self.dev)
         split, cs = hat["split"], hat["cs"]
         if hat.get("data_ready") is not None:
             main.wait_event(hat["data_ready"])            # this fold's (normalised) targets and their column scales
         self.info.update(precision="f16x3" if split else "f32", fused_alphas=Ad,
                           series_terms=SERIES_TERMS if moments else 0, folds_per_launch=1)
         nbuf = F if moments else 1                        # two passes over the folds keep every fold's operands
-        ystat = torch.empty((nbuf, 3, self.Vp), dtype=torch.float32, device=self.dev)
-        yblk = torch.empty((nbuf, M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
-        yv = torch.empty((nbuf, M, self.Vp), dtype=torch.float32, device=self.dev)
+        ystat = torch.empty((nbuf, 3, Vp_), dtype=torch.float32, device=self.dev)
+        yblk = torch.empty((nbuf, M // LC_MB, Vp_), dtype=torch.float32, device=self.dev)
+        yv = torch.empty((nbuf, M, Vp_), dtype=torch.float32, device=self.dev)
         shared = hat.get("shared") if split else None
         if split:
             rows_pad = ops.pad_to(max(Ad, 1) * M, 256)
             Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
             rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
-            Vt = ops.pad_to(self.Vp, 256)
+            Vt = ops.pad_to(Vp_, 256)
             if shared is not None:
                 # the targets of the whole outer training set split once; every inner fold contracts it minus one
                 # aligned block (B view): saves F - 1 passes over Y per outer fold
                 union, gaps = shared
                 Yu = torch.empty(Vt * len(union) * 2, dtype=torch.float16, device=self.dev)
-                ops.split_cols_f16(Y, self.Vp, ops.idx_tensor(union, len(union), self.dev), len(union), cs, Yu)
+                ops.split_cols_f16(Y, Vp_, ops.idx_tensor(union, len(union), self.dev), len(union), cs, Yu)
                 Yt = [Yu] * nbuf
                 views = [(len(union), g0, gl) for g0, gl in gaps]
                 hat["image"] = (Yu, union)                # the refit permutes its operand out of it (_refit_operands)
@@ -933,100 +940,115 @@ class RidgeCVEngine:
         # the operators' fp16 images made with the hat matrices (_hat_matrices), per chunk: fold f0 + j is group j
         imgs = hat.get("imgs") or [None] * len(hat["Hs"])
         img_of = {f0 + j: (im, j) for (f0, fc, _, _), im in zip(hat["Hs"], imgs) if im is not None for j in range(fc)}
-        if moments:
-            # ---- pass 1: validation statistics, operand split, series contraction + moment kernel
-            Tm, rowmap, slab_light = self._series_layout(M)
-            fused = slab_light is None                   # layout of the moments epilogue: the terms are never stored
-            # all inner folds in ONE launch per pass (stacked A images, one shared target image with a gap per fold):
-            # the folds are independent, and one launch fills the chip where F small ones each end in a partial round
-            # of workgroups -- at 10 000 voxels per rank (8 GPUs) a fold's launch is 1.25 rounds
-            merged = fused and shared is not None and F <= 64 and self.opt.folds_in_one_launch
-            nst = F if merged else 1
-            tp = ops.pad_to(Tm, 256)
-            Pt = torch.empty(nst * tp * N * 2, dtype=torch.float16, device=self.dev)
-            rs_p = torch.empty(nst * tp, dtype=torch.float32, device=self.dev)
-            if fused:
-                part_s = torch.empty((nst, M // LC_MB, 18, self.Vp), dtype=torch.float32, device=self.dev)
-            else:
-                Tbuf = torch.empty((Tm, Vt), dtype=torch.float32, device=self.dev)
-            cs_inv = self._cs_inv_padded(cs, Vt)                               # padded to the plain GEMM's tiles
-            if hat.get("series_ready") is not None:
-                main.wait_event(hat["series_ready"])
-            # validation statistics of all inner folds in one launch (the blocks are independent)
-            for f0 in range(0, F, 64):
-                f1 = min(F, f0 + 64)
-                ops.val_stats_folds(Y, self.Vp, va[f0:f1], f1 - f0, M, n_v[f0:f1], ystat[f0:f1], yblk[f0:f1], yv[f0:f1])
-            if merged:
-                for f0, fc, H, P in hat["Hs"]:           # the folds' terms follow one another in P: one split per chunk
-                    ops.split_rows_f16_groups(P.view(-1, N), fc, Tm, N, Pt[f0 * tp * N * 2:], rs_p[f0 * tp:])
-                for f in range(F):
-                    self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
-                self.info["plain_launches"] += 1
-                ops.series_sweep_scores_f16x3_folds(Pt, rs_p, M, n_v, N, Yu, cs_inv, Vt, yv, self.Vp, ystat, yblk,
-                                                    self.d_coef, hat["d_ser"], part_s, scores, False, views)
-            for f, j, H, P in (() if merged else folds):
-                if shared is None:
-                    ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[f])
-                Pt_f, rs_p_f = Pt, rs_p
-                if f in img_of:
-                    im, g = img_of[f]
-                    Pt_f, rs_p_f = im["Pt"][g * im["tp"] * N * 2:], im["rs_p"][g * im["tp"]:]
-                else:
-                    ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
-                self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * self.V
-                self.info["plain_launches"] += 1
+        merged, fused = False, False
+        Pt = rs_p = part_s = Tbuf = cs_inv = rowmap = slab_light = Tm = None
+
+        def series_part():
+            nonlocal merged, fused, Pt, rs_p, part_s, Tbuf, cs_inv, rowmap, slab_light, Tm
+            if moments:
+                # ---- pass 1: validation statistics, operand split, series contraction + moment kernel
+                Tm, rowmap, slab_light = self._series_layout(M)
+                fused = slab_light is None                   # layout of the moments epilogue: the terms are never stored
+                # all inner folds in ONE launch per pass (stacked A images, one shared target image with a gap per fold):
+                # the folds are independent, and one launch fills the chip where F small ones each end in a partial round
+                # of workgroups -- at 10 000 voxels per rank (8 GPUs) a fold's launch is 1.25 rounds
+                merged = fused and shared is not None and F <= 64 and self.opt.folds_in_one_launch
+                nst = F if merged else 1
+                tp = ops.pad_to(Tm, 256)
+                Pt = torch.empty(nst * tp * N * 2, dtype=torch.float16, device=self.dev)
+                rs_p = torch.empty(nst * tp, dtype=torch.float32, device=self.dev)
                 if fused:
-                    ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], N, Yt[f], cs_inv, Vt, yv[f], self.Vp, ystat[f], yblk[f],
-                                                  self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0,
-                                                  bview=views[f])
-                    continue
-                ops.gemm_grouped_f16x3(Pt_f, rs_p_f, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
-                                       bview=views[f])
-                ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], self.Vp, yv[f], ystat[f], self.d_coef, hat["d_ser"],
-                                  scores, accumulate=f > 0, rowmap=rowmap)
-        if done is not None:
-            main.wait_event(done)
-        # ---- pass 2 (the only one without the moment path): fused sweeps of the alphas that have hat matrices
-        if moments and merged and Ad:
-            Ht = torch.empty(F * rows_pad * N * 2, dtype=torch.float16, device=self.dev)
-            rs_inv = torch.empty(F * rows_pad, dtype=torch.float32, device=self.dev)
-            part = torch.empty((F, Ad * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
-            for f0, fc, H, P in hat["Hs"]:
-                ops.split_rows_f16_groups(H.view(-1, N), fc, Ad * M, N, Ht[f0 * rows_pad * N * 2:], rs_inv[f0 * rows_pad:])
-            ops.alpha_sweep_scores_f16x3_folds(Ht, rs_inv, Ad, M, N, Yu, cs[self.Vp:], yv, self.Vp, n_v, ystat, yblk, self.mode,
-                                               part, scores_d, False, views)
-            self.info["fused_flops"] += sum(2.0 * Ad * n_v[f] * hat["n_i"][f] * self.V for f in range(F))
-            self.info["fused_launches"] += 1
-            self.info["folds_per_launch"] = F
-        for f, j, H, P in (() if (moments and merged) else folds):
-            b = f if moments else 0
-            if not moments:
-                ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat[b], yblk[b], yv[b])
-            if split:
-                if not moments and shared is None:
-                    ops.split_cols_f16(Y, self.Vp, tr[f], N, cs, Yt[b])
-                if Ad:
-                    self.info["fused_flops"] += 2.0 * Ad * n_v[f] * hat["n_i"][f] * self.V
-                    self.info["fused_launches"] += 1
-                    Ht_f, rs_h_f = Ht, rs_inv
-                    if moments and f in img_of and img_of[f][0]["Ht"] is not None:
+                    part_s = torch.empty((nst, M // LC_MB, 18, Vp_), dtype=torch.float32, device=self.dev)
+                else:
+                    Tbuf = torch.empty((Tm, Vt), dtype=torch.float32, device=self.dev)
+                cs_inv = self._cs_inv_padded(cs, Vt)                               # padded to the plain GEMM's tiles
+                if hat.get("series_ready") is not None:
+                    main.wait_event(hat["series_ready"])
+                # validation statistics of all inner folds in one launch (the blocks are independent)
+                for f0 in range(0, F, 64):
+                    f1 = min(F, f0 + 64)
+                    ops.val_stats_folds(Y, Vp_, va[f0:f1], f1 - f0, M, n_v[f0:f1], ystat[f0:f1], yblk[f0:f1], yv[f0:f1])
+                if merged:
+                    for f0, fc, H, P in hat["Hs"]:           # the folds' terms follow one another in P: one split per chunk
+                        ops.split_rows_f16_groups(P.view(-1, N), fc, Tm, N, Pt[f0 * tp * N * 2:], rs_p[f0 * tp:])
+                    for f in range(F):
+                        self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * V_
+                    self.info["plain_launches"] += 1
+                    ops.series_sweep_scores_f16x3_folds(Pt, rs_p, M, n_v, N, Yu, cs_inv, Vt, yv, Vp_, ystat, yblk,
+                                                        self.d_coef, hat["d_ser"], part_s, scores, False, views)
+                for f, j, H, P in (() if merged else folds):
+                    if shared is None:
+                        ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[f])
+                    Pt_f, rs_p_f = Pt, rs_p
+                    if f in img_of:
                         im, g = img_of[f]
-                        Ht_f, rs_h_f = im["Ht"][g * im["hp"] * N * 2:], im["rs_h"][g * im["hp"]:]
+                        Pt_f, rs_p_f = im["Pt"][g * im["tp"] * N * 2:], im["rs_p"][g * im["tp"]:]
                     else:
-                        ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
-                    ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, N, Yt[b], cs[self.Vp:], yv[b], self.Vp, n_v[f], ystat[b],
-                                                 yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f])
-            else:
-                self.info["fused_flops"] += 2.0 * A * n_v[f] * hat["n_i"][f] * self.V
+                        ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
+                    self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * V_
+                    self.info["plain_launches"] += 1
+                    if fused:
+                        ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], N, Yt[f], cs_inv, Vt, yv[f], Vp_, ystat[f], yblk[f],
+                                                      self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0,
+                                                      bview=views[f])
+                        continue
+                    ops.gemm_grouped_f16x3(Pt_f, rs_p_f, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
+                                           bview=views[f])
+                    ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], Vp_, yv[f], ystat[f], self.d_coef, hat["d_ser"],
+                                      scores, accumulate=f > 0, rowmap=rowmap)
+
+        def fused_part():
+            nonlocal Ht, rs_inv, part
+            if done is not None:
+                main.wait_event(done)
+            # ---- pass 2 (the only one without the moment path): fused sweeps of the alphas that have hat matrices
+            if moments and merged and Ad:
+                Ht = torch.empty(F * rows_pad * N * 2, dtype=torch.float16, device=self.dev)
+                rs_inv = torch.empty(F * rows_pad, dtype=torch.float32, device=self.dev)
+                part = torch.empty((F, Ad * M // LC_MB, 4, Vp_), dtype=torch.float32, device=self.dev)
+                for f0, fc, H, P in hat["Hs"]:
+                    ops.split_rows_f16_groups(H.view(-1, N), fc, Ad * M, N, Ht[f0 * rows_pad * N * 2:], rs_inv[f0 * rows_pad:])
+                ops.alpha_sweep_scores_f16x3_folds(Ht, rs_inv, Ad, M, N, Yu, cs[Vp_:], yv, Vp_, n_v, ystat, yblk, self.mode,
+                                                   part, scores_d, False, views)
+                self.info["fused_flops"] += sum(2.0 * Ad * n_v[f] * hat["n_i"][f] * V_ for f in range(F))
                 self.info["fused_launches"] += 1
-                ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, self.Vp, tr[f], yv[b], n_v[f], ystat[b], yblk[b],
-                                       self.mode, part, scores, accumulate=f > 0)
-        if moments and Ad and not cho_first:
-            for i, a in enumerate(cho):
-                scores[a].copy_(scores_d[i])
-        self.sweeps_done = torch.cuda.Event()
-        self.sweeps_done.record()
-        return scores
+                self.info["folds_per_launch"] = F
+            for f, j, H, P in (() if (moments and merged) else folds):
+                b = f if moments else 0
+                if not moments:
+                    ops.val_stats(Y, Vp_, va[f], M, n_v[f], ystat[b], yblk[b], yv[b])
+                if split:
+                    if not moments and shared is None:
+                        ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[b])
+                    if Ad:
+                        self.info["fused_flops"] += 2.0 * Ad * n_v[f] * hat["n_i"][f] * V_
+                        self.info["fused_launches"] += 1
+                        Ht_f, rs_h_f = Ht, rs_inv
+                        if moments and f in img_of and img_of[f][0]["Ht"] is not None:
+                            im, g = img_of[f]
+                            Ht_f, rs_h_f = im["Ht"][g * im["hp"] * N * 2:], im["rs_h"][g * im["hp"]:]
+                        else:
+                            ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
+                        ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, N, Yt[b], cs[Vp_:], yv[b], Vp_, n_v[f], ystat[b],
+                                                     yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f])
+                else:
+                    self.info["fused_flops"] += 2.0 * A * n_v[f] * hat["n_i"][f] * V_
+                    self.info["fused_launches"] += 1
+                    ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, Vp_, tr[f], yv[b], n_v[f], ystat[b], yblk[b],
+                                           self.mode, part, scores, accumulate=f > 0)
+            if moments and Ad and not cho_first:
+                for i, a in enumerate(cho):
+                    scores[a].copy_(scores_d[i])
+            self.sweeps_done = torch.cuda.Event()
+            self.sweeps_done.record()
+            return scores
+
+
+        if not moments:                                   # one pass only: nothing to put another step's work behind
+            out = fused_part()
+            return (lambda: out) if split_phase else out
+        series_part()
+        return fused_part if split_phase else fused_part()
 
     def _alpha_scores(self, K, Y, inner_abs):
         cs, split = self._target_scales(Y)
@@ -1822,7 +1844,7 @@ class RidgeCVEngine:
         n = last.storage_offset() + last.numel() - first.storage_offset()
         return torch.as_strided(first, (n,), (1,), first.storage_offset())
 
-    def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None, lmax_pre=None, step=None):
+    def fold_begin(self, tr_rows, te_rows, inner_rel, prepared=None, lmax_pre=None, step=None, split_phase=False):
         """The V-wide inner CV of one (fold, voxel range) step.  ``prepared``: the fold's V-independent state
         (prepare_folds), shared by all ranges of the fold; ``step`` = (fold number, (c0, c1)) from plan_steps, default:
         fold 0, all columns.  Returns the step's own state: the fold's entries plus the range's targets, column scales
@@ -1840,8 +1862,21 @@ class RidgeCVEngine:
         hat = dict(base["hat"])
         hat.update(cs=cs, split=split)
         st.update(Y=Y, cs=cs, split=split, hat=hat)
-        st["scores"] = self._sweeps(hat, Y, st["done"])
         st["info"] = hat["info"]
+        if split_phase:
+            # only the part of the sweeps that does not wait for the fold's Cholesky chains; fold_sweeps_finish queues the
+            # rest (the driver puts the next step's first part in between)
+            st["sweeps_rest"] = self._sweeps(hat, Y, st["done"], split_phase=True)
+            st["scores"] = None
+            return st
+        st["scores"] = self._sweeps(hat, Y, st["done"])
+        return st
+
+    def fold_sweeps_finish(self, st):
+        """Second part of a step begun with ``split_phase``: the fused sweeps behind the fold's hat matrices."""
+        if st.get("sweeps_rest") is not None:
+            self._enter(st)
+            st["scores"] = st.pop("sweeps_rest")()
         return st
 
     def _refit_stream(self, st):
@@ -2544,13 +2579,33 @@ class NestedCVModel(BasePredictivityModel):
             interleaved = any(f_ < n - 1 for f_, _ in plan[first_last:])           # last two folds voxel-major: spread anyway
             early_out = (hosted and weights_on_host and n > 1 and not interleaved
                          and sum(1 for f_, _ in plan if f_ == n - 1) > 1)
+            # look-ahead of the sweeps' FIRST part (validation statistics, operand split, series contraction: it needs the
+            # series operands only): step k + 2's first part is queued before step k + 1's fused sweeps, so that the main
+            # stream has V-wide work while those wait for a fold's Cholesky chains (fold 0's, then the big batch's)
+            # (measured: resident 129.4 -> 128.6 ms, host to host 141.3 -> 141.9: kept for resident inputs only)
+            ahead_ok = bool(drv_opt.series_lookahead) and not hosted and hasattr(eng, "fold_sweeps_finish")
+            begun = {}
+
+            def begin_series(j):
+                if ahead_ok and j < len(plan) and j not in begun:
+                    fj = plan[j][0]
+                    begun[j] = eng.fold_begin(*outer[fj], prepared=prepared[fj], step=plan[j], split_phase=True)
+
+            def begin_step(j):
+                """Step j with all its sweeps queued (its first part may be there already)."""
+                fj = plan[j][0]
+                if not ahead_ok:
+                    return eng.fold_begin(*outer[fj], prepared=prepared[fj], step=plan[j])
+                begin_series(j)
+                begin_series(j + 1)
+                return eng.fold_sweeps_finish(begun.pop(j))
+
             for k, (f, _) in enumerate(plan):
                 eng.fold_choose(st, single_alpha)               # main: argmax + grouping; the histogram leaves asynchronously
                 look = k + 1 < len(plan) and not (early_out and k in (first_last - 1, first_last))
                 st_next = None
                 if look:                                        # main: sweeps of the next (fold, range)
-                    f2 = plan[k + 1][0]
-                    st_next = eng.fold_begin(*outer[f2], prepared=prepared[f2], step=plan[k + 1])
+                    st_next = begin_step(k + 1)
                 st = eng.fold_select(st, single_alpha)          # host waits for the histogram of this step here
                 if k == 0 and defer_ahead:
                     eng.refit_ahead(prepared[1:], alphas=st["used_all"])
@@ -2561,8 +2616,7 @@ class NestedCVModel(BasePredictivityModel):
                     pending = None
                 pending = eng.fold_finish(st, scale)            # main: V-wide refit of this step behind those sweeps
                 if not look and k + 1 < len(plan):
-                    f2 = plan[k + 1][0]
-                    st_next = eng.fold_begin(*outer[f2], prepared=prepared[f2], step=plan[k + 1])
+                    st_next = begin_step(k + 1)
                 st = st_next
             tail(pending)
             return eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan
