@@ -1008,6 +1008,17 @@ def test_voxel_panels_are_bitwise_neutral(lc):
         for k in ref[0]:
             assert np.array_equal(np.asarray(got[0][k]), np.asarray(ref[0][k]), equal_nan=True), (tail_folds, k)
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), tail_folds
+    # more outer folds than one pass of the fold-mean kernel takes (lc_combine_folds_f32 carries 8 per launch): the mean
+    # over NINE folds, with and without panels, and against the oracle's mean weights
+    import oracle.nested_cv as onc
+    kw = dict(folding_type="kfold", n_outer_folds=9, n_inner_folds=3, alphas=np.logspace(0, 4, 5))
+    ref = lc.NestedCVModel("r", panel_cols=0).fit_predict(X, Y, **kw)
+    got = lc.NestedCVModel("r", panel_cols=512).fit_predict(X, Y, **kw)
+    assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    mo, Wo, ao = onc.fit_predict(X, Y, **kw)
+    same = np.asarray(ref[2]) == np.asarray(ao)
+    assert same.mean() > 0.9
+    np.testing.assert_allclose(ref[1][:, same], Wo[:, same], rtol=1e-4, atol=2e-5)
     # train / test mode: one fold that is first (panels arrive) and last (panels leave) at once
     kw = dict(folding_type="kfold", n_inner_folds=3, alphas=np.logspace(-1, 5, 8))
     ref = lc.NestedCVModel("r", panel_cols=0).fit_predict(X[:330], Y[:330], X_test=X[330:], y_test=Y[330:], **kw)
