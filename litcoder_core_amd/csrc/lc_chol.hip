@@ -575,48 +575,45 @@ constexpr int ST_LDC = NB + 2;     // row stride of the C tile in LDS
 // already in LDS (row stride ST_LDC) and depth == 64.
 template <bool BT, bool A_LDS>
 __device__ __forceinline__ void tile_mac(double (&acc)[4][4], const double* A, long long lda, int a_rows,
-                                const double* B, long long ldb, int depth, double* sA, double* sB) {
+                                         const double* B, long long ldb, int depth, double* sA, double* sB) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    f64x2 ra[2], rb[2];
-    auto fetch = [&](int k0) {
+    // Operand chunks are fetched TWO chunks ahead into two register sets (round 3): one chunk of MFMAs is ~0.5 us, a
+    // global load 1-2 us, so with the next chunk alone in flight every chunk waited for its operands (matrix pipe busy
+    // 0.2-0.3 in the step kernels).  Same MFMA order, same sums: the same bits.
+    f64x2 ra[2][2], rb[2][2];
+    auto fetch = [&](int k0, f64x2 (&xa)[2], f64x2 (&xb)[2]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = t + 256 * q;
             const int row = e >> 3, kp = e & 7;
             if (!A_LDS)
-                ra[q] = row < a_rows ? *reinterpret_cast<const f64x2*>(A + (long long)row * lda + k0 + 2 * kp) : f64x2{0.0, 0.0};
+                xa[q] = row < a_rows ? *reinterpret_cast<const f64x2*>(A + (long long)row * lda + k0 + 2 * kp) : f64x2{0.0, 0.0};
             if (BT) {
-                rb[q] = *reinterpret_cast<const f64x2*>(B + (long long)row * ldb + k0 + 2 * kp);
+                xb[q] = *reinterpret_cast<const f64x2*>(B + (long long)row * ldb + k0 + 2 * kp);
             } else {
                 const int kr = e >> 5, cp = e & 31;
-                rb[q] = *reinterpret_cast<const f64x2*>(B + (long long)(k0 + kr) * ldb + 2 * cp);
+                xb[q] = *reinterpret_cast<const f64x2*>(B + (long long)(k0 + kr) * ldb + 2 * cp);
             }
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](const f64x2 (&xa)[2], const f64x2 (&xb)[2]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int e = t + 256 * q;
             const int row = e >> 3, kp = e & 7;
-            if (!A_LDS) *reinterpret_cast<f64x2*>(sA + row * MM_LD + 2 * kp) = ra[q];
+            if (!A_LDS) *reinterpret_cast<f64x2*>(sA + row * MM_LD + 2 * kp) = xa[q];
             if (BT) {
-                *reinterpret_cast<f64x2*>(sB + row * MM_LD + 2 * kp) = rb[q];
+                *reinterpret_cast<f64x2*>(sB + row * MM_LD + 2 * kp) = xb[q];
             } else {
                 const int kr = e >> 5, cp = e & 31;
-                sB[(2 * cp) * MM_LD + kr] = rb[q].x;
-                sB[(2 * cp + 1) * MM_LD + kr] = rb[q].y;
+                sB[(2 * cp) * MM_LD + kr] = xb[q].x;
+                sB[(2 * cp + 1) * MM_LD + kr] = xb[q].y;
             }
         }
     };
-    fetch(0);
-    __syncthreads();                                   // the previous user of sA / sB is done
-    stash();
-    __syncthreads();
     const double* pb = sB + li * MM_LD + lq;
-    for (int k0 = 0; k0 < depth; k0 += MM_KC) {
-        const bool more = k0 + MM_KC < depth;
-        if (more) fetch(k0 + MM_KC);
+    auto mma = [&](int k0) {
         const double* pa = A_LDS ? A + (w * 16 + (lane & 3)) * ST_LDC + k0 + lq : sA + (w * 16 + (lane & 3)) * MM_LD + lq;
         constexpr int LDA = A_LDS ? ST_LDC : MM_LD;
 #pragma unroll
@@ -632,12 +629,29 @@ __device__ __forceinline__ void tile_mac(double (&acc)[4][4], const double* A, l
                 for (int j = 0; j < 4; ++j)
                     asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[i]), "v"(fb[j]));
         }
-        if (more) {
+    };
+    const int nk = depth / MM_KC;
+    fetch(0, ra[0], rb[0]);
+    if (nk > 1) fetch(MM_KC, ra[1], rb[1]);
+    __syncthreads();                                   // the previous user of sA / sB is done
+    stash(ra[0], rb[0]);
+    __syncthreads();
+    int k = 0;
+    for (; k + 2 <= nk; k += 2) {                      // chunk k is in LDS, chunk k+1 in register set 1, set 0 is free
+        if (k + 2 < nk) fetch((k + 2) * MM_KC, ra[0], rb[0]);
+        mma(k * MM_KC);
+        __syncthreads();
+        stash(ra[1], rb[1]);
+        __syncthreads();
+        if (k + 3 < nk) fetch((k + 3) * MM_KC, ra[1], rb[1]);
+        mma((k + 1) * MM_KC);
+        if (k + 2 < nk) {
             __syncthreads();
-            stash();
+            stash(ra[0], rb[0]);
             __syncthreads();
         }
     }
+    if (k < nk) mma(k * MM_KC);                        // odd chunk count: the last one was stashed by the pair before it
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the MFMAs above are opaque to the hazard recogniser
 }
 
