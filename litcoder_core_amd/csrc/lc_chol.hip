@@ -37,11 +37,12 @@ __device__ inline double rsqrt_nr(double d) {
     return r;
 }
 
-// The body, for the workgroup of system b (256 threads): L = NB x PD_LD doubles and rdiag = NB doubles of LDS.
+// The body, for the workgroup of system b (256 threads): L = NB x PD_LD doubles and rdiag = NB + 768 doubles of LDS.
 // PRELOADED: the caller has put the tile into L already (a barrier follows here either way).
-template <bool PRELOADED>
-__device__ inline void potrf_diag_tile(double* __restrict__ aug, int N, int M, int k, int b, double* __restrict__ linv,
-                                       int* __restrict__ info, double* L, double* rdiag) {
+// (MODE is for tools/potrf_bench.hip only: 0 = everything, 1 = no Linv, 2 = load and store alone, 3 = Linv alone)
+template <bool PRELOADED, int MODE = 0>
+__device__ inline void potrf_diag_tile_v(double* __restrict__ aug, int N, int M, int k, int b, double* __restrict__ linv,
+                                         int* __restrict__ info, double* L, double* rdiag) {
     const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
     double* a = aug + (long long)b * (N + M) * N + (long long)k * NB * N + k * NB;
     if (!PRELOADED)
@@ -51,7 +52,7 @@ __device__ inline void potrf_diag_tile(double* __restrict__ aug, int N, int M, i
     // in registers, transforms the panel rows it needs on the fly (l = a G^-T, six FMAs) and applies the rank-4
     // update; the scaled panel is written after the second barrier.  Latency, not flops, is what this kernel
     // costs (one workgroup per system), and the barrier count is its latency.
-    for (int j = 0; j < NB; j += 4) {
+    for (int j = 0; j < (MODE >= 2 ? 0 : NB); j += 4) {
         __syncthreads();                              // columns j..j+3 are final up to their scaling
         double g00 = L[j * PD_LD + j];
         const double a10 = L[(j + 1) * PD_LD + j], a11 = L[(j + 1) * PD_LD + j + 1];
@@ -116,36 +117,92 @@ __device__ inline void potrf_diag_tile(double* __restrict__ aug, int N, int M, i
         const int i = e >> 6, j = e & 63;
         a[(long long)i * N + j] = j <= i ? L[i * PD_LD + j] : 0.0;
     }
-    // Linv = inv(L): column c by forward substitution, four lanes per column -- lane part r keeps the entries
-    // x_q with q = r (mod 4) and sums their share of every row's dot product, two shuffles combine the shares.
-    {
-        const int c = t >> 2, r = t & 3;
-        double x[NB / 4];
+    // Linv = inv(L), blocked 4 x 4 in 16 x 16 blocks, in place over L in LDS (round 3; one forward substitution over all
+    // 64 rows -- 64 dependent steps of ~0.26 us -- was 17 of the kernel's 41 us):
+    //   (a) the four diagonal blocks at once: column c by forward substitution INSIDE its block (16 dependent steps), four
+    //       lanes per column -- lane part r keeps the entries x_q with q = r (mod 4), two shuffles combine their shares;
+    //   (b) block row bi = 1, 2, 3:  X[bi][j] = -X[bi][bi] (sum_{kb = j .. bi-1} L[bi][kb] X[kb][j]),  one element per
+    //       thread and block, the inner sums through a 3 x 256 scratch (rdiag + NB: the callers provide NB + 768 doubles).
+    // The rows of L above block row bi already hold X; L itself went to global memory just above.
+    if (MODE == 0 || MODE == 3) {
+        if (MODE == 3 && t < NB) rdiag[t] = 1.0 / L[t * PD_LD + t];
+        __syncthreads();                               // the store loop above has read L; rdiag is complete
+        double* T = rdiag + NB;
         double* lo = linv + ((long long)b * (N / NB) + k) * NB * NB;
+        {
+            const int c = t >> 2, r = t & 3, d0 = (c >> 4) << 4;
+            double x[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            double sp = 0.0;
+            for (int ii = 0; ii < 16; ++ii) {
+                const int i = d0 + ii;
+                double sp = 0.0;
 #pragma unroll
-            for (int m = 0; m < NB / 4; ++m)
-                if (4 * m < i) {                             // static bound; the lane's own q = 4m + r may still be >= i
-                    const int q = 4 * m + r;
-                    if (q < i) sp = fma(L[i * PD_LD + q], x[m], sp);
-                }
-            sp += __shfl_xor(sp, 1);
-            sp += __shfl_xor(sp, 2);
-            const double xi = ((i == c ? 1.0 : 0.0) - sp) * rdiag[i];
-            if (r == (i & 3)) {
-                x[i >> 2] = xi;
-                lo[i * NB + c] = xi;
+                for (int m = 0; m < 4; ++m)
+                    if (4 * m < ii) {                        // static bound; the lane's own entry 4m + r may still be >= ii
+                        if (4 * m + r < ii) sp = fma(L[i * PD_LD + d0 + 4 * m + r], x[m], sp);
+                    }
+                sp += __shfl_xor(sp, 1);
+                sp += __shfl_xor(sp, 2);
+                const double xi = ((i == c ? 1.0 : 0.0) - sp) * rdiag[i];
+                if (r == (ii & 3)) x[ii >> 2] = xi;
             }
+            __syncthreads();                           // every lane has read its diagonal block
+#pragma unroll
+            for (int m = 0; m < 4; ++m) L[(d0 + 4 * m + r) * PD_LD + c] = x[m];     // zeros above the diagonal included
+        }
+        __syncthreads();
+        const int ra = t >> 4, cc = t & 15;
+#pragma unroll
+        for (int bi = 1; bi < 4; ++bi) {
+            double tv[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < bi) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int kb = 0; kb < 3; ++kb)
+                        if (kb >= j && kb < bi) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q)
+                                sacc = fma(L[(16 * bi + ra) * PD_LD + 16 * kb + q], L[(16 * kb + q) * PD_LD + 16 * j + cc], sacc);
+                        }
+                    tv[j] = sacc;
+                }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < bi) T[j * 256 + ra * 16 + cc] = tv[j];
+            __syncthreads();                           // T complete; every read of L[bi][*] (the original blocks) is done
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < bi) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) sacc = fma(L[(16 * bi + ra) * PD_LD + 16 * bi + q], T[j * 256 + q * 16 + cc], sacc);
+                    tv[j] = -sacc;
+                }
+            __syncthreads();                           // T has been read
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < bi) L[(16 * bi + ra) * PD_LD + 16 * j + cc] = tv[j];
+            __syncthreads();
+        }
+        for (int e = t; e < NB * NB; e += 256) {
+            const int i = e >> 6, j = e & 63;
+            lo[e] = j <= i ? L[i * PD_LD + j] : 0.0;
         }
     }
+}
+
+template <bool PRELOADED>
+__device__ inline void potrf_diag_tile(double* __restrict__ aug, int N, int M, int k, int b, double* __restrict__ linv,
+                                       int* __restrict__ info, double* L, double* rdiag) {
+    potrf_diag_tile_v<PRELOADED, 0>(aug, N, M, k, b, linv, info, L, rdiag);
 }
 
 __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ aug, int N, int M, int k,
                                                     double* __restrict__ linv, int* __restrict__ info) {
     __shared__ double L[NB * PD_LD];
-    __shared__ double rdiag[NB];                       // 1 / L[i][i]
+    __shared__ double rdiag[NB + 768];                 // 1 / L[i][i], then the scratch of the blocked inverse
     potrf_diag_tile<false>(aug, N, M, k, blockIdx.x, linv, info, L, rdiag);
 }
 
