@@ -39,7 +39,8 @@ def wrap(name, label):
     setattr(ncv.RidgeCVEngine, name, inner)
 
 
-for n, lab in (("_sweeps", "MAIN sweeps"), ("fold_finish", "MAIN refit apply + statistics"), ("fold_choose", "MAIN choose + group"),
+for n, lab in (("_sweeps", "MAIN sweeps (with a look-ahead: their first part)"), ("fold_sweeps_finish", "MAIN sweeps, fused part"),
+               ("fold_finish", "MAIN refit apply + statistics"), ("fold_choose", "MAIN choose + group"),
                ("lmax_systems", "aux  lanczos"), ("_hat_matrices", "aux  hat matrices (series chain + cholesky)"),
                ("_refit_chol", "aux2 refit cholesky"), ("_refit_systems", "aux2 refit systems (poly chain, copies)"),
                ("refit_ahead", "aux2 refit_ahead (entry/exit on the issuing stream)")):
