@@ -72,6 +72,9 @@ class FitOptions:
                                             # 145.2 for 73 728, 151.6 without panels)
     panel_min_cols: int = 16384             # below twice this many voxels a fit is not cut into panels
     tail_panels_geometric: bool = True      # the end of a host-to-host fit in few panels of falling width (_download_panels)
+    tail_last_frac: float = 0.3             # ... the last panel's share of the voxels (0: the geometric plan's own last panel):
+                                            # its weights + transfer (~7 ms) run while the host builds the metrics dictionary
+                                            # (measured 140.0 -> 138.1 / 137.8 ms at 0.27 / 0.35)
     tail_folds: int = 2                     # ... spread over this many folds, voxel-major (plan_steps)
     refit_ahead_behind_hat_batch: bool = False     # host inputs: the later folds' refit inverses behind their hat-matrix batch
     series_lookahead: bool = True           # the next step's first sweep part queued before a step's fused sweeps (driver)
@@ -244,7 +247,7 @@ def _column_panels(V, cols=None, min_cols=None, v_ref=None):
     return [(int(edges[i]), int(edges[i + 1])) for i in range(len(widths))]
 
 
-def _download_panels(V, first=8.0 / 15.0, ratio=0.5, min_cols=None, v_ref=None, last_min=4096):
+def _download_panels(V, first=8.0 / 15.0, ratio=0.5, min_cols=None, v_ref=None, last_min=4096, last_frac=0.0):
     """[c0, c1) panels the END of a host-to-host fit works in (the last two folds voxel-major, plan_steps): a panel's
     finished weights cross PCIe while the next panel is computed, so what is not hidden is the LAST panel's transfer --
     and wide panels run the V-wide kernels more efficiently than narrow ones.  Widths fall geometrically: two folds of
@@ -257,6 +260,16 @@ def _download_panels(V, first=8.0 / 15.0, ratio=0.5, min_cols=None, v_ref=None, 
     if v_ref < 2 * min_cols:
         return [(0, int(V))]
     last_min = max(256, min(int(last_min), min_cols // 4))
+    if last_frac > 0.0:
+        # ... unless the caller has host work of its own after the last fold's results (the metrics dictionary: ~7 ms at
+        # cfg2, during which the GPU would idle): then the LAST panel is sized so that its weights, their mean and its
+        # transfer take about that long -- what runs after the last results are out is hidden behind the host, and the
+        # results themselves are out that much earlier
+        tail = max(last_min, int(round(v_ref * last_frac / 256.0)) * 256)
+        head = max(256, (v_ref - tail) // 256 * 256)
+        h1 = max(256, int(round(head * 0.6 / 256.0)) * 256)
+        edges = [0, h1, head, int(V)] if head - h1 >= last_min else [0, head, int(V)]
+        return [(int(edges[i]), int(edges[i + 1])) for i in range(len(edges) - 1)]
     widths, left, w = [], v_ref, v_ref * first
     while left > 0:
         wi = max(256, int(round(w / 256.0)) * 256)
@@ -2477,7 +2490,8 @@ class NestedCVModel(BasePredictivityModel):
             # the end of the fit: fewer, wider panels of geometrically falling width (explicit panel_cols: the same panels
             # at both ends, what the tests of the panel logic ask for)
             if self.panel_cols is None and o.tail_panels_geometric:
-                down_panels = _download_panels(V_rank, min_cols=o.panel_min_cols, v_ref=V_total // max(shard.world, 1))
+                down_panels = _download_panels(V_rank, min_cols=o.panel_min_cols, v_ref=V_total // max(shard.world, 1),
+                                               last_frac=o.tail_last_frac)
 
         def attempt(form, precision, X_in, Y_in):
             eng = RidgeCVEngine(X_in, Y_in, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
