@@ -2265,11 +2265,27 @@ class RidgeCVEngine:
         (every rank, redundantly): (p_comb, reject, adjusted p) as host arrays."""
         # on the communication stream, behind the last fold's results: the main stream is still busy with the weight
         # rows of that fold's refit, which nothing here depends on
+        return self.combined_significance_end(self.combined_significance_begin())
+
+    def combined_significance_begin(self):
+        """Queues Fisher + BH-FDR + the copies to page-locked memory on the communication stream and returns at once."""
+        Vt = self.V_total
         with torch.cuda.stream(self.comm):
             pcomb = ops.fisher_combine(self.p_folds[: self.n_folds])
             rej, padj = ops.bh_fdr(pcomb, self.alpha_fdr)
-            out = pcomb.cpu().numpy(), rej.cpu().numpy().astype(bool), padj.cpu().numpy()
-        return out
+            h_pc = torch.empty(Vt, dtype=torch.float64, pin_memory=True)
+            h_rej = torch.empty(Vt, dtype=torch.uint8, pin_memory=True)
+            h_padj = torch.empty(Vt, dtype=torch.float64, pin_memory=True)
+            for h, d in ((h_pc, pcomb), (h_rej, rej), (h_padj, padj)):
+                h.copy_(d, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        return dict(done=done, host=(h_pc, h_rej, h_padj), keep=(pcomb, rej, padj))
+
+    def combined_significance_end(self, pend):
+        pend["done"].synchronize()
+        h_pc, h_rej, h_padj = pend["host"]
+        return h_pc.numpy().copy(), h_rej.numpy().astype(bool), h_padj.numpy().copy()
 
     def run_fold(self, tr_rows, te_rows, inner_rel, single_alpha, weight_scale) -> _FoldResult:
         st = self.fold_begin(tr_rows, te_rows, inner_rel)
@@ -2680,10 +2696,12 @@ class NestedCVModel(BasePredictivityModel):
 
         # np.mean(fold_scores, axis=0) of the reference (nested_cv.py:276): the nested lists hold np.float32
         # scalars, plus Python 0.0 where r was NaN -- numpy then builds a float64 array, else a float32 one
+        # (the device part of the combined significance is queued first: it runs while the host forms the means below)
+        pend_sig = eng.combined_significance_begin() if hasattr(eng, "combined_significance_begin") else None
         scores = np.mean(np.stack(score_rows).astype(np.float64 if any(any_nan) else np.float32), axis=0)
-        pcomb, sig, padj = eng.combined_significance()
         majority = np.sum([s for s, _ in fold_sig], axis=0) >= (n_outer_folds // 2 + 1)
         mean_alphas = np.mean(fold_alpha, axis=0)
+        pcomb, sig, padj = eng.combined_significance_end(pend_sig) if pend_sig is not None else eng.combined_significance()
         metrics = stats.full_cv_metrics(scores, pcomb, padj, sig, majority, mean_alphas, np.sum(sig), np.sum(majority),
                                         part=part)
         return metrics, weights_now(), mean_alphas if part is None else mean_alphas[part]
