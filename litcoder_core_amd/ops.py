@@ -287,7 +287,9 @@ class PanelUploader:
         self._handle = ctypes.c_void_p()
         self._done = False
         import os
-        n_threads = max(2, min(len(pinned), (os.cpu_count() or 4) // 2))
+        # staging threads: half the cores, shared out over the processes of the node (one per GPU under torchrun)
+        per_node = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+        n_threads = max(2, min(len(pinned), (os.cpu_count() or 4) // 2 // per_node))
         _UPLOAD_LOCK.acquire()                          # the staging ring is the process's: one upload at a time owns it
         try:
             _lib.call("lc_upload_start", ctypes.cast(self._native, ctypes.c_void_p), len(native),
