@@ -18,7 +18,8 @@ split over the ranks (north_star's 80 000-voxel job on 1/2/4/8 GPUs).  At N > 1 
 the headline `value` in the chosen mode and the other mode under `other_scaling`.
 
 Extra legs in the same JSON line (N = 1): `resident_path` = the same fit with the fp32 inputs already in
-HBM and the weights left there (what `value` was in rounds 1-2); `f32_path` = the resident fit with the
+HBM and the weights left there (what `value` was in rounds 1-2), with `roofline_full_width_launches` = the dominant
+kernel's roofline over that leg's 25 full-width launches per step; `f32_path` = the resident fit with the
 exact-fp32 MFMA sweep (precision="f32"), with a roofline of its own, and `parity_vs_f32_path` = how far
 the headline's f16x3 results are from it over ALL voxels of the bench data.
 
@@ -335,10 +336,16 @@ def main():
             out["other_scaling"] = other
         if world == 1 and not args.no_extra_legs:
             del host
-            e_res, r_res, _, _ = timed_fits(model, dX, dY, p, V, V_total, alphas, 3, 1, 1, dev)
+            e_res, r_res, k_res, f_res = timed_fits(model, dX, dY, p, V, V_total, alphas, 3, 1, 1, dev, collect_kernels=True)
+            roof_res = sweep_roofline(dict(model.last_fit), k_res, f_res, 3, split)
             out["resident_path"] = {"value": V * 3 / e_res, "unit": "voxels/sec", "ms_per_step": 1e3 * e_res / 3, "steps": 3,
                                     "what": "fp32 inputs resident in HBM, weights left resident (the headline of rounds 1-2)",
-                                    "median_score": r_res[0]["median_score"]}
+                                    "median_score": r_res[0]["median_score"],
+                                    "roofline_full_width_launches": {
+                                        k: roof_res.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "mfma_issue_frac",
+                                                                     "avg_launch_ms", "launches_per_step")},
+                                    "note": "the same dominant kernel in launches of all 80 000 voxels (the headline's steps cut "
+                                            "the first fold and the last two into voxel panels: launches of 12 288-80 000 columns)"}
             if args.precision != "f32":
                 m32 = NestedCVModel("ridge_regression", precision="f32")
                 e32, r32, k32, f32 = timed_fits(m32, dX, dY, p, V, V_total, alphas, 2, 1, 1, dev, collect_kernels=True)
