@@ -23,6 +23,11 @@ kernel's roofline over that leg's 25 full-width launches per step; `f32_path` = 
 exact-fp32 MFMA sweep (precision="f32"), with a roofline of its own, and `parity_vs_f32_path` = how far
 the headline's f16x3 results are from it over ALL voxels of the bench data.
 
+`roofline.traffic` (N = 1): measured for THIS run -- before the process touches the GPU, two child passes
+`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over one resident fit (`measured_traffic`; about a
+minute; `--no-traffic` skips them, and so does running under a profiler) -- with the committed profile's figure
+beside it (`traffic_in_committed_profile`), which is also the fallback.
+
 Prints ONE JSON line on rank 0.  The `roofline` object is for the dominant kernel, the fp16x3 MFMA
 contraction k_sweep_f16x3, in its fused-score launches (the alphas that go through the batched
 Cholesky: all their predictions reduced to scores in the epilogue): algorithmic flops per launch x 3
@@ -69,6 +74,65 @@ def synth_inputs(V, rank, dev):
     dY[:, :V] = dX[:, :p] @ W + torch.randn((T, V), generator=g, device=dev, dtype=torch.float32)
     del W
     return dX, dY, p
+
+
+def measured_traffic(voxels, per_pass_timeout=240):
+    """L2-side traffic of ONE full-width fused launch of k_sweep_f16x3, measured for this run: two child processes --
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes, counters only, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes) over one resident fit of the bench workload
+    (tools/resident_fit_loop.py) -- started BEFORE this process touches the GPU.  Corrections of the guide: the counters
+    are in KiB; FETCH_SIZE reports half of a 16 B/lane streaming read on gfx950 -> doubled.
+    Returns (bytes per launch or None, source text)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "not measured: this process itself runs under a profiler"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "not measured: rocprofv3 not found"
+    child = os.path.join(ROOT, "tools", "resident_fit_loop.py")
+    work = tempfile.mkdtemp(prefix="lc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    means = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, child, "1", str(voxels)]
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=per_pass_timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)          # the process group this call started, nothing else
+                proc.wait()
+                return None, f"not measured: the {counter} pass exceeded {per_pass_timeout}s"
+            if rc != 0:
+                return None, f"not measured: the {counter} pass exited with code {rc}"
+            rows = []
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row.get("Counter_Name") == counter and "k_sweep_f16x3<true" in row.get("Kernel_Name", ""):
+                            rows.append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+            if not rows:
+                return None, f"not measured: no k_sweep_f16x3 launch in the {counter} pass"
+            full = max(g for g, _ in rows)                    # full-width launches only
+            vals = [v for g, v in rows if g == full]
+            means[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    fetch, nf = means["FETCH_SIZE"]
+    write, nw = means["WRITE_SIZE"]
+    total = fetch * 1024 * 2 + write * 1024
+    return total, (f"measured in this run, before the timed fits: child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` "
+                   f"and `--pmc WRITE_SIZE` over one resident fit (tools/resident_fit_loop.py), mean over the {nf} / {nw} "
+                   f"full-width fused launches: FETCH_SIZE {fetch:.0f} KiB x2 (gfx950 wide-read correction) + WRITE_SIZE "
+                   f"{write:.0f} KiB; counts Infinity-Cache hits (traffic leaving L2, an upper bound on HBM bytes)")
 
 
 def cpu_baseline(dX, dY, p, V_full, alphas, v_sample=2000):
@@ -222,6 +286,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip host_path / f32_path / other_scaling")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only)")
     ap.add_argument("--precision", default="auto", choices=["auto", "f32", "f16x3"],
                     help="arithmetic of the alpha sweep (auto = f16x3 unless the targets' dynamic range forbids it)")
     args = ap.parse_args()
@@ -234,6 +300,9 @@ def main():
     # LITCODER_BENCH_ONE_GPU=1 (smoke test of the N > 1 code path on a single-GPU box): every rank on device 0, gloo
     # instead of RCCL (which refuses two ranks on one device); the numbers of such a run mean nothing
     one_gpu = os.environ.get("LITCODER_BENCH_ONE_GPU", "0") == "1"
+    live_traffic = None
+    if world == 1 and not args.no_traffic and not args.no_extra_legs and args.precision != "f32":
+        live_traffic = measured_traffic(args.voxels)         # child processes; this one has not touched the GPU yet
     if one_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -290,17 +359,21 @@ def main():
                      "mfma_tflops": 3 * flops["plain"] / (plain_ms * 1e-3) / 1e12,
                      "what": f"{sweep.get('series_terms', 0)} shared series terms x 25 inner folds + 5 refits "
                              "(weights and test predictions) per step; includes the f32 MFMA launches of that slot"}
-        traffic = traffic_src = None
+        traffic = traffic_src = committed = None
         tpath = os.path.join(ROOT, "profiles", "alpha_sweep_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                entry = tj.get(sweep["precision"], tj)
-                traffic = entry.get("hbm_bytes_per_launch")
-                traffic_src = ("profiles/alpha_sweep_traffic.json (static: FETCH_SIZE x2 + WRITE_SIZE per full-width fused "
-                               "launch from separate rocprofv3 --pmc passes of this command; not measured in this run)")
+                committed = tj.get(sweep["precision"], tj).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                committed = None
+        if live_traffic is not None and live_traffic[0] is not None and split:
+            traffic, traffic_src = live_traffic
+        elif committed is not None:
+            traffic = committed
+            traffic_src = ("profiles/alpha_sweep_traffic.json (static: FETCH_SIZE x2 + WRITE_SIZE per full-width fused "
+                           "launch from separate rocprofv3 --pmc passes of this command; "
+                           + (live_traffic[1] if live_traffic is not None else "not measured in this run") + ")")
         from litcoder_core_amd.nested_cv import _main_stream
         roof.update({
             "note": ("achieved/frac = ALGORITHMIC flops of the caller's contraction (2 x A_fused x n_val x n_train x V per "
@@ -309,7 +382,7 @@ def main():
                      "fp16 MFMA datasheet figure at 2.4 GHz; under this kernel the chip holds 1.4-1.8 GHz (in-kernel "
                      "s_memtime/s_memrealtime, profiles/).  The first fold's launches are panel-wide (the targets are still "
                      "arriving), the others full width") if split else None,
-            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_in_committed_profile": committed,
             "cus_of_256_the_kernel_runs_on": 224 if _main_stream() is not None else 256,
             "plain_launches_same_kernel": plain})
         renamed = {"batch_chol_solve": "batch_chol_solve_stream_ms_incl_waits_for_cus"}
