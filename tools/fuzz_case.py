@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""One case of tools/fuzz_vs_oracle.py again, with a float64 ground truth beside both fits: who is off, and by how much.
+    python tools/fuzz_case.py seed case"""
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import litcoder_core_amd as lc  # noqa: E402
+import oracle.folds as ofolds  # noqa: E402
+import oracle.nested_cv as onc  # noqa: E402
+
+seed, want = int(sys.argv[1]), int(sys.argv[2])
+rng = np.random.default_rng(seed)
+for case in range(want + 1):
+    T = int(rng.integers(90, 420))
+    p = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 40, 70, 130, 300]))
+    V = int(rng.choice([1, 3, 17, 64, 100, 129, 257, 300]))
+    fold = str(rng.choice(["kfold", "chunked", "kfold_trimmed", "chunked_trimmed", "timeseries", "group"]))
+    use_corr = bool(rng.random() < 0.8)
+    kw = dict(folding_type=fold, n_outer_folds=int(rng.integers(2, 4)), n_inner_folds=int(rng.integers(2, 4)),
+              alphas=np.logspace(rng.uniform(-2, 0), rng.uniform(1, 5), int(rng.integers(1, 9))),
+              normalpha=bool(rng.random() < 0.7), use_corr=use_corr, single_alpha=bool(rng.random() < 0.25),
+              normalize_features=bool(rng.random() < 0.2), normalize_targets=bool(rng.random() < 0.2))
+    if "chunked" in fold:
+        kw["chunk_length"] = int(rng.integers(5, 30))
+    tt = int(rng.integers(30, 90)) if rng.random() < 0.3 else 0
+    if fold == "group":
+        kw["groups"] = rng.integers(0, 8, size=T - tt)
+    signal = 1.0 if not use_corr else float(rng.choice([0.3, 1.0]))
+    X = rng.standard_normal((T, p)) * rng.uniform(0.5, 2.0, p)
+    Y = X @ (rng.standard_normal((p, V)) * (signal / np.sqrt(p))) + rng.standard_normal((T, V)) + rng.uniform(-3, 3)
+    precision = str(rng.choice(["auto", "auto", "f32"]))
+assert tt == 0, "cross-validated cases only"
+print(f"T{T} p{p} V{V} {fold} {precision}", {k: v for k, v in kw.items() if k != "groups"})
+random.seed(want); np.random.seed(want)
+detail = {}
+m_o, W_o, a_o = onc.fit_predict(X, Y, detail=detail, **kw)
+random.seed(want); np.random.seed(want)
+model = lc.NestedCVModel("r", precision=precision)
+m, W, a = model.fit_predict(X, Y, **kw)
+print("form", model.last_form, model.last_fit.get("precision"))
+# float64 ground truth: the reference's arithmetic (fp32 inputs, train-statistics normaliser, S[0] of the normalised
+# training design) carried out in float64, at the ORACLE's alphas
+X32, Y32 = X.astype(np.float32).astype(np.float64), Y.astype(np.float32).astype(np.float64)
+Wt = np.zeros((p, V))
+for f, (tr, te) in enumerate(detail["outer"]):
+    tr = np.asarray(tr)
+    Xtr, Ytr = X32[tr], Y32[tr]
+    if kw["normalize_features"]:
+        Xtr = (Xtr - Xtr.mean(0)) / (Xtr.std(0, ddof=1) + 1e-8)
+    if kw["normalize_targets"]:
+        Ytr = (Ytr - Ytr.mean(0)) / (Ytr.std(0, ddof=1) + 1e-8)
+    U, S, Vh = np.linalg.svd(Xtr, full_matrices=False)
+    al = np.asarray(detail["fold_alphas"][f], dtype=np.float64)
+    na = al * S[0] if kw["normalpha"] else al
+    UR = U.T @ Ytr
+    Wf = np.empty((p, V))
+    for v in range(V):
+        Wf[:, v] = Vh.T @ ((S / (S ** 2 + na[v] ** 2)) * UR[:, v])
+    Wt += Wf / len(detail["outer"])
+    print(f"fold {f}: n_train {len(tr)}  S0 {S[0]:.4g}  Smin {S[-1]:.4g}  alphas {np.unique(al)}")
+scale = np.abs(Wt).max()
+print(f"max|W_true| {scale:.4g}")
+print(f"ours   - truth: max abs {np.abs(W - Wt).max():.3g}   oracle - truth: max abs {np.abs(W_o - Wt).max():.3g}   "
+      f"ours - oracle: {np.abs(W - W_o).max():.3g}")
+same = np.isclose(np.asarray(a), np.asarray(a_o), rtol=1e-6)
+print(f"alphas equal for {same.mean():.3f} of the voxels")
