@@ -2,7 +2,8 @@
 """Random small problems through NestedCVModel.fit_predict against the CPU oracle (tests/_oracle_check.py: every alpha
 that differs must be a proven near-tie of the oracle's own score table).  A bug hunt, not a test: shapes, fold types,
 normalisers, scoring, single / per-voxel alpha, CV / train-test, precisions and all three forms (dual, primal, block
-products) are drawn at random.     python tools/fuzz_vs_oracle.py [n_cases [seed]]"""
+products) are drawn at random.     python tools/fuzz_vs_oracle.py [n_cases [seed [large]]]
+``large``: T 500-1400, p up to 1536, V up to 5000 (several tiles of every kernel, ragged edges; ~10-20 s of oracle per case)."""
 import os
 import random
 import sys
@@ -19,6 +20,7 @@ from _oracle_check import assert_matches_oracle  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+large = len(sys.argv) > 3 and sys.argv[3] == "large"
 rng = np.random.default_rng(seed)
 fails = skipped = 0
 forms = {}
@@ -26,6 +28,10 @@ for case in range(n_cases):
     T = int(rng.integers(90, 420))
     p = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 40, 70, 130, 300]))
     V = int(rng.choice([1, 3, 17, 64, 100, 129, 257, 300]))
+    if large:
+        T = int(rng.integers(500, 1400))
+        p = int(rng.choice([40, 300, 517, 768, 1000, 1536]))
+        V = int(rng.choice([300, 1025, 2000, 3333, 5000]))
     fold = str(rng.choice(["kfold", "chunked", "kfold_trimmed", "chunked_trimmed", "timeseries", "group"]))
     use_corr = bool(rng.random() < 0.8)
     kw = dict(folding_type=fold, n_outer_folds=int(rng.integers(2, 4)), n_inner_folds=int(rng.integers(2, 4)),
