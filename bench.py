@@ -24,9 +24,11 @@ exact-fp32 MFMA sweep (precision="f32"), with a roofline of its own, and `parity
 the headline's f16x3 results are from it over ALL voxels of the bench data.
 
 `roofline.traffic` (N = 1): measured for THIS run -- before the process touches the GPU, two child passes
-`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over one resident fit (`measured_traffic`; about a
-minute; `--no-traffic` skips them, and so does running under a profiler) -- with the committed profile's figure
-beside it (`traffic_in_committed_profile`), which is also the fallback.
+`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over one host-to-host fit (`measured_traffic`; about a
+minute; `--no-traffic` skips them, and so does running under a profiler): bytes per launch averaged over the same
+mixed-width launches `avg_launch_ms` averages over; the full-width launches' figure sits in
+`resident_path.roofline_full_width_launches.traffic` next to THEIR average duration, with the committed profile's
+figure beside it (`traffic_in_committed_profile`, also the fallback there).
 
 Prints ONE JSON line on rank 0.  The `roofline` object is for the dominant kernel, the fp16x3 MFMA
 contraction k_sweep_f16x3, in its fused-score launches (the alphas that go through the batched
@@ -76,13 +78,44 @@ def synth_inputs(V, rank, dev):
     return dX, dY, p
 
 
+_LIVE_CHILDREN = []
+
+
+def _kill_children(*_):
+    """The rocprofv3 child passes run in process groups of their own: when this process ends early (harness timeout,
+    SIGTERM) they must not stay behind on the GPU and perturb the next timed run."""
+    import signal
+    for proc in list(_LIVE_CHILDREN):
+        if proc.poll() is None:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)      # the group this process started, nothing else
+            except OSError:
+                pass
+
+
+def _die_with_parent():
+    """preexec of a child pass: its own session (so that the whole group can be killed) and SIGKILL when the parent dies
+    without running its handlers (PR_SET_PDEATHSIG = 1)."""
+    import ctypes
+    import signal
+    os.setsid()
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)
+    except OSError:
+        pass
+
+
 def measured_traffic(voxels, per_pass_timeout=240):
-    """L2-side traffic of ONE full-width fused launch of k_sweep_f16x3, measured for this run: two child processes --
+    """L2-side traffic per fused launch of k_sweep_f16x3, measured for this run: two child processes --
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes, counters only, as
-    /opt/skills/guides/MI355X_MICROARCH.md prescribes) over one resident fit of the bench workload
-    (tools/resident_fit_loop.py) -- started BEFORE this process touches the GPU.  Corrections of the guide: the counters
-    are in KiB; FETCH_SIZE reports half of a 16 B/lane streaming read on gfx950 -> doubled.
-    Returns (bytes per launch or None, source text)."""
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes) over ONE HOST-TO-HOST fit of the bench workload
+    (tools/host_fit_loop.py: the same 60 launches of 12 288-80 000 columns a timed step issues) -- started BEFORE this
+    process touches the GPU.  Corrections of the guide: the counters are in KiB; FETCH_SIZE reports half of a
+    16 B/lane streaming read on gfx950 -> doubled.
+    Returns ({"all": bytes per launch averaged over ALL fused launches of the step -- the population `avg_launch_ms` of
+    the headline roofline averages over --, "full_width": the same over the full-width launches only, "launches": ...}
+    or None, source text)."""
+    import atexit
     import csv
     import glob
     import shutil
@@ -94,9 +127,11 @@ def measured_traffic(voxels, per_pass_timeout=240):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "not measured: rocprofv3 not found"
-    child = os.path.join(ROOT, "tools", "resident_fit_loop.py")
+    child = os.path.join(ROOT, "tools", "host_fit_loop.py")
     work = tempfile.mkdtemp(prefix="lc_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
+    atexit.register(_kill_children)
+    old_term = signal.signal(signal.SIGTERM, lambda *a: (_kill_children(), sys.exit(143)))
     means = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -104,13 +139,17 @@ def measured_traffic(voxels, per_pass_timeout=240):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
                    sys.executable, child, "1", str(voxels)]
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                    start_new_session=True)
+                                    preexec_fn=_die_with_parent)
+            _LIVE_CHILDREN.append(proc)
             try:
                 rc = proc.wait(timeout=per_pass_timeout)
             except subprocess.TimeoutExpired:
                 os.killpg(proc.pid, signal.SIGKILL)          # the process group this call started, nothing else
                 proc.wait()
                 return None, f"not measured: the {counter} pass exceeded {per_pass_timeout}s"
+            finally:
+                if proc.poll() is not None:
+                    _LIVE_CHILDREN.remove(proc)
             if rc != 0:
                 return None, f"not measured: the {counter} pass exited with code {rc}"
             rows = []
@@ -121,18 +160,21 @@ def measured_traffic(voxels, per_pass_timeout=240):
                             rows.append((int(row["Grid_Size"]), float(row["Counter_Value"])))
             if not rows:
                 return None, f"not measured: no k_sweep_f16x3 launch in the {counter} pass"
-            full = max(g for g, _ in rows)                    # full-width launches only
-            vals = [v for g, v in rows if g == full]
-            means[counter] = (sum(vals) / len(vals), len(vals))
+            full = max(g for g, _ in rows)
+            wide = [v for g, v in rows if g == full]
+            means[counter] = (sum(v for _, v in rows) / len(rows), len(rows), sum(wide) / len(wide), len(wide))
     finally:
+        signal.signal(signal.SIGTERM, old_term)
         shutil.rmtree(work, ignore_errors=True)
-    fetch, nf = means["FETCH_SIZE"]
-    write, nw = means["WRITE_SIZE"]
-    total = fetch * 1024 * 2 + write * 1024
-    return total, (f"measured in this run, before the timed fits: child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` "
-                   f"and `--pmc WRITE_SIZE` over one resident fit (tools/resident_fit_loop.py), mean over the {nf} / {nw} "
-                   f"full-width fused launches: FETCH_SIZE {fetch:.0f} KiB x2 (gfx950 wide-read correction) + WRITE_SIZE "
-                   f"{write:.0f} KiB; counts Infinity-Cache hits (traffic leaving L2, an upper bound on HBM bytes)")
+    fa, na, ff, nf = means["FETCH_SIZE"]
+    wa, nwa, wf, nwf = means["WRITE_SIZE"]
+    res = {"all": fa * 1024 * 2 + wa * 1024, "full_width": ff * 1024 * 2 + wf * 1024, "launches": na, "launches_full_width": nf}
+    return res, (f"measured in this run, before the timed fits: child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` "
+                 f"and `--pmc WRITE_SIZE` over one host-to-host fit (tools/host_fit_loop.py), mean over its {na} fused "
+                 f"launches of all widths (the population avg_launch_ms averages over): FETCH_SIZE {fa:.0f} KiB x2 (gfx950 "
+                 f"wide-read correction) + WRITE_SIZE {wa:.0f} KiB; the {nf} full-width launches alone: {ff:.0f} KiB x2 + "
+                 f"{wf:.0f} KiB (resident_path.roofline_full_width_launches.traffic); counts Infinity-Cache hits (traffic "
+                 f"leaving L2, an upper bound on HBM bytes)")
 
 
 def cpu_baseline(dX, dY, p, V_full, alphas, v_sample=2000):
@@ -367,13 +409,16 @@ def main():
                 committed = tj.get(sweep["precision"], tj).get("hbm_bytes_per_launch")
             except Exception:
                 committed = None
+        traffic_full = None
         if live_traffic is not None and live_traffic[0] is not None and split:
-            traffic, traffic_src = live_traffic
+            traffic, traffic_full, traffic_src = live_traffic[0]["all"], live_traffic[0]["full_width"], live_traffic[1]
         elif committed is not None:
-            traffic = committed
-            traffic_src = ("profiles/alpha_sweep_traffic.json (static: FETCH_SIZE x2 + WRITE_SIZE per full-width fused "
-                           "launch from separate rocprofv3 --pmc passes of this command; "
-                           + (live_traffic[1] if live_traffic is not None else "not measured in this run") + ")")
+            # the committed figure is per FULL-WIDTH launch: it belongs with the resident leg's full-width roofline, whose
+            # avg_launch_ms it can be divided by; the headline's mixed-width launches get no figure then
+            traffic_full = committed
+            traffic_src = ("not measured in this run ("
+                           + (live_traffic[1] if live_traffic is not None else "child passes skipped")
+                           + "); resident_path.roofline_full_width_launches.traffic carries profiles/alpha_sweep_traffic.json")
         from litcoder_core_amd.nested_cv import _main_stream
         roof.update({
             "note": ("achieved/frac = ALGORITHMIC flops of the caller's contraction (2 x A_fused x n_val x n_train x V per "
@@ -382,7 +427,8 @@ def main():
                      "fp16 MFMA datasheet figure at 2.4 GHz; under this kernel the chip holds 1.4-1.8 GHz (in-kernel "
                      "s_memtime/s_memrealtime, profiles/).  The first fold's launches are panel-wide (the targets are still "
                      "arriving), the others full width") if split else None,
-            "traffic": traffic, "traffic_source": traffic_src, "traffic_in_committed_profile": committed,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_population": "bytes per launch averaged over the same launches avg_launch_ms averages over",
             "cus_of_256_the_kernel_runs_on": 224 if _main_stream() is not None else 256,
             "plain_launches_same_kernel": plain})
         renamed = {"batch_chol_solve": "batch_chol_solve_stream_ms_incl_waits_for_cus"}
@@ -414,9 +460,12 @@ def main():
             out["resident_path"] = {"value": V * 3 / e_res, "unit": "voxels/sec", "ms_per_step": 1e3 * e_res / 3, "steps": 3,
                                     "what": "fp32 inputs resident in HBM, weights left resident (the headline of rounds 1-2)",
                                     "median_score": r_res[0]["median_score"],
-                                    "roofline_full_width_launches": {
-                                        k: roof_res.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "mfma_issue_frac",
-                                                                     "avg_launch_ms", "launches_per_step")},
+                                    "roofline_full_width_launches": dict(
+                                        {k: roof_res.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac",
+                                                                      "mfma_issue_frac", "avg_launch_ms", "launches_per_step")},
+                                        traffic=traffic_full, traffic_in_committed_profile=committed,
+                                        traffic_note="bytes leaving L2 per full-width fused launch (comparable with this "
+                                                     "object's avg_launch_ms)"),
                                     "note": "the same dominant kernel in launches of all 80 000 voxels (the headline's steps cut "
                                             "the first fold and the last two into voxel panels: launches of 12 288-80 000 columns)"}
             if args.precision != "f32":

@@ -83,6 +83,25 @@ int lc_lanczos_interp(const void* d_data, int dtype, int64_t n_old, int64_t D, i
                       double cutoff, double window, int rectify,
                       double* d_out, int64_t ld_out, lc_stream_t stream);
 
+/* lanczosinterp2D for ALL stories of a run in one launch (encoding/trainer.py:125-157 + 174-201 call the downsampler
+ * once per story).  Inputs and outputs of the stories are concatenated by rows; d_stories: n_stories records
+ * {int64 old_off, n_old, new_off; double cutoff; int32 sorted (+ padding)} = 40 bytes each, where cutoff =
+ * 1 / mean(diff(newtime_s)) * cutoff_mult (interpdata.py:107) and sorted = 1 when the story's sample times are
+ * non-decreasing (only the samples within `window` lobes of an output time are then visited -- same weights, same
+ * order of accumulation, same bits as lc_lanczos_interp); d_row_story (n_new_total int32): the story of each output row. */
+int lc_lanczos_interp_stories(const void* d_data, int dtype, int64_t D, int64_t ld_in, const double* d_oldtime,
+                              const double* d_newtime, int64_t n_new_total, const int32_t* d_row_story,
+                              const void* d_stories, int n_stories, double window, int rectify, double* d_out,
+                              int64_t ld_out, lc_stream_t stream);
+
+/* The float32 design matrix of a story-structured fit in one launch (encoding/trainer.py:203-209 FIR.make_delayed per
+ * story; :235-257 zs(features[start:end]) per story, np.vstack, np.nan_to_num; models/nested_cv.py:99 float32 cast):
+ * d_feat = the stories' (downsampled) float64 features concatenated by rows; d_stories: n_stories records of five int64
+ * {in_off, n_in, a, b, out_row0} -- trimmed rows [a, b) of the delayed story land in rows out_row0.. of d_x (ldx
+ * floats per row, columns k*ndim + c for delay k).  Sums in numpy's order, no fused multiply-adds: the reference's bits. */
+int lc_story_design_f32(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,
+                        const int64_t* h_delays, int nd, float* d_x, int64_t ldx, lc_stream_t stream);
+
 /* sincinterp2D (downsample/interpdata.py:66-84) with sincfun (:29-42, array branch): same banded
  * weighted-row-sum kernel as Lanczos with the sinc weight, optional causal mask and per-output-row
  * renormalisation (weights / sum(weights) unless the sum is exactly 0). */
@@ -151,7 +170,16 @@ typedef struct lc_upload_job {
     void* dst;         /* device float32 matrix (row 0, column 0) */
     int64_t ld_dst;    /* elements between its rows */
     int64_t dst_row0;  /* destination row of the block's first row */
+    int transform;     /* LC_UPLOAD_CAST: the cast alone; LC_UPLOAD_ZSCORE: the block is ONE story and is z-scored on the way
+                        * (encoding/utils.py:23-29 zs as trainer.py:235-257 applies it per story: population std, zero-std
+                        * columns only de-meaned, in the block's own precision, numpy's summation order -- bit-identical to
+                        * the reference's zs followed by its float32 cast) */
 } lc_upload_job;
+enum { LC_UPLOAD_CAST = 0, LC_UPLOAD_ZSCORE = 1 };
+/* HOST code, no device: the z-scoring of one story block exactly as a LC_UPLOAD_ZSCORE job stages it -- float32
+ * out[r, c] = fl32(zs(src)[r, c]) (utils.py:23-29 + nested_cv.py:99-100) -- for callers and tests without a GPU. */
+int lc_host_zscore_story(const void* src, int dtype, int64_t ld_src, int64_t rows, int64_t cols, float* out,
+                         int64_t ld_out);
 typedef struct lc_upload lc_upload_t;
 int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* const* pinned_slots, int n_slots, int64_t slot_bytes,
                     int n_threads, int device, lc_stream_t stream, lc_upload_t** out);
@@ -599,6 +627,9 @@ int lc_select_alpha(const float* d_scores, int A, int64_t V, int32_t* d_best, do
 /* single_alpha (nested_cv.py:396-403): best[v] = first argmax_a rowsum[a] for every v -- `rowsum` being the per-alpha
  * score sums after the all-reduce over the voxel shards, so the choice never visits the host. */
 int lc_fill_argmax(const double* d_rowsum, int A, int32_t* d_best, int64_t V, lc_stream_t stream);
+/* d_acc[i] += d_x[i]: the per-alpha score sums of the voxel ranges of ONE fold added up on the device when a
+ * single_alpha fit works through its targets panel by panel (nested_cv.py:396-400 takes the mean over ALL voxels). */
+int lc_accumulate_f64(const double* d_x, double* d_acc, int64_t n, lc_stream_t stream);
 
 /* One fold's per-voxel results of this rank as ONE (4, ld) f64 block in natural voxel order, the unit of the
  * all-gather over voxel shards (SURVEY 8e "single gather"; nested_cv.py:152-158, 252-263 are its consumers):
@@ -632,6 +663,11 @@ int lc_fold_unpack(const double* d_src, int world, int64_t ld, const int64_t* d_
  * no group (banded ridge with a search over band scales: the voxels another candidate's refit takes). */
 int lc_group_by_alpha(const int32_t* d_best, int64_t V, int A, int pad, int32_t* d_perm,
                       int32_t* d_count, lc_stream_t stream);
+/* The same for the alpha indices a0 .. a0+A-1 only (A <= 64 per call): the reference groups by ANY number of distinct
+ * alphas (torch.unique, ridge_regression.py:46-50); a grid of more than 64 is grouped range by range, each range
+ * into a perm of its own (V + A*pad entries, pre-filled with -1), d_count (A) = the sizes of ITS groups. */
+int lc_group_by_alpha_range(const int32_t* d_best, int64_t V, int a0, int A, int pad, int32_t* d_perm,
+                            int32_t* d_count, lc_stream_t stream);
 
 /* Grouped plain GEMM, C[:, tile] = A_g(tile) . B[:, tile]   (f32 MFMA, 128-column tiles):
  *   ridge_torch's  wt[:, sel] = Vh' diag(D) U' Y[:, sel]  (ridge_regression.py:56-61) with

@@ -70,6 +70,7 @@ SIGNATURES = {
                                 c_int, c_float, _ptr, c_int64, _ptr, _ptr]),
     "lc_lambda_max_strided": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_fill_argmax": (c_int, [_ptr, c_int, _ptr, c_int64, _ptr]),
+    "lc_accumulate_f64": (c_int, [_ptr, _ptr, c_int64, _ptr]),
     "lc_fold_pack": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr, c_int, _ptr, c_int, _ptr, c_int64, _ptr]),
     "lc_fold_pack_at": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr, c_int, _ptr, c_int, _ptr, c_int64, c_int64, c_int,
                                 _ptr]),
@@ -78,6 +79,10 @@ SIGNATURES = {
     "lc_host_cast_f64_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64]),
     "lc_host_copy_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64]),
     "lc_upload_start": (c_int, [_ptr, c_int, _ptr, c_int, c_int64, c_int, c_int, _ptr, _ptr]),
+    "lc_host_zscore_story": (c_int, [_ptr, c_int, c_int64, c_int64, c_int64, _ptr, c_int64]),
+    "lc_lanczos_interp_stories": (c_int, [_ptr, c_int, c_int64, c_int64, _ptr, _ptr, c_int64, _ptr, _ptr, c_int, c_double,
+                                          c_int, _ptr, c_int64, _ptr]),
+    "lc_story_design_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, POINTER(c_int64), c_int, _ptr, c_int64, _ptr]),
     "lc_upload_wait": (c_int, [_ptr, c_int, _ptr]),
     "lc_upload_finish": (c_int, [_ptr]),
     "lc_upload_free": (c_int, [_ptr]),
@@ -138,6 +143,7 @@ SIGNATURES = {
                                       POINTER(c_int32), c_int, _ptr, c_int64, c_int64, c_int64, _ptr]),
     "lc_select_alpha": (c_int, [_ptr, c_int, c_int64, _ptr, _ptr, _ptr]),
     "lc_group_by_alpha": (c_int, [_ptr, c_int64, c_int, c_int, _ptr, _ptr, _ptr]),
+    "lc_group_by_alpha_range": (c_int, [_ptr, c_int64, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_gemm_grouped_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, _ptr, _ptr, c_int64, c_int64, c_int64,
                                     c_int64, POINTER(c_int32), c_int, _ptr]),
 }

@@ -140,6 +140,145 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos(const T* __restrict__ da
     }
 }
 
+// All stories of a training run in ONE launch (trainer.py:125-157 calls the downsampler once per story: 27 launches of
+// 26 us each, every block evaluating the fp64 sines of ALL 2500 word times of its story).  A story table gives each
+// story's slice of the concatenated inputs / outputs; a block is one (output row, 256-column slab) of some story.  When
+// a story's sample times are non-decreasing (``sorted``: word onsets always are) the samples that can carry weight --
+// |t| <= window lobes around the output time -- are a contiguous index range found by bisection with the SAME
+// comparison lanczosfun applies (interpdata.py:62), so only ~64 instead of ~2500 weights are evaluated; an unsorted
+// story scans everything.  Weights, their order of accumulation and the arithmetic are those of k_lanczos: same bits.
+struct LzStory {
+    long long old_off, n_old, new_off;
+    double cutoff;
+    int sorted;
+};
+
+template <typename T, bool RECTIFY>
+__global__ void __launch_bounds__(LZ_THREADS) k_lanczos_stories(const T* __restrict__ data, long long D, long long ld_in,
+                                                                const double* __restrict__ oldtime,
+                                                                const double* __restrict__ newtime,
+                                                                const int* __restrict__ row_story,
+                                                                const LzStory* __restrict__ stories, double window,
+                                                                double* __restrict__ out, long long ld_out) {
+    __shared__ double w[LZ_CHUNK];
+    __shared__ int wj[LZ_CHUNK];
+    __shared__ int wave_cnt[LZ_THREADS / 64];
+    const long long i = blockIdx.x;                                    // output row in the concatenation
+    const LzStory st = stories[row_story[i]];
+    const long long c = (long long)blockIdx.y * LZ_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double tn = newtime[i];
+    const double* ot = oldtime + st.old_off;
+    const T* dat = data + st.old_off * ld_in;
+    long long jlo = 0, jhi = st.n_old;
+    if (st.sorted) {
+        // (tn - ot[j]) * cutoff is non-increasing in j: first j with t <= window, first j with t < -window
+        long long a = 0, b = st.n_old;
+        while (a < b) {
+            const long long m = (a + b) >> 1;
+            if ((tn - ot[m]) * st.cutoff > window) a = m + 1; else b = m;
+        }
+        jlo = a;
+        b = st.n_old;
+        while (a < b) {
+            const long long m = (a + b) >> 1;
+            if ((tn - ot[m]) * st.cutoff >= -window) a = m + 1; else b = m;
+        }
+        jhi = a;
+    }
+    double acc = 0.0, accp = 0.0;
+    int fill = 0;
+    for (long long j0 = jlo; j0 < jhi || fill > 0; j0 += LZ_THREADS) {
+        const long long j = j0 + threadIdx.x;
+        double wt = 0.0;
+        if (j < jhi) wt = interp_weight<WK_LANCZOS>(tn - ot[j], st.cutoff, window, 0);
+        const unsigned long long m = __ballot(wt != 0.0);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int base = fill, total = 0;
+#pragma unroll
+        for (int q = 0; q < LZ_THREADS / 64; ++q) {
+            if (q < wave) base += wave_cnt[q];
+            total += wave_cnt[q];
+        }
+        if (wt != 0.0) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            w[pos] = wt;
+            wj[pos] = (int)j;
+        }
+        fill += total;
+        __syncthreads();
+        const bool last = j0 + LZ_THREADS >= jhi;
+        if (fill > LZ_CHUNK - LZ_THREADS || last) {
+            if (c < D)
+                for (int e = 0; e < fill; ++e) {
+                    const double x = (double)dat[(long long)wj[e] * ld_in + c];
+                    if (RECTIFY) {
+                        acc += w[e] * fmin(x, 0.0);
+                        accp += w[e] * fmax(x, 0.0);
+                    } else {
+                        acc += w[e] * x;
+                    }
+                }
+            fill = 0;
+            __syncthreads();
+            if (last) break;
+        }
+    }
+    if (c < D) {
+        out[i * ld_out + c] = acc;
+        if (RECTIFY) out[i * ld_out + D + c] = accp;
+    }
+}
+
+// The design matrix of a story-structured fit in one launch (trainer.py:203-209 FIR.make_delayed per story, then
+// :235-257 per story zs(features[start:end]), np.vstack, np.nan_to_num; nested_cv.py:99 the float32 cast):
+//   X[row0_s + (t - a_s), k ndim + c] = fl32( nan_to_num( zs_s( delayed_s )[t, k ndim + c] ) ),  a_s <= t < b_s,
+// delayed_s[t, k ndim + c] = feat_s[t - d_k, c] (0 outside the story; circpad is not used by the trainer).  One thread
+// per (story, output column) walks the trimmed rows three times -- mean, squared deviations, normalise -- adding in row
+// order without fused multiply-adds, i.e. numpy's own axis-0 reduction: the same bits as the reference's float64
+// pipeline followed by its cast.  Neighbouring threads read neighbouring features of one row: coalesced.
+struct StoryRows {
+    long long in_off, n_in;      // the story's rows in the concatenated (downsampled) features
+    long long a, b;              // trimmed row range [a, b) of the delayed story
+    long long out_row0;          // first row of the story in X
+};
+
+__global__ void __launch_bounds__(256) k_story_design(const double* __restrict__ feat, long long ndim, long long ld_in,
+                                                      const StoryRows* __restrict__ stories, FirDelays dl,
+                                                      float* __restrict__ X, long long ldx) {
+#pragma clang fp contract(off)
+    const StoryRows st = stories[blockIdx.y];
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)dl.n * ndim) return;
+    const int k = (int)(e / ndim);
+    const long long c = e - (long long)k * ndim;
+    const long long d = dl.d[k];
+    const double* f = feat + st.in_off * ld_in + c;
+    const long long n = st.b - st.a;
+    auto val = [&](long long t) -> double {
+        const long long src = t - d;
+        return (src >= 0 && src < st.n_in && d < st.n_in && -d < st.n_in) ? f[src * ld_in] : 0.0;
+    };
+    double mean = 0.0;
+    for (long long t = st.a; t < st.b; ++t) mean = mean + val(t);
+    mean = mean / (double)n;
+    double ss = 0.0;
+    for (long long t = st.a; t < st.b; ++t) {
+        const double dv = val(t) - mean;
+        ss = ss + dv * dv;
+    }
+    const double sd = sqrt(ss / (double)n);
+    float* x = X + st.out_row0 * ldx + e;
+    for (long long t = st.a; t < st.b; ++t) {
+        double m = val(t) - mean;
+        if (sd != 0.0) m = m / sd;
+        // np.nan_to_num: NaN -> 0, +-inf -> +-DBL_MAX (which the float32 cast turns back into +-inf: nothing to do)
+        if (m != m) m = 0.0;
+        x[(t - st.a) * ldx] = (float)m;
+    }
+}
+
 // Per-TR reducers (downsampling.py:24-136,180-319): out[s] = mean | sum | last of the rows idx[seg[s] .. seg[s+1]),
 // zero for an empty segment.  One block row per segment, lanes across the feature axis.
 enum { SR_MEAN = 0, SR_SUM = 1, SR_LAST = 2 };
@@ -252,4 +391,43 @@ extern "C" int lc_segment_reduce(const void* d_data, int dtype, int64_t D, int64
         hipLaunchKernelGGL(k_segment_reduce<double>, grid, dim3(256), 0, s, (const double*)d_data, (long long)D,
                            (long long)ld_in, (const long long*)d_seg, d_idx, how, d_out, (long long)ld_out);
     return lc::launched("k_segment_reduce");
+}
+
+extern "C" int lc_lanczos_interp_stories(const void* d_data, int dtype, int64_t D, int64_t ld_in, const double* d_oldtime,
+                                         const double* d_newtime, int64_t n_new_total, const int32_t* d_row_story,
+                                         const void* d_stories, int n_stories, double window, int rectify, double* d_out,
+                                         int64_t ld_out, lc_stream_t stream) {
+    LC_REQUIRE(d_data && d_oldtime && d_newtime && d_row_story && d_stories && d_out, LC_E_BADARG,
+               "lc_lanczos_interp_stories: null pointer");
+    LC_REQUIRE(dtype == LC_F32 || dtype == LC_F64, LC_E_BADARG, "lc_lanczos_interp_stories: dtype %d unsupported", dtype);
+    LC_REQUIRE(D >= 0 && n_new_total >= 0 && n_stories > 0 && ld_in >= D && ld_out >= (rectify ? 2 * D : D), LC_E_SHAPE,
+               "lc_lanczos_interp_stories: bad shape");
+    if (n_new_total == 0 || D == 0) return LC_OK;
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_LANCZOS, s);
+    dim3 grid((unsigned)n_new_total, (unsigned)lc::ceil_div<long long>(D, LZ_THREADS));
+#define LC_LZS(T, R)                                                                                                  \
+    hipLaunchKernelGGL((k_lanczos_stories<T, R>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, (long long)D,      \
+                       (long long)ld_in, d_oldtime, d_newtime, d_row_story, (const LzStory*)d_stories, window, d_out,  \
+                       (long long)ld_out)
+    if (dtype == LC_F32) { if (rectify) LC_LZS(float, true); else LC_LZS(float, false); }
+    else                 { if (rectify) LC_LZS(double, true); else LC_LZS(double, false); }
+#undef LC_LZS
+    return lc::launched("k_lanczos_stories");
+}
+
+extern "C" int lc_story_design_f32(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,
+                                   const int64_t* h_delays, int nd, float* d_x, int64_t ldx, lc_stream_t stream) {
+    LC_REQUIRE(d_feat && d_stories && h_delays && d_x, LC_E_BADARG, "lc_story_design_f32: null pointer");
+    LC_REQUIRE(ndim > 0 && n_stories > 0 && nd > 0 && nd <= FIR_MAX_DELAYS && ld_in >= ndim && ldx >= ndim * nd, LC_E_SHAPE,
+               "lc_story_design_f32: bad shape (at most %d delays)", FIR_MAX_DELAYS);
+    FirDelays dl;
+    dl.n = nd;
+    for (int k = 0; k < nd; ++k) dl.d[k] = h_delays[k];
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_FIR, s);
+    dim3 grid((unsigned)lc::ceil_div<long long>((long long)nd * ndim, 256), (unsigned)n_stories);
+    hipLaunchKernelGGL(k_story_design, grid, dim3(256), 0, s, d_feat, (long long)ndim, (long long)ld_in,
+                       (const StoryRows*)d_stories, dl, d_x, (long long)ldx);
+    return lc::launched("k_story_design");
 }

@@ -68,7 +68,20 @@ __global__ void __launch_bounds__(256) k_fill_argmax(const double* __restrict__ 
     if (v < V) best[v] = k;
 }
 
+__global__ void __launch_bounds__(256) k_accumulate_f64(const double* __restrict__ x, double* __restrict__ acc, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] += x[i];
+}
+
 }  // namespace
+
+extern "C" int lc_accumulate_f64(const double* d_x, double* d_acc, int64_t n, lc_stream_t stream) {
+    LC_REQUIRE(d_x && d_acc && n >= 0, LC_E_BADARG, "lc_accumulate_f64: bad argument");
+    if (n == 0) return LC_OK;
+    hipLaunchKernelGGL(k_accumulate_f64, dim3((unsigned)lc::ceil_div<long long>(n, 256)), dim3(256), 0, lc::as_stream(stream),
+                       d_x, d_acc, (long long)n);
+    return lc::launched("k_accumulate_f64");
+}
 
 extern "C" int lc_fold_pack_at(const double* d_r_sorted, const double* d_p_sorted, const int32_t* d_perm, int64_t Vs,
                                const int32_t* d_best, int64_t V, const int32_t* d_info_a, int n_a, const int32_t* d_info_b,

@@ -142,31 +142,35 @@ __global__ void __launch_bounds__(256) k_col_normalize(float* __restrict__ x, lo
 
 // Per-story z-scoring of the trainer (utils.py:23-29 ``zs``): float64, POPULATION std, a column whose std is
 // exactly 0 is only de-meaned; optional np.nan_to_num on the result (trainer.py:235,250 applies it to X).
-__global__ void __launch_bounds__(64 * CM_RG) k_zscore_story(const double* __restrict__ x, long long ld_in, long long rows,
-                                                             long long cols, int nan_to_num, double* __restrict__ out,
-                                                             long long ld_out) {
-    __shared__ double sm[CM_RG][64];
-    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
-    const bool live = c < cols;
+// One thread per column walks the rows in order -- numpy reduces axis 0 of a C-ordered matrix row by row, one running
+// sum per column -- without fused multiply-adds: mean, std and the normalised values are the reference's bit for bit
+// (round 4; rounds 1-3 summed in row groups and were a few ulps off).  Lanes across columns: coalesced.
+__global__ void __launch_bounds__(256) k_zscore_story(const double* __restrict__ x, long long ld_in, long long rows,
+                                                      long long cols, int nan_to_num, double* __restrict__ out,
+                                                      long long ld_out) {
+#pragma clang fp contract(off)
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const double* col = x + c;
     double s = 0.0;
-    if (live)
-        for (long long i = threadIdx.y; i < rows; i += CM_RG) s += x[i * ld_in + c];
-    const double mean = block_colsum<CM_RG>(s, sm) / (double)rows;
+    for (long long i = 0; i < rows; ++i) s = s + col[i * ld_in];
+    const double mean = s / (double)rows;
     double q = 0.0;
-    if (live)
-        for (long long i = threadIdx.y; i < rows; i += CM_RG) { const double d = x[i * ld_in + c] - mean; q += d * d; }
-    const double sd = sqrt(block_colsum<CM_RG>(q, sm) / (double)rows);
-    if (live)
-        for (long long i = threadIdx.y; i < rows; i += CM_RG) {
-            double v = x[i * ld_in + c] - mean;
-            if (sd != 0.0) v /= sd;
-            if (nan_to_num) {
-                if (v != v) v = 0.0;
-                else if (v > 1.7976931348623157e308) v = 1.7976931348623157e308;
-                else if (v < -1.7976931348623157e308) v = -1.7976931348623157e308;
-            }
-            out[i * ld_out + c] = v;
+    for (long long i = 0; i < rows; ++i) {
+        const double d = col[i * ld_in] - mean;
+        q = q + d * d;
+    }
+    const double sd = sqrt(q / (double)rows);
+    for (long long i = 0; i < rows; ++i) {
+        double v = col[i * ld_in] - mean;
+        if (sd != 0.0) v = v / sd;
+        if (nan_to_num) {
+            if (v != v) v = 0.0;
+            else if (v > 1.7976931348623157e308) v = 1.7976931348623157e308;
+            else if (v < -1.7976931348623157e308) v = -1.7976931348623157e308;
         }
+        out[i * ld_out + c] = v;
+    }
 }
 
 // Validation-target statistics for the fused scorer.  ystat = [mean | std | var] (unbiased),
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__(1024) k_rowsum(const float* __restrict__ score
 constexpr int GB_THREADS = 512;
 constexpr int GB_MAX_A = 64;
 
-__global__ void __launch_bounds__(GB_THREADS) k_group_by_alpha(const int* __restrict__ best, long long V, int A, int pad,
+__global__ void __launch_bounds__(GB_THREADS) k_group_by_alpha(const int* __restrict__ best, long long V, int a0, int A, int pad,
                                                                int* __restrict__ perm, int* __restrict__ count, int staged) {
     extern __shared__ int hist[];            // A * GB_THREADS, then (staged) V bytes of alpha indices
     __shared__ int carry;
@@ -435,10 +439,14 @@ __global__ void __launch_bounds__(GB_THREADS) k_group_by_alpha(const int* __rest
     const long long lo = (long long)t * L, hi = min(V, lo + L);
     // every thread walks its own contiguous segment twice: straight from global memory that is one dependent ~1 us
     // load per voxel and thread (2 x 157 at V = 80 000: the whole kernel).  With `staged` the indices (< 64: one byte)
-    // are first copied into LDS with coalesced loads and the segments are walked there.
+    // are first copied into LDS with coalesced loads and the segments are walked there.  Indices are taken relative
+    // to a0 (a grid of more than 64 alphas is grouped in ranges of 64, lc_group_by_alpha_range); 255 = in no group.
     unsigned char* stage = reinterpret_cast<unsigned char*>(hist + A * GB_THREADS);
     if (staged) {
-        for (long long v = t; v < V; v += GB_THREADS) stage[v] = (unsigned char)best[v];
+        for (long long v = t; v < V; v += GB_THREADS) {
+            const unsigned rel = (unsigned)(best[v] - a0);
+            stage[v] = rel < (unsigned)A ? (unsigned char)rel : (unsigned char)255;
+        }
         __syncthreads();
     }
     for (int a = 0; a < A; ++a) hist[a * GB_THREADS + t] = 0;
@@ -448,7 +456,7 @@ __global__ void __launch_bounds__(GB_THREADS) k_group_by_alpha(const int* __rest
             if ((int)stage[v] < A) hist[stage[v] * GB_THREADS + t] += 1;
     } else {
         for (long long v = lo; v < hi; ++v)
-            if ((unsigned)best[v] < (unsigned)A) hist[best[v] * GB_THREADS + t] += 1;
+            if ((unsigned)(best[v] - a0) < (unsigned)A) hist[(best[v] - a0) * GB_THREADS + t] += 1;
     }
     if (t == 0) carry = 0;
     __syncthreads();
@@ -477,7 +485,7 @@ __global__ void __launch_bounds__(GB_THREADS) k_group_by_alpha(const int* __rest
         __syncthreads();
     }
     for (long long v = lo; v < hi; ++v) {
-        const int a = staged ? (int)stage[v] : best[v];
+        const int a = staged ? (int)stage[v] : best[v] - a0;
         if ((unsigned)a < (unsigned)A) perm[hist[a * GB_THREADS + t]++] = (int)v;
     }
 }
@@ -738,18 +746,24 @@ extern "C" int lc_select_alpha(const float* d_scores, int A, int64_t V, int32_t*
     return LC_OK;
 }
 
-extern "C" int lc_group_by_alpha(const int32_t* d_best, int64_t V, int A, int pad, int32_t* d_perm,
-                                 int32_t* d_count, lc_stream_t stream) {
+extern "C" int lc_group_by_alpha_range(const int32_t* d_best, int64_t V, int a0, int A, int pad, int32_t* d_perm,
+                                       int32_t* d_count, lc_stream_t stream) {
     LC_REQUIRE(d_best && d_perm && d_count, LC_E_BADARG, "lc_group_by_alpha: null pointer");
-    LC_REQUIRE(A > 0 && A <= GB_MAX_A && pad >= 1, LC_E_SHAPE, "lc_group_by_alpha: A must be in 1..%d, pad >= 1", GB_MAX_A);
+    LC_REQUIRE(a0 >= 0 && A > 0 && A <= GB_MAX_A && pad >= 1, LC_E_SHAPE,
+               "lc_group_by_alpha: a0 >= 0, A in 1..%d per call (larger grids: one call per range of alphas), pad >= 1", GB_MAX_A);
     LC_REQUIRE(V >= 0 && V < (1ll << 31), LC_E_SHAPE, "lc_group_by_alpha: V out of range");
     size_t lds = (size_t)A * GB_THREADS * sizeof(int);
     const int staged = lds + (size_t)V + 16 <= 150 * 1024 ? 1 : 0;      // the indices as bytes behind the histogram table
     if (staged) lds += ((size_t)V + 15) / 16 * 16;
     if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_group_by_alpha), 150 * 1024)) return rc;
-    hipLaunchKernelGGL(k_group_by_alpha, dim3(1), dim3(GB_THREADS), lds, lc::as_stream(stream), d_best, V, A, pad,
+    hipLaunchKernelGGL(k_group_by_alpha, dim3(1), dim3(GB_THREADS), lds, lc::as_stream(stream), d_best, V, a0, A, pad,
                        d_perm, d_count, staged);
     return lc::launched("k_group_by_alpha");
+}
+
+extern "C" int lc_group_by_alpha(const int32_t* d_best, int64_t V, int A, int pad, int32_t* d_perm,
+                                 int32_t* d_count, lc_stream_t stream) {
+    return lc_group_by_alpha_range(d_best, V, 0, A, pad, d_perm, d_count, stream);
 }
 
 extern "C" int lc_pearson_pvalues(const double* d_r, int64_t V, int64_t n, double* d_p, lc_stream_t stream) {
@@ -768,7 +782,7 @@ extern "C" int lc_zscore_story_f64(const double* d_x, int64_t ld_in, int64_t row
     LC_REQUIRE(rows > 0 && cols >= 0 && ld_in >= cols && ld_out >= cols, LC_E_SHAPE, "lc_zscore_story_f64: bad shape");
     if (cols == 0) return LC_OK;
     lc::ScopedTimer timer_(lc::T_COLSTATS, lc::as_stream(stream));
-    hipLaunchKernelGGL(k_zscore_story, dim3((unsigned)lc::ceil_div<long long>(cols, 64)), dim3(64, CM_RG), 0,
+    hipLaunchKernelGGL(k_zscore_story, dim3((unsigned)lc::ceil_div<long long>(cols, 256)), dim3(256), 0,
                        lc::as_stream(stream), d_x, (long long)ld_in, (long long)rows, (long long)cols, nan_to_num, d_out,
                        (long long)ld_out);
     return lc::launched("k_zscore_story");

@@ -16,6 +16,7 @@
 #include "lc_common.h"
 
 #include <atomic>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -28,7 +29,73 @@ namespace {
 struct Chunk {
     int job;
     int64_t r0, r1;        // rows of the job's source block
+    int64_t x0, x1;        // columns of the job's panel, relative to c0 (z-scored jobs are cut by columns, all rows)
 };
+
+// utils.zs (encoding/utils.py:23-29) on a (n rows) x (x1 - x0 columns) block of ONE story, written as float32 into the
+// staging slot (row stride w_stage): per column  m = v - v.mean(0);  s = v.std(0) (population);  m /= s where s != 0 --
+// in the block's own precision (float64 for float64 data, float32 for float32 data, as numpy computes it), then the
+// cast of torch.tensor(..., dtype=float32) (nested_cv.py:99-100).  numpy reduces axis 0 of a C-ordered matrix row by
+// row, one running sum per column: the loops below add in exactly that order, without fused multiply-adds, so the result
+// is the reference's bit for bit.  Sub-tiles of ZS_TILE columns keep the block in cache between its three passes.
+constexpr int64_t ZS_TILE = 256;
+
+template <typename T>
+static inline __attribute__((always_inline)) void zscore_body(const T* src, int64_t ld_src, int64_t n, int64_t x0,
+                                                              int64_t x1, float* stage, int64_t w_stage) {
+#pragma clang fp contract(off)
+    T mean[ZS_TILE], sdev[ZS_TILE];
+    const T cnt = (T)n;
+    for (int64_t t0 = x0; t0 < x1; t0 += ZS_TILE) {
+        const int64_t tw = (x1 - t0 < ZS_TILE) ? x1 - t0 : ZS_TILE;
+        const T* a0 = src + t0;
+        for (int64_t x = 0; x < tw; ++x) mean[x] = (T)0;
+        for (int64_t r = 0; r < n; ++r) {
+            const T* __restrict__ a = a0 + r * ld_src;
+            for (int64_t x = 0; x < tw; ++x) mean[x] += a[x];
+        }
+        for (int64_t x = 0; x < tw; ++x) {
+            mean[x] = mean[x] / cnt;
+            sdev[x] = (T)0;
+        }
+        for (int64_t r = 0; r < n; ++r) {
+            const T* __restrict__ a = a0 + r * ld_src;
+            for (int64_t x = 0; x < tw; ++x) {
+                const T d = a[x] - mean[x];
+                sdev[x] += d * d;
+            }
+        }
+        for (int64_t x = 0; x < tw; ++x) sdev[x] = std::sqrt(sdev[x] / cnt);
+        for (int64_t r = 0; r < n; ++r) {
+            const T* __restrict__ a = a0 + r * ld_src;
+            float* __restrict__ d = stage + r * w_stage + (t0 - x0);
+            for (int64_t x = 0; x < tw; ++x) {
+                T m = a[x] - mean[x];
+                if (sdev[x] != (T)0) m = m / sdev[x];
+                d[x] = (float)m;
+            }
+        }
+    }
+}
+
+// the same loops compiled for AVX2 (no FMA: target("avx2") does not enable it) and for the baseline ISA
+template <typename T>
+__attribute__((target("avx2"))) void zscore_avx2(const T* src, int64_t ld, int64_t n, int64_t x0, int64_t x1, float* st,
+                                                 int64_t ws) {
+    zscore_body<T>(src, ld, n, x0, x1, st, ws);
+}
+
+template <typename T>
+void zscore_base(const T* src, int64_t ld, int64_t n, int64_t x0, int64_t x1, float* st, int64_t ws) {
+    zscore_body<T>(src, ld, n, x0, x1, st, ws);
+}
+
+template <typename T>
+void zscore_block(const T* src, int64_t ld, int64_t n, int64_t x0, int64_t x1, float* st, int64_t ws) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) zscore_avx2<T>(src, ld, n, x0, x1, st, ws);
+    else zscore_base<T>(src, ld, n, x0, x1, st, ws);
+}
 
 struct Slot {
     std::mutex mu;
@@ -91,23 +158,28 @@ void worker(lc_upload* u) {
         }
         const Chunk& c = u->chunks[k];
         const lc_upload_job& j = u->jobs[c.job];
-        const int64_t n = c.r1 - c.r0, w = j.c1 - j.c0;
+        const int64_t n = c.r1 - c.r0, w = c.x1 - c.x0;
         Slot& s = u->slots[k % u->slots.size()];
         std::lock_guard<std::mutex> hold(s.mu);          // one chunk at a time per staging slot
         if (s.used) UP_HIP(hipEventSynchronize(s.ev));   // the slot's previous copy has left it
         float* stage = static_cast<float*>(u->slot_ptr[k % u->slots.size()]);
-        if (j.dtype == LC_F64) {
-            const double* src = static_cast<const double*>(j.src) + c.r0 * j.ld_src + j.c0;
+        if (j.transform == LC_UPLOAD_ZSCORE) {
+            if (j.dtype == LC_F64)
+                zscore_block(static_cast<const double*>(j.src) + j.c0 + c.x0, j.ld_src, n, 0, w, stage, w);
+            else
+                zscore_block(static_cast<const float*>(j.src) + j.c0 + c.x0, j.ld_src, n, 0, w, stage, w);
+        } else if (j.dtype == LC_F64) {
+            const double* src = static_cast<const double*>(j.src) + c.r0 * j.ld_src + j.c0 + c.x0;
             for (int64_t r = 0; r < n; ++r) {
                 const double* __restrict__ a = src + r * j.ld_src;
                 float* __restrict__ d = stage + r * w;
                 for (int64_t x = 0; x < w; ++x) d[x] = (float)a[x];
             }
         } else {
-            const float* src = static_cast<const float*>(j.src) + c.r0 * j.ld_src + j.c0;
+            const float* src = static_cast<const float*>(j.src) + c.r0 * j.ld_src + j.c0 + c.x0;
             for (int64_t r = 0; r < n; ++r) memcpy(stage + r * w, src + r * j.ld_src, (size_t)w * sizeof(float));
         }
-        float* dst = static_cast<float*>(j.dst) + (j.dst_row0 + c.r0) * j.ld_dst + j.c0;
+        float* dst = static_cast<float*>(j.dst) + (j.dst_row0 + c.r0) * j.ld_dst + j.c0 + c.x0;
         if (j.ld_dst == w)
             UP_HIP(hipMemcpyAsync(dst, stage, (size_t)(n * w) * sizeof(float), hipMemcpyHostToDevice, u->stream));
         else
@@ -165,10 +237,29 @@ extern "C" int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* cons
     for (int j = 0; j < n_jobs && rc == LC_OK; ++j) {
         const lc_upload_job& b = jobs[j];
         const int64_t w = b.c1 - b.c0;
+        const bool zs = b.transform == LC_UPLOAD_ZSCORE;
         if (!(b.src && b.dst && b.rows >= 0 && w > 0 && b.ld_src >= b.c1 && b.ld_dst >= b.c1 &&
-              (b.dtype == LC_F32 || b.dtype == LC_F64) && w * 4 <= slot_bytes)) {
-            rc = lc::fail(LC_E_SHAPE, "lc_upload_start: job %d: bad shape, or a row of the panel does not fit a staging slot", j);
+              (b.dtype == LC_F32 || b.dtype == LC_F64) && (b.transform == LC_UPLOAD_CAST || zs) &&
+              (zs ? b.rows * 4 : w * 4) <= slot_bytes)) {
+            rc = lc::fail(LC_E_SHAPE, "lc_upload_start: job %d: bad shape or transform, or a row (z-scored jobs: a column) of "
+                                      "the panel does not fit a staging slot", j);
             break;
+        }
+        if (zs) {
+            // a story's column statistics need ALL its rows: chunks are column ranges (all rows), as wide as a staging
+            // slot allows but no wider than the job's share per thread; whole ZS_TILE sub-tiles, >= 1 MB where possible
+            if (b.rows == 0) continue;
+            int64_t step = slot_bytes / (b.rows * 4);
+            const int64_t share = (w + u->n_threads - 1) / (u->n_threads > 0 ? u->n_threads : 1);
+            const int64_t floor_cols = ((1 << 20) + b.rows * 4 - 1) / (b.rows * 4);
+            if (share < step) step = share > floor_cols ? share : (floor_cols < step ? floor_cols : step);
+            if (step >= ZS_TILE) step = step / ZS_TILE * ZS_TILE;
+            if (step < 1) step = 1;
+            for (int64_t x0 = 0; x0 < w; x0 += step) {
+                u->chunks.push_back({j, 0, b.rows, x0, x0 + step < w ? x0 + step : w});
+                ++u->chunks_left[j];
+            }
+            continue;
         }
         // rows per chunk: what fits a staging slot, but no more than the job's share per thread -- the design (3000 x 3072)
         // fitted three 16 MB slots, so only three threads cast it (2.4 ms at the head of every fit); chunks stay >= 1 MB
@@ -178,7 +269,7 @@ extern "C" int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* cons
         if (share < step) step = share > floor_rows ? share : (floor_rows < step ? floor_rows : step);
         if (step < 1) step = 1;
         for (int64_t r0 = 0; r0 < b.rows; r0 += step) {
-            u->chunks.push_back({j, r0, r0 + step < b.rows ? r0 + step : b.rows});
+            u->chunks.push_back({j, r0, r0 + step < b.rows ? r0 + step : b.rows, 0, w});
             ++u->chunks_left[j];
         }
     }
@@ -197,6 +288,18 @@ extern "C" int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* cons
     }
     u->coordinator = std::thread(coordinate, u);
     *out = u;
+    return LC_OK;
+}
+
+// HOST code (no device involved): what a z-scored upload job does to one story block, callable by itself -- the CPU test
+// suite holds it to numpy's zs + float32 cast bit for bit (tests/test_host_logic.py).
+extern "C" int lc_host_zscore_story(const void* src, int dtype, int64_t ld_src, int64_t rows, int64_t cols, float* out,
+                                    int64_t ld_out) {
+    LC_REQUIRE(src && out, LC_E_BADARG, "lc_host_zscore_story: null pointer");
+    LC_REQUIRE((dtype == LC_F32 || dtype == LC_F64) && rows > 0 && cols >= 0 && ld_src >= cols && ld_out >= cols, LC_E_SHAPE,
+               "lc_host_zscore_story: bad shape or dtype");
+    if (dtype == LC_F64) zscore_block(static_cast<const double*>(src), ld_src, rows, 0, cols, out, ld_out);
+    else zscore_block(static_cast<const float*>(src), ld_src, rows, 0, cols, out, ld_out);
     return LC_OK;
 }
 

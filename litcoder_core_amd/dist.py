@@ -81,11 +81,19 @@ class ShardContext:
         if self._dist is not None and (self.world > 1 or self.always):
             ranks = tuple(self._dist.get_process_group_ranks(group)) if group is not None else None
             key = (ranks, raw)
+            # the lanes live as long as the process-group WORLD they were made in: after destroy_process_group() +
+            # init_process_group() (test sessions, notebooks, repeated jobs) the cached communicators belong to a dead
+            # world and a collective on them fails or hangs -- the entry remembers its world object (held
+            # strongly, so its identity cannot be recycled) and entries of other worlds are dropped
+            world_now = self._dist.group.WORLD
+            for k in [k for k, (w, _) in _LANES.items() if w is not world_now]:
+                del _LANES[k]
             if key not in _LANES:                       # the lanes span exactly the ranks of ``group``
                 be = None if raw in ("", "undefined") else raw
-                _LANES[key] = {lane: self._dist.new_group(ranks=list(ranks) if ranks is not None else None, backend=be)
-                               for lane in ("hat", "refit")}               # same order on every process
-            self._lanes = _LANES[key]
+                _LANES[key] = (world_now, {lane: self._dist.new_group(ranks=list(ranks) if ranks is not None else None,
+                                                                       backend=be)
+                                           for lane in ("hat", "refit")})  # same order on every process
+            self._lanes = _LANES[key][1]
 
     @classmethod
     def single(cls, device=None):

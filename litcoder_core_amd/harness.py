@@ -94,25 +94,108 @@ def structure_concatenated(features, brain, order: Sequence[str], trimming: dict
 
 
 class StoryPipeline:
-    """Stories in, metrics out, with the matrices resident on the GPU from the FIR kernel to the fit
-    (the Lebel-style train/test paradigm of ``AbstractTrainer.train``, trainer.py:284-320)."""
+    """Stories in, metrics out: the Lebel-style train/test paradigm of ``AbstractTrainer.train`` (trainer.py:284-320 with
+    :125-262) as ONE pipelined pass, built around the host link (round 4):
+
+    * features: all stories' Lanczos resampling in one launch (``fit_words``; lc_lanczos_interp_stories), then FIR delays
+      + trim + per-story ``zs`` + ``nan_to_num`` + float32 cast of ALL stories in one launch straight into the design
+      matrix (lc_story_design_f32) -- sums in numpy's order, so the design has the reference's bits;
+    * brain data: never copied or z-scored by Python.  The stories' trimmed row ranges go to the fit's own native
+      uploader as z-scored jobs (ops.HostRows(zscore=True)): its staging threads compute ``zs`` of each (story, column
+      chunk) in the data's own precision -- bit-identical to ``utils.zs`` + the float32 cast of nested_cv.py:99-100 -- and
+      4 bytes per value cross the link, story by story into their rows of the (T, V) target matrix, voxel panel by voxel
+      panel, while the fit already works on the panels that have landed.
+
+    The result equals ``NestedCVModel.fit_predict`` on the matrices ``structure_train_test`` / the reference's trainer
+    builds, bit for bit given the same design (tests/test_gpu_configs.py)."""
 
     def __init__(self, fir_delays: Sequence[int], trimming: dict, model: Optional[NestedCVModel] = None):
         self.fir_delays = [int(d) for d in fir_delays]
         self.trimming = dict(trimming)
         self.model = model or NestedCVModel("ridge_regression")
+        self.last_design = None                        # (dX, T, Tt, p) of the most recent fit (tests)
+
+    # ---------------------------------------------------------------- features
+    def _feature_rows(self, features):
+        """The stories' (downsampled) features as one float64 device matrix, stories concatenated by rows:
+        (matrix, per-story row offsets, per-story row counts)."""
+        dev = ops.device()
+        names = list(features.keys())
+        n_in = [int(features[s].shape[0]) for s in names]
+        off = np.concatenate([[0], np.cumsum(n_in)]).astype(np.int64)
+        ndim = int(features[names[0]].shape[1])
+        feat = torch.empty((int(off[-1]), ndim), dtype=torch.float64, device=dev)
+        for i, s in enumerate(names):
+            f = features[s]
+            if f.shape[1] != ndim:
+                raise RuntimeError("stories with different numbers of feature columns")
+            feat[off[i]:off[i + 1]].copy_(f if torch.is_tensor(f) else _dev_f64(f, dev), non_blocking=True)
+        return feat, off, n_in
+
+    def design(self, feat, off, n_in, names):
+        """The float32 design matrix [Rstim ; Pstim] (zero-padded to 32 columns) from the concatenated features: one
+        launch (lc_story_design_f32).  Returns (dX, T, Tt, p, per-story (start, stop) of the trimmed TARGET rows)."""
+        g = self.trimming.get
+        nd, ndim = len(self.fir_delays), feat.shape[1]
+        p = nd * ndim
+        train, test = names[:-1], names[-1:]
+        a, b = [], []
+        for i, s in enumerate(names):
+            kind = "train" if s in train else "test"
+            lo, hi, _ = slice(g(f"{kind}_features_start", 0), g(f"{kind}_features_end", None)).indices(n_in[i])
+            if hi - lo < 1:
+                raise ValueError("a story is empty after trimming")
+            a.append(lo)
+            b.append(hi)
+        rows = np.asarray(b) - np.asarray(a)
+        row0 = np.concatenate([[0], np.cumsum(rows)])[:-1]
+        T, Tt = int(rows[:len(train)].sum()), int(rows[len(train):].sum())
+        dX = ops.zeros((T + Tt, ops.pad_to(p, 32)), torch.float32, feat.device)
+        ops.story_design(feat, off[:-1], n_in, a, b, row0, self.fir_delays, dX)
+        return dX, T, Tt, p, rows
+
+    def _targets(self, brain, names, rows):
+        """The brain data's trimmed story blocks as the fit's host targets (z-scored in the upload threads)."""
+        g = self.trimming.get
+        blocks = []
+        for i, s in enumerate(names):
+            kind = "train" if i < len(names) - 1 else "test"
+            blk = np.asarray(brain[s])[g(f"{kind}_targets_start", 0):g(f"{kind}_targets_end", None)]
+            if blk.shape[0] < 1:
+                raise ValueError("a story is empty after trimming")
+            if blk.shape[0] != rows[i]:
+                raise RuntimeError("features and targets have different numbers of rows after trimming")
+            blocks.append(blk)
+        return ops.HostRows(blocks, zscore=True)
 
     def fit(self, features: Dict[str, np.ndarray], brain: Dict[str, np.ndarray], **model_kwargs):
-        delayed = apply_fir_delays(features, self.fir_delays)
-        d = structure_train_test_device(delayed, brain, self.trimming)
-        dev = d["Rstim"].device
-        T, Tt = d["Rstim"].shape[0], d["Pstim"].shape[0]
-        p, V = d["Rstim"].shape[1], d["Rresp"].shape[1]
-        if d["Rresp"].shape[0] != T or d["Presp"].shape[0] != Tt:
-            raise RuntimeError("features and targets have different numbers of rows after trimming")
-        X = torch.zeros((T + Tt, ops.pad_to(p, 32)), dtype=torch.float32, device=dev)
-        Y = torch.zeros((T + Tt, ops.pad_to(V, 128)), dtype=torch.float32, device=dev)
-        for dst, top, bottom, n in ((X, d["Rstim"], d["Pstim"], p), (Y, d["Rresp"], d["Presp"], V)):
-            ops.cast_f64_f32(top, dst[:T], T, n)
-            ops.cast_f64_f32(bottom, dst[T:], Tt, n)
-        return self.model.fit_predict_device(X, Y, p, V, n_test_rows=Tt, weights_on_host=True, **model_kwargs)
+        """``features``: per story the (downsampled) feature matrix, host or device; ``brain``: per story the (TRs,
+        voxels) host array.  kwargs as ``NestedCVModel.fit_predict``.  Returns (metrics, float32 host weights, alphas)."""
+        names = list(features.keys())
+        feat, off, n_in = self._feature_rows(features)
+        return self._fit_rows(feat, off, n_in, names, brain, model_kwargs)
+
+    def fit_words(self, words, word_times, tr_times, brain, window=3, cutoff_mult=1.0, **model_kwargs):
+        """From word-level features: per story ``words`` (n_words, D) float32 / float64 host arrays at ``word_times``,
+        resampled to ``tr_times`` by the Lanczos filter (Downsampler(method="lanczos"), trainer.py:174-201) for all
+        stories in one launch, then as ``fit``."""
+        dev = ops.device()
+        names = list(words.keys())
+        blocks = [np.asarray(words[s]) for s in names]
+        if all(b.dtype == np.float32 for b in blocks):
+            rows = ops.HostRows(blocks)
+            dW = ops.upload_f32(rows, rows.shape[1], dev)                # native staging threads, no cast needed
+        else:
+            dW = torch.cat([_dev_f64(b, dev) for b in blocks], dim=0)
+        feat, off = ops.lanczos_interp_stories(dW, [word_times[s] for s in names], [tr_times[s] for s in names],
+                                               window, cutoff_mult, False)
+        n_in = [len(tr_times[s]) for s in names]
+        return self._fit_rows(feat, off, n_in, names, brain, model_kwargs)
+
+    def _fit_rows(self, feat, off, n_in, names, brain, model_kwargs):
+        if len(names) < 2:
+            raise ValueError("the train/test paradigm needs at least two stories")
+        dX, T, Tt, p, rows = self.design(feat, off, n_in, names)
+        Y = self._targets(brain, names, rows)
+        self.last_design = (dX, T, Tt, p)
+        return self.model.fit_predict_device(dX, Y, p, Y.shape[1], n_test_rows=Tt, weights_on_host=True, **model_kwargs)

@@ -41,7 +41,8 @@ SERIES_TERMS = 4                    # terms of the polynomial form of the hat ma
                                     # moments epilogue of the sweep kernel is laid out for exactly four
 SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singcutoff enters a prediction with weight
                                     # S^2 / (S^2 + a^2) <= (singcutoff / a)^2: below 1e-6 it is invisible in fp32
-MAX_ALPHAS = 64                     # lc_group_by_alpha / the grouped GEMMs carry at most 64 alpha groups per launch
+GROUPS_PER_LAUNCH = ops.GROUP_RANGE  # lc_group_by_alpha / the grouped GEMMs carry 64 alpha groups per launch: a larger
+                                    # grid (the reference takes any number, ridge_regression.py:46-50,115) goes range by range
 MAX_INNER_FOLDS = 64                # inner folds per grouped launch of the series chain / per batch of outer folds prepared together
                                     # (more inner folds than this are taken in chunks: no limit on n_inner_folds)
 
@@ -66,6 +67,7 @@ class FitOptions:
     primal_moments_max_p: int = 16          # up to this many features the tall form scores from block products X'Y alone
     primal_max_p: int = 512                 # the primal (p x p) form is taken for tall designs up to this many features
     speculate_first_fold: bool = True       # the first fold's refit systems for every factorised alpha, beside its chain
+    speculate_max_rows: int = 4608          # ... and any refit system ahead of its alpha choice only up to this many rows
     refit_from_image: bool = True           # the refit's alpha-sorted fp16 operand gathered out of the inner CV's image
     panel_cols: int = 36864                 # voxel columns per panel of a host-to-host fit (_column_panels): 12 288 / 24 576 /
                                             # 30 720 / 12 416 at cfg2 (measured 144.1 ms against 145.2 for 24 576-wide panels,
@@ -111,13 +113,11 @@ def check_penalties(alphas, singcutoff, normalpha, n_inner_folds=None):
     al = np.asarray(list(alphas), dtype=np.float64).reshape(-1)
     if al.size == 0:
         raise ValueError("alphas is empty")
-    if al.size > MAX_ALPHAS:
-        raise ValueError(f"at most {MAX_ALPHAS} alphas per fit (got {al.size}): the alpha-grouped kernels carry "
-                         f"{MAX_ALPHAS} groups per launch")
     if n_inner_folds is not None and int(n_inner_folds) < 1:
         raise ValueError("n_inner_folds must be >= 1")
-    if not np.all(np.isfinite(al)) or np.any(al < 0):
-        raise ValueError("alphas must be finite and >= 0 (the penalty is alpha^2: ridge_regression.py:56,117)")
+    if not np.all(np.isfinite(al)):
+        raise ValueError("alphas must be finite (the penalty is alpha^2: ridge_regression.py:56,117)")
+    al = np.abs(al)                                    # ... so a negative alpha is the penalty of |alpha|
     sc = float(singcutoff)
     if not (sc >= 0) or not np.isfinite(sc):
         raise ValueError("singcutoff must be a finite number >= 0")
@@ -313,7 +313,9 @@ class RidgeCVEngine:
             raise RuntimeError(f"shape mismatch: features have {self.Ttot} rows, targets {Y_all.shape[0]}")
         self.p_pad = ops.pad_to(self.p, K_TILE)
         self.Vp_rank = ops.pad_to(max(self.V_rank, 1), COL_TILE)
-        self.alphas = [float(a) for a in alphas]
+        # the penalty is alpha^2 (ridge_regression.py:56,117): a negative grid value IS |alpha| for every operator; the
+        # caller's own values (sign included) come back in best_alphas (_alpha_vector works on the caller's grid)
+        self.alphas = [abs(float(a)) for a in alphas]
         self.A = len(self.alphas)
         self.normalpha = bool(normalpha)
         self.mode = LC_SCORE_CORR if use_corr else LC_SCORE_R2
@@ -1094,6 +1096,8 @@ class RidgeCVEngine:
         perm, count_h, ev = pending
         ev.synchronize()
         count_h = count_h.numpy()
+        if isinstance(perm, list):                       # more than 64 alphas: grouped range by range, joined now
+            perm = ops.join_group_ranges(perm, count_h[0], tile)
         used = [a for a in range(self.A) if count_h[0, a] > 0]
         used_all = [a for a in range(self.A) if count_h[1, a] > 0]       # over all voxel shards
         if self.shard.simulate:     # one rank run alone for timing: its peers' choices are unknown -- assume they
@@ -1915,7 +1919,14 @@ class RidgeCVEngine:
     def refit_ahead_pays(self):
         """Forming the refit operators of EVERY factorised alpha of every fold before any alpha is chosen is cheap enough
         on one GPU when they come from explicit inverses (N^3 flops each) and the grid has only a few such alphas."""
-        return bool(self.cho) and len(self.cho) <= 8 and not self.primal and self._refit_by_inverse(self.cho)
+        return (bool(self.cho) and len(self.cho) <= 8 and not self.primal and self._refit_by_inverse(self.cho)
+                and self.speculation_pays())
+
+    def speculation_pays(self):
+        """Refit systems solved BEFORE the alpha choice cost N^3 fp64 flops each whether or not their alpha is chosen: at
+        cfg2's 2400 training rows that is 14 GFLOP (0.4 ms), hidden beside the sweeps; at 9000 rows (LeBel-style
+        train/test fits) 730 GFLOP -- ~20 ms of the fp64 pipe per alpha nobody may choose.  Ahead only while cheap."""
+        return self.Ttot <= self.opt.speculate_max_rows
 
     def refit_ahead(self, states, alphas=None, after_hat=False):
         """Voxel shards: the refit systems of ALL the given (prepared) folds for ALL factorised alphas in one
@@ -2047,6 +2058,25 @@ class RidgeCVEngine:
         if not self.moments:                           # the moments form refits voxel by voxel: no grouping by alpha
             st["grouping"] = self._group_async(st["best"], st["split"])
         return st
+
+    def fold_choose_joint(self, sts):
+        """``single_alpha`` when a fold is worked through in several voxel ranges (host inputs arriving panel by panel):
+        the ONE alpha is the argmax of the across-voxel mean of the scores (nested_cv.py:396-400), so the per-alpha sums
+        of all ranges -- and of all voxel shards -- are added up on the device before any range is grouped.  Every
+        range's state gets its ``best`` vector and its grouping, as fold_choose would give it."""
+        total = None
+        for st in sts:
+            self._enter(st)
+            _, rowsum = ops.select_alpha(st["scores"], self.A, self.Vp, want_best=False, want_rowsum=True)
+            total = rowsum if total is None else ops.accumulate_f64(rowsum, total)
+        self.shard.all_reduce_(total, "sum")
+        for st in sts:
+            self._enter(st)
+            best = torch.empty(self.Vp, dtype=torch.int32, device=self.dev)
+            st["best"] = ops.fill_argmax(total, self.A, best, self.Vp)
+            if not self.moments:
+                st["grouping"] = self._group_async(st["best"], st["split"])
+        return sts
 
     def fold_select(self, st, single_alpha):
         """Waits for the fold's alpha histogram (fold_choose; the one host synchronisation of a fold) and puts the
@@ -2318,6 +2348,19 @@ class RidgeCVEngine:
             shape = (self.p, self.V_rank)
             self._host_weights = ops.misc_pool().submit(lambda: torch.empty(shape, dtype=torch.float32, pin_memory=True))
 
+    def abandon(self):
+        """The fit is given up half-way (an exception in the driver): wait for everything that still writes into host
+        memory this engine owns -- weight panels on the download stream, staging threads of the upload."""
+        try:
+            self.dl.synchronize()
+            self.comm.synchronize()
+        finally:
+            self._host_weights = self._host_w = None
+            try:
+                self.finish_uploads()
+            except Exception:  # noqa: BLE001 -- the original error is the one to report
+                pass
+
     def finish_uploads(self):
         """Host inputs: wait until every panel of the targets is resident (the fit is being abandoned or repeated)."""
         if self.uploader is not None:
@@ -2448,7 +2491,10 @@ class NestedCVModel(BasePredictivityModel):
             opt["alphas"] = np.logspace(-1, 8, 10)
         check_penalties(opt["alphas"], opt["singcutoff"], opt["normalpha"], opt["n_inner_folds"])
         T = features_dev.shape[0] - n_test_rows
-        shapes = _DeviceShapes(features_dev, n_features), _DeviceShapes(targets_dev, n_voxels_local)
+        # (the targets may also be host row blocks -- ops.HostRows, e.g. the stories of harness.StoryPipeline, z-scored in
+        # the upload threads -- beside a resident design: they then arrive panel by panel like fit_predict's)
+        shapes = (_DeviceShapes(features_dev, n_features),
+                  targets_dev if isinstance(targets_dev, ops.HostRows) else _DeviceShapes(targets_dev, n_voxels_local))
         return self._run(shapes[0], shapes[1], T, n_test_rows, n_voxels_total or n_voxels_local, opt["groups"],
                          opt["folding_type"], opt["n_outer_folds"], opt["n_inner_folds"], opt["chunk_length"],
                          opt["alphas"], opt["alpha_fdr"], opt["single_alpha"], opt["normalpha"], opt["use_corr"],
@@ -2552,6 +2598,41 @@ class NestedCVModel(BasePredictivityModel):
             # find the chip to themselves (fp64 chains beside the MFMA sweeps cost a resident fit ~20 of 137 ms)
             hosted = getattr(eng, "uploader", None) is not None and shard.world == 1
             ahead = shard.world > 1 or (hosted and eng.refit_ahead_pays())
+            if (single_alpha and hosted and len(eng.upload_panels) > 1 and hasattr(eng, "fold_choose_joint")):
+                # ---- single_alpha with host inputs (example.py:104-117, the LeBel-style train/test call): the choice needs
+                # the scores of ALL voxels, but not their sweeps at once -- every fold's sweeps run range by range (the first
+                # fold's as the upload panels land, instead of after the last one: ~55 ms of PCIe at cfg3's 2.9 GB), the
+                # per-alpha sums of the ranges are added on the device (fold_choose_joint), and each range is then refitted
+                # with the one alpha; a range's weights leave for the host as soon as its last fold is in
+                self._plan = list(eng.upload_panels)
+                first = eng.prepare_folds(outer[:1], lmax_pre[:1])[0]
+                if ahead:
+                    eng.refit_ahead([first])
+                sts = [eng.fold_begin(*outer[0], prepared=first, step=(0, eng.upload_panels[0]))]
+                prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else [])
+                if ahead:
+                    eng.refit_ahead(prepared[1:])
+                elif getattr(eng, "cho", None) and eng.opt.speculate_first_fold and eng.speculation_pays():
+                    eng.fold_speculate(first, list(eng.cho), early=True)
+                sts += [eng.fold_begin(*outer[0], prepared=first, step=(0, c)) for c in eng.upload_panels[1:]]
+                for f in range(n):
+                    eng.fold_choose_joint(sts)
+                    nxt = None
+                    if f + 1 < n:                              # the next fold's sweeps behind this fold's choice
+                        cols = eng.download_panels if (f + 1 == n - 1 and weights_on_host) else [(0, eng.V_rank)]
+                        nxt = [eng.fold_begin(*outer[f + 1], prepared=prepared[f + 1], step=(f + 1, c)) for c in cols]
+                    for i, st in enumerate(sts):
+                        st = eng.fold_select(st, True)
+                        if i == 0 and f + 1 < n:
+                            eng.fold_speculate(prepared[f + 1], st["used_all"])
+                        pend = eng.fold_finish(st, scale)
+                        if pend is not None:
+                            if pending is not None:
+                                tail(pending)
+                            pending = pend
+                    sts = nxt
+                tail(pending)
+                return eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan
             plan = eng.plan_steps(n, single_alpha, ahead=hosted and ahead)
             self._plan = sorted({c for _, c in plan})
             # V-independent part of every fold, ahead of everything on the auxiliary stream: fold 0 by itself (its sweeps
@@ -2597,7 +2678,7 @@ class NestedCVModel(BasePredictivityModel):
                 # 145.8-147.6 ms: the fit is bound by the total work of the streams, not by which batch the main stream
                 # waits for; all refit inverses ahead in one batch, as with voxel shards, costs 4 ms here: work for
                 # alphas nobody chooses, beside the fused launches)
-                if getattr(eng, "cho", None) and eng.opt.speculate_first_fold:
+                if getattr(eng, "cho", None) and eng.opt.speculate_first_fold and eng.speculation_pays():
                     eng.fold_speculate(first, list(eng.cho), early=True)      # aux2: fold 0's refit systems, all of them
                 st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
                 prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:], chol_after=eng.chain_gate())
@@ -2651,9 +2732,25 @@ class NestedCVModel(BasePredictivityModel):
             tail(pending)
             return eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan
 
-        def run(form):
+        def run_(form):
             try:
                 return attempt(form, self.precision, X_all, Y_all)
+            except (_WideTargets, _PrimalUnsuitable):
+                raise                                   # handled below / by the caller: the engine lives on
+            except BaseException:
+                # the fit is being abandoned (e.g. "Cholesky failed" from fold_collect in the last folds): finished weight
+                # panels may still be crossing PCIe into the page-locked result buffer through the library's own copies,
+                # which torch's caching host allocator knows nothing about -- drain them (and the uploads) before the
+                # buffer can go back to the allocator
+                eng = getattr(self, "_engine", None)
+                if eng is not None and hasattr(eng, "abandon"):
+                    eng.abandon()
+                self._engine = None
+                raise
+
+        def run(form):
+            try:
+                return run_(form)
             except _WideTargets as why:
                 # host inputs + precision "auto": a panel that arrived later is too wide for the fp16 split -- once, on
                 # the f32 MFMA path, with everything that is resident by now

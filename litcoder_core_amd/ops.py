@@ -163,6 +163,77 @@ def lanczos_interp(data, oldtime, newtime, cutoff, window, rectify):
     return out
 
 
+def story_table(fields, dev):
+    """A table of per-story records for the batched preprocessing kernels: ``fields`` = [(numpy dtype, values), ...] in
+    the C struct's field order (int64 / float64 / int32 members; an int32 tail is padded to the 8-byte record stride)."""
+    n = len(fields[0][1])
+    names = [f"f{i}" for i in range(len(fields))]
+    dt = np.dtype({"names": names, "formats": [f[0] for f in fields]}, align=True)
+    rec = np.zeros(n, dtype=dt)
+    for name, (_, vals) in zip(names, fields):
+        rec[name] = vals
+    return upload(rec.view(np.uint8).reshape(n, dt.itemsize), dev), dt.itemsize
+
+
+def lanczos_interp_stories(data, oldtimes, newtimes, window, cutoff_mult, rectify):
+    """lanczosinterp2D for many stories in ONE launch (lc_lanczos_interp_stories).  ``data``: (sum n_old, D) f32|f64 device
+    matrix, the stories' samples concatenated; ``oldtimes`` / ``newtimes``: per story host float64 arrays.  Returns the
+    (sum n_new, D or 2 D) f64 device matrix of the stories' outputs, concatenated, and the output row offsets."""
+    dt = LC_F32 if data.dtype == torch.float32 else LC_F64
+    _need(data, torch.float32 if dt == LC_F32 else torch.float64, "lanczos_interp_stories")
+    dev = data.device
+    old = [np.asarray(t, dtype=np.float64).reshape(-1) for t in oldtimes]
+    new = [np.asarray(t, dtype=np.float64).reshape(-1) for t in newtimes]
+    n_old = np.asarray([len(t) for t in old], dtype=np.int64)
+    n_new = np.asarray([len(t) for t in new], dtype=np.int64)
+    old_off = np.concatenate([[0], np.cumsum(n_old)])
+    new_off = np.concatenate([[0], np.cumsum(n_new)])
+    if int(old_off[-1]) != data.shape[0]:
+        raise RuntimeError(f"shape mismatch: {data.shape[0]} sample rows, {int(old_off[-1])} sample times")
+    with np.errstate(all="ignore"):                     # (a story with < 2 output times: nan cutoff, like the reference)
+        cutoff = np.asarray([1.0 / np.mean(np.diff(t)) * cutoff_mult if len(t) else 0.0 for t in new], dtype=np.float64)
+    ordered = np.asarray([int(bool(np.all(np.diff(t) >= 0))) for t in old], dtype=np.int32)
+    table, stride = story_table([(np.int64, old_off[:-1]), (np.int64, n_old), (np.int64, new_off[:-1]), (np.float64, cutoff),
+                                 (np.int32, ordered)], dev)
+    assert stride == 40
+    row_story = upload(np.repeat(np.arange(len(new), dtype=np.int32), n_new), dev)
+    d_old = upload(np.concatenate(old) if old else np.zeros(0), dev)
+    d_new = upload(np.concatenate(new) if new else np.zeros(0), dev)
+    D = data.shape[1]
+    ld_out = 2 * D if rectify else D
+    out = torch.empty((int(new_off[-1]), ld_out), dtype=torch.float64, device=dev)
+    _lib.call("lc_lanczos_interp_stories", _p(data), dt, D, data.stride(0), _p(d_old), _p(d_new), int(new_off[-1]),
+              _p(row_story), _p(table), len(new), float(window), int(bool(rectify)), _p(out), ld_out, _s())
+    return out, new_off
+
+
+def story_design(feat, in_off, n_in, a, b, out_row0, delays, X):
+    """The float32 design matrix of a story-structured fit in one launch (lc_story_design_f32): FIR delays + trim +
+    per-story zs + nan_to_num + cast.  ``feat``: (sum n_in, ndim) f64 device matrix (stories concatenated by rows);
+    per story its row offset / count, the trimmed range [a, b) of its delayed rows and its first row in ``X``."""
+    _need(feat, torch.float64, "story_design")
+    table, stride = story_table([(np.int64, in_off), (np.int64, n_in), (np.int64, a), (np.int64, b), (np.int64, out_row0)],
+                                feat.device)
+    assert stride == 40
+    nd = len(delays)
+    arr = (ctypes.c_int64 * max(nd, 1))(*[int(d) for d in delays])
+    _lib.call("lc_story_design_f32", _p(feat), feat.shape[1], feat.stride(0), _p(table), len(in_off), arr, nd, _p(X),
+              X.stride(0), _s())
+    return X
+
+
+def host_zscore_story(block):
+    """float32 (rows, cols) = fl32(zs(block)) on the HOST, exactly as a z-scored upload job stages a story
+    (lc_host_zscore_story; no device involved -- the CPU tests compare it with numpy bit for bit)."""
+    (_, b), = HostRows([block]).blocks
+    out = np.empty(b.shape, dtype=np.float32)
+    item = b.dtype.itemsize
+    _lib.call("lc_host_zscore_story", ctypes.c_void_p(b.ctypes.data), LC_F64 if b.dtype == np.float64 else LC_F32,
+              b.strides[0] // item if b.shape[0] > 1 else max(b.shape[1], 1), b.shape[0], b.shape[1],
+              ctypes.c_void_p(out.ctypes.data), max(b.shape[1], 1))
+    return out
+
+
 def sinc_interp(data, oldtime, newtime, cutoff, window, causal, renorm):
     dt = LC_F32 if data.dtype == torch.float32 else LC_F64
     _need(data, torch.float32 if dt == LC_F32 else torch.float64, "sinc_interp")
@@ -192,14 +263,18 @@ _UPLOAD_DEPTH = 12                  # chunks in flight
 _UPLOAD_LOCK = threading.Lock()     # the ring is the process's: one upload job at a time owns it
 
 
-def _upload_ring():
-    """Pinned staging chunks + staging threads of the process (created on first use)."""
+_UPLOAD_DEPTH_ZS = 32               # ... of an upload that z-scores stories on the way (three passes per chunk on the host:
+                                    # more threads in flight to keep the link busy)
+
+
+def _upload_ring(depth=None):
+    """Pinned staging chunks of the process (created on first use; grown when a deeper ring is asked for)."""
+    depth = _UPLOAD_DEPTH if depth is None else int(depth)
     if _UPLOAD["pinned"] is None:
-        from concurrent.futures import ThreadPoolExecutor
-        import os
-        _UPLOAD["pinned"] = [torch.empty(_UPLOAD_CHUNK, dtype=torch.uint8, pin_memory=True) for _ in range(_UPLOAD_DEPTH)]
-        _UPLOAD["pool"] = ThreadPoolExecutor(max_workers=max(2, min(_UPLOAD_DEPTH, (os.cpu_count() or 4) // 2)))
-    return _UPLOAD["pinned"], _UPLOAD["pool"]
+        _UPLOAD["pinned"] = []
+    while len(_UPLOAD["pinned"]) < depth:
+        _UPLOAD["pinned"].append(torch.empty(_UPLOAD_CHUNK, dtype=torch.uint8, pin_memory=True))
+    return _UPLOAD["pinned"][:depth], None
 
 
 def misc_pool():
@@ -221,10 +296,13 @@ def upload_stream(dev):
 
 class HostRows:
     """Row blocks of host matrices with the same column count, seen as one (rows, cols) matrix without concatenating
-    them (train/test mode hands over the training and the test targets as two arrays)."""
+    them (train/test mode hands over the training and the test targets as two arrays; a story-structured fit one block
+    per story).  ``zscore``: every block is ONE story and is z-scored on its way to the device (utils.zs as the
+    trainer applies it per story, trainer.py:235-257 -- LC_UPLOAD_ZSCORE jobs of the native uploader)."""
 
-    def __init__(self, blocks):
+    def __init__(self, blocks, zscore=False):
         self.blocks = []
+        self.zscore = bool(zscore)
         r = 0
         for b in blocks:
             b = np.asarray(b)
@@ -232,7 +310,11 @@ class HostRows:
                 raise ValueError("expected 2-D arrays")
             if b.dtype not in (np.float32, np.float64):
                 b = b.astype(np.float64)
-            if b.shape[1] and b.strides[1] != b.dtype.itemsize:
+            item = b.dtype.itemsize
+            if b.shape[1] and (b.strides[1] != item or (b.shape[0] > 1 and (
+                    b.strides[0] < b.shape[1] * item or b.strides[0] % item))):
+                # anything the staging threads cannot walk as rows of a positive whole-element stride (a transposed,
+                # row-reversed or broadcast view: the reference's torch.tensor(x) accepts them all) is copied once
                 b = np.ascontiguousarray(b)
             self.blocks.append((r, b))
             r += b.shape[0]
@@ -246,7 +328,10 @@ class _UploadJob(ctypes.Structure):
     """lc_upload_job of include/litcoder_hip.h."""
     _fields_ = [("src", ctypes.c_void_p), ("ld_src", ctypes.c_int64), ("dtype", ctypes.c_int), ("rows", ctypes.c_int64),
                 ("c0", ctypes.c_int64), ("c1", ctypes.c_int64), ("dst", ctypes.c_void_p), ("ld_dst", ctypes.c_int64),
-                ("dst_row0", ctypes.c_int64)]
+                ("dst_row0", ctypes.c_int64), ("transform", ctypes.c_int)]
+
+
+LC_UPLOAD_CAST, LC_UPLOAD_ZSCORE = 0, 1
 
 
 class PanelUploader:
@@ -277,12 +362,15 @@ class PanelUploader:
             first = len(native)
             for row0, blk in host.blocks:
                 item = blk.dtype.itemsize
+                if host.zscore and blk.shape[0] * 4 > _UPLOAD_CHUNK:
+                    raise ValueError("a z-scored story block has more rows than a staging slot holds values")
                 native.append(_UploadJob(blk.ctypes.data, blk.strides[0] // item if blk.shape[0] > 1 else max(blk.shape[1], 1),
                                          LC_F64 if blk.dtype == np.float64 else LC_F32, blk.shape[0], c0, c1,
-                                         dst.data_ptr(), dst.stride(0), row0))
+                                         dst.data_ptr(), dst.stride(0), row0,
+                                         LC_UPLOAD_ZSCORE if host.zscore else LC_UPLOAD_CAST))
             self._natives.append(list(range(first, len(native))))     # the panel = its row blocks' native jobs
         self._native = (_UploadJob * len(native))(*native)
-        pinned, _ = _upload_ring()
+        pinned, _ = _upload_ring(_UPLOAD_DEPTH_ZS if any(h.zscore for h, _, _, _ in self.jobs) else None)
         self._slots = (ctypes.c_void_p * len(pinned))(*[p.data_ptr() for p in pinned])
         self._handle = ctypes.c_void_p()
         self._done = False
@@ -785,6 +873,22 @@ def alpha_sweep_scores_f16x3(ht, rowscale_inv, A, M, N, yt, cscale_inv, yv, V, n
 def gemm_grouped_f16x3(at, rowscale_inv, Mrows, bt, cscale_inv, c, ldc, Ncols, K, group_tiles, slab_light=None,
                        bview=(0, 0, 0)):
     G = len(group_tiles) - 1
+    if G > GROUP_RANGE:
+        # more column groups than one launch carries (a refit over more than 64 distinct alphas): one launch per range
+        # of 64 groups, on views of the operands (group g's A image / row scales and column tile t's B image, column
+        # scales and output columns are contiguous blocks)
+        if slab_light is not None or tuple(bview) != (0, 0, 0):
+            raise ValueError("gemm_grouped_f16x3: more than 64 groups only without slab flags / B views")
+        a_stride = pad_to(Mrows, 256) * K * 2
+        for g0 in range(0, G, GROUP_RANGE):
+            g1 = min(G, g0 + GROUP_RANGE)
+            t0, t1 = int(group_tiles[g0]), int(group_tiles[g1])
+            if t1 == t0:
+                continue
+            gemm_grouped_f16x3(at[g0 * a_stride:], rowscale_inv[g0 * pad_to(Mrows, 256):], Mrows, bt[t0 * 256 * K * 2:],
+                               cscale_inv[t0 * 256:], c[:, t0 * 256:], ldc, (t1 - t0) * 256, K,
+                               [int(t) - t0 for t in group_tiles[g0:g1 + 1]])
+        return
     arr = (ctypes.c_int32 * (G + 1))(*[int(t) for t in group_tiles])
     _lib.call("lc_gemm_grouped_f16x3", _p(at), _p(rowscale_inv), Mrows, _p(bt), _p(cscale_inv), _p(c), ldc, Ncols, K,
               arr, G, _p(slab_light), *bview, _s())
@@ -830,6 +934,11 @@ def select_alpha(scores, A, V, want_best=True, want_rowsum=False):
     return best, rowsum
 
 
+def accumulate_f64(x, acc):
+    _lib.call("lc_accumulate_f64", _p(x), _p(acc), x.numel(), _s())
+    return acc
+
+
 def fill_argmax(rowsum, A, best, V):
     _lib.call("lc_fill_argmax", _p(rowsum), A, _p(best), V, _s())
     return best
@@ -846,16 +955,56 @@ def fold_unpack(src, world, ld, lo, w_max, r, p, idx, p_clean, bad):
     _lib.call("lc_fold_unpack", _p(src), world, ld, _p(lo), w_max, _p(r), _p(p), _p(idx), _p(p_clean), _p(bad), _s())
 
 
+GROUP_RANGE = 64                    # alpha groups one grouping launch / one grouped GEMM launch carries
+
+
 def group_by_alpha(best, V, A, pad):
-    perm = filled((V + A * pad,), torch.int32, best.device, 0xFF)             # -1 everywhere
+    """Counting sort of the voxels by alpha index.  Returns (perm, count (2, A)): for A <= 64 ``perm`` is the one device
+    vector of lc_group_by_alpha; for a larger grid (the reference groups by any number of distinct alphas,
+    ridge_regression.py:46-50) a LIST with one such vector per range of 64 alphas (lc_group_by_alpha_range) -- the caller
+    joins them once the group sizes are on the host (join_group_ranges)."""
     count = torch.empty((2, A), dtype=torch.int32, device=best.device)       # row 0: counts; row 1: a copy (callers
-    _lib.call("lc_group_by_alpha", _p(best), V, A, pad, _p(perm), _p(count), _s())      # all-reduce it over shards)
+    if A <= GROUP_RANGE:                                                      # all-reduce it over shards)
+        perm = filled((V + A * pad,), torch.int32, best.device, 0xFF)         # -1 everywhere
+        _lib.call("lc_group_by_alpha", _p(best), V, A, pad, _p(perm), _p(count), _s())
+    else:
+        perm = []
+        for a0 in range(0, A, GROUP_RANGE):
+            n = min(GROUP_RANGE, A - a0)
+            part = filled((V + n * pad,), torch.int32, best.device, 0xFF)
+            _lib.call("lc_group_by_alpha_range", _p(best), V, a0, n, pad, _p(part), _p(count[0, a0:]), _s())
+            perm.append(part)
     count[1].copy_(count[0])
     return perm, count
 
 
+def join_group_ranges(perms, counts, pad):
+    """One alpha-sorted voxel list from the per-range lists of group_by_alpha (A > 64): range k's groups, each padded to
+    ``pad`` columns, follow range k-1's.  ``counts``: the (A,) group sizes on the host."""
+    lens = []
+    for k in range(len(perms)):
+        c = counts[k * GROUP_RANGE:(k + 1) * GROUP_RANGE]
+        lens.append(int(sum((int(x) + pad - 1) // pad * pad for x in c)))
+    out = filled((max(sum(lens), 1),), torch.int32, perms[0].device, 0xFF)
+    o = 0
+    for part, n in zip(perms, lens):
+        if n:
+            out[o:o + n].copy_(part[:n])
+        o += n
+    return out
+
+
 def gemm_grouped(a, lda, a_group_stride, b, ldb, brows, c, ldc, Mrows, Ncols, K, group_tiles):
     G = len(group_tiles) - 1
+    if G > GROUP_RANGE:                                 # (see gemm_grouped_f16x3: one launch per range of 64 groups)
+        for g0 in range(0, G, GROUP_RANGE):
+            g1 = min(G, g0 + GROUP_RANGE)
+            t0, t1 = int(group_tiles[g0]), int(group_tiles[g1])
+            if t1 > t0:
+                gemm_grouped(a.reshape(-1)[g0 * a_group_stride:], lda, a_group_stride, b[:, t0 * COL_TILE:], ldb, brows,
+                             c[:, t0 * COL_TILE:], ldc, Mrows, (t1 - t0) * COL_TILE, K,
+                             [int(t) - t0 for t in group_tiles[g0:g1 + 1]])
+        return
     arr = (ctypes.c_int32 * (G + 1))(*[int(t) for t in group_tiles])
     _lib.call("lc_gemm_grouped_f32", _p(a), lda, a_group_stride, _p(b), ldb, _p(brows), _p(c), ldc, Mrows, Ncols, K,
               arr, G, _s())

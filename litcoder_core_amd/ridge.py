@@ -4,15 +4,17 @@
 score of every alpha for every voxel.  ``ridge`` = ``ridge_torch`` (``:9-63``): weights with a
 per-voxel (or scalar) alpha.  Both take and return host arrays; the arithmetic is the same HIP
 pipeline ``NestedCVModel`` uses (Gram + batched Cholesky instead of the SVD, fused MFMA sweep).
-``singcutoff``: nothing is truncated here; a direction with singular value <= cutoff enters a prediction
-with weight <= (cutoff / a)^2, and a value that is not negligible against the smallest penalty raises
-(``nested_cv.check_penalties``), as does alpha = 0.
+``singcutoff``: a value that is negligible against the smallest penalty truncates nothing visible in fp32 (a direction
+with singular value <= cutoff enters a prediction with weight <= (cutoff / a)^2); alpha = 0 or a cutoff that bites take
+the spectral route (``nested_cv.check_penalties``), which reproduces ``svd_wrapper``'s truncation.  Any number of
+distinct alphas, negative values included (the penalty is alpha^2).
 """
 from typing import Sequence, Union
 
 import numpy as np
 import torch
 
+from . import ops
 from .nested_cv import RidgeCVEngine
 
 
@@ -22,6 +24,10 @@ def ridge_corr(Rstim, Pstim, Rresp, Presp, alphas: Sequence[float], singcutoff: 
     sqrt|R^2|; NaN -> 0."""
     Rstim, Pstim = np.asarray(Rstim), np.asarray(Pstim)
     n_tr, n_va = len(Rstim), len(Pstim)
+    if n_va == 0:
+        # an empty validation block: z_score of nothing is NaN, nan_to_num makes every score 0 (ridge_regression.py:124-133)
+        ops.device()                                   # (still no CPU path: raises without a gfx950 device)
+        return np.zeros((len(list(alphas)), np.shape(Rresp)[1]), dtype=np.float32)
     eng = RidgeCVEngine(np.concatenate([Rstim, Pstim]), np.concatenate([np.asarray(Rresp), np.asarray(Presp)]),
                         alphas, normalpha, use_corr, False, False, singcutoff=singcutoff)
     scores, info = eng._alpha_scores(eng.K, eng.dY, [(np.arange(n_tr), n_tr + np.arange(n_va))])

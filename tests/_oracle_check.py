@@ -20,10 +20,11 @@ def _alpha_index(alphas, values):
 
 
 def assert_matches_oracle(lc, model, ours, oracle, detail, X, Y, kw, tag, corr_atol=3e-5, w_rtol=2e-4, w_atol=3e-6,
-                          gap_tol=2e-6, min_same=0.9, X_test=None, y_test=None, cols=None):
+                          gap_tol=2e-6, min_same=0.9, X_test=None, y_test=None, cols=None, w_cols=None):
     """``ours`` / ``oracle``: (metrics, W, alphas) of the two fits on the same inputs; ``detail``: the oracle's
     per-fold intermediates (oracle.nested_cv.fit_predict(detail=...)); ``cols``: columns of ``ours`` the oracle was run
-    on (a voxel sample), default all.  Returns the number of flipped (fold, voxel) pairs."""
+    on (a voxel sample), default all; ``w_cols``: the oracle's weight matrix holds only its first ``w_cols`` columns
+    (the reference-generated config fixtures keep 32).  Returns the number of flipped (fold, voxel) pairs."""
     from litcoder_core_amd import ridge
     (m, W, a), (m_o, W_o, a_o) = ours, oracle
     cols = np.arange(len(a_o)) if cols is None else np.asarray(cols)
@@ -59,9 +60,10 @@ def assert_matches_oracle(lc, model, ours, oracle, detail, X, Y, kw, tag, corr_a
     assert clean.mean() >= min_same, f"{tag}: only {clean.mean():.3f} of the voxels chose the oracle's alpha in every fold"
     r, r_o = np.asarray(m["correlations"], dtype=np.float64)[cols], np.asarray(m_o["correlations"], dtype=np.float64)
     np.testing.assert_allclose(r[clean], r_o[clean], rtol=0, atol=corr_atol, err_msg=tag)
-    Wc = W[:, cols]
-    np.testing.assert_allclose(Wc[:, clean], W_o[:, clean], rtol=w_rtol, atol=w_atol * max(1.0, float(np.abs(W_o).max())),
-                               err_msg=tag)
+    nw = len(cols) if w_cols is None else int(w_cols)
+    Wc = np.asarray(W[:, cols[:nw]])
+    np.testing.assert_allclose(Wc[:, clean[:nw]], W_o[:, :nw][:, clean[:nw]], rtol=w_rtol,
+                               atol=w_atol * max(1.0, float(np.abs(W_o).max())), err_msg=tag)
     np.testing.assert_allclose(np.asarray(a)[cols][clean], np.asarray(a_o)[clean], rtol=1e-6, err_msg=tag)
     # flipped voxels: the fold correlation at the ORACLE's alpha, through this package's ridge solver
     plain = not (kw.get("normalize_features") or kw.get("normalize_targets")) and not single

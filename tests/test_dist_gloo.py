@@ -133,6 +133,15 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     out = dict(m=m, W=W, a=a, lo=lo, hi=hi, m2=m2, a2=a2, m3=m3, a3=a3, m4=m4, a4=a4)
     pickle.dump(out, open(os.path.join(sys.argv[3], f"rank{shard.rank}_{mode}.pkl"), "wb"))
     dist.destroy_process_group()
+    # a second world in the same process (notebooks, repeated jobs): the bulk lanes of the destroyed one must not be
+    # reused (ADVICE r3) -- a gather on a lane and a whole sharded fit again
+    dist.init_process_group("gloo")
+    shard2 = ShardContext()
+    g = shard2.all_gather(torch.full((3,), float(shard2.rank)), lane="hat")
+    assert g[:, 0].tolist() == [0.0, 1.0]
+    m5, W5, a5 = ncv.NestedCVModel("r", shard=shard2).fit_predict(X, Y, **kw)
+    assert np.array_equal(W5, W) and np.array_equal(a5, a) and m5["median_score"] == m["median_score"]
+    dist.destroy_process_group()
 else:
     m, W, a = ncv.NestedCVModel("r").fit_predict(X, Y, **kw)
     m2, W2, a2 = ncv.NestedCVModel("r").fit_predict(X[:90], Y[:90], X_test=X[90:], y_test=Y[90:], **kw)

@@ -53,13 +53,14 @@ def test_penalty_grid_validation_and_route():
     assert check_penalties([0.1], 1e-6, True)                            # normalpha: S[0] unknown yet -> the safe route
     model = lc.NestedCVModel("r")
     X, Y = np.zeros((40, 3)), np.zeros((40, 2))
-    for bad in ([-1.0], [np.nan], [np.inf]):
-        with pytest.raises(ValueError, match="alphas must be finite and >= 0"):
+    for bad in ([np.nan], [np.inf]):
+        with pytest.raises(ValueError, match="alphas must be finite"):
             model.fit_predict(X, Y, alphas=bad, folding_type="kfold")
+    # the reference squares alpha (ridge_regression.py:56,117) and takes any number of them (:46-50,115): no refusal
+    assert not check_penalties([-1.0, 2.0], 1e-10, True) and not check_penalties(np.logspace(-1, 8, 200), 1e-10, True)
+    assert check_penalties([-1.0, 0.0], 1e-10, True)                     # ... and 0 still means the spectral route
     with pytest.raises(ValueError, match="singcutoff must be a finite number"):
         model.fit_predict(X, Y, alphas=[1.0], singcutoff=-1.0, folding_type="kfold")
-    with pytest.raises(ValueError, match="at most 64 alphas"):
-        model.fit_predict(X, Y, alphas=np.logspace(-1, 8, 65), folding_type="kfold")
     with pytest.raises(ValueError, match="n_inner_folds must be >= 1"):
         model.fit_predict(X, Y, alphas=[1.0], n_inner_folds=0, folding_type="kfold")
     with pytest.raises(ValueError):
@@ -272,3 +273,23 @@ def test_oracle_banded_search_reduces_to_the_plain_fit():
     det = {}
     oband.fit_predict_search(X, Y, bands, [[1.0, 1.0], [0.5, 3.0]], detail=det, **kw)
     assert det["fold_candidates"].shape == (3, 9) and det["fold_tables"].shape == (3, 8, 9)
+
+
+def test_host_rows_accepts_any_view():
+    """torch.tensor(x, dtype=float32) (nested_cv.py:99-100) takes any array view; the native uploader walks rows of a
+    positive whole-element stride, so HostRows copies what is not that: row-reversed, broadcast,
+    column-strided and Fortran-ordered views -- and keeps plain row slices as views."""
+    from litcoder_core_amd.ops import HostRows
+    Y = np.arange(20.0).reshape(5, 4)
+    views = [Y[::-1], np.broadcast_to(Y[0], (5, 4)), Y[:, ::-1], np.asfortranarray(Y), Y[:, ::2], Y[::2], Y[1:4],
+             Y.astype(np.float32)[::-1], np.arange(20).reshape(5, 4)]
+    for v in views:
+        (r0, b), = HostRows([v]).blocks
+        assert r0 == 0 and np.array_equal(b, v) and b.dtype in (np.float32, np.float64)
+        item = b.dtype.itemsize
+        assert b.strides[1] == item and (b.shape[0] < 2 or (b.strides[0] >= b.shape[1] * item and b.strides[0] % item == 0))
+    assert np.shares_memory(HostRows([Y[::2]]).blocks[0][1], Y) and np.shares_memory(HostRows([Y[1:4]]).blocks[0][1], Y)
+    h = HostRows([Y[:3], Y[::-1]])
+    assert h.shape == (8, 4) and [r for r, _ in h.blocks] == [0, 3]
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        HostRows([Y, Y[:, :2]])
