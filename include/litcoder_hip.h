@@ -432,6 +432,10 @@ int lc_scale_cast_f64_f32(const double* d_src, const double* d_divisor, float* d
                           lc_stream_t stream);
 int lc_combine_terms_f32(const float* const* h_terms, const float* h_coef, int terms, float* d_out, int64_t n,
                          lc_stream_t stream);
+/* The same in float64: the p x p Gram matrices of the primal form's training sets as sums / differences of the
+ * validation blocks' (an inner training set = the outer block minus its validation block, nested_cv.py:366-374). */
+int lc_combine_terms_f64(const double* const* h_terms, const double* h_coef, int terms, double* d_out, int64_t n,
+                         lc_stream_t stream);
 
 /* out[f][i][j] = K[rows[f][i], cols[f][j]] in fp64 (index -1 -> 0): d_out (F, R, C) contiguous.  The test-row block
  * K[te, tr] of the refit's augmented rows (the hat matrix of the test rows, nested_cv.py:151,251). */

@@ -711,7 +711,34 @@ __global__ void __launch_bounds__(256) k_combine_terms(const float* __restrict__
         out[i] = m;
     }
 }
+
+__global__ void __launch_bounds__(256) k_combine_terms_f64(const double* __restrict__ t0, const double* __restrict__ t1,
+                                                           const double* __restrict__ t2, const double* __restrict__ t3,
+                                                           double c0, double c1, double c2, double c3, int terms,
+                                                           double* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        double m = __dmul_rn(t0[i], c0);
+        if (terms > 1) m = __dadd_rn(m, __dmul_rn(t1[i], c1));
+        if (terms > 2) m = __dadd_rn(m, __dmul_rn(t2[i], c2));
+        if (terms > 3) m = __dadd_rn(m, __dmul_rn(t3[i], c3));
+        out[i] = m;
+    }
+}
 }  // namespace
+
+extern "C" int lc_combine_terms_f64(const double* const* h_terms, const double* h_coef, int terms, double* d_out,
+                                    int64_t n, lc_stream_t stream) {
+    LC_REQUIRE(h_terms && h_coef && d_out && terms >= 1 && terms <= 4 && n >= 0, LC_E_BADARG,
+               "lc_combine_terms_f64: need 1..4 terms");
+    for (int j = 0; j < terms; ++j) LC_REQUIRE(h_terms[j], LC_E_BADARG, "lc_combine_terms_f64: null term");
+    if (n == 0) return LC_OK;
+    const double* t[4] = {h_terms[0], terms > 1 ? h_terms[1] : nullptr, terms > 2 ? h_terms[2] : nullptr,
+                          terms > 3 ? h_terms[3] : nullptr};
+    double c[4] = {h_coef[0], terms > 1 ? h_coef[1] : 0.0, terms > 2 ? h_coef[2] : 0.0, terms > 3 ? h_coef[3] : 0.0};
+    hipLaunchKernelGGL(k_combine_terms_f64, dim3((unsigned)lc::imin(lc::ceil_div<long long>(n, 256), 65535)), dim3(256), 0,
+                       lc::as_stream(stream), t[0], t[1], t[2], t[3], c[0], c[1], c[2], c[3], terms, d_out, (long long)n);
+    return lc::launched("k_combine_terms_f64");
+}
 
 extern "C" int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_k, int64_t ldk,
                            lc_stream_t stream) {

@@ -65,7 +65,11 @@ class FitOptions:
                                             # neutral at 10 000 voxels per rank, 2 ms slower at 80 000 -- off; tested
     series_fused_moments: bool = True       # series terms reduced to moments in the contraction's epilogue (never stored)
     primal_moments_max_p: int = 16          # up to this many features the tall form scores from block products X'Y alone
-    primal_max_p: int = 512                 # the primal (p x p) form is taken for tall designs up to this many features
+    primal_max_p: int = 4096                # the primal (p x p) form is taken for tall designs up to this many features
+                                            # (round 4: 512 before; LeBel-style train/test fits have 9000 rows x 3072 features)
+    primal_series_min_p: int = 256          # from this many (padded) features on the primal form shares the large alphas'
+                                            # polynomial terms and takes Gram matrices / block products of the inner training
+                                            # sets as sums over the OTHER folds' validation blocks (_prepare_primal)
     speculate_first_fold: bool = True       # the first fold's refit systems for every factorised alpha, beside its chain
     speculate_max_rows: int = 4608          # ... and any refit system ahead of its alpha choice only up to this many rows
     refit_from_image: bool = True           # the refit's alpha-sorted fp16 operand gathered out of the inner CV's image
@@ -333,7 +337,8 @@ class RidgeCVEngine:
             # the n x n Gram blocks (dual form for every shape; see check_penalties and _spectral_operators)
             logger.info("penalty grid outside the Cholesky route (alpha = 0 or singcutoff not negligible): spectral route")
             self.primal = False
-        self.PP = ops.pad_to(self.p, LC_NB)            # primal: padded system size
+        # primal: padded system size (whole 128-column tiles from 256 features on: the polynomial chain's f32 / fp16x3 GEMMs)
+        self.PP = ops.pad_to(self.p, COL_TILE if self.p >= self.opt.primal_series_min_p else LC_NB)
         # a handful of features + correlation scoring: the whole nested CV from block products X'Y (_prepare_moments)
         self.moments = self.primal and self.p <= self.opt.primal_moments_max_p and bool(use_corr)
         # ---- the targets: resident already, or arriving from the host panel by panel on a background thread (started
@@ -373,7 +378,11 @@ class RidgeCVEngine:
         # alphas whose penalty dwarfs the spectrum take the polynomial form of the inverse (shared matrix powers,
         # minimax coefficients: series.py), the rest the batched Cholesky.  Needs normalpha (a^2 = alpha^2 lambda_max
         # makes the coefficients a function of alpha alone).
-        self.ser = [a for a in range(self.A) if not self.primal       # primal: every alpha is a tiny p x p factorisation
+        # (primal form: a handful of features -> every alpha is a tiny p x p factorisation; from primal_series_min_p
+        # features on the polynomial in G / lambda_max shares its terms exactly as the one in K / lambda_max does)
+        self.primal_series = (self.primal and not self.moments and self.PP % COL_TILE == 0
+                              and self.PP >= self.opt.primal_series_min_p)
+        self.ser = [a for a in range(self.A) if (not self.primal or self.primal_series)
                     and not self.spectral                             # spectral: every alpha from the eigenpairs
                     and self.normalpha and series.residual_bound(self.alphas[a], SERIES_TERMS) <= self.opt.series_tol]
         self.cho = [a for a in range(self.A) if a not in self.ser]
@@ -718,6 +727,7 @@ class RidgeCVEngine:
             for j in range(SERIES_TERMS):
                 rowmap[j * M:(j + 1) * M] = 256 * (b // 2) + 128 * (j >> 1) + 32 * (2 * (j & 1) + (b & 1)) + i % LC_MB
             self._layout = (rows, ops.upload(rowmap, self.dev), None)
+            self._rowmap_host = rowmap
             self._layout_key = key
         if getattr(self, "_layout_key", None) != key:
             per = (M + 127) // 128
@@ -741,6 +751,7 @@ class RidgeCVEngine:
                 lo, hi = s * 128, min(M, (s + 1) * 128)
                 rowmap[j * M + lo:j * M + hi] = slab * 128 + np.arange(hi - lo)
             self._layout = (rows, ops.upload(rowmap, self.dev), ops.upload(np.asarray(cls, dtype=np.uint8), self.dev))
+            self._rowmap_host = rowmap
             self._layout_key = key
         return self._layout
 
@@ -1476,7 +1487,8 @@ class RidgeCVEngine:
         (f0, fc, H, P), = hat["Hs"]
         per = len(hat["cho"]) if hat["moments"] else self.A          # hat matrices kept per inner fold
         sub = dict(hat)
-        sub.update(F=Fo, n_v=hat["n_v"][s:s + Fo], n_i=hat["n_i"][s:s + Fo], tr=hat["tr"][s:s + Fo], va=hat["va"][s:s + Fo],
+        sub.update(F=Fo, n_v=hat["n_v"][s:s + Fo], n_i=hat["n_i"][s:s + Fo],
+                   tr=None if hat["tr"] is None else hat["tr"][s:s + Fo], va=hat["va"][s:s + Fo],
                    lmax=None if hat["lmax"] is None else hat["lmax"][s:s + Fo], a2=hat["a2"][s * self.A:(s + Fo) * self.A],
                    shared=self._shared_image(inner_abs, hat["N"]), xt_off=hat.get("xt_off", 0) + s,
                    Hs=[(0, Fo, None if H is None else H[s * per:(s + Fo) * per], None if P is None else P[s:s + Fo])])
@@ -1622,31 +1634,82 @@ class RidgeCVEngine:
         n_i = [len(t) for t, _ in inner_all]
         n_v = [len(v) for _, v in inner_all]
         M = ops.pad_to(max(n_v), LC_MB)
-        sets = [t for t, _ in inner_all] + [metas[i]["tr"] for i in g]       # inner training sets, then the outer ones
-        Nmax = ops.pad_to(max(len(t) for t in sets), LC_NB)
-        rows_all = ops.idx_matrix(sets, Nmax, self.dev)                      # (S, Nmax)
-        S = len(sets)
-        Xt = ops.gather_transpose_f32(X, rows_all, S, Nmax, p, PP)           # (S * PP, Nmax): Rstim' of every set
-        G = ops.gram_blocks(Xt, S, PP, Nmax)                                 # (S, PP, PP) f64
-        ident = ops.idx_matrix([np.arange(p)] * S, PP, self.dev)             # rows / columns of a system: 0..p-1
+        va = ops.idx_matrix([v for _, v in inner_all], M, self.dev)
+        ident = ops.idx_matrix([np.arange(p)] * (F + len(g)), PP, self.dev)  # rows / columns of a system: 0..p-1
+        # ---- round 4, designs of hundreds to thousands of features (LeBel-style train/test fits: 9000 rows x 3072):
+        # (a) the alphas on the polynomial series share their terms  P'_j = Pstim G^j / lambda^(j+1)  (scored from moments
+        #     in the contraction's epilogue, like the dual form's); (b) when every inner training set is its outer block
+        #     minus its validation block (every fold type but the trimmed ones), the Gram matrix and the block product
+        #     B = Rstim'Rresp of a training set are the SUMS over the other folds' validation blocks: one pass over the
+        #     rows of the outer block instead of one per inner fold, and no transposed copy of the training rows
+        use_series = bool(self.ser) and self._series_by_moments(split) and min(n_v) > 1
+        cho = list(self.cho) if use_series else list(range(A))
+        ser = list(self.ser) if use_series else []
+        by_blocks = self.PP >= self.opt.primal_series_min_p and all(self._inner_partition(metas[i]) for i in g)
+        Xt = Xt_val = None
+        Nmax = ops.pad_to(max(len(t) for t in [t for t, _ in inner_all] + [metas[i]["tr"] for i in g]), LC_NB)
+        rows_all = None
+        if by_blocks:
+            Xt_val = ops.gather_transpose_f32(X, va, F, M, p, PP)            # (F * PP, M): Pstim' of every inner fold
+            G_val = ops.gram_blocks(Xt_val, F, PP, M)                        # (F, PP, PP) f64
+            G = torch.empty((F + len(g), PP, PP), dtype=torch.float64, device=self.dev)
+            s0 = 0
+            for k, i in enumerate(g):
+                Fo = len(metas[i]["inner_abs"])
+                ops.combine_many([G_val[s0 + j] for j in range(Fo)], [1.0] * Fo, G[F + k])          # the outer block's
+                for j in range(Fo):
+                    ops.combine_many([G_val[s0 + q] for q in range(Fo) if q != j], [1.0] * (Fo - 1), G[s0 + j])
+                s0 += Fo
+        else:
+            sets = [t for t, _ in inner_all] + [metas[i]["tr"] for i in g]   # inner training sets, then the outer ones
+            rows_all = ops.idx_matrix(sets, Nmax, self.dev)                  # (S, Nmax)
+            Xt = ops.gather_transpose_f32(X, rows_all, len(sets), Nmax, p, PP)   # (S * PP, Nmax): Rstim' of every set
+            G = ops.gram_blocks(Xt, len(sets), PP, Nmax)                     # (S, PP, PP) f64
+        S = F + len(g)
         lmax = ops.lambda_max_strided(G, PP, PP * PP, ident, S, PP, self.steps) if self.normalpha else None
         self._check_singcutoff(lmax)
-        self._check_feature_scales(G[F])
+        for k in range(len(g)):
+            self._check_feature_scales(G[F + k])
         a2 = ops.penalties(None if lmax is None else lmax[:F], F, self.d_alphas, self.normalpha)
-        va = ops.idx_matrix([v for _, v in inner_all], M, self.dev)
         rhs = ops.gather_rows_f64(X, va, F, M, p, PP)                        # (F, M, PP): Pstim of every inner fold
+        Ac = len(cho)
+        grid_id = [(j // Ac) * A + cho[j % Ac] for j in range(F * Ac)] if Ac else []
 
-        def assemble(jobs):                                                  # job = system f * A + a of the grid
+        def assemble(jobs):                                                  # job -> system fold * A + alpha of the grid
             aug = torch.empty((len(jobs), PP + M, PP), dtype=torch.float64, device=self.dev)
-            sysv = ops.upload(np.asarray(jobs, dtype=np.int32), self.dev)
+            sysv = ops.upload(np.asarray([grid_id[j] for j in jobs], dtype=np.int32), self.dev)
             ops.batch_assemble_sel(G, ident, None, rhs, a2, sysv, len(jobs), A, PP, M, aug, k_fold_stride=PP * PP)
             return aug
 
-        H, info = self._sharded_solve(F * A, PP, M, assemble)                # (>= F * A, M, PP) f32: A_alpha
-        hat = dict(F=F, N=PP, M=M, n_v=n_v, n_i=n_i, tr=rows_all[:F], va=va, shared=None, Hs=[(0, F, H, None)],
-                   info=info, lmax=None if lmax is None else lmax[:F], a2=a2, cho=list(range(A)), ser=[], d_ser=None,
-                   moments=False, series_ready=None, split=split, data_ready=data_ready, Xt=Xt, Nmax=Nmax,
-                   xt_off=0)
+        if Ac:
+            H, info = self._sharded_solve(F * Ac, PP, M, assemble)           # (>= F * Ac, M, PP) f32: A_alpha
+        else:
+            H, info = None, ops.zeros(1, torch.int32, self.dev)
+        P = None
+        if use_series:
+            # the shared terms of the large alphas:  P'_0 = Pstim / lambda,  P'_j = P'_(j-1) (G / lambda)  -- term j enters a
+            # prediction scaled by rho^j, so fp16x3 products (22-bit operands, fp32 accumulation) keep fp32 accuracy, as
+            # in the refit's chain (_refit_systems) -- placed into the slab layout of the moments epilogue
+            rows_p, rowmap, _ = self._series_layout(M)
+            inv = np.full(rows_p, -1, dtype=np.int32)
+            live = self._rowmap_host >= 0
+            inv[self._rowmap_host[live]] = np.arange(SERIES_TERMS * M, dtype=np.int32)[live]
+            inv = ops.upload(inv, self.dev)
+            P = torch.empty((F, rows_p, PP), dtype=torch.float32, device=self.dev)
+            stack = torch.empty((SERIES_TERMS * M, PP), dtype=torch.float32, device=self.dev)
+            Gn = torch.empty((1, PP, PP), dtype=torch.float32, device=self.dev)
+            for f in range(F):
+                ops.gather_sub_f32(G[f], ident[:1], ident[:1], 1, PP, PP, lmax[f:f + 1], Gn)
+                ops.scale_cast_f64_f32(rhs[f], lmax[f:f + 1], stack[:M])
+                for j in range(1, SERIES_TERMS):
+                    stack[j * M:(j + 1) * M].copy_(self._times_symmetric(stack[(j - 1) * M:j * M], Gn)[0])
+                ops.gather(stack, PP, inv, rows_p, None, PP, P[f])
+        series_ready = torch.cuda.Event()
+        series_ready.record()
+        hat = dict(F=F, N=PP, M=M, n_v=n_v, n_i=n_i, tr=None if rows_all is None else rows_all[:F], va=va, shared=None,
+                   Hs=[(0, F, H, P)], info=info, lmax=None if lmax is None else lmax[:F], a2=a2, cho=cho, ser=ser,
+                   d_ser=self.d_ser if use_series else None, moments=use_series, series_ready=None, split=split,
+                   data_ready=data_ready, Xt=Xt, Xt_val=Xt_val, Nmax=Nmax, xt_off=0)
         done = torch.cuda.Event()
         s = 0
         for k, i in enumerate(g):
@@ -1654,17 +1717,33 @@ class RidgeCVEngine:
             Fo = len(m["inner_abs"])
             sub = dict(hat) if len(g) == 1 else self._hat_slice(hat, s, Fo, m["inner_abs"])
             # one tiled image of the outer training targets for all inner folds (see _shared_image): possible when the
-            # inner training sets need no padding rows
+            # inner training sets need no padding rows (only the route that contracts over the training rows uses it)
             n_in = len(m["inner_abs"][0][0])
-            sub["shared"] = self._shared_image(m["inner_abs"], n_in) if n_in % (2 * K_TILE) == 0 else None
+            sub["shared"] = (self._shared_image(m["inner_abs"], n_in) if (n_in % (2 * K_TILE) == 0 and not by_blocks)
+                             else None)
             s += Fo
             out[i] = dict(tr=m["tr"], te=m["te"], X=X, K=G[F + k], split=split, hat=sub, done=done,
                           tr_o=ident[:1], lmax_o=None if lmax is None else lmax[F + k:F + k + 1],
-                          Xt_o=Xt[(F + k) * PP:(F + k + 1) * PP], tr_o_rows=rows_all[F + k], Nmax=Nmax)
+                          Xt_o=None if Xt is None else Xt[(F + k) * PP:(F + k + 1) * PP],
+                          tr_o_rows=None if rows_all is None else rows_all[F + k], Nmax=Nmax)
         done.record()
-        for t in (X, Xt, G, ident, lmax, a2, va, rows_all, rhs, H, info):
+        for t in (X, Xt, Xt_val, G, ident, lmax, a2, va, rows_all, rhs, H, P, info):
             if t is not None and t.is_cuda:
                 t.record_stream(main)                      # allocated on aux, consumed on main
+
+    @staticmethod
+    def _inner_partition(meta):
+        """Every inner training set of the outer fold is its training block minus the fold's validation block, and the
+        validation blocks partition the training block (K-folds, chunked folds; not the trimmed fold types, not
+        time-series splits): Gram matrices and block products of the training sets are then sums over validation blocks."""
+        tr = np.sort(np.asarray(meta["tr"], dtype=np.int64))
+        vals = [np.asarray(v, dtype=np.int64) for _, v in meta["inner_abs"]]
+        if len(vals) < 2 or sum(len(v) for v in vals) != len(tr) or not np.array_equal(np.sort(np.concatenate(vals)), tr):
+            return False
+        for t, v in meta["inner_abs"]:
+            if len(t) + len(v) != len(tr) or not np.array_equal(np.sort(np.concatenate([np.asarray(t, dtype=np.int64), v])), tr):
+                return False
+        return True
 
     def _prepare_moments(self, g, metas, X, data_ready, out, main):
         """prepare_folds for a group of outer folds when p <= FitOptions.primal_moments_max_p and the scores are correlations
@@ -1764,58 +1843,110 @@ class RidgeCVEngine:
         if hat.get("moments_p"):
             return self._sweeps_moments(hat, Y, done)
         A, PP, M, tr, va, n_v, n_i = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"], hat["n_i"]
-        F, Xt, Nmax, off = hat["F"], hat["Xt"], hat["Nmax"], hat["xt_off"]
-        (_, _, H, _), = hat["Hs"]
+        F, Xt, Xt_val, Nmax, off = hat["F"], hat.get("Xt"), hat.get("Xt_val"), hat["Nmax"], hat["xt_off"]
+        (_, _, H, P), = hat["Hs"]
+        moments, cho = hat["moments"], hat["cho"]
+        Ad = len(cho)                                      # alphas with hat matrices (all of them without the series)
+        cho_first = list(cho) == list(range(Ad))
         main = torch.cuda.current_stream()
         split, cs = hat["split"], hat["cs"]
         if hat.get("data_ready") is not None:
             main.wait_event(hat["data_ready"])
         if done is not None:
             main.wait_event(done)
-        self.info.update(precision="f16x3" if split else "f32", fused_alphas=A, series_terms=0)
-        scores = torch.empty((A, self.Vp), dtype=torch.float32, device=self.dev)
-        part = torch.empty((A * M // LC_MB, 4, self.Vp), dtype=torch.float32, device=self.dev)
-        ystat = torch.empty((3, self.Vp), dtype=torch.float32, device=self.dev)
-        yblk = torch.empty((M // LC_MB, self.Vp), dtype=torch.float32, device=self.dev)
-        yv = torch.empty((M, self.Vp), dtype=torch.float32, device=self.dev)
-        Vt = ops.pad_to(self.Vp, 256)
+        self.info.update(precision="f16x3" if split else "f32", fused_alphas=Ad, series_terms=SERIES_TERMS if moments else 0)
+        Vp_, V_ = self.Vp, self.V
+        scores = torch.empty((A, Vp_), dtype=torch.float32, device=self.dev)
+        scores_d = scores if not moments else (scores[:Ad] if cho_first else
+                                               torch.empty((max(Ad, 1), Vp_), dtype=torch.float32, device=self.dev))
+        part = torch.empty((max(Ad, 1) * M // LC_MB, 4, Vp_), dtype=torch.float32, device=self.dev)
+        ystat = torch.empty((3, Vp_), dtype=torch.float32, device=self.dev)
+        yblk = torch.empty((M // LC_MB, Vp_), dtype=torch.float32, device=self.dev)
+        yv = torch.empty((M, Vp_), dtype=torch.float32, device=self.dev)
+        Vt = ops.pad_to(Vp_, 256)
         B = ops.zeros((PP, Vt), torch.float32, self.dev)
         ident = ops.idx_tensor(np.arange(self.p), PP, self.dev)
         shared = hat.get("shared") if split else None
         views = [(0, 0, 0)] * F
+        by_blocks = Xt_val is not None
         if split:
-            At = torch.empty(256 * Nmax * 2, dtype=torch.float16, device=self.dev)
-            rs_a = torch.empty(256, dtype=torch.float32, device=self.dev)
+            depth = M if by_blocks else Nmax
+            At = torch.empty(ops.pad_to(PP, 256) * depth * 2, dtype=torch.float16, device=self.dev)
+            rs_a = torch.empty(ops.pad_to(PP, 256), dtype=torch.float32, device=self.dev)
             if shared is not None:
                 union, gaps = shared
                 Yt = torch.empty(Vt * len(union) * 2, dtype=torch.float16, device=self.dev)
-                ops.split_cols_f16(Y, self.Vp, ops.idx_tensor(union, len(union), self.dev), len(union), cs, Yt)
+                ops.split_cols_f16(Y, Vp_, ops.idx_tensor(union, len(union), self.dev), len(union), cs, Yt)
                 views = [(len(union), g0, gl) for g0, gl in gaps]
             else:
-                Yt = torch.empty(Vt * Nmax * 2, dtype=torch.float16, device=self.dev)
+                Yt = torch.empty(Vt * depth * 2, dtype=torch.float16, device=self.dev)
             cs_inv = self._cs_inv_padded(cs, Vt)
             Bt = torch.empty(Vt * PP * 2, dtype=torch.float16, device=self.dev)
-            rows_pad = ops.pad_to(A * M, 256)
-            Ht = torch.empty(rows_pad * PP * 2, dtype=torch.float16, device=self.dev)
-            rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
+            if Ad:
+                rows_pad = ops.pad_to(Ad * M, 256)
+                Ht = torch.empty(rows_pad * PP * 2, dtype=torch.float16, device=self.dev)
+                rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
+            if moments:
+                Tm, rowmap, _ = self._series_layout(M)
+                tp = ops.pad_to(Tm, 256)
+                Pt = torch.empty(tp * PP * 2, dtype=torch.float16, device=self.dev)
+                rs_p = torch.empty(tp, dtype=torch.float32, device=self.dev)
+                part_s = torch.empty((1, M // LC_MB, 18, Vp_), dtype=torch.float32, device=self.dev)
+        Bv = None
+        if by_blocks:
+            # the block products of the validation blocks, X_v' Y_v (one pass over the rows of the outer training block);
+            # an inner training set's  B = Rstim'Rresp  is the sum over the OTHER folds' (fp32 adds, fold order)
+            Bv = torch.empty((F, PP, Vt), dtype=torch.float32, device=self.dev)
+            for f in range(F):
+                Xv = Xt_val[(off + f) * PP:(off + f + 1) * PP]
+                if split:
+                    ops.split_cols_f16(Y, Vp_, va[f], M, cs, Yt)
+                    ops.split_rows_f16(Xv, PP, M, At, rs_a)
+                    ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, Bv[f], Vt, Vt, M, [0, Vt // 256])
+                    self.info["plain_flops"] += 2.0 * self.p * n_v[f] * V_
+                    self.info["plain_launches"] += 1
+                else:
+                    ops.gemm_grouped(Xv, M, 0, Y, Y.stride(0), va[f], Bv[f], Vt, PP, Vp_, M, [0, Vp_ // COL_TILE])
         for f in range(F):
-            Ni = ops.pad_to(n_i[f], 2 * K_TILE)                                   # contraction depth, padded rows are -1
-            Xt_f = Xt[(off + f) * PP:(off + f + 1) * PP]
-            ops.val_stats(Y, self.Vp, va[f], M, n_v[f], ystat, yblk, yv)
-            if split:
-                if shared is None:
-                    ops.split_cols_f16(Y, self.Vp, tr[f], Ni, cs, Yt)
-                ops.split_rows_f16(Xt_f, PP, Ni, At, rs_a)
-                ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, B, Vt, Vt, Ni, [0, Vt // 256], bview=views[f])
-                csB, _ = ops.col_scales_f16(B, self.p, self.Vp)
-                ops.split_cols_f16(B, self.Vp, ident, PP, csB, Bt)
-                ops.split_rows_f16(H[f * A:(f + 1) * A].reshape(A * M, PP), A * M, PP, Ht, rs_inv)
-                ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, PP, Bt, csB[self.Vp:], yv, self.Vp, n_v[f], ystat, yblk,
-                                             self.mode, part, scores, accumulate=f > 0)
+            ops.val_stats(Y, Vp_, va[f], M, n_v[f], ystat, yblk, yv)
+            if by_blocks:
+                ops.combine_many([Bv[q] for q in range(F) if q != f], [1.0] * (F - 1), B)
             else:
-                ops.gemm_grouped(Xt_f, Nmax, 0, Y, Y.stride(0), tr[f], B, Vt, PP, self.Vp, Ni, [0, self.Vp // COL_TILE])
-                ops.alpha_sweep_scores(H[f * A:(f + 1) * A], A, M, PP, B, self.Vp, ident, yv, n_v[f], ystat, yblk,
+                Ni = ops.pad_to(n_i[f], 2 * K_TILE)                               # contraction depth, padded rows are -1
+                Xt_f = Xt[(off + f) * PP:(off + f + 1) * PP]
+            if split:
+                if not by_blocks:
+                    if shared is None:
+                        ops.split_cols_f16(Y, Vp_, tr[f], Ni, cs, Yt)
+                    ops.split_rows_f16(Xt_f, PP, Ni, At, rs_a)
+                    ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, B, Vt, Vt, Ni, [0, Vt // 256], bview=views[f])
+                    self.info["plain_flops"] += 2.0 * self.p * n_i[f] * V_
+                    self.info["plain_launches"] += 1
+                csB, _ = ops.col_scales_f16(B, self.p, Vp_)
+                ops.split_cols_f16(B, Vp_, ident, PP, csB, Bt)
+                if moments:
+                    ops.split_rows_f16(P[f], Tm, PP, Pt, rs_p)
+                    self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * self.p * V_
+                    self.info["plain_launches"] += 1
+                    ops.series_sweep_scores_f16x3(Pt, rs_p, M, n_v[f], PP, Bt, self._cs_inv_padded(csB, Vt), Vt, yv, Vp_, ystat,
+                                                  yblk, self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0)
+                if Ad:
+                    ops.split_rows_f16(H[f * Ad:(f + 1) * Ad].reshape(Ad * M, PP), Ad * M, PP, Ht, rs_inv)
+                    self.info["fused_flops"] += 2.0 * Ad * n_v[f] * self.p * V_
+                    self.info["fused_launches"] += 1
+                    ops.alpha_sweep_scores_f16x3(Ht, rs_inv, Ad, M, PP, Bt, csB[Vp_:], yv, Vp_, n_v[f], ystat, yblk,
+                                                 self.mode, part, scores_d, accumulate=f > 0)
+            else:
+                if not by_blocks:
+                    ops.gemm_grouped(Xt_f, Nmax, 0, Y, Y.stride(0), tr[f], B, Vt, PP, Vp_, Ni, [0, Vp_ // COL_TILE])
+                ops.alpha_sweep_scores(H[f * A:(f + 1) * A], A, M, PP, B, Vp_, ident, yv, n_v[f], ystat, yblk,
                                        self.mode, part, scores, accumulate=f > 0)
+        if moments and Ad and not cho_first:
+            for i, a in enumerate(cho):
+                scores[a].copy_(scores_d[i])
+        if by_blocks:
+            # the outer block's product = the sum of all its validation blocks': the refit's operand (_primal_refit_inputs)
+            hat["B_all"] = ops.combine_many([Bv[q] for q in range(F)], [1.0] * F, B)
         self.sweeps_done = torch.cuda.Event()
         self.sweeps_done.record()
         return scores
@@ -1829,9 +1960,14 @@ class RidgeCVEngine:
         Vt = ops.pad_to(self.Vp, 256)
         No = ops.pad_to(len(st["tr"]), 2 * K_TILE)
         ext = ops.zeros((PP + n_t, Vt), torch.float32, self.dev)
-        if st["split"]:
-            At = torch.empty(256 * st["Nmax"] * 2, dtype=torch.float16, device=self.dev)
-            rs_a = torch.empty(256, dtype=torch.float32, device=self.dev)
+        B_all = st["hat"].get("B_all")
+        if B_all is not None:
+            # the inner CV of this step left  B_o = Rstim'Rresp  of the outer block (the sum of its validation blocks')
+            ext[:PP].copy_(B_all)
+            csB = ops.col_scales_f16(ext, self.p, self.Vp)[0] if st["split"] else None
+        elif st["split"]:
+            At = torch.empty(ops.pad_to(PP, 256) * st["Nmax"] * 2, dtype=torch.float16, device=self.dev)
+            rs_a = torch.empty(ops.pad_to(PP, 256), dtype=torch.float32, device=self.dev)
             Yt = torch.empty(Vt * No * 2, dtype=torch.float16, device=self.dev)
             cs_inv = self._cs_inv_padded(st["cs"], Vt)
             ops.split_cols_f16(Y, self.Vp, st["tr_o_rows"], No, st["cs"], Yt)
@@ -1926,7 +2062,7 @@ class RidgeCVEngine:
         """Refit systems solved BEFORE the alpha choice cost N^3 fp64 flops each whether or not their alpha is chosen: at
         cfg2's 2400 training rows that is 14 GFLOP (0.4 ms), hidden beside the sweeps; at 9000 rows (LeBel-style
         train/test fits) 730 GFLOP -- ~20 ms of the fp64 pipe per alpha nobody may choose.  Ahead only while cheap."""
-        return self.Ttot <= self.opt.speculate_max_rows
+        return self.primal or self.Ttot <= self.opt.speculate_max_rows        # (primal: p x p systems, always cheap)
 
     def refit_ahead(self, states, alphas=None, after_hat=False):
         """Voxel shards: the refit systems of ALL the given (prepared) folds for ALL factorised alphas in one

@@ -804,6 +804,26 @@ def combine_terms(terms, coef, out):
     return out
 
 
+def combine_many(terms, coef, out):
+    """out = sum_j coef[j] * terms[j] for ANY number of contiguous tensors of out's size and dtype (f32 / f64), left to
+    right: lc_combine_terms_f32 / _f64 in chunks of four (the running sum is the first term of the next chunk)."""
+    f64 = out.dtype == torch.float64
+    name, ctype = ("lc_combine_terms_f64", ctypes.c_double) if f64 else ("lc_combine_terms_f32", ctypes.c_float)
+    terms, coef = list(terms), [float(c) for c in coef]
+    first = True
+    while terms:
+        take = 4 if first else 3
+        ts, cs = terms[:take], coef[:take]
+        terms, coef = terms[take:], coef[take:]
+        if not first:
+            ts, cs = [out] + ts, [1.0] + cs
+        n = len(ts)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        _lib.call(name, ptrs, (ctype * n)(*cs), n, _p(out), out.numel(), _s())
+        first = False
+    return out
+
+
 def gather_sub_f32(k, rows, cols, F, R, C, scale, out):
     _lib.call("lc_gather_sub_f32", _p(k), k.stride(0), _p(rows), _p(cols), F, R, C, _p(scale), _p(out), _s())
 

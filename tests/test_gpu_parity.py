@@ -286,7 +286,7 @@ def test_constant_and_degenerate_voxels(lc):
     with pytest.raises(ValueError):
         lc.NestedCVModel("r").fit_predict(X, Y, folding_type="nope")
     with pytest.raises(ValueError):
-        lc.NestedCVModel("r").fit_predict(X, Y, folding_type="kfold", alphas=[-1.0, 1.0])
+        lc.NestedCVModel("r").fit_predict(X, Y, folding_type="kfold", alphas=[np.nan, 1.0])
     with pytest.raises(RuntimeError):
         lc.NestedCVModel("r").fit_predict(X, Y[:100], folding_type="kfold")
 
@@ -975,7 +975,7 @@ def test_story_pipeline_pieces_bitwise(lc):
                    for n in lens]
         for st in stories:
             st[:, 7] = 3.5                                       # zero std: left un-divided (utils.py:26-28)
-            st[1, 11] = np.nan
+            st[4, 11] = np.nan                                   # (row 4: the first row of the trimmed view)
         views = [st[4:-5] for st in stories]                     # trimmed row ranges: views, like the pipeline's
         host = ops.HostRows(views, zscore=True)
         T = host.shape[0]

@@ -223,3 +223,26 @@ def test_fisher_known_answers():
     got = stats.fisher_combine([[0.01, 1.0], [0.2, 1.0], [0.5, 1.0]])
     assert got[1] == 1.0
     assert abs(got[0] - chi2.sf(-2 * np.log(0.01 * 0.2 * 0.5), 6)) < 1e-15
+
+
+def test_oracle_at_a_config_shape_against_the_reference(golden_dir):
+    """The oracle at a BASELINE config's own shape (cfg4: T = 2226, p = 3072, 20 alphas, 5 x 5 K-folds, 64 of the
+    fixture's 256 voxels) against what the REFERENCE returned there (tests/golden/configs.npz, made by
+    make_golden_configs.py): per-fold alphas identical, per-fold test correlations and score tables to fp32 rounding.
+    (~25 s: thirty SVDs of 1780 x 3072; the other configs' fixtures are held to by the HIP path in the GPU tests.)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _config_problems as cp
+    import _fixtures as fx
+    import oracle.nested_cv as onc
+    g, spec = fx.load(golden_dir)
+    X, Y, kw = cp.matrix_problem("cfg4")
+    fx.check_inputs(g, "cfg4__checks", X, Y)
+    nv = 64
+    detail = {}
+    m, W, a = onc.fit_predict(X, Y[:, :nv], detail=detail, **kw)
+    assert np.array_equal(np.asarray(detail["fold_alphas"]), g["cfg4__fold_alphas"][:, :nv])
+    np.testing.assert_allclose(detail["fold_mean_scores"], g["cfg4__fold_tables"][:, :, :nv], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(detail["fold_scores"], g["cfg4__fold_r"][:, :nv], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(W[:, :32], g["cfg4__W"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(m["correlations"]), g["cfg4__correlations"][:nv], rtol=0, atol=1e-6)
