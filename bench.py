@@ -30,6 +30,10 @@ mixed-width launches `avg_launch_ms` averages over; the full-width launches' fig
 `resident_path.roofline_full_width_launches.traffic` next to THEIR average duration, with the committed profile's
 figure beside it (`traffic_in_committed_profile`, also the fallback there).
 
+`cfg3_pipeline` (N = 1): BASELINE configs[2] -- the config north_star's target sentence names -- end to end and host to
+host through harness.StoryPipeline.fit_words (word features -> Lanczos -> FIR -> per-story zs -> train/test fit,
+single_alpha), with its link floor measured on this box and a `cpu_baseline` of its own (`--no-cfg3` skips it).
+
 Prints ONE JSON line on rank 0.  The `roofline` object is for the dominant kernel, the fp16x3 MFMA
 contraction k_sweep_f16x3, in its fused-score launches (the alphas that go through the batched
 Cholesky: all their predictions reduced to scores in the epilogue): algorithmic flops per launch x 3
@@ -218,6 +222,157 @@ def cpu_baseline(dX, dY, p, V_full, alphas, v_sample=2000):
     }
 
 
+# ------------------------------------------------------------------ cfg3: the LeBel-style story pipeline
+CFG3_TRIM = {"train_features_start": 10, "train_features_end": -5, "train_targets_start": 0, "train_targets_end": None,
+             "test_features_start": 50, "test_features_end": -5, "test_targets_start": 40, "test_targets_end": None}
+CFG3_KW = dict(folding_type="kfold", n_inner_folds=5, chunk_length=20, single_alpha=True, normalpha=True, use_corr=True)
+
+
+def synth_stories(V, dev, seed=0, n_train=26, D=768):
+    """BASELINE configs[2] as synthetic data: 26 training stories + 1 test story of 260-440 TRs (T ~ 9000), per story
+    word-level 768-d float32 features (AR(1)-smoothed, ~3.6 words/s) at irregular word times, TR times (15 more feature
+    TRs than brain TRs: LeBel trimming [10:-5]) and float64 brain data of V voxels in pageable host memory =
+    (z-scored delayed features) W + noise, un-normalised like BOLD data (3 y + 100).  Made on the device (data synthesis
+    only; the Lanczos / FIR kernels used here are the product's own)."""
+    from litcoder_core_amd import Downsampler, ops
+    rng = np.random.default_rng(seed)
+    n_trs = [int(n) for n in rng.integers(260, 440, n_train)] + [291]
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed + 1)
+    Wtrue = 0.004 * torch.randn((4 * D, V), generator=g, device=dev, dtype=torch.float32)
+    words, wtimes, trtimes, brain = {}, {}, {}, {}
+    for i, n_tr in enumerate(n_trs):
+        name = "story%02d" % i
+        n_words = int(7.2 * n_tr)
+        wt = np.sort(rng.uniform(0, 2.0 * (n_tr + 15), n_words))
+        emb = rng.standard_normal((n_words, D)).astype(np.float32)
+        emb[1:] = 0.6 * emb[:-1] + 0.8 * emb[1:]
+        tr_t = 1.0 + 2.0 * np.arange(n_tr + 15)
+        words[name], wtimes[name], trtimes[name] = emb, wt, tr_t
+        ds = Downsampler().downsample(emb, wt, tr_t, method="lanczos", window=3, cutoff_mult=1.0)
+        Xd = ops.fir_delay(torch.from_numpy(ds).to(dev), [1, 2, 3, 4], False)[10:-5]
+        Xd = ((Xd - Xd.mean(0)) / Xd.std(0, unbiased=False)).to(torch.float32)
+        y = Xd @ Wtrue + torch.randn((n_tr, V), generator=g, device=dev, dtype=torch.float32)
+        brain[name] = (3.0 * y + 100.0).cpu().numpy().astype(np.float64)
+    return words, wtimes, trtimes, brain
+
+
+def cfg3_cpu_baseline(words, wtimes, trtimes, brain, v_sample=1500):
+    """The oracle's own pipeline (oracle.lanczos / fir / harness / nested_cv: the reference's algorithm restated) on
+    `v_sample` voxels: the V-independent part (Lanczos, FIR, feature zs, the six SVDs) is timed apart from the part
+    proportional to V (brain zs, projections, sweeps, refit, pearsonr loop)."""
+    import oracle.fir as ofir
+    import oracle.harness as oh
+    import oracle.lanczos as olz
+    import oracle.nested_cv as onc
+    import oracle.ridge as oridge
+    names = list(words)
+    V_full = brain[names[0]].shape[1]
+    t0 = time.perf_counter()
+    feats = {s: ofir.make_delayed(olz.lanczos_interp(words[s], wtimes[s], trtimes[s], window=3, cutoff_mult=1.0), [1, 2, 3, 4])
+             for s in names}
+    t_pre = time.perf_counter() - t0
+    small = {s: brain[s][:, :v_sample] for s in names}
+    t0 = time.perf_counter()
+    mats = oh.train_test_matrices(feats, small, CFG3_TRIM)
+    t_struct = time.perf_counter() - t0
+    svd_time = [0.0]
+    raw_svd = oridge.thin_svd
+
+    def timed_svd(M, cutoff):
+        t = time.perf_counter()
+        out = raw_svd(M, cutoff)
+        svd_time[0] += time.perf_counter() - t
+        return out
+
+    oridge.thin_svd = timed_svd
+    try:
+        t0 = time.perf_counter()
+        onc.fit_predict(mats["Rstim"], mats["Rresp"], X_test=mats["Pstim"], y_test=mats["Presp"], **CFG3_KW)
+        t_fit = time.perf_counter() - t0
+    finally:
+        oridge.thin_svd = raw_svd
+    t_fixed = t_pre + svd_time[0]
+    t_prop = t_struct + t_fit - svd_time[0]
+    t_full = t_fixed + t_prop * V_full / v_sample
+    return {"value": V_full / t_full, "unit": "voxels/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": (f"oracle pipeline (Lanczos + FIR + per-story zs + train/test nested-CV fit, reference algorithm restated) "
+                       f"on {v_sample} of {V_full} voxels: {t_pre + t_struct + t_fit:.1f}s measured ({t_fixed:.1f}s V-independent: "
+                       f"preprocessing {t_pre:.1f}s + six SVDs {svd_time[0]:.1f}s; {t_prop:.1f}s proportional to V); extrapolated "
+                       f"as t_fixed + t_prop*V/{v_sample} = {t_full:.0f}s")}
+
+
+def cfg3_leg(V, dev, steps=3, warmup=1, cpu=True):
+    """BASELINE configs[2] end to end, host to host: per-story word features + float64 brain data in pageable host memory ->
+    Lanczos -> 4 FIR delays -> trim + per-story zs -> train/test nested-CV fit (example.py:104-117: K-folds, default
+    10-alpha grid, single_alpha) -> metrics + float32 host weights, through harness.StoryPipeline.fit_words."""
+    from litcoder_core_amd import NestedCVModel, StoryPipeline, ops
+    words, wtimes, trtimes, brain = synth_stories(V, dev)
+    names = list(words)
+    model = NestedCVModel("ridge_regression")
+    pipe = StoryPipeline([1, 2, 3, 4], CFG3_TRIM, model=model)
+
+    def step():
+        out = pipe.fit_words(words, wtimes, trtimes, brain, **CFG3_KW)
+        torch.cuda.synchronize()
+        return out
+
+    for _ in range(warmup):
+        step()
+    ops.timing_enable(True)
+    ops.timing_read()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = None
+        out = step()
+    elapsed = time.perf_counter() - t0
+    kern = ops.timing_read()
+    ops.timing_enable(False)
+    dX, T, Tt, p = pipe.last_design
+    # the link: float32 of every trimmed brain row up, word features up, float32 weights down -- against the page-locked
+    # rate of THIS box, measured here with a 1 GiB copy each way
+    n = 1 << 30
+    h = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    d = torch.empty(n, dtype=torch.uint8, device=dev)
+    rates = []
+    for src, dst in ((h, d), (d, h)):
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        rates.append(3 * n / (time.perf_counter() - t))
+    del h, d
+    up = (T + Tt) * V * 4 + sum(w.nbytes for w in words.values())
+    down = p * V * 4
+    floor_ms = 1e3 * max(up / rates[0], down / rates[1])
+    ms = 1e3 * elapsed / steps
+    fit = dict(model.last_fit)
+    leg = {
+        "value": V * steps / elapsed, "unit": "voxels/sec", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+        "workload": (f"cfg3 synthetic LeBel-like: {len(names) - 1} training stories + 1 test story (T={T} / {Tt} TRs after "
+                     f"trimming), word-level 768-d float32 features -> Lanczos(window 3) -> 4 FIR delays (p={p}) -> per-story zs "
+                     f"-> train/test fit, V={V}, 10 alphas logspace(-1,8), 5 inner K-folds, single_alpha, normalpha, corr "
+                     f"(example.py:104-117)"),
+        "inputs": "per-story float32 word features + float64 brain data in pageable host memory -> metrics dict + float32 "
+                  "host weights (harness.StoryPipeline.fit_words); every step fenced",
+        "form": model.last_form, "arithmetic": fit.get("precision"), "chosen_alpha": float(out[2][0]),
+        "median_score": out[0]["median_score"], "panels": [list(c) for c in (fit.get("panels") or [])],
+        "link": {"host_brain_bytes_float64": int(sum(b.nbytes for b in brain.values())), "h2d_bytes_float32": int(up),
+                 "d2h_bytes": int(down), "measured_h2d_GBps": rates[0] / 1e9, "measured_d2h_GBps": rates[1] / 1e9,
+                 "link_floor_ms": floor_ms, "ms_per_step_over_link_floor": ms / floor_ms,
+                 "note": "link_floor = max(up bytes / H2D rate, down bytes / D2H rate): what the transfers alone take on this "
+                         "box; the fit's V-wide MFMA work at this shape is several times that (DESIGN.md 5b)"},
+        "sweep_flops_per_step": {"fused": fit.get("fused_flops"), "plain": fit.get("plain_flops")},
+        "kernel_ms_per_step": {k: round(v[0] / steps, 3) for k, v in sorted(kern.items())},
+    }
+    if cpu:
+        leg["cpu_baseline"] = cfg3_cpu_baseline(words, wtimes, trtimes, brain)
+    return leg
+
+
 def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, collect_kernels=False, host=None):
     """`warmup` untimed + `steps` timed fits, barrier + synchronize on both sides, MAX over ranks.  ``host`` = (X, Y)
     float64 numpy arrays: the host-to-host call (the headline), every step followed by a device synchronisation;
@@ -328,6 +483,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip host_path / f32_path / other_scaling")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg3_pipeline leg (N = 1 only)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only)")
     ap.add_argument("--precision", default="auto", choices=["auto", "f32", "f16x3"],
@@ -478,6 +634,10 @@ def main():
                 out["parity_vs_f32_path"] = parity_of(res, r32, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dX, dY, p, V, alphas)
+        if world == 1 and not args.no_extra_legs and not args.no_cfg3:
+            del dX, dY
+            torch.cuda.empty_cache()
+            out["cfg3_pipeline"] = cfg3_leg(args.voxels, dev, cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

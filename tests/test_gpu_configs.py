@@ -436,6 +436,83 @@ def test_primal_form_for_tall_designs(lc):
     np.testing.assert_allclose(ours64[1], ours[1], rtol=2e-4, atol=1e-5)
 
 
+def test_primal_form_with_shared_series_terms_and_block_sums(lc):
+    """Round 4: tall designs of HUNDREDS of features (the LeBel-style train/test shape is 9000 rows x 3072 features: the
+    p x p side is 13x less fp64 work than the n x n one and the sweeps contract over p instead of n).  From 256 features
+    on the primal form (a) scores the alphas on the polynomial series from the moments of shared terms
+    P'_j = Pstim G^j / lambda^(j+1), and (b) takes the Gram matrix and the block product Rstim'Rresp of every inner
+    training set as the sum over the OTHER folds' validation blocks when the folds partition the training block.
+    Against the oracle (ties proven) and against the dual form: K-folds and chunked folds (block sums), trimmed K-folds
+    (no partition: the route that contracts over the training rows, still with the series), R^2 scores and exact-fp32
+    arithmetic (no moments: every alpha a p x p factorisation), train/test + single_alpha, p not a multiple of 128, and a
+    host-to-host fit in voxel panels equal to the resident one bit for bit."""
+    import random
+    import oracle.nested_cv as onc
+    from litcoder_core_amd import ops
+    rng = np.random.default_rng(43)
+    cases = (
+        # (the primal form needs 2 p <= the smallest inner training set)
+        (256, 1800, 900, dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=3, alphas=np.logspace(-1, 5, 9))),
+        (300, 2600, 700, dict(folding_type="chunked", n_outer_folds=2, n_inner_folds=2, chunk_length=25,
+                              alphas=np.logspace(-1, 4, 7), single_alpha=True)),
+        (256, 1900, 500, dict(folding_type="kfold_trimmed", n_outer_folds=2, n_inner_folds=3, alphas=np.logspace(0, 5, 7))),
+        (384, 3300, 400, dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=np.logspace(-1, 3, 5),
+                              use_corr=False)),
+    )
+    for p, T, V, kw in cases:
+        X = rng.standard_normal((T, p))
+        X[1:] = 0.5 * X[:-1] + 0.87 * X[1:]                        # correlated rows, like delayed LM features
+        Y = X @ (rng.standard_normal((p, V)) * (0.4 / np.sqrt(p)) * np.exp(rng.uniform(np.log(0.05), np.log(2.0), V))) \
+            + rng.standard_normal((T, V))
+        Y[:, 2] = -1.0
+        r2 = not kw.get("use_corr", True)
+        tol = dict(corr_atol=1e-3 if r2 else 3e-5, gap_tol=2e-3 if r2 else 2e-6)
+        for tt in (False, True):
+            kw_run = {k: v for k, v in kw.items() if not (tt and k == "n_outer_folds")}
+            args = (X[:-200], Y[:-200]) if tt else (X, Y)
+            extra = dict(X_test=X[-200:], y_test=Y[-200:]) if tt else {}
+            detail = {}
+            random.seed(11)
+            oracle = onc.fit_predict(*args, detail=detail, **extra, **kw_run)
+            for precision in ("auto", "f32"):
+                tag = f"p={p} {kw['folding_type']} tt={tt} {precision}"
+                model = lc.NestedCVModel("r", precision=precision)
+                random.seed(11)
+                ours = model.fit_predict(*args, **extra, **kw_run)
+                assert model.last_form == "primal", tag
+                want_terms = 4 if (precision == "auto" and not r2 and max(kw["alphas"]) >= 8.0) else 0
+                assert model.last_fit["series_terms"] == want_terms, (tag, model.last_fit)
+                assert_matches_oracle(lc, model, ours, oracle, detail, args[0], args[1], kw_run, tag, min_same=0.95, **tol,
+                                      **({k: extra[k] for k in extra} if tt else {}))
+                if precision == "auto":
+                    first = ours
+            dual = lc.NestedCVModel("r", form="dual")
+            random.seed(11)
+            m_d, W_d, a_d = dual.fit_predict(*args, **extra, **kw_run)
+            assert dual.last_form == "dual"
+            same = np.isclose(a_d, first[2], rtol=1e-6)
+            assert same.mean() >= 0.95
+            np.testing.assert_allclose(np.asarray(m_d["correlations"])[same], np.asarray(first[0]["correlations"])[same],
+                                       atol=1e-3 if r2 else 3e-5)
+            np.testing.assert_allclose(W_d[:, same], first[1][:, same], rtol=2e-4, atol=1e-5)
+    # host-to-host in voxel panels == resident, bit for bit (the block sums are per range)
+    p, T, V = 256, 2300, 3000
+    X = rng.standard_normal((T, p))
+    Y = X @ (rng.standard_normal((p, V)) * 0.03) + rng.standard_normal((T, V))
+    kw = dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=np.logspace(-1, 4, 6))
+    dev = ops.device()
+    dX, dY = ops.upload_f32(X, ops.pad_to(p, 32), dev), ops.upload_f32(Y, ops.pad_to(V, 128), dev)
+    res = lc.NestedCVModel("r").fit_predict_device(dX, dY, p, V, weights_on_host=True, **kw)
+    for single in (False, True):
+        kws = dict(kw, single_alpha=single)
+        res = lc.NestedCVModel("r").fit_predict_device(dX, dY, p, V, weights_on_host=True, **kws)
+        host = lc.NestedCVModel("r", panel_cols=1024)
+        out = host.fit_predict(X, Y, **kws)
+        assert host.last_form == "primal" and len(host.last_fit["panels"]) > 1
+        assert np.array_equal(out[1], res[1]) and np.array_equal(out[2], res[2])
+        assert np.array_equal(np.asarray(out[0]["correlations"]), np.asarray(res[0]["correlations"]))
+
+
 def test_block_product_form_on_odd_folds_against_oracle(lc):
     """The moments form of the primal route (p <= 16, correlation scores: csrc/lc_primal.hip) where its bookkeeping
     differs from the plain K-fold case: time-series and trimmed folds (inner training sets that are NOT the outer

@@ -1215,6 +1215,72 @@ def test_wide_target_scales_and_planted_signal(lc):
     np.testing.assert_allclose(W[:, 0], Wtrue, atol=2e-3)
 
 
+def test_bad_voxels_stay_in_their_columns(lc):
+    """Voxels a real mask routinely delivers -- all NaN, one NaN sample, one Inf sample, all zero -- no longer put the fit
+    on the f32 path (one such voxel in 80 000 cost 5x): every V-wide kernel keeps a voxel's arithmetic in its
+    own column, so a bad voxel ends where the reference's fp32 arithmetic ends it (scores NaN -> 0, alpha = alphas[0],
+    r NaN -> (0, 1), non-finite weights) and its neighbours' results are BIT-IDENTICAL to a fit without it.  A column with
+    a spike of 300 x its rms stays on f16x3 too (typical entries keep 17 bits of the split): held to the oracle at 2e-4;
+    a column of float32 denormals must come out finite with alpha = alphas[0] like the oracle's (its r is rounding
+    noise in any arithmetic).  Per-voxel and single alpha (the across-voxel mean must skip the NaN voxels' zeros alike)."""
+    import warnings
+    import oracle.nested_cv as onc
+    from _oracle_check import assert_matches_oracle
+    rng = np.random.default_rng(31)
+    T, p, V = 420, 90, 700
+    X = rng.standard_normal((T, p))
+    Yc = X @ (rng.standard_normal((p, V)) * 0.25 / np.sqrt(p)) * np.exp(rng.uniform(-2, 1, V)) + rng.standard_normal((T, V))
+    Y = Yc.copy()
+    Y[:, 3] = np.nan
+    Y[57, 10] = np.nan
+    Y[200, 17] = np.inf
+    Y[:, 25] = 0.0
+    Y[133, 30] = 300.0 * Y[:, 30].std()
+    Y[:, 41] *= 1e-39                                  # float32 denormals (< 1.18e-38)
+    nonfinite, special = [3, 10, 17], [3, 10, 17, 25, 30, 41]
+    clean = np.setdiff1d(np.arange(V), special)
+    alphas = np.logspace(-1, 3, 5)
+    for single in (False, True):
+        kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=alphas, single_alpha=single)
+        model = lc.NestedCVModel("r")
+        m, W, a = model.fit_predict(X, Y, **kw)
+        assert model.last_fit["precision"] == "f16x3", "a non-finite voxel must not move the fit to the f32 path"
+        detail = {}
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore")
+            m_o, W_o, a_o = onc.fit_predict(X, Y, detail=detail, **kw)
+        r, r_o = np.asarray(m["correlations"]), np.asarray(m_o["correlations"])
+        for v in nonfinite + [25]:
+            assert r[v] == 0.0 and r_o[v] == 0.0 and m["p_values"][v] == 1.0 and not m["significant_mask"][v], v
+            assert a[v] == a_o[v], v
+        for v in nonfinite:
+            assert not np.isfinite(W[:, v]).any() and not np.isfinite(W_o[:, v]).any(), v
+        assert not W[:, 25].any() and not W_o[:, 25].any()
+        assert np.isfinite(W[:, clean]).all() and np.isfinite(r).all()
+        # (float32 denormals of ~1e-39 carry about six digits in ANY fp32 arithmetic, the oracle's too)
+        assert np.isfinite(W[:, 41]).all() and abs(r[41] - r_o[41]) < 0.01 and a[41] == a_o[41]
+        # every clean voxel against the oracle (ties proven); the spiked one a little looser
+        keep = np.r_[clean, 30]
+        sub = ({k: (np.asarray(v)[keep] if isinstance(v, list) and len(v) == V else v) for k, v in m.items()}, W[:, keep], a[keep])
+        sub_o = ({"correlations": r_o[keep]}, W_o[:, keep], np.asarray(a_o)[keep])
+        if single:
+            assert np.array_equal(a, a_o)
+            np.testing.assert_allclose(r[clean], r_o[clean], atol=3e-5)
+            np.testing.assert_allclose(W[:, clean], W_o[:, clean], rtol=2e-4, atol=3e-6 * float(np.abs(W_o[:, clean]).max()))
+        else:
+            det = dict(detail, fold_alphas=np.asarray(detail["fold_alphas"])[:, keep],
+                       fold_mean_scores=np.asarray(detail["fold_mean_scores"])[:, :, keep],
+                       fold_scores=np.asarray(detail["fold_scores"])[:, keep])
+            model.last_fold_alphas = [np.asarray(f)[keep] for f in model.last_fold_alphas]
+            assert_matches_oracle(lc, model, sub, sub_o, det, X, Y[:, keep], kw, f"bad voxels single={single}",
+                                  corr_atol=2e-4, w_rtol=2e-3, w_atol=1e-5, min_same=0.97)
+        # the neighbours never see the bad voxels: the same fit with ordinary data in their columns
+        m2, W2, a2 = lc.NestedCVModel("r").fit_predict(X, np.where(np.isin(np.arange(V), special)[None, :], Yc, Y), **kw)
+        if not single:                                 # (the one alpha is a mean over ALL voxels: different data, other mean)
+            assert np.array_equal(np.asarray(m2["correlations"])[clean], r[clean]) and np.array_equal(a2[clean], a[clean])
+            assert np.array_equal(W2[:, clean], W[:, clean])
+
+
 def test_precision_policy(lc):
     """'auto' takes the fp16x3 sweep on ordinary data and falls back to the f32 MFMA when a target column has
     an outlier far above its rms (the 22-bit split would lose the small values); both agree with 'f32'."""

@@ -293,3 +293,28 @@ def test_host_rows_accepts_any_view():
     assert h.shape == (8, 4) and [r for r, _ in h.blocks] == [0, 3]
     with pytest.raises(RuntimeError, match="shape mismatch"):
         HostRows([Y, Y[:, :2]])
+
+
+def test_host_zscore_of_a_story_is_numpys_bit_for_bit():
+    """What a z-scored upload job (LC_UPLOAD_ZSCORE, csrc/lc_upload.hip) stages for one story: utils.zs
+    (encoding/utils.py:23-29: population std, zero-std columns only de-meaned) in the data's own precision followed by the
+    float32 cast of nested_cv.py:99-100.  numpy reduces axis 0 of a C-ordered matrix row by row, one running sum per
+    column; the staging threads add in that order without fused multiply-adds -- so the bytes that cross PCIe are the
+    reference's.  Host code: runs without a GPU (lc_host_zscore_story)."""
+    from litcoder_core_amd import ops
+    import oracle.harness as oh
+    rng = np.random.default_rng(0)
+    for dt in (np.float64, np.float32):
+        for shape in ((337, 1000), (5, 3), (291, 3001), (2, 17), (1, 9)):
+            v = (rng.standard_normal(shape) * rng.uniform(0.1, 30, shape[1]) + rng.uniform(-100, 100, shape[1])).astype(dt)
+            v[:, 1] = 0.5                                            # zero std: de-meaned, not divided
+            if shape[0] > 1 and shape[1] > 5:
+                v[1, 4] = np.nan
+            with np.errstate(all="ignore"):
+                want = oh.zs(v.copy()).astype(np.float32)
+            got = ops.host_zscore_story(v)
+            assert got.dtype == np.float32 and np.array_equal(got, want, equal_nan=True), (dt, shape)
+            assert not got[:, 1].any()
+        big = rng.standard_normal((400, 5000)).astype(dt)
+        view = big[10:-5, 100:4000]                                  # a trimmed story inside a wider matrix
+        assert np.array_equal(ops.host_zscore_story(view), oh.zs(view.copy()).astype(np.float32))
