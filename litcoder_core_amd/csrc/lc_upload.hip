@@ -16,9 +16,11 @@
 #include "lc_common.h"
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -30,6 +32,20 @@ struct Chunk {
     int job;
     int64_t r0, r1;        // rows of the job's source block
     int64_t x0, x1;        // columns of the job's panel, relative to c0 (z-scored jobs are cut by columns, all rows)
+    int first_task, n_tasks;
+};
+
+// A chunk is ONE staging slot and ONE 2-D copy (wide rows: a copy engine takes ~1.5 us per row whatever its width, so a
+// story's 350 rows should be tens of KB each, not 2 KB); its staging work is cut into TASKS -- column sub-ranges of a
+// z-scored chunk -- that the threads take one by one, and whoever finishes a chunk's last task issues its copy.
+struct Task {
+    int chunk;
+    int64_t m0, m1;        // columns relative to the chunk's x0
+};
+
+struct Slot {
+    hipEvent_t ev = nullptr;
+    bool recorded = false;  // written by the one thread that issues the slot's current chunk
 };
 
 // utils.zs (encoding/utils.py:23-29) on a (n rows) x (x1 - x0 columns) block of ONE story, written as float32 into the
@@ -39,6 +55,7 @@ struct Chunk {
 // row, one running sum per column: the loops below add in exactly that order, without fused multiply-adds, so the result
 // is the reference's bit for bit.  Sub-tiles of ZS_TILE columns keep the block in cache between its three passes.
 constexpr int64_t ZS_TILE = 256;
+constexpr int64_t ZS_TASK = 1024;     // columns per staging task of a z-scored chunk (a multiple of ZS_TILE)
 
 template <typename T>
 static inline __attribute__((always_inline)) void zscore_body(const T* src, int64_t ld_src, int64_t n, int64_t x0,
@@ -97,17 +114,14 @@ void zscore_block(const T* src, int64_t ld, int64_t n, int64_t x0, int64_t x1, f
     else zscore_base<T>(src, ld, n, x0, x1, st, ws);
 }
 
-struct Slot {
-    std::mutex mu;
-    hipEvent_t ev = nullptr;
-    bool used = false;
-};
-
 }  // namespace
 
 struct lc_upload {
     std::vector<lc_upload_job> jobs;
     std::vector<Chunk> chunks;
+    std::vector<Task> tasks;
+    std::unique_ptr<std::atomic<int>[]> tasks_left;     // per chunk: staging tasks not yet done
+    std::unique_ptr<std::atomic<int>[]> chunk_issued;   // per chunk: its copy is in the stream, its slot event recorded
     std::vector<int> chunks_left;          // per job: chunks not yet issued
     std::vector<hipEvent_t> job_ev;        // recorded on the upload stream behind the job's last copy
     std::vector<char> job_issued;
@@ -149,36 +163,52 @@ void fail_upload(lc_upload* u, const std::string& what) {
 
 void worker(lc_upload* u) {
     UP_HIP(hipSetDevice(u->device));
+    const int n_slots = (int)u->slots.size();
     for (;;) {
-        const size_t k = u->next.fetch_add(1);
-        if (k >= u->chunks.size()) return;
+        const size_t t = u->next.fetch_add(1);
+        if (t >= u->tasks.size()) return;
         {
             std::lock_guard<std::mutex> lk(u->mu);
             if (u->failed) return;
         }
+        const Task& tk = u->tasks[t];
+        const int k = tk.chunk;
         const Chunk& c = u->chunks[k];
         const lc_upload_job& j = u->jobs[c.job];
-        const int64_t n = c.r1 - c.r0, w = c.x1 - c.x0;
-        Slot& s = u->slots[k % u->slots.size()];
-        std::lock_guard<std::mutex> hold(s.mu);          // one chunk at a time per staging slot
-        if (s.used) UP_HIP(hipEventSynchronize(s.ev));   // the slot's previous copy has left it
-        float* stage = static_cast<float*>(u->slot_ptr[k % u->slots.size()]);
+        const int64_t n = c.r1 - c.r0, w = c.x1 - c.x0, mw = tk.m1 - tk.m0;
+        Slot& s = u->slots[k % n_slots];
+        if (k >= n_slots) {
+            // the slot's previous chunk (k - n_slots): every task of it was taken before this one (tasks are handed out in
+            // order) by a thread that finishes it without waiting for anything later -- so this wait ends -- and its copy
+            // must have left the slot before the slot is written again
+            while (!u->chunk_issued[k - n_slots].load(std::memory_order_acquire)) {
+                {
+                    std::lock_guard<std::mutex> lk(u->mu);
+                    if (u->failed) return;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            UP_HIP(hipEventSynchronize(s.ev));
+        }
+        float* stage = static_cast<float*>(u->slot_ptr[k % n_slots]);
         if (j.transform == LC_UPLOAD_ZSCORE) {
             if (j.dtype == LC_F64)
-                zscore_block(static_cast<const double*>(j.src) + j.c0 + c.x0, j.ld_src, n, 0, w, stage, w);
+                zscore_block(static_cast<const double*>(j.src) + j.c0 + c.x0 + tk.m0, j.ld_src, n, 0, mw, stage + tk.m0, w);
             else
-                zscore_block(static_cast<const float*>(j.src) + j.c0 + c.x0, j.ld_src, n, 0, w, stage, w);
+                zscore_block(static_cast<const float*>(j.src) + j.c0 + c.x0 + tk.m0, j.ld_src, n, 0, mw, stage + tk.m0, w);
         } else if (j.dtype == LC_F64) {
-            const double* src = static_cast<const double*>(j.src) + c.r0 * j.ld_src + j.c0 + c.x0;
+            const double* src = static_cast<const double*>(j.src) + c.r0 * j.ld_src + j.c0 + c.x0 + tk.m0;
             for (int64_t r = 0; r < n; ++r) {
                 const double* __restrict__ a = src + r * j.ld_src;
-                float* __restrict__ d = stage + r * w;
-                for (int64_t x = 0; x < w; ++x) d[x] = (float)a[x];
+                float* __restrict__ d = stage + r * w + tk.m0;
+                for (int64_t x = 0; x < mw; ++x) d[x] = (float)a[x];
             }
         } else {
-            const float* src = static_cast<const float*>(j.src) + c.r0 * j.ld_src + j.c0 + c.x0;
-            for (int64_t r = 0; r < n; ++r) memcpy(stage + r * w, src + r * j.ld_src, (size_t)w * sizeof(float));
+            const float* src = static_cast<const float*>(j.src) + c.r0 * j.ld_src + j.c0 + c.x0 + tk.m0;
+            for (int64_t r = 0; r < n; ++r) memcpy(stage + r * w + tk.m0, src + r * j.ld_src, (size_t)mw * sizeof(float));
         }
+        if (u->tasks_left[k].fetch_sub(1, std::memory_order_acq_rel) != 1) continue;
+        // this thread staged the chunk's last piece: the chunk's ONE copy (rows of w floats), then its slot event
         float* dst = static_cast<float*>(j.dst) + (j.dst_row0 + c.r0) * j.ld_dst + j.c0 + c.x0;
         if (j.ld_dst == w)
             UP_HIP(hipMemcpyAsync(dst, stage, (size_t)(n * w) * sizeof(float), hipMemcpyHostToDevice, u->stream));
@@ -186,7 +216,8 @@ void worker(lc_upload* u) {
             UP_HIP(hipMemcpy2DAsync(dst, (size_t)j.ld_dst * sizeof(float), stage, (size_t)w * sizeof(float),
                                     (size_t)w * sizeof(float), (size_t)n, hipMemcpyHostToDevice, u->stream));
         UP_HIP(hipEventRecord(s.ev, u->stream));
-        s.used = true;
+        s.recorded = true;
+        u->chunk_issued[k].store(1, std::memory_order_release);
         bool last;
         {
             std::lock_guard<std::mutex> lk(u->mu);
@@ -229,7 +260,7 @@ extern "C" int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* cons
     u->slot_bytes = slot_bytes;
     u->device = device;
     u->stream = lc::as_stream(stream);
-    u->n_threads = n_threads < n_slots ? n_threads : n_slots;
+    u->n_threads = n_threads;
     u->chunks_left.assign(n_jobs, 0);
     u->job_issued.assign(n_jobs, 0);
     u->job_ev.assign(n_jobs, nullptr);
@@ -246,17 +277,21 @@ extern "C" int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* cons
             break;
         }
         if (zs) {
-            // a story's column statistics need ALL its rows: chunks are column ranges (all rows), as wide as a staging
-            // slot allows but no wider than the job's share per thread; whole ZS_TILE sub-tiles, >= 1 MB where possible
+            // a story's column statistics need ALL its rows: a chunk is a column range (all rows), as WIDE as a staging
+            // slot allows -- its copy then moves rows of tens of KB -- and its z-scoring is cut into tasks of ZS_TASK
+            // columns that the threads share
             if (b.rows == 0) continue;
             int64_t step = slot_bytes / (b.rows * 4);
-            const int64_t share = (w + u->n_threads - 1) / (u->n_threads > 0 ? u->n_threads : 1);
-            const int64_t floor_cols = ((1 << 20) + b.rows * 4 - 1) / (b.rows * 4);
-            if (share < step) step = share > floor_cols ? share : (floor_cols < step ? floor_cols : step);
             if (step >= ZS_TILE) step = step / ZS_TILE * ZS_TILE;
             if (step < 1) step = 1;
             for (int64_t x0 = 0; x0 < w; x0 += step) {
-                u->chunks.push_back({j, 0, b.rows, x0, x0 + step < w ? x0 + step : w});
+                const int64_t x1 = x0 + step < w ? x0 + step : w;
+                Chunk c{j, 0, b.rows, x0, x1, (int)u->tasks.size(), 0};
+                for (int64_t m0 = 0; m0 < x1 - x0; m0 += ZS_TASK) {
+                    u->tasks.push_back({(int)u->chunks.size(), m0, m0 + ZS_TASK < x1 - x0 ? m0 + ZS_TASK : x1 - x0});
+                    ++c.n_tasks;
+                }
+                u->chunks.push_back(c);
                 ++u->chunks_left[j];
             }
             continue;
@@ -269,9 +304,16 @@ extern "C" int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* cons
         if (share < step) step = share > floor_rows ? share : (floor_rows < step ? floor_rows : step);
         if (step < 1) step = 1;
         for (int64_t r0 = 0; r0 < b.rows; r0 += step) {
-            u->chunks.push_back({j, r0, r0 + step < b.rows ? r0 + step : b.rows, 0, w});
+            u->tasks.push_back({(int)u->chunks.size(), 0, w});                  // a plain chunk is one task
+            u->chunks.push_back({j, r0, r0 + step < b.rows ? r0 + step : b.rows, 0, w, (int)u->tasks.size() - 1, 1});
             ++u->chunks_left[j];
         }
+    }
+    u->tasks_left.reset(new std::atomic<int>[u->chunks.size() + 1]);
+    u->chunk_issued.reset(new std::atomic<int>[u->chunks.size() + 1]);
+    for (size_t k = 0; k < u->chunks.size(); ++k) {
+        u->tasks_left[k].store(u->chunks[k].n_tasks);
+        u->chunk_issued[k].store(0);
     }
     if (rc == LC_OK && hipSetDevice(device) != hipSuccess) rc = lc::fail(LC_E_HIP, "lc_upload_start: hipSetDevice failed");
     for (int j = 0; j < n_jobs && rc == LC_OK; ++j)
@@ -321,7 +363,7 @@ extern "C" int lc_upload_finish(lc_upload_t* u) {
     if (u->failed) rc = lc::fail(LC_E_HIP, "upload failed: %s", u->error.c_str());
     // the staging ring belongs to the process: leave it idle (every slot's last copy has left it)
     for (auto& s : u->slots)
-        if (s.used && rc == LC_OK && hipEventSynchronize(s.ev) != hipSuccess) rc = lc::fail(LC_E_HIP, "lc_upload_finish: sync failed");
+        if (s.recorded && rc == LC_OK && hipEventSynchronize(s.ev) != hipSuccess) rc = lc::fail(LC_E_HIP, "lc_upload_finish: sync failed");
     return rc;
 }
 

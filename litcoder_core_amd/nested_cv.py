@@ -1492,6 +1492,15 @@ class RidgeCVEngine:
                    lmax=None if hat["lmax"] is None else hat["lmax"][s:s + Fo], a2=hat["a2"][s * self.A:(s + Fo) * self.A],
                    shared=self._shared_image(inner_abs, hat["N"]), xt_off=hat.get("xt_off", 0) + s,
                    Hs=[(0, Fo, None if H is None else H[s * per:(s + Fo) * per], None if P is None else P[s:s + Fo])])
+        pim = hat.get("img")
+        if pim is not None:                            # primal form: images of the block-product / series / hat operands
+            Mv, PPn, ap, tp, hp = hat["M"], hat["N"], pim["ap"], pim["tp"], pim["hp"]
+            sub["img"] = dict(ap=ap, tp=tp, hp=hp, At=pim["At"][s * ap * Mv * 2:(s + Fo) * ap * Mv * 2],
+                              rs_a=pim["rs_a"][s * ap:(s + Fo) * ap],
+                              **({"Pt": pim["Pt"][s * tp * PPn * 2:(s + Fo) * tp * PPn * 2], "rs_p": pim["rs_p"][s * tp:(s + Fo) * tp]}
+                                 if "Pt" in pim else {}),
+                              **({"Ht": pim["Ht"][s * hp * PPn * 2:(s + Fo) * hp * PPn * 2], "rs_h": pim["rs_h"][s * hp:(s + Fo) * hp]}
+                                 if "Ht" in pim else {}))
         img = (hat.get("imgs") or [None])[0]
         if img is not None:
             N, tp, hp = hat["N"], img["tp"], img["hp"]
@@ -1649,8 +1658,17 @@ class RidgeCVEngine:
         Xt = Xt_val = None
         Nmax = ops.pad_to(max(len(t) for t in [t for t, _ in inner_all] + [metas[i]["tr"] for i in g]), LC_NB)
         rows_all = None
+        blocks_ready, img = None, None
         if by_blocks:
             Xt_val = ops.gather_transpose_f32(X, va, F, M, p, PP)            # (F * PP, M): Pstim' of every inner fold
+            if split:
+                # its fp16 hi/lo image (the A side of the block products), once per fold, shared by every voxel range
+                ap = ops.pad_to(PP, 256)
+                img = dict(ap=ap, tp=0, hp=0, At=torch.empty(F * ap * M * 2, dtype=torch.float16, device=self.dev),
+                           rs_a=torch.empty(F * ap, dtype=torch.float32, device=self.dev))
+                ops.split_rows_f16_groups(Xt_val, F, PP, M, img["At"], img["rs_a"])
+            blocks_ready = torch.cuda.Event()                                # what the block products X_v'Y_v need: they
+            blocks_ready.record()                                            # run while the p x p side is still at work
             G_val = ops.gram_blocks(Xt_val, F, PP, M)                        # (F, PP, PP) f64
             G = torch.empty((F + len(g), PP, PP), dtype=torch.float64, device=self.dev)
             s0 = 0
@@ -1704,9 +1722,23 @@ class RidgeCVEngine:
                 for j in range(1, SERIES_TERMS):
                     stack[j * M:(j + 1) * M].copy_(self._times_symmetric(stack[(j - 1) * M:j * M], Gn)[0])
                 ops.gather(stack, PP, inv, rows_p, None, PP, P[f])
-        series_ready = torch.cuda.Event()
-        series_ready.record()
+        # the fp16 hi/lo images of the V-independent operands (the A sides of the V-wide contractions), once per fold on
+        # this stream, shared by every voxel range of the fold (a host-to-host fit works through the targets panel by panel)
+        if img is not None:
+            tp = hp = 0
+            if use_series:
+                tp = ops.pad_to(P.shape[1], 256)
+                img.update(Pt=torch.empty(F * tp * PP * 2, dtype=torch.float16, device=self.dev),
+                           rs_p=torch.empty(F * tp, dtype=torch.float32, device=self.dev))
+                ops.split_rows_f16_groups(P.view(-1, PP), F, P.shape[1], PP, img["Pt"], img["rs_p"])
+            if Ac:
+                hp = ops.pad_to(Ac * M, 256)
+                img.update(Ht=torch.empty(F * hp * PP * 2, dtype=torch.float16, device=self.dev),
+                           rs_h=torch.empty(F * hp, dtype=torch.float32, device=self.dev))
+                ops.split_rows_f16_groups(H.view(-1, PP), F, Ac * M, PP, img["Ht"], img["rs_h"])
+            img.update(tp=tp, hp=hp)
         hat = dict(F=F, N=PP, M=M, n_v=n_v, n_i=n_i, tr=None if rows_all is None else rows_all[:F], va=va, shared=None,
+                   img=img, blocks_ready=blocks_ready,
                    Hs=[(0, F, H, P)], info=info, lmax=None if lmax is None else lmax[:F], a2=a2, cho=cho, ser=ser,
                    d_ser=self.d_ser if use_series else None, moments=use_series, series_ready=None, split=split,
                    data_ready=data_ready, Xt=Xt, Xt_val=Xt_val, Nmax=Nmax, xt_off=0)
@@ -1727,7 +1759,8 @@ class RidgeCVEngine:
                           Xt_o=None if Xt is None else Xt[(F + k) * PP:(F + k + 1) * PP],
                           tr_o_rows=None if rows_all is None else rows_all[F + k], Nmax=Nmax)
         done.record()
-        for t in (X, Xt, Xt_val, G, ident, lmax, a2, va, rows_all, rhs, H, P, info):
+        for t in (X, Xt, Xt_val, G, ident, lmax, a2, va, rows_all, rhs, H, P, info) + (
+                tuple(v for v in img.values() if torch.is_tensor(v)) if img else ()):
             if t is not None and t.is_cuda:
                 t.record_stream(main)                      # allocated on aux, consumed on main
 
@@ -1852,7 +1885,13 @@ class RidgeCVEngine:
         split, cs = hat["split"], hat["cs"]
         if hat.get("data_ready") is not None:
             main.wait_event(hat["data_ready"])
-        if done is not None:
+        by_blocks = Xt_val is not None
+        img = hat.get("img") if split else None
+        # the block products need the transposed validation rows only: they run BEFORE the wait for the fold's p x p side
+        # (Lanczos run, Cholesky chains, series terms: ~40 ms at the LeBel shape, while the first target panels land)
+        if by_blocks and hat.get("blocks_ready") is not None:
+            main.wait_event(hat["blocks_ready"])
+        elif done is not None:
             main.wait_event(done)
         self.info.update(precision="f16x3" if split else "f32", fused_alphas=Ad, series_terms=SERIES_TERMS if moments else 0)
         Vp_, V_ = self.Vp, self.V
@@ -1868,7 +1907,6 @@ class RidgeCVEngine:
         ident = ops.idx_tensor(np.arange(self.p), PP, self.dev)
         shared = hat.get("shared") if split else None
         views = [(0, 0, 0)] * F
-        by_blocks = Xt_val is not None
         if split:
             depth = M if by_blocks else Nmax
             At = torch.empty(ops.pad_to(PP, 256) * depth * 2, dtype=torch.float16, device=self.dev)
@@ -1901,12 +1939,18 @@ class RidgeCVEngine:
                 Xv = Xt_val[(off + f) * PP:(off + f + 1) * PP]
                 if split:
                     ops.split_cols_f16(Y, Vp_, va[f], M, cs, Yt)
-                    ops.split_rows_f16(Xv, PP, M, At, rs_a)
-                    ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, Bv[f], Vt, Vt, M, [0, Vt // 256])
+                    At_f, rs_a_f = At, rs_a
+                    if img is not None:                    # (the images of a fold group are sliced per outer fold: index f)
+                        At_f, rs_a_f = img["At"][f * img["ap"] * M * 2:], img["rs_a"][f * img["ap"]:]
+                    else:
+                        ops.split_rows_f16(Xv, PP, M, At, rs_a)
+                    ops.gemm_grouped_f16x3(At_f, rs_a_f, PP, Yt, cs_inv, Bv[f], Vt, Vt, M, [0, Vt // 256])
                     self.info["plain_flops"] += 2.0 * self.p * n_v[f] * V_
                     self.info["plain_launches"] += 1
                 else:
                     ops.gemm_grouped(Xv, M, 0, Y, Y.stride(0), va[f], Bv[f], Vt, PP, Vp_, M, [0, Vp_ // COL_TILE])
+        if by_blocks and done is not None:
+            main.wait_event(done)                          # from here on: the hat matrices / series terms of the fold
         for f in range(F):
             ops.val_stats(Y, Vp_, va[f], M, n_v[f], ystat, yblk, yv)
             if by_blocks:
@@ -1925,16 +1969,24 @@ class RidgeCVEngine:
                 csB, _ = ops.col_scales_f16(B, self.p, Vp_)
                 ops.split_cols_f16(B, Vp_, ident, PP, csB, Bt)
                 if moments:
-                    ops.split_rows_f16(P[f], Tm, PP, Pt, rs_p)
+                    Pt_f, rs_p_f = Pt, rs_p
+                    if img is not None and "Pt" in img:
+                        Pt_f, rs_p_f = img["Pt"][f * img["tp"] * PP * 2:], img["rs_p"][f * img["tp"]:]
+                    else:
+                        ops.split_rows_f16(P[f], Tm, PP, Pt, rs_p)
                     self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * self.p * V_
                     self.info["plain_launches"] += 1
-                    ops.series_sweep_scores_f16x3(Pt, rs_p, M, n_v[f], PP, Bt, self._cs_inv_padded(csB, Vt), Vt, yv, Vp_, ystat,
-                                                  yblk, self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0)
+                    ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], PP, Bt, self._cs_inv_padded(csB, Vt), Vt, yv, Vp_,
+                                                  ystat, yblk, self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0)
                 if Ad:
-                    ops.split_rows_f16(H[f * Ad:(f + 1) * Ad].reshape(Ad * M, PP), Ad * M, PP, Ht, rs_inv)
+                    Ht_f, rs_h_f = Ht, rs_inv
+                    if img is not None and "Ht" in img:
+                        Ht_f, rs_h_f = img["Ht"][f * img["hp"] * PP * 2:], img["rs_h"][f * img["hp"]:]
+                    else:
+                        ops.split_rows_f16(H[f * Ad:(f + 1) * Ad].reshape(Ad * M, PP), Ad * M, PP, Ht, rs_inv)
                     self.info["fused_flops"] += 2.0 * Ad * n_v[f] * self.p * V_
                     self.info["fused_launches"] += 1
-                    ops.alpha_sweep_scores_f16x3(Ht, rs_inv, Ad, M, PP, Bt, csB[Vp_:], yv, Vp_, n_v[f], ystat, yblk,
+                    ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, PP, Bt, csB[Vp_:], yv, Vp_, n_v[f], ystat, yblk,
                                                  self.mode, part, scores_d, accumulate=f > 0)
             else:
                 if not by_blocks:

@@ -263,6 +263,7 @@ _UPLOAD_DEPTH = 12                  # chunks in flight
 _UPLOAD_LOCK = threading.Lock()     # the ring is the process's: one upload job at a time owns it
 
 
+_UPLOAD_THREADS_ZS = 48             # staging threads of such an upload (capped at half the cores)
 _UPLOAD_DEPTH_ZS = 32               # ... of an upload that z-scores stories on the way (three passes per chunk on the host:
                                     # more threads in flight to keep the link busy)
 
@@ -377,7 +378,8 @@ class PanelUploader:
         import os
         # staging threads: half the cores, shared out over the processes of the node (one per GPU under torchrun)
         per_node = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
-        n_threads = max(2, min(len(pinned), (os.cpu_count() or 4) // 2 // per_node))
+        zs = any(h.zscore for h, _, _, _ in self.jobs)   # (z-scored chunks are shared by several threads: more of them)
+        n_threads = max(2, min(_UPLOAD_THREADS_ZS if zs else len(pinned), (os.cpu_count() or 4) // 2 // per_node))
         _UPLOAD_LOCK.acquire()                          # the staging ring is the process's: one upload at a time owns it
         try:
             _lib.call("lc_upload_start", ctypes.cast(self._native, ctypes.c_void_p), len(native),
