@@ -112,19 +112,23 @@ __global__ void __launch_bounds__(512) k_col_scales(const float* __restrict__ y,
     for (int g = 0; g < 8; ++g) mx = fmaxf(mx, sm[g][threadIdx.x]);
     const float small = mx * (1.f / 512.f);
     int n_small = 0;
-    if (c < V)
-        for (int i = threadIdx.y; i < T; i += 8) n_small += fabsf(y[(long long)i * ldy + c]) < small;
-    cnt[threadIdx.y][threadIdx.x] = n_small;
-    __syncthreads();
+    if (flag != nullptr) {                 // (block-uniform; without a flag pointer the scales alone: one pass over y)
+        if (c < V)
+            for (int i = threadIdx.y; i < T; i += 8) n_small += fabsf(y[(long long)i * ldy + c]) < small;
+        cnt[threadIdx.y][threadIdx.x] = n_small;
+        __syncthreads();
+    }
     if (threadIdx.y == 0 && c < V) {
+        if (flag != nullptr) {
 #pragma unroll
-        for (int g = 1; g < 8; ++g) n_small += cnt[g][threadIdx.x];
+            for (int g = 1; g < 8; ++g) n_small += cnt[g][threadIdx.x];
+        }
         int e = 0;
         if (mx > 0.f) frexpf(mx, &e);
         e = max(-120, min(120, e));
         cs[c] = ldexpf(1.f, -e);
         cs[V + c] = ldexpf(1.f, e);
-        if (mx > 0.f && 2 * n_small > T) atomicOr(flag, 1);
+        if (flag != nullptr && mx > 0.f && 2 * n_small > T) atomicOr(flag, 1);
     }
 }
 
@@ -854,7 +858,7 @@ extern "C" int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int
 
 extern "C" int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
                                  int32_t* d_flag, lc_stream_t stream) {
-    LC_REQUIRE(d_y && d_cscale && d_flag, LC_E_BADARG, "lc_col_scales_f16: null pointer");
+    LC_REQUIRE(d_y && d_cscale, LC_E_BADARG, "lc_col_scales_f16: null pointer");     // d_flag may be NULL: scales only
     LC_REQUIRE(T > 0 && V > 0 && ldy >= V, LC_E_SHAPE, "lc_col_scales_f16: bad shape");
     lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
     hipLaunchKernelGGL(k_col_scales, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, 8), 0,

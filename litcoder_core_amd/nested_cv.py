@@ -423,6 +423,7 @@ class RidgeCVEngine:
         self._d_one = ops.upload(np.ones(1, dtype=np.float64), self.dev)
         self._eye, self._eye_key = None, None
         self._eig_cache, self._n_real = {}, {}         # spectral route: eigenpairs of a fold's outer block; list lengths
+        self._scale_checks = []                        # primal form: pending looks at the features' column norms
         # what this fit ran, for the caller (NestedCVModel.last_fit; bench.py prices the roofline with it): arithmetic
         # of the sweeps, alphas scored inside the fused launch, algorithmic flops of the plain fp16x3 GEMMs.  Per
         # engine: two fits in one process do not share it.
@@ -1861,13 +1862,26 @@ class RidgeCVEngine:
     def _check_feature_scales(self, G_o):
         """The primal V-wide contraction sums over FEATURES: with the fp16 hi/lo operands (22 bits relative to a
         row's / column's largest entry) a feature whose scale is orders of magnitude below another's would lose
-        its digits.  One look at the column norms (the Gram diagonal; a p-long copy to the host)."""
+        its digits.  One look at the column norms (the Gram diagonal; a p-long copy to page-locked memory, looked at
+        by _verify_feature_scales when the fold's first V-wide phase is queued -- the host does not wait here, where it
+        would wait for everything queued on this stream before: round 4)."""
         if self.precision == "f32":
             return
-        d = torch.sqrt(G_o.diagonal()[: self.p]).cpu().numpy()
-        d = d[d > 0]
-        if d.size and float(d.max() / d.min()) > self.opt.primal_max_scale_ratio:
-            raise _PrimalUnsuitable(f"feature column norms span a factor {float(d.max() / d.min()):.3g}")
+        h = torch.empty(self.p, dtype=torch.float64, pin_memory=True)
+        h.copy_(G_o.diagonal()[: self.p], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._scale_checks.append((ev, h))
+
+    def _verify_feature_scales(self):
+        while self._scale_checks:
+            ev, h = self._scale_checks.pop(0)
+            ev.synchronize()
+            d = np.sqrt(h.numpy())
+            d = d[d > 0]
+            if d.size and float(d.max() / d.min()) > self.opt.primal_max_scale_ratio:
+                self._scale_checks.clear()
+                raise _PrimalUnsuitable(f"feature column norms span a factor {float(d.max() / d.min()):.3g}")
 
     def _sweeps_primal(self, hat, Y, done=None):
         """_sweeps in the primal form: per inner fold  B = Rstim'Rresp  (one plain contraction over the training rows,
@@ -1966,7 +1980,7 @@ class RidgeCVEngine:
                     ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, B, Vt, Vt, Ni, [0, Vt // 256], bview=views[f])
                     self.info["plain_flops"] += 2.0 * self.p * n_i[f] * V_
                     self.info["plain_launches"] += 1
-                csB, _ = ops.col_scales_f16(B, self.p, Vp_)
+                csB, _ = ops.col_scales_f16(B, self.p, Vp_, want_flag=False)
                 ops.split_cols_f16(B, Vp_, ident, PP, csB, Bt)
                 if moments:
                     Pt_f, rs_p_f = Pt, rs_p
@@ -2016,7 +2030,7 @@ class RidgeCVEngine:
         if B_all is not None:
             # the inner CV of this step left  B_o = Rstim'Rresp  of the outer block (the sum of its validation blocks')
             ext[:PP].copy_(B_all)
-            csB = ops.col_scales_f16(ext, self.p, self.Vp)[0] if st["split"] else None
+            csB = ops.col_scales_f16(ext, self.p, self.Vp, want_flag=False)[0] if st["split"] else None
         elif st["split"]:
             At = torch.empty(ops.pad_to(PP, 256) * st["Nmax"] * 2, dtype=torch.float16, device=self.dev)
             rs_a = torch.empty(ops.pad_to(PP, 256), dtype=torch.float32, device=self.dev)
@@ -2025,7 +2039,7 @@ class RidgeCVEngine:
             ops.split_cols_f16(Y, self.Vp, st["tr_o_rows"], No, st["cs"], Yt)
             ops.split_rows_f16(st["Xt_o"], PP, No, At, rs_a)
             ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, ext, Vt, Vt, No, [0, Vt // 256])
-            csB, _ = ops.col_scales_f16(ext, self.p, self.Vp)
+            csB, _ = ops.col_scales_f16(ext, self.p, self.Vp, want_flag=False)
         else:
             ops.gemm_grouped(st["Xt_o"], st["Nmax"], 0, Y, Y.stride(0), st["tr_o_rows"], ext, Vt, PP, self.Vp, No,
                              [0, self.Vp // COL_TILE])
@@ -2055,6 +2069,8 @@ class RidgeCVEngine:
         fold 0, all columns.  Returns the step's own state: the fold's entries plus the range's targets, column scales
         and scores."""
         base = prepared if prepared is not None else self.fold_prepare(tr_rows, te_rows, inner_rel, lmax_pre)
+        if self._scale_checks:
+            self._verify_feature_scales()              # primal form: may send the driver to the dual form
         fold_no, cols = step if step is not None else (0, None)
         rg = self.full if cols is None else self.range_of(*cols)
         st = dict(base)

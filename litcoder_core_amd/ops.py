@@ -865,11 +865,11 @@ def split_rows_f16_groups(h, groups, rows, K, tiled, rowscale_inv):
     _lib.call("lc_split_rows_f16_groups", _p(h), h.stride(0), groups, rows, K, _p(tiled), _p(rowscale_inv), _s())
 
 
-def col_scales_f16(y, T, V):
+def col_scales_f16(y, T, V, want_flag=True):
     """(cs, flag): cs[:V] = 2^-e, cs[V:] = 2^e per column; flag (device int32) != 0 when some column's
-    dynamic range is too wide for the fp16 hi/lo split."""
+    dynamic range is too wide for the fp16 hi/lo split (``want_flag=False``: the scales alone, one pass over y)."""
     cs = torch.empty(2 * V, dtype=torch.float32, device=y.device)
-    flag = zeros(1, torch.int32, y.device)
+    flag = zeros(1, torch.int32, y.device) if want_flag else None
     _lib.call("lc_col_scales_f16", _p(y), y.stride(0), T, V, _p(cs), _p(flag), _s())
     return cs, flag
 

@@ -145,3 +145,30 @@ def test_one_rank_through_rccl_collectives(runs):
     for key, want in ref.items():
         if isinstance(key, tuple):
             _same(out[key], want, 0, out["hi"], key)
+
+
+def test_bench_runs_on_two_ranks_of_one_gpu(tmp_path):
+    """The N > 1 path of bench.py itself (what the driver launches on an 8-GPU node: one process per GPU under
+    torch.distributed.run, barrier + MAX-over-ranks timing, per-rank inputs, the other scaling mode beside the headline)
+    on the hardware there is: two ranks on the one GPU, LITCODER_BENCH_ONE_GPU=1 (every rank on device 0, gloo for the
+    exchanges -- RCCL refuses two ranks on one device).  The numbers mean nothing; the line must be complete, the job's
+    voxel count right in both scaling modes, the scores sane -- so that this path cannot rot unmeasured."""
+    import json
+    env = dict(os.environ, LITCODER_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    for k, scaling in enumerate(("weak", "strong")):
+        port = 29500 + (os.getpid() % 1500) + 17 + k
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                            "--warmup", "1", "--voxels", "6144", "--scaling", scaling, "--no-cpu-baseline"],
+                           env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["unit"] == "voxels/sec" and out["value"] > 0
+        total = 2 * 6144 if scaling == "weak" else 6144
+        assert out["config"]["voxels_total"] == total and abs(out["value"] - total / (1e-3 * out["ms_per_step"])) < 1e-6 * out["value"]
+        other = out["other_scaling"]
+        assert other["scaling"] == ("strong" if scaling == "weak" else "weak") and other["voxels_total"] == (6144 if scaling == "weak" else 2 * 6144)
+        assert 0.2 < out["config"]["median_score"] < 0.6 and 0.2 < other["median_score"] < 0.6
+        assert out["roofline"]["launches"] > 0 and "cfg3_pipeline" not in out and "cpu_baseline" not in out
