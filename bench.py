@@ -575,7 +575,6 @@ def main():
             traffic_src = ("not measured in this run ("
                            + (live_traffic[1] if live_traffic is not None else "child passes skipped")
                            + "); resident_path.roofline_full_width_launches.traffic carries profiles/alpha_sweep_traffic.json")
-        from litcoder_core_amd.nested_cv import _main_stream
         roof.update({
             "note": ("achieved/frac = ALGORITHMIC flops of the caller's contraction (2 x A_fused x n_val x n_train x V per "
                      "inner fold, summed over the launches of the timed steps) / the launches' HIP-event time; the kernel "
@@ -585,7 +584,6 @@ def main():
                      "arriving), the others full width") if split else None,
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_population": "bytes per launch averaged over the same launches avg_launch_ms averages over",
-            "cus_of_256_the_kernel_runs_on": 224 if _main_stream() is not None else 256,
             "plain_launches_same_kernel": plain})
         renamed = {"batch_chol_solve": "batch_chol_solve_stream_ms_incl_waits_for_cus"}
         out = {

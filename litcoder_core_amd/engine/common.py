@@ -1,0 +1,223 @@
+"""What every part of the fit engine shares: constants, the per-fit options, the penalty-grid check, voxel ranges and
+the panel plans of a host-to-host fit, auxiliary streams, small containers."""
+import dataclasses
+import logging
+import os
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import ops, series, stats
+from .._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2
+
+logger = logging.getLogger("litcoder_core_amd.nested_cv")
+
+
+SERIES_TERMS = 4                    # terms of the polynomial form of the hat matrices of large alphas (series.py): the
+                                    # moments epilogue of the sweep kernel is laid out for exactly four
+SINGCUTOFF_REL = 1e-3               # a direction with singular value S <= singcutoff enters a prediction with weight
+                                    # S^2 / (S^2 + a^2) <= (singcutoff / a)^2: below 1e-6 it is invisible in fp32
+GROUPS_PER_LAUNCH = ops.GROUP_RANGE  # lc_group_by_alpha / the grouped GEMMs carry 64 alpha groups per launch: a larger
+                                    # grid (the reference takes any number, ridge_regression.py:46-50,115) goes range by range
+MAX_INNER_FOLDS = 64                # inner folds per grouped launch of the series chain / per batch of outer folds prepared together
+                                    # (more inner folds than this are taken in chunks: no limit on n_inner_folds)
+
+
+@dataclasses.dataclass
+class FitOptions:
+    """Policy switches and tuning values of ONE fit.  Every engine carries its own copy (``NestedCVModel(options=...)``,
+    ``RidgeCVEngine(options=...)``): two fits in one process with different settings do not see each other's (until round
+    3 these were module-level constants that tests and tools assigned).  The defaults are the measured choices."""
+    lanczos_steps: int = 64                 # Lanczos iterations for S[0]^2: <= 1e-11 relative on the cfg2 Grams (profiles/);
+                                            # the reference's own S[0] is an fp32 SVD value (~1e-7)
+    aug_budget_bytes: int = 24 << 30        # cap on the batched (fold, alpha) fp64 systems resident at once
+    series_tol: float = 2e-9                # an alpha takes the polynomial form when its worst relative error over the
+                                            # spectrum, 1 / T_d(1 + 2 alpha^2), is <= this: 30x below the fp32 epsilon
+    primal_max_scale_ratio: float = 64.0    # primal V-wide route: feature column norms within this factor (fp16x3)
+    refit_by_inverse: bool = True           # refit operators through the explicit inverse + one fp16x3 product
+    refit_inverse_min_alpha: float = 0.05   # ... for alphas (in units of S[0]) from here on
+    refit_inverse_max_world: int = 4        # ... and up to this many voxel-shard ranks
+    series_fused_moments: bool = True       # series terms reduced to moments in the contraction's epilogue (never stored)
+    primal_moments_max_p: int = 16          # up to this many features the tall form scores from block products X'Y alone
+    primal_max_p: int = 4096                # the primal (p x p) form is taken for tall designs up to this many features
+                                            # (round 4: 512 before; LeBel-style train/test fits have 9000 rows x 3072 features)
+    primal_series_min_p: int = 256          # from this many (padded) features on the primal form shares the large alphas'
+                                            # polynomial terms and takes Gram matrices / block products of the inner training
+                                            # sets as sums over the OTHER folds' validation blocks (_prepare_primal)
+    speculate_first_fold: bool = True       # the first fold's refit systems for every factorised alpha, beside its chain
+    speculate_max_rows: int = 4608          # ... and any refit system ahead of its alpha choice only up to this many rows
+    refit_from_image: bool = True           # the refit's alpha-sorted fp16 operand gathered out of the inner CV's image
+    panel_cols: int = 36864                 # voxel columns per panel of a host-to-host fit (_column_panels): 12 288 / 24 576 /
+                                            # 30 720 / 12 416 at cfg2 (measured 144.1 ms against 145.2 for 24 576-wide panels,
+                                            # 145.2 for 73 728, 151.6 without panels)
+    panel_min_cols: int = 16384             # below twice this many voxels a fit is not cut into panels
+    tail_panels_geometric: bool = True      # the end of a host-to-host fit in few panels of falling width (_download_panels)
+    tail_last_frac: float = 0.3             # ... the last panel's share of the voxels (0: the geometric plan's own last panel):
+                                            # its weights + transfer (~7 ms) run while the host builds the metrics dictionary
+                                            # (measured 140.0 -> 138.1 / 137.8 ms at 0.27 / 0.35)
+    tail_folds: int = 2                     # ... spread over this many folds, voxel-major (plan_steps)
+    series_lookahead: bool = True           # the next step's first sweep part queued before a step's fused sweeps (driver)
+    resident_refit_batch: bool = True       # resident inputs: refit inverses of folds 1.. as one batch after fold 0's choice
+    alpha_progress_log: bool = dataclasses.field(       # per-alpha progress lines (ridge_regression.py:136-139): a device
+        default_factory=lambda: os.environ.get("LITCODER_AMD_ALPHA_LOG", "0") == "1")   # round trip per fold, opt-in
+    chol_outer_block: int = 512             # lc_batch_chol_solve: columns per outer block of the two-level blocking
+    chol_big_kernel: int = 2                # ... deep updates: 2 = 4x4x4 fp64 MFMA, 1 = vector ALU, 0 = 16x16x4 MFMA
+    chol_fused_steps: bool = True           # ... fused left-looking 64-column steps
+    chol_persistent: int = 1                # ... bit 0: the back substitution's steps of an outer block in one launch
+    lanczos_mfma: bool = True               # lc_lambda_max_masked: the matvec on the fp64 MFMA
+
+
+def check_penalties(alphas, singcutoff, normalpha, n_inner_folds=None):
+    """Host-side validation of the penalty grid, before anything touches the device.  Returns True when the fit has to
+    take the SPECTRAL route (csrc/lc_eig.hip) instead of the Cholesky one.
+
+    The reference takes a thin SVD, DROPS singular values <= ``singcutoff`` (ridge_utils.py:44-63) and shrinks the
+    rest by S / (S^2 + a^2) (ridge_regression.py:56,117), which is defined for alpha = 0 (pseudo-inverse).  The fast
+    route factors (K + a^2 I) by Cholesky: it needs a^2 > 0, and it truncates nothing -- a direction the reference
+    would drop contributes at most (singcutoff / a)^2 to a prediction, < 1e-6 (invisible in fp32) whenever
+    singcutoff <= 1e-3 a_min, which holds for every shipped caller (singcutoff 1e-10 / 1e-30, alphas >= 0.1).
+    Outside that range -- alpha = 0 in the grid, or a singcutoff that is not negligible against the smallest penalty
+    (with ``normalpha`` a = alpha S[0] and S[0] is not known yet: not negligible against alpha_min itself) -- the
+    operators come from the eigendecomposition of K[tr, tr] with exactly the reference's truncation, in fp64, slower."""
+    al = np.asarray(list(alphas), dtype=np.float64).reshape(-1)
+    if al.size == 0:
+        raise ValueError("alphas is empty")
+    if n_inner_folds is not None and int(n_inner_folds) < 1:
+        raise ValueError("n_inner_folds must be >= 1")
+    if not np.all(np.isfinite(al)):
+        raise ValueError("alphas must be finite (the penalty is alpha^2: ridge_regression.py:56,117)")
+    al = np.abs(al)                                    # ... so a negative alpha is the penalty of |alpha|
+    sc = float(singcutoff)
+    if not (sc >= 0) or not np.isfinite(sc):
+        raise ValueError("singcutoff must be a finite number >= 0")
+    pos = al[al > 0]
+    if pos.size < al.size:
+        return True                                    # alpha = 0: the pseudo-inverse of the kept directions
+    return bool(sc > (1e-6 if normalpha else SINGCUTOFF_REL) * float(pos.min()))
+
+
+class _PrimalUnsuitable(Exception):
+    """Raised while preparing a fit in the primal form when the data rule it out; the driver falls back to the dual."""
+
+
+class _FoldResult:
+    __slots__ = ("r", "p", "best_idx", "n_test", "sig")
+
+    def __init__(self, r, p, best_idx, n_test, sig=None):
+        self.r, self.p, self.best_idx, self.n_test = r, p, best_idx, n_test
+        self.sig = sig             # (reject mask, adjusted p) of the fold when the device made them (one GPU), else None
+
+
+_AUX_STREAMS: Dict[Any, Any] = {}
+
+
+def _aux_stream(dev, which=0):
+    """The auxiliary streams of a device, created once for the life of the process.  A fresh ``torch.cuda.Stream()`` per
+    engine walks through torch's pool of 32 streams, and the FIRST cross-stream wait on a stream that has never run
+    anything blocks the host for ~6 ms (its hardware queue is created there): every fit of a series paid that before
+    its first fold was queued."""
+    key = (dev.type, dev.index, which)
+    if key not in _AUX_STREAMS:
+        _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _AUX_STREAMS[key]
+
+
+class _WideTargets(Exception):
+    """precision="auto" met a target column whose dynamic range the fp16 hi/lo split cannot carry AFTER the fit was set up
+    for it (host inputs arrive panel by panel, so the decision cannot be taken up front): the driver repeats the fit on
+    the f32 MFMA path with the targets that are resident by then."""
+
+
+class _Range:
+    """A contiguous range [c0, c0 + V) of this rank's voxel columns: the unit a V-wide phase of a fold works on.  The
+    targets and the mean weights of the rank live in ONE (T, Vp) / (p, Vp) buffer each; a range sees column views of
+    them (row stride = the buffer's), so a fold can be processed full width or panel by panel -- panels while the
+    targets are still arriving from the host (first fold) and while the finished weights leave for it (last fold).
+    Interior boundaries are multiples of 256 columns (the widest column tile), so only the last range carries padding."""
+    __slots__ = ("c0", "V", "Vp", "Y", "W", "scales", "natural", "key")
+
+    def __init__(self, c0, V, Vp, Y, W):
+        self.c0, self.V, self.Vp, self.Y, self.W = int(c0), int(V), int(Vp), Y, W
+        self.scales = None             # (cs, split) of the un-normalised targets of the range (_target_scales)
+        self.natural = None            # 0 .. V-1 on the device (moments form)
+        self.key = (self.c0, self.V)
+
+
+def _column_panels(V, cols=None, min_cols=None, v_ref=None):
+    """[c0, c1) panels of V voxel columns for a host-to-host fit, boundaries on multiples of 256: ``cols`` wide in the
+    middle, ramping up from cols / 3 at the front (the first fold starts on the first panel while the others still
+    cross PCIe: a narrow one is there early) and down to <= cols / 3 at the end (the last panel's weights are the only
+    download nothing overlaps).  With the default width the panels of the sweeps' 8 M-tiles are whole rounds of
+    workgroups on 256 CUs (8192 columns = one round).  ``v_ref``: the column count the PLAN is derived from (voxel
+    shards: the narrowest rank's, so that every rank cuts its block into the same number of panels -- the ranks'
+    collectives pair up range by range); the last panel absorbs the difference."""
+    cols = FitOptions.panel_cols if cols is None else int(cols)
+    min_cols = FitOptions.panel_min_cols if min_cols is None else int(min_cols)
+    v_ref = int(V) if v_ref is None else min(int(v_ref), int(V))
+    if cols % 256:
+        raise ValueError("panel width must be a multiple of 256 columns")
+    if v_ref < 2 * min_cols or v_ref <= cols:
+        return [(0, int(V))]
+    third = max(256, (cols // 3) // 256 * 256)
+    widths, left = [], v_ref
+    for w in (third, 2 * third):                           # ramp up
+        if left > w + third:
+            widths.append(w)
+            left -= w
+    while left > cols + third:                             # full panels
+        widths.append(cols)
+        left -= cols
+    if left > 2 * 256:                                     # ramp down: what is left, minus a narrow last panel
+        tail = min(third, (left // 2) // 256 * 256)
+        body = (left - tail) // 256 * 256
+        widths += [body, left - body]
+    else:
+        widths.append(left)
+    edges = np.concatenate([[0], np.cumsum(widths)]).astype(np.int64)
+    edges[-1] = int(V)
+    return [(int(edges[i]), int(edges[i + 1])) for i in range(len(widths))]
+
+
+def _download_panels(V, first=8.0 / 15.0, ratio=0.5, min_cols=None, v_ref=None, last_min=4096, last_frac=0.0):
+    """[c0, c1) panels the END of a host-to-host fit works in (the last two folds voxel-major, plan_steps): a panel's
+    finished weights cross PCIe while the next panel is computed, so what is not hidden is the LAST panel's transfer --
+    and wide panels run the V-wide kernels more efficiently than narrow ones.  Widths fall geometrically: two folds of
+    V-wide work on a panel take ~2.2x its transfer time (cfg2: 40 ms of work, 18 ms of PCIe for all voxels), so with
+    ``ratio`` = 1/2 every transfer ends before the next panel's work does, and the tail is the transfer of 1/15 of the
+    voxels (~1.2 ms) with four panels instead of five equal ones.  Boundaries on multiples of 256; ``v_ref`` as in
+    _column_panels (the same number of panels on every rank of a sharded fit)."""
+    min_cols = FitOptions.panel_min_cols if min_cols is None else int(min_cols)
+    v_ref = int(V) if v_ref is None else min(int(v_ref), int(V))
+    if v_ref < 2 * min_cols:
+        return [(0, int(V))]
+    last_min = max(256, min(int(last_min), min_cols // 4))
+    if last_frac > 0.0:
+        # ... unless the caller has host work of its own after the last fold's results (the metrics dictionary: ~7 ms at
+        # cfg2, during which the GPU would idle): then the LAST panel is sized so that its weights, their mean and its
+        # transfer take about that long -- what runs after the last results are out is hidden behind the host, and the
+        # results themselves are out that much earlier
+        tail = max(last_min, int(round(v_ref * last_frac / 256.0)) * 256)
+        head = max(256, (v_ref - tail) // 256 * 256)
+        h1 = max(256, int(round(head * 0.6 / 256.0)) * 256)
+        edges = [0, h1, head, int(V)] if head - h1 >= last_min else [0, head, int(V)]
+        return [(int(edges[i]), int(edges[i + 1])) for i in range(len(edges) - 1)]
+    widths, left, w = [], v_ref, v_ref * first
+    while left > 0:
+        wi = max(256, int(round(w / 256.0)) * 256)
+        if left - wi < last_min or wi < last_min:
+            widths.append(left)
+            break
+        widths.append(wi)
+        left -= wi
+        w *= ratio
+    edges = np.concatenate([[0], np.cumsum(widths)]).astype(np.int64)
+    edges[-1] = int(V)
+    return [(int(edges[i]), int(edges[i + 1])) for i in range(len(widths))]
+
+
+class _DeviceShapes:
+    """A resident, zero-padded device matrix together with its logical column count."""
+
+    def __init__(self, tensor: torch.Tensor, n_cols: int):
+        self.tensor, self.shape = tensor, (tensor.shape[0], int(n_cols))

@@ -1,0 +1,368 @@
+"""The inner CV in the dual (n x n) form: hat matrices of every (inner fold, alpha) -- batched Cholesky for the small
+alphas, the shared polynomial series for the large ones -- and the V-wide fused sweeps.
+"""
+import dataclasses
+import logging
+import os
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import ops, series, stats
+from .._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2
+from ..dist import ShardContext, job_share
+from .common import (SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions, check_penalties, _PrimalUnsuitable, _WideTargets, _FoldResult, _aux_stream, _Range, _column_panels, _download_panels, _DeviceShapes, logger)
+
+
+class DualSweeps:
+    """ridge_corr_torch for all inner folds of an outer fold (ridge_regression.py:66-141, nested_cv.py:334-415)."""
+
+    # -------------------------------------------------------------- inner CV: hat matrices, then the sweeps
+    def _series_layout(self, M):
+        """Row layout of the stacked series terms for the plain fp16x3 GEMM: every term padded to whole 128-row
+        slabs, heavy slabs (terms 0 and 1: full three-MFMA products) paired with light ones (terms >= 2, which
+        enter a prediction scaled by rho^2 <= 2.7e-4 relative to term 0 and only need fp16 operands) inside the
+        256-row tiles, so that the two waves of a SIMD together issue 32 instead of 48 MFMAs per K-tile.
+        Returns (rows, rowmap (terms*M,) int32 device, slab_light uint8 device)."""
+        key = ("series_layout", M, self.opt.series_fused_moments)
+        if getattr(self, "_layout_key", None) != key and self.opt.series_fused_moments and SERIES_TERMS == 4:
+            # the moments epilogue (lc_series_sweep_scores_f16x3): every 256-row tile holds all four terms of two
+            # 32-row validation blocks -- wave row 0: [T0 b0, T0 b1, T1 b0, T1 b1], wave row 1: the same of T2, T3
+            nblk = M // LC_MB
+            rows = 256 * ((nblk + 1) // 2)
+            rowmap = np.empty(SERIES_TERMS * M, dtype=np.int32)
+            i = np.arange(M)
+            b = i // LC_MB
+            for j in range(SERIES_TERMS):
+                rowmap[j * M:(j + 1) * M] = 256 * (b // 2) + 128 * (j >> 1) + 32 * (2 * (j & 1) + (b & 1)) + i % LC_MB
+            self._layout = (rows, ops.upload(rowmap, self.dev), None)
+            self._rowmap_host = rowmap
+            self._layout_key = key
+        if getattr(self, "_layout_key", None) != key:
+            per = (M + 127) // 128
+            heavy = [(j, s) for j in range(min(2, SERIES_TERMS)) for s in range(per)]
+            light = [(j, s) for j in range(2, SERIES_TERMS) for s in range(per)]
+            order, cls = [], []
+            while heavy or light:                        # one 256-row tile per round: (wm = 0 slab, wm = 1 slab)
+                for _ in range(2):
+                    if heavy and (not cls or len(cls) % 2 == 0 or not light):
+                        order.append(heavy.pop(0)); cls.append(0)
+                    elif light:
+                        order.append(light.pop(0)); cls.append(1)
+                    else:
+                        order.append(None); cls.append(1)
+            rows = 128 * len(order)
+            rowmap = np.full(SERIES_TERMS * M, -1, dtype=np.int32)
+            for slab, js in enumerate(order):
+                if js is None:
+                    continue
+                j, s = js
+                lo, hi = s * 128, min(M, (s + 1) * 128)
+                rowmap[j * M + lo:j * M + hi] = slab * 128 + np.arange(hi - lo)
+            self._layout = (rows, ops.upload(rowmap, self.dev), ops.upload(np.asarray(cls, dtype=np.uint8), self.dev))
+            self._rowmap_host = rowmap
+            self._layout_key = key
+        return self._layout
+
+    def _shared_image(self, inner_abs, N):
+        """One tiled fp16 image of the targets for all inner folds of an outer fold: possible when every inner
+        training set is the same row sequence minus one block whose position and length are multiples of 16 (the
+        K-tile of the MFMA kernels) and no padding rows are needed -- contiguous K-folds of a multiple-of-16 fold
+        length.  Returns (union rows, [(gap_begin, gap_rows) per fold]) or None (one split per inner fold)."""
+        sets = [np.asarray(t_, dtype=np.int64) for t_, _ in inner_abs]
+        if len(sets) < 2 or any(len(s_) != N for s_ in sets):
+            return None
+        union = np.unique(np.concatenate(sets))
+        if len(union) % 16 or (len(union) - N) % 16:
+            return None
+        gaps = []
+        for s_ in sets:
+            idx = np.searchsorted(union, s_)                 # position of every row in the (sorted) union
+            if np.any(np.diff(idx) <= 0):
+                return None                                  # not in the union's order
+            missing = np.setdiff1d(np.arange(len(union)), idx)
+            if len(missing) != len(union) - N or (len(missing) and
+                                                  (missing[-1] - missing[0] + 1 != len(missing) or missing[0] % 16)):
+                return None
+            gaps.append((int(missing[0]) if len(missing) else N, int(len(missing))))
+        return union, gaps
+
+    def _series_by_moments(self, split):
+        """Score the series alphas from the moments of the shared terms T_j = P'_j Y (one contraction for all of
+        them, lc_series_scores) instead of one hat matrix per alpha: correlation scoring on the fp16x3 path only
+        (the R2 score needs the elementwise fl32 residual, see lc_epilogue.h)."""
+        return bool(self.normalpha and self.mode == LC_SCORE_CORR and split)
+
+    def _hat_matrices(self, K, inner_abs, lmax=None, moments=False, chol_after=None):
+        """V-independent part of the inner CV of one outer fold: row lists, S[0]^2 (Lanczos), penalties and the
+        hat matrices H_alpha of every (inner fold, alpha) -- batched Cholesky for the small alphas, the shared
+        polynomial series for the large ones (as hat matrices, or with ``moments`` as the scaled matrix powers
+        themselves).  Returns a dict the sweeps consume."""
+        F, A = len(inner_abs), self.A
+        n_i = [len(t) for t, _ in inner_abs]
+        n_v = [len(v) for _, v in inner_abs]
+        if min(n_i) < 1 or min(n_v) < 1:
+            raise ValueError("every inner fold needs at least one training and one validation row")
+        N = ops.pad_to(max(n_i), LC_NB)
+        M = ops.pad_to(max(n_v), LC_MB)
+        tr = ops.idx_matrix([t for t, _ in inner_abs], N, self.dev)          # (F, N) / (F, M) int32, -1 padded
+        va = ops.idx_matrix([v for _, v in inner_abs], M, self.dev)
+        if self.normalpha and lmax is None:
+            lmax = self.lmax_systems(K, [t for t, _ in inner_abs])
+            self._check_singcutoff(lmax)
+        a2 = ops.penalties(lmax, F, self.d_alphas, self.normalpha)
+        ser, cho, d_ser = self.ser, self.cho, self.d_ser
+        moments = bool(moments and ser and min(n_v) > 1)
+        Ac = len(cho)
+        per_sys = (N + M) * N * 8
+        chunk = max(1, min(F, MAX_INNER_FOLDS, self.opt.aug_budget_bytes // max(1, per_sys * max(Ac, 1))))
+        infos, Hs, imgs = [], [], []
+        for f0 in range(0, F, chunk):
+            fc = min(chunk, F - f0)
+            H = torch.empty((fc * A, M, N), dtype=torch.float32, device=self.dev) if not moments else None
+            P = None
+            if ser and moments:
+                rows_p, rowmap, _ = self._series_layout(M)
+                # voxel shards: the chains of the folds are independent and V-independent -- dealt out like the Cholesky
+                # systems (contiguous shares, all-gathered into fold order); one rank: all of them
+                n_per, mine = job_share(fc, self.shard.world, self.shard.rank) if self.shard.active else (fc, range(fc))
+                m0, fcl = (mine[0], len(mine)) if len(mine) else (0, 0)
+                P = ops.zeros((n_per, rows_p, N), torch.float32, self.dev)
+                g0 = f0 + m0
+                if fcl and N % COL_TILE == 0:
+                    # the chain P'_j = P'_(j-1) (K[tr,tr] / lambda) on the f32 MFMA: its terms enter a prediction
+                    # scaled by rho^j, fp32 products with fp32 accumulation keep them at full fp32 accuracy.
+                    # Run transposed, Q_j = Kn Q_(j-1) with the folds as column groups of one grouped launch.
+                    Mq = ops.pad_to(M, COL_TILE)
+                    Kn = torch.empty((fcl, N, N), dtype=torch.float32, device=self.dev)
+                    ops.gather_sub_f32(K, tr[g0:g0 + fcl], tr[g0:g0 + fcl], fcl, N, N, lmax[g0:g0 + fcl], Kn)
+                    # Q_0[n][f][i] = K[tr_f[n], va_f[i]] / lambda_f  (K symmetric), zero in the padding columns
+                    Q = ops.zeros((N, fcl, Mq), torch.float32, self.dev)
+                    ops.gather_sub_f32_strided(K, tr[g0:g0 + fcl], va[g0:g0 + fcl], fcl, N, M, lmax[g0:g0 + fcl], Q, Mq,
+                                               fcl * Mq, 1)
+                    tiles = [f * (Mq // COL_TILE) for f in range(fcl + 1)]
+                    for j in range(SERIES_TERMS):
+                        if j:
+                            Qn = torch.empty_like(Q)
+                            ops.gemm_grouped(Kn, N, N * N, Q, fcl * Mq, None, Qn, fcl * Mq, N, fcl * Mq, N, tiles)
+                            Q = Qn
+                        ops.series_place(Q, N, fcl, Mq, M, rowmap[j * M:(j + 1) * M], P, rows_p)
+                elif fcl:
+                    ops.batch_series_terms(K, tr[g0:g0 + fcl], va[g0:g0 + fcl], fcl, N, M, lmax[g0:g0 + fcl], SERIES_TERMS,
+                                           P, rowmap)
+                if self.shard.active:
+                    P = self.shard.all_gather(P, lane="hat").view(self.shard.world * n_per, rows_p, N)
+            elif ser:
+                ops.batch_series_hat(K, tr[f0:f0 + fc], va[f0:f0 + fc], fc, N, M, lmax[f0:f0 + fc], self.d_coef, d_ser, A,
+                                     SERIES_TERMS, H)
+            # the fp16 hi/lo images of the operators (the A operands of the V-wide contractions) are V-independent too:
+            # made HERE, once per outer fold, and shared by every voxel range of the fold -- a host-to-host fit works
+            # through the first and the last folds panel by panel, and each panel used to split the same matrices again
+            img = None
+            if moments and P is not None and self._split_assumed():
+                tp = ops.pad_to(P.shape[1], 256)
+                img = dict(tp=tp, Pt=torch.empty(fc * tp * N * 2, dtype=torch.float16, device=self.dev),
+                           rs_p=torch.empty(fc * tp, dtype=torch.float32, device=self.dev), Ht=None, rs_h=None, hp=0)
+                ops.split_rows_f16_groups(P.view(-1, N), fc, P.shape[1], N, img["Pt"], img["rs_p"])
+            series_ready = torch.cuda.Event() if self.dev.type == "cuda" else None
+            if series_ready is not None:
+                series_ready.record()           # the series operands of this chunk are complete; Cholesky follows
+            if Ac and self.spectral:
+                if chol_after is not None:
+                    torch.cuda.current_stream().wait_event(chol_after)
+                # every alpha of every inner fold of the chunk from ONE eigendecomposition per fold (replicated on every
+                # rank of a sharded fit: no collective)
+                rows_f = tr[f0:f0 + fc]
+                Hs_ = self._spectral_operators(K, rows_f, va[f0:f0 + fc], None, fc, N, M, a2[f0 * A:(f0 + fc) * A], A,
+                                               [min(n_i[f0 + j], self.p) for j in range(fc)], out=H)
+                infos.append(ops.zeros(fc * A, torch.int32, self.dev))
+                assert Hs_ is H
+            elif Ac:
+                if chol_after is not None:
+                    torch.cuda.current_stream().wait_event(chol_after)
+                # job j = (inner fold f0 + j // Ac, Cholesky alpha j % Ac) = system (f0 + j // Ac) * A + cho[j % Ac] of
+                # the (fold, alpha) grid that tr / va / a2 are laid out on
+                grid_id = [(f0 + j // Ac) * A + cho[j % Ac] for j in range(fc * Ac)]
+
+                def assemble(jobs, grid_id=grid_id):
+                    aug = torch.empty((len(jobs), N + M, N), dtype=torch.float64, device=self.dev)
+                    sysv = ops.upload(np.asarray([grid_id[j] for j in jobs], dtype=np.int32), self.dev)
+                    ops.batch_assemble_sel(K, tr, va, None, a2, sysv, len(jobs), A, N, M, aug)
+                    return aug
+
+                slot = None if moments else ops.upload(np.asarray(
+                    [(j // Ac) * A + cho[j % Ac] for j in range(fc * Ac)], dtype=np.int32), self.dev)
+                Hc, info_c = self._sharded_solve(fc * Ac, N, M, assemble, out=H, slot=slot)
+                infos.append(info_c)
+                if moments:
+                    H = Hc                                   # (>= fc * Ac, M, N): fold j's alphas at [j * Ac, (j + 1) * Ac)
+                elif Hc is not H:
+                    for j in range(fc * Ac):                 # voxel shards: beside the series alphas' hat matrices
+                        H[(j // Ac) * A + cho[j % Ac]].copy_(Hc[j])          # (D2D copies)
+            if img is not None and Ac and H is not None:
+                hp = ops.pad_to(Ac * M, 256)
+                img.update(hp=hp, Ht=torch.empty(fc * hp * N * 2, dtype=torch.float16, device=self.dev),
+                           rs_h=torch.empty(fc * hp, dtype=torch.float32, device=self.dev))
+                ops.split_rows_f16_groups(H.view(-1, N), fc, Ac * M, N, img["Ht"], img["rs_h"])
+            Hs.append((f0, fc, H, P))
+            imgs.append(img)
+        info = self._join_flags(infos)
+        return dict(F=F, N=N, M=M, n_v=n_v, n_i=n_i, tr=tr, va=va, shared=self._shared_image(inner_abs, N), Hs=Hs, info=info, lmax=lmax, a2=a2, cho=cho, ser=ser,
+                    d_ser=d_ser, moments=moments, series_ready=series_ready, imgs=imgs)
+
+    def _sweeps(self, hat, Y, done=None, split_phase=False):
+        """Sum over inner folds of the (A, Vp) validation scores (ridge_corr_torch for every fold,
+        nested_cv.py:366-393): the V-wide fused MFMA sweeps, plus -- with ``hat["moments"]`` -- one plain
+        contraction of the shared series terms and the moment kernel for the alphas on the series.  ``done``: event
+        after which the hat matrices are complete; the series part only waits for ``hat["series_ready"]`` and
+        runs first, so the main stream has work while the auxiliary stream is still in the Cholesky chains.
+        ``split_phase``: queue only that first part now and return a callable that queues the rest (the fused sweeps
+        behind ``done``) and returns the scores -- the driver puts the NEXT step's first part in between, so that the
+        main stream has V-wide work while it waits for a fold's Cholesky chains (the range the phases work on is
+        captured here: the engine's current range may have moved on when the callable runs)."""
+        Vp_, V_ = self.Vp, self.V
+        if hat.get("no_inner"):
+            # no inner fold of this outer fold has validation rows: the reference scores every alpha 0 for every voxel
+            # (z_score of an empty block -> NaN -> nan_to_num, ridge_regression.py:124-133) and its first-maximum
+            # argmax takes alphas[0]
+            scores = ops.zeros((self.A, Vp_), torch.float32, self.dev)
+            self.info.update(precision="f16x3" if hat["split"] else "f32", fused_alphas=0, series_terms=0)
+            self.sweeps_done = torch.cuda.Event()
+            self.sweeps_done.record()
+            return (lambda: scores) if split_phase else scores
+        if self.primal:
+            out = self._sweeps_primal(hat, Y, done)
+            return (lambda: out) if split_phase else out
+        A, N, M, tr, va, n_v = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"]
+        F = hat["F"]
+        moments, cho = hat["moments"], hat["cho"]
+        Ad = len(cho) if moments else A                   # alphas that go through the fused sweep
+        main = torch.cuda.current_stream()
+        scores = torch.empty((A, Vp_), dtype=torch.float32, device=self.dev)
+        cho_first = list(cho) == list(range(len(cho)))     # ascending grids: the factorised alphas are rows 0 .. Ad-1
+        scores_d = scores
+        if moments and Ad:
+            scores_d = scores[:Ad] if cho_first else torch.empty((Ad, Vp_), dtype=torch.float32, device=self.dev)
+        part = torch.empty((max(Ad, 1) * M // LC_MB, 4, Vp_), dtype=torch.float32, device=self.dev)
+        split, cs = hat["split"], hat["cs"]
+        if hat.get("data_ready") is not None:
+            main.wait_event(hat["data_ready"])            # this fold's (normalised) targets and their column scales
+        self.info.update(precision="f16x3" if split else "f32", fused_alphas=Ad,
+                          series_terms=SERIES_TERMS if moments else 0, folds_per_launch=1)
+        nbuf = F if moments else 1                        # two passes over the folds keep every fold's operands
+        ystat = torch.empty((nbuf, 3, Vp_), dtype=torch.float32, device=self.dev)
+        yblk = torch.empty((nbuf, M // LC_MB, Vp_), dtype=torch.float32, device=self.dev)
+        yv = torch.empty((nbuf, M, Vp_), dtype=torch.float32, device=self.dev)
+        shared = hat.get("shared") if split else None
+        if split:
+            rows_pad = ops.pad_to(max(Ad, 1) * M, 256)
+            Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=self.dev)
+            rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=self.dev)
+            Vt = ops.pad_to(Vp_, 256)
+            if shared is not None:
+                # the targets of the whole outer training set split once; every inner fold contracts it minus one
+                # aligned block (B view): saves F - 1 passes over Y per outer fold
+                union, gaps = shared
+                Yu = torch.empty(Vt * len(union) * 2, dtype=torch.float16, device=self.dev)
+                ops.split_cols_f16(Y, Vp_, ops.idx_tensor(union, len(union), self.dev), len(union), cs, Yu)
+                Yt = [Yu] * nbuf
+                views = [(len(union), g0, gl) for g0, gl in gaps]
+                hat["image"] = (Yu, union)                # the refit permutes its operand out of it (_refit_operands)
+            else:
+                Yt = [torch.empty(Vt * N * 2, dtype=torch.float16, device=self.dev) for _ in range(nbuf)]
+                views = [(0, 0, 0)] * F
+        folds = [(f0 + j, j, H, P) for f0, fc, H, P in hat["Hs"] for j in range(fc)]
+        # the operators' fp16 images made with the hat matrices (_hat_matrices), per chunk: fold f0 + j is group j
+        imgs = hat.get("imgs") or [None] * len(hat["Hs"])
+        img_of = {f0 + j: (im, j) for (f0, fc, _, _), im in zip(hat["Hs"], imgs) if im is not None for j in range(fc)}
+        fused = False
+        Pt = rs_p = part_s = Tbuf = cs_inv = rowmap = slab_light = Tm = None
+
+        def series_part():
+            nonlocal fused, Pt, rs_p, part_s, Tbuf, cs_inv, rowmap, slab_light, Tm
+            if moments:
+                # ---- pass 1: validation statistics, operand split, series contraction + moment kernel
+                Tm, rowmap, slab_light = self._series_layout(M)
+                fused = slab_light is None                   # layout of the moments epilogue: the terms are never stored
+                tp = ops.pad_to(Tm, 256)
+                Pt = torch.empty(tp * N * 2, dtype=torch.float16, device=self.dev)
+                rs_p = torch.empty(tp, dtype=torch.float32, device=self.dev)
+                if fused:
+                    part_s = torch.empty((1, M // LC_MB, 18, Vp_), dtype=torch.float32, device=self.dev)
+                else:
+                    Tbuf = torch.empty((Tm, Vt), dtype=torch.float32, device=self.dev)
+                cs_inv = self._cs_inv_padded(cs, Vt)                               # padded to the plain GEMM's tiles
+                if hat.get("series_ready") is not None:
+                    main.wait_event(hat["series_ready"])
+                # validation statistics of all inner folds in one launch (the blocks are independent)
+                for f0 in range(0, F, 64):
+                    f1 = min(F, f0 + 64)
+                    ops.val_stats_folds(Y, Vp_, va[f0:f1], f1 - f0, M, n_v[f0:f1], ystat[f0:f1], yblk[f0:f1], yv[f0:f1])
+                for f, j, H, P in folds:
+                    if shared is None:
+                        ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[f])
+                    Pt_f, rs_p_f = Pt, rs_p
+                    if f in img_of:
+                        im, g = img_of[f]
+                        Pt_f, rs_p_f = im["Pt"][g * im["tp"] * N * 2:], im["rs_p"][g * im["tp"]:]
+                    else:
+                        ops.split_rows_f16(P[j], Tm, N, Pt, rs_p)
+                    self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * V_
+                    self.info["plain_launches"] += 1
+                    if fused:
+                        ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], N, Yt[f], cs_inv, Vt, yv[f], Vp_, ystat[f], yblk[f],
+                                                      self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0,
+                                                      bview=views[f])
+                        continue
+                    ops.gemm_grouped_f16x3(Pt_f, rs_p_f, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
+                                           bview=views[f])
+                    ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], Vp_, yv[f], ystat[f], self.d_coef, hat["d_ser"],
+                                      scores, accumulate=f > 0, rowmap=rowmap)
+
+        def fused_part():
+            if done is not None:
+                main.wait_event(done)
+            # ---- pass 2 (the only one without the moment path): fused sweeps of the alphas that have hat matrices
+            for f, j, H, P in folds:
+                b = f if moments else 0
+                if not moments:
+                    ops.val_stats(Y, Vp_, va[f], M, n_v[f], ystat[b], yblk[b], yv[b])
+                if split:
+                    if not moments and shared is None:
+                        ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[b])
+                    if Ad:
+                        self.info["fused_flops"] += 2.0 * Ad * n_v[f] * hat["n_i"][f] * V_
+                        self.info["fused_launches"] += 1
+                        Ht_f, rs_h_f = Ht, rs_inv
+                        if moments and f in img_of and img_of[f][0]["Ht"] is not None:
+                            im, g = img_of[f]
+                            Ht_f, rs_h_f = im["Ht"][g * im["hp"] * N * 2:], im["rs_h"][g * im["hp"]:]
+                        else:
+                            ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
+                        ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, N, Yt[b], cs[Vp_:], yv[b], Vp_, n_v[f], ystat[b],
+                                                     yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f])
+                else:
+                    self.info["fused_flops"] += 2.0 * A * n_v[f] * hat["n_i"][f] * V_
+                    self.info["fused_launches"] += 1
+                    ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, Vp_, tr[f], yv[b], n_v[f], ystat[b], yblk[b],
+                                           self.mode, part, scores, accumulate=f > 0)
+            if moments and Ad and not cho_first:
+                for i, a in enumerate(cho):
+                    scores[a].copy_(scores_d[i])
+            self.sweeps_done = torch.cuda.Event()
+            self.sweeps_done.record()
+            return scores
+
+
+        if not moments:                                   # one pass only: nothing to put another step's work behind
+            out = fused_part()
+            return (lambda: out) if split_phase else out
+        series_part()
+        return fused_part if split_phase else fused_part()
+
+    def _alpha_scores(self, K, Y, inner_abs):
+        cs, split = self._target_scales(Y)
+        hat = self._hat_matrices(K, inner_abs, moments=self._series_by_moments(split))
+        hat.update(cs=cs, split=split)
+        return self._sweeps(hat, Y), hat["info"]

@@ -527,16 +527,6 @@ def test_shared_target_image_is_bitwise_neutral(lc):
     eng = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
     assert eng._shared_image(inner, 384) is not None
     s_shared, _ = eng._alpha_scores(eng.K, eng.dY, inner)
-    # all inner folds in one launch per pass (lc_*_f16x3_folds: stacked A images, a gap per fold, fold-parallel
-    # finalisation): the same tiles, the same fp32 fold sums -- bit for bit
-    import litcoder_core_amd.nested_cv as ncv
-    keep = eng.opt.folds_in_one_launch
-    try:
-        eng.opt.folds_in_one_launch = not keep
-        s_other, _ = eng._alpha_scores(eng.K, eng.dY, inner)
-    finally:
-        eng.opt.folds_in_one_launch = keep
-    assert torch.equal(s_shared, s_other)
     eng._shared_image = lambda *a: None
     s_plain, _ = eng._alpha_scores(eng.K, eng.dY, inner)
     assert torch.equal(s_shared, s_plain)
@@ -622,27 +612,6 @@ def test_refit_operators_by_inverse_match_the_solves(lc):
     assert np.array_equal(got[2], ref[2])
     np.testing.assert_allclose(got[0]["correlations"], ref[0]["correlations"], atol=3e-6)
     np.testing.assert_allclose(got[1], ref[1], rtol=2e-5, atol=2e-5 * float(np.abs(ref[1]).max()))
-
-
-def test_cu_mask_option_is_neutral(lc, monkeypatch):
-    """LITCODER_AMD_CU_MASK=1 runs the fit on a main stream restricted to a CU subset (nested_cv._main_stream): a
-    scheduling option only -- results identical bit for bit; and the stream plumbing (caller's stream ordered before
-    and after the fit) leaves the weights usable on the caller's stream."""
-    from litcoder_core_amd import nested_cv as ncv
-    rng = np.random.default_rng(33)
-    T, p, V = 360, 24, 150
-    X = rng.standard_normal((T, p))
-    Y = X @ (rng.standard_normal((p, V)) * 0.3) + rng.standard_normal((T, V))
-    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 3, 5).tolist(),
-              single_alpha=False)
-    base = lc.NestedCVModel("ridge_regression").fit_predict(features=X, targets=Y, **kw)
-    monkeypatch.setenv("LITCODER_AMD_CU_MASK", "1")
-    ncv._MAIN_STREAMS.clear()
-    masked = lc.NestedCVModel("ridge_regression").fit_predict(features=X, targets=Y, **kw)
-    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
-        assert ncv._main_stream() is not None
-    assert np.array_equal(base[1], masked[1]) and np.array_equal(base[2], masked[2])
-    assert base[0]["correlations"] == masked[0]["correlations"]
 
 
 def test_refit_with_large_alphas_polynomial_route(lc):
