@@ -62,9 +62,10 @@ FIT_KW = dict(folding_type="kfold", n_outer_folds=N_OUTER, n_inner_folds=N_INNER
               normalize_targets=False)
 
 
-def synth_inputs(V, rank, dev):
+def synth_inputs(V, rank, dev, T=T, F0=F0, DELAYS=DELAYS):
     """SURVEY.md 8d generator: X0 ~ N(0,1) (T, 768) -> FIR delays (HIP kernel) -> X (T, 3072);
-    Y = X (0.02 N(0,1)) + N(0,1), made on the device in fp32 (data synthesis only)."""
+    Y = X (0.02 N(0,1)) + N(0,1), made on the device in fp32 (data synthesis only).  (T / F0 / DELAYS: the other
+    configs' shapes, tools/scaling_model.py.)"""
     from litcoder_core_amd import ops
     rng = np.random.default_rng(0)
     X0 = rng.standard_normal((T, F0))

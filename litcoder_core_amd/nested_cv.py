@@ -32,7 +32,8 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 import numpy as np
 import torch
 
-from . import ops, stats
+from . import ops, series, stats  # noqa: F401
+from ._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2  # noqa: F401  (names tests / tools reach through here)
 from .dist import ShardContext
 from .engine.common import (SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions,  # noqa: F401
                             check_penalties, _PrimalUnsuitable, _WideTargets, _FoldResult, _aux_stream, _Range,
