@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -54,8 +55,18 @@ struct Slot {
 // cast of torch.tensor(..., dtype=float32) (nested_cv.py:99-100).  numpy reduces axis 0 of a C-ordered matrix row by
 // row, one running sum per column: the loops below add in exactly that order, without fused multiply-adds, so the result
 // is the reference's bit for bit.  Sub-tiles of ZS_TILE columns keep the block in cache between its three passes.
-constexpr int64_t ZS_TILE = 256;
+constexpr int64_t ZS_TILE = 256;       // widest column sub-tile (the stack buffers); zs_tile() = the width in use
 constexpr int64_t ZS_TASK = 1024;     // columns per staging task of a z-scored chunk (a multiple of ZS_TILE)
+
+// columns per sub-tile: a story's sub-tile (rows x width x 8 bytes) should stay in the core's L2 between the three passes
+inline int64_t zs_tile() {
+    static const int64_t w = [] {
+        const char* e = getenv("LITCODER_AMD_ZS_TILE");
+        int64_t v = e ? atoll(e) : 128;
+        return v < 8 ? 8 : (v > ZS_TILE ? ZS_TILE : v);
+    }();
+    return w;
+}
 
 template <typename T>
 static inline __attribute__((always_inline)) void zscore_body(const T* src, int64_t ld_src, int64_t n, int64_t x0,
@@ -63,8 +74,9 @@ static inline __attribute__((always_inline)) void zscore_body(const T* src, int6
 #pragma clang fp contract(off)
     T mean[ZS_TILE], sdev[ZS_TILE];
     const T cnt = (T)n;
-    for (int64_t t0 = x0; t0 < x1; t0 += ZS_TILE) {
-        const int64_t tw = (x1 - t0 < ZS_TILE) ? x1 - t0 : ZS_TILE;
+    const int64_t TW = zs_tile();
+    for (int64_t t0 = x0; t0 < x1; t0 += TW) {
+        const int64_t tw = (x1 - t0 < TW) ? x1 - t0 : TW;
         const T* a0 = src + t0;
         for (int64_t x = 0; x < tw; ++x) mean[x] = (T)0;
         for (int64_t r = 0; r < n; ++r) {

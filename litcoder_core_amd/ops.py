@@ -380,6 +380,8 @@ class PanelUploader:
         per_node = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
         zs = any(h.zscore for h, _, _, _ in self.jobs)   # (z-scored chunks are shared by several threads: more of them)
         n_threads = max(2, min(_UPLOAD_THREADS_ZS if zs else len(pinned), (os.cpu_count() or 4) // 2 // per_node))
+        if os.environ.get("LITCODER_AMD_UPLOAD_THREADS"):      # (tuning probes: tools/upload_probe.py)
+            n_threads = max(1, int(os.environ["LITCODER_AMD_UPLOAD_THREADS"]))
         _UPLOAD_LOCK.acquire()                          # the staging ring is the process's: one upload at a time owns it
         try:
             _lib.call("lc_upload_start", ctypes.cast(self._native, ctypes.c_void_p), len(native),
