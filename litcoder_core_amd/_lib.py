@@ -79,6 +79,7 @@ SIGNATURES = {
     "lc_host_cast_f64_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64]),
     "lc_host_copy_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64]),
     "lc_upload_start": (c_int, [_ptr, c_int, _ptr, c_int, c_int64, c_int, c_int, _ptr, _ptr]),
+    "lc_upload_start_staged": (c_int, [_ptr, c_int, _ptr, _ptr, c_int, c_int64, c_int, c_int, _ptr, _ptr]),
     "lc_host_zscore_story": (c_int, [_ptr, c_int, c_int64, c_int64, c_int64, _ptr, c_int64]),
     "lc_lanczos_interp_stories": (c_int, [_ptr, c_int, c_int64, c_int64, _ptr, _ptr, c_int64, _ptr, _ptr, c_int, c_double,
                                           c_int, _ptr, c_int64, _ptr]),

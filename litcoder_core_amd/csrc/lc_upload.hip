@@ -138,6 +138,7 @@ struct lc_upload {
     std::vector<hipEvent_t> job_ev;        // recorded on the upload stream behind the job's last copy
     std::vector<char> job_issued;
     std::vector<void*> slot_ptr;
+    std::vector<void*> dev_slot_ptr;       // optional device staging slots (one per host slot): see the worker
     std::vector<Slot> slots;
     int64_t slot_bytes = 0;
     int device = 0;
@@ -222,11 +223,22 @@ void worker(lc_upload* u) {
         if (u->tasks_left[k].fetch_sub(1, std::memory_order_acq_rel) != 1) continue;
         // this thread staged the chunk's last piece: the chunk's ONE copy (rows of w floats), then its slot event
         float* dst = static_cast<float*>(j.dst) + (j.dst_row0 + c.r0) * j.ld_dst + j.c0 + c.x0;
-        if (j.ld_dst == w)
+        if (j.ld_dst == w) {
             UP_HIP(hipMemcpyAsync(dst, stage, (size_t)(n * w) * sizeof(float), hipMemcpyHostToDevice, u->stream));
-        else
+        } else if (!u->dev_slot_ptr.empty()) {
+            // a strided (2-D) copy across PCIe pays per row: measured 30-38 GB/s for rows of 40-48 KB against 57 GB/s for
+            // one contiguous copy of the same bytes (profiles/r04_upload_probe.txt).  So the chunk crosses the link as ONE
+            // contiguous copy into a device staging slot and is laid out into the panel's columns by a device-to-device
+            // 2-D copy (HBM to HBM: microseconds), both on the upload stream, in order -- the device slot is free again
+            // when the next chunk that maps to it is copied
+            void* ds = u->dev_slot_ptr[k % n_slots];
+            UP_HIP(hipMemcpyAsync(ds, stage, (size_t)(n * w) * sizeof(float), hipMemcpyHostToDevice, u->stream));
+            UP_HIP(hipMemcpy2DAsync(dst, (size_t)j.ld_dst * sizeof(float), ds, (size_t)w * sizeof(float),
+                                    (size_t)w * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice, u->stream));
+        } else {
             UP_HIP(hipMemcpy2DAsync(dst, (size_t)j.ld_dst * sizeof(float), stage, (size_t)w * sizeof(float),
                                     (size_t)w * sizeof(float), (size_t)n, hipMemcpyHostToDevice, u->stream));
+        }
         UP_HIP(hipEventRecord(s.ev, u->stream));
         s.recorded = true;
         u->chunk_issued[k].store(1, std::memory_order_release);
@@ -264,11 +276,18 @@ void coordinate(lc_upload* u) {
 
 extern "C" int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* const* pinned_slots, int n_slots,
                                int64_t slot_bytes, int n_threads, int device, lc_stream_t stream, lc_upload_t** out) {
+    return lc_upload_start_staged(jobs, n_jobs, pinned_slots, nullptr, n_slots, slot_bytes, n_threads, device, stream, out);
+}
+
+extern "C" int lc_upload_start_staged(const lc_upload_job* jobs, int n_jobs, void* const* pinned_slots,
+                                      void* const* device_slots, int n_slots, int64_t slot_bytes, int n_threads, int device,
+                                      lc_stream_t stream, lc_upload_t** out) {
     LC_REQUIRE(jobs && pinned_slots && out && n_jobs > 0 && n_slots > 0 && slot_bytes > 0 && n_threads > 0, LC_E_BADARG,
                "lc_upload_start: bad argument");
     lc_upload* u = new lc_upload(n_slots);
     u->jobs.assign(jobs, jobs + n_jobs);
     u->slot_ptr.assign(pinned_slots, pinned_slots + n_slots);
+    if (device_slots) u->dev_slot_ptr.assign(device_slots, device_slots + n_slots);
     u->slot_bytes = slot_bytes;
     u->device = device;
     u->stream = lc::as_stream(stream);
@@ -311,7 +330,10 @@ extern "C" int lc_upload_start(const lc_upload_job* jobs, int n_jobs, void* cons
         // rows per chunk: what fits a staging slot, but no more than the job's share per thread -- the design (3000 x 3072)
         // fitted three 16 MB slots, so only three threads cast it (2.4 ms at the head of every fit); chunks stay >= 1 MB
         int64_t step = slot_bytes / (w * 4);
-        const int64_t share = (b.rows + u->n_threads - 1) / (u->n_threads > 0 ? u->n_threads : 1);
+        // (threads per job: with many jobs -- the story blocks of a panel -- the jobs themselves run in parallel, and a
+        // story is then one chunk, one copy)
+        const int64_t par = u->n_threads / n_jobs > 1 ? u->n_threads / n_jobs : 1;
+        const int64_t share = (b.rows + par - 1) / par;
         const int64_t floor_rows = ((1 << 20) + w * 4 - 1) / (w * 4);
         if (share < step) step = share > floor_rows ? share : (floor_rows < step ? floor_rows : step);
         if (step < 1) step = 1;

@@ -5,6 +5,7 @@ torch is used here only as the device-memory container (``torch.empty(..., devic
 liblitcoder_hip.so.  No function here has a CPU path.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -373,9 +374,15 @@ class PanelUploader:
         self._native = (_UploadJob * len(native))(*native)
         pinned, _ = _upload_ring(_UPLOAD_DEPTH_ZS if any(h.zscore for h, _, _, _ in self.jobs) else None)
         self._slots = (ctypes.c_void_p * len(pinned))(*[p.data_ptr() for p in pinned])
+        # device staging slots, one per host slot (created once per device): chunks cross the link contiguously
+        key = (dev.type, dev.index)
+        dslots = _UPLOAD.setdefault("dev_slots", {}).setdefault(key, [])
+        use_dev = os.environ.get("LITCODER_AMD_UPLOAD_DEVICE_STAGING", "1") != "0"
+        while use_dev and len(dslots) < len(pinned):
+            dslots.append(torch.empty(_UPLOAD_CHUNK, dtype=torch.uint8, device=dev))
+        self._dslots = (ctypes.c_void_p * len(pinned))(*[d.data_ptr() for d in dslots[:len(pinned)]]) if use_dev else None
         self._handle = ctypes.c_void_p()
         self._done = False
-        import os
         # staging threads: half the cores, shared out over the processes of the node (one per GPU under torchrun)
         per_node = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
         zs = any(h.zscore for h, _, _, _ in self.jobs)   # (z-scored chunks are shared by several threads: more of them)
@@ -384,8 +391,10 @@ class PanelUploader:
             n_threads = max(1, int(os.environ["LITCODER_AMD_UPLOAD_THREADS"]))
         _UPLOAD_LOCK.acquire()                          # the staging ring is the process's: one upload at a time owns it
         try:
-            _lib.call("lc_upload_start", ctypes.cast(self._native, ctypes.c_void_p), len(native),
-                      ctypes.cast(self._slots, ctypes.c_void_p), len(pinned), _UPLOAD_CHUNK, n_threads,
+            _lib.call("lc_upload_start_staged", ctypes.cast(self._native, ctypes.c_void_p), len(native),
+                      ctypes.cast(self._slots, ctypes.c_void_p),
+                      ctypes.cast(self._dslots, ctypes.c_void_p) if self._dslots is not None else None, len(pinned),
+                      _UPLOAD_CHUNK, n_threads,
                       dev.index if dev.index is not None else torch.cuda.current_device(),
                       ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(self._handle))
         except BaseException:
