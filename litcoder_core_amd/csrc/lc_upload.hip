@@ -16,6 +16,9 @@
 #include "lc_common.h"
 
 #include <atomic>
+#include <fstream>
+#include <pthread.h>
+#include <sched.h>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -55,7 +58,7 @@ struct Slot {
 // cast of torch.tensor(..., dtype=float32) (nested_cv.py:99-100).  numpy reduces axis 0 of a C-ordered matrix row by
 // row, one running sum per column: the loops below add in exactly that order, without fused multiply-adds, so the result
 // is the reference's bit for bit.  Sub-tiles of ZS_TILE columns keep the block in cache between its three passes.
-constexpr int64_t ZS_TILE = 256;       // widest column sub-tile (the stack buffers); zs_tile() = the width in use
+constexpr int64_t ZS_TILE = 1024;      // widest column sub-tile (the stack buffers); zs_tile() = the width in use
 constexpr int64_t ZS_TASK = 1024;     // columns per staging task of a z-scored chunk (a multiple of ZS_TILE)
 
 // columns per sub-tile: a story's sub-tile (rows x width x 8 bytes) should stay in the core's L2 between the three passes
@@ -150,8 +153,10 @@ struct lc_upload {
     std::string error;
     bool failed = false;
     std::thread coordinator;
+    cpu_set_t cpus;                         // CPUs of the caller's NUMA node (n_cpus > 0: the staging threads stay on it)
+    int n_cpus = 0;
 
-    explicit lc_upload(int n_slots) : slots(n_slots) {}
+    explicit lc_upload(int n_slots) : slots(n_slots) { CPU_ZERO(&cpus); }
 };
 
 namespace {
@@ -204,7 +209,10 @@ void worker(lc_upload* u) {
             UP_HIP(hipEventSynchronize(s.ev));
         }
         float* stage = static_cast<float*>(u->slot_ptr[k % n_slots]);
-        if (j.transform == LC_UPLOAD_ZSCORE) {
+        static const int diag = getenv("LITCODER_AMD_UPLOAD_DIAG") ? atoi(getenv("LITCODER_AMD_UPLOAD_DIAG")) : 0;
+        if (diag == 2) {
+            // (diagnostic: no staging work, the copies alone)
+        } else if (j.transform == LC_UPLOAD_ZSCORE) {
             if (j.dtype == LC_F64)
                 zscore_block(static_cast<const double*>(j.src) + j.c0 + c.x0 + tk.m0, j.ld_src, n, 0, mw, stage + tk.m0, w);
             else
@@ -223,7 +231,9 @@ void worker(lc_upload* u) {
         if (u->tasks_left[k].fetch_sub(1, std::memory_order_acq_rel) != 1) continue;
         // this thread staged the chunk's last piece: the chunk's ONE copy (rows of w floats), then its slot event
         float* dst = static_cast<float*>(j.dst) + (j.dst_row0 + c.r0) * j.ld_dst + j.c0 + c.x0;
-        if (j.ld_dst == w) {
+        if (diag == 1) {
+            // (diagnostic: staging alone, nothing crosses the link)
+        } else if (j.ld_dst == w) {
             UP_HIP(hipMemcpyAsync(dst, stage, (size_t)(n * w) * sizeof(float), hipMemcpyHostToDevice, u->stream));
         } else if (!u->dev_slot_ptr.empty()) {
             // a strided (2-D) copy across PCIe pays per row: measured 30-38 GB/s for rows of 40-48 KB against 57 GB/s for
@@ -256,9 +266,60 @@ void worker(lc_upload* u) {
     }
 }
 
+// The CPUs of the NUMA node the calling thread runs on (/sys/devices/system/node/node<k>/cpulist), into u->cpus.
+// The caller's arrays were, as a rule, first touched by that thread, so their pages live on its node; staging threads
+// scheduled on the other socket read them across the socket link and the upload takes 1.5-2x as long, with stalls of
+// tens of ms (measured on the 2-socket EPYC 9575F box: z-scored 6 GB 62-71 ms bound to one node, 93-148 ms unbound,
+// profiles/r04_upload_probe_numa.txt).  Any failure leaves the threads unbound.
+void caller_node_cpus(lc_upload* u) {
+    if (getenv("LITCODER_AMD_UPLOAD_NO_AFFINITY")) return;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return;
+    for (int node = 0; node < 64; ++node) {
+        std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+        if (!f) break;
+        std::string list;
+        std::getline(f, list);
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        int n = 0;
+        bool mine = false;
+        size_t i = 0;
+        while (i < list.size()) {                       // "0-63,128-191"
+            size_t e = list.find(',', i);
+            if (e == std::string::npos) e = list.size();
+            const std::string part = list.substr(i, e - i);
+            const size_t dash = part.find('-');
+            const int lo = atoi(part.c_str()), hi = dash == std::string::npos ? lo : atoi(part.c_str() + dash + 1);
+            for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c) {
+                CPU_SET(c, &set);
+                ++n;
+                mine |= c == cpu;
+            }
+            i = e + 1;
+        }
+        if (mine) {
+            // only CPUs this process may use at all
+            cpu_set_t allowed;
+            if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+                CPU_AND(&set, &set, &allowed);
+                n = CPU_COUNT(&set);
+            }
+            if (n > 0) {
+                u->cpus = set;
+                u->n_cpus = n;
+            }
+            return;
+        }
+    }
+}
+
 void coordinate(lc_upload* u) {
     std::vector<std::thread> pool;
-    for (int t = 0; t < u->n_threads; ++t) pool.emplace_back(worker, u);
+    for (int t = 0; t < u->n_threads; ++t) {
+        pool.emplace_back(worker, u);
+        if (u->n_cpus > 0) (void)pthread_setaffinity_np(pool.back().native_handle(), sizeof(u->cpus), &u->cpus);
+    }
     for (auto& t : pool) t.join();
     // jobs without rows never had a chunk: mark them issued (their event is recorded here)
     if (hipSetDevice(u->device) == hipSuccess) {
@@ -330,9 +391,10 @@ extern "C" int lc_upload_start_staged(const lc_upload_job* jobs, int n_jobs, voi
         // rows per chunk: what fits a staging slot, but no more than the job's share per thread -- the design (3000 x 3072)
         // fitted three 16 MB slots, so only three threads cast it (2.4 ms at the head of every fit); chunks stay >= 1 MB
         int64_t step = slot_bytes / (w * 4);
-        // (threads per job: with many jobs -- the story blocks of a panel -- the jobs themselves run in parallel, and a
-        // story is then one chunk, one copy)
-        const int64_t par = u->n_threads / n_jobs > 1 ? u->n_threads / n_jobs : 1;
+        // (threads per job: a few big jobs -- the design, the panels of one target matrix -- are each cut into a chunk per
+        // thread; with many jobs -- the story blocks of every panel -- the jobs themselves run in parallel and a story is
+        // one chunk, one copy: 1 MB chunks there ran the link at 23 GB/s, whole stories at 42, profiles/r04_upload_probe*)
+        const int64_t par = 2 * n_jobs >= u->n_threads ? 1 : u->n_threads;
         const int64_t share = (b.rows + par - 1) / par;
         const int64_t floor_rows = ((1 << 20) + w * 4 - 1) / (w * 4);
         if (share < step) step = share > floor_rows ? share : (floor_rows < step ? floor_rows : step);
@@ -362,6 +424,7 @@ extern "C" int lc_upload_start_staged(const lc_upload_job* jobs, int n_jobs, voi
         delete u;
         return rc;
     }
+    caller_node_cpus(u);                                 // (on the CALLER's thread: its node is the one that counts)
     u->coordinator = std::thread(coordinate, u);
     *out = u;
     return LC_OK;

@@ -264,7 +264,8 @@ _UPLOAD_DEPTH = 12                  # chunks in flight
 _UPLOAD_LOCK = threading.Lock()     # the ring is the process's: one upload job at a time owns it
 
 
-_UPLOAD_THREADS_ZS = 48             # staging threads of such an upload (capped at half the cores)
+_UPLOAD_THREADS_ZS = 24             # staging threads of such an upload (capped at half the cores; measured: 24 on the
+                                    # caller's NUMA node beat 48 and 96, profiles/r04_upload_probe*.txt)
 _UPLOAD_DEPTH_ZS = 32               # ... of an upload that z-scores stories on the way (three passes per chunk on the host:
                                     # more threads in flight to keep the link busy)
 
