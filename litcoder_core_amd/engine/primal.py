@@ -92,10 +92,6 @@ class PrimalForm:
             ops.batch_assemble_sel(G, ident, None, rhs, a2, sysv, len(jobs), A, PP, M, aug, k_fold_stride=PP * PP)
             return aug
 
-        if Ac:
-            H, info = self._sharded_solve(F * Ac, PP, M, assemble)           # (>= F * Ac, M, PP) f32: A_alpha
-        else:
-            H, info = None, ops.zeros(1, torch.int32, self.dev)
         P = None
         if use_series:
             # the shared terms of the large alphas:  P'_0 = Pstim / lambda,  P'_j = P'_(j-1) (G / lambda)  -- term j enters a
@@ -115,15 +111,24 @@ class PrimalForm:
                 for j in range(1, SERIES_TERMS):
                     stack[j * M:(j + 1) * M].copy_(self._times_symmetric(stack[(j - 1) * M:j * M], Gn)[0])
                 ops.gather(stack, PP, inv, rows_p, None, PP, P[f])
-        # the fp16 hi/lo images of the V-independent operands (the A sides of the V-wide contractions), once per fold on
-        # this stream, shared by every voxel range of the fold (a host-to-host fit works through the targets panel by panel)
+        # (the series operands first, the Cholesky chains after them: the series part of the sweeps -- it needs only P --
+        # runs on the main stream while this stream is still in the chains, _sweeps_primal)
+        tp = hp = 0
+        if img is not None and use_series:
+            tp = ops.pad_to(P.shape[1], 256)
+            img.update(Pt=torch.empty(F * tp * PP * 2, dtype=torch.float16, device=self.dev),
+                       rs_p=torch.empty(F * tp, dtype=torch.float32, device=self.dev))
+            ops.split_rows_f16_groups(P.view(-1, PP), F, P.shape[1], PP, img["Pt"], img["rs_p"])
+        series_ready = torch.cuda.Event()
+        series_ready.record()
+        if Ac:
+            H, info = self._sharded_solve(F * Ac, PP, M, assemble)           # (>= F * Ac, M, PP) f32: A_alpha
+        else:
+            H, info = None, ops.zeros(1, torch.int32, self.dev)
+        # the fp16 hi/lo images of the V-independent operands (the A sides of the V-wide contractions) are made once per fold
+        # on this stream and shared by every voxel range of the fold (a host-to-host fit works through the targets panel by
+        # panel)
         if img is not None:
-            tp = hp = 0
-            if use_series:
-                tp = ops.pad_to(P.shape[1], 256)
-                img.update(Pt=torch.empty(F * tp * PP * 2, dtype=torch.float16, device=self.dev),
-                           rs_p=torch.empty(F * tp, dtype=torch.float32, device=self.dev))
-                ops.split_rows_f16_groups(P.view(-1, PP), F, P.shape[1], PP, img["Pt"], img["rs_p"])
             if Ac:
                 hp = ops.pad_to(Ac * M, 256)
                 img.update(Ht=torch.empty(F * hp * PP * 2, dtype=torch.float16, device=self.dev),
@@ -133,7 +138,7 @@ class PrimalForm:
         hat = dict(F=F, N=PP, M=M, n_v=n_v, n_i=n_i, tr=None if rows_all is None else rows_all[:F], va=va, shared=None,
                    img=img, blocks_ready=blocks_ready,
                    Hs=[(0, F, H, P)], info=info, lmax=None if lmax is None else lmax[:F], a2=a2, cho=cho, ser=ser,
-                   d_ser=self.d_ser if use_series else None, moments=use_series, series_ready=None, split=split,
+                   d_ser=self.d_ser if use_series else None, moments=use_series, series_ready=series_ready, split=split,
                    data_ready=data_ready, Xt=Xt, Xt_val=Xt_val, Nmax=Nmax, xt_off=0)
         done = torch.cuda.Event()
         s = 0
@@ -305,9 +310,15 @@ class PrimalForm:
         scores_d = scores if not moments else (scores[:Ad] if cho_first else
                                                torch.empty((max(Ad, 1), Vp_), dtype=torch.float32, device=self.dev))
         part = torch.empty((max(Ad, 1) * M // LC_MB, 4, Vp_), dtype=torch.float32, device=self.dev)
-        ystat = torch.empty((3, Vp_), dtype=torch.float32, device=self.dev)
-        yblk = torch.empty((M // LC_MB, Vp_), dtype=torch.float32, device=self.dev)
-        yv = torch.empty((M, Vp_), dtype=torch.float32, device=self.dev)
+        # two passes over the inner folds when the series terms are ready before the hat matrices (the p x p side forms the
+        # terms first, then runs its Cholesky chains): pass 1 = validation statistics, B_f, its image, the series sweep of
+        # every fold; pass 2, behind the chains = the fused sweeps, on the images pass 1 kept -- the main stream works through
+        # the ~20 ms of the chains instead of waiting for them (LeBel shape: 5 x 0.98 GB of images per full-width range)
+        two_pass = bool(moments and Ad and split and by_blocks and hat.get("series_ready") is not None)
+        nbuf = F if two_pass else 1
+        ystat = torch.empty((nbuf, 3, Vp_), dtype=torch.float32, device=self.dev)
+        yblk = torch.empty((nbuf, M // LC_MB, Vp_), dtype=torch.float32, device=self.dev)
+        yv = torch.empty((nbuf, M, Vp_), dtype=torch.float32, device=self.dev)
         Vt = ops.pad_to(Vp_, 256)
         B = ops.zeros((PP, Vt), torch.float32, self.dev)
         ident = ops.idx_tensor(np.arange(self.p), PP, self.dev)
@@ -325,7 +336,8 @@ class PrimalForm:
             else:
                 Yt = torch.empty(Vt * depth * 2, dtype=torch.float16, device=self.dev)
             cs_inv = self._cs_inv_padded(cs, Vt)
-            Bt = torch.empty(Vt * PP * 2, dtype=torch.float16, device=self.dev)
+            Bts = [torch.empty(Vt * PP * 2, dtype=torch.float16, device=self.dev) for _ in range(nbuf)]
+            csBs = [None] * nbuf
             if Ad:
                 rows_pad = ops.pad_to(Ad * M, 256)
                 Ht = torch.empty(rows_pad * PP * 2, dtype=torch.float16, device=self.dev)
@@ -355,10 +367,25 @@ class PrimalForm:
                     self.info["plain_launches"] += 1
                 else:
                     ops.gemm_grouped(Xv, M, 0, Y, Y.stride(0), va[f], Bv[f], Vt, PP, Vp_, M, [0, Vp_ // COL_TILE])
-        if by_blocks and done is not None:
+        if two_pass:
+            main.wait_event(hat["series_ready"])           # from here on: the series terms; the hat matrices in pass 2
+        elif by_blocks and done is not None:
             main.wait_event(done)                          # from here on: the hat matrices / series terms of the fold
+
+        def fused_sweep(f, b):
+            Ht_f, rs_h_f = Ht, rs_inv
+            if img is not None and "Ht" in img:
+                Ht_f, rs_h_f = img["Ht"][f * img["hp"] * PP * 2:], img["rs_h"][f * img["hp"]:]
+            else:
+                ops.split_rows_f16(H[f * Ad:(f + 1) * Ad].reshape(Ad * M, PP), Ad * M, PP, Ht, rs_inv)
+            self.info["fused_flops"] += 2.0 * Ad * n_v[f] * self.p * V_
+            self.info["fused_launches"] += 1
+            ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, PP, Bts[b], csBs[b][Vp_:], yv[b], Vp_, n_v[f], ystat[b], yblk[b],
+                                         self.mode, part, scores_d, accumulate=f > 0)
+
         for f in range(F):
-            ops.val_stats(Y, Vp_, va[f], M, n_v[f], ystat, yblk, yv)
+            b = f if two_pass else 0
+            ops.val_stats(Y, Vp_, va[f], M, n_v[f], ystat[b], yblk[b], yv[b])
             if by_blocks:
                 ops.combine_many([Bv[q] for q in range(F) if q != f], [1.0] * (F - 1), B)
             else:
@@ -373,6 +400,7 @@ class PrimalForm:
                     self.info["plain_flops"] += 2.0 * self.p * n_i[f] * V_
                     self.info["plain_launches"] += 1
                 csB, _ = ops.col_scales_f16(B, self.p, Vp_, want_flag=False)
+                Bt, csBs[b] = Bts[b], csB
                 ops.split_cols_f16(B, Vp_, ident, PP, csB, Bt)
                 if moments:
                     Pt_f, rs_p_f = Pt, rs_p
@@ -382,23 +410,21 @@ class PrimalForm:
                         ops.split_rows_f16(P[f], Tm, PP, Pt, rs_p)
                     self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * self.p * V_
                     self.info["plain_launches"] += 1
-                    ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], PP, Bt, self._cs_inv_padded(csB, Vt), Vt, yv, Vp_,
-                                                  ystat, yblk, self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0)
-                if Ad:
-                    Ht_f, rs_h_f = Ht, rs_inv
-                    if img is not None and "Ht" in img:
-                        Ht_f, rs_h_f = img["Ht"][f * img["hp"] * PP * 2:], img["rs_h"][f * img["hp"]:]
-                    else:
-                        ops.split_rows_f16(H[f * Ad:(f + 1) * Ad].reshape(Ad * M, PP), Ad * M, PP, Ht, rs_inv)
-                    self.info["fused_flops"] += 2.0 * Ad * n_v[f] * self.p * V_
-                    self.info["fused_launches"] += 1
-                    ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, PP, Bt, csB[Vp_:], yv, Vp_, n_v[f], ystat, yblk,
-                                                 self.mode, part, scores_d, accumulate=f > 0)
+                    ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], PP, Bt, self._cs_inv_padded(csB, Vt), Vt, yv[b], Vp_,
+                                                  ystat[b], yblk[b], self.d_coef, hat["d_ser"], part_s, scores,
+                                                  accumulate=f > 0)
+                if Ad and not two_pass:
+                    fused_sweep(f, b)
             else:
                 if not by_blocks:
                     ops.gemm_grouped(Xt_f, Nmax, 0, Y, Y.stride(0), tr[f], B, Vt, PP, Vp_, Ni, [0, Vp_ // COL_TILE])
-                ops.alpha_sweep_scores(H[f * A:(f + 1) * A], A, M, PP, B, Vp_, ident, yv, n_v[f], ystat, yblk,
+                ops.alpha_sweep_scores(H[f * A:(f + 1) * A], A, M, PP, B, Vp_, ident, yv[b], n_v[f], ystat[b], yblk[b],
                                        self.mode, part, scores, accumulate=f > 0)
+        if two_pass:
+            if done is not None:
+                main.wait_event(done)
+            for f in range(F):
+                fused_sweep(f, f)
         if moments and Ad and not cho_first:
             for i, a in enumerate(cho):
                 scores[a].copy_(scores_d[i])
