@@ -3,7 +3,9 @@
 that differs must be a proven near-tie of the oracle's own score table).  A bug hunt, not a test: shapes, fold types,
 normalisers, scoring, single / per-voxel alpha, CV / train-test, precisions and all three forms (dual, primal, block
 products) are drawn at random.     python tools/fuzz_vs_oracle.py [n_cases [seed [large]]]
-``large``: T 500-1400, p up to 1536, V up to 5000 (several tiles of every kernel, ragged edges; ~10-20 s of oracle per case)."""
+``large``: T 500-1400, p up to 1536, V up to 5000 (several tiles of every kernel, ragged edges; ~10-20 s of oracle per case);
+``tall``: T 1800-3400, p 256-640, V up to 3000: the primal form with shared series terms / sums over validation blocks
+(round 4)."""
 import os
 import random
 import sys
@@ -21,6 +23,7 @@ from _oracle_check import assert_matches_oracle  # noqa: E402
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 large = len(sys.argv) > 3 and sys.argv[3] == "large"
+tall = len(sys.argv) > 3 and sys.argv[3] == "tall"
 rng = np.random.default_rng(seed)
 fails = skipped = 0
 forms = {}
@@ -32,6 +35,10 @@ for case in range(n_cases):
         T = int(rng.integers(500, 1400))
         p = int(rng.choice([40, 300, 517, 768, 1000, 1536]))
         V = int(rng.choice([300, 1025, 2000, 3333, 5000]))
+    if tall:
+        T = int(rng.integers(1800, 3400))
+        p = int(rng.choice([256, 300, 320, 384, 517, 640]))
+        V = int(rng.choice([300, 1025, 2000, 3000]))
     fold = str(rng.choice(["kfold", "chunked", "kfold_trimmed", "chunked_trimmed", "timeseries", "group"]))
     use_corr = bool(rng.random() < 0.8)
     kw = dict(folding_type=fold, n_outer_folds=int(rng.integers(2, 4)), n_inner_folds=int(rng.integers(2, 4)),
