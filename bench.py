@@ -277,29 +277,39 @@ def cfg3_cpu_baseline(words, wtimes, trtimes, brain, v_sample=1500):
     t0 = time.perf_counter()
     mats = oh.train_test_matrices(feats, small, CFG3_TRIM)
     t_struct = time.perf_counter() - t0
-    svd_time = [0.0]
+    # the six SVDs (five inner training sets + the outer one: ~11 s each here) are V-independent and differ in shape only
+    # by a row: each distinct shape is TIMED once and that time counted for every SVD of the shape -- the decomposition
+    # handed back for a repeated shape is the cached one, which makes this sample's numbers meaningless and leaves its
+    # timing (the only thing read) what it would be
+    svd_time, svd_run, cache = [0.0], [0.0], {}
     raw_svd = oridge.thin_svd
 
     def timed_svd(M, cutoff):
-        t = time.perf_counter()
-        out = raw_svd(M, cutoff)
-        svd_time[0] += time.perf_counter() - t
-        return out
+        key = tuple(M.shape)
+        if key not in cache:
+            t = time.perf_counter()
+            out = raw_svd(M, cutoff)
+            cache[key] = (out, time.perf_counter() - t)
+            svd_run[0] += cache[key][1]
+        svd_time[0] += cache[key][1]
+        return cache[key][0]
 
     oridge.thin_svd = timed_svd
     try:
         t0 = time.perf_counter()
         onc.fit_predict(mats["Rstim"], mats["Rresp"], X_test=mats["Pstim"], y_test=mats["Presp"], **CFG3_KW)
-        t_fit = time.perf_counter() - t0
+        t_fit = time.perf_counter() - t0 - svd_run[0] + svd_time[0]      # as if every SVD had been computed
     finally:
         oridge.thin_svd = raw_svd
+    n_shapes = len(cache)
     t_fixed = t_pre + svd_time[0]
     t_prop = t_struct + t_fit - svd_time[0]
     t_full = t_fixed + t_prop * V_full / v_sample
     return {"value": V_full / t_full, "unit": "voxels/sec", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": (f"oracle pipeline (Lanczos + FIR + per-story zs + train/test nested-CV fit, reference algorithm restated) "
-                       f"on {v_sample} of {V_full} voxels: {t_pre + t_struct + t_fit:.1f}s measured ({t_fixed:.1f}s V-independent: "
-                       f"preprocessing {t_pre:.1f}s + six SVDs {svd_time[0]:.1f}s; {t_prop:.1f}s proportional to V); extrapolated "
+                       f"on {v_sample} of {V_full} voxels: {t_pre + t_struct + t_fit:.1f}s ({t_fixed:.1f}s V-independent: preprocessing "
+                       f"{t_pre:.1f}s + six SVDs {svd_time[0]:.1f}s -- {n_shapes} distinct shapes timed once each, "
+                       f"{svd_run[0]:.1f}s run; {t_prop:.1f}s proportional to V); extrapolated "
                        f"as t_fixed + t_prop*V/{v_sample} = {t_full:.0f}s")}
 
 

@@ -36,7 +36,8 @@ class FitOptions:
                                             # spectrum, 1 / T_d(1 + 2 alpha^2), is <= this: 30x below the fp32 epsilon
     primal_max_scale_ratio: float = 64.0    # primal V-wide route: feature column norms within this factor (fp16x3)
     refit_by_inverse: bool = True           # refit operators through the explicit inverse + one fp16x3 product
-    refit_inverse_min_alpha: float = 0.05   # ... for alphas (in units of S[0]) from here on
+    refit_inverse_min_alpha: float = 0.1    # ... for alphas (in units of S[0]) from here on (0.05 until round 4: a fuzz case
+                                            # at alpha = 0.066 came out 5e-5 of max|W| off a float64 solve, 17x the solves' error)
     refit_inverse_max_world: int = 4        # ... and up to this many voxel-shard ranks
     series_fused_moments: bool = True       # series terms reduced to moments in the contraction's epilogue (never stored)
     primal_moments_max_p: int = 16          # up to this many features the tall form scores from block products X'Y alone

@@ -182,7 +182,7 @@ class Refit:
         solves with every row of R (N^3/3 + 2 N^2 rows: 3.4x the fp64 work).  The operator goes through 22-bit fp16
         triples afterwards anyway (the V-wide contraction), but in the product R P the entries of P ~ 1/a^2 cancel
         down to ~ 1/(2 a S0): the relative error is ~ 2^-22 x 2 S0 / a = 2^-21 / alpha for alpha S[0] scaling -- taken
-        for alpha >= 0.05 (< 1e-5), on the fp16x3 path, with normalpha (S[0] known); the solves otherwise."""
+        for alpha >= 0.1 (< 5e-6), on the fp16x3 path, with normalpha (S[0] known); the solves otherwise."""
         # (voxel shards: every rank applies every inverse it needs itself -- the same products on every rank -- while
         # the row-sliced solves shrink with the ranks: measured per simulated rank 81.8 vs 84.2 ms at 2, 53.6 vs 53.8
         # at 4, 40.2 vs 39.0 ms at 8 ranks; so the solves from 8 ranks on)

@@ -588,22 +588,22 @@ def test_refit_operators_by_inverse_match_the_solves(lc):
     alphas = [0.02, 0.05, 0.1, 0.5, 2.0]
     tr, te = np.r_[0:520], np.r_[520:700]
     eng = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
-    assert not eng._refit_by_inverse([0, 1]) and eng._refit_by_inverse([1, 2, 3, 4])
+    assert not eng._refit_by_inverse([0, 1]) and not eng._refit_by_inverse([1, 2]) and eng._refit_by_inverse([2, 3, 4])
     assert not RidgeCVEngine(X, Y, alphas, False, True, False, False)._refit_by_inverse([2])       # raw alphas
     assert not RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f32")._refit_by_inverse([2])
     N_o = ncv.ops.pad_to(len(tr), ncv.LC_NB)
     tr_o = ncv.ops.idx_tensor(tr, N_o, eng.dev).reshape(1, N_o)
     lmax_o = ncv.ops.lambda_max(eng.K, tr_o, 1, N_o, eng.steps)
     rhs = eng._refit_rhs(eng.dX, eng.K, tr, tr_o, te)
-    M_inv, info = eng._refit_chol(eng.K, tr_o, lmax_o, rhs, [1, 2, 3, 4])
+    M_inv, info = eng._refit_chol(eng.K, tr_o, lmax_o, rhs, [2, 3, 4])
     try:
         eng.opt.refit_by_inverse = False                    # this engine's own options
-        M_sol, info2 = eng._refit_chol(eng.K, tr_o, lmax_o, rhs, [1, 2, 3, 4])
+        M_sol, info2 = eng._refit_chol(eng.K, tr_o, lmax_o, rhs, [2, 3, 4])
     finally:
         eng.opt.refit_by_inverse = True
     assert not info.cpu().numpy().any() and not info2.cpu().numpy().any()
     a, b = M_inv.cpu().numpy().astype(np.float64), M_sol.cpu().numpy().astype(np.float64)
-    for i, al in enumerate(alphas[1:]):
+    for i, al in enumerate(alphas[2:]):
         err = np.abs(a[i] - b[i]).max() / np.abs(b[i]).max()
         assert err < 2.0 ** -21 / al + 1e-6, (al, err)       # + the floor of a depth-N product of 22-bit operands
     kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=alphas[1:], normalpha=True)

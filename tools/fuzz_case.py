@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One case of tools/fuzz_vs_oracle.py again, with a float64 ground truth beside both fits: who is off, and by how much.
-    python tools/fuzz_case.py seed case [large]"""
+    python tools/fuzz_case.py seed case [large | tall]"""
 import os
 import random
 import sys
@@ -15,6 +15,7 @@ import oracle.nested_cv as onc  # noqa: E402
 
 seed, want = int(sys.argv[1]), int(sys.argv[2])
 large = len(sys.argv) > 3 and sys.argv[3] == "large"
+tall = len(sys.argv) > 3 and sys.argv[3] == "tall"
 rng = np.random.default_rng(seed)
 for case in range(want + 1):
     T = int(rng.integers(90, 420))
@@ -24,6 +25,10 @@ for case in range(want + 1):
         T = int(rng.integers(500, 1400))
         p = int(rng.choice([40, 300, 517, 768, 1000, 1536]))
         V = int(rng.choice([300, 1025, 2000, 3333, 5000]))
+    if tall:
+        T = int(rng.integers(1800, 3400))
+        p = int(rng.choice([256, 300, 320, 384, 517, 640]))
+        V = int(rng.choice([300, 1025, 2000, 3000]))
     fold = str(rng.choice(["kfold", "chunked", "kfold_trimmed", "chunked_trimmed", "timeseries", "group"]))
     use_corr = bool(rng.random() < 0.8)
     kw = dict(folding_type=fold, n_outer_folds=int(rng.integers(2, 4)), n_inner_folds=int(rng.integers(2, 4)),
@@ -39,14 +44,19 @@ for case in range(want + 1):
     X = rng.standard_normal((T, p)) * rng.uniform(0.5, 2.0, p)
     Y = X @ (rng.standard_normal((p, V)) * (signal / np.sqrt(p))) + rng.standard_normal((T, V)) + rng.uniform(-3, 3)
     precision = str(rng.choice(["auto", "auto", "f32"]))
-assert tt == 0, "cross-validated cases only"
-print(f"T{T} p{p} V{V} {fold} {precision}", {k: v for k, v in kw.items() if k != "groups"})
+print(f"T{T} p{p} V{V} {fold} tt{tt} {precision}", {k: v for k, v in kw.items() if k != "groups"})
+args = (X[:T - tt], Y[:T - tt])
+extra = dict(X_test=X[T - tt:], y_test=Y[T - tt:]) if tt else {}
+kw_run = {k: v for k, v in kw.items() if not (tt and k == "n_outer_folds")}
 random.seed(want); np.random.seed(want)
 detail = {}
-m_o, W_o, a_o = onc.fit_predict(X, Y, detail=detail, **kw)
+m_o, W_o, a_o = onc.fit_predict(*args, detail=detail, **extra, **kw_run)
 random.seed(want); np.random.seed(want)
 model = lc.NestedCVModel("r", precision=precision)
-m, W, a = model.fit_predict(X, Y, **kw)
+m, W, a = model.fit_predict(*args, **extra, **kw_run)
+if tt:                                       # train/test: one "fold" = all training rows, the oracle's alphas
+    detail = dict(outer=[(np.arange(T - tt), None)], fold_alphas=[np.asarray(a_o, dtype=np.float64)])
+X, Y = args
 print("form", model.last_form, model.last_fit.get("precision"))
 # float64 ground truth: the reference's arithmetic (fp32 inputs, train-statistics normaliser, S[0] of the normalised
 # training design) carried out in float64, at the ORACLE's alphas
