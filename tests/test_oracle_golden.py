@@ -246,3 +246,25 @@ def test_oracle_at_a_config_shape_against_the_reference(golden_dir):
     np.testing.assert_allclose(detail["fold_scores"], g["cfg4__fold_r"][:, :nv], rtol=0, atol=2e-6)
     np.testing.assert_allclose(W[:, :32], g["cfg4__W"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(np.asarray(m["correlations"]), g["cfg4__correlations"][:nv], rtol=0, atol=1e-6)
+
+
+def test_bh_fdr_against_scipys_implementation():
+    """statsmodels' ``fdrcorrection`` (nested_cv.py:158,263,282) is absent here, so the Benjamini-Hochberg step is restated
+    (parity unpinned at that boundary) -- but scipy >= 1.11 ships an independent implementation of the same
+    published procedure, ``scipy.stats.false_discovery_control(ps, method="bh")``: the oracle's adjusted p-values must be
+    its, and the rejection mask ``p_adj <= alpha`` (what ``fdrcorrection(method="indep")`` returns).  Ties, ones, a single
+    value, 5 000 values."""
+    scipy_stats = pytest.importorskip("scipy.stats")
+    if not hasattr(scipy_stats, "false_discovery_control"):
+        pytest.skip("scipy < 1.11")
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 7, 100, 5000):
+        p = rng.uniform(0, 1, n) ** 3
+        p[rng.integers(0, n, max(1, n // 10))] = 1.0
+        if n > 3:
+            p[1] = p[2]
+        for alpha in (0.05, 0.2):
+            rej, padj = stats.bh_fdr(p, alpha)
+            ref = scipy_stats.false_discovery_control(p, method="bh")
+            np.testing.assert_allclose(padj, ref, rtol=1e-13, atol=0)
+            assert np.array_equal(rej, ref <= alpha)
