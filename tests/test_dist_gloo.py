@@ -135,7 +135,10 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     dist.destroy_process_group()
     # a second world in the same process (notebooks, repeated jobs): the bulk lanes of the destroyed one must not be
     # reused (ADVICE r3) -- a gather on a lane and a whole sharded fit again
-    dist.init_process_group("gloo")
+    # (a rendezvous of its own: a file store in the test's directory -- re-using the launcher's TCP store for a second
+    # world in the same job proved flaky)
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(sys.argv[3], f"rendezvous2_{mode}"),
+                            rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     shard2 = ShardContext()
     g = shard2.all_gather(torch.full((3,), float(shard2.rank)), lane="hat")
     assert g[:, 0].tolist() == [0.0, 1.0]
