@@ -504,6 +504,17 @@ int lc_split_rows_f16_groups(const float* d_h, int64_t ld, int groups, int64_t r
 int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
                       int32_t* d_flag, lc_stream_t stream);
 
+/* The primal form's operand  B_f = B_all - B_val(f)  (Rstim'Rresp of an inner training set as the outer block's minus
+ * the validation block's, nested_cv.py:366-374 -> ridge_regression.py:104-106) and its column scales in ONE pass:
+ *   lc_combine_terms_colmax_f32  out = c0 T0 + c1 T1 + ... (<= 4 terms, lc_combine_terms_f32's arithmetic) over (rows,
+ *                                cols) matrices of leading dimension ld (16-byte aligned, cols %% 4 == 0); d_colmax
+ *                                (cols uint32, caller-zeroed, NULL = none) receives the bits of max |out| over the FINITE
+ *                                entries of every column (several calls may accumulate into it);
+ *   lc_col_scales_from_max       d_cscale[v] = 2^-e, d_cscale[V + v] = 2^e from those maxima: lc_col_scales_f16's scales. */
+int lc_combine_terms_colmax_f32(const float* const* h_terms, const float* h_coef, int terms, float* d_out,
+                                int64_t ld, int64_t rows, int64_t cols, uint32_t* d_colmax, lc_stream_t stream);
+int lc_col_scales_from_max(const uint32_t* d_colmax, int64_t V, float* d_cscale, lc_stream_t stream);
+
 /* Y[d_rows] (K rows incl. -1 padding, V columns) * cscale -> tiled fp16 hi/lo image
  * (pad256(V) * K * 2 halves).  K % 32 == 0. */
 int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_rows, int K,

@@ -112,6 +112,9 @@ SIGNATURES = {
     "lc_series_place": (c_int, [_ptr, c_int, c_int, c_int, c_int, _ptr, _ptr, c_int, _ptr]),
     "lc_scale_cast_f64_f32": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr]),
     "lc_combine_terms_f32": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, _ptr, c_int64, _ptr]),
+    "lc_combine_terms_colmax_f32": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, _ptr, c_int64, c_int64, c_int64, _ptr,
+                                            _ptr]),
+    "lc_col_scales_from_max": (c_int, [_ptr, c_int64, _ptr, _ptr]),
     "lc_combine_terms_f64": (c_int, [POINTER(c_void_p), POINTER(c_double), c_int, _ptr, c_int64, _ptr]),
     "lc_gather_sub_f64": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr]),
     "lc_gather_sub_f32": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),

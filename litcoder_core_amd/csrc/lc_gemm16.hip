@@ -93,35 +93,58 @@ __global__ void __launch_bounds__(256) k_split_rows_f16(const float* __restrict_
 // every V-wide kernel keeps a voxel's arithmetic inside its own column, so such a voxel ends where the reference's own
 // fp32 arithmetic ends it -- every score NaN -> 0 (ridge_regression.py:133), alpha = alphas[0], non-finite weights,
 // r = NaN -> (0, 1) (nested_cv.py:434-436) -- and its neighbours never see it (tests/test_gpu_parity.py).
-__global__ void __launch_bounds__(512) k_col_scales(const float* __restrict__ y, long long ldy, int T, long long V,
-                                                    float* __restrict__ cs, int* __restrict__ flag) {
-    __shared__ float sm[8][64];
-    __shared__ int cnt[8][64];
+constexpr int CS_RG = 16, CS_UNROLL = 8;   // row groups per block, rows in flight per thread
+__global__ void __launch_bounds__(64 * CS_RG) k_col_scales(const float* __restrict__ y, long long ldy, int T, long long V,
+                                                           float* __restrict__ cs, int* __restrict__ flag) {
+    __shared__ float sm[CS_RG][64];
+    __shared__ int cnt[CS_RG][64];
     const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
     float mx = 0.f;
-    if (c < V)
-        for (int i = threadIdx.y; i < T; i += 8) {
-            const float v = y[(long long)i * ldy + c];
+    if (c < V) {
+        const float* col = y + c;
+        // CS_UNROLL independent loads per trip: a column walk with one load in flight ran at 0.6-1.2 TB/s (round 4)
+        for (int i0 = ty; i0 < T; i0 += CS_RG * CS_UNROLL) {
+            float v[CS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CS_UNROLL; ++u) {
+                const int i = i0 + u * CS_RG;
+                v[u] = i < T ? col[(long long)i * ldy] : 0.f;
+            }
             // the scale comes from the FINITE entries: a voxel with one Inf / NaN sample still has outer folds whose
             // training rows are clean (the reference then chooses a real alpha there), and those must be split well
-            if (fabsf(v) < 3.0e38f) mx = fmaxf(mx, fabsf(v));
+#pragma unroll
+            for (int u = 0; u < CS_UNROLL; ++u)
+                if (fabsf(v[u]) < 3.0e38f) mx = fmaxf(mx, fabsf(v[u]));
         }
+    }
     sm[threadIdx.y][threadIdx.x] = mx;
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < 8; ++g) mx = fmaxf(mx, sm[g][threadIdx.x]);
+    for (int g = 0; g < CS_RG; ++g) mx = fmaxf(mx, sm[g][threadIdx.x]);
     const float small = mx * (1.f / 512.f);
     int n_small = 0;
     if (flag != nullptr) {                 // (block-uniform; without a flag pointer the scales alone: one pass over y)
-        if (c < V)
-            for (int i = threadIdx.y; i < T; i += 8) n_small += fabsf(y[(long long)i * ldy + c]) < small;
+        if (c < V) {
+            const float* col = y + c;
+            for (int i0 = ty; i0 < T; i0 += CS_RG * CS_UNROLL) {
+                float v[CS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < CS_UNROLL; ++u) {
+                    const int i = i0 + u * CS_RG;
+                    v[u] = i < T ? col[(long long)i * ldy] : __builtin_huge_valf();
+                }
+#pragma unroll
+                for (int u = 0; u < CS_UNROLL; ++u) n_small += fabsf(v[u]) < small;
+            }
+        }
         cnt[threadIdx.y][threadIdx.x] = n_small;
         __syncthreads();
     }
     if (threadIdx.y == 0 && c < V) {
         if (flag != nullptr) {
 #pragma unroll
-            for (int g = 1; g < 8; ++g) n_small += cnt[g][threadIdx.x];
+            for (int g = 1; g < CS_RG; ++g) n_small += cnt[g][threadIdx.x];
         }
         int e = 0;
         if (mx > 0.f) frexpf(mx, &e);
@@ -130,6 +153,80 @@ __global__ void __launch_bounds__(512) k_col_scales(const float* __restrict__ y,
         cs[V + c] = ldexpf(1.f, e);
         if (flag != nullptr && mx > 0.f && 2 * n_small > T) atomicOr(flag, 1);
     }
+}
+
+// out = c0 T0 + c1 T1 + ... (k_combine_terms' arithmetic: fl32 products and sums, left to right, no contraction) over a
+// (rows, ld) matrix, 16 bytes per lane, and -- in the same pass -- the columns' maxima of |out| over the FINITE entries,
+// as float bits in colmax (caller-zeroed; atomicMax on the bits of a non-negative float orders like the float): the
+// primal form's  B_f = B_all - B_val(f)  needs its column scales before its fp16 image can be written, and a separate
+// k_col_scales pass over it was a fifth of the HBM traffic of an inner fold at the LeBel shape.
+constexpr int CC_ROWS = 64;                // rows per block: 4 waves x 16 rows, 256 columns
+__global__ void __launch_bounds__(256) k_combine_colmax(const float* __restrict__ t0, const float* __restrict__ t1,
+                                                        const float* __restrict__ t2, const float* __restrict__ t3,
+                                                        float c0, float c1, float c2, float c3, int terms,
+                                                        float* __restrict__ out, long long ld, int rows, long long cols4,
+                                                        unsigned* __restrict__ colmax) {
+    __shared__ float4 sm[4][64];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long long c4 = (long long)blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * CC_ROWS, r1 = min(rows, r0 + CC_ROWS);
+    float4 mx = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < cols4) {
+#pragma unroll 4
+        for (int r = r0 + w; r < r1; r += 4) {
+            const long long o = (long long)r * ld + c4 * 4;
+            float4 m = *reinterpret_cast<const float4*>(t0 + o);
+            m.x = __fmul_rn(m.x, c0); m.y = __fmul_rn(m.y, c0); m.z = __fmul_rn(m.z, c0); m.w = __fmul_rn(m.w, c0);
+            if (terms > 1) {
+                const float4 t = *reinterpret_cast<const float4*>(t1 + o);
+                m.x = __fadd_rn(m.x, __fmul_rn(t.x, c1)); m.y = __fadd_rn(m.y, __fmul_rn(t.y, c1));
+                m.z = __fadd_rn(m.z, __fmul_rn(t.z, c1)); m.w = __fadd_rn(m.w, __fmul_rn(t.w, c1));
+            }
+            if (terms > 2) {
+                const float4 t = *reinterpret_cast<const float4*>(t2 + o);
+                m.x = __fadd_rn(m.x, __fmul_rn(t.x, c2)); m.y = __fadd_rn(m.y, __fmul_rn(t.y, c2));
+                m.z = __fadd_rn(m.z, __fmul_rn(t.z, c2)); m.w = __fadd_rn(m.w, __fmul_rn(t.w, c2));
+            }
+            if (terms > 3) {
+                const float4 t = *reinterpret_cast<const float4*>(t3 + o);
+                m.x = __fadd_rn(m.x, __fmul_rn(t.x, c3)); m.y = __fadd_rn(m.y, __fmul_rn(t.y, c3));
+                m.z = __fadd_rn(m.z, __fmul_rn(t.z, c3)); m.w = __fadd_rn(m.w, __fmul_rn(t.w, c3));
+            }
+            *reinterpret_cast<float4*>(out + o) = m;
+            if (fabsf(m.x) < 3.0e38f) mx.x = fmaxf(mx.x, fabsf(m.x));
+            if (fabsf(m.y) < 3.0e38f) mx.y = fmaxf(mx.y, fabsf(m.y));
+            if (fabsf(m.z) < 3.0e38f) mx.z = fmaxf(mx.z, fabsf(m.z));
+            if (fabsf(m.w) < 3.0e38f) mx.w = fmaxf(mx.w, fabsf(m.w));
+        }
+    }
+    if (colmax == nullptr) return;                         // (kernel-uniform)
+    sm[w][lane] = mx;
+    __syncthreads();
+    if (w == 0 && c4 < cols4) {
+#pragma unroll
+        for (int g = 1; g < 4; ++g) {
+            const float4 o = sm[g][lane];
+            mx.x = fmaxf(mx.x, o.x); mx.y = fmaxf(mx.y, o.y); mx.z = fmaxf(mx.z, o.z); mx.w = fmaxf(mx.w, o.w);
+        }
+        unsigned* dst = colmax + c4 * 4;
+        if (mx.x > 0.f) atomicMax(dst + 0, __float_as_uint(mx.x));
+        if (mx.y > 0.f) atomicMax(dst + 1, __float_as_uint(mx.y));
+        if (mx.z > 0.f) atomicMax(dst + 2, __float_as_uint(mx.z));
+        if (mx.w > 0.f) atomicMax(dst + 3, __float_as_uint(mx.w));
+    }
+}
+
+// k_col_scales' scales from such maxima: cs[v] = 2^-e, cs[V + v] = 2^e.
+__global__ void __launch_bounds__(256) k_scales_from_max(const unsigned* __restrict__ colmax, long long V,
+                                                         float* __restrict__ cs) {
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= V) return;
+    const float mx = __uint_as_float(colmax[c]);
+    int e = 0;
+    if (mx > 0.f) frexpf(mx, &e);
+    e = max(-120, min(120, e));
+    cs[c] = ldexpf(1.f, -e);
+    cs[V + c] = ldexpf(1.f, e);
 }
 
 // Tiled fp16 hi/lo image of Y[rows] (K = padded row count, -1 rows -> 0): thread = (column, 8-row group).
@@ -861,9 +958,41 @@ extern "C" int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64
     LC_REQUIRE(d_y && d_cscale, LC_E_BADARG, "lc_col_scales_f16: null pointer");     // d_flag may be NULL: scales only
     LC_REQUIRE(T > 0 && V > 0 && ldy >= V, LC_E_SHAPE, "lc_col_scales_f16: bad shape");
     lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
-    hipLaunchKernelGGL(k_col_scales, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, 8), 0,
+    hipLaunchKernelGGL(k_col_scales, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, CS_RG), 0,
                        lc::as_stream(stream), d_y, (long long)ldy, (int)T, (long long)V, d_cscale, d_flag);
     return lc::launched("k_col_scales");
+}
+
+extern "C" int lc_combine_terms_colmax_f32(const float* const* h_terms, const float* h_coef, int terms, float* d_out,
+                                          int64_t ld, int64_t rows, int64_t cols, uint32_t* d_colmax, lc_stream_t stream) {
+    LC_REQUIRE(h_terms && h_coef && d_out && terms >= 1 && terms <= 4, LC_E_BADARG,
+               "lc_combine_terms_colmax_f32: need 1..4 terms");
+    LC_REQUIRE(rows >= 0 && rows < (1ll << 31) && cols >= 0 && cols % 4 == 0 && ld >= cols && ld % 4 == 0, LC_E_SHAPE,
+               "lc_combine_terms_colmax_f32: need cols %% 4 == 0, ld %% 4 == 0, ld >= cols");
+    LC_REQUIRE((reinterpret_cast<uintptr_t>(d_out) & 15) == 0, LC_E_BADARG, "lc_combine_terms_colmax_f32: d_out not 16-byte aligned");
+    for (int j = 0; j < terms; ++j)
+        LC_REQUIRE(h_terms[j] && (reinterpret_cast<uintptr_t>(h_terms[j]) & 15) == 0, LC_E_BADARG,
+                   "lc_combine_terms_colmax_f32: null or misaligned term");
+    if (rows == 0 || cols == 0) return LC_OK;
+    const float* t[4] = {h_terms[0], terms > 1 ? h_terms[1] : nullptr, terms > 2 ? h_terms[2] : nullptr,
+                         terms > 3 ? h_terms[3] : nullptr};
+    const float c[4] = {h_coef[0], terms > 1 ? h_coef[1] : 0.f, terms > 2 ? h_coef[2] : 0.f, terms > 3 ? h_coef[3] : 0.f};
+    const long long cols4 = cols / 4;
+    const long long gy = lc::ceil_div<long long>(rows, CC_ROWS);
+    LC_REQUIRE(gy <= 65535, LC_E_SHAPE, "lc_combine_terms_colmax_f32: too many rows");
+    dim3 grid((unsigned)lc::ceil_div<long long>(cols4, 64), (unsigned)gy);
+    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_combine_colmax, grid, dim3(256), 0, lc::as_stream(stream), t[0], t[1], t[2], t[3], c[0], c[1],
+                       c[2], c[3], terms, d_out, (long long)ld, (int)rows, cols4, d_colmax);
+    return lc::launched("k_combine_colmax");
+}
+
+extern "C" int lc_col_scales_from_max(const uint32_t* d_colmax, int64_t V, float* d_cscale, lc_stream_t stream) {
+    LC_REQUIRE(d_colmax && d_cscale, LC_E_BADARG, "lc_col_scales_from_max: null pointer");
+    LC_REQUIRE(V > 0, LC_E_SHAPE, "lc_col_scales_from_max: bad shape");
+    hipLaunchKernelGGL(k_scales_from_max, dim3((unsigned)lc::ceil_div<long long>(V, 256)), dim3(256), 0,
+                       lc::as_stream(stream), d_colmax, (long long)V, d_cscale);
+    return lc::launched("k_scales_from_max");
 }
 
 extern "C" int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_rows, int K,

@@ -182,57 +182,6 @@ struct FoldRows {
     int n_val[64];
 };
 
-__global__ void __launch_bounds__(64 * CM_RG) k_val_stats(const float* __restrict__ y, long long ldy, long long V,
-                                                          const int* __restrict__ va, int M, FoldRows fr,
-                                                          float* __restrict__ ystat, float* __restrict__ yblk,
-                                                          float* __restrict__ yv) {
-    __shared__ double sm[CM_RG][64];
-    const int fold = blockIdx.y, n_val = fr.n_val[fold];
-    va += (long long)fold * M;
-    ystat += (long long)fold * 3 * V;
-    yblk += (long long)fold * (M / LC_MB) * V;
-    yv += (long long)fold * M * V;
-    // row group = wave (blockDim = (64, CM_RG)): a scalar, so that the row indices va[i] are scalar loads and
-    // the strided target loads of consecutive trips can be in flight together
-    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
-    const bool live = c < V;
-    double s = 0.0;
-    if (live)
-        for (int i = ty; i < n_val; i += CM_RG) s += (double)y[(long long)va[i] * ldy + c];
-    const double mean = block_colsum<CM_RG>(s, sm) / (double)n_val;
-    const float meanf = (float)mean;
-    double q = 0.0;
-    if (live)
-        for (int i = ty; i < n_val; i += CM_RG) {
-            const double d = (double)y[(long long)va[i] * ldy + c] - mean;
-            q += d * d;
-        }
-    const double m2 = block_colsum<CM_RG>(q, sm);
-    if (live && ty == 0) {
-        const double var = m2 / (double)(n_val - 1);
-        ystat[c] = meanf;
-        ystat[V + c] = (float)sqrt(var);
-        ystat[2 * V + c] = (float)var;
-    }
-    if (live)
-        for (int b = ty; b < M / LC_MB; b += CM_RG) {
-            float t = 0.f;
-            for (int i4 = b * LC_MB; i4 < (b + 1) * LC_MB; i4 += 4) {
-                float4 quad;                                 // row-quad interleaved layout, see lc_epilogue.h
-                float* qv = reinterpret_cast<float*>(&quad);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = i4 + j;
-                    qv[j] = i < n_val ? y[(long long)va[i] * ldy + c] : 0.f;   // zero padding rows
-                    if (i < n_val) t += qv[j] - meanf;
-                }
-                reinterpret_cast<float4*>(yv)[(long long)(i4 >> 2) * V + c] = quad;
-            }
-            yblk[(long long)b * V + c] = t;
-        }
-}
-
 // ------------------------------------------------------------------ Pearson r per column
 constexpr int PR_RG = 16;
 
@@ -594,8 +543,8 @@ extern "C" int lc_col_normalize_f32(float* d_x, int64_t ld, int64_t n_rows, int6
 namespace {
 // The same statistics with the validation rows held in registers: one pass over Y instead of three.  A wave owns
 // whole 32-row blocks (b = ty, ty + CM_RG, ...; at most NBLK of them), so the values it loaded are the ones whose
-// block sums and row-quad copies it writes.  The float arithmetic per element is that of k_val_stats; only the order
-// of the fp64 sums behind mean and variance differs (by rounding of the last bit of a double).
+// block sums and row-quad copies it writes.  The fp64 sums behind mean and variance run over a wave's own rows first, then
+// over the waves of the block.
 template <int NBLK>
 __global__ void __launch_bounds__(64 * CM_RG) k_val_stats_regs(const float* __restrict__ y, long long ldy, long long V,
                                                                const int* __restrict__ va, int M, FoldRows fr,
@@ -667,6 +616,86 @@ __global__ void __launch_bounds__(64 * CM_RG) k_val_stats_regs(const float* __re
             }
         }
 }
+
+// More than 512 validation rows (the LeBel-style pipeline: 1 844 per inner fold): the same statistics in two passes of
+// register-sized chunks (CM_RG x NBLK 32-row blocks = 512 rows per trip, 64 independent loads per thread in flight) --
+// pass 1 the mean, pass 2 the variance about it, the block sums and the row-quad copies.  (Rounds 1-3 walked the rows three times with one load in flight per thread: 0.8 TB/s of the 2.95 GB x 2 per fit there.)
+template <int NBLK>
+__global__ void __launch_bounds__(64 * CM_RG) k_val_stats_chunks(const float* __restrict__ y, long long ldy, long long V,
+                                                                 const int* __restrict__ va, int M, FoldRows fr,
+                                                                 float* __restrict__ ystat, float* __restrict__ yblk,
+                                                                 float* __restrict__ yv) {
+    __shared__ double sm[CM_RG][64];
+    const int fold = blockIdx.y, n_val = fr.n_val[fold];
+    va += (long long)fold * M;
+    ystat += (long long)fold * 3 * V;
+    yblk += (long long)fold * (M / LC_MB) * V;
+    yv += (long long)fold * M * V;
+    const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = c < V;
+    const int nblocks = M / LC_MB;
+    float cache[NBLK][LC_MB];
+    double s = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += CM_RG * NBLK) {
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k) {
+            const int b = b0 + ty + k * CM_RG;
+#pragma unroll
+            for (int r = 0; r < LC_MB; ++r) {
+                const int i = b * LC_MB + r;
+                cache[k][r] = (live && b < nblocks && i < n_val) ? y[(long long)va[i] * ldy + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k)
+#pragma unroll
+            for (int r = 0; r < LC_MB; ++r) s += (double)cache[k][r];      // padding entries are exact zeros
+    }
+    const double mean = block_colsum<CM_RG>(s, sm) / (double)n_val;
+    const float meanf = (float)mean;
+    double q = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += CM_RG * NBLK) {
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k) {
+            const int b = b0 + ty + k * CM_RG;
+#pragma unroll
+            for (int r = 0; r < LC_MB; ++r) {
+                const int i = b * LC_MB + r;
+                cache[k][r] = (live && b < nblocks && i < n_val) ? y[(long long)va[i] * ldy + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k) {
+            const int b = b0 + ty + k * CM_RG;
+            if (b >= nblocks) continue;
+            float t = 0.f;
+#pragma unroll
+            for (int r4 = 0; r4 < LC_MB; r4 += 4) {
+                float4 quad;                                 // row-quad interleaved layout, see lc_epilogue.h
+                float* qv = reinterpret_cast<float*>(&quad);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    qv[j] = cache[k][r4 + j];
+                    if (b * LC_MB + r4 + j < n_val) {
+                        const double d = (double)qv[j] - mean;
+                        q += d * d;
+                        t += qv[j] - meanf;
+                    }
+                }
+                if (live) reinterpret_cast<float4*>(yv)[(long long)((b * LC_MB + r4) >> 2) * V + c] = quad;
+            }
+            if (live) yblk[(long long)b * V + c] = t;
+        }
+    }
+    const double m2 = block_colsum<CM_RG>(q, sm);
+    if (live && ty == 0) {
+        const double var = m2 / (double)(n_val - 1);
+        ystat[c] = meanf;
+        ystat[V + c] = (float)sqrt(var);
+        ystat[2 * V + c] = (float)var;
+    }
+}
 }  // namespace
 
 extern "C" int lc_val_stats_folds(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int F, int M,
@@ -686,9 +715,9 @@ extern "C" int lc_val_stats_folds(const float* d_y, int64_t ldy, int64_t V, cons
     if (M / LC_MB <= 2 * CM_RG)                              // up to 512 validation rows: held in registers, one pass
         hipLaunchKernelGGL(k_val_stats_regs<2>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V, d_va,
                            M, fr, d_ystat, d_yblk, d_yv);
-    else
-        hipLaunchKernelGGL(k_val_stats, grid, block, 0, lc::as_stream(stream), d_y, ldy, V, d_va, M, fr, d_ystat, d_yblk,
-                           d_yv);
+    else                                                     // any number: two passes of register-sized chunks
+        hipLaunchKernelGGL(k_val_stats_chunks<2>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V,
+                           d_va, M, fr, d_ystat, d_yblk, d_yv);
     return lc::launched("k_val_stats");
 }
 

@@ -19,6 +19,10 @@
 #include <fstream>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <cstdio>
+#include <cstdint>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -153,7 +157,7 @@ struct lc_upload {
     std::string error;
     bool failed = false;
     std::thread coordinator;
-    cpu_set_t cpus;                         // CPUs of the caller's NUMA node (n_cpus > 0: the staging threads stay on it)
+    cpu_set_t cpus;                         // CPUs of the source arrays' NUMA node (n_cpus > 0: the staging threads stay on it)
     int n_cpus = 0;
 
     explicit lc_upload(int n_slots) : slots(n_slots) { CPU_ZERO(&cpus); }
@@ -266,15 +270,45 @@ void worker(lc_upload* u) {
     }
 }
 
-// The CPUs of the NUMA node the calling thread runs on (/sys/devices/system/node/node<k>/cpulist), into u->cpus.
-// The caller's arrays were, as a rule, first touched by that thread, so their pages live on its node; staging threads
-// scheduled on the other socket read them across the socket link and the upload takes 1.5-2x as long, with stalls of
-// tens of ms (measured on the 2-socket EPYC 9575F box: z-scored 6 GB 62-71 ms bound to one node, 93-148 ms unbound,
-// profiles/r04_upload_probe_numa.txt).  Any failure leaves the threads unbound.
-void caller_node_cpus(lc_upload* u) {
+// The NUMA node most of the jobs' source pages live on (move_pages with a NULL node list only reports), -1 = unknown.
+int source_node(const lc_upload* u) {
+    std::vector<void*> pages;
+    const long page = sysconf(_SC_PAGESIZE);
+    if (page <= 0) return -1;
+    const size_t per_job = u->jobs.size() >= 32 ? 2 : 64 / (u->jobs.size() ? u->jobs.size() : 1);
+    for (const lc_upload_job& b : u->jobs) {
+        if (b.rows <= 0) continue;
+        const size_t es = b.dtype == LC_F64 ? 8 : 4;
+        for (size_t k = 0; k < per_job && pages.size() < 128; ++k) {
+            const int64_t r = (int64_t)((2 * k + 1) * (size_t)b.rows / (2 * per_job));
+            const uintptr_t a = reinterpret_cast<uintptr_t>(b.src) + (uintptr_t)((r * b.ld_src + b.c0) * (int64_t)es);
+            pages.push_back(reinterpret_cast<void*>(a / (uintptr_t)page * (uintptr_t)page));
+        }
+    }
+    if (pages.empty()) return -1;
+    std::vector<int> status(pages.size(), -1);
+    if (syscall(SYS_move_pages, 0, (unsigned long)pages.size(), pages.data(), nullptr, status.data(), 0) != 0) return -1;
+    int votes[64] = {0};
+    for (int st : status)
+        if (st >= 0 && st < 64) ++votes[st];
+    int best = -1;
+    for (int n = 0; n < 64; ++n)
+        if (votes[n] > 0 && (best < 0 || votes[n] > votes[best])) best = n;
+    return best;
+}
+
+// The CPUs of ONE NUMA node (/sys/devices/system/node/node<k>/cpulist) into u->cpus: the node the jobs' source arrays
+// live on -- asked of the kernel page by page -- or, when that cannot be told, the node the calling thread runs on (its
+// arrays were, as a rule, first touched there).  Staging threads scheduled on the other socket read the arrays across
+// the socket link and the upload takes 1.5-2x as long, with stalls of tens of ms (measured on the 2-socket EPYC 9575F box:
+// z-scored 6 GB 62-71 ms bound to the data's node, 93-148 ms unbound, profiles/r04_upload_probe_numa.txt; bound to
+// the CALLER's node a fit was 40 ms slower whenever the scheduler had moved the Python thread to the other socket
+// since it filled its arrays).  Any failure leaves the threads unbound.
+void source_node_cpus(lc_upload* u) {
     if (getenv("LITCODER_AMD_UPLOAD_NO_AFFINITY")) return;
+    const int want = source_node(u);
     const int cpu = sched_getcpu();
-    if (cpu < 0) return;
+    if (want < 0 && cpu < 0) return;
     for (int node = 0; node < 64; ++node) {
         std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
         if (!f) break;
@@ -298,7 +332,7 @@ void caller_node_cpus(lc_upload* u) {
             }
             i = e + 1;
         }
-        if (mine) {
+        if (want >= 0 ? node == want : mine) {
             // only CPUs this process may use at all
             cpu_set_t allowed;
             if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
@@ -309,6 +343,9 @@ void caller_node_cpus(lc_upload* u) {
                 u->cpus = set;
                 u->n_cpus = n;
             }
+            if (getenv("LITCODER_AMD_UPLOAD_DIAG_NODE"))
+                fprintf(stderr, "lc_upload: source node %d, caller cpu %d, staging threads on node %d (%d cpus)\n", want, cpu,
+                        node, n);
             return;
         }
     }
@@ -424,7 +461,7 @@ extern "C" int lc_upload_start_staged(const lc_upload_job* jobs, int n_jobs, voi
         delete u;
         return rc;
     }
-    caller_node_cpus(u);                                 // (on the CALLER's thread: its node is the one that counts)
+    source_node_cpus(u);
     u->coordinator = std::thread(coordinate, u);
     *out = u;
     return LC_OK;

@@ -386,7 +386,11 @@ class PrimalForm:
         for f in range(F):
             b = f if two_pass else 0
             ops.val_stats(Y, Vp_, va[f], M, n_v[f], ystat[b], yblk[b], yv[b])
-            if by_blocks:
+            csB = None
+            if by_blocks and split:
+                # B_f and its fp16 column scales in one pass (the maxima are taken while the sum is written)
+                _, csB = ops.combine_colmax([Bv[q] for q in range(F) if q != f], [1.0] * (F - 1), B, Vt, want_scales_for=Vp_)
+            elif by_blocks:
                 ops.combine_many([Bv[q] for q in range(F) if q != f], [1.0] * (F - 1), B)
             else:
                 Ni = ops.pad_to(n_i[f], 2 * K_TILE)                               # contraction depth, padded rows are -1
@@ -399,7 +403,8 @@ class PrimalForm:
                     ops.gemm_grouped_f16x3(At, rs_a, PP, Yt, cs_inv, B, Vt, Vt, Ni, [0, Vt // 256], bview=views[f])
                     self.info["plain_flops"] += 2.0 * self.p * n_i[f] * V_
                     self.info["plain_launches"] += 1
-                csB, _ = ops.col_scales_f16(B, self.p, Vp_, want_flag=False)
+                if csB is None:
+                    csB, _ = ops.col_scales_f16(B, self.p, Vp_, want_flag=False)
                 Bt, csBs[b] = Bts[b], csB
                 ops.split_cols_f16(B, Vp_, ident, PP, csB, Bt)
                 if moments:
@@ -430,7 +435,11 @@ class PrimalForm:
                 scores[a].copy_(scores_d[i])
         if by_blocks:
             # the outer block's product = the sum of all its validation blocks': the refit's operand (_primal_refit_inputs)
-            hat["B_all"] = ops.combine_many([Bv[q] for q in range(F)], [1.0] * F, B)
+            if split:
+                hat["B_all"], hat["csB_all"] = ops.combine_colmax([Bv[q] for q in range(F)], [1.0] * F, B, Vt,
+                                                                  want_scales_for=Vp_)
+            else:
+                hat["B_all"] = ops.combine_many([Bv[q] for q in range(F)], [1.0] * F, B)
         self.sweeps_done = torch.cuda.Event()
         self.sweeps_done.record()
         return scores
@@ -448,7 +457,9 @@ class PrimalForm:
         if B_all is not None:
             # the inner CV of this step left  B_o = Rstim'Rresp  of the outer block (the sum of its validation blocks')
             ext[:PP].copy_(B_all)
-            csB = ops.col_scales_f16(ext, self.p, self.Vp, want_flag=False)[0] if st["split"] else None
+            csB = st["hat"].get("csB_all") if st["split"] else None          # (taken while B_all was written)
+            if st["split"] and csB is None:
+                csB = ops.col_scales_f16(ext, self.p, self.Vp, want_flag=False)[0]
         elif st["split"]:
             At = torch.empty(ops.pad_to(PP, 256) * st["Nmax"] * 2, dtype=torch.float16, device=self.dev)
             rs_a = torch.empty(ops.pad_to(PP, 256), dtype=torch.float32, device=self.dev)

@@ -265,7 +265,7 @@ _UPLOAD_LOCK = threading.Lock()     # the ring is the process's: one upload job 
 
 
 _UPLOAD_THREADS_ZS = 24             # staging threads of such an upload (capped at half the cores; measured: 24 on the
-                                    # caller's NUMA node beat 48 and 96, profiles/r04_upload_probe*.txt)
+                                    # data's NUMA node beat 48 and 96, profiles/r04_upload_probe*.txt)
 _UPLOAD_DEPTH_ZS = 32               # ... of an upload that z-scores stories on the way (three passes per chunk on the host:
                                     # more threads in flight to keep the link busy)
 
@@ -836,6 +836,32 @@ def combine_many(terms, coef, out):
         _lib.call(name, ptrs, (ctype * n)(*cs), n, _p(out), out.numel(), _s())
         first = False
     return out
+
+
+def combine_colmax(terms, coef, out, cols, want_scales_for=None):
+    """out = sum_j coef[j] * terms[j] over (rows, ld) float32 matrices (contiguous, ld = out.stride(0)), any number of
+    terms, left to right as ``combine_many``; with ``want_scales_for`` = V also the fp16 column scales of the result
+    (``col_scales_f16``'s, (2 V,) float32) from the column maxima the last pass takes while it writes."""
+    terms, coef = list(terms), [float(c) for c in coef]
+    rows, ld = out.shape[0], out.stride(0)
+    colmax = zeros(cols, torch.int32, out.device) if want_scales_for else None
+    first = True
+    while terms:
+        take = 4 if first else 3
+        ts, cs = terms[:take], coef[:take]
+        terms, coef = terms[take:], coef[take:]
+        if not first:
+            ts, cs = [out] + ts, [1.0] + cs
+        n = len(ts)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        _lib.call("lc_combine_terms_colmax_f32", ptrs, (ctypes.c_float * n)(*cs), n, _p(out), ld, rows, cols,
+                  _p(colmax) if not terms else None, _s())
+        first = False
+    if not want_scales_for:
+        return out, None
+    cs_out = torch.empty(2 * want_scales_for, dtype=torch.float32, device=out.device)
+    _lib.call("lc_col_scales_from_max", _p(colmax), want_scales_for, _p(cs_out), _s())
+    return out, cs_out
 
 
 def gather_sub_f32(k, rows, cols, F, R, C, scale, out):

@@ -801,6 +801,76 @@ def test_block_product_kernels_against_numpy(lc):
         np.testing.assert_allclose(r_d.cpu().numpy(), r_want, atol=1e-9, equal_nan=True)
 
 
+def test_operand_preparation_kernels_against_numpy(lc):
+    """The HBM-bound passes around the V-wide contractions, kernel by kernel: validation statistics (lc_val_stats: both the
+    register route up to 512 rows and the chunked one above; mean / unbiased std / var as ridge_regression.py:108,111 takes
+    them, the 32-row block sums of fl32(y - mean), the row-quad copy), the column scales (lc_col_scales_f16: max over the
+    FINITE entries, the outlier flag) and the fused sum + column maxima (lc_combine_terms_colmax_f32 +
+    lc_col_scales_from_max == combine, then lc_col_scales_f16, bit for bit)."""
+    from litcoder_core_amd import ops
+    from litcoder_core_amd._lib import LC_MB
+    dev = ops.device(0)
+    rng = np.random.default_rng(404)
+    T, V = 2500, 333
+    Vp = ops.pad_to(V, 256)
+    Y = (rng.standard_normal((T, V)) * rng.uniform(0.1, 30.0, V) + rng.uniform(-5, 5, V)).astype(np.float32)
+    Y[:, 7] = 1.25                                                           # constant voxel
+    dY = ops.upload_f32(Y, Vp, dev)
+    for n_val in (37, 480, 512, 513, 1844, 2500):
+        M = ops.pad_to(n_val, 2 * LC_MB)
+        va = rng.permutation(T)[:n_val]
+        ystat = torch.full((3, Vp), 9.0, dtype=torch.float32, device=dev)
+        yblk = torch.full((M // LC_MB, Vp), 9.0, dtype=torch.float32, device=dev)
+        yv = torch.full((M, Vp), 9.0, dtype=torch.float32, device=dev)
+        ops.val_stats(dY, Vp, ops.idx_tensor(va, M, dev), M, n_val, ystat, yblk, yv)
+        Yv = Y[va].astype(np.float64)
+        st = ystat.cpu().numpy()[:, :V]
+        np.testing.assert_allclose(st[0], Yv.mean(0), rtol=1e-6, atol=1e-7, err_msg=str(n_val))
+        np.testing.assert_allclose(st[1], Yv.std(0, ddof=1), rtol=1e-6, atol=1e-12, err_msg=str(n_val))
+        np.testing.assert_allclose(st[2], Yv.var(0, ddof=1), rtol=2e-6, atol=1e-12, err_msg=str(n_val))
+        assert st[1][7] == 0 and st[2][7] == 0
+        quads = yv.cpu().numpy().reshape(M // 4, Vp, 4)                      # row-quad interleaved: [i / 4][column][i % 4]
+        rows = np.zeros((M, V), dtype=np.float32)
+        rows[:n_val] = Y[va]
+        assert np.array_equal(quads[:, :V].transpose(0, 2, 1).reshape(M, V), rows), n_val
+        cen = (rows - st[0][None, :]).astype(np.float32)
+        cen[n_val:] = 0
+        want_blk = np.zeros((M // LC_MB, V), dtype=np.float32)
+        for i in range(M):                                                   # sequential fp32 adds inside a block
+            want_blk[i // LC_MB] = want_blk[i // LC_MB] + cen[i]
+        assert np.array_equal(yblk.cpu().numpy()[:, :V], want_blk), n_val
+    # column scales
+    B = [(rng.standard_normal((300, Vp)) * rng.uniform(1e-6, 1e6, Vp)).astype(np.float32) for _ in range(5)]
+    for b in B:
+        b[:, V:] = 0
+    B[1][5, 11], B[2][17, 12], B[3][40, 13] = np.inf, np.nan, -np.inf
+    B[0][:, 14] = 0
+    dB = [ops.upload_f32(b, Vp, dev) for b in B]
+    for n in (1, 2, 4, 5):
+        coef = [1.0, -1.0, 1.0, 0.5, 1.0][:n]
+        out = torch.empty((300, Vp), dtype=torch.float32, device=dev)
+        ref = torch.empty((300, Vp), dtype=torch.float32, device=dev)
+        _, cs = ops.combine_colmax(dB[:n], coef, out, Vp, want_scales_for=V)
+        ops.combine_many(dB[:n], coef, ref)
+        assert torch.equal(torch.nan_to_num(out, 1.0, 2.0, 3.0), torch.nan_to_num(ref, 1.0, 2.0, 3.0)), n
+        cs_ref, flag = ops.col_scales_f16(ref, 300, V, want_flag=True)
+        assert torch.equal(cs, cs_ref), n
+        assert int(flag.cpu()) == 0
+        with np.errstate(invalid="ignore"):
+            want = B[0] * np.float32(coef[0])                                # fl32 products and sums, left to right
+            for b, c in zip(B[1:n], coef[1:]):
+                want = want + b * np.float32(c)
+        assert want.dtype == np.float32
+        fin = np.where(np.isfinite(want), np.abs(want), 0).max(0)[:V]
+        e = np.where(fin > 0, np.frexp(fin)[1], 0)
+        np.testing.assert_array_equal(cs.cpu().numpy()[:V], np.ldexp(np.float32(1), -e).astype(np.float32))
+        np.testing.assert_array_equal(cs.cpu().numpy()[V:], np.ldexp(np.float32(1), e).astype(np.float32))
+    spike = np.ones((300, V), dtype=np.float32)
+    spike[3, 20] = 1e6                                                       # most entries 2^9 below the maximum -> flag
+    _, flag = ops.col_scales_f16(ops.upload_f32(spike, Vp, dev), 300, V, want_flag=True)
+    assert int(flag.cpu()) == 1
+
+
 def test_fit_nested_cv_alias(lc):
     rng = np.random.default_rng(6)
     X = rng.standard_normal((150, 24))

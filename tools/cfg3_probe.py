@@ -71,6 +71,23 @@ def main():
           f"brain float64 on the host: {sum(b.nbytes for b in brain.values()) / 1e9:.2f} GB; made in {time.perf_counter() - t0:.1f} s",
           flush=True)
 
+    if os.environ.get("LITCODER_PROBE_MIGRATE"):
+        # the scheduler's worst case, forced: the caller's thread moves to the OTHER socket after it filled its arrays
+        def cpus(node):
+            out = set()
+            for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                out |= set(range(int(lo), int(hi or lo) + 1))
+            return out
+        import ctypes
+        here = 0 if ctypes.CDLL(None).sched_getcpu() in cpus(0) else 1
+        try:
+            os.sched_setaffinity(0, cpus(1 - here) & os.sched_getaffinity(0))
+            print(f"caller moved from node {here} to node {1 - here}", flush=True)
+        except (OSError, ValueError) as e:
+            print(f"could not move the caller: {e}", flush=True)
+        only = [k for k in only if k != "migrate"]
+
     def want(k):
         return not only or k in only
 

@@ -2,7 +2,7 @@
 """Per-queue view of a rocprofv3 --kernel-trace CSV: the LAST fit of the trace (from the last k_gram / first kernel after the
 longest idle gap on), for the queue that runs the MFMA sweeps: every kernel with start, duration and the idle time
 before it, consecutive launches of one kernel merged; then the kernel-time totals of the other queues in that window.
-    python tools/queue_timeline.py <kernel_trace.csv> [min_us_to_list]"""
+    python tools/queue_timeline.py <kernel_trace.csv> [min_us_to_list] [all]      (all: list the other queues the same way)"""
 import collections
 import csv
 import re
@@ -31,22 +31,30 @@ fit = rows[i0:]
 t0 = fit[0][0]
 sweep_q = collections.Counter(r[3] for r in fit if r[2].startswith("k_sweep")).most_common(1)[0][0]
 print(f"last fit: {(max(r[1] for r in fit) - t0) / 1e6:.2f} ms, {len(fit)} kernels; main queue = {sweep_q}")
-main = [r for r in fit if r[3] == sweep_q]
-prev_end, run = None, None
-out = []
-for s, e, n, q in main:
-    gap = 0 if prev_end is None else max(0, s - prev_end)
-    if run is not None and run[2] == n and gap < 5_000:
-        run[1] = e; run[3] += 1; run[4] += e - s
-    else:
-        if run is not None:
-            out.append(run)
-        run = [s, e, n, 1, e - s, gap]
-    prev_end = max(prev_end or e, e)
-out.append(run)
-for s, e, n, c, busy, gap in out:
-    if busy / 1e3 >= min_us or gap / 1e3 >= 50:
-        print(f"{(s - t0) / 1e6:9.3f} ms  {busy / 1e3:9.1f} us  x{c:<3d} gap {gap / 1e3:7.1f} us  {n}")
+
+
+def list_queue(kernels):
+    prev_end, run, out = None, None, []
+    for s, e, n, q in kernels:
+        gap = 0 if prev_end is None else max(0, s - prev_end)
+        if run is not None and run[2] == n and gap < 5_000:
+            run[1] = e; run[3] += 1; run[4] += e - s
+        else:
+            if run is not None:
+                out.append(run)
+            run = [s, e, n, 1, e - s, gap]
+        prev_end = max(prev_end or e, e)
+    out.append(run)
+    for s, e, n, c, busy, gap in out:
+        if busy / 1e3 >= min_us or gap / 1e3 >= 50:
+            print(f"{(s - t0) / 1e6:9.3f} ms  {busy / 1e3:9.1f} us  x{c:<3d} gap {gap / 1e3:7.1f} us  {n}")
+
+
+list_queue([r for r in fit if r[3] == sweep_q])
+if "all" in sys.argv[3:]:
+    for q in sorted({r[3] for r in fit} - {sweep_q}):
+        print(f"--- queue {q}")
+        list_queue([r for r in fit if r[3] == q])
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 for s, e, n, q in fit:
     tot[q][n] += (e - s) / 1e6
