@@ -36,7 +36,7 @@ class EngineCore:
         self.shard = shard or ShardContext.single()
         if not isinstance(X_all, _DeviceShapes):
             X_all = np.asarray(X_all)
-        if not isinstance(Y_all, (_DeviceShapes, ops.HostRows)):
+        if not isinstance(Y_all, (_DeviceShapes, ops.HostRows, ops.TargetsInFlight)):
             Y_all = ops.HostRows([Y_all])
         self.Ttot, self.p = X_all.shape
         self.V_rank = Y_all.shape[1]                   # voxel columns of this rank (all its ranges together)
@@ -81,8 +81,21 @@ class EngineCore:
             if self.Ttot and self.p:
                 jobs.append((X_all, self.dX, 0, self.p))
         self._x_job = 0 if jobs else None
+        self._y_job0 = 0
+        in_flight = isinstance(Y_all, ops.TargetsInFlight)
         if isinstance(Y_all, _DeviceShapes):
             self.dY_full = self._resident(Y_all, self.Vp_rank)
+        elif in_flight:
+            # the caller put the targets on the link before this engine existed (ops.TargetsInFlight): its buffer, its
+            # panels, its uploader -- the design is then resident already (no job of this engine's own)
+            if jobs or Y_all.Vp != self.Vp_rank:
+                raise ValueError("targets in flight go with a resident design and this engine's column padding")
+            self.dY_full = Y_all.buffer
+            self.upload_panels = list(Y_all.panels)
+            self.download_panels = ([(int(a), int(b)) for a, b in down_panels] if down_panels else list(self.upload_panels))
+            self._y_job0 = Y_all.n_lead
+            self.uploader = Y_all.uploader
+            panels = self.upload_panels
         else:
             self.dY_full = torch.empty((self.Ttot, self.Vp_rank), dtype=torch.float32, device=self.dev)
             ops.zero_cols(self.dY_full, self.V_rank, self.Vp_rank)
@@ -159,7 +172,7 @@ class EngineCore:
         if self.uploader is not None:
             if self._x_job is not None:
                 self.uploader.wait(self._x_job)        # the design is needed now (Gram matrix)
-            if len(jobs) == (1 if self._x_job is not None else 0):
+            if not in_flight and len(jobs) == (1 if self._x_job is not None else 0):
                 self.uploader.join()                   # resident targets: nothing arrives later
                 self.uploader = None
             elif panels is None:

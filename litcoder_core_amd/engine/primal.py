@@ -77,10 +77,10 @@ class PrimalForm:
             Xt = ops.gather_transpose_f32(X, rows_all, len(sets), Nmax, p, PP)   # (S * PP, Nmax): Rstim' of every set
             G = ops.gram_blocks(Xt, len(sets), PP, Nmax)                     # (S, PP, PP) f64
         S = F + len(g)
+        for k in range(len(g)):                        # (before the Lanczos run: the host looks at this when it queues the
+            self._check_feature_scales(G[F + k])       # fold's first V-wide phase, and must not wait for the run there)
         lmax = ops.lambda_max_strided(G, PP, PP * PP, ident, S, PP, self.steps) if self.normalpha else None
         self._check_singcutoff(lmax)
-        for k in range(len(g)):
-            self._check_feature_scales(G[F + k])
         a2 = ops.penalties(None if lmax is None else lmax[:F], F, self.d_alphas, self.normalpha)
         rhs = ops.gather_rows_f64(X, va, F, M, p, PP)                        # (F, M, PP): Pstim of every inner fold
         Ac = len(cho)

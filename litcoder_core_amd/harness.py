@@ -132,21 +132,26 @@ class StoryPipeline:
             feat[off[i]:off[i + 1]].copy_(f if torch.is_tensor(f) else _dev_f64(f, dev), non_blocking=True)
         return feat, off, n_in
 
-    def design(self, feat, off, n_in, names):
-        """The float32 design matrix [Rstim ; Pstim] (zero-padded to 32 columns) from the concatenated features: one
-        launch (lc_story_design_f32).  Returns (dX, T, Tt, p, per-story (start, stop) of the trimmed TARGET rows)."""
+    def _trimmed_rows(self, n_in, names):
+        """Per story the (first, one-past-last) feature row that survives trimming (trainer.py:231-249)."""
         g = self.trimming.get
-        nd, ndim = len(self.fir_delays), feat.shape[1]
-        p = nd * ndim
-        train, test = names[:-1], names[-1:]
         a, b = [], []
-        for i, s in enumerate(names):
-            kind = "train" if s in train else "test"
+        for i in range(len(names)):
+            kind = "train" if i < len(names) - 1 else "test"
             lo, hi, _ = slice(g(f"{kind}_features_start", 0), g(f"{kind}_features_end", None)).indices(n_in[i])
             if hi - lo < 1:
                 raise ValueError("a story is empty after trimming")
             a.append(lo)
             b.append(hi)
+        return a, b
+
+    def design(self, feat, off, n_in, names):
+        """The float32 design matrix [Rstim ; Pstim] (zero-padded to 32 columns) from the concatenated features: one
+        launch (lc_story_design_f32).  Returns (dX, T, Tt, p, per-story number of rows after trimming)."""
+        nd, ndim = len(self.fir_delays), feat.shape[1]
+        p = nd * ndim
+        train = names[:-1]
+        a, b = self._trimmed_rows(n_in, names)
         rows = np.asarray(b) - np.asarray(a)
         row0 = np.concatenate([[0], np.cumsum(rows)])[:-1]
         T, Tt = int(rows[:len(train)].sum()), int(rows[len(train):].sum())
@@ -172,8 +177,9 @@ class StoryPipeline:
         """``features``: per story the (downsampled) feature matrix, host or device; ``brain``: per story the (TRs,
         voxels) host array.  kwargs as ``NestedCVModel.fit_predict``.  Returns (metrics, float32 host weights, alphas)."""
         names = list(features.keys())
-        feat, off, n_in = self._feature_rows(features)
-        return self._fit_rows(feat, off, n_in, names, brain, model_kwargs)
+        feat, off, n_in = self._feature_rows(features)      # (small, and first on the link: everything waits for the design)
+        flying = self._start_targets(brain, names, n_in)
+        return self._fit_rows(feat, off, n_in, names, flying, model_kwargs)
 
     def fit_words(self, words, word_times, tr_times, brain, window=3, cutoff_mult=1.0, **model_kwargs):
         """From word-level features: per story ``words`` (n_words, D) float32 / float64 host arrays at ``word_times``,
@@ -182,20 +188,30 @@ class StoryPipeline:
         dev = ops.device()
         names = list(words.keys())
         blocks = [np.asarray(words[s]) for s in names]
+        n_in = [len(tr_times[s]) for s in names]
         if all(b.dtype == np.float32 for b in blocks):
+            # the word features cross the link first, the brain data right behind them through the same staging ring --
+            # the resampling, the design and the fit's set-up run while the first voxel panel is already on its way
             rows = ops.HostRows(blocks)
-            dW = ops.upload_f32(rows, rows.shape[1], dev)                # native staging threads, no cast needed
+            dW = ops.zeros(rows.shape, torch.float32, dev)
+            flying = self._start_targets(brain, names, n_in, lead=[(rows, dW, 0, rows.shape[1])])
+            flying.wait_lead()
         else:
+            flying = self._start_targets(brain, names, n_in)
             dW = torch.cat([_dev_f64(b, dev) for b in blocks], dim=0)
         feat, off = ops.lanczos_interp_stories(dW, [word_times[s] for s in names], [tr_times[s] for s in names],
                                                window, cutoff_mult, False)
-        n_in = [len(tr_times[s]) for s in names]
-        return self._fit_rows(feat, off, n_in, names, brain, model_kwargs)
+        return self._fit_rows(feat, off, n_in, names, flying, model_kwargs)
 
-    def _fit_rows(self, feat, off, n_in, names, brain, model_kwargs):
+    def _start_targets(self, brain, names, n_in, lead=()):
+        """The brain data's trimmed, z-scored story blocks on their way to the device (NestedCVModel.start_targets)."""
         if len(names) < 2:
             raise ValueError("the train/test paradigm needs at least two stories")
-        dX, T, Tt, p, rows = self.design(feat, off, n_in, names)
-        Y = self._targets(brain, names, rows)
+        a, b = self._trimmed_rows(n_in, names)
+        return self.model.start_targets(self._targets(brain, names, np.asarray(b) - np.asarray(a)), lead=lead)
+
+    def _fit_rows(self, feat, off, n_in, names, flying, model_kwargs):
+        dX, T, Tt, p, _ = self.design(feat, off, n_in, names)
         self.last_design = (dX, T, Tt, p)
-        return self.model.fit_predict_device(dX, Y, p, Y.shape[1], n_test_rows=Tt, weights_on_host=True, **model_kwargs)
+        return self.model.fit_predict_device(dX, flying, p, flying.shape[1], n_test_rows=Tt, weights_on_host=True,
+                                             **model_kwargs)

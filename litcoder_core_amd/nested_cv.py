@@ -185,14 +185,43 @@ class NestedCVModel(BasePredictivityModel):
         check_penalties(opt["alphas"], opt["singcutoff"], opt["normalpha"], opt["n_inner_folds"])
         T = features_dev.shape[0] - n_test_rows
         # (the targets may also be host row blocks -- ops.HostRows, e.g. the stories of harness.StoryPipeline, z-scored in
-        # the upload threads -- beside a resident design: they then arrive panel by panel like fit_predict's)
+        # the upload threads -- beside a resident design: they then arrive panel by panel like fit_predict's; or such
+        # blocks already on the link, start_targets)
         shapes = (_DeviceShapes(features_dev, n_features),
-                  targets_dev if isinstance(targets_dev, ops.HostRows) else _DeviceShapes(targets_dev, n_voxels_local))
+                  targets_dev if isinstance(targets_dev, (ops.HostRows, ops.TargetsInFlight))
+                  else _DeviceShapes(targets_dev, n_voxels_local))
         return self._run_on_current_stream(shapes[0], shapes[1], T, n_test_rows, n_voxels_total or n_voxels_local, opt["groups"],
                          opt["folding_type"], opt["n_outer_folds"], opt["n_inner_folds"], opt["chunk_length"],
                          opt["alphas"], opt["alpha_fdr"], opt["single_alpha"], opt["normalpha"], opt["use_corr"],
                          opt["normalize_features"], opt["normalize_targets"], weights_on_host=weights_on_host,
                          singcutoff=opt["singcutoff"])
+
+    def _panel_plan(self, V_rank, V_total):
+        """(upload panels, download panels) of host targets of ``V_rank`` columns: the column ranges they cross the link
+        in at the start of a fit, and the ranges the end of the fit works in when the weights go back to the host."""
+        shard = self.shard or ShardContext.single()
+        o = self.options or FitOptions()
+        # the same NUMBER of panels on every rank of a sharded fit (narrowest rank decides)
+        panels = [(0, V_rank)] if self.panel_cols == 0 else _column_panels(
+            V_rank, o.panel_cols if self.panel_cols is None else self.panel_cols,
+            o.panel_min_cols if self.panel_cols is None else 256, v_ref=V_total // max(shard.world, 1))
+        # the end of the fit: fewer, wider panels of geometrically falling width (explicit panel_cols: the same panels
+        # at both ends, what the tests of the panel logic ask for)
+        down_panels = None
+        if self.panel_cols is None and o.tail_panels_geometric:
+            down_panels = _download_panels(V_rank, min_cols=o.panel_min_cols, v_ref=V_total // max(shard.world, 1),
+                                           last_frac=o.tail_last_frac)
+        return panels, down_panels
+
+    def start_targets(self, targets, n_voxels_total: Optional[int] = None, lead=()):
+        """Puts host targets (a host matrix or ops.HostRows of this rank's voxel block) on the link NOW, in the panels a
+        fit of this model will work through, and returns the ops.TargetsInFlight that ``fit_predict_device`` takes in
+        place of the targets: for callers that still have the design to build (harness.StoryPipeline).  ``lead``: upload
+        jobs that go first through the same staging ring."""
+        targets = targets if isinstance(targets, ops.HostRows) else ops.HostRows([np.asarray(targets)])
+        V_rank = targets.shape[1]
+        panels, _ = self._panel_plan(V_rank, n_voxels_total or V_rank)
+        return ops.TargetsInFlight(targets, ops.device(), panels, lead=lead)
 
     def _run_on_current_stream(self, X_all, Y_all, T, n_test_rows, V_total, groups, folding_type, n_outer_folds,
                                n_inner_folds, chunk_length, alphas, alpha_fdr, single_alpha, normalpha, use_corr,
@@ -221,16 +250,9 @@ class NestedCVModel(BasePredictivityModel):
         V_rank = Y_all.shape[1]
         panels = down_panels = None
         if not isinstance(Y_all, _DeviceShapes):
-            # the same NUMBER of panels on every rank of a sharded fit (narrowest rank decides)
-            o = self.options or FitOptions()
-            panels = [(0, V_rank)] if self.panel_cols == 0 else _column_panels(
-                V_rank, o.panel_cols if self.panel_cols is None else self.panel_cols,
-                o.panel_min_cols if self.panel_cols is None else 256, v_ref=V_total // max(shard.world, 1))
-            # the end of the fit: fewer, wider panels of geometrically falling width (explicit panel_cols: the same panels
-            # at both ends, what the tests of the panel logic ask for)
-            if self.panel_cols is None and o.tail_panels_geometric:
-                down_panels = _download_panels(V_rank, min_cols=o.panel_min_cols, v_ref=V_total // max(shard.world, 1),
-                                               last_frac=o.tail_last_frac)
+            panels, down_panels = self._panel_plan(V_rank, V_total)
+            if isinstance(Y_all, ops.TargetsInFlight):
+                panels = list(Y_all.panels)             # (already crossing the link in these)
 
         def attempt(form, precision, X_in, Y_in):
             eng = RidgeCVEngine(X_in, Y_in, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,

@@ -438,6 +438,34 @@ class PanelUploader:
             pass
 
 
+class TargetsInFlight:
+    """Host targets (HostRows) on their way into their (T, pad(V)) float32 device matrix, column panel by column panel,
+    started BEFORE the engine that will fit them exists -- harness.StoryPipeline puts the brain data on the link first
+    and builds the design (Lanczos resampling, FIR delays, z-scoring: ~8 ms of host and device work) beside it, where the
+    engine's own uploader starts only when the design is there.  ``lead``: [(host rows, destination, c0, c1)] jobs that
+    cross the link FIRST through the same staging ring (the word-level features the design is built from);
+    ``wait_lead`` makes a stream wait for them.  RidgeCVEngine takes the object in place of the host targets."""
+
+    def __init__(self, host_rows, dev, panels, lead=()):
+        self.host = host_rows if isinstance(host_rows, HostRows) else HostRows([host_rows])
+        self.shape = self.host.shape
+        T, V = self.shape
+        if T < 1 or V < 1:
+            raise ValueError("targets in flight need at least one row and one column")
+        self.Vp = pad_to(V, COL_TILE)
+        self.panels = [(int(a), int(b)) for a, b in panels]
+        self.buffer = torch.empty((T, self.Vp), dtype=torch.float32, device=dev)
+        zero_cols(self.buffer, V, self.Vp)
+        zeroed = torch.cuda.Event()
+        zeroed.record()
+        self.n_lead = len(lead)
+        self.uploader = PanelUploader(list(lead) + [(self.host, self.buffer, a, b) for a, b in self.panels], dev, after=zeroed)
+
+    def wait_lead(self, stream=None):
+        for j in range(self.n_lead):
+            self.uploader.wait(j, stream)
+
+
 def upload_f32(host, ld, dev, rows_pad=None):
     """Host (rows, cols) real array -> zero-padded (rows_pad or rows, ld) f32 device buffer, ordered on the current
     stream.  float64 input is cast to float32 on the host while it is staged (PanelUploader), mirroring

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Rate of the native uploader alone (no fit): float64 host stories -> float32 device matrix, plain cast vs z-scored in the
 staging threads.  python tools/upload_probe.py [V]      (threads / sub-tile through LITCODER_AMD_UPLOAD_THREADS /
-LITCODER_AMD_ZS_TILE, one process per setting: the sub-tile width is read once)"""
+LITCODER_AMD_ZS_TILE, one process per setting: the sub-tile width is read once)
+    python tools/upload_probe.py V busy    the z-scored upload once more beside ~120 ms of MFMA work on another stream (fp16x3
+                                           sweeps of the fit's own kernel): what the fit's V-wide phases do to the copies"""
 import os
 import sys
 import time
@@ -41,3 +43,50 @@ for zs in (False, True):
         dt = time.perf_counter() - t0
         print(f"  zscore={zs}: {1e3 * dt:.1f} ms = {nbytes / dt / 1e9:.1f} GB/s of float64 read, {nbytes / 2 / dt / 1e9:.1f} GB/s on the "
               f"link; panels resident after {[round(m, 1) for m in marks]} ms", flush=True)
+
+if "busy" in sys.argv[2:]:
+    # the same upload while the chip is busy: plain fp16x3 contractions (the fit's dominant kernel) back to back on the
+    # current stream, the upload on its own stream beside them
+    Vb, M, K = 32768, 3072, 1856
+    a = torch.randn((M, K), device=dev)
+    b = torch.randn((K, Vb), device=dev)
+    At = torch.empty(ops.pad_to(M, 256) * K * 2, dtype=torch.float16, device=dev)
+    rs = torch.empty(ops.pad_to(M, 256), dtype=torch.float32, device=dev)
+    ops.split_rows_f16(a, M, K, At, rs)
+    cs, _ = ops.col_scales_f16(b, K, Vb, want_flag=False)
+    Bt = torch.empty(Vb * K * 2, dtype=torch.float16, device=dev)
+    ops.split_cols_f16(b, Vb, ops.idx_tensor(np.arange(K), K, dev), K, cs, Bt)
+    cs_inv = cs[Vb:].contiguous()
+    C = torch.empty((M, Vb), dtype=torch.float32, device=dev)
+
+    hbm = "hbm" in sys.argv[2:]          # ... or HBM-bound passes instead (sums of 0.4 GB matrices: the fit's B_f)
+    terms = [torch.randn((M, Vb), device=dev) for _ in range(4)] if hbm else None
+
+    def work(n):
+        for _ in range(n):
+            if hbm:
+                ops.combine_colmax(terms, [1.0] * 4, C, Vb)
+            else:
+                ops.gemm_grouped_f16x3(At, rs, M, Bt, cs_inv, C, Vb, Vb, K, [0, Vb // 256])
+
+    work(3); torch.cuda.synchronize()
+    t0 = time.perf_counter(); work(20); torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / 20
+    print(f"busy work: {1e3 * per:.2f} ms per launch alone (" + (f"{5 * M * Vb * 4 / per / 1e12:.2f} TB/s)" if hbm else
+                                                                f"{2.0 * M * K * Vb / per / 1e12:.0f} TF)"))
+    host = ops.HostRows(stories, zscore=True)
+    for beside in (False, True, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        up = ops.PanelUploader([(host, dY, a_, b_) for a_, b_ in panels], dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        if beside:
+            e0.record(); work(int(0.12 / per)); e1.record()
+        up.join()
+        side = torch.cuda.Stream()
+        up.wait(len(panels) - 1, side)
+        side.synchronize()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        extra = f"; the MFMA work took {e0.elapsed_time(e1):.1f} ms ({int(0.12 / per)} launches: {1e3 * per * int(0.12 / per):.1f} alone)" if beside else ""
+        print(f"  z-scored upload {'beside MFMA work' if beside else 'alone'}: all panels resident after {1e3 * dt:.1f} ms{extra}", flush=True)
