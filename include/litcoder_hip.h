@@ -496,6 +496,12 @@ int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int64_t K, voi
  * series terms): every group is padded to whole 256-row tiles in the image and in d_rowscale_inv, one launch. */
 int lc_split_rows_f16_groups(const float* d_h, int64_t ld, int groups, int64_t rows, int64_t K, void* d_tiled,
                              float* d_rowscale_inv, lc_stream_t stream);
+/* The A image of lc_alpha_sweep_scores_f16x3: per group (inner fold) the A hat matrices H_a (M x K each, stacked alpha by
+ * alpha in d_h: rows a M + i), with the 32-row blocks taken in the order (validation block, alpha) -- image block s =
+ * rows [32 (s / A), 32 (s / A) + 32) of alpha s %% A -- so that every 256-row tile of the sweep holds all alphas of the
+ * same few validation rows and its epilogue fetches those rows of the targets once, not once per alpha.  M %% 32 == 0. */
+int lc_split_rows_f16_alphas(const float* d_h, int64_t ld, int groups, int A, int64_t M, int64_t K, void* d_tiled,
+                             float* d_rowscale_inv, lc_stream_t stream);
 
 /* Per-voxel power-of-two scale from max|y| over rows 0..T-1: d_cscale[v] = 2^-e, d_cscale[V + v] = 2^e.
  * *d_flag (caller-zeroed) is OR-ed with 1 when some column is non-finite or has most of its entries more

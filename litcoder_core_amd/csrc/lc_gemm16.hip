@@ -39,16 +39,26 @@ __device__ inline int xcd_tile_id16(int bid, int nwg) {
 // One wave per row of H: exact power-of-two scale to [0.5, 1), split, scatter into the tiled layout.
 // Groups (the inner folds of an outer fold): group g = source rows [g rows, (g + 1) rows), padded to rows_pad (whole
 // 256-row tiles) in the image and in rs_inv, so that the groups' images are stacked tile-aligned.
+// il_A > 0 (the hat matrices of the fused sweep: il_A alphas x M = rows / il_A validation rows each, stacked alpha by
+// alpha in h): the image takes the 32-row blocks in the order (validation block, alpha) -- image block s = source block
+// (s / il_A) of alpha (s % il_A) -- so that a 256-row tile of the sweep holds ALL alphas of a few validation blocks and
+// its epilogue needs those few blocks of the validation targets, not eight different ones (round 4: the fused launch
+// fetched the targets once per alpha, 0.61 GB of its 2.75 GB at cfg2).
 __global__ void __launch_bounds__(256) k_split_rows_f16(const float* __restrict__ h, long long ld, int rows, int K,
                                                         uint4* __restrict__ out, float* __restrict__ rs_inv,
-                                                        int rows_pad, int groups) {
+                                                        int rows_pad, int groups, int il_A) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);          // row of the stacked, padded image
     const int lane = threadIdx.x & 63;
     if (r >= rows_pad * groups) return;
     const int KT = K / TK;
     const int g = r / rows_pad, rg = r - g * rows_pad;
     const bool live = rg < rows;
-    const float* src = h + ((long long)g * rows + rg) * ld;
+    int rsrc = rg;
+    if (il_A > 0 && live) {
+        const int s = rg >> 5, ib = s / il_A, a = s - ib * il_A;
+        rsrc = a * (rows / il_A) + ib * 32 + (rg & 31);
+    }
+    const float* src = h + ((long long)g * rows + rsrc) * ld;
     float mx = 0.f;
     if (live)
         for (int k = lane * 4; k < K; k += 256) {
@@ -285,6 +295,7 @@ struct Score16Args {
     float* part;
     long long V;           // padded voxel count of part / scores (multiple of 128)
     int M, n_val, mode, Mrows;
+    int A;                 // score mode: alphas in the image, whose 32-row blocks are ordered (validation block, alpha)
 };
 
 // Which K-tiles of the tiled B image a launch contracts: the image may hold MORE rows than the product uses (the
@@ -449,8 +460,9 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     }
     // targets of epilogue step s = 2 mi + ni (32 rows x this lane's column of panel ni)
     auto load_t = [&](int step, lc::EpiTargets& t) {
-        const int rb0 = mt * TM + wm * 128 + (step >> 1) * 32;                      // yv rows are i0 < M
-        lc::epi_load_targets(sa.yv, V, rb0 % sa.M, lh, colc[step & 1], t);
+        const int blk = mt * (TM / 32) + wm * 4 + (step >> 1);                      // image block = (validation block, alpha)
+        // (blocks past the image's last one -- the padding of its last tile -- load the last validation block: unused)
+        lc::epi_load_targets(sa.yv, V, min(blk / sa.A, (sa.M >> 5) - 1) * 32, lh, colc[step & 1], t);
     };
     lc::EpiTargets tb0, tb1, tb2;
 
@@ -737,8 +749,9 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             rs[q] = *reinterpret_cast<const lc::ep_f32x4*>(lds_rs + wm * 128 + mi * 32 + 8 * q + 4 * lh);
-        lc::epi_block_dispatch<true>(corr, acc[mi][ni], t, rs, cscv[ni], ymv[ni], rb0 % sa.M, sa.n_val, lh,
-                                     sa.part + (long long)(rb0 >> 5) * 4 * V + colc[ni], V, cok[ni]);
+        const int blk = rb0 >> 5, ib = blk / sa.A, al = blk - ib * sa.A;            // partials stay alpha-major
+        lc::epi_block_dispatch<true>(corr, acc[mi][ni], t, rs, cscv[ni], ymv[ni], ib * 32, sa.n_val, lh,
+                                     sa.part + (long long)(al * (sa.M >> 5) + ib) * 4 * V + colc[ni], V, cok[ni]);
     };
 #define EPI_FENCE() __builtin_amdgcn_sched_barrier(0)
     load_t(2, tb2); EPI_FENCE();
@@ -944,7 +957,21 @@ extern "C" int lc_split_rows_f16_groups(const float* d_h, int64_t ld, int groups
     LC_REQUIRE(rows_pad * groups < (1ll << 31), LC_E_SHAPE, "lc_split_rows_f16: too many rows");
     lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
     hipLaunchKernelGGL(k_split_rows_f16, dim3((unsigned)(rows_pad * groups / 4)), dim3(256), 0, lc::as_stream(stream), d_h,
-                       (long long)ld, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad, groups);
+                       (long long)ld, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad, groups, 0);
+    return lc::launched("k_split_rows_f16");
+}
+
+extern "C" int lc_split_rows_f16_alphas(const float* d_h, int64_t ld, int groups, int A, int64_t M, int64_t K, void* d_tiled,
+                                        float* d_rowscale_inv, lc_stream_t stream) {
+    LC_REQUIRE(d_h && d_tiled && d_rowscale_inv, LC_E_BADARG, "lc_split_rows_f16_alphas: null pointer");
+    LC_REQUIRE(groups > 0 && A > 0 && M > 0 && M % LC_MB == 0 && K > 0 && K % TK == 0 && ld % 4 == 0 && ld >= K, LC_E_SHAPE,
+               "lc_split_rows_f16_alphas: need M %% %d == 0, K %% %d == 0 and ld %% 4 == 0", LC_MB, TK);
+    const long long rows = (long long)A * M;
+    const long long rows_pad = lc::ceil_div<long long>(rows, TM) * TM;
+    LC_REQUIRE(rows_pad * groups < (1ll << 31), LC_E_SHAPE, "lc_split_rows_f16_alphas: too many rows");
+    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_split_rows_f16, dim3((unsigned)(rows_pad * groups / 4)), dim3(256), 0, lc::as_stream(stream), d_h,
+                       (long long)ld, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad, groups, A);
     return lc::launched("k_split_rows_f16");
 }
 
@@ -1059,7 +1086,7 @@ extern "C" int lc_alpha_sweep_scores_f16x3_folds(const void* d_ht, const float* 
     LC_REQUIRE((long long)F * Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: grid too large");
     fv.mt_per_fold = Mtiles;
     fv.part_stride = (long long)(Mrows / LC_MB) * 4 * V;
-    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, 0, mode, Mrows};
+    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, 0, mode, Mrows, A};
     {
         lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
         Plain16Args pa{};
@@ -1117,6 +1144,7 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
                pa.start[G], Ntiles);
     LC_REQUIRE((long long)Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_gemm_grouped_f16x3: grid too large");
     Score16Args sa{};
+    sa.A = 1;
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
     if (d_slab_light)
@@ -1160,7 +1188,7 @@ extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float*
     LC_REQUIRE((long long)F * Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_series_sweep_scores_f16x3: grid too large");
     fv.mt_per_fold = Mtiles;
     fv.part_stride = (long long)nblk * lc::EPI_SERIES_PARTS * V;
-    Score16Args sa{d_yv, d_ystat, nullptr, nullptr, d_part, (long long)V, M, 0, LC_SCORE_CORR, Mtiles * TM};
+    Score16Args sa{d_yv, d_ystat, nullptr, nullptr, d_part, (long long)V, M, 0, LC_SCORE_CORR, Mtiles * TM, 1};
     Plain16Args pa{};
     pa.rs_inv = d_rowscale_inv;
     pa.cs_inv = d_cscale_inv;
@@ -1204,7 +1232,7 @@ extern "C" int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale
     const int Mrows = A * M;
     const int Mtiles = lc::ceil_div(Mrows, TM);
     const long long Ntiles = lc::ceil_div<long long>(V, TN);
-    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val, LC_SCORE_CORR, Mrows};
+    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val, LC_SCORE_CORR, Mrows, A};
     Plain16Args pa{};
     FoldViews fv{};
     fv.mt_per_fold = Mtiles;

@@ -204,7 +204,7 @@ class DualSweeps:
                 hp = ops.pad_to(Ac * M, 256)
                 img.update(hp=hp, Ht=torch.empty(fc * hp * N * 2, dtype=torch.float16, device=self.dev),
                            rs_h=torch.empty(fc * hp, dtype=torch.float32, device=self.dev))
-                ops.split_rows_f16_groups(H.view(-1, N), fc, Ac * M, N, img["Ht"], img["rs_h"])
+                ops.split_rows_f16_alphas(H.view(-1, N), fc, Ac, M, N, img["Ht"], img["rs_h"])
             Hs.append((f0, fc, H, P))
             imgs.append(img)
         info = self._join_flags(infos)
@@ -339,7 +339,7 @@ class DualSweeps:
                             im, g = img_of[f]
                             Ht_f, rs_h_f = im["Ht"][g * im["hp"] * N * 2:], im["rs_h"][g * im["hp"]:]
                         else:
-                            ops.split_rows_f16(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ht, rs_inv)
+                            ops.split_rows_f16_alphas(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), 1, Ad, M, N, Ht, rs_inv)
                         ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, N, Yt[b], cs[Vp_:], yv[b], Vp_, n_v[f], ystat[b],
                                                      yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f])
                 else:

@@ -133,7 +133,7 @@ class PrimalForm:
                 hp = ops.pad_to(Ac * M, 256)
                 img.update(Ht=torch.empty(F * hp * PP * 2, dtype=torch.float16, device=self.dev),
                            rs_h=torch.empty(F * hp, dtype=torch.float32, device=self.dev))
-                ops.split_rows_f16_groups(H.view(-1, PP), F, Ac * M, PP, img["Ht"], img["rs_h"])
+                ops.split_rows_f16_alphas(H.view(-1, PP), F, Ac, M, PP, img["Ht"], img["rs_h"])
             img.update(tp=tp, hp=hp)
         hat = dict(F=F, N=PP, M=M, n_v=n_v, n_i=n_i, tr=None if rows_all is None else rows_all[:F], va=va, shared=None,
                    img=img, blocks_ready=blocks_ready,
@@ -377,7 +377,7 @@ class PrimalForm:
             if img is not None and "Ht" in img:
                 Ht_f, rs_h_f = img["Ht"][f * img["hp"] * PP * 2:], img["rs_h"][f * img["hp"]:]
             else:
-                ops.split_rows_f16(H[f * Ad:(f + 1) * Ad].reshape(Ad * M, PP), Ad * M, PP, Ht, rs_inv)
+                ops.split_rows_f16_alphas(H[f * Ad:(f + 1) * Ad].reshape(Ad * M, PP), 1, Ad, M, PP, Ht, rs_inv)
             self.info["fused_flops"] += 2.0 * Ad * n_v[f] * self.p * V_
             self.info["fused_launches"] += 1
             ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, PP, Bts[b], csBs[b][Vp_:], yv[b], Vp_, n_v[f], ystat[b], yblk[b],

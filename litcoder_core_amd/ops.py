@@ -926,6 +926,12 @@ def split_rows_f16(h, rows, K, tiled, rowscale_inv):
     _lib.call("lc_split_rows_f16", _p(h), h.stride(0), rows, K, _p(tiled), _p(rowscale_inv), _s())
 
 
+def split_rows_f16_alphas(h, groups, A, M, K, tiled, rowscale_inv):
+    """The A image of the fused sweep (alpha_sweep_scores_f16x3): per group A hat matrices of M rows each, 32-row blocks in
+    (validation block, alpha) order -- see lc_split_rows_f16_alphas."""
+    _lib.call("lc_split_rows_f16_alphas", _p(h), h.stride(0), groups, A, M, K, _p(tiled), _p(rowscale_inv), _s())
+
+
 def split_rows_f16_groups(h, groups, rows, K, tiled, rowscale_inv):
     """``groups`` consecutive row blocks of ``rows`` rows of h, each padded to whole 256-row tiles in the image."""
     _lib.call("lc_split_rows_f16_groups", _p(h), h.stride(0), groups, rows, K, _p(tiled), _p(rowscale_inv), _s())

@@ -77,7 +77,7 @@ if "sweep16" in what:
     rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=dev)
     Yt = torch.empty(ops.pad_to(V, 256) * N * 2, dtype=torch.float16, device=dev)
     cs, _flag = ops.col_scales_f16(Y, T, V)
-    prep = lambda: (ops.split_rows_f16(H, A * M, N, Ht, rs_inv), ops.split_cols_f16(Y, V, tr, N, cs, Yt))
+    prep = lambda: (ops.split_rows_f16_alphas(H, 1, A, M, N, Ht, rs_inv), ops.split_cols_f16(Y, V, tr, N, cs, Yt))
     print(f"f16 operand split (H rows + Y cols): {timeit(prep):.2f} ms")
     fn = lambda: ops.alpha_sweep_scores_f16x3(Ht, rs_inv, A, M, N, Yt, cs[V:], yv, V, n_v, ystat, yblk, LC_SCORE_CORR,
                                               part, scores, False)

@@ -32,7 +32,7 @@ Ht = torch.empty(rows_pad * N * 2, dtype=torch.float16, device=dev)
 rs_inv = torch.empty(rows_pad, dtype=torch.float32, device=dev)
 Yt = torch.empty(ops.pad_to(V, 256) * N * 2, dtype=torch.float16, device=dev)
 cs, _ = ops.col_scales_f16(Y, T, V)
-ops.split_rows_f16(H, A * M, N, Ht, rs_inv)
+ops.split_rows_f16_alphas(H, 1, A, M, N, Ht, rs_inv)
 ops.split_cols_f16(Y, V, tr, N, cs, Yt)
 
 B_, N_, M_ = 20, 1920, 480
