@@ -136,12 +136,13 @@ class _Range:
     them (row stride = the buffer's), so a fold can be processed full width or panel by panel -- panels while the
     targets are still arriving from the host (first fold) and while the finished weights leave for it (last fold).
     Interior boundaries are multiples of 256 columns (the widest column tile), so only the last range carries padding."""
-    __slots__ = ("c0", "V", "Vp", "Y", "W", "scales", "natural", "key")
+    __slots__ = ("c0", "V", "Vp", "Y", "W", "scales", "natural", "key", "flag_check")
 
     def __init__(self, c0, V, Vp, Y, W):
         self.c0, self.V, self.Vp, self.Y, self.W = int(c0), int(V), int(Vp), Y, W
         self.scales = None             # (cs, split) of the un-normalised targets of the range (_target_scales)
         self.natural = None            # 0 .. V-1 on the device (moments form)
+        self.flag_check = None         # (event, pinned flag) of the range's dynamic-range check, not looked at yet
         self.key = (self.c0, self.V)
 
 

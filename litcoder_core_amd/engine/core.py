@@ -321,9 +321,18 @@ class EngineCore:
                 ev = torch.cuda.Event()
                 ev.record()
             cs.record_stream(main)
-            ev.synchronize()
             main.wait_event(ev)
-            wide = bool(int(flag_h[0]))
+            if self._assume_split:
+                # the operators are prepared for the split already and a wide panel means a restart on the f32 path
+                # whenever it is noticed: the host does not wait for the panel here -- it would wait for the panel's copies
+                # AND for whatever shares the side stream's hardware queue (four queues for all streams of a process:
+                # tools/stream_queue_probe.py), with the main stream idle until it had queued the sweeps afterwards.  The
+                # flag is looked at when the range's scores are (fold_select -> _verify_target_flag).
+                rg.flag_check = (ev, flag_h)
+                wide = False
+            else:
+                ev.synchronize()
+                wide = bool(int(flag_h[0]))
         else:
             cs, flag = ops.col_scales_f16(Y, self.Ttot, rg.Vp)
             wide = False
@@ -345,6 +354,17 @@ class EngineCore:
                 self._cs_all[1, rg.c0:rg.c0 + rg.Vp].copy_(cs[rg.Vp:])
                 self._cs_known[rg.c0 // 256:(rg.c0 + rg.Vp + 255) // 256] = True
         return out
+
+    def _verify_target_flag(self, rg=None):
+        """The deferred look at a range's dynamic-range flag (_target_scales); ``rg`` None: every range of the fit."""
+        for r in ([rg] if rg is not None else list(self._ranges.values())):
+            if r.flag_check is None:
+                continue
+            ev, flag_h = r.flag_check
+            r.flag_check = None
+            ev.synchronize()
+            if int(flag_h[0]):
+                raise _WideTargets("target dynamic range too wide for the fp16x3 sweep")
 
     # -------------------------------------------------------------- S[0]^2 of every train set (Lanczos)
     def lmax_systems(self, K, row_sets):

@@ -274,6 +274,7 @@ class FoldPhases:
             self.fold_choose(st, single_alpha)
         best, split = st["best"], st["split"]
         perm, used, tiles, Vs, used_all = self._refit_groups(best, split, st.pop("grouping"))
+        self._verify_target_flag(st["rg"])             # (its event lies before the sweeps whose histogram just arrived)
         main = torch.cuda.current_stream()
         base = st.get("base", st)
         spec = base.get("spec")
