@@ -622,6 +622,20 @@ int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A
                             int64_t V, int n_val, const float* d_ystat, float* d_part,
                             unsigned long long* d_stamps, lc_stream_t stream);
 
+/* The test rows of the refit without their predictions ever reaching HBM (nested_cv.py:151-155, 251-257: pred = Pstim wt,
+ * then Pearson r per voxel; SURVEY K8 + K9): the grouped contraction of lc_gemm_grouped_f16x3 over Mrows = the test rows
+ * (d_at: per alpha group the rows  X_te (K + a^2 I)^-1 ...  of the refit operator), whose epilogue reduces the fp32
+ * predictions -- the very values lc_gemm_grouped_f16x3 would store -- per 128-row slab and column to count, means and
+ * centred sums in fp64 against the test targets  d_y[d_y_rows[i] * ldy + d_y_cols[column]]  (NULL lists: row i / the
+ * column itself; d_y_cols[j] < 0: a padding column, r = NaN); the slabs are merged by the pairwise update formulas:
+ * d_r (Ncols) f64 = Pearson r as lc_pearson_cols gives it on the stored predictions (same two-pass arithmetic per slab;
+ * agreement ~1e-15).  d_part: workspace, ceil(Mrows / 128) * 6 * Ncols doubles. */
+int lc_gemm_grouped_f16x3_pearson(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
+                                  const float* d_cscale_inv, int64_t Ncols, int64_t K,
+                                  const int32_t* h_group_tiles, int G, const float* d_y, int64_t ldy,
+                                  const int32_t* d_y_rows, const int32_t* d_y_cols, double* d_part, double* d_r,
+                                  lc_stream_t stream);
+
 /* Diagnostics only (tools/gpu_kernel_bench.py plain16): the single-group plain contraction of lc_gemm_grouped_f16x3 on
  * v_mfma_f32_16x16x32_f16 instead of 32x32x16 (an experiment kernel; not used by the product path). */
 int lc_debug_gemm_f16x3_wide(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,

@@ -147,6 +147,8 @@ SIGNATURES = {
                                         _ptr]),
     "lc_gemm_grouped_f16x3": (c_int, [_ptr, _ptr, c_int64, _ptr, _ptr, _ptr, c_int64, c_int64, c_int64,
                                       POINTER(c_int32), c_int, _ptr, c_int64, c_int64, c_int64, _ptr]),
+    "lc_gemm_grouped_f16x3_pearson": (c_int, [_ptr, _ptr, c_int64, _ptr, _ptr, c_int64, c_int64, POINTER(c_int32), c_int,
+                                              _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_select_alpha": (c_int, [_ptr, c_int, c_int64, _ptr, _ptr, _ptr]),
     "lc_group_by_alpha": (c_int, [_ptr, c_int64, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_group_by_alpha_range": (c_int, [_ptr, c_int64, c_int, c_int, c_int, _ptr, _ptr, _ptr]),

@@ -330,6 +330,15 @@ struct Plain16Args {
     int start[MAX_GROUPS16 + 1];   // first 256-column tile of each group; start[G] = number of column tiles
     const unsigned char* slab_light;   // optional, per 128-row slab (G * Mtiles * 2): nonzero = hi*hi term only
     long long col_limit;   // columns >= col_limit are not stored (ldc may then be smaller than the padded column count)
+    // PEARSON mode: the Mrows rows are predictions of the test rows; instead of being stored they are reduced, per
+    // 128-row slab and column, to (n, mean p, mean y, sum dp^2, sum dy^2, sum dp dy) in fp64 against the test targets
+    // y[pr_rows[i], pr_cols[column]] (NULL lists: i / the column itself; pr_cols[j] < 0: no such column)
+    const float* pr_y;
+    long long pr_ldy;
+    const int* pr_rows;
+    const int* pr_cols;
+    double* pr_part;       // (slabs, 6, Ncols)
+    long long pr_ncols;
 };
 
 #define MFMA16(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
@@ -348,7 +357,7 @@ struct Plain16Args {
 // and the epilogue reduces them to the blocks' partial moments (lc::epi_series_block) instead of storing them: the two
 // waves that share a column panel swap halves through the (then idle) LDS ring, so that each holds all four terms of
 // ONE 32-column block for both validation blocks.
-template <bool SCORE, bool STAMP, bool LIGHTCAP = false, bool SERMOM = false>
+template <bool SCORE, bool STAMP, bool LIGHTCAP = false, bool SERMOM = false, bool PEARSON = false>
 __global__ void __launch_bounds__(512, 2)
 k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT, int Mtiles, Score16Args sa,
               Plain16Args pa, BView bv, FoldViews fv) {
@@ -708,6 +717,89 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
             float* dstp = sa.part + (long long)(blk0 + b) * lc::EPI_SERIES_PARTS * V + colm;
             if (i0 + 32 <= sa.n_val) lc::epi_series_block<false>(T, tg[b], ym, i0, sa.n_val, lh, dstp, V, cok[wm]);
             else lc::epi_series_block<true>(T, tg[b], ym, i0, sa.n_val, lh, dstp, V, cok[wm]);
+        }
+        return;
+    }
+
+    if (PEARSON) {
+        // ---- Pearson epilogue (the test rows of the refit, nested_cv.py:151-155, 251-257): the predictions
+        // fl32(acc * row scale * column scale) -- the values the plain epilogue would store -- never leave the registers.
+        // A lane holds 64 rows of a column (two columns): it sums p - p0, y - y0 and their products in fp64 about ITS first
+        // row's values (a shift by a sample of the same column: the centred sums that follow lose two digits of sixteen at
+        // most, and a constant column gives exact zeros), turns them into (n, means, centred sums), merges with the lane
+        // that holds the other rows of the 128-row slab, and k_pearson_from_parts merges the slabs -- all by the pairwise
+        // update formulas.  One pass, no copy of the targets in registers (the accumulators leave room for little else).
+        const int colw = wn * 64 + li;
+        const int rbase = mt * TM + wm * 128;
+        if (rbase >= pa.Mrows) return;                       // a slab past the last test row: no partial of its own
+        const float* rsp = pa.rs_inv + (long long)grp * Mtiles * TM;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            __builtin_amdgcn_sched_barrier(0);
+            const long long cj = (long long)nt * TN + colw + ni * 32;
+            const int src_c = cj < pa.col_limit ? (pa.pr_cols ? pa.pr_cols[cj] : (int)cj) : -1;
+            const float csc = pa.cs_inv[cj];
+            const float* ycol = pa.pr_y + (src_c >= 0 ? src_c : 0);
+            double sa = 0.0, sb = 0.0, qa = 0.0, qb = 0.0, qab = 0.0, p0 = 0.0, y0 = 0.0;
+            int cnt = 0;
+#pragma unroll
+            for (int h8 = 0; h8 < 8; ++h8) {               // eight rows at a time (register room)
+                const int mi = h8 >> 1, rr0 = (h8 & 1) * 8;
+                float pv[8], yv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = rr0 + k;
+                    const int row = rbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pv[k] = acc[mi][ni][r] * rsp[row] * csc;
+                    const bool ok = row < pa.Mrows && src_c >= 0;
+                    const long long yr = ok ? (pa.pr_rows ? (long long)pa.pr_rows[row] : (long long)row) : -1;
+                    yv[k] = yr >= 0 ? ycol[yr * pa.pr_ldy] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = rr0 + k;
+                    const int row = rbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < pa.Mrows && src_c >= 0) {
+                        if (cnt == 0) { p0 = (double)pv[k]; y0 = (double)yv[k]; }
+                        const double da = (double)pv[k] - p0, db = (double)yv[k] - y0;
+                        sa += da; sb += db;
+                        qa += da * da; qb += db * db; qab += da * db;
+                        ++cnt;
+                    }
+                }
+            }
+            // this lane's rows: count, means, centred sums
+            double n = (double)cnt;
+            const double inv = cnt > 0 ? 1.0 / n : 0.0;
+            double ma = p0 + sa * inv, mb = y0 + sb * inv;
+            qa -= sa * sa * inv;
+            qb -= sb * sb * inv;
+            qab -= sa * sb * inv;
+            // ... merged with the lane that holds the slab's other rows of this column (lh ^ 1)
+            const double n2 = __shfl_xor(n, 32), ma2 = __shfl_xor(ma, 32), mb2 = __shfl_xor(mb, 32);
+            const double qa2 = __shfl_xor(qa, 32), qb2 = __shfl_xor(qb, 32), qab2 = __shfl_xor(qab, 32);
+            if (lh == 0 && cj < pa.pr_ncols) {
+                if (n2 > 0.0) {
+                    if (n > 0.0) {
+                        const double tot = n + n2, da = ma2 - ma, db = mb2 - mb, w = n * n2 / tot;
+                        qa += qa2 + da * da * w;
+                        qb += qb2 + db * db * w;
+                        qab += qab2 + da * db * w;
+                        ma += da * (n2 / tot);
+                        mb += db * (n2 / tot);
+                        n = tot;
+                    } else {
+                        n = n2; ma = ma2; mb = mb2; qa = qa2; qb = qb2; qab = qab2;
+                    }
+                }
+                double* dst = pa.pr_part + ((long long)(mt * 2 + wm) * 6) * pa.pr_ncols + cj;
+                dst[0] = n;
+                dst[pa.pr_ncols] = ma;
+                dst[2 * pa.pr_ncols] = mb;
+                dst[3 * pa.pr_ncols] = qa;
+                dst[4 * pa.pr_ncols] = qb;
+                dst[5 * pa.pr_ncols] = qab;
+            }
         }
         return;
     }
@@ -1154,6 +1246,89 @@ extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_i
         hipLaunchKernelGGL((k_sweep_f16x3<false, false>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
                            (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa, bv, FoldViews{});
     return lc::launched("k_sweep_f16x3<plain>");
+}
+
+namespace {
+// Pearson r per column from the slabs' partials (PEARSON epilogue): the pairwise update of means and centred sums.
+__global__ void __launch_bounds__(256) k_pearson_from_parts(const double* __restrict__ part, int slabs, long long ncols,
+                                                            double* __restrict__ r_out) {
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    double n = 0.0, ma = 0.0, mb = 0.0, qa = 0.0, qb = 0.0, qab = 0.0;
+    for (int s = 0; s < slabs; ++s) {
+        const double* p = part + (long long)s * 6 * ncols + c;
+        const double ns = p[0];
+        if (!(ns > 0.0)) continue;
+        const double mas = p[ncols], mbs = p[2 * ncols];
+        if (n == 0.0) {
+            n = ns; ma = mas; mb = mbs; qa = p[3 * ncols]; qb = p[4 * ncols]; qab = p[5 * ncols];
+        } else {
+            const double tot = n + ns, da = mas - ma, db = mbs - mb, w = n * ns / tot;
+            qa += p[3 * ncols] + da * da * w;
+            qb += p[4 * ncols] + db * db * w;
+            qab += p[5 * ncols] + da * db * w;
+            ma += da * (ns / tot);
+            mb += db * (ns / tot);
+            n = tot;
+        }
+    }
+    double r = qab / (sqrt(qa) * sqrt(qb));
+    if (r > 1.0) r = 1.0;
+    if (r < -1.0) r = -1.0;
+    r_out[c] = r;
+}
+}  // namespace
+
+extern "C" int lc_gemm_grouped_f16x3_pearson(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
+                                             const float* d_cscale_inv, int64_t Ncols, int64_t K,
+                                             const int32_t* h_group_tiles, int G, const float* d_y, int64_t ldy,
+                                             const int32_t* d_y_rows, const int32_t* d_y_cols, double* d_part, double* d_r,
+                                             lc_stream_t stream) {
+    LC_REQUIRE(d_at && d_rowscale_inv && d_bt && d_cscale_inv && h_group_tiles && d_y && d_part && d_r, LC_E_BADARG,
+               "lc_gemm_grouped_f16x3_pearson: null pointer");
+    LC_REQUIRE(G >= 1 && G <= MAX_GROUPS16, LC_E_SHAPE, "lc_gemm_grouped_f16x3_pearson: G must be in 1..%d", MAX_GROUPS16);
+    LC_REQUIRE(Mrows > 0 && K > 0 && K % (2 * TK) == 0 && Ncols > 0 && Ncols % TN == 0 && ldy > 0, LC_E_SHAPE,
+               "lc_gemm_grouped_f16x3_pearson: need K %% %d == 0, Ncols %% %d == 0", 2 * TK, TN);
+    const void* kern = reinterpret_cast<const void*>(k_sweep_f16x3<false, false, false, false, true>);
+    if (int rc = lc::ensure_dynamic_lds(kern, LDS16_BYTES)) return rc;
+    const int Mtiles = (int)lc::ceil_div<long long>(Mrows, TM);
+    const long long Ntiles = Ncols / TN;
+    BView bv;
+    if (int rc = make_bview("lc_gemm_grouped_f16x3_pearson", K, 0, 0, 0, &bv)) return rc;
+    Plain16Args pa{};
+    pa.rs_inv = d_rowscale_inv;
+    pa.cs_inv = d_cscale_inv;
+    pa.Mrows = (int)Mrows;
+    pa.G = G;
+    pa.col_limit = Ncols;
+    pa.pr_y = d_y;
+    pa.pr_ldy = ldy;
+    pa.pr_rows = d_y_rows;
+    pa.pr_cols = d_y_cols;
+    pa.pr_part = d_part;
+    pa.pr_ncols = Ncols;
+    for (int g = 0; g <= G; ++g) {
+        pa.start[g] = h_group_tiles[g];
+        LC_REQUIRE(g == 0 ? pa.start[0] == 0 : pa.start[g] >= pa.start[g - 1], LC_E_SHAPE,
+                   "lc_gemm_grouped_f16x3_pearson: group tile offsets must start at 0 and be non-decreasing");
+    }
+    LC_REQUIRE(pa.start[G] == Ntiles, LC_E_SHAPE, "lc_gemm_grouped_f16x3_pearson: last group offset %d != %lld column tiles",
+               pa.start[G], Ntiles);
+    LC_REQUIRE((long long)Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_gemm_grouped_f16x3_pearson: grid too large");
+    Score16Args sa{};
+    sa.A = 1;
+    hipStream_t s = lc::as_stream(stream);
+    {
+        lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
+        hipLaunchKernelGGL((k_sweep_f16x3<false, false, false, false, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512),
+                           LDS16_BYTES, s, (const uint4*)d_at, (const uint4*)d_bt, (int)(K / TK), Mtiles, sa, pa, bv,
+                           FoldViews{});
+    }
+    if (int rc = lc::launched("k_sweep_f16x3<pearson>")) return rc;
+    lc::ScopedTimer timer_(lc::T_PEARSON, s);
+    hipLaunchKernelGGL(k_pearson_from_parts, dim3((unsigned)lc::ceil_div<long long>(Ncols, 256)), dim3(256), 0, s, d_part,
+                       (int)lc::ceil_div<long long>(Mrows, 128), (long long)Ncols, d_r);     // (slabs that hold rows)
+    return lc::launched("k_pearson_from_parts");
 }
 
 // defined in lc_gemm.hip

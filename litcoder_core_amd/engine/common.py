@@ -35,6 +35,8 @@ class FitOptions:
     series_tol: float = 2e-9                # an alpha takes the polynomial form when its worst relative error over the
                                             # spectrum, 1 / T_d(1 + 2 alpha^2), is <= this: 30x below the fp32 epsilon
     primal_max_scale_ratio: float = 64.0    # primal V-wide route: feature column norms within this factor (fp16x3)
+    refit_fused_pearson: bool = True        # test predictions reduced to Pearson r in the contraction's epilogue (fp16x3
+                                            # path): never stored, lc_pearson_cols never reads them back (SURVEY K8 + K9)
     refit_by_inverse: bool = True           # refit operators through the explicit inverse + one fp16x3 product
     refit_inverse_min_alpha: float = 0.1    # ... for alphas (in units of S[0]) from here on (0.05 until round 4: a fuzz case
                                             # at alpha = 0.066 came out 5e-5 of max|W| off a float64 solve, 17x the solves' error)

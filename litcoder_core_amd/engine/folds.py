@@ -336,11 +336,14 @@ class FoldPhases:
         # to the same targets) and per-voxel Pearson r (:152-155, 252-257); the weight rows of the same contraction
         # follow once the fold's results are on their way to the host
         o.update(used=tuple(st["used"]), img_cache=st.get("base", st).setdefault("refit_cache", {}).setdefault("imgs", {}))
-        pred = self._refit_product(o, row0, st["Malpha"][0].shape[0], n_t)[:n_t]
-        if o.get("te_src") is not None:
-            r_s = ops.pearson_cols_gather(*o["te_src"], pred, n_t, Vs)
+        if o["split"] and self.opt.refit_fused_pearson:
+            r_s = self._refit_pearson(o, row0, n_t)        # the predictions stay in the contraction's registers
         else:
-            r_s = ops.pearson_cols(o["Ys_te"], pred, n_t, Vs)
+            pred = self._refit_product(o, row0, st["Malpha"][0].shape[0], n_t)[:n_t]
+            if o.get("te_src") is not None:
+                r_s = ops.pearson_cols_gather(*o["te_src"], pred, n_t, Vs)
+            else:
+                r_s = ops.pearson_cols(o["Ys_te"], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
         pend = self._publish(st, r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t)
         # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then

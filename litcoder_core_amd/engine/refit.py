@@ -327,7 +327,7 @@ class Refit:
         if from_image:
             rows_x = ops.idx_tensor(np.asarray(extra_rows, dtype=np.int64), n_x, self.dev)
             Ys_te, te_src = None, None
-            if 0 < n_x <= 640:                           # Pearson r reads the test rows through (rows, perm) in place
+            if n_x > 0 and (n_x <= 640 or self.opt.refit_fused_pearson):   # Pearson r reads the test rows through (rows, perm) in place
                 te_src = (Y, rows_x, perm)
             else:
                 Ys_te = torch.empty((n_x, Vs), dtype=torch.float32, device=self.dev)
@@ -384,6 +384,34 @@ class Refit:
                 Ms[g].copy_(Malpha[g][r0:r1])                       # (D2D copies: the groups' operators side by side)
             ops.gemm_grouped(Ms, N_o, Ms.stride(0), o["Ys"], Vs, None, C, C.stride(0), rows, Vs, N_o, o["tiles"])
         return C
+
+    def _refit_pearson(self, o, r0, n_t):
+        """Pearson r of the test rows (alpha-sorted voxel order) straight from the contraction: rows [r0, r0 + n_t) of the
+        operators applied to the sorted targets and reduced against the test targets in the launch's epilogue
+        (lc_gemm_grouped_f16x3_pearson) -- the predictions are never stored and lc_pearson_cols never reads them back
+        (nested_cv.py:151-155, 251-257; fp16x3 arithmetic only)."""
+        Malpha, Vs, N_o, Kc = o["Malpha"], o["Vs"], o["N_o"], o["K"]
+        G, rows_pad = len(Malpha), ops.pad_to(n_t, 256)
+        key = (o.get("used"), r0, r0 + n_t, Kc)
+        cache = o.get("img_cache")
+        if cache is not None and key in cache:
+            At, rs_inv = cache[key]
+        else:
+            At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
+            rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
+            for g in range(G):
+                ops.split_rows_f16(Malpha[g][r0:r0 + n_t], n_t, Kc, At[g * rows_pad * Kc * 2:], rs_inv[g * rows_pad:])
+            if cache is not None and o.get("used") is not None:
+                cache[key] = (At, rs_inv)
+        r_s = torch.empty(Vs, dtype=torch.float64, device=self.dev)
+        if o.get("te_src") is not None:
+            y, y_rows, y_cols = o["te_src"]
+        else:
+            y, y_rows, y_cols = o["Ys_te"], None, None
+        ops.gemm_grouped_f16x3_pearson(At, rs_inv, n_t, o["Yt"], o["cs_s"][1], Vs, Kc, o["tiles"], y, y_rows, y_cols, r_s)
+        self.info["plain_flops"] += 2.0 * n_t * o["n_o"] * self.V
+        self.info["plain_launches"] += 1
+        return r_s
 
     def _refit_apply(self, Y, tr_rows, extra_rows, perm, tiles, Vs, Malpha, split, cs):
         """C (rows, Vs) = [M_alpha ; H_te,alpha](group) . Ys -- the weights in its first p_pad rows, the test

@@ -988,6 +988,28 @@ def gemm_grouped_f16x3(at, rowscale_inv, Mrows, bt, cscale_inv, c, ldc, Ncols, K
               arr, G, _p(slab_light), *bview, _s())
 
 
+def gemm_grouped_f16x3_pearson(at, rowscale_inv, Mrows, bt, cscale_inv, Ncols, K, group_tiles, y, y_rows, y_cols, r_out):
+    """Pearson r per column between the rows of the grouped product (never stored) and the targets
+    ``y[y_rows[i], y_cols[column]]`` (None lists: row i / the column itself), into ``r_out`` (Ncols,) float64: the test
+    rows of the refit (lc_gemm_grouped_f16x3_pearson).  More than 64 column groups: one launch per range of 64."""
+    G = len(group_tiles) - 1
+    slabs = -(-Mrows // 128)
+    a_stride = pad_to(Mrows, 256) * K * 2
+    for g0 in range(0, G, GROUP_RANGE):
+        g1 = min(G, g0 + GROUP_RANGE)
+        t0, t1 = int(group_tiles[g0]), int(group_tiles[g1])
+        if t1 == t0:
+            continue
+        n = (t1 - t0) * 256
+        part = torch.empty(slabs * 6 * n, dtype=torch.float64, device=r_out.device)
+        arr = (ctypes.c_int32 * (g1 - g0 + 1))(*[int(t) - t0 for t in group_tiles[g0:g1 + 1]])
+        y_c = y if y_cols is not None else y[:, t0 * 256:]
+        _lib.call("lc_gemm_grouped_f16x3_pearson", _p(at[g0 * a_stride:]), _p(rowscale_inv[g0 * pad_to(Mrows, 256):]), Mrows,
+                  _p(bt[t0 * 256 * K * 2:]), _p(cscale_inv[t0 * 256:]), n, K, arr, g1 - g0, _p(y_c), y.stride(0), _p(y_rows),
+                  _p(None if y_cols is None else y_cols[t0 * 256:]), _p(part), _p(r_out[t0 * 256:]), _s())
+    return r_out
+
+
 def series_sweep_scores_f16x3(pt, rowscale_inv, M, n_val, K, yt, cscale_inv, Ncols, yv, V, ystat, yblk, coef, aidx, part,
                               scores, accumulate, bview=(0, 0, 0)):
     """Series contraction with the moments epilogue + the scores of the series alphas (lc_series_sweep_scores_f16x3)."""

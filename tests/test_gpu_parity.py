@@ -614,6 +614,85 @@ def test_refit_operators_by_inverse_match_the_solves(lc):
     np.testing.assert_allclose(got[1], ref[1], rtol=2e-5, atol=2e-5 * float(np.abs(ref[1]).max()))
 
 
+def test_test_predictions_reduced_in_the_contraction(lc):
+    """Pearson r of the test rows from the epilogue of the refit contraction (lc_gemm_grouped_f16x3_pearson: the
+    predictions never reach HBM, nested_cv.py:151-155, 251-257) against the route it replaces -- the same grouped product
+    stored, then lc_pearson_cols on it: the same fp32 predictions, fp64 moments either way, so r agrees to ~1e-14;
+    gathered targets (row list + column permutation with padding columns), plain ones, a constant prediction, a
+    constant target, row counts that end inside a 32-row block / a slab / a tile; and whole fits with the option on and
+    off: alphas and weights bit-equal, r within 1e-12."""
+    from litcoder_core_amd import ops, nested_cv as ncv
+    dev = ops.device(0)
+    rng = np.random.default_rng(99)
+    K, V, G = 512, 1024, 3
+    tiles = [0, 1, 3, 4]                                               # column tiles (256) per alpha group
+    Ytr = (rng.standard_normal((K, V)) * rng.uniform(0.5, 20.0, V)).astype(np.float32)
+    dYtr = ops.upload_f32(Ytr, V, dev)
+    cs, _ = ops.col_scales_f16(dYtr, K, V, want_flag=False)
+    Yt = torch.empty(V * K * 2, dtype=torch.float16, device=dev)
+    ops.split_cols_f16(dYtr, V, ops.idx_tensor(np.arange(K), K, dev), K, cs, Yt)
+    cs_inv = cs[V:].contiguous()
+    T_all = 900
+    Ysrc = (rng.standard_normal((T_all, V + 300)) * 3.0 + 50.0).astype(np.float32)   # test targets live in a wider matrix
+    Ysrc[:, 17] = 2.5                                                  # a constant target
+    dYsrc = ops.upload_f32(Ysrc, V + 300, dev)
+    for n_t in (600, 291, 37, 128, 257, 800):
+        rows_pad = ops.pad_to(n_t, 256)
+        A = [(rng.standard_normal((n_t, K)) / np.sqrt(K)).astype(np.float32) for _ in range(G)]
+        A[1][:, :] = 0.0                                               # group 1: every prediction 0 -> r = NaN
+        At = torch.empty(G * rows_pad * K * 2, dtype=torch.float16, device=dev)
+        rs = torch.empty(G * rows_pad, dtype=torch.float32, device=dev)
+        for g in range(G):
+            ops.split_rows_f16(ops.upload_f32(A[g], K, dev), n_t, K, At[g * rows_pad * K * 2:], rs[g * rows_pad:])
+        pred = torch.empty((n_t, V), dtype=torch.float32, device=dev)
+        ops.gemm_grouped_f16x3(At, rs, n_t, Yt, cs_inv, pred, V, V, K, tiles)
+        te_rows = rng.permutation(T_all)[:n_t]
+        perm = rng.permutation(V + 300)[:V].astype(np.int32)
+        perm[[5, 300, 1023]] = -1                                      # padding columns of the alpha-sorted order
+        d_rows, d_perm = ops.idx_tensor(te_rows, n_t, dev), ops.upload(perm, dev)
+        if n_t <= 640:
+            want = ops.pearson_cols_gather(dYsrc, d_rows, d_perm, pred, n_t, V).cpu().numpy()
+        else:                                                          # (the in-place kernel stops at 640 rows)
+            Yg = torch.empty((n_t, V), dtype=torch.float32, device=dev)
+            ops.gather(dYsrc, dYsrc.stride(0), d_rows, n_t, ops.upload(np.where(perm >= 0, perm, 0).astype(np.int32), dev), V, Yg)
+            want = ops.pearson_cols(Yg, pred, n_t, V).cpu().numpy()
+        got = torch.full((V,), 7.0, dtype=torch.float64, device=dev)
+        ops.gemm_grouped_f16x3_pearson(At, rs, n_t, Yt, cs_inv, V, K, tiles, dYsrc, d_rows, d_perm, got)
+        got = got.cpu().numpy()
+        live = perm >= 0
+        assert np.isnan(got[256:768]).all() and np.isnan(want[256:768][live[256:768]]).all(), n_t    # zero predictions
+        assert np.isnan(got[perm == 17]).all(), n_t                    # constant target
+        ok = live & ~np.isnan(want)
+        assert ok.sum() > 400 and not np.isnan(got[ok]).any(), n_t
+        np.testing.assert_allclose(got[ok], want[ok], rtol=0, atol=1e-12, err_msg=str(n_t))
+        assert np.isnan(got[~live]).all(), n_t
+        # plain targets: the sorted copy itself, no lists
+        Ys_te = torch.empty((n_t, V), dtype=torch.float32, device=dev)
+        ops.gather(dYsrc, dYsrc.stride(0), d_rows, n_t, ops.upload(np.where(perm >= 0, perm, 0).astype(np.int32), dev), V, Ys_te)
+        want2 = ops.pearson_cols(Ys_te, pred, n_t, V).cpu().numpy()
+        got2 = torch.empty(V, dtype=torch.float64, device=dev)
+        ops.gemm_grouped_f16x3_pearson(At, rs, n_t, Yt, cs_inv, V, K, tiles, Ys_te, None, None, got2)
+        np.testing.assert_allclose(got2.cpu().numpy(), want2, rtol=0, atol=1e-12, equal_nan=True, err_msg=str(n_t))
+    # whole fits
+    T, p, Vf = 420, 96, 700
+    X = rng.standard_normal((T, p))
+    Y = X @ (rng.standard_normal((p, Vf)) * 0.2) + rng.standard_normal((T, Vf)) + 30.0
+    Y[:, 9] = 1.0
+    for kw in (dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 4, 8)),
+               dict(folding_type="chunked", chunk_length=15, n_inner_folds=3, alphas=np.logspace(0, 3, 4), single_alpha=True,
+                    X_test=rng.standard_normal((77, p)), y_test=rng.standard_normal((77, Vf)))):
+        random.seed(5)                                                 # (chunked folds are dealt out at random)
+        on = lc.NestedCVModel("r", precision="f16x3").fit_predict(X, Y, **kw)
+        random.seed(5)
+        off = lc.NestedCVModel("r", precision="f16x3", options=ncv.FitOptions(refit_fused_pearson=False)).fit_predict(X, Y, **kw)
+        dW = np.abs(on[1] - off[1]).max(0)
+        assert np.array_equal(on[2], off[2]), np.nonzero(on[2] != off[2])[0][:10]
+        assert np.array_equal(on[1], off[1]), (np.nonzero(dW > 0)[0][:10], float(dW.max()), int(np.isnan(on[1]).sum()), int(np.isnan(off[1]).sum()))
+        np.testing.assert_allclose(np.asarray(on[0]["correlations"], dtype=np.float64),
+                                   np.asarray(off[0]["correlations"], dtype=np.float64), rtol=0, atol=1e-12)
+        assert on[0]["significant_mask"] == off[0]["significant_mask"] if "significant_mask" in on[0] else True
+
+
 def test_refit_with_large_alphas_polynomial_route(lc):
     """Weights for voxels whose alpha lies on the polynomial series (no factorisation: shared powers of K on the
     f32 MFMA) next to voxels that need the Cholesky route, against the oracle's SVD-route ridge."""
