@@ -30,6 +30,10 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/p_cfg3 -- python3 $R/tools/
 python3 $R/tools/queue_timeline.py $(find /tmp/p_cfg3 -name "*kernel_trace.csv" | head -1) 200 > $O/cfg3_queue_timeline.txt 2>&1
 python3 $R/tools/cfg3_probe.py 80000 h2d pipe fit > $O/cfg3_probe.txt 2>&1
 python3 $R/tools/upload_probe.py > $O/upload_probe.txt 2>&1
+python3 $R/tools/upload_probe.py 80000 busy 2>&1 | tail -4 > $O/upload_probe_beside_mfma.txt
+python3 $R/tools/upload_probe.py 80000 busy hbm 2>&1 | tail -4 > $O/upload_probe_beside_hbm_passes.txt
+python3 $R/tools/stream_queue_probe.py > $O/stream_queue_probe.txt 2>&1
+python3 $R/tools/host_path_timeline.py 80000 cfg3 > $O/cfg3_host_path_timeline.txt 2>&1
 python3 $R/tools/main_stream_events.py 80000 8 0 > $O/device_timeline_rank0_of_8.txt 2>&1
 python3 $R/tools/main_stream_events.py 80000 > $O/device_timeline_1gpu.txt 2>&1
 python3 $R/tools/host_path_timeline.py > $O/host_path_timeline.txt 2>&1
