@@ -61,6 +61,10 @@ int lc_check_device(int dev);
  * returns the summed milliseconds / call count of a slot and clears it.  Slot 0 is the fused
  * alpha-sweep MFMA kernel alone. */
 int lc_timing_enable(int on);
+/* ... for the slots whose bits are set only (bit i = slot i; 0 = off): every timed launch is bracketed by two event
+ * records that keep it from overlapping its neighbours on the stream, so a measurement of ONE kernel class inside a timed
+ * region (bench.py: slot 0 during the headline fits) should not time the ~900 other launches of a fit as well. */
+int lc_timing_enable_slots(uint64_t mask);
 int lc_timing_slots(void);
 const char* lc_timing_name(int slot);
 int lc_timing_read(int slot, double* total_ms, int* calls);

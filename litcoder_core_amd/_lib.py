@@ -6,7 +6,7 @@ raises.  Build the library with ``python -c "import __graft_entry__ as g; g.buil
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblitcoder_hip.so")
@@ -26,6 +26,7 @@ SIGNATURES = {
     "lc_stream_create_cu_mask": (c_int, [_ptr, c_int, _ptr]),
     "lc_stream_destroy": (c_int, [_ptr]),
     "lc_timing_enable": (c_int, [c_int]),
+    "lc_timing_enable_slots": (c_int, [c_uint64]),
     "lc_timing_slots": (c_int, []),
     "lc_timing_name": (c_char_p, [c_int]),
     "lc_timing_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int)]),

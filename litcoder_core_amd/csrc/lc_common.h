@@ -44,13 +44,13 @@ enum TimingSlot {
     T_SWEEP_GEMM = 0, T_SWEEP_FINALIZE, T_GROUPED_GEMM, T_CHOL_SOLVE, T_LAMBDA_MAX, T_GRAM, T_ASSEMBLE,
     T_VAL_STATS, T_PEARSON, T_GATHER, T_SCATTER, T_SELECT, T_FIR, T_LANCZOS, T_CAST, T_COLSTATS, T_SPLIT16, T_SERIES, T_SLOTS
 };
-bool timing_on();
+bool timing_on(int slot);
 void timing_begin(int slot, hipStream_t s);
 void timing_end(int slot, hipStream_t s);
 
 struct ScopedTimer {
     int slot; hipStream_t s; bool on;
-    ScopedTimer(int slot_, hipStream_t s_) : slot(slot_), s(s_), on(timing_on()) { if (on) timing_begin(slot, s); }
+    ScopedTimer(int slot_, hipStream_t s_) : slot(slot_), s(s_), on(timing_on(slot_)) { if (on) timing_begin(slot, s); }
     ~ScopedTimer() { if (on) timing_end(slot, s); }
 };
 

@@ -21,7 +21,7 @@ namespace lc {
 namespace {
 struct EventPair { hipEvent_t a, b; };
 std::mutex g_mu;
-bool g_on = false;
+unsigned long long g_mask = 0;           // timed slots (bit per slot)
 std::vector<EventPair> g_events[T_SLOTS];
 std::vector<hipEvent_t> g_open[T_SLOTS];
 const char* const g_names[T_SLOTS] = {
@@ -30,7 +30,7 @@ const char* const g_names[T_SLOTS] = {
     "lanczos_interp", "cast", "col_stats", "split_f16", "series_hat"};
 }  // namespace
 
-bool timing_on() { return g_on; }
+bool timing_on(int slot) { return (g_mask >> slot) & 1ull; }
 
 void timing_begin(int slot, hipStream_t s) {
     hipEvent_t e;
@@ -70,7 +70,13 @@ extern "C" int lc_version(void) { return 101; }
 
 extern "C" int lc_timing_enable(int on) {
     std::lock_guard<std::mutex> lk(lc::g_mu);
-    lc::g_on = on != 0;
+    lc::g_mask = on ? ~0ull : 0ull;
+    return LC_OK;
+}
+
+extern "C" int lc_timing_enable_slots(uint64_t mask) {
+    std::lock_guard<std::mutex> lk(lc::g_mu);
+    lc::g_mask = mask;
     return LC_OK;
 }
 

@@ -121,7 +121,16 @@ def upload(arr, dev):
     return out
 
 
-def timing_enable(on=True):
+def timing_enable(on=True, only=None):
+    """Event timers of the library's kernel classes on / off; ``only``: the slot names to time (the others stay off)."""
+    if on and only:
+        lib = _lib.load()
+        names = [lib.lc_timing_name(s).decode() for s in range(lib.lc_timing_slots())]
+        mask = 0
+        for n in only:
+            mask |= 1 << names.index(n)
+        _lib.call("lc_timing_enable_slots", mask)
+        return
     _lib.call("lc_timing_enable", int(bool(on)))
 
 
