@@ -1422,6 +1422,24 @@ def test_precision_policy(lc):
     assert model16.last_fit["precision"] == "f32"
     with pytest.raises(ValueError):
         lc.NestedCVModel("r", precision="fp8").fit_predict(X, Y, **kw)
+    # a wide column in a LATER voxel panel of host inputs: the flag of a panel is looked at after its sweeps were queued
+    # (round 4), the fit is then repeated on the f32 path with what is resident -- the engine's own uploader and targets put
+    # on the link by the caller beforehand (start_targets) must end at the same, f32, result
+    from litcoder_core_amd import ops
+    X3, Y3 = _synthetic(360, 48, 2048, 12)
+    Y3[11, 1700] = 3e6
+    ref = lc.NestedCVModel("r", precision="f32").fit_predict(X3, Y3, **kw)
+    own = lc.NestedCVModel("r", precision="auto", panel_cols=512)
+    got = own.fit_predict(X3, Y3, **kw)
+    assert own.last_fit["precision"] == "f32"          # (last_fit describes the repeated, resident fit)
+    fly = lc.NestedCVModel("r", precision="auto", panel_cols=512)
+    dX = ops.upload_f32(X3, ops.pad_to(X3.shape[1], 32), ops.device())
+    flying = fly.start_targets(Y3)
+    got2 = fly.fit_predict_device(dX, flying, X3.shape[1], Y3.shape[1], weights_on_host=True, **kw)
+    assert fly.last_fit["precision"] == "f32"
+    for g in (got, got2):
+        assert np.array_equal(g[2], ref[2]) and np.array_equal(g[1], ref[1])
+        assert g[0]["correlations"] == ref[0]["correlations"]
 
 
 def test_baseline_shape_against_reference_fixture(lc, golden_dir):
