@@ -351,6 +351,25 @@ class Refit:
             o.update(cs_s=cs_s, Yt=Yt)
         return o
 
+    def _refit_images(self, o, r0, r1):
+        """(tiled fp16 image, row scales) of rows [r0, r1) of every alpha group's operator, groups stacked tile-aligned.
+        The operators' images are the same for every voxel range of the fold whose voxels chose the same alphas: kept in
+        the fold's cache."""
+        Malpha, N_o, Kc = o["Malpha"], o["N_o"], o["K"]        # contraction depth Kc: the training rows (the operators'
+        G, rows = len(Malpha), r1 - r0                         # padding columns beyond them are zero)
+        rows_pad = ops.pad_to(rows, 256)
+        key = (o.get("used"), r0, r1, Kc)
+        cache = o.get("img_cache")
+        if cache is not None and key in cache:
+            return cache[key]
+        At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
+        rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
+        for g in range(G):
+            ops.split_rows_f16(Malpha[g][r0:r1], rows, Kc, At[g * rows_pad * Kc * 2:], rs_inv[g * rows_pad:])
+        if cache is not None and o.get("used") is not None:
+            cache[key] = (At, rs_inv)
+        return At, rs_inv
+
     def _refit_product(self, o, r0, r1, useful_rows, out=None):
         """Rows [r0, r1) of  C = [M_alpha ; H_te,alpha](group) . Ys  as an (r1 - r0, Vs) f32 matrix (fp16x3 path: the
         rows of every group split to fp16 triples, one grouped launch).  The caller takes the test predictions first
@@ -360,22 +379,8 @@ class Refit:
         G, rows = len(Malpha), r1 - r0
         C = out if out is not None else torch.empty((rows, Vs), dtype=torch.float32, device=self.dev)
         if o["split"]:
-            rows_pad = ops.pad_to(rows, 256)
-            Kc = o["K"]                                  # contraction depth: the training rows (the operators' padding
-            # columns beyond them are zero).  The operators' images are the same for every voxel range of the fold
-            # whose voxels chose the same alphas: kept in the fold's cache
-            key = (o.get("used"), r0, r1, Kc)
-            cache = o.get("img_cache")
-            if cache is not None and key in cache:
-                At, rs_inv = cache[key]
-            else:
-                At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
-                rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
-                for g in range(G):
-                    ops.split_rows_f16(Malpha[g][r0:r1], rows, Kc, At[g * rows_pad * Kc * 2:], rs_inv[g * rows_pad:])
-                if cache is not None and o.get("used") is not None:
-                    cache[key] = (At, rs_inv)
-            ops.gemm_grouped_f16x3(At, rs_inv, rows, o["Yt"], o["cs_s"][1], C, C.stride(0), Vs, Kc, o["tiles"])
+            At, rs_inv = self._refit_images(o, r0, r1)
+            ops.gemm_grouped_f16x3(At, rs_inv, rows, o["Yt"], o["cs_s"][1], C, C.stride(0), Vs, o["K"], o["tiles"])
             self.info["plain_flops"] += 2.0 * useful_rows * o["n_o"] * self.V
             self.info["plain_launches"] += 1
         else:
@@ -390,25 +395,14 @@ class Refit:
         operators applied to the sorted targets and reduced against the test targets in the launch's epilogue
         (lc_gemm_grouped_f16x3_pearson) -- the predictions are never stored and lc_pearson_cols never reads them back
         (nested_cv.py:151-155, 251-257; fp16x3 arithmetic only)."""
-        Malpha, Vs, N_o, Kc = o["Malpha"], o["Vs"], o["N_o"], o["K"]
-        G, rows_pad = len(Malpha), ops.pad_to(n_t, 256)
-        key = (o.get("used"), r0, r0 + n_t, Kc)
-        cache = o.get("img_cache")
-        if cache is not None and key in cache:
-            At, rs_inv = cache[key]
-        else:
-            At = torch.empty(G * rows_pad * N_o * 2, dtype=torch.float16, device=self.dev)
-            rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
-            for g in range(G):
-                ops.split_rows_f16(Malpha[g][r0:r0 + n_t], n_t, Kc, At[g * rows_pad * Kc * 2:], rs_inv[g * rows_pad:])
-            if cache is not None and o.get("used") is not None:
-                cache[key] = (At, rs_inv)
+        Vs = o["Vs"]
+        At, rs_inv = self._refit_images(o, r0, r0 + n_t)
         r_s = torch.empty(Vs, dtype=torch.float64, device=self.dev)
         if o.get("te_src") is not None:
             y, y_rows, y_cols = o["te_src"]
         else:
             y, y_rows, y_cols = o["Ys_te"], None, None
-        ops.gemm_grouped_f16x3_pearson(At, rs_inv, n_t, o["Yt"], o["cs_s"][1], Vs, Kc, o["tiles"], y, y_rows, y_cols, r_s)
+        ops.gemm_grouped_f16x3_pearson(At, rs_inv, n_t, o["Yt"], o["cs_s"][1], Vs, o["K"], o["tiles"], y, y_rows, y_cols, r_s)
         self.info["plain_flops"] += 2.0 * n_t * o["n_o"] * self.V
         self.info["plain_launches"] += 1
         return r_s
