@@ -306,3 +306,47 @@ if "hbm" in what:
     out = torch.empty((3000, 80000), dtype=torch.float32, device=dev)
     ms = timeit(lambda: ops.gather(Y, 80000, rows, 3000, perm, 80000, out), reps=5)
     report("gather (alpha-sorted copy) 3000x80000 f32", 2 * 3000 * 80000 * 4, ms)
+    # ---- round 4: the operand passes of the LeBel-style fit (cfg3: 1 844 validation rows, p = 3072), one voxel panel wide
+    del out, Y
+    Vp_ = 30720
+    Yb = torch.randn((9513, Vp_), generator=g, device=dev, dtype=torch.float32)
+    vab = ops.idx_tensor(np.r_[1844:3688], 1856, dev)
+    ystat = torch.empty((3, Vp_), dtype=torch.float32, device=dev)
+    yblk = torch.empty((58, Vp_), dtype=torch.float32, device=dev)
+    yv_ = torch.empty((1856, Vp_), dtype=torch.float32, device=dev)
+    ms = timeit(lambda: ops.val_stats(Yb, Vp_, vab, 1856, 1844, ystat, yblk, yv_), reps=10)
+    report(f"val_stats 1844x{Vp_} f32 (chunked: two reads, one write of the rows)", 3 * 1844 * Vp_ * 4, ms)
+    ms = timeit(lambda: ops.col_scales_f16(Yb, 9513, Vp_, want_flag=True), reps=10)
+    report(f"col_scales + flag 9513x{Vp_} f32 (two passes)", 2 * 9513 * Vp_ * 4, ms)
+    Bs = [torch.randn((3072, Vp_), generator=g, device=dev, dtype=torch.float32) for _ in range(4)]
+    Bo = torch.empty((3072, Vp_), dtype=torch.float32, device=dev)
+    ms = timeit(lambda: ops.combine_colmax(Bs, [1.0] * 4, Bo, Vp_, want_scales_for=Vp_), reps=10)
+    report(f"combine_colmax 4 terms 3072x{Vp_} f32 (sum + column maxima + scales)", 5 * 3072 * Vp_ * 4, ms)
+    ms = timeit(lambda: (ops.combine_many(Bs, [1.0] * 4, Bo), ops.col_scales_f16(Bo, 3072, Vp_, want_flag=False)), reps=10)
+    report("   the two passes it replaces (combine_terms, col_scales)", 6 * 3072 * Vp_ * 4, ms)
+    csb, _ = ops.col_scales_f16(Bo, 3072, Vp_, want_flag=False)
+    Bt_ = torch.empty(Vp_ * 3072 * 2, dtype=torch.float16, device=dev)
+    ident_ = ops.idx_tensor(np.arange(3072), 3072, dev)
+    ms = timeit(lambda: ops.split_cols_f16(Bo, Vp_, ident_, 3072, csb, Bt_), reps=10)
+    report(f"split_cols_f16 3072x{Vp_} (f32 in, fp16 hi + lo image out)", 2 * 3072 * Vp_ * 4, ms)
+    # the test rows of a cfg2 refit: product + Pearson r, stored route against the reduced one
+    Kr, n_t, Vr = 2400, 600, 80128
+    Ar = (torch.randn((n_t, Kr), generator=g, device=dev, dtype=torch.float32) / 49.0)
+    Yr = torch.randn((Kr, Vr), generator=g, device=dev, dtype=torch.float32)
+    Yte = torch.randn((n_t, Vr), generator=g, device=dev, dtype=torch.float32)
+    Atr = torch.empty(ops.pad_to(n_t, 256) * Kr * 2, dtype=torch.float16, device=dev)
+    rsr = torch.empty(ops.pad_to(n_t, 256), dtype=torch.float32, device=dev)
+    ops.split_rows_f16(Ar, n_t, Kr, Atr, rsr)
+    csr, _ = ops.col_scales_f16(Yr, Kr, Vr, want_flag=False)
+    Ytr_ = torch.empty(Vr * Kr * 2, dtype=torch.float16, device=dev)
+    ops.split_cols_f16(Yr, Vr, ops.idx_tensor(np.arange(Kr), Kr, dev), Kr, csr, Ytr_)
+    csi = csr[Vr:].contiguous()
+    predr = torch.empty((n_t, Vr), dtype=torch.float32, device=dev)
+    tiles_r = [0, Vr // 256]
+    ms_a = timeit(lambda: (ops.gemm_grouped_f16x3(Atr, rsr, n_t, Ytr_, csi, predr, Vr, Vr, Kr, tiles_r),
+                           ops.pearson_cols(Yte, predr, n_t, Vr)), reps=10)
+    r_out = torch.empty(Vr, dtype=torch.float64, device=dev)
+    ms_b = timeit(lambda: ops.gemm_grouped_f16x3_pearson(Atr, rsr, n_t, Ytr_, csi, Vr, Kr, tiles_r, Yte, None, None, r_out), reps=10)
+    print(f"test rows of a refit ({n_t} x {Kr} x {Vr}): product stored + pearson_cols {ms_a * 1e3:.0f} us; reduced in the epilogue "
+          f"{ms_b * 1e3:.0f} us ({2.0 * n_t * Kr * Vr / ms_b / 1e9:.0f} TF algorithmic); max |r difference| "
+          f"{float((r_out - ops.pearson_cols(Yte, predr, n_t, Vr)).abs().max()):.1e}")
