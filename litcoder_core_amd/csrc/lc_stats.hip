@@ -617,14 +617,17 @@ __global__ void __launch_bounds__(64 * CM_RG) k_val_stats_regs(const float* __re
         }
 }
 
-// More than 512 validation rows (the LeBel-style pipeline: 1 844 per inner fold): the same statistics in two passes of
-// register-sized chunks (CM_RG x NBLK 32-row blocks = 512 rows per trip, 64 independent loads per thread in flight) --
-// pass 1 the mean, pass 2 the variance about it, the block sums and the row-quad copies.  (Rounds 1-3 walked the rows three times with one load in flight per thread: 0.8 TB/s of the 2.95 GB x 2 per fit there.)
+// More than 512 validation rows (the LeBel-style pipeline: 1 844 per inner fold): the same statistics in two passes over
+// the rows -- pass 1 the mean, pass 2 the variance about it, the block sums and the row-quad copies -- a wave taking every
+// CM_RG-th 32-row block with two register sets, so that the 32 loads of its next block are in flight while it works on
+// this one.  (Rounds 1-3 walked the rows three times with one load in flight per thread: 0.8 TB/s of the 2.95 GB x 2 per
+// fit there; a first round-4 version loaded 64 rows per trip and waited for them: 2.1 TB/s.)
 template <int NBLK>
 __global__ void __launch_bounds__(64 * CM_RG) k_val_stats_chunks(const float* __restrict__ y, long long ldy, long long V,
                                                                  const int* __restrict__ va, int M, FoldRows fr,
                                                                  float* __restrict__ ystat, float* __restrict__ yblk,
                                                                  float* __restrict__ yv) {
+    static_assert(NBLK == 1, "one 32-row block per wave and trip, two register sets in flight");
     __shared__ double sm[CM_RG][64];
     const int fold = blockIdx.y, n_val = fr.n_val[fold];
     va += (long long)fold * M;
@@ -635,58 +638,56 @@ __global__ void __launch_bounds__(64 * CM_RG) k_val_stats_chunks(const float* __
     const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
     const bool live = c < V;
     const int nblocks = M / LC_MB;
-    float cache[NBLK][LC_MB];
-    double s = 0.0;
-    for (int b0 = 0; b0 < nblocks; b0 += CM_RG * NBLK) {
+    // a wave walks the blocks ty, ty + CM_RG, ...; the loads of its NEXT block are in flight while it works on this one
+    auto load = [&](float (&buf)[LC_MB], int b) {
 #pragma unroll
-        for (int k = 0; k < NBLK; ++k) {
-            const int b = b0 + ty + k * CM_RG;
-#pragma unroll
-            for (int r = 0; r < LC_MB; ++r) {
-                const int i = b * LC_MB + r;
-                cache[k][r] = (live && b < nblocks && i < n_val) ? y[(long long)va[i] * ldy + c] : 0.f;
-            }
+        for (int r = 0; r < LC_MB; ++r) {
+            const int i = b * LC_MB + r;
+            buf[r] = (live && b < nblocks && i < n_val) ? y[(long long)va[i] * ldy + c] : 0.f;
         }
+    };
+    float A[LC_MB], B[LC_MB];
+    double s = 0.0;
+    auto sum = [&](const float (&buf)[LC_MB]) {
 #pragma unroll
-        for (int k = 0; k < NBLK; ++k)
-#pragma unroll
-            for (int r = 0; r < LC_MB; ++r) s += (double)cache[k][r];      // padding entries are exact zeros
+        for (int r = 0; r < LC_MB; ++r) s += (double)buf[r];              // padding entries are exact zeros
+    };
+    load(A, ty);
+    for (int b = ty; b < nblocks; b += 2 * CM_RG) {
+        load(B, b + CM_RG);
+        sum(A);
+        load(A, b + 2 * CM_RG);
+        sum(B);
     }
     const double mean = block_colsum<CM_RG>(s, sm) / (double)n_val;
     const float meanf = (float)mean;
     double q = 0.0;
-    for (int b0 = 0; b0 < nblocks; b0 += CM_RG * NBLK) {
+    auto finish = [&](const float (&buf)[LC_MB], int b) {
+        if (b >= nblocks) return;
+        float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < NBLK; ++k) {
-            const int b = b0 + ty + k * CM_RG;
+        for (int r4 = 0; r4 < LC_MB; r4 += 4) {
+            float4 quad;                                     // row-quad interleaved layout, see lc_epilogue.h
+            float* qv = reinterpret_cast<float*>(&quad);
 #pragma unroll
-            for (int r = 0; r < LC_MB; ++r) {
-                const int i = b * LC_MB + r;
-                cache[k][r] = (live && b < nblocks && i < n_val) ? y[(long long)va[i] * ldy + c] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NBLK; ++k) {
-            const int b = b0 + ty + k * CM_RG;
-            if (b >= nblocks) continue;
-            float t = 0.f;
-#pragma unroll
-            for (int r4 = 0; r4 < LC_MB; r4 += 4) {
-                float4 quad;                                 // row-quad interleaved layout, see lc_epilogue.h
-                float* qv = reinterpret_cast<float*>(&quad);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    qv[j] = cache[k][r4 + j];
-                    if (b * LC_MB + r4 + j < n_val) {
-                        const double d = (double)qv[j] - mean;
-                        q += d * d;
-                        t += qv[j] - meanf;
-                    }
+            for (int j = 0; j < 4; ++j) {
+                qv[j] = buf[r4 + j];
+                if (b * LC_MB + r4 + j < n_val) {
+                    const double d = (double)qv[j] - mean;
+                    q += d * d;
+                    t += qv[j] - meanf;
                 }
-                if (live) reinterpret_cast<float4*>(yv)[(long long)((b * LC_MB + r4) >> 2) * V + c] = quad;
             }
-            if (live) yblk[(long long)b * V + c] = t;
+            if (live) reinterpret_cast<float4*>(yv)[(long long)((b * LC_MB + r4) >> 2) * V + c] = quad;
         }
+        if (live) yblk[(long long)b * V + c] = t;
+    };
+    load(A, ty);
+    for (int b = ty; b < nblocks; b += 2 * CM_RG) {
+        load(B, b + CM_RG);
+        finish(A, b);
+        load(A, b + 2 * CM_RG);
+        finish(B, b + CM_RG);
     }
     const double m2 = block_colsum<CM_RG>(q, sm);
     if (live && ty == 0) {
@@ -716,7 +717,7 @@ extern "C" int lc_val_stats_folds(const float* d_y, int64_t ldy, int64_t V, cons
         hipLaunchKernelGGL(k_val_stats_regs<2>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V, d_va,
                            M, fr, d_ystat, d_yblk, d_yv);
     else                                                     // any number: two passes of register-sized chunks
-        hipLaunchKernelGGL(k_val_stats_chunks<2>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V,
+        hipLaunchKernelGGL(k_val_stats_chunks<1>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V,
                            d_va, M, fr, d_ystat, d_yblk, d_yv);
     return lc::launched("k_val_stats");
 }
