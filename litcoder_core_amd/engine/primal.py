@@ -320,7 +320,10 @@ class PrimalForm:
         yblk = torch.empty((nbuf, M // LC_MB, Vp_), dtype=torch.float32, device=self.dev)
         yv = torch.empty((nbuf, M, Vp_), dtype=torch.float32, device=self.dev)
         Vt = ops.pad_to(Vp_, 256)
-        B = ops.zeros((PP, Vt), torch.float32, self.dev)
+        # (sums of whole block products overwrite every entry; a contraction over the training rows leaves the padding
+        # rows / columns to the zero fill)
+        B = (torch.empty((PP, Vt), dtype=torch.float32, device=self.dev) if Xt_val is not None
+             else ops.zeros((PP, Vt), torch.float32, self.dev))
         ident = ops.idx_tensor(np.arange(self.p), PP, self.dev)
         shared = hat.get("shared") if split else None
         views = [(0, 0, 0)] * F
