@@ -205,7 +205,7 @@ class FoldPhases:
         if bool(split) != bool(base["split"]) and not self.moments:
             raise _WideTargets("the fold's operators were prepared for the other arithmetic")
         hat = dict(base["hat"])
-        hat.update(cs=cs, split=split)
+        hat.update(cs=cs, split=split, n_te=len(base["te"]))
         st.update(Y=Y, cs=cs, split=split, hat=hat)
         st["info"] = hat["info"]
         if split_phase:

@@ -439,8 +439,12 @@ class PrimalForm:
         if by_blocks:
             # the outer block's product = the sum of all its validation blocks': the refit's operand (_primal_refit_inputs)
             if split:
-                hat["B_all"], hat["csB_all"] = ops.combine_colmax([Bv[q] for q in range(F)], [1.0] * F, B, Vt,
+                # ... written straight into the rows it has in the refit's operand [B_o ; Y_te] (_primal_refit_inputs: the
+                # refit is on the critical tail of a single-alpha fit -- no fill and no copy of 1 GB there)
+                ext = torch.empty((PP + int(hat.get("n_te") or 0), Vt), dtype=torch.float32, device=self.dev)
+                hat["B_all"], hat["csB_all"] = ops.combine_colmax([Bv[q] for q in range(F)], [1.0] * F, ext[:PP], Vt,
                                                                   want_scales_for=Vp_)
+                hat["ext"] = ext
             else:
                 hat["B_all"] = ops.combine_many([Bv[q] for q in range(F)], [1.0] * F, B)
         self.sweeps_done = torch.cuda.Event()
@@ -455,11 +459,16 @@ class PrimalForm:
         n_t = len(te)
         Vt = ops.pad_to(self.Vp, 256)
         No = ops.pad_to(len(st["tr"]), 2 * K_TILE)
-        ext = ops.zeros((PP + n_t, Vt), torch.float32, self.dev)
         B_all = st["hat"].get("B_all")
+        ext = st["hat"].get("ext")
+        if ext is not None and ext.shape[0] == PP + n_t:
+            ext[PP:, self.Vp:].zero_()                                       # (B_o is in place already, _sweeps_primal)
+        else:
+            ext = ops.zeros((PP + n_t, Vt), torch.float32, self.dev)
+            if B_all is not None:
+                ext[:PP].copy_(B_all)
         if B_all is not None:
             # the inner CV of this step left  B_o = Rstim'Rresp  of the outer block (the sum of its validation blocks')
-            ext[:PP].copy_(B_all)
             csB = st["hat"].get("csB_all") if st["split"] else None          # (taken while B_all was written)
             if st["split"] and csB is None:
                 csB = ops.col_scales_f16(ext, self.p, self.Vp, want_flag=False)[0]
