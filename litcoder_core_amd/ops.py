@@ -474,6 +474,17 @@ class TargetsInFlight:
         for j in range(self.n_lead):
             self.uploader.wait(j, stream)
 
+    def __del__(self):
+        # dropped before a fit took it to its end (an exception on the caller's side): the staging threads and the copies
+        # they queued still write into the buffer -- it goes back to the allocator only when they are done
+        try:
+            up = getattr(self, "uploader", None)
+            if up is not None:
+                up.thread.join()
+                up.stream.synchronize()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
 
 def upload_f32(host, ld, dev, rows_pad=None):
     """Host (rows, cols) real array -> zero-padded (rows_pad or rows, ld) f32 device buffer, ordered on the current
