@@ -177,10 +177,19 @@ def test_two_rank_shard_equals_unsharded(tmp_path, mode):
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     subprocess.run([sys.executable, str(script), ROOT, mode, str(tmp_path)], check=True, env=env, timeout=300)
-    port = 29500 + (os.getpid() % 2000) + (0 if mode == "single" else 1)
-    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                    "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, mode, str(tmp_path)],
-                   check=True, env=env, timeout=600)
+    for attempt in range(3):                   # (a free port asked of the kernel; once more should the agent still lose it)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        done = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                               "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, mode,
+                               str(tmp_path)], env=env, timeout=600)
+        if done.returncode == 0:
+            break
+        for f in tmp_path.glob("rendezvous2_*"):
+            f.unlink()                          # the second world's file store must start empty
+    assert done.returncode == 0
     ref = pickle.load(open(tmp_path / f"single_{mode}.pkl", "rb"))
     ranks = [pickle.load(open(tmp_path / f"rank{r}_{mode}.pkl", "rb")) for r in range(2)]
     for out in ranks:
