@@ -92,6 +92,14 @@ def _same(got, want, lo, hi, what):
     assert W.shape == (W0.shape[0], hi - lo) and np.array_equal(W, W0[:, lo:hi]), what
 
 
+def _free_port():
+    """A TCP port the kernel just handed out (derived-from-the-pid ports collide now and then on a shared host)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 @pytest.fixture(scope="module")
 def runs(tmp_path_factory):
     d = tmp_path_factory.mktemp("shards")
@@ -105,7 +113,7 @@ def runs(tmp_path_factory):
 
 def test_two_real_engine_ranks_on_one_gpu_equal_the_unsharded_fit(runs):
     d, script, env, ref = runs
-    port = 29900 + os.getpid() % 500
+    port = _free_port()
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                     "127.0.0.1", "--master-port", str(port), str(script), ROOT, "gloo", str(d)], check=True, env=env,
                    timeout=1500)
@@ -125,7 +133,7 @@ def test_three_ranks_uneven_shares(runs):
     """Three ranks: 777 voxels split 259 / 259 / 259, job counts that do not divide by three (ranks with one job fewer
     or none at all, row-sliced refit systems with an idle rank) -- still the unsharded fit bit for bit on every rank."""
     d, script, env, ref = runs
-    port = 29700 + os.getpid() % 200
+    port = _free_port()
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr",
                     "127.0.0.1", "--master-port", str(port), str(script), ROOT, "gloo", str(d)], check=True, env=env,
                    timeout=1500)
@@ -156,7 +164,7 @@ def test_bench_runs_on_two_ranks_of_one_gpu(tmp_path):
     import json
     env = dict(os.environ, LITCODER_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
     for k, scaling in enumerate(("weak", "strong")):
-        port = 29500 + (os.getpid() % 1500) + 17 + k
+        port = _free_port()
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                             "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
                             "--warmup", "1", "--voxels", "6144", "--scaling", scaling, "--no-cpu-baseline"],
