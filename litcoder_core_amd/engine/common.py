@@ -35,6 +35,14 @@ class FitOptions:
     series_tol: float = 2e-9                # an alpha takes the polynomial form when its worst relative error over the
                                             # spectrum, 1 / T_d(1 + 2 alpha^2), is <= this: 30x below the fp32 epsilon
     primal_max_scale_ratio: float = 64.0    # primal V-wide route: feature column norms within this factor (fp16x3)
+    single_alpha_guess: bool = True         # train/test fits with ONE alpha and host inputs / weights: once all voxel panels
+                                            # but the last have been swept, refit them with the alpha they choose and send
+                                            # their weights home while the last panel is swept (0.98 GB at the LeBel shape:
+                                            # 17 ms of PCIe that followed the last sweep); the choice over ALL voxels is then
+                                            # checked against it -- another alpha: the fit is repeated without the guess
+    single_alpha_guess_margin: float = 1e-4  # ... only when the early panels' best alpha leads the second best by this
+                                            # much in mean score per voxel (the LeBel-shaped bench data: 2.1e-4; the last
+                                            # panel, 15 % of the voxels, would have to average six times that the other way)
     refit_fused_pearson: bool = True        # test predictions reduced to Pearson r in the contraction's epilogue (fp16x3
                                             # path): never stored, lc_pearson_cols never reads them back (SURVEY K8 + K9)
     refit_by_inverse: bool = True           # refit operators through the explicit inverse + one fp16x3 product
@@ -130,6 +138,12 @@ class _WideTargets(Exception):
     """precision="auto" met a target column whose dynamic range the fp16 hi/lo split cannot carry AFTER the fit was set up
     for it (host inputs arrive panel by panel, so the decision cannot be taken up front): the driver repeats the fit on
     the f32 MFMA path with the targets that are resident by then."""
+
+
+class _GuessMissed(Exception):
+    """single_alpha with host inputs: the early voxel panels were refitted with the alpha THEY chose while the last panel was
+    still being swept, and the choice over all voxels turned out to be another one -- the driver repeats the fit with
+    what is resident (same result as without the guess; FitOptions.single_alpha_guess)."""
 
 
 class _Range:

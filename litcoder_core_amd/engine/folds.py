@@ -242,24 +242,25 @@ class FoldPhases:
             st["grouping"] = self._group_async(st["best"], st["split"])
         return st
 
-    def fold_choose_joint(self, sts):
+    def fold_choose_joint(self, sts, assign=None):
         """``single_alpha`` when a fold is worked through in several voxel ranges (host inputs arriving panel by panel):
         the ONE alpha is the argmax of the across-voxel mean of the scores (nested_cv.py:396-400), so the per-alpha sums
         of all ranges -- and of all voxel shards -- are added up on the device before any range is grouped.  Every
-        range's state gets its ``best`` vector and its grouping, as fold_choose would give it."""
+        range's state (``assign``: only these) gets its ``best`` vector and its grouping, as fold_choose would give it.
+        Returns the (A,) device vector of the sums."""
         total = None
         for st in sts:
             self._enter(st)
             _, rowsum = ops.select_alpha(st["scores"], self.A, self.Vp, want_best=False, want_rowsum=True)
             total = rowsum if total is None else ops.accumulate_f64(rowsum, total)
         self.shard.all_reduce_(total, "sum")
-        for st in sts:
+        for st in (sts if assign is None else assign):
             self._enter(st)
             best = torch.empty(self.Vp, dtype=torch.int32, device=self.dev)
             st["best"] = ops.fill_argmax(total, self.A, best, self.Vp)
             if not self.moments:
                 st["grouping"] = self._group_async(st["best"], st["split"])
-        return sts
+        return total
 
     def fold_select(self, st, single_alpha):
         """Waits for the fold's alpha histogram (fold_choose; the one host synchronisation of a fold) and puts the

@@ -36,7 +36,7 @@ from . import ops, series, stats  # noqa: F401
 from ._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2  # noqa: F401  (names tests / tools reach through here)
 from .dist import ShardContext
 from .engine.common import (SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions,  # noqa: F401
-                            check_penalties, _PrimalUnsuitable, _WideTargets, _FoldResult, _aux_stream, _Range,
+                            check_penalties, _PrimalUnsuitable, _WideTargets, _GuessMissed, _FoldResult, _aux_stream, _Range,
                             _column_panels, _download_panels, _DeviceShapes)
 from .engine.core import EngineCore
 from .engine.dual import DualSweeps
@@ -313,7 +313,39 @@ class NestedCVModel(BasePredictivityModel):
                     eng.refit_ahead(prepared[1:])
                 elif getattr(eng, "cho", None) and eng.opt.speculate_first_fold and eng.speculation_pays():
                     eng.fold_speculate(first, list(eng.cho), early=True)
-                sts += [eng.fold_begin(*outer[0], prepared=first, step=(0, c)) for c in eng.upload_panels[1:]]
+                guessed = None
+                if (n == 1 and weights_on_host and len(eng.upload_panels) >= 3 and drv_opt.single_alpha_guess
+                        and not getattr(eng, "moments", False)):
+                    # ---- the tail of such a fit was: last sweep -> choice -> refit of every range -> 0.98 GB of weights over
+                    # the link (17 ms at the LeBel shape), all behind the last panel's sweeps.  Once every panel BUT the last
+                    # has been swept their alpha is almost always THE alpha: refit them with it now, let their weights leave
+                    # while the last panel is swept, and check the choice over all voxels afterwards (_GuessMissed: once more,
+                    # without the guess)
+                    sts += [eng.fold_begin(*outer[0], prepared=first, step=(0, c)) for c in eng.upload_panels[1:-1]]
+                    early_sums = eng.fold_choose_joint(sts).cpu().numpy()        # (host: these panels' sweeps are done)
+                    order = np.argsort(-early_sums, kind="stable")
+                    v_early = sum(c1 - c0 for c0, c1 in eng.upload_panels[:-1]) * max(1, shard.world)
+                    lead = (early_sums[order[0]] - early_sums[order[1]]) if len(order) > 1 else np.inf
+                    eng.info["single_alpha_lead"] = float(lead / max(v_early, 1))     # mean score per voxel, best - second
+                    if np.isfinite(early_sums).all() and lead >= drv_opt.single_alpha_guess_margin * v_early:
+                        guessed = int(order[0])
+                        for st in sts:
+                            st = eng.fold_select(st, True)
+                            eng.fold_finish(st, scale)                           # (not the fold's last range: nothing pending)
+                        last = eng.fold_begin(*outer[0], prepared=first, step=(0, eng.upload_panels[-1]))
+                        sums = eng.fold_choose_joint(sts + [last], assign=[last]).cpu().numpy()
+                        if int(np.argsort(-sums, kind="stable")[0]) != guessed:
+                            raise _GuessMissed(f"alpha {alphas[guessed]:g} of the first {len(sts)} voxel panels, "
+                                               f"{alphas[int(np.argsort(-sums, kind='stable')[0])]:g} over all voxels")
+                        last = eng.fold_select(last, True)
+                        pending = eng.fold_finish(last, scale)
+                        eng.info["single_alpha_guess"] = "held"
+                        tail(pending)
+                        return eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan
+                    eng.info["single_alpha_guess"] = "not decisive"
+                    sts.append(eng.fold_begin(*outer[0], prepared=first, step=(0, eng.upload_panels[-1])))
+                else:
+                    sts += [eng.fold_begin(*outer[0], prepared=first, step=(0, c)) for c in eng.upload_panels[1:]]
                 for f in range(n):
                     eng.fold_choose_joint(sts)
                     nxt = None
@@ -428,7 +460,7 @@ class NestedCVModel(BasePredictivityModel):
         def run_(form):
             try:
                 return attempt(form, self.precision, X_all, Y_all)
-            except (_WideTargets, _PrimalUnsuitable):
+            except (_WideTargets, _PrimalUnsuitable, _GuessMissed):
                 raise                                   # handled below / by the caller: the engine lives on
             except BaseException:
                 # the fit is being abandoned (e.g. "Cholesky failed" from fold_collect in the last folds): finished weight
@@ -444,6 +476,15 @@ class NestedCVModel(BasePredictivityModel):
         def run(form):
             try:
                 return run_(form)
+            except _GuessMissed as why:
+                # single_alpha, host inputs: the early panels' alpha was not the alpha of all voxels -- once more, resident
+                eng = self._engine
+                logger.info("single-alpha guess missed (%s): the fit is repeated without it", why)
+                eng.abandon()                           # the early panels' weights may still be on their way to the host
+                torch.cuda.synchronize()
+                out = attempt(form, self.precision, _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
+                out[0].info["single_alpha_guess"] = "missed"
+                return out
             except _WideTargets as why:
                 # host inputs + precision "auto": a panel that arrived later is too wide for the fp16 split -- once, on
                 # the f32 MFMA path, with everything that is resident by now

@@ -1442,6 +1442,58 @@ def test_precision_policy(lc):
         assert g[0]["correlations"] == ref[0]["correlations"]
 
 
+def test_single_alpha_guess_from_the_early_panels(lc):
+    """Train/test fits with ONE alpha and host inputs: once every voxel panel but the last has been swept, those panels
+    are refitted with the alpha THEY choose and their weights leave for the host while the last panel is swept; the choice
+    over all voxels is checked afterwards.  Held, missed (the last panel holds the voxels that decide: the fit is repeated
+    without the guess) and not decisive (margin not reached: the old order) -- all three equal the fit without the guess,
+    bit for bit."""
+    from litcoder_core_amd import nested_cv as ncv
+    rng = np.random.default_rng(31)
+    T, p, V = 420, 64, 2048
+    X = rng.standard_normal((T + 80, p))
+    Wt = rng.standard_normal((p, V)) * 0.05
+    Y = X @ Wt + rng.standard_normal((T + 80, V))
+    kw = dict(folding_type="kfold", n_inner_folds=3, alphas=np.logspace(-1, 3, 5), single_alpha=True,
+              X_test=X[T:], y_test=Y[T:])
+
+    def fit(Yh, **opt):
+        m = lc.NestedCVModel("r", panel_cols=512, options=ncv.FitOptions(**opt))
+        out = m.fit_predict(X[:T], Yh[:T], **dict(kw, y_test=Yh[T:]))
+        return out, m.last_fit.get("single_alpha_guess")
+
+    ref, tag = fit(Y, single_alpha_guess=False)
+    assert tag is None
+    for opt, want in ((dict(single_alpha_guess_margin=0.0), "held"), (dict(single_alpha_guess_margin=10.0), "not decisive")):
+        got, tag = fit(Y, **opt)
+        assert tag == want, (tag, want)
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and got[0] == ref[0], want
+    # the last panel decides: the first three hold a weak signal along the design's largest directions (a large alpha wins
+    # there), the last one a strong signal along its smallest ones (a small alpha wins by far, and wins the mean)
+    panels, _ = lc.NestedCVModel("r", panel_cols=512)._panel_plan(V, V)
+    c_last = panels[-1][0]                                                 # first column of the last upload panel
+    assert len(panels) >= 3 and 0 < c_last < V
+    Xs = rng.standard_normal((T + 80, p)) * np.linspace(3.0, 0.05, p)
+    W_top = np.zeros((p, c_last)); W_top[:3] = rng.standard_normal((3, c_last)) * 0.03
+    W_low = np.zeros((p, V - c_last)); W_low[-24:] = rng.standard_normal((24, V - c_last)) * 60.0 * c_last / (V - c_last)
+    Y2 = rng.standard_normal((T + 80, V))
+    Y2[:, :c_last] += Xs @ W_top
+    Y2[:, c_last:] += Xs @ W_low
+    kw2 = dict(kw, X_test=Xs[T:])
+
+    def fit2(Yh, **opt):
+        m = lc.NestedCVModel("r", panel_cols=512, options=ncv.FitOptions(**opt))
+        out = m.fit_predict(Xs[:T], Yh[:T], **dict(kw2, y_test=Yh[T:]))
+        return out, m.last_fit.get("single_alpha_guess")
+
+    ref2, _ = fit2(Y2, single_alpha_guess=False)
+    early_only, _ = fit2(np.ascontiguousarray(Y2[:, :c_last]), single_alpha_guess=False)
+    assert early_only[2][0] != ref2[2][0], (early_only[2][0], ref2[2][0])      # (the premise: another alpha without the last panel)
+    got2, tag = fit2(Y2, single_alpha_guess_margin=0.0)
+    assert tag == "missed", tag
+    assert np.array_equal(got2[1], ref2[1]) and np.array_equal(got2[2], ref2[2]) and got2[0] == ref2[0]
+
+
 def test_baseline_shape_against_reference_fixture(lc, golden_dir):
     """BASELINE cfg2 (T=3000, p=3072, 20 alphas, 5 x 5 K-folds) against the REFERENCE ITSELF on 256 voxels
     (tests/golden/configs.npz: made in the build container by tests/golden/make_golden_configs.py, inputs rebuilt here
