@@ -520,9 +520,10 @@ class NestedCVModel(BasePredictivityModel):
             part = slice(*shard.bounds(V_total))
         if train_test:
             sig, padj = fold_sig[0]
+            # (the scalar summaries from the ARRAY the list was made of -- np.asarray of a list of 80 000 np.float32 scalars is
+            # a millisecond, twice, on the tail of the fit; same dtype rule: float64 when a Python 0.0 stands for a NaN)
             metrics = stats.train_test_metrics(fold_scores[0], fold_p[0], padj, sig, fold_alpha[0], np.sum(sig), part=part,
-                                               all_scores=None if part is None else
-                                               score_rows[0].astype(np.float64 if any_nan[0] else np.float32))
+                                               all_scores=score_rows[0].astype(np.float64 if any_nan[0] else np.float32))
             return metrics, weights_now(), fold_alpha[0] if part is None else fold_alpha[0][part]
 
         # np.mean(fold_scores, axis=0) of the reference (nested_cv.py:276): the nested lists hold np.float32

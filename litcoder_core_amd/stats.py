@@ -158,12 +158,18 @@ def train_test_metrics(correlations, pvalues, corrected, significant, best_alpha
     ``significant`` / ``n_significant`` are those of all voxels and feed the scalar summaries."""
     scores_all = correlations if all_scores is None else all_scores
     sl = slice(None) if part is None else part
-    m = _summary(scores_all)
-    m.update({"best_alphas": best_alphas[sl].tolist(), "correlations": correlations, "p_values": pvalues,
-              "corrected_p_values": corrected[sl].tolist(), "significant_mask": significant[sl].tolist(),
-              "n_significant": int(n_significant),
-              "percent_significant": float(n_significant / len(scores_all) * 100)})
-    _subset(m, scores_all, significant, n_significant, "significant")
+    big = len(scores_all) >= 20000 and isinstance(scores_all, np.ndarray)     # (as in full_cv_metrics below)
+    if big:
+        pool = _pool()
+        f_all = pool.submit(_summary, scores_all)
+        f_sig = pool.submit(_subset_values, scores_all, significant, n_significant, "significant")
+    lists = {"best_alphas": best_alphas[sl].tolist(), "correlations": correlations, "p_values": pvalues,
+             "corrected_p_values": corrected[sl].tolist(), "significant_mask": significant[sl].tolist(),
+             "n_significant": int(n_significant),
+             "percent_significant": float(n_significant / len(scores_all) * 100)}
+    m = f_all.result() if big else _summary(scores_all)
+    m.update(lists)
+    m.update(f_sig.result() if big else _subset_values(scores_all, significant, n_significant, "significant"))
     return m
 
 
