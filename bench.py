@@ -138,10 +138,13 @@ def measured_traffic(voxels, per_pass_timeout=240):
     atexit.register(_kill_children)
     old_term = signal.signal(signal.SIGTERM, lambda *a: (_kill_children(), sys.exit(143)))
     means = {}
+    clock = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        # (GRBM_GUI_ACTIVE and the SQ counter ride along in the FETCH_SIZE pass: GRBM / SQ slots are independent of the
+        # TCC's, MI355X_MICROARCH.md "rocprofv3 PMC slots"; counters only, no other trace domain)
+        for counter, extra in (("FETCH_SIZE", ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"]), ("WRITE_SIZE", [])):
             out = os.path.join(work, counter)
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+            cmd = [exe, "--kernel-trace", "--pmc", counter, *extra, "--output-format", "csv", "-d", out, "--",
                    sys.executable, child, "1", str(voxels)]
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                     preexec_fn=_die_with_parent)
@@ -158,11 +161,30 @@ def measured_traffic(voxels, per_pass_timeout=240):
             if rc != 0:
                 return None, f"not measured: the {counter} pass exited with code {rc}"
             rows = []
+            per_dispatch = {}
             for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
                     for row in csv.DictReader(f):
-                        if row.get("Counter_Name") == counter and "k_sweep_f16x3<true" in row.get("Kernel_Name", ""):
+                        if "k_sweep_f16x3<true" not in row.get("Kernel_Name", ""):
+                            continue
+                        if row.get("Counter_Name") == counter:
                             rows.append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+                        elif row.get("Counter_Name") in extra:
+                            d = per_dispatch.setdefault(row["Dispatch_Id"], {"grid": int(row["Grid_Size"])})
+                            d[row["Counter_Name"]] = float(row["Counter_Value"])
+                            d["ns"] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            if extra:
+                # the clock the chip holds under the dominant kernel: GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                # (MI355X_MICROARCH.md "DVFS give-back"); the matrix pipe's busy share of those cycles over 1024 SIMDs
+                full_grid = max((d["grid"] for d in per_dispatch.values()), default=0)
+                ds = [d for d in per_dispatch.values() if d.get("ns", 0) > 0 and "GRBM_GUI_ACTIVE" in d]
+                for tag, sel in (("all", ds), ("full_width", [d for d in ds if d["grid"] == full_grid])):
+                    if sel:
+                        cyc = sum(d["GRBM_GUI_ACTIVE"] for d in sel) / 8.0
+                        ns = sum(d["ns"] for d in sel)
+                        busy = sum(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for d in sel)
+                        clock[tag] = {"ghz": cyc / ns, "launches": len(sel), "avg_launch_ms_in_pmc_pass": 1e-6 * ns / len(sel),
+                                      "mfma_pipe_busy": busy / (1024.0 * cyc) if cyc > 0 and busy > 0 else None}
             if not rows:
                 return None, f"not measured: no k_sweep_f16x3 launch in the {counter} pass"
             full = max(g for g, _ in rows)
@@ -173,7 +195,8 @@ def measured_traffic(voxels, per_pass_timeout=240):
         shutil.rmtree(work, ignore_errors=True)
     fa, na, ff, nf = means["FETCH_SIZE"]
     wa, nwa, wf, nwf = means["WRITE_SIZE"]
-    res = {"all": fa * 1024 * 2 + wa * 1024, "full_width": ff * 1024 * 2 + wf * 1024, "launches": na, "launches_full_width": nf}
+    res = {"all": fa * 1024 * 2 + wa * 1024, "full_width": ff * 1024 * 2 + wf * 1024, "launches": na, "launches_full_width": nf,
+           "clock": clock or None}
     return res, (f"measured in this run, before the timed fits: child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` "
                  f"and `--pmc WRITE_SIZE` over one host-to-host fit (tools/host_fit_loop.py), mean over its {na} fused "
                  f"launches of all widths (the population avg_launch_ms averages over): FETCH_SIZE {fa:.0f} KiB x2 (gfx950 "
@@ -229,17 +252,18 @@ CFG3_TRIM = {"train_features_start": 10, "train_features_end": -5, "train_target
 CFG3_KW = dict(folding_type="kfold", n_inner_folds=5, chunk_length=20, single_alpha=True, normalpha=True, use_corr=True)
 
 
-def synth_stories(V, dev, seed=0, n_train=26, D=768):
+def synth_stories(V, dev, seed=0, n_train=26, D=768, rank=0):
     """BASELINE configs[2] as synthetic data: 26 training stories + 1 test story of 260-440 TRs (T ~ 9000), per story
     word-level 768-d float32 features (AR(1)-smoothed, ~3.6 words/s) at irregular word times, TR times (15 more feature
     TRs than brain TRs: LeBel trimming [10:-5]) and float64 brain data of V voxels in pageable host memory =
     (z-scored delayed features) W + noise, un-normalised like BOLD data (3 y + 100).  Made on the device (data synthesis
-    only; the Lanczos / FIR kernels used here are the product's own)."""
+    only; the Lanczos / FIR kernels used here are the product's own).  ``rank``: the stories (lengths, word times, word
+    features) are the same on every rank of a sharded run, the V voxels (true weights, noise) are the rank's own."""
     from litcoder_core_amd import Downsampler, ops
     rng = np.random.default_rng(seed)
     n_trs = [int(n) for n in rng.integers(260, 440, n_train)] + [291]
     g = torch.Generator(device=dev)
-    g.manual_seed(seed + 1)
+    g.manual_seed(seed + 1 + 7919 * int(rank))
     Wtrue = 0.004 * torch.randn((4 * D, V), generator=g, device=dev, dtype=torch.float32)
     words, wtimes, trtimes, brain = {}, {}, {}, {}
     for i, n_tr in enumerate(n_trs):
@@ -313,14 +337,19 @@ def cfg3_cpu_baseline(words, wtimes, trtimes, brain, v_sample=1500):
                        f"as t_fixed + t_prop*V/{v_sample} = {t_full:.0f}s")}
 
 
-def cfg3_leg(V, dev, steps=5, warmup=2, cpu=True):
+def cfg3_leg(V_total, dev, steps=5, warmup=2, cpu=True, shard=None, world=1, rank=0):
     """BASELINE configs[2] end to end, host to host: per-story word features + float64 brain data in pageable host memory ->
     Lanczos -> 4 FIR delays -> trim + per-story zs -> train/test nested-CV fit (example.py:104-117: K-folds, default
-    10-alpha grid, single_alpha) -> metrics + float32 host weights, through harness.StoryPipeline.fit_words."""
+    10-alpha grid, single_alpha) -> metrics + float32 host weights, through harness.StoryPipeline.fit_words.
+    ``world`` > 1: the V_total voxels split over the ranks (every rank holds its own block of the brain data,
+    ``local_targets``; the per-alpha sums all-reduced, nested_cv.py:396-400), barrier + MAX over ranks like the headline."""
     from litcoder_core_amd import NestedCVModel, StoryPipeline, ops
-    words, wtimes, trtimes, brain = synth_stories(V, dev)
+    from litcoder_core_amd.dist import shard_bounds
+    lo, hi = shard_bounds(V_total, world, rank)
+    V = hi - lo
+    words, wtimes, trtimes, brain = synth_stories(V, dev, rank=rank)
     names = list(words)
-    model = NestedCVModel("ridge_regression")
+    model = NestedCVModel("ridge_regression", shard=shard, local_targets=world > 1)
     pipe = StoryPipeline([1, 2, 3, 4], CFG3_TRIM, model=model)
 
     def step():
@@ -328,14 +357,28 @@ def cfg3_leg(V, dev, steps=5, warmup=2, cpu=True):
         torch.cuda.synchronize()
         return out
 
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
+    fence()
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(steps):
         out = None
+        ts = time.perf_counter()
         out = step()
+        step_ms.append(1e3 * (time.perf_counter() - ts))
+    fence()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
     # per-kernel ms from ONE more fit with the library's event timers on (two event records per launch: they stay out of
     # the timed fits above)
     ops.timing_enable(True)
@@ -365,11 +408,13 @@ def cfg3_leg(V, dev, steps=5, warmup=2, cpu=True):
     ms = 1e3 * elapsed / steps
     fit = dict(model.last_fit)
     leg = {
-        "value": V * steps / elapsed, "unit": "voxels/sec", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+        "value": V_total * steps / elapsed, "unit": "voxels/sec", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+        "ms_per_step_distribution": step_stats(step_ms, V_total),
+        "n_gpus": world, "scaling": "strong" if world > 1 else None, "voxels_total": V_total, "voxels_rank0": V,
         "workload": (f"cfg3 synthetic LeBel-like: {len(names) - 1} training stories + 1 test story (T={T} / {Tt} TRs after "
                      f"trimming), word-level 768-d float32 features -> Lanczos(window 3) -> 4 FIR delays (p={p}) -> per-story zs "
-                     f"-> train/test fit, V={V}, 10 alphas logspace(-1,8), 5 inner K-folds, single_alpha, normalpha, corr "
-                     f"(example.py:104-117)"),
+                     f"-> train/test fit, V={V_total}" + (f" in total over {world} GPUs" if world > 1 else "")
+                     + ", 10 alphas logspace(-1,8), 5 inner K-folds, single_alpha, normalpha, corr (example.py:104-117)"),
         "inputs": "per-story float32 word features + float64 brain data in pageable host memory -> metrics dict + float32 "
                   "host weights (harness.StoryPipeline.fit_words); every step fenced",
         "form": model.last_form, "arithmetic": fit.get("precision"), "chosen_alpha": float(out[2][0]),
@@ -377,8 +422,9 @@ def cfg3_leg(V, dev, steps=5, warmup=2, cpu=True):
         "link": {"host_brain_bytes_float64": int(sum(b.nbytes for b in brain.values())), "h2d_bytes_float32": int(up),
                  "d2h_bytes": int(down), "measured_h2d_GBps": rates[0] / 1e9, "measured_d2h_GBps": rates[1] / 1e9,
                  "link_floor_ms": floor_ms, "ms_per_step_over_link_floor": ms / floor_ms,
-                 "note": "link_floor = max(up bytes / H2D rate, down bytes / D2H rate): what the transfers alone take on this "
-                         "box; the fit's V-wide MFMA work at this shape is several times that (DESIGN.md 5b)"},
+                 "note": "link_floor = max(up bytes / H2D rate, down bytes / D2H rate) of RANK 0's voxel block: what the "
+                         "transfers alone take on this box; the fit's V-wide MFMA work at this shape is several times that "
+                         "(DESIGN.md 5b)"},
         "sweep_flops_per_step": {"fused": fit.get("fused_flops"), "plain": fit.get("plain_flops")},
         "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(kern.items())},
     }
@@ -417,12 +463,14 @@ def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, 
         # ~900 launches of a fit cost the headline 4 % (145 ms where an untimed loop of the same fits took 139.5)
         ops.timing_enable(True, only=["alpha_sweep_gemm"] if collect_kernels == "sweep" else None)
         ops.timing_read()
-    flops = {"plain": 0.0, "fused": 0.0, "fused_launches": 0}
+    flops = {"plain": 0.0, "fused": 0.0, "fused_launches": 0, "step_ms": []}
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = None                                           # the previous step's weights are released first
+        ts = time.perf_counter()
         out = step()
+        flops["step_ms"].append(1e3 * (time.perf_counter() - ts))     # this rank's own (host) view of each step
         flops["plain"] += model.last_fit.get("plain_flops", 0.0)
         flops["fused"] += model.last_fit.get("fused_flops", 0.0)
         flops["fused_launches"] += model.last_fit.get("fused_launches", 0)
@@ -470,6 +518,17 @@ def parity_of(res16, res32, dev):
                     "ties against the oracle)"}
 
 
+def step_stats(step_ms, voxels):
+    """min / median / max of the timed steps as rank 0's host saw them (every host-to-host step is fenced, so a step's time is
+    one call's latency), and the rate at the median step: a slow outlier step moves `value` (total / total), not this."""
+    if not step_ms:
+        return None
+    a = np.sort(np.asarray(step_ms, dtype=np.float64))
+    med = float(np.median(a))
+    return {"min": float(a[0]), "median": med, "max": float(a[-1]), "steps": int(len(a)),
+            "value_at_median_step": voxels / (1e-3 * med), "unit": "ms; voxels/sec"}
+
+
 def sweep_roofline(sweep, kern, flops, steps, split):
     """roofline object of the fused alpha-sweep kernel from the library's HIP events around its launches (on the launch
     stream) and the algorithmic flops the engine counted for them."""
@@ -497,7 +556,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--voxels", type=int, default=80000,
                     help="voxels per GPU (weak scaling) / voxels in total (strong scaling)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1: 'strong' (default) = --voxels IN TOTAL split over the ranks -- the job BASELINE.json's configs "
+                         "name (80 000 voxels); 'weak' = --voxels per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip host_path / f32_path / other_scaling")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg3_pipeline leg (N = 1 only)")
@@ -509,6 +570,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.scaling is None:
+        # BASELINE.json's configs fix the job (80 000 voxels in total): at N > 1 the headline is that job split over the
+        # ranks; the weak-scaled job (80 000 voxels PER rank, a volume no config names) goes to `other_scaling`
+        args.scaling = "weak" if world == 1 else "strong" 
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -565,6 +630,16 @@ def main():
         e2, r2, _, _ = timed_fits(model, dX, dY, p, V2, V2_total, alphas, args.steps, args.warmup, world, dev, host=host)
         other = {"scaling": mode2, "value": V2_total * args.steps / e2, "unit": "voxels/sec",
                  "ms_per_step": 1e3 * e2 / args.steps, "voxels_total": V2_total, "median_score": r2[0]["median_score"]}
+    cfg3_sharded = None
+    if world > 1 and not args.no_extra_legs and not args.no_cfg3:
+        # BASELINE configs[2] -- the config north_star's >= 6x-at-8-GPUs sentence is on -- strong-scaled: the story pipeline on
+        # every rank's block of the 80 000 voxels (every rank calls: the leg is collective)
+        try:
+            del dX, dY, host
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        cfg3_sharded = cfg3_leg(args.voxels, dev, cpu=False, shard=shard, world=world, rank=rank)
 
     if rank == 0:
         split = sweep["precision"] == "f16x3"
@@ -607,16 +682,34 @@ def main():
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_population": "bytes per launch averaged over the same launches avg_launch_ms averages over",
             "plain_launches_same_kernel": plain})
+        clk = (live_traffic[0] or {}).get("clock") if live_traffic is not None else None
+        if clk and clk.get("all") and roof.get("frac"):
+            # what the box's clock explains of a run-to-run difference: the same kernel on a chip that holds a lower clock
+            # under it reads a lower `frac`; against the peak AT THE CLOCK HELD the figure should not move
+            ghz = clk["all"]["ghz"]
+            roof.update({
+                "clock_ghz": ghz, "mfma_pipe_busy": clk["all"]["mfma_pipe_busy"],
+                "roofline_at_clock": roof["frac"] * 2.4 / ghz,
+                "mfma_issue_frac_at_clock": (roof["mfma_issue_frac"] * 2.4 / ghz) if roof.get("mfma_issue_frac") else None,
+                "clock_full_width_launches": clk.get("full_width"),
+                "clock_source": "GRBM_GUI_ACTIVE / 8 / dispatch duration of this kernel's launches in the FETCH_SIZE child pass "
+                                "of this run (counters serialise the dispatches: the kernel runs alone there; a profiled pass "
+                                "holds 2-3 % less clock than an un-profiled one); roofline_at_clock = frac x 2.4 GHz / clock_ghz "
+                                "= fraction of the fp16 MFMA peak at the clock the chip holds under this kernel; "
+                                "mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x those cycles)"})
         renamed = {"batch_chol_solve": "batch_chol_solve_stream_ms_incl_waits_for_cus"}
         out = {
             "metric": "voxels/sec full nested-CV ridge fit (LeBel UTS03, GPT-2 768x4 delays, ~80k voxels)",
             "value": V_total * args.steps / elapsed, "unit": "voxels/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "ms_per_step_distribution": step_stats(flops["step_ms"], V_total),
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f16x3+f32acc (fp16 hi+lo operands, fp32 accumulate; Gram/Cholesky in f64)" if split
                      else "f32 (Gram/Cholesky in f64)", "data": "synthetic",
             "config": {"workload": f"cfg2 synthetic T={T} F={F0}x{len(DELAYS)} delays (p={p}) "
-                                   + (f"V={args.voxels}/GPU" if args.scaling == "weak" else f"V={args.voxels} in total")
+                                   + (f"V={args.voxels}/GPU" if args.scaling == "weak"
+                                      else f"V={args.voxels} in total" + (f" split over {world} GPUs (BASELINE configs[1] strong-scaled)"
+                                                                          if world > 1 else ""))
                                    + f" A={A} alphas {N_OUTER}x{N_INNER} kfold, per-voxel alpha, normalpha, corr",
                        "voxels_total": V_total, "voxels_rank0": V,
                        "inputs": "float64 numpy features/targets in pageable host memory -> metrics dict + float32 host "
@@ -629,11 +722,14 @@ def main():
         }
         if other is not None:
             out["other_scaling"] = other
+        if cfg3_sharded is not None:
+            out["cfg3_pipeline"] = cfg3_sharded
         if world == 1 and not args.no_extra_legs:
             del host
             e_res, r_res, k_res, f_res = timed_fits(model, dX, dY, p, V, V_total, alphas, 3, 1, 1, dev, collect_kernels="sweep")
             roof_res = sweep_roofline(dict(model.last_fit), k_res, f_res, 3, split)
             out["resident_path"] = {"value": V * 3 / e_res, "unit": "voxels/sec", "ms_per_step": 1e3 * e_res / 3, "steps": 3,
+                                    "ms_per_step_distribution": step_stats(f_res["step_ms"], V),
                                     "what": "fp32 inputs resident in HBM, weights left resident (the headline of rounds 1-2)",
                                     "median_score": r_res[0]["median_score"],
                                     "roofline_full_width_launches": dict(

@@ -60,9 +60,9 @@ __global__ void __launch_bounds__(256) k_fill_argmax(const double* __restrict__ 
                                                      long long V) {
     int k = 0;
     double m = rowsum[0];
-    for (int a = 1; a < A; ++a) {                       // first maximum, like torch.argmax; NaN never wins
-        const double x = rowsum[a];
-        if (x > m) { m = x; k = a; }
+    for (int a = 1; a < A; ++a) {                       // first maximum, like torch.argmax; NaN never wins -- not
+        const double x = rowsum[a];                     // as the seed either (all NaN: index 0)
+        if (x > m || (m != m && x == x)) { m = x; k = a; }
     }
     const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
     if (v < V) best[v] = k;

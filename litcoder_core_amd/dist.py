@@ -72,6 +72,7 @@ class ShardContext:
         self._cpu_direct = "gloo" in raw or "mpi" in raw
         self.backend = ("nccl" if raw == "nccl" else "gloo" if raw == "gloo" else raw) if self._dist else None
         self.simulate = False
+        self.bytes_received = 0                        # payload of the all-gathers so far (what the wire carries INTO this rank)
         self.global_lists = bool(global_lists)
         self.always = bool(always_collective) and self._dist is not None
         # Collectives of one communicator execute in issue order on its one internal stream.  The operator all-gathers
@@ -100,7 +101,7 @@ class ShardContext:
         """A one-rank context that ignores any initialised process group (what a model without ``shard=`` runs in)."""
         ctx = cls.__new__(cls)
         ctx._dist, ctx.group, ctx.device, ctx.rank, ctx.world, ctx.backend = None, None, device, 0, 1, None
-        ctx.simulate, ctx.always, ctx._lanes, ctx.global_lists = False, False, {}, True
+        ctx.simulate, ctx.always, ctx._lanes, ctx.global_lists, ctx.bytes_received = False, False, {}, True, 0
         ctx._cuda_direct, ctx._cpu_direct = False, False
         return ctx
 
@@ -140,6 +141,7 @@ class ShardContext:
         if not self.active:
             return t.unsqueeze(0)
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.bytes_received += (self.world - 1) * t.numel() * t.element_size()
         if self.simulate:
             out.copy_(t.unsqueeze(0).expand_as(out))
             return out

@@ -40,9 +40,11 @@ class FitOptions:
                                             # their weights home while the last panel is swept (0.98 GB at the LeBel shape:
                                             # 17 ms of PCIe that followed the last sweep); the choice over ALL voxels is then
                                             # checked against it -- another alpha: the fit is repeated without the guess
-    single_alpha_guess_margin: float = 1e-4  # ... only when the early panels' best alpha leads the second best by this
-                                            # much in mean score per voxel (the LeBel-shaped bench data: 2.1e-4; the last
-                                            # panel, 15 % of the voxels, would have to average six times that the other way)
+    single_alpha_guess_margin: float = 2e-5  # ... only when the early panels' best alpha leads the second best by this
+                                            # much in mean score per voxel and inner fold (the LeBel-shaped bench data:
+                                            # 4.2e-5; the last panel, 15 % of the voxels, would have to average six times
+                                            # that the other way.  Until round 4 the value read 1e-4 and was compared with
+                                            # the lead SUMMED over the five inner folds: the same gate, in its real unit)
     refit_fused_pearson: bool = True        # test predictions reduced to Pearson r in the contraction's epilogue (fp16x3
                                             # path): never stored, lc_pearson_cols never reads them back (SURVEY K8 + K9)
     refit_by_inverse: bool = True           # refit operators through the explicit inverse + one fp16x3 product

@@ -107,13 +107,21 @@ class StoryPipeline:
       panel, while the fit already works on the panels that have landed.
 
     The result equals ``NestedCVModel.fit_predict`` on the matrices ``structure_train_test`` / the reference's trainer
-    builds, bit for bit given the same design (tests/test_gpu_configs.py)."""
+    builds, bit for bit given the same design (tests/test_gpu_configs.py).
+
+    Voxel shards (round 5): with ``model = NestedCVModel(..., shard=ShardContext(...))`` every rank runs the same
+    pipeline on ITS block of voxel columns -- the features (V-independent, ~1 ms of kernels) are resampled and stacked on
+    every rank, each rank's uploader stages and z-scores only its own columns of every story (a rank's share of the link
+    and of the host's z-scoring is V / G), the fit's collectives are those of DESIGN.md 6 (``single_alpha``: the per-alpha
+    sums all-reduced, nested_cv.py:396-400) -- and returns the metrics of ALL voxels with its own block of the weights,
+    bit-identical to the one-GPU pipeline (tests/test_gpu_shards.py)."""
 
     def __init__(self, fir_delays: Sequence[int], trimming: dict, model: Optional[NestedCVModel] = None):
         self.fir_delays = [int(d) for d in fir_delays]
         self.trimming = dict(trimming)
         self.model = model or NestedCVModel("ridge_regression")
         self.last_design = None                        # (dX, T, Tt, p) of the most recent fit (tests)
+        self._V_total = None                           # voxels of the whole job (all shards) of the fit being set up
 
     # ---------------------------------------------------------------- features
     def _feature_rows(self, features):
@@ -159,13 +167,32 @@ class StoryPipeline:
         ops.story_design(feat, off[:-1], n_in, a, b, row0, self.fir_delays, dX)
         return dX, T, Tt, p, rows
 
-    def _targets(self, brain, names, rows):
-        """The brain data's trimmed story blocks as the fit's host targets (z-scored in the upload threads)."""
+    def _voxel_block(self, brain, names):
+        """(lo, hi, V_total): this rank's block of voxel columns of the stories' brain arrays and the voxel count of the
+        whole job.  One GPU: everything.  Voxel shards (``NestedCVModel(shard=...)``): ``brain`` holds all voxels and the
+        rank takes columns [lo, hi) of every story as views -- z-scoring is per voxel (utils.zs, trainer.py:235-257), so a
+        rank's columns are the reference's whatever the other ranks hold -- or, with ``local_targets``, ``brain`` holds the
+        rank's own block already and the total is the sum over the ranks (one all-reduce before the fit, as
+        NestedCVModel.fit_predict does)."""
+        shard = self.model.shard
+        V = int(np.shape(brain[names[0]])[1])
+        if shard is None or shard.world == 1:
+            return 0, V, V
+        if self.model.local_targets:
+            mine = np.zeros(shard.world)
+            mine[shard.rank] = V
+            return 0, V, int(round(shard.allreduce_sum(mine).sum()))
+        lo, hi = shard.bounds(V)
+        return lo, hi, V
+
+    def _targets(self, brain, names, rows, lo=0, hi=None):
+        """The brain data's trimmed story blocks (columns [lo, hi): this rank's voxels) as the fit's host targets
+        (z-scored in the upload threads)."""
         g = self.trimming.get
         blocks = []
         for i, s in enumerate(names):
             kind = "train" if i < len(names) - 1 else "test"
-            blk = np.asarray(brain[s])[g(f"{kind}_targets_start", 0):g(f"{kind}_targets_end", None)]
+            blk = np.asarray(brain[s])[g(f"{kind}_targets_start", 0):g(f"{kind}_targets_end", None), lo:hi]
             if blk.shape[0] < 1:
                 raise ValueError("a story is empty after trimming")
             if blk.shape[0] != rows[i]:
@@ -208,10 +235,12 @@ class StoryPipeline:
         if len(names) < 2:
             raise ValueError("the train/test paradigm needs at least two stories")
         a, b = self._trimmed_rows(n_in, names)
-        return self.model.start_targets(self._targets(brain, names, np.asarray(b) - np.asarray(a)), lead=lead)
+        lo, hi, self._V_total = self._voxel_block(brain, names)
+        return self.model.start_targets(self._targets(brain, names, np.asarray(b) - np.asarray(a), lo, hi),
+                                        n_voxels_total=self._V_total, lead=lead)
 
     def _fit_rows(self, feat, off, n_in, names, flying, model_kwargs):
         dX, T, Tt, p, _ = self.design(feat, off, n_in, names)
         self.last_design = (dX, T, Tt, p)
-        return self.model.fit_predict_device(dX, flying, p, flying.shape[1], n_test_rows=Tt, weights_on_host=True,
-                                             **model_kwargs)
+        return self.model.fit_predict_device(dX, flying, p, flying.shape[1], n_voxels_total=self._V_total, n_test_rows=Tt,
+                                             weights_on_host=True, **model_kwargs)

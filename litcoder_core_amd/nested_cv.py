@@ -295,9 +295,13 @@ class NestedCVModel(BasePredictivityModel):
             # the hat matrices of all folds (aux) and the refit operators of every fold for every factorised alpha (aux2,
             # refit_ahead: explicit inverses, cheap enough to form for alphas nobody will choose); the V-wide phases then
             # find the chip to themselves (fp64 chains beside the MFMA sweeps cost a resident fit ~20 of 137 ms)
-            hosted = getattr(eng, "uploader", None) is not None and shard.world == 1
+            arriving = getattr(eng, "uploader", None) is not None        # host targets, crossing the link panel by panel
+            hosted = arriving and shard.world == 1
             ahead = shard.world > 1 or (hosted and eng.refit_ahead_pays())
-            if (single_alpha and hosted and len(eng.upload_panels) > 1 and hasattr(eng, "fold_choose_joint")):
+            # (voxel shards, round 5: the panelled single-alpha path below runs on every rank alike -- each rank's block is cut
+            # into the SAME number of panels (_panel_plan: v_ref), the per-alpha sums are all-reduced inside fold_choose_joint,
+            # and everything the host decides from them it decides from the all-reduced values)
+            if (single_alpha and arriving and len(eng.upload_panels) > 1 and hasattr(eng, "fold_choose_joint")):
                 # ---- single_alpha with host inputs (example.py:104-117, the LeBel-style train/test call): the choice needs
                 # the scores of ALL voxels, but not their sweeps at once -- every fold's sweeps run range by range (the first
                 # fold's as the upload panels land, instead of after the last one: ~55 ms of PCIe at cfg3's 2.9 GB), the
@@ -324,16 +328,23 @@ class NestedCVModel(BasePredictivityModel):
                     sts += [eng.fold_begin(*outer[0], prepared=first, step=(0, c)) for c in eng.upload_panels[1:-1]]
                     early_sums = eng.fold_choose_joint(sts).cpu().numpy()        # (host: these panels' sweeps are done)
                     order = np.argsort(-early_sums, kind="stable")
+                    # the sums run over the voxels of the early panels of ALL ranks (every rank's panels but the last have
+                    # the plan's widths: _column_panels, v_ref) and over the inner folds that were scored (the scores of a
+                    # step are accumulated over them) -- the lead is quoted per voxel AND per inner fold
                     v_early = sum(c1 - c0 for c0, c1 in eng.upload_panels[:-1]) * max(1, shard.world)
+                    n_scored = max(1, int(first["hat"].get("F", 1)))
                     lead = (early_sums[order[0]] - early_sums[order[1]]) if len(order) > 1 else np.inf
-                    eng.info["single_alpha_lead"] = float(lead / max(v_early, 1))     # mean score per voxel, best - second
-                    if np.isfinite(early_sums).all() and lead >= drv_opt.single_alpha_guess_margin * v_early:
+                    eng.info["single_alpha_lead"] = float(lead / (max(v_early, 1) * n_scored))   # mean score, best - second
+                    if np.isfinite(early_sums).all() and lead >= drv_opt.single_alpha_guess_margin * v_early * n_scored:
                         guessed = int(order[0])
                         for st in sts:
                             st = eng.fold_select(st, True)
                             eng.fold_finish(st, scale)                           # (not the fold's last range: nothing pending)
                         last = eng.fold_begin(*outer[0], prepared=first, step=(0, eng.upload_panels[-1]))
                         sums = eng.fold_choose_joint(sts + [last], assign=[last]).cpu().numpy()
+                        if not np.isfinite(sums).all():
+                            # (the host's argsort and the device's first-maximum rule part ways on a NaN: no shortcut then)
+                            raise _GuessMissed("non-finite score sums over all voxels")
                         if int(np.argsort(-sums, kind="stable")[0]) != guessed:
                             raise _GuessMissed(f"alpha {alphas[guessed]:g} of the first {len(sts)} voxel panels, "
                                                f"{alphas[int(np.argsort(-sums, kind='stable')[0])]:g} over all voxels")
@@ -457,9 +468,10 @@ class NestedCVModel(BasePredictivityModel):
             tail(pending)
             return eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan
 
-        def run_(form):
+        def run_(form, precision=None, X_in=None, Y_in=None):
             try:
-                return attempt(form, self.precision, X_all, Y_all)
+                return attempt(form, self.precision if precision is None else precision, X_all if X_in is None else X_in,
+                               Y_all if Y_in is None else Y_in)
             except (_WideTargets, _PrimalUnsuitable, _GuessMissed):
                 raise                                   # handled below / by the caller: the engine lives on
             except BaseException:
@@ -473,16 +485,17 @@ class NestedCVModel(BasePredictivityModel):
                 self._engine = None
                 raise
 
-        def run(form):
+        def run(form, X_in=None, Y_in=None):
             try:
-                return run_(form)
+                return run_(form, None, X_in, Y_in)
             except _GuessMissed as why:
                 # single_alpha, host inputs: the early panels' alpha was not the alpha of all voxels -- once more, resident
                 eng = self._engine
                 logger.info("single-alpha guess missed (%s): the fit is repeated without it", why)
                 eng.abandon()                           # the early panels' weights may still be on their way to the host
                 torch.cuda.synchronize()
-                out = attempt(form, self.precision, _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
+                # (through the guard as well: a failure of the repeated fit must drain ITS weight panels too -- ADVICE r4)
+                out = run_(form, self.precision, _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
                 out[0].info["single_alpha_guess"] = "missed"
                 return out
             except _WideTargets as why:
@@ -492,7 +505,7 @@ class NestedCVModel(BasePredictivityModel):
                 logger.info("%s: the fit is repeated on the f32 MFMA path", why)
                 eng.finish_uploads()
                 torch.cuda.synchronize()
-                return attempt(form, "f32", _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
+                return run_(form, "f32", _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
 
         try:
             eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = run(self.form)
@@ -502,8 +515,8 @@ class NestedCVModel(BasePredictivityModel):
             logger.info("primal form not used (%s): dual form", why)
             prev = self._engine
             prev.finish_uploads()
-            eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = attempt(
-                "dual", self.precision, _DeviceShapes(prev.dX, prev.p), _DeviceShapes(prev.dY_full, prev.V_rank))
+            eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = run(
+                "dual", _DeviceShapes(prev.dX, prev.p), _DeviceShapes(prev.dY_full, prev.V_rank))
         self._engine = None
         self.last_form = "primal" if eng.primal else "dual"
         self.last_fit = dict(getattr(eng, "info", {}), form=self.last_form, panels=self._plan)

@@ -796,6 +796,10 @@ def test_device_statistics_tail_matches_host(lc):  # noqa: C901
     best = torch.empty(77, dtype=torch.int32, device=dev)                # single_alpha: argmax of the all-reduced sums
     ops.fill_argmax(torch.tensor([0.5, np.nan, 2.0, 2.0, -1.0], dtype=torch.float64, device=dev), 5, best, 77)
     assert best.cpu().unique().tolist() == [2]                           # first maximum, NaN never wins
+    ops.fill_argmax(torch.tensor([np.nan, 0.5, 2.0, np.nan, 2.0], dtype=torch.float64, device=dev), 5, best, 77)
+    assert best.cpu().unique().tolist() == [2]                           # ... not as the seed either
+    ops.fill_argmax(torch.tensor([np.nan, np.nan], dtype=torch.float64, device=dev), 2, best, 77)
+    assert best.cpu().unique().tolist() == [0]
 
 
 def test_block_product_kernels_against_numpy(lc):

@@ -73,6 +73,44 @@ for name, kw in cases.items():
             assert model.last_fit["precision"] == "f32", "every rank falls back together"
         kw_tt = {k: v for k, v in kw.items() if k != "n_outer_folds"}
         out[name, prec, "tt"] = model.fit_predict(Xc[:330], Yc[:330], X_test=Xc[330:], y_test=Yc[330:], **kw_tt)
+# ---- the story pipeline (harness.StoryPipeline.fit_words: BASELINE configs[2]'s route) under the same shard context: word
+# features -> Lanczos -> FIR -> per-story zs -> train/test fit in the primal form with shared series terms (p_pad = 256,
+# 2 p <= the inner training sets), the brain data of every rank's voxel block z-scored in ITS upload threads, panel by
+# panel (panel_cols = 256: 3-4 upload panels per rank); single_alpha (the per-alpha sums of all panels and all ranks
+# added on the device, the early panels refitted with the alpha they choose) and per-voxel alpha; ``local_targets``:
+# every rank is handed its own block of the brain data only
+from litcoder_core_amd import StoryPipeline
+rs = np.random.default_rng(11)
+Vs_, D = 2600, 64
+n_trs = [150, 170, 160, 180, 165, 175, 155, 120]
+Wt = rs.standard_normal((4 * D, Vs_)) * 0.05 * rs.uniform(0.0, 2.0, Vs_)
+words, wtimes, trtimes, brain = {}, {}, {}, {}
+for i, n_tr in enumerate(n_trs):
+    nm = "s%d" % i
+    nw = int(6.5 * n_tr)
+    wtimes[nm] = np.sort(rs.uniform(0, 2.0 * (n_tr + 15), nw))
+    emb = rs.standard_normal((nw, D)).astype(np.float32)
+    emb[1:] = 0.6 * emb[:-1] + 0.8 * emb[1:]
+    words[nm] = emb
+    trtimes[nm] = 1.0 + 2.0 * np.arange(n_tr + 15)
+    brain[nm] = 3.0 * (rs.standard_normal((n_tr, 4 * D)) @ Wt + rs.standard_normal((n_tr, Vs_))) + 100.0
+brain["s2"][:, 9] = 7.0                            # a voxel that is constant within one story
+TRIM = {"train_features_start": 10, "train_features_end": -5, "train_targets_start": 0, "train_targets_end": None,
+        "test_features_start": 10, "test_features_end": -5, "test_targets_start": 0, "test_targets_end": None}
+slo, shi = (shard.bounds(Vs_) if shard else (0, Vs_))
+out["story_lo"], out["story_hi"] = slo, shi
+for name, kw, local in (("story_single", dict(single_alpha=True), False), ("story_pervoxel", dict(single_alpha=False), False),
+                        ("story_single_local", dict(single_alpha=True), True)):
+    model = NestedCVModel("r", shard=shard, panel_cols=256, local_targets=local)
+    pipe = StoryPipeline([1, 2, 3, 4], TRIM, model=model)
+    data = {k: v[:, slo:shi] for k, v in brain.items()} if (local and shard is not None) else brain
+    out["story", name] = pipe.fit_words(words, wtimes, trtimes, data, folding_type="kfold", n_inner_folds=5,
+                                        alphas=np.logspace(-1, 8, 10), **kw)
+    assert model.last_form == "primal" and model.last_fit["series_terms"] == 4, model.last_fit
+    assert len(model.last_fit["panels"]) >= 3, model.last_fit["panels"]
+    if kw["single_alpha"]:
+        assert model.last_fit.get("single_alpha_guess") in ("held", "not decisive"), model.last_fit
+    out["story_info", name] = {k: model.last_fit.get(k) for k in ("single_alpha_guess", "single_alpha_lead", "panels")}
 tag = "single" if backend == "none" else f"{backend}{world}_rank{shard.rank}"
 pickle.dump(out, open(os.path.join(out_dir, tag + ".pkl"), "wb"))
 if shard is not None:
@@ -121,12 +159,13 @@ def test_two_real_engine_ranks_on_one_gpu_equal_the_unsharded_fit(runs):
     assert (ranks[0]["lo"], ranks[0]["hi"], ranks[1]["lo"], ranks[1]["hi"]) == (0, 389, 389, 777)
     n = 0
     for key, want in ref.items():
-        if not isinstance(key, tuple):
+        if not isinstance(key, tuple) or key[0] in ("story", "story_info"):
             continue
         for r, out in enumerate(ranks):
             _same(out[key], want, out["lo"], out["hi"], (key, r))
             n += 1
     assert n == 2 * 2 * 8
+    _stories_same(ranks, ref, [(0, 1300), (1300, 2600)])
 
 
 def test_three_ranks_uneven_shares(runs):
@@ -140,9 +179,30 @@ def test_three_ranks_uneven_shares(runs):
     ranks = [pickle.load(open(d / f"gloo3_rank{r}.pkl", "rb")) for r in range(3)]
     assert [(o["lo"], o["hi"]) for o in ranks] == [(0, 259), (259, 518), (518, 777)]
     for key, want in ref.items():
-        if isinstance(key, tuple):
+        if isinstance(key, tuple) and key[0] not in ("story", "story_info"):
             for r, out in enumerate(ranks):
                 _same(out[key], want, out["lo"], out["hi"], (key, r))
+    _stories_same(ranks, ref, [(0, 867), (867, 1734), (1734, 2600)])
+
+
+def _stories_same(ranks, ref, blocks):
+    """harness.StoryPipeline.fit_words on every rank (its voxel block of every story, z-scored in its own upload threads,
+    panel by panel) equals the one-GPU pipeline bit for bit: metrics of all voxels, alphas, its block of the weights --
+    single_alpha (panelled joint choice, all-reduced sums) and per-voxel alpha, whole brain arrays or local blocks."""
+    assert [(o["story_lo"], o["story_hi"]) for o in ranks] == blocks
+    n = 0
+    for key, want in ref.items():
+        if isinstance(key, tuple) and key[0] == "story":
+            base = ref["story", key[1].replace("_local", "")]
+            _same(want, base, 0, blocks[-1][1], (key, "one GPU, local == global"))
+            for r, out in enumerate(ranks):
+                _same(out[key], want, out["story_lo"], out["story_hi"], (key, r))
+                n += 1
+    assert n == 3 * len(ranks)
+    # every rank took the same decision about the early panels' alpha (it is taken from all-reduced sums)
+    for name in ("story_single", "story_single_local"):
+        tags = {o["story_info", name]["single_alpha_guess"] for o in ranks}
+        assert len(tags) == 1, tags
 
 
 def test_one_rank_through_rccl_collectives(runs):
@@ -151,8 +211,8 @@ def test_one_rank_through_rccl_collectives(runs):
     subprocess.run([sys.executable, str(script), ROOT, "nccl", str(d)], check=True, env=env, timeout=900)
     out = pickle.load(open(d / "nccl1_rank0.pkl", "rb"))
     for key, want in ref.items():
-        if isinstance(key, tuple):
-            _same(out[key], want, 0, out["hi"], key)
+        if isinstance(key, tuple) and key[0] != "story_info":
+            _same(out[key], want, 0, out["story_hi"] if key[0] == "story" else out["hi"], key)
 
 
 def test_bench_runs_on_two_ranks_of_one_gpu(tmp_path):
@@ -165,10 +225,13 @@ def test_bench_runs_on_two_ranks_of_one_gpu(tmp_path):
     env = dict(os.environ, LITCODER_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
     for k, scaling in enumerate(("weak", "strong")):
         port = _free_port()
+        # the default at N > 1 IS the strong-scaled job (BASELINE's configs fix the voxel total): no flag in that run, which
+        # also carries the cfg3 story pipeline sharded over the two ranks
+        flags = ["--scaling", "weak", "--no-cfg3"] if scaling == "weak" else []
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                             "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
-                            "--warmup", "1", "--voxels", "6144", "--scaling", scaling, "--no-cpu-baseline"],
-                           env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+                            "--warmup", "1", "--voxels", "6144", "--no-cpu-baseline"] + flags,
+                           env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, r.stdout[-2000:]
@@ -179,4 +242,13 @@ def test_bench_runs_on_two_ranks_of_one_gpu(tmp_path):
         other = out["other_scaling"]
         assert other["scaling"] == ("strong" if scaling == "weak" else "weak") and other["voxels_total"] == (6144 if scaling == "weak" else 2 * 6144)
         assert 0.2 < out["config"]["median_score"] < 0.6 and 0.2 < other["median_score"] < 0.6
-        assert out["roofline"]["launches"] > 0 and "cfg3_pipeline" not in out and "cpu_baseline" not in out
+        assert out["roofline"]["launches"] > 0 and "cpu_baseline" not in out
+        dist_ = out["ms_per_step_distribution"]
+        assert dist_["steps"] == 1 and dist_["min"] <= dist_["median"] <= dist_["max"]
+        if scaling == "weak":
+            assert "cfg3_pipeline" not in out
+        else:
+            c3 = out["cfg3_pipeline"]
+            assert c3["n_gpus"] == 2 and c3["voxels_total"] == 6144 and c3["voxels_rank0"] == 3072 and c3["form"] == "primal"
+            assert abs(c3["value"] - 6144 / (1e-3 * c3["ms_per_step"])) < 1e-6 * c3["value"] and 0.0 < c3["median_score"] < 0.9
+            assert "in total" in out["config"]["workload"] and "split over 2 GPUs" in out["config"]["workload"]

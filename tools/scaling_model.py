@@ -13,6 +13,11 @@ cfg2: T 3000, p 3072, 20 alphas, 80 000 voxels in total (north_star's strong-sca
 cfg4: Narratives-like T 2226, p 3072, 20 alphas, 200 000 voxels sharded over the ranks (BASELINE configs[3]);
 cfg5: Whisper-like T 3000, p 7680 (1280 x 6 delays), 32 alphas, 80 000 voxels (configs[4]; the band scales only rescale
 the design: the fit is the same work).
+cfg3: the LeBel-style story pipeline (BASELINE configs[2], the config north_star's target sentence names), HOST TO HOST
+through harness.StoryPipeline.fit_words: 26 + 1 stories, T ~ 9 200 + 291, p 3072, 10 alphas, single_alpha, 80 000 voxels;
+a rank stages, z-scores and uploads only its V / G columns of every story (its share of the link), with the staging
+threads a rank of G gets on this box (cores / 2 / G), and downloads its block of the weights.  What the model cannot see:
+G ranks' staging threads competing for the host's memory bandwidth at the same time.
 """
 import json
 import os
@@ -33,7 +38,7 @@ CONFIGS = {
     "cfg4": dict(T=2226, F0=768, DELAYS=[1, 2, 3, 4], A=20, V_total=200000, weak=False),
     "cfg5": dict(T=3000, F0=1280, DELAYS=[1, 2, 3, 4, 5, 6], A=32, V_total=80000, weak=False),
 }
-which = [a for a in sys.argv[1:] if a in CONFIGS] or ["cfg2"]
+which = [a for a in sys.argv[1:] if a in CONFIGS or a == "cfg3"] or ["cfg2"]
 all_ranks = "--ranks" in sys.argv and sys.argv[sys.argv.index("--ranks") + 1] == "all"
 XGMI_ALLGATHER_GBPS = 300.0          # assumed all-gather rate INTO one rank (7 links x ~153 GB/s peak; RCCL ~1/3)
 dev = ops.device(0)
@@ -50,7 +55,54 @@ def timed(fit, n):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
+def cfg3_model(V_total=80000):
+    """BASELINE configs[2] at 1 / 2 / 4 / 8 simulated ranks, host to host (see the module docstring)."""
+    from litcoder_core_amd import StoryPipeline
+    words, wtimes, trtimes, brain = bench.synth_stories(V_total, dev)
+    out = {"shape": dict(stories=len(words), V_total=V_total, alphas=10, single_alpha=True,
+                         host_brain_bytes_float64=int(sum(b.nbytes for b in brain.values()))), "per_world": {}}
+    t1 = None
+    cores = os.cpu_count() or 4
+    for G in (1, 2, 4, 8):
+        per_rank, wire, info = {}, {}, {}
+        os.environ["LITCODER_AMD_UPLOAD_THREADS"] = str(max(2, min(24, cores // 2 // G)))
+        for r in (range(G) if all_ranks else sorted({0, G - 1})):
+            shard = ShardContext.simulated(G, r, device=dev, global_lists=False) if G > 1 else None
+            model = NestedCVModel("ridge_regression", shard=shard)
+            pipe = StoryPipeline([1, 2, 3, 4], bench.CFG3_TRIM, model=model)
+
+            def fit():
+                pipe.fit_words(words, wtimes, trtimes, brain, **bench.CFG3_KW)
+                torch.cuda.synchronize()
+
+            per_rank[r] = timed(fit, 5)
+            b0 = shard.bytes_received if shard is not None else 0
+            fit()
+            wire[r] = (shard.bytes_received - b0) if shard is not None else 0
+            info[r] = {k: model.last_fit.get(k) for k in ("form", "precision", "single_alpha_guess", "panels")}
+        t = max(per_rank.values())
+        rx = max(wire.values())
+        wire_ms = 1e3 * rx / (XGMI_ALLGATHER_GBPS * 1e9)
+        if G == 1:
+            t1 = t
+        lo, hi = shard_bounds(V_total, G, 0)
+        out["per_world"][G] = {"ms_per_rank_alone": {str(k): round(v, 2) for k, v in per_rank.items()}, "max_ms": round(t, 2),
+                               "staging_threads_per_rank": int(os.environ["LITCODER_AMD_UPLOAD_THREADS"]),
+                               "allgather_bytes_received": int(rx), "wire_ms_if_not_hidden": round(wire_ms, 2),
+                               "predicted_ms": round(t + wire_ms, 2), "predicted_speedup": round(t1 / (t + wire_ms), 2),
+                               "voxels_per_sec": round(V_total / (1e-3 * (t + wire_ms))),
+                               "rank0_link_bytes": {"up_float32": int(sum(b.shape[0] for b in brain.values()) * (hi - lo) * 4),
+                                                    "down": int(3072 * (hi - lo) * 4)},
+                               "rank0_fit": info[0]}
+        print(f"cfg3 G={G}: {out['per_world'][G]}", file=sys.stderr, flush=True)
+    os.environ.pop("LITCODER_AMD_UPLOAD_THREADS", None)
+    return out
+
+
 for name in which:
+    if name == "cfg3":
+        result["configs"][name] = cfg3_model()
+        continue
     c = CONFIGS[name]
     T, V_total = c["T"], c["V_total"]
     alphas = np.logspace(-1, 8, c["A"])
