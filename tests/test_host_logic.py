@@ -322,3 +322,20 @@ def test_host_zscore_of_a_story_is_numpys_bit_for_bit():
         big = rng.standard_normal((400, 5000)).astype(dt)
         view = big[10:-5, 100:4000]                                  # a trimmed story inside a wider matrix
         assert np.array_equal(ops.host_zscore_story(view), oh.zs(view.copy()).astype(np.float32))
+
+
+def test_host_side_of_the_library_under_sanitizers(tmp_path):
+    """csrc/lc_upload.hip (staging threads, slot ring, coordinator) and csrc/lc_core.hip (host casts, 2-D copies, event timers)
+    built by g++ with -fsanitize=address,undefined and with -fsanitize=thread against the HIP stand-in of
+    tools/sanitize/hip_stub/ and run through the upload job matrix (plain / z-scored / lead jobs / device staging / abandoned
+    uploads / injected copy failures, tools/sanitize/host_upload_test.cpp): clean runs, every destination byte equal to a scalar
+    restatement (sanitizers run on the CPU build only)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_host.sh"), str(tmp_path), "1"], capture_output=True,
+                       text=True, timeout=600)
+    logs = "".join(open(os.path.join(tmp_path, f)).read()[-3000:] for f in sorted(os.listdir(tmp_path)) if f.endswith(".log"))
+    assert r.returncode == 0, r.stdout + r.stderr + logs
+    assert "asan_ubsan clean" in r.stdout and "tsan clean" in r.stdout
