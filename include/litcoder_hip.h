@@ -290,6 +290,19 @@ int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* 
                          double* d_work, double* d_lmax, lc_stream_t stream);
 int lc_lambda_max_masked_opt(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
                              double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream);
+/* ... with a convergence stop (round 5): `steps` is the most a system runs; every 8 steps from the 24th on its top Ritz
+ * value is looked at, and the system stops once that value has moved by <= tol (relative) over the last 8 steps (tol = 0:
+ * never; the later launches of a stopped system return at once, the matvec launches once every system has stopped).  The
+ * top Ritz value converges geometrically (1e-3 per 16 steps on the bench designs): a move of <= 1e-6 over 8 steps leaves
+ * an error of ~3e-8 -- below the fp32 epsilon of everything downstream, and of the reference's own S[0], an fp32 SVD
+ * value (ridge_regression.py:39,97). */
+int lc_lambda_max_masked_tol(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps, double tol,
+                             double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream);
+/* Systems that are the LEADING n x n blocks of their own matrices (the primal form's p x p Gram matrices: matrix f at
+ * d_k + f k_stride, no row lists): a streaming matvec (16-byte loads, the vector through LDS), the same recurrence, the
+ * same stop.  N = padded vector length (>= n, even); d_work: F*(3*N + 2*steps + 8) f64, 16-byte aligned like d_k. */
+int lc_lambda_max_dense(const double* d_k, int64_t ldk, int64_t k_stride, int F, int N, int n, int steps, double tol,
+                        double* d_work, double* d_lmax, lc_stream_t stream);
 
 /* a2[f*A + a] = (alphas[a] * (normalpha ? sqrt(lmax[f]) : 1))^2
  * (ridge_regression.py:99-101,117: D = S/(S^2 + nalpha^2)). */

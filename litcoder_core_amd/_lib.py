@@ -99,6 +99,8 @@ SIGNATURES = {
     "lc_batch_chol_solve_opt": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_batch_chol_inverse_opt": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_lambda_max_masked_opt": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, _ptr, _ptr, c_int, _ptr]),
+    "lc_lambda_max_masked_tol": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, c_double, _ptr, _ptr, c_int, _ptr]),
+    "lc_lambda_max_dense": (c_int, [_ptr, c_int64, c_int64, c_int, c_int, c_int, c_int, c_double, _ptr, _ptr, _ptr]),
     "lc_batch_series_hat": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int, c_int, c_int,
                                     _ptr, _ptr, _ptr]),
     "lc_batch_series_terms": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, c_int, _ptr, _ptr, _ptr, c_int,

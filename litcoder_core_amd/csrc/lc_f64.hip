@@ -116,19 +116,21 @@ __device__ inline double* lz_base(double* work, int f, int N, int steps) {
     return work + (long long)f * (3ll * N + 2ll * steps + 8);
 }
 
-__global__ void __launch_bounds__(256) k_lz_init(const int* __restrict__ rows, int N, int steps, double* work) {
+__global__ void __launch_bounds__(256) k_lz_init(const int* __restrict__ rows, int N, int steps, double* work,
+                                                 int n_dense = 0) {
     __shared__ double red[256];
     const int f = blockIdx.x;
     double* base = lz_base(work, f, N, steps);
     double* v = base;
     double* vp = base + N;
-    const int* rw = rows + (long long)f * N;
+    const int* rw = rows ? rows + (long long)f * N : nullptr;      // NULL: the leading n_dense entries are the system
     double ss = 0.0;
     for (int i = threadIdx.x; i < N; i += 256) {
         // fixed pseudo-random start vector (integer hash -> (-1, 1)), zero on padding rows
         unsigned h = (unsigned)i * 2654435761u + 12345u;
         h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        const double x = rw[i] >= 0 ? ((double)(h & 0xFFFFFF) / 8388608.0 - 1.0) + 1.5 : 0.0;
+        const bool live = rw ? rw[i] >= 0 : i < n_dense;
+        const double x = live ? ((double)(h & 0xFFFFFF) / 8388608.0 - 1.0) + 1.5 : 0.0;
         v[i] = x;
         vp[i] = 0.0;
         ss += x * x;
@@ -150,6 +152,7 @@ __global__ void __launch_bounds__(256) k_lz_symv(const double* __restrict__ Kmat
     const int lane = threadIdx.x & 63;
     if (i >= N) return;
     double* base = lz_base(work, f, N, steps);
+    if (base[3ll * N + 2ll * steps + 1] != 0.0) return;   // the system has stopped (invariant subspace / converged)
     const double* v = base;
     double* w = base + 2ll * N;
     const int* rw = rows + (long long)f * N;
@@ -167,6 +170,101 @@ __global__ void __launch_bounds__(256) k_lz_symv(const double* __restrict__ Kmat
     if (lane == 0) w[i] = s;
 }
 
+// w = K_f[0:n, 0:n] v for systems that ARE the leading blocks of their own matrices (the primal form's p x p Gram
+// matrices: no row lists).  The gather version above moves one 8-byte K element, one index and one vector element per
+// lane and trip with one row per wave: 2.2 TB/s on six 3072 x 3072 systems -- and the Lanczos run sits at the head of a
+// LeBel-shaped fit's critical path (13 of its 150 ms, round 4).  Here a block takes 16 rows of one system: the vector
+// chunk goes through LDS once per block, a wave streams FOUR rows at a time with 16-byte loads (eight in flight per
+// lane), so the iteration is bound by streaming the matrices.  Sums: per row a fixed lane-strided order, butterfly at the
+// end (deterministic; not the gather version's order -- the two differ in the last bits).
+constexpr int LZD_ROWS = 16, LZD_CHUNK = 4096;
+__global__ void __launch_bounds__(256) k_lz_symv_dense(const double* __restrict__ Kmat, long long ldk, long long k_stride,
+                                                       int N, int n, int steps, double* work) {
+    __shared__ double vs[LZD_CHUNK];
+    const int f = blockIdx.y;
+    double* base = lz_base(work, f, N, steps);
+    if (base[3ll * N + 2ll * steps + 1] != 0.0) return;   // stopped
+    const double* v = base;
+    double* w = base + 2ll * N;
+    Kmat += (long long)f * k_stride;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * LZD_ROWS + wv * 4;
+    const double* kr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kr[q] = Kmat + (long long)min(i0 + q, n - 1) * ldk;    // rows past the end: clamped, unused
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int n2 = (n + 1) & ~1;                       // (n odd: the vector's entry n is a zero; K's column n is in the row's padding)
+    for (int c0 = 0; c0 < n2; c0 += LZD_CHUNK) {
+        const int cw = min(LZD_CHUNK, n2 - c0);
+        __syncthreads();
+        for (int j = threadIdx.x * 2; j < cw; j += 512) *reinterpret_cast<double2*>(vs + j) = *reinterpret_cast<const double2*>(v + c0 + j);
+        __syncthreads();
+        int j = lane * 2;
+        for (; j + 128 < cw; j += 256) {               // two trips per pass: eight 16-byte loads in flight
+            double2 k0[4], k1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                k0[q] = *reinterpret_cast<const double2*>(kr[q] + c0 + j);
+                k1[q] = *reinterpret_cast<const double2*>(kr[q] + c0 + j + 128);
+            }
+            const double2 v0 = *reinterpret_cast<const double2*>(vs + j), v1 = *reinterpret_cast<const double2*>(vs + j + 128);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[q] += k0[q].x * v0.x;
+                acc[q] += k0[q].y * v0.y;
+                acc[q] += k1[q].x * v1.x;
+                acc[q] += k1[q].y * v1.y;
+            }
+        }
+        for (; j < cw; j += 128) {
+            const double2 v0 = *reinterpret_cast<const double2*>(vs + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 k0 = *reinterpret_cast<const double2*>(kr[q] + c0 + j);
+                acc[q] += k0.x * v0.x;
+                acc[q] += k0.y * v0.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double t = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        if (lane == 0 && i0 + q < N) w[i0 + q] = i0 + q < n ? t : 0.0;     // (the padding entries of the vectors stay zero)
+    }
+}
+
+// Largest eigenvalue of the k x k tridiagonal (al, be) by 64-way multisection on the Sturm count, one wave: count(x) =
+// number of eigenvalues < x; [lo, hi] shrinks around the smallest x with count(x) == k, 65-fold per round.
+__device__ inline double lz_theta(const double* al, const double* be, int k, int rounds, int lane) {
+    double lo = al[0], hi = al[0];
+    for (int i = 0; i < k; ++i) {
+        const double bl = i > 0 ? fabs(be[i - 1]) : 0.0, br = i + 1 < k ? fabs(be[i]) : 0.0;
+        lo = fmin(lo, al[i] - bl - br);
+        hi = fmax(hi, al[i] + bl + br);
+    }
+    for (int round = 0; round < rounds && hi > lo; ++round) {
+        const double w = (hi - lo) / 65.0;
+        const double x = lo + w * (lane + 1);
+        int cnt = 0;
+        double q = al[0] - x;
+        if (q < 0.0) ++cnt;
+        for (int i = 1; i < k; ++i) {
+            const double den = q != 0.0 ? q : 1e-300;
+            q = al[i] - x - be[i - 1] * be[i - 1] / den;
+            if (q < 0.0) ++cnt;
+        }
+        const unsigned long long full = __ballot(cnt >= k);      // lanes whose x is above every eigenvalue
+        const int first = full ? __ffsll((long long)full) - 1 : 64;
+        const double nlo = first == 0 ? lo : lo + w * first;     // x of lane first-1
+        const double nhi = first == 64 ? hi : lo + w * (first + 1);
+        lo = nlo;
+        hi = nhi;
+    }
+    return hi;
+}
+
 // Sum over the 1024 threads of a block, every thread gets it: butterfly inside the waves, the 16 wave sums through LDS
 // in fixed order (two barriers; the tree through LDS it replaces had eleven -- this kernel is 128 dependent launches of a
 // Lanczos run and nothing but latency).
@@ -182,10 +280,17 @@ __device__ inline double block_sum_1024(double x, double* red) {
 }
 
 // One Lanczos recurrence step per fold: a = v.w ; w -= a v + b_prev vprev ; b = |w| ; rotate.
+// tol > 0: every LZ_CHECK steps from LZ_CHECK_FROM on the top Ritz value is computed (one wave, ~10 us) and the run of
+// this system STOPS once it has moved by <= tol (relative) over the last LZ_CHECK steps; the later launches of the system
+// return at once.  The top Ritz value rises monotonically and, past its first few digits, geometrically -- by 1e-3 per 16
+// steps on the bench designs (profiles/r04_lanczos_convergence.txt): a move of <= 1e-6 over 8 steps leaves ~3e-8.
+constexpr int LZ_CHECK = 8, LZ_CHECK_FROM = 24, LZ_CHECK_MAX = 256;
 __global__ void __launch_bounds__(1024) k_lz_step(int N, int steps, int step, double* work,
                                                   const double* __restrict__ part = nullptr, int nsplit = 0,
-                                                  const unsigned* __restrict__ member = nullptr) {
+                                                  const unsigned* __restrict__ member = nullptr, double tol = 0.0) {
     __shared__ double red[1024];
+    __shared__ double s_al[LZ_CHECK_MAX], s_be[LZ_CHECK_MAX];
+    __shared__ int s_conv;
     const int f = blockIdx.x;
     double* base = lz_base(work, f, N, steps);
     double* v = base;
@@ -218,12 +323,32 @@ __global__ void __launch_bounds__(1024) k_lz_step(int N, int steps, int step, do
         vp[i] = v[i];
         v[i] = w[i] * inv;
     }
+    const int kk = step + 1;
+    bool conv = false;
+    if (tol > 0.0 && !stop && kk >= LZ_CHECK_FROM && kk % LZ_CHECK == 0 && kk <= LZ_CHECK_MAX) {     // (block-uniform)
+        for (int i = threadIdx.x; i < kk; i += 1024) {
+            s_al[i] = i == step ? a : al[i];
+            s_be[i] = i == step ? b : be[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const double theta = lz_theta(s_al, s_be, kk, 8, threadIdx.x);
+            if (threadIdx.x == 0) {
+                const double prev = meta[3];
+                meta[3] = theta;
+                s_conv = (prev > 0.0 && theta - prev <= tol * theta) ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        conv = s_conv != 0;
+    }
     if (threadIdx.x == 0) {
         al[step] = a;
         be[step] = b;
         meta[0] = (double)(step + 1);
         meta[2] = b;
         if (stop) meta[1] = 1.0;
+        else if (conv) meta[1] = 2.0;
     }
 }
 
@@ -237,30 +362,7 @@ __global__ void __launch_bounds__(64) k_lz_eig(int N, int steps, double* work, d
     const double* be = al + steps;
     const int k = (int)(be + steps)[0];
     if (k <= 0) { if (lane == 0) lmax[f] = 0.0; return; }
-    double lo = al[0], hi = al[0];
-    for (int i = 0; i < k; ++i) {
-        const double bl = i > 0 ? fabs(be[i - 1]) : 0.0, br = i + 1 < k ? fabs(be[i]) : 0.0;
-        lo = fmin(lo, al[i] - bl - br);
-        hi = fmax(hi, al[i] + bl + br);
-    }
-    for (int round = 0; round < 14 && hi > lo; ++round) {
-        const double w = (hi - lo) / 65.0;
-        const double x = lo + w * (lane + 1);
-        int cnt = 0;
-        double q = al[0] - x;
-        if (q < 0.0) ++cnt;
-        for (int i = 1; i < k; ++i) {
-            const double den = q != 0.0 ? q : 1e-300;
-            q = al[i] - x - be[i - 1] * be[i - 1] / den;
-            if (q < 0.0) ++cnt;
-        }
-        const unsigned long long full = __ballot(cnt >= k);      // lanes whose x is above every eigenvalue
-        const int first = full ? __ffsll((long long)full) - 1 : 64;
-        const double nlo = first == 0 ? lo : lo + w * first;     // x of lane first-1
-        const double nhi = first == 64 ? hi : lo + w * (first + 1);
-        lo = nlo;
-        hi = nhi;
-    }
+    const double hi = lz_theta(al, be, k, 14, lane);
     if (lane == 0) lmax[f] = hi;
 }
 
@@ -307,6 +409,7 @@ __global__ void __launch_bounds__(256) k_lz_symv_multi(const double* __restrict_
     __shared__ double Vs[LZM_JT][33];
     const int tid = threadIdx.x, f = tid & 31, g = tid >> 5;
     const int i0 = blockIdx.x * LZM_ROWS;
+    if (__syncthreads_count(tid < F && lz_base(work, tid, T, steps)[3ll * T + 2ll * steps + 1] == 0.0) == 0) return;  // all stopped
     double kreg[4], vreg[16];
     auto fetch = [&](int j0) {
 #pragma unroll
@@ -371,6 +474,7 @@ __global__ void __launch_bounds__(256) k_lz_symv_mfma(const double* __restrict__
     const int i0 = blockIdx.x * LZQ_ROWS;
     const int jb = blockIdx.y * jspan, je = min(T, jb + jspan);
     if (jb >= je) return;
+    if (__syncthreads_count(tid < F && lz_base(work, tid, T, steps)[3ll * T + 2ll * steps + 1] == 0.0) == 0) return;  // all stopped
     double kreg[8], vreg[4];
     auto fetch = [&](int j0) {
 #pragma unroll
@@ -806,10 +910,31 @@ extern "C" int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_ro
     return lc_lambda_max_strided(d_k, ldk, 0, d_rows, F, N, steps, d_work, d_lmax, stream);
 }
 
+extern "C" int lc_lambda_max_dense(const double* d_k, int64_t ldk, int64_t k_stride, int F, int N, int n, int steps,
+                                   double tol, double* d_work, double* d_lmax, lc_stream_t stream) {
+    LC_REQUIRE(d_k && d_work && d_lmax, LC_E_BADARG, "lc_lambda_max_dense: null pointer");
+    LC_REQUIRE(F > 0 && F <= 65535 && n > 0 && N >= n && N % 2 == 0 && steps > 0 && k_stride >= 0 && ldk >= n && ldk % 2 == 0 &&
+                   k_stride % 2 == 0 && tol >= 0.0, LC_E_SHAPE,
+               "lc_lambda_max_dense: need N >= n, even N / ldk / k_stride, tol >= 0");
+    LC_REQUIRE((reinterpret_cast<uintptr_t>(d_k) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_work) & 15) == 0, LC_E_BADARG,
+               "lc_lambda_max_dense: matrices and work area must be 16-byte aligned");
+    hipStream_t s = lc::as_stream(stream);
+    lc::ScopedTimer timer_(lc::T_LAMBDA_MAX, s);
+    hipLaunchKernelGGL(k_lz_init, dim3(F), dim3(256), 0, s, (const int*)nullptr, N, steps, d_work, n);
+    if (int rc = lc::launched("k_lz_init")) return rc;
+    for (int it = 0; it < steps; ++it) {
+        hipLaunchKernelGGL(k_lz_symv_dense, dim3((unsigned)lc::ceil_div(N, LZD_ROWS), (unsigned)F), dim3(256), 0, s, d_k,
+                           (long long)ldk, (long long)k_stride, N, n, steps, d_work);
+        hipLaunchKernelGGL(k_lz_step, dim3(F), dim3(1024), 0, s, N, steps, it, d_work, (const double*)nullptr, 0,
+                           (const unsigned*)nullptr, tol);
+    }
+    if (int rc = lc::launched("k_lz_step")) return rc;
+    hipLaunchKernelGGL(k_lz_eig, dim3(F), dim3(64), 0, s, N, steps, d_work, d_lmax);
+    return lc::launched("k_lz_eig");
+}
+
 // use_mfma: the masked multi-system matvec on the fp64 MFMA (k_lz_symv_mfma, the default) or on the vector ALU
 // (k_lz_symv_multi) -- a per-call choice, no process-wide switch
-extern "C" int lc_lambda_max_masked_opt(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
-                                        double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream);
 
 extern "C" int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
                                     double* d_work, double* d_lmax, lc_stream_t stream) {
@@ -818,9 +943,14 @@ extern "C" int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const
 
 extern "C" int lc_lambda_max_masked_opt(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
                                         double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream) {
+    return lc_lambda_max_masked_tol(d_k, ldk, T, d_member, F, steps, 0.0, d_work, d_lmax, use_mfma, stream);
+}
+
+extern "C" int lc_lambda_max_masked_tol(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
+                                        double tol, double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream) {
     LC_REQUIRE(d_k && d_member && d_work && d_lmax, LC_E_BADARG, "lc_lambda_max_masked: null pointer");
-    LC_REQUIRE(F > 0 && F <= 32 && T > 0 && steps > 0 && ldk >= T, LC_E_SHAPE,
-               "lc_lambda_max_masked: need 1 <= F <= 32 systems, T > 0, steps > 0");
+    LC_REQUIRE(F > 0 && F <= 32 && T > 0 && steps > 0 && ldk >= T && tol >= 0.0, LC_E_SHAPE,
+               "lc_lambda_max_masked: need 1 <= F <= 32 systems, T > 0, steps > 0, tol >= 0");
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_LAMBDA_MAX, s);
     hipLaunchKernelGGL(k_lz_init_masked, dim3(F), dim3(256), 0, s, d_member, T, steps, d_work);
@@ -838,7 +968,7 @@ extern "C" int lc_lambda_max_masked_opt(const double* d_k, int64_t ldk, int T, c
             hipLaunchKernelGGL(k_lz_symv_multi, dim3((unsigned)lc::ceil_div(T, LZM_ROWS), (unsigned)nsplit), dim3(256), 0, s, d_k,
                                (long long)ldk, d_member, T, F, steps, d_work, part, jspan);
         hipLaunchKernelGGL(k_lz_step, dim3(F), dim3(1024), 0, s, T, steps, it, d_work, (const double*)part, nsplit,
-                           (const unsigned*)d_member);
+                           (const unsigned*)d_member, tol);
     }
     if (int rc = lc::launched("k_lz_step")) return rc;
     hipLaunchKernelGGL(k_lz_eig, dim3(F), dim3(64), 0, s, T, steps, d_work, d_lmax);

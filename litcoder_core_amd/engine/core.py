@@ -378,7 +378,7 @@ class EngineCore:
                 bits[np.asarray(rows, dtype=np.int64)] |= np.uint32(1 << f)
             member = ops.upload(bits.view(np.int32), self.dev)
             ops.lambda_max_masked(K, self.Ttot, member, len(chunk), self.steps, out=res[c0:c0 + len(chunk)],
-                                  use_mfma=self.opt.lanczos_mfma)
+                                  use_mfma=self.opt.lanczos_mfma, tol=self.opt.lanczos_tol)
         return res
 
     def _check_singcutoff(self, lmax):

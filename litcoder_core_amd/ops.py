@@ -610,13 +610,23 @@ def lambda_max(k, rows, F, N, steps):
     return out
 
 
-def lambda_max_masked(k, T, member, F, steps, out=None, use_mfma=True):
-    """lambda_max of K[I_f, I_f] for F <= 32 row sets given as bit f of member[i] (int32 tensor of T words)."""
+def lambda_max_masked(k, T, member, F, steps, out=None, use_mfma=True, tol=0.0):
+    """lambda_max of K[I_f, I_f] for F <= 32 row sets given as bit f of member[i] (int32 tensor of T words).  ``tol`` > 0:
+    a system stops once its top Ritz value has moved by <= tol (relative) over 8 steps (lc_lambda_max_masked_tol)."""
     work = torch.empty(F * (3 * T + 2 * steps + 8) + 16 * 32 * T, dtype=torch.float64, device=k.device)
     if out is None:
         out = torch.empty(F, dtype=torch.float64, device=k.device)
-    _lib.call("lc_lambda_max_masked_opt", _p(k), k.stride(0), T, _p(member), F, steps, _p(work), _p(out),
+    _lib.call("lc_lambda_max_masked_tol", _p(k), k.stride(0), T, _p(member), F, steps, float(tol), _p(work), _p(out),
               int(bool(use_mfma)), _s())
+    return out
+
+
+def lambda_max_dense(k, ldk, k_stride, F, N, n, steps, tol=0.0):
+    """lambda_max of the leading n x n blocks of F matrices (matrix f at k + f k_stride doubles, row stride ldk): the
+    streaming matvec of lc_lambda_max_dense.  N: padded vector length."""
+    work = torch.empty(F * (3 * N + 2 * steps + 8), dtype=torch.float64, device=k.device)
+    out = torch.empty(F, dtype=torch.float64, device=k.device)
+    _lib.call("lc_lambda_max_dense", _p(k), ldk, k_stride, F, N, n, steps, float(tol), _p(work), _p(out), _s())
     return out
 
 

@@ -479,6 +479,60 @@ def test_batch_chol_solve_against_fp64_solves(lc):
                 assert np.array_equal(r_, res[0]), (B, N, M, inv)
 
 
+def test_lambda_max_kernels_against_numpy(lc):
+    """S[0]^2 of a training block (ridge_regression.py:39,97 `norm = S[0]`) from the Lanczos kernels against numpy's
+    eigvalsh: the gather version (row lists), the masked multi-system version (principal blocks of one Gram matrix, MFMA and
+    vector-ALU matvec) and the streaming version for leading blocks of separate matrices (odd n, padded vectors) -- each with
+    the full 64 steps (<= 1e-9 here) and with the convergence stop of round 5 (tol 1e-6 over 8 steps: <= 1e-7 promised,
+    far less observed), plus a rank-deficient system whose run ends early by itself."""
+    from litcoder_core_amd import ops
+    dev = ops.device(0)
+    rng = np.random.default_rng(5)
+    T, p = 700, 900
+    X = rng.standard_normal((T, p)) * rng.uniform(0.2, 2.0, p)
+    X[:, :40] += 2.0 * rng.standard_normal((T, 1))                  # a dominant direction, like real designs
+    K = X @ X.T
+    dK = torch.from_numpy(K).to(dev)
+    sets = [np.sort(rng.choice(T, size=n, replace=False)) for n in (512, 500, 448, 640)] + [np.arange(T)]
+    want = np.array([np.linalg.eigvalsh(K[np.ix_(s_, s_)])[-1] for s_ in sets])
+    N = 640
+    rows = ops.idx_matrix(sets[:4], N, dev)
+    got = ops.lambda_max(dK, rows, 4, N, 64).cpu().numpy()
+    assert np.abs(got / want[:4] - 1).max() < 1e-9
+    bits = np.zeros(T, dtype=np.uint32)
+    for f, s_ in enumerate(sets):
+        bits[s_] |= np.uint32(1 << f)
+    member = ops.upload(bits.view(np.int32), dev)
+    for mfma in (True, False):
+        full = ops.lambda_max_masked(dK, T, member, len(sets), 64, use_mfma=mfma).cpu().numpy()
+        assert np.abs(full / want - 1).max() < 1e-9, mfma
+        early = ops.lambda_max_masked(dK, T, member, len(sets), 64, use_mfma=mfma, tol=1e-6).cpu().numpy()
+        assert np.abs(early / want - 1).max() < 1e-7, (mfma, np.abs(early / want - 1).max())
+        assert np.all(early <= want * (1 + 1e-12))                 # Ritz values approach from below
+    # leading blocks of separate matrices: n odd, vectors padded to N, row stride > n
+    n, Np, S = 333, 384, 3
+    G = np.zeros((S, Np, Np))
+    ev = []
+    for k in range(S):
+        A = rng.standard_normal((1000 + 50 * k, n)) * rng.uniform(0.3, 1.5, n)
+        A[:, :30] += 1.5 * rng.standard_normal((A.shape[0], 1))
+        G[k, :n, :n] = A.T @ A
+        G[k, :n, n] = 123.0                                          # junk in the padding column: never multiplied in
+        ev.append(np.linalg.eigvalsh(G[k, :n, :n])[-1])
+    dG = torch.from_numpy(G).to(dev)
+    for tol, bound in ((0.0, 1e-9), (1e-6, 1e-7)):
+        got = ops.lambda_max_dense(dG, Np, Np * Np, S, Np, n, 64, tol=tol).cpu().numpy()
+        assert np.abs(got / np.array(ev) - 1).max() < bound, (tol, got, ev)
+    ident = ops.idx_matrix([np.arange(n)] * S, Np, dev)
+    ref = ops.lambda_max_strided(dG, Np, Np * Np, ident, S, Np, 64).cpu().numpy()
+    assert np.abs(ref / np.array(ev) - 1).max() < 1e-9
+    # rank 3: the recurrence ends by itself after a few steps (invariant subspace), the value is exact
+    B = rng.standard_normal((200, 3))
+    low = torch.from_numpy(B @ B.T).to(dev).reshape(1, 200, 200)
+    got = ops.lambda_max_dense(low, 200, 0, 1, 200, 200, 64, tol=1e-6).cpu().numpy()
+    assert abs(got[0] / np.linalg.eigvalsh(B.T @ B)[-1] - 1) < 1e-10
+
+
 def test_series_moments_match_per_alpha_hat_matrices(lc):
     """The alphas on the polynomial series are scored from the moments of the shared terms (one contraction, light
     slabs, f32-MFMA chain or fp64 chain) -- against the same alphas expanded into per-alpha hat matrices and sent
