@@ -34,6 +34,7 @@ class FitOptions:
     lanczos_tol: float = 1e-6               # ... a system stops before that once its top Ritz value has moved by <= this
                                             # (relative) over 8 steps: ~3e-8 left by the geometric convergence (round 5: 48
                                             # instead of 64 steps on the LeBel-shaped Gram matrices, 56 at cfg2; 0 = never)
+    lanczos_dense: bool = True              # primal form: the streaming matvec for the p x p Gram blocks (lc_lambda_max_dense)
     aug_budget_bytes: int = 24 << 30        # cap on the batched (fold, alpha) fp64 systems resident at once
     series_tol: float = 2e-9                # an alpha takes the polynomial form when its worst relative error over the
                                             # spectrum, 1 / T_d(1 + 2 alpha^2), is <= this: 30x below the fp32 epsilon

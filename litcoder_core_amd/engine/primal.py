@@ -80,7 +80,10 @@ class PrimalForm:
         for k in range(len(g)):                        # (before the Lanczos run: the host looks at this when it queues the
             self._check_feature_scales(G[F + k])       # fold's first V-wide phase, and must not wait for the run there)
         # (the systems are the leading p x p blocks of their own matrices: the streaming matvec, round 5)
-        lmax = ops.lambda_max_dense(G, PP, PP * PP, S, PP, p, self.steps, tol=self.opt.lanczos_tol) if self.normalpha else None
+        lmax = None
+        if self.normalpha:
+            lmax = (ops.lambda_max_dense(G, PP, PP * PP, S, PP, p, self.steps, tol=self.opt.lanczos_tol) if self.opt.lanczos_dense
+                    else ops.lambda_max_strided(G, PP, PP * PP, ident, S, PP, self.steps))
         self._check_singcutoff(lmax)
         a2 = ops.penalties(None if lmax is None else lmax[:F], F, self.d_alphas, self.normalpha)
         rhs = ops.gather_rows_f64(X, va, F, M, p, PP)                        # (F, M, PP): Pstim of every inner fold

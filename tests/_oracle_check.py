@@ -11,6 +11,25 @@ re-derived at the ORACLE's alpha through this package's own ridge solver and com
 import numpy as np
 
 
+def _record_flips(tag, n_flips, n_folds, n_voxels, n_voxels_flipped, min_same, gap_tol):
+    """One line per comparison into gpurun_out/parity_flips.txt (LITCODER_PARITY_FLIPS_FILE overrides; the round's copy is
+    profiles/rNN_parity_flips.txt): how many (fold, voxel) alpha choices differed from the oracle's / the reference's -- every
+    one a proven near-tie, or the comparison fails -- and how far that is from the limit the test allows."""
+    import os
+    path = os.environ.get("LITCODER_PARITY_FLIPS_FILE")
+    if path is None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.path.join(root, "gpurun_out", "parity_flips.txt")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(f"{tag}: {n_flips} of {n_folds * n_voxels} (fold, voxel) pairs flipped ({n_folds} folds x {n_voxels} voxels); "
+                    f"{n_voxels_flipped} voxels flipped in some fold = {n_voxels_flipped / max(n_voxels, 1):.4f} "
+                    f"(limit {1 - min_same:.2f}); every flip a near-tie <= {gap_tol:g} of the oracle's own score table\n")
+    except OSError:
+        pass
+
+
 def _alpha_index(alphas, values):
     al = np.asarray(alphas, dtype=np.float64)
     v = np.asarray(values, dtype=np.float64)
@@ -57,6 +76,7 @@ def assert_matches_oracle(lc, model, ours, oracle, detail, X, Y, kw, tag, corr_a
         flipped |= diff
         n_flips += int(diff.sum())
     clean = ~flipped
+    _record_flips(tag, n_flips, len(fold_orc), len(cols), int(flipped.sum()), min_same, gap_tol)
     assert clean.mean() >= min_same, f"{tag}: only {clean.mean():.3f} of the voxels chose the oracle's alpha in every fold"
     r, r_o = np.asarray(m["correlations"], dtype=np.float64)[cols], np.asarray(m_o["correlations"], dtype=np.float64)
     np.testing.assert_allclose(r[clean], r_o[clean], rtol=0, atol=corr_atol, err_msg=tag)

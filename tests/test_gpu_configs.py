@@ -328,26 +328,65 @@ def test_cfg4_narratives_shape_full_volume(lc, golden_dir):
                                   corr_atol=1e-4, w_rtol=1e-3, w_atol=1e-4, cols=np.arange(nv), min_same=0.95,
                                   w_cols=spec["cfg4"]["w_cols"])
     assert abs(np.median(r[:nv]) - spec["cfg4"]["median_score"]) < 1e-3, f"{flips} flipped (fold, voxel) pairs"
+    # ---- the metric's own call at this config: float64 numpy features / targets in pageable
+    # host memory in (3.56 GB of targets, cast to float32 in the staging threads, crossing the link in voxel panels while the
+    # first fold runs), metrics + float32 HOST weights out (2.46 GB, leaving panel by panel during the last folds) -- equal to
+    # the resident fit bit for bit
+    W_res = W.cpu().numpy()
+    del W, W_b, W_p, blk
+    Yh = np.empty((T, V), dtype=np.float64)
+    for c in range(0, V, 16384):
+        Yh[:, c:c + 16384] = dY[:, c:min(V, c + 16384)].cpu().numpy()
+    del dY
+    torch.cuda.empty_cache()
+    model_h = lc.NestedCVModel("r")
+    m_h, W_h, a_h = model_h.fit_predict(X, Yh, **kw)
+    assert len(model_h.last_fit["panels"]) > 1, "200 000 voxels must cross the link in panels"
+    assert W_h.dtype == np.float32 and W_h.shape == (p, V)
+    assert np.array_equal(np.asarray(m_h["correlations"]), r) and np.array_equal(a_h, a)
+    assert np.array_equal(np.asarray(m_h["p_values"]), np.asarray(m["p_values"]))
+    assert np.array_equal(np.asarray(m_h["significant_mask"]), np.asarray(m["significant_mask"]))
+    assert np.array_equal(W_h, W_res), "host-to-host weights differ from the resident fit's"
 
 
 def test_cfg5_whisper_shape_banded(lc, golden_dir):
     """Whisper-like: 1280-d speech features x 6 FIR delays = 7680 columns (p > n), 32 alphas logspace(-1, 8), two feature
-    bands with penalty scales (1, 2) (BandedNestedCVModel: ridge on the rescaled design), T = 3000,
-    V = 2048: the first 256 voxels against what the REFERENCE returned on the rescaled design (configs.npz; 12-13 distinct
-    alphas chosen per fold), 5 x 5 K-folds."""
+    bands with penalty scales (1, 2) (BandedNestedCVModel: ridge on the rescaled design), T = 3000, at the
+    config's full width V = 80 000 and HOST TO HOST (round 5; 2 048 voxels before): float64 numpy arrays in -- 1.92 GB of
+    targets in voxel panels -- metrics + 2.46 GB of float32 host weights out.  The first 256 voxels against what the
+    REFERENCE returned on the rescaled design (configs.npz; 12-13 distinct alphas chosen per fold), 5 x 5 K-folds; the rest
+    of the volume finite and, for a 4 096-voxel block fitted alone, equal to its slice bit for bit."""
     import _config_problems as cp
     import _fixtures as fx
+    from litcoder_core_amd import ops
     g, spec = fx.load(golden_dir)
     Xs, Y, kw = cp.matrix_problem("cfg5")                      # the fixture's design is the RESCALED one, X / gamma
     fx.check_inputs(g, "cfg5__checks", Xs, Y)
-    T, p, nv, V = len(Xs), Xs.shape[1], cp.N_FIX, 2048
+    T, p, nv, V = len(Xs), Xs.shape[1], cp.N_FIX, 80000
     gamma = np.r_[np.full(p // 2, 1.0), np.full(p - p // 2, 2.0)]
     X = Xs * gamma                                             # exact (powers of two): the banded model divides it back
-    rng = np.random.default_rng(23)
-    Yw = np.hstack([Y, Xs @ (0.015 * rng.standard_normal((p, V - nv))) + rng.standard_normal((T, V - nv))])
+    dev = ops.device(0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(23)
+    dXs = torch.from_numpy(Xs.astype(np.float32)).to(dev)
+    Yw = np.empty((T, V), dtype=np.float64)
+    Yw[:, :nv] = Y
+    for c in range(nv, V, 16384):                              # (data synthesis on the device, column blocks)
+        w = min(16384, V - c)
+        blk = dXs @ (0.015 * torch.randn((p, w), generator=gen, device=dev)) + torch.randn((T, w), generator=gen, device=dev)
+        Yw[:, c:c + w] = blk.cpu().numpy()
+    del dXs, blk
+    torch.cuda.empty_cache()
     model = lc.BandedNestedCVModel("r")
     m, W, a = model.fit_predict(X, Yw, bands=[(0, p // 2), (p // 2, p)], band_scales=[1.0, 2.0], **kw)
-    assert W.shape == (p, V) and np.isfinite(W).all() and np.isfinite(np.asarray(m["correlations"])).all()
+    assert W.shape == (p, V) and W.dtype == np.float32 and np.isfinite(W).all() and np.isfinite(np.asarray(m["correlations"])).all()
+    assert len(model.last_fit["panels"]) > 1, "80 000 voxels must cross the link in panels"
+    lo, hi = 40960, 45056
+    m_b, W_b, a_b = lc.BandedNestedCVModel("r").fit_predict(X, Yw[:, lo:hi], bands=[(0, p // 2), (p // 2, p)],
+                                                            band_scales=[1.0, 2.0], **kw)
+    # (np.mean over the folds is float32 in both fits: no NaN r anywhere in this volume, nested_cv.py:276)
+    assert np.array_equal(np.asarray(m_b["correlations"]), np.asarray(m["correlations"])[lo:hi]) and np.array_equal(a_b, a[lo:hi])
+    assert np.array_equal(W_b, W[:, lo:hi])
     oracle, detail = fx.reference_fit(g, "cfg5", n_rows=T)
     # weights come back on the ORIGINAL feature scale: w_b = w'_b / gamma_b
     assert_matches_oracle(lc, model, (m, W * gamma[:, None].astype(np.float32), a), oracle, detail, Xs, Yw, kw,
