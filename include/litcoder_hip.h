@@ -618,7 +618,7 @@ int lc_fisher_combine(const double* d_p, int k, int64_t V, double* d_out, lc_str
 
 /* Benjamini-Hochberg step-up (statsmodels `fdrcorrection(pvals, alpha, method="indep")`, call sites
  * nested_cv.py:158,263,282): d_reject (n) u8 and d_padj (n) f64 in input order.  d_work: at least
- * lc_bh_fdr_work_bytes(n) bytes (sorted copies + hipCUB radix-sort temporary), caller-owned. */
+ * lc_bh_fdr_work_bytes(n) bytes (sorted copies + the scratch of the library's own LSD radix sort), caller-owned. */
 int64_t lc_bh_fdr_work_bytes(int64_t n);
 int lc_bh_fdr(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, double* d_padj,
               void* d_work, int64_t work_bytes, lc_stream_t stream);
@@ -630,14 +630,6 @@ int lc_bh_fdr(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, dou
  * p-values that hug the BH line from above make it fall one step at a time): *d_status = 0 and the mask is written, or
  * *d_status = 1 and it is not -- the caller then runs lc_bh_fdr on that vector. */
 int lc_bh_reject(const double* d_p, int64_t n, double alpha, uint8_t* d_reject, int32_t* d_status, lc_stream_t stream);
-
-/* Diagnostics only (tools/gpu_kernel_bench.py stamps): the fp16x3 sweep with s_memtime stamps at its phase
- * boundaries; d_stamps (32 x uint64, caller-zeroed) receives per wave-group sums of the five segments of an
- * iteration.  Not used by the product path. */
-int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
-                            const void* d_yt, const float* d_cscale_inv, const float* d_yv,
-                            int64_t V, int n_val, const float* d_ystat, float* d_part,
-                            unsigned long long* d_stamps, lc_stream_t stream);
 
 /* The test rows of the refit without their predictions ever reaching HBM (nested_cv.py:151-155, 251-257: pred = Pstim wt,
  * then Pearson r per voxel; SURVEY K8 + K9): the grouped contraction of lc_gemm_grouped_f16x3 over Mrows = the test rows
@@ -653,11 +645,8 @@ int lc_gemm_grouped_f16x3_pearson(const void* d_at, const float* d_rowscale_inv,
                                   const int32_t* d_y_rows, const int32_t* d_y_cols, double* d_part, double* d_r,
                                   lc_stream_t stream);
 
-/* Diagnostics only (tools/gpu_kernel_bench.py plain16): the single-group plain contraction of lc_gemm_grouped_f16x3 on
- * v_mfma_f32_16x16x32_f16 instead of 32x32x16 (an experiment kernel; not used by the product path). */
-int lc_debug_gemm_f16x3_wide(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
-                             const float* d_cscale_inv, float* d_c, int64_t ldc, int64_t Ncols, int64_t K,
-                             lc_stream_t stream);
+/* (The diagnostic builds of that kernel -- in-kernel stamps, the 16x16x32 experiment -- are not part of this library since
+ * round 5: tools/debug_kernels/, built into tools/bin/liblitcoder_debug.so.) */
 
 /* Grouped GEMM of the refit (lc_gemm_grouped_f32's job) on the same fp16x3 scheme:
  * C[:, tile] = A_g(tile) . B[:, tile].  d_at: G tiled images made by lc_split_rows_f16 (one per group, each

@@ -130,7 +130,6 @@ SIGNATURES = {
     "lc_series_sweep_scores_f16x3_folds": (c_int, [_ptr, _ptr, c_int, c_int, POINTER(c_int32), c_int64, _ptr, _ptr, c_int64,
                                                    _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr, c_int,
                                                    c_int64, POINTER(c_int64), POINTER(c_int64), _ptr]),
-    "lc_debug_gemm_f16x3_wide": (c_int, [_ptr, _ptr, c_int64, _ptr, _ptr, _ptr, c_int64, c_int64, c_int64, _ptr]),
     "lc_series_scores": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr,
                                  c_int, _ptr]),
     "lc_transpose_rows_f64": (c_int, [_ptr, c_int64, _ptr, c_int, c_int64, _ptr, _ptr]),
@@ -146,8 +145,6 @@ SIGNATURES = {
     "lc_permute_cols_f16": (c_int, [_ptr, _ptr, c_int64, c_int, _ptr, _ptr]),
     "lc_alpha_sweep_scores_f16x3": (c_int, [_ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int, _ptr, _ptr,
                                             c_int, _ptr, _ptr, c_int, c_int64, c_int64, c_int64, _ptr]),
-    "lc_debug_sweep16_stamps": (c_int, [_ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int, _ptr, _ptr, _ptr,
-                                        _ptr]),
     "lc_gemm_grouped_f16x3": (c_int, [_ptr, _ptr, c_int64, _ptr, _ptr, _ptr, c_int64, c_int64, c_int64,
                                       POINTER(c_int32), c_int, _ptr, c_int64, c_int64, c_int64, _ptr]),
     "lc_gemm_grouped_f16x3_pearson": (c_int, [_ptr, _ptr, c_int64, _ptr, _ptr, c_int64, c_int64, POINTER(c_int32), c_int,

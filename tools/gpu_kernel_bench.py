@@ -94,11 +94,14 @@ if "sweep16" in what:
     print("   max |score - fp64 ref| on sample columns:", float((scores[:, cols].double() - ref).abs().max()))
     if "stamps" in what:
         import ctypes
-        from litcoder_core_amd import _lib
+        sys.path.insert(0, os.path.join(ROOT, "tools", "debug_kernels"))
+        import build as debug_build                      # tools/bin/liblitcoder_debug.so: the diagnostics left the product ABI
+        dbg = debug_build.load()
         st = torch.zeros(32, dtype=torch.int64, device=dev)
         p_ = lambda t: ctypes.c_void_p(t.data_ptr())
-        _lib.call("lc_debug_sweep16_stamps", p_(Ht), p_(rs_inv), A, M, N, p_(Yt), p_(cs[V:]), p_(yv), V, n_v, p_(ystat),
-                  p_(part), p_(st), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = dbg.lc_debug_sweep16_stamps(p_(Ht), p_(rs_inv), A, M, N, p_(Yt), p_(cs[V:]), p_(yv), ctypes.c_int64(V), n_v,
+                                         p_(ystat), p_(part), p_(st), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
         torch.cuda.synchronize()
         h = st.cpu().numpy().reshape(2, 16)
         for g_ in range(2):
@@ -137,10 +140,14 @@ if "plain16" in what:
             err_l = float((C2[128:132, :512].double() - ref_l).abs().max() / ref_l.abs().max())
             print(f"   with light slabs (8 of 16): {ms_l:.2f} ms; rel err of a light row {err_l:.1e}")
         fl = 2.0 * rows * K * V
-        from litcoder_core_amd import _lib
+        import ctypes
+        sys.path.insert(0, os.path.join(ROOT, "tools", "debug_kernels"))
+        import build as debug_build
+        dbg = debug_build.load()
         Cw = torch.zeros((rows, Vt), dtype=torch.float32, device=dev)
-        fw = lambda: _lib.call("lc_debug_gemm_f16x3_wide", ops._p(At), ops._p(rs), rows, ops._p(Yt), ops._p(cs_inv), ops._p(Cw),
-                               Vt, Vt, K, ops._s())
+        i64 = ctypes.c_int64
+        fw = lambda: dbg.lc_debug_gemm_f16x3_wide(ops._p(At), ops._p(rs), i64(rows), ops._p(Yt), ops._p(cs_inv), ops._p(Cw),
+                                                  i64(Vt), i64(Vt), i64(K), ops._s())
         ms_w = timeit(fw)
         dw = float((Cw[:, :V] - C[:, :V]).abs().max() / C[:, :V].abs().max())
         print(f"   the same on v_mfma_f32_16x16x32_f16 (experiment kernel): {ms_w:.2f} ms; max difference to the 32x32x16 "
