@@ -142,92 +142,133 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos(const T* __restrict__ da
 
 // All stories of a training run in ONE launch (trainer.py:125-157 calls the downsampler once per story: 27 launches of
 // 26 us each, every block evaluating the fp64 sines of ALL 2500 word times of its story).  A story table gives each
-// story's slice of the concatenated inputs / outputs; a block is one (output row, 256-column slab) of some story.  When
-// a story's sample times are non-decreasing (``sorted``: word onsets always are) the samples that can carry weight --
-// |t| <= window lobes around the output time -- are a contiguous index range found by bisection with the SAME
-// comparison lanczosfun applies (interpdata.py:62), so only ~64 instead of ~2500 weights are evaluated; an unsorted
-// story scans everything.  Weights, their order of accumulation and the arithmetic are those of k_lanczos: same bits.
+// story's slice of the concatenated inputs / outputs.  When a story's sample times are non-decreasing (``sorted``: word
+// onsets always are) the samples that can carry weight -- |t| <= window lobes around the output time -- are a contiguous
+// index range found by bisection with the SAME comparison lanczosfun applies (interpdata.py:62), so only ~64 instead of
+// ~2500 weights are evaluated per output row; an unsorted story scans everything.  (Round 4's kernel, one block per
+// output row, is gone: k_lanczos_rows below.)
 struct LzStory {
     long long old_off, n_old, new_off;
     double cutoff;
     int sorted;
 };
 
+// Round 5: LZR consecutive output rows per block.  Neighbouring TRs share most of their words (a window of +-3 lobes is
+// ~60 words, a TR step ~7): the block-per-row kernel above re-read every input row ~9 times (from L2) with one 4-byte load
+// per thread and trip behind two 11-step bisections -- 0.95 TB/s of algorithmic bytes on the 27 stories of a LeBel run,
+// 0.12 of the HBM roof.  Here a block finds the windows of its LZR rows at once (one lane per row), builds
+// the dense (row, sample) weight table of their UNION range in LDS (zeros outside a row's own window), and every thread
+// streams its column down the union ONCE, feeding LZR accumulators: ~14 instead of ~64 loads per output value.  Weights
+// are lanczosfun's (interpdata.py:59-63) evaluated exactly as above, every output adds its non-zero terms in increasing
+// sample order: the same bits as k_lanczos / k_lanczos_stories.  A story whose times are not sorted (or whose cutoff is not
+// a positive finite number: fewer than two output times, decreasing output times) takes its whole sample range as the
+// window -- correct, slow, and not what word onsets look like.
+constexpr int LZR = 8;            // output rows per block
+constexpr int LZ_SPAN = 256;      // samples of the union range per pass (LDS: LZR x LZ_SPAN doubles = 16 KB)
+
 template <typename T, bool RECTIFY>
-__global__ void __launch_bounds__(LZ_THREADS) k_lanczos_stories(const T* __restrict__ data, long long D, long long ld_in,
-                                                                const double* __restrict__ oldtime,
-                                                                const double* __restrict__ newtime,
-                                                                const int* __restrict__ row_story,
-                                                                const LzStory* __restrict__ stories, double window,
-                                                                double* __restrict__ out, long long ld_out) {
-    __shared__ double w[LZ_CHUNK];
-    __shared__ int wj[LZ_CHUNK];
-    __shared__ int wave_cnt[LZ_THREADS / 64];
-    const long long i = blockIdx.x;                                    // output row in the concatenation
-    const LzStory st = stories[row_story[i]];
+__global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict__ data, long long D, long long ld_in,
+                                                             const double* __restrict__ oldtime,
+                                                             const double* __restrict__ newtime, long long n_new_total,
+                                                             const int* __restrict__ row_story,
+                                                             const LzStory* __restrict__ stories, double window,
+                                                             double* __restrict__ out, long long ld_out) {
+    __shared__ double W[LZ_SPAN][LZR];                                 // [sample of the pass][row]: a thread reads 64 B per sample
+    __shared__ long long s_lo[LZR], s_hi[LZR];                         // windows as sample indices of the CONCATENATION
+    __shared__ double s_tn[LZR], s_cut[LZR];
+    const long long i0 = (long long)blockIdx.x * LZR;
+    const int nrows = (int)min((long long)LZR, n_new_total - i0);
     const long long c = (long long)blockIdx.y * LZ_THREADS + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double tn = newtime[i];
-    const double* ot = oldtime + st.old_off;
-    const T* dat = data + st.old_off * ld_in;
-    long long jlo = 0, jhi = st.n_old;
-    if (st.sorted) {
-        // (tn - ot[j]) * cutoff is non-increasing in j: first j with t <= window, first j with t < -window
-        long long a = 0, b = st.n_old;
-        while (a < b) {
-            const long long m = (a + b) >> 1;
-            if ((tn - ot[m]) * st.cutoff > window) a = m + 1; else b = m;
+    if (threadIdx.x < LZR) {
+        const int r = threadIdx.x;
+        long long lo = 0, hi = 0;
+        double tn = 0.0, cut = 0.0;
+        if (r < nrows) {
+            const LzStory st = stories[row_story[i0 + r]];
+            tn = newtime[i0 + r];
+            cut = st.cutoff;
+            const double* ot = oldtime + st.old_off;
+            long long a = 0, b = st.n_old;
+            if (st.sorted) {
+                // (tn - ot[j]) * cutoff is non-increasing in j: first j with t <= window, first j with t < -window
+                while (a < b) {
+                    const long long m = (a + b) >> 1;
+                    if ((tn - ot[m]) * cut > window) a = m + 1; else b = m;
+                }
+                lo = a;
+                b = st.n_old;
+                while (a < b) {
+                    const long long m = (a + b) >> 1;
+                    if ((tn - ot[m]) * cut >= -window) a = m + 1; else b = m;
+                }
+                hi = a;
+            } else {
+                hi = st.n_old;
+            }
+            lo += st.old_off;
+            hi += st.old_off;
         }
-        jlo = a;
-        b = st.n_old;
-        while (a < b) {
-            const long long m = (a + b) >> 1;
-            if ((tn - ot[m]) * st.cutoff >= -window) a = m + 1; else b = m;
-        }
-        jhi = a;
+        s_lo[r] = lo; s_hi[r] = hi; s_tn[r] = tn; s_cut[r] = cut;
     }
-    double acc = 0.0, accp = 0.0;
-    int fill = 0;
-    for (long long j0 = jlo; j0 < jhi || fill > 0; j0 += LZ_THREADS) {
-        const long long j = j0 + threadIdx.x;
-        double wt = 0.0;
-        if (j < jhi) wt = interp_weight<WK_LANCZOS>(tn - ot[j], st.cutoff, window, 0);
-        const unsigned long long m = __ballot(wt != 0.0);
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int base = fill, total = 0;
+    __syncthreads();
+    long long gmin = 0, gmax = 0;
+    bool any = false;
 #pragma unroll
-        for (int q = 0; q < LZ_THREADS / 64; ++q) {
-            if (q < wave) base += wave_cnt[q];
-            total += wave_cnt[q];
+    for (int r = 0; r < LZR; ++r)
+        if (r < nrows && s_hi[r] > s_lo[r]) {
+            gmin = any ? min(gmin, s_lo[r]) : s_lo[r];
+            gmax = any ? max(gmax, s_hi[r]) : s_hi[r];
+            any = true;
         }
-        if (wt != 0.0) {
-            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            w[pos] = wt;
-            wj[pos] = (int)j;
+    double acc[LZR], accp[LZR];
+#pragma unroll
+    for (int r = 0; r < LZR; ++r) { acc[r] = 0.0; accp[r] = 0.0; }
+    for (long long g0 = gmin; g0 < gmax; g0 += LZ_SPAN) {
+        const int span = (int)min((long long)LZ_SPAN, gmax - g0);
+        // the pass's weight table: entry (jj, r) by thread (jj * LZR + r) mod 256 -- LZR weights of one sample are neighbours
+        for (int e = threadIdx.x; e < span * LZR; e += LZ_THREADS) {
+            const int jj = e / LZR, r = e - jj * LZR;
+            const long long g = g0 + jj;
+            double wt = 0.0;
+            if (r < nrows && g >= s_lo[r] && g < s_hi[r]) wt = interp_weight<WK_LANCZOS>(s_tn[r] - oldtime[g], s_cut[r], window, 0);
+            W[jj][r] = wt;
         }
-        fill += total;
         __syncthreads();
-        const bool last = j0 + LZ_THREADS >= jhi;
-        if (fill > LZ_CHUNK - LZ_THREADS || last) {
-            if (c < D)
-                for (int e = 0; e < fill; ++e) {
-                    const double x = (double)dat[(long long)wj[e] * ld_in + c];
-                    if (RECTIFY) {
-                        acc += w[e] * fmin(x, 0.0);
-                        accp += w[e] * fmax(x, 0.0);
-                    } else {
-                        acc += w[e] * x;
+        if (c < D) {
+            const T* col = data + g0 * ld_in + c;
+            constexpr int U = 8;                                       // samples in flight per thread
+            for (int j0 = 0; j0 < span; j0 += U) {
+                double x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[u] = j0 + u < span ? (double)col[(long long)(j0 + u) * ld_in] : 0.0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (j0 + u < span) {
+#pragma unroll
+                        for (int r = 0; r < LZR; ++r) {
+                            const double w = W[j0 + u][r];
+                            if (w != 0.0) {                            // (a zero weight adds nothing -- also for a NaN sample)
+                                if (RECTIFY) {
+                                    acc[r] += w * fmin(x[u], 0.0);
+                                    accp[r] += w * fmax(x[u], 0.0);
+                                } else {
+                                    acc[r] += w * x[u];
+                                }
+                            }
+                        }
                     }
                 }
-            fill = 0;
-            __syncthreads();
-            if (last) break;
+            }
         }
+        __syncthreads();
     }
     if (c < D) {
-        out[i * ld_out + c] = acc;
-        if (RECTIFY) out[i * ld_out + D + c] = accp;
+#pragma unroll
+        for (int r = 0; r < LZR; ++r)
+            if (r < nrows) {
+                out[(i0 + r) * ld_out + c] = acc[r];
+                if (RECTIFY) out[(i0 + r) * ld_out + D + c] = accp[r];
+            }
     }
 }
 
@@ -260,22 +301,47 @@ __global__ void __launch_bounds__(256) k_story_design(const double* __restrict__
         const long long src = t - d;
         return (src >= 0 && src < st.n_in && d < st.n_in && -d < st.n_in) ? f[src * ld_in] : 0.0;
     };
+    // (round 5: SD_U rows are loaded before any of them is added -- the sums still take the rows one by one, numpy's order,
+    // but a thread no longer waits a memory round trip per row: the kernel was a chain of ~1000 dependent loads per thread
+    // at little over one wave per SIMD, 0.47 ms for 27 stories = 0.05 of the HBM roof on its algorithmic bytes)
+    constexpr int SD_U = 16;
     double mean = 0.0;
-    for (long long t = st.a; t < st.b; ++t) mean = mean + val(t);
+    for (long long t0 = st.a; t0 < st.b; t0 += SD_U) {
+        double v[SD_U];
+#pragma unroll
+        for (int u = 0; u < SD_U; ++u) v[u] = t0 + u < st.b ? val(t0 + u) : 0.0;
+#pragma unroll
+        for (int u = 0; u < SD_U; ++u)
+            if (t0 + u < st.b) mean = mean + v[u];
+    }
     mean = mean / (double)n;
     double ss = 0.0;
-    for (long long t = st.a; t < st.b; ++t) {
-        const double dv = val(t) - mean;
-        ss = ss + dv * dv;
+    for (long long t0 = st.a; t0 < st.b; t0 += SD_U) {
+        double v[SD_U];
+#pragma unroll
+        for (int u = 0; u < SD_U; ++u) v[u] = t0 + u < st.b ? val(t0 + u) : 0.0;
+#pragma unroll
+        for (int u = 0; u < SD_U; ++u)
+            if (t0 + u < st.b) {
+                const double dv = v[u] - mean;
+                ss = ss + dv * dv;
+            }
     }
     const double sd = sqrt(ss / (double)n);
     float* x = X + st.out_row0 * ldx + e;
-    for (long long t = st.a; t < st.b; ++t) {
-        double m = val(t) - mean;
-        if (sd != 0.0) m = m / sd;
-        // np.nan_to_num: NaN -> 0, +-inf -> +-DBL_MAX (which the float32 cast turns back into +-inf: nothing to do)
-        if (m != m) m = 0.0;
-        x[(t - st.a) * ldx] = (float)m;
+    for (long long t0 = st.a; t0 < st.b; t0 += SD_U) {
+        double v[SD_U];
+#pragma unroll
+        for (int u = 0; u < SD_U; ++u) v[u] = t0 + u < st.b ? val(t0 + u) : 0.0;
+#pragma unroll
+        for (int u = 0; u < SD_U; ++u)
+            if (t0 + u < st.b) {
+                double m = v[u] - mean;
+                if (sd != 0.0) m = m / sd;
+                // np.nan_to_num: NaN -> 0, +-inf -> +-DBL_MAX (which the float32 cast turns back into +-inf: nothing to do)
+                if (m != m) m = 0.0;
+                x[(t0 + u - st.a) * ldx] = (float)m;
+            }
     }
 }
 
@@ -405,15 +471,15 @@ extern "C" int lc_lanczos_interp_stories(const void* d_data, int dtype, int64_t 
     if (n_new_total == 0 || D == 0) return LC_OK;
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_LANCZOS, s);
-    dim3 grid((unsigned)n_new_total, (unsigned)lc::ceil_div<long long>(D, LZ_THREADS));
+    dim3 grid((unsigned)lc::ceil_div<long long>(n_new_total, LZR), (unsigned)lc::ceil_div<long long>(D, LZ_THREADS));
 #define LC_LZS(T, R)                                                                                                  \
-    hipLaunchKernelGGL((k_lanczos_stories<T, R>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, (long long)D,      \
-                       (long long)ld_in, d_oldtime, d_newtime, d_row_story, (const LzStory*)d_stories, window, d_out,  \
-                       (long long)ld_out)
+    hipLaunchKernelGGL((k_lanczos_rows<T, R>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, (long long)D,         \
+                       (long long)ld_in, d_oldtime, d_newtime, (long long)n_new_total, d_row_story,                   \
+                       (const LzStory*)d_stories, window, d_out, (long long)ld_out)
     if (dtype == LC_F32) { if (rectify) LC_LZS(float, true); else LC_LZS(float, false); }
     else                 { if (rectify) LC_LZS(double, true); else LC_LZS(double, false); }
 #undef LC_LZS
-    return lc::launched("k_lanczos_stories");
+    return lc::launched("k_lanczos_rows");
 }
 
 extern "C" int lc_story_design_f32(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,

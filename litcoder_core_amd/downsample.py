@@ -34,10 +34,15 @@ def _times(data, data_times, tr_times):
 def _lanczos(data, data_times, tr_times, window=3, cutoff_mult=1.0, rectify=False):
     """interpdata.py:87-126.  cutoff = 1/mean(diff(newtime))*cutoff_mult (:107)."""
     oldtime, newtime = _times(data, data_times, tr_times)
-    cutoff = 1 / np.mean(np.diff(newtime)) * cutoff_mult
     dev = ops.device()
-    out = ops.lanczos_interp(_to_device(data, dev), torch.from_numpy(oldtime).to(dev), torch.from_numpy(newtime).to(dev),
-                             cutoff, window, rectify)
+    if len(newtime) == 0 or np.shape(data)[0] == 0:
+        cutoff = 1 / np.mean(np.diff(newtime)) * cutoff_mult
+        out = ops.lanczos_interp(_to_device(data, dev), torch.from_numpy(oldtime).to(dev), torch.from_numpy(newtime).to(dev),
+                                 cutoff, window, rectify)
+        return out.cpu().numpy()
+    # one story through the batched kernel (round 5: several output rows per workgroup, the window found by bisection when
+    # the sample times are sorted; same cutoff expression, same weights, same order of accumulation: the same bits)
+    out, _ = ops.lanczos_interp_stories(_to_device(data, dev), [oldtime], [newtime], window, cutoff_mult, rectify)
     return out.cpu().numpy()
 
 

@@ -202,7 +202,11 @@ def lanczos_interp_stories(data, oldtimes, newtimes, window, cutoff_mult, rectif
         raise RuntimeError(f"shape mismatch: {data.shape[0]} sample rows, {int(old_off[-1])} sample times")
     with np.errstate(all="ignore"):                     # (a story with < 2 output times: nan cutoff, like the reference)
         cutoff = np.asarray([1.0 / np.mean(np.diff(t)) * cutoff_mult if len(t) else 0.0 for t in new], dtype=np.float64)
-    ordered = np.asarray([int(bool(np.all(np.diff(t) >= 0))) for t in old], dtype=np.int32)
+    # the bisected window needs (tn - ot[j]) * cutoff to be non-increasing in j: sorted sample times AND a positive finite
+    # cutoff -- decreasing output times give a negative one, fewer than two a NaN (lanczosfun then yields NaN weights, which
+    # only the full scan reproduces: ADVICE r4)
+    ordered = np.asarray([int(bool(np.all(np.diff(t) >= 0)) and bool(np.isfinite(c) and c > 0)) for t, c in zip(old, cutoff)],
+                         dtype=np.int32)
     table, stride = story_table([(np.int64, old_off[:-1]), (np.int64, n_old), (np.int64, new_off[:-1]), (np.float64, cutoff),
                                  (np.int32, ordered)], dev)
     assert stride == 40

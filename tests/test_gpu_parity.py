@@ -1170,7 +1170,7 @@ def test_story_pipeline_pieces_bitwise(lc):
     # ---- Lanczos for all stories in one launch
     D = 70
     olds, news, datas = [], [], []
-    for k, n_tr in enumerate((40, 1, 77, 25)):
+    for k, n_tr in enumerate((40, 1, 77, 25, 9, 30)):
         n_w = int(7.1 * n_tr) + 3
         t_old = np.sort(rng.uniform(0, 2.0 * n_tr, n_w))
         if k == 2:
@@ -1179,7 +1179,12 @@ def test_story_pipeline_pieces_bitwise(lc):
             t_old[5] = 7.0
             t_old.sort()                                         # an exact hit on an output time (t == 0 branch)
         olds.append(t_old)
-        news.append(1.0 + 2.0 * np.arange(n_tr + 2))
+        t_new = 1.0 + 2.0 * np.arange(n_tr + 2)
+        if k == 4:
+            t_new = t_new[:1]                                    # ONE output time: cutoff = 1 / mean(diff([])) = NaN -> NaN rows,
+        if k == 5:                                               # as lanczosfun gives them
+            t_new = t_new[::-1].copy()                           # decreasing output times: a negative cutoff
+        news.append(t_new)
         datas.append(rng.standard_normal((n_w, D)).astype(np.float32 if k % 2 else np.float64))
     for dt in (np.float32, np.float64):
         dat = [d.astype(dt) for d in datas]
@@ -1191,9 +1196,16 @@ def test_story_pipeline_pieces_bitwise(lc):
                     cutoff = 1.0 / np.mean(np.diff(news[k])) * 1.0
                 single = ops.lanczos_interp(torch.from_numpy(dat[k]).to(dev), torch.from_numpy(olds[k]).to(dev),
                                             torch.from_numpy(news[k]).to(dev), cutoff, 3, rectify)
-                assert torch.equal(out[off[k]:off[k + 1]], single), (k, dt, rectify)
-                want = olz.lanczos_interp(dat[k], olds[k], news[k], window=3, cutoff_mult=1.0, rectify=rectify)
-                np.testing.assert_allclose(out[off[k]:off[k + 1]].cpu().numpy(), want, rtol=0, atol=1e-12)
+                got_k = out[off[k]:off[k + 1]].cpu().numpy()
+                assert np.array_equal(got_k, single.cpu().numpy(), equal_nan=True), (k, dt, rectify)
+                with np.errstate(all="ignore"):
+                    want = olz.lanczos_interp(dat[k], olds[k], news[k], window=3, cutoff_mult=1.0, rectify=rectify)
+                np.testing.assert_allclose(got_k, want, rtol=0, atol=1e-12)
+                assert np.isnan(got_k).all() == (k == 4) and (k == 4 or np.isfinite(got_k).all()), k
+                if k not in (2, 4):                              # the Downsampler front-end takes the same kernel
+                    ds = lc.Downsampler().downsample(dat[k], olds[k], news[k], method="lanczos", window=3, cutoff_mult=1.0,
+                                                     rectify=rectify)
+                    assert np.array_equal(ds, got_k), (k, dt, rectify)
     # ---- FIR + trim + zs + nan_to_num + cast in one launch
     ndim, delays = 13, [1, 2, 3, 4]
     feats = [rng.standard_normal((n, ndim)) * 3 + 1 for n in (60, 23, 18, 91)]

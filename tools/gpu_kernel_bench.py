@@ -157,6 +157,55 @@ if "plain16" in what:
         print(f"plain f16x3 GEMM {label} ({rows} x {K} x {V}): {ms:.2f} ms -> {fl / ms / 1e9:.1f} TFLOP/s algorithmic, "
               f"{3 * fl / ms / 1e9:.0f} TF of fp16 MFMA; rel err {err:.1e}")
 
+if "preproc" in what:
+    # the preprocessing launches BASELINE configs[2] actually issues (harness.StoryPipeline.fit_words): ALL 27 stories'
+    # Lanczos resampling in one launch (lc_lanczos_interp_stories) and their design matrix in one launch
+    # (lc_story_design_f32), against the HBM roof on their algorithmic bytes (n_old D in_bytes + n_new D 8 for
+    # the resampler; features read once + the float32 design written for the design kernel); and one story of the speech
+    # shape (7000 x 1280 -> 350) through the same resampler
+    import bench
+    rng = np.random.default_rng(0)
+    words, wtimes, trtimes, _brain = bench.synth_stories(256, dev)
+    names = list(words)
+    dW = torch.cat([torch.from_numpy(words[s_]).to(dev) for s_ in names])
+    olds, news = [wtimes[s_] for s_ in names], [trtimes[s_] for s_ in names]
+    n_old, n_new, D = dW.shape[0], sum(len(t) for t in news), dW.shape[1]
+
+    def report_p(name, nbytes, ms):
+        print(f"{name}: {ms * 1e3:.1f} us, {nbytes / 1e6:.1f} MB algorithmic -> {nbytes / ms / 1e6:.0f} GB/s "
+              f"({nbytes / ms / 1e6 / 8000:.2f} of 8 TB/s)")
+    # (the launch alone: tables and times are uploaded once here, as a caller that resamples repeatedly would)
+    ms = timeit(lambda: ops.lanczos_interp_stories(dW, olds, news, 3, 1.0, False), reps=10)
+    print(f"lanczos_interp_stories incl. its host-side table uploads: {ms * 1e3:.0f} us")
+    import ctypes
+    from litcoder_core_amd import _lib
+    old_off = np.concatenate([[0], np.cumsum([len(t) for t in olds])])
+    new_off = np.concatenate([[0], np.cumsum([len(t) for t in news])])
+    cutoff = np.asarray([1.0 / np.mean(np.diff(t)) for t in news])
+    table, _stride = ops.story_table([(np.int64, old_off[:-1]), (np.int64, [len(t) for t in olds]), (np.int64, new_off[:-1]),
+                                      (np.float64, cutoff), (np.int32, np.ones(len(olds), dtype=np.int32))], dev)
+    row_story = ops.upload(np.repeat(np.arange(len(news), dtype=np.int32), [len(t) for t in news]), dev)
+    d_old, d_new = ops.upload(np.concatenate(olds), dev), ops.upload(np.concatenate(news), dev)
+    feat = torch.empty((n_new, D), dtype=torch.float64, device=dev)
+    launch = lambda: _lib.call("lc_lanczos_interp_stories", ops._p(dW), 0, D, dW.stride(0), ops._p(d_old), ops._p(d_new), n_new,
+                               ops._p(row_story), ops._p(table), len(news), 3.0, 0, ops._p(feat), D, ops._s())
+    ms = timeit(launch, reps=20)
+    report_p(f"k_lanczos_rows, {len(news)} stories: {n_old} words x {D} f32 -> {n_new} TRs f64 (one launch)",
+             n_old * D * 4 + n_new * D * 8, ms)
+    pipe_ = __import__("litcoder_core_amd").StoryPipeline([1, 2, 3, 4], bench.CFG3_TRIM)
+    n_in = [len(t) for t in news]
+    ms = timeit(lambda: pipe_.design(feat, new_off, n_in, names), reps=10)
+    dX_, T_, Tt_, p_, _ = pipe_.design(feat, new_off, n_in, names)
+    report_p(f"k_story_design, {len(news)} stories: FIR x 4 + trim + zs + nan_to_num + f32 cast -> ({T_ + Tt_}, {p_}) "
+             "(incl. the zero fill of the design and the table upload)", n_new * D * 8 + (T_ + Tt_) * p_ * 4, ms)
+    # one story at the speech shape
+    n_o, Ds = 7000, 1280
+    ot_ = np.sort(rng.uniform(0, 700, n_o))
+    nt_ = 1.0 + 2.0 * np.arange(350)
+    ds_ = torch.randn((n_o, Ds), device=dev, dtype=torch.float64)
+    ms = timeit(lambda: ops.lanczos_interp_stories(ds_, [ot_], [nt_], 3, 1.0, False), reps=20)
+    report_p(f"lanczos, one story {n_o}x{Ds}->350 f64 (incl. table uploads)", n_o * Ds * 8 + 350 * Ds * 8, ms)
+
 if "series" in what:
     # lc_series_scores at the cfg2 shape: 4 terms x 480 rows x 80000 voxels, 16 alphas
     g = torch.Generator(device=dev); g.manual_seed(2)
