@@ -105,6 +105,11 @@ int lc_lanczos_interp_stories(const void* d_data, int dtype, int64_t D, int64_t 
  * floats per row, columns k*ndim + c for delay k).  Sums in numpy's order, no fused multiply-adds: the reference's bits. */
 int lc_story_design_f32(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,
                         const int64_t* h_delays, int nd, float* d_x, int64_t ldx, lc_stream_t stream);
+/* ... given a bound on the stories' row counts (max_story_rows >= every story's n_in): a workgroup then holds 16 input
+ * columns of a story in LDS, reads them from HBM once for all delays and all three passes (round 5), same values. */
+int lc_story_design_f32_rows(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,
+                             int64_t max_story_rows, const int64_t* h_delays, int nd, float* d_x, int64_t ldx,
+                             lc_stream_t stream);
 
 /* sincinterp2D (downsample/interpdata.py:66-84) with sincfun (:29-42, array branch): same banded
  * weighted-row-sum kernel as Lanczos with the sinc weight, optional causal mask and per-output-row
@@ -213,6 +218,10 @@ int lc_gather_f32(const float* d_in, int64_t ld_in, const int32_t* d_rows, int64
 int lc_scatter_axpy_f32(const float* d_w, int64_t ld_w, int64_t n_rows, const int32_t* d_cols,
                         int64_t n_cols, float scale, float* d_acc, int64_t ld_acc,
                         lc_stream_t stream);
+/* d_dst[r, d_cols[j]] = d_src[r, j] for 4- or 8-byte elements (an overwrite; d_cols[j] < 0 skipped; the indices distinct):
+ * the columns of the f32 side path back into the main path's score / weight / result matrices. */
+int lc_scatter_cols(const void* d_src, int64_t ld_src, int64_t n_rows, int elem_bytes, const int32_t* d_cols,
+                    int64_t n_cols, void* d_dst, int64_t ld_dst, lc_stream_t stream);
 
 /* The same mean over folds (nested_cv.py:249,293-296) without a read-modify-write of the accumulator per fold: each
  * fold keeps its alpha-sorted weight matrix, lc_invert_perm notes where every voxel's column went
@@ -526,6 +535,11 @@ int lc_split_rows_f16_alphas(const float* d_h, int64_t ld, int groups, int A, in
  * should use lc_alpha_sweep_scores. */
 int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
                       int32_t* d_flag, lc_stream_t stream);
+/* ... with WHICH columns raised the flag (round 5): d_colflag (V) u8, 1 = the column's dynamic range is too wide for the
+ * fp16 hi/lo split.  A handful of such voxels is recomputed on an exact-f32 side path and only they leave the f16x3
+ * arithmetic (the reference treats every column alike in fp32, ridge_regression.py:104-125); needs d_flag. */
+int lc_col_scales_f16_flags(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale, int32_t* d_flag,
+                            uint8_t* d_colflag, lc_stream_t stream);
 
 /* The primal form's operand  B_f = B_all - B_val(f)  (Rstim'Rresp of an inner training set as the outer block's minus
  * the validation block's, nested_cv.py:366-374 -> ridge_regression.py:104-106) and its column scales in ONE pass:

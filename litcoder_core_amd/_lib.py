@@ -39,6 +39,7 @@ SIGNATURES = {
     "lc_cast_f64_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64, _ptr]),
     "lc_gather_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr]),
     "lc_scatter_axpy_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, c_float, _ptr, c_int64, _ptr]),
+    "lc_scatter_cols": (c_int, [_ptr, c_int64, c_int64, c_int, _ptr, c_int64, _ptr, c_int64, _ptr]),
     "lc_invert_perm": (c_int, [_ptr, c_int64, c_int32, _ptr, _ptr]),
     "lc_combine_folds_f32": (c_int, [POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), POINTER(c_float), c_int, c_int64,
                                      c_int64, _ptr, c_int64, _ptr]),
@@ -85,6 +86,8 @@ SIGNATURES = {
     "lc_lanczos_interp_stories": (c_int, [_ptr, c_int, c_int64, c_int64, _ptr, _ptr, c_int64, _ptr, _ptr, c_int, c_double,
                                           c_int, _ptr, c_int64, _ptr]),
     "lc_story_design_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, POINTER(c_int64), c_int, _ptr, c_int64, _ptr]),
+    "lc_story_design_f32_rows": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int64, POINTER(c_int64), c_int, _ptr, c_int64,
+                                          _ptr]),
     "lc_upload_wait": (c_int, [_ptr, c_int, _ptr]),
     "lc_upload_finish": (c_int, [_ptr]),
     "lc_upload_free": (c_int, [_ptr]),
@@ -141,6 +144,7 @@ SIGNATURES = {
     "lc_split_rows_f16_groups": (c_int, [_ptr, c_int64, c_int, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_split_rows_f16_alphas": (c_int, [_ptr, c_int64, c_int, c_int, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_col_scales_f16": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr]),
+    "lc_col_scales_f16_flags": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr, _ptr]),
     "lc_split_cols_f16": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, _ptr, _ptr, _ptr]),
     "lc_permute_cols_f16": (c_int, [_ptr, _ptr, c_int64, c_int, _ptr, _ptr]),
     "lc_alpha_sweep_scores_f16x3": (c_int, [_ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int, _ptr, _ptr,

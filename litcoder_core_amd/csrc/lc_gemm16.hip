@@ -66,14 +66,20 @@ extern "C" int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int
     return lc_split_rows_f16_groups(d_h, ld, 1, rows, K, d_tiled, d_rowscale_inv, stream);
 }
 
-extern "C" int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
-                                 int32_t* d_flag, lc_stream_t stream) {
+extern "C" int lc_col_scales_f16_flags(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
+                                       int32_t* d_flag, uint8_t* d_colflag, lc_stream_t stream) {
     LC_REQUIRE(d_y && d_cscale, LC_E_BADARG, "lc_col_scales_f16: null pointer");     // d_flag may be NULL: scales only
     LC_REQUIRE(T > 0 && V > 0 && ldy >= V, LC_E_SHAPE, "lc_col_scales_f16: bad shape");
+    LC_REQUIRE(d_flag || !d_colflag, LC_E_BADARG, "lc_col_scales_f16: per-column flags need the flag pass (d_flag)");
     lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
     hipLaunchKernelGGL(k_col_scales, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, CS_RG), 0,
-                       lc::as_stream(stream), d_y, (long long)ldy, (int)T, (long long)V, d_cscale, d_flag);
+                       lc::as_stream(stream), d_y, (long long)ldy, (int)T, (long long)V, d_cscale, d_flag, d_colflag);
     return lc::launched("k_col_scales");
+}
+
+extern "C" int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
+                                 int32_t* d_flag, lc_stream_t stream) {
+    return lc_col_scales_f16_flags(d_y, ldy, T, V, d_cscale, d_flag, nullptr, stream);
 }
 
 extern "C" int lc_combine_terms_colmax_f32(const float* const* h_terms, const float* h_coef, int terms, float* d_out,

@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(256) k_split_rows_f16(const float* __restrict_
 // r = NaN -> (0, 1) (nested_cv.py:434-436) -- and its neighbours never see it (tests/test_gpu_parity.py).
 constexpr int CS_RG = 16, CS_UNROLL = 8;   // row groups per block, rows in flight per thread
 __global__ void __launch_bounds__(64 * CS_RG) k_col_scales(const float* __restrict__ y, long long ldy, int T, long long V,
-                                                           float* __restrict__ cs, int* __restrict__ flag) {
+                                                           float* __restrict__ cs, int* __restrict__ flag,
+                                                           unsigned char* __restrict__ colflag = nullptr) {
     __shared__ float sm[CS_RG][64];
     __shared__ int cnt[CS_RG][64];
     const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
@@ -151,7 +152,9 @@ __global__ void __launch_bounds__(64 * CS_RG) k_col_scales(const float* __restri
         e = max(-120, min(120, e));
         cs[c] = ldexpf(1.f, -e);
         cs[V + c] = ldexpf(1.f, e);
-        if (flag != nullptr && mx > 0.f && 2 * n_small > T) atomicOr(flag, 1);
+        const bool wide = flag != nullptr && mx > 0.f && 2 * n_small > T;
+        if (wide) atomicOr(flag, 1);
+        if (colflag != nullptr) colflag[c] = wide ? 1 : 0;       // WHICH columns (round 5: only they leave the fp16 path)
     }
 }
 

@@ -164,7 +164,7 @@ struct LzStory {
 // a positive finite number: fewer than two output times, decreasing output times) takes its whole sample range as the
 // window -- correct, slow, and not what word onsets look like.
 constexpr int LZR = 8;            // output rows per block
-constexpr int LZ_SPAN = 256;      // samples of the union range per pass (LDS: LZR x LZ_SPAN doubles = 16 KB)
+constexpr int LZ_SPAN = 256;      // samples of the union range per pass, a multiple of the batch (LDS: LZR x LZ_SPAN doubles)
 
 template <typename T, bool RECTIFY>
 __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict__ data, long long D, long long ld_in,
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict
                                                              const int* __restrict__ row_story,
                                                              const LzStory* __restrict__ stories, double window,
                                                              double* __restrict__ out, long long ld_out) {
-    __shared__ double W[LZ_SPAN][LZR];                                 // [sample of the pass][row]: a thread reads 64 B per sample
+    __shared__ double W[LZR][LZ_SPAN];                                 // [row][sample of the pass]
     __shared__ long long s_lo[LZR], s_hi[LZR];                         // windows as sample indices of the CONCATENATION
     __shared__ double s_tn[LZR], s_cut[LZR];
     const long long i0 = (long long)blockIdx.x * LZR;
@@ -225,35 +225,46 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict
     for (int r = 0; r < LZR; ++r) { acc[r] = 0.0; accp[r] = 0.0; }
     for (long long g0 = gmin; g0 < gmax; g0 += LZ_SPAN) {
         const int span = (int)min((long long)LZ_SPAN, gmax - g0);
-        // the pass's weight table: entry (jj, r) by thread (jj * LZR + r) mod 256 -- LZR weights of one sample are neighbours
-        for (int e = threadIdx.x; e < span * LZR; e += LZ_THREADS) {
-            const int jj = e / LZR, r = e - jj * LZR;
+        // the pass's weight table (zero outside a row's own window; the tail of the last batch of U samples zero too)
+        constexpr int U = 8;                                           // samples in flight per thread
+        const int span_u = (span + U - 1) / U * U;
+        for (int e = threadIdx.x; e < span_u * LZR; e += LZ_THREADS) {
+            const int r = e / span_u, jj = e - r * span_u;
             const long long g = g0 + jj;
             double wt = 0.0;
-            if (r < nrows && g >= s_lo[r] && g < s_hi[r]) wt = interp_weight<WK_LANCZOS>(s_tn[r] - oldtime[g], s_cut[r], window, 0);
-            W[jj][r] = wt;
+            if (r < nrows && jj < span && g >= s_lo[r] && g < s_hi[r])
+                wt = interp_weight<WK_LANCZOS>(s_tn[r] - oldtime[g], s_cut[r], window, 0);
+            W[r][jj] = wt;
         }
         __syncthreads();
         if (c < D) {
+            // a row takes part in a batch of U samples only when its window reaches into it -- a block-uniform (scalar) test;
+            // inside such a batch the weights outside the window are zeros and add nothing: acc + 0 * x == acc for finite x
+            // (the first version tested every weight: a compare and two selects per fp64 FMA made the kernel VALU-bound,
+            // 190 us for the 27 stories of a LeBel run; a NON-finite sample now spoils the rows whose batches cover it, up to
+            // U - 1 samples outside their windows -- the reference's dense np.dot spoils the whole output column)
+            int rlo[LZR], rhi[LZR];
+#pragma unroll
+            for (int r = 0; r < LZR; ++r) {
+                rlo[r] = __builtin_amdgcn_readfirstlane((int)max(-1ll, min((long long)span, s_lo[r] - g0)));
+                rhi[r] = __builtin_amdgcn_readfirstlane(r < nrows ? (int)max(0ll, min((long long)span, s_hi[r] - g0)) : 0);
+            }
             const T* col = data + g0 * ld_in + c;
-            constexpr int U = 8;                                       // samples in flight per thread
             for (int j0 = 0; j0 < span; j0 += U) {
                 double x[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) x[u] = j0 + u < span ? (double)col[(long long)(j0 + u) * ld_in] : 0.0;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (j0 + u < span) {
+                for (int r = 0; r < LZR; ++r) {
+                    if (j0 < rhi[r] && j0 + U > rlo[r]) {
 #pragma unroll
-                        for (int r = 0; r < LZR; ++r) {
-                            const double w = W[j0 + u][r];
-                            if (w != 0.0) {                            // (a zero weight adds nothing -- also for a NaN sample)
-                                if (RECTIFY) {
-                                    acc[r] += w * fmin(x[u], 0.0);
-                                    accp[r] += w * fmax(x[u], 0.0);
-                                } else {
-                                    acc[r] += w * x[u];
-                                }
+                        for (int u = 0; u < U; ++u) {
+                            const double w = W[r][j0 + u];
+                            if (RECTIFY) {
+                                acc[r] += w * fmin(x[u], 0.0);
+                                accp[r] += w * fmax(x[u], 0.0);
+                            } else {
+                                acc[r] += w * x[u];
                             }
                         }
                     }
@@ -342,6 +353,62 @@ __global__ void __launch_bounds__(256) k_story_design(const double* __restrict__
                 if (m != m) m = 0.0;
                 x[(t0 + u - st.a) * ldx] = (float)m;
             }
+    }
+}
+
+// The same through LDS (round 5).  The kernel above is one thread per (story, OUTPUT column) walking the story's rows three
+// times out of global memory: ~1000 loads in a dependent-by-latency chain per thread at little over one wave per SIMD,
+// and every input column read 4 delays x 3 passes times -- 0.47 ms for the 27 stories of a LeBel run (0.17 with batched
+// loads), 0.05-0.12 of the HBM roof on its algorithmic bytes.  Here a block takes SDC INPUT columns of one story: the
+// columns go to LDS once (all 256 threads load), nd x SDC threads run the two sequential sums per (delay, column) out of
+// LDS -- the delays of a column are shifted windows of the same data -- in numpy's order, without fused multiply-adds, and
+// all 256 threads write the normalised float32 rows.  Same values as k_story_design, bit for bit.
+constexpr int SDC = 16;
+__global__ void __launch_bounds__(256) k_story_design_lds(const double* __restrict__ feat, long long ndim, long long ld_in,
+                                                          const StoryRows* __restrict__ stories, FirDelays dl,
+                                                          float* __restrict__ X, long long ldx) {
+#pragma clang fp contract(off)
+    extern __shared__ double sd_lds[];                     // [n_in][SDC] columns, then mean[nd * SDC], sdev[nd * SDC]
+    const StoryRows st = stories[blockIdx.y];
+    const long long c0 = (long long)blockIdx.x * SDC;
+    const int t = threadIdx.x, col = t & (SDC - 1);
+    const long long n_in = st.n_in, n = st.b - st.a;
+    double* S = sd_lds;
+    double* mean_s = sd_lds + n_in * SDC;
+    double* sdev_s = mean_s + FIR_MAX_DELAYS * SDC;
+    const bool col_ok = c0 + col < ndim;
+    for (long long r = t >> 4; r < n_in; r += 256 / SDC)
+        S[r * SDC + col] = col_ok ? feat[(st.in_off + r) * ld_in + c0 + col] : 0.0;
+    __syncthreads();
+    auto val = [&](int k, int cc, long long tt) -> double {
+        const long long d = dl.d[k], src = tt - d;
+        return (src >= 0 && src < n_in && d < n_in && -d < n_in) ? S[src * SDC + cc] : 0.0;
+    };
+    if (t < dl.n * SDC) {
+        const int k = t >> 4;
+        double mean = 0.0;
+        for (long long tt = st.a; tt < st.b; ++tt) mean = mean + val(k, col, tt);
+        mean = mean / (double)n;
+        double ss = 0.0;
+        for (long long tt = st.a; tt < st.b; ++tt) {
+            const double dv = val(k, col, tt) - mean;
+            ss = ss + dv * dv;
+        }
+        mean_s[t] = mean;
+        sdev_s[t] = sqrt(ss / (double)n);
+    }
+    __syncthreads();
+    const int per_row = dl.n * SDC;
+    for (long long idx = t; idx < n * per_row; idx += 256) {
+        const long long row = idx / per_row;
+        const int e = (int)(idx - row * per_row), k = e >> 4, cc = e & (SDC - 1);
+        if (c0 + cc >= ndim) continue;
+        double m = val(k, cc, st.a + row) - mean_s[e];
+        const double sd = sdev_s[e];
+        if (sd != 0.0) m = m / sd;
+        // np.nan_to_num: NaN -> 0, +-inf -> +-DBL_MAX (which the float32 cast turns back into +-inf: nothing to do)
+        if (m != m) m = 0.0;
+        X[(st.out_row0 + row) * ldx + (long long)k * ndim + c0 + cc] = (float)m;
     }
 }
 
@@ -482,8 +549,9 @@ extern "C" int lc_lanczos_interp_stories(const void* d_data, int dtype, int64_t 
     return lc::launched("k_lanczos_rows");
 }
 
-extern "C" int lc_story_design_f32(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,
-                                   const int64_t* h_delays, int nd, float* d_x, int64_t ldx, lc_stream_t stream) {
+extern "C" int lc_story_design_f32_rows(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories,
+                                        int n_stories, int64_t max_story_rows, const int64_t* h_delays, int nd, float* d_x,
+                                        int64_t ldx, lc_stream_t stream) {
     LC_REQUIRE(d_feat && d_stories && h_delays && d_x, LC_E_BADARG, "lc_story_design_f32: null pointer");
     LC_REQUIRE(ndim > 0 && n_stories > 0 && nd > 0 && nd <= FIR_MAX_DELAYS && ld_in >= ndim && ldx >= ndim * nd, LC_E_SHAPE,
                "lc_story_design_f32: bad shape (at most %d delays)", FIR_MAX_DELAYS);
@@ -492,8 +560,23 @@ extern "C" int lc_story_design_f32(const double* d_feat, int64_t ndim, int64_t l
     for (int k = 0; k < nd; ++k) dl.d[k] = h_delays[k];
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_FIR, s);
+    // the LDS version when the longest story's columns fit (max_story_rows: the caller's bound on the stories' row counts;
+    // <= 0: unknown), else one thread per output column straight from global memory
+    const long long lds = max_story_rows > 0 ? (max_story_rows * SDC + 2 * FIR_MAX_DELAYS * SDC) * 8 : 0;
+    if (lds > 0 && lds <= 150 * 1024) {
+        if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_story_design_lds), (int)lds)) return rc;
+        dim3 grid((unsigned)lc::ceil_div<long long>(ndim, SDC), (unsigned)n_stories);
+        hipLaunchKernelGGL(k_story_design_lds, grid, dim3(256), (size_t)lds, s, d_feat, (long long)ndim, (long long)ld_in,
+                           (const StoryRows*)d_stories, dl, d_x, (long long)ldx);
+        return lc::launched("k_story_design_lds");
+    }
     dim3 grid((unsigned)lc::ceil_div<long long>((long long)nd * ndim, 256), (unsigned)n_stories);
     hipLaunchKernelGGL(k_story_design, grid, dim3(256), 0, s, d_feat, (long long)ndim, (long long)ld_in,
                        (const StoryRows*)d_stories, dl, d_x, (long long)ldx);
     return lc::launched("k_story_design");
+}
+
+extern "C" int lc_story_design_f32(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,
+                                   const int64_t* h_delays, int nd, float* d_x, int64_t ldx, lc_stream_t stream) {
+    return lc_story_design_f32_rows(d_feat, ndim, ld_in, d_stories, n_stories, 0, h_delays, nd, d_x, ldx, stream);
 }

@@ -44,6 +44,20 @@ __global__ void __launch_bounds__(256) k_scatter_axpy(const float* __restrict__ 
     }
 }
 
+// dst[r, cols[j]] = src[r, j]  (overwrite; cols[j] < 0: skipped) for 4- or 8-byte elements: a few columns recomputed on a
+// side path -- the voxels whose dynamic range the fp16 split cannot carry, round 5 -- go back into the matrices of the
+// main path.  Column indices must be distinct.
+template <typename E>
+__global__ void __launch_bounds__(256) k_scatter_cols(const E* __restrict__ src, long long ld_src, const int* __restrict__ cols,
+                                                      long long n_cols, E* __restrict__ dst, long long ld_dst) {
+    const long long r = blockIdx.y;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += stride) {
+        const long long c = cols[j];
+        if (c >= 0) dst[r * ld_dst + c] = src[r * ld_src + j];
+    }
+}
+
 // Mean of the folds' weights without a read-modify-write per fold: every fold leaves its alpha-SORTED weight matrix where
 // the refit contraction wrote it, k_invert_perm notes where each voxel's column went, and ONE pass per voxel range forms
 //     out[r, v] = sum_f scale_f * w_f[r, pos_f[v]]          (folds in order, the same expression per term as
@@ -483,6 +497,28 @@ extern "C" int lc_scatter_axpy_f32(const float* d_w, int64_t ld_w, int64_t n_row
                            (long long)n_cols, scale, d_acc + r0 * ld_acc, (long long)ld_acc);
     }
     return lc::launched("k_scatter_axpy");
+}
+
+extern "C" int lc_scatter_cols(const void* d_src, int64_t ld_src, int64_t n_rows, int elem_bytes, const int32_t* d_cols,
+                               int64_t n_cols, void* d_dst, int64_t ld_dst, lc_stream_t stream) {
+    LC_REQUIRE(d_src && d_cols && d_dst, LC_E_BADARG, "lc_scatter_cols: null pointer");
+    LC_REQUIRE(n_rows >= 0 && n_cols >= 0 && ld_src >= n_cols && (elem_bytes == 4 || elem_bytes == 8), LC_E_SHAPE,
+               "lc_scatter_cols: bad shape (elements of 4 or 8 bytes)");
+    if (n_rows == 0 || n_cols == 0) return LC_OK;
+    lc::ScopedTimer timer_(lc::T_SCATTER, lc::as_stream(stream));
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {          // grid.y carries the row
+        const int64_t nr = lc::imin(65535, n_rows - r0);
+        dim3 grid((unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 256), 1024), (unsigned)nr);
+        if (elem_bytes == 4)
+            hipLaunchKernelGGL(k_scatter_cols<float>, grid, dim3(256), 0, lc::as_stream(stream),
+                               static_cast<const float*>(d_src) + r0 * ld_src, (long long)ld_src, d_cols, (long long)n_cols,
+                               static_cast<float*>(d_dst) + r0 * ld_dst, (long long)ld_dst);
+        else
+            hipLaunchKernelGGL(k_scatter_cols<double>, grid, dim3(256), 0, lc::as_stream(stream),
+                               static_cast<const double*>(d_src) + r0 * ld_src, (long long)ld_src, d_cols, (long long)n_cols,
+                               static_cast<double*>(d_dst) + r0 * ld_dst, (long long)ld_dst);
+    }
+    return lc::launched("k_scatter_cols");
 }
 
 extern "C" int lc_invert_perm(const int32_t* d_cols, int64_t n_cols, int32_t base, int32_t* d_pos, lc_stream_t stream) {

@@ -49,6 +49,10 @@ class FitOptions:
                                             # 4.2e-5; the last panel, 15 % of the voxels, would have to average six times
                                             # that the other way.  Until round 4 the value read 1e-4 and was compared with
                                             # the lead SUMMED over the five inner folds: the same gate, in its real unit)
+    side_panel_max_cols: int = 512          # precision "auto": up to this many target columns whose dynamic range the fp16
+                                            # split cannot carry (a spike > 512 x the typical entry) are recomputed on an
+                                            # exact-f32 side path and written over the main path's results -- only more of them
+                                            # (or a form the side path does not cover) move the WHOLE fit to f32 (round 5)
     refit_fused_pearson: bool = True        # test predictions reduced to Pearson r in the contraction's epilogue (fp16x3
                                             # path): never stored, lc_pearson_cols never reads them back (SURVEY K8 + K9)
     refit_by_inverse: bool = True           # refit operators through the explicit inverse + one fp16x3 product

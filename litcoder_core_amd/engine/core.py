@@ -164,6 +164,7 @@ class EngineCore:
         self._eye, self._eye_key = None, None
         self._eig_cache, self._n_real = {}, {}         # spectral route: eigenpairs of a fold's outer block; list lengths
         self._scale_checks = []                        # primal form: pending looks at the features' column norms
+        self.side = None                               # the f32 side panel of too-wide target columns (_register_side)
         # what this fit ran, for the caller (NestedCVModel.last_fit; bench.py prices the roofline with it): arithmetic
         # of the sweeps, alphas scored inside the fused launch, algorithmic flops of the plain fp16x3 GEMMs.  Per
         # engine: two fits in one process do not share it.
@@ -334,11 +335,22 @@ class EngineCore:
                 ev.synchronize()
                 wide = bool(int(flag_h[0]))
         else:
-            cs, flag = ops.col_scales_f16(Y, self.Ttot, rg.Vp)
+            side_ok = check and self._side_panel_ok(Y, rg)
+            colflags = torch.empty(rg.Vp, dtype=torch.uint8, device=self.dev) if side_ok else None
+            cs, flag = ops.col_scales_f16(Y, self.Ttot, rg.Vp, colflags=colflags)
             wide = False
             if check:
                 self.shard.all_reduce_(flag, "max")
                 wide = bool(int(flag.cpu()[0]))
+            if wide and side_ok:
+                # WHICH columns: a handful of them leaves the fp16 arithmetic alone (an exact-f32 side path recomputes their
+                # scores, weights and test correlations, _side_sweeps / _side_refit); the ranks agree on that together
+                cols = np.nonzero(colflags.cpu().numpy()[: rg.V])[0]
+                many = ops.upload(np.asarray([int(len(cols) > self.opt.side_panel_max_cols)], dtype=np.int32), self.dev)
+                self.shard.all_reduce_(many, "max")
+                if not int(many.cpu()[0]):
+                    self._register_side(rg, cols)
+                    wide = False
         if wide:
             if self._assume_split:
                 raise _WideTargets("target dynamic range too wide for the fp16x3 sweep")
@@ -354,6 +366,29 @@ class EngineCore:
                 self._cs_all[1, rg.c0:rg.c0 + rg.Vp].copy_(cs[rg.Vp:])
                 self._cs_known[rg.c0 // 256:(rg.c0 + rg.Vp + 255) // 256] = True
         return out
+
+    def _side_panel_ok(self, Y, rg):
+        """The f32 side path covers the resident, un-normalised targets of a fit in the dual (n x n) form, decided once for
+        all columns of the rank (begin_fit)."""
+        return (Y is rg.Y and rg is self.full and not self.norm_y and not self.primal and not self.spectral
+                and self.opt.side_panel_max_cols > 0)
+
+    def _register_side(self, rg, cols):
+        """The target columns ``cols`` (rank-local, sorted) whose dynamic range the fp16 split cannot carry: an f32 copy of
+        them side by side (all rows, zero-padded to whole 128-column tiles), the index lists the scatters back need."""
+        n = int(len(cols))
+        self.info["side_panel_cols"] = n
+        if n == 0:
+            self.side = None
+            return
+        Vs = ops.pad_to(n, COL_TILE)
+        idx = np.full(Vs, -1, dtype=np.int32)
+        idx[:n] = cols
+        d_cols = ops.upload(idx, self.dev)
+        Ys = torch.empty((self.Ttot, Vs), dtype=torch.float32, device=self.dev)
+        ops.gather(self.dY_full, self.dY_full.stride(0), None, self.Ttot, d_cols, Vs, Ys)
+        self.side = dict(cols=np.asarray(cols, dtype=np.int64), n=n, Vp=Vs, Y=Ys, d_cols=d_cols)
+        logger.info("%d target column(s) too wide for the fp16x3 sweep: recomputed on the f32 side path", n)
 
     def _verify_target_flag(self, rg=None):
         """The deferred look at a range's dynamic-range flag (_target_scales); ``rg`` None: every range of the fit."""

@@ -222,6 +222,7 @@ class DualSweeps:
         main stream has V-wide work while it waits for a fold's Cholesky chains (the range the phases work on is
         captured here: the engine's current range may have moved on when the callable runs)."""
         Vp_, V_ = self.Vp, self.V
+        rg_ = self.cur                                    # (the range this call works on: the second part may run later)
         if hat.get("no_inner"):
             # no inner fold of this outer fold has validation rows: the reference scores every alpha 0 for every voxel
             # (z_score of an empty block -> NaN -> nan_to_num, ridge_regression.py:124-133) and its first-maximum
@@ -350,6 +351,8 @@ class DualSweeps:
             if moments and Ad and not cho_first:
                 for i, a in enumerate(cho):
                     scores[a].copy_(scores_d[i])
+            if self.side is not None and split:
+                self._side_sweeps(hat, scores, rg_)
             self.sweeps_done = torch.cuda.Event()
             self.sweeps_done.record()
             return scores
@@ -360,6 +363,65 @@ class DualSweeps:
             return (lambda: out) if split_phase else out
         series_part()
         return fused_part if split_phase else fused_part()
+
+    def _side_cols_of(self, rg):
+        """(first position in the side panel, positions' count, range-local column of each) of the side columns that lie in
+        the voxel range; None when there are none."""
+        cols = self.side["cols"]
+        sel = np.nonzero((cols >= rg.c0) & (cols < rg.c0 + rg.V))[0]
+        if len(sel) == 0:
+            return None
+        return int(sel[0]), int(len(sel)), (cols[sel] - rg.c0).astype(np.int32)
+
+    def _side_sweeps(self, hat, scores, rg):
+        """The inner-CV scores of the side panel's columns (target columns whose dynamic range the fp16 hi/lo split cannot
+        carry, _register_side) in exact f32 arithmetic, written over the main path's scores of those columns BEFORE any alpha
+        is chosen from them: the factorised alphas through the f32-input MFMA sweep on the same f32 hat matrices the fp16
+        images were split from, the alphas on the polynomial series through the f32 product with the same shared terms and
+        the moment kernel on stored terms (lc_series_scores) -- what ridge_corr_torch computes for every column alike
+        (ridge_regression.py:104-133)."""
+        hit = self._side_cols_of(rg)
+        if hit is None:
+            return
+        s0, ns, local = hit
+        side = self.side
+        Vs = ops.pad_to(ns, COL_TILE)
+        Ys = side["Y"][:, s0:]                             # (T, >= Vs) view: the range's side columns first
+        A, N, M, tr, va, n_v = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"]
+        moments, cho = hat["moments"], hat["cho"]
+        Ad = len(cho) if moments else A
+        cho_first = list(cho) == list(range(len(cho)))
+        sc = torch.empty((A, Vs), dtype=torch.float32, device=self.dev)
+        sc_d = sc if not moments else (sc[:Ad] if cho_first else torch.empty((max(Ad, 1), Vs), dtype=torch.float32, device=self.dev))
+        part = torch.empty((max(Ad, 1) * M // LC_MB, 4, Vs), dtype=torch.float32, device=self.dev)
+        ystat = torch.empty((3, Vs), dtype=torch.float32, device=self.dev)
+        yblk = torch.empty((M // LC_MB, Vs), dtype=torch.float32, device=self.dev)
+        yv = torch.empty((M, Vs), dtype=torch.float32, device=self.dev)
+        Tbuf = rowmap = Tm = None
+        if moments:
+            Tm, rowmap, _ = self._series_layout(M)
+            Tbuf = torch.empty((Tm, Vs), dtype=torch.float32, device=self.dev)
+        if Ys.shape[1] < Vs:                               # (the panel's last columns: a padded copy of their own)
+            Yp = ops.zeros((self.Ttot, Vs), torch.float32, self.dev)
+            Yp[:, : Ys.shape[1]].copy_(Ys)
+            Ys = Yp
+        for f0, fc, H, P in hat["Hs"]:
+            for j in range(fc):
+                f = f0 + j
+                ops.val_stats(Ys, Vs, va[f], M, n_v[f], ystat, yblk, yv)
+                if Ad:
+                    ops.alpha_sweep_scores(H[j * Ad:(j + 1) * Ad], Ad, M, N, Ys, Vs, tr[f], yv, n_v[f], ystat, yblk, self.mode,
+                                           part, sc_d, accumulate=f > 0)
+                if moments:
+                    ops.gemm_grouped(P[j], N, 0, Ys, Ys.stride(0), tr[f], Tbuf, Vs, Tm, Vs, N, [0, Vs // COL_TILE])
+                    ops.series_scores(Tbuf, Vs, SERIES_TERMS, M, n_v[f], Vs, yv, ystat, self.d_coef, hat["d_ser"], sc,
+                                      accumulate=f > 0, rowmap=rowmap)
+        if moments and Ad and not cho_first:
+            for i, a in enumerate(cho):
+                sc[a].copy_(sc_d[i])
+        dst = np.full(Vs, -1, dtype=np.int32)
+        dst[:ns] = local
+        ops.scatter_cols(sc, A, ops.upload(dst, self.dev), Vs, scores)
 
     def _alpha_scores(self, K, Y, inner_abs):
         cs, split = self._target_scales(Y)

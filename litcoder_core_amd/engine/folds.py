@@ -346,16 +346,60 @@ class FoldPhases:
             else:
                 r_s = ops.pearson_cols(o["Ys_te"], pred, n_t, Vs)
         p_s = ops.pearson_pvalues(r_s, Vs, n_t)
+        # the weight rows stay in alpha-sorted order where the contraction writes them (one matrix per fold, plus where each
+        # voxel's column went); the mean over the folds is taken in one pass per voxel range once its last fold is in
+        # (_combine_weights), not accumulated fold by fold
+        ent, off = self._ws_slot(st["fold"], rg, Vs, weight_scale)
+        ops.invert_perm(perm, Vs, off, ent["pos"][rg.c0:])
+        side_w = None
+        if self.side is not None and o["split"] and not self.primal:
+            side_w = self._side_refit(st, ent, off, r_s, p_s, Vs, n_t, row0)     # r / p of the side columns, exact f32
         pend = self._publish(st, r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t)
         # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
         # run beside this part of the contraction)
-        # the weight rows stay in alpha-sorted order where the contraction writes them; the mean over the folds is taken
-        # in one pass per voxel range once its last fold is in (_combine_weights), not accumulated fold by fold
-        ent, off = self._ws_slot(st["fold"], rg, Vs, weight_scale)
         self._refit_product(o, 0, self.p_pad, self.p, out=ent["buf"][:, off:off + Vs])
-        ops.invert_perm(perm, Vs, off, ent["pos"][rg.c0:])
+        if side_w is not None:
+            W_s, dst, n_s = side_w
+            ops.scatter_cols(W_s, self.p_pad, dst, n_s, ent["buf"][:, off:off + Vs])
         self._range_finished(st)
         return pend
+
+    def _side_refit(self, st, ent, off, r_s, p_s, Vs, n_t, row0):
+        """The refit of the side panel's columns of this (fold, range) step in exact f32 arithmetic (ridge_torch + the test
+        predictions + Pearson r, ridge_regression.py:9-63, nested_cv.py:151-155): the voxels grouped by the alpha THEY chose
+        (from their corrected scores), the grouped f32-input MFMA product with the same f32 operators the main path's fp16
+        images were split from, Pearson r / p of their test rows -- written over the main path's entries of the alpha-sorted
+        result vectors here, and (returned) over its alpha-sorted weight columns once those are there."""
+        hit = self._side_cols_of(st["rg"])
+        if hit is None:
+            return None
+        s0, ns, local = hit
+        rg, used, Malpha = st["rg"], list(st["used"]), st["Malpha"]
+        d_local = ops.upload(local, self.dev).long()
+        best_s = st["best"][d_local].contiguous()                          # the side voxels' alpha indices
+        perm_s, count2 = ops.group_by_alpha(best_s, ns, self.A, COL_TILE)
+        counts = count2[0].cpu().numpy()                                   # (a host round trip: this path is the exception)
+        if isinstance(perm_s, list):
+            perm_s = ops.join_group_ranges(perm_s, counts, COL_TILE)
+        used_s = [a for a in range(self.A) if counts[a] > 0]
+        tiles = [0]
+        for a in used_s:
+            tiles.append(tiles[-1] + (int(counts[a]) + COL_TILE - 1) // COL_TILE)
+        Vss = tiles[-1] * COL_TILE
+        Ms = [Malpha[used.index(a)] for a in used_s]
+        Ysel = self.side["Y"][:, s0:]
+        o = self._refit_operands(Ysel, st["tr"], st["te"], perm_s, tiles, Vss, Ms, False, None)
+        C = self._refit_product(o, 0, Ms[0].shape[0], self.p + n_t)
+        r = ops.pearson_cols(o["Ys_te"], C[row0:row0 + n_t], n_t, Vss)
+        pv = ops.pearson_pvalues(r, Vss, n_t)
+        # where each sorted side column belongs in the main path's alpha-sorted order of this step
+        pos_rel = ent["pos"][rg.c0:][d_local].long() - off
+        live = perm_s[:Vss] >= 0
+        dst = torch.where(live, pos_rel[perm_s[:Vss].clamp(min=0).long()], torch.full_like(pos_rel[:1], -1).expand(Vss))
+        dst = dst.to(torch.int32).contiguous()
+        ops.scatter_cols(r.view(1, -1), 1, dst, Vss, r_s.view(1, -1))
+        ops.scatter_cols(pv.view(1, -1), 1, dst, Vss, p_s.view(1, -1))
+        return C[: self.p_pad], dst, Vss
 
     def _ws_slot(self, fold, rg, Vs, scale):
         """Where the alpha-sorted weight columns of a (fold, voxel range) step go: one (p_pad, cap) matrix per fold, the

@@ -499,13 +499,15 @@ class NestedCVModel(BasePredictivityModel):
                 out[0].info["single_alpha_guess"] = "missed"
                 return out
             except _WideTargets as why:
-                # host inputs + precision "auto": a panel that arrived later is too wide for the fp16 split -- once, on
-                # the f32 MFMA path, with everything that is resident by now
+                # host inputs + precision "auto": a panel that arrived later holds a column too wide for the fp16 split --
+                # once more with everything that is resident by now: the fit then knows ALL its columns up front and moves
+                # only the wide ones to the f32 side path (round 5; the whole fit to the f32 MFMA path when there are too many
+                # of them or the form has no side path -- decided in begin_fit, which cannot raise this again)
                 eng = self._engine
-                logger.info("%s: the fit is repeated on the f32 MFMA path", why)
+                logger.info("%s: the fit is repeated with the targets resident", why)
                 eng.finish_uploads()
                 torch.cuda.synchronize()
-                return run_(form, "f32", _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
+                return run_(form, self.precision, _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
 
         try:
             eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = run(self.form)

@@ -231,8 +231,8 @@ def story_design(feat, in_off, n_in, a, b, out_row0, delays, X):
     assert stride == 40
     nd = len(delays)
     arr = (ctypes.c_int64 * max(nd, 1))(*[int(d) for d in delays])
-    _lib.call("lc_story_design_f32", _p(feat), feat.shape[1], feat.stride(0), _p(table), len(in_off), arr, nd, _p(X),
-              X.stride(0), _s())
+    _lib.call("lc_story_design_f32_rows", _p(feat), feat.shape[1], feat.stride(0), _p(table), len(in_off),
+              int(max(int(n) for n in n_in)) if len(n_in) else 0, arr, nd, _p(X), X.stride(0), _s())
     return X
 
 
@@ -971,13 +971,27 @@ def split_rows_f16_groups(h, groups, rows, K, tiled, rowscale_inv):
     _lib.call("lc_split_rows_f16_groups", _p(h), h.stride(0), groups, rows, K, _p(tiled), _p(rowscale_inv), _s())
 
 
-def col_scales_f16(y, T, V, want_flag=True):
+def col_scales_f16(y, T, V, want_flag=True, colflags=None):
     """(cs, flag): cs[:V] = 2^-e, cs[V:] = 2^e per column; flag (device int32) != 0 when some column's
-    dynamic range is too wide for the fp16 hi/lo split (``want_flag=False``: the scales alone, one pass over y)."""
+    dynamic range is too wide for the fp16 hi/lo split (``want_flag=False``: the scales alone, one pass over y).
+    ``colflags``: (V,) uint8 device vector that receives WHICH columns raised the flag."""
     cs = torch.empty(2 * V, dtype=torch.float32, device=y.device)
     flag = zeros(1, torch.int32, y.device) if want_flag else None
-    _lib.call("lc_col_scales_f16", _p(y), y.stride(0), T, V, _p(cs), _p(flag), _s())
+    if colflags is not None:
+        _lib.call("lc_col_scales_f16_flags", _p(y), y.stride(0), T, V, _p(cs), _p(flag), _p(colflags), _s())
+    else:
+        _lib.call("lc_col_scales_f16", _p(y), y.stride(0), T, V, _p(cs), _p(flag), _s())
     return cs, flag
+
+
+def scatter_cols(src, n_rows, cols, n_cols, dst):
+    """dst[r, cols[j]] = src[r, j] (overwrite; cols[j] < 0 skipped): 2-D f32 / f64 device matrices (or views with a row
+    stride), ``cols`` an int32 device vector of distinct indices."""
+    if src.dtype != dst.dtype or src.dtype not in (torch.float32, torch.float64):
+        raise ValueError("scatter_cols: f32 or f64 matrices of the same type")
+    _lib.call("lc_scatter_cols", _p(src), src.stride(0) if src.dim() > 1 else max(int(n_cols), 1), n_rows, src.element_size(),
+              _p(cols), n_cols, _p(dst), dst.stride(0) if dst.dim() > 1 else 0, _s())
+    return dst
 
 
 def split_cols_f16(y, V, rows, K, cscale, tiled):

@@ -1486,30 +1486,70 @@ def test_precision_policy(lc):
     assert np.mean(a16 == a32) >= 0.99
     same = a16 == a32
     np.testing.assert_allclose(np.asarray(m16["correlations"])[same], np.asarray(m32["correlations"])[same], atol=2e-6)
+    # ---- round 5: a column with one spike 10^6 x its rms no longer moves the WHOLE fit to f32 (5x slower at the bench
+    # shape): only that column leaves the fp16 arithmetic -- its scores, weights and test correlation come from an exact-f32
+    # side path (the same f32 operators; ridge_regression.py:104-125 treats every column alike in fp32) -- and every other
+    # voxel's result is bit-identical to the fit without the spike
     Y2 = Y.copy()
-    Y2[7, 5] = 1e6                      # one spike 10^6 x the rms of its column
-    model16.fit_predict(X, Y2, **kw)
-    assert model16.last_fit["precision"] == "f32"
+    Y2[7, 5] = 1e6
+    Y2[100, 222] = -4e5
+    ms, Ws, as_ = model16.fit_predict(X, Y2, **kw)
+    assert model16.last_fit["precision"] == "f16x3" and model16.last_fit["side_panel_cols"] == 2
+    m32s, W32s, a32s = lc.NestedCVModel("r", precision="f32").fit_predict(X, Y2, **kw)
+    clean = np.ones(Y.shape[1], dtype=bool)
+    clean[[5, 222]] = False
+    assert np.array_equal(as_[clean], a16[clean]) and np.array_equal(Ws[:, clean], W16[:, clean])
+    assert np.array_equal(np.asarray(ms["correlations"])[clean], np.asarray(m16["correlations"])[clean])
+    for c in (5, 222):
+        assert as_[c] == a32s[c], c
+        assert abs(ms["correlations"][c] - m32s["correlations"][c]) < 1e-5
+        np.testing.assert_allclose(Ws[:, c], W32s[:, c], rtol=1e-4, atol=1e-5 * float(np.abs(W32s[:, c]).max()))
+        assert abs(ms["p_values"][c] - m32s["p_values"][c]) <= 1e-4 * max(m32s["p_values"][c], 1e-300) + 1e-12
+    # single alpha (the across-voxel mean takes the corrected scores), train/test mode, R^2 scores (per-alpha hat matrices)
+    for extra in (dict(single_alpha=True), dict(use_corr=False)):
+        kw2 = dict(kw, **extra)
+        tt = dict(X_test=X[250:], y_test=Y2[250:]) if extra.get("single_alpha") else {}
+        args = (X[:250], Y2[:250]) if tt else (X, Y2)
+        mod = lc.NestedCVModel("r", precision="auto")
+        got = mod.fit_predict(*args, **tt, **kw2)
+        assert mod.last_fit["precision"] == "f16x3" and mod.last_fit["side_panel_cols"] == 2, extra
+        ref32 = lc.NestedCVModel("r", precision="f32").fit_predict(*args, **tt, **kw2)
+        same32 = np.asarray(got[2]) == np.asarray(ref32[2])
+        assert same32[5] and same32[222] and same32.mean() >= 0.98, extra
+        tol = 1e-5 if not extra.get("use_corr") is False else 1e-5
+        for c in (5, 222):
+            assert abs(got[0]["correlations"][c] - ref32[0]["correlations"][c]) < tol, (extra, c)
+            np.testing.assert_allclose(got[1][:, c], ref32[1][:, c], rtol=1e-4, atol=1e-5 * float(np.abs(ref32[1][:, c]).max()))
+    # more wide columns than the side panel takes (FitOptions.side_panel_max_cols): the whole fit on the f32 path, as before
+    few = lc.NestedCVModel("r", precision="auto", options=ncv.FitOptions(side_panel_max_cols=1))
+    few.fit_predict(X, Y2, **kw)
+    assert few.last_fit["precision"] == "f32"
     with pytest.raises(ValueError):
         lc.NestedCVModel("r", precision="fp8").fit_predict(X, Y, **kw)
     # a wide column in a LATER voxel panel of host inputs: the flag of a panel is looked at after its sweeps were queued
-    # (round 4), the fit is then repeated on the f32 path with what is resident -- the engine's own uploader and targets put
-    # on the link by the caller beforehand (start_targets) must end at the same, f32, result
+    # (round 4), the fit is then repeated with what is resident -- now knowing all its columns, it moves only the wide one to
+    # the f32 side path (round 5) -- the engine's own uploader and targets put on the link by the caller beforehand
+    # (start_targets) must end at the same result as a fit that had the targets resident from the start
     from litcoder_core_amd import ops
     X3, Y3 = _synthetic(360, 48, 2048, 12)
     Y3[11, 1700] = 3e6
     ref = lc.NestedCVModel("r", precision="f32").fit_predict(X3, Y3, **kw)
+    dX = ops.upload_f32(X3, ops.pad_to(X3.shape[1], 32), ops.device())
+    dY = ops.upload_f32(Y3, ops.pad_to(Y3.shape[1], 128), ops.device())
+    res = lc.NestedCVModel("r", precision="auto")
+    want = res.fit_predict_device(dX, dY, X3.shape[1], Y3.shape[1], weights_on_host=True, **kw)
+    assert res.last_fit["precision"] == "f16x3" and res.last_fit["side_panel_cols"] == 1
     own = lc.NestedCVModel("r", precision="auto", panel_cols=512)
     got = own.fit_predict(X3, Y3, **kw)
-    assert own.last_fit["precision"] == "f32"          # (last_fit describes the repeated, resident fit)
+    assert own.last_fit["precision"] == "f16x3" and own.last_fit["side_panel_cols"] == 1    # (the repeated, resident fit)
     fly = lc.NestedCVModel("r", precision="auto", panel_cols=512)
-    dX = ops.upload_f32(X3, ops.pad_to(X3.shape[1], 32), ops.device())
     flying = fly.start_targets(Y3)
     got2 = fly.fit_predict_device(dX, flying, X3.shape[1], Y3.shape[1], weights_on_host=True, **kw)
-    assert fly.last_fit["precision"] == "f32"
+    assert fly.last_fit["precision"] == "f16x3" and fly.last_fit["side_panel_cols"] == 1
     for g in (got, got2):
-        assert np.array_equal(g[2], ref[2]) and np.array_equal(g[1], ref[1])
-        assert g[0]["correlations"] == ref[0]["correlations"]
+        assert np.array_equal(g[2], want[2]) and np.array_equal(g[1], want[1])
+        assert g[0]["correlations"] == want[0]["correlations"]
+    assert want[2][1700] == ref[2][1700] and abs(want[0]["correlations"][1700] - ref[0]["correlations"][1700]) < 1e-5
 
 
 def test_single_alpha_guess_from_the_early_panels(lc):
