@@ -52,7 +52,9 @@ __device__ inline double interp_weight(double dt, double c, double window, int c
         const double t = dt * c;
         if (t == 0.0) return 1.0;
         if (fabs(t) > window) return 0.0;
-        return window * sin(PI * t) * sin(PI * t / window) / ((PI * PI) * (t * t));
+        // sin(pi x) as sinpi(x): the argument reduction is exact and a fraction of sin's (the weights are a third of the
+        // resampler's arithmetic); the value differs from sin(PI * x) by the rounding of PI * x, ~1e-16 relative
+        return window * sinpi(t) * sinpi(t / window) / ((PI * PI) * (t * t));
     } else {
         // interpdata.py:31-36 (sincfun, array branch): 2B sin(2 pi B t) / (2 pi B t + 1e-20), windowed, causal
         if (fabs(dt) > window / (2 * c)) return 0.0;
@@ -178,9 +180,11 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict
     __shared__ double s_tn[LZR], s_cut[LZR];
     const long long i0 = (long long)blockIdx.x * LZR;
     const int nrows = (int)min((long long)LZR, n_new_total - i0);
-    const long long c = (long long)blockIdx.y * LZ_THREADS + threadIdx.x;
-    if (threadIdx.x < LZR) {
-        const int r = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- the rows' windows: wave w finds those of rows 2 w and 2 w + 1 by a 64-way search (the block-per-row kernel ran two
+    // bisections of ~11 dependent loads in every thread; here a search is 2-3 rounds of one load per lane)
+    for (int q = 0; q < LZR / (LZ_THREADS / 64); ++q) {
+        const int r = wave * (LZR / (LZ_THREADS / 64)) + q;
         long long lo = 0, hi = 0;
         double tn = 0.0, cut = 0.0;
         if (r < nrows) {
@@ -188,27 +192,34 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict
             tn = newtime[i0 + r];
             cut = st.cutoff;
             const double* ot = oldtime + st.old_off;
-            long long a = 0, b = st.n_old;
             if (st.sorted) {
-                // (tn - ot[j]) * cutoff is non-increasing in j: first j with t <= window, first j with t < -window
-                while (a < b) {
-                    const long long m = (a + b) >> 1;
-                    if ((tn - ot[m]) * cut > window) a = m + 1; else b = m;
-                }
-                lo = a;
-                b = st.n_old;
-                while (a < b) {
-                    const long long m = (a + b) >> 1;
-                    if ((tn - ot[m]) * cut >= -window) a = m + 1; else b = m;
-                }
-                hi = a;
+                // (tn - ot[j]) * cutoff is non-increasing in j.  first(pred): the first j in [a, b) whose pred is false,
+                // pred true on a prefix -- narrowed 64-fold per round by one probe per lane
+                auto first = [&](long long a, long long b, auto pred) {
+                    while (b - a > 0) {
+                        const long long step = (b - a + 63) / 64;
+                        const long long m = a + (long long)lane * step;             // probes a, a + step, ...
+                        const bool p = m < b ? pred(ot[m]) : false;
+                        const unsigned long long mask = __ballot(p);                // a prefix of ones
+                        const int k = mask == ~0ull ? 64 : __ffsll((long long)~mask) - 1;   // first lane whose probe fails
+                        // the answer lies in (probe k-1, probe k]: all probes true -> beyond the last one
+                        const long long na = k == 0 ? a : a + (long long)(k - 1) * step + 1;
+                        const long long nb = k == 64 ? b : min(b, a + (long long)k * step);
+                        if (step == 1) { a = nb; break; }
+                        a = na;
+                        b = nb;
+                    }
+                    return a;
+                };
+                lo = first(0, st.n_old, [&](double o) { return (tn - o) * cut > window; });
+                hi = first(lo, st.n_old, [&](double o) { return (tn - o) * cut >= -window; });
             } else {
                 hi = st.n_old;
             }
             lo += st.old_off;
             hi += st.old_off;
         }
-        s_lo[r] = lo; s_hi[r] = hi; s_tn[r] = tn; s_cut[r] = cut;
+        if (lane == 0) { s_lo[r] = lo; s_hi[r] = hi; s_tn[r] = tn; s_cut[r] = cut; }
     }
     __syncthreads();
     long long gmin = 0, gmax = 0;
@@ -220,13 +231,10 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict
             gmax = any ? max(gmax, s_hi[r]) : s_hi[r];
             any = true;
         }
-    double acc[LZR], accp[LZR];
-#pragma unroll
-    for (int r = 0; r < LZR; ++r) { acc[r] = 0.0; accp[r] = 0.0; }
-    for (long long g0 = gmin; g0 < gmax; g0 += LZ_SPAN) {
-        const int span = (int)min((long long)LZ_SPAN, gmax - g0);
-        // the pass's weight table (zero outside a row's own window; the tail of the last batch of U samples zero too)
-        constexpr int U = 8;                                           // samples in flight per thread
+    constexpr int U = 8;                                               // samples in flight per thread
+    // the weight table of one pass over the union range (zero outside a row's own window; the tail of the last batch of U
+    // samples zero too)
+    auto build = [&](long long g0, int span) {
         const int span_u = (span + U - 1) / U * U;
         for (int e = threadIdx.x; e < span_u * LZR; e += LZ_THREADS) {
             const int r = e / span_u, jj = e - r * span_u;
@@ -236,50 +244,78 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict
                 wt = interp_weight<WK_LANCZOS>(s_tn[r] - oldtime[g], s_cut[r], window, 0);
             W[r][jj] = wt;
         }
-        __syncthreads();
-        if (c < D) {
-            // a row takes part in a batch of U samples only when its window reaches into it -- a block-uniform (scalar) test;
-            // inside such a batch the weights outside the window are zeros and add nothing: acc + 0 * x == acc for finite x
-            // (the first version tested every weight: a compare and two selects per fp64 FMA made the kernel VALU-bound,
-            // 190 us for the 27 stories of a LeBel run; a NON-finite sample now spoils the rows whose batches cover it, up to
-            // U - 1 samples outside their windows -- the reference's dense np.dot spoils the whole output column)
-            int rlo[LZR], rhi[LZR];
+    };
+    // one column of the slab down the pass: a row takes part in a batch of U samples only when its window reaches into it -- a
+    // block-uniform (scalar) test; inside such a batch the weights outside the window are zeros and add nothing:
+    // acc + 0 * x == acc for finite x (the first version tested every weight: a compare and two selects per fp64 FMA made the
+    // kernel VALU-bound; a NON-finite sample now spoils the rows whose batches cover it, up to U - 1 samples outside their
+    // windows -- the reference's dense np.dot spoils the whole output column)
+    auto stream = [&](long long g0, int span, long long c, double (&acc)[LZR], double (&accp)[LZR]) {
+        int rlo[LZR], rhi[LZR];
+#pragma unroll
+        for (int r = 0; r < LZR; ++r) {
+            rlo[r] = __builtin_amdgcn_readfirstlane((int)max(-1ll, min((long long)span, s_lo[r] - g0)));
+            rhi[r] = __builtin_amdgcn_readfirstlane(r < nrows ? (int)max(0ll, min((long long)span, s_hi[r] - g0)) : 0);
+        }
+        const T* col = data + g0 * ld_in + c;
+        for (int j0 = 0; j0 < span; j0 += U) {
+            double x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = j0 + u < span ? (double)col[(long long)(j0 + u) * ld_in] : 0.0;
 #pragma unroll
             for (int r = 0; r < LZR; ++r) {
-                rlo[r] = __builtin_amdgcn_readfirstlane((int)max(-1ll, min((long long)span, s_lo[r] - g0)));
-                rhi[r] = __builtin_amdgcn_readfirstlane(r < nrows ? (int)max(0ll, min((long long)span, s_hi[r] - g0)) : 0);
-            }
-            const T* col = data + g0 * ld_in + c;
-            for (int j0 = 0; j0 < span; j0 += U) {
-                double x[U];
+                if (j0 < rhi[r] && j0 + U > rlo[r]) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) x[u] = j0 + u < span ? (double)col[(long long)(j0 + u) * ld_in] : 0.0;
-#pragma unroll
-                for (int r = 0; r < LZR; ++r) {
-                    if (j0 < rhi[r] && j0 + U > rlo[r]) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const double w = W[r][j0 + u];
-                            if (RECTIFY) {
-                                acc[r] += w * fmin(x[u], 0.0);
-                                accp[r] += w * fmax(x[u], 0.0);
-                            } else {
-                                acc[r] += w * x[u];
-                            }
+                    for (int u = 0; u < U; ++u) {
+                        const double w = W[r][j0 + u];
+                        if (RECTIFY) {
+                            acc[r] += w * fmin(x[u], 0.0);
+                            accp[r] += w * fmax(x[u], 0.0);
+                        } else {
+                            acc[r] += w * x[u];
                         }
                     }
                 }
             }
         }
-        __syncthreads();
-    }
-    if (c < D) {
+    };
+    auto store = [&](long long c, const double (&acc)[LZR], const double (&accp)[LZR]) {
 #pragma unroll
         for (int r = 0; r < LZR; ++r)
             if (r < nrows) {
                 out[(i0 + r) * ld_out + c] = acc[r];
                 if (RECTIFY) out[(i0 + r) * ld_out + D + c] = accp[r];
             }
+    };
+    const bool one_pass = gmax - gmin <= LZ_SPAN;                      // (sorted stories: always -- ~120 samples)
+    if (one_pass) {
+        // the weights ONCE for all columns of the rows (grid.y = 1: the first version computed them per 256-column slab --
+        // two fp64 sines per weight, a third of the kernel's arithmetic)
+        const int span = (int)(gmax - gmin);
+        build(gmin, span);
+        __syncthreads();
+        for (long long c = threadIdx.x; c < D; c += LZ_THREADS) {
+            double acc[LZR], accp[LZR];
+#pragma unroll
+            for (int r = 0; r < LZR; ++r) { acc[r] = 0.0; accp[r] = 0.0; }
+            if (span > 0) stream(gmin, span, c, acc, accp);
+            store(c, acc, accp);
+        }
+        return;
+    }
+    for (long long c0 = 0; c0 < D; c0 += LZ_THREADS) {                 // (block-uniform trip counts: the barriers below)
+        const long long c = c0 + threadIdx.x;
+        double acc[LZR], accp[LZR];
+#pragma unroll
+        for (int r = 0; r < LZR; ++r) { acc[r] = 0.0; accp[r] = 0.0; }
+        for (long long g0 = gmin; g0 < gmax; g0 += LZ_SPAN) {
+            const int span = (int)min((long long)LZ_SPAN, gmax - g0);
+            __syncthreads();
+            build(g0, span);
+            __syncthreads();
+            if (c < D) stream(g0, span, c, acc, accp);
+        }
+        if (c < D) store(c, acc, accp);
     }
 }
 
@@ -385,14 +421,31 @@ __global__ void __launch_bounds__(256) k_story_design_lds(const double* __restri
         return (src >= 0 && src < n_in && d < n_in && -d < n_in) ? S[src * SDC + cc] : 0.0;
     };
     if (t < dl.n * SDC) {
+        // (SD_U rows are read before any of them is added: the sums take the rows one by one, numpy's order, without a read
+        // round trip between two additions)
+        constexpr int SD_U = 16;
         const int k = t >> 4;
         double mean = 0.0;
-        for (long long tt = st.a; tt < st.b; ++tt) mean = mean + val(k, col, tt);
+        for (long long t0 = st.a; t0 < st.b; t0 += SD_U) {
+            double v[SD_U];
+#pragma unroll
+            for (int u = 0; u < SD_U; ++u) v[u] = t0 + u < st.b ? val(k, col, t0 + u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < SD_U; ++u)
+                if (t0 + u < st.b) mean = mean + v[u];
+        }
         mean = mean / (double)n;
         double ss = 0.0;
-        for (long long tt = st.a; tt < st.b; ++tt) {
-            const double dv = val(k, col, tt) - mean;
-            ss = ss + dv * dv;
+        for (long long t0 = st.a; t0 < st.b; t0 += SD_U) {
+            double v[SD_U];
+#pragma unroll
+            for (int u = 0; u < SD_U; ++u) v[u] = t0 + u < st.b ? val(k, col, t0 + u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < SD_U; ++u)
+                if (t0 + u < st.b) {
+                    const double dv = v[u] - mean;
+                    ss = ss + dv * dv;
+                }
         }
         mean_s[t] = mean;
         sdev_s[t] = sqrt(ss / (double)n);
@@ -538,7 +591,7 @@ extern "C" int lc_lanczos_interp_stories(const void* d_data, int dtype, int64_t 
     if (n_new_total == 0 || D == 0) return LC_OK;
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_LANCZOS, s);
-    dim3 grid((unsigned)lc::ceil_div<long long>(n_new_total, LZR), (unsigned)lc::ceil_div<long long>(D, LZ_THREADS));
+    dim3 grid((unsigned)lc::ceil_div<long long>(n_new_total, LZR));      // a block: LZR rows x ALL columns
 #define LC_LZS(T, R)                                                                                                  \
     hipLaunchKernelGGL((k_lanczos_rows<T, R>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, (long long)D,         \
                        (long long)ld_in, d_oldtime, d_newtime, (long long)n_new_total, d_row_story,                   \

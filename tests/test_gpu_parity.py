@@ -1508,8 +1508,9 @@ def test_precision_policy(lc):
     # single alpha (the across-voxel mean takes the corrected scores), train/test mode, R^2 scores (per-alpha hat matrices)
     for extra in (dict(single_alpha=True), dict(use_corr=False)):
         kw2 = dict(kw, **extra)
-        tt = dict(X_test=X[250:], y_test=Y2[250:]) if extra.get("single_alpha") else {}
-        args = (X[:250], Y2[:250]) if tt else (X, Y2)
+        # (200 training rows: 2 p = 160 > the inner training sets, the fit stays in the dual form -- the side path's form)
+        tt = dict(X_test=X[200:], y_test=Y2[200:]) if extra.get("single_alpha") else {}
+        args = (X[:200], Y2[:200]) if tt else (X, Y2)
         mod = lc.NestedCVModel("r", precision="auto")
         got = mod.fit_predict(*args, **tt, **kw2)
         assert mod.last_fit["precision"] == "f16x3" and mod.last_fit["side_panel_cols"] == 2, extra
