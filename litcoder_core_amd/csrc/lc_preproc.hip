@@ -288,13 +288,14 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict
             }
     };
     const bool one_pass = gmax - gmin <= LZ_SPAN;                      // (sorted stories: always -- ~120 samples)
+    const long long cstep = (long long)gridDim.y * LZ_THREADS;         // grid.y > 1 only when there are few row groups
     if (one_pass) {
-        // the weights ONCE for all columns of the rows (grid.y = 1: the first version computed them per 256-column slab --
+        // the weights ONCE for all the block's columns of the rows (the first version computed them per 256-column slab --
         // two fp64 sines per weight, a third of the kernel's arithmetic)
         const int span = (int)(gmax - gmin);
         build(gmin, span);
         __syncthreads();
-        for (long long c = threadIdx.x; c < D; c += LZ_THREADS) {
+        for (long long c = (long long)blockIdx.y * LZ_THREADS + threadIdx.x; c < D; c += cstep) {
             double acc[LZR], accp[LZR];
 #pragma unroll
             for (int r = 0; r < LZR; ++r) { acc[r] = 0.0; accp[r] = 0.0; }
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict
         }
         return;
     }
-    for (long long c0 = 0; c0 < D; c0 += LZ_THREADS) {                 // (block-uniform trip counts: the barriers below)
+    for (long long c0 = (long long)blockIdx.y * LZ_THREADS; c0 < D; c0 += cstep) {   // (block-uniform trips: the barriers below)
         const long long c = c0 + threadIdx.x;
         double acc[LZR], accp[LZR];
 #pragma unroll
@@ -451,15 +452,31 @@ __global__ void __launch_bounds__(256) k_story_design_lds(const double* __restri
         sdev_s[t] = sqrt(ss / (double)n);
     }
     __syncthreads();
+    // the writes: thread t owns (delay, column) slot e = t mod (nd SDC) -- its mean / deviation stay in registers -- and
+    // every (256 / (nd SDC))-th row (32-bit index arithmetic: no division in the loop)
     const int per_row = dl.n * SDC;
-    for (long long idx = t; idx < n * per_row; idx += 256) {
-        const long long row = idx / per_row;
-        const int e = (int)(idx - row * per_row), k = e >> 4, cc = e & (SDC - 1);
+    if (per_row <= 256 && 256 % per_row == 0) {
+        const int e = t % per_row, k = e >> 4, cc = e & (SDC - 1), rstep = 256 / per_row;
+        if (c0 + cc < ndim) {
+            const double mean = mean_s[e], sd = sdev_s[e];
+            float* x = X + st.out_row0 * ldx + (long long)k * ndim + c0 + cc;
+            for (int row = t / per_row; row < (int)n; row += rstep) {
+                double m = val(k, cc, st.a + row) - mean;
+                if (sd != 0.0) m = m / sd;
+                // np.nan_to_num: NaN -> 0, +-inf -> +-DBL_MAX (which the float32 cast turns back into +-inf: nothing to do)
+                if (m != m) m = 0.0;
+                x[(long long)row * ldx] = (float)m;
+            }
+        }
+        return;
+    }
+    for (int idx = t; idx < (int)n * per_row; idx += 256) {
+        const int row = idx / per_row;
+        const int e = idx - row * per_row, k = e >> 4, cc = e & (SDC - 1);
         if (c0 + cc >= ndim) continue;
         double m = val(k, cc, st.a + row) - mean_s[e];
         const double sd = sdev_s[e];
         if (sd != 0.0) m = m / sd;
-        // np.nan_to_num: NaN -> 0, +-inf -> +-DBL_MAX (which the float32 cast turns back into +-inf: nothing to do)
         if (m != m) m = 0.0;
         X[(st.out_row0 + row) * ldx + (long long)k * ndim + c0 + cc] = (float)m;
     }
@@ -591,7 +608,11 @@ extern "C" int lc_lanczos_interp_stories(const void* d_data, int dtype, int64_t 
     if (n_new_total == 0 || D == 0) return LC_OK;
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_LANCZOS, s);
-    dim3 grid((unsigned)lc::ceil_div<long long>(n_new_total, LZR));      // a block: LZR rows x ALL columns
+    // a block: LZR rows x all columns (the weights are evaluated once) -- unless that leaves the chip idle: with few row
+    // groups (one story) the 256-column slabs are dealt out over grid.y
+    const long long gx = lc::ceil_div<long long>(n_new_total, LZR), slabs = lc::ceil_div<long long>(D, LZ_THREADS);
+    const long long gy = lc::imin(slabs, gx >= 1024 ? 1 : lc::ceil_div<long long>(1024, gx));
+    dim3 grid((unsigned)gx, (unsigned)gy);
 #define LC_LZS(T, R)                                                                                                  \
     hipLaunchKernelGGL((k_lanczos_rows<T, R>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, (long long)D,         \
                        (long long)ld_in, d_oldtime, d_newtime, (long long)n_new_total, d_row_story,                   \

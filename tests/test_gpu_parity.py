@@ -1532,7 +1532,7 @@ def test_precision_policy(lc):
     # the f32 side path (round 5) -- the engine's own uploader and targets put on the link by the caller beforehand
     # (start_targets) must end at the same result as a fit that had the targets resident from the start
     from litcoder_core_amd import ops
-    X3, Y3 = _synthetic(360, 48, 2048, 12)
+    X3, Y3 = _synthetic(360, 96, 2048, 12)             # (2 p > the inner training sets: the dual form, which has the side path)
     Y3[11, 1700] = 3e6
     ref = lc.NestedCVModel("r", precision="f32").fit_predict(X3, Y3, **kw)
     dX = ops.upload_f32(X3, ops.pad_to(X3.shape[1], 32), ops.device())
