@@ -105,11 +105,7 @@ int lc_lanczos_interp_stories(const void* d_data, int dtype, int64_t D, int64_t 
  * floats per row, columns k*ndim + c for delay k).  Sums in numpy's order, no fused multiply-adds: the reference's bits. */
 int lc_story_design_f32(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,
                         const int64_t* h_delays, int nd, float* d_x, int64_t ldx, lc_stream_t stream);
-/* ... given a bound on the stories' row counts (max_story_rows >= every story's n_in): a workgroup then holds 16 input
- * columns of a story in LDS, reads them from HBM once for all delays and all three passes (round 5), same values. */
-int lc_story_design_f32_rows(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,
-                             int64_t max_story_rows, const int64_t* h_delays, int nd, float* d_x, int64_t ldx,
-                             lc_stream_t stream);
+
 
 /* sincinterp2D (downsample/interpdata.py:66-84) with sincfun (:29-42, array branch): same banded
  * weighted-row-sum kernel as Lanczos with the sinc weight, optional causal mask and per-output-row

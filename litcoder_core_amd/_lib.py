@@ -86,8 +86,6 @@ SIGNATURES = {
     "lc_lanczos_interp_stories": (c_int, [_ptr, c_int, c_int64, c_int64, _ptr, _ptr, c_int64, _ptr, _ptr, c_int, c_double,
                                           c_int, _ptr, c_int64, _ptr]),
     "lc_story_design_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, POINTER(c_int64), c_int, _ptr, c_int64, _ptr]),
-    "lc_story_design_f32_rows": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int64, POINTER(c_int64), c_int, _ptr, c_int64,
-                                          _ptr]),
     "lc_upload_wait": (c_int, [_ptr, c_int, _ptr]),
     "lc_upload_finish": (c_int, [_ptr]),
     "lc_upload_free": (c_int, [_ptr]),

@@ -168,7 +168,9 @@ struct LzStory {
 constexpr int LZR = 8;            // output rows per block
 constexpr int LZ_SPAN = 256;      // samples of the union range per pass, a multiple of the batch (LDS: LZR x LZ_SPAN doubles)
 
-template <typename T, bool RECTIFY>
+// VEC columns per thread (16-byte loads: 4 float / 2 double columns -- a LeBel story's 768 float columns are ONE pass of 192
+// threads; 1 = any alignment)
+template <typename T, bool RECTIFY, int VEC>
 __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict__ data, long long D, long long ld_in,
                                                              const double* __restrict__ oldtime,
                                                              const double* __restrict__ newtime, long long n_new_total,
@@ -250,7 +252,9 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict
     // acc + 0 * x == acc for finite x (the first version tested every weight: a compare and two selects per fp64 FMA made the
     // kernel VALU-bound; a NON-finite sample now spoils the rows whose batches cover it, up to U - 1 samples outside their
     // windows -- the reference's dense np.dot spoils the whole output column)
-    auto stream = [&](long long g0, int span, long long c, double (&acc)[LZR], double (&accp)[LZR]) {
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    typedef double vecD __attribute__((ext_vector_type(VEC)));
+    auto stream = [&](long long g0, int span, long long c, vecD (&acc)[LZR], vecD (&accp)[LZR]) {
         int rlo[LZR], rhi[LZR];
 #pragma unroll
         for (int r = 0; r < LZR; ++r) {
@@ -259,56 +263,66 @@ __global__ void __launch_bounds__(LZ_THREADS) k_lanczos_rows(const T* __restrict
         }
         const T* col = data + g0 * ld_in + c;
         for (int j0 = 0; j0 < span; j0 += U) {
-            double x[U];
+            vecT xv[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = j0 + u < span ? (double)col[(long long)(j0 + u) * ld_in] : 0.0;
+            for (int u = 0; u < U; ++u) {
+                if (j0 + u < span) xv[u] = *reinterpret_cast<const vecT*>(col + (long long)(j0 + u) * ld_in);
+                else xv[u] = vecT(0);
+            }
 #pragma unroll
             for (int r = 0; r < LZR; ++r) {
                 if (j0 < rhi[r] && j0 + U > rlo[r]) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const double w = W[r][j0 + u];
-                        if (RECTIFY) {
-                            acc[r] += w * fmin(x[u], 0.0);
-                            accp[r] += w * fmax(x[u], 0.0);
-                        } else {
-                            acc[r] += w * x[u];
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            const double x = (double)xv[u][q];
+                            if (RECTIFY) {
+                                acc[r][q] += w * fmin(x, 0.0);
+                                accp[r][q] += w * fmax(x, 0.0);
+                            } else {
+                                acc[r][q] += w * x;
+                            }
                         }
                     }
                 }
             }
         }
     };
-    auto store = [&](long long c, const double (&acc)[LZR], const double (&accp)[LZR]) {
+    auto store = [&](long long c, const vecD (&acc)[LZR], const vecD (&accp)[LZR]) {
 #pragma unroll
         for (int r = 0; r < LZR; ++r)
             if (r < nrows) {
-                out[(i0 + r) * ld_out + c] = acc[r];
-                if (RECTIFY) out[(i0 + r) * ld_out + D + c] = accp[r];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    out[(i0 + r) * ld_out + c + q] = acc[r][q];
+                    if (RECTIFY) out[(i0 + r) * ld_out + D + c + q] = accp[r][q];
+                }
             }
     };
     const bool one_pass = gmax - gmin <= LZ_SPAN;                      // (sorted stories: always -- ~120 samples)
-    const long long cstep = (long long)gridDim.y * LZ_THREADS;         // grid.y > 1 only when there are few row groups
+    const long long cstep = (long long)gridDim.y * LZ_THREADS * VEC;   // grid.y > 1 only when there are few row groups
     if (one_pass) {
         // the weights ONCE for all the block's columns of the rows (the first version computed them per 256-column slab --
         // two fp64 sines per weight, a third of the kernel's arithmetic)
         const int span = (int)(gmax - gmin);
         build(gmin, span);
         __syncthreads();
-        for (long long c = (long long)blockIdx.y * LZ_THREADS + threadIdx.x; c < D; c += cstep) {
-            double acc[LZR], accp[LZR];
+        for (long long c = ((long long)blockIdx.y * LZ_THREADS + threadIdx.x) * VEC; c < D; c += cstep) {
+            vecD acc[LZR], accp[LZR];
 #pragma unroll
-            for (int r = 0; r < LZR; ++r) { acc[r] = 0.0; accp[r] = 0.0; }
+            for (int r = 0; r < LZR; ++r) { acc[r] = vecD(0.0); accp[r] = vecD(0.0); }
             if (span > 0) stream(gmin, span, c, acc, accp);
             store(c, acc, accp);
         }
         return;
     }
-    for (long long c0 = (long long)blockIdx.y * LZ_THREADS; c0 < D; c0 += cstep) {   // (block-uniform trips: the barriers below)
-        const long long c = c0 + threadIdx.x;
-        double acc[LZR], accp[LZR];
+    for (long long c0 = (long long)blockIdx.y * LZ_THREADS * VEC; c0 < D; c0 += cstep) {   // (block-uniform trips: the barriers)
+        const long long c = c0 + (long long)threadIdx.x * VEC;
+        vecD acc[LZR], accp[LZR];
 #pragma unroll
-        for (int r = 0; r < LZR; ++r) { acc[r] = 0.0; accp[r] = 0.0; }
+        for (int r = 0; r < LZR; ++r) { acc[r] = vecD(0.0); accp[r] = vecD(0.0); }
         for (long long g0 = gmin; g0 < gmax; g0 += LZ_SPAN) {
             const int span = (int)min((long long)LZ_SPAN, gmax - g0);
             __syncthreads();
@@ -351,8 +365,11 @@ __global__ void __launch_bounds__(256) k_story_design(const double* __restrict__
     };
     // (round 5: SD_U rows are loaded before any of them is added -- the sums still take the rows one by one, numpy's order,
     // but a thread no longer waits a memory round trip per row: the kernel was a chain of ~1000 dependent loads per thread
-    // at little over one wave per SIMD, 0.47 ms for 27 stories = 0.05 of the HBM roof on its algorithmic bytes)
-    constexpr int SD_U = 16;
+    // at little over one wave per SIMD, 0.47 ms for 27 stories = 0.05 of the HBM roof on its algorithmic bytes; 0.19 ms
+    // with 16 rows in flight.  A version that staged 16 input columns of a story in LDS -- read once for all delays and
+    // passes -- was built and measured SLOWER, 0.30-0.36 ms: 64 of its 256 threads ran the sequential sums while the
+    // others waited, 78 % of its wave cycles parked)
+    constexpr int SD_U = 48;
     double mean = 0.0;
     for (long long t0 = st.a; t0 < st.b; t0 += SD_U) {
         double v[SD_U];
@@ -390,95 +407,6 @@ __global__ void __launch_bounds__(256) k_story_design(const double* __restrict__
                 if (m != m) m = 0.0;
                 x[(t0 + u - st.a) * ldx] = (float)m;
             }
-    }
-}
-
-// The same through LDS (round 5).  The kernel above is one thread per (story, OUTPUT column) walking the story's rows three
-// times out of global memory: ~1000 loads in a dependent-by-latency chain per thread at little over one wave per SIMD,
-// and every input column read 4 delays x 3 passes times -- 0.47 ms for the 27 stories of a LeBel run (0.17 with batched
-// loads), 0.05-0.12 of the HBM roof on its algorithmic bytes.  Here a block takes SDC INPUT columns of one story: the
-// columns go to LDS once (all 256 threads load), nd x SDC threads run the two sequential sums per (delay, column) out of
-// LDS -- the delays of a column are shifted windows of the same data -- in numpy's order, without fused multiply-adds, and
-// all 256 threads write the normalised float32 rows.  Same values as k_story_design, bit for bit.
-constexpr int SDC = 16;
-__global__ void __launch_bounds__(256) k_story_design_lds(const double* __restrict__ feat, long long ndim, long long ld_in,
-                                                          const StoryRows* __restrict__ stories, FirDelays dl,
-                                                          float* __restrict__ X, long long ldx) {
-#pragma clang fp contract(off)
-    extern __shared__ double sd_lds[];                     // [n_in][SDC] columns, then mean[nd * SDC], sdev[nd * SDC]
-    const StoryRows st = stories[blockIdx.y];
-    const long long c0 = (long long)blockIdx.x * SDC;
-    const int t = threadIdx.x, col = t & (SDC - 1);
-    const long long n_in = st.n_in, n = st.b - st.a;
-    double* S = sd_lds;
-    double* mean_s = sd_lds + n_in * SDC;
-    double* sdev_s = mean_s + FIR_MAX_DELAYS * SDC;
-    const bool col_ok = c0 + col < ndim;
-    for (long long r = t >> 4; r < n_in; r += 256 / SDC)
-        S[r * SDC + col] = col_ok ? feat[(st.in_off + r) * ld_in + c0 + col] : 0.0;
-    __syncthreads();
-    auto val = [&](int k, int cc, long long tt) -> double {
-        const long long d = dl.d[k], src = tt - d;
-        return (src >= 0 && src < n_in && d < n_in && -d < n_in) ? S[src * SDC + cc] : 0.0;
-    };
-    if (t < dl.n * SDC) {
-        // (SD_U rows are read before any of them is added: the sums take the rows one by one, numpy's order, without a read
-        // round trip between two additions)
-        constexpr int SD_U = 16;
-        const int k = t >> 4;
-        double mean = 0.0;
-        for (long long t0 = st.a; t0 < st.b; t0 += SD_U) {
-            double v[SD_U];
-#pragma unroll
-            for (int u = 0; u < SD_U; ++u) v[u] = t0 + u < st.b ? val(k, col, t0 + u) : 0.0;
-#pragma unroll
-            for (int u = 0; u < SD_U; ++u)
-                if (t0 + u < st.b) mean = mean + v[u];
-        }
-        mean = mean / (double)n;
-        double ss = 0.0;
-        for (long long t0 = st.a; t0 < st.b; t0 += SD_U) {
-            double v[SD_U];
-#pragma unroll
-            for (int u = 0; u < SD_U; ++u) v[u] = t0 + u < st.b ? val(k, col, t0 + u) : 0.0;
-#pragma unroll
-            for (int u = 0; u < SD_U; ++u)
-                if (t0 + u < st.b) {
-                    const double dv = v[u] - mean;
-                    ss = ss + dv * dv;
-                }
-        }
-        mean_s[t] = mean;
-        sdev_s[t] = sqrt(ss / (double)n);
-    }
-    __syncthreads();
-    // the writes: thread t owns (delay, column) slot e = t mod (nd SDC) -- its mean / deviation stay in registers -- and
-    // every (256 / (nd SDC))-th row (32-bit index arithmetic: no division in the loop)
-    const int per_row = dl.n * SDC;
-    if (per_row <= 256 && 256 % per_row == 0) {
-        const int e = t % per_row, k = e >> 4, cc = e & (SDC - 1), rstep = 256 / per_row;
-        if (c0 + cc < ndim) {
-            const double mean = mean_s[e], sd = sdev_s[e];
-            float* x = X + st.out_row0 * ldx + (long long)k * ndim + c0 + cc;
-            for (int row = t / per_row; row < (int)n; row += rstep) {
-                double m = val(k, cc, st.a + row) - mean;
-                if (sd != 0.0) m = m / sd;
-                // np.nan_to_num: NaN -> 0, +-inf -> +-DBL_MAX (which the float32 cast turns back into +-inf: nothing to do)
-                if (m != m) m = 0.0;
-                x[(long long)row * ldx] = (float)m;
-            }
-        }
-        return;
-    }
-    for (int idx = t; idx < (int)n * per_row; idx += 256) {
-        const int row = idx / per_row;
-        const int e = idx - row * per_row, k = e >> 4, cc = e & (SDC - 1);
-        if (c0 + cc >= ndim) continue;
-        double m = val(k, cc, st.a + row) - mean_s[e];
-        const double sd = sdev_s[e];
-        if (sd != 0.0) m = m / sd;
-        if (m != m) m = 0.0;
-        X[(st.out_row0 + row) * ldx + (long long)k * ndim + c0 + cc] = (float)m;
     }
 }
 
@@ -610,22 +538,29 @@ extern "C" int lc_lanczos_interp_stories(const void* d_data, int dtype, int64_t 
     lc::ScopedTimer timer_(lc::T_LANCZOS, s);
     // a block: LZR rows x all columns (the weights are evaluated once) -- unless that leaves the chip idle: with few row
     // groups (one story) the 256-column slabs are dealt out over grid.y
-    const long long gx = lc::ceil_div<long long>(n_new_total, LZR), slabs = lc::ceil_div<long long>(D, LZ_THREADS);
+    const int esz = dtype == LC_F32 ? 4 : 8, vec = 16 / esz;
+    const bool wide = D % vec == 0 && ld_in % vec == 0 && (reinterpret_cast<uintptr_t>(d_data) & 15) == 0;
+    const long long per_block = (long long)LZ_THREADS * (wide ? vec : 1);
+    const long long gx = lc::ceil_div<long long>(n_new_total, LZR), slabs = lc::ceil_div<long long>(D, per_block);
     const long long gy = lc::imin(slabs, gx >= 1024 ? 1 : lc::ceil_div<long long>(1024, gx));
     dim3 grid((unsigned)gx, (unsigned)gy);
-#define LC_LZS(T, R)                                                                                                  \
-    hipLaunchKernelGGL((k_lanczos_rows<T, R>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, (long long)D,         \
+#define LC_LZS(T, R, V)                                                                                               \
+    hipLaunchKernelGGL((k_lanczos_rows<T, R, V>), grid, dim3(LZ_THREADS), 0, s, (const T*)d_data, (long long)D,      \
                        (long long)ld_in, d_oldtime, d_newtime, (long long)n_new_total, d_row_story,                   \
                        (const LzStory*)d_stories, window, d_out, (long long)ld_out)
-    if (dtype == LC_F32) { if (rectify) LC_LZS(float, true); else LC_LZS(float, false); }
-    else                 { if (rectify) LC_LZS(double, true); else LC_LZS(double, false); }
+    if (dtype == LC_F32) {
+        if (wide) { if (rectify) LC_LZS(float, true, 4); else LC_LZS(float, false, 4); }
+        else      { if (rectify) LC_LZS(float, true, 1); else LC_LZS(float, false, 1); }
+    } else {
+        if (wide) { if (rectify) LC_LZS(double, true, 2); else LC_LZS(double, false, 2); }
+        else      { if (rectify) LC_LZS(double, true, 1); else LC_LZS(double, false, 1); }
+    }
 #undef LC_LZS
     return lc::launched("k_lanczos_rows");
 }
 
-extern "C" int lc_story_design_f32_rows(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories,
-                                        int n_stories, int64_t max_story_rows, const int64_t* h_delays, int nd, float* d_x,
-                                        int64_t ldx, lc_stream_t stream) {
+extern "C" int lc_story_design_f32(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,
+                                   const int64_t* h_delays, int nd, float* d_x, int64_t ldx, lc_stream_t stream) {
     LC_REQUIRE(d_feat && d_stories && h_delays && d_x, LC_E_BADARG, "lc_story_design_f32: null pointer");
     LC_REQUIRE(ndim > 0 && n_stories > 0 && nd > 0 && nd <= FIR_MAX_DELAYS && ld_in >= ndim && ldx >= ndim * nd, LC_E_SHAPE,
                "lc_story_design_f32: bad shape (at most %d delays)", FIR_MAX_DELAYS);
@@ -634,23 +569,8 @@ extern "C" int lc_story_design_f32_rows(const double* d_feat, int64_t ndim, int6
     for (int k = 0; k < nd; ++k) dl.d[k] = h_delays[k];
     hipStream_t s = lc::as_stream(stream);
     lc::ScopedTimer timer_(lc::T_FIR, s);
-    // the LDS version when the longest story's columns fit (max_story_rows: the caller's bound on the stories' row counts;
-    // <= 0: unknown), else one thread per output column straight from global memory
-    const long long lds = max_story_rows > 0 ? (max_story_rows * SDC + 2 * FIR_MAX_DELAYS * SDC) * 8 : 0;
-    if (lds > 0 && lds <= 150 * 1024) {
-        if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_story_design_lds), (int)lds)) return rc;
-        dim3 grid((unsigned)lc::ceil_div<long long>(ndim, SDC), (unsigned)n_stories);
-        hipLaunchKernelGGL(k_story_design_lds, grid, dim3(256), (size_t)lds, s, d_feat, (long long)ndim, (long long)ld_in,
-                           (const StoryRows*)d_stories, dl, d_x, (long long)ldx);
-        return lc::launched("k_story_design_lds");
-    }
     dim3 grid((unsigned)lc::ceil_div<long long>((long long)nd * ndim, 256), (unsigned)n_stories);
     hipLaunchKernelGGL(k_story_design, grid, dim3(256), 0, s, d_feat, (long long)ndim, (long long)ld_in,
                        (const StoryRows*)d_stories, dl, d_x, (long long)ldx);
     return lc::launched("k_story_design");
-}
-
-extern "C" int lc_story_design_f32(const double* d_feat, int64_t ndim, int64_t ld_in, const void* d_stories, int n_stories,
-                                   const int64_t* h_delays, int nd, float* d_x, int64_t ldx, lc_stream_t stream) {
-    return lc_story_design_f32_rows(d_feat, ndim, ld_in, d_stories, n_stories, 0, h_delays, nd, d_x, ldx, stream);
 }

@@ -231,8 +231,8 @@ def story_design(feat, in_off, n_in, a, b, out_row0, delays, X):
     assert stride == 40
     nd = len(delays)
     arr = (ctypes.c_int64 * max(nd, 1))(*[int(d) for d in delays])
-    _lib.call("lc_story_design_f32_rows", _p(feat), feat.shape[1], feat.stride(0), _p(table), len(in_off),
-              int(max(int(n) for n in n_in)) if len(n_in) else 0, arr, nd, _p(X), X.stride(0), _s())
+    _lib.call("lc_story_design_f32", _p(feat), feat.shape[1], feat.stride(0), _p(table), len(in_off), arr, nd, _p(X),
+              X.stride(0), _s())
     return X
 
 
