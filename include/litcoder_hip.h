@@ -36,6 +36,7 @@ extern "C" {
 
 #define LC_F32 0
 #define LC_F64 1
+#define LC_I32 2           /* (collectives only) */
 
 #define LC_SCORE_CORR 0    /* ridge_regression.py:122-125 */
 #define LC_SCORE_R2 1      /* ridge_regression.py:126-130 */
@@ -737,6 +738,27 @@ int lc_gemm_grouped_f32(const float* d_a, int64_t lda, int64_t a_group_stride,
                         const float* d_b, int64_t ldb, const int32_t* d_brows,
                         float* d_c, int64_t ldc, int64_t Mrows, int64_t Ncols, int64_t K,
                         const int32_t* h_group_tiles, int G, lc_stream_t stream);
+
+/* ---------------------------------------------------------------- collectives over xGMI
+ * Thin RCCL wrappers: what a voxel-sharded fit exchanges -- the V-independent f32 operators of the (fold, alpha) systems
+ * dealt out over the ranks (all-gather; ridge_regression.py:104-125 is voxel-independent given them), the per-alpha score
+ * sums of single_alpha (nested_cv.py:396-400) and the alpha histogram (all-reduce), the packed per-fold results
+ * (all-gather) -- on device pointers and a HIP stream.  RCCL is resolved at the first call (the copy the process has
+ * loaded, else librccl.so.1): a one-GPU process never loads it.
+ *   lc_comm_unique_id        h_id (lc_comm_unique_id_bytes() bytes): a fresh id, made on ONE rank and handed to the others
+ *                            by the host side (the Python layer broadcasts it once through torch.distributed);
+ *   lc_comm_create           collective over `world` ranks: this rank's communicator on `device`;
+ *   lc_allgather_f32 / _bytes  d_recv (world x count) = every rank's d_send, rank-major, ordered on `stream`;
+ *   lc_allreduce             in place, op 0 = sum, 1 = max; dtype LC_F32 / LC_F64 / LC_I32;  lc_allreduce_sum_f32: the f32 sum. */
+typedef struct lc_comm lc_comm_t;
+int lc_comm_unique_id_bytes(void);
+int lc_comm_unique_id(void* h_id, int bytes);
+int lc_comm_create(const void* h_id, int bytes, int world, int rank, int device, lc_comm_t** out);
+int lc_comm_destroy(lc_comm_t* comm);
+int lc_allgather_f32(lc_comm_t* comm, const float* d_send, float* d_recv, int64_t count, lc_stream_t stream);
+int lc_allgather_bytes(lc_comm_t* comm, const void* d_send, void* d_recv, int64_t bytes, lc_stream_t stream);
+int lc_allreduce(lc_comm_t* comm, void* d_buf, int64_t count, int dtype, int op, lc_stream_t stream);
+int lc_allreduce_sum_f32(lc_comm_t* comm, float* d_buf, int64_t count, lc_stream_t stream);
 
 #ifdef __cplusplus
 }

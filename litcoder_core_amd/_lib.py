@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblitcoder_hip.so")
 
-LC_F32, LC_F64 = 0, 1
+LC_F32, LC_F64, LC_I32 = 0, 1, 2
 LC_SCORE_CORR, LC_SCORE_R2 = 0, 1
 LC_NB, LC_MB = 64, 32
 COL_TILE = 128          # voxel-axis padding granule of the MFMA kernels
@@ -156,6 +156,14 @@ SIGNATURES = {
     "lc_group_by_alpha_range": (c_int, [_ptr, c_int64, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_gemm_grouped_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, _ptr, _ptr, c_int64, c_int64, c_int64,
                                     c_int64, POINTER(c_int32), c_int, _ptr]),
+    "lc_comm_unique_id_bytes": (c_int, []),
+    "lc_comm_unique_id": (c_int, [_ptr, c_int]),
+    "lc_comm_create": (c_int, [_ptr, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "lc_comm_destroy": (c_int, [_ptr]),
+    "lc_allgather_f32": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr]),
+    "lc_allgather_bytes": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr]),
+    "lc_allreduce": (c_int, [_ptr, _ptr, c_int64, c_int, c_int, _ptr]),
+    "lc_allreduce_sum_f32": (c_int, [_ptr, _ptr, c_int64, _ptr]),
 }
 
 _lib = None

@@ -18,6 +18,13 @@ of voxel columns and the V-wide data path needs no collective.  What the ranks e
 
 All of these take and return DEVICE tensors.  Backend "nccl" is RCCL over xGMI on ROCm and moves them directly;
 under "gloo" (the CPU tests, and the two-ranks-on-one-GPU parity test) the same calls stage through the host.
+
+Round 5: with ``direct_rccl=True`` (or LITCODER_AMD_RCCL_DIRECT=1) and the "nccl" backend the device-tensor collectives
+do not go through torch.distributed at all but through the library's own thin RCCL wrappers (``lc_allgather_f32`` /
+``lc_allgather_bytes`` / ``lc_allreduce``, include/litcoder_hip.h; SURVEY 8b's export list): one communicator per lane,
+created from a unique id that rank 0 makes and torch.distributed broadcasts ONCE -- PyTorch then is a container and a
+rendezvous, nothing on the data path.  Off by default: this pool has no multi-GPU node to run it on, the one-rank test
+(tests/test_gpu_shards.py) is all the hardware evidence there is, and torch.distributed's transport is the tested one.
 ``ShardContext.simulated`` runs one rank of a W-rank job alone (collectives become local copies): the results are
 meaningless, the per-rank timeline is what an W-GPU run would see minus the wire time -- used by
 ``tools/scaling_model.py`` on the single-GPU box.
@@ -51,7 +58,7 @@ class ShardContext:
     seen (torch.distributed.new_group must be entered by every process, members or not): build it on every rank, in
     the same order."""
 
-    def __init__(self, group=None, device=None, always_collective=False, global_lists=True):
+    def __init__(self, group=None, device=None, always_collective=False, global_lists=True, direct_rccl=None):
         """``always_collective``: issue the backend's collectives even in a one-rank group (they are no-ops
         arithmetically) -- lets a single GPU exercise the RCCL calls of the sharded path.
         ``global_lists``: the per-voxel containers of the metrics dictionary (correlations, p-values, masks, alphas)
@@ -59,8 +66,10 @@ class ShardContext:
         the statistics behind them (BH-FDR ranks all p-values) are global either way; the lists are V_total Python
         objects each -- ~70 ms of interpreter time per rank at 8 x 80 000 voxels, on every rank -- so a job that only
         needs each rank's own voxels (like its block of the weights) turns them off."""
+        import os
         import torch.distributed as dist
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self._comms = {}                               # lane -> lc_comm_t* of the direct RCCL path (None: torch.distributed)
         self.group = group
         self.device = device
         self.rank = self._dist.get_rank(group) if self._dist else 0
@@ -95,6 +104,33 @@ class ShardContext:
                                                                        backend=be)
                                            for lane in ("hat", "refit")})  # same order on every process
             self._lanes = _LANES[key][1]
+        if direct_rccl is None:
+            direct_rccl = os.environ.get("LITCODER_AMD_RCCL_DIRECT", "0") == "1"
+        if direct_rccl and self._dist is not None and self._cuda_direct and (self.world > 1 or self.always):
+            self._init_direct_rccl()
+
+    def _init_direct_rccl(self):
+        """One RCCL communicator per lane through the library's own wrappers (lc_comm_create): rank 0 makes the unique ids,
+        one object broadcast hands them round (collective over the group: every rank constructs its context alike)."""
+        import ctypes
+        import torch
+        from . import _lib
+        lib = _lib.load()
+        n = lib.lc_comm_unique_id_bytes()
+        lanes = (None, "hat", "refit")
+        ids = [None] * len(lanes)
+        if self.rank == 0:
+            for i in range(len(lanes)):
+                buf = ctypes.create_string_buffer(n)
+                _lib.call("lc_comm_unique_id", buf, n)
+                ids[i] = bytes(buf.raw)
+        src = self._dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        self._dist.broadcast_object_list(ids, src=src, group=self.group)
+        dev = self.device.index if (self.device is not None and self.device.index is not None) else torch.cuda.current_device()
+        for lane, raw in zip(lanes, ids):
+            h = ctypes.c_void_p()
+            _lib.call("lc_comm_create", ctypes.c_char_p(raw), n, self.world, self.rank, int(dev), ctypes.byref(h))
+            self._comms[lane] = h
 
     @classmethod
     def single(cls, device=None):
@@ -102,6 +138,7 @@ class ShardContext:
         ctx = cls.__new__(cls)
         ctx._dist, ctx.group, ctx.device, ctx.rank, ctx.world, ctx.backend = None, None, device, 0, 1, None
         ctx.simulate, ctx.always, ctx._lanes, ctx.global_lists, ctx.bytes_received = False, False, {}, True, 0
+        ctx._comms = {}
         ctx._cuda_direct, ctx._cpu_direct = False, False
         return ctx
 
@@ -146,6 +183,18 @@ class ShardContext:
             out.copy_(t.unsqueeze(0).expand_as(out))
             return out
         t = t.contiguous()
+        if self._comms and t.is_cuda:
+            # the library's own RCCL call, ordered on the current stream (flat: rank-major blocks)
+            import ctypes
+            from . import _lib
+            comm = self._comms.get(lane, self._comms[None])
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if t.dtype == torch.float32:
+                _lib.call("lc_allgather_f32", comm, ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(out.data_ptr()), t.numel(), stream)
+            else:
+                _lib.call("lc_allgather_bytes", comm, ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                          t.numel() * t.element_size(), stream)
+            return out
         group = self._lanes.get(lane, self.group)
         if self._direct(t):
             self._dist.all_gather_into_tensor(out.view(-1), t.view(-1), group=group)         # flat: rank-major blocks
@@ -161,6 +210,15 @@ class ShardContext:
         """In-place element-wise sum / max over ranks of a small device tensor, ordered on the current stream."""
         if not self.active or self.simulate:
             return t
+        if self._comms and t.is_cuda and t.is_contiguous():
+            import ctypes
+            import torch
+            from . import _lib
+            code = {torch.float32: _lib.LC_F32, torch.float64: _lib.LC_F64, torch.int32: _lib.LC_I32}.get(t.dtype)
+            if code is not None:
+                _lib.call("lc_allreduce", self._comms[None], ctypes.c_void_p(t.data_ptr()), t.numel(), code, 0 if op == "sum" else 1,
+                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                return t
         rop = self._dist.ReduceOp.SUM if op == "sum" else self._dist.ReduceOp.MAX
         if self._direct(t):
             self._dist.all_reduce(t, op=rop, group=self.group)

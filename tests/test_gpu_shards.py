@@ -57,7 +57,7 @@ if backend != "none":
     shard = ShardContext(device=torch.device("cuda", 0), always_collective=(world == 1))
     assert shard.active
 lo, hi = (shard.bounds(V) if shard else (0, V))
-out = {"lo": lo, "hi": hi}
+out = {"lo": lo, "hi": hi, "direct_rccl": bool(shard is not None and shard._comms)}
 for name, kw in cases.items():
     kw = dict(kw)
     Xc = X[:, : kw.pop("_p", p)]
@@ -115,7 +115,7 @@ for name, kw, local in (("story_single", dict(single_alpha=True), False), ("stor
     if kw["single_alpha"]:
         assert model.last_fit.get("single_alpha_guess") in ("held", "not decisive"), model.last_fit
     out["story_info", name] = {k: model.last_fit.get(k) for k in ("single_alpha_guess", "single_alpha_lead", "panels")}
-tag = "single" if backend == "none" else f"{backend}{world}_rank{shard.rank}"
+tag = "single" if backend == "none" else f"{backend}{world}_rank{shard.rank}" + ("_direct" if out["direct_rccl"] else "")
 pickle.dump(out, open(os.path.join(out_dir, tag + ".pkl"), "wb"))
 if shard is not None:
     dist.destroy_process_group()
@@ -214,6 +214,21 @@ def test_one_rank_through_rccl_collectives(runs):
     env = dict(env, RANK="0", WORLD_SIZE="1", MASTER_PORT=str(29950 + os.getpid() % 40))
     subprocess.run([sys.executable, str(script), ROOT, "nccl", str(d)], check=True, env=env, timeout=900)
     out = pickle.load(open(d / "nccl1_rank0.pkl", "rb"))
+    for key, want in ref.items():
+        if isinstance(key, tuple) and key[0] != "story_info":
+            _same(out[key], want, 0, out["story_hi"] if key[0] == "story" else out["hi"], key)
+
+
+def test_one_rank_through_the_librarys_own_rccl_wrappers(runs):
+    """The same one-rank run with LITCODER_AMD_RCCL_DIRECT=1: every device-tensor collective of the sharded fit is the
+    library's own RCCL call (lc_allgather_f32 / lc_allgather_bytes / lc_allreduce on communicators made by lc_comm_create from
+    a unique id that torch.distributed only hands round; include/litcoder_hip.h) instead of torch.distributed's --
+    the results are the plain fit's, bit for bit."""
+    d, script, env, ref = runs
+    env = dict(env, RANK="0", WORLD_SIZE="1", MASTER_PORT=str(_free_port()), LITCODER_AMD_RCCL_DIRECT="1")
+    subprocess.run([sys.executable, str(script), ROOT, "nccl", str(d)], check=True, env=env, timeout=900)
+    out = pickle.load(open(d / "nccl1_rank0_direct.pkl", "rb"))
+    assert out["direct_rccl"]
     for key, want in ref.items():
         if isinstance(key, tuple) and key[0] != "story_info":
             _same(out[key], want, 0, out["story_hi"] if key[0] == "story" else out["hi"], key)
