@@ -137,6 +137,7 @@ class EngineCore:
         self.aux3 = _aux_stream(self.dev, 3)            # voxel shards: what a fold's refit still needs after refit_ahead
         self.dl = _aux_stream(self.dev, 4)              # finished weight panels on their way to the host
         self.scales_stream = _aux_stream(self.dev, 5)   # column scales of target panels as they arrive (_target_scales)
+        self.side_stream = _aux_stream(self.dev, 6)     # the f32 side path of too-wide target columns (_side_sweeps_begin)
         # voxel shards: this rank's block is columns [lo[rank], lo[rank + 1]) of V_total; the statistics tail (BH-FDR
         # ranks ALL p-values) runs on the gathered vectors, on the device, on every rank; the driver sets alpha_fdr
         self.V_total = int(V_total) if V_total is not None else self.V_rank
@@ -344,7 +345,7 @@ class EngineCore:
                 wide = bool(int(flag.cpu()[0]))
             if wide and side_ok:
                 # WHICH columns: a handful of them leaves the fp16 arithmetic alone (an exact-f32 side path recomputes their
-                # scores, weights and test correlations, _side_sweeps / _side_refit); the ranks agree on that together
+                # scores, weights and test correlations, _side_sweeps_begin / _side_refit_begin); the ranks agree on that together
                 cols = np.nonzero(colflags.cpu().numpy()[: rg.V])[0]
                 many = ops.upload(np.asarray([int(len(cols) > self.opt.side_panel_max_cols)], dtype=np.int32), self.dev)
                 self.shard.all_reduce_(many, "max")

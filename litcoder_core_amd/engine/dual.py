@@ -324,6 +324,9 @@ class DualSweeps:
         def fused_part():
             if done is not None:
                 main.wait_event(done)
+            # the f32 side path of too-wide target columns runs on a stream of its own BESIDE the sweeps queued below (a
+            # few dozen workgroups per launch); its scores are written over the main path's before any alpha is chosen
+            side_job = self._side_sweeps_begin(hat, rg_) if (self.side is not None and split) else None
             # ---- pass 2 (the only one without the moment path): fused sweeps of the alphas that have hat matrices
             for f, j, H, P in folds:
                 b = f if moments else 0
@@ -351,8 +354,8 @@ class DualSweeps:
             if moments and Ad and not cho_first:
                 for i, a in enumerate(cho):
                     scores[a].copy_(scores_d[i])
-            if self.side is not None and split:
-                self._side_sweeps(hat, scores, rg_)
+            if side_job is not None:
+                self._side_sweeps_end(side_job, scores)
             self.sweeps_done = torch.cuda.Event()
             self.sweeps_done.record()
             return scores
@@ -373,55 +376,71 @@ class DualSweeps:
             return None
         return int(sel[0]), int(len(sel)), (cols[sel] - rg.c0).astype(np.int32)
 
-    def _side_sweeps(self, hat, scores, rg):
+    def _side_sweeps_begin(self, hat, rg):
         """The inner-CV scores of the side panel's columns (target columns whose dynamic range the fp16 hi/lo split cannot
-        carry, _register_side) in exact f32 arithmetic, written over the main path's scores of those columns BEFORE any alpha
-        is chosen from them: the factorised alphas through the f32-input MFMA sweep on the same f32 hat matrices the fp16
-        images were split from, the alphas on the polynomial series through the f32 product with the same shared terms and
-        the moment kernel on stored terms (lc_series_scores) -- what ridge_corr_torch computes for every column alike
-        (ridge_regression.py:104-133)."""
+        carry, _register_side) in exact f32 arithmetic: the factorised alphas through the f32-input MFMA sweep on the same
+        f32 hat matrices the fp16 images were split from, the alphas on the polynomial series through the f32 product with
+        the same shared terms and the moment kernel on stored terms (lc_series_scores) -- what ridge_corr_torch computes for
+        every column alike (ridge_regression.py:104-133).  Queued on the side stream behind everything the current stream
+        has queued so far (the hat matrices are complete there); _side_sweeps_end writes the result over the main path's
+        scores of those columns BEFORE any alpha is chosen from them.  Returns the job, or None."""
         hit = self._side_cols_of(rg)
         if hit is None:
-            return
+            return None
         s0, ns, local = hit
         side = self.side
         Vs = ops.pad_to(ns, COL_TILE)
-        Ys = side["Y"][:, s0:]                             # (T, >= Vs) view: the range's side columns first
         A, N, M, tr, va, n_v = self.A, hat["N"], hat["M"], hat["tr"], hat["va"], hat["n_v"]
         moments, cho = hat["moments"], hat["cho"]
         Ad = len(cho) if moments else A
         cho_first = list(cho) == list(range(len(cho)))
-        sc = torch.empty((A, Vs), dtype=torch.float32, device=self.dev)
-        sc_d = sc if not moments else (sc[:Ad] if cho_first else torch.empty((max(Ad, 1), Vs), dtype=torch.float32, device=self.dev))
-        part = torch.empty((max(Ad, 1) * M // LC_MB, 4, Vs), dtype=torch.float32, device=self.dev)
-        ystat = torch.empty((3, Vs), dtype=torch.float32, device=self.dev)
-        yblk = torch.empty((M // LC_MB, Vs), dtype=torch.float32, device=self.dev)
-        yv = torch.empty((M, Vs), dtype=torch.float32, device=self.dev)
-        Tbuf = rowmap = Tm = None
-        if moments:
-            Tm, rowmap, _ = self._series_layout(M)
-            Tbuf = torch.empty((Tm, Vs), dtype=torch.float32, device=self.dev)
-        if Ys.shape[1] < Vs:                               # (the panel's last columns: a padded copy of their own)
-            Yp = ops.zeros((self.Ttot, Vs), torch.float32, self.dev)
-            Yp[:, : Ys.shape[1]].copy_(Ys)
-            Ys = Yp
-        for f0, fc, H, P in hat["Hs"]:
-            for j in range(fc):
-                f = f0 + j
-                ops.val_stats(Ys, Vs, va[f], M, n_v[f], ystat, yblk, yv)
-                if Ad:
-                    ops.alpha_sweep_scores(H[j * Ad:(j + 1) * Ad], Ad, M, N, Ys, Vs, tr[f], yv, n_v[f], ystat, yblk, self.mode,
-                                           part, sc_d, accumulate=f > 0)
-                if moments:
-                    ops.gemm_grouped(P[j], N, 0, Ys, Ys.stride(0), tr[f], Tbuf, Vs, Tm, Vs, N, [0, Vs // COL_TILE])
-                    ops.series_scores(Tbuf, Vs, SERIES_TERMS, M, n_v[f], Vs, yv, ystat, self.d_coef, hat["d_ser"], sc,
-                                      accumulate=f > 0, rowmap=rowmap)
-        if moments and Ad and not cho_first:
-            for i, a in enumerate(cho):
-                sc[a].copy_(sc_d[i])
+        main, ss = torch.cuda.current_stream(), self.side_stream
         dst = np.full(Vs, -1, dtype=np.int32)
         dst[:ns] = local
-        ops.scatter_cols(sc, A, ops.upload(dst, self.dev), Vs, scores)
+        d_dst = ops.upload(dst, self.dev)                      # (on the current stream, before the event the side stream waits for)
+        start = torch.cuda.Event()
+        start.record()
+        ss.wait_event(start)
+        with torch.cuda.stream(ss):
+            Ys = side["Y"][:, s0:]                             # (T, >= ns) view: the range's side columns first
+            if Ys.shape[1] < Vs:                               # (the panel's last columns: a padded copy of their own)
+                Yp = ops.zeros((self.Ttot, Vs), torch.float32, self.dev)
+                Yp[:, : Ys.shape[1]].copy_(Ys)
+                Ys = Yp
+            sc = torch.empty((A, Vs), dtype=torch.float32, device=self.dev)
+            sc_d = sc if not moments else (sc[:Ad] if cho_first else
+                                           torch.empty((max(Ad, 1), Vs), dtype=torch.float32, device=self.dev))
+            part = torch.empty((max(Ad, 1) * M // LC_MB, 4, Vs), dtype=torch.float32, device=self.dev)
+            ystat = torch.empty((3, Vs), dtype=torch.float32, device=self.dev)
+            yblk = torch.empty((M // LC_MB, Vs), dtype=torch.float32, device=self.dev)
+            yv = torch.empty((M, Vs), dtype=torch.float32, device=self.dev)
+            Tbuf = rowmap = Tm = None
+            if moments:
+                Tm, rowmap, _ = self._series_layout(M)
+                Tbuf = torch.empty((Tm, Vs), dtype=torch.float32, device=self.dev)
+            for f0, fc, H, P in hat["Hs"]:
+                for j in range(fc):
+                    f = f0 + j
+                    ops.val_stats(Ys, Vs, va[f], M, n_v[f], ystat, yblk, yv)
+                    if Ad:
+                        ops.alpha_sweep_scores(H[j * Ad:(j + 1) * Ad], Ad, M, N, Ys, Vs, tr[f], yv, n_v[f], ystat, yblk,
+                                               self.mode, part, sc_d, accumulate=f > 0)
+                    if moments:
+                        ops.gemm_grouped(P[j], N, 0, Ys, Ys.stride(0), tr[f], Tbuf, Vs, Tm, Vs, N, [0, Vs // COL_TILE])
+                        ops.series_scores(Tbuf, Vs, SERIES_TERMS, M, n_v[f], Vs, yv, ystat, self.d_coef, hat["d_ser"], sc,
+                                          accumulate=f > 0, rowmap=rowmap)
+            if moments and Ad and not cho_first:
+                for i, a in enumerate(cho):
+                    sc[a].copy_(sc_d[i])
+            done = torch.cuda.Event()
+            done.record()
+        sc.record_stream(main)
+        return sc, d_dst, Vs, done
+
+    def _side_sweeps_end(self, job, scores):
+        sc, d_dst, Vs, done = job
+        torch.cuda.current_stream().wait_event(done)
+        ops.scatter_cols(sc, self.A, d_dst, Vs, scores)
 
     def _alpha_scores(self, K, Y, inner_abs):
         cs, split = self._target_scales(Y)

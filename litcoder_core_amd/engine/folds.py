@@ -326,6 +326,8 @@ class FoldPhases:
         best, perm, Vs = st["best"], st["perm"], st["Vs"]
         torch.cuda.current_stream().wait_event(st["systems_ready"])
         row0 = self.p_pad                              # first row of the test-row hat matrix inside M_alpha
+        # (too-wide target columns: their refit in exact f32, on the side stream, beside the main path's below)
+        side_job = (self._side_refit_begin(st, row0, n_t) if (self.side is not None and st["split"] and not self.primal) else None)
         if self.primal:
             row0 = self.PP
             ext, rows_b, rows_t, csB = self._primal_refit_inputs(st)
@@ -352,8 +354,8 @@ class FoldPhases:
         ent, off = self._ws_slot(st["fold"], rg, Vs, weight_scale)
         ops.invert_perm(perm, Vs, off, ent["pos"][rg.c0:])
         side_w = None
-        if self.side is not None and o["split"] and not self.primal:
-            side_w = self._side_refit(st, ent, off, r_s, p_s, Vs, n_t, row0)     # r / p of the side columns, exact f32
+        if side_job is not None:
+            side_w = self._side_refit_end(side_job, ent, off, r_s, p_s)          # r / p of the side columns, exact f32
         pend = self._publish(st, r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t)
         # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
         # run beside this part of the contraction)
@@ -364,42 +366,57 @@ class FoldPhases:
         self._range_finished(st)
         return pend
 
-    def _side_refit(self, st, ent, off, r_s, p_s, Vs, n_t, row0):
+    def _side_refit_begin(self, st, row0, n_t):
         """The refit of the side panel's columns of this (fold, range) step in exact f32 arithmetic (ridge_torch + the test
-        predictions + Pearson r, ridge_regression.py:9-63, nested_cv.py:151-155): the voxels grouped by the alpha THEY chose
-        (from their corrected scores), the grouped f32-input MFMA product with the same f32 operators the main path's fp16
-        images were split from, Pearson r / p of their test rows -- written over the main path's entries of the alpha-sorted
-        result vectors here, and (returned) over its alpha-sorted weight columns once those are there."""
+        predictions + Pearson r, ridge_regression.py:9-63, nested_cv.py:151-155), queued on the side stream: one column tile
+        per alpha in use -- a side voxel sits in the tile of the alpha IT chose (from its corrected scores), the other
+        columns of the tiles are zeros, so that nothing has to come to the host --, the grouped f32-input MFMA product with
+        the same f32 operators the main path's fp16 images were split from, Pearson r / p of the test rows."""
         hit = self._side_cols_of(st["rg"])
         if hit is None:
             return None
         s0, ns, local = hit
-        rg, used, Malpha = st["rg"], list(st["used"]), st["Malpha"]
-        d_local = ops.upload(local, self.dev).long()
-        best_s = st["best"][d_local].contiguous()                          # the side voxels' alpha indices
-        perm_s, count2 = ops.group_by_alpha(best_s, ns, self.A, COL_TILE)
-        counts = count2[0].cpu().numpy()                                   # (a host round trip: this path is the exception)
-        if isinstance(perm_s, list):
-            perm_s = ops.join_group_ranges(perm_s, counts, COL_TILE)
-        used_s = [a for a in range(self.A) if counts[a] > 0]
-        tiles = [0]
-        for a in used_s:
-            tiles.append(tiles[-1] + (int(counts[a]) + COL_TILE - 1) // COL_TILE)
-        Vss = tiles[-1] * COL_TILE
-        Ms = [Malpha[used.index(a)] for a in used_s]
-        Ysel = self.side["Y"][:, s0:]
-        o = self._refit_operands(Ysel, st["tr"], st["te"], perm_s, tiles, Vss, Ms, False, None)
-        C = self._refit_product(o, 0, Ms[0].shape[0], self.p + n_t)
-        r = ops.pearson_cols(o["Ys_te"], C[row0:row0 + n_t], n_t, Vss)
-        pv = ops.pearson_pvalues(r, Vss, n_t)
-        # where each sorted side column belongs in the main path's alpha-sorted order of this step
-        pos_rel = ent["pos"][rg.c0:][d_local].long() - off
-        live = perm_s[:Vss] >= 0
-        dst = torch.where(live, pos_rel[perm_s[:Vss].clamp(min=0).long()], torch.full_like(pos_rel[:1], -1).expand(Vss))
-        dst = dst.to(torch.int32).contiguous()
-        ops.scatter_cols(r.view(1, -1), 1, dst, Vss, r_s.view(1, -1))
-        ops.scatter_cols(pv.view(1, -1), 1, dst, Vss, p_s.view(1, -1))
-        return C[: self.p_pad], dst, Vss
+        used, Malpha = list(st["used"]), st["Malpha"]
+        G, Vg = len(used), ops.pad_to(ns, COL_TILE)
+        main, ss = torch.cuda.current_stream(), self.side_stream
+        d_local = ops.upload(local, self.dev)                  # (on the current stream, before the event the side stream waits for)
+        d_used = ops.upload(np.asarray(used, dtype=np.int32), self.dev)
+        start = torch.cuda.Event()
+        start.record()
+        ss.wait_event(start)
+        with torch.cuda.stream(ss):
+            best_s = torch.full((Vg,), -2, dtype=torch.int32, device=self.dev)
+            best_s[:ns] = st["best"][d_local.long()]
+            j = torch.arange(Vg, dtype=torch.int32, device=self.dev)
+            perm_s = torch.where(best_s[None, :] == d_used[:, None], j[None, :], torch.full_like(j, -1)[None, :])
+            perm_s = perm_s.reshape(-1).contiguous()                       # (G Vg): voxel j in its alpha's tile, else -1
+            tiles = [g * (Vg // COL_TILE) for g in range(G + 1)]
+            Vss = G * Vg
+            Ysel = self.side["Y"][:, s0:]
+            o = self._refit_operands(Ysel, st["tr"], st["te"], perm_s, tiles, Vss, Malpha, False, None)
+            C = self._refit_product(o, 0, Malpha[0].shape[0], self.p + n_t)
+            r = ops.pearson_cols(o["Ys_te"], C[row0:row0 + n_t], n_t, Vss)
+            pv = ops.pearson_pvalues(r, Vss, n_t)
+            done = torch.cuda.Event()
+            done.record()
+        for t in (C, r, pv, perm_s):
+            t.record_stream(main)
+        d_local.record_stream(ss)
+        d_used.record_stream(ss)
+        return dict(C=C, r=r, p=pv, perm=perm_s, Vss=Vss, d_local=d_local, done=done, rg=st["rg"])
+
+    def _side_refit_end(self, job, ent, off, r_s, p_s):
+        """Main stream: the side refit's Pearson r / p over the main path's entries of the alpha-sorted result vectors;
+        returns (weights, destination columns, count) for the scatter over its alpha-sorted weight columns once those are
+        there."""
+        torch.cuda.current_stream().wait_event(job["done"])
+        rg, perm_s, Vss = job["rg"], job["perm"], job["Vss"]
+        # where each side column belongs in the main path's alpha-sorted order of this step (lc_invert_perm has run)
+        pos_rel = ent["pos"][rg.c0:][job["d_local"].long()] - off
+        dst = torch.where(perm_s >= 0, pos_rel[perm_s.clamp(min=0).long()], torch.full_like(perm_s, -1)).to(torch.int32).contiguous()
+        ops.scatter_cols(job["r"].view(1, -1), 1, dst, Vss, r_s.view(1, -1))
+        ops.scatter_cols(job["p"].view(1, -1), 1, dst, Vss, p_s.view(1, -1))
+        return job["C"][: self.p_pad], dst, Vss
 
     def _ws_slot(self, fold, rg, Vs, scale):
         """Where the alpha-sorted weight columns of a (fold, voxel range) step go: one (p_pad, cap) matrix per fold, the

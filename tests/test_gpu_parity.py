@@ -1363,16 +1363,21 @@ def test_voxel_panels_are_bitwise_neutral(lc):
         for k in ref[0]:
             assert np.array_equal(np.asarray(got[0][k]), np.asarray(ref[0][k]), equal_nan=True), (p, k)
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), p
-    # precision "auto" meets a too-wide column in a LATE panel: the fit is repeated on the f32 path and equals it
+    # precision "auto" meets a too-wide column in a LATE panel: the fit is repeated with the targets resident -- the wide
+    # column on the f32 side path (round 5; the whole fit on the f32 path before) -- and equals the fit without panels
     Y2 = Y.copy()
     Y2[7, 1000] = 1e6
     kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 5, 8))
     m_auto = lc.NestedCVModel("r", panel_cols=256)
     got = m_auto.fit_predict(X, Y2, **kw)
-    assert m_auto.last_fit["precision"] == "f32"
-    ref = lc.NestedCVModel("r", precision="f32", panel_cols=0).fit_predict(X, Y2, **kw)
+    assert m_auto.last_fit["precision"] == "f16x3" and m_auto.last_fit["side_panel_cols"] == 1
+    m_ref = lc.NestedCVModel("r", panel_cols=0)
+    ref = m_ref.fit_predict(X, Y2, **kw)
+    assert m_ref.last_fit["precision"] == "f16x3" and m_ref.last_fit["side_panel_cols"] == 1
     assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
     assert np.array_equal(np.asarray(got[0]["correlations"]), np.asarray(ref[0]["correlations"]))
+    ref32 = lc.NestedCVModel("r", precision="f32", panel_cols=0).fit_predict(X, Y2, **kw)
+    assert ref[2][1000] == ref32[2][1000] and abs(ref[0]["correlations"][1000] - ref32[0]["correlations"][1000]) < 1e-5
 
 
 def test_wide_target_scales_and_planted_signal(lc):
