@@ -133,14 +133,14 @@ class _FoldResult:
 _AUX_STREAMS: Dict[Any, Any] = {}
 
 
-def _aux_stream(dev, which=0):
+def _aux_stream(dev, which=0, priority=0):
     """The auxiliary streams of a device, created once for the life of the process.  A fresh ``torch.cuda.Stream()`` per
     engine walks through torch's pool of 32 streams, and the FIRST cross-stream wait on a stream that has never run
     anything blocks the host for ~6 ms (its hardware queue is created there): every fit of a series paid that before
     its first fold was queued."""
     key = (dev.type, dev.index, which)
     if key not in _AUX_STREAMS:
-        _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+        _AUX_STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
     return _AUX_STREAMS[key]
 
 

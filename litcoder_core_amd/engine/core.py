@@ -137,7 +137,10 @@ class EngineCore:
         self.aux3 = _aux_stream(self.dev, 3)            # voxel shards: what a fold's refit still needs after refit_ahead
         self.dl = _aux_stream(self.dev, 4)              # finished weight panels on their way to the host
         self.scales_stream = _aux_stream(self.dev, 5)   # column scales of target panels as they arrive (_target_scales)
-        self.side_stream = _aux_stream(self.dev, 6)     # the f32 side path of too-wide target columns (_side_sweeps_begin)
+        # the f32 side path of too-wide target columns (_side_sweeps_begin): a few dozen workgroups per launch, beside the
+        # sweeps' thousands (a HIGH-priority stream for it was measured: one spiked column then costs a cfg2 fit 12.6 %
+        # instead of 5.1 % -- as with the fp64 chains, priorities only move the waiting around)
+        self.side_stream = _aux_stream(self.dev, 6)
         # voxel shards: this rank's block is columns [lo[rank], lo[rank + 1]) of V_total; the statistics tail (BH-FDR
         # ranks ALL p-values) runs on the gathered vectors, on the device, on every rank; the driver sets alpha_fdr
         self.V_total = int(V_total) if V_total is not None else self.V_rank

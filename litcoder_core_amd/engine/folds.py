@@ -353,15 +353,14 @@ class FoldPhases:
         # (_combine_weights), not accumulated fold by fold
         ent, off = self._ws_slot(st["fold"], rg, Vs, weight_scale)
         ops.invert_perm(perm, Vs, off, ent["pos"][rg.c0:])
-        side_w = None
-        if side_job is not None:
-            side_w = self._side_refit_end(side_job, ent, off, r_s, p_s)          # r / p of the side columns, exact f32
-        pend = self._publish(st, r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t)
+        # (the side columns' r / p, exact f32, go over the main path's on the communication stream, just before the fold's
+        # results are exchanged: the main stream does not wait for the side refit here)
+        pend = self._publish(st, r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t, side_job=side_job)
         # the weights last: nothing the host waits for depends on them (for the last fold the host statistics then
         # run beside this part of the contraction)
         self._refit_product(o, 0, self.p_pad, self.p, out=ent["buf"][:, off:off + Vs])
-        if side_w is not None:
-            W_s, dst, n_s = side_w
+        if side_job is not None:
+            W_s, dst, n_s = self._side_refit_end(side_job, ent, off)
             ops.scatter_cols(W_s, self.p_pad, dst, n_s, ent["buf"][:, off:off + Vs])
         self._range_finished(st)
         return pend
@@ -405,18 +404,29 @@ class FoldPhases:
         d_used.record_stream(ss)
         return dict(C=C, r=r, p=pv, perm=perm_s, Vss=Vss, d_local=d_local, done=done, rg=st["rg"])
 
-    def _side_refit_end(self, job, ent, off, r_s, p_s):
-        """Main stream: the side refit's Pearson r / p over the main path's entries of the alpha-sorted result vectors;
-        returns (weights, destination columns, count) for the scatter over its alpha-sorted weight columns once those are
-        there."""
+    def _side_refit_end(self, job, ent, off):
+        """Main stream, behind the main path's weight product of the step: (weights, destination columns, count) for the
+        scatter of the side refit's weights over the main path's alpha-sorted weight columns."""
         torch.cuda.current_stream().wait_event(job["done"])
         rg, perm_s, Vss = job["rg"], job["perm"], job["Vss"]
         # where each side column belongs in the main path's alpha-sorted order of this step (lc_invert_perm has run)
         pos_rel = ent["pos"][rg.c0:][job["d_local"].long()] - off
         dst = torch.where(perm_s >= 0, pos_rel[perm_s.clamp(min=0).long()], torch.full_like(perm_s, -1)).to(torch.int32).contiguous()
-        ops.scatter_cols(job["r"].view(1, -1), 1, dst, Vss, r_s.view(1, -1))
-        ops.scatter_cols(job["p"].view(1, -1), 1, dst, Vss, p_s.view(1, -1))
         return job["C"][: self.p_pad], dst, Vss
+
+    def _side_results_into(self, blk, jobs):
+        """Current (communication) stream: the side refits' Pearson r / p of a fold over the main path's entries of the
+        packed result block (natural voxel order: rows 0 / 1, lc_fold_pack_at)."""
+        cur = torch.cuda.current_stream()
+        for job in jobs:
+            cur.wait_event(job["done"])
+            rg, perm_s, Vss = job["rg"], job["perm"], job["Vss"]
+            nat = job["d_local"] + rg.c0
+            dst = torch.where(perm_s >= 0, nat[perm_s.clamp(min=0).long()], torch.full_like(perm_s, -1)).to(torch.int32).contiguous()
+            ops.scatter_cols(job["r"].view(1, -1), 1, dst, Vss, blk[0:1])
+            ops.scatter_cols(job["p"].view(1, -1), 1, dst, Vss, blk[1:2])
+            for t in (job["r"], job["p"], perm_s, job["d_local"]):
+                t.record_stream(cur)
 
     def _ws_slot(self, fold, rg, Vs, scale):
         """Where the alpha-sorted weight columns of a (fold, voxel range) step go: one (p_pad, cap) matrix per fold, the
@@ -464,7 +474,7 @@ class FoldPhases:
         ops.download_cols(rg.W, self._host_w, rg.c0, rg.V, self.dl)
         self._sent += rg.V
 
-    def _publish(self, st, r_s, p_s, perm, Vs, best, info, info_o, n_t):
+    def _publish(self, st, r_s, p_s, perm, Vs, best, info, info_o, n_t, side_job=None):
         """The per-voxel results of one (fold, range) step go into the rank's packed block of the fold, natural voxel
         order (r, p, alpha index, pivot flags).  Once every range of the fold is in, the block is all-gathered over the
         voxel shards, unpacked to V_total-long vectors, and the fold's BH-FDR runs on ALL p-values -- on the
@@ -474,10 +484,12 @@ class FoldPhases:
         ent = self._fold_blk.get(fold_no)
         if ent is None:
             ent = self._fold_blk[fold_no] = dict(
-                blk=torch.empty((4, max(self.w_max, 2)), dtype=torch.float64, device=self.dev), cols=0, keep=[])
+                blk=torch.empty((4, max(self.w_max, 2)), dtype=torch.float64, device=self.dev), cols=0, keep=[], side=[])
         ops.fold_pack(r_s, p_s, perm, Vs, best, rg.V, info, info_o, ent["blk"], col0=rg.c0, clear=ent["cols"] == 0)
         ent["cols"] += rg.V
         ent["keep"] += [r_s, p_s, perm, best, info, info_o]
+        if side_job is not None:
+            ent["side"].append(side_job)
         if ent["cols"] < self.V_rank:
             return None
         blk = ent["blk"]
@@ -486,6 +498,8 @@ class FoldPhases:
         self.comm.wait_event(packed)
         Vt = self.V_total
         with torch.cuda.stream(self.comm):
+            if ent["side"]:
+                self._side_results_into(blk, ent["side"])
             gathered = self.shard.all_gather(blk)                                  # (world, 4, ld)
             dres = torch.empty((2, Vt), dtype=torch.float64, device=self.dev)      # r, p of all voxels
             didx = torch.empty(Vt, dtype=torch.int32, device=self.dev)
