@@ -11,7 +11,7 @@
 namespace lc {
 void set_error(const char*, ...) {}
 int ensure_dynamic_lds(const void*, int) { return 0; }
-bool timing_on() { return false; }
+bool timing_on(int) { return false; }
 void timing_begin(int, hipStream_t) {}
 void timing_end(int, hipStream_t) {}
 }  // namespace lc
