@@ -41,7 +41,7 @@ extern "C" {
 #define LC_SCORE_CORR 0    /* ridge_regression.py:122-125 */
 #define LC_SCORE_R2 1      /* ridge_regression.py:126-130 */
 
-/* Padding granules the batched routines require (see DESIGN.md "Data layout"). */
+/* Padding granules the batched routines require. */
 #define LC_NB 64           /* Gram/Cholesky block: N (train rows, padded) % LC_NB == 0 */
 #define LC_MB 32           /* score row-block: M (validation rows, padded) % LC_MB == 0 */
 

@@ -1,6 +1,6 @@
 // Diagnostic builds of the dominant kernel, OUTSIDE the product library: the score kernel with
 // s_memtime / s_memrealtime stamps (in-kernel clock, per-phase cycles) and the experiment kernel on
-// v_mfma_f32_16x16x32_f16 (plain mode only; measured 1-2 % faster than the 32x32x16 kernel, not adopted: DESIGN.md).
+// v_mfma_f32_16x16x32_f16 (plain mode only; measured 1-2 % faster than the 32x32x16 kernel, not adopted: HISTORY.md 4.1).
 // Built by tools/debug_kernels/build.py into tools/bin/liblitcoder_debug.so; tools/gpu_kernel_bench.py loads it.
 #include "../../litcoder_core_amd/csrc/lc_gemm16_kernel.h"
 #include "lc_debug.h"
