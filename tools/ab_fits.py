@@ -6,6 +6,7 @@ rounds, and the distribution per arm is printed (median, min, max) with the resu
     python tools/ab_fits.py <cfg2h|cfg2r|cfg3> <rounds> [<name>=<value>[,<name>=<value>...] | default] ...
 e.g. python tools/ab_fits.py cfg3 8 default lanczos_dense=0,lanczos_tol=0
      cfg2h = the bench headline (host float64 arrays in, host weights out), cfg2r = resident inputs, cfg3 = the story pipeline
+     AB_RANK=G,r (cfg2r): as simulated rank r of G (its AB_VOXELS / G voxels, its share of the V-independent systems)
 """
 import dataclasses
 import os
@@ -17,7 +18,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from litcoder_core_amd import NestedCVModel, StoryPipeline, ops  # noqa: E402
+from litcoder_core_amd import NestedCVModel, ShardContext, StoryPipeline, ops  # noqa: E402
+from litcoder_core_amd.dist import shard_bounds  # noqa: E402
 from litcoder_core_amd.engine.common import FitOptions  # noqa: E402
 
 work, rounds = sys.argv[1], int(sys.argv[2])
@@ -38,19 +40,25 @@ def options(spec):
     return FitOptions(**kw)
 
 
-models = {a: NestedCVModel("ridge_regression", options=options(a)) for a in arms}
+G, rank = (int(x) for x in os.environ.get("AB_RANK", "1,0").split(","))
+V_total = V
+if G > 1:
+    lo, hi = shard_bounds(V_total, G, rank)
+    V = hi - lo
+shard = lambda: ShardContext.simulated(G, rank, device=dev, global_lists=False) if G > 1 else None
+models = {a: NestedCVModel("ridge_regression", options=options(a), shard=shard()) for a in arms}
 if work == "cfg3":
     words, wtimes, trtimes, brain = bench.synth_stories(V, dev)
     pipes = {a: StoryPipeline([1, 2, 3, 4], bench.CFG3_TRIM, model=m) for a, m in models.items()}
     run = lambda a: pipes[a].fit_words(words, wtimes, trtimes, brain, **bench.CFG3_KW)
 else:
-    dX, dY, p = bench.synth_inputs(V, 0, dev)
+    dX, dY, p = bench.synth_inputs(V, rank, dev)
     alphas = np.logspace(-1, 8, bench.A)
     if work == "cfg2h":
         host = bench.host_arrays(dX, dY, p, V)
         run = lambda a: models[a].fit_predict(host[0], host[1], alphas=alphas, **bench.FIT_KW)
     else:
-        run = lambda a: models[a].fit_predict_device(dX, dY, p, V, alphas=alphas, **bench.FIT_KW)
+        run = lambda a: models[a].fit_predict_device(dX, dY, p, V, n_voxels_total=V_total, alphas=alphas, **bench.FIT_KW)
 
 times = {a: [] for a in arms}
 res = {}
