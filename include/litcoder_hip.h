@@ -219,6 +219,14 @@ int lc_scatter_axpy_f32(const float* d_w, int64_t ld_w, int64_t n_rows, const in
  * the columns of the f32 side path back into the main path's score / weight / result matrices. */
 int lc_scatter_cols(const void* d_src, int64_t ld_src, int64_t n_rows, int elem_bytes, const int32_t* d_cols,
                     int64_t n_cols, void* d_dst, int64_t ld_dst, lc_stream_t stream);
+/* The same side path when it holds a handful of columns (ns <= 8; one outlier voxel is the usual case): the products of
+ * ridge_regression.py:46-61, 104-120 for those columns alone, streamed instead of tiled --
+ *     d_c[m, j] = sum_k d_a[m, k] * d_y[d_rows[k] * ldy + j]      (m < M, k < K; d_rows[k] < 0: 0; d_rows NULL: row k)
+ * for the columns j < ns with d_sel[j] == want (d_sel NULL: all; the other columns of d_c are left alone), f32 inputs,
+ * fp64 accumulation, f32 result.  K % 4 == 0, lda % 4 == 0, d_a 16-byte aligned. */
+int lc_gemv_cols_f32(const float* d_a, int64_t lda, int64_t M, int64_t K, const float* d_y, int64_t ldy,
+                     const int32_t* d_rows, const int32_t* d_sel, int ns, int32_t want, float* d_c, int64_t ldc,
+                     lc_stream_t stream);
 
 /* The same mean over folds (nested_cv.py:249,293-296) without a read-modify-write of the accumulator per fold: each
  * fold keeps its alpha-sorted weight matrix, lc_invert_perm notes where every voxel's column went

@@ -40,6 +40,7 @@ SIGNATURES = {
     "lc_gather_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr]),
     "lc_scatter_axpy_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, c_float, _ptr, c_int64, _ptr]),
     "lc_scatter_cols": (c_int, [_ptr, c_int64, c_int64, c_int, _ptr, c_int64, _ptr, c_int64, _ptr]),
+    "lc_gemv_cols_f32": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, c_int64, _ptr, _ptr, c_int, c_int32, _ptr, c_int64, _ptr]),
     "lc_invert_perm": (c_int, [_ptr, c_int64, c_int32, _ptr, _ptr]),
     "lc_combine_folds_f32": (c_int, [POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), POINTER(c_float), c_int, c_int64,
                                      c_int64, _ptr, c_int64, _ptr]),

@@ -58,6 +58,67 @@ __global__ void __launch_bounds__(256) k_scatter_cols(const E* __restrict__ src,
     }
 }
 
+// A few columns of a V-wide product, streamed (round 5: the f32 side panel when it holds a handful of columns -- one outlier
+// voxel among 80 000 is the usual case).  C[m][j] = sum_k A[m][k] Y[rows[k]][j] for the ns <= GV_NS columns j whose
+// sel[j] == want (sel == NULL: all), fp64 accumulation of the f32 products, written as f32.  The 128-column MFMA tiles of
+// lc_alpha_sweep_scores / lc_gemm_grouped_f32 spend 127 / 128 of their work on padding there and hold 15-30 CUs for
+// ~0.3 ms per launch beside the fit's fp16 sweeps; this reads A once at HBM speed (a hat-matrix stack of 15 MB: ~10 us).
+// Block: 8 rows of A (two per wave), the Y columns staged through LDS in chunks of GV_KC rows.
+constexpr int GV_NS = 8, GV_KC = 1024;
+__global__ void __launch_bounds__(256) k_gemv_cols(const float* __restrict__ A, long long lda, long long M, long long K,
+                                                   const float* __restrict__ Y, long long ldy, const int* __restrict__ rows,
+                                                   const int* __restrict__ sel, int ns, int want, float* __restrict__ C,
+                                                   long long ldc) {
+    __shared__ float ys[GV_NS][GV_KC];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    unsigned active = 0;
+    for (int j = 0; j < ns; ++j)
+        if (!sel || sel[j] == want) active |= 1u << j;
+    if (!active) return;                                 // (block-uniform)
+    const long long m0 = (long long)blockIdx.x * 8 + 2 * w;
+    double acc[2][GV_NS];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < GV_NS; ++j) acc[r][j] = 0.0;
+    for (long long k0 = 0; k0 < K; k0 += GV_KC) {
+        const int kc = (int)(K - k0 < GV_KC ? K - k0 : GV_KC);
+        __syncthreads();                                 // the previous chunk has been consumed
+        for (int e = t; e < kc * ns; e += 256) {
+            const int k = e / ns, j = e - k * ns;
+            const long long row = rows ? rows[k0 + k] : k0 + k;
+            ys[j][k] = (row >= 0 && ((active >> j) & 1u)) ? Y[row * ldy + j] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const long long m = m0 + r;
+            if (m >= M) break;
+            const float* a = A + m * lda + k0;
+            for (int k = 4 * lane; k < kc; k += 256) {
+                const float4 av = *reinterpret_cast<const float4*>(a + k);          // (K % 4 == 0)
+#pragma unroll
+                for (int j = 0; j < GV_NS; ++j) {
+                    if (!((active >> j) & 1u)) continue;
+                    const float4 yv = *reinterpret_cast<const float4*>(&ys[j][k]);
+                    acc[r][j] += (double)av.x * (double)yv.x + (double)av.y * (double)yv.y + (double)av.z * (double)yv.z +
+                                 (double)av.w * (double)yv.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < GV_NS; ++j) {
+            if (!((active >> j) & 1u)) continue;         // (wave-uniform)
+            double v = acc[r][j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && m0 + r < M) C[(m0 + r) * ldc + j] = (float)v;
+        }
+}
+
 // Mean of the folds' weights without a read-modify-write per fold: every fold leaves its alpha-SORTED weight matrix where
 // the refit contraction wrote it, k_invert_perm notes where each voxel's column went, and ONE pass per voxel range forms
 //     out[r, v] = sum_f scale_f * w_f[r, pos_f[v]]          (folds in order, the same expression per term as
@@ -519,6 +580,20 @@ extern "C" int lc_scatter_cols(const void* d_src, int64_t ld_src, int64_t n_rows
                                static_cast<double*>(d_dst) + r0 * ld_dst, (long long)ld_dst);
     }
     return lc::launched("k_scatter_cols");
+}
+
+extern "C" int lc_gemv_cols_f32(const float* d_a, int64_t lda, int64_t M, int64_t K, const float* d_y, int64_t ldy,
+                                const int32_t* d_rows, const int32_t* d_sel, int ns, int32_t want, float* d_c, int64_t ldc,
+                                lc_stream_t stream) {
+    LC_REQUIRE(d_a && d_y && d_c, LC_E_BADARG, "lc_gemv_cols_f32: null pointer");
+    LC_REQUIRE(M >= 0 && K >= 0 && ns >= 1 && ns <= GV_NS && K % 4 == 0 && lda >= K && lda % 4 == 0 && ldc >= ns &&
+                   (reinterpret_cast<uintptr_t>(d_a) & 15) == 0,
+               LC_E_SHAPE, "lc_gemv_cols_f32: need 1 <= ns <= %d, K %% 4 == 0, lda >= K, lda %% 4 == 0, A 16-byte aligned", GV_NS);
+    if (M == 0 || K == 0) return LC_OK;
+    hipLaunchKernelGGL(k_gemv_cols, dim3((unsigned)lc::ceil_div<long long>(M, 8)), dim3(256), 0, lc::as_stream(stream), d_a,
+                       (long long)lda, (long long)M, (long long)K, d_y, (long long)ldy, d_rows, d_sel, ns, (int)want, d_c,
+                       (long long)ldc);
+    return lc::launched("k_gemv_cols");
 }
 
 extern "C" int lc_invert_perm(const int32_t* d_cols, int64_t n_cols, int32_t base, int32_t* d_pos, lc_stream_t stream) {

@@ -398,6 +398,14 @@ class DualSweeps:
         dst = np.full(Vs, -1, dtype=np.int32)
         dst[:ns] = local
         d_dst = ops.upload(dst, self.dev)                      # (on the current stream, before the event the side stream waits for)
+        # a handful of columns (one outlier voxel among 80 000 is the usual case): their products streamed (lc_gemv_cols_f32,
+        # fp64 accumulation) instead of 128-column MFMA tiles that are 127 / 128 padding and hold 15-30 CUs for ~0.3 ms per
+        # launch beside the fit's own sweeps; the factorised alphas' predictions go through the moment kernel too, as
+        # "terms" with unit coefficients -- the same score formula for every alpha
+        few = bool(moments and ns <= ops.GEMV_MAX_COLS and Ad <= 8)
+        if few and side.get("unit") is None:
+            side["unit"] = (ops.upload(np.eye(max(Ad, 1), dtype=np.float64), self.dev),
+                            ops.upload(np.asarray(list(cho) or [0], dtype=np.int32), self.dev))
         start = torch.cuda.Event()
         start.record()
         ss.wait_event(start)
@@ -418,10 +426,22 @@ class DualSweeps:
             if moments:
                 Tm, rowmap, _ = self._series_layout(M)
                 Tbuf = torch.empty((Tm, Vs), dtype=torch.float32, device=self.dev)
+            if few:
+                Tbuf = ops.zeros((Tm, Vs), torch.float32, self.dev)                 # (columns >= ns stay zero)
+                Tcho = ops.zeros((max(Ad, 1) * M, Vs), torch.float32, self.dev)
+                unit, d_cho = side["unit"]
             for f0, fc, H, P in hat["Hs"]:
                 for j in range(fc):
                     f = f0 + j
                     ops.val_stats(Ys, Vs, va[f], M, n_v[f], ystat, yblk, yv)
+                    if few:
+                        if Ad:
+                            ops.gemv_cols(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), Ad * M, N, Ys, tr[f], ns, Tcho)
+                            ops.series_scores(Tcho, Vs, Ad, M, n_v[f], Vs, yv, ystat, unit, d_cho, sc, accumulate=f > 0)
+                        ops.gemv_cols(P[j], Tm, N, Ys, tr[f], ns, Tbuf)
+                        ops.series_scores(Tbuf, Vs, SERIES_TERMS, M, n_v[f], Vs, yv, ystat, self.d_coef, hat["d_ser"], sc,
+                                          accumulate=f > 0, rowmap=rowmap)
+                        continue
                     if Ad:
                         ops.alpha_sweep_scores(H[j * Ad:(j + 1) * Ad], Ad, M, N, Ys, Vs, tr[f], yv, n_v[f], ystat, yblk,
                                                self.mode, part, sc_d, accumulate=f > 0)
@@ -429,7 +449,7 @@ class DualSweeps:
                         ops.gemm_grouped(P[j], N, 0, Ys, Ys.stride(0), tr[f], Tbuf, Vs, Tm, Vs, N, [0, Vs // COL_TILE])
                         ops.series_scores(Tbuf, Vs, SERIES_TERMS, M, n_v[f], Vs, yv, ystat, self.d_coef, hat["d_ser"], sc,
                                           accumulate=f > 0, rowmap=rowmap)
-            if moments and Ad and not cho_first:
+            if moments and Ad and not cho_first and not few:
                 for i, a in enumerate(cho):
                     sc[a].copy_(sc_d[i])
             done = torch.cuda.Event()

@@ -380,12 +380,38 @@ class FoldPhases:
         main, ss = torch.cuda.current_stream(), self.side_stream
         d_local = ops.upload(local, self.dev)                  # (on the current stream, before the event the side stream waits for)
         d_used = ops.upload(np.asarray(used, dtype=np.int32), self.dev)
+        few = ns <= ops.GEMV_MAX_COLS                          # a handful of columns: streamed products (see _side_sweeps_begin)
+        if few:
+            N_o = Malpha[0].shape[1]
+            d_tr = ops.idx_tensor(st["tr"], N_o, self.dev)
+            d_te = ops.idx_tensor(st["te"], n_t, self.dev)
         start = torch.cuda.Event()
         start.record()
         ss.wait_event(start)
         with torch.cuda.stream(ss):
             best_s = torch.full((Vg,), -2, dtype=torch.int32, device=self.dev)
             best_s[:ns] = st["best"][d_local.long()]
+            if few:
+                # column j of C is side column j, refitted with the operator of the alpha IT chose: one streamed product per
+                # alpha in use, each taking the columns that chose it (decided on the device: nothing comes to the host)
+                rows_all = Malpha[0].shape[0]
+                Ysel = self.side["Y"][:, s0:]
+                C = ops.zeros((rows_all, Vg), torch.float32, self.dev)
+                for g, a in enumerate(used):
+                    ops.gemv_cols(Malpha[g], rows_all, N_o, Ysel, d_tr, ns, C, sel=best_s, want=int(a))
+                Ys_te = ops.zeros((n_t, Vg), torch.float32, self.dev)
+                ops.gather(Ysel, Ysel.stride(0), d_te, n_t, None, min(Vg, Ysel.shape[1]), Ys_te)
+                r = ops.pearson_cols(Ys_te, C[row0:row0 + n_t], n_t, Vg)
+                pv = ops.pearson_pvalues(r, Vg, n_t)
+                perm_s = torch.arange(Vg, dtype=torch.int32, device=self.dev)
+                perm_s[ns:] = -1
+                done = torch.cuda.Event()
+                done.record()
+                for t in (C, r, pv, perm_s):
+                    t.record_stream(main)
+                for t in (d_local, d_used, d_tr, d_te):
+                    t.record_stream(ss)
+                return dict(C=C, r=r, p=pv, perm=perm_s, Vss=Vg, d_local=d_local, done=done, rg=st["rg"])
             j = torch.arange(Vg, dtype=torch.int32, device=self.dev)
             perm_s = torch.where(best_s[None, :] == d_used[:, None], j[None, :], torch.full_like(j, -1)[None, :])
             perm_s = perm_s.reshape(-1).contiguous()                       # (G Vg): voxel j in its alpha's tile, else -1

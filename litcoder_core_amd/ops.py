@@ -994,6 +994,18 @@ def scatter_cols(src, n_rows, cols, n_cols, dst):
     return dst
 
 
+GEMV_MAX_COLS = 8
+
+
+def gemv_cols(a, M, K, y, rows, ns, out, sel=None, want=0):
+    """out[m, j] = sum_k a[m, k] * y[rows[k], j] for the ns <= GEMV_MAX_COLS first columns of ``y`` (those with sel[j] ==
+    want when ``sel`` is given; the others are left alone): f32 in, fp64 accumulation, f32 out (lc_gemv_cols_f32).
+    ``a``: (M, >= K) f32 rows of stride a.stride(-2); ``rows``: int32 device list (K) or None."""
+    _lib.call("lc_gemv_cols_f32", _p(a), a.stride(-2), M, K, _p(y), y.stride(0), _p(rows), _p(sel), int(ns), int(want),
+              _p(out), out.stride(0), _s())
+    return out
+
+
 def split_cols_f16(y, V, rows, K, cscale, tiled):
     _lib.call("lc_split_cols_f16", _p(y), y.stride(0), V, _p(rows), K, _p(cscale), _p(tiled), _s())
 

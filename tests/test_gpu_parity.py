@@ -1476,6 +1476,41 @@ def test_bad_voxels_stay_in_their_columns(lc):
             np.testing.assert_allclose(np.asarray(m2["correlations"])[clean], r[clean], rtol=0, atol=6e-8)
 
 
+def test_gemv_cols_against_numpy(lc):
+    """lc_gemv_cols_f32 (the streamed products of the f32 side panel when it holds a handful of columns): a row list with
+    padding entries, a column selection, columns left alone, a depth over several LDS chunks, a ragged last row block."""
+    from litcoder_core_amd import ops
+    dev = ops.device()
+    rng = np.random.default_rng(5)
+    M, K, T, ns = 203, 2432, 3000, 5
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Y = rng.standard_normal((T, 128)).astype(np.float32)
+    rows = rng.permutation(T)[:K].astype(np.int32)
+    rows[K - 37:] = -1
+    dA, dY = torch.from_numpy(A).to(dev), torch.from_numpy(Y).to(dev)
+    d_rows = torch.from_numpy(rows).to(dev)
+    Yg = np.where(rows[:, None] >= 0, Y[np.maximum(rows, 0)], 0.0).astype(np.float64)
+    want = A.astype(np.float64) @ Yg[:, :ns]
+    out = torch.full((M, 128), 7.0, dtype=torch.float32, device=dev)
+    ops.gemv_cols(dA, M, K, dY, d_rows, ns, out)
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got[:, :ns], want, rtol=2e-7, atol=1e-5)
+    assert np.all(got[:, ns:] == 7.0)
+    sel = torch.tensor([3, 1, 3, -2, 3], dtype=torch.int32, device=dev)
+    out.fill_(7.0)
+    ops.gemv_cols(dA, M, K, dY, d_rows, ns, out, sel=sel, want=3)
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got[:, [0, 2, 4]], want[:, [0, 2, 4]], rtol=2e-7, atol=1e-5)
+    assert np.all(got[:, [1, 3]] == 7.0)
+    ops.gemv_cols(dA, M, K, dY, d_rows, ns, out, sel=sel, want=9)           # no column selected: nothing written
+    assert np.array_equal(out.cpu().numpy(), got)
+    out2 = torch.empty((M, 8), dtype=torch.float32, device=dev)
+    ops.gemv_cols(dA[:, :64], M, 64, dY, None, 8, out2)                        # no row list, a row stride beyond the depth
+    np.testing.assert_allclose(out2.cpu().numpy(), A[:, :64].astype(np.float64) @ Y[:64, :8].astype(np.float64), rtol=2e-7, atol=1e-5)
+    with pytest.raises(ValueError):
+        ops.gemv_cols(dA, M, K, dY, d_rows, 9, out)
+
+
 def test_precision_policy(lc):
     """'auto' takes the fp16x3 sweep on ordinary data and falls back to the f32 MFMA when a target column has
     an outlier far above its rms (the 22-bit split would lose the small values); both agree with 'f32'."""
@@ -1526,6 +1561,21 @@ def test_precision_policy(lc):
         for c in (5, 222):
             assert abs(got[0]["correlations"][c] - ref32[0]["correlations"][c]) < tol, (extra, c)
             np.testing.assert_allclose(got[1][:, c], ref32[1][:, c], rtol=1e-4, atol=1e-5 * float(np.abs(ref32[1][:, c]).max()))
+    # more side columns than the streamed products take (ops.GEMV_MAX_COLS): the side path's 128-column f32 MFMA tiles
+    Y4 = Y.copy()
+    wide = [3 + 29 * i for i in range(10)]
+    for i, c in enumerate(wide):
+        Y4[(7 * i) % 300, c] = 1e6 * (1 + i)
+    m4, W4, a4 = model16.fit_predict(X, Y4, **kw)
+    assert model16.last_fit["precision"] == "f16x3" and model16.last_fit["side_panel_cols"] == 10
+    m432, W432, a432 = lc.NestedCVModel("r", precision="f32").fit_predict(X, Y4, **kw)
+    clean4 = np.ones(Y.shape[1], dtype=bool)
+    clean4[wide] = False
+    assert np.array_equal(a4[clean4], a16[clean4]) and np.array_equal(W4[:, clean4], W16[:, clean4])
+    for c in wide:
+        assert a4[c] == a432[c], c
+        assert abs(m4["correlations"][c] - m432["correlations"][c]) < 1e-5
+        np.testing.assert_allclose(W4[:, c], W432[:, c], rtol=1e-4, atol=1e-5 * float(np.abs(W432[:, c]).max()))
     # more wide columns than the side panel takes (FitOptions.side_panel_max_cols): the whole fit on the f32 path, as before
     few = lc.NestedCVModel("r", precision="auto", options=ncv.FitOptions(side_panel_max_cols=1))
     few.fit_predict(X, Y2, **kw)

@@ -22,6 +22,8 @@ if G > 1:
     lo, hi = shard_bounds(V_total, G, rank)
     V = hi - lo
 dX, dY, p = bench.synth_inputs(V, rank, dev)
+if os.environ.get("FIT_SPIKE"):                          # one outlier-dominated column: the f32 side panel's path
+    dY[7, V // 2 + 123] = 1e6
 alphas = np.logspace(-1, 8, bench.A)
 shard = ShardContext.simulated(G, rank, device=dev, global_lists=False) if G > 1 else None
 model = NestedCVModel("ridge_regression", shard=shard)
