@@ -617,8 +617,9 @@ __global__ void __launch_bounds__(256, 2) k_mm64q(const MMArgs g) {
 //   (2) forms  L[i,k] = C Linv_kk'  (C goes through LDS as the A operand) and stores it, and
 //   (3) PRE-UPDATES its tile of the next column with everything that is already final:
 //           A[i,k+1] -= sum_{j = K0 .. k-1} L[i,j] L[k+1,j]'      (one product of depth 64 (k - K0), no RMW per 64),
-//       the j = k term being the one step (1) of the next launch adds -- except in row tile k+1 itself, whose own
-//       L[k+1,k] is at hand, so that the next diagonal tile is final when this launch ends.
+//       the j = k term being the one step (1) of the next launch adds -- except for the DIAGONAL tiles of the outer
+//       block, which every row tile keeps current step by step ((2'), round 5), so that the next diagonal tile is final
+//       one depth-64 product after L[k+1,k] and is factored in the same launch (4).
 // Same flops, one read-modify-write per tile and block column instead of one per 64 columns of depth, 38 instead of
 // ~170 workgroups per system and step.  The back substitution is restructured the same way (k_bstep: one launch per
 // step,  H[i,k] = (Z[i,k] - sum_{j > k} H[i,j] L[j,k]) Linv_kk ).
@@ -746,33 +747,40 @@ __global__ void __launch_bounds__(256, 3) k_lstep(double* __restrict__ aug, int 
         LC_FOR_TILE(i, j) if (LC_TILE_ROW(i) < a_rows) dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] = acc[i][j];
     }
     if (k + 1 >= K1) return;
-    // (3) pre-update of the tile in column k+1
-    const bool own = i_t == k + 1;                     // row tile k+1: its L[k+1,k] is the tile just formed
-    if (own) {
-        __syncthreads();                               // everyone has read sC as the A operand
+    const bool own = i_t == k + 1;                     // row tile k+1: the next diagonal tile is its own
+    // (2') round 5: every row tile INSIDE the outer block keeps its own diagonal tile current, step by step:
+    //          A[i,i] -= L[i,k] L[i,k]'           (both operands are the tile just formed)
+    // so that the next diagonal tile is final after ONE product of depth 64 -- before, the workgroup of row tile k+1 first
+    // ran the pre-update (3) of its column-(k+1) tile, which IS the diagonal tile, at depth 64 (k - K0): ~14 us on average
+    // on the path every step waits for (the chain of a rank's 3 systems is 30 such steps).  Same flops; the diagonal tiles
+    // are summed step by step instead of once per outer block.
+    double old[4][4];
+    if (i_t < K1) {
+        __syncthreads();                               // everyone has read sC as the A operand of (2)
         LC_FOR_TILE(i, j) sC[LC_TILE_ROW(i) * ST_LDC + LC_TILE_COL(j)] = acc[i][j];
-    }
-    if (!own && k == K0) return;                       // nothing final to apply yet
-    LC_FOR_TILE(i, j) acc[i][j] = 0.0;
-    if (k > K0)
-        tile_mac<true, false>(acc, Arow + K0 * NB, N, a_rows, Ab + (long long)(k + 1) * NB * N + K0 * NB, N, (k - K0) * NB, sA, sB);
-    if (own) {                                         // + L[k+1,k] L[k+1,k]': both operands are the tile in sC
+        LC_FOR_TILE(i, j) acc[i][j] = 0.0;
         __syncthreads();                               // tile_mac fetches B (= sC here) before its first barrier
         tile_mac<true, true>(acc, sC, 0, a_rows, sC, ST_LDC, NB, sA, sB);
+        double* dd = Arow + i_t * NB;
+        LC_FOR_TILE(i, j) old[i][j] = dd[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] - acc[i][j];
+        if (!own) LC_FOR_TILE(i, j) dd[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] = old[i][j];
     }
-    double* dst = Arow + (k + 1) * NB;
-    double old[4][4];
-    LC_FOR_TILE(i, j) old[i][j] = LC_TILE_ROW(i) < a_rows ? dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] : 0.0;
-    LC_FOR_TILE(i, j) old[i][j] -= acc[i][j];
-    LC_FOR_TILE(i, j) if (LC_TILE_ROW(i) < a_rows) dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] = old[i][j];
-    // (4) the workgroup of row tile k+1 has just completed the NEXT diagonal tile: it factors it right away (L, Linv:
-    // potrf_diag_tile on the values at hand, in the LDS of sC / sA) -- one launch per step instead of two, and the
-    // diagonal factorisation runs beside the other workgroups' tiles instead of after them
     if (own) {
+        // (4) the next diagonal tile is complete: factor it right away (L, Linv: potrf_diag_tile on the values at hand, in
+        // the LDS of sC / sA) -- one launch per step instead of two, beside the other workgroups' tiles
         __syncthreads();                               // sC was an operand of the product above
         LC_FOR_TILE(i, j) sC[LC_TILE_ROW(i) * PD_LD + LC_TILE_COL(j)] = old[i][j];
         potrf_diag_tile<true>(aug, N, M, k + 1, b, linv, info, sC, sA);
+        return;
     }
+    // (3) pre-update of the tile in column k+1 with everything that is final
+    if (k == K0) return;                               // nothing final to apply yet
+    LC_FOR_TILE(i, j) acc[i][j] = 0.0;
+    tile_mac<true, false>(acc, Arow + K0 * NB, N, a_rows, Ab + (long long)(k + 1) * NB * N + K0 * NB, N, (k - K0) * NB, sA, sB);
+    double* dst = Arow + (k + 1) * NB;
+    LC_FOR_TILE(i, j) old[i][j] = LC_TILE_ROW(i) < a_rows ? dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] : 0.0;
+    LC_FOR_TILE(i, j) old[i][j] -= acc[i][j];
+    LC_FOR_TILE(i, j) if (LC_TILE_ROW(i) < a_rows) dst[(long long)LC_TILE_ROW(i) * N + LC_TILE_COL(j)] = old[i][j];
 }
 
 // one 64-row tile of the bottom block, one step of the back substitution (see k_lstep's header)
