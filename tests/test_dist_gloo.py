@@ -130,6 +130,28 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     shard_l = ShardContext(global_lists=False)
     m3, W3, a3 = ncv.NestedCVModel("r", shard=shard_l).fit_predict(X, Y, **kw)
     m4, W4, a4 = ncv.NestedCVModel("r", shard=shard_l).fit_predict(X[:90], Y[:90], X_test=X[90:], y_test=Y[90:], **kw)
+    # ---- the story pipeline's share of a sharded job (harness.StoryPipeline, round 5): which columns of every story's brain
+    # array a rank stages -- views of its block [lo, hi) when it is handed all voxels; with local_targets the array it is
+    # handed IS its block and the job's voxel count comes from one all-reduce (trainer.py:235-257 z-scores per voxel)
+    from litcoder_core_amd.harness import StoryPipeline
+    rs = np.random.default_rng(5)
+    brain = {s: rs.standard_normal((n, 37)) for s, n in (("s1", 40), ("s2", 31), ("s3", 25))}
+    trim = dict(train_targets_start=3, train_targets_end=-2, test_targets_start=1, test_targets_end=None)
+    names = list(brain)
+    pipe = StoryPipeline([1, 2], trim, model=ncv.NestedCVModel("r", shard=shard))
+    assert pipe._voxel_block(brain, names) == (lo, hi, 37)
+    tg = pipe._targets(brain, names, [35, 26, 24], lo, hi)
+    assert tg.zscore and tg.shape == (85, hi - lo) and [r0 for r0, _ in tg.blocks] == [0, 35, 61]
+    assert all(np.shares_memory(b, brain[s]) for (_, b), s in zip(tg.blocks, names))            # views, no copies
+    assert np.array_equal(tg.blocks[1][1], brain["s2"][3:-2, lo:hi]) and np.array_equal(tg.blocks[2][1], brain["s3"][1:, lo:hi])
+    mine = {s: np.ascontiguousarray(b[:, lo:hi]) for s, b in brain.items()}
+    pipe_l = StoryPipeline([1, 2], trim, model=ncv.NestedCVModel("r", shard=shard, local_targets=True))
+    assert pipe_l._voxel_block(mine, names) == (0, hi - lo, 37)
+    try:
+        pipe._targets(brain, names, [35, 27, 24], lo, hi)
+        raise AssertionError("a row count that differs from the features' must be refused")
+    except RuntimeError:
+        pass
     out = dict(m=m, W=W, a=a, lo=lo, hi=hi, m2=m2, a2=a2, m3=m3, a3=a3, m4=m4, a4=a4)
     pickle.dump(out, open(os.path.join(sys.argv[3], f"rank{shard.rank}_{mode}.pkl"), "wb"))
     dist.destroy_process_group()
