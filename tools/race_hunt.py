@@ -2,7 +2,9 @@
 the first bit for bit -- per-fold r / p / alpha index of every voxel and the weights.  Any mismatch is printed with the
 fold, the quantity and the voxel columns (a race between streams shows up as a run-to-run difference).
 
-    python tools/race_hunt.py [reps] [voxels] [host]
+    python tools/race_hunt.py [reps] [voxels] [host | spike | cfg3]
+spike: one outlier-dominated target column (the f32 side panel's stream beside the fit, round 5); cfg3: the story pipeline
+host to host (StoryPipeline.fit_words: staging threads with z-scoring, voxel panels, the single-alpha guess).
 """
 import os
 import sys
@@ -18,9 +20,15 @@ import litcoder_core_amd.nested_cv as ncv  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 V = int(sys.argv[2]) if len(sys.argv) > 2 else 80000
-host_mode = len(sys.argv) > 3 and sys.argv[3] == "host"
+mode = sys.argv[3] if len(sys.argv) > 3 else "resident"
+host_mode = mode == "host"
 dev = ops.device(0)
 dX, dY, p = bench.synth_inputs(V, 0, dev)
+if mode == "spike":
+    dY[7, V // 2 + 123] = 1e6
+if mode == "cfg3":
+    from litcoder_core_amd import StoryPipeline
+    words, wtimes, trtimes, brain = bench.synth_stories(V, dev)
 alphas = np.logspace(-1, 8, bench.A)
 captured = []
 real = ncv.RidgeCVEngine.fold_collect
@@ -39,7 +47,9 @@ bad = 0
 for it in range(reps):
     captured.clear()
     model = NestedCVModel("r")
-    if host_mode:
+    if mode == "cfg3":
+        m, W, a = StoryPipeline([1, 2, 3, 4], bench.CFG3_TRIM, model=model).fit_words(words, wtimes, trtimes, brain, **bench.CFG3_KW)
+    elif host_mode:
         m, W, a = model.fit_predict(host[0], host[1], alphas=alphas, **bench.FIT_KW)
     else:
         m, W, a = model.fit_predict_device(dX, dY, p, V, weights_on_host=True, alphas=alphas, **bench.FIT_KW)
@@ -59,4 +69,5 @@ for it in range(reps):
     if dW.size:
         bad += 1
         print(f"rep {it} W: {dW.size} columns differ, first {dW[:8]}, last {dW[-3:]}", flush=True)
-print(f"{reps} repetitions, V={V}, {'host' if host_mode else 'resident'}: {bad} mismatching quantities", flush=True)
+print(f"{reps} repetitions, V={V}, {mode}: {bad} mismatching quantities" + (f"; side panel columns "
+      f"{model.last_fit.get('side_panel_cols')}" if mode == "spike" else ""), flush=True)
