@@ -31,9 +31,13 @@ class FitOptions:
     3 these were module-level constants that tests and tools assigned).  The defaults are the measured choices."""
     lanczos_steps: int = 64                 # Lanczos iterations for S[0]^2: <= 1e-11 relative on the cfg2 Grams (profiles/);
                                             # the reference's own S[0] is an fp32 SVD value (~1e-7)
-    lanczos_tol: float = 1e-6               # ... a system stops before that once its top Ritz value has moved by <= this
-                                            # (relative) over 8 steps: ~3e-8 left by the geometric convergence (round 5: 48
-                                            # instead of 64 steps on the LeBel-shaped Gram matrices, 56 at cfg2; 0 = never)
+    lanczos_tol: float = 0.0                # > 0: a system stops before that once its top Ritz value has moved by <= this
+                                            # (relative) over 8 steps.  OFF by default: a Lanczos run whose start vector is
+                                            # short of the top eigenvector sits on the SECOND eigenvalue for a while before
+                                            # it finds the first, and a stop on the Ritz value's movement (or on its
+                                            # residual) takes that plateau for convergence -- tools/fuzz_vs_oracle.py, seed
+                                            # 1234 / case 4: S[0] 60.10 instead of 60.27 for one training set at 1e-6, the
+                                            # weights 9e-4 off (profiles/r05_lanczos_stop_misfire.txt); 1.3 ms of cfg3's 136
     lanczos_dense: bool = True              # primal form: the streaming matvec for the p x p Gram blocks (lc_lambda_max_dense)
     aug_budget_bytes: int = 24 << 30        # cap on the batched (fold, alpha) fp64 systems resident at once
     series_tol: float = 2e-9                # an alpha takes the polynomial form when its worst relative error over the

@@ -1225,6 +1225,18 @@ def test_story_pipeline_pieces_bitwise(lc):
         want = np.nan_to_num(np.vstack([oh.zs(ofir.make_delayed(f, delays)[lo:hi]) for f, (lo, hi) in zip(feats, trims)]))
     got = dX.cpu().numpy()
     assert np.array_equal(got[:, :ndim * 4], want.astype(np.float32)) and not got[:, ndim * 4:].any()
+    # other delay sets: unsorted with a negative and a zero delay, one as long as the shortest story (that story's copy is
+    # all zeros: NaN -> 0 after zs), one delay alone -- the kernel with one thread per input column for all delays (round 5:
+    # up to 8 of them) -- and nine delays, which take the kernel with one thread per output column
+    for delays in ([3, -2, 0, 1], [1, 20, 2], [2], list(range(1, 10))):
+        nd = len(delays)
+        dX = torch.zeros((int(rows.sum()), ops.pad_to(ndim * nd, 32) + 32), dtype=torch.float32, device=dev)
+        ops.story_design(torch.from_numpy(np.concatenate(feats)).to(dev), off[:-1], n_in, a, b, row0, delays, dX)
+        with np.errstate(all="ignore"):
+            want = np.nan_to_num(np.vstack([oh.zs(ofir.make_delayed(f, delays)[lo:hi]) for f, (lo, hi) in zip(feats, trims)]))
+        got = dX.cpu().numpy()
+        assert np.array_equal(got[:, :ndim * nd], want.astype(np.float32)), delays
+        assert not got[:, ndim * nd:].any(), delays
 
 
 # ------------------------------------------------------------------ size-independent properties, larger sizes

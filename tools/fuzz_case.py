@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One case of tools/fuzz_vs_oracle.py again, with a float64 ground truth beside both fits: who is off, and by how much.
-    python tools/fuzz_case.py seed case [large | tall]"""
+    python tools/fuzz_case.py seed case [large | tall] [FitOptions field=value ...]"""
 import os
 import random
 import sys
@@ -52,7 +52,24 @@ random.seed(want); np.random.seed(want)
 detail = {}
 m_o, W_o, a_o = onc.fit_predict(*args, detail=detail, **extra, **kw_run)
 random.seed(want); np.random.seed(want)
-model = lc.NestedCVModel("r", precision=precision)
+if os.environ.get("FUZZ_TRACE_LMAX"):       # print every lambda_max the fit computes (S0 = its square root)
+    from litcoder_core_amd import ops as _ops
+    _real = _ops.lambda_max_masked
+
+    def _traced(*a, **k):
+        out = _real(*a, **k)
+        print("  lambda_max_masked tol", k.get("tol"), "-> S0", np.sqrt(out.cpu().numpy()))
+        return out
+    _ops.lambda_max_masked = _traced
+opt_kw = {}
+for item in sys.argv[3:]:
+    if "=" in item:
+        k_, v_ = item.split("=")
+        opt_kw[k_] = float(v_) if "." in v_ or "e" in v_ else int(v_)
+from litcoder_core_amd.engine.common import FitOptions  # noqa: E402
+model = lc.NestedCVModel("r", precision=precision, options=FitOptions(**opt_kw) if opt_kw else None)
+if opt_kw:
+    print("options", opt_kw)
 m, W, a = model.fit_predict(*args, **extra, **kw_run)
 if tt:                                       # train/test: one "fold" = all training rows, the oracle's alphas
     detail = dict(outer=[(np.arange(T - tt), None)], fold_alphas=[np.asarray(a_o, dtype=np.float64)])
