@@ -4,7 +4,7 @@ different processes or on different boxes): every arm is a set of FitOptions ove
 rounds, and the distribution per arm is printed (median, min, max) with the results' equality across arms.
 
     python tools/ab_fits.py <cfg2h|cfg2r|cfg3> <rounds> [<name>=<value>[,<name>=<value>...] | default] ...
-e.g. python tools/ab_fits.py cfg3 8 default lanczos_dense=0,lanczos_tol=0
+e.g. python tools/ab_fits.py cfg3 8 default lanczos_dense=0 lanczos_tol=1e-6
      cfg2h = the bench headline (host float64 arrays in, host weights out), cfg2r = resident inputs, cfg3 = the story pipeline
      AB_RANK=G,r (cfg2r): as simulated rank r of G (its AB_VOXELS / G voxels, its share of the V-independent systems)
 """

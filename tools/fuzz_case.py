@@ -44,6 +44,10 @@ for case in range(want + 1):
     X = rng.standard_normal((T, p)) * rng.uniform(0.5, 2.0, p)
     Y = X @ (rng.standard_normal((p, V)) * (signal / np.sqrt(p))) + rng.standard_normal((T, V)) + rng.uniform(-3, 3)
     precision = str(rng.choice(["auto", "auto", "f32"]))
+if "spikes" in sys.argv[3:]:
+    rs = np.random.default_rng(1000003 * seed + want)
+    for c in rs.choice(V, size=min(V, int(rs.integers(1, 4))), replace=False):
+        Y[int(rs.integers(0, T - tt)), int(c)] = float(rs.choice([-1.0, 1.0]) * 10.0 ** rs.uniform(4, 6))
 print(f"T{T} p{p} V{V} {fold} tt{tt} {precision}", {k: v for k, v in kw.items() if k != "groups"})
 args = (X[:T - tt], Y[:T - tt])
 extra = dict(X_test=X[T - tt:], y_test=Y[T - tt:]) if tt else {}

@@ -5,7 +5,10 @@ normalisers, scoring, single / per-voxel alpha, CV / train-test, precisions and 
 products) are drawn at random.     python tools/fuzz_vs_oracle.py [n_cases [seed [large]]]
 ``large``: T 500-1400, p up to 1536, V up to 5000 (several tiles of every kernel, ragged edges; ~10-20 s of oracle per case);
 ``tall``: T 1800-3400, p 256-640, V up to 3000: the primal form with shared series terms / sums over validation blocks
-(round 4)."""
+(round 4);
+a further word ``spikes`` (round 5): a few target columns get one entry 1e4 .. 1e6 times their scale from a generator of
+its own (the cases' streams stay what they are): the f32 side panel of the fp16x3 fits, the fit-wide f32 fallback where
+there is no side panel."""
 import os
 import random
 import sys
@@ -53,6 +56,10 @@ for case in range(n_cases):
     signal = 1.0 if not use_corr else float(rng.choice([0.3, 1.0]))
     X = rng.standard_normal((T, p)) * rng.uniform(0.5, 2.0, p)
     Y = X @ (rng.standard_normal((p, V)) * (signal / np.sqrt(p))) + rng.standard_normal((T, V)) + rng.uniform(-3, 3)
+    if "spikes" in sys.argv[3:]:
+        rs = np.random.default_rng(1000003 * seed + case)
+        for c in rs.choice(V, size=min(V, int(rs.integers(1, 4))), replace=False):
+            Y[int(rs.integers(0, T - tt)), int(c)] = float(rs.choice([-1.0, 1.0]) * 10.0 ** rs.uniform(4, 6))
     args = (X[:T - tt], Y[:T - tt])
     extra = dict(X_test=X[T - tt:], y_test=Y[T - tt:]) if tt else {}
     kw_run = {k: v for k, v in kw.items() if not (tt and k == "n_outer_folds")}
@@ -84,7 +91,7 @@ for case in range(n_cases):
                               corr_atol=2e-3 if r2 else 5e-5, gap_tol=4e-3 if r2 else 4e-6, **extra)
         key = model.last_form + ("/blocks" if model.last_fit.get("precision") == "f64 block products" else "")
         forms[key] = forms.get(key, 0) + 1
-        print("ok  ", tag, "->", key, flush=True)
+        print("ok  ", tag, "->", key, "side panel columns", model.last_fit.get("side_panel_cols"), flush=True)
     except Exception as e:                                   # noqa: BLE001
         fails += 1
         print("FAIL", tag, "\n     ", type(e).__name__, str(e)[:400], flush=True)

@@ -27,7 +27,7 @@ python3 $R/tools/gpu_kernel_bench.py sweep sweep16 stamps plain16 series lanczos
 python3 $R/tools/chol_ab.py > $O/chol_fused_ab.txt 2>&1
 python3 $R/tools/scaling_model.py cfg2 cfg4 cfg5 cfg3 > $O/scaling_model.json 2> $O/scaling_model.err
 python3 $R/tools/outlier_ab.py 8 > $O/outlier_ab.txt 2>&1
-python3 $R/tools/ab_fits.py cfg3 8 default lanczos_dense=0,lanczos_tol=0 > $O/ab_cfg3_lanczos.txt 2>&1
+python3 $R/tools/ab_fits.py cfg3 8 default lanczos_dense=0 lanczos_tol=1e-6 > $O/ab_cfg3_lanczos.txt 2>&1
 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_cfg3 -- python3 $R/tools/cfg3_fit_loop.py 3 > $O/cfg3_fits.txt 2>&1
 python3 $R/tools/queue_timeline.py $(find /tmp/p_cfg3 -name "*kernel_trace.csv" | head -1) 200 > $O/cfg3_queue_timeline.txt 2>&1
 python3 $R/tools/cfg3_probe.py 80000 h2d pipe fit > $O/cfg3_probe.txt 2>&1
