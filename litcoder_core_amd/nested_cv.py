@@ -507,7 +507,17 @@ class NestedCVModel(BasePredictivityModel):
                 logger.info("%s: the fit is repeated with the targets resident", why)
                 eng.finish_uploads()
                 torch.cuda.synchronize()
-                return run_(form, self.precision, _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
+                # (targets normalised fold by fold -- normalize_targets -- are looked at fold by fold as well: there is no
+                # decision up front and no side panel for them, the repeated fit takes the f32 path as a whole; and should
+                # a repeated "auto" fit meet a wide column after all, the f32 path is what is left)
+                retry = "f32" if normalize_targets else self.precision
+                try:
+                    return run_(form, retry, _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
+                except _WideTargets as again:
+                    eng = self._engine
+                    logger.info("%s: the fit is repeated on the f32 path", again)
+                    torch.cuda.synchronize()
+                    return run_(form, "f32", _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
 
         try:
             eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = run(self.form)

@@ -1589,6 +1589,16 @@ def test_precision_policy(lc):
         assert a4[c] == a432[c], c
         assert abs(m4["correlations"][c] - m432["correlations"][c]) < 1e-5
         np.testing.assert_allclose(W4[:, c], W432[:, c], rtol=1e-4, atol=1e-5 * float(np.abs(W432[:, c]).max()))
+    # targets normalised fold by fold (normalize_targets) have no side panel and no decision up front: a wide column is met
+    # in a fold, the fit is repeated on the f32 path as a whole -- and equals the f32 fit (round 5's fuzzing: the repeated
+    # fit had been left on "auto" and met the column again)
+    kwn = dict(kw, normalize_targets=True)
+    mn = lc.NestedCVModel("r", precision="auto")
+    gotn = mn.fit_predict(X, Y2, **kwn)
+    assert mn.last_fit["precision"] == "f32"
+    refn = lc.NestedCVModel("r", precision="f32").fit_predict(X, Y2, **kwn)
+    assert np.array_equal(gotn[2], refn[2]) and np.array_equal(gotn[1], refn[1])
+    assert gotn[0]["correlations"] == refn[0]["correlations"]
     # more wide columns than the side panel takes (FitOptions.side_panel_max_cols): the whole fit on the f32 path, as before
     few = lc.NestedCVModel("r", precision="auto", options=ncv.FitOptions(side_panel_max_cols=1))
     few.fit_predict(X, Y2, **kw)
