@@ -126,6 +126,7 @@ class Refit:
         over the ranks as (alpha, row slice) jobs -- with fewer alphas than ranks every system's augmented rows are
         cut into S slices (each job then factors K + a^2 I again, N^3/3 of the system's N^3/3 + 2 N^2 rows flops) --
         and all-gathered; every rank must be called with the same ``alphas_idx``."""
+        alphas_idx = list(alphas_idx)
         Gc, (rows, N_o) = len(alphas_idx), rhs.shape
         if self.spectral:
             d_al = ops.upload(np.asarray([self.alphas[a] for a in alphas_idx], dtype=np.float64), self.dev)
@@ -134,6 +135,21 @@ class Refit:
                                          [min(self._real_rows(tr_o), self.p)], cache_key=("refit", tr_o.data_ptr()))
             return H.view(Gc, rows, N_o), ops.zeros(max(Gc, 1), torch.int32, self.dev)
         a2_o = ops.penalties(lmax_o, 1, self.d_alphas, self.normalpha)              # (A,): grid F = 1
+        inv = [a for a in alphas_idx if self._refit_by_inverse([a])]
+        if inv and len(inv) < Gc:
+            # a grid on both sides of refit_inverse_min_alpha: every alpha takes the route IT qualifies for, whatever else
+            # is asked for in the same call -- an alpha's operator must not depend on which other alphas the voxels of a
+            # range, a panel plan or a voxel shard happen to need at the same moment (round 5's shard fuzzing: a sharded
+            # fit solved all factorised alphas ahead in one list, the unsharded one only those in use, and the lists fell
+            # on different sides of the threshold: last-bit differences between the two)
+            sol = [a for a in alphas_idx if a not in inv]
+            M_i, info_i = self._refit_chol(K, tr_o, lmax_o, rhs, inv)
+            M_s, info_s = self._refit_chol(K, tr_o, lmax_o, rhs, sol)
+            out = torch.empty((Gc, rows, N_o), dtype=torch.float32, device=self.dev)
+            for src, part in ((M_i, inv), (M_s, sol)):
+                for k, a in enumerate(part):
+                    out[alphas_idx.index(a)].copy_(src[k])
+            return out, self._join_flags([info_i, info_s])
         if self._refit_by_inverse(alphas_idx):
             eye = self._identity_rows(N_o)
 
@@ -486,6 +502,11 @@ class Refit:
             rows = rhss[0].shape[0]
             if any(st["tr_o"].shape[-1] != N_o for st in sts) or any(r.shape[0] != rows for r in rhss):
                 return
+            inv = [a for a in cho if self._refit_by_inverse([a])]
+            if inv and len(inv) < len(cho):
+                # (a grid on both sides of refit_inverse_min_alpha: the inverses of the alphas that qualify ahead; the
+                # others are solved when somebody has chosen them -- each alpha by its own route: _refit_chol)
+                cho = inv
             Gc, nF = len(cho), len(sts)
             a2s = [ops.penalties(st["lmax_o"], 1, self.d_alphas, self.normalpha) for st in sts]
             if self._refit_by_inverse(cho):
