@@ -78,6 +78,15 @@ for case in range(n_cases):
         m, W, a = model.fit_predict(*a_, **e_, **kw_run)
         out[case] = dict(tag=tag + f" spiked{spiked}", m=m, W=np.asarray(W), a=np.asarray(a), lo=lo, hi=hi, form=model.last_form,
                          prec=model.last_fit.get("precision"), side=model.last_fit.get("side_panel_cols"))
+        if shard is None and V >= 600:
+            # the unsharded fit once more with the OTHER panel plan of its host targets (none / 256-column panels): per-voxel
+            # results must not depend on the plan, bit for bit
+            random.seed(case); np.random.seed(case)
+            m2, W2, a2 = NestedCVModel("r", precision=precision, panel_cols=0 if panel_cols else 256).fit_predict(*args, **extra, **kw_run)
+            bad = [k for k, v in m.items() if not (np.array_equal(np.asarray(m2[k]), np.asarray(v), equal_nan=True)
+                                                  if isinstance(v, list) else (m2[k] == v or (m2[k] != m2[k] and v != v)))]
+            if bad or not np.array_equal(np.asarray(W2), np.asarray(W), equal_nan=True) or not np.array_equal(a2, a):
+                out[case]["plan"] = f"panel plans differ: metrics {bad[:4]}, weights {not np.array_equal(np.asarray(W2), np.asarray(W), equal_nan=True)}"
     except ValueError as e:
         out[case] = dict(tag=tag, err="ValueError: " + str(e)[:120], lo=lo, hi=hi)
 name = "single" if shard is None else f"w{world}_r{shard.rank}"
@@ -137,6 +146,8 @@ def main():
                     why.append(f"rank {r}: weights differ in columns {dw[:6].tolist()} ({dw.size} in all)")
                 if got["form"] != want["form"] or got["prec"] != want["prec"]:
                     why.append(f"rank {r}: {got['form']} / {got['prec']} vs {want['form']} / {want['prec']}")
+            if world == 2 and want.get("plan"):
+                why.append(want["plan"])
             if why:
                 fails += 1
                 print(f"FAIL world {world} {want['tag']}\n      " + "\n      ".join(why[:8]), flush=True)
