@@ -49,6 +49,10 @@ cases = {
     # (hence the same collectives) on every rank -- the flag is all-reduced before anybody acts on it (ADVICE r2); since
     # round 5 that column alone is recomputed in f32 by the rank that holds it
     "outlier": dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 5, 8), _spike=(7, 700)),
+    # factorised alphas on BOTH sides of FitOptions.refit_inverse_min_alpha (0.1): a sharded fit solves the refit systems of
+    # all of them ahead, an unsharded one those in use -- each alpha must take the route (explicit inverse / augmented
+    # solves) IT qualifies for, whatever its companions (round 5's shard fuzzing: the route was decided per list)
+    "straddle": dict(folding_type="kfold", n_outer_folds=2, n_inner_folds=2, alphas=[0.02, 0.06, 0.3, 2.0, 300.0]),
 }
 shard = None
 if backend != "none":
@@ -168,7 +172,7 @@ def test_two_real_engine_ranks_on_one_gpu_equal_the_unsharded_fit(runs):
         for r, out in enumerate(ranks):
             _same(out[key], want, out["lo"], out["hi"], (key, r))
             n += 1
-    assert n == 2 * 2 * 8
+    assert n == 2 * 2 * 9
     _stories_same(ranks, ref, [(0, 1300), (1300, 2600)])
 
 
