@@ -60,8 +60,11 @@ class FitOptions:
     refit_fused_pearson: bool = True        # test predictions reduced to Pearson r in the contraction's epilogue (fp16x3
                                             # path): never stored, lc_pearson_cols never reads them back (SURVEY K8 + K9)
     refit_by_inverse: bool = True           # refit operators through the explicit inverse + one fp16x3 product
-    refit_inverse_min_alpha: float = 0.1    # ... for alphas (in units of S[0]) from here on (0.05 until round 4: a fuzz case
-                                            # at alpha = 0.066 came out 5e-5 of max|W| off a float64 solve, 17x the solves' error)
+    refit_inverse_min_alpha: float = 0.2    # ... for alphas (in units of S[0]) from here on, decided alpha by alpha (0.05 until
+                                            # round 4: a fuzz case at alpha = 0.066 came out 5e-5 of max|W| off a float64
+                                            # solve; 0.1 until round 5: one at alpha = 0.1003 2.5e-5, against 7e-7 with that
+                                            # alpha on the solves and its neighbour 0.68 on the inverse -- the error is ~1 /
+                                            # alpha.  Alphas below it are solved when somebody has CHOSEN them, not ahead)
     refit_inverse_max_world: int = 4        # ... and up to this many voxel-shard ranks
     series_fused_moments: bool = True       # series terms reduced to moments in the contraction's epilogue (never stored)
     primal_moments_max_p: int = 16          # up to this many features the tall form scores from block products X'Y alone

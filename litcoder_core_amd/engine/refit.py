@@ -146,10 +146,14 @@ class Refit:
             M_i, info_i = self._refit_chol(K, tr_o, lmax_o, rhs, inv)
             M_s, info_s = self._refit_chol(K, tr_o, lmax_o, rhs, sol)
             out = torch.empty((Gc, rows, N_o), dtype=torch.float32, device=self.dev)
-            for src, part in ((M_i, inv), (M_s, sol)):
+            one = self.shard.world == 1                # (one rank: flag k belongs to alpha k of the call, fold_speculate)
+            info = torch.empty(Gc, dtype=torch.int32, device=self.dev) if one else None
+            for src, flags, part in ((M_i, info_i, inv), (M_s, info_s, sol)):
                 for k, a in enumerate(part):
                     out[alphas_idx.index(a)].copy_(src[k])
-            return out, self._join_flags([info_i, info_s])
+                    if one:
+                        info[alphas_idx.index(a):alphas_idx.index(a) + 1].copy_(flags[k:k + 1])
+            return out, (info if one else self._join_flags([info_i, info_s]))
         if self._refit_by_inverse(alphas_idx):
             eye = self._identity_rows(N_o)
 
@@ -198,7 +202,8 @@ class Refit:
         solves with every row of R (N^3/3 + 2 N^2 rows: 3.4x the fp64 work).  The operator goes through 22-bit fp16
         triples afterwards anyway (the V-wide contraction), but in the product R P the entries of P ~ 1/a^2 cancel
         down to ~ 1/(2 a S0): the relative error is ~ 2^-22 x 2 S0 / a = 2^-21 / alpha for alpha S[0] scaling -- taken
-        for alpha >= 0.1 (< 5e-6), on the fp16x3 path, with normalpha (S[0] known); the solves otherwise."""
+        for alpha >= FitOptions.refit_inverse_min_alpha (0.2: measured 2.5e-5 of max|W| at alpha = 0.1, 7e-7 at 0.68), on the
+        fp16x3 path, with normalpha (S[0] known); the solves otherwise.  Asked alpha by alpha: [a]."""
         # (voxel shards: every rank applies every inverse it needs itself -- the same products on every rank -- while
         # the row-sliced solves shrink with the ranks: measured per simulated rank 81.8 vs 84.2 ms at 2, 53.6 vs 53.8
         # at 4, 40.2 vs 39.0 ms at 8 ranks; so the solves from 8 ranks on)
@@ -471,8 +476,8 @@ class Refit:
     def refit_ahead_pays(self):
         """Forming the refit operators of EVERY factorised alpha of every fold before any alpha is chosen is cheap enough
         on one GPU when they come from explicit inverses (N^3 flops each) and the grid has only a few such alphas."""
-        return (bool(self.cho) and len(self.cho) <= 8 and not self.primal and self._refit_by_inverse(self.cho)
-                and self.speculation_pays())
+        return (bool(self.cho) and len(self.cho) <= 8 and not self.primal and self.speculation_pays()
+                and any(self._refit_by_inverse([a]) for a in self.cho))
 
     def speculation_pays(self):
         """Refit systems solved BEFORE the alpha choice cost N^3 fp64 flops each whether or not their alpha is chosen: at
@@ -579,6 +584,12 @@ class Refit:
         start once its first histogram is on the host."""
         st = st.get("base", st)                        # the fold's V-independent state (shared by its voxel ranges)
         todo = [a for a in alphas_idx if a in self.cho] if st.get("tr_o") is not None else []
+        if early:
+            # the first fold's systems for EVERY factorised alpha, before anybody has chosen: those that come from explicit
+            # inverses (N^3 flops each) -- an alpha below refit_inverse_min_alpha costs 3.4x that through the solves and is
+            # solved when somebody has chosen it (fold_select)
+            inv = [a for a in todo if self._refit_by_inverse([a])]
+            todo = inv if inv else todo
         if not todo or "spec" in st:                   # nothing to factor, or refit_ahead has covered the fold
             return
         if early and st.get("ids_ready") is not None:

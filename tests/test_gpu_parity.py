@@ -632,18 +632,20 @@ def test_refit_operators_by_inverse_match_the_solves(lc):
     """The refit operators  [Xtr' ; K[te,tr]] (K + a^2 I)^-1  through the explicit inverse and one fp16x3 product
     (lc_batch_chol_inverse, RidgeCVEngine._refit_by_inverse) against the augmented fp64 solves they replace: relative
     error within the stated bound 2^-21 / alpha (alpha in units of S[0]) plus the fp32 rounding of either route, down
-    to the smallest alpha the route is taken for; below it, raw alphas and the exact-f32 path keep the solves; whole
-    fits agree in alphas / scores / weights."""
+    to the smallest alpha the route is taken for (0.2 since round 5); below it, raw alphas and the exact-f32 path keep the
+    solves; a call on both sides of the threshold takes each alpha by its own route; whole fits agree in alphas / scores /
+    weights."""
     from litcoder_core_amd import nested_cv as ncv
     from litcoder_core_amd.nested_cv import RidgeCVEngine
     rng = np.random.default_rng(5)
     T, p, V = 700, 900, 96
     X = rng.standard_normal((T, p)) * np.linspace(1.0, 0.05, p)
     Y = X @ (rng.standard_normal((p, V)) * 0.05) + rng.standard_normal((T, V))
-    alphas = [0.02, 0.05, 0.1, 0.5, 2.0]
+    alphas = [0.02, 0.05, 0.2, 0.5, 2.0]
     tr, te = np.r_[0:520], np.r_[520:700]
     eng = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
     assert not eng._refit_by_inverse([0, 1]) and not eng._refit_by_inverse([1, 2]) and eng._refit_by_inverse([2, 3, 4])
+    assert eng.opt.refit_inverse_min_alpha == 0.2
     assert not RidgeCVEngine(X, Y, alphas, False, True, False, False)._refit_by_inverse([2])       # raw alphas
     assert not RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f32")._refit_by_inverse([2])
     N_o = ncv.ops.pad_to(len(tr), ncv.LC_NB)
@@ -661,6 +663,13 @@ def test_refit_operators_by_inverse_match_the_solves(lc):
     for i, al in enumerate(alphas[2:]):
         err = np.abs(a[i] - b[i]).max() / np.abs(b[i]).max()
         assert err < 2.0 ** -21 / al + 1e-6, (al, err)       # + the floor of a depth-N product of 22-bit operands
+    # a call on both sides of the threshold: every alpha by its OWN route, whatever else is asked for with it (round 5: the
+    # route had been decided for the list as a whole, so an alpha's operator depended on its companions) -- bit for bit
+    # the operators of the single-route calls, pivot flags in the call's order
+    M_mix, info_mix = eng._refit_chol(eng.K, tr_o, lmax_o, rhs, [3, 1, 2])
+    M_low, _ = eng._refit_chol(eng.K, tr_o, lmax_o, rhs, [1])
+    assert torch.equal(M_mix[0], M_inv[1]) and torch.equal(M_mix[2], M_inv[0]) and torch.equal(M_mix[1], M_low[0])
+    assert info_mix.numel() == 3 and not info_mix.cpu().numpy().any()
     kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=2, alphas=alphas[1:], normalpha=True)
     got = lc.NestedCVModel("r").fit_predict(X, Y, **kw)
     ref = lc.NestedCVModel("r", options=ncv.FitOptions(refit_by_inverse=False)).fit_predict(X, Y, **kw)
