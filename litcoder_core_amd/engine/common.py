@@ -60,11 +60,16 @@ class FitOptions:
     refit_fused_pearson: bool = True        # test predictions reduced to Pearson r in the contraction's epilogue (fp16x3
                                             # path): never stored, lc_pearson_cols never reads them back (SURVEY K8 + K9)
     refit_by_inverse: bool = True           # refit operators through the explicit inverse + one fp16x3 product
-    refit_inverse_min_alpha: float = 0.2    # ... for alphas (in units of S[0]) from here on, decided alpha by alpha (0.05 until
+    refit_inverse_min_alpha: float = 0.1    # ... for alphas (in units of S[0]) from here on, decided alpha by alpha (0.05 until
                                             # round 4: a fuzz case at alpha = 0.066 came out 5e-5 of max|W| off a float64
-                                            # solve; 0.1 until round 5: one at alpha = 0.1003 2.5e-5, against 7e-7 with that
-                                            # alpha on the solves and its neighbour 0.68 on the inverse -- the error is ~1 /
-                                            # alpha.  Alphas below it are solved when somebody has CHOSEN them, not ahead)
+                                            # solve; the error is ~2.5e-6 / alpha: 2.5e-5 at 0.1003, 1.7e-7 at 0.68, round 5.
+                                            # Raising it was tried: with many more operator rows than training samples --
+                                            # 7680 features -- the solves cost 7x the inverse, and the cfg5 shape, whose voxels
+                                            # do choose alpha = 0.1, went from 207 to 221 ms)
+    refit_ahead_min_alpha: float = 0.15     # ... and AHEAD of the alpha choice (first fold's speculation, the batch over all
+                                            # folds of host inputs / voxel shards) only from here on: smaller alphas are
+                                            # rarely chosen, and an operator nobody uses is wasted fp64 work (cfg2's grid
+                                            # starts at 0.1, which no voxel of the bench takes: 140.0 -> 137.6 ms host to host)
     refit_inverse_max_world: int = 4        # ... and up to this many voxel-shard ranks
     series_fused_moments: bool = True       # series terms reduced to moments in the contraction's epilogue (never stored)
     primal_moments_max_p: int = 16          # up to this many features the tall form scores from block products X'Y alone

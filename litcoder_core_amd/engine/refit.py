@@ -202,7 +202,7 @@ class Refit:
         solves with every row of R (N^3/3 + 2 N^2 rows: 3.4x the fp64 work).  The operator goes through 22-bit fp16
         triples afterwards anyway (the V-wide contraction), but in the product R P the entries of P ~ 1/a^2 cancel
         down to ~ 1/(2 a S0): the relative error is ~ 2^-22 x 2 S0 / a = 2^-21 / alpha for alpha S[0] scaling -- taken
-        for alpha >= FitOptions.refit_inverse_min_alpha (0.2: measured 2.5e-5 of max|W| at alpha = 0.1, 7e-7 at 0.68), on the
+        for alpha >= FitOptions.refit_inverse_min_alpha (0.1: measured 2.5e-5 of max|W| at alpha = 0.1, 1.7e-7 at 0.68), on the
         fp16x3 path, with normalpha (S[0] known); the solves otherwise.  Asked alpha by alpha: [a]."""
         # (voxel shards: every rank applies every inverse it needs itself -- the same products on every rank -- while
         # the row-sliced solves shrink with the ranks: measured per simulated rank 81.8 vs 84.2 ms at 2, 53.6 vs 53.8
@@ -477,7 +477,12 @@ class Refit:
         """Forming the refit operators of EVERY factorised alpha of every fold before any alpha is chosen is cheap enough
         on one GPU when they come from explicit inverses (N^3 flops each) and the grid has only a few such alphas."""
         return (bool(self.cho) and len(self.cho) <= 8 and not self.primal and self.speculation_pays()
-                and any(self._refit_by_inverse([a]) for a in self.cho))
+                and bool(self._ahead_alphas(self.cho)))
+
+    def _ahead_alphas(self, alphas_idx):
+        """Those of the listed alphas whose refit operators are formed BEFORE anybody has chosen them: explicit inverses
+        (cheap) of alphas that are likely to be used (FitOptions.refit_ahead_min_alpha)."""
+        return [a for a in alphas_idx if self._refit_by_inverse([a]) and self.alphas[a] >= self.opt.refit_ahead_min_alpha]
 
     def speculation_pays(self):
         """Refit systems solved BEFORE the alpha choice cost N^3 fp64 flops each whether or not their alpha is chosen: at
@@ -507,10 +512,10 @@ class Refit:
             rows = rhss[0].shape[0]
             if any(st["tr_o"].shape[-1] != N_o for st in sts) or any(r.shape[0] != rows for r in rhss):
                 return
-            inv = [a for a in cho if self._refit_by_inverse([a])]
+            inv = self._ahead_alphas(cho)
             if inv and len(inv) < len(cho):
-                # (a grid on both sides of refit_inverse_min_alpha: the inverses of the alphas that qualify ahead; the
-                # others are solved when somebody has chosen them -- each alpha by its own route: _refit_chol)
+                # (the inverses of the alphas that qualify, ahead; the others when somebody has chosen them -- each alpha by
+                # its own route: _refit_chol)
                 cho = inv
             Gc, nF = len(cho), len(sts)
             a2s = [ops.penalties(st["lmax_o"], 1, self.d_alphas, self.normalpha) for st in sts]
@@ -586,9 +591,9 @@ class Refit:
         todo = [a for a in alphas_idx if a in self.cho] if st.get("tr_o") is not None else []
         if early:
             # the first fold's systems for EVERY factorised alpha, before anybody has chosen: those that come from explicit
-            # inverses (N^3 flops each) -- an alpha below refit_inverse_min_alpha costs 3.4x that through the solves and is
-            # solved when somebody has chosen it (fold_select)
-            inv = [a for a in todo if self._refit_by_inverse([a])]
+            # inverses (N^3 flops each) and are likely to be used (refit_ahead_min_alpha); the others when somebody has
+            # chosen them (fold_select)
+            inv = self._ahead_alphas(todo)
             todo = inv if inv else todo
         if not todo or "spec" in st:                   # nothing to factor, or refit_ahead has covered the fold
             return

@@ -632,7 +632,7 @@ def test_refit_operators_by_inverse_match_the_solves(lc):
     """The refit operators  [Xtr' ; K[te,tr]] (K + a^2 I)^-1  through the explicit inverse and one fp16x3 product
     (lc_batch_chol_inverse, RidgeCVEngine._refit_by_inverse) against the augmented fp64 solves they replace: relative
     error within the stated bound 2^-21 / alpha (alpha in units of S[0]) plus the fp32 rounding of either route, down
-    to the smallest alpha the route is taken for (0.2 since round 5); below it, raw alphas and the exact-f32 path keep the
+    to the smallest alpha the route is taken for; below it, raw alphas and the exact-f32 path keep the
     solves; a call on both sides of the threshold takes each alpha by its own route; whole fits agree in alphas / scores /
     weights."""
     from litcoder_core_amd import nested_cv as ncv
@@ -641,11 +641,11 @@ def test_refit_operators_by_inverse_match_the_solves(lc):
     T, p, V = 700, 900, 96
     X = rng.standard_normal((T, p)) * np.linspace(1.0, 0.05, p)
     Y = X @ (rng.standard_normal((p, V)) * 0.05) + rng.standard_normal((T, V))
-    alphas = [0.02, 0.05, 0.2, 0.5, 2.0]
+    alphas = [0.02, 0.05, 0.1, 0.5, 2.0]
     tr, te = np.r_[0:520], np.r_[520:700]
     eng = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
     assert not eng._refit_by_inverse([0, 1]) and not eng._refit_by_inverse([1, 2]) and eng._refit_by_inverse([2, 3, 4])
-    assert eng.opt.refit_inverse_min_alpha == 0.2
+    assert eng.opt.refit_inverse_min_alpha == 0.1 and eng._ahead_alphas([0, 1, 2, 3, 4]) == [3, 4]
     assert not RidgeCVEngine(X, Y, alphas, False, True, False, False)._refit_by_inverse([2])       # raw alphas
     assert not RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f32")._refit_by_inverse([2])
     N_o = ncv.ops.pad_to(len(tr), ncv.LC_NB)

@@ -32,6 +32,13 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from litcoder_core_amd import NestedCVModel, ShardContext, ops, series  # noqa: E402
 from litcoder_core_amd.dist import shard_bounds  # noqa: E402
+from litcoder_core_amd.engine.common import FitOptions  # noqa: E402
+
+# A simulated rank computes with copies of ITS OWN operators where the other ranks' would be, so its voxels choose arbitrary
+# alphas -- the grid's smallest among them, which no voxel of these targets chooses in a real fit and which (below
+# FitOptions.refit_ahead_min_alpha) is formed only once chosen.  The simulated ranks therefore keep EVERY factorised alpha
+# ahead, as all fits did until round 5: an upper bound on what a real rank does.
+SIM_OPTIONS = dict(refit_ahead_min_alpha=0.0)
 
 CONFIGS = {
     "cfg2": dict(T=3000, F0=768, DELAYS=[1, 2, 3, 4], A=20, V_total=80000, weak=True),
@@ -68,7 +75,7 @@ def cfg3_model(V_total=80000):
         os.environ["LITCODER_AMD_UPLOAD_THREADS"] = str(max(2, min(24, cores // 2 // G)))
         for r in (range(G) if all_ranks else sorted({0, G - 1})):
             shard = ShardContext.simulated(G, r, device=dev, global_lists=False) if G > 1 else None
-            model = NestedCVModel("ridge_regression", shard=shard)
+            model = NestedCVModel("ridge_regression", shard=shard, options=FitOptions(**SIM_OPTIONS) if G > 1 else None)
             pipe = StoryPipeline([1, 2, 3, 4], bench.CFG3_TRIM, model=model)
 
             def fit():
@@ -120,7 +127,7 @@ for name in which:
             lo, hi = shard_bounds(V_total, G, r)
             dX, dY, p_ = bench.synth_inputs(hi - lo, r, dev, T=T, F0=c["F0"], DELAYS=c["DELAYS"])
             shard = ShardContext.simulated(G, r, device=dev, global_lists=False) if G > 1 else None
-            model = NestedCVModel("ridge_regression", shard=shard)
+            model = NestedCVModel("ridge_regression", shard=shard, options=FitOptions(**SIM_OPTIONS) if G > 1 else None)
             per_rank[r] = timed(lambda: model.fit_predict_device(dX, dY, p_, hi - lo, n_voxels_total=V_total, alphas=alphas,
                                                                  **bench.FIT_KW), 4)
             del dX, dY
@@ -145,7 +152,8 @@ for name in which:
         out["weak"] = {}
         for G in (2, 4, 8):
             dX, dY, p_ = bench.synth_inputs(V_total, 0, dev, T=T, F0=c["F0"], DELAYS=c["DELAYS"])
-            model = NestedCVModel("ridge_regression", shard=ShardContext.simulated(G, 0, device=dev, global_lists=False))
+            model = NestedCVModel("ridge_regression", shard=ShardContext.simulated(G, 0, device=dev, global_lists=False),
+                                  options=FitOptions(**SIM_OPTIONS))
             ms = timed(lambda: model.fit_predict_device(dX, dY, p_, V_total, n_voxels_total=V_total * G, alphas=alphas,
                                                         **bench.FIT_KW), 4)
             out["weak"][G] = {"ms_rank0_alone": round(ms, 1), "voxels_per_sec": round(V_total * G / (1e-3 * ms)),
