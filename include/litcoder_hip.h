@@ -416,7 +416,8 @@ int lc_batch_chol_inverse(double* d_aug, int B, int N, double* d_linv, float* d_
 /* The variants of lc_batch_chol_solve / lc_batch_chol_inverse as PER-CALL options (NULL = the defaults); the library
  * keeps no process-wide switches, so fits with different settings coexist in one process:
  *   outer_block  columns per outer block of the two-level blocking (a multiple of LC_NB; default 512)
- *   big_kernel   kernel of the deep updates: 2 = 4x4x4 fp64 MFMA (default), 1 = vector ALU, 0 = 16x16x4 fp64 MFMA
+ *   big_kernel   kernel of the deep updates: 2 = 4x4x4 fp64 MFMA (default: 128 x 128 tiles, 64 x 64 ones for small batches --
+ *                the same bits), 3 = the 64 x 64 tiles always, 4 = the 128 x 128 ones always, 1 = vector ALU, 0 = 16x16x4 fp64 MFMA
  *   fused_steps  1 (default) = fused left-looking 64-column steps, 0 = the first version's panel + update launches
  *   left_deep    1 = the deep updates left-looking too (measured: no gain), 0 (default) = right-looking
  *   persistent   bit 0 (default on): the steps of the back substitution inside an outer block as ONE launch (a row tile's

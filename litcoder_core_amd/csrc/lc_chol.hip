@@ -842,16 +842,49 @@ __global__ void __launch_bounds__(256, 3) k_bsteps(double* __restrict__ aug, int
         }
     }
 }
+// The deep updates of SMALL batches (round 5): C (rows x cols) -= A B' (BT) or A B per system in 64 x 64 tiles on tile_mac
+// -- the same MFMA, the same order of the sums over the depth as k_mm64q: the same bits -- for batches whose 128 x 128 tiles
+// do not fill the chip: a rank of 8 holds 3 systems of a fold's 20, its first deep update is ~300 tiles of 150 us each on
+// 256 CUs; in 64 x 64 tiles it is 1200 of ~30 us, three to a CU.
+template <bool BT>
+__global__ void __launch_bounds__(256, 3) k_mm64s(const MMArgs g) {
+    __shared__ double sA[NB * MM_LD], sB[NB * MM_LD];
+    const int r0 = blockIdx.y * NB, c0 = blockIdx.x * NB;
+    if (g.tri && g.row0 + r0 + NB - 1 < g.col0 + c0) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const double* A = g.a + (long long)blockIdx.z * g.a_sys + (long long)r0 * g.lda;
+    const double* B = g.b + (long long)blockIdx.z * g.b_sys + (BT ? (long long)c0 * g.ldb : (long long)c0);
+    const int a_rows = min(NB, g.rows - r0);
+    double acc[4][4];
+    LC_FOR_TILE(i, j) acc[i][j] = 0.0;
+    tile_mac<BT, false>(acc, A, g.lda, a_rows, B, g.ldb, g.depth, sA, sB);
+    double* C = g.c + (long long)blockIdx.z * g.c_sys + (long long)r0 * g.ldc + c0;
+    double old[4][4];
+    LC_FOR_TILE(i, j) old[i][j] = (g.subtract && LC_TILE_ROW(i) < a_rows) ? C[(long long)LC_TILE_ROW(i) * g.ldc + LC_TILE_COL(j)] : 0.0;
+    LC_FOR_TILE(i, j) if (LC_TILE_ROW(i) < a_rows)
+        C[(long long)LC_TILE_ROW(i) * g.ldc + LC_TILE_COL(j)] = g.subtract ? old[i][j] - acc[i][j] : acc[i][j];
+}
 #undef LC_TILE_ROW
 #undef LC_TILE_COL
 #undef LC_FOR_TILE
 
-// deep updates: big_kernel 2 = 4x4x4 MFMA (k_mm64q, the default), 1 = vector ALU (k_mm64v), 0 = 16x16x4 MFMA (k_mm64<4>)
+// deep updates: big_kernel 2 = 4x4x4 MFMA (k_mm64q, the default; k_mm64s -- the same bits -- while the batch has fewer than
+// MM_SMALL_BELOW 128 x 128 tiles: measured -9 .. -12 % of a whole solve from 1 to 20 systems of 1920, -5 % at 40, equal at
+// 80: tools/chol_small_tiles.py), 3 = k_mm64s always, 4 = k_mm64q always, 1 = vector ALU (k_mm64v), 0 = 16x16x4 MFMA (k_mm64<4>)
+constexpr long long MM_SMALL_BELOW = 4096;
 template <bool BT>
-void launch_big(const MMArgs& g, int B, hipStream_t s, int big_kernel) {
+void launch_big(const MMArgs& g, int B, hipStream_t s, int big_kernel, long long small_tiles_below = 0) {
     if (g.rows <= 0 || g.cols <= 0) return;
     const dim3 grid((unsigned)lc::ceil_div(g.cols, 128), (unsigned)lc::ceil_div(g.rows, 128), (unsigned)B);
-    if (big_kernel == 2) {                           // LDS attribute: set (and checked) by lc_batch_chol_solve
+    // small batches: 64 x 64 tiles (k_mm64s: same bits) while the 128 x 128 ones would not fill the chip twice over
+    const long long tiles128 = (long long)grid.x * grid.y * grid.z / (g.tri ? 2 : 1);
+    if ((big_kernel == 2 && tiles128 < small_tiles_below && g.cols % NB == 0) || big_kernel == 3) {
+        hipLaunchKernelGGL((k_mm64s<BT>), dim3((unsigned)lc::ceil_div(g.cols, NB), (unsigned)lc::ceil_div(g.rows, NB), (unsigned)B),
+                           dim3(256), 0, s, g);
+        return;
+    }
+    if (big_kernel == 2 || big_kernel == 4) {        // LDS attribute: set (and checked) by lc_batch_chol_solve
         hipLaunchKernelGGL((k_mm64q<BT>), grid, dim3(256), MQ_LDS_BYTES, s, g);
     } else if (big_kernel == 1) {
         hipLaunchKernelGGL((k_mm64v<BT>), grid, dim3(256), 0, s, g);
@@ -919,8 +952,8 @@ extern "C" int lc_batch_chol_inverse(double* d_aug, int B, int N, double* d_linv
 static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,
                            int32_t* d_info, lc_stream_t stream, bool inverse, const lc_chol_options* opt) {
     const lc_chol_options o = opt ? *opt : chol_defaults();
-    LC_REQUIRE(o.outer_block > 0 && o.outer_block % NB == 0 && o.big_kernel >= 0 && o.big_kernel <= 2, LC_E_SHAPE,
-               "lc_batch_chol_solve: options: outer_block must be a multiple of %d, big_kernel in 0..2", NB);
+    LC_REQUIRE(o.outer_block > 0 && o.outer_block % NB == 0 && o.big_kernel >= 0 && o.big_kernel <= 4, LC_E_SHAPE,
+               "lc_batch_chol_solve: options: outer_block must be a multiple of %d, big_kernel in 0..4", NB);
     LC_REQUIRE(d_aug && d_linv && d_h && d_info, LC_E_BADARG, "lc_batch_chol_solve: null pointer");
     LC_REQUIRE(B > 0 && B <= 65535 && N > 0 && N % LC_NB == 0 && M > 0 && M % LC_MB == 0, LC_E_SHAPE,
                "lc_batch_chol_solve: need N %% %d == 0, M %% %d == 0, B <= 65535", LC_NB, LC_MB);
@@ -951,7 +984,7 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
             g.c = d_aug + (long long)c0 * N + c0;
             g.rows = R - c0; g.cols = (K1 - K0) * NB; g.depth = c0;
             g.row0 = g.col0 = c0; g.tri = 1; g.subtract = 1;
-            launch_big<true>(g, B, s, o.big_kernel);
+            launch_big<true>(g, B, s, o.big_kernel, MM_SMALL_BELOW);
         }
         for (int k = K0; k < K1; ++k) {
             // fused steps: only the first diagonal tile of an outer block (completed by the deep update) needs a launch
@@ -993,7 +1026,7 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
         g.rows = inverse ? (N - c1) + min(M, c1) : R - c1;   // inverse: bottom rows beyond c1 are still zero in this block
         g.cols = N - c1; g.depth = (K1 - K0) * NB;
         g.row0 = g.col0 = c1; g.tri = 1; g.subtract = 1;
-        launch_big<true>(g, B, s, o.big_kernel);
+        launch_big<true>(g, B, s, o.big_kernel, MM_SMALL_BELOW);
     }
     if (int rc = lc::launched("cholesky sweep")) return rc;
     // H L = Z from the last block column to the first:  H_k = Z_k Linv_kk,  Z_j -= H_k L_kj (j < k)
@@ -1009,7 +1042,7 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
             g.ldb = N;
             g.rows = M; g.cols = (K1 - K0) * NB; g.depth = (nb - K1) * NB;
             g.row0 = g.col0 = 0; g.tri = 0; g.subtract = 1;
-            launch_big<false>(g, B, s, o.big_kernel);
+            launch_big<false>(g, B, s, o.big_kernel, MM_SMALL_BELOW);
         }
         if (fused && (o.persistent & 1)) {
             // every step of the outer block in one launch (k_bsteps); inverse: row tiles 0 .. K1-1 at most
@@ -1048,7 +1081,7 @@ static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, f
         g.rows = inverse ? min(M, K0 * NB) : M;              // inverse: block columns < K0 need row tiles < K0 only
         g.cols = K0 * NB; g.depth = (K1 - K0) * NB;
         g.tri = 0; g.subtract = 1;
-        launch_big<false>(g, B, s, o.big_kernel);
+        launch_big<false>(g, B, s, o.big_kernel, MM_SMALL_BELOW);
     }
     if (int rc = lc::launched("back substitution")) return rc;
     if (inverse) hipLaunchKernelGGL(k_extract_sym, dim3(N, B), dim3(256), 0, s, d_aug, N, d_h, d_slot);
