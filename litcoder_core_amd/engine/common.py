@@ -92,6 +92,9 @@ class FitOptions:
     tail_folds: int = 2                     # ... spread over this many folds, voxel-major (plan_steps)
     series_lookahead: bool = True           # the next step's first sweep part queued before a step's fused sweeps (driver)
     resident_refit_batch: bool = True       # resident inputs: refit inverses of folds 1.. as one batch after fold 0's choice
+    folds_in_one_launch_tiles: int = 512    # all inner folds of a step in ONE launch per pass while a fold's launch has fewer
+                                            # 256 x 256 tiles than this (narrow voxel ranges: partial rounds of workgroups; measured -2.8 %
+                                            # at 10 000 voxels, -0.5 % at 20 000 on one GPU, +1.7 % for a rank of 4 at 20 000); 0: never
     alpha_progress_log: bool = dataclasses.field(       # per-alpha progress lines (ridge_regression.py:136-139): a device
         default_factory=lambda: os.environ.get("LITCODER_AMD_ALPHA_LOG", "0") == "1")   # round trip per fold, opt-in
     chol_outer_block: int = 512             # lc_batch_chol_solve: columns per outer block of the two-level blocking

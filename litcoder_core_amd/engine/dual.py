@@ -279,6 +279,16 @@ class DualSweeps:
         img_of = {f0 + j: (im, j) for (f0, fc, _, _), im in zip(hat["Hs"], imgs) if im is not None for j in range(fc)}
         fused = False
         Pt = rs_p = part_s = Tbuf = cs_inv = rowmap = slab_light = Tm = None
+        # (round 5) narrow ranges -- a rank's 10 000 voxels of an 8-GPU job, the first panels of host targets -- are 1.25 rounds
+        # of workgroups per inner fold and launch: ALL inner folds of the step in one launch each (lc_*_f16x3_folds: the
+        # folds' stacked operator images against the one target image, every fold skipping its own block) fill the chip
+        # instead of ending every fold in a partial round.  The same kernel, the same fold order of the fp32 adds: the same
+        # bits.  Needs the shared target image and all folds' images in one stack; wide ranges keep the launch per fold
+        # (measured slower merged at 80 000 voxels: profiles/experiments/README.md)
+        one_launch = bool(moments and split and shared is not None and len(hat["Hs"]) == 1 and imgs[0] is not None
+                          and imgs[0].get("Pt") is not None and (Ad == 0 or imgs[0].get("Ht") is not None)
+                          and 1 < F <= 64 and self.opt.folds_in_one_launch_tiles > 0
+                          and ((max(Ad, 1) * M + 255) // 256) * (Vt // 256) < self.opt.folds_in_one_launch_tiles)
 
         def series_part():
             nonlocal fused, Pt, rs_p, part_s, Tbuf, cs_inv, rowmap, slab_light, Tm
@@ -300,6 +310,14 @@ class DualSweeps:
                 for f0 in range(0, F, 64):
                     f1 = min(F, f0 + 64)
                     ops.val_stats_folds(Y, Vp_, va[f0:f1], f1 - f0, M, n_v[f0:f1], ystat[f0:f1], yblk[f0:f1], yv[f0:f1])
+                if one_launch and fused:
+                    im = imgs[0]
+                    part_f = torch.empty((F, M // LC_MB, 18, Vp_), dtype=torch.float32, device=self.dev)
+                    self.info["plain_flops"] += sum(2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * V_ for f in range(F))
+                    self.info["plain_launches"] += 1
+                    ops.series_sweep_scores_f16x3_folds(im["Pt"], im["rs_p"], M, n_v, N, Yt[0], cs_inv, Vt, yv, Vp_, ystat, yblk,
+                                                        self.d_coef, hat["d_ser"], part_f, scores, False, views)
+                    return
                 for f, j, H, P in folds:
                     if shared is None:
                         ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[f])
@@ -328,7 +346,15 @@ class DualSweeps:
             # few dozen workgroups per launch); its scores are written over the main path's before any alpha is chosen
             side_job = self._side_sweeps_begin(hat, rg_) if (self.side is not None and split) else None
             # ---- pass 2 (the only one without the moment path): fused sweeps of the alphas that have hat matrices
-            for f, j, H, P in folds:
+            if one_launch and fused and Ad:
+                im = imgs[0]
+                part_f = torch.empty((F, Ad * M // LC_MB, 4, Vp_), dtype=torch.float32, device=self.dev)
+                self.info["fused_flops"] += sum(2.0 * Ad * n_v[f] * hat["n_i"][f] * V_ for f in range(F))
+                self.info["fused_launches"] += 1
+                self.info["folds_per_launch"] = F
+                ops.alpha_sweep_scores_f16x3_folds(im["Ht"], im["rs_h"], Ad, M, N, Yt[0], cs[Vp_:], yv, Vp_, n_v, ystat, yblk,
+                                                   self.mode, part_f, scores_d, False, views)
+            for f, j, H, P in (() if (one_launch and fused) else folds):
                 b = f if moments else 0
                 if not moments:
                     ops.val_stats(Y, Vp_, va[f], M, n_v[f], ystat[b], yblk[b], yv[b])
