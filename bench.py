@@ -13,6 +13,9 @@ latency).  `value` = voxels of all ranks x steps / max-over-ranks wall time.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--voxels V] [--scaling weak|strong] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With N > 1 and no launcher around it (WORLD_SIZE unset) the process starts its N ranks itself (launch_ranks: N child
+processes, one GPU each, 127.0.0.1 rendezvous), relays rank 0's line and exits with the worst rank's return code.
+
 Scaling: "weak" (default) = every rank fits `--voxels` voxels; "strong" = `--voxels` voxels IN TOTAL,
 split over the ranks (north_star's 80 000-voxel job on 1/2/4/8 GPUs).  At N > 1 the line carries both:
 the headline `value` in the chosen mode and the other mode under `other_scaling`.
@@ -162,10 +165,21 @@ def measured_traffic(voxels, per_pass_timeout=240):
                 return None, f"not measured: the {counter} pass exited with code {rc}"
             rows = []
             per_dispatch = {}
-            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            paths = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            # the fused score launches: with the screening pass on (round 6) those are the HI2 instantiation's (the few
+            # three-MFMA launches of the undecided voxels' panel are another kernel: not mixed into the averages)
+            names = {}
+            for path in paths:
                 with open(path) as f:
                     for row in csv.DictReader(f):
-                        if "k_sweep_f16x3<true" not in row.get("Kernel_Name", ""):
+                        nm = row.get("Kernel_Name", "")
+                        if "k_sweep_f16x3<true" in nm:
+                            names[nm] = names.get(nm, 0) + 1
+            wanted = max(names, key=names.get) if names else None
+            for path in paths:
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if wanted is None or row.get("Kernel_Name", "") != wanted:
                             continue
                         if row.get("Counter_Name") == counter:
                             rows.append((int(row["Grid_Size"]), float(row["Counter_Value"])))
@@ -480,9 +494,13 @@ def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, 
     if collect_kernels:
         kern = ops.timing_read()
         ops.timing_enable(False)
+    flops["rank_seconds"] = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        cdev = dev if torch.distributed.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)                # every rank's own clock around the same K steps
+        flops["rank_seconds"] = [float(x.item()) for x in every]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, out, kern, flops
@@ -534,12 +552,18 @@ def sweep_roofline(sweep, kern, flops, steps, split):
     stream) and the algorithmic flops the engine counted for them."""
     ms, launches = kern.get("alpha_sweep_gemm", (0.0, 0))
     alg_tflops = flops["fused"] / (ms * 1e-3) / 1e12 if launches and ms > 0 else None
-    mfma_per_product = 3 if split else 1
+    screened = bool(split and sweep.get("screen_terms", 3) == 1)
+    mfma_per_product = (1 if screened else 3) if split else 1
     peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     issued = alg_tflops * mfma_per_product if alg_tflops else None
     return {"bound": "mfma",
-            "kernel": "k_sweep_f16x3 (fused alpha sweep, 3 fp16 MFMAs per product)" if split
+            "kernel": ("k_sweep_f16x3<score, HI2> (fused alpha sweep of the inner CV's SCREENING pass: 1 fp16 MFMA per product; "
+                       "the undecided voxels' three-MFMA launches are inside the same timer, their flops are not counted)"
+                       if screened else "k_sweep_f16x3 (fused alpha sweep, 3 fp16 MFMAs per product)") if split
                       else "k_gemm_f32<score> (fused alpha sweep, f32-input MFMA)",
+            "screening": ({"undecided_voxel_folds": sweep.get("undecided"), "screened_voxel_folds": sweep.get("screened"),
+                           "undecided_frac": (sweep.get("undecided", 0) / max(sweep.get("screened", 0), 1)),
+                           "overflows": sweep.get("screen_overflows", 0)} if screened else None),
             "achieved": alg_tflops, "peak": peak, "unit": "TFLOP/s", "frac": (alg_tflops / peak) if alg_tflops else None,
             "mfma_per_product": mfma_per_product, "mfma_issue_tflops": issued,
             "mfma_issue_frac": (issued / peak) if issued else None,
@@ -547,6 +571,50 @@ def sweep_roofline(sweep, kern, flops, steps, split):
             "flops_per_step": flops["fused"] / max(steps, 1), "launches_per_step": launches / max(steps, 1),
             "avg_launch_ms": ms / max(launches, 1), "launches": launches,
             "fused_alphas_per_launch": sweep.get("fused_alphas"), "inner_folds_per_launch": sweep.get("folds_per_launch", 1)}
+
+
+def launch_ranks(n, argv):
+    """`python3 bench.py --gpus N` by itself (no launcher around it): this process -- which never touches the GPU -- starts N
+    fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, one GPU each),
+    relays rank 0's JSON line and exits with the worst rank's return code.  No exec of anything: the ranks are children."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:                               # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True,
+                                      start_new_session=True))
+
+    def stop(*_):
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)          # exactly the groups started here
+                except OSError:
+                    pass
+    signal.signal(signal.SIGTERM, lambda *a: (stop(), sys.exit(143)))
+    try:
+        out, _ = procs[0].communicate()
+        rcs = [procs[0].returncode]
+        for q in procs[1:]:
+            try:
+                rcs.append(q.wait(timeout=120))               # (a rank that outlives rank 0 by two minutes hangs)
+            except subprocess.TimeoutExpired:
+                rcs.append(124)
+    finally:
+        stop()
+    sys.stdout.write(out or "")
+    sys.stdout.flush()
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst:
+        print(f"bench.py: rank return codes {rcs}", file=sys.stderr)
+    return worst
 
 
 def main():
@@ -568,6 +636,10 @@ def main():
                     help="arithmetic of the alpha sweep (auto = f16x3 unless the targets' dynamic range forbids it)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the bare `python3 bench.py --gpus N` form: this process becomes the launcher of its N ranks (it has not touched,
+        # and never touches, the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.scaling is None:
@@ -576,7 +648,7 @@ def main():
         args.scaling = "weak" if world == 1 else "strong" 
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus disagree")
     # LITCODER_BENCH_ONE_GPU=1 (smoke test of the N > 1 code path on a single-GPU box): every rank on device 0, gloo
     # instead of RCCL (which refuses two ranks on one device); the numbers of such a run mean nothing
     one_gpu = os.environ.get("LITCODER_BENCH_ONE_GPU", "0") == "1"
@@ -703,8 +775,14 @@ def main():
             "value": V_total * args.steps / elapsed, "unit": "voxels/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "ms_per_step_distribution": step_stats(flops["step_ms"], V_total),
+            "ms_per_step_by_rank": [1e3 * t / args.steps for t in flops["rank_seconds"]],
+            "rccl_ranks": (torch.distributed.get_world_size() if world > 1 else 1),
+            "collective_backend": (torch.distributed.get_backend() if world > 1 else None),
             "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f16x3+f32acc (fp16 hi+lo operands, fp32 accumulate; Gram/Cholesky in f64)" if split
+            "dtype": ("f16x3+f32acc (fp16 hi+lo operands, fp32 accumulate; Gram/Cholesky in f64)"
+                      + ("; inner-CV scores screened on fp16 hi operands, the undecided voxels re-scored on hi+lo: the fit "
+                         "equals the all-hi+lo fit (unscreened_path.same_alphas_as_headline_fit)"
+                         if sweep.get("screen_terms", 3) == 1 else "")) if split
                      else "f32 (Gram/Cholesky in f64)", "data": "synthetic",
             "config": {"workload": f"cfg2 synthetic T={T} F={F0}x{len(DELAYS)} delays (p={p}) "
                                    + (f"V={args.voxels}/GPU" if args.scaling == "weak"
@@ -740,6 +818,22 @@ def main():
                                                      "object's avg_launch_ms)"),
                                     "note": "the same dominant kernel in launches of all 80 000 voxels (the headline's steps cut "
                                             "the first fold and the last two into voxel panels: launches of 12 288-80 000 columns)"}
+            if split and sweep.get("screen_terms", 3) == 1:
+                # the same resident fit with every inner-CV product on three fp16 MFMAs (FitOptions.screen_inner off: rounds
+                # 2-5's arithmetic throughout) -- what the screening pass buys, in the same run on the same box
+                from litcoder_core_amd.engine.common import FitOptions
+                m3 = NestedCVModel("ridge_regression", precision=args.precision, options=FitOptions(screen_inner=False))
+                e3, r3, k3, f3 = timed_fits(m3, dX, dY, p, V, V_total, alphas, 3, 1, 1, dev, collect_kernels="sweep")
+                out["unscreened_path"] = {
+                    "value": V * 3 / e3, "unit": "voxels/sec", "ms_per_step": 1e3 * e3 / 3, "steps": 3,
+                    "what": "resident fit, inner CV on three fp16 MFMAs per product for every voxel (no screening pass)",
+                    "roofline": {k: v for k, v in sweep_roofline(dict(m3.last_fit), k3, f3, 3, True).items()
+                                 if k in ("kernel", "achieved", "peak", "unit", "frac", "mfma_per_product", "mfma_issue_frac",
+                                          "avg_launch_ms", "launches_per_step")},
+                    "same_alphas_as_headline_fit": bool(np.array_equal(np.asarray(r3[2].cpu() if torch.is_tensor(r3[2]) else r3[2]),
+                                                                       np.asarray(r_res[2].cpu() if torch.is_tensor(r_res[2]) else r_res[2]))),
+                    "max_abs_weight_difference_to_resident_fit": float((r3[1] - r_res[1]).abs().max())
+                    if torch.is_tensor(r3[1]) else float(np.abs(np.asarray(r3[1]) - np.asarray(r_res[1])).max())}
             if args.precision != "f32":
                 m32 = NestedCVModel("ridge_regression", precision="f32")
                 e32, r32, k32, f32 = timed_fits(m32, dX, dY, p, V, V_total, alphas, 2, 1, 1, dev, collect_kernels="sweep")

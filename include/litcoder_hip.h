@@ -575,12 +575,6 @@ int lc_permute_cols_f16(const void* d_tiled, const int32_t* d_perm, int64_t Vs, 
  * (the validation block of an inner fold).  b_rows = rows of the image (0: the image is exactly the K rows),
  * b_gap_begin / b_gap_rows = first row and length of the skipped block in image rows; all multiples of 16, and
  * K + b_gap_rows <= b_rows. */
-int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
-                                const void* d_yt, const float* d_cscale_inv,
-                                const float* d_yv, int64_t V, int n_val,
-                                const float* d_ystat, const float* d_yblk,
-                                int mode, float* d_part, float* d_scores, int accumulate,
-                                int64_t b_rows, int64_t b_gap_begin, int64_t b_gap_rows, lc_stream_t stream);
 
 /* Correlation scores (mode LC_SCORE_CORR, same formula and nan_to_num as lc_alpha_sweep_scores) of S series
  * alphas of ONE inner fold from d_t (terms*M, ldt) f32 = the stacked T_j = P'_j Y (lc_batch_series_terms +
@@ -602,32 +596,52 @@ int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val,
  * 18, V) f32 workspace), from which the scores of the S series alphas follow as in lc_series_scores (same formula:
  * ridge_regression.py:124-133 for pred = sum_j c_j T_j).  d_yt / d_cscale_inv / Ncols / b_*: the tiled target image as
  * in lc_gemm_grouped_f16x3;  d_yv, d_ystat, d_yblk: lc_val_stats of the fold;  d_scores: (A, V) f32, V %% 128 == 0. */
-int lc_series_sweep_scores_f16x3(const void* d_pt, const float* d_rowscale_inv, int M, int n_val, int64_t K,
-                                 const void* d_yt, const float* d_cscale_inv, int64_t Ncols,
-                                 const float* d_yv, int64_t V, const float* d_ystat, const float* d_yblk,
-                                 const double* d_coef, const int32_t* d_aidx, int S, float* d_part,
-                                 float* d_scores, int accumulate, int64_t b_rows, int64_t b_gap_begin,
-                                 int64_t b_gap_rows, lc_stream_t stream);
 
-/* Both contractions for F (<= 64) inner folds of an outer fold in ONE launch each: the folds' tiled A images (and row
+
+/* The entry points of the two contractions above, for F (1 <= F <= 64) inner folds of an outer fold in ONE launch each
+ * (round 6: the single-fold forms lc_alpha_sweep_scores_f16x3 / lc_series_sweep_scores_f16x3 are gone -- F = 1 is that
+ * call): the folds' tiled A images (and row
  * scales) are stacked, every fold padded to whole 256-row tiles; d_yv / d_ystat / d_yblk / d_part are (F, ...) stacks
  * (lc_val_stats_folds); all folds contract the same tiled target image d_yt, fold f skipping its own gap
  * (h_gap_begin[f], h_gap_rows[f]; b_rows = 0: no gap).  Scores of the folds are added in fp32, fold order
  * (nested_cv.py:373-380).  The folds are independent: one launch fills the chip where F small ones each end in a
- * partial round of workgroups (a rank of an 8-GPU job holds 10 000 voxels: 1.25 rounds per fold). */
+ * partial round of workgroups (a rank of an 8-GPU job holds 10 000 voxels: 1.25 rounds per fold).
+ * terms: 3 = every product as hi*hi + hi*lo + lo*hi (22-bit operands: fp32-level scores, what ridge_corr_torch's fp32
+ * matmuls give, ridge_regression.py:120-133);  1 = the SCREENING pass of the inner CV (round 6): hi*hi
+ * alone, 11-bit operands -- scores good to ~1e-5, from which the alpha of every voxel whose best two alphas are further
+ * apart than that is already decided (nested_cv.py:408-411 only takes the argmax); the others are scored again with
+ * terms = 3 (lc_undecided_cols picks them).  terms = 1 needs N (K) % 64 == 0 and correlation scores.
+ * d_live_cols (NULL: all): device int32, read by the kernel -- only the column tiles below *d_live_cols do any work (the
+ * refinement's column panel has a fixed capacity; how many undecided columns it holds is known on the device only). */
 int lc_alpha_sweep_scores_f16x3_folds(const void* d_ht, const float* d_rowscale_inv, int F, int A, int M, int N,
                                       const void* d_yt, const float* d_cscale_inv, const float* d_yv,
                                       int64_t V, const int32_t* h_n_val, const float* d_ystat,
                                       const float* d_yblk, int mode, float* d_part, float* d_scores,
                                       int accumulate, int64_t b_rows, const int64_t* h_gap_begin,
-                                      const int64_t* h_gap_rows, lc_stream_t stream);
+                                      const int64_t* h_gap_rows, int terms, const int32_t* d_live_cols,
+                                      lc_stream_t stream);
 int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float* d_rowscale_inv, int F, int M,
                                        const int32_t* h_n_val, int64_t K, const void* d_yt,
                                        const float* d_cscale_inv, int64_t Ncols, const float* d_yv, int64_t V,
                                        const float* d_ystat, const float* d_yblk, const double* d_coef,
                                        const int32_t* d_aidx, int S, float* d_part, float* d_scores,
                                        int accumulate, int64_t b_rows, const int64_t* h_gap_begin,
-                                       const int64_t* h_gap_rows, lc_stream_t stream);
+                                       const int64_t* h_gap_rows, int terms, const int32_t* d_live_cols,
+                                       lc_stream_t stream);
+
+/* The voxels whose alpha the SCREENING pass of the inner CV (terms = 1 above) does not decide (round 6, DESIGN.md 4.2;
+ * the reference takes the argmax of the fold-mean scores, nested_cv.py:408-411 -- a voxel whose best two alphas are
+ * further apart than the screening error has that argmax already).  d_scores: (A, ld) f32 sums over the scored inner
+ * folds; voxel v < V is undecided when its two largest sums are closer than tau_sum * kappa(v), kappa = rms / std of the
+ * validation rows of d_ystat ((3, ld_stat) f32 of lc_val_stats: mean, std, variance; NULL: 1) -- a column on an offset
+ * loses the operand bits the offset takes -- or when a sum is non-finite; a voxel whose sums are ALL exactly zero
+ * (constant column) is decided (alphas[0] by the first-maximum rule in either arithmetic).
+ * d_list (cap) int32 receives the undecided columns in ascending order, -1 behind them; d_count[0] = columns in the
+ * list, d_count[1] = undecided columns found (> cap: the list does not hold them all -- the caller scores the whole
+ * range again), d_count[2] = that condition as 0 / 1 (three int32).  Workspaces: d_flags (V) u8, d_block_count (ceil(V / 256)) int32.  Deterministic, no atomics. */
+int lc_undecided_cols(const float* d_scores, int A, int64_t ld, int64_t V, float tau_sum, const float* d_ystat,
+                      int64_t ld_stat, uint8_t* d_flags, int32_t* d_block_count, int32_t* d_list, int cap,
+                      int32_t* d_count, lc_stream_t stream);
 
 /* ---------------------------------------------------------------- statistics tail */
 

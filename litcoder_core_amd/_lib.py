@@ -123,15 +123,13 @@ SIGNATURES = {
     "lc_combine_terms_f64": (c_int, [POINTER(c_void_p), POINTER(c_double), c_int, _ptr, c_int64, _ptr]),
     "lc_gather_sub_f64": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr]),
     "lc_gather_sub_f32": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
-    "lc_series_sweep_scores_f16x3": (c_int, [_ptr, _ptr, c_int, c_int, c_int64, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr,
-                                             _ptr, _ptr, _ptr, c_int, _ptr, _ptr, c_int, c_int64, c_int64, c_int64,
-                                             _ptr]),
     "lc_alpha_sweep_scores_f16x3_folds": (c_int, [_ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64,
                                                   POINTER(c_int32), _ptr, _ptr, c_int, _ptr, _ptr, c_int, c_int64,
-                                                  POINTER(c_int64), POINTER(c_int64), _ptr]),
+                                                  POINTER(c_int64), POINTER(c_int64), c_int, _ptr, _ptr]),
     "lc_series_sweep_scores_f16x3_folds": (c_int, [_ptr, _ptr, c_int, c_int, POINTER(c_int32), c_int64, _ptr, _ptr, c_int64,
                                                    _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr, c_int,
-                                                   c_int64, POINTER(c_int64), POINTER(c_int64), _ptr]),
+                                                   c_int64, POINTER(c_int64), POINTER(c_int64), c_int, _ptr, _ptr]),
+    "lc_undecided_cols": (c_int, [_ptr, c_int, c_int64, c_int64, c_float, _ptr, c_int64, _ptr, _ptr, _ptr, c_int, _ptr, _ptr]),
     "lc_series_scores": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr,
                                  c_int, _ptr]),
     "lc_transpose_rows_f64": (c_int, [_ptr, c_int64, _ptr, c_int, c_int64, _ptr, _ptr]),
@@ -146,8 +144,6 @@ SIGNATURES = {
     "lc_col_scales_f16_flags": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr, _ptr]),
     "lc_split_cols_f16": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, _ptr, _ptr, _ptr]),
     "lc_permute_cols_f16": (c_int, [_ptr, _ptr, c_int64, c_int, _ptr, _ptr]),
-    "lc_alpha_sweep_scores_f16x3": (c_int, [_ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int, _ptr, _ptr,
-                                            c_int, _ptr, _ptr, c_int, c_int64, c_int64, c_int64, _ptr]),
     "lc_gemm_grouped_f16x3": (c_int, [_ptr, _ptr, c_int64, _ptr, _ptr, _ptr, c_int64, c_int64, c_int64,
                                       POINTER(c_int32), c_int, _ptr, c_int64, c_int64, c_int64, _ptr]),
     "lc_gemm_grouped_f16x3_pearson": (c_int, [_ptr, _ptr, c_int64, _ptr, _ptr, c_int64, c_int64, POINTER(c_int32), c_int,

@@ -3,18 +3,40 @@
 // alpha histogram (all-reduce), the packed per-fold results (all-gather of f64) -- as plain calls on device pointers and a
 // HIP stream, with an opaque communicator created from a unique id the host side passes around by whatever means it has
 // (litcoder_core_amd/dist.py: one torch.distributed object broadcast, once).  north_star wants PyTorch for containers
-// only; through round 4 the collectives themselves went through torch.distributed (which stays the default transport and
-// the only one under gloo: see ShardContext).
+// only; through round 4 the collectives themselves went through torch.distributed (since round 6 that is the transport
+// under gloo only: with the "nccl" backend ShardContext takes these wrappers by default).
 //
 // RCCL is NOT a link-time dependency of this library: the entry points are looked up at the first use -- in the RCCL the
 // process has loaded already (PyTorch-ROCm ships one), else in librccl.so.1 of the ROCm installation -- so a single-GPU
-// process never loads it.
+// process never loads it.  Nor is its header a hard BUILD dependency: on a ROCm installation without
+// <rccl/rccl.h> the library still builds and every entry point below returns LC_E_HIP with a message saying so.
 #include "lc_common.h"
 
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
+
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#define LC_HAVE_RCCL_HEADER 1
+#else
+#define LC_HAVE_RCCL_HEADER 0
+#endif
+
+#if !LC_HAVE_RCCL_HEADER
+struct lc_comm {
+    int unused;
+};
+#define LC_NO_RCCL(who) return lc::fail(LC_E_HIP, who ": this library was built without <rccl/rccl.h>: no RCCL transport")
+extern "C" int lc_comm_unique_id_bytes(void) { return 0; }
+extern "C" int lc_comm_unique_id(void*, int) { LC_NO_RCCL("lc_comm_unique_id"); }
+extern "C" int lc_comm_create(const void*, int, int, int, int, lc_comm_t**) { LC_NO_RCCL("lc_comm_create"); }
+extern "C" int lc_comm_destroy(lc_comm_t*) { LC_NO_RCCL("lc_comm_destroy"); }
+extern "C" int lc_allgather_bytes(lc_comm_t*, const void*, void*, int64_t, lc_stream_t) { LC_NO_RCCL("lc_allgather_bytes"); }
+extern "C" int lc_allgather_f32(lc_comm_t*, const float*, float*, int64_t, lc_stream_t) { LC_NO_RCCL("lc_allgather_f32"); }
+extern "C" int lc_allreduce(lc_comm_t*, void*, int64_t, int, int, lc_stream_t) { LC_NO_RCCL("lc_allreduce"); }
+extern "C" int lc_allreduce_sum_f32(lc_comm_t*, float*, int64_t, lc_stream_t) { LC_NO_RCCL("lc_allreduce_sum_f32"); }
+#else
 
 namespace {
 
@@ -86,11 +108,17 @@ extern "C" int lc_comm_create(const void* h_id, int bytes, int world, int rank, 
     LC_REQUIRE(h_id && out && bytes == (int)sizeof(ncclUniqueId) && world >= 1 && rank >= 0 && rank < world, LC_E_BADARG,
                "lc_comm_create: bad argument");
     if (int rc = need_api("lc_comm_create")) return rc;
+    // the communicator belongs to `device`; the calling thread's current device is put back afterwards (the
+    // call used to leave it changed)
+    int before = -1;
+    LC_HIP(hipGetDevice(&before));
     LC_HIP(hipSetDevice(device));
     ncclUniqueId id;
     memcpy(&id, h_id, sizeof id);
     ncclComm_t c = nullptr;
-    LC_RCCL(api().CommInitRank(&c, world, id, rank));
+    const ncclResult_t r = api().CommInitRank(&c, world, id, rank);
+    if (before >= 0 && before != device) (void)hipSetDevice(before);
+    if (r != ncclSuccess) return lc::fail(LC_E_HIP, "ncclCommInitRank: %s", api().GetErrorString(r));
     *out = new lc_comm{c, rank, world};
     return LC_OK;
 }
@@ -133,3 +161,4 @@ extern "C" int lc_allreduce(lc_comm_t* comm, void* d_buf, int64_t count, int dty
 extern "C" int lc_allreduce_sum_f32(lc_comm_t* comm, float* d_buf, int64_t count, lc_stream_t stream) {
     return lc_allreduce(comm, d_buf, count, LC_F32, 0, stream);
 }
+#endif  // LC_HAVE_RCCL_HEADER

@@ -159,14 +159,19 @@ extern "C" int lc_alpha_sweep_scores_f16x3_folds(const void* d_ht, const float* 
                                                  int64_t V, const int32_t* h_n_val, const float* d_ystat,
                                                  const float* d_yblk, int mode, float* d_part, float* d_scores,
                                                  int accumulate, int64_t b_rows, const int64_t* h_gap_begin,
-                                                 const int64_t* h_gap_rows, lc_stream_t stream) {
+                                                 const int64_t* h_gap_rows, int terms, const int32_t* d_live_cols,
+        lc_stream_t stream) {
     LC_REQUIRE(d_ht && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_part && d_scores &&
                    h_n_val, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: null pointer");
+    LC_REQUIRE(terms == 3 || (terms == 1 && N % (4 * TK) == 0 && mode == LC_SCORE_CORR), LC_E_BADARG,
+               "lc_alpha_sweep_scores_f16x3: terms must be 3, or 1 (screening: correlation scores, N %% %d == 0)", 4 * TK);
     LC_REQUIRE(A > 0 && M > 0 && M % LC_MB == 0 && N > 0 && N % (2 * TK) == 0, LC_E_SHAPE,
                "lc_alpha_sweep_scores_f16x3: need M %% %d == 0, N %% %d == 0", LC_MB, 2 * TK);
     LC_REQUIRE(V > 0 && V % 128 == 0, LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: V must be a multiple of 128");
     LC_REQUIRE(mode == LC_SCORE_CORR || mode == LC_SCORE_R2, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: bad mode");
-    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<true, false>), LDS16_BYTES)) return rc;
+    const void* kern = terms == 1 ? reinterpret_cast<const void*>(k_sweep_f16x3<true, false, false, false, false, true>)
+                                  : reinterpret_cast<const void*>(k_sweep_f16x3<true, false>);
+    if (int rc = lc::ensure_dynamic_lds(kern, LDS16_BYTES)) return rc;
     hipStream_t s = lc::as_stream(stream);
     BView bv;
     FoldViews fv{};
@@ -178,27 +183,20 @@ extern "C" int lc_alpha_sweep_scores_f16x3_folds(const void* d_ht, const float* 
     LC_REQUIRE((long long)F * Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: grid too large");
     fv.mt_per_fold = Mtiles;
     fv.part_stride = (long long)(Mrows / LC_MB) * 4 * V;
-    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, 0, mode, Mrows, A};
+    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, 0, mode, Mrows, A, d_live_cols};
     {
         lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
         Plain16Args pa{};
-        hipLaunchKernelGGL((k_sweep_f16x3<true, false>), dim3((unsigned)(F * Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
-                           (const uint4*)d_ht, (const uint4*)d_yt, N / TK, F * Mtiles, sa, pa, bv, fv);
+        if (terms == 1)
+            hipLaunchKernelGGL((k_sweep_f16x3<true, false, false, false, false, true>), dim3((unsigned)(F * Mtiles * Ntiles)),
+                               dim3(512), LDS16_BYTES, s, (const uint4*)d_ht, (const uint4*)d_yt, N / TK, F * Mtiles, sa, pa,
+                               bv, fv);
+        else
+            hipLaunchKernelGGL((k_sweep_f16x3<true, false>), dim3((unsigned)(F * Mtiles * Ntiles)), dim3(512), LDS16_BYTES, s,
+                               (const uint4*)d_ht, (const uint4*)d_yt, N / TK, F * Mtiles, sa, pa, bv, fv);
     }
     if (int rc = lc::launched("k_sweep_f16x3")) return rc;
     return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, h_n_val, F, (long long)V, mode, d_scores, accumulate, s);
-}
-
-extern "C" int lc_alpha_sweep_scores_f16x3(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N,
-                                           const void* d_yt, const float* d_cscale_inv, const float* d_yv,
-                                           int64_t V, int n_val, const float* d_ystat,
-                                           const float* d_yblk, int mode, float* d_part, float* d_scores,
-                                           int accumulate, int64_t b_rows, int64_t b_gap_begin, int64_t b_gap_rows,
-                                           lc_stream_t stream) {
-    const int32_t nv = n_val;
-    return lc_alpha_sweep_scores_f16x3_folds(d_ht, d_rowscale_inv, 1, A, M, N, d_yt, d_cscale_inv, d_yv, V, &nv, d_ystat,
-                                             d_yblk, mode, d_part, d_scores, accumulate, b_rows, &b_gap_begin, &b_gap_rows,
-                                             stream);
 }
 
 extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
@@ -342,15 +340,19 @@ extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float*
                                                   const float* d_ystat, const float* d_yblk, const double* d_coef,
                                                   const int32_t* d_aidx, int S, float* d_part, float* d_scores,
                                                   int accumulate, int64_t b_rows, const int64_t* h_gap_begin,
-                                                  const int64_t* h_gap_rows, lc_stream_t stream) {
+                                                  const int64_t* h_gap_rows, int terms, const int32_t* d_live_cols,
+        lc_stream_t stream) {
     LC_REQUIRE(d_pt && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_coef && d_aidx &&
                    d_part && d_scores && h_n_val, LC_E_BADARG, "lc_series_sweep_scores_f16x3: null pointer");
+    LC_REQUIRE(terms == 3 || (terms == 1 && K % (4 * TK) == 0), LC_E_BADARG,
+               "lc_series_sweep_scores_f16x3: terms must be 3, or 1 (screening: K %% %d == 0)", 4 * TK);
     LC_REQUIRE(M > 0 && M % LC_MB == 0 && K > 0 && K % (2 * TK) == 0 && S > 0, LC_E_SHAPE,
                "lc_series_sweep_scores_f16x3: need M %% %d == 0, K %% %d == 0", LC_MB, 2 * TK);
     LC_REQUIRE(V > 0 && V % 128 == 0 && Ncols >= V && Ncols % TN == 0, LC_E_SHAPE,
                "lc_series_sweep_scores_f16x3: V must be a multiple of 128, Ncols >= V a multiple of %d", TN);
-    if (int rc = lc::ensure_dynamic_lds(reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true, true>), LDS16_BYTES))
-        return rc;
+    const void* kern = terms == 1 ? reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true, true, false, true>)
+                                  : reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true, true>);
+    if (int rc = lc::ensure_dynamic_lds(kern, LDS16_BYTES)) return rc;
     hipStream_t s = lc::as_stream(stream);
     BView bv;
     FoldViews fv{};
@@ -363,7 +365,7 @@ extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float*
     LC_REQUIRE((long long)F * Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_series_sweep_scores_f16x3: grid too large");
     fv.mt_per_fold = Mtiles;
     fv.part_stride = (long long)nblk * lc::EPI_SERIES_PARTS * V;
-    Score16Args sa{d_yv, d_ystat, nullptr, nullptr, d_part, (long long)V, M, 0, LC_SCORE_CORR, Mtiles * TM, 1};
+    Score16Args sa{d_yv, d_ystat, nullptr, nullptr, d_part, (long long)V, M, 0, LC_SCORE_CORR, Mtiles * TM, 1, d_live_cols};
     Plain16Args pa{};
     pa.rs_inv = d_rowscale_inv;
     pa.cs_inv = d_cscale_inv;
@@ -374,22 +376,15 @@ extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float*
     pa.slab_light = nullptr;
     {
         lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
-        hipLaunchKernelGGL((k_sweep_f16x3<false, false, true, true>), dim3((unsigned)(F * Mtiles * Ntiles)), dim3(512),
-                           LDS16_BYTES, s, (const uint4*)d_pt, (const uint4*)d_yt, (int)(K / TK), F * Mtiles, sa, pa, bv, fv);
+        if (terms == 1)
+            hipLaunchKernelGGL((k_sweep_f16x3<false, false, true, true, false, true>), dim3((unsigned)(F * Mtiles * Ntiles)),
+                               dim3(512), LDS16_BYTES, s, (const uint4*)d_pt, (const uint4*)d_yt, (int)(K / TK), F * Mtiles,
+                               sa, pa, bv, fv);
+        else
+            hipLaunchKernelGGL((k_sweep_f16x3<false, false, true, true>), dim3((unsigned)(F * Mtiles * Ntiles)), dim3(512),
+                               LDS16_BYTES, s, (const uint4*)d_pt, (const uint4*)d_yt, (int)(K / TK), F * Mtiles, sa, pa, bv, fv);
     }
     if (int rc = lc::launched("k_sweep_f16x3<series moments>")) return rc;
     return lc_series_finalize_launch(d_part, d_ystat, d_yblk, M, h_n_val, F, (long long)V, d_coef, d_aidx, S, d_scores,
                                      accumulate, s);
-}
-
-extern "C" int lc_series_sweep_scores_f16x3(const void* d_pt, const float* d_rowscale_inv, int M, int n_val, int64_t K,
-                                            const void* d_yt, const float* d_cscale_inv, int64_t Ncols,
-                                            const float* d_yv, int64_t V, const float* d_ystat, const float* d_yblk,
-                                            const double* d_coef, const int32_t* d_aidx, int S, float* d_part,
-                                            float* d_scores, int accumulate, int64_t b_rows, int64_t b_gap_begin,
-                                            int64_t b_gap_rows, lc_stream_t stream) {
-    const int32_t nv = n_val;
-    return lc_series_sweep_scores_f16x3_folds(d_pt, d_rowscale_inv, 1, M, &nv, K, d_yt, d_cscale_inv, Ncols, d_yv, V,
-                                              d_ystat, d_yblk, d_coef, d_aidx, S, d_part, d_scores, accumulate, b_rows,
-                                              &b_gap_begin, &b_gap_rows, stream);
 }

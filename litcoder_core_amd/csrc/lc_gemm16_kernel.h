@@ -289,6 +289,7 @@ struct Score16Args {
     long long V;           // padded voxel count of part / scores (multiple of 128)
     int M, n_val, mode, Mrows;
     int A;                 // score mode: alphas in the image, whose 32-row blocks are ordered (validation block, alpha)
+    const int* live_cols;  // optional (score / series-moments modes): column tiles from *live_cols on do nothing
 };
 
 // Which K-tiles of the tiled B image a launch contracts: the image may hold MORE rows than the product uses (the
@@ -350,10 +351,16 @@ struct Plain16Args {
 // and the epilogue reduces them to the blocks' partial moments (lc::epi_series_block) instead of storing them: the two
 // waves that share a column panel swap halves through the (then idle) LDS ring, so that each holds all four terms of
 // ONE 32-column block for both validation blocks.
-template <bool SCORE, bool STAMP, bool LIGHTCAP = false, bool SERMOM = false, bool PEARSON = false>
+// HI2 (score and series-moments modes; "screening" arithmetic): ONE MFMA per product -- the hi planes
+// alone, 11-bit operands, fp32 accumulation -- with TWO K-tiles per ring stage and barrier: the slot of a stage that
+// holds a K-tile's lo plane in the three-MFMA modes holds the NEXT K-tile's hi plane (same 32 KB stages, same fragment
+// addresses, same four DMA pieces per step and thread, 16 MFMAs per wave and step instead of 24 for twice the depth).
+template <bool SCORE, bool STAMP, bool LIGHTCAP = false, bool SERMOM = false, bool PEARSON = false, bool HI2 = false>
 __global__ void __launch_bounds__(512, 2)
-k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT, int Mtiles, Score16Args sa,
+k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT_tiles, int Mtiles, Score16Args sa,
               Plain16Args pa, BView bv, FoldViews fv) {
+    static_assert(!HI2 || ((SCORE || SERMOM) && !STAMP && !PEARSON), "HI2 is a mode of the score / series-moments kernels");
+    const int KT = HI2 ? KT_tiles / 2 : KT_tiles;       // ring steps (HI2: two K-tiles each; the host checks K % 64 == 0)
     extern __shared__ __attribute__((aligned(16))) uint4 lds16[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform (scalar)
@@ -363,6 +370,9 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     const int tile = xcd_tile_id16(blockIdx.x, gridDim.x);
     const int mt_all = tile % Mtiles, nt = tile / Mtiles;
     constexpr bool FOLDS = SCORE || SERMOM;
+    // the refinement's column panel: its capacity is fixed when the launch is queued, how many columns it
+    // holds only the device knows -- the tiles behind them leave at once (block-uniform: before any barrier)
+    if (FOLDS && sa.live_cols != nullptr && (long long)nt * TN >= (long long)*sa.live_cols) return;
     const int fold = FOLDS ? mt_all / fv.mt_per_fold : 0;
     const int mt = FOLDS ? mt_all - fold * fv.mt_per_fold : mt_all;          // M-tile inside the fold
     if (FOLDS) {
@@ -376,12 +386,12 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     if (!SCORE) {
         while (grp + 1 < pa.G && nt >= pa.start[grp + 1]) ++grp;
     }
-    const uint4* a_src = At + ((long long)grp * Mtiles + mt_all) * KT * CHUNK16 + tid;
+    const uint4* a_src = At + ((long long)grp * Mtiles + mt_all) * KT_tiles * CHUNK16 + tid;
     const uint4* b_src = Bt + (long long)nt * bv.kt_total * CHUNK16 + tid;
 #define BKT(kt_) ((kt_) + ((kt_) >= b_cut ? b_skip : 0))
     // "light" slabs (plain mode): rows whose product only needs fp16 accuracy (11-bit operands) -- the higher
     // terms of a series, which enter the caller's result scaled down by >= 2^-11 -- take the hi*hi MFMA alone
-    const bool light = SERMOM ? wm != 0
+    const bool light = HI2 ? false : SERMOM ? wm != 0
                               : (LIGHTCAP && !SCORE && pa.slab_light != nullptr &&
                                  __builtin_amdgcn_readfirstlane((int)pa.slab_light[((long long)grp * Mtiles + mt_all) * 2 + wm]) != 0);
 
@@ -412,14 +422,18 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
                      : "=&s"(keep_) : "v"(gp_), "s"(m0_) : "memory");                                          \
     }
+    // the two pieces of an operand's share of ring step t: hi and lo plane of K-tile t, or (HI2) the hi planes of the
+    // K-tiles 2t and 2t + 1 (a thread's unit of a plane: + tid, in a_src / b_src already; the lo plane follows 512 units on)
+#define SRC_A0(t_) (a_src + (long long)(HI2 ? 2 * (t_) : (t_)) * CHUNK16)
+#define SRC_A1(t_) (HI2 ? a_src + (long long)(2 * (t_) + 1) * CHUNK16 : a_src + (long long)(t_) * CHUNK16 + 512)
+#define SRC_B0(t_) (b_src + (long long)BKT(HI2 ? 2 * (t_) : (t_)) * CHUNK16)
+#define SRC_B1(t_) (HI2 ? b_src + (long long)BKT(2 * (t_) + 1) * CHUNK16 : b_src + (long long)BKT(t_) * CHUNK16 + 512)
 #define GLDS16(kt_, stg_)                                                           \
     {                                                                               \
-        const uint4* pa_ = a_src + (long long)(kt_) * CHUNK16;                      \
-        const uint4* pb_ = b_src + (long long)BKT(kt_) * CHUNK16;                   \
-        DMA16(pa_, (stg_) * STAGE16);                                               \
-        DMA16(pa_ + 512, (stg_) * STAGE16 + 512);                                   \
-        DMA16(pb_, (stg_) * STAGE16 + CHUNK16);                                     \
-        DMA16(pb_ + 512, (stg_) * STAGE16 + CHUNK16 + 512);                         \
+        DMA16(SRC_A0(kt_), (stg_) * STAGE16);                                       \
+        DMA16(SRC_A1(kt_), (stg_) * STAGE16 + 512);                                 \
+        DMA16(SRC_B0(kt_), (stg_) * STAGE16 + CHUNK16);                             \
+        DMA16(SRC_B1(kt_), (stg_) * STAGE16 + CHUNK16 + 512);                       \
     }
 #define PHASE_BARRIER()                        \
     __builtin_amdgcn_sched_barrier(0);         \
@@ -579,6 +593,47 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
     };
+    // HI2: one ring step = two K-tiles, hi planes only.  The fragments sit where the three-MFMA step finds them -- "ah / bh"
+    // are K-tile 2 kt, "al / bl" K-tile 2 kt + 1 -- so the step is the heavy one without its cross terms: 16 MFMAs in 8
+    // slots, the 12 fragment reads of the next step and the four DMA pieces of step kt + 4 spread over them.
+    auto kstep_hi2 = [&](const int kt, const Frag& cur, Frag& nxt, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool STEADY = MODE == 0, LAST = MODE == 2;
+        const bool has_next = STEADY || (!LAST && kt + 1 < KT);
+        const bool do_dma = STEADY || (!LAST && kt + 4 < KT);
+        const uint4* stn = lds16 + ((kt + 1) & 3) * STAGE16;
+        const int stg = kt & 3;
+        if (LAST && SCORE) { load_t(0, tb0); load_t(1, tb1); }
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * sl + h, mi = (i & 7) >> 1, ni = i & 1;
+                if (i < 8) MFMA16(acc[mi][ni], cur.ah[mi], cur.bh[ni]);
+                else MFMA16(acc[mi][ni], cur.al[mi], cur.bl[ni]);
+            }
+            if (has_next) {
+                // reads in the order the next step consumes them: bh, ah (K-tile 2 kt' first), then bl, al
+                if (sl == 0) { read_frag(nxt, stn, 0); read_frag(nxt, stn, 1); }
+                if (sl == 1) { read_frag(nxt, stn, 8); read_frag(nxt, stn, 9); }
+                if (sl == 2) { read_frag(nxt, stn, 10); read_frag(nxt, stn, 11); }
+                if (sl == 3) { read_frag(nxt, stn, 6); read_frag(nxt, stn, 7); }
+                if (sl >= 4) read_frag(nxt, stn, sl - 2);
+            }
+            if (do_dma) {
+                if (sl == 1) DMA16(SRC_A0(kt + 4), stg * STAGE16);
+                if (sl == 3) DMA16(SRC_A1(kt + 4), stg * STAGE16 + 512);
+                if (sl == 5) DMA16(SRC_B0(kt + 4), stg * STAGE16 + CHUNK16);
+                if (sl == 7) DMA16(SRC_B1(kt + 4), stg * STAGE16 + CHUNK16 + 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (LAST) return;
+        if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
+    };
     // a 128-row slab with no valid rows (the last M-tile of A x 480 = 1920 score rows is half padding): its waves only
     // keep up their share of the DMA ring and the barriers; the other wave of each SIMD then has the matrix pipe to
     // itself and the tile takes half the time -- 1/16 of a fused launch
@@ -587,12 +642,10 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         constexpr bool STEADY = MODE == 0, LAST = MODE == 2;
         if (STEADY || (!LAST && kt + 4 < KT)) {
             const int stg = kt & 3;
-            const uint4* pa_ = a_src + (long long)(kt + 4) * CHUNK16;
-            const uint4* pb_ = b_src + (long long)BKT(kt + 4) * CHUNK16;
-            DMA16(pa_, stg * STAGE16);
-            DMA16(pa_ + 512, stg * STAGE16 + 512);
-            DMA16(pb_, stg * STAGE16 + CHUNK16);
-            DMA16(pb_ + 512, stg * STAGE16 + CHUNK16 + 512);
+            DMA16(SRC_A0(kt + 4), stg * STAGE16);
+            DMA16(SRC_A1(kt + 4), stg * STAGE16 + 512);
+            DMA16(SRC_B0(kt + 4), stg * STAGE16 + CHUNK16);
+            DMA16(SRC_B1(kt + 4), stg * STAGE16 + CHUNK16 + 512);
         }
         if (LAST) return;
         if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -605,7 +658,18 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     using Last = std::integral_constant<int, 2>;
     const bool slab_empty = !SERMOM && !STAMP && mt * TM + wm * 128 >= (SCORE ? sa.Mrows : pa.Mrows);
     int kt = 0;
-    if (slab_empty) {
+    if (HI2 && !slab_empty) {
+        for (; kt + 5 < KT; kt += 2) {
+            kstep_hi2(kt, fa, fb, Steady{});
+            kstep_hi2(kt + 1, fb, fa, Steady{});
+        }
+        for (; kt + 2 < KT; kt += 2) {
+            kstep_hi2(kt, fa, fb, Tail{});
+            kstep_hi2(kt + 1, fb, fa, Tail{});
+        }
+        kstep_hi2(kt, fa, fb, Tail{});               // KT (steps) is even: K % 64 == 0
+        kstep_hi2(kt + 1, fb, fa, Last{});
+    } else if (slab_empty) {
         for (; kt + 5 < KT; kt += 2) {
             kstep_empty(kt, Steady{});
             kstep_empty(kt + 1, Steady{});

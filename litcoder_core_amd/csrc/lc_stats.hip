@@ -418,6 +418,105 @@ __global__ void __launch_bounds__(256) k_pearson_pvalues(const double* __restric
     p[v] = out;
 }
 
+// ------------------------------------------------------------------ undecided voxels of the screening pass (round 6)
+// scores: (A, ld) f32, the SUM over the scored inner folds of the screening pass (one MFMA per product).  Voxel v is
+// UNDECIDED when the two largest of its A sums lie closer than  tau_sum * kappa(v)  -- the screening scores are good to
+// ~1e-5 of a fold-mean score for a centred column; a column riding on an offset loses the bits the offset takes:
+// kappa = rms / std of its validation rows (>= 1) -- unless all A sums are exactly zero (a constant / non-finite
+// column: every alpha scores 0 in either arithmetic, the first-maximum rule takes alphas[0]).  Two kernels, no atomics:
+// flags + per-block counts, then every block places its own columns behind the blocks before it -- the list is in
+// ascending column order, run to run.
+constexpr int UD_THREADS = 256;
+
+__global__ void __launch_bounds__(UD_THREADS) k_undecided_flags(const float* __restrict__ scores, int A, long long ld,
+                                                               long long V, float tau_sum, const float* __restrict__ ystat,
+                                                               long long ld_stat, unsigned char* __restrict__ flags,
+                                                               int* __restrict__ block_count) {
+    __shared__ int wsum[UD_THREADS / 64];
+    const long long v = (long long)blockIdx.x * UD_THREADS + threadIdx.x;
+    bool und = false;
+    if (v < V) {
+        float top = -__builtin_huge_valf(), second = -__builtin_huge_valf();
+        bool all_zero = true, finite = true;
+        for (int a = 0; a < A; ++a) {
+            const float sc = scores[(long long)a * ld + v];
+            all_zero = all_zero && sc == 0.f;
+            finite = finite && fabsf(sc) < 3.0e38f;
+            if (sc > top) { second = top; top = sc; }
+            else if (sc > second) second = sc;
+        }
+        float kappa = 1.f;
+        if (ystat != nullptr) {
+            const float m = ystat[v], sd = ystat[ld_stat + v], var = ystat[2 * ld_stat + v];
+            const float k2 = sd > 0.f ? sqrtf(m * m + var) / sd : 1.f;
+            kappa = (k2 >= 1.f && k2 < 3.0e38f) ? k2 : 1.f;
+        }
+        if (all_zero) und = false;
+        else if (!finite) und = true;
+        else if (A < 2) und = false;
+        else und = !(top - second >= tau_sum * kappa);           // (a NaN gap counts as undecided)
+        flags[v] = und ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(und);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < UD_THREADS / 64; ++w) t += wsum[w];
+        block_count[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(UD_THREADS) k_undecided_place(const unsigned char* __restrict__ flags, long long V,
+                                                               const int* __restrict__ block_count, int n_blocks,
+                                                               int* __restrict__ list, int cap, int* __restrict__ count) {
+    __shared__ int red[2][UD_THREADS];
+    __shared__ int wbase[UD_THREADS / 64 + 1];
+    int before = 0, total = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += UD_THREADS) {
+        const int c = block_count[b];
+        total += c;
+        if (b < (int)blockIdx.x) before += c;
+    }
+    red[0][threadIdx.x] = before;
+    red[1][threadIdx.x] = total;
+    __syncthreads();
+    for (int w = UD_THREADS / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    before = red[0][0];
+    total = red[1][0];
+    const long long v = (long long)blockIdx.x * UD_THREADS + threadIdx.x;
+    const bool und = v < V && flags[v] != 0;
+    const unsigned long long m = __ballot(und);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wbase[wave + 1] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        wbase[0] = 0;
+        for (int w = 1; w <= UD_THREADS / 64; ++w) wbase[w] += wbase[w - 1];
+    }
+    __syncthreads();
+    if (und) {
+        const int pos = before + wbase[wave] + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < cap) list[pos] = (int)v;
+    }
+    // the tail of the list: no column
+    for (long long j = (long long)total + (long long)blockIdx.x * UD_THREADS + threadIdx.x; j < cap;
+         j += (long long)gridDim.x * UD_THREADS)
+        list[j] = -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        count[0] = total < cap ? total : cap;       // columns in the list (what the refinement's launches cover)
+        count[1] = total;                           // undecided columns found: > cap = the list does not hold them all
+        count[2] = total > cap ? 1 : 0;             // ... as a flag (voxel shards: MAX all-reduced in place)
+    }
+}
+
 // ------------------------------------------------------------------ alpha selection
 __global__ void __launch_bounds__(256) k_argmax_alpha(const float* __restrict__ scores, int A, long long V,
                                                       int* __restrict__ best) {
@@ -589,7 +688,7 @@ extern "C" int lc_gemv_cols_f32(const float* d_a, int64_t lda, int64_t M, int64_
     LC_REQUIRE(M >= 0 && K >= 0 && ns >= 1 && ns <= GV_NS && K % 4 == 0 && lda >= K && lda % 4 == 0 && ldc >= ns &&
                    (reinterpret_cast<uintptr_t>(d_a) & 15) == 0,
                LC_E_SHAPE, "lc_gemv_cols_f32: need 1 <= ns <= %d, K %% 4 == 0, lda >= K, lda %% 4 == 0, A 16-byte aligned", GV_NS);
-    if (M == 0 || K == 0) return LC_OK;
+    if (M == 0) return LC_OK;                        // (K == 0: an empty sum -- the kernel writes the zeros)
     hipLaunchKernelGGL(k_gemv_cols, dim3((unsigned)lc::ceil_div<long long>(M, 8)), dim3(256), 0, lc::as_stream(stream), d_a,
                        (long long)lda, (long long)M, (long long)K, d_y, (long long)ldy, d_rows, d_sel, ns, (int)want, d_c,
                        (long long)ldc);
@@ -868,6 +967,22 @@ extern "C" int lc_pearson_cols_gather(const float* d_y, int64_t ld_y, const int3
     else
         launch_pearson_regs<20>(d_y, ld_y, d_rows, d_cols, d_b, ldb, n, V, d_r, lc::as_stream(stream));
     return lc::launched("k_pearson_cols_regs");
+}
+
+extern "C" int lc_undecided_cols(const float* d_scores, int A, int64_t ld, int64_t V, float tau_sum, const float* d_ystat,
+                                 int64_t ld_stat, uint8_t* d_flags, int32_t* d_block_count, int32_t* d_list, int cap,
+                                 int32_t* d_count, lc_stream_t stream) {
+    LC_REQUIRE(d_scores && d_flags && d_block_count && d_list && d_count, LC_E_BADARG, "lc_undecided_cols: null pointer");
+    LC_REQUIRE(A > 0 && V > 0 && V < (1ll << 31) && ld >= V && cap > 0 && tau_sum >= 0.f && (!d_ystat || ld_stat >= V),
+               LC_E_SHAPE, "lc_undecided_cols: need A > 0, 0 < V <= ld, cap > 0, tau_sum >= 0");
+    hipStream_t s = lc::as_stream(stream);
+    const int nb = (int)lc::ceil_div<long long>(V, UD_THREADS);
+    hipLaunchKernelGGL(k_undecided_flags, dim3((unsigned)nb), dim3(UD_THREADS), 0, s, d_scores, A, (long long)ld, (long long)V,
+                       tau_sum, d_ystat, (long long)ld_stat, d_flags, d_block_count);
+    if (int rc = lc::launched("k_undecided_flags")) return rc;
+    hipLaunchKernelGGL(k_undecided_place, dim3((unsigned)nb), dim3(UD_THREADS), 0, s, d_flags, (long long)V, d_block_count, nb,
+                       d_list, cap, d_count);
+    return lc::launched("k_undecided_place");
 }
 
 extern "C" int lc_select_alpha(const float* d_scores, int A, int64_t V, int32_t* d_best, double* d_rowsum,

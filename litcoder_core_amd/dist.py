@@ -19,12 +19,23 @@ of voxel columns and the V-wide data path needs no collective.  What the ranks e
 All of these take and return DEVICE tensors.  Backend "nccl" is RCCL over xGMI on ROCm and moves them directly;
 under "gloo" (the CPU tests, and the two-ranks-on-one-GPU parity test) the same calls stage through the host.
 
-Round 5: with ``direct_rccl=True`` (or LITCODER_AMD_RCCL_DIRECT=1) and the "nccl" backend the device-tensor collectives
-do not go through torch.distributed at all but through the library's own thin RCCL wrappers (``lc_allgather_f32`` /
-``lc_allgather_bytes`` / ``lc_allreduce``, include/litcoder_hip.h; SURVEY 8b's export list): one communicator per lane,
-created from a unique id that rank 0 makes and torch.distributed broadcasts ONCE -- PyTorch then is a container and a
-rendezvous, nothing on the data path.  Off by default: this pool has no multi-GPU node to run it on, the one-rank test
-(tests/test_gpu_shards.py) is all the hardware evidence there is, and torch.distributed's transport is the tested one.
+Transport.  With the "nccl" backend the device-tensor collectives do not go through torch.distributed at all but through
+the library's own thin RCCL wrappers (``lc_allgather_f32`` / ``lc_allgather_bytes`` / ``lc_allreduce``,
+include/litcoder_hip.h; SURVEY 8b's export list) on communicators created from a unique id that rank 0 makes and
+torch.distributed broadcasts ONCE -- PyTorch is a container and a rendezvous, nothing on the data path.  Round 5 built
+this as an option; since round 6 it is the DEFAULT under "nccl" (``direct_rccl=False`` / LITCODER_AMD_RCCL_DIRECT=0 goes
+back to torch.distributed's calls; under gloo -- the CPU tests, two ranks on one GPU -- torch.distributed is the only
+transport).  Two knobs give a first multi-GPU run a conservative mode without a code change:
+
+  * LITCODER_AMD_RCCL_LANES=0 -- every collective on ONE communicator (no "hat" / "refit" lanes of their own for the bulk
+    all-gathers): one issue order for everything, at the price of a 20-int all-reduce queueing behind a batch gather;
+  * LITCODER_AMD_RCCL_DIRECT=0 -- torch.distributed's transport (its own communicators and streams).
+
+Ordering rule of the direct transport: a communicator executes its collectives in ISSUE ORDER; every rank issues the same
+collectives in the same host order by construction (job lists, panel counts and flags are identical on all ranks), whatever
+HIP stream each is ordered on.  The default communicator carries the small exchanges (flags, per-alpha sums, histograms,
+the packed fold results) from the main / scales / communication streams; the lanes carry the operator gathers.  This pool
+has no multi-GPU node: the one-rank RCCL test (tests/test_gpu_shards.py) is the hardware evidence there is.
 ``ShardContext.simulated`` runs one rank of a W-rank job alone (collectives become local copies): the results are
 meaningless, the per-rank timeline is what an W-GPU run would see minus the wire time -- used by
 ``tools/scaling_model.py`` on the single-GPU box.
@@ -88,6 +99,7 @@ class ShardContext:
         # are issued far ahead (whole batches of later folds) and wait for their fp64 chains; a 20-int all-reduce that
         # fold 0 needs NOW must not sit behind them -- so the bulk traffic gets communicators ("lanes") of its own.
         self._lanes = {}
+        self.use_lanes = True
         if self._dist is not None and (self.world > 1 or self.always):
             ranks = tuple(self._dist.get_process_group_ranks(group)) if group is not None else None
             key = (ranks, raw)
@@ -98,16 +110,41 @@ class ShardContext:
             world_now = self._dist.group.WORLD
             for k in [k for k, (w, _) in _LANES.items() if w is not world_now]:
                 del _LANES[k]
-            if key not in _LANES:                       # the lanes span exactly the ranks of ``group``
-                be = None if raw in ("", "undefined") else raw
-                _LANES[key] = (world_now, {lane: self._dist.new_group(ranks=list(ranks) if ranks is not None else None,
-                                                                       backend=be)
-                                           for lane in ("hat", "refit")})  # same order on every process
-            self._lanes = _LANES[key][1]
+            self.use_lanes = os.environ.get("LITCODER_AMD_RCCL_LANES", "1") != "0"
+            direct_wanted = (direct_rccl if direct_rccl is not None
+                             else os.environ.get("LITCODER_AMD_RCCL_DIRECT", "1") != "0") and self._cuda_direct
+            # torch.distributed lane groups only where its transport carries the bulk traffic (gloo, or nccl with the
+            # direct transport switched off): the direct transport makes its own communicators (_init_direct_rccl)
+            if self.use_lanes and not direct_wanted:
+                if key not in _LANES:                   # the lanes span exactly the ranks of ``group``
+                    be = None if raw in ("", "undefined") else raw
+                    _LANES[key] = (world_now, {lane: self._dist.new_group(ranks=list(ranks) if ranks is not None else None,
+                                                                           backend=be)
+                                               for lane in ("hat", "refit")})  # same order on every process
+                self._lanes = _LANES[key][1]
         if direct_rccl is None:
-            direct_rccl = os.environ.get("LITCODER_AMD_RCCL_DIRECT", "0") == "1"
+            direct_rccl = os.environ.get("LITCODER_AMD_RCCL_DIRECT", "1") != "0"
         if direct_rccl and self._dist is not None and self._cuda_direct and (self.world > 1 or self.always):
             self._init_direct_rccl()
+
+    def close(self):
+        """Destroys the direct transport's communicators (lc_comm_destroy).  The context falls back to torch.distributed's
+        calls afterwards.  Collective in spirit: call it on every rank once the last fit is done (nothing
+        released them before)."""
+        comms, self._comms = self._comms, {}
+        if comms:
+            from . import _lib
+            for h in {id(h): h for h in comms.values()}.values():
+                try:
+                    _lib.call("lc_comm_destroy", h)
+                except Exception:  # noqa: BLE001 -- tearing down: the process group may be gone already
+                    pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def _init_direct_rccl(self):
         """One RCCL communicator per lane through the library's own wrappers (lc_comm_create): rank 0 makes the unique ids,
@@ -117,7 +154,7 @@ class ShardContext:
         from . import _lib
         lib = _lib.load()
         n = lib.lc_comm_unique_id_bytes()
-        lanes = (None, "hat", "refit")
+        lanes = (None, "hat", "refit") if self.use_lanes else (None,)
         ids = [None] * len(lanes)
         if self.rank == 0:
             for i in range(len(lanes)):
@@ -139,6 +176,7 @@ class ShardContext:
         ctx._dist, ctx.group, ctx.device, ctx.rank, ctx.world, ctx.backend = None, None, device, 0, 1, None
         ctx.simulate, ctx.always, ctx._lanes, ctx.global_lists, ctx.bytes_received = False, False, {}, True, 0
         ctx._comms = {}
+        ctx.use_lanes = True
         ctx._cuda_direct, ctx._cpu_direct = False, False
         return ctx
 
@@ -240,6 +278,27 @@ class ShardContext:
             t = t.to(self.device)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
+
+    def total_of_local_blocks(self, n_local: int) -> int:
+        """``local_targets``: every rank holds ITS block of the voxel columns; returns the job's total -- and checks, on every
+        rank alike (from the same all-reduced vector), that the blocks are the ones ``bounds`` deals out: a rank with
+        another width would cut its block into another number of panels and pair its collectives with nobody's (ADVICE r5:
+        a hang instead of an error).  One rank of a simulated job stands for ``world`` equal blocks."""
+        n_local = int(n_local)
+        if self.world == 1:
+            return n_local
+        if self.simulate:
+            return n_local * self.world
+        mine = np.zeros(self.world)
+        mine[self.rank] = n_local
+        every = np.rint(self.allreduce_sum(mine)).astype(np.int64)
+        total = int(every.sum())
+        want = np.asarray([shard_bounds(total, self.world, r)[1] - shard_bounds(total, self.world, r)[0]
+                           for r in range(self.world)], dtype=np.int64)
+        if not np.array_equal(every, want):
+            raise ValueError(f"local_targets: the ranks hold {every.tolist()} voxel columns; the blocks of a {total}-voxel job over "
+                             f"{self.world} ranks are {want.tolist()} (ShardContext.bounds)")
+        return total
 
     def allgather_cols(self, arr: np.ndarray, n_total: int) -> np.ndarray:
         """``arr`` is (k, n_local) for this rank's block; returns (k, n_total) on every rank (host arrays)."""

@@ -4,7 +4,17 @@
 weighted row sums with the weights evaluated on the fly in fp64 (``lc_lanczos_interp`` / ``lc_sinc_interp``);
 the per-TR reducers (rect / average / sum / last / legacy_*) are one segment-reduction kernel
 (``lc_segment_reduce``) fed with row-index lists the host derives from time windows, TR labels or split points.
-Only ``gabor`` (never used by a shipped config) stays a short numpy routine.
+Only ``gabor`` (never used by a shipped config) stays a short HOST numpy routine (the one
+method of this class that does not touch the device).
+
+Where the banded kernels differ from the reference's dense ``sincmat @ data`` (interpdata.py:118-126), by construction:
+  * a NON-FINITE sample (NaN / Inf word feature) makes the reference's WHOLE output column of that story NaN (every
+    sample is multiplied by a weight, zeros included: 0 * NaN); here only the output rows whose sample batches (8
+    samples) cover it are NaN -- the rows whose window holds it plus at most 7 samples either side
+    (tests/test_gpu_parity.py::test_lanczos_non_finite_sample_is_confined).  Downstream the trainer's ``np.nan_to_num``
+    on the design (trainer.py:257) zeroes such entries either way;
+  * the window weights use sin(pi t) evaluated as sinpi (exactly 0 at integer t; np.sin(np.pi * t) leaves ~1e-16 there):
+    golden outputs agree to 1e-12.
 """
 from typing import List
 

@@ -95,6 +95,18 @@ class FitOptions:
     folds_in_one_launch_tiles: int = 512    # all inner folds of a step in ONE launch per pass while a fold's launch has fewer
                                             # 256 x 256 tiles than this (narrow voxel ranges: partial rounds of workgroups; measured -2.8 %
                                             # at 10 000 voxels, -0.5 % at 20 000 on one GPU, +1.7 % for a rank of 4 at 20 000); 0: never
+    screen_inner: bool = True               # (round 6) the inner CV in two precisions: a SCREENING pass with one fp16 MFMA per
+                                            # product (hi planes: 11-bit operands) decides the alpha of every voxel whose two
+                                            # best alphas lie further apart than the screening error can bridge; the other
+                                            # voxels (~1 % at cfg2) are scored again with the three-MFMA products
+    screen_tau: float = 5e-3                # ... a voxel is undecided when the gap between its two best fold-MEAN scores is
+                                            # below screen_tau / sqrt(validation rows scored over all inner folds) (x rms / std
+                                            # of the column): the screening error of a fold-mean score is that of ~2e-4-relative
+                                            # prediction errors averaged over those rows -- measured rms 3.7e-6, max 4.1e-5 over
+                                            # 8e6 scores at cfg2 (2400 rows: gap 1.0e-4 = 27 rms; the largest gap of a voxel
+                                            # whose screening argmax was wrong: 1.4e-5; profiles/r06_screen_probe_cfg2.txt)
+    screen_panel_cols: int = 0              # ... columns of the refinement's panel (0: adaptive, _refine_capacity; tests force
+                                            # the overflow path with a small value)
     alpha_progress_log: bool = dataclasses.field(       # per-alpha progress lines (ridge_regression.py:136-139): a device
         default_factory=lambda: os.environ.get("LITCODER_AMD_ALPHA_LOG", "0") == "1")   # round trip per fold, opt-in
     chol_outer_block: int = 512             # lc_batch_chol_solve: columns per outer block of the two-level blocking

@@ -273,6 +273,15 @@ class DualSweeps:
             else:
                 Yt = [torch.empty(Vt * N * 2, dtype=torch.float16, device=self.dev) for _ in range(nbuf)]
                 views = [(0, 0, 0)] * F
+        # screening arithmetic (FitOptions.screen_inner): one MFMA per product for both contractions of the inner CV
+        panel = bool(hat.get("panel"))                    # this call scores the refinement's column panel (_refine_undecided)
+        live = hat.get("live") if panel else None
+        # (only where the table feeds a per-voxel ARGMAX and nothing else -- the nested-CV driver says so, argmax_only; a
+        # caller that wants the scores themselves, ridge.ridge_corr = ridge_corr_torch, gets the three-MFMA scores)
+        terms = 1 if (self.opt.screen_inner and getattr(self, "argmax_only", False) and moments and split
+                      and self.mode == LC_SCORE_CORR and N % 64 == 0 and not panel and not hat.get("exact")) else 3
+        if not panel:
+            self.info["screen_terms"] = terms
         folds = [(f0 + j, j, H, P) for f0, fc, H, P in hat["Hs"] for j in range(fc)]
         # the operators' fp16 images made with the hat matrices (_hat_matrices), per chunk: fold f0 + j is group j
         imgs = hat.get("imgs") or [None] * len(hat["Hs"])
@@ -316,7 +325,8 @@ class DualSweeps:
                     self.info["plain_flops"] += sum(2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * V_ for f in range(F))
                     self.info["plain_launches"] += 1
                     ops.series_sweep_scores_f16x3_folds(im["Pt"], im["rs_p"], M, n_v, N, Yt[0], cs_inv, Vt, yv, Vp_, ystat, yblk,
-                                                        self.d_coef, hat["d_ser"], part_f, scores, False, views)
+                                                        self.d_coef, hat["d_ser"], part_f, scores, False, views, terms=terms,
+                                                        live=live)
                     return
                 for f, j, H, P in folds:
                     if shared is None:
@@ -332,7 +342,7 @@ class DualSweeps:
                     if fused:
                         ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], N, Yt[f], cs_inv, Vt, yv[f], Vp_, ystat[f], yblk[f],
                                                       self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0,
-                                                      bview=views[f])
+                                                      bview=views[f], terms=terms, live=live)
                         continue
                     ops.gemm_grouped_f16x3(Pt_f, rs_p_f, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
                                            bview=views[f])
@@ -344,7 +354,7 @@ class DualSweeps:
                 main.wait_event(done)
             # the f32 side path of too-wide target columns runs on a stream of its own BESIDE the sweeps queued below (a
             # few dozen workgroups per launch); its scores are written over the main path's before any alpha is chosen
-            side_job = self._side_sweeps_begin(hat, rg_) if (self.side is not None and split) else None
+            side_job = self._side_sweeps_begin(hat, rg_) if (self.side is not None and split and not panel) else None
             # ---- pass 2 (the only one without the moment path): fused sweeps of the alphas that have hat matrices
             if one_launch and fused and Ad:
                 im = imgs[0]
@@ -353,7 +363,7 @@ class DualSweeps:
                 self.info["fused_launches"] += 1
                 self.info["folds_per_launch"] = F
                 ops.alpha_sweep_scores_f16x3_folds(im["Ht"], im["rs_h"], Ad, M, N, Yt[0], cs[Vp_:], yv, Vp_, n_v, ystat, yblk,
-                                                   self.mode, part_f, scores_d, False, views)
+                                                   self.mode, part_f, scores_d, False, views, terms=terms, live=live)
             for f, j, H, P in (() if (one_launch and fused) else folds):
                 b = f if moments else 0
                 if not moments:
@@ -371,7 +381,8 @@ class DualSweeps:
                         else:
                             ops.split_rows_f16_alphas(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), 1, Ad, M, N, Ht, rs_inv)
                         ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, N, Yt[b], cs[Vp_:], yv[b], Vp_, n_v[f], ystat[b],
-                                                     yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f])
+                                                     yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f],
+                                                     terms=terms, live=live)
                 else:
                     self.info["fused_flops"] += 2.0 * A * n_v[f] * hat["n_i"][f] * V_
                     self.info["fused_launches"] += 1
@@ -380,6 +391,10 @@ class DualSweeps:
             if moments and Ad and not cho_first:
                 for i, a in enumerate(cho):
                     scores[a].copy_(scores_d[i])
+            if terms == 1:
+                # the voxels the screening pass leaves undecided: scored again with the three-MFMA products, their columns
+                # of the table overwritten -- before the side path's columns are, and before any alpha is chosen
+                self._refine_undecided(hat, Y, scores, ystat[0], F, sum(n_v))
             if side_job is not None:
                 self._side_sweeps_end(side_job, scores)
             self.sweeps_done = torch.cuda.Event()
@@ -392,6 +407,59 @@ class DualSweeps:
             return (lambda: out) if split_phase else out
         series_part()
         return fused_part if split_phase else fused_part()
+
+    def _refine_capacity(self, V):
+        """Columns of the refinement's panel for a voxel range of V columns: twice the largest share of undecided voxels a
+        step of this fit has reported so far (the host learns a step's count at its one synchronisation, fold_select: two
+        steps behind what is being queued), V / 16 (at least 2048 columns) before that; whole 256-column tiles."""
+        if self.opt.screen_panel_cols > 0:
+            return int(min(ops.pad_to(self.opt.screen_panel_cols, 256), ops.pad_to(V, 256)))
+        fracs = getattr(self, "_undecided_fracs", None)
+        cap = int(2.0 * max(fracs) * V) + 256 if fracs else max(V // 16, 2048)     # (narrow ranges: generously, it costs nothing)
+        return int(min(ops.pad_to(max(cap, 256), 256), ops.pad_to(V, 256)))
+
+    def _refine_undecided(self, hat, Y, scores, ystat0, F, n_val_rows):
+        """Second half of the two-precision inner CV (FitOptions.screen_inner).  ``scores`` holds the sums
+        over the F inner folds of the SCREENING scores (one fp16 MFMA per product: good to ~1e-5 of a fold-mean score).
+        nested_cv.py:408-411 only takes each voxel's argmax of them, so a voxel whose two best alphas lie further apart
+        than screen_tau / sqrt(validation rows scored) (scaled by rms / std of the column: an offset costs operand bits) is
+        decided; the others --
+        lc_undecided_cols: ~1 % at cfg2 -- are gathered into a column panel, scored again by the SAME sweeps with the
+        three-MFMA products (every V-wide kernel keeps a voxel's arithmetic inside its own column: the panel's scores are,
+        bit for bit, what the full-width three-MFMA sweeps give those voxels) and written over their columns of the table.
+        The panel's capacity is fixed when its launches are queued; how many columns it holds only the device knows -- the
+        sweeps' tiles behind the last one leave at once (live), and a count beyond the capacity is reported to fold_select,
+        which scores the whole range again (hat["screen_check"])."""
+        Vp_, V_, A = self.Vp, self.V, self.A
+        cap = self._refine_capacity(V_)
+        # (the table holds SUMS over the F folds: the gap of the fold means x F)
+        tau_sum = self.opt.screen_tau * F / float(np.sqrt(max(int(n_val_rows), 1)))
+        lst, count = ops.undecided_cols(scores, A, V_, tau_sum, ystat0, cap)
+        over = count[2:3]                                      # "the panel does not hold them all": MAX over the voxel shards --
+        if self.shard.active:                                  # every rank must take the same decision in fold_select
+            self.shard.all_reduce_(over, "max")
+        Yp = torch.empty((self.Ttot, cap), dtype=torch.float32, device=self.dev)
+        ops.gather(Y, Y.stride(0), None, self.Ttot, lst, cap, Yp)
+        cs_p, _ = ops.col_scales_f16(Yp, self.Ttot, cap, want_flag=False)    # (per column, from the same values: the same scales)
+        hp = dict(hat)
+        hp.update(cs=cs_p, split=True, panel=True, live=count[0:1], data_ready=None, series_ready=None)
+        keep = {k: self.info.get(k) for k in ("plain_flops", "plain_launches", "fused_flops", "fused_launches",
+                                              "precision", "fused_alphas", "series_terms", "folds_per_launch")}
+        prev = self.cur
+        self.cur = _Range(0, cap, cap, Yp, None)
+        try:
+            sc = self._sweeps(hp, Yp, None)
+        finally:
+            self.cur = prev
+            self.info.update(keep)                             # (the counters describe the full-width launches)
+        ops.scatter_cols(sc, A, lst, cap, scores)
+        host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        host[1:2].copy_(over, non_blocking=True)
+        host[0:1].copy_(count[1:2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        hat["screen_check"] = (ev, host, V_, cap, bool(self.shard.active))
+        self.info["refine_launch_cols"] = self.info.get("refine_launch_cols", 0) + cap
 
     def _side_cols_of(self, rg):
         """(first position in the side panel, positions' count, range-local column of each) of the side columns that lie in

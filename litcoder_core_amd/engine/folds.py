@@ -229,6 +229,8 @@ class FoldPhases:
         histogram travels to pinned memory asynchronously, so the caller can queue the next fold's sweeps on the
         main stream BEFORE waiting for it in fold_select (the stream then never idles through the host round trip)."""
         self._enter(st)
+        if getattr(self, "debug_scores", None) is not None:      # (tools/screen_probe.py: the score tables of a fit)
+            self.debug_scores.append((st["fold"], st["rg"].c0, st["scores"].clone()))
         st["best"] = self.choose(st["scores"], single_alpha)
         if self.opt.alpha_progress_log and logger.isEnabledFor(logging.INFO):
             # ridge_regression.py:136-139 logs "Alpha=..., mean corr=..." per alpha and inner fold; here the scores exist
@@ -273,6 +275,7 @@ class FoldPhases:
             return st
         if "grouping" not in st:
             self.fold_choose(st, single_alpha)
+        self._screen_check(st, single_alpha)
         best, split = st["best"], st["split"]
         perm, used, tiles, Vs, used_all = self._refit_groups(best, split, st.pop("grouping"))
         self._verify_target_flag(st["rg"])             # (its event lies before the sweeps whose histogram just arrived)
@@ -302,6 +305,35 @@ class FoldPhases:
         st.update(best=best, perm=perm, used=used, used_all=used_all, tiles=tiles, Vs=Vs, split=split, Malpha=Malpha,
                   info_o=info_o, systems_ready=ready)
         return st
+
+    def _screen_check(self, st, single_alpha):
+        """Two-precision inner CV: how many voxels the step's screening pass left undecided (known here, at the step's one
+        host synchronisation; DualSweeps._refine_undecided).  More than the refinement's panel held -- on this rank or, voxel
+        shards, on any -- and the whole range is scored again with the three-MFMA products and chosen again (every rank
+        alike: the choice's histogram is all-reduced); otherwise the share is remembered for the next panels' capacity."""
+        chk = st["hat"].pop("screen_check", None)
+        if chk is None:
+            return
+        ev, host, V, cap, sharded = chk
+        ev.synchronize()
+        found = int(host[0])
+        over = int(host[1]) > 0 if sharded else found > cap
+        self.info["undecided"] = self.info.get("undecided", 0) + min(found, cap)
+        self.info["screened"] = self.info.get("screened", 0) + V
+        if not hasattr(self, "_undecided_fracs"):
+            self._undecided_fracs = []
+        self._undecided_fracs.append(min(found, V) / max(V, 1))
+        if not over:
+            return
+        logger.info("screening pass: %d of %d voxels undecided, the panel held %d: the range is scored again", found, V, cap)
+        self.info["screen_overflows"] = self.info.get("screen_overflows", 0) + 1
+        hat = dict(st["hat"])
+        hat["exact"] = True
+        self._enter(st)
+        st["scores"] = self._sweeps(hat, st["Y"], st["done"])
+        self.info["screen_terms"] = 1                  # (the fit's mode; this range's second scoring is counted above)
+        st.pop("grouping", None)
+        self.fold_choose(st, single_alpha)
 
     def fold_finish(self, st, weight_scale):
         """V-wide half of the refit of one (fold, voxel range) step, test predictions, Pearson r / p-values.  Returns the

@@ -513,10 +513,19 @@ class Refit:
             if any(st["tr_o"].shape[-1] != N_o for st in sts) or any(r.shape[0] != rows for r in rhss):
                 return
             inv = self._ahead_alphas(cho)
-            if inv and len(inv) < len(cho):
+            if inv:
                 # (the inverses of the alphas that qualify, ahead; the others when somebody has chosen them -- each alpha by
                 # its own route: _refit_chol)
                 cho = inv
+            else:
+                # no alpha qualifies for an inverse AHEAD of the choice: ahead by solves only those whose route IS the solves
+                # (a grid like 0.05 / 0.12 -- nothing reaches refit_ahead_min_alpha, 0.12 is above
+                # refit_inverse_min_alpha -- used to send 0.12 through the row-sliced solves here and through the explicit
+                # inverse on one GPU: last-bit differences between a sharded and an unsharded fit); an inverse-route alpha
+                # below the ahead threshold is built when somebody has chosen it, as on one GPU (_refit_chol)
+                cho = [a for a in cho if not self._refit_by_inverse([a])]
+                if not cho:
+                    return
             Gc, nF = len(cho), len(sts)
             a2s = [ops.penalties(st["lmax_o"], 1, self.d_alphas, self.normalpha) for st in sts]
             if self._refit_by_inverse(cho):

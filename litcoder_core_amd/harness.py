@@ -179,9 +179,7 @@ class StoryPipeline:
         if shard is None or shard.world == 1:
             return 0, V, V
         if self.model.local_targets:
-            mine = np.zeros(shard.world)
-            mine[shard.rank] = V
-            return 0, V, int(round(shard.allreduce_sum(mine).sum()))
+            return 0, V, shard.total_of_local_blocks(V)        # (checked on every rank alike: the blocks are bounds()'s)
         lo, hi = shard.bounds(V)
         return lo, hi, V
 

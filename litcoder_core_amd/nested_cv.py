@@ -114,6 +114,7 @@ class NestedCVModel(BasePredictivityModel):
         self.last_form = None
         self.last_fit = {}                             # RidgeCVEngine.info of the most recent fit (+ "form")
         self.last_fold_alphas = None
+        self.debug_scores = None                       # a list: receives (fold, first column, score table) per step
 
     def fit_predict(
         self,
@@ -148,9 +149,7 @@ class NestedCVModel(BasePredictivityModel):
         train_test = X_test is not None and y_test is not None
         V_total = np.shape(targets)[1]
         if self.local_targets and shard.world > 1:
-            mine = np.zeros(shard.world)
-            mine[shard.rank] = V_total
-            V_total = int(round(shard.allreduce_sum(mine).sum()))
+            V_total = shard.total_of_local_blocks(V_total)       # (checked on every rank alike: the blocks are bounds()'s)
         lo, hi = shard.bounds(V_total)
 
         def cols(y):                       # this rank's voxel block (the whole matrix on one GPU): a view, no copy
@@ -260,6 +259,12 @@ class NestedCVModel(BasePredictivityModel):
                                 min_train_rows=min_train, form=form, panels=panels, options=self.options,
                                 down_panels=down_panels)
             self._engine = eng
+            # the inner CV's score tables are consumed by a per-voxel argmax and nothing else (nested_cv.py:405-411): the
+            # engine may screen them (FitOptions.screen_inner).  ONE alpha for all voxels is the argmax of the voxel MEAN
+            # (:396-400): another rule, not screened
+            eng.argmax_only = not bool(single_alpha)
+            if self.debug_scores is not None:
+                eng.debug_scores = self.debug_scores
             drv_opt = getattr(eng, "opt", None) or FitOptions()     # (the tests' oracle-backed engine has none)
             scale = 1.0 if train_test else 1.0 / len(outer)
             fold_scores, fold_p, fold_alpha, fold_sig = [], [], [], []
@@ -486,38 +491,44 @@ class NestedCVModel(BasePredictivityModel):
                 raise
 
         def run(form, X_in=None, Y_in=None):
-            try:
-                return run_(form, None, X_in, Y_in)
-            except _GuessMissed as why:
-                # single_alpha, host inputs: the early panels' alpha was not the alpha of all voxels -- once more, resident
-                eng = self._engine
-                logger.info("single-alpha guess missed (%s): the fit is repeated without it", why)
-                eng.abandon()                           # the early panels' weights may still be on their way to the host
-                torch.cuda.synchronize()
-                # (through the guard as well: a failure of the repeated fit must drain ITS weight panels too -- ADVICE r4)
-                out = run_(form, self.precision, _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
-                out[0].info["single_alpha_guess"] = "missed"
-                return out
-            except _WideTargets as why:
-                # host inputs + precision "auto": a panel that arrived later holds a column too wide for the fp16 split --
-                # once more with everything that is resident by now: the fit then knows ALL its columns up front and moves
-                # only the wide ones to the f32 side path (round 5; the whole fit to the f32 MFMA path when there are too many
-                # of them or the form has no side path -- decided in begin_fit, which cannot raise this again)
-                eng = self._engine
-                logger.info("%s: the fit is repeated with the targets resident", why)
-                eng.finish_uploads()
-                torch.cuda.synchronize()
-                # (targets normalised fold by fold -- normalize_targets -- are looked at fold by fold as well: there is no
-                # decision up front and no side panel for them, the repeated fit takes the f32 path as a whole; and should
-                # a repeated "auto" fit meet a wide column after all, the f32 path is what is left)
-                retry = "f32" if normalize_targets else self.precision
+            """The fit, repeated on what is resident when a shortcut of the first attempt did not hold -- as a LOOP, so that
+            a repeated fit that meets the other condition is handled like a first one (an exception raised inside
+            one ``except`` clause is not caught by its sibling, and a missed single-alpha guess whose repeat met a wide
+            target column escaped with an internal exception)."""
+            precision, missed, wide_tries = None, False, 0
+            while True:
                 try:
-                    return run_(form, retry, _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
-                except _WideTargets as again:
+                    out = run_(form, precision, X_in, Y_in)
+                    if missed:
+                        out[0].info["single_alpha_guess"] = "missed"
+                    return out
+                except _GuessMissed as why:
+                    # single_alpha, host inputs: the early panels' alpha was not the alpha of all voxels -- once more,
+                    # resident (no panels: no guess the second time)
                     eng = self._engine
-                    logger.info("%s: the fit is repeated on the f32 path", again)
+                    logger.info("single-alpha guess missed (%s): the fit is repeated without it", why)
+                    eng.abandon()                       # the early panels' weights may still be on their way to the host
                     torch.cuda.synchronize()
-                    return run_(form, "f32", _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank))
+                    missed = True
+                    precision = self.precision if precision is None else precision
+                except _WideTargets as why:
+                    # host inputs + precision "auto": a panel that arrived later holds a column too wide for the fp16 split
+                    # -- once more with everything that is resident by now: the fit then knows ALL its columns up front and
+                    # moves only the wide ones to the f32 side path (round 5; the whole fit to the f32 MFMA path when there
+                    # are too many of them or the form has no side path -- decided in begin_fit).  Targets normalised fold by
+                    # fold (normalize_targets) are looked at fold by fold as well: no decision up front, no side panel --
+                    # their repeat takes the f32 path as a whole; and should a repeated "auto" fit meet a wide column after
+                    # all, the f32 path is what is left (it never raises this)
+                    eng = self._engine
+                    wide_tries += 1
+                    if wide_tries > 2:
+                        raise RuntimeError(f"the f32 path reported a wide target column ({why})") from None
+                    logger.info("%s: the fit is repeated %s", why,
+                                "with the targets resident" if wide_tries == 1 else "on the f32 path")
+                    eng.finish_uploads()
+                    torch.cuda.synchronize()
+                    precision = "f32" if (normalize_targets or wide_tries == 2) else self.precision
+                X_in, Y_in = _DeviceShapes(eng.dX, eng.p), _DeviceShapes(eng.dY_full, eng.V_rank)
 
         try:
             eng, fold_scores, fold_p, fold_alpha, fold_sig, score_rows, any_nan = run(self.form)

@@ -1017,11 +1017,11 @@ def permute_cols_f16(tiled, perm, Vs, K, out):
 
 
 def alpha_sweep_scores_f16x3(ht, rowscale_inv, A, M, N, yt, cscale_inv, yv, V, n_val, ystat, yblk, mode, part, scores,
-                             accumulate, bview=(0, 0, 0)):
-    """``bview`` = (rows of the tiled image yt, first row of the skipped block, its length); (0, 0, 0): yt holds
-    exactly the N contracted rows."""
-    _lib.call("lc_alpha_sweep_scores_f16x3", _p(ht), _p(rowscale_inv), A, M, N, _p(yt), _p(cscale_inv), _p(yv), V, n_val,
-              _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), *bview, _s())
+                             accumulate, bview=(0, 0, 0), terms=3, live=None):
+    """One inner fold (F = 1 of lc_alpha_sweep_scores_f16x3_folds).  ``bview`` = (rows of the tiled image yt, first row
+    of the skipped block, its length); (0, 0, 0): yt holds exactly the N contracted rows."""
+    alpha_sweep_scores_f16x3_folds(ht, rowscale_inv, A, M, N, yt, cscale_inv, yv, V, [n_val], ystat, yblk, mode, part, scores,
+                                   accumulate, [bview], terms=terms, live=live)
 
 
 def gemm_grouped_f16x3(at, rowscale_inv, Mrows, bt, cscale_inv, c, ldc, Ncols, K, group_tiles, slab_light=None,
@@ -1071,11 +1071,11 @@ def gemm_grouped_f16x3_pearson(at, rowscale_inv, Mrows, bt, cscale_inv, Ncols, K
 
 
 def series_sweep_scores_f16x3(pt, rowscale_inv, M, n_val, K, yt, cscale_inv, Ncols, yv, V, ystat, yblk, coef, aidx, part,
-                              scores, accumulate, bview=(0, 0, 0)):
-    """Series contraction with the moments epilogue + the scores of the series alphas (lc_series_sweep_scores_f16x3)."""
-    _lib.call("lc_series_sweep_scores_f16x3", _p(pt), _p(rowscale_inv), M, n_val, K, _p(yt), _p(cscale_inv), Ncols, _p(yv),
-              V, _p(ystat), _p(yblk), _p(coef), _p(aidx), aidx.numel(), _p(part), _p(scores), int(bool(accumulate)), *bview,
-              _s())
+                              scores, accumulate, bview=(0, 0, 0), terms=3, live=None):
+    """Series contraction with the moments epilogue + the scores of the series alphas, one inner fold (F = 1 of
+    lc_series_sweep_scores_f16x3_folds)."""
+    series_sweep_scores_f16x3_folds(pt, rowscale_inv, M, [n_val], K, yt, cscale_inv, Ncols, yv, V, ystat, yblk, coef, aidx,
+                                    part, scores, accumulate, [bview], terms=terms, live=live)
 
 
 def _fold_arrays(n_vals, views):
@@ -1088,19 +1088,36 @@ def _fold_arrays(n_vals, views):
 
 
 def alpha_sweep_scores_f16x3_folds(ht, rowscale_inv, A, M, N, yt, cscale_inv, yv, V, n_vals, ystat, yblk, mode, part, scores,
-                                   accumulate, views):
-    """All inner folds in one launch (see lc_alpha_sweep_scores_f16x3_folds); views: per fold (b_rows, gap0, gap rows)."""
+                                   accumulate, views, terms=3, live=None):
+    """All inner folds in one launch (see lc_alpha_sweep_scores_f16x3_folds); views: per fold (b_rows, gap0, gap rows).
+    ``terms``: 3 = fp32-level products, 1 = the screening pass (hi planes only); ``live``: device int32 -- only the
+    column tiles below that many columns do any work."""
     F, nv, b_rows, g0, gl = _fold_arrays(n_vals, views)
     _lib.call("lc_alpha_sweep_scores_f16x3_folds", _p(ht), _p(rowscale_inv), F, A, M, N, _p(yt), _p(cscale_inv), _p(yv), V,
-              nv, _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), b_rows, g0, gl, _s())
+              nv, _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), b_rows, g0, gl, int(terms),
+              _p(live), _s())
 
 
 def series_sweep_scores_f16x3_folds(pt, rowscale_inv, M, n_vals, K, yt, cscale_inv, Ncols, yv, V, ystat, yblk, coef, aidx,
-                                    part, scores, accumulate, views):
+                                    part, scores, accumulate, views, terms=3, live=None):
     F, nv, b_rows, g0, gl = _fold_arrays(n_vals, views)
     _lib.call("lc_series_sweep_scores_f16x3_folds", _p(pt), _p(rowscale_inv), F, M, nv, K, _p(yt), _p(cscale_inv), Ncols,
               _p(yv), V, _p(ystat), _p(yblk), _p(coef), _p(aidx), aidx.numel(), _p(part), _p(scores),
-              int(bool(accumulate)), b_rows, g0, gl, _s())
+              int(bool(accumulate)), b_rows, g0, gl, int(terms), _p(live), _s())
+
+
+def undecided_cols(scores, A, V, tau_sum, ystat, cap):
+    """(list (cap,) int32 of the undecided columns of the screening pass' score sums, ascending, -1 behind them; count (3,)
+    int32: columns in the list / undecided columns found / 1 when the list does not hold them all) -- lc_undecided_cols.  ``scores``: (A, >= V) f32 of row stride
+    scores.stride(0); ``ystat``: (3, ld) f32 validation statistics of one inner fold, or None."""
+    dev = scores.device
+    flags = torch.empty(V, dtype=torch.uint8, device=dev)
+    blocks = torch.empty((V + 255) // 256, dtype=torch.int32, device=dev)
+    lst = torch.empty(cap, dtype=torch.int32, device=dev)
+    count = torch.empty(3, dtype=torch.int32, device=dev)
+    _lib.call("lc_undecided_cols", _p(scores), A, scores.stride(0), V, float(tau_sum), _p(ystat),
+              ystat.stride(0) if ystat is not None else 0, _p(flags), _p(blocks), _p(lst), int(cap), _p(count), _s())
+    return lst, count
 
 
 def select_alpha(scores, A, V, want_best=True, want_rowsum=False):

@@ -1,0 +1,171 @@
+"""The two-precision inner CV (round 6; FitOptions.screen_inner): a screening pass with ONE fp16 MFMA per
+product decides the alpha of every voxel whose best two alphas are clearly apart, the others are scored again with the
+three-MFMA products.  nested_cv.py:408-411 only takes each voxel's argmax of the fold-mean scores, so the fit must come out
+as the three-MFMA fit does -- alphas identical, hence weights and test scores bit for bit -- and both must match the oracle.
+Every test here needs a real MI355X:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lc():
+    import litcoder_core_amd as pkg
+    from litcoder_core_amd import ops
+    ops.device()                     # raises (no CPU fallback) when there is no gfx950
+    return pkg
+
+
+def _problem(rng, T, p, V, noise_cols=0.3, signal=0.4):
+    X = rng.standard_normal((T, p))
+    W = rng.standard_normal((p, V)) * (signal / np.sqrt(p))
+    W[:, rng.uniform(size=V) < noise_cols] = 0.0                 # pure-noise voxels: flat score curves, near-ties
+    return X, X @ W + rng.standard_normal((T, V))
+
+
+def test_undecided_columns_kernel_against_numpy(lc):
+    """lc_undecided_cols: the list (ascending, -1 behind), the counts and the overflow flag against numpy, incl. the offset
+    scaling (kappa = rms / std of the validation rows), all-zero columns (decided), non-finite sums (undecided), a capacity
+    smaller than the number found, and widths that are not multiples of the block."""
+    from litcoder_core_amd import ops
+    dev = ops.device()
+    rng = np.random.default_rng(11)
+    for (A, V, ld, cap, tau) in ((20, 5000, 5120, 1024, 0.02), (7, 257, 384, 256, 0.05), (3, 999, 1024, 256, 0.3), (1, 300, 384, 256, 0.1)):
+        sc = rng.uniform(-1, 1, (A, ld)).astype(np.float32)
+        sc[:, 5] = 0.0                                           # constant column: decided
+        sc[0, 6] = np.inf                                        # non-finite: undecided
+        if A > 1:
+            sc[:, 7] = 0.25                                      # exact tie of non-zero sums: undecided
+            sc[:, 8] = -3.0
+            sc[1, 8] = 2.0                                       # clear winner: decided
+        mean = rng.uniform(-3, 3, ld).astype(np.float32)
+        std = rng.uniform(0.5, 2, ld).astype(np.float32)
+        std[9] = 0.0
+        ystat = np.stack([mean, std, std * std]).astype(np.float32)
+        for use_stat in (False, True):
+            lst, cnt = ops.undecided_cols(torch.from_numpy(sc).to(dev), A, V, tau, torch.from_numpy(ystat).to(dev) if use_stat else None, cap)
+            lst, cnt = lst.cpu().numpy(), cnt.cpu().numpy()
+            srt = np.sort(sc[:, :V].astype(np.float32), axis=0)
+            kappa = np.ones(V, dtype=np.float32)
+            if use_stat:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    k = np.sqrt(mean[:V] * mean[:V] + ystat[2, :V]) / std[:V]
+                kappa = np.where((std[:V] > 0) & (k >= 1) & np.isfinite(k), k, 1.0).astype(np.float32)
+            with np.errstate(invalid="ignore"):
+                gap = (srt[-1] - srt[-2]) if A > 1 else np.full(V, np.inf, dtype=np.float32)
+                und = ~(gap >= np.float32(tau) * kappa) if A > 1 else np.zeros(V, dtype=bool)
+            und |= ~np.isfinite(sc[:, :V]).all(0)
+            und &= ~(sc[:, :V] == 0).all(0)
+            want = np.nonzero(und)[0]
+            assert cnt[1] == len(want) and cnt[0] == min(len(want), cap) and cnt[2] == int(len(want) > cap)
+            np.testing.assert_array_equal(lst[:cnt[0]], want[:cap])
+            assert (lst[cnt[0]:] == -1).all()
+            assert not und[5] and und[6]
+            if A > 1:
+                assert und[7] and not und[8]
+
+
+def test_screening_scores_are_close_and_the_panel_is_bitwise(lc):
+    """The screening pass' score table against the three-MFMA table (same operators, same images): close (the error of
+    11-bit operands averaged over the rows), never exact garbage; and the refinement's panel -- the same sweeps on a
+    gathered copy of some columns -- reproduces the three-MFMA scores of those columns bit for bit, wherever they sit in the
+    panel (every V-wide kernel keeps a voxel's arithmetic inside its own column)."""
+    from litcoder_core_amd.nested_cv import RidgeCVEngine
+    from litcoder_core_amd.engine.common import FitOptions
+    rng = np.random.default_rng(5)
+    T, p, V = 640, 200, 1500
+    X, Y = _problem(rng, T, p, V)
+    alphas = np.logspace(-1, 5, 13)
+    tr_o = np.r_[0:128, 256:640]
+    inner = [(np.delete(tr_o, np.s_[k * 128:(k + 1) * 128]), tr_o[k * 128:(k + 1) * 128]) for k in range(4)]
+    e3 = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3")
+    s3, _ = e3._alpha_scores(e3.K, e3.dY, inner)
+    e1 = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3", options=FitOptions(screen_inner=True, screen_tau=0.0))
+    e1.argmax_only = True                                        # (what NestedCVModel's driver tells its engine)
+    s1, _ = e1._alpha_scores(e1.K, e1.dY, inner)
+    assert e1.info["screen_terms"] == 1 and e3.info["screen_terms"] == 3
+    d = (s1[:, :V] - s3[:, :V]).abs().cpu().numpy() / len(inner)
+    assert 1e-8 < d.max() < 3e-4 and np.sqrt((d ** 2).mean()) < 3e-5, (d.max(), np.sqrt((d ** 2).mean()))
+    # tau = +inf-like: every voxel undecided -> with a panel as wide as the range the table IS the three-MFMA table
+    eall = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3",
+                         options=FitOptions(screen_inner=True, screen_tau=1e3, screen_panel_cols=2048))
+    eall.argmax_only = True
+    sall, _ = eall._alpha_scores(eall.K, eall.dY, inner)
+    assert torch.equal(sall[:, :V], s3[:, :V])
+    # a realistic tau: refined columns carry the three-MFMA bits, the others the screening pass' bits
+    emix = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3",
+                         options=FitOptions(screen_inner=True, screen_tau=2e-3 * np.sqrt(512.0), screen_panel_cols=1024))
+    emix.argmax_only = True
+    smix, _ = emix._alpha_scores(emix.K, emix.dY, inner)
+    eq3 = (smix[:, :V] == s3[:, :V]).all(0).cpu().numpy()
+    eq1 = (smix[:, :V] == s1[:, :V]).all(0).cpu().numpy()
+    assert (eq3 | eq1).all() and 10 < eq3.sum() < V and eq1.sum() > 10
+    top = torch.topk(s1[:, :V], 2, dim=0).values
+    und = ((top[0] - top[1]) < 2e-3 * len(inner)).cpu().numpy()
+    assert eq3[und].all(), "every undecided voxel must have been scored again"
+
+
+@pytest.mark.parametrize("case", ["cv", "cv_offset", "traintest", "small_panel"])
+def test_screened_fit_equals_the_three_mfma_fit(lc, case):
+    """Full fits: FitOptions.screen_inner on / off -> the same alphas in every fold, hence the same weights, correlations and
+    p-values bit for bit.  cv_offset: targets riding on large per-voxel offsets (the rms / std scaling of the gap sends them
+    to the refinement); small_panel: a forced 256-column panel that cannot hold the undecided voxels -- the overflow path
+    (the range is scored again) must give the same fit."""
+    from litcoder_core_amd import NestedCVModel
+    from litcoder_core_amd.engine.common import FitOptions
+    rng = np.random.default_rng({"cv": 1, "cv_offset": 2, "traintest": 3, "small_panel": 4}[case])
+    T, p, V = 900, 300, 3000
+    X, Y = _problem(rng, T, p, V, noise_cols=0.5)
+    if case == "cv_offset":
+        Y = Y + rng.uniform(-300, 300, V)[None, :] * (rng.uniform(size=V) < 0.5)
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=4, alphas=np.logspace(-1, 6, 15))
+    opts = dict(screen_inner=True)
+    if case == "small_panel":
+        opts.update(screen_tau=0.1, screen_panel_cols=256)
+    extra = {}
+    if case == "traintest":
+        Xt, Yt = X[700:], Y[700:]
+        X, Y = X[:700], Y[:700]
+        extra = dict(X_test=Xt, y_test=Yt)
+        kw.pop("n_outer_folds")
+    m3 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(screen_inner=False))
+    out3 = m3.fit_predict(X, Y, **extra, **kw)
+    m1 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(**opts))
+    out1 = m1.fit_predict(X, Y, **extra, **kw)
+    assert m1.last_fit["screen_terms"] == 1 and m3.last_fit["screen_terms"] == 3
+    assert 0 < m1.last_fit["undecided"] < m1.last_fit["screened"]
+    if case == "small_panel":
+        assert m1.last_fit.get("screen_overflows", 0) >= 1
+    else:
+        assert m1.last_fit.get("screen_overflows", 0) == 0, m1.last_fit
+        assert m1.last_fit["undecided"] < 0.5 * m1.last_fit["screened"]
+    for a3, a1 in zip(m3.last_fold_alphas, m1.last_fold_alphas):
+        np.testing.assert_array_equal(a1, a3)
+    np.testing.assert_array_equal(out1[2], out3[2])
+    np.testing.assert_array_equal(out1[1], out3[1])
+    for key in ("correlations", "p_values", "corrected_p_values", "significant_mask"):
+        if key in out3[0]:
+            np.testing.assert_array_equal(np.asarray(out1[0][key]), np.asarray(out3[0][key]), err_msg=key)
+    assert out1[0]["median_score"] == out3[0]["median_score"]
+
+
+def test_screened_fit_against_the_oracle(lc):
+    """... and against the CPU oracle (the reference's algorithm), with the rule of tests/_oracle_check.py: every alpha
+    that differs from the oracle's must be a near-tie of the ORACLE's own fold-mean score table."""
+    import oracle.nested_cv as onc
+    from litcoder_core_amd import NestedCVModel
+    from litcoder_core_amd.engine.common import FitOptions
+    from _oracle_check import assert_matches_oracle
+    rng = np.random.default_rng(21)
+    T, p, V = 600, 192, 700
+    X, Y = _problem(rng, T, p, V, noise_cols=0.4)
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 6, 12))
+    detail = {}
+    orc = onc.fit_predict(X, Y, detail=detail, **kw)
+    model = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(screen_inner=True))
+    ours = model.fit_predict(X, Y, **kw)
+    assert model.last_fit["screen_terms"] == 1
+    assert_matches_oracle(lc, model, ours, orc, detail, X, Y, kw, "screened fit vs oracle")
