@@ -536,6 +536,72 @@ def parity_of(res16, res32, dev):
                     "ties against the oracle)"}
 
 
+
+def preproc_leg(dev, cpu=True, reps=20):
+    """The two preprocessing steps that feed the fit, through the PUBLIC API, host arrays in -> host arrays out, with the
+    kernels' own HIP-event time (the library's timers, on the launch stream) priced against the HBM roof on the ALGORITHMIC
+    bytes of SURVEY 8d, and the oracle's CPU time for the same call on this box:
+      * FIR.make_delayed, 3000 x 768 float64, delays 1..4  (FIR_expander.py:24-43);  bytes = nt ndim (8 + nd 8)
+      * Downsampler.downsample(method="lanczos"), one story: 2500 words x 768 float64 -> 350 TRs  (interpdata.py:87-126);
+        bytes = n_old D 8 + n_new D 8
+      * the same resampling for the 27 stories of cfg3 in ONE launch (what harness.StoryPipeline issues)."""
+    from litcoder_core_amd import FIR, Downsampler, ops
+    import oracle.fir as ofir
+    import oracle.lanczos as olz
+    rng = np.random.default_rng(4)
+    PEAK = 8000.0                                              # GB/s, MI355X_MICROARCH.md "HBM3E ~8 TB/s"
+    out = {"hbm_peak_gbs": PEAK}
+
+    def run(tag, fn, slot, nbytes, cpu_fn, what):
+        fn()                                                   # warm-up (module load, page-locking)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        host_ms = 1e3 * (time.perf_counter() - t0) / 3
+        ops.timing_enable(True, only=[slot])
+        ops.timing_read()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        ms, n = ops.timing_read().get(slot, (0.0, 0))
+        ops.timing_enable(False)
+        per = ms / max(n, 1) * max(n // reps, 1)               # kernel time of ONE call (its launches together)
+        ent = {"what": what, "api_host_to_host_ms": host_ms, "kernel_ms": per, "kernel_launches_per_call": n // reps,
+               "algorithmic_bytes": nbytes, "achieved_gbs": (nbytes / (per * 1e-3) / 1e9) if per > 0 else None}
+        ent["frac_of_hbm_peak"] = ent["achieved_gbs"] / PEAK if ent["achieved_gbs"] else None
+        if cpu and cpu_fn is not None:
+            t0 = time.perf_counter()
+            cpu_fn()
+            ent["cpu_oracle_ms"] = 1e3 * (time.perf_counter() - t0)
+            ent["cpu_cores"] = int(torch.get_num_threads())
+        out[tag] = ent
+
+    X0 = rng.standard_normal((T, F0))
+    run("fir_make_delayed", lambda: FIR.make_delayed(X0, DELAYS), "fir_delay", T * F0 * (8 + len(DELAYS) * 8),
+        lambda: ofir.make_delayed(X0, DELAYS), f"FIR.make_delayed({T}x{F0} float64, delays {DELAYS}) -> ({T}, {F0 * len(DELAYS)}) float64")
+    n_old, n_new = 2500, 350
+    wt = np.sort(rng.uniform(0, 700, n_old))
+    tr = 1.0 + 2.0 * np.arange(n_new)
+    emb = rng.standard_normal((n_old, F0))
+    ds = Downsampler()
+    run("lanczos_one_story", lambda: ds.downsample(emb, wt, tr, method="lanczos", window=3, cutoff_mult=1.0), "lanczos_interp",
+        (n_old + n_new) * F0 * 8, lambda: olz.lanczos_interp(emb, wt, tr, 3, 1.0),
+        f"Downsampler.downsample(lanczos, window 3): {n_old} words x {F0} float64 -> {n_new} TRs")
+    # cfg3's 27 stories in one launch: resident float32 word features (as harness.StoryPipeline holds them)
+    words, wtimes, trtimes, _ = synth_stories(256, dev)
+    names = list(words)
+    cat = torch.from_numpy(np.concatenate([words[s] for s in names])).to(dev)
+    nb = sum(words[s].shape[0] * words[s].shape[1] * 4 + len(trtimes[s]) * words[s].shape[1] * 8 for s in names)
+    run("lanczos_27_stories_one_launch",
+        lambda: ops.lanczos_interp_stories(cat, [wtimes[s] for s in names], [trtimes[s] for s in names], 3, 1.0, False),
+        "lanczos_interp", nb, None,
+        f"lc_lanczos_interp_stories: {cat.shape[0]} words x {cat.shape[1]} float32 (resident) -> {sum(len(trtimes[s]) for s in names)} TRs float64, "
+        "27 stories, one launch (device in -> device out: no host leg)")
+    out["lanczos_27_stories_one_launch"]["api_host_to_host_ms"] = None
+    return out
+
+
 def step_stats(step_ms, voxels):
     """min / median / max of the timed steps as rank 0's host saw them (every host-to-host step is fenced, so a step's time is
     one call's latency), and the rate at the median step: a slow outlier step moves `value` (total / total), not this."""
@@ -844,6 +910,8 @@ def main():
                 out["parity_vs_f32_path"] = parity_of(res, r32, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dX, dY, p, V, alphas)
+        if world == 1 and not args.no_extra_legs:
+            out["preproc"] = preproc_leg(dev, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_extra_legs and not args.no_cfg3:
             del dX, dY
             torch.cuda.empty_cache()

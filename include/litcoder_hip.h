@@ -286,11 +286,15 @@ int lc_gram_f64(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_k
 int lc_gram_f64_mfma(const float* d_x, int64_t ldx, int64_t T, int64_t p, double* d_work, double* d_k,
                      int64_t ldk, lc_stream_t stream);
 
-/* Largest eigenvalue of K[rows_f, rows_f] for F row lists (each N entries, -1 padded)
- * by `steps` Lanczos iterations + bisection: S[0]^2 of the fold's design matrix
- * (ridge_regression.py:39,97 `norm = S[0].item()`).  d_work: F*(3*N + 2*steps + 8) f64.
- * d_lmax: (F) f64. */
-int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, int N, int steps,
+/* S[0]^2 of a fold's design matrix (ridge_regression.py:39,97 `norm = S[0].item()`) = the largest eigenvalue of a Gram
+ * block, by `steps` Lanczos iterations + bisection.  THREE entry points since round 6 (ten variants before), one per
+ * way the systems are given:
+ *   lc_lambda_max         F row lists (each N entries, -1 padded) into matrix f at d_k + f k_stride (k_stride = 0: all
+ *                         lists index ONE matrix, the dual form's K; rows_per^2: the primal form's Gram block of fold f);
+ *   lc_lambda_max_masked  up to 32 row sets of one matrix as membership bits, one pass over K per iteration;
+ *   lc_lambda_max_dense   the leading n x n blocks of F matrices, streaming matvec.
+ * d_work: F*(3*N + 2*steps + 8) f64.  d_lmax: (F) f64. */
+int lc_lambda_max(const double* d_k, int64_t ldk, int64_t k_stride, const int32_t* d_rows, int F, int N, int steps,
                   double* d_work, double* d_lmax, lc_stream_t stream);
 
 /* The same for up to 32 row sets of ONE Gram matrix in a single pass over K per iteration: bit f of
@@ -298,20 +302,13 @@ int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, 
  * train sets and their inner train sets) is a principal submatrix of K, so one call serves the whole fit.
  * d_work: F*(3*T + 2*steps + 8) + 16*32*T f64 (the matvec -- K times the 32 systems' vectors on the fp64 MFMA -- is
  * split over up to 16 column ranges whose partial sums are added in fixed order).  d_lmax: (F) f64.
- * lc_lambda_max_masked_opt: use_mfma = 0 takes the vector-ALU matvec of round 1 (a per-call choice: the library has no
- * process-wide switches). */
-int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
-                         double* d_work, double* d_lmax, lc_stream_t stream);
-int lc_lambda_max_masked_opt(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
-                             double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream);
-/* ... with a convergence stop (round 5): `steps` is the most a system runs; every 8 steps from the 24th on its top Ritz
+ * use_mfma = 0 takes the vector-ALU matvec of round 1 (a per-call choice: the library has no process-wide switches).
+ * tol: a convergence stop (round 5): `steps` is the most a system runs; every 8 steps from the 24th on its top Ritz
  * value is looked at, and the system stops once that value has moved by <= tol (relative) over the last 8 steps (tol = 0:
- * never; the later launches of a stopped system return at once, the matvec launches once every system has stopped).  The
- * top Ritz value converges geometrically (1e-3 per 16 steps on the bench designs): a move of <= 1e-6 over 8 steps leaves
- * an error of ~3e-8 -- below the fp32 epsilon of everything downstream, and of the reference's own S[0], an fp32 SVD
- * value (ridge_regression.py:39,97). */
-int lc_lambda_max_masked_tol(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps, double tol,
-                             double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream);
+ * never -- the default of every caller: a run short of the top eigenvector can sit on the SECOND eigenvalue for a while,
+ * which such a stop takes for convergence; profiles/r05_lanczos_stop_misfire.txt). */
+int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps, double tol,
+                         double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream);
 /* Systems that are the LEADING n x n blocks of their own matrices (the primal form's p x p Gram matrices: matrix f at
  * d_k + f k_stride, no row lists): a streaming matvec (16-byte loads, the vector through LDS), the same recurrence, the
  * same stop.  N = padded vector length (>= n, even); d_work: F*(3*N + 2*steps + 8) f64, 16-byte aligned like d_k. */
@@ -349,15 +346,13 @@ int lc_batch_assemble_sel(const double* d_k, int64_t ldk, int64_t k_fold_stride,
  *                            N); -1 -> zero row; -(2 + c) -> unit row e_c: the augmented rows Pstim (inner folds) /
  *                            [I ; X_test] (refit: weights operator above the test-row hat matrix);
  *   lc_batch_assemble_sel with k_fold_stride = rows_per^2 then takes the top block of fold f from ITS Gram matrix
- *   (0 = one shared matrix, the dual form), and lc_lambda_max_strided does the same for S[0]^2. */
+ *   (0 = one shared matrix, the dual form), and lc_lambda_max's k_stride does the same for S[0]^2. */
 int lc_gather_transpose_f32(const float* d_x, int64_t ldx, const int32_t* d_rows, int F, int N, int p,
                             int p_pad, float* d_out, lc_stream_t stream);
 int lc_gram_blocks_f64(const float* d_xt, int64_t ldx, int n_blocks, int rows_per, int depth, double* d_g,
                        lc_stream_t stream);
 int lc_gather_rows_f64(const float* d_x, int64_t ldx, const int32_t* d_rows, int F, int M, int p, int N,
                        double* d_out, lc_stream_t stream);
-int lc_lambda_max_strided(const double* d_k, int64_t ldk, int64_t k_stride, const int32_t* d_rows, int F, int N,
-                          int steps, double* d_work, double* d_lmax, lc_stream_t stream);
 
 /* Primal form for a handful of features, p <= 16 (csrc/lc_primal.hip): every statistic the nested CV takes from a
  * prediction X w is a linear / quadratic form in w = (G + a^2 I)^-1 Rstim'y, so the V-wide work of an outer fold is one
@@ -400,9 +395,11 @@ int lc_primal_refit(const double* d_part, int RS, int chunk, const int32_t* d_nr
  * i.e. the hat matrices  Xva Xtr' (Xtr Xtr' + a^2 I)^-1  (= Pstim Vh' diag(S/(S^2+a^2)) U',
  * ridge_regression.py:104-105,117-120).  Result written as f32 to d_h (B, M, N).
  * d_linv: workspace (B, N/LC_NB, LC_NB, LC_NB) f64.  d_info: (B) int32, nonzero = failed pivot.
- * d_slot: optional (B) int32, system b is written to slot d_slot[b] of d_h (NULL = b). */
-int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
-                        const int32_t* d_slot, int32_t* d_info, lc_stream_t stream);
+ * d_slot: optional (B) int32, system b is written to slot d_slot[b] of d_h (NULL = b).
+ * opt: per-call variants (lc_chol_options below; NULL = the defaults). */
+struct lc_chol_options;
+int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,
+                        int32_t* d_info, const struct lc_chol_options* opt, lc_stream_t stream);
 
 /* The explicit inverse of the same top blocks: d_aug (B, 2N, N) f64 with the N x N IDENTITY as bottom block (the
  * caller assembles it like any other right-hand side); d_p (B, N, N) f32 <- (top)^-1.  Same kernels; the rows of
@@ -411,7 +408,7 @@ int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, floa
  * N^3/3 + 2 N^3.  The refit applies  [Xtr' ; K[te,tr]] (K + a^2 I)^-1  (ridge_regression.py:56-61, nested_cv.py:151) as a
  * product with this inverse on the fp16x3 MFMA where its accuracy allows. */
 int lc_batch_chol_inverse(double* d_aug, int B, int N, double* d_linv, float* d_p, const int32_t* d_slot,
-                          int32_t* d_info, lc_stream_t stream);
+                          int32_t* d_info, const struct lc_chol_options* opt, lc_stream_t stream);
 
 /* The variants of lc_batch_chol_solve / lc_batch_chol_inverse as PER-CALL options (NULL = the defaults); the library
  * keeps no process-wide switches, so fits with different settings coexist in one process:
@@ -425,10 +422,7 @@ int lc_batch_chol_inverse(double* d_aug, int B, int N, double* d_linv, float* d_
 typedef struct lc_chol_options {
     int outer_block, big_kernel, fused_steps, left_deep, persistent;
 } lc_chol_options;
-int lc_batch_chol_solve_opt(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,
-                            int32_t* d_info, const lc_chol_options* opt, lc_stream_t stream);
-int lc_batch_chol_inverse_opt(double* d_aug, int B, int N, double* d_linv, float* d_p, const int32_t* d_slot,
-                              int32_t* d_info, const lc_chol_options* opt, lc_stream_t stream);
+/* (round 6: the option pointer is a parameter of the two entry points above; the *_opt twins are gone) */
 
 /* The same hat matrices for alphas whose penalty dwarfs the spectrum, as a polynomial in K[tr,tr]:
  *   K[va,tr] (K[tr,tr] + a^2 I)^-1  ~=  sum_{j<terms} c_sj K[va,tr] K[tr,tr]^j / scale_f^(j+1)

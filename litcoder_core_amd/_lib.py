@@ -52,8 +52,8 @@ SIGNATURES = {
     "lc_pearson_pvalues": (c_int, [_ptr, c_int64, c_int64, _ptr, _ptr]),
     "lc_gram_f64": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, c_int64, _ptr]),
     "lc_gram_f64_mfma": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, c_int64, _ptr]),
-    "lc_lambda_max": (c_int, [_ptr, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
-    "lc_lambda_max_masked": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, _ptr, _ptr, _ptr]),
+    "lc_lambda_max": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
+    "lc_lambda_max_masked": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, c_double, _ptr, _ptr, c_int, _ptr]),
     "lc_penalties": (c_int, [_ptr, c_int, _ptr, c_int, c_int, _ptr, _ptr]),
     "lc_batch_assemble": (c_int, [_ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr]),
     "lc_batch_assemble_sel": (c_int, [_ptr, c_int64, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, c_int, c_int, c_int, c_int, _ptr,
@@ -71,7 +71,6 @@ SIGNATURES = {
                                  c_int, _ptr, c_int64, _ptr]),
     "lc_primal_refit": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, c_int64, c_int64, c_int, c_int, _ptr, _ptr, _ptr,
                                 c_int, c_float, _ptr, c_int64, _ptr, _ptr]),
-    "lc_lambda_max_strided": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr]),
     "lc_fill_argmax": (c_int, [_ptr, c_int, _ptr, c_int64, _ptr]),
     "lc_accumulate_f64": (c_int, [_ptr, _ptr, c_int64, _ptr]),
     "lc_fold_pack": (c_int, [_ptr, _ptr, _ptr, c_int64, _ptr, c_int64, _ptr, c_int, _ptr, c_int, _ptr, c_int64, _ptr]),
@@ -96,12 +95,8 @@ SIGNATURES = {
     "lc_batch_spectral_apply": (c_int, [_ptr, _ptr, c_int, c_int, _ptr, c_int, _ptr, c_int, c_double, _ptr, _ptr, c_int64, _ptr,
                                         POINTER(c_int32), _ptr, _ptr]),
     "lc_fold_unpack": (c_int, [_ptr, c_int, c_int64, _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    "lc_batch_chol_solve": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    "lc_batch_chol_inverse": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    "lc_batch_chol_solve_opt": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    "lc_batch_chol_inverse_opt": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
-    "lc_lambda_max_masked_opt": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, _ptr, _ptr, c_int, _ptr]),
-    "lc_lambda_max_masked_tol": (c_int, [_ptr, c_int64, c_int, _ptr, c_int, c_int, c_double, _ptr, _ptr, c_int, _ptr]),
+    "lc_batch_chol_solve": (c_int, [_ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "lc_batch_chol_inverse": (c_int, [_ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_lambda_max_dense": (c_int, [_ptr, c_int64, c_int64, c_int, c_int, c_int, c_int, c_double, _ptr, _ptr, _ptr]),
     "lc_batch_series_hat": (c_int, [_ptr, c_int64, _ptr, _ptr, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int, c_int, c_int,
                                     _ptr, _ptr, _ptr]),

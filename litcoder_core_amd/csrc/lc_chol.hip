@@ -928,25 +928,15 @@ static lc_chol_options chol_defaults() { return lc_chol_options{512, 2, 1, 0, 1}
 static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,
                            int32_t* d_info, lc_stream_t stream, bool inverse, const lc_chol_options* opt);
 
-extern "C" int lc_batch_chol_solve_opt(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
-                                       const int32_t* d_slot, int32_t* d_info, const lc_chol_options* opt,
-                                       lc_stream_t stream) {
+extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
+                                   const int32_t* d_slot, int32_t* d_info, const lc_chol_options* opt,
+                                   lc_stream_t stream) {
     return chol_solve_impl(d_aug, B, N, M, d_linv, d_h, d_slot, d_info, stream, false, opt);
 }
 
-extern "C" int lc_batch_chol_inverse_opt(double* d_aug, int B, int N, double* d_linv, float* d_p, const int32_t* d_slot,
-                                         int32_t* d_info, const lc_chol_options* opt, lc_stream_t stream) {
-    return chol_solve_impl(d_aug, B, N, N, d_linv, d_p, d_slot, d_info, stream, true, opt);
-}
-
-extern "C" int lc_batch_chol_solve(double* d_aug, int B, int N, int M, double* d_linv, float* d_h,
-                                   const int32_t* d_slot, int32_t* d_info, lc_stream_t stream) {
-    return chol_solve_impl(d_aug, B, N, M, d_linv, d_h, d_slot, d_info, stream, false, nullptr);
-}
-
 extern "C" int lc_batch_chol_inverse(double* d_aug, int B, int N, double* d_linv, float* d_p, const int32_t* d_slot,
-                                     int32_t* d_info, lc_stream_t stream) {
-    return chol_solve_impl(d_aug, B, N, N, d_linv, d_p, d_slot, d_info, stream, true, nullptr);
+                                     int32_t* d_info, const lc_chol_options* opt, lc_stream_t stream) {
+    return chol_solve_impl(d_aug, B, N, N, d_linv, d_p, d_slot, d_info, stream, true, opt);
 }
 
 static int chol_solve_impl(double* d_aug, int B, int N, int M, double* d_linv, float* d_h, const int32_t* d_slot,

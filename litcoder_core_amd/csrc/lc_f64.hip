@@ -887,8 +887,8 @@ extern "C" int lc_gather_rows_f64(const float* d_x, int64_t ldx, const int32_t* 
     return lc::launched("k_gather_rows_f64");
 }
 
-extern "C" int lc_lambda_max_strided(const double* d_k, int64_t ldk, int64_t k_stride, const int32_t* d_rows, int F,
-                                     int N, int steps, double* d_work, double* d_lmax, lc_stream_t stream) {
+extern "C" int lc_lambda_max(const double* d_k, int64_t ldk, int64_t k_stride, const int32_t* d_rows, int F,
+                             int N, int steps, double* d_work, double* d_lmax, lc_stream_t stream) {
     LC_REQUIRE(d_k && d_rows && d_work && d_lmax, LC_E_BADARG, "lc_lambda_max: null pointer");
     LC_REQUIRE(F > 0 && F <= 65535 && N > 0 && steps > 0 && k_stride >= 0, LC_E_SHAPE, "lc_lambda_max: bad shape");
     hipStream_t s = lc::as_stream(stream);
@@ -903,11 +903,6 @@ extern "C" int lc_lambda_max_strided(const double* d_k, int64_t ldk, int64_t k_s
     if (int rc = lc::launched("k_lz_step")) return rc;
     hipLaunchKernelGGL(k_lz_eig, dim3(F), dim3(64), 0, s, N, steps, d_work, d_lmax);
     return lc::launched("k_lz_eig");
-}
-
-extern "C" int lc_lambda_max(const double* d_k, int64_t ldk, const int32_t* d_rows, int F, int N, int steps,
-                             double* d_work, double* d_lmax, lc_stream_t stream) {
-    return lc_lambda_max_strided(d_k, ldk, 0, d_rows, F, N, steps, d_work, d_lmax, stream);
 }
 
 extern "C" int lc_lambda_max_dense(const double* d_k, int64_t ldk, int64_t k_stride, int F, int N, int n, int steps,
@@ -937,17 +932,7 @@ extern "C" int lc_lambda_max_dense(const double* d_k, int64_t ldk, int64_t k_str
 // (k_lz_symv_multi) -- a per-call choice, no process-wide switch
 
 extern "C" int lc_lambda_max_masked(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
-                                    double* d_work, double* d_lmax, lc_stream_t stream) {
-    return lc_lambda_max_masked_opt(d_k, ldk, T, d_member, F, steps, d_work, d_lmax, 1, stream);
-}
-
-extern "C" int lc_lambda_max_masked_opt(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
-                                        double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream) {
-    return lc_lambda_max_masked_tol(d_k, ldk, T, d_member, F, steps, 0.0, d_work, d_lmax, use_mfma, stream);
-}
-
-extern "C" int lc_lambda_max_masked_tol(const double* d_k, int64_t ldk, int T, const uint32_t* d_member, int F, int steps,
-                                        double tol, double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream) {
+                                    double tol, double* d_work, double* d_lmax, int use_mfma, lc_stream_t stream) {
     LC_REQUIRE(d_k && d_member && d_work && d_lmax, LC_E_BADARG, "lc_lambda_max_masked: null pointer");
     LC_REQUIRE(F > 0 && F <= 32 && T > 0 && steps > 0 && ldk >= T && tol >= 0.0, LC_E_SHAPE,
                "lc_lambda_max_masked: need 1 <= F <= 32 systems, T > 0, steps > 0, tol >= 0");

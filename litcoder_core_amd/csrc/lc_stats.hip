@@ -260,6 +260,11 @@ struct FoldRows {
 // ------------------------------------------------------------------ Pearson r per column
 constexpr int PR_RG = 16;
 
+// ONE pass over both operands (round 6; two before: the second pass missed L2 and the kernel ran at 0.24 of the HBM roof):
+// every thread sums  d = x - x0  about the column's FIRST-ROW values (a sample of the same column: the centred sums that
+// follow lose a digit or two of sixteen, and a constant column gives exact zeros -> 0 / 0 = NaN as before) with
+// PR_UNROLL independent loads of each operand in flight; fp64 throughout, fixed reduction order.
+constexpr int PR_UNROLL = 8;
 __global__ void __launch_bounds__(64 * PR_RG) k_pearson_cols(const float* __restrict__ a, long long lda,
                                                              const float* __restrict__ b, long long ldb,
                                                              long long n, long long V, double* __restrict__ r_out) {
@@ -267,27 +272,39 @@ __global__ void __launch_bounds__(64 * PR_RG) k_pearson_cols(const float* __rest
     const int ty = __builtin_amdgcn_readfirstlane(threadIdx.y);      // row group = wave: scalar row offsets
     const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
     const bool live = c < V;
-    double sa = 0.0, sb = 0.0;
+    const float a0 = live ? a[c] : 0.f, b0 = live ? b[c] : 0.f;
+    double sa = 0.0, sb = 0.0, qa = 0.0, qb = 0.0, qab = 0.0;
     if (live)
-        for (long long i = ty; i < n; i += PR_RG) {
-            sa += (double)a[i * lda + c];
-            sb += (double)b[i * ldb + c];
+        for (long long i0 = ty; i0 < n; i0 += (long long)PR_RG * PR_UNROLL) {
+            float va[PR_UNROLL], vb[PR_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PR_UNROLL; ++u) {
+                const long long i = i0 + (long long)u * PR_RG;
+                va[u] = i < n ? a[i * lda + c] : a0;                 // (past the last row: the shift itself, d = 0)
+                vb[u] = i < n ? b[i * ldb + c] : b0;
+            }
+#pragma unroll
+            for (int u = 0; u < PR_UNROLL; ++u) {
+                const double da = (double)va[u] - (double)a0, db = (double)vb[u] - (double)b0;
+                sa += da;
+                sb += db;
+                qa += da * da;
+                qb += db * db;
+                qab += da * db;
+            }
         }
-    const double ma = block_colsum<PR_RG>(sa, sm) / (double)n;
-    const double mb = block_colsum<PR_RG>(sb, sm) / (double)n;
-    double qa = 0.0, qb = 0.0, qab = 0.0;
-    if (live)
-        for (long long i = ty; i < n; i += PR_RG) {
-            const double da = (double)a[i * lda + c] - ma;
-            const double db = (double)b[i * ldb + c] - mb;
-            qa += da * da;
-            qb += db * db;
-            qab += da * db;
-        }
+    sa = block_colsum<PR_RG>(sa, sm);
+    sb = block_colsum<PR_RG>(sb, sm);
     qa = block_colsum<PR_RG>(qa, sm);
     qb = block_colsum<PR_RG>(qb, sm);
     qab = block_colsum<PR_RG>(qab, sm);
     if (live && ty == 0) {
+        const double inv = 1.0 / (double)n;
+        qa -= sa * sa * inv;
+        qb -= sb * sb * inv;
+        qab -= sa * sb * inv;
+        if (qa < 0.0) qa = 0.0;                      // (rounding of the shifted form; the two-pass form cannot go below 0)
+        if (qb < 0.0) qb = 0.0;
         double r = qab / (sqrt(qa) * sqrt(qb));       // 0/0 -> NaN for a constant column
         if (r > 1.0) r = 1.0;
         if (r < -1.0) r = -1.0;

@@ -105,6 +105,10 @@ class FitOptions:
                                             # prediction errors averaged over those rows -- measured rms 3.7e-6, max 4.1e-5 over
                                             # 8e6 scores at cfg2 (2400 rows: gap 1.0e-4 = 27 rms; the largest gap of a voxel
                                             # whose screening argmax was wrong: 1.4e-5; profiles/r06_screen_probe_cfg2.txt)
+    screen_max_undecided: float = 0.35      # ... once a step reports a larger share of undecided voxels the rest of the fit is
+                                            # scored on three MFMAs throughout (flat score curves -- pure-noise voxels on the
+                                            # plateau of the large alphas, where neighbouring alphas agree to fp32 rounding --
+                                            # cannot be decided by screening; scoring most voxels twice costs more than it saves)
     screen_panel_cols: int = 0              # ... columns of the refinement's panel (0: adaptive, _refine_capacity; tests force
                                             # the overflow path with a small value)
     alpha_progress_log: bool = dataclasses.field(       # per-alpha progress lines (ridge_regression.py:136-139): a device

@@ -281,7 +281,7 @@ class DualSweeps:
         terms = 1 if (self.opt.screen_inner and getattr(self, "argmax_only", False) and moments and split
                       and self.mode == LC_SCORE_CORR and N % 64 == 0 and not panel and not hat.get("exact")) else 3
         if not panel:
-            self.info["screen_terms"] = terms
+            self.info["screen_terms"] = min(self.info.get("screen_terms", 3), terms)     # (1: some step of the fit screened)
         folds = [(f0 + j, j, H, P) for f0, fc, H, P in hat["Hs"] for j in range(fc)]
         # the operators' fp16 images made with the hat matrices (_hat_matrices), per chunk: fold f0 + j is group j
         imgs = hat.get("imgs") or [None] * len(hat["Hs"])
@@ -435,9 +435,11 @@ class DualSweeps:
         # (the table holds SUMS over the F folds: the gap of the fold means x F)
         tau_sum = self.opt.screen_tau * F / float(np.sqrt(max(int(n_val_rows), 1)))
         lst, count = ops.undecided_cols(scores, A, V_, tau_sum, ystat0, cap)
-        over = count[2:3]                                      # "the panel does not hold them all": MAX over the voxel shards --
-        if self.shard.active:                                  # every rank must take the same decision in fold_select
-            self.shard.all_reduce_(over, "max")
+        # voxel shards: every rank must take the same decisions in fold_select -- score the range again (the choice that
+        # follows all-reduces its histogram) and switch the screening off (this very all-reduce would then be missing on one
+        # rank): (undecided columns found, "the panel does not hold them all") as the MAX over the ranks, in place
+        if self.shard.active:
+            self.shard.all_reduce_(count[1:3], "max")
         Yp = torch.empty((self.Ttot, cap), dtype=torch.float32, device=self.dev)
         ops.gather(Y, Y.stride(0), None, self.Ttot, lst, cap, Yp)
         cs_p, _ = ops.col_scales_f16(Yp, self.Ttot, cap, want_flag=False)    # (per column, from the same values: the same scales)
@@ -454,8 +456,7 @@ class DualSweeps:
             self.info.update(keep)                             # (the counters describe the full-width launches)
         ops.scatter_cols(sc, A, lst, cap, scores)
         host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-        host[1:2].copy_(over, non_blocking=True)
-        host[0:1].copy_(count[1:2], non_blocking=True)
+        host.copy_(count[1:3], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         hat["screen_check"] = (ev, host, V_, cap, bool(self.shard.active))

@@ -316,13 +316,18 @@ class FoldPhases:
             return
         ev, host, V, cap, sharded = chk
         ev.synchronize()
-        found = int(host[0])
-        over = int(host[1]) > 0 if sharded else found > cap
+        found = int(host[0])                           # (voxel shards: the largest count of any rank)
+        over = int(host[1]) > 0
         self.info["undecided"] = self.info.get("undecided", 0) + min(found, cap)
         self.info["screened"] = self.info.get("screened", 0) + V
         if not hasattr(self, "_undecided_fracs"):
             self._undecided_fracs = []
         self._undecided_fracs.append(min(found, V) / max(V, 1))
+        if self._undecided_fracs[-1] > self.opt.screen_max_undecided and self.opt.screen_panel_cols == 0:
+            # most voxels scored twice: no gain -- the steps queued from here on take the three-MFMA sweeps throughout (this
+            # engine's own copy of the options; voxel shards: from all-reduced counts, every rank alike)
+            self.opt.screen_inner = False
+            self.info["screen_switched_off"] = True
         if not over:
             return
         logger.info("screening pass: %d of %d voxels undecided, the panel held %d: the range is scored again", found, V, cap)
@@ -331,7 +336,6 @@ class FoldPhases:
         hat["exact"] = True
         self._enter(st)
         st["scores"] = self._sweeps(hat, st["Y"], st["done"])
-        self.info["screen_terms"] = 1                  # (the fit's mode; this range's second scoring is counted above)
         st.pop("grouping", None)
         self.fold_choose(st, single_alpha)
 

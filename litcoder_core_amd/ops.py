@@ -610,17 +610,17 @@ def gram(x, T, p):
 def lambda_max(k, rows, F, N, steps):
     work = torch.empty(F * (3 * N + 2 * steps + 8), dtype=torch.float64, device=k.device)
     out = torch.empty(F, dtype=torch.float64, device=k.device)
-    _lib.call("lc_lambda_max", _p(k), k.stride(0), _p(rows), F, N, steps, _p(work), _p(out), _s())
+    _lib.call("lc_lambda_max", _p(k), k.stride(0), 0, _p(rows), F, N, steps, _p(work), _p(out), _s())
     return out
 
 
 def lambda_max_masked(k, T, member, F, steps, out=None, use_mfma=True, tol=0.0):
     """lambda_max of K[I_f, I_f] for F <= 32 row sets given as bit f of member[i] (int32 tensor of T words).  ``tol`` > 0:
-    a system stops once its top Ritz value has moved by <= tol (relative) over 8 steps (lc_lambda_max_masked_tol)."""
+    a system stops once its top Ritz value has moved by <= tol (relative) over 8 steps (lc_lambda_max_masked)."""
     work = torch.empty(F * (3 * T + 2 * steps + 8) + 16 * 32 * T, dtype=torch.float64, device=k.device)
     if out is None:
         out = torch.empty(F, dtype=torch.float64, device=k.device)
-    _lib.call("lc_lambda_max_masked_tol", _p(k), k.stride(0), T, _p(member), F, steps, float(tol), _p(work), _p(out),
+    _lib.call("lc_lambda_max_masked", _p(k), k.stride(0), T, _p(member), F, steps, float(tol), _p(work), _p(out),
               int(bool(use_mfma)), _s())
     return out
 
@@ -729,7 +729,7 @@ def primal_refit(part, nrows, shrow, y, V, set_train, set_test, xstat, pinv, bes
 def lambda_max_strided(k, ldk, k_stride, rows, F, N, steps):
     work = torch.empty(F * (3 * N + 2 * steps + 8), dtype=torch.float64, device=k.device)
     out = torch.empty(F, dtype=torch.float64, device=k.device)
-    _lib.call("lc_lambda_max_strided", _p(k), ldk, k_stride, _p(rows), F, N, steps, _p(work), _p(out), _s())
+    _lib.call("lc_lambda_max", _p(k), ldk, k_stride, _p(rows), F, N, steps, _p(work), _p(out), _s())
     return out
 
 
@@ -755,7 +755,7 @@ def chol_options(outer_block=512, big_kernel=2, fused_steps=True, left_deep=Fals
 def batch_chol_solve(aug, B, N, M, h, slot=None, options=None):
     linv = torch.empty((B, N // LC_NB, LC_NB, LC_NB), dtype=torch.float64, device=aug.device)
     info = torch.empty(B, dtype=torch.int32, device=aug.device)
-    _lib.call("lc_batch_chol_solve_opt", _p(aug), B, N, M, _p(linv), _p(h), _p(slot), _p(info),
+    _lib.call("lc_batch_chol_solve", _p(aug), B, N, M, _p(linv), _p(h), _p(slot), _p(info),
               ctypes.byref(options) if options is not None else None, _s())
     return info
 
@@ -764,7 +764,7 @@ def batch_chol_inverse(aug, B, N, p, slot=None, options=None):
     """aug: (B, 2N, N) f64 systems with the identity as bottom block; p (B, N, N) f32 <- inverse of the top blocks."""
     linv = torch.empty((B, N // LC_NB, LC_NB, LC_NB), dtype=torch.float64, device=aug.device)
     info = torch.empty(B, dtype=torch.int32, device=aug.device)
-    _lib.call("lc_batch_chol_inverse_opt", _p(aug), B, N, _p(linv), _p(p), _p(slot), _p(info),
+    _lib.call("lc_batch_chol_inverse", _p(aug), B, N, _p(linv), _p(p), _p(slot), _p(info),
               ctypes.byref(options) if options is not None else None, _s())
     return info
 

@@ -118,7 +118,7 @@ def test_screened_fit_equals_the_three_mfma_fit(lc, case):
     from litcoder_core_amd.engine.common import FitOptions
     rng = np.random.default_rng({"cv": 1, "cv_offset": 2, "traintest": 3, "small_panel": 4}[case])
     T, p, V = 900, 300, 3000
-    X, Y = _problem(rng, T, p, V, noise_cols=0.5)
+    X, Y = _problem(rng, T, p, V, noise_cols=0.05)
     if case == "cv_offset":
         Y = Y + rng.uniform(-300, 300, V)[None, :] * (rng.uniform(size=V) < 0.5)
     kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=4, alphas=np.logspace(-1, 6, 15))
@@ -136,12 +136,12 @@ def test_screened_fit_equals_the_three_mfma_fit(lc, case):
     m1 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(**opts))
     out1 = m1.fit_predict(X, Y, **extra, **kw)
     assert m1.last_fit["screen_terms"] == 1 and m3.last_fit["screen_terms"] == 3
-    assert 0 < m1.last_fit["undecided"] < m1.last_fit["screened"]
+    # (how many voxels the screening leaves undecided depends on how flat the data's score curves are -- 1 % at cfg2, 20-40 %
+    # on small weak-signal problems like this one: tools/screen_probe.py -- the first steps' panels may overflow, later ones
+    # are sized from the shares seen; the FIT must not depend on any of that)
+    assert 0 < m1.last_fit["undecided"] < m1.last_fit["screened"], m1.last_fit
     if case == "small_panel":
         assert m1.last_fit.get("screen_overflows", 0) >= 1
-    else:
-        assert m1.last_fit.get("screen_overflows", 0) == 0, m1.last_fit
-        assert m1.last_fit["undecided"] < 0.5 * m1.last_fit["screened"]
     for a3, a1 in zip(m3.last_fold_alphas, m1.last_fold_alphas):
         np.testing.assert_array_equal(a1, a3)
     np.testing.assert_array_equal(out1[2], out3[2])
@@ -150,6 +150,30 @@ def test_screened_fit_equals_the_three_mfma_fit(lc, case):
         if key in out3[0]:
             np.testing.assert_array_equal(np.asarray(out1[0][key]), np.asarray(out3[0][key]), err_msg=key)
     assert out1[0]["median_score"] == out3[0]["median_score"]
+
+
+def test_screening_switches_itself_off_on_flat_score_curves(lc):
+    """Pure-noise voxels have flat score curves: on the plateau of the large alphas the scores of neighbouring alphas agree
+    to fp32 rounding, the argmax there is rounding noise in ANY arithmetic (the reference's included), and the screening
+    pass cannot decide it -- such a voxel is scored again.  When most voxels are like that the second pass costs more than
+    the screening saves: the engine notices (the share of undecided voxels comes back with every step's histogram) and
+    scores the remaining folds on three MFMAs throughout.  The fit is the three-MFMA fit either way."""
+    from litcoder_core_amd import NestedCVModel
+    from litcoder_core_amd.engine.common import FitOptions
+    rng = np.random.default_rng(9)
+    T, p, V = 900, 300, 3000
+    X, Y = _problem(rng, T, p, V, noise_cols=0.9)
+    kw = dict(folding_type="kfold", n_outer_folds=4, n_inner_folds=3, alphas=np.logspace(-1, 8, 15))
+    m3 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(screen_inner=False))
+    out3 = m3.fit_predict(X, Y, **kw)
+    m1 = NestedCVModel("ridge_regression", precision="f16x3")
+    out1 = m1.fit_predict(X, Y, **kw)
+    assert m1.last_fit.get("screen_switched_off"), m1.last_fit
+    assert m1.last_fit["screened"] < 4 * V                          # not every fold went through the screening pass
+    for a3, a1 in zip(m3.last_fold_alphas, m1.last_fold_alphas):
+        np.testing.assert_array_equal(a1, a3)
+    np.testing.assert_array_equal(out1[1], out3[1])
+    np.testing.assert_array_equal(np.asarray(out1[0]["correlations"]), np.asarray(out3[0]["correlations"]))
 
 
 def test_screened_fit_against_the_oracle(lc):
@@ -167,5 +191,5 @@ def test_screened_fit_against_the_oracle(lc):
     orc = onc.fit_predict(X, Y, detail=detail, **kw)
     model = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(screen_inner=True))
     ours = model.fit_predict(X, Y, **kw)
-    assert model.last_fit["screen_terms"] == 1
+    assert model.last_fit["screen_terms"] == 1 and model.last_fit["screened"] >= V, model.last_fit
     assert_matches_oracle(lc, model, ours, orc, detail, X, Y, kw, "screened fit vs oracle")

@@ -21,7 +21,8 @@ from litcoder_core_amd import NestedCVModel, ops  # noqa: E402
 from litcoder_core_amd.engine.common import FitOptions  # noqa: E402
 
 SHAPES = {"cfg2": dict(T=3000, F0=768, DELAYS=[1, 2, 3, 4], A=20), "cfg4": dict(T=2226, F0=768, DELAYS=[1, 2, 3, 4], A=20),
-          "cfg5": dict(T=3000, F0=1280, DELAYS=[1, 2, 3, 4, 5, 6], A=32)}
+          "cfg5": dict(T=3000, F0=1280, DELAYS=[1, 2, 3, 4, 5, 6], A=32),
+          "small": dict(T=900, F0=75, DELAYS=[1, 2, 3, 4], A=15), "tiny": dict(T=300, F0=40, DELAYS=[1, 2, 3, 4], A=12)}
 
 
 def fit(dX, dY, p, V, alphas, screen, capture, **kw):
@@ -62,6 +63,10 @@ def main():
         gap1 = top1.values[0] - top1.values[1]
         b3, b1 = s3.argmax(0), s1.argmax(0)
         flips = b3 != b1
+        rows = n_in * ((sh["T"] - sh["T"] // bench.N_OUTER) // n_in)
+        worst = gap1[flips].max().item() if flips.any() else 0.0
+        print(f"         in units of 1/sqrt(validation rows = {rows}): rms error {d.pow(2).mean().sqrt().item() * rows ** 0.5:.2e}, "
+              f"max error {d.max().item() * rows ** 0.5:.2e}, largest screening gap of a voxel whose argmax is wrong {worst * rows ** 0.5:.2e}")
         line = (f"fold {f3}: |d score| (fold mean) max {d.max().item():.2e}  99.9 % {torch.quantile(d.flatten()[::7].float(), 0.999).item():.2e}"
                 f"  rms {d.pow(2).mean().sqrt().item():.2e};  argmax differs for {int(flips.sum())} voxels"
                 f" (largest screening gap among them {gap1[flips].max().item() if flips.any() else 0.0:.2e})")
