@@ -163,15 +163,16 @@ extern "C" int lc_alpha_sweep_scores_f16x3_folds(const void* d_ht, const float* 
         lc_stream_t stream) {
     LC_REQUIRE(d_ht && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_part && d_scores &&
                    h_n_val, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: null pointer");
-    LC_REQUIRE(terms == 3 || (terms == 1 && N % (4 * TK) == 0 && mode == LC_SCORE_CORR), LC_E_BADARG,
-               "lc_alpha_sweep_scores_f16x3: terms must be 3, or 1 (screening: correlation scores, N %% %d == 0)", 4 * TK);
+    LC_REQUIRE(terms == 3 || ((terms == 1 || terms == 101) && N % (4 * TK) == 0 && mode == LC_SCORE_CORR), LC_E_BADARG,
+               "lc_alpha_sweep_scores_f16x3: terms must be 3, or 1 / 101 (screening: correlation scores, N %% %d == 0)", 4 * TK);
     LC_REQUIRE(A > 0 && M > 0 && M % LC_MB == 0 && N > 0 && N % (2 * TK) == 0, LC_E_SHAPE,
                "lc_alpha_sweep_scores_f16x3: need M %% %d == 0, N %% %d == 0", LC_MB, 2 * TK);
     LC_REQUIRE(V > 0 && V % 128 == 0, LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: V must be a multiple of 128");
     LC_REQUIRE(mode == LC_SCORE_CORR || mode == LC_SCORE_R2, LC_E_BADARG, "lc_alpha_sweep_scores_f16x3: bad mode");
-    const void* kern = terms == 1 ? reinterpret_cast<const void*>(k_sweep_f16x3<true, false, false, false, false, true>)
-                                  : reinterpret_cast<const void*>(k_sweep_f16x3<true, false>);
-    if (int rc = lc::ensure_dynamic_lds(kern, LDS16_BYTES)) return rc;
+    const void* kern = terms == 1     ? reinterpret_cast<const void*>(k_sweep_hi2<true>)
+                       : terms == 101 ? reinterpret_cast<const void*>(k_sweep_f16x3<true, false, false, false, false, true>)
+                                      : reinterpret_cast<const void*>(k_sweep_f16x3<true, false>);
+    if (int rc = lc::ensure_dynamic_lds(kern, terms == 1 ? H2_LDS_BYTES : LDS16_BYTES)) return rc;
     hipStream_t s = lc::as_stream(stream);
     BView bv;
     FoldViews fv{};
@@ -180,14 +181,17 @@ extern "C" int lc_alpha_sweep_scores_f16x3_folds(const void* d_ht, const float* 
     const int Mrows = A * M;
     const int Mtiles = lc::ceil_div(Mrows, TM);            // per fold: the folds' images are stacked tile-aligned
     const long long Ntiles = lc::ceil_div<long long>(V, TN);
-    LC_REQUIRE((long long)F * Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: grid too large");
+    LC_REQUIRE((long long)F * Mtiles * Ntiles * 2 < (1ll << 31), LC_E_SHAPE, "lc_alpha_sweep_scores_f16x3: grid too large");
     fv.mt_per_fold = Mtiles;
     fv.part_stride = (long long)(Mrows / LC_MB) * 4 * V;
     Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, 0, mode, Mrows, A, d_live_cols};
     {
         lc::ScopedTimer timer_(lc::T_SWEEP_GEMM, s);
         Plain16Args pa{};
-        if (terms == 1)
+        if (terms == 1)                    // screening, two 4-wave workgroups per CU on 256 x 128 tiles
+            hipLaunchKernelGGL((k_sweep_hi2<true>), dim3((unsigned)(F * Mtiles * Ntiles * 2)), dim3(H2_THREADS), H2_LDS_BYTES,
+                               s, (const uint4*)d_ht, (const uint4*)d_yt, N / TK, F * Mtiles, sa, pa, bv, fv);
+        else if (terms == 101)             // screening, the one-workgroup-per-CU form (kept for A/B measurements)
             hipLaunchKernelGGL((k_sweep_f16x3<true, false, false, false, false, true>), dim3((unsigned)(F * Mtiles * Ntiles)),
                                dim3(512), LDS16_BYTES, s, (const uint4*)d_ht, (const uint4*)d_yt, N / TK, F * Mtiles, sa, pa,
                                bv, fv);
@@ -344,15 +348,16 @@ extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float*
         lc_stream_t stream) {
     LC_REQUIRE(d_pt && d_rowscale_inv && d_yt && d_cscale_inv && d_yv && d_ystat && d_yblk && d_coef && d_aidx &&
                    d_part && d_scores && h_n_val, LC_E_BADARG, "lc_series_sweep_scores_f16x3: null pointer");
-    LC_REQUIRE(terms == 3 || (terms == 1 && K % (4 * TK) == 0), LC_E_BADARG,
-               "lc_series_sweep_scores_f16x3: terms must be 3, or 1 (screening: K %% %d == 0)", 4 * TK);
+    LC_REQUIRE(terms == 3 || ((terms == 1 || terms == 101) && K % (4 * TK) == 0), LC_E_BADARG,
+               "lc_series_sweep_scores_f16x3: terms must be 3, or 1 / 101 (screening: K %% %d == 0)", 4 * TK);
     LC_REQUIRE(M > 0 && M % LC_MB == 0 && K > 0 && K % (2 * TK) == 0 && S > 0, LC_E_SHAPE,
                "lc_series_sweep_scores_f16x3: need M %% %d == 0, K %% %d == 0", LC_MB, 2 * TK);
     LC_REQUIRE(V > 0 && V % 128 == 0 && Ncols >= V && Ncols % TN == 0, LC_E_SHAPE,
                "lc_series_sweep_scores_f16x3: V must be a multiple of 128, Ncols >= V a multiple of %d", TN);
-    const void* kern = terms == 1 ? reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true, true, false, true>)
-                                  : reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true, true>);
-    if (int rc = lc::ensure_dynamic_lds(kern, LDS16_BYTES)) return rc;
+    const void* kern = terms == 1     ? reinterpret_cast<const void*>(k_sweep_hi2<false>)
+                       : terms == 101 ? reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true, true, false, true>)
+                                      : reinterpret_cast<const void*>(k_sweep_f16x3<false, false, true, true>);
+    if (int rc = lc::ensure_dynamic_lds(kern, terms == 1 ? H2_LDS_BYTES : LDS16_BYTES)) return rc;
     hipStream_t s = lc::as_stream(stream);
     BView bv;
     FoldViews fv{};
@@ -362,7 +367,7 @@ extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float*
     const int nblk = M / LC_MB;
     const int Mtiles = (nblk + 1) / 2;                     // two 32-row validation blocks x four terms per tile
     const long long Ntiles = Ncols / TN;
-    LC_REQUIRE((long long)F * Mtiles * Ntiles < (1ll << 31), LC_E_SHAPE, "lc_series_sweep_scores_f16x3: grid too large");
+    LC_REQUIRE((long long)F * Mtiles * Ntiles * 2 < (1ll << 31), LC_E_SHAPE, "lc_series_sweep_scores_f16x3: grid too large");
     fv.mt_per_fold = Mtiles;
     fv.part_stride = (long long)nblk * lc::EPI_SERIES_PARTS * V;
     Score16Args sa{d_yv, d_ystat, nullptr, nullptr, d_part, (long long)V, M, 0, LC_SCORE_CORR, Mtiles * TM, 1, d_live_cols};
@@ -377,6 +382,9 @@ extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float*
     {
         lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
         if (terms == 1)
+            hipLaunchKernelGGL((k_sweep_hi2<false>), dim3((unsigned)(F * Mtiles * Ntiles * 2)), dim3(H2_THREADS), H2_LDS_BYTES, s,
+                               (const uint4*)d_pt, (const uint4*)d_yt, (int)(K / TK), F * Mtiles, sa, pa, bv, fv);
+        else if (terms == 101)
             hipLaunchKernelGGL((k_sweep_f16x3<false, false, true, true, false, true>), dim3((unsigned)(F * Mtiles * Ntiles)),
                                dim3(512), LDS16_BYTES, s, (const uint4*)d_pt, (const uint4*)d_yt, (int)(K / TK), F * Mtiles,
                                sa, pa, bv, fv);

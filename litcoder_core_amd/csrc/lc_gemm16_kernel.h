@@ -942,4 +942,301 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     }
 }
 
+// ------------------------------------------------------------------ screening sweeps, two workgroups per CU (round 6)
+// The HI2 modes of k_sweep_f16x3 (one MFMA per product) spend a third of a tile outside the main loop -- 8.6 k cycles of
+// prologue (the ring's first fill), 32-37 k of epilogue (target batches, packed statistics, partial stores: latency, not
+// work) against ~78 k of main loop -- with the matrix pipe idle, because the ONE workgroup of a CU is in the same phase on
+// all four SIMDs.  This kernel is the same contraction in workgroups of FOUR waves (2 x 2, wave tile 128 x 64 as before)
+// on 256 x 128 tiles -- one M-tile of the operator image against HALF a column tile of the target image (same images,
+// no new layout) -- with a ring of THREE 24 KB stages (72 KB + the row scales: two workgroups per CU, one wave of each
+// per SIMD, <= 256 VGPRs): whatever one workgroup waits for -- its barrier, its first fill, its epilogue's loads -- the
+// other's MFMAs run under.  Ring discipline (step t = K-tiles 2t, 2t+1 lives in stage t % 3):
+//   prologue: steps 0..2 -> stages 0..2; fragments of step 0 -> registers; barrier;
+//   iteration j: MFMAs of step j (registers) | read step j+1 from stage (j+1) % 3 | DMA step j+3 -> stage j % 3 (read out
+//   during iteration j-1, before the last barrier);  end of iteration j: wait until this wave's pieces of step j+2 have
+//   landed (counted vmcnt: the six pieces of step j+3 may still fly) and for its own fragment reads, then the barrier.
+// A thread moves six 16-byte units per step: four of A (the hi planes of two K-tiles, 512 units each, units tid and tid + 256)
+// and two of B (per K-tile the hi plane's two k-groups x 128 columns of this half).
+constexpr int H2_THREADS = 256, H2_TN = 128;
+constexpr int H2_A16 = 2 * 512;                     // A units per stage: two hi planes of 256 rows x 2 k-groups
+constexpr int H2_B16 = 2 * KG * H2_TN;              // B units per stage: two K-tiles x 2 k-groups x 128 columns
+constexpr int H2_STAGE16 = H2_A16 + H2_B16;         // 1536 units = 24 KB
+constexpr int H2_NSTAGE = 3;
+constexpr int H2_LDS_BYTES = H2_NSTAGE * H2_STAGE16 * 16 + TM * 4;
+
+template <bool SCORE>                                // true: fused score epilogue;  false: series-moments epilogue
+__global__ void __launch_bounds__(H2_THREADS, 2)
+k_sweep_hi2(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT_tiles, int Mtiles, Score16Args sa,
+            Plain16Args pa, BView bv, FoldViews fv) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds16[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int KT = KT_tiles / 2;                     // ring steps of two K-tiles (the host checks K % 64 == 0)
+
+    const int tile = xcd_tile_id16(blockIdx.x, gridDim.x);
+    const int mt_all = tile % Mtiles, nh = tile / Mtiles;       // nh = half column tile
+    const int nt = nh >> 1, hb = nh & 1;
+    const long long ncol0 = (long long)nt * TN + hb * H2_TN;    // first column of this workgroup
+    if (sa.live_cols != nullptr && ncol0 >= (long long)*sa.live_cols) return;
+    const int fold = mt_all / fv.mt_per_fold;
+    const int mt = mt_all - fold * fv.mt_per_fold;
+    sa.yv += (long long)fold * sa.M * sa.V;
+    sa.ymean += (long long)fold * 3 * sa.V;
+    sa.part += (long long)fold * fv.part_stride;
+    sa.n_val = fv.n_val[fold];
+    const int b_cut = fv.cut[fold], b_skip = fv.skip[fold];
+    const uint4* a_src = At + (long long)mt_all * KT_tiles * CHUNK16 + tid;
+    // B: K-tile chunk = [plane][k-group][256 columns]; this thread's unit of a hi plane's half: k-group tid >> 7, column tid & 127
+    const uint4* b_src = Bt + (long long)nt * bv.kt_total * CHUNK16 + (tid >> 7) * 256 + hb * H2_TN + (tid & 127);
+#define H2_BKT(kt_) ((kt_) + ((kt_) >= b_cut ? b_skip : 0))
+    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) uint4*)lds16);
+#define H2_DMA(gptr_, unit_)                                                                                  \
+    {                                                                                                         \
+        const unsigned m0_ = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((unit_) + (wave << 6)) * 16u); \
+        const uint4* gp_ = (gptr_);                                                                           \
+        unsigned keep_;                                                                                       \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(gp_), "s"(m0_) : "memory");                                          \
+    }
+    // piece q = 0..5 of ring step t into stage s
+#define H2_PIECE(q_, t_, s_)                                                                                   \
+    {                                                                                                          \
+        if ((q_) == 0) H2_DMA(a_src + (long long)(2 * (t_)) * CHUNK16, (s_) * H2_STAGE16);                     \
+        if ((q_) == 1) H2_DMA(a_src + (long long)(2 * (t_)) * CHUNK16 + 256, (s_) * H2_STAGE16 + 256);         \
+        if ((q_) == 2) H2_DMA(a_src + (long long)(2 * (t_) + 1) * CHUNK16, (s_) * H2_STAGE16 + 512);           \
+        if ((q_) == 3) H2_DMA(a_src + (long long)(2 * (t_) + 1) * CHUNK16 + 256, (s_) * H2_STAGE16 + 768);     \
+        if ((q_) == 4) H2_DMA(b_src + (long long)H2_BKT(2 * (t_)) * CHUNK16, (s_) * H2_STAGE16 + H2_A16);      \
+        if ((q_) == 5) H2_DMA(b_src + (long long)H2_BKT(2 * (t_) + 1) * CHUNK16, (s_) * H2_STAGE16 + H2_A16 + 256); \
+    }
+#define H2_BARRIER()                           \
+    __builtin_amdgcn_sched_barrier(0);         \
+    __builtin_amdgcn_s_barrier();              \
+    __builtin_amdgcn_sched_barrier(0)
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int t = 0; t < H2_NSTAGE && t < KT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) H2_PIECE(q, t, t);
+    }
+
+    // epilogue operands that do not depend on the accumulators: row scales -> LDS behind the ring, column constants
+    float* lds_rs = reinterpret_cast<float*>(lds16 + H2_NSTAGE * H2_STAGE16);
+    const long long V = sa.V;
+    const long long col0 = ncol0 + wn * 64 + li;
+    const bool cok[2] = {col0 < V, col0 + 32 < V};
+    const long long colc[2] = {cok[0] ? col0 : 0, cok[1] ? col0 + 32 : 0};
+    float ymv[2] = {0.f, 0.f}, cscv[2] = {0.f, 0.f};
+    if (SCORE) {
+        lds_rs[tid] = sa.rs_inv[mt_all * TM + tid];                              // (256 threads = the tile's 256 rows)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            ymv[ni] = sa.ymean[colc[ni]];
+            cscv[ni] = sa.cs_inv[colc[ni]];
+        }
+    } else {                                            // series moments: this wave's column block after the swap: ni = wm
+        lds_rs[tid] = pa.rs_inv[(long long)mt_all * TM + tid];
+        ymv[0] = sa.ymean[colc[wm]];
+        cscv[0] = pa.cs_inv[ncol0 + wn * 64 + wm * 32 + li];
+    }
+    auto load_t = [&](int step, lc::EpiTargets& t) {
+        const int blk = mt * (TM / 32) + wm * 4 + (step >> 1);                      // image block = (validation block, alpha)
+        lc::epi_load_targets(sa.yv, V, min(blk / sa.A, (sa.M >> 5) - 1) * 32, lh, colc[step & 1], t);
+    };
+    lc::EpiTargets tb0, tb1, tb2;
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    H2_BARRIER();
+
+    // fragment addresses (16-byte units) inside a stage.  A: ((K-tile q * KG + lh) * 256 + row);  B: A16 + ((q * KG + lh) * 128 + col)
+    const int a_frag = lh * 256 + wm * 128 + li;
+    const int b_frag = H2_A16 + lh * H2_TN + wn * 64 + li;
+    struct Frag {
+        h8 a0[4], a1[4], b0[2], b1[2];                  // K-tile 2t (a0, b0) and 2t+1 (a1, b1)
+    };
+    auto read_frag = [&](Frag& f, const uint4* st, const int k) {
+        if (k < 2) {
+            const uint4 v = st[b_frag + k * 32];
+            f.b0[k] = *reinterpret_cast<const h8*>(&v);
+        } else if (k < 6) {
+            const uint4 v = st[a_frag + (k - 2) * 32];
+            f.a0[k - 2] = *reinterpret_cast<const h8*>(&v);
+        } else if (k < 8) {
+            const uint4 v = st[b_frag + KG * H2_TN + (k - 6) * 32];
+            f.b1[k - 6] = *reinterpret_cast<const h8*>(&v);
+        } else {
+            const uint4 v = st[a_frag + KG * 256 + (k - 8) * 32];
+            f.a1[k - 8] = *reinterpret_cast<const h8*>(&v);
+        }
+    };
+    Frag fa, fb;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) read_frag(fa, lds16, k);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    H2_BARRIER();                                       // everybody holds step 0: stage 0 may be overwritten
+
+    // a 128-row slab with no valid rows (the padded half of a fold's last M-tile): its waves keep up their share of the DMA
+    // ring and the barriers only
+    const bool slab_empty = SCORE && mt * TM + wm * 128 >= sa.Mrows;
+    int s_cur = 0;                                      // stage of step kt (kt % 3), carried along
+    // MODE 0 = steady (kt + 3 < KT: a DMA step, a next step), 1 = guarded tail, 2 = the last step
+    auto kstep = [&](const int kt, const Frag& cur, Frag& nxt, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool STEADY = MODE == 0, LAST = MODE == 2;
+        const bool has_next = STEADY || (!LAST && kt + 1 < KT);
+        const bool do_dma = STEADY || (!LAST && kt + 3 < KT);
+        const int s_nxt = s_cur == 2 ? 0 : s_cur + 1;
+        const uint4* stn = lds16 + s_nxt * H2_STAGE16;
+        if (LAST && SCORE) { load_t(0, tb0); load_t(1, tb1); }
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            if (!slab_empty) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = 2 * sl + h, mi = (i & 7) >> 1, ni = i & 1;
+                    if (i < 8) MFMA16(acc[mi][ni], cur.a0[mi], cur.b0[ni]);
+                    else MFMA16(acc[mi][ni], cur.a1[mi], cur.b1[ni]);
+                }
+                if (has_next) {
+                    if (sl == 0) { read_frag(nxt, stn, 0); read_frag(nxt, stn, 1); }
+                    if (sl == 1) { read_frag(nxt, stn, 2); read_frag(nxt, stn, 3); }
+                    if (sl == 2) { read_frag(nxt, stn, 4); read_frag(nxt, stn, 5); }
+                    if (sl == 3) { read_frag(nxt, stn, 6); read_frag(nxt, stn, 7); }
+                    if (sl >= 4) read_frag(nxt, stn, sl + 4);
+                }
+            }
+            if (do_dma) {
+                if (sl == 0) H2_PIECE(0, kt + 3, s_cur);
+                if (sl == 1) H2_PIECE(1, kt + 3, s_cur);
+                if (sl == 3) H2_PIECE(2, kt + 3, s_cur);
+                if (sl == 4) H2_PIECE(3, kt + 3, s_cur);
+                if (sl == 5) H2_PIECE(4, kt + 3, s_cur);
+                if (sl == 7) H2_PIECE(5, kt + 3, s_cur);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        s_cur = s_nxt;
+        if (LAST) return;
+        // publish step kt+2 (read during iteration kt+1): its pieces were issued in iteration kt-1 (or the prologue); the
+        // six pieces of step kt+3, if any were issued now, may still fly.  lgkmcnt(0): this wave's fragment reads of step
+        // kt+1 have returned before it reports at the barrier (the next iteration's first DMA piece goes into their stage)
+        if (STEADY || kt + 3 < KT) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (STEADY || kt + 2 < KT) { H2_BARRIER(); }
+    };
+    using Steady = std::integral_constant<int, 0>;
+    using Tail = std::integral_constant<int, 1>;
+    using Last = std::integral_constant<int, 2>;
+    int kt = 0;
+    for (; kt + 4 < KT; kt += 2) {                     // (kt + 1) + 3 < KT: both steps issue a DMA step
+        kstep(kt, fa, fb, Steady{});
+        kstep(kt + 1, fb, fa, Steady{});
+    }
+    for (; kt + 2 < KT; kt += 2) {
+        kstep(kt, fa, fb, Tail{});
+        kstep(kt + 1, fb, fa, Tail{});
+    }
+    kstep(kt, fa, fb, Tail{});                         // KT (steps) is even: kt == KT - 2 here
+    kstep(kt + 1, fb, fa, Last{});
+
+    if (!SCORE) {
+        // ---- series-moments epilogue (as k_sweep_f16x3<SERMOM>; the swap buffer is the idle ring: 4 waves x 16 KB)
+        const long long colm = colc[wm];
+        const int blk0 = 2 * mt;
+        lc::EpiTargets tg[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if ((blk0 + b) * 32 < sa.M) lc::epi_load_targets(sa.yv, V, (blk0 + b) * 32, lh, colm, tg[b]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        H2_BARRIER();                                   // every wave is done with the ring: it becomes the swap buffer
+        lc::ep_f32x4* xch = reinterpret_cast<lc::ep_f32x4*>(lds16);
+        {
+            lc::ep_f32x4* dst = xch + (wn * 2 + wm) * 16 * 64 + lane;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const lc::ep_f32x4 rs = *reinterpret_cast<const lc::ep_f32x4*>(lds_rs + wm * 128 + mi * 32 + 8 * q + 4 * lh);
+                    lc::ep_f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (wm ? acc[mi][0][4 * q + j] : acc[mi][1][4 * q + j]) * rs[j];
+                    dst[(mi * 4 + q) * 64] = v;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        H2_BARRIER();
+        const lc::ep_f32x4* src = xch + (wn * 2 + (1 - wm)) * 16 * 64 + lane;
+        const float cs = cscv[0], ym = ymv[0];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int i0 = (blk0 + b) * 32;
+            if (i0 >= sa.n_val) continue;
+            float own[2][16], oth[2][16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mi = 2 * h + b;
+                    const lc::ep_f32x4 rs = *reinterpret_cast<const lc::ep_f32x4*>(lds_rs + wm * 128 + mi * 32 + 8 * q + 4 * lh);
+                    const lc::ep_f32x4 o = src[(mi * 4 + q) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        own[h][4 * q + j] = (wm ? acc[mi][1][4 * q + j] : acc[mi][0][4 * q + j]) * rs[j] * cs;
+                        oth[h][4 * q + j] = o[j] * cs;
+                    }
+                }
+            float T[4][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                T[0][r] = wm ? oth[0][r] : own[0][r];
+                T[1][r] = wm ? oth[1][r] : own[1][r];
+                T[2][r] = wm ? own[0][r] : oth[0][r];
+                T[3][r] = wm ? own[1][r] : oth[1][r];
+            }
+            float* dstp = sa.part + (long long)(blk0 + b) * lc::EPI_SERIES_PARTS * V + colm;
+            if (i0 + 32 <= sa.n_val) lc::epi_series_block<false>(T, tg[b], ym, i0, sa.n_val, lh, dstp, V, cok[wm]);
+            else lc::epi_series_block<true>(T, tg[b], ym, i0, sa.n_val, lh, dstp, V, cok[wm]);
+        }
+        return;
+    }
+
+    // ---- score epilogue (as k_sweep_f16x3<SCORE>): two target batches are in registers, the third is issued first
+    const bool corr = sa.mode == LC_SCORE_CORR;
+    auto reduce = [&](int step, const lc::EpiTargets& t) {
+        const int mi = step >> 1, ni = step & 1;
+        const int rb0 = mt * TM + wm * 128 + mi * 32;
+        if (rb0 >= sa.Mrows) return;
+        lc::ep_f32x4 rs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            rs[q] = *reinterpret_cast<const lc::ep_f32x4*>(lds_rs + wm * 128 + mi * 32 + 8 * q + 4 * lh);
+        const int blk = rb0 >> 5, ib = blk / sa.A, al = blk - ib * sa.A;
+        lc::epi_block_dispatch<true>(corr, acc[mi][ni], t, rs, cscv[ni], ymv[ni], ib * 32, sa.n_val, lh,
+                                     sa.part + (long long)(al * (sa.M >> 5) + ib) * 4 * V + colc[ni], V, cok[ni]);
+    };
+#define H2_FENCE() __builtin_amdgcn_sched_barrier(0)
+    load_t(2, tb2); H2_FENCE();
+    reduce(0, tb0); H2_FENCE(); load_t(3, tb0); H2_FENCE();
+    reduce(1, tb1); H2_FENCE(); load_t(4, tb1); H2_FENCE();
+    reduce(2, tb2); H2_FENCE(); load_t(5, tb2); H2_FENCE();
+    reduce(3, tb0); H2_FENCE(); load_t(6, tb0); H2_FENCE();
+    reduce(4, tb1); H2_FENCE(); load_t(7, tb1); H2_FENCE();
+    reduce(5, tb2);
+    reduce(6, tb0);
+    reduce(7, tb1);
+#undef H2_FENCE
+#undef H2_BARRIER
+#undef H2_PIECE
+#undef H2_DMA
+#undef H2_BKT
+}
+
 }  // namespace

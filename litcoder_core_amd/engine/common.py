@@ -105,6 +105,13 @@ class FitOptions:
                                             # prediction errors averaged over those rows -- measured rms 3.7e-6, max 4.1e-5 over
                                             # 8e6 scores at cfg2 (2400 rows: gap 1.0e-4 = 27 rms; the largest gap of a voxel
                                             # whose screening argmax was wrong: 1.4e-5; profiles/r06_screen_probe_cfg2.txt)
+    screen_two_workgroups: bool = False     # ... True: the screening sweeps in 4-wave workgroups on 256 x 128 tiles, two per CU
+                                            # (k_sweep_hi2: one's prologue / epilogue / barrier under the other's MFMAs; VERDICT
+                                            # r5 #1a).  Built, bit-identical scores, MEASURED SLOWER and not adopted: 0.574 ms
+                                            # against 0.533 per full-width score launch, matrix pipe busy 0.54 against 0.58 at the
+                                            # same 1.83 GHz, 1.94 GB leaving L2 against 1.31 (half tiles fetch the operator
+                                            # slabs 1.5 x as often): profiles/experiments/r06_hi2_kernel_forms_pmc.txt; a cfg2
+                                            # fit 103.4 against 100.9 ms interleaved
     screen_max_undecided: float = 0.35      # ... once a step reports a larger share of undecided voxels the rest of the fit is
                                             # scored on three MFMAs throughout (flat score curves -- pure-noise voxels on the
                                             # plateau of the large alphas, where neighbouring alphas agree to fp32 rounding --

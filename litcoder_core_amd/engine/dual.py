@@ -282,6 +282,8 @@ class DualSweeps:
                       and self.mode == LC_SCORE_CORR and N % 64 == 0 and not panel and not hat.get("exact")) else 3
         if not panel:
             self.info["screen_terms"] = min(self.info.get("screen_terms", 3), terms)     # (1: some step of the fit screened)
+        if terms == 1 and not self.opt.screen_two_workgroups:
+            terms = 101                                   # (lc_*_sweep_scores_f16x3_folds: the one-workgroup-per-CU kernel)
         folds = [(f0 + j, j, H, P) for f0, fc, H, P in hat["Hs"] for j in range(fc)]
         # the operators' fp16 images made with the hat matrices (_hat_matrices), per chunk: fold f0 + j is group j
         imgs = hat.get("imgs") or [None] * len(hat["Hs"])
@@ -391,7 +393,7 @@ class DualSweeps:
             if moments and Ad and not cho_first:
                 for i, a in enumerate(cho):
                     scores[a].copy_(scores_d[i])
-            if terms == 1:
+            if terms in (1, 101):
                 # the voxels the screening pass leaves undecided: scored again with the three-MFMA products, their columns
                 # of the table overwritten -- before the side path's columns are, and before any alpha is chosen
                 self._refine_undecided(hat, Y, scores, ystat[0], F, sum(n_v))

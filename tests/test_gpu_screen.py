@@ -87,6 +87,13 @@ def test_screening_scores_are_close_and_the_panel_is_bitwise(lc):
     e1.argmax_only = True                                        # (what NestedCVModel's driver tells its engine)
     s1, _ = e1._alpha_scores(e1.K, e1.dY, inner)
     assert e1.info["screen_terms"] == 1 and e3.info["screen_terms"] == 3
+    # the two forms of the screening sweeps -- 4-wave workgroups on 256 x 128 tiles, two per CU (k_sweep_hi2, the default) and
+    # the HI2 mode of the 8-wave kernel -- issue the same products in the same order: the same table bit for bit
+    e1b = RidgeCVEngine(X, Y, alphas, True, True, False, False, precision="f16x3",
+                        options=FitOptions(screen_inner=True, screen_tau=0.0, screen_two_workgroups=False))
+    e1b.argmax_only = True
+    s1b, _ = e1b._alpha_scores(e1b.K, e1b.dY, inner)
+    assert torch.equal(s1, s1b)
     d = (s1[:, :V] - s3[:, :V]).abs().cpu().numpy() / len(inner)
     assert 1e-8 < d.max() < 3e-4 and np.sqrt((d ** 2).mean()) < 3e-5, (d.max(), np.sqrt((d ** 2).mean()))
     # tau = +inf-like: every voxel undecided -> with a panel as wide as the range the table IS the three-MFMA table

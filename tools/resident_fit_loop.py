@@ -26,7 +26,12 @@ if os.environ.get("FIT_SPIKE"):                          # one outlier-dominated
     dY[7, V // 2 + 123] = 1e6
 alphas = np.logspace(-1, 8, bench.A)
 shard = ShardContext.simulated(G, rank, device=dev, global_lists=False) if G > 1 else None
-model = NestedCVModel("ridge_regression", shard=shard)
+opts = None
+if os.environ.get("FIT_OPTS"):                           # e.g. FIT_OPTS="screen_inner=0" or "screen_two_workgroups=0": FitOptions fields
+    from litcoder_core_amd.engine.common import FitOptions
+    kv = dict(item.split("=") for item in os.environ["FIT_OPTS"].split(","))
+    opts = FitOptions(**{k: type(getattr(FitOptions(), k))(float(v)) for k, v in kv.items()})
+model = NestedCVModel("ridge_regression", shard=shard, options=opts)
 for i in range(n):
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -87,11 +87,11 @@ def main():
               f"(overflows {m2.last_fit.get('screen_overflows', 0)}, panel columns queued {m2.last_fit.get('refine_launch_cols')}); "
               f"columns of the five score tables equal, bit for bit, to the three-MFMA tables': {5 * V - nd}")
     # timings: interleaved
-    for screen in (False, True, False, True):
+    for screen in (False, True, "one workgroup per CU", False, True, "one workgroup per CU"):
         ops.timing_enable(True)
         ts = []
         for _ in range(a.reps):
-            ms, _, m = fit(dX, dY, p, V, alphas, screen, False)
+            ms, _, m = fit(dX, dY, p, V, alphas, screen, False, **({"screen_two_workgroups": False} if isinstance(screen, str) else {}))
             ts.append(ms)
         tm = ops.timing_read()
         ops.timing_enable(False)
