@@ -637,6 +637,12 @@ int lc_undecided_cols(const float* d_scores, int A, int64_t ld, int64_t V, float
                       int64_t ld_stat, uint8_t* d_flags, int32_t* d_block_count, int32_t* d_list, int cap,
                       int32_t* d_count, lc_stream_t stream);
 
+/* single_alpha (nested_cv.py:396-400: ONE alpha = argmax of the voxel MEAN of the scores) under the screening pass: the mean of
+ * V screening scores is good to ~(screening error) x sqrt(sum kappa^2) / V when the voxels' errors are independent -- d_out[0] =
+ * sum kappa, d_out[1] = sum kappa^2 over the V voxels (kappa as in lc_undecided_cols), from which the host decides whether the
+ * two best alphas' means are far enough apart; if not the fit is repeated on three MFMAs. */
+int lc_kappa_sums(const float* d_ystat, int64_t ld_stat, int64_t V, double* d_out, lc_stream_t stream);
+
 /* ---------------------------------------------------------------- statistics tail */
 
 /* Fisher's combination of k p-values per voxel, nested_cv.py:441-477 (`_combine_pvalues_across_folds`):

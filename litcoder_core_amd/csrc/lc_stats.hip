@@ -564,6 +564,32 @@ __global__ void __launch_bounds__(1024) k_rowsum(const float* __restrict__ score
     if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
 
+// sum of kappa and of kappa^2 over the voxels, kappa = rms / std of the validation rows of d_ystat (as in k_undecided_flags):
+// what the error of a voxel-MEAN of screening scores scales with (single_alpha: nested_cv.py:396-400).  One block, fixed order.
+__global__ void __launch_bounds__(1024) k_kappa_sums(const float* __restrict__ ystat, long long ld, long long V,
+                                                     double* __restrict__ out) {
+    __shared__ double sm[2][1024];
+    double k1 = 0.0, k2 = 0.0;
+    for (long long v = threadIdx.x; v < V; v += 1024) {
+        const float m = ystat[v], sd = ystat[ld + v], var = ystat[2 * ld + v];
+        const float k = sd > 0.f ? sqrtf(m * m + var) / sd : 1.f;
+        const double kap = (k >= 1.f && k < 3.0e38f) ? (double)k : 1.0;
+        k1 += kap;
+        k2 += kap * kap;
+    }
+    sm[0][threadIdx.x] = k1;
+    sm[1][threadIdx.x] = k2;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sm[0][threadIdx.x] += sm[0][threadIdx.x + w];
+            sm[1][threadIdx.x] += sm[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sm[0][0]; out[1] = sm[1][0]; }
+}
+
 // Stable counting sort of voxel ids by alpha index, one block.  Thread t owns the contiguous
 // voxel segment [t*L, (t+1)*L); hist[a][t] is scanned alpha-major so that equal alphas keep
 // voxel order.
@@ -1000,6 +1026,14 @@ extern "C" int lc_undecided_cols(const float* d_scores, int A, int64_t ld, int64
     hipLaunchKernelGGL(k_undecided_place, dim3((unsigned)nb), dim3(UD_THREADS), 0, s, d_flags, (long long)V, d_block_count, nb,
                        d_list, cap, d_count);
     return lc::launched("k_undecided_place");
+}
+
+extern "C" int lc_kappa_sums(const float* d_ystat, int64_t ld_stat, int64_t V, double* d_out, lc_stream_t stream) {
+    LC_REQUIRE(d_ystat && d_out, LC_E_BADARG, "lc_kappa_sums: null pointer");
+    LC_REQUIRE(V > 0 && ld_stat >= V, LC_E_SHAPE, "lc_kappa_sums: need 0 < V <= ld_stat");
+    hipLaunchKernelGGL(k_kappa_sums, dim3(1), dim3(1024), 0, lc::as_stream(stream), d_ystat, (long long)ld_stat, (long long)V,
+                       d_out);
+    return lc::launched("k_kappa_sums");
 }
 
 extern "C" int lc_select_alpha(const float* d_scores, int A, int64_t V, int32_t* d_best, double* d_rowsum,

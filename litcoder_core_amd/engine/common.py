@@ -116,6 +116,10 @@ class FitOptions:
                                             # scored on three MFMAs throughout (flat score curves -- pure-noise voxels on the
                                             # plateau of the large alphas, where neighbouring alphas agree to fp32 rounding --
                                             # cannot be decided by screening; scoring most voxels twice costs more than it saves)
+    screen_mean_coherent: float = 0.02      # ... single_alpha: the ONE alpha is the argmax of the voxel mean of the scores; the
+                                            # screening error of that mean is taken as screen_tau / sqrt(rows) x max(0.4 sqrt(sum
+                                            # kappa^2), this x sum kappa) / V -- independent errors, or this share of them coherent
+                                            # across voxels -- and a smaller lead of the best alpha repeats the fit on three MFMAs
     screen_panel_cols: int = 0              # ... columns of the refinement's panel (0: adaptive, _refine_capacity; tests force
                                             # the overflow path with a small value)
     alpha_progress_log: bool = dataclasses.field(       # per-alpha progress lines (ridge_regression.py:136-139): a device
@@ -192,6 +196,12 @@ class _GuessMissed(Exception):
     """single_alpha with host inputs: the early voxel panels were refitted with the alpha THEY chose while the last panel was
     still being swept, and the choice over all voxels turned out to be another one -- the driver repeats the fit with
     what is resident (same result as without the guess; FitOptions.single_alpha_guess)."""
+
+
+class _ScreenMissed(Exception):
+    """single_alpha under the screening pass (FitOptions.screen_inner): the voxel MEANS of the screening scores of the two best
+    alphas lie closer than the screening error can vouch for -- the driver repeats the fit with every score on three MFMAs
+    (what is resident stays resident)."""
 
 
 class _Range:

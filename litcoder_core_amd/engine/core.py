@@ -170,6 +170,7 @@ class EngineCore:
         self._scale_checks = []                        # primal form: pending looks at the features' column norms
         self.side = None                               # the f32 side panel of too-wide target columns (_register_side)
         self.argmax_only = False                       # the driver's word that score tables only feed per-voxel argmaxes (_sweeps)
+        self.mean_only = False                         # ... or only the argmax of their voxel mean (single_alpha)
         # what this fit ran, for the caller (NestedCVModel.last_fit; bench.py prices the roofline with it): arithmetic
         # of the sweeps, alphas scored inside the fused launch, algorithmic flops of the plain fp16x3 GEMMs.  Per
         # engine: two fits in one process do not share it.

@@ -12,7 +12,7 @@ import torch
 from .. import ops, series, stats
 from .._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2
 from ..dist import ShardContext, job_share
-from .common import (SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions, check_penalties, _PrimalUnsuitable, _WideTargets, _FoldResult, _aux_stream, _Range, _column_panels, _download_panels, _DeviceShapes, logger)
+from .common import (_ScreenMissed, SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions, check_penalties, _PrimalUnsuitable, _WideTargets, _FoldResult, _aux_stream, _Range, _column_panels, _download_panels, _DeviceShapes, logger)
 
 
 class DualSweeps:
@@ -276,10 +276,7 @@ class DualSweeps:
         # screening arithmetic (FitOptions.screen_inner): one MFMA per product for both contractions of the inner CV
         panel = bool(hat.get("panel"))                    # this call scores the refinement's column panel (_refine_undecided)
         live = hat.get("live") if panel else None
-        # (only where the table feeds a per-voxel ARGMAX and nothing else -- the nested-CV driver says so, argmax_only; a
-        # caller that wants the scores themselves, ridge.ridge_corr = ridge_corr_torch, gets the three-MFMA scores)
-        terms = 1 if (self.opt.screen_inner and getattr(self, "argmax_only", False) and moments and split
-                      and self.mode == LC_SCORE_CORR and N % 64 == 0 and not panel and not hat.get("exact")) else 3
+        terms = self._screen_terms(hat, moments, split, N)
         if not panel:
             self.info["screen_terms"] = min(self.info.get("screen_terms", 3), terms)     # (1: some step of the fit screened)
         if terms == 1 and not self.opt.screen_two_workgroups:
@@ -394,9 +391,7 @@ class DualSweeps:
                 for i, a in enumerate(cho):
                     scores[a].copy_(scores_d[i])
             if terms in (1, 101):
-                # the voxels the screening pass leaves undecided: scored again with the three-MFMA products, their columns
-                # of the table overwritten -- before the side path's columns are, and before any alpha is chosen
-                self._refine_undecided(hat, Y, scores, ystat[0], F, sum(n_v))
+                self._after_screening(hat, Y, scores, ystat[0], F, sum(n_v))
             if side_job is not None:
                 self._side_sweeps_end(side_job, scores)
             self.sweeps_done = torch.cuda.Event()
@@ -409,6 +404,29 @@ class DualSweeps:
             return (lambda: out) if split_phase else out
         series_part()
         return fused_part if split_phase else fused_part()
+
+    def _screen_terms(self, hat, moments, split, depth):
+        """1 when this call of the sweeps runs on the screening arithmetic (one fp16 MFMA per product), else 3.  Only where
+        the score table feeds an ARGMAX and nothing else, and the driver has said which: ``argmax_only`` -- every voxel's own
+        (nested_cv.py:405-411): undecided voxels are scored again (_refine_undecided) --, or ``mean_only`` -- single_alpha, the
+        argmax of the voxel MEAN (:396-400): checked in fold_select (_mean_check).  A caller that wants the scores themselves
+        (ridge.ridge_corr = ridge_corr_torch) gets three-MFMA scores.  Needs the moments form of the series alphas, the fp16
+        path, correlation scores and a contraction depth that is a multiple of 64 (two K-tiles per ring stage)."""
+        panel = bool(hat.get("panel"))
+        ok = (self.opt.screen_inner and (getattr(self, "argmax_only", False) or getattr(self, "mean_only", False))
+              and moments and split and self.mode == LC_SCORE_CORR and depth % 64 == 0 and not panel and not hat.get("exact"))
+        return 1 if ok else 3
+
+    def _after_screening(self, hat, Y, scores, ystat0, F, n_val_rows):
+        """What follows a screening pass' score table (sums over the F inner folds), before any alpha is chosen from it."""
+        if getattr(self, "mean_only", False):
+            # single_alpha: nothing per voxel to decide -- what the voxel MEAN's error scales with goes along with the
+            # per-alpha sums (fold_choose / fold_choose_joint), the lead of the best alpha is checked in fold_select
+            hat["mean_check"] = dict(ksums=ops.kappa_sums(ystat0, self.V), F=int(F), rows=int(n_val_rows))
+            return
+        # the voxels the screening pass leaves undecided: scored again with the three-MFMA products, their columns of the
+        # table overwritten -- before the side path's columns are, and before any alpha is chosen
+        self._refine_undecided(hat, Y, scores, ystat0, F, n_val_rows)
 
     def _refine_capacity(self, V):
         """Columns of the refinement's panel for a voxel range of V columns: twice the largest share of undecided voxels a

@@ -13,7 +13,7 @@ import torch
 from .. import ops, series, stats
 from .._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2
 from ..dist import ShardContext, job_share
-from .common import (SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions, check_penalties, _PrimalUnsuitable, _WideTargets, _FoldResult, _aux_stream, _Range, _column_panels, _download_panels, _DeviceShapes, logger)
+from .common import (_ScreenMissed, SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions, check_penalties, _PrimalUnsuitable, _WideTargets, _FoldResult, _aux_stream, _Range, _column_panels, _download_panels, _DeviceShapes, logger)
 
 
 class FoldPhases:
@@ -231,7 +231,7 @@ class FoldPhases:
         self._enter(st)
         if getattr(self, "debug_scores", None) is not None:      # (tools/screen_probe.py: the score tables of a fit)
             self.debug_scores.append((st["fold"], st["rg"].c0, st["scores"].clone()))
-        st["best"] = self.choose(st["scores"], single_alpha)
+        st["best"] = self.choose(st["scores"], single_alpha, check=st["hat"].get("mean_check") if single_alpha else None)
         if self.opt.alpha_progress_log and logger.isEnabledFor(logging.INFO):
             # ridge_regression.py:136-139 logs "Alpha=..., mean corr=..." per alpha and inner fold; here the scores exist
             # as the sum over the inner folds, so one line per alpha and outer fold (a device round trip: opt-in)
@@ -255,7 +255,9 @@ class FoldPhases:
             self._enter(st)
             _, rowsum = ops.select_alpha(st["scores"], self.A, self.Vp, want_best=False, want_rowsum=True)
             total = rowsum if total is None else ops.accumulate_f64(rowsum, total)
-        self.shard.all_reduce_(total, "sum")
+        # (screening pass: the ranges' kappa sums ride along, the all-reduced result leaves for fold_select's check)
+        checks = [st["hat"]["mean_check"] for st in sts if st["hat"].get("mean_check")]
+        total = self._mean_sums(total, checks if len(checks) == len(sts) else [])
         for st in (sts if assign is None else assign):
             self._enter(st)
             best = torch.empty(self.Vp, dtype=torch.int32, device=self.dev)
@@ -268,6 +270,7 @@ class FoldPhases:
         """Waits for the fold's alpha histogram (fold_choose; the one host synchronisation of a fold) and puts the
         fp64 systems of the refit on the auxiliary stream -- they run beside whatever the main stream does next."""
         self._enter(st)
+        self._mean_check(st)
         if self.moments:                               # nothing to factor after the choice, and no host sync
             if "best" not in st:
                 self.fold_choose(st, single_alpha)
@@ -305,6 +308,32 @@ class FoldPhases:
         st.update(best=best, perm=perm, used=used, used_all=used_all, tiles=tiles, Vs=Vs, split=split, Malpha=Malpha,
                   info_o=info_o, systems_ready=ready)
         return st
+
+    def _mean_check(self, st):
+        """single_alpha under the screening pass: the ONE alpha is the argmax of the voxel mean of the scores
+        (nested_cv.py:396-400).  The mean of V screening scores is good to ~2e-4 / sqrt(rows) x sqrt(sum kappa^2) / V when the
+        voxels' errors are independent (tools/screen_probe.py: rms 1.9e-4 per voxel in those units); the lead of the best
+        alpha over the runner-up must exceed  screen_tau / sqrt(rows) x max(0.4 sqrt(sum kappa^2), screen_mean_coherent x
+        sum kappa)  -- ten such sigmas, or 2 % of the per-voxel bound coherent across all voxels -- else _ScreenMissed: the
+        driver repeats the fit on three MFMAs.  Voxel shards: every rank decides from the same all-reduced numbers."""
+        chk = st["hat"].get("mean_check")
+        if not chk or "host" not in chk or chk.get("done"):
+            return
+        chk["ev"].synchronize()
+        chk["done"] = True
+        h = chk["host"].numpy()
+        A = self.A
+        sums, k1, k2 = h[:A], float(h[A]), float(h[A + 1])
+        self.info["screened"] = self.info.get("screened", 0) + int(st["rg"].V)
+        if A < 2:
+            return
+        order = np.argsort(-sums, kind="stable")
+        lead = float(sums[order[0]] - sums[order[1]])
+        thr = (self.opt.screen_tau * chk["F"] / np.sqrt(max(chk["rows"], 1))
+               * max(0.4 * np.sqrt(max(k2, 0.0)), self.opt.screen_mean_coherent * k1))
+        self.info["screen_mean_lead_over_threshold"] = lead / thr if thr > 0 else float("inf")
+        if not np.isfinite(sums).all() or not (lead >= thr):
+            raise _ScreenMissed(f"the best alpha's score sum leads by {lead:.3g}, the screening pass vouches for {thr:.3g}")
 
     def _screen_check(self, st, single_alpha):
         """Two-precision inner CV: how many voxels the step's screening pass left undecided (known here, at the step's one

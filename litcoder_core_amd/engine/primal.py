@@ -309,6 +309,15 @@ class PrimalForm:
         elif done is not None:
             main.wait_event(done)
         self.info.update(precision="f16x3" if split else "f32", fused_alphas=Ad, series_terms=SERIES_TERMS if moments else 0)
+        # screening arithmetic for the two sweeps of an inner fold (DualSweeps._screen_terms; the block products B = X'Y feed
+        # the refit as well and stay on three MFMAs)
+        panel = bool(hat.get("panel"))
+        live = hat.get("live") if panel else None
+        terms = self._screen_terms(hat, moments, split, PP)
+        if not panel:
+            self.info["screen_terms"] = min(self.info.get("screen_terms", 3), terms)
+        if terms == 1 and not self.opt.screen_two_workgroups:
+            terms = 101
         Vp_, V_ = self.Vp, self.V
         scores = torch.empty((A, Vp_), dtype=torch.float32, device=self.dev)
         scores_d = scores if not moments else (scores[:Ad] if cho_first else
@@ -388,7 +397,7 @@ class PrimalForm:
             self.info["fused_flops"] += 2.0 * Ad * n_v[f] * self.p * V_
             self.info["fused_launches"] += 1
             ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, PP, Bts[b], csBs[b][Vp_:], yv[b], Vp_, n_v[f], ystat[b], yblk[b],
-                                         self.mode, part, scores_d, accumulate=f > 0)
+                                         self.mode, part, scores_d, accumulate=f > 0, terms=terms, live=live)
 
         for f in range(F):
             b = f if two_pass else 0
@@ -424,7 +433,7 @@ class PrimalForm:
                     self.info["plain_launches"] += 1
                     ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], PP, Bt, self._cs_inv_padded(csB, Vt), Vt, yv[b], Vp_,
                                                   ystat[b], yblk[b], self.d_coef, hat["d_ser"], part_s, scores,
-                                                  accumulate=f > 0)
+                                                  accumulate=f > 0, terms=terms, live=live)
                 if Ad and not two_pass:
                     fused_sweep(f, b)
             else:
@@ -440,6 +449,8 @@ class PrimalForm:
         if moments and Ad and not cho_first:
             for i, a in enumerate(cho):
                 scores[a].copy_(scores_d[i])
+        if terms in (1, 101):
+            self._after_screening(hat, Y, scores, ystat[0], F, sum(n_v))
         if by_blocks:
             # the outer block's product = the sum of all its validation blocks': the refit's operand (_primal_refit_inputs)
             if split:

@@ -20,16 +20,39 @@ class Refit:
     """The refit half of RidgeCVEngine."""
 
     # -------------------------------------------------------------- alpha selection
-    def choose(self, scores, single_alpha):
+    def choose(self, scores, single_alpha, check=None):
         """(Vp,) int32 device vector of alpha indices: per-voxel first argmax (nested_cv.py:405-411)
         or, for ``single_alpha``, the argmax of the across-voxel mean (:396-400; the per-alpha sums
-        are all-reduced over the voxel shards)."""
+        are all-reduced over the voxel shards).  ``check``: the screening pass' note for the voxel mean
+        (DualSweeps._after_screening) -- its kappa sums travel with the per-alpha sums, see _mean_sums."""
         if single_alpha:
             _, rowsum = ops.select_alpha(scores, self.A, self.Vp, want_best=False, want_rowsum=True)
-            self.shard.all_reduce_(rowsum, "sum")          # A doubles, on the device: the choice never visits the host
+            rowsum = self._mean_sums(rowsum, [check] if check else [])     # A doubles, on the device: the choice never visits the host
             best = torch.empty(self.Vp, dtype=torch.int32, device=self.dev)
             return ops.fill_argmax(rowsum, self.A, best, self.Vp)     # first maximum, like torch.argmax
         return ops.select_alpha(scores, self.A, self.Vp)[0]
+
+    def _mean_sums(self, rowsum, checks):
+        """The per-alpha score sums of all voxel shards (all-reduce, on the device).  Under the screening pass (``checks``: the
+        notes of the ranges summed) the sums of kappa and kappa^2 ride along in the same all-reduce, and the result leaves for
+        pinned memory: fold_select looks at the lead of the best alpha there (_mean_check).  Returns the (A,) sums."""
+        A = self.A
+        if not checks:
+            self.shard.all_reduce_(rowsum, "sum")
+            return rowsum
+        tot = torch.empty(A + 2, dtype=torch.float64, device=self.dev)
+        tot[:A].copy_(rowsum)
+        tot[A:].copy_(checks[0]["ksums"])
+        for c in checks[1:]:
+            ops.accumulate_f64(c["ksums"], tot[A:])
+        self.shard.all_reduce_(tot, "sum")
+        host = torch.empty(A + 2, dtype=torch.float64, pin_memory=True)
+        host.copy_(tot, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        for c in checks:
+            c.update(host=host, ev=ev, done=False)
+        return tot[:A]
 
     # -------------------------------------------------------------- refit (ridge_torch)
     # three steps, so that the driver can put the fp64 systems on the auxiliary stream beside the next fold's
@@ -299,7 +322,12 @@ class Refit:
         # systems solved ahead of the choice enter the fold's cache when an alpha that has one is first used
         ahead = [a for a in used_all if a in have and a not in done_M and a not in on_series]
         if ahead and spec.get("P") is not None:          # refit_ahead left the inverses: apply them to the rows now
-            Pa = spec["P"] if ahead == have else torch.stack([spec["P"][have.index(a)] for a in ahead])
+            if ahead == have:
+                Pa = spec["P"]
+            else:                                       # (device-to-device copies into one block: no framework stack kernel)
+                Pa = torch.empty((len(ahead),) + tuple(spec["P"].shape[1:]), dtype=spec["P"].dtype, device=self.dev)
+                for i, a in enumerate(ahead):
+                    Pa[i].copy_(spec["P"][have.index(a)])
             Ma = self._apply_inverses(rhs, Pa)
             for i, a in enumerate(ahead):
                 done_M[a] = Ma[i]

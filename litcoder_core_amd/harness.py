@@ -223,7 +223,7 @@ class StoryPipeline:
             flying.wait_lead()
         else:
             flying = self._start_targets(brain, names, n_in)
-            dW = torch.cat([_dev_f64(b, dev) for b in blocks], dim=0)
+            dW = _dev_f64(np.concatenate(blocks, axis=0), dev)     # (joined on the host: one upload, no framework cat kernel)
         feat, off = ops.lanczos_interp_stories(dW, [word_times[s] for s in names], [tr_times[s] for s in names],
                                                window, cutoff_mult, False)
         return self._fit_rows(feat, off, n_in, names, flying, model_kwargs)

@@ -35,7 +35,7 @@ import torch
 from . import ops, series, stats  # noqa: F401
 from ._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2  # noqa: F401  (names tests / tools reach through here)
 from .dist import ShardContext
-from .engine.common import (SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions,  # noqa: F401
+from .engine.common import (_ScreenMissed, SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions,  # noqa: F401
                             check_penalties, _PrimalUnsuitable, _WideTargets, _GuessMissed, _FoldResult, _aux_stream, _Range,
                             _column_panels, _download_panels, _DeviceShapes)
 from .engine.core import EngineCore
@@ -253,16 +253,19 @@ class NestedCVModel(BasePredictivityModel):
             if isinstance(Y_all, ops.TargetsInFlight):
                 panels = list(Y_all.panels)             # (already crossing the link in these)
 
+        options_now = [None]                            # (a repeated fit's own options: _ScreenMissed)
+
         def attempt(form, precision, X_in, Y_in):
             eng = RidgeCVEngine(X_in, Y_in, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
                                 precision=precision, singcutoff=singcutoff, V_total=V_total,
-                                min_train_rows=min_train, form=form, panels=panels, options=self.options,
-                                down_panels=down_panels)
+                                min_train_rows=min_train, form=form, panels=panels,
+                                options=options_now[0] if options_now[0] is not None else self.options, down_panels=down_panels)
             self._engine = eng
-            # the inner CV's score tables are consumed by a per-voxel argmax and nothing else (nested_cv.py:405-411): the
-            # engine may screen them (FitOptions.screen_inner).  ONE alpha for all voxels is the argmax of the voxel MEAN
-            # (:396-400): another rule, not screened
+            # the inner CV's score tables are consumed by a per-voxel argmax and nothing else (nested_cv.py:405-411), or --
+            # ONE alpha for all voxels -- by the argmax of their voxel mean (:396-400): the engine may screen them
+            # (FitOptions.screen_inner)
             eng.argmax_only = not bool(single_alpha)
+            eng.mean_only = bool(single_alpha)              # ... its voxel mean is, with a check of the winner's lead (_mean_check)
             if self.debug_scores is not None:
                 eng.debug_scores = self.debug_scores
             drv_opt = getattr(eng, "opt", None) or FitOptions()     # (the tests' oracle-backed engine has none)
@@ -477,7 +480,7 @@ class NestedCVModel(BasePredictivityModel):
             try:
                 return attempt(form, self.precision if precision is None else precision, X_all if X_in is None else X_in,
                                Y_all if Y_in is None else Y_in)
-            except (_WideTargets, _PrimalUnsuitable, _GuessMissed):
+            except (_WideTargets, _PrimalUnsuitable, _GuessMissed, _ScreenMissed):
                 raise                                   # handled below / by the caller: the engine lives on
             except BaseException:
                 # the fit is being abandoned (e.g. "Cholesky failed" from fold_collect in the last folds): finished weight
@@ -495,12 +498,14 @@ class NestedCVModel(BasePredictivityModel):
             a repeated fit that meets the other condition is handled like a first one (an exception raised inside
             one ``except`` clause is not caught by its sibling, and a missed single-alpha guess whose repeat met a wide
             target column escaped with an internal exception)."""
-            precision, missed, wide_tries = None, False, 0
+            precision, missed, wide_tries, rescored = None, False, 0, False
             while True:
                 try:
                     out = run_(form, precision, X_in, Y_in)
                     if missed:
                         out[0].info["single_alpha_guess"] = "missed"
+                    if rescored:
+                        out[0].info["screen_mean_repeated"] = True
                     return out
                 except _GuessMissed as why:
                     # single_alpha, host inputs: the early panels' alpha was not the alpha of all voxels -- once more,
@@ -510,6 +515,16 @@ class NestedCVModel(BasePredictivityModel):
                     eng.abandon()                       # the early panels' weights may still be on their way to the host
                     torch.cuda.synchronize()
                     missed = True
+                    precision = self.precision if precision is None else precision
+                except _ScreenMissed as why:
+                    # single_alpha: the screening pass cannot vouch for the winner of the voxel-mean scores -- once more on
+                    # three MFMAs throughout, with what is resident
+                    eng = self._engine
+                    logger.info("screening pass not decisive (%s): the fit is repeated on three MFMAs", why)
+                    eng.abandon()                       # (early panels' weights may be on their way to the host)
+                    torch.cuda.synchronize()
+                    options_now[0] = dataclasses.replace(self.options or FitOptions(), screen_inner=False)
+                    rescored = True
                     precision = self.precision if precision is None else precision
                 except _WideTargets as why:
                     # host inputs + precision "auto": a panel that arrived later holds a column too wide for the fp16 split

@@ -1120,6 +1120,13 @@ def undecided_cols(scores, A, V, tau_sum, ystat, cap):
     return lst, count
 
 
+def kappa_sums(ystat, V):
+    """(2,) f64 device: sum and sum of squares over V voxels of kappa = rms / std of the validation rows (lc_kappa_sums)."""
+    out = torch.empty(2, dtype=torch.float64, device=ystat.device)
+    _lib.call("lc_kappa_sums", _p(ystat), ystat.stride(0), V, _p(out), _s())
+    return out
+
+
 def select_alpha(scores, A, V, want_best=True, want_rowsum=False):
     best = torch.empty(V, dtype=torch.int32, device=scores.device) if want_best else None
     rowsum = torch.empty(A, dtype=torch.float64, device=scores.device) if want_rowsum else None

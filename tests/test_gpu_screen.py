@@ -200,3 +200,47 @@ def test_screened_fit_against_the_oracle(lc):
     ours = model.fit_predict(X, Y, **kw)
     assert model.last_fit["screen_terms"] == 1 and model.last_fit["screened"] >= V, model.last_fit
     assert_matches_oracle(lc, model, ours, orc, detail, X, Y, kw, "screened fit vs oracle")
+
+
+@pytest.mark.parametrize("case", ["dual_single", "dual_single_missed", "primal_pervoxel", "primal_single", "primal_single_traintest"])
+def test_screening_single_alpha_and_primal_form(lc, case):
+    """single_alpha: the ONE alpha is the argmax of the voxel MEAN of the scores (nested_cv.py:396-400) -- screened sweeps, no
+    per-voxel refinement, the winner's lead checked against what the screening pass vouches for (_mean_check); a lead it cannot
+    vouch for (forced here with a huge screen_tau) repeats the fit on three MFMAs.  Primal (p x p) form: the two sweeps of an
+    inner fold on the screening arithmetic, the block products X'Y (which the refit shares) on three MFMAs; per-voxel alpha
+    with the undecided voxels' panel through the primal sweeps.  Every fit equals the unscreened one bit for bit."""
+    from litcoder_core_amd import NestedCVModel
+    from litcoder_core_amd.engine.common import FitOptions
+    rng = np.random.default_rng({"dual_single": 31, "dual_single_missed": 32, "primal_pervoxel": 33, "primal_single": 34,
+                                 "primal_single_traintest": 35}[case])
+    primal = case.startswith("primal")
+    T, p, V = (1500, 250, 2000) if primal else (900, 300, 2500)
+    X, Y = _problem(rng, T, p, V, noise_cols=0.1, signal=0.5)
+    single = "single" in case
+    kw = dict(folding_type="kfold", n_outer_folds=3, n_inner_folds=3, alphas=np.logspace(-1, 6, 15), single_alpha=single)
+    extra = {}
+    if case.endswith("traintest"):
+        extra = dict(X_test=X[1200:], y_test=Y[1200:])
+        X, Y = X[:1200], Y[:1200]
+        kw.pop("n_outer_folds")
+    opts = dict(screen_inner=True)
+    if case == "dual_single_missed":
+        opts["screen_tau"] = 1e6
+    m3 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(screen_inner=False))
+    out3 = m3.fit_predict(X, Y, **extra, **kw)
+    m1 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(**opts))
+    out1 = m1.fit_predict(X, Y, **extra, **kw)
+    assert m1.last_form == m3.last_form == ("primal" if primal else "dual")
+    if case == "dual_single_missed":
+        assert m1.last_fit.get("screen_mean_repeated") and m1.last_fit["screen_terms"] == 3, m1.last_fit
+    else:
+        assert m1.last_fit["screen_terms"] == 1 and m3.last_fit["screen_terms"] == 3, (m1.last_fit, m3.last_fit)
+        assert not m1.last_fit.get("screen_mean_repeated")
+        if single:
+            assert m1.last_fit["screen_mean_lead_over_threshold"] >= 1.0
+    for a3, a1 in zip(m3.last_fold_alphas, m1.last_fold_alphas):
+        np.testing.assert_array_equal(a1, a3)
+    np.testing.assert_array_equal(out1[2], out3[2])
+    np.testing.assert_array_equal(out1[1], out3[1])
+    np.testing.assert_array_equal(np.asarray(out1[0]["correlations"]), np.asarray(out3[0]["correlations"]))
+    np.testing.assert_array_equal(np.asarray(out1[0]["p_values"]), np.asarray(out3[0]["p_values"]))
