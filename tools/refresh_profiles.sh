@@ -1,7 +1,7 @@
 # Regenerates the round artefacts kept under profiles/ (run on the GPU box: gpurun -- bash tools/refresh_profiles.sh [tag]);
 # outputs land in gpurun_out/<tag>_final/ and are copied into profiles/ by hand (see profiles/README.md).
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${TAG}_final
@@ -16,6 +16,8 @@ done
 python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "k_sweep_f16x3<true" $O/sweep_fused_pmc.json > /dev/null
 python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "k_sweep_f16x3<false, false, true, true" $O/sweep_series_pmc.json > /dev/null
 python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "k_sweep_f16x3<false, false, false, false" $O/sweep_plain_pmc.json > /dev/null
+# round 6: clock / matrix-pipe busy / bytes leaving L2 of the sweeps' full-width launches in one table (screening pass and refit)
+python3 $R/tools/pmc_kernel_summary.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES -- "k_sweep_f16x3<true" "k_sweep_f16x3<false, false, true, true" "k_sweep_f16x3<false, false, false, false, false, false>" "k_sweep_f16x3<false, false, false, false, true" > $O/sweep_kernels_pmc.json 2>&1
 for K in k_mm64q k_lstep k_bstep k_potrf_diag; do
   python3 $R/tools/parse_pmc.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE /tmp/pmc_SQ_VALU_MFMA_BUSY_CYCLES "$K" $O/chol_${K}_pmc.json > /dev/null
 done
@@ -41,4 +43,5 @@ python3 $R/tools/main_stream_events.py 80000 > $O/device_timeline_1gpu.txt 2>&1
 python3 $R/tools/host_path_timeline.py > $O/host_path_timeline.txt 2>&1
 python3 $R/tools/other_configs.py > $O/other_configs.txt 2>&1
 python3 $R/tools/kstats.py /tmp/prof_stats 60 > $O/bench_kernel_stats.txt 2>&1 < /dev/null
+python3 $R/tools/screen_probe.py --reps 3 > $O/screen_probe_cfg2.txt 2>&1
 ls -la $O
