@@ -92,6 +92,10 @@ class FitOptions:
     tail_folds: int = 2                     # ... spread over this many folds, voxel-major (plan_steps)
     series_lookahead: bool = True           # the next step's first sweep part queued before a step's fused sweeps (driver)
     resident_refit_batch: bool = True       # resident inputs: refit inverses of folds 1.. as one batch after fold 0's choice
+    prepare_batch_folds: int = 0            # outer folds 1.. are prepared (Lanczos slices, series chains, Cholesky chains) in
+                                            # batches of this many folds (0: all of them as ONE batch -- a chain of N / 64
+                                            # dependent steps costs the same for 20 systems as for 80; a fold's sweeps can only
+                                            # start when ITS batch is complete, though)
     folds_in_one_launch_tiles: int = 512    # all inner folds of a step in ONE launch per pass while a fold's launch has fewer
                                             # 256 x 256 tiles than this (narrow voxel ranges: partial rounds of workgroups; measured -2.8 %
                                             # at 10 000 voxels, -0.5 % at 20 000 on one GPU, +1.7 % for a rank of 4 at 20 000); 0: never

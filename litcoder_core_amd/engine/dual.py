@@ -434,6 +434,8 @@ class DualSweeps:
         steps behind what is being queued), V / 16 (at least 2048 columns) before that; whole 256-column tiles."""
         if self.opt.screen_panel_cols > 0:
             return int(min(ops.pad_to(self.opt.screen_panel_cols, 256), ops.pad_to(V, 256)))
+        if self.shard.simulate:                          # (timing studies: the panel a real rank's ~1 % would get, _screen_check)
+            return int(min(ops.pad_to(max(V // 32, 512), 256), ops.pad_to(V, 256)))
         fracs = getattr(self, "_undecided_fracs", None)
         cap = int(2.0 * max(fracs) * V) + 256 if fracs else max(V // 16, 2048)     # (narrow ranges: generously, it costs nothing)
         return int(min(ops.pad_to(max(cap, 256), 256), ops.pad_to(V, 256)))

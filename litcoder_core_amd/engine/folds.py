@@ -347,6 +347,12 @@ class FoldPhases:
         ev.synchronize()
         found = int(host[0])                           # (voxel shards: the largest count of any rank)
         over = int(host[1]) > 0
+        if self.shard.simulate:
+            # one rank of a W-rank job run alone for timing (tools/scaling_model.py): its peers' operators are copies of its
+            # own, its scores mean nothing -- and neither does the share of voxels they leave undecided.  The rank is timed
+            # with a panel of the usual size (_refine_capacity) and no second scoring: what a real rank's step costs
+            self.info["screened"] = self.info.get("screened", 0) + V
+            return
         self.info["undecided"] = self.info.get("undecided", 0) + min(found, cap)
         self.info["screened"] = self.info.get("screened", 0) + V
         if not hasattr(self, "_undecided_fracs"):

@@ -255,6 +255,22 @@ class NestedCVModel(BasePredictivityModel):
 
         options_now = [None]                            # (a repeated fit's own options: _ScreenMissed)
 
+        def prepare_rest(eng, drv_opt, chol_after=None):
+            """The V-independent state of the outer folds 1.. : one batch, or batches of FitOptions.prepare_batch_folds folds."""
+            k = int(getattr(drv_opt, "prepare_batch_folds", 0) or 0)
+            if len(outer) <= 1:
+                return []
+            if k <= 0:
+                return eng.prepare_folds(outer[1:], lmax_pre_all[0][1:], chol_after=chol_after) if chol_after is not None \
+                    else eng.prepare_folds(outer[1:], lmax_pre_all[0][1:])
+            out = []
+            for i in range(1, len(outer), k):
+                kw = dict(chol_after=chol_after) if (chol_after is not None and i == 1) else {}
+                out += eng.prepare_folds(outer[i:i + k], lmax_pre_all[0][i:i + k], **kw)
+            return out
+
+        lmax_pre_all = [None]
+
         def attempt(form, precision, X_in, Y_in):
             eng = RidgeCVEngine(X_in, Y_in, alphas, normalpha, use_corr, normalize_features, normalize_targets, shard,
                                 precision=precision, singcutoff=singcutoff, V_total=V_total,
@@ -296,6 +312,7 @@ class NestedCVModel(BasePredictivityModel):
             n = len(outer)
             eng.begin_fit(n)                                    # resident targets: the one host sync of the set-up
             lmax_pre = eng.precompute_lmax(outer)               # one Lanczos run for every train set of the fit
+            lmax_pre_all[0] = lmax_pre
             # the (fold, voxel range) steps in execution order: folds full width, the first / last one panel by panel
             # while the targets arrive from / the weights leave for the host
             # host inputs: the targets need ~30 ms to cross PCIe, and until they are there the chip has little V-wide
@@ -403,7 +420,7 @@ class NestedCVModel(BasePredictivityModel):
                     st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
                 # (voxel shards: fold 0's sweeps queued before the batch, or fold 1's systems as a batch of their own, were
                 # measured and gave nothing -- profiles/experiments/README.md)
-                prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:]) if n > 1 else [])
+                prepared = [first] + prepare_rest(eng, drv_opt)
                 # (one GPU, host inputs: forming the later folds' inverses only for the alphas the first panel chose was
                 # measured 2.4 ms slower than forming all of them in the upload window -- profiles/experiments/README.md)
                 defer_ahead = False
@@ -425,8 +442,7 @@ class NestedCVModel(BasePredictivityModel):
                 if getattr(eng, "cho", None) and eng.opt.speculate_first_fold and eng.speculation_pays():
                     eng.fold_speculate(first, list(eng.cho), early=True)      # aux2: fold 0's refit systems, all of them
                 st = eng.fold_begin(*outer[0], prepared=first, step=plan[0])
-                prepared = [first] + (eng.prepare_folds(outer[1:], lmax_pre[1:], chol_after=eng.chain_gate())
-                                      if n > 1 else [])
+                prepared = [first] + prepare_rest(eng, drv_opt, chol_after=eng.chain_gate())
             # the weights leave panel by panel during the last fold (0.98 GB at cfg2: ~18 ms of PCIe): its first panel is
             # taken through refit BEFORE the next panel's sweeps are queued (no look-ahead at that step and at the one
             # before it), so that the link starts at the head of the fold and the rest of the fold hides the transfer

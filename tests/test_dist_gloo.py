@@ -121,6 +121,14 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     cols = shard.allgather_cols(np.arange(lo, hi, dtype=np.float64)[None, :] * 2.0, 37)
     assert np.array_equal(cols[0], 2.0 * np.arange(37)) and list(shard.all_bounds(37)) == [0, 19, 37]
     assert shard.allreduce_sum(np.array([r + 1.0, 0.5])).tolist() == [3.0, 1.0]
+    # local_targets: the job's total from the ranks' own block widths -- and a block that is not ShardContext.bounds' block is
+    # refused on EVERY rank alike, from the one all-reduced vector (ADVICE r5: it used to raise on one rank and hang the others)
+    assert shard.total_of_local_blocks(hi - lo) == 37
+    try:
+        shard.total_of_local_blocks((hi - lo) + (5 if shard.rank == 0 else 0))
+        raise AssertionError("uneven caller-supplied blocks must be refused")
+    except ValueError as e:
+        assert "local_targets" in str(e)
     # ---- the driver loop
     m, W, a = ncv.NestedCVModel("r", shard=shard).fit_predict(X, Y, **kw)
     assert W.shape == (12, hi - lo)
