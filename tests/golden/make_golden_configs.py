@@ -2,7 +2,7 @@
 """Config-shape fixtures: the REFERENCE itself (/root/reference, imported unmodified through _refimport.py) run in the
 build container on BASELINE.json's configs at their own shapes, 256 voxels each.  Minutes of CPU (30 SVDs per config):
 
-    python tests/golden/make_golden_configs.py [cfg2 cfg3 cfg4 cfg5]
+    python tests/golden/make_golden_configs.py [cfg2 cfg3 cfg4 cfg5 cfg2_r2 cfg2_single]
 
 Inputs are rebuilt from seeds (tests/_config_problems.py), so ``configs.npz`` stores only fingerprints of the inputs and
 the reference's OUTPUTS: per outer fold the chosen alphas, the fold-mean inner-CV score table (what a differing alpha
@@ -97,8 +97,16 @@ def run_fit(tag, out, spec, args, kwargs):
     print(tag, spec[tag], flush=True)
 
 
+VARIANTS = {"r2": dict(use_corr=False), "single": dict(single_alpha=True)}     # cfg2_r2, cfg2_single: round 6
+
+
 def gen_matrix(name, out, spec):
-    X, Y, kw = cp.matrix_problem(name)
+    """``name``: a config of _config_problems.CONFIGS, or config_variant (VARIANTS: the same inputs, another scoring rule /
+    alpha rule: ridge_regression.py:126-130, nested_cv.py:396-403)."""
+    base, _, var = name.partition("_")
+    X, Y, kw = cp.matrix_problem(base)
+    if var:
+        kw.update(VARIANTS[var])
     out[f"{name}__checks"] = cp.checks(X, Y)
     run_fit(name, out, spec, (X, Y), kw)
 
@@ -132,10 +140,11 @@ def gen_cfg3(out, spec):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4", "cfg5"]
+    ALL = ["cfg2", "cfg3", "cfg4", "cfg5", "cfg2_r2", "cfg2_single"]
+    which = sys.argv[1:] or ALL
     path = os.path.join(HERE, "configs.npz")
     out, spec = {}, {}
-    if os.path.exists(path) and len(which) < 4:         # partial regeneration keeps the other configs
+    if os.path.exists(path) and len(which) < len(ALL):  # partial regeneration keeps the other configs
         out = dict(np.load(path))
         spec = json.load(open(os.path.join(HERE, "configs.json")))
     for name in which:

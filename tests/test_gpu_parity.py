@@ -1806,3 +1806,35 @@ def test_lanczos_non_finite_sample_is_confined(lc):
         db0 = d.copy()
         db0[bad_row, bad_col] = 0.0
         np.testing.assert_allclose(out[far, bad_col], lanczos_interp(db0, ot, nt, 3, 1.0)[far, bad_col], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["cfg2_r2", "cfg2_single"])
+def test_baseline_shape_other_rules_against_reference_fixture(lc, golden_dir, tag):
+    """BASELINE cfg2's shape (T 3000, p 3072, 20 alphas, 5 x 5 K-folds) under the two other rules of the reference, against
+    outputs of the REFERENCE ITSELF on the 256 fixture voxels (round 6, VERDICT r5 #4: `configs.npz` was correlation scores /
+    per-voxel alpha only): cfg2_r2 = use_corr=False -- signed sqrt|R^2| scores, every alpha through its own hat matrix,
+    exact-zero ties at the heavy end (ridge_regression.py:126-130) -- and cfg2_single = single_alpha=True -- ONE alpha per
+    outer fold from the voxel mean of the scores (nested_cv.py:396-403; under the screening pass with its lead check)."""
+    import _config_problems as cp
+    import _fixtures as fx
+    from _oracle_check import assert_matches_oracle
+    import sys
+    sys.path.insert(0, os.path.join(golden_dir))
+    g, spec = fx.load(golden_dir)
+    X, Y, kw = cp.matrix_problem("cfg2")
+    kw.update(dict(use_corr=False) if tag == "cfg2_r2" else dict(single_alpha=True))
+    fx.check_inputs(g, f"{tag}__checks", X, Y)
+    oracle, detail = fx.reference_fit(g, tag, n_rows=len(X))
+    model = lc.NestedCVModel("r")
+    m, W, a = model.fit_predict(X, Y, **kw)
+    flips = assert_matches_oracle(lc, model, (m, W, a), oracle, detail, X, Y, kw, f"{tag} vs reference", corr_atol=1e-4,
+                                  w_rtol=1e-3, w_atol=1e-4, min_same=0.9, w_cols=spec[tag]["w_cols"])
+    got = np.asarray(m["correlations"])
+    np.testing.assert_allclose(got, oracle[0]["correlations"], rtol=0, atol=1e-3, err_msg=f"{flips} flipped (fold, voxel) pairs")
+    assert abs(np.median(got) - spec[tag]["median_score"]) < 1e-3
+    assert a.dtype == np.dtype(spec[tag]["alphas_dtype"])
+    if tag == "cfg2_single":
+        assert model.last_fit.get("screen_terms") == 1 and not model.last_fit.get("screen_mean_repeated"), model.last_fit
+        assert all(len(np.unique(f)) == 1 for f in model.last_fold_alphas)
+    else:
+        assert model.last_fit.get("screen_terms", 3) == 3          # R^2 scores are never screened
