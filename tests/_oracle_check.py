@@ -39,7 +39,7 @@ def _alpha_index(alphas, values):
 
 
 def assert_matches_oracle(lc, model, ours, oracle, detail, X, Y, kw, tag, corr_atol=3e-5, w_rtol=2e-4, w_atol=3e-6,
-                          gap_tol=2e-6, min_same=0.9, X_test=None, y_test=None, cols=None, w_cols=None):
+                          gap_tol=2e-6, min_same=0.9, X_test=None, y_test=None, cols=None, w_cols=None, r2_space=False):
     """``ours`` / ``oracle``: (metrics, W, alphas) of the two fits on the same inputs; ``detail``: the oracle's
     per-fold intermediates (oracle.nested_cv.fit_predict(detail=...)); ``cols``: columns of ``ours`` the oracle was run
     on (a voxel sample), default all; ``w_cols``: the oracle's weight matrix holds only its first ``w_cols`` columns
@@ -69,10 +69,16 @@ def assert_matches_oracle(lc, model, ours, oracle, detail, X, Y, kw, tag, corr_a
         else:
             v = np.nonzero(diff)[0]
             gap = tab[ko, v] - tab[km, v]
+            if r2_space:
+                # R^2 scores are signed sqrt|R^2| (ridge_regression.py:126-130): near R^2 = 0 the square root amplifies the
+                # fp32 rounding of 1 - resvar / var by 1 / (2 sqrt|R^2|) -- the near-tie is judged where the rounding
+                # happens, on R^2 itself: gap = R^2[oracle's alpha] - R^2[ours], R^2 = s |s|
+                gap = tab[ko, v] * np.abs(tab[ko, v]) - tab[km, v] * np.abs(tab[km, v])
             worst = int(np.argmax(np.abs(gap)))
             assert np.all(gap >= 0) and np.all(gap <= gap_tol), (
                 f"{tag}: fold {f}: {diff.sum()} alphas differ; voxel {v[worst]} oracle alpha {ao[diff][worst]:g} vs "
-                f"{am[diff][worst]:g} with an oracle score gap of {gap[worst]:.3g} > {gap_tol:g}: not a near-tie")
+                f"{am[diff][worst]:g} with an oracle score gap of {gap[worst]:.3g} > {gap_tol:g} (scores "
+                f"{tab[ko, v][worst]:.6g} / {tab[km, v][worst]:.6g}): not a near-tie")
         flipped |= diff
         n_flips += int(diff.sum())
     clean = ~flipped

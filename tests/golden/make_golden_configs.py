@@ -146,7 +146,7 @@ if __name__ == "__main__":
     out, spec = {}, {}
     if os.path.exists(path) and len(which) < len(ALL):  # partial regeneration keeps the other configs
         out = dict(np.load(path))
-        spec = json.load(open(os.path.join(HERE, "configs.json")))
+        spec = json.load(open(os.path.join(HERE, "configs.json")))["fits"]
     for name in which:
         for k in [k for k in out if k.split("__")[0].rstrip("sv") == name or k.split("__")[0] == name]:
             del out[k]

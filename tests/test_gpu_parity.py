@@ -1827,8 +1827,16 @@ def test_baseline_shape_other_rules_against_reference_fixture(lc, golden_dir, ta
     oracle, detail = fx.reference_fit(g, tag, n_rows=len(X))
     model = lc.NestedCVModel("r")
     m, W, a = model.fit_predict(X, Y, **kw)
+    # (R^2 scores: a differing alpha must be a near-tie of the reference's R^2 table -- <= 5e-6, a few dozen fp32 roundings of
+    # 1 - resvar / var -- judged on R^2 itself, not on its square root: _oracle_check)
+    r2 = tag == "cfg2_r2"
     flips = assert_matches_oracle(lc, model, (m, W, a), oracle, detail, X, Y, kw, f"{tag} vs reference", corr_atol=1e-4,
-                                  w_rtol=1e-3, w_atol=1e-4, min_same=0.9, w_cols=spec[tag]["w_cols"])
+                                  w_rtol=1e-3, w_atol=1e-4, min_same=0.7 if r2 else 0.9, w_cols=spec[tag]["w_cols"],
+                                  gap_tol=5e-6 if r2 else 2e-6, r2_space=r2)
+    # (R^2 at this shape: a fifth of the fixture's voxels -- signal strengths over two decades, R^2 of 1e-4 .. 1e-2 for most --
+    # have two alphas whose R^2 agree to a few fp32 roundings of 1 - resvar / var in the REFERENCE's own table; which of them
+    # wins is rounding noise in any arithmetic.  Every such flip is checked against that table above; the test scores of ALL
+    # voxels, flipped or not, must still agree below)
     got = np.asarray(m["correlations"])
     np.testing.assert_allclose(got, oracle[0]["correlations"], rtol=0, atol=1e-3, err_msg=f"{flips} flipped (fold, voxel) pairs")
     assert abs(np.median(got) - spec[tag]["median_score"]) < 1e-3
