@@ -67,6 +67,17 @@ def main():
         worst = gap1[flips].max().item() if flips.any() else 0.0
         print(f"         in units of 1/sqrt(validation rows = {rows}): rms error {d.pow(2).mean().sqrt().item() * rows ** 0.5:.2e}, "
               f"max error {d.max().item() * rows ** 0.5:.2e}, largest screening gap of a voxel whose argmax is wrong {worst * rows ** 0.5:.2e}")
+        # pairs of alphas on the polynomial series share the screening pass' moments: the error of a DIFFERENCE of their scores
+        # should shrink like 1 / alpha_min^2 -- per adjacent pair: max |d(light diff) - d(exact diff)| x alpha_min^2
+        ser = [i for i, al in enumerate(alphas) if al >= 7.9]
+        pair = []
+        for i, j in zip(ser[:-1], ser[1:]):
+            e = ((s1[i] - s1[j]) - (s3[i] - s3[j])).abs().max().item()
+            pair.append(e * float(alphas[i]) ** 2 * rows ** 0.5)
+        hat = [i for i, al in enumerate(alphas) if al < 7.9]
+        pair_h = [((s1[i] - s1[j]) - (s3[i] - s3[j])).abs().max().item() * rows ** 0.5 for i, j in zip(hat[:-1] + hat[-1:], hat[1:] + ser[:1])]
+        print(f"         error of score DIFFERENCES, max over voxels, units of 1/sqrt(rows): adjacent series pairs x alpha_min^2: "
+              + " ".join(f"{x:.1e}" for x in pair) + ";  pairs with a factorised alpha (no factor): " + " ".join(f"{x:.1e}" for x in pair_h))
         line = (f"fold {f3}: |d score| (fold mean) max {d.max().item():.2e}  99.9 % {torch.quantile(d.flatten()[::7].float(), 0.999).item():.2e}"
                 f"  rms {d.pow(2).mean().sqrt().item():.2e};  argmax differs for {int(flips.sum())} voxels"
                 f" (largest screening gap among them {gap1[flips].max().item() if flips.any() else 0.0:.2e})")
