@@ -359,7 +359,7 @@ template <bool SCORE, bool STAMP, bool LIGHTCAP = false, bool SERMOM = false, bo
 __global__ void __launch_bounds__(512, 2)
 k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT_tiles, int Mtiles, Score16Args sa,
               Plain16Args pa, BView bv, FoldViews fv) {
-    static_assert(!HI2 || ((SCORE || SERMOM) && !STAMP && !PEARSON), "HI2 is a mode of the score / series-moments kernels");
+    static_assert(!HI2 || ((SCORE || SERMOM) && !PEARSON), "HI2 is a mode of the score / series-moments kernels");
     const int KT = HI2 ? KT_tiles / 2 : KT_tiles;       // ring steps (HI2: two K-tiles each; the host checks K % 64 == 0)
     extern __shared__ __attribute__((aligned(16))) uint4 lds16[];
     const int tid = threadIdx.x;
@@ -475,12 +475,16 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         }
     }
     // targets of epilogue step s = 2 mi + ni (32 rows x this lane's column of panel ni)
-    auto load_t = [&](int step, lc::EpiTargets& t) {
-        const int blk = mt * (TM / 32) + wm * 4 + (step >> 1);                      // image block = (validation block, alpha)
-        // (blocks past the image's last one -- the padding of its last tile -- load the last validation block: unused)
-        lc::epi_load_targets(sa.yv, V, min(blk / sa.A, (sa.M >> 5) - 1) * 32, lh, colc[step & 1], t);
+    // Epilogue targets.  A wave's four 32-row blocks mi = 0..3 are image blocks mt 8 + wm 4 + mi = (validation block, alpha)
+    // pairs in that order, so consecutive mi mostly belong to the SAME validation block (always, with the fit's four
+    // factorised alphas): its targets -- 32 rows x this lane's column of the two panels -- are loaded once and kept (round 6;
+    // they used to be loaded again for every alpha: eight batches per wave where two do), the next block's only when it changes.
+    auto val_block = [&](int mi) {
+        // (blocks past the image's last one -- the padding of its last tile -- take the last validation block: unused)
+        return min((mt * (TM / 32) + wm * 4 + mi) / sa.A, (sa.M >> 5) - 1);
     };
-    lc::EpiTargets tb0, tb1, tb2;
+    auto load_vb = [&](int ib, int ni, lc::EpiTargets& t) { lc::epi_load_targets(sa.yv, V, ib * 32, lh, colc[ni], t); };
+    lc::EpiTargets tc0, tc1;                         // the current validation block's targets, panels 0 and 1
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     PHASE_BARRIER();
@@ -528,7 +532,7 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         const int stg = kt & 3;
         const uint4* pa_ = a_src + (long long)(kt + 4) * CHUNK16;
         const uint4* pb_ = b_src + (long long)BKT(kt + 4) * CHUNK16;
-        if (LAST && SCORE) { load_t(0, tb0); load_t(1, tb1); }   // land under the MFMAs of the last tile
+        if (LAST && SCORE) { load_vb(val_block(0), 0, tc0); load_vb(val_block(0), 1, tc1); }   // land under the MFMAs of the last tile
         // 12 slots of two MFMAs, term-major (the eight accumulators take the lo*hi terms, then hi*lo, then
         // hi*hi: small terms first, and consecutive MFMAs never wait for each other's result)
 #pragma unroll
@@ -603,7 +607,7 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         const bool do_dma = STEADY || (!LAST && kt + 4 < KT);
         const uint4* stn = lds16 + ((kt + 1) & 3) * STAGE16;
         const int stg = kt & 3;
-        if (LAST && SCORE) { load_t(0, tb0); load_t(1, tb1); }
+        if (LAST && SCORE) { load_vb(val_block(0), 0, tc0); load_vb(val_block(0), 1, tc1); }
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
 #pragma unroll
@@ -903,27 +907,22 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
                                      sa.part + (long long)(al * (sa.M >> 5) + ib) * 4 * V + colc[ni], V, cok[ni]);
     };
 #define EPI_FENCE() __builtin_amdgcn_sched_barrier(0)
-    load_t(2, tb2); EPI_FENCE();
     unsigned long long ter = 0;
-    if (STAMP) {                       // diagnostics: run step 0 twice, the second pass finds code and data warm
-#pragma unroll 1
-        for (int rep = 0; rep < 2; ++rep) {
-            reduce(0, tb0); EPI_FENCE();
-            if (rep == 0) { STAMP_T(ter); }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        reduce(2 * mi, tc0); EPI_FENCE();
+        reduce(2 * mi + 1, tc1); EPI_FENCE();
+        if (mi < 3) {
+            const int ib_next = val_block(mi + 1);
+            if (ib_next != val_block(mi)) {                      // (wave-uniform; never with the fit's four factorised alphas)
+                load_vb(ib_next, 0, tc0);
+                load_vb(ib_next, 1, tc1);
+            }
         }
-        load_t(3, tb0); EPI_FENCE();
-    } else {
-        reduce(0, tb0); EPI_FENCE(); load_t(3, tb0); EPI_FENCE();
+        EPI_FENCE();
+        if (mi == 0) { STAMP_T(ter); STAMP_T(te1); }
+        if (mi == 2) { STAMP_T(te2); }
     }
-    STAMP_T(te1);
-    reduce(1, tb1); EPI_FENCE(); load_t(4, tb1); EPI_FENCE();
-    reduce(2, tb2); EPI_FENCE(); load_t(5, tb2); EPI_FENCE();
-    reduce(3, tb0); EPI_FENCE(); load_t(6, tb0); EPI_FENCE();
-    reduce(4, tb1); EPI_FENCE(); load_t(7, tb1); EPI_FENCE();
-    reduce(5, tb2);
-    reduce(6, tb0);
-    STAMP_T(te2);
-    reduce(7, tb1);
     STAMP_T(te3);
 #undef EPI_FENCE
     if (STAMP) {
@@ -933,10 +932,10 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(pa.c) + wm * 16;
             atomicAdd(dbg + 7, tk3 - tk2);
             atomicAdd(dbg + 8, te0 - tk2);       // group-0 catch-up barrier
-            atomicAdd(dbg + 9, ter - te0);       // first reduce step (cold)
-            atomicAdd(dbg + 13, te1 - ter);      // the same step again (warm)
-            atomicAdd(dbg + 10, te2 - te1);      // steps 1..6
-            atomicAdd(dbg + 11, te3 - te2);      // step 7
+            atomicAdd(dbg + 9, ter - te0);       // block mi = 0 (two reduce steps, cold)
+            atomicAdd(dbg + 13, te1 - ter);      // (nothing between: the repeated step of rounds 3-5 is gone)
+            atomicAdd(dbg + 10, te2 - te1);      // blocks mi = 1, 2
+            atomicAdd(dbg + 11, te3 - te2);      // block mi = 3
             atomicAdd(dbg + 12, tk3 - te3);      // store drain
         }
     }
@@ -1047,11 +1046,9 @@ k_sweep_hi2(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT_t
         ymv[0] = sa.ymean[colc[wm]];
         cscv[0] = pa.cs_inv[ncol0 + wn * 64 + wm * 32 + li];
     }
-    auto load_t = [&](int step, lc::EpiTargets& t) {
-        const int blk = mt * (TM / 32) + wm * 4 + (step >> 1);                      // image block = (validation block, alpha)
-        lc::epi_load_targets(sa.yv, V, min(blk / sa.A, (sa.M >> 5) - 1) * 32, lh, colc[step & 1], t);
-    };
-    lc::EpiTargets tb0, tb1, tb2;
+    auto val_block = [&](int mi) { return min((mt * (TM / 32) + wm * 4 + mi) / sa.A, (sa.M >> 5) - 1); };
+    auto load_vb = [&](int ib, int ni, lc::EpiTargets& t) { lc::epi_load_targets(sa.yv, V, ib * 32, lh, colc[ni], t); };
+    lc::EpiTargets tc0, tc1;                         // the current validation block's targets, panels 0 and 1 (as in k_sweep_f16x3)
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     H2_BARRIER();
@@ -1095,7 +1092,7 @@ k_sweep_hi2(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT_t
         const bool do_dma = STEADY || (!LAST && kt + 3 < KT);
         const int s_nxt = s_cur == 2 ? 0 : s_cur + 1;
         const uint4* stn = lds16 + s_nxt * H2_STAGE16;
-        if (LAST && SCORE) { load_t(0, tb0); load_t(1, tb1); }
+        if (LAST && SCORE) { load_vb(val_block(0), 0, tc0); load_vb(val_block(0), 1, tc1); }
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
             if (!slab_empty) {
@@ -1223,15 +1220,19 @@ k_sweep_hi2(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT_t
                                      sa.part + (long long)(al * (sa.M >> 5) + ib) * 4 * V + colc[ni], V, cok[ni]);
     };
 #define H2_FENCE() __builtin_amdgcn_sched_barrier(0)
-    load_t(2, tb2); H2_FENCE();
-    reduce(0, tb0); H2_FENCE(); load_t(3, tb0); H2_FENCE();
-    reduce(1, tb1); H2_FENCE(); load_t(4, tb1); H2_FENCE();
-    reduce(2, tb2); H2_FENCE(); load_t(5, tb2); H2_FENCE();
-    reduce(3, tb0); H2_FENCE(); load_t(6, tb0); H2_FENCE();
-    reduce(4, tb1); H2_FENCE(); load_t(7, tb1); H2_FENCE();
-    reduce(5, tb2);
-    reduce(6, tb0);
-    reduce(7, tb1);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        reduce(2 * mi, tc0); H2_FENCE();
+        reduce(2 * mi + 1, tc1); H2_FENCE();
+        if (mi < 3) {
+            const int ib_next = val_block(mi + 1);
+            if (ib_next != val_block(mi)) {
+                load_vb(ib_next, 0, tc0);
+                load_vb(ib_next, 1, tc1);
+            }
+        }
+        H2_FENCE();
+    }
 #undef H2_FENCE
 #undef H2_BARRIER
 #undef H2_PIECE

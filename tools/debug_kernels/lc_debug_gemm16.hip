@@ -171,6 +171,31 @@ extern "C" int lc_debug_sweep16_stamps(const void* d_ht, const float* d_rowscale
     return lc::launched("k_sweep_f16x3<stamp>");
 }
 
+// ... the same for the HI2 mode (round 6: the screening pass; one MFMA per product, two K-tiles per ring step): d_stamps[.][5]
+// counts ring STEPS (N / 32 per tile and wave)
+extern "C" int lc_debug_sweep16_stamps_hi2(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N, const void* d_yt,
+                                           const float* d_cscale_inv, const float* d_yv, int64_t V, int n_val,
+                                           const float* d_ystat, float* d_part,
+                                           unsigned long long* d_stamps, lc_stream_t stream) {
+    LC_REQUIRE(d_ht && d_yt && d_stamps && N % 64 == 0, LC_E_BADARG, "lc_debug_sweep16_stamps_hi2: null pointer / N %% 64");
+    LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<true, true, false, false, false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
+    const int Mrows = A * M;
+    const int Mtiles = lc::ceil_div(Mrows, TM);
+    const long long Ntiles = lc::ceil_div<long long>(V, TN);
+    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val, LC_SCORE_CORR, Mrows, A};
+    Plain16Args pa{};
+    FoldViews fv{};
+    fv.mt_per_fold = Mtiles;
+    fv.n_val[0] = n_val;
+    fv.cut[0] = N / TK;
+    pa.c = reinterpret_cast<float*>(d_stamps);
+    hipLaunchKernelGGL((k_sweep_f16x3<true, true, false, false, false, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512),
+                       LDS16_BYTES, lc::as_stream(stream), (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa,
+                       BView{N / TK, N / TK, 0}, fv);
+    return lc::launched("k_sweep_f16x3<stamp, HI2>");
+}
+
 // Diagnostics: the single-group plain contraction on the 16x16x32 MFMA variant (see k_sweep16w_plain); same operands
 // and output as lc_gemm_grouped_f16x3 with one group.
 extern "C" int lc_debug_gemm_f16x3_wide(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,

@@ -111,6 +111,21 @@ if "sweep16" in what:
                   f"({h[g_, 0] / nw / 120:.0f} per K-tile; in-kernel clock {ghz:.2f} GHz), epilogue {h[g_, 7] / nw:.0f} cycles "
                   f"(step 0 {h[g_, 9] / nw:.0f}, again {h[g_, 13] / nw:.0f}, steps 1-6 {h[g_, 10] / nw:.0f}, "
                   f"step 7 {h[g_, 11] / nw:.0f}, drain {h[g_, 12] / nw:.0f})")
+        # the same stamps for the screening pass' form (HI2: one MFMA per product, 60 ring steps of two K-tiles; 4 alphas as in a fit)
+        A4 = 4
+        st = torch.zeros(32, dtype=torch.int64, device=dev)
+        rc = dbg.lc_debug_sweep16_stamps_hi2(p_(Ht), p_(rs_inv), A4, M, N, p_(Yt), p_(cs[V:]), p_(yv), ctypes.c_int64(V), n_v,
+                                             p_(ystat), p_(part), p_(st), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        h = st.cpu().numpy().reshape(2, 16)
+        for g_ in range(2):
+            nw = max(int(h[g_, 5]), 1) / 60
+            ghz = h[g_, 0] / max(h[g_, 14], 1) * 0.1
+            print(f"   HI2 (screening) waves {4 * g_}-{4 * g_ + 3}: per tile and wave: prologue {h[g_, 6] / nw:.0f}, main loop {h[g_, 0] / nw:.0f} "
+                  f"({h[g_, 0] / nw / 60:.0f} per ring step of two K-tiles, MFMA floor 1024; in-kernel clock {ghz:.2f} GHz), epilogue {h[g_, 7] / nw:.0f} cycles "
+                  f"(step 0 {h[g_, 9] / nw:.0f}, again {h[g_, 13] / nw:.0f}, steps 1-6 {h[g_, 10] / nw:.0f}, "
+                  f"step 7 {h[g_, 11] / nw:.0f}, drain {h[g_, 12] / nw:.0f})")
 
 if "plain16" in what:
     # the plain (store) launches of k_sweep_f16x3: series terms (2400 x 1920) and refit (3680 x 2400), V = 80000
