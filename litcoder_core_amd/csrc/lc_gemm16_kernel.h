@@ -8,7 +8,17 @@
 #include "lc_common.h"
 #include "lc_epilogue.h"
 
+// Experiment bits of the sweep kernel (tools/debug_kernels builds only: tools/sweep_delivery_probe.py); 0 in the product
+#ifndef LC_SWEEP_EXPERIMENTS
+#define LC_SWEEP_EXPERIMENTS 0
+#endif
+#ifndef LC_SWEEP_EXP_BITS
+#define LC_SWEEP_EXP_BITS (-1)                     // >= 0: the bits as a compile-time constant (no run-time branches in the loop)
+#endif
+
 namespace {
+
+constexpr bool EXPK = LC_SWEEP_EXPERIMENTS != 0;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -386,8 +396,25 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     if (!SCORE) {
         while (grp + 1 < pa.G && nt >= pa.start[grp + 1]) ++grp;
     }
-    const uint4* a_src = At + ((long long)grp * Mtiles + mt_all) * KT_tiles * CHUNK16 + tid;
-    const uint4* b_src = Bt + (long long)nt * bv.kt_total * CHUNK16 + tid;
+    // debug builds only (EXPK, tools/debug_kernels): experiment bits in pa.G, which the score modes do not use -- 1: the HI2 step
+    // fetches 16 KB contiguous per operand (the hi AND lo plane of K-tile t: wrong numbers, the same bytes) instead of two
+    // 8 KB hi planes 16 KB apart; 2: no MFMAs, no fragment reads (every wave only keeps the ring going: what the operand
+    // delivery alone takes); 4: every workgroup fetches tile (0, 0) (everything hits L2)
+    const int exp_bits = (EXPK && SCORE) ? (LC_SWEEP_EXP_BITS >= 0 ? LC_SWEEP_EXP_BITS : pa.G) : 0;
+    const bool exp_contig = exp_bits & 1, exp_dma_only = exp_bits & 2, exp_same = exp_bits & 4, exp_no_dma = exp_bits & 8;
+    // 8: no DMA in the main loop (MFMAs and fragment reads alone); 16: every tile starts its K loop at another K-tile and
+    // wraps (the workgroups of a round do not walk their slabs at the same offsets)
+    const bool exp_no_reads = exp_bits & 64, exp_no_mfma = exp_bits & 128;   // 64: no fragment reads; 128: no MFMAs (reads + DMA)
+    const bool exp_dword = exp_bits & 32;          // 32: every 1 KB LDS-DMA piece as four global_load_lds_dword of 256 B
+    // 256: every workgroup fetches a private 2 x 32 KB region over and over (L2-resident, spread over the channels)
+    const bool exp_private = exp_bits & 256;
+    const int exp_rot = (EXPK && (exp_bits & 16)) ? (int)(((long long)(tile / Mtiles) * 13 + (tile % Mtiles) * 7) % KT) : 0;
+    const uint4* a_src = At + ((long long)grp * Mtiles + (exp_same ? 0 : mt_all)) * KT_tiles * CHUNK16 + tid;
+    const uint4* b_src = Bt + (long long)(exp_same ? 0 : nt) * bv.kt_total * CHUNK16 + tid;
+    if (EXPK && exp_private) {
+        a_src = Bt + (long long)(blockIdx.x & 255) * 4 * CHUNK16 + tid;
+        b_src = Bt + (long long)(256 + (blockIdx.x & 255)) * 4 * CHUNK16 + tid;
+    }
 #define BKT(kt_) ((kt_) + ((kt_) >= b_cut ? b_skip : 0))
     // "light" slabs (plain mode): rows whose product only needs fp16 accuracy (11-bit operands) -- the higher
     // terms of a series, which enter the caller's result scaled down by >= 2^-11 -- take the hi*hi MFMA alone
@@ -414,7 +441,7 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     //   end of iteration j: wait (counted vmcnt: tiles j+3, j+4 may still fly) until this wave's share of tile
     //   j+2 has landed, then the barrier publishes it -- two iterations of latency budget per DMA.
     const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) uint4*)lds16);
-#define DMA16(gptr_, unit_)                                                                                   \
+#define DMA16_X4(gptr_, unit_)                                                                                \
     {                                                                                                         \
         const unsigned m0_ = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((unit_) + (wave << 6)) * 16u); \
         const uint4* gp_ = (gptr_);                                                                           \
@@ -422,12 +449,32 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
                      : "=&s"(keep_) : "v"(gp_), "s"(m0_) : "memory");                                          \
     }
+    // (STAMP experiment: the same 1 KB piece as four 256-byte pieces, one dword per lane)
+#define DMA16_D1Q(gp_, m0_)                                                                                   \
+    {                                                                                                         \
+        unsigned keep_;                                                                                       \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(gp_), "s"(m0_) : "memory");                                          \
+    }
+#define DMA16_D1(gptr_, unit_)                                                                                \
+    {                                                                                                         \
+        const unsigned m0b_ = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((unit_) + (wave << 6)) * 16u); \
+        const char* gpb_ = reinterpret_cast<const char*>(gptr_) - lane * 12;                                  \
+        DMA16_D1Q(gpb_, m0b_);                                                                                \
+        DMA16_D1Q(gpb_ + 256, m0b_ + 256u);                                                                   \
+        DMA16_D1Q(gpb_ + 512, m0b_ + 512u);                                                                   \
+        DMA16_D1Q(gpb_ + 768, m0b_ + 768u);                                                                   \
+    }
+#define DMA16(gptr_, unit_)                                   \
+    { if (EXPK && exp_dword) DMA16_D1(gptr_, unit_) else DMA16_X4(gptr_, unit_) }
     // the two pieces of an operand's share of ring step t: hi and lo plane of K-tile t, or (HI2) the hi planes of the
     // K-tiles 2t and 2t + 1 (a thread's unit of a plane: + tid, in a_src / b_src already; the lo plane follows 512 units on)
-#define SRC_A0(t_) (a_src + (long long)(HI2 ? 2 * (t_) : (t_)) * CHUNK16)
-#define SRC_A1(t_) (HI2 ? a_src + (long long)(2 * (t_) + 1) * CHUNK16 : a_src + (long long)(t_) * CHUNK16 + 512)
-#define SRC_B0(t_) (b_src + (long long)BKT(HI2 ? 2 * (t_) : (t_)) * CHUNK16)
-#define SRC_B1(t_) (HI2 ? b_src + (long long)BKT(2 * (t_) + 1) * CHUNK16 : b_src + (long long)BKT(t_) * CHUNK16 + 512)
+#define HI2_STRIDED (HI2 && !(EXPK && exp_contig))
+#define ROT_T(t_) (EXPK ? (exp_private ? ((t_) & 1) : ((t_) + exp_rot) >= KT ? (t_) + exp_rot - KT : (t_) + exp_rot) : (t_))
+#define SRC_A0(t_) (a_src + (long long)(HI2_STRIDED ? 2 * ROT_T(t_) : ROT_T(t_)) * CHUNK16)
+#define SRC_A1(t_) (HI2_STRIDED ? a_src + (long long)(2 * ROT_T(t_) + 1) * CHUNK16 : a_src + (long long)ROT_T(t_) * CHUNK16 + 512)
+#define SRC_B0(t_) (b_src + (long long)BKT(HI2_STRIDED ? 2 * ROT_T(t_) : ROT_T(t_)) * CHUNK16)
+#define SRC_B1(t_) (HI2_STRIDED ? b_src + (long long)BKT(2 * ROT_T(t_) + 1) * CHUNK16 : b_src + (long long)BKT(ROT_T(t_)) * CHUNK16 + 512)
 #define GLDS16(kt_, stg_)                                                           \
     {                                                                               \
         DMA16(SRC_A0(kt_), (stg_) * STAGE16);                                       \
@@ -604,19 +651,20 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr bool STEADY = MODE == 0, LAST = MODE == 2;
         const bool has_next = STEADY || (!LAST && kt + 1 < KT);
-        const bool do_dma = STEADY || (!LAST && kt + 4 < KT);
+        const bool do_dma = (STEADY || (!LAST && kt + 4 < KT)) && !(EXPK && exp_no_dma);
         const uint4* stn = lds16 + ((kt + 1) & 3) * STAGE16;
         const int stg = kt & 3;
         if (LAST && SCORE) { load_vb(val_block(0), 0, tc0); load_vb(val_block(0), 1, tc1); }
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
+            if (!(EXPK && exp_no_mfma))
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int i = 2 * sl + h, mi = (i & 7) >> 1, ni = i & 1;
                 if (i < 8) MFMA16(acc[mi][ni], cur.ah[mi], cur.bh[ni]);
                 else MFMA16(acc[mi][ni], cur.al[mi], cur.bl[ni]);
             }
-            if (has_next) {
+            if (has_next && !(EXPK && exp_no_reads)) {
                 // reads in the order the next step consumes them: bh, ah (K-tile 2 kt' first), then bl, al
                 if (sl == 0) { read_frag(nxt, stn, 0); read_frag(nxt, stn, 1); }
                 if (sl == 1) { read_frag(nxt, stn, 8); read_frag(nxt, stn, 9); }
@@ -633,7 +681,11 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
             __builtin_amdgcn_sched_barrier(0);
         }
         if (LAST) return;
-        if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        if (EXPK && exp_dword) {
+            if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
+            else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
@@ -652,7 +704,11 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
             DMA16(SRC_B1(kt + 4), stg * STAGE16 + CHUNK16 + 512);
         }
         if (LAST) return;
-        if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (EXPK && exp_dword) {
+            if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (STEADY || kt + 4 < KT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (kt + 3 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (STEADY || kt + 2 < KT) { PHASE_BARRIER(); }
@@ -660,8 +716,9 @@ k_sweep_f16x3(const uint4* __restrict__ At, const uint4* __restrict__ Bt, int KT
     using Steady = std::integral_constant<int, 0>;
     using Tail = std::integral_constant<int, 1>;
     using Last = std::integral_constant<int, 2>;
-    const bool slab_empty = !SERMOM && !STAMP && mt * TM + wm * 128 >= (SCORE ? sa.Mrows : pa.Mrows);
+    const bool slab_empty = (EXPK && exp_dma_only) || (!SERMOM && !STAMP && mt * TM + wm * 128 >= (SCORE ? sa.Mrows : pa.Mrows));
     int kt = 0;
+    if (EXPK && exp_no_reads) fb = fa;
     if (HI2 && !slab_empty) {
         for (; kt + 5 < KT; kt += 2) {
             kstep_hi2(kt, fa, fb, Steady{});

@@ -244,3 +244,36 @@ def test_screening_single_alpha_and_primal_form(lc, case):
     np.testing.assert_array_equal(out1[1], out3[1])
     np.testing.assert_array_equal(np.asarray(out1[0]["correlations"]), np.asarray(out3[0]["correlations"]))
     np.testing.assert_array_equal(np.asarray(out1[0]["p_values"]), np.asarray(out3[0]["p_values"]))
+
+
+@pytest.mark.parametrize("case", ["single_missed_in_panels", "pervoxel_overflow_in_panels"])
+def test_screening_fallbacks_with_host_panels(lc, case):
+    """The two fall-backs of the screening pass while the targets are still arriving from the host in voxel panels (explicit
+    256-column panels: nine of them): single_alpha with a lead the screening cannot vouch for (forced: huge screen_tau) -- the
+    early panels' weights may already be on their way back when the fit is given up and repeated on three MFMAs --, and
+    per-voxel alpha with a refinement panel that cannot hold a step's undecided voxels (forced: 256 columns, generous gap) --
+    the step is scored again.  Either way the fit equals the unscreened one bit for bit."""
+    from litcoder_core_amd import NestedCVModel
+    from litcoder_core_amd.engine.common import FitOptions
+    rng = np.random.default_rng(77 if case.startswith("single") else 78)
+    T, p, V = 700, 300, 2300
+    X, Y = _problem(rng, T, p, V, noise_cols=0.1, signal=0.5)
+    single = case.startswith("single")
+    kw = dict(folding_type="kfold", n_inner_folds=3, alphas=np.logspace(-1, 6, 15), single_alpha=single)
+    extra = dict(X_test=X[560:], y_test=Y[560:])
+    X, Y = X[:560], Y[:560]
+    opts = dict(screen_inner=True, screen_tau=1e6) if single else dict(screen_inner=True, screen_tau=0.2, screen_panel_cols=256)
+    m3 = NestedCVModel("ridge_regression", precision="f16x3", panel_cols=256, options=FitOptions(screen_inner=False))
+    out3 = m3.fit_predict(X, Y, **extra, **kw)
+    m1 = NestedCVModel("ridge_regression", precision="f16x3", panel_cols=256, options=FitOptions(**opts))
+    out1 = m1.fit_predict(X, Y, **extra, **kw)
+    assert len(m3.last_fit["panels"]) >= 3, m3.last_fit["panels"]            # (the plan both models start with)
+    if single:
+        # (last_fit describes the REPEATED fit: resident by then, one range)
+        assert m1.last_fit.get("screen_mean_repeated"), m1.last_fit
+    else:
+        assert len(m1.last_fit["panels"]) >= 3, m1.last_fit["panels"]
+        assert m1.last_fit.get("screen_overflows", 0) >= 1, m1.last_fit
+    np.testing.assert_array_equal(out1[2], out3[2])
+    np.testing.assert_array_equal(out1[1], out3[1])
+    np.testing.assert_array_equal(np.asarray(out1[0]["correlations"]), np.asarray(out3[0]["correlations"]))

@@ -2,6 +2,7 @@
 // s_memtime / s_memrealtime stamps (in-kernel clock, per-phase cycles) and the experiment kernel on
 // v_mfma_f32_16x16x32_f16 (plain mode only; measured 1-2 % faster than the 32x32x16 kernel, not adopted: HISTORY.md 4.1).
 // Built by tools/debug_kernels/build.py into tools/bin/liblitcoder_debug.so; tools/gpu_kernel_bench.py loads it.
+#define LC_SWEEP_EXPERIMENTS 1
 #include "../../litcoder_core_amd/csrc/lc_gemm16_kernel.h"
 #include "lc_debug.h"
 
@@ -194,6 +195,59 @@ extern "C" int lc_debug_sweep16_stamps_hi2(const void* d_ht, const float* d_rows
                        LDS16_BYTES, lc::as_stream(stream), (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa,
                        BView{N / TK, N / TK, 0}, fv);
     return lc::launched("k_sweep_f16x3<stamp, HI2>");
+}
+
+// ... and with the kernel's experiment bits (round 6, lc_gemm16_kernel.h: 1 = contiguous 16 KB fetches per operand and HI2
+// step, 2 = operand delivery alone (no MFMAs, no fragment reads), 4 = every workgroup fetches tile (0, 0)); hi2 = 0: the
+// three-MFMA form (bit 1 has no meaning there)
+extern "C" int lc_debug_sweep16_stamps_exp(const void* d_ht, const float* d_rowscale_inv, int A, int M, int N, const void* d_yt,
+                                           const float* d_cscale_inv, const float* d_yv, int64_t V, int n_val,
+                                           const float* d_ystat, float* d_part, unsigned long long* d_stamps, int hi2,
+                                           int exp_bits, lc_stream_t stream) {
+    LC_REQUIRE(d_ht && d_yt && N % 64 == 0, LC_E_BADARG, "lc_debug_sweep16_stamps_exp: null pointer / N %% 64");
+    if (d_stamps == nullptr) {
+        // no stamps: the PRODUCT instantiation (this translation unit's copy of it, with the experiment bits live)
+        LC_REQUIRE(hi2, LC_E_BADARG, "lc_debug_sweep16_stamps_exp: the un-stamped experiment build is the HI2 form");
+        LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_f16x3<true, false, false, false, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
+        const int Mrows = A * M;
+        const int Mtiles = lc::ceil_div(Mrows, TM);
+        const long long Ntiles = lc::ceil_div<long long>(V, TN);
+        Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val, LC_SCORE_CORR, Mrows, A};
+        Plain16Args pa{};
+        FoldViews fv{};
+        fv.mt_per_fold = Mtiles;
+        fv.n_val[0] = n_val;
+        fv.cut[0] = N / TK;
+        pa.G = exp_bits;
+        hipLaunchKernelGGL((k_sweep_f16x3<true, false, false, false, false, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512),
+                           LDS16_BYTES, lc::as_stream(stream), (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa,
+                           BView{N / TK, N / TK, 0}, fv);
+        return lc::launched("k_sweep_f16x3<HI2, exp>");
+    }
+    const void* fn = hi2 ? reinterpret_cast<const void*>(k_sweep_f16x3<true, true, false, false, false, true>)
+                         : reinterpret_cast<const void*>(k_sweep_f16x3<true, true>);
+    LC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS16_BYTES));
+    const int Mrows = A * M;
+    const int Mtiles = lc::ceil_div(Mrows, TM);
+    const long long Ntiles = lc::ceil_div<long long>(V, TN);
+    Score16Args sa{d_yv, d_ystat, d_rowscale_inv, d_cscale_inv, d_part, (long long)V, M, n_val, LC_SCORE_CORR, Mrows, A};
+    Plain16Args pa{};
+    FoldViews fv{};
+    fv.mt_per_fold = Mtiles;
+    fv.n_val[0] = n_val;
+    fv.cut[0] = N / TK;
+    pa.c = reinterpret_cast<float*>(d_stamps);
+    pa.G = exp_bits;
+    if (hi2)
+        hipLaunchKernelGGL((k_sweep_f16x3<true, true, false, false, false, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512),
+                           LDS16_BYTES, lc::as_stream(stream), (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa,
+                           BView{N / TK, N / TK, 0}, fv);
+    else
+        hipLaunchKernelGGL((k_sweep_f16x3<true, true>), dim3((unsigned)(Mtiles * Ntiles)), dim3(512), LDS16_BYTES,
+                           lc::as_stream(stream), (const uint4*)d_ht, (const uint4*)d_yt, N / TK, Mtiles, sa, pa,
+                           BView{N / TK, N / TK, 0}, fv);
+    return lc::launched("k_sweep_f16x3<stamp, exp>");
 }
 
 // Diagnostics: the single-group plain contraction on the 16x16x32 MFMA variant (see k_sweep16w_plain); same operands
