@@ -522,6 +522,15 @@ int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int64_t K, voi
  * series terms): every group is padded to whole 256-row tiles in the image and in d_rowscale_inv, one launch. */
 int lc_split_rows_f16_groups(const float* d_h, int64_t ld, int groups, int64_t rows, int64_t K, void* d_tiled,
                              float* d_rowscale_inv, lc_stream_t stream);
+/* The image of the MEAN of the folds' refit operators (round 6; replaces the per-fold weight products of ridge_torch,
+ * ridge_regression.py:46-61, followed by np.mean(fold_weights), nested_cv.py:249,293-296, for voxels that chose the same
+ * alpha tuple over the folds):  C[r][t] = scale * sum_f (maps[f][t] >= 0 ? mats[f][r * ld[f] + maps[f][t]] : 0), t < K, as
+ * the tiled fp16 hi/lo image lc_split_rows_f16 would make of C (pad256(rows) * K * 2 halves; d_rowscale_inv as there).
+ * h_mats / h_ld / h_maps: HOST arrays of n_folds (<= 16) entries -- device pointers to the (rows, ld) f32 operators and to
+ * the (K,) int32 column maps (16-byte aligned).  K %% 16 == 0, K <= 8192. */
+int lc_mean_operator_image_f16(const float* const* h_mats, const int64_t* h_ld, const int32_t* const* h_maps, int n_folds,
+                               float scale, int64_t rows, int64_t K, void* d_tiled, float* d_rowscale_inv,
+                               lc_stream_t stream);
 /* The A image of lc_alpha_sweep_scores_f16x3: per group (inner fold) the A hat matrices H_a (M x K each, stacked alpha by
  * alpha in d_h: rows a M + i), with the 32-row blocks taken in the order (validation block, alpha) -- image block s =
  * rows [32 (s / A), 32 (s / A) + 32) of alpha s %% A -- so that every 256-row tile of the sweep holds all alphas of the

@@ -66,6 +66,32 @@ extern "C" int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int
     return lc_split_rows_f16_groups(d_h, ld, 1, rows, K, d_tiled, d_rowscale_inv, stream);
 }
 
+extern "C" int lc_mean_operator_image_f16(const float* const* h_mats, const int64_t* h_ld, const int32_t* const* h_maps,
+                                          int n_folds, float scale, int64_t rows, int64_t K, void* d_tiled,
+                                          float* d_rowscale_inv, lc_stream_t stream) {
+    LC_REQUIRE(h_mats && h_ld && h_maps && d_tiled && d_rowscale_inv, LC_E_BADARG, "lc_mean_operator_image_f16: null pointer");
+    LC_REQUIRE(n_folds >= 1 && n_folds <= MO_MAX_FOLDS, LC_E_SHAPE, "lc_mean_operator_image_f16: 1..%d folds", MO_MAX_FOLDS);
+    LC_REQUIRE(rows > 0 && K > 0 && K % TK == 0 && K <= 512 * MO_UNITS, LC_E_SHAPE,
+               "lc_mean_operator_image_f16: need K %% %d == 0 and K <= %d", TK, 512 * MO_UNITS);
+    MeanOpArgs a{};
+    for (int f = 0; f < n_folds; ++f) {
+        LC_REQUIRE(h_mats[f] && h_maps[f], LC_E_BADARG, "lc_mean_operator_image_f16: null operator / map");
+        LC_REQUIRE((reinterpret_cast<uintptr_t>(h_maps[f]) & 15) == 0, LC_E_BADARG,
+                   "lc_mean_operator_image_f16: maps must be 16-byte aligned");
+        a.m[f] = h_mats[f];
+        a.ld[f] = (long long)h_ld[f];
+        a.map[f] = h_maps[f];
+    }
+    a.nf = n_folds;
+    a.scale = scale;
+    const long long rows_pad = lc::ceil_div<long long>(rows, TM) * TM;
+    LC_REQUIRE(rows_pad < (1ll << 31), LC_E_SHAPE, "lc_mean_operator_image_f16: too many rows");
+    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_mean_operator_image, dim3((unsigned)(rows_pad / 4)), dim3(256), 0, lc::as_stream(stream), a, (int)rows,
+                       (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad);
+    return lc::launched("k_mean_operator_image");
+}
+
 extern "C" int lc_col_scales_f16_flags(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
                                        int32_t* d_flag, uint8_t* d_colflag, lc_stream_t stream) {
     LC_REQUIRE(d_y && d_cscale, LC_E_BADARG, "lc_col_scales_f16: null pointer");     // d_flag may be NULL: scales only

@@ -95,6 +95,87 @@ __global__ void __launch_bounds__(256) k_split_rows_f16(const float* __restrict_
     }
 }
 
+// The image of the MEAN of several folds' refit operators (round 6): row r of the result is
+//     C[r][t] = scale * sum_f ( map_f[t] >= 0 ? M_f[r][map_f[t]] : 0 ),   t = 0 .. K-1   (fp32 sums, folds in order)
+// -- M_f (rows x ld_f) the operator of fold f at the alpha a group of voxels chose there (its columns are the fold's
+// training rows), map_f[t] the column of M_f that belongs to row t of the targets (-1: row t is not a training row of fold
+// f).  nested_cv.py:293-296 returns the mean of the folds' weight matrices and nothing else of them, and
+// mean_f (M_f Y[tr_f]) = (mean_f M_f scattered to all rows) Y: one contraction of depth T per group of voxels with the
+// same alpha in every fold instead of one of depth n_train per fold.  One wave per row: the sums stay in registers between
+// the row maximum and the split (MO_UNITS units of 8 columns per lane: K <= 512 MO_UNITS), image layout of k_split_rows_f16.
+constexpr int MO_MAX_FOLDS = 16, MO_UNITS = 16;
+struct MeanOpArgs {
+    const float* m[MO_MAX_FOLDS];
+    long long ld[MO_MAX_FOLDS];
+    const int* map[MO_MAX_FOLDS];
+    int nf;
+    float scale;
+};
+__global__ void __launch_bounds__(256) k_mean_operator_image(const MeanOpArgs a, int rows, int K, uint4* __restrict__ out,
+                                                             float* __restrict__ rs_inv, int rows_pad) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows_pad) return;
+    const int KT = K / TK, units = K / 8;
+    const bool live = r < rows;
+    float x[MO_UNITS][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < MO_UNITS; ++u) {
+        const int c = lane + 64 * u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[u][j] = 0.f;
+        if (!live || c >= units) continue;
+        for (int f = 0; f < a.nf; ++f) {
+            const int4 m0 = *reinterpret_cast<const int4*>(a.map[f] + c * 8);
+            const int4 m1 = *reinterpret_cast<const int4*>(a.map[f] + c * 8 + 4);
+            const float* src = a.m[f] + (long long)r * a.ld[f];
+            const int mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            if (m0.x >= 0 && m1.w == m0.x + 7 && (m0.x & 3) == 0 && (a.ld[f] & 3) == 0) {       // an aligned run of 8 columns
+                const float4 v0 = *reinterpret_cast<const float4*>(src + m0.x);
+                const float4 v1 = *reinterpret_cast<const float4*>(src + m0.x + 4);
+                x[u][0] = __fadd_rn(x[u][0], v0.x); x[u][1] = __fadd_rn(x[u][1], v0.y);
+                x[u][2] = __fadd_rn(x[u][2], v0.z); x[u][3] = __fadd_rn(x[u][3], v0.w);
+                x[u][4] = __fadd_rn(x[u][4], v1.x); x[u][5] = __fadd_rn(x[u][5], v1.y);
+                x[u][6] = __fadd_rn(x[u][6], v1.z); x[u][7] = __fadd_rn(x[u][7], v1.w);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (mm[j] >= 0) x[u][j] = __fadd_rn(x[u][j], src[mm[j]]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[u][j] = __fmul_rn(x[u][j], a.scale);
+            mx = fmaxf(mx, fabsf(x[u][j]));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) frexpf(mx, &e);
+    e = max(-120, min(120, e));
+    const float s = ldexpf(1.f, -e);
+    if (lane == 0) rs_inv[r] = ldexpf(1.f, e);
+    const long long tile_base = (long long)(r >> 8) * KT * CHUNK16;
+    const int rr = r & 255;
+#pragma unroll
+    for (int u = 0; u < MO_UNITS; ++u) {
+        const int c = lane + 64 * u;
+        if (c >= units) continue;
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = x[u][j] * s;
+            hi[j] = (_Float16)v;
+            lo[j] = (_Float16)(v - (float)hi[j]);
+        }
+        const long long o = tile_base + (long long)(c / KG) * CHUNK16 + (c % KG) * 256 + rr;
+        out[o] = *reinterpret_cast<uint4*>(&hi);
+        out[o + KG * 256] = *reinterpret_cast<uint4*>(&lo);
+    }
+}
+
 // Per-column power-of-two scale from max |y| over all T rows: cs[v] = 2^-e, cs[V + v] = 2^e.
 // *flag is OR-ed with 1 when most of a FINITE column's entries lie more than 2^9 below its maximum (outliers: the
 // 22-bit hi+lo split, whose precision is absolute w.r.t. the column maximum, would then resolve the typical entries

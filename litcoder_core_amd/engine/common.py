@@ -81,6 +81,14 @@ class FitOptions:
     speculate_first_fold: bool = True       # the first fold's refit systems for every factorised alpha, beside its chain
     speculate_max_rows: int = 4608          # ... and any refit system ahead of its alpha choice only up to this many rows
     refit_from_image: bool = True           # the refit's alpha-sorted fp16 operand gathered out of the inner CV's image
+    mean_operator_refit: bool = True        # (round 6) the mean weights of a cross-validated fit from the MEAN of the folds'
+                                            # refit operators, one contraction of depth T per group of voxels with the same alpha
+                                            # in every fold, instead of one of depth n_train per fold (engine/mean_refit.py)
+    mean_operator_min_cols: int = 16384     # ... for fits of at least this many voxels in all (small fits keep the folds' own
+                                            # products: an operator image per alpha tuple costs what ~3 column tiles do)
+    mean_operator_max_tuples: int = 256     # ... and while a voxel range has at most this many distinct alpha tuples
+    mean_operator_cost_ratio: float = 0.85  # ... and the grouped contraction + the operator images it needs are estimated at
+                                            # no more than this share of the folds' own products (tests force the path: 1e9)
     panel_cols: int = 36864                 # voxel columns per panel of a host-to-host fit (_column_panels): 12 288 / 24 576 /
                                             # 30 720 / 12 416 at cfg2 (measured 144.1 ms against 145.2 for 24 576-wide panels,
                                             # 145.2 for 73 728, 151.6 without panels)

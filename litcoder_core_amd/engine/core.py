@@ -161,6 +161,7 @@ class EngineCore:
         self._cs_all, self._cs_known = None, None      # column scales of the target panels that have arrived (_target_scales)
         self._ws = {}                                  # fold -> its alpha-sorted weight matrix + where each voxel went (_ws_slot)
         self._combined = 0                             # voxel columns whose mean weights are final (_combine_weights)
+        self._mo = None                                # the mean-operator refit's state (engine/mean_refit.py): decided at the first refit
         self._assume_split = None                      # the arithmetic the operators are prepared for (_split_assumed)
         self._decided = False                          # ... decided from ALL resident target columns (begin_fit)
         # constants of the fit that every stream reads: made here, before ``ready``

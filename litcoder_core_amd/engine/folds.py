@@ -280,7 +280,9 @@ class FoldPhases:
             self.fold_choose(st, single_alpha)
         self._screen_check(st, single_alpha)
         best, split = st["best"], st["split"]
-        perm, used, tiles, Vs, used_all = self._refit_groups(best, split, st.pop("grouping"))
+        grouping = st.pop("grouping")
+        perm, used, tiles, Vs, used_all = self._refit_groups(best, split, grouping)
+        st["best_h"] = grouping[3].numpy() if (len(grouping) > 3 and grouping[3] is not None) else None
         self._verify_target_flag(st["rg"])             # (its event lies before the sweeps whose histogram just arrived)
         main = torch.cuda.current_stream()
         base = st.get("base", st)
@@ -422,6 +424,13 @@ class FoldPhases:
         # the weight rows stay in alpha-sorted order where the contraction writes them (one matrix per fold, plus where each
         # voxel's column went); the mean over the folds is taken in one pass per voxel range once its last fold is in
         # (_combine_weights), not accumulated fold by fold
+        if not self.primal and self._mo_enabled(st):
+            # (round 6) no weight rows per fold: the range's mean weights come from the MEAN of the folds' operators once its
+            # last fold has chosen (engine/mean_refit.py) -- one contraction of depth T instead of one of depth n_train per fold
+            self._mo_record(st, weight_scale)
+            pend = self._publish(st, r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t, side_job=side_job)
+            self._range_finished(st)
+            return pend
         ent, off = self._ws_slot(st["fold"], rg, Vs, weight_scale)
         ops.invert_perm(perm, Vs, off, ent["pos"][rg.c0:])
         # (the side columns' r / p, exact f32, go over the main path's on the communication stream, just before the fold's
@@ -558,7 +567,9 @@ class FoldPhases:
         on the host (reserve_host_weights) it leaves NOW, on the download stream, beside the next range's refit."""
         if st["fold"] != self.n_folds - 1:
             return
-        if not self.moments:                           # (the moments form accumulates voxel by voxel: lc_primal_refit)
+        if getattr(self, "_mo", None):
+            self._mean_operator_weights(st["rg"])      # (the folds left their weight rows to this point)
+        elif not self.moments:                         # (the moments form accumulates voxel by voxel: lc_primal_refit)
             self._combine_weights(st["rg"])
         if self._host_weights is None:
             return

@@ -1,0 +1,223 @@
+"""The mean weights of a cross-validated fit from the MEAN of the folds' refit operators (round 6).
+
+nested_cv.py:293-296 returns ``np.mean(fold_weights, axis=0)`` and nothing else of the folds' weight matrices, and a fold's
+weights are linear in its training targets:  W_f[:, v] = M_f(alpha_f(v)) Y[tr_f, v]  (ridge_regression.py:46-61).  For the
+voxels that chose the same alpha TUPLE (alpha_0, .., alpha_{F-1}) over the folds,
+
+    mean_f W_f[:, v] = C Y[:, v],    C = 1/F sum_f M_f(alpha_f) scattered to the columns of its training rows   (p x T)
+
+-- ONE contraction of depth T per tuple group instead of one of depth n_train per fold: 5 x 2400 -> 3000 rows of depth at
+cfg2, where the folds' alphas of a voxel come from two neighbouring grid values (32 tuples, 40 with the rare ones).  The test
+predictions of every fold (Pearson r, p) are per fold by definition and keep their own contraction (FoldPhases.fold_finish).
+Tuples that a handful of voxels share (flat score curves: every fold another alpha) do not pay for an operator image of
+their own: their voxels take the folds' own weight products, restricted to them -- bit for bit what a fold-by-fold refit
+gives them.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from .common import logger
+
+
+class MeanOperatorRefit:
+    """Mixin of RidgeCVEngine: weights of a voxel range once its last fold has chosen."""
+
+    def _mo_possible(self):
+        """Static conditions (known before any alpha is chosen): a cross-validated fit in the dual form on the fp16x3 path whose
+        targets are the resident ones in every fold."""
+        o = self.opt
+        Kd = ops.pad_to(max(self.Ttot, 1), 32)
+        return bool(o.mean_operator_refit and self.n_folds >= 2 and self.n_folds <= 16 and not self.moments and not self.primal
+                    and not self.spectral and not self.norm_y and self.precision != "f32" and 64 <= Kd <= 8192
+                    and self.V_total >= o.mean_operator_min_cols)
+
+    def _mo_enabled(self, st):
+        """Decided at the first refit of the fit (the side panel of too-wide columns, which has a refit of its own, and the
+        arithmetic are known by then) and kept for all of it."""
+        if getattr(self, "_mo", None) is None:
+            ok = self._mo_possible() and bool(st["split"]) and self.side is None and st.get("best_h") is not None
+            self._mo = dict(folds={}, images={}, maps={}, done=0) if ok else False
+            self.info["mean_operator"] = dict(on=bool(ok), ranges=0, tuples=0, tiles=0, built=0, voxels=0, other_voxels=0)
+        return bool(self._mo)
+
+    def _mo_record(self, st, weight_scale):
+        """A (fold, range) step whose weight rows are NOT formed now: the alphas its voxels chose, the fold's operators (one
+        dictionary per fold, shared by its ranges: it fills as alphas are first used), the natural-order image of the range."""
+        f, rg = int(st["fold"]), st["rg"]
+        ent = self._mo["folds"].get(f)
+        if ent is None:
+            base = st.get("base", st)
+            cache = base.setdefault("refit_cache", {})
+            ent = self._mo["folds"][f] = dict(best=np.full(max(self.V_rank, 1), -1, dtype=np.int64), M=cache.setdefault("M", {}),
+                                              imgs=cache.setdefault("imgs", {}), tr=np.asarray(st["tr"], dtype=np.int64),
+                                              scale=float(weight_scale), images={})
+        if st.get("best_h") is None or not st["split"]:
+            raise RuntimeError("mean-operator refit: a step without host alpha indices / on the f32 path in a fit set up for it")
+        ent["best"][rg.c0:rg.c0 + rg.V] = st["best_h"][: rg.V]
+        ent["images"][rg.key] = st["hat"].get("image")
+
+    def _mo_map(self, fold, tr_rows, Kd):
+        """(Kd,) int32 device: column of fold ``fold``'s operators that belongs to target row t (-1: not a training row)."""
+        m = self._mo["maps"].get(fold)
+        if m is None:
+            h = np.full(Kd, -1, dtype=np.int32)
+            h[tr_rows] = np.arange(len(tr_rows), dtype=np.int32)
+            m = self._mo["maps"][fold] = ops.upload(h, self.dev)
+        return m
+
+    @staticmethod
+    def _padded_groups(order, cnt):
+        """Column list of voxels sorted into groups (``order``: the voxels group after group, ``cnt``: the groups' sizes), every
+        group starting on a 256-column tile: (perm (Vs,) int32 with -1 padding, tile starts (G + 1,))."""
+        cnt = np.asarray(cnt, dtype=np.int64)
+        tiles_g = (cnt + 255) // 256
+        start = np.concatenate([[0], np.cumsum(tiles_g)]).astype(np.int64)
+        perm = np.full(int(start[-1]) * 256, -1, dtype=np.int32)
+        if len(order):
+            gi = np.repeat(np.arange(len(cnt)), cnt)
+            first = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+            perm[start[gi] * 256 + (np.arange(len(order)) - first[gi])] = np.asarray(order, dtype=np.int32)
+        return perm, start
+
+    def _mean_operator_weights(self, rg):
+        """W of the range once its last fold has chosen: one grouped contraction of depth T over the voxels sorted by alpha
+        tuple (module docstring) for the tuples that pay for their operator image, the folds' own weight products for the
+        voxels of the others.  The tuples are formed on the host from the folds' alpha indices (they arrive with each fold's
+        histogram, fold_choose); a fold may have been worked through in other voxel ranges than this one (upload panels at the
+        start of a host-to-host fit, download panels at its end): only its alphas and its operators are needed here."""
+        mo, info = self._mo, self.info["mean_operator"]
+        folds = sorted(mo["folds"])
+        ents = [mo["folds"][f] for f in folds]
+        V, A, c0 = rg.V, self.A, rg.c0
+        best = [e["best"][c0:c0 + V] for e in ents]
+        if len(folds) != self.n_folds or any((b < 0).any() or (b >= A).any() for b in best):
+            raise RuntimeError("mean-operator refit: a voxel range finished before every fold had chosen its alphas")
+        Kd = ops.pad_to(self.Ttot, 32)
+        cs, _split = self._target_scales(rg.Y, rg)
+        # ---- host: mixed-radix tuple keys (digit f = rank of the voxel's alpha among the alphas fold f uses in this range)
+        key = np.zeros(V, dtype=np.int64)
+        stride, radix, used = 1, [], []
+        for b in best:
+            hist = np.bincount(b, minlength=A)
+            u = np.nonzero(hist)[0]
+            table = np.zeros(A, dtype=np.int64)
+            table[u] = np.arange(len(u))
+            if stride * len(u) > (1 << 62):
+                stride = None
+                break
+            key += table[b] * stride
+            radix.append(len(u))
+            used.append(u)
+            stride *= len(u)
+        n_o = [len(e["tr"]) for e in ents]
+        scales = {e["scale"] for e in ents}
+        pays = None
+        if stride is not None and len(scales) == 1:
+            if stride <= 65535:
+                k16 = key.astype(np.uint16)
+                order = np.argsort(k16, kind="stable")     # (radix sort)
+                counts = np.bincount(k16, minlength=stride)
+                live = np.nonzero(counts)[0]
+                cnt = counts[live]
+            else:
+                order = np.argsort(key, kind="stable")
+                live, cnt = np.unique(key, return_counts=True)
+            tuples = []
+            for kq in live:
+                q, tup = int(kq), []
+                for u in used:
+                    tup.append(int(u[q % len(u)]))
+                    q //= len(u)
+                tuples.append(tuple(tup))
+            # which tuples pay.  Costs in (column tile x depth row) units of the grouped contraction (3.7 ns at cfg2); one
+            # operator image costs ~12 900 of them there (46 us: the folds' operators read, the image written), a cached one
+            # a quarter (a device copy); the folds' own products cost a tuple's voxels their share of sum_f n_train depth rows
+            build = 0.85 * (sum(ops.pad_to(n, 64) for n in n_o) + Kd)
+            cached = np.asarray([t in mo["images"] for t in tuples], dtype=bool)
+            cost_new = ((cnt + 255) // 256) * Kd + np.where(cached, 0.25, 1.0) * build
+            cost_old = cnt / 256.0 * float(sum(n_o))
+            pays = cost_new <= self.opt.mean_operator_cost_ratio * cost_old
+            if pays.sum() > self.opt.mean_operator_max_tuples:
+                keep = np.argsort(-cnt, kind="stable")[: self.opt.mean_operator_max_tuples]
+                mask = np.zeros(len(cnt), dtype=bool)
+                mask[keep] = True
+                pays &= mask
+        parts = []
+        rest = np.arange(V)
+        if pays is not None and pays.any():
+            sel_sorted = np.repeat(pays, cnt)          # per voxel in ``order``
+            sel_groups = np.nonzero(pays)[0]
+            G = len(sel_groups)
+            perm_h, start = self._padded_groups(order[sel_sorted], cnt[sel_groups])
+            rest = np.sort(order[~sel_sorted])
+            Vs = len(perm_h)
+            perm = ops.upload(perm_h, self.dev)
+            # operands: the natural-order image of ALL target rows of the range, its columns gathered tuple by tuple
+            Vt = ops.pad_to(rg.Vp, 256)
+            rows_all = ops.idx_tensor(np.arange(self.Ttot), Kd, self.dev)
+            Yu = torch.empty(Vt * Kd * 2, dtype=torch.float16, device=self.dev)
+            ops.split_cols_f16(rg.Y, rg.Vp, rows_all, Kd, cs, Yu)
+            Yt = torch.empty(Vs * Kd * 2, dtype=torch.float16, device=self.dev)
+            ops.permute_cols_f16(Yu, perm, Vs, Kd, Yt)
+            del Yu
+            cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)
+            ops.gather(cs.reshape(2, rg.Vp), rg.Vp, None, 2, perm, Vs, cs_s)
+            # ... and the groups' mean-operator images
+            rows = self.p_pad
+            rows_pad = ops.pad_to(rows, 256)
+            At = torch.empty(G * rows_pad * Kd * 2, dtype=torch.float16, device=self.dev)
+            rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
+            maps = [self._mo_map(f, e["tr"], Kd) for f, e in zip(folds, ents)]
+            new_imgs = 0
+            for g, gq in enumerate(sel_groups):
+                tup = tuples[gq]
+                a_g, r_g = At[g * rows_pad * Kd * 2:(g + 1) * rows_pad * Kd * 2], rs_inv[g * rows_pad:(g + 1) * rows_pad]
+                hit = mo["images"].get(tup)
+                if hit is not None:
+                    a_g.copy_(hit[0])
+                    r_g.copy_(hit[1])
+                    continue
+                ops.mean_operator_image([e["M"][a][:rows] for e, a in zip(ents, tup)], maps, ents[0]["scale"], rows, Kd, a_g, r_g)
+                mo["images"][tup] = (a_g, r_g)
+                new_imgs += 1
+            C = torch.empty((rows, Vs), dtype=torch.float32, device=self.dev)
+            ops.gemm_grouped_f16x3(At, rs_inv, rows, Yt, cs_s[1], C, Vs, Vs, Kd, [int(t) for t in start])
+            n_comb = int(sel_sorted.sum())
+            self.info["plain_flops"] += 2.0 * self.p * self.Ttot * n_comb
+            self.info["plain_launches"] += 1
+            pos = ops.filled((max(V, 1),), torch.int32, self.dev, 0xFF)
+            ops.invert_perm(perm, Vs, 0, pos)
+            parts.append((C, pos, 1.0))
+            info["tuples"] += G
+            info["tiles"] += int(start[-1])
+            info["built"] += new_imgs
+            info["voxels"] += n_comb
+        # ---- the other voxels: the folds' own products, restricted to them (the operands and the arithmetic a fold-by-fold
+        # refit gives them: alpha groups in ascending order, voxels in ascending order inside)
+        if len(rest):
+            for f, e, b in zip(folds, ents, best):
+                a_r = b[rest]
+                o_r = np.argsort(a_r.astype(np.uint16), kind="stable")
+                c_r = np.bincount(a_r, minlength=A)
+                used_r = [int(a) for a in np.nonzero(c_r)[0]]
+                perm_r, start_r = self._padded_groups(rest[o_r], c_r[used_r])
+                Vs_r = len(perm_r)
+                d_perm_r = ops.upload(perm_r, self.dev)
+                o = self._refit_operands(rg.Y, e["tr"], (), d_perm_r, [int(t) for t in start_r], Vs_r,
+                                         [e["M"][a] for a in used_r], True, cs, image=e["images"].get(rg.key))
+                o.update(used=tuple(used_r), img_cache=e["imgs"])
+                buf = torch.empty((self.p_pad, Vs_r), dtype=torch.float32, device=self.dev)
+                self._refit_product(o, 0, self.p_pad, self.p, out=buf)
+                pos_r = ops.filled((max(V, 1),), torch.int32, self.dev, 0xFF)
+                ops.invert_perm(d_perm_r, Vs_r, 0, pos_r)
+                parts.append((buf, pos_r, e["scale"]))
+            info["other_voxels"] += int(len(rest))
+        ops.combine_folds(parts, self.p, V, rg.W)      # natural voxel order: every voxel has exactly one source
+        info["ranges"] += 1
+        mo["done"] += V
+        if mo["done"] >= self.V_rank:                  # every range of the rank is final: nothing of the fit is kept
+            mo["folds"].clear()
+            mo["images"].clear()
+            mo["maps"].clear()
+            mo["done"] = 0

@@ -64,7 +64,7 @@ class Refit:
         tile = 256 if split else COL_TILE                 # column-tile width of the GEMM that follows
         if pending is None:
             pending = self._group_async(best, split)
-        perm, count_h, ev = pending
+        perm, count_h, ev = pending[:3]
         ev.synchronize()
         count_h = count_h.numpy()
         if isinstance(perm, list):                       # more than 64 alphas: grouped range by range, joined now
@@ -86,9 +86,15 @@ class Refit:
         self.shard.all_reduce_(count2[1], "sum")                         # row 1 -> the histogram over all voxel shards
         count_h = torch.empty((2, self.A), dtype=torch.int32, pin_memory=True)
         count_h.copy_(count2, non_blocking=True)
+        best_h = None
+        if getattr(self, "_mo", None) is not False and self._mo_possible():
+            # the alpha indices themselves travel with the histogram: the mean-operator refit groups the voxels by their alpha
+            # TUPLE over the folds on the host (engine/mean_refit.py; 4 bytes per voxel)
+            best_h = torch.empty(self.Vp, dtype=torch.int32, pin_memory=True)
+            best_h.copy_(best[: self.Vp], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return perm, count_h, ev
+        return perm, count_h, ev, best_h
 
     def _refit_row_granule(self):
         """The augmented rows of a refit system can be cut into up to ``world`` slices (a power of two) that different
@@ -374,11 +380,11 @@ class Refit:
         from_image = (split and image is not None and self.opt.refit_from_image and n_o % K_TILE == 0
                       and len(image[1]) == n_o and np.array_equal(np.asarray(image[1]), np.asarray(tr_rows)))
         if from_image:
-            rows_x = ops.idx_tensor(np.asarray(extra_rows, dtype=np.int64), n_x, self.dev)
+            rows_x = ops.idx_tensor(np.asarray(extra_rows, dtype=np.int64), n_x, self.dev) if n_x > 0 else None
             Ys_te, te_src = None, None
             if n_x > 0 and (n_x <= 640 or self.opt.refit_fused_pearson):   # Pearson r reads the test rows through (rows, perm) in place
                 te_src = (Y, rows_x, perm)
-            else:
+            elif n_x > 0:
                 Ys_te = torch.empty((n_x, Vs), dtype=torch.float32, device=self.dev)
                 ops.gather(Y, Y.stride(0), rows_x, n_x, perm, Vs, Ys_te)
             cs_s = torch.empty((2, Vs), dtype=torch.float32, device=self.dev)

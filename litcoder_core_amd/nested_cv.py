@@ -41,6 +41,7 @@ from .engine.common import (_ScreenMissed, SERIES_TERMS, SINGCUTOFF_REL, GROUPS_
 from .engine.core import EngineCore
 from .engine.dual import DualSweeps
 from .engine.folds import FoldPhases
+from .engine.mean_refit import MeanOperatorRefit
 from .engine.primal import PrimalForm
 from .engine.refit import Refit
 from .folding import create_folds
@@ -58,7 +59,7 @@ class BasePredictivityModel:
         raise NotImplementedError
 
 
-class RidgeCVEngine(EngineCore, DualSweeps, PrimalForm, Refit, FoldPhases):
+class RidgeCVEngine(EngineCore, DualSweeps, PrimalForm, Refit, MeanOperatorRefit, FoldPhases):
     """Device-resident state of one fit: fp32 copies of X / Y (zero padded), the Gram matrix, and the
     per-fold pipeline.  ``Y`` holds only this rank's voxel block."""
 

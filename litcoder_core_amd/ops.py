@@ -971,6 +971,17 @@ def split_rows_f16_groups(h, groups, rows, K, tiled, rowscale_inv):
     _lib.call("lc_split_rows_f16_groups", _p(h), h.stride(0), groups, rows, K, _p(tiled), _p(rowscale_inv), _s())
 
 
+def mean_operator_image(mats, maps, scale, rows, K, tiled, rowscale_inv):
+    """The tiled fp16 image of  scale * sum_f scatter_f(mats[f][:rows])  -- the mean of the folds' refit operators, fold f's
+    columns sent to the target rows ``maps[f]`` lists ((K,) int32 device: column of mats[f] per target row, -1 none) -- and
+    its row scales (lc_mean_operator_image_f16)."""
+    n = len(mats)
+    m = (ctypes.c_void_p * n)(*[x.data_ptr() for x in mats])
+    ld = (ctypes.c_int64 * n)(*[int(x.stride(0)) for x in mats])
+    mp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in maps])
+    _lib.call("lc_mean_operator_image_f16", m, ld, mp, n, float(scale), rows, K, _p(tiled), _p(rowscale_inv), _s())
+
+
 def col_scales_f16(y, T, V, want_flag=True, colflags=None):
     """(cs, flag): cs[:V] = 2^-e, cs[V:] = 2^e per column; flag (device int32) != 0 when some column's
     dynamic range is too wide for the fp16 hi/lo split (``want_flag=False``: the scales alone, one pass over y).

@@ -78,7 +78,16 @@ def test_cfg2_full_size_properties(lc):
     blk[:, : hi - lo] = dY[:, lo:hi]
     m_b, W_b, a_b = lc.NestedCVModel("r").fit_predict_device(dX, blk, p, hi - lo, weights_on_host=True, **kw)
     assert np.array_equal(np.asarray(m_b["correlations"]), r[lo:hi]) and np.array_equal(a_b, a[lo:hi])
-    assert np.array_equal(W_b, W[:, lo:hi])
+    # (round 6) the big fit forms its mean weights from the MEAN of the folds' operators (engine/mean_refit.py: one product
+    # of depth T per alpha tuple), the block -- too narrow for a tuple to pay for its operator -- from the folds' own
+    # products: the same numbers to fp32 rounding of the two summation orders; bit for bit when both take the folds' products
+    assert model.last_fit["mean_operator"]["voxels"] > 0.9 * V, model.last_fit["mean_operator"]
+    assert np.abs(W_b - W[:, lo:hi]).max() <= 2e-6 * np.abs(W).max()
+    from litcoder_core_amd.engine.common import FitOptions
+    off = FitOptions(mean_operator_refit=False)
+    _, W0, a0 = lc.NestedCVModel("r", options=off).fit_predict_device(dX, dY, p, V, weights_on_host=True, **kw)
+    assert np.array_equal(a0, a) and np.abs(W0 - W).max() <= 2e-6 * np.abs(W).max()
+    assert np.array_equal(W_b, W0[:, lo:hi])
 
 
 def test_cfg3_synthetic_lebel_like_story_pipeline_train_test(lc):
@@ -315,13 +324,16 @@ def test_cfg4_narratives_shape_full_volume(lc, golden_dir):
     blk[:, : hi - lo] = dY[:, lo:hi]
     m_b, W_b, a_b = lc.NestedCVModel("r").fit_predict_device(dX, blk, p, hi - lo, weights_on_host=False, **kw)
     assert np.array_equal(np.asarray(m_b["correlations"]), r[lo:hi]) and np.array_equal(a_b, a[lo:hi])
-    assert torch.equal(W_b, W[:, lo:hi])
+    # (round 6: the mean weights of the wide fit come from the MEAN of the folds' operators per alpha tuple, those of the
+    # narrow block -- where fewer tuples pay for an operator image -- partly from the folds' own products: equal to fp32
+    # rounding of the two summation orders; bit for bit with the option off, test_cfg2_full_size_properties)
+    assert float((W_b - W[:, lo:hi]).abs().max()) <= 2e-6 * float(W.abs().max())
     perm = torch.randperm(hi - lo, device=dY.device, generator=torch.Generator(device=dY.device).manual_seed(1))
     blk[:, : hi - lo] = dY[:, lo:hi][:, perm]
     m_p, W_p, a_p = lc.NestedCVModel("r").fit_predict_device(dX, blk, p, hi - lo, weights_on_host=False, **kw)
     ph = perm.cpu().numpy()
     assert np.array_equal(np.asarray(m_p["correlations"]), r[lo:hi][ph]) and np.array_equal(a_p, a[lo:hi][ph])
-    assert torch.equal(W_p, W[:, lo:hi][:, perm])
+    assert torch.equal(W_p, W_b[:, perm])                                    # (the same block, its voxels shuffled: bit for bit)
     nv = cp.N_FIX
     oracle, detail = fx.reference_fit(g, "cfg4", n_rows=T)
     flips = assert_matches_oracle(lc, model, (m, W[:, :nv].cpu().numpy(), a), oracle, detail, X, Y, kw, "cfg4 vs reference",
@@ -346,7 +358,9 @@ def test_cfg4_narratives_shape_full_volume(lc, golden_dir):
     assert np.array_equal(np.asarray(m_h["correlations"]), r) and np.array_equal(a_h, a)
     assert np.array_equal(np.asarray(m_h["p_values"]), np.asarray(m["p_values"]))
     assert np.array_equal(np.asarray(m_h["significant_mask"]), np.asarray(m["significant_mask"]))
-    assert np.array_equal(W_h, W_res), "host-to-host weights differ from the resident fit's"
+    # (round 6: which alpha tuples get a mean operator is decided per voxel range from the range's own counts; a tuple near the
+    # break-even point may go one way in a download panel and the other way at full width -- the same weights to fp32 rounding)
+    assert np.abs(W_h - W_res).max() <= 2e-6 * np.abs(W_res).max(), "host-to-host weights differ from the resident fit's"
 
 
 def test_cfg5_whisper_shape_banded(lc, golden_dir):
@@ -388,7 +402,7 @@ def test_cfg5_whisper_shape_banded(lc, golden_dir):
     m_b, W_b, a_b = lc.BandedNestedCVModel("r").fit_predict(X, Yw[:, lo:hi], bands=[(0, p // 2), (p // 2, p)],
                                                             band_scales=[1.0, 2.0], **kw)
     assert np.array_equal(np.asarray(m_b["correlations"]), np.asarray(m["correlations"])[lo:hi]) and np.array_equal(a_b, a[lo:hi])
-    assert np.array_equal(W_b, W[:, lo:hi])
+    assert np.abs(W_b - W[:, lo:hi]).max() <= 2e-6 * np.abs(W).max()         # (round 6: see test_cfg4_narratives_shape_full_volume)
     oracle, detail = fx.reference_fit(g, "cfg5", n_rows=T)
     # weights come back on the ORIGINAL feature scale: w_b = w'_b / gamma_b
     assert_matches_oracle(lc, model, (m, W * gamma[:, None].astype(np.float32), a), oracle, detail, Xs, Yw, kw,
