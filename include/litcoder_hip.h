@@ -537,6 +537,11 @@ int lc_mean_operator_image_f16(const float* const* h_mats, const int64_t* h_ld, 
  * same few validation rows and its epilogue fetches those rows of the targets once, not once per alpha.  M %% 32 == 0. */
 int lc_split_rows_f16_alphas(const float* d_h, int64_t ld, int groups, int A, int64_t M, int64_t K, void* d_tiled,
                              float* d_rowscale_inv, lc_stream_t stream);
+/* The same of the FIRST A of the A_src hat matrices every group holds in d_h (group stride A_src * M rows): the screening
+ * pass of the inner CV (one fp16 MFMA per product: scores good to ~2e-4 relative) takes the largest factorised alphas from the
+ * shared series terms instead, where the 4-term series is accurate to << that (FitOptions.screen_series_tol). */
+int lc_split_rows_f16_alphas_sel(const float* d_h, int64_t ld, int groups, int A_src, int A, int64_t M, int64_t K,
+                                 void* d_tiled, float* d_rowscale_inv, lc_stream_t stream);
 
 /* Per-voxel power-of-two scale from max|y| over rows 0..T-1: d_cscale[v] = 2^-e, d_cscale[V + v] = 2^e.
  * *d_flag (caller-zeroed) is OR-ed with 1 when some column is non-finite or has most of its entries more

@@ -43,22 +43,29 @@ extern "C" int lc_split_rows_f16_groups(const float* d_h, int64_t ld, int groups
     LC_REQUIRE(rows_pad * groups < (1ll << 31), LC_E_SHAPE, "lc_split_rows_f16: too many rows");
     lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
     hipLaunchKernelGGL(k_split_rows_f16, dim3((unsigned)(rows_pad * groups / 4)), dim3(256), 0, lc::as_stream(stream), d_h,
-                       (long long)ld, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad, groups, 0);
+                       (long long)ld, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad, groups, 0, (int)rows);
+    return lc::launched("k_split_rows_f16");
+}
+
+extern "C" int lc_split_rows_f16_alphas_sel(const float* d_h, int64_t ld, int groups, int A_src, int A, int64_t M, int64_t K,
+                                            void* d_tiled, float* d_rowscale_inv, lc_stream_t stream) {
+    LC_REQUIRE(d_h && d_tiled && d_rowscale_inv, LC_E_BADARG, "lc_split_rows_f16_alphas: null pointer");
+    LC_REQUIRE(groups > 0 && A > 0 && A_src >= A && M > 0 && M % LC_MB == 0 && K > 0 && K % TK == 0 && ld % 4 == 0 && ld >= K,
+               LC_E_SHAPE, "lc_split_rows_f16_alphas: need 0 < A <= A_src, M %% %d == 0, K %% %d == 0 and ld %% 4 == 0", LC_MB, TK);
+    const long long rows = (long long)A * M;
+    const long long rows_pad = lc::ceil_div<long long>(rows, TM) * TM;
+    LC_REQUIRE(rows_pad * groups < (1ll << 31) && (long long)A_src * M < (1ll << 31), LC_E_SHAPE,
+               "lc_split_rows_f16_alphas: too many rows");
+    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_split_rows_f16, dim3((unsigned)(rows_pad * groups / 4)), dim3(256), 0, lc::as_stream(stream), d_h,
+                       (long long)ld, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad, groups, A,
+                       (int)((long long)A_src * M));
     return lc::launched("k_split_rows_f16");
 }
 
 extern "C" int lc_split_rows_f16_alphas(const float* d_h, int64_t ld, int groups, int A, int64_t M, int64_t K, void* d_tiled,
                                         float* d_rowscale_inv, lc_stream_t stream) {
-    LC_REQUIRE(d_h && d_tiled && d_rowscale_inv, LC_E_BADARG, "lc_split_rows_f16_alphas: null pointer");
-    LC_REQUIRE(groups > 0 && A > 0 && M > 0 && M % LC_MB == 0 && K > 0 && K % TK == 0 && ld % 4 == 0 && ld >= K, LC_E_SHAPE,
-               "lc_split_rows_f16_alphas: need M %% %d == 0, K %% %d == 0 and ld %% 4 == 0", LC_MB, TK);
-    const long long rows = (long long)A * M;
-    const long long rows_pad = lc::ceil_div<long long>(rows, TM) * TM;
-    LC_REQUIRE(rows_pad * groups < (1ll << 31), LC_E_SHAPE, "lc_split_rows_f16_alphas: too many rows");
-    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
-    hipLaunchKernelGGL(k_split_rows_f16, dim3((unsigned)(rows_pad * groups / 4)), dim3(256), 0, lc::as_stream(stream), d_h,
-                       (long long)ld, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad, groups, A);
-    return lc::launched("k_split_rows_f16");
+    return lc_split_rows_f16_alphas_sel(d_h, ld, groups, A, A, M, K, d_tiled, d_rowscale_inv, stream);
 }
 
 extern "C" int lc_split_rows_f16(const float* d_h, int64_t ld, int64_t rows, int64_t K, void* d_tiled,

@@ -44,9 +44,11 @@ __device__ inline int xcd_tile_id16(int bid, int nwg) {
 // (s / il_A) of alpha (s % il_A) -- so that a 256-row tile of the sweep holds ALL alphas of a few validation blocks and
 // its epilogue needs those few blocks of the validation targets, not eight different ones (round 4: the fused launch
 // fetched the targets once per alpha, 0.61 GB of its 2.75 GB at cfg2).
+// src_rows: the rows a group occupies in h (>= rows; the screening pass' image of the fused sweep takes the FIRST il_A alphas
+// of every group and leaves the others out).
 __global__ void __launch_bounds__(256) k_split_rows_f16(const float* __restrict__ h, long long ld, int rows, int K,
                                                         uint4* __restrict__ out, float* __restrict__ rs_inv,
-                                                        int rows_pad, int groups, int il_A) {
+                                                        int rows_pad, int groups, int il_A, int src_rows) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);          // row of the stacked, padded image
     const int lane = threadIdx.x & 63;
     if (r >= rows_pad * groups) return;
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__(256) k_split_rows_f16(const float* __restrict_
         const int s = rg >> 5, ib = s / il_A, a = s - ib * il_A;
         rsrc = a * (rows / il_A) + ib * 32 + (rg & 31);
     }
-    const float* src = h + ((long long)g * rows + rsrc) * ld;
+    const float* src = h + ((long long)g * src_rows + rsrc) * ld;
     float mx = 0.f;
     if (live)
         for (int k = lane * 4; k < K; k += 256) {

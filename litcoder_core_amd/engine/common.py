@@ -117,6 +117,11 @@ class FitOptions:
                                             # prediction errors averaged over those rows -- measured rms 3.7e-6, max 4.1e-5 over
                                             # 8e6 scores at cfg2 (2400 rows: gap 1.0e-4 = 27 rms; the largest gap of a voxel
                                             # whose screening argmax was wrong: 1.4e-5; profiles/r06_screen_probe_cfg2.txt)
+    screen_series_tol: float = 1e-5         # ... and the LARGEST factorised alphas whose 4-term series is accurate to this (relative:
+                                            # 1 / T_4(1 + 2 alpha^2); 2.5e-6 at alpha = 2.64, far below the screening arithmetic's
+                                            # own ~2e-4) are screened from the shared series terms, not from their hat matrices:
+                                            # the fused screening launch carries fewer alphas (3 of cfg2's 4; 0: never).  The
+                                            # undecided voxels' three-MFMA scores use the hat matrices of all of them, as before
     screen_two_workgroups: bool = False     # ... True: the screening sweeps in 4-wave workgroups on 256 x 128 tiles, two per CU
                                             # (k_sweep_hi2: one's prologue / epilogue / barrier under the other's MFMAs; VERDICT
                                             # r5 #1a).  Built, bit-identical scores, MEASURED SLOWER and not adopted: 0.574 ms

@@ -131,6 +131,20 @@ class EngineCore:
                                     for a in self.ser]) if self.ser else None)
         self.d_coef = ops.upload(np.asarray(self.coef_host, dtype=np.float64), self.dev) if self.ser else None
         self.d_cho = ops.upload(np.asarray(self.cho, dtype=np.int32), self.dev)
+        # the screening pass (FitOptions.screen_inner) takes the trailing factorised alphas whose series residual is far below
+        # its own arithmetic error from the series terms as well (screen_series_tol): scr_drop of them, in the order of cho
+        self.scr_drop = 0
+        if self.ser is not None and self.normalpha and not self.primal and self.opt.screen_series_tol > 0:
+            while (self.scr_drop < len(self.cho)
+                   and series.residual_bound(self.alphas[self.cho[len(self.cho) - 1 - self.scr_drop]], SERIES_TERMS)
+                   <= self.opt.screen_series_tol):
+                self.scr_drop += 1
+        self.d_ser_scr = self.d_coef_scr = None
+        if self.scr_drop:
+            ser_scr = list(self.ser) + list(self.cho[len(self.cho) - self.scr_drop:])
+            self.d_ser_scr = ops.upload(np.asarray(ser_scr, dtype=np.int32), self.dev)
+            self.d_coef_scr = ops.upload(np.stack([series.minimax_inverse_coefficients(self.alphas[a], SERIES_TERMS)
+                                                   for a in ser_scr]).astype(np.float64), self.dev)
         self.aux = _aux_stream(self.dev)
         self.aux2 = _aux_stream(self.dev, 1)            # refit systems (see _refit_stream)
         self.comm = _aux_stream(self.dev, 2)            # per-fold result exchange + global statistics

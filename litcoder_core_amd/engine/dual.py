@@ -205,6 +205,13 @@ class DualSweeps:
                 img.update(hp=hp, Ht=torch.empty(fc * hp * N * 2, dtype=torch.float16, device=self.dev),
                            rs_h=torch.empty(fc * hp, dtype=torch.float32, device=self.dev))
                 ops.split_rows_f16_alphas(H.view(-1, N), fc, Ac, M, N, img["Ht"], img["rs_h"])
+                Ac_s = Ac - int(getattr(self, "scr_drop", 0))
+                if 0 < Ac_s < Ac and self.opt.screen_inner:
+                    # the screening pass' image: the first Ac_s alphas only (the others are screened from the series terms)
+                    hp_s = ops.pad_to(Ac_s * M, 256)
+                    img.update(hp_s=hp_s, Ht_s=torch.empty(fc * hp_s * N * 2, dtype=torch.float16, device=self.dev),
+                               rs_hs=torch.empty(fc * hp_s, dtype=torch.float32, device=self.dev))
+                    ops.split_rows_f16_alphas_sel(H.view(-1, N), fc, Ac, Ac_s, M, N, img["Ht_s"], img["rs_hs"])
             Hs.append((f0, fc, H, P))
             imgs.append(img)
         info = self._join_flags(infos)
@@ -279,6 +286,16 @@ class DualSweeps:
         terms = self._screen_terms(hat, moments, split, N)
         if not panel:
             self.info["screen_terms"] = min(self.info.get("screen_terms", 3), terms)     # (1: some step of the fit screened)
+        # screening pass: the trailing factorised alphas that the 4-term series serves to << the screening error are scored from
+        # the series moments (FitOptions.screen_series_tol): the fused launch carries Ad_f < Ad alphas, from an image of its own
+        imgs_ = hat.get("imgs") or []
+        drop = int(getattr(self, "scr_drop", 0)) if (terms == 1 and moments and cho_first and self.d_ser is not None) else 0
+        if drop and not (drop == Ad or (imgs_ and all(im is not None and im.get("Ht_s") is not None for im in imgs_))):
+            drop = 0
+        Ad_f = Ad - drop
+        coef_s, dser_s = (self.d_coef_scr, self.d_ser_scr) if drop else (self.d_coef, hat["d_ser"])
+        if not panel:
+            self.info["fused_alphas"] = Ad_f
         if terms == 1 and not self.opt.screen_two_workgroups:
             terms = 101                                   # (lc_*_sweep_scores_f16x3_folds: the one-workgroup-per-CU kernel)
         folds = [(f0 + j, j, H, P) for f0, fc, H, P in hat["Hs"] for j in range(fc)]
@@ -324,7 +341,7 @@ class DualSweeps:
                     self.info["plain_flops"] += sum(2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * V_ for f in range(F))
                     self.info["plain_launches"] += 1
                     ops.series_sweep_scores_f16x3_folds(im["Pt"], im["rs_p"], M, n_v, N, Yt[0], cs_inv, Vt, yv, Vp_, ystat, yblk,
-                                                        self.d_coef, hat["d_ser"], part_f, scores, False, views, terms=terms,
+                                                        coef_s, dser_s, part_f, scores, False, views, terms=terms,
                                                         live=live)
                     return
                 for f, j, H, P in folds:
@@ -340,12 +357,12 @@ class DualSweeps:
                     self.info["plain_launches"] += 1
                     if fused:
                         ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], N, Yt[f], cs_inv, Vt, yv[f], Vp_, ystat[f], yblk[f],
-                                                      self.d_coef, hat["d_ser"], part_s, scores, accumulate=f > 0,
+                                                      coef_s, dser_s, part_s, scores, accumulate=f > 0,
                                                       bview=views[f], terms=terms, live=live)
                         continue
                     ops.gemm_grouped_f16x3(Pt_f, rs_p_f, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
                                            bview=views[f])
-                    ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], Vp_, yv[f], ystat[f], self.d_coef, hat["d_ser"],
+                    ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], Vp_, yv[f], ystat[f], coef_s, dser_s,
                                       scores, accumulate=f > 0, rowmap=rowmap)
 
         def fused_part():
@@ -355,14 +372,15 @@ class DualSweeps:
             # few dozen workgroups per launch); its scores are written over the main path's before any alpha is chosen
             side_job = self._side_sweeps_begin(hat, rg_) if (self.side is not None and split and not panel) else None
             # ---- pass 2 (the only one without the moment path): fused sweeps of the alphas that have hat matrices
-            if one_launch and fused and Ad:
+            if one_launch and fused and Ad_f:
                 im = imgs[0]
-                part_f = torch.empty((F, Ad * M // LC_MB, 4, Vp_), dtype=torch.float32, device=self.dev)
-                self.info["fused_flops"] += sum(2.0 * Ad * n_v[f] * hat["n_i"][f] * V_ for f in range(F))
+                part_f = torch.empty((F, Ad_f * M // LC_MB, 4, Vp_), dtype=torch.float32, device=self.dev)
+                self.info["fused_flops"] += sum(2.0 * Ad_f * n_v[f] * hat["n_i"][f] * V_ for f in range(F))
                 self.info["fused_launches"] += 1
                 self.info["folds_per_launch"] = F
-                ops.alpha_sweep_scores_f16x3_folds(im["Ht"], im["rs_h"], Ad, M, N, Yt[0], cs[Vp_:], yv, Vp_, n_v, ystat, yblk,
-                                                   self.mode, part_f, scores_d, False, views, terms=terms, live=live)
+                ops.alpha_sweep_scores_f16x3_folds(im["Ht_s" if drop else "Ht"], im["rs_hs" if drop else "rs_h"], Ad_f, M, N, Yt[0],
+                                                   cs[Vp_:], yv, Vp_, n_v, ystat, yblk, self.mode, part_f, scores_d, False, views,
+                                                   terms=terms, live=live)
             for f, j, H, P in (() if (one_launch and fused) else folds):
                 b = f if moments else 0
                 if not moments:
@@ -370,16 +388,19 @@ class DualSweeps:
                 if split:
                     if not moments and shared is None:
                         ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[b])
-                    if Ad:
-                        self.info["fused_flops"] += 2.0 * Ad * n_v[f] * hat["n_i"][f] * V_
+                    if Ad_f:
+                        self.info["fused_flops"] += 2.0 * Ad_f * n_v[f] * hat["n_i"][f] * V_
                         self.info["fused_launches"] += 1
                         Ht_f, rs_h_f = Ht, rs_inv
-                        if moments and f in img_of and img_of[f][0]["Ht"] is not None:
+                        if drop:                             # (the images exist: checked where ``drop`` was decided)
+                            im, g = img_of[f]
+                            Ht_f, rs_h_f = im["Ht_s"][g * im["hp_s"] * N * 2:], im["rs_hs"][g * im["hp_s"]:]
+                        elif moments and f in img_of and img_of[f][0]["Ht"] is not None:
                             im, g = img_of[f]
                             Ht_f, rs_h_f = im["Ht"][g * im["hp"] * N * 2:], im["rs_h"][g * im["hp"]:]
                         else:
                             ops.split_rows_f16_alphas(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), 1, Ad, M, N, Ht, rs_inv)
-                        ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad, M, N, Yt[b], cs[Vp_:], yv[b], Vp_, n_v[f], ystat[b],
+                        ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad_f, M, N, Yt[b], cs[Vp_:], yv[b], Vp_, n_v[f], ystat[b],
                                                      yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f],
                                                      terms=terms, live=live)
                 else:

@@ -53,6 +53,10 @@ class FoldPhases:
             sub["imgs"] = [dict(tp=tp, hp=hp, Pt=img["Pt"][s * tp * N * 2:(s + Fo) * tp * N * 2], rs_p=img["rs_p"][s * tp:(s + Fo) * tp],
                                 Ht=None if img["Ht"] is None else img["Ht"][s * hp * N * 2:(s + Fo) * hp * N * 2],
                                 rs_h=None if img["rs_h"] is None else img["rs_h"][s * hp:(s + Fo) * hp])]
+            if img.get("Ht_s") is not None:            # (the screening pass' image of the fused sweep: fewer alphas)
+                hs = img["hp_s"]
+                sub["imgs"][0].update(hp_s=hs, Ht_s=img["Ht_s"][s * hs * N * 2:(s + Fo) * hs * N * 2],
+                                      rs_hs=img["rs_hs"][s * hs:(s + Fo) * hs])
         return sub
 
     def prepare_folds(self, folds, lmax_pre, chol_after=None):
@@ -166,7 +170,8 @@ class FoldPhases:
                 for t in ([X, K, hat["tr"], hat["va"], hat["info"], hat["a2"], hat["lmax"], hat["d_ser"]]
                           + [out[i]["tr_o"] for i in g] + lmax_os
                           + [h for _, _, h, _ in hat["Hs"]] + [q for _, _, _, q in hat["Hs"]]
-                          + [im[k] for im in (hat.get("imgs") or []) if im is not None for k in ("Pt", "rs_p", "Ht", "rs_h")]):
+                          + [im.get(k) for im in (hat.get("imgs") or []) if im is not None
+                             for k in ("Pt", "rs_p", "Ht", "rs_h", "Ht_s", "rs_hs")]):
                     if t is not None and t.is_cuda:
                         t.record_stream(main)              # allocated on aux, consumed on main
         return out

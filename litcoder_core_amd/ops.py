@@ -966,6 +966,11 @@ def split_rows_f16_alphas(h, groups, A, M, K, tiled, rowscale_inv):
     _lib.call("lc_split_rows_f16_alphas", _p(h), h.stride(0), groups, A, M, K, _p(tiled), _p(rowscale_inv), _s())
 
 
+def split_rows_f16_alphas_sel(h, groups, A_src, A, M, K, tiled, rowscale_inv):
+    """split_rows_f16_alphas of the first ``A`` of the ``A_src`` hat matrices each group holds (lc_split_rows_f16_alphas_sel)."""
+    _lib.call("lc_split_rows_f16_alphas_sel", _p(h), h.stride(0), groups, A_src, A, M, K, _p(tiled), _p(rowscale_inv), _s())
+
+
 def split_rows_f16_groups(h, groups, rows, K, tiled, rowscale_inv):
     """``groups`` consecutive row blocks of ``rows`` rows of h, each padded to whole 256-row tiles in the image."""
     _lib.call("lc_split_rows_f16_groups", _p(h), h.stride(0), groups, rows, K, _p(tiled), _p(rowscale_inv), _s())
