@@ -117,6 +117,9 @@ class FitOptions:
                                             # prediction errors averaged over those rows -- measured rms 3.7e-6, max 4.1e-5 over
                                             # 8e6 scores at cfg2 (2400 rows: gap 1.0e-4 = 27 rms; the largest gap of a voxel
                                             # whose screening argmax was wrong: 1.4e-5; profiles/r06_screen_probe_cfg2.txt)
+    refine_on_side_stream: bool = True      # ... the undecided voxels' panel (a few column tiles: a quarter of the chip for ~1 ms
+                                            # per step) and the alpha choice behind it on a stream of their own, beside the NEXT
+                                            # step's full-width sweeps instead of in front of them (one GPU, no side panel)
     screen_series_tol: float = 1e-5         # ... and the LARGEST factorised alphas whose 4-term series is accurate to this (relative:
                                             # 1 / T_4(1 + 2 alpha^2); 2.5e-6 at alpha = 2.64, far below the screening arithmetic's
                                             # own ~2e-4) are screened from the shared series terms, not from their hat matrices:

@@ -447,6 +447,21 @@ class DualSweeps:
             return
         # the voxels the screening pass leaves undecided: scored again with the three-MFMA products, their columns of the
         # table overwritten -- before the side path's columns are, and before any alpha is chosen
+        if (self.opt.refine_on_side_stream and not self.shard.active and self.side is None and not hat.get("panel")
+                and self.dev.type == "cuda"):
+            # ... on a stream of its own: the panel is a few column tiles (64 workgroups at cfg2, ~1 ms of latency per step
+            # with three quarters of the chip idle), and nothing the main stream queues next -- the next step's sweeps --
+            # depends on it; the alpha choice follows on the same stream (fold_choose), the step's refit waits for both
+            rs = self.refine_stream
+            ev = torch.cuda.Event()
+            ev.record()
+            rs.wait_event(ev)
+            for t in (scores, ystat0):
+                t.record_stream(rs)                    # (made on the main stream, read / written over there)
+            with torch.cuda.stream(rs):
+                self._refine_undecided(hat, Y, scores, ystat0, F, n_val_rows)
+            hat["refine_stream"] = rs
+            return
         self._refine_undecided(hat, Y, scores, ystat0, F, n_val_rows)
 
     def _refine_capacity(self, V):
@@ -604,4 +619,10 @@ class DualSweeps:
         cs, split = self._target_scales(Y)
         hat = self._hat_matrices(K, inner_abs, moments=self._series_by_moments(split))
         hat.update(cs=cs, split=split)
-        return self._sweeps(hat, Y), hat["info"]
+        scores = self._sweeps(hat, Y)
+        if hat.get("refine_stream") is not None:       # (the table is completed on the refinement's stream: the caller reads it here)
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(hat["refine_stream"]):
+                ev.record()
+            torch.cuda.current_stream().wait_event(ev)
+        return scores, hat["info"]

@@ -234,6 +234,19 @@ class FoldPhases:
         histogram travels to pinned memory asynchronously, so the caller can queue the next fold's sweeps on the
         main stream BEFORE waiting for it in fold_select (the stream then never idles through the host round trip)."""
         self._enter(st)
+        rs = st["hat"].get("refine_stream")
+        if rs is not None and not st.get("_on_refine_stream"):
+            # the step's score table is being completed on the refinement's stream (DualSweeps._after_screening): the choice
+            # and the grouping follow it there; fold_finish makes the main stream wait for them
+            st["_on_refine_stream"] = True
+            try:
+                with torch.cuda.stream(rs):
+                    self.fold_choose(st, single_alpha)
+                    st["choose_done"] = torch.cuda.Event()
+                    st["choose_done"].record()
+            finally:
+                st.pop("_on_refine_stream", None)
+            return st
         if getattr(self, "debug_scores", None) is not None:      # (tools/screen_probe.py: the score tables of a fit)
             self.debug_scores.append((st["fold"], st["rg"].c0, st["scores"].clone()))
         st["best"] = self.choose(st["scores"], single_alpha, check=st["hat"].get("mean_check") if single_alpha else None)
@@ -376,6 +389,9 @@ class FoldPhases:
         self.info["screen_overflows"] = self.info.get("screen_overflows", 0) + 1
         hat = dict(st["hat"])
         hat["exact"] = True
+        hat.pop("refine_stream", None)
+        st["hat"].pop("refine_stream", None)           # (the new table is made, and chosen from, on the current stream)
+        st.pop("choose_done", None)
         self._enter(st)
         st["scores"] = self._sweeps(hat, st["Y"], st["done"])
         st.pop("grouping", None)
@@ -402,6 +418,11 @@ class FoldPhases:
             self._range_finished(st)
             return pend
         best, perm, Vs = st["best"], st["perm"], st["Vs"]
+        if st.get("choose_done") is not None:          # the choice was made on the refinement's stream (fold_choose)
+            torch.cuda.current_stream().wait_event(st["choose_done"])
+            for t in (best, perm):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(torch.cuda.current_stream())
         torch.cuda.current_stream().wait_event(st["systems_ready"])
         row0 = self.p_pad                              # first row of the test-row hat matrix inside M_alpha
         # (too-wide target columns: their refit in exact f32, on the side stream, beside the main path's below)
