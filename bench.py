@@ -168,31 +168,38 @@ def measured_traffic(voxels, per_pass_timeout=240):
             paths = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             # the fused score launches: with the screening pass on (round 6) those are the HI2 instantiation's (the few
             # three-MFMA launches of the undecided voxels' panel are another kernel: not mixed into the averages)
-            names = {}
+            # (round 6) ... and the series-moments launches of the same kernel, the inner CV's other contraction: the roofline's
+            # population is both kinds (sweep_roofline); the most frequent instantiation of each kind
+            names = {"score": {}, "series": {}}
             for path in paths:
                 with open(path) as f:
                     for row in csv.DictReader(f):
                         nm = row.get("Kernel_Name", "")
-                        if "k_sweep_f16x3<true" in nm:
-                            names[nm] = names.get(nm, 0) + 1
-            wanted = max(names, key=names.get) if names else None
+                        kind = ("score" if "k_sweep_f16x3<true" in nm else
+                                "series" if "k_sweep_f16x3<false, false, true, true" in nm else None)
+                        if kind:
+                            names[kind][nm] = names[kind].get(nm, 0) + 1
+            wanted = {max(d_, key=d_.get): kind for kind, d_ in names.items() if d_}
             for path in paths:
                 with open(path) as f:
                     for row in csv.DictReader(f):
-                        if wanted is None or row.get("Kernel_Name", "") != wanted:
+                        kind = wanted.get(row.get("Kernel_Name", ""))
+                        if kind is None:
                             continue
                         if row.get("Counter_Name") == counter:
-                            rows.append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+                            rows.append((int(row["Grid_Size"]), float(row["Counter_Value"]), kind))
                         elif row.get("Counter_Name") in extra:
-                            d = per_dispatch.setdefault(row["Dispatch_Id"], {"grid": int(row["Grid_Size"])})
+                            d = per_dispatch.setdefault(row["Dispatch_Id"], {"grid": int(row["Grid_Size"]), "kind": kind})
                             d[row["Counter_Name"]] = float(row["Counter_Value"])
                             d["ns"] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
             if extra:
                 # the clock the chip holds under the dominant kernel: GRBM_GUI_ACTIVE is summed over the 8 XCDs
                 # (MI355X_MICROARCH.md "DVFS give-back"); the matrix pipe's busy share of those cycles over 1024 SIMDs
-                full_grid = max((d["grid"] for d in per_dispatch.values()), default=0)
+                full_grid = {k: max((d["grid"] for d in per_dispatch.values() if d["kind"] == k), default=0) for k in names}
                 ds = [d for d in per_dispatch.values() if d.get("ns", 0) > 0 and "GRBM_GUI_ACTIVE" in d]
-                for tag, sel in (("all", ds), ("full_width", [d for d in ds if d["grid"] == full_grid])):
+                for tag, sel in (("all", ds), ("full_width", [d for d in ds if d["grid"] == full_grid[d["kind"]]]),
+                                 ("score_launches", [d for d in ds if d["kind"] == "score"]),
+                                 ("series_launches", [d for d in ds if d["kind"] == "series"])):
                     if sel:
                         cyc = sum(d["GRBM_GUI_ACTIVE"] for d in sel) / 8.0
                         ns = sum(d["ns"] for d in sel)
@@ -201,9 +208,9 @@ def measured_traffic(voxels, per_pass_timeout=240):
                                       "mfma_pipe_busy": busy / (1024.0 * cyc) if cyc > 0 and busy > 0 else None}
             if not rows:
                 return None, f"not measured: no k_sweep_f16x3 launch in the {counter} pass"
-            full = max(g for g, _ in rows)
-            wide = [v for g, v in rows if g == full]
-            means[counter] = (sum(v for _, v in rows) / len(rows), len(rows), sum(wide) / len(wide), len(wide))
+            full = {k: max((g for g, _, kk in rows if kk == k), default=0) for k in names}
+            wide = [v for g, v, k in rows if g == full[k]]
+            means[counter] = (sum(v for _, v, _ in rows) / len(rows), len(rows), sum(wide) / len(wide), len(wide))
     finally:
         signal.signal(signal.SIGTERM, old_term)
         shutil.rmtree(work, ignore_errors=True)
@@ -212,8 +219,8 @@ def measured_traffic(voxels, per_pass_timeout=240):
     res = {"all": fa * 1024 * 2 + wa * 1024, "full_width": ff * 1024 * 2 + wf * 1024, "launches": na, "launches_full_width": nf,
            "clock": clock or None}
     return res, (f"measured in this run, before the timed fits: child passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` "
-                 f"and `--pmc WRITE_SIZE` over one host-to-host fit (tools/host_fit_loop.py), mean over its {na} fused "
-                 f"launches of all widths (the population avg_launch_ms averages over): FETCH_SIZE {fa:.0f} KiB x2 (gfx950 "
+                 f"and `--pmc WRITE_SIZE` over one host-to-host fit (tools/host_fit_loop.py), mean over its {na} score + "
+                 f"series-moments launches of all widths (the population avg_launch_ms averages over): FETCH_SIZE {fa:.0f} KiB x2 (gfx950 "
                  f"wide-read correction) + WRITE_SIZE {wa:.0f} KiB; the {nf} full-width launches alone: {ff:.0f} KiB x2 + "
                  f"{wf:.0f} KiB (resident_path.roofline_full_width_launches.traffic); counts Infinity-Cache hits (traffic "
                  f"leaving L2, an upper bound on HBM bytes)")
@@ -475,9 +482,9 @@ def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, 
         # "sweep": the dominant kernel's launches only (the roofline's avg_launch_ms, measured inside the timed region) --
         # every timed launch is bracketed by two event records that keep it from overlapping its neighbours, and timing all
         # ~900 launches of a fit cost the headline 4 % (145 ms where an untimed loop of the same fits took 139.5)
-        ops.timing_enable(True, only=["alpha_sweep_gemm"] if collect_kernels == "sweep" else None)
+        ops.timing_enable(True, only=["alpha_sweep_gemm", "series_sweep_gemm"] if collect_kernels == "sweep" else None)
         ops.timing_read()
-    flops = {"plain": 0.0, "fused": 0.0, "fused_launches": 0, "step_ms": []}
+    flops = {"plain": 0.0, "fused": 0.0, "fused_launches": 0, "series": 0.0, "series_launches": 0, "step_ms": []}
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -488,6 +495,8 @@ def timed_fits(model, dX, dY, p, V, V_total, alphas, steps, warmup, world, dev, 
         flops["plain"] += model.last_fit.get("plain_flops", 0.0)
         flops["fused"] += model.last_fit.get("fused_flops", 0.0)
         flops["fused_launches"] += model.last_fit.get("fused_launches", 0)
+        flops["series"] += model.last_fit.get("series_flops", 0.0)
+        flops["series_launches"] += model.last_fit.get("series_launches", 0)
     fence()
     elapsed = time.perf_counter() - t0
     kern = None
@@ -616,17 +625,41 @@ def step_stats(step_ms, voxels):
 def sweep_roofline(sweep, kern, flops, steps, split):
     """roofline object of the fused alpha-sweep kernel from the library's HIP events around its launches (on the launch
     stream) and the algorithmic flops the engine counted for them."""
-    ms, launches = kern.get("alpha_sweep_gemm", (0.0, 0))
-    alg_tflops = flops["fused"] / (ms * 1e-3) / 1e12 if launches and ms > 0 else None
+    ms_f, launches_f = kern.get("alpha_sweep_gemm", (0.0, 0))
+    ms_s, launches_s = kern.get("series_sweep_gemm", (0.0, 0))
     screened = bool(split and sweep.get("screen_terms", 3) == 1)
     mfma_per_product = (1 if screened else 3) if split else 1
     peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    score_tflops = flops["fused"] / (ms_f * 1e-3) / 1e12 if launches_f and ms_f > 0 else None
+    series_tflops = flops.get("series", 0.0) / (ms_s * 1e-3) / 1e12 if launches_s and ms_s > 0 and flops.get("series") else None
+    # (round 6) the dominant kernel is k_sweep_f16x3 in BOTH its inner-CV instantiations: the fused score launches (the
+    # factorised alphas' hat matrices of an inner fold) and the series-moments launches (the four shared series terms of the
+    # same fold, the larger share of a fit since the fused launch carries three alphas).  Priced together on the flops each
+    # actually contracts; `score_launches` keeps the quantity rounds 1-5 reported alone
+    both = series_tflops is not None and split
+    ms, launches = (ms_f + ms_s, launches_f + launches_s) if both else (ms_f, launches_f)
+    total = flops["fused"] + (flops.get("series", 0.0) if both else 0.0)
+    alg_tflops = total / (ms * 1e-3) / 1e12 if launches and ms > 0 else None
     issued = alg_tflops * mfma_per_product if alg_tflops else None
+    per_kind = {"score_launches": {"what": "fused alpha sweep: 2 x A_fused x n_val x n_train x V flop per inner fold",
+                                   "achieved": score_tflops, "frac": (score_tflops / peak) if score_tflops else None,
+                                   "avg_launch_ms": ms_f / max(launches_f, 1), "launches_per_step": launches_f / max(steps, 1),
+                                   "flops_per_step": flops["fused"] / max(steps, 1)},
+                "series_launches": ({"what": "series-moments sweep: 2 x 4 terms x n_val x n_train x V flop per inner fold",
+                                     "achieved": series_tflops, "frac": series_tflops / peak,
+                                     "avg_launch_ms": ms_s / max(launches_s, 1), "launches_per_step": launches_s / max(steps, 1),
+                                     "flops_per_step": flops["series"] / max(steps, 1)} if both else None)}
     return {"bound": "mfma",
-            "kernel": ("k_sweep_f16x3<score, HI2> (fused alpha sweep of the inner CV's SCREENING pass: 1 fp16 MFMA per product; "
-                       "the undecided voxels' three-MFMA launches are inside the same timer, their flops are not counted)"
-                       if screened else "k_sweep_f16x3 (fused alpha sweep, 3 fp16 MFMAs per product)") if split
+            "kernel": (("k_sweep_f16x3<.., HI2>: the two contractions of the inner CV's SCREENING pass (fused score launches: the "
+                        "factorised alphas' hat matrices; series-moments launches: the shared series terms), 1 fp16 MFMA per "
+                        "product; the undecided voxels' three-MFMA launches are inside the same timers, their flops are not counted"
+                        if both else
+                        "k_sweep_f16x3<score, HI2> (fused alpha sweep of the inner CV's SCREENING pass: 1 fp16 MFMA per product; "
+                        "the undecided voxels' three-MFMA launches are inside the same timer, their flops are not counted)")
+                       if screened else ("k_sweep_f16x3 (fused score + series-moments sweeps, 3 fp16 MFMAs per product)" if both
+                                         else "k_sweep_f16x3 (fused alpha sweep, 3 fp16 MFMAs per product)")) if split
                       else "k_gemm_f32<score> (fused alpha sweep, f32-input MFMA)",
+            **per_kind,
             "screening": ({"undecided_voxel_folds": sweep.get("undecided"), "screened_voxel_folds": sweep.get("screened"),
                            "undecided_frac": (sweep.get("undecided", 0) / max(sweep.get("screened", 0), 1)),
                            "overflows": sweep.get("screen_overflows", 0)} if screened else None),
@@ -634,7 +667,7 @@ def sweep_roofline(sweep, kern, flops, steps, split):
             "mfma_per_product": mfma_per_product, "mfma_issue_tflops": issued,
             "mfma_issue_frac": (issued / peak) if issued else None,
             "frac_vs_f32_mfma_peak": (alg_tflops / PEAK_F32_MFMA_TFLOPS) if alg_tflops else None,
-            "flops_per_step": flops["fused"] / max(steps, 1), "launches_per_step": launches / max(steps, 1),
+            "flops_per_step": total / max(steps, 1), "launches_per_step": launches / max(steps, 1),
             "avg_launch_ms": ms / max(launches, 1), "launches": launches,
             "fused_alphas_per_launch": sweep.get("fused_alphas"), "inner_folds_per_launch": sweep.get("folds_per_launch", 1)}
 
@@ -788,8 +821,9 @@ def main():
             plain = {"launches": plain_n, "ms_per_step": plain_ms,
                      "algorithmic_tflops": flops_all["plain"] / (plain_ms * 1e-3) / 1e12,
                      "mfma_tflops": 3 * flops_all["plain"] / (plain_ms * 1e-3) / 1e12,
-                     "what": f"{sweep.get('series_terms', 0)} shared series terms x 25 inner folds + 5 refits "
-                             "(weights and test predictions) per step; includes the f32 MFMA launches of that slot"}
+                     "what": "the other launches of the same kernel per step: the folds' test-row products, the mean-operator "
+                             "weight product (round 6) and the undecided voxels' panels; includes the f32 MFMA launches of "
+                             "that timer slot (the series-moments launches have a slot of their own since round 6)"}
         traffic = traffic_src = committed = None
         tpath = os.path.join(ROOT, "profiles", "alpha_sweep_traffic.json")
         if os.path.exists(tpath):
@@ -809,8 +843,10 @@ def main():
                            + (live_traffic[1] if live_traffic is not None else "child passes skipped")
                            + "); resident_path.roofline_full_width_launches.traffic carries profiles/alpha_sweep_traffic.json")
         roof.update({
-            "note": ("achieved/frac = ALGORITHMIC flops of the caller's contraction (2 x A_fused x n_val x n_train x V per "
-                     "inner fold, summed over the launches of the timed steps) / the launches' HIP-event time; the kernel "
+            "note": ("achieved/frac = ALGORITHMIC flops of the caller's contractions (score launches: 2 x A_fused x n_val x "
+                     "n_train x V per inner fold; series-moments launches: 2 x 4 terms x n_val x n_train x V; summed over the "
+                     "launches of the timed steps) / the launches' HIP-event time -- `score_launches` alone is the quantity of "
+                     "rounds 1-5; the kernel "
                      "issues mfma_per_product fp16 MFMAs per product (mfma_issue_tflops / mfma_issue_frac).  peak = dense "
                      "fp16 MFMA datasheet figure at 2.4 GHz; under this kernel the chip holds 1.4-1.8 GHz (in-kernel "
                      "s_memtime/s_memrealtime, profiles/).  The first fold's launches are panel-wide (the targets are still "

@@ -637,6 +637,16 @@ int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float* d_rowscale
                                        const int64_t* h_gap_rows, int terms, const int32_t* d_live_cols,
                                        lc_stream_t stream);
 
+/* accumulate = 2 in the two calls above: the contraction alone (partials into d_part, no scores).  The second halves for F
+ * such folds at once (d_part / d_ystat / d_yblk: the (F, ...) stacks the contractions wrote slice by slice) -- one pass over
+ * all folds' partials instead of one small launch per fold (25 + 25 per fit at cfg2); folds added in order, as above. */
+int lc_alpha_sweep_finalize_folds(const float* d_part, const float* d_ystat, const float* d_yblk, int F, int A, int M,
+                                  const int32_t* h_n_val, int64_t V, int mode, float* d_scores, int accumulate,
+                                  lc_stream_t stream);
+int lc_series_sweep_finalize_folds(const float* d_part, const float* d_ystat, const float* d_yblk, int F, int M,
+                                   const int32_t* h_n_val, int64_t V, const double* d_coef, const int32_t* d_aidx, int S,
+                                   float* d_scores, int accumulate, lc_stream_t stream);
+
 /* The voxels whose alpha the SCREENING pass of the inner CV (terms = 1 above) does not decide (round 6, DESIGN.md 4.2;
  * the reference takes the argmax of the fold-mean scores, nested_cv.py:408-411 -- a voxel whose best two alphas are
  * further apart than the screening error has that argmax already).  d_scores: (A, ld) f32 sums over the scored inner

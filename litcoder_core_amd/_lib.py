@@ -121,6 +121,10 @@ SIGNATURES = {
     "lc_alpha_sweep_scores_f16x3_folds": (c_int, [_ptr, _ptr, c_int, c_int, c_int, c_int, _ptr, _ptr, _ptr, c_int64,
                                                   POINTER(c_int32), _ptr, _ptr, c_int, _ptr, _ptr, c_int, c_int64,
                                                   POINTER(c_int64), POINTER(c_int64), c_int, _ptr, _ptr]),
+    "lc_alpha_sweep_finalize_folds": (c_int, [_ptr, _ptr, _ptr, c_int, c_int, c_int, POINTER(c_int32), c_int64, c_int, _ptr, c_int,
+                                              _ptr]),
+    "lc_series_sweep_finalize_folds": (c_int, [_ptr, _ptr, _ptr, c_int, c_int, POINTER(c_int32), c_int64, _ptr, _ptr, c_int, _ptr,
+                                               c_int, _ptr]),
     "lc_series_sweep_scores_f16x3_folds": (c_int, [_ptr, _ptr, c_int, c_int, POINTER(c_int32), c_int64, _ptr, _ptr, c_int64,
                                                    _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr, c_int,
                                                    c_int64, POINTER(c_int64), POINTER(c_int64), c_int, _ptr, _ptr]),

@@ -42,7 +42,8 @@ int ensure_dynamic_lds(const void* kernel, int bytes);
 // Optional per-kernel-class timing with HIP events on the launch stream (lc_timing_enable).
 enum TimingSlot {
     T_SWEEP_GEMM = 0, T_SWEEP_FINALIZE, T_GROUPED_GEMM, T_CHOL_SOLVE, T_LAMBDA_MAX, T_GRAM, T_ASSEMBLE,
-    T_VAL_STATS, T_PEARSON, T_GATHER, T_SCATTER, T_SELECT, T_FIR, T_LANCZOS, T_CAST, T_COLSTATS, T_SPLIT16, T_SERIES, T_SLOTS
+    T_VAL_STATS, T_PEARSON, T_GATHER, T_SCATTER, T_SELECT, T_FIR, T_LANCZOS, T_CAST, T_COLSTATS, T_SPLIT16, T_SERIES, T_SERIES_SWEEP,
+    T_SLOTS
 };
 bool timing_on(int slot);
 void timing_begin(int slot, hipStream_t s);

@@ -27,7 +27,7 @@ std::vector<hipEvent_t> g_open[T_SLOTS];
 const char* const g_names[T_SLOTS] = {
     "alpha_sweep_gemm", "alpha_sweep_finalize", "grouped_gemm", "batch_chol_solve", "lambda_max", "gram",
     "batch_assemble", "val_stats", "pearson_cols", "gather", "scatter_axpy", "select_group", "fir_delay",
-    "lanczos_interp", "cast", "col_stats", "split_f16", "series_hat"};
+    "lanczos_interp", "cast", "col_stats", "split_f16", "series_hat", "series_sweep_gemm"};
 }  // namespace
 
 bool timing_on(int slot) { return (g_mask >> slot) & 1ull; }

@@ -233,7 +233,20 @@ extern "C" int lc_alpha_sweep_scores_f16x3_folds(const void* d_ht, const float* 
                                (const uint4*)d_ht, (const uint4*)d_yt, N / TK, F * Mtiles, sa, pa, bv, fv);
     }
     if (int rc = lc::launched("k_sweep_f16x3")) return rc;
+    if (accumulate == 2) return LC_OK;                    // the contraction alone: the caller finalises several folds at once
     return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, h_n_val, F, (long long)V, mode, d_scores, accumulate, s);
+}
+
+// The second halves of the two sweeps alone, for F folds whose contractions were launched one by one with accumulate = 2
+// (each into its slice of the (F, ...) stacks): one pass over all folds' partials instead of one small launch per fold.
+extern "C" int lc_alpha_sweep_finalize_folds(const float* d_part, const float* d_ystat, const float* d_yblk, int F, int A, int M,
+                                             const int32_t* h_n_val, int64_t V, int mode, float* d_scores, int accumulate,
+                                             lc_stream_t stream) {
+    LC_REQUIRE(d_part && d_ystat && d_yblk && d_scores && h_n_val, LC_E_BADARG, "lc_alpha_sweep_finalize_folds: null pointer");
+    LC_REQUIRE(F >= 1 && F <= MAX_FOLDS16 && A > 0 && M > 0 && M % LC_MB == 0 && V > 0 && V % 128 == 0, LC_E_SHAPE,
+               "lc_alpha_sweep_finalize_folds: bad shape");
+    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, h_n_val, F, (long long)V, mode, d_scores, accumulate ? 1 : 0,
+                                    lc::as_stream(stream));
 }
 
 extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
@@ -413,7 +426,7 @@ extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float*
     pa.start[1] = (int)Ntiles;
     pa.slab_light = nullptr;
     {
-        lc::ScopedTimer timer_(lc::T_GROUPED_GEMM, s);
+        lc::ScopedTimer timer_(lc::T_SERIES_SWEEP, s);
         if (terms == 1)
             hipLaunchKernelGGL((k_sweep_hi2<false>), dim3((unsigned)(F * Mtiles * Ntiles * 2)), dim3(H2_THREADS), H2_LDS_BYTES, s,
                                (const uint4*)d_pt, (const uint4*)d_yt, (int)(K / TK), F * Mtiles, sa, pa, bv, fv);
@@ -426,6 +439,19 @@ extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float*
                                LDS16_BYTES, s, (const uint4*)d_pt, (const uint4*)d_yt, (int)(K / TK), F * Mtiles, sa, pa, bv, fv);
     }
     if (int rc = lc::launched("k_sweep_f16x3<series moments>")) return rc;
+    if (accumulate == 2) return LC_OK;                    // (see lc_series_sweep_finalize_folds)
     return lc_series_finalize_launch(d_part, d_ystat, d_yblk, M, h_n_val, F, (long long)V, d_coef, d_aidx, S, d_scores,
                                      accumulate, s);
+}
+
+extern "C" int lc_series_sweep_finalize_folds(const float* d_part, const float* d_ystat, const float* d_yblk, int F, int M,
+                                              const int32_t* h_n_val, int64_t V, const double* d_coef, const int32_t* d_aidx,
+                                              int S, float* d_scores, int accumulate, lc_stream_t stream) {
+    LC_REQUIRE(d_part && d_ystat && d_yblk && d_scores && h_n_val && d_coef && d_aidx, LC_E_BADARG,
+               "lc_series_sweep_finalize_folds: null pointer");
+    LC_REQUIRE(F >= 1 && F <= MAX_FOLDS16 && M > 0 && M % LC_MB == 0 && V > 0 && V % 128 == 0 && S > 0, LC_E_SHAPE,
+               "lc_series_sweep_finalize_folds: bad shape");
+    for (int f = 0; f < F; ++f) LC_REQUIRE(h_n_val[f] > 1, LC_E_SHAPE, "lc_series_sweep_finalize_folds: need n_val > 1");
+    return lc_series_finalize_launch(d_part, d_ystat, d_yblk, M, h_n_val, F, (long long)V, d_coef, d_aidx, S, d_scores,
+                                     accumulate ? 1 : 0, lc::as_stream(stream));
 }

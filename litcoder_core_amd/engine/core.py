@@ -191,7 +191,8 @@ class EngineCore:
         # of the sweeps, alphas scored inside the fused launch, algorithmic flops of the plain fp16x3 GEMMs.  Per
         # engine: two fits in one process do not share it.
         self.info = {"precision": None, "fused_alphas": self.A, "series_terms": 0, "plain_flops": 0.0,
-                     "plain_launches": 0, "used_all": None, "fused_flops": 0.0, "fused_launches": 0}
+                     "plain_launches": 0, "used_all": None, "fused_flops": 0.0, "fused_launches": 0, "series_flops": 0.0,
+                     "series_launches": 0}
         if self.uploader is not None:
             if self._x_job is not None:
                 self.uploader.wait(self._x_job)        # the design is needed now (Gram matrix)

@@ -315,6 +315,8 @@ class DualSweeps:
                           and 1 < F <= 64 and self.opt.folds_in_one_launch_tiles > 0
                           and ((max(Ad, 1) * M + 255) // 256) * (Vt // 256) < self.opt.folds_in_one_launch_tiles)
 
+        at_once = bool(self.opt.finalize_folds_at_once and moments and split and 1 < F <= 64)
+
         def series_part():
             nonlocal fused, Pt, rs_p, part_s, Tbuf, cs_inv, rowmap, slab_light, Tm
             if moments:
@@ -340,10 +342,14 @@ class DualSweeps:
                     part_f = torch.empty((F, M // LC_MB, 18, Vp_), dtype=torch.float32, device=self.dev)
                     self.info["plain_flops"] += sum(2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * V_ for f in range(F))
                     self.info["plain_launches"] += 1
+                    self.info["series_flops"] = self.info.get("series_flops", 0.0) + sum(2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * V_ for f in range(F))
+                    self.info["series_launches"] = self.info.get("series_launches", 0) + 1
                     ops.series_sweep_scores_f16x3_folds(im["Pt"], im["rs_p"], M, n_v, N, Yt[0], cs_inv, Vt, yv, Vp_, ystat, yblk,
                                                         coef_s, dser_s, part_f, scores, False, views, terms=terms,
                                                         live=live)
                     return
+                part_sf = (torch.empty((F, M // LC_MB, 18, Vp_), dtype=torch.float32, device=self.dev)
+                           if (fused and at_once) else None)
                 for f, j, H, P in folds:
                     if shared is None:
                         ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[f])
@@ -356,14 +362,21 @@ class DualSweeps:
                     self.info["plain_flops"] += 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * V_
                     self.info["plain_launches"] += 1
                     if fused:
+                        # (the launches of the series-moments instantiation of k_sweep_f16x3: bench.py prices them with the
+                        # score launches -- the same kernel, the inner CV's other contraction)
+                        self.info["series_flops"] = self.info.get("series_flops", 0.0) + 2.0 * SERIES_TERMS * n_v[f] * hat["n_i"][f] * V_
+                        self.info["series_launches"] = self.info.get("series_launches", 0) + 1
                         ops.series_sweep_scores_f16x3(Pt_f, rs_p_f, M, n_v[f], N, Yt[f], cs_inv, Vt, yv[f], Vp_, ystat[f], yblk[f],
-                                                      coef_s, dser_s, part_s, scores, accumulate=f > 0,
+                                                      coef_s, dser_s, part_s if part_sf is None else part_sf[f], scores,
+                                                      accumulate=(f > 0) if part_sf is None else 2,
                                                       bview=views[f], terms=terms, live=live)
                         continue
                     ops.gemm_grouped_f16x3(Pt_f, rs_p_f, Tm, Yt[f], cs_inv, Tbuf, Vt, Vt, N, [0, Vt // 256], slab_light,
                                            bview=views[f])
                     ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], Vp_, yv[f], ystat[f], coef_s, dser_s,
                                       scores, accumulate=f > 0, rowmap=rowmap)
+                if part_sf is not None:                      # the folds' partial moments -> scores, all folds in one pass
+                    ops.series_sweep_finalize_folds(part_sf, ystat, yblk, M, n_v, Vp_, coef_s, dser_s, scores, accumulate=False)
 
         def fused_part():
             if done is not None:
@@ -381,6 +394,8 @@ class DualSweeps:
                 ops.alpha_sweep_scores_f16x3_folds(im["Ht_s" if drop else "Ht"], im["rs_hs" if drop else "rs_h"], Ad_f, M, N, Yt[0],
                                                    cs[Vp_:], yv, Vp_, n_v, ystat, yblk, self.mode, part_f, scores_d, False, views,
                                                    terms=terms, live=live)
+            part_ff = (torch.empty((F, Ad_f * M // LC_MB, 4, Vp_), dtype=torch.float32, device=self.dev)
+                       if (at_once and fused and Ad_f and not one_launch) else None)
             for f, j, H, P in (() if (one_launch and fused) else folds):
                 b = f if moments else 0
                 if not moments:
@@ -401,13 +416,16 @@ class DualSweeps:
                         else:
                             ops.split_rows_f16_alphas(H[j * Ad:(j + 1) * Ad].reshape(Ad * M, N), 1, Ad, M, N, Ht, rs_inv)
                         ops.alpha_sweep_scores_f16x3(Ht_f, rs_h_f, Ad_f, M, N, Yt[b], cs[Vp_:], yv[b], Vp_, n_v[f], ystat[b],
-                                                     yblk[b], self.mode, part, scores_d, accumulate=f > 0, bview=views[f],
+                                                     yblk[b], self.mode, part if part_ff is None else part_ff[f], scores_d,
+                                                     accumulate=(f > 0) if part_ff is None else 2, bview=views[f],
                                                      terms=terms, live=live)
                 else:
                     self.info["fused_flops"] += 2.0 * A * n_v[f] * hat["n_i"][f] * V_
                     self.info["fused_launches"] += 1
                     ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, Vp_, tr[f], yv[b], n_v[f], ystat[b], yblk[b],
                                            self.mode, part, scores, accumulate=f > 0)
+            if part_ff is not None:                          # the folds' partial moments -> scores, all folds in one pass
+                ops.alpha_sweep_finalize_folds(part_ff, ystat, yblk, Ad_f, M, n_v, Vp_, self.mode, scores_d, accumulate=False)
             if moments and Ad and not cho_first:
                 for i, a in enumerate(cho):
                     scores[a].copy_(scores_d[i])
@@ -503,8 +521,8 @@ class DualSweeps:
         cs_p, _ = ops.col_scales_f16(Yp, self.Ttot, cap, want_flag=False)    # (per column, from the same values: the same scales)
         hp = dict(hat)
         hp.update(cs=cs_p, split=True, panel=True, live=count[0:1], data_ready=None, series_ready=None)
-        keep = {k: self.info.get(k) for k in ("plain_flops", "plain_launches", "fused_flops", "fused_launches",
-                                              "precision", "fused_alphas", "series_terms", "folds_per_launch")}
+        keep = {k: self.info.get(k) for k in ("plain_flops", "plain_launches", "fused_flops", "fused_launches", "series_flops",
+                                              "series_launches", "precision", "fused_alphas", "series_terms", "folds_per_launch")}
         prev = self.cur
         self.cur = _Range(0, cap, cap, Yp, None)
         try:

@@ -138,6 +138,13 @@ class MeanOperatorRefit:
             cost_new = ((cnt + 255) // 256) * Kd + np.where(cached, 0.25, 1.0) * build
             cost_old = cnt / 256.0 * float(sum(n_o))
             pays = cost_new <= self.opt.mean_operator_cost_ratio * cost_old
+            if pays.any() and not pays.all():
+                # the folds' own products for the voxels of the other tuples are one small launch per fold whatever their
+                # number (~20 tile-rows of latency per depth row: 170 us at cfg2): a handful of rare tuples is cheaper served
+                # by operators of their own
+                rest_as_folds = 20.0 * float(sum(n_o)) + float(cost_old[~pays].sum())
+                if float(cost_new[~pays].sum()) <= rest_as_folds:
+                    pays[:] = True
             if pays.sum() > self.opt.mean_operator_max_tuples:
                 keep = np.argsort(-cnt, kind="stable")[: self.opt.mean_operator_max_tuples]
                 mask = np.zeros(len(cnt), dtype=bool)

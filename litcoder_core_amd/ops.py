@@ -1110,8 +1110,8 @@ def alpha_sweep_scores_f16x3_folds(ht, rowscale_inv, A, M, N, yt, cscale_inv, yv
     column tiles below that many columns do any work."""
     F, nv, b_rows, g0, gl = _fold_arrays(n_vals, views)
     _lib.call("lc_alpha_sweep_scores_f16x3_folds", _p(ht), _p(rowscale_inv), F, A, M, N, _p(yt), _p(cscale_inv), _p(yv), V,
-              nv, _p(ystat), _p(yblk), mode, _p(part), _p(scores), int(bool(accumulate)), b_rows, g0, gl, int(terms),
-              _p(live), _s())
+              nv, _p(ystat), _p(yblk), mode, _p(part), _p(scores), 2 if accumulate == 2 else int(bool(accumulate)), b_rows, g0, gl,
+              int(terms), _p(live), _s())
 
 
 def series_sweep_scores_f16x3_folds(pt, rowscale_inv, M, n_vals, K, yt, cscale_inv, Ncols, yv, V, ystat, yblk, coef, aidx,
@@ -1119,7 +1119,23 @@ def series_sweep_scores_f16x3_folds(pt, rowscale_inv, M, n_vals, K, yt, cscale_i
     F, nv, b_rows, g0, gl = _fold_arrays(n_vals, views)
     _lib.call("lc_series_sweep_scores_f16x3_folds", _p(pt), _p(rowscale_inv), F, M, nv, K, _p(yt), _p(cscale_inv), Ncols,
               _p(yv), V, _p(ystat), _p(yblk), _p(coef), _p(aidx), aidx.numel(), _p(part), _p(scores),
-              int(bool(accumulate)), b_rows, g0, gl, int(terms), _p(live), _s())
+              2 if accumulate == 2 else int(bool(accumulate)), b_rows, g0, gl, int(terms), _p(live), _s())
+
+
+def alpha_sweep_finalize_folds(part, ystat, yblk, A, M, n_vals, V, mode, scores, accumulate=False):
+    """Scores of F folds whose fused contractions were launched with accumulate=2 (lc_alpha_sweep_finalize_folds)."""
+    F = len(n_vals)
+    nv = (ctypes.c_int32 * F)(*[int(n) for n in n_vals])
+    _lib.call("lc_alpha_sweep_finalize_folds", _p(part), _p(ystat), _p(yblk), F, A, M, nv, V, mode, _p(scores),
+              int(bool(accumulate)), _s())
+
+
+def series_sweep_finalize_folds(part, ystat, yblk, M, n_vals, V, coef, aidx, scores, accumulate=False):
+    """... and of the series-moments contractions (lc_series_sweep_finalize_folds)."""
+    F = len(n_vals)
+    nv = (ctypes.c_int32 * F)(*[int(n) for n in n_vals])
+    _lib.call("lc_series_sweep_finalize_folds", _p(part), _p(ystat), _p(yblk), F, M, nv, V, _p(coef), _p(aidx), aidx.numel(),
+              _p(scores), int(bool(accumulate)), _s())
 
 
 def undecided_cols(scores, A, V, tau_sum, ystat, cap):
