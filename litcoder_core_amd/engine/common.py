@@ -117,6 +117,9 @@ class FitOptions:
                                             # prediction errors averaged over those rows -- measured rms 3.7e-6, max 4.1e-5 over
                                             # 8e6 scores at cfg2 (2400 rows: gap 1.0e-4 = 27 rms; the largest gap of a voxel
                                             # whose screening argmax was wrong: 1.4e-5; profiles/r06_screen_probe_cfg2.txt)
+    series_chain_f16x3: bool = True         # the V-independent chain Q_j = (K[tr,tr] / lambda) Q_(j-1) of the shared series terms on
+                                            # the fp16x3 MFMA kernel (three fp16 MFMAs per product, 22-bit operands: as accurate
+                                            # as the f32-input MFMA, ~4x its rate) instead of k_gemm_f32
     finalize_folds_at_once: bool = True     # the partial moments of an outer fold's inner folds turned into scores in ONE pass per
                                             # sweep kind instead of one small launch per inner fold (50 -> 10 launches per fit)
     refine_on_side_stream: bool = True      # ... the undecided voxels' panel (a few column tiles: a quarter of the chip for ~1 ms

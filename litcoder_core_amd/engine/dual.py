@@ -142,10 +142,28 @@ class DualSweeps:
                     ops.gather_sub_f32_strided(K, tr[g0:g0 + fcl], va[g0:g0 + fcl], fcl, N, M, lmax[g0:g0 + fcl], Q, Mq,
                                                fcl * Mq, 1)
                     tiles = [f * (Mq // COL_TILE) for f in range(fcl + 1)]
+                    # (round 6) the chain's products on the fp16x3 kernel: Kn's images once, Q_(j-1)'s per term
+                    x3 = bool(self.opt.series_chain_f16x3 and self._split_assumed() and Mq % 256 == 0 and N % 32 == 0 and N >= 64
+                              and fcl <= 64)
+                    if x3:
+                        Np = ops.pad_to(N, 256)                      # (every group's image is padded to whole 256-row tiles)
+                        Kt = torch.empty(fcl * Np * N * 2, dtype=torch.float16, device=self.dev)
+                        rs_k = torch.empty(fcl * Np, dtype=torch.float32, device=self.dev)
+                        ops.split_rows_f16_groups(Kn.view(-1, N), fcl, N, N, Kt, rs_k)
+                        rows_n = ops.idx_tensor(np.arange(N), N, self.dev)
+                        tiles3 = [f * (Mq // 256) for f in range(fcl + 1)]
+                        Qt = torch.empty(fcl * Mq * N * 2, dtype=torch.float16, device=self.dev)
                     for j in range(SERIES_TERMS):
                         if j:
                             Qn = torch.empty_like(Q)
-                            ops.gemm_grouped(Kn, N, N * N, Q, fcl * Mq, None, Qn, fcl * Mq, N, fcl * Mq, N, tiles)
+                            if x3:
+                                Q2 = Q.view(N, fcl * Mq)
+                                cs_q, _ = ops.col_scales_f16(Q2, N, fcl * Mq, want_flag=False)
+                                ops.split_cols_f16(Q2, fcl * Mq, rows_n, N, cs_q, Qt)
+                                ops.gemm_grouped_f16x3(Kt, rs_k, N, Qt, cs_q[fcl * Mq:], Qn.view(N, fcl * Mq), fcl * Mq, fcl * Mq, N,
+                                                       tiles3)
+                            else:
+                                ops.gemm_grouped(Kn, N, N * N, Q, fcl * Mq, None, Qn, fcl * Mq, N, fcl * Mq, N, tiles)
                             Q = Qn
                         ops.series_place(Q, N, fcl, Mq, M, rowmap[j * M:(j + 1) * M], P, rows_p)
                 elif fcl:
