@@ -84,8 +84,9 @@ class FitOptions:
     mean_operator_refit: bool = True        # (round 6) the mean weights of a cross-validated fit from the MEAN of the folds'
                                             # refit operators, one contraction of depth T per group of voxels with the same alpha
                                             # in every fold, instead of one of depth n_train per fold (engine/mean_refit.py)
-    mean_operator_min_cols: int = 16384     # ... for fits of at least this many voxels in all (small fits keep the folds' own
-                                            # products: an operator image per alpha tuple costs what ~3 column tiles do)
+    mean_operator_min_cols: int = 16384     # ... for fits of at least this many voxels on this rank (small fits and narrow voxel
+                                            # shards keep the folds' own products: an operator image per alpha tuple costs what
+                                            # ~3 column tiles do, and a rank of 10 000 voxels has no tuple that pays)
     mean_operator_max_tuples: int = 256     # ... and while a voxel range has at most this many distinct alpha tuples
     mean_operator_cost_ratio: float = 0.85  # ... and the grouped contraction + the operator images it needs are estimated at
                                             # no more than this share of the folds' own products (tests force the path: 1e9)

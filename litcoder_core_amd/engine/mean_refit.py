@@ -30,18 +30,18 @@ class MeanOperatorRefit:
         Kd = ops.pad_to(max(self.Ttot, 1), 32)
         return bool(o.mean_operator_refit and self.n_folds >= 2 and self.n_folds <= 16 and not self.moments and not self.primal
                     and not self.spectral and not self.norm_y and self.precision != "f32" and 64 <= Kd <= 8192
-                    and self.V_total >= o.mean_operator_min_cols)
+                    and self.V_rank >= o.mean_operator_min_cols)      # (this rank's voxels: a narrow voxel shard keeps the folds' own products,
+                                                                      #  formed fold by fold beside the next fold's sweeps)
 
     def _mo_enabled(self, st):
-        """Decided at the first refit of the fit (the side panel of too-wide columns, which has a refit of its own, and the
-        arithmetic are known by then) and kept for all of it."""
+        """Decided at the first refit of the fit (the arithmetic is known by then) and kept for all of it."""
         if getattr(self, "_mo", None) is None:
-            ok = self._mo_possible() and bool(st["split"]) and self.side is None and st.get("best_h") is not None
+            ok = self._mo_possible() and bool(st["split"]) and st.get("best_h") is not None
             self._mo = dict(folds={}, images={}, maps={}, done=0) if ok else False
             self.info["mean_operator"] = dict(on=bool(ok), ranges=0, tuples=0, tiles=0, built=0, voxels=0, other_voxels=0)
         return bool(self._mo)
 
-    def _mo_record(self, st, weight_scale):
+    def _mo_record(self, st, weight_scale, side_job=None):
         """A (fold, range) step whose weight rows are NOT formed now: the alphas its voxels chose, the fold's operators (one
         dictionary per fold, shared by its ranges: it fills as alphas are first used), the natural-order image of the range."""
         f, rg = int(st["fold"]), st["rg"]
@@ -51,11 +51,13 @@ class MeanOperatorRefit:
             cache = base.setdefault("refit_cache", {})
             ent = self._mo["folds"][f] = dict(best=np.full(max(self.V_rank, 1), -1, dtype=np.int64), M=cache.setdefault("M", {}),
                                               imgs=cache.setdefault("imgs", {}), tr=np.asarray(st["tr"], dtype=np.int64),
-                                              scale=float(weight_scale), images={})
+                                              scale=float(weight_scale), images={}, side=[])
         if st.get("best_h") is None or not st["split"]:
             raise RuntimeError("mean-operator refit: a step without host alpha indices / on the f32 path in a fit set up for it")
         ent["best"][rg.c0:rg.c0 + rg.V] = st["best_h"][: rg.V]
         ent["images"][rg.key] = st["hat"].get("image")
+        if side_job is not None:                       # the step's exact-f32 weights of the side panel's columns (_side_refit_begin)
+            ent["side"].append((side_job, rg.c0))
 
     def _mo_map(self, fold, tr_rows, Kd):
         """(Kd,) int32 device: column of fold ``fold``'s operators that belongs to target row t (-1: not a training row)."""
@@ -65,6 +67,30 @@ class MeanOperatorRefit:
             h[tr_rows] = np.arange(len(tr_rows), dtype=np.int32)
             m = self._mo["maps"][fold] = ops.upload(h, self.dev)
         return m
+
+    def _mo_side_columns(self, rg, ents):
+        """Too-wide target columns (the f32 side panel): their weights of every fold came from the side refit in exact f32
+        (FoldPhases._side_refit_begin); the range's mean over them -- zero, then scale_f W_f added fold by fold, the sums a
+        fold-by-fold refit forms -- goes over whatever the fp16 path left in those columns."""
+        jobs = [(e, job, c0) for e in ents for job, c0 in e["side"]]
+        if not jobs:
+            return
+        main = torch.cuda.current_stream()
+        cols = np.asarray(self.side["cols"], dtype=np.int64) if self.side is not None else np.zeros(0, dtype=np.int64)
+        sel = cols[(cols >= rg.c0) & (cols < rg.c0 + rg.V)] - rg.c0
+        if len(sel) == 0:
+            return
+        ops.scatter_cols(ops.zeros((self.p, len(sel)), torch.float32, self.dev), self.p, ops.upload(sel.astype(np.int32), self.dev),
+                         len(sel), rg.W)
+        for e, job, c0 in jobs:
+            main.wait_event(job["done"])
+            perm_s, Vss = job["perm"], job["Vss"]
+            nat = job["d_local"] + (c0 - rg.c0)        # columns of THIS range (a step may have worked on another range)
+            dst = torch.where(perm_s >= 0, nat[perm_s.clamp(min=0).long()], torch.full_like(perm_s, -1))
+            dst = torch.where((dst >= 0) & (dst < rg.V), dst, torch.full_like(dst, -1)).to(torch.int32).contiguous()
+            ops.scatter_axpy(job["C"], self.p, dst, Vss, e["scale"], rg.W)
+            for t in (job["C"], perm_s, job["d_local"]):
+                t.record_stream(main)
 
     @staticmethod
     def _padded_groups(order, cnt):
@@ -223,6 +249,7 @@ class MeanOperatorRefit:
                 parts.append((buf, pos_r, e["scale"]))
             info["other_voxels"] += int(len(rest))
         ops.combine_folds(parts, self.p, V, rg.W)      # natural voxel order: every voxel has exactly one source
+        self._mo_side_columns(rg, ents)
         info["ranges"] += 1
         mo["done"] += V
         if mo["done"] >= self.V_rank:                  # every range of the rank is final: nothing of the fit is kept

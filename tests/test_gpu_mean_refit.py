@@ -177,3 +177,32 @@ def test_mean_operator_leaves_scattered_tuples_to_the_folds(lc):
     np.testing.assert_array_equal(out1[2], out0[2])
     np.testing.assert_array_equal(np.asarray(out1[1]), np.asarray(out0[1]))
     np.testing.assert_array_equal(np.asarray(out1[0]["correlations"]), np.asarray(out0[0]["correlations"]))
+
+
+def test_mean_operator_with_a_wide_target_column(lc):
+    """A target column dominated by an outlier (the f32 side panel, round 5) in a fit on the mean-operator refit: the column's
+    weights are the folds' exact-f32 weights averaged fold by fold -- bit for bit the fit without the option --, the other
+    voxels' weights equal to fp32 rounding; alphas and test scores identical."""
+    from litcoder_core_amd import NestedCVModel, ops
+    from litcoder_core_amd.engine.common import FitOptions
+    rng = np.random.default_rng(51)
+    T, p, V = 600, 200, 1900
+    X, Y = _problem(rng, T, p, V, noise_cols=0.1, signal=0.8)
+    Y[7, 1234] = 1e6
+    Y[300, 17] = -3e5
+    kw = dict(folding_type="kfold", n_outer_folds=4, n_inner_folds=3, alphas=np.logspace(-1, 5, 13))
+    dev = ops.device()
+    dX = ops.upload_f32(X, ops.pad_to(p, 32), dev)
+    dY = ops.upload_f32(Y, ops.pad_to(V, 128), dev)
+    outs = []
+    for opt in (FitOptions(mean_operator_refit=False), FitOptions(mean_operator_min_cols=0, mean_operator_cost_ratio=1e9)):
+        m = NestedCVModel("ridge_regression", options=opt)
+        outs.append(m.fit_predict_device(dX, dY, p, V, weights_on_host=True, **kw))
+        assert m.last_fit.get("side_panel_cols") == 2 and m.last_fit["precision"] == "f16x3", m.last_fit
+    assert outs and m.last_fit["mean_operator"]["on"] and m.last_fit["mean_operator"]["voxels"] > 0, m.last_fit["mean_operator"]
+    (m0, W0, a0), (m1, W1, a1) = outs
+    np.testing.assert_array_equal(a1, a0)
+    np.testing.assert_array_equal(np.asarray(m1["correlations"]), np.asarray(m0["correlations"]))
+    W0, W1 = np.asarray(W0), np.asarray(W1)
+    np.testing.assert_array_equal(W1[:, [17, 1234]], W0[:, [17, 1234]])
+    assert np.abs(W1.astype(np.float64) - W0).max() <= 2e-6 * np.abs(W0).max()
