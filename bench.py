@@ -37,13 +37,15 @@ figure beside it (`traffic_in_committed_profile`, also the fallback there).
 host through harness.StoryPipeline.fit_words (word features -> Lanczos -> FIR -> per-story zs -> train/test fit,
 single_alpha), with its link floor measured on this box and a `cpu_baseline` of its own (`--no-cfg3` skips it).
 
-Prints ONE JSON line on rank 0.  The `roofline` object is for the dominant kernel, the fp16x3 MFMA
-contraction k_sweep_f16x3, in its fused-score launches (the alphas that go through the batched
-Cholesky: all their predictions reduced to scores in the epilogue): algorithmic flops per launch x 3
-MFMAs per product / mean HIP-event duration over the timed steps, against the 2.5 PFLOP/s dense fp16
-MFMA peak.  The same kernel's plain launches (the shared series terms of the large alphas, the refit)
-are summarised beside it.  `cpu_baseline` times the CPU oracle (the reference algorithm restated, SVD
-route) on a bounded sample on this box's host cores.
+Prints ONE JSON line on rank 0.  The `roofline` object is for the dominant kernel, the fp16 MFMA contraction
+k_sweep_f16x3, in the two launches an inner fold of the inner CV makes of it -- the fused score launch (the hat matrices
+of the alphas that go through the batched Cholesky, their predictions reduced to scores in the epilogue) and the
+series-moments launch (the four shared series terms of the large alphas, reduced to moments) -- since round 6 in the
+screening arithmetic (ONE MFMA per product, hi planes): the flops those launches contract / their HIP-event time over
+the timed steps, against the 2.5 PFLOP/s dense fp16 MFMA peak; `roofline.score_launches` alone is what rounds 1-5 reported.
+The same kernel's other launches (test-row products, the mean-operator weight product, the undecided voxels' panels) are
+summarised beside it.  `cpu_baseline` times the CPU oracle (the reference algorithm restated, SVD route) on a bounded
+sample on this box's host cores.
 """
 import argparse
 import json
