@@ -28,6 +28,12 @@ class EngineCore:
         p <= FitOptions.primal_max_p.  ``Y_all``: a host array / ops.HostRows (uploaded in the column ``panels`` [(c0, c1), ...] on a
         background thread while the fit is being set up) or resident targets (_DeviceShapes)."""
         self.opt = dataclasses.replace(options) if options is not None else FitOptions()    # this engine's own copy
+        if os.environ.get("LITCODER_AMD_FIT_OPTS"):
+            # debugging / fuzzing aid: FitOptions fields over whatever the caller passed, e.g.
+            # LITCODER_AMD_FIT_OPTS="mean_operator_min_cols=0,mean_operator_cost_ratio=1e9" (tools/fuzz_*.py on small problems)
+            for item in os.environ["LITCODER_AMD_FIT_OPTS"].split(","):
+                k, v = item.split("=")
+                setattr(self.opt, k.strip(), type(getattr(self.opt, k.strip()))(float(v)))
         self._chol_opt = ops.chol_options(self.opt.chol_outer_block, self.opt.chol_big_kernel, self.opt.chol_fused_steps,
                                           False, self.opt.chol_persistent)
         self.spectral = check_penalties(alphas, singcutoff, normalpha)

@@ -93,6 +93,44 @@ class MeanOperatorRefit:
                 t.record_stream(main)
 
     @staticmethod
+    def _alpha_tuples(best, A):
+        """The voxels of a range grouped by the alpha TUPLE they chose over the folds.  ``best``: per fold an integer vector of
+        alpha indices (0 <= index < A), all of the same length V.  Returns (order (V,) -- the voxels tuple after tuple, tuples in
+        ascending order of their mixed-radix key (digit f = rank of the alpha among those fold f uses, fold 0 least significant),
+        voxels ascending inside a tuple --, counts per tuple, the tuples as alpha-index tuples), or None when the key space
+        overflows 62 bits.  Host side, numpy: a radix sort of 16-bit keys for the usual few alphas per fold."""
+        V = len(best[0])
+        key = np.zeros(V, dtype=np.int64)
+        stride, used = 1, []
+        for b in best:
+            b = np.asarray(b, dtype=np.int64)
+            u = np.nonzero(np.bincount(b, minlength=A))[0]
+            table = np.zeros(A, dtype=np.int64)
+            table[u] = np.arange(len(u))
+            if stride * max(len(u), 1) > (1 << 62):
+                return None
+            key += table[b] * stride
+            used.append(u)
+            stride *= max(len(u), 1)
+        if stride <= 65535:
+            k16 = key.astype(np.uint16)
+            order = np.argsort(k16, kind="stable")         # (numpy radix-sorts 16-bit keys)
+            counts = np.bincount(k16, minlength=stride)
+            live = np.nonzero(counts)[0]
+            cnt = counts[live]
+        else:
+            order = np.argsort(key, kind="stable")
+            live, cnt = np.unique(key, return_counts=True)
+        tuples = []
+        for kq in live:
+            q, tup = int(kq), []
+            for u in used:
+                tup.append(int(u[q % len(u)]))
+                q //= len(u)
+            tuples.append(tuple(tup))
+        return order, np.asarray(cnt, dtype=np.int64), tuples
+
+    @staticmethod
     def _padded_groups(order, cnt):
         """Column list of voxels sorted into groups (``order``: the voxels group after group, ``cnt``: the groups' sizes), every
         group starting on a 256-column tile: (perm (Vs,) int32 with -1 padding, tile starts (G + 1,))."""
@@ -127,41 +165,12 @@ class MeanOperatorRefit:
         rows_all = ops.idx_tensor(np.arange(self.Ttot), Kd, self.dev)
         Yu = torch.empty(Vt * Kd * 2, dtype=torch.float16, device=self.dev)
         ops.split_cols_f16(rg.Y, rg.Vp, rows_all, Kd, cs, Yu)
-        # ---- host: mixed-radix tuple keys (digit f = rank of the voxel's alpha among the alphas fold f uses in this range)
-        key = np.zeros(V, dtype=np.int64)
-        stride, radix, used = 1, [], []
-        for b in best:
-            hist = np.bincount(b, minlength=A)
-            u = np.nonzero(hist)[0]
-            table = np.zeros(A, dtype=np.int64)
-            table[u] = np.arange(len(u))
-            if stride * len(u) > (1 << 62):
-                stride = None
-                break
-            key += table[b] * stride
-            radix.append(len(u))
-            used.append(u)
-            stride *= len(u)
         n_o = [len(e["tr"]) for e in ents]
         scales = {e["scale"] for e in ents}
         pays = None
-        if stride is not None and len(scales) == 1:
-            if stride <= 65535:
-                k16 = key.astype(np.uint16)
-                order = np.argsort(k16, kind="stable")     # (radix sort)
-                counts = np.bincount(k16, minlength=stride)
-                live = np.nonzero(counts)[0]
-                cnt = counts[live]
-            else:
-                order = np.argsort(key, kind="stable")
-                live, cnt = np.unique(key, return_counts=True)
-            tuples = []
-            for kq in live:
-                q, tup = int(kq), []
-                for u in used:
-                    tup.append(int(u[q % len(u)]))
-                    q //= len(u)
-                tuples.append(tuple(tup))
+        grouped = self._alpha_tuples(best, A) if len(scales) == 1 else None
+        if grouped is not None:
+            order, cnt, tuples = grouped
             # which tuples pay.  Costs in (column tile x depth row) units of the grouped contraction (3.7 ns at cfg2); one
             # operator image costs ~12 900 of them there (46 us: the folds' operators read, the image written), a cached one
             # a quarter (a device copy); the folds' own products cost a tuple's voxels their share of sum_f n_train depth rows

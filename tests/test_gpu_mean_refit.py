@@ -77,13 +77,13 @@ def test_mean_operator_image_against_numpy(lc):
         assert torch.equal(img, img2)
 
 
-@pytest.mark.parametrize("case", ["kfold", "chunked_norm_x", "single_alpha", "panels", "own_choice"])
+@pytest.mark.parametrize("case", ["kfold", "chunked_norm_x", "single_alpha", "single_alpha_panels", "panels", "own_choice"])
 def test_mean_operator_fit_equals_fold_by_fold_fit(lc, case):
     """The same fit with and without the mean-operator refit: alphas, correlations, p-values identical (the folds' test-row
     contractions are untouched), weights equal to fp32 rounding of the two summation orders."""
     from litcoder_core_amd import NestedCVModel
     from litcoder_core_amd.engine.common import FitOptions
-    rng = np.random.default_rng({"kfold": 1, "chunked_norm_x": 2, "single_alpha": 3, "panels": 4, "own_choice": 5}[case])
+    rng = np.random.default_rng({"kfold": 1, "chunked_norm_x": 2, "single_alpha": 3, "panels": 4, "own_choice": 5, "single_alpha_panels": 6}[case])
     T, p, V = 600, 200, 1900
     if case == "own_choice":                                   # (the cost rule decides which tuples get an operator: wide enough
         T, p, V = 640, 330, 24000                               #  for some to pay, noise voxels for the others)
@@ -92,10 +92,10 @@ def test_mean_operator_fit_equals_fold_by_fold_fit(lc, case):
     mkw = {}
     if case == "chunked_norm_x":
         kw.update(folding_type="chunked", chunk_length=25, normalize_features=True, n_outer_folds=5)
-    if case == "single_alpha":
+    if case in ("single_alpha", "single_alpha_panels"):
         kw.update(single_alpha=True)
-    if case == "panels":
-        mkw.update(panel_cols=512)
+    if case in ("panels", "single_alpha_panels"):              # (single alpha + host panels: the joint choice over the ranges,
+        mkw.update(panel_cols=512)                               #  early panels refitted with the alpha they guess)
     import random
     random.seed(7)                                             # (chunked folds shuffle with Python's global generator)
     m0 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(mean_operator_refit=False), **mkw)
@@ -106,10 +106,10 @@ def test_mean_operator_fit_equals_fold_by_fold_fit(lc, case):
     out1 = m1.fit_predict(X, Y, **kw)
     mo = m1.last_fit.get("mean_operator")
     assert mo and mo["on"] and mo["ranges"] >= 1, mo
-    if case != "single_alpha":
+    if not case.startswith("single_alpha"):
         assert mo["voxels"] > 0 and mo["other_voxels"] > 0, mo    # both routes ran (30 % noise voxels: tuples of their own)
     assert not (m0.last_fit.get("mean_operator") or {}).get("on")
-    if case == "panels":
+    if case in ("panels", "single_alpha_panels"):
         assert len(m1.last_fit["panels"]) >= 3 and mo["ranges"] >= 2, (m1.last_fit["panels"], mo)
     np.testing.assert_array_equal(out1[2], out0[2])
     for k in ("correlations", "p_values"):

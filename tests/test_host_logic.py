@@ -339,3 +339,40 @@ def test_host_side_of_the_library_under_sanitizers(tmp_path):
     logs = "".join(open(os.path.join(tmp_path, f)).read()[-3000:] for f in sorted(os.listdir(tmp_path)) if f.endswith(".log"))
     assert r.returncode == 0, r.stdout + r.stderr + logs
     assert "asan_ubsan clean" in r.stdout and "tsan clean" in r.stdout
+
+
+def test_mean_operator_tuple_grouping_and_column_layout():
+    """engine/mean_refit.py's host side (round 6): voxels grouped by the alpha tuple they chose over the folds -- against a
+    dictionary-based grouping --, tuples in ascending mixed-radix order, voxels ascending inside a tuple, every voxel exactly
+    once; the padded column layout (every group on a 256-column tile boundary, -1 padding); the 16-bit and the wide key path."""
+    from litcoder_core_amd.engine.mean_refit import MeanOperatorRefit as MO
+    rng = np.random.default_rng(3)
+    for (F, A, V, spread) in ((5, 20, 5000, 2), (4, 13, 777, 5), (3, 64, 300, 64), (7, 40, 2000, 9), (2, 3, 1, 1)):
+        pool = rng.choice(A, size=min(spread, A), replace=False)
+        best = [pool[rng.integers(0, len(pool), V)].astype(np.int64) for _ in range(F)]
+        order, cnt, tuples = MO._alpha_tuples(best, A)
+        want = {}
+        for v in range(V):
+            want.setdefault(tuple(int(b[v]) for b in best), []).append(v)
+        assert sorted(order.tolist()) == list(range(V)) and int(cnt.sum()) == V and len(tuples) == len(want) == len(cnt)
+        pos = 0
+        for t, c in zip(tuples, cnt):
+            assert order[pos:pos + c].tolist() == want[t], (F, A, V, t)         # ascending voxel order inside the tuple
+            pos += int(c)
+        used = [np.unique(b) for b in best]
+        keys = [sum(int(np.searchsorted(u, a)) * int(np.prod([len(x) for x in used[:f]], dtype=np.int64)) for f, (u, a) in
+                    enumerate(zip(used, t))) for t in tuples]
+        assert keys == sorted(keys)                                              # ascending mixed-radix keys
+        perm, start = MO._padded_groups(order, cnt)
+        assert len(perm) == int(start[-1]) * 256 and start[0] == 0 and len(start) == len(cnt) + 1
+        for g, c in enumerate(cnt):
+            blk = perm[int(start[g]) * 256:int(start[g + 1]) * 256]
+            assert blk[:c].tolist() == want[tuples[g]] and (blk[c:] == -1).all()
+    # more key space than 16 bits: the sort-based path, same contract
+    best = [rng.integers(0, 30, 400).astype(np.int64) for _ in range(5)]
+    order, cnt, tuples = MO._alpha_tuples(best, 30)
+    assert sorted(order.tolist()) == list(range(400)) and all(c >= 1 for c in cnt)
+    pos = 0
+    for t, c in zip(tuples, cnt):
+        assert all(tuple(int(b[v]) for b in best) == t for v in order[pos:pos + c])
+        pos += int(c)
