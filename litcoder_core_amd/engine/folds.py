@@ -453,8 +453,8 @@ class FoldPhases:
         if not self.primal and self._mo_enabled(st):
             # (round 6) no weight rows per fold: the range's mean weights come from the MEAN of the folds' operators once its
             # last fold has chosen (engine/mean_refit.py) -- one contraction of depth T instead of one of depth n_train per fold
-            self._mo_record(st, weight_scale, side_job)
             pend = self._publish(st, r_s, p_s, perm, Vs, best, st["info"], st["info_o"], n_t, side_job=side_job)
+            self._mo_record(st, weight_scale, side_job, o=o, perm=perm, Vs=Vs)     # (may decide against the option: _mo_decide)
             self._range_finished(st)
             return pend
         ent, off = self._ws_slot(st["fold"], rg, Vs, weight_scale)

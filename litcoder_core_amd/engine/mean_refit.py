@@ -37,11 +37,11 @@ class MeanOperatorRefit:
         """Decided at the first refit of the fit (the arithmetic is known by then) and kept for all of it."""
         if getattr(self, "_mo", None) is None:
             ok = self._mo_possible() and bool(st["split"]) and st.get("best_h") is not None
-            self._mo = dict(folds={}, images={}, maps={}, done=0) if ok else False
+            self._mo = dict(folds={}, images={}, maps={}, done=0, pending=[], decided=self.n_folds <= 2) if ok else False
             self.info["mean_operator"] = dict(on=bool(ok), ranges=0, tuples=0, tiles=0, built=0, voxels=0, other_voxels=0)
         return bool(self._mo)
 
-    def _mo_record(self, st, weight_scale, side_job=None):
+    def _mo_record(self, st, weight_scale, side_job=None, o=None, perm=None, Vs=None):
         """A (fold, range) step whose weight rows are NOT formed now: the alphas its voxels chose, the fold's operators (one
         dictionary per fold, shared by its ranges: it fills as alphas are first used), the natural-order image of the range."""
         f, rg = int(st["fold"]), st["rg"]
@@ -58,6 +58,52 @@ class MeanOperatorRefit:
         ent["images"][rg.key] = st["hat"].get("image")
         if side_job is not None:                       # the step's exact-f32 weights of the side panel's columns (_side_refit_begin)
             ent["side"].append((side_job, rg.c0))
+        if not self._mo["decided"]:
+            # until the first two folds have chosen nobody knows whether the voxels' alphas repeat over the folds: the step's
+            # operands are kept, so that its own weight product can still be formed (_mo_decide)
+            self._mo["pending"].append(dict(fold=f, rg=rg, o=o, perm=perm, Vs=int(Vs), scale=float(weight_scale), side_job=side_job))
+            self._mo_decide()
+
+    def _mo_decide(self):
+        """After the first two folds' choices: does the mean-operator refit pay on THESE data?  The (alpha_0, alpha_1) pairs of
+        the rank's voxels stand in for the tuples over all folds -- a pair shared by c voxels of V is expected to split into
+        tuples of ~c (c / V)^((F - 2) / 2) voxels; the voxels of pairs whose tuples would reach the size at which an operator
+        pays (mean_operator_cost_ratio) must make up mean_operator_min_share of all.  Otherwise the option is dropped for the
+        rest of the fit: the kept steps' own weight products are formed now, the later folds' as they always were."""
+        mo, A = self._mo, self.A
+        ents = [mo["folds"].get(f) for f in (0, 1)]
+        if any(e is None or (e["best"][: self.V_rank] < 0).any() for e in ents):
+            return                                     # (a fold still has voxel ranges to come)
+        V = self.V_rank
+        b0, b1 = ents[0]["best"][:V], ents[1]["best"][:V]
+        c2 = np.bincount(b0 * A + b1, minlength=A * A).astype(np.float64)
+        c2 = c2[c2 > 0]
+        size = c2 * (c2 / V) ** ((self.n_folds - 2) / 2.0)
+        n_o = float(len(ents[0]["tr"])) * self.n_folds
+        Kd = ops.pad_to(self.Ttot, 32)
+        build = 0.85 * (self.n_folds * ops.pad_to(len(ents[0]["tr"]), 64) + Kd)
+        cnt_min = 256.0 * (Kd + build) / max(self.opt.mean_operator_cost_ratio * n_o, 1.0)
+        share = float(c2[size >= cnt_min].sum() / max(V, 1))
+        self.info["mean_operator"]["expected_share"] = round(share, 4)
+        mo["decided"] = True
+        pending, mo["pending"] = mo["pending"], []
+        if share >= self.opt.mean_operator_min_share:
+            return                                     # on: the kept operands are dropped
+        logger.info("mean-operator refit: %.0f %% of the voxels expected in alpha tuples that pay: the folds' own weight products",
+                    100.0 * share)
+        self.info["mean_operator"]["on"] = False
+        self._mo = False
+        for s in pending:                              # what fold_finish does without the option, for the steps gone by
+            ent, off = self._ws_slot(s["fold"], s["rg"], s["Vs"], s["scale"])
+            ops.invert_perm(s["perm"], s["Vs"], off, ent["pos"][s["rg"].c0:])
+            prev, self.cur = self.cur, s["rg"]
+            try:
+                self._refit_product(s["o"], 0, self.p_pad, self.p, out=ent["buf"][:, off:off + s["Vs"]])
+                if s["side_job"] is not None:
+                    W_s, dst, n_s = self._side_refit_end(s["side_job"], ent, off)
+                    ops.scatter_cols(W_s, self.p_pad, dst, n_s, ent["buf"][:, off:off + s["Vs"]])
+            finally:
+                self.cur = prev
 
     def _mo_map(self, fold, tr_rows, Kd):
         """(Kd,) int32 device: column of fold ``fold``'s operators that belongs to target row t (-1: not a training row)."""

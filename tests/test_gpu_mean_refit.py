@@ -101,7 +101,8 @@ def test_mean_operator_fit_equals_fold_by_fold_fit(lc, case):
     m0 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(mean_operator_refit=False), **mkw)
     out0 = m0.fit_predict(X, Y, **kw)
     random.seed(7)
-    opt1 = FitOptions(mean_operator_min_cols=0) if case == "own_choice" else FitOptions(mean_operator_min_cols=0, mean_operator_cost_ratio=1e9)
+    opt1 = (FitOptions(mean_operator_min_cols=0, mean_operator_min_share=0.0) if case == "own_choice"
+            else FitOptions(mean_operator_min_cols=0, mean_operator_cost_ratio=1e9))
     m1 = NestedCVModel("ridge_regression", precision="f16x3", options=opt1, **mkw)
     out1 = m1.fit_predict(X, Y, **kw)
     mo = m1.last_fit.get("mean_operator")
@@ -170,7 +171,7 @@ def test_mean_operator_leaves_scattered_tuples_to_the_folds(lc):
     kw = dict(folding_type="kfold", n_outer_folds=4, n_inner_folds=3, alphas=np.logspace(-1, 6, 15))
     m0 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(mean_operator_refit=False))
     out0 = m0.fit_predict(X, Y, **kw)
-    m1 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(mean_operator_min_cols=0))
+    m1 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(mean_operator_min_cols=0, mean_operator_min_share=0.0))
     out1 = m1.fit_predict(X, Y, **kw)
     mo = m1.last_fit["mean_operator"]
     assert mo["on"] and mo["voxels"] == 0 and mo["other_voxels"] == V, mo
@@ -206,3 +207,26 @@ def test_mean_operator_with_a_wide_target_column(lc):
     W0, W1 = np.asarray(W0), np.asarray(W1)
     np.testing.assert_array_equal(W1[:, [17, 1234]], W0[:, [17, 1234]])
     assert np.abs(W1.astype(np.float64) - W0).max() <= 2e-6 * np.abs(W0).max()
+
+
+@pytest.mark.parametrize("layout", ["resident", "host_panels"])
+def test_mean_operator_is_dropped_when_the_first_two_folds_say_so(lc, layout):
+    """Weak-signal targets: after the first two folds' choices the expected share of voxels in alpha tuples that pay is far below
+    mean_operator_min_share -- the option is dropped, the steps gone by form their own weight products at once, the later folds
+    theirs as they always did: bit for bit the fit without the option (host panels: the first fold's steps were voxel ranges)."""
+    from litcoder_core_amd import NestedCVModel
+    from litcoder_core_amd.engine.common import FitOptions
+    rng = np.random.default_rng(61)
+    T, p, V = 520, 170, 2100
+    X, Y = _problem(rng, T, p, V, noise_cols=0.5, signal=0.25)
+    kw = dict(folding_type="kfold", n_outer_folds=5, n_inner_folds=3, alphas=np.logspace(-1, 6, 15))
+    mkw = dict(panel_cols=512) if layout == "host_panels" else {}
+    m0 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(mean_operator_refit=False), **mkw)
+    out0 = m0.fit_predict(X, Y, **kw)
+    m1 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(mean_operator_min_cols=0), **mkw)
+    out1 = m1.fit_predict(X, Y, **kw)
+    mo = m1.last_fit["mean_operator"]
+    assert not mo["on"] and mo["expected_share"] < 0.5 and mo["ranges"] == 0, mo
+    np.testing.assert_array_equal(out1[2], out0[2])
+    np.testing.assert_array_equal(np.asarray(out1[1]), np.asarray(out0[1]))
+    np.testing.assert_array_equal(np.asarray(out1[0]["correlations"]), np.asarray(out0[0]["correlations"]))
