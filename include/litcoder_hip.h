@@ -205,10 +205,14 @@ int lc_cast_f64_f32(const double* d_in, int64_t ld_in, float* d_out, int64_t ld_
                     int64_t rows, int64_t cols, lc_stream_t stream);
 
 /* out[r, j] = in[rows[r], cols ? cols[j] : j]   (nested_cv.py:200-201 row splits, plus the
- * alpha-sorted voxel order used by the grouped refit).  rows[r] == -1 or cols[j] == -1 -> 0. */
+ * alpha-sorted voxel order used by the grouped refit).  rows[r] == -1 or cols[j] == -1 -> 0.
+ * d_live_cols (NULL: all; here and in lc_val_stats_folds / lc_col_scales_f16_flags / lc_split_cols_f16): device int32, read
+ * by the kernel -- only the first *d_live_cols columns (rounded up to whole 256-column tiles) are touched: the screening
+ * pass' refinement panel has a fixed capacity, how many undecided voxels it holds is known on the device only (round 6:
+ * every pass over the panel costs what its voxels cost, not what its capacity would). */
 int lc_gather_f32(const float* d_in, int64_t ld_in, const int32_t* d_rows, int64_t n_rows,
                   const int32_t* d_cols, int64_t n_cols, float* d_out, int64_t ld_out,
-                  lc_stream_t stream);
+                  const int32_t* d_live_cols, lc_stream_t stream);
 
 /* acc[:, cols[j]] += scale * w[:, j]  (np.mean(fold_weights) accumulated on device,
  * nested_cv.py:249,296); cols[j] == -1 skipped. */
@@ -497,7 +501,7 @@ int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, 
  * (F, M, V).  The five validation blocks of an outer fold are independent; one launch instead of five. */
 int lc_val_stats_folds(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int F, int M,
                        const int32_t* h_n_val, float* d_ystat, float* d_yblk, float* d_yv,
-                       lc_stream_t stream);
+                       const int32_t* d_live_cols, lc_stream_t stream);
 
 /* Fused alpha sweep of one inner fold (ridge_regression.py:115-133, K4+K5 of SURVEY 2.2):
  *   pred_a = H_a (M x N) . Y[tr_rows] (N x V)    for a = 0..A-1, never stored;
@@ -553,7 +557,7 @@ int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float
  * fp16 hi/lo split.  A handful of such voxels is recomputed on an exact-f32 side path and only they leave the f16x3
  * arithmetic (the reference treats every column alike in fp32, ridge_regression.py:104-125); needs d_flag. */
 int lc_col_scales_f16_flags(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale, int32_t* d_flag,
-                            uint8_t* d_colflag, lc_stream_t stream);
+                            uint8_t* d_colflag, const int32_t* d_live_cols, lc_stream_t stream);
 
 /* The primal form's operand  B_f = B_all - B_val(f)  (Rstim'Rresp of an inner training set as the outer block's minus
  * the validation block's, nested_cv.py:366-374 -> ridge_regression.py:104-106) and its column scales in ONE pass:
@@ -569,7 +573,7 @@ int lc_col_scales_from_max(const uint32_t* d_colmax, int64_t V, float* d_cscale,
 /* Y[d_rows] (K rows incl. -1 padding, V columns) * cscale -> tiled fp16 hi/lo image
  * (pad256(V) * K * 2 halves).  K % 32 == 0. */
 int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_rows, int K,
-                      const float* d_cscale, void* d_tiled, lc_stream_t stream);
+                      const float* d_cscale, void* d_tiled, const int32_t* d_live_cols, lc_stream_t stream);
 
 /* The tiled image of the same K rows with the voxel columns permuted: column j of the output image is column
  * d_perm[j] of d_tiled (-1: a zero column), j < Vs (a multiple of 256).  The alpha-sorted operand of the refit
@@ -642,10 +646,10 @@ int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float* d_rowscale
  * all folds' partials instead of one small launch per fold (25 + 25 per fit at cfg2); folds added in order, as above. */
 int lc_alpha_sweep_finalize_folds(const float* d_part, const float* d_ystat, const float* d_yblk, int F, int A, int M,
                                   const int32_t* h_n_val, int64_t V, int mode, float* d_scores, int accumulate,
-                                  lc_stream_t stream);
+                                  const int32_t* d_live_cols, lc_stream_t stream);
 int lc_series_sweep_finalize_folds(const float* d_part, const float* d_ystat, const float* d_yblk, int F, int M,
                                    const int32_t* h_n_val, int64_t V, const double* d_coef, const int32_t* d_aidx, int S,
-                                   float* d_scores, int accumulate, lc_stream_t stream);
+                                   float* d_scores, int accumulate, const int32_t* d_live_cols, lc_stream_t stream);
 
 /* The voxels whose alpha the SCREENING pass of the inner CV (terms = 1 above) does not decide (round 6, DESIGN.md 4.2;
  * the reference takes the argmax of the fold-mean scores, nested_cv.py:408-411 -- a voxel whose best two alphas are

@@ -37,7 +37,7 @@ SIGNATURES = {
                                c_int, _ptr, c_int64, _ptr]),
     "lc_segment_reduce": (c_int, [_ptr, c_int, c_int64, c_int64, _ptr, _ptr, c_int64, c_int, _ptr, c_int64, _ptr]),
     "lc_cast_f64_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, c_int64, c_int64, _ptr]),
-    "lc_gather_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr]),
+    "lc_gather_f32": (c_int, [_ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr, c_int64, _ptr, _ptr]),
     "lc_scatter_axpy_f32": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int64, c_float, _ptr, c_int64, _ptr]),
     "lc_scatter_cols": (c_int, [_ptr, c_int64, c_int64, c_int, _ptr, c_int64, _ptr, c_int64, _ptr]),
     "lc_gemv_cols_f32": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, c_int64, _ptr, _ptr, c_int, c_int32, _ptr, c_int64, _ptr]),
@@ -122,9 +122,9 @@ SIGNATURES = {
                                                   POINTER(c_int32), _ptr, _ptr, c_int, _ptr, _ptr, c_int, c_int64,
                                                   POINTER(c_int64), POINTER(c_int64), c_int, _ptr, _ptr]),
     "lc_alpha_sweep_finalize_folds": (c_int, [_ptr, _ptr, _ptr, c_int, c_int, c_int, POINTER(c_int32), c_int64, c_int, _ptr, c_int,
-                                              _ptr]),
+                                              _ptr, _ptr]),
     "lc_series_sweep_finalize_folds": (c_int, [_ptr, _ptr, _ptr, c_int, c_int, POINTER(c_int32), c_int64, _ptr, _ptr, c_int, _ptr,
-                                               c_int, _ptr]),
+                                               c_int, _ptr, _ptr]),
     "lc_series_sweep_scores_f16x3_folds": (c_int, [_ptr, _ptr, c_int, c_int, POINTER(c_int32), c_int64, _ptr, _ptr, c_int64,
                                                    _ptr, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr, c_int,
                                                    c_int64, POINTER(c_int64), POINTER(c_int64), c_int, _ptr, _ptr]),
@@ -133,7 +133,7 @@ SIGNATURES = {
     "lc_series_scores": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, _ptr, _ptr, _ptr, _ptr, c_int, _ptr, _ptr,
                                  c_int, _ptr]),
     "lc_transpose_rows_f64": (c_int, [_ptr, c_int64, _ptr, c_int, c_int64, _ptr, _ptr]),
-    "lc_val_stats_folds": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, POINTER(c_int32), _ptr, _ptr, _ptr, _ptr]),
+    "lc_val_stats_folds": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, POINTER(c_int32), _ptr, _ptr, _ptr, _ptr, _ptr]),
     "lc_val_stats": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, c_int, _ptr, _ptr, _ptr, _ptr]),
     "lc_alpha_sweep_scores": (c_int, [_ptr, c_int, c_int, c_int, _ptr, c_int64, c_int64, _ptr, _ptr, c_int, _ptr, _ptr,
                                       c_int, _ptr, _ptr, c_int, _ptr]),
@@ -144,8 +144,8 @@ SIGNATURES = {
     "lc_split_rows_f16_alphas": (c_int, [_ptr, c_int64, c_int, c_int, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_split_rows_f16_alphas_sel": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_col_scales_f16": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr]),
-    "lc_col_scales_f16_flags": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr, _ptr]),
-    "lc_split_cols_f16": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, _ptr, _ptr, _ptr]),
+    "lc_col_scales_f16_flags": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "lc_split_cols_f16": (c_int, [_ptr, c_int64, c_int64, _ptr, c_int, _ptr, _ptr, _ptr, _ptr]),
     "lc_permute_cols_f16": (c_int, [_ptr, _ptr, c_int64, c_int, _ptr, _ptr]),
     "lc_gemm_grouped_f16x3": (c_int, [_ptr, _ptr, c_int64, _ptr, _ptr, _ptr, c_int64, c_int64, c_int64,
                                       POINTER(c_int32), c_int, _ptr, c_int64, c_int64, c_int64, _ptr]),

@@ -234,7 +234,8 @@ struct FoldCounts {
 __global__ void __launch_bounds__(256) k_score_finalize(const float* __restrict__ part_all, const float* __restrict__ ystat_all,
                                                         const float* __restrict__ yblk_all, int A, int M, FoldCounts fc,
                                                         int F, long long V, int mode, float* __restrict__ scores,
-                                                        int accumulate) {
+                                                        int accumulate, const int* __restrict__ live_cols = nullptr) {
+    if (live_cols && (long long)blockIdx.x * blockDim.x >= (((long long)*live_cols + 255) & ~255ll)) return;   // (the refinement's panel: no voxel here)
     const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int a = blockIdx.y;
     if (v >= V) return;
@@ -310,7 +311,8 @@ template <int FW, int COLS>
 __global__ void __launch_bounds__(COLS * FW) k_score_finalize_fw(const float* __restrict__ part_all, const float* __restrict__ ystat_all,
                                                         const float* __restrict__ yblk_all, int A, int M, FoldCounts fc,
                                                         int F, long long V, int mode, float* __restrict__ scores,
-                                                        int accumulate) {
+                                                        int accumulate, const int* __restrict__ live_cols = nullptr) {
+    if (live_cols && (long long)blockIdx.x * COLS >= (((long long)*live_cols + 255) & ~255ll)) return;   // (the refinement's panel: no voxel here)
     __shared__ float sc_lds[FW][COLS];
     const long long v = (long long)blockIdx.x * COLS + threadIdx.x;
     const int a = blockIdx.y, fy = threadIdx.y;
@@ -508,7 +510,8 @@ __global__ void __launch_bounds__(256) k_series_scores_part(const float* __restr
                                                             const float* __restrict__ yblk_all, int M, FoldCounts fc, int F,
                                                             long long V, const double* __restrict__ coefs,
                                                             const int* __restrict__ aidx, int S,
-                                                            float* __restrict__ scores, int accumulate) {
+                                                            float* __restrict__ scores, int accumulate, const int* __restrict__ live_cols = nullptr) {
+    if (live_cols && (long long)blockIdx.x * blockDim.x >= (((long long)*live_cols + 255) & ~255ll)) return;   // (the refinement's panel: no voxel here)
     constexpr int NP = lc::EPI_SERIES_PARTS;
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;    // 64 columns per workgroup: one thread per
     if (c >= V) return;                                                      // column is a dependent chain over the blocks,
@@ -581,7 +584,8 @@ __global__ void __launch_bounds__(COLS * FW) k_series_scores_part_fw(const float
                                                             const float* __restrict__ yblk_all, int M, FoldCounts fc, int F,
                                                             long long V, const double* __restrict__ coefs,
                                                             const int* __restrict__ aidx, int S,
-                                                            float* __restrict__ scores, int accumulate) {
+                                                            float* __restrict__ scores, int accumulate, const int* __restrict__ live_cols = nullptr) {
+    if (live_cols && (long long)blockIdx.x * COLS >= (((long long)*live_cols + 255) & ~255ll)) return;   // (the refinement's panel: no voxel here)
     constexpr int NP = lc::EPI_SERIES_PARTS;
     __shared__ float sc_lds[FW][FIN_FW][COLS];             // [fold worker][alpha of the chunk][column]
     const long long c = (long long)blockIdx.x * COLS + threadIdx.x;
@@ -700,31 +704,31 @@ int set_lds_attr() {
 // shared with the fp16x3 variant (lc_gemm16.hip)
 int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int A, int M,
                              const int* h_n_val, int F, long long V, int mode, float* d_scores, int accumulate,
-                             hipStream_t s) {
+                             hipStream_t s, const int* d_live_cols) {
     FoldCounts fc{};
     for (int f = 0; f < F && f < 64; ++f) fc.n_val[f] = h_n_val[f];
     lc::ScopedTimer timer_(lc::T_SWEEP_FINALIZE, s);
     if (V < FIN_WIDE_V && F > 1)
         hipLaunchKernelGGL((k_score_finalize_fw<FIN_FW, 64>), dim3((unsigned)lc::ceil_div<long long>(V, 64), (unsigned)A),
-                           dim3(64, FIN_FW), 0, s, d_part, d_ystat, d_yblk, A, M, fc, F, V, mode, d_scores, accumulate);
+                           dim3(64, FIN_FW), 0, s, d_part, d_ystat, d_yblk, A, M, fc, F, V, mode, d_scores, accumulate, d_live_cols);
     else
         hipLaunchKernelGGL(k_score_finalize, dim3((unsigned)lc::ceil_div<long long>(V, 256), (unsigned)A), dim3(256), 0, s,
-                           d_part, d_ystat, d_yblk, A, M, fc, F, V, mode, d_scores, accumulate);
+                           d_part, d_ystat, d_yblk, A, M, fc, F, V, mode, d_scores, accumulate, d_live_cols);
     return lc::launched("k_score_finalize");
 }
 
 int lc_series_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int M, const int* h_n_val,
                               int F, long long V, const double* d_coef, const int* d_aidx, int S, float* d_scores,
-                              int accumulate, hipStream_t s) {
+                              int accumulate, hipStream_t s, const int* d_live_cols) {
     FoldCounts fc{};
     for (int f = 0; f < F && f < 64; ++f) fc.n_val[f] = h_n_val[f];
     lc::ScopedTimer timer_(lc::T_SWEEP_FINALIZE, s);
     if (V < FIN_WIDE_V && F > 1)
         hipLaunchKernelGGL((k_series_scores_part_fw<FIN_FW, 64>), dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, FIN_FW),
-                           0, s, d_part, d_ystat, d_yblk, M, fc, F, V, d_coef, d_aidx, S, d_scores, accumulate);
+                           0, s, d_part, d_ystat, d_yblk, M, fc, F, V, d_coef, d_aidx, S, d_scores, accumulate, d_live_cols);
     else
         hipLaunchKernelGGL(k_series_scores_part, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64), 0, s, d_part,
-                           d_ystat, d_yblk, M, fc, F, V, d_coef, d_aidx, S, d_scores, accumulate);
+                           d_ystat, d_yblk, M, fc, F, V, d_coef, d_aidx, S, d_scores, accumulate, d_live_cols);
     return lc::launched("k_series_scores_part");
 }
 
@@ -757,7 +761,7 @@ extern "C" int lc_alpha_sweep_scores(const float* d_h, int A, int M, int N, cons
                            (long long)V, sa);
     }
     if (int rc = lc::launched("k_gemm_f32<score>")) return rc;
-    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, &n_val, 1, (long long)V, mode, d_scores, accumulate, s);
+    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, &n_val, 1, (long long)V, mode, d_scores, accumulate, s, nullptr);
 }
 
 extern "C" int lc_series_scores(const float* d_t, int64_t ldt, int terms, int M, int n_val, int64_t V, const float* d_yv,

@@ -19,7 +19,7 @@
 // defined in lc_gemm.hip: combines the per-block partial moments into scores (F folds: fp32 sum in fold order)
 int lc_score_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int A, int M,
                              const int* h_n_val, int F, long long V, int mode, float* d_scores, int accumulate,
-                             hipStream_t s);
+                             hipStream_t s, const int* d_live_cols);
 
 // B view from the C-ABI triple (rows of the image, first row of the gap, rows of the gap; all multiples of 16)
 static int make_bview(const char* who, int64_t K, int64_t b_rows, int64_t gap_begin, int64_t gap_rows, BView* bv) {
@@ -100,19 +100,19 @@ extern "C" int lc_mean_operator_image_f16(const float* const* h_mats, const int6
 }
 
 extern "C" int lc_col_scales_f16_flags(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
-                                       int32_t* d_flag, uint8_t* d_colflag, lc_stream_t stream) {
+                                       int32_t* d_flag, uint8_t* d_colflag, const int32_t* d_live_cols, lc_stream_t stream) {
     LC_REQUIRE(d_y && d_cscale, LC_E_BADARG, "lc_col_scales_f16: null pointer");     // d_flag may be NULL: scales only
     LC_REQUIRE(T > 0 && V > 0 && ldy >= V, LC_E_SHAPE, "lc_col_scales_f16: bad shape");
     LC_REQUIRE(d_flag || !d_colflag, LC_E_BADARG, "lc_col_scales_f16: per-column flags need the flag pass (d_flag)");
     lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
     hipLaunchKernelGGL(k_col_scales, dim3((unsigned)lc::ceil_div<long long>(V, 64)), dim3(64, CS_RG), 0,
-                       lc::as_stream(stream), d_y, (long long)ldy, (int)T, (long long)V, d_cscale, d_flag, d_colflag);
+                       lc::as_stream(stream), d_y, (long long)ldy, (int)T, (long long)V, d_cscale, d_flag, d_colflag, d_live_cols);
     return lc::launched("k_col_scales");
 }
 
 extern "C" int lc_col_scales_f16(const float* d_y, int64_t ldy, int64_t T, int64_t V, float* d_cscale,
                                  int32_t* d_flag, lc_stream_t stream) {
-    return lc_col_scales_f16_flags(d_y, ldy, T, V, d_cscale, d_flag, nullptr, stream);
+    return lc_col_scales_f16_flags(d_y, ldy, T, V, d_cscale, d_flag, nullptr, nullptr, stream);
 }
 
 extern "C" int lc_combine_terms_colmax_f32(const float* const* h_terms, const float* h_coef, int terms, float* d_out,
@@ -148,13 +148,13 @@ extern "C" int lc_col_scales_from_max(const uint32_t* d_colmax, int64_t V, float
 }
 
 extern "C" int lc_split_cols_f16(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_rows, int K,
-                                 const float* d_cscale, void* d_tiled, lc_stream_t stream) {
+                                 const float* d_cscale, void* d_tiled, const int32_t* d_live_cols, lc_stream_t stream) {
     LC_REQUIRE(d_y && d_rows && d_cscale && d_tiled, LC_E_BADARG, "lc_split_cols_f16: null pointer");
     LC_REQUIRE(V > 0 && K > 0 && K % TK == 0 && ldy >= V, LC_E_SHAPE, "lc_split_cols_f16: need K %% %d == 0", TK);
     lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
     dim3 grid((unsigned)lc::ceil_div<long long>(V, TN), (unsigned)(K / 8));
     hipLaunchKernelGGL(k_split_cols_f16, grid, dim3(256), 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V,
-                       d_rows, K, d_cscale, (uint4*)d_tiled);
+                       d_rows, K, d_cscale, (uint4*)d_tiled, d_live_cols);
     return lc::launched("k_split_cols_f16");
 }
 
@@ -234,19 +234,20 @@ extern "C" int lc_alpha_sweep_scores_f16x3_folds(const void* d_ht, const float* 
     }
     if (int rc = lc::launched("k_sweep_f16x3")) return rc;
     if (accumulate == 2) return LC_OK;                    // the contraction alone: the caller finalises several folds at once
-    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, h_n_val, F, (long long)V, mode, d_scores, accumulate, s);
+    return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, h_n_val, F, (long long)V, mode, d_scores, accumulate, s,
+                                    d_live_cols);
 }
 
 // The second halves of the two sweeps alone, for F folds whose contractions were launched one by one with accumulate = 2
 // (each into its slice of the (F, ...) stacks): one pass over all folds' partials instead of one small launch per fold.
 extern "C" int lc_alpha_sweep_finalize_folds(const float* d_part, const float* d_ystat, const float* d_yblk, int F, int A, int M,
                                              const int32_t* h_n_val, int64_t V, int mode, float* d_scores, int accumulate,
-                                             lc_stream_t stream) {
+                                             const int32_t* d_live_cols, lc_stream_t stream) {
     LC_REQUIRE(d_part && d_ystat && d_yblk && d_scores && h_n_val, LC_E_BADARG, "lc_alpha_sweep_finalize_folds: null pointer");
     LC_REQUIRE(F >= 1 && F <= MAX_FOLDS16 && A > 0 && M > 0 && M % LC_MB == 0 && V > 0 && V % 128 == 0, LC_E_SHAPE,
                "lc_alpha_sweep_finalize_folds: bad shape");
     return lc_score_finalize_launch(d_part, d_ystat, d_yblk, A, M, h_n_val, F, (long long)V, mode, d_scores, accumulate ? 1 : 0,
-                                    lc::as_stream(stream));
+                                    lc::as_stream(stream), d_live_cols);
 }
 
 extern "C" int lc_gemm_grouped_f16x3(const void* d_at, const float* d_rowscale_inv, int64_t Mrows, const void* d_bt,
@@ -382,7 +383,7 @@ extern "C" int lc_gemm_grouped_f16x3_pearson(const void* d_at, const float* d_ro
 // defined in lc_gemm.hip
 int lc_series_finalize_launch(const float* d_part, const float* d_ystat, const float* d_yblk, int M, const int* h_n_val,
                               int F, long long V, const double* d_coef, const int* d_aidx, int S, float* d_scores,
-                              int accumulate, hipStream_t s);
+                              int accumulate, hipStream_t s, const int* d_live_cols);
 
 extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float* d_rowscale_inv, int F, int M,
                                                   const int32_t* h_n_val, int64_t K, const void* d_yt,
@@ -441,17 +442,18 @@ extern "C" int lc_series_sweep_scores_f16x3_folds(const void* d_pt, const float*
     if (int rc = lc::launched("k_sweep_f16x3<series moments>")) return rc;
     if (accumulate == 2) return LC_OK;                    // (see lc_series_sweep_finalize_folds)
     return lc_series_finalize_launch(d_part, d_ystat, d_yblk, M, h_n_val, F, (long long)V, d_coef, d_aidx, S, d_scores,
-                                     accumulate, s);
+                                     accumulate, s, d_live_cols);
 }
 
 extern "C" int lc_series_sweep_finalize_folds(const float* d_part, const float* d_ystat, const float* d_yblk, int F, int M,
                                               const int32_t* h_n_val, int64_t V, const double* d_coef, const int32_t* d_aidx,
-                                              int S, float* d_scores, int accumulate, lc_stream_t stream) {
+                                              int S, float* d_scores, int accumulate, const int32_t* d_live_cols,
+                                              lc_stream_t stream) {
     LC_REQUIRE(d_part && d_ystat && d_yblk && d_scores && h_n_val && d_coef && d_aidx, LC_E_BADARG,
                "lc_series_sweep_finalize_folds: null pointer");
     LC_REQUIRE(F >= 1 && F <= MAX_FOLDS16 && M > 0 && M % LC_MB == 0 && V > 0 && V % 128 == 0 && S > 0, LC_E_SHAPE,
                "lc_series_sweep_finalize_folds: bad shape");
     for (int f = 0; f < F; ++f) LC_REQUIRE(h_n_val[f] > 1, LC_E_SHAPE, "lc_series_sweep_finalize_folds: need n_val > 1");
     return lc_series_finalize_launch(d_part, d_ystat, d_yblk, M, h_n_val, F, (long long)V, d_coef, d_aidx, S, d_scores,
-                                     accumulate ? 1 : 0, lc::as_stream(stream));
+                                     accumulate ? 1 : 0, lc::as_stream(stream), d_live_cols);
 }

@@ -189,7 +189,10 @@ __global__ void __launch_bounds__(256) k_mean_operator_image(const MeanOpArgs a,
 constexpr int CS_RG = 16, CS_UNROLL = 8;   // row groups per block, rows in flight per thread
 __global__ void __launch_bounds__(64 * CS_RG) k_col_scales(const float* __restrict__ y, long long ldy, int T, long long V,
                                                            float* __restrict__ cs, int* __restrict__ flag,
-                                                           unsigned char* __restrict__ colflag = nullptr) {
+                                                           unsigned char* __restrict__ colflag = nullptr,
+                                                           const int* __restrict__ live = nullptr) {
+    // live (the refinement's column panel): only the first *live columns, in whole 256-column tiles, hold voxels
+    if (live && (long long)blockIdx.x * 64 >= (((long long)*live + 255) & ~255ll)) return;
     __shared__ float sm[CS_RG][64];
     __shared__ int cnt[CS_RG][64];
     const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
@@ -328,8 +331,9 @@ __global__ void __launch_bounds__(256) k_scales_from_max(const unsigned* __restr
 // Tiled fp16 hi/lo image of Y[rows] (K = padded row count, -1 rows -> 0): thread = (column, 8-row group).
 __global__ void __launch_bounds__(256) k_split_cols_f16(const float* __restrict__ y, long long ldy, long long V,
                                                         const int* __restrict__ rows, int K, const float* __restrict__ cs,
-                                                        uint4* __restrict__ out) {
+                                                        uint4* __restrict__ out, const int* __restrict__ live = nullptr) {
     const int nt = blockIdx.x, g = blockIdx.y;              // g = K-tile * KG + k-group
+    if (live && (long long)nt * 256 >= (long long)*live) return;     // (the refinement's panel: no voxel in this column tile)
     const int col = threadIdx.x;
     const long long c = (long long)nt * 256 + col;
     const int KT = K / TK;

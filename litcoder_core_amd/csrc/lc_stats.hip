@@ -21,10 +21,13 @@ __global__ void __launch_bounds__(256) k_cast_f64_f32(const double* __restrict__
 // (2.2x on the alpha-sorted copy of the targets; several rows per workgroup were slower again).
 __global__ void __launch_bounds__(256) k_gather(const float* __restrict__ in, long long ld_in,
                                                 const int* __restrict__ rows, const int* __restrict__ cols,
-                                                long long n_cols, float* __restrict__ out, long long ld_out) {
+                                                long long n_cols, float* __restrict__ out, long long ld_out,
+                                                const int* __restrict__ live) {
     const long long r = blockIdx.y;
     const long long src = rows ? rows[r] : r;
     const long long stride = (long long)gridDim.x * blockDim.x;
+    // live (the refinement's column panel): only the first *live columns (whole 256-column tiles) hold voxels
+    if (live) n_cols = min(n_cols, ((long long)*live + 255) & ~255ll);
     for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += stride) {
         float v = 0.f;
         const long long c = cols ? cols[j] : j;
@@ -672,7 +675,7 @@ extern "C" int lc_cast_f64_f32(const double* d_in, int64_t ld_in, float* d_out, 
 
 extern "C" int lc_gather_f32(const float* d_in, int64_t ld_in, const int32_t* d_rows, int64_t n_rows,
                              const int32_t* d_cols, int64_t n_cols, float* d_out, int64_t ld_out,
-                             lc_stream_t stream) {
+                             const int32_t* d_live_cols, lc_stream_t stream) {
     LC_REQUIRE(d_in && d_out, LC_E_BADARG, "lc_gather_f32: null pointer");
     LC_REQUIRE(n_rows >= 0 && n_cols >= 0 && ld_out >= n_cols, LC_E_SHAPE, "lc_gather_f32: bad shape");
     if (n_rows == 0 || n_cols == 0) return LC_OK;
@@ -682,7 +685,7 @@ extern "C" int lc_gather_f32(const float* d_in, int64_t ld_in, const int32_t* d_
         dim3 grid((unsigned)lc::imin(lc::ceil_div<long long>(n_cols, 1024), 1024), (unsigned)nr);
         hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, lc::as_stream(stream), d_rows ? d_in : d_in + r0 * ld_in,
                            (long long)ld_in, d_rows ? d_rows + r0 : nullptr, d_cols, (long long)n_cols, d_out + r0 * ld_out,
-                           (long long)ld_out);
+                           (long long)ld_out, d_live_cols);
     }
     return lc::launched("k_gather");
 }
@@ -802,7 +805,8 @@ template <int NBLK>
 __global__ void __launch_bounds__(64 * CM_RG) k_val_stats_regs(const float* __restrict__ y, long long ldy, long long V,
                                                                const int* __restrict__ va, int M, FoldRows fr,
                                                                float* __restrict__ ystat, float* __restrict__ yblk,
-                                                               float* __restrict__ yv) {
+                                                               float* __restrict__ yv, const int* __restrict__ live_cols) {
+    if (live_cols && (long long)blockIdx.x * 64 >= (((long long)*live_cols + 255) & ~255ll)) return;   // (block-uniform: no voxel here)
     __shared__ double sm[CM_RG][64];
     const int fold = blockIdx.y, n_val = fr.n_val[fold];
     va += (long long)fold * M;
@@ -879,8 +883,9 @@ template <int NBLK>
 __global__ void __launch_bounds__(64 * CM_RG) k_val_stats_chunks(const float* __restrict__ y, long long ldy, long long V,
                                                                  const int* __restrict__ va, int M, FoldRows fr,
                                                                  float* __restrict__ ystat, float* __restrict__ yblk,
-                                                                 float* __restrict__ yv) {
+                                                                 float* __restrict__ yv, const int* __restrict__ live_cols) {
     static_assert(NBLK == 1, "one 32-row block per wave and trip, two register sets in flight");
+    if (live_cols && (long long)blockIdx.x * 64 >= (((long long)*live_cols + 255) & ~255ll)) return;   // (block-uniform: no voxel here)
     __shared__ double sm[CM_RG][64];
     const int fold = blockIdx.y, n_val = fr.n_val[fold];
     va += (long long)fold * M;
@@ -954,7 +959,7 @@ __global__ void __launch_bounds__(64 * CM_RG) k_val_stats_chunks(const float* __
 
 extern "C" int lc_val_stats_folds(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int F, int M,
                                   const int32_t* h_n_val, float* d_ystat, float* d_yblk, float* d_yv,
-                                  lc_stream_t stream) {
+                                  const int32_t* d_live_cols, lc_stream_t stream) {
     LC_REQUIRE(d_y && d_va && h_n_val && d_ystat && d_yblk && d_yv, LC_E_BADARG, "lc_val_stats: null pointer");
     LC_REQUIRE(F >= 1 && F <= 64 && M > 0 && M % LC_MB == 0, LC_E_SHAPE, "lc_val_stats: need 1 <= F <= 64, M %% %d == 0",
                LC_MB);
@@ -968,17 +973,17 @@ extern "C" int lc_val_stats_folds(const float* d_y, int64_t ldy, int64_t V, cons
     const dim3 grid((unsigned)lc::ceil_div<long long>(V, 64), (unsigned)F), block(64, CM_RG);
     if (M / LC_MB <= 2 * CM_RG)                              // up to 512 validation rows: held in registers, one pass
         hipLaunchKernelGGL(k_val_stats_regs<2>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V, d_va,
-                           M, fr, d_ystat, d_yblk, d_yv);
+                           M, fr, d_ystat, d_yblk, d_yv, d_live_cols);
     else                                                     // any number: two passes of register-sized chunks
         hipLaunchKernelGGL(k_val_stats_chunks<1>, grid, block, 0, lc::as_stream(stream), d_y, (long long)ldy, (long long)V,
-                           d_va, M, fr, d_ystat, d_yblk, d_yv);
+                           d_va, M, fr, d_ystat, d_yblk, d_yv, d_live_cols);
     return lc::launched("k_val_stats");
 }
 
 extern "C" int lc_val_stats(const float* d_y, int64_t ldy, int64_t V, const int32_t* d_va, int M, int n_val,
                             float* d_ystat, float* d_yblk, float* d_yv, lc_stream_t stream) {
     const int32_t n = n_val;
-    return lc_val_stats_folds(d_y, ldy, V, d_va, 1, M, &n, d_ystat, d_yblk, d_yv, stream);
+    return lc_val_stats_folds(d_y, ldy, V, d_va, 1, M, &n, d_ystat, d_yblk, d_yv, nullptr, stream);
 }
 
 extern "C" int lc_pearson_cols(const float* d_a, int64_t lda, const float* d_b, int64_t ldb, int64_t n, int64_t V,

@@ -146,6 +146,14 @@ class FitOptions:
                                             # scored on three MFMAs throughout (flat score curves -- pure-noise voxels on the
                                             # plateau of the large alphas, where neighbouring alphas agree to fp32 rounding --
                                             # cannot be decided by screening; scoring most voxels twice costs more than it saves)
+    screen_panel_first: float = 0.5         # ... share of a range the refinement's panel can hold (at least; twice the largest share
+                                            # of undecided voxels seen if that is more).  Generous since every pass over the panel
+                                            # reads the number of voxels it holds on the device: 1/16 until then, and two steps of
+                                            # a weak-signal fit overflowed before the host knew better (~8 ms each)
+    screen_second_panel_max: float = 0.6    # ... a panel that cannot hold a step's undecided voxels is followed by ONE that can (the
+                                            # count is known by then) while they are at most this share of the range; beyond it
+                                            # the range is scored again on three MFMAs (what every overflow cost before: ~15 ms
+                                            # per step at cfg2's shape with a fifth of the voxels undecided)
     screen_mean_coherent: float = 0.02      # ... single_alpha: the ONE alpha is the argmax of the voxel mean of the scores; the
                                             # screening error of that mean is taken as screen_tau / sqrt(rows) x max(0.4 sqrt(sum
                                             # kappa^2), this x sum kappa) / V -- independent errors, or this share of them coherent

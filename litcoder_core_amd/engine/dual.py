@@ -291,7 +291,8 @@ class DualSweeps:
                 # aligned block (B view): saves F - 1 passes over Y per outer fold
                 union, gaps = shared
                 Yu = torch.empty(Vt * len(union) * 2, dtype=torch.float16, device=self.dev)
-                ops.split_cols_f16(Y, Vp_, ops.idx_tensor(union, len(union), self.dev), len(union), cs, Yu)
+                ops.split_cols_f16(Y, Vp_, ops.idx_tensor(union, len(union), self.dev), len(union), cs, Yu,
+                                   live=hat.get("live") if hat.get("panel") else None)
                 Yt = [Yu] * nbuf
                 views = [(len(union), g0, gl) for g0, gl in gaps]
                 hat["image"] = (Yu, union)                # the refit permutes its operand out of it (_refit_operands)
@@ -331,7 +332,8 @@ class DualSweeps:
         one_launch = bool(moments and split and shared is not None and len(hat["Hs"]) == 1 and imgs[0] is not None
                           and imgs[0].get("Pt") is not None and (Ad == 0 or imgs[0].get("Ht") is not None)
                           and 1 < F <= 64 and self.opt.folds_in_one_launch_tiles > 0
-                          and ((max(Ad, 1) * M + 255) // 256) * (Vt // 256) < self.opt.folds_in_one_launch_tiles)
+                          # (the refinement's panel: its capacity is generous, the voxels it holds are few -- always one launch)
+                          and (panel or ((max(Ad, 1) * M + 255) // 256) * (Vt // 256) < self.opt.folds_in_one_launch_tiles))
 
         at_once = bool(self.opt.finalize_folds_at_once and moments and split and 1 < F <= 64)
 
@@ -354,7 +356,7 @@ class DualSweeps:
                 # validation statistics of all inner folds in one launch (the blocks are independent)
                 for f0 in range(0, F, 64):
                     f1 = min(F, f0 + 64)
-                    ops.val_stats_folds(Y, Vp_, va[f0:f1], f1 - f0, M, n_v[f0:f1], ystat[f0:f1], yblk[f0:f1], yv[f0:f1])
+                    ops.val_stats_folds(Y, Vp_, va[f0:f1], f1 - f0, M, n_v[f0:f1], ystat[f0:f1], yblk[f0:f1], yv[f0:f1], live=live)
                 if one_launch and fused:
                     im = imgs[0]
                     part_f = torch.empty((F, M // LC_MB, 18, Vp_), dtype=torch.float32, device=self.dev)
@@ -370,7 +372,7 @@ class DualSweeps:
                            if (fused and at_once) else None)
                 for f, j, H, P in folds:
                     if shared is None:
-                        ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[f])
+                        ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[f], live=live)
                     Pt_f, rs_p_f = Pt, rs_p
                     if f in img_of:
                         im, g = img_of[f]
@@ -394,7 +396,7 @@ class DualSweeps:
                     ops.series_scores(Tbuf, Vt, SERIES_TERMS, M, n_v[f], Vp_, yv[f], ystat[f], coef_s, dser_s,
                                       scores, accumulate=f > 0, rowmap=rowmap)
                 if part_sf is not None:                      # the folds' partial moments -> scores, all folds in one pass
-                    ops.series_sweep_finalize_folds(part_sf, ystat, yblk, M, n_v, Vp_, coef_s, dser_s, scores, accumulate=False)
+                    ops.series_sweep_finalize_folds(part_sf, ystat, yblk, M, n_v, Vp_, coef_s, dser_s, scores, accumulate=False, live=live)
 
         def fused_part():
             if done is not None:
@@ -420,7 +422,7 @@ class DualSweeps:
                     ops.val_stats(Y, Vp_, va[f], M, n_v[f], ystat[b], yblk[b], yv[b])
                 if split:
                     if not moments and shared is None:
-                        ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[b])
+                        ops.split_cols_f16(Y, Vp_, tr[f], N, cs, Yt[b], live=live)
                     if Ad_f:
                         self.info["fused_flops"] += 2.0 * Ad_f * n_v[f] * hat["n_i"][f] * V_
                         self.info["fused_launches"] += 1
@@ -443,7 +445,7 @@ class DualSweeps:
                     ops.alpha_sweep_scores(H[j * A:(j + 1) * A], A, M, N, Y, Vp_, tr[f], yv[b], n_v[f], ystat[b], yblk[b],
                                            self.mode, part, scores, accumulate=f > 0)
             if part_ff is not None:                          # the folds' partial moments -> scores, all folds in one pass
-                ops.alpha_sweep_finalize_folds(part_ff, ystat, yblk, Ad_f, M, n_v, Vp_, self.mode, scores_d, accumulate=False)
+                ops.alpha_sweep_finalize_folds(part_ff, ystat, yblk, Ad_f, M, n_v, Vp_, self.mode, scores_d, accumulate=False, live=live)
             if moments and Ad and not cho_first:
                 for i, a in enumerate(cho):
                     scores[a].copy_(scores_d[i])
@@ -501,18 +503,21 @@ class DualSweeps:
         self._refine_undecided(hat, Y, scores, ystat0, F, n_val_rows)
 
     def _refine_capacity(self, V):
-        """Columns of the refinement's panel for a voxel range of V columns: twice the largest share of undecided voxels a
-        step of this fit has reported so far (the host learns a step's count at its one synchronisation, fold_select: two
-        steps behind what is being queued), V / 16 (at least 2048 columns) before that; whole 256-column tiles."""
+        """Columns of the refinement's panel for a voxel range of V columns: FitOptions.screen_panel_first of them (half), or
+        twice the largest share of undecided voxels a step of this fit has reported so far if that is more; whole 256-column
+        tiles."""
         if self.opt.screen_panel_cols > 0:
             return int(min(ops.pad_to(self.opt.screen_panel_cols, 256), ops.pad_to(V, 256)))
         if self.shard.simulate:                          # (timing studies: the panel a real rank's ~1 % would get, _screen_check)
             return int(min(ops.pad_to(max(V // 32, 512), 256), ops.pad_to(V, 256)))
         fracs = getattr(self, "_undecided_fracs", None)
-        cap = int(2.0 * max(fracs) * V) + 256 if fracs else max(V // 16, 2048)     # (narrow ranges: generously, it costs nothing)
+        # (round 6, later: every pass over the panel costs what its voxels cost -- lc_gather_f32 / lc_col_scales_f16 /
+        # lc_split_cols_f16 / lc_val_stats_folds / the sweeps all read the count on the device -- so the capacity is generous
+        # from the first step on: a panel that cannot hold a step's undecided voxels costs a second pass and a host round trip)
+        cap = max(int(self.opt.screen_panel_first * V), int(2.0 * max(fracs) * V) + 256 if fracs else 0, 2048)
         return int(min(ops.pad_to(max(cap, 256), 256), ops.pad_to(V, 256)))
 
-    def _refine_undecided(self, hat, Y, scores, ystat0, F, n_val_rows):
+    def _refine_undecided(self, hat, Y, scores, ystat0, F, n_val_rows, cap=None):
         """Second half of the two-precision inner CV (FitOptions.screen_inner).  ``scores`` holds the sums
         over the F inner folds of the SCREENING scores (one fp16 MFMA per product: good to ~1e-5 of a fold-mean score).
         nested_cv.py:408-411 only takes each voxel's argmax of them, so a voxel whose two best alphas lie further apart
@@ -525,7 +530,8 @@ class DualSweeps:
         sweeps' tiles behind the last one leave at once (live), and a count beyond the capacity is reported to fold_select,
         which scores the whole range again (hat["screen_check"])."""
         Vp_, V_, A = self.Vp, self.V, self.A
-        cap = self._refine_capacity(V_)
+        cap = self._refine_capacity(V_) if cap is None else int(min(ops.pad_to(max(int(cap), 256), 256), ops.pad_to(V_, 256)))
+        hat["refine_args"] = (ystat0, F, n_val_rows)          # (a panel that overflows is followed by one that does not: _screen_check)
         # (the table holds SUMS over the F folds: the gap of the fold means x F)
         tau_sum = self.opt.screen_tau * F / float(np.sqrt(max(int(n_val_rows), 1)))
         lst, count = ops.undecided_cols(scores, A, V_, tau_sum, ystat0, cap)
@@ -534,9 +540,11 @@ class DualSweeps:
         # rank): (undecided columns found, "the panel does not hold them all") as the MAX over the ranks, in place
         if self.shard.active:
             self.shard.all_reduce_(count[1:3], "max")
+        # (every pass over the panel honours count[0], the number of columns it holds: it costs what its voxels cost, not
+        # what its capacity would -- which is why the capacity can be generous, _refine_capacity)
         Yp = torch.empty((self.Ttot, cap), dtype=torch.float32, device=self.dev)
-        ops.gather(Y, Y.stride(0), None, self.Ttot, lst, cap, Yp)
-        cs_p, _ = ops.col_scales_f16(Yp, self.Ttot, cap, want_flag=False)    # (per column, from the same values: the same scales)
+        ops.gather(Y, Y.stride(0), None, self.Ttot, lst, cap, Yp, live=count[0:1])
+        cs_p, _ = ops.col_scales_f16(Yp, self.Ttot, cap, want_flag=False, live=count[0:1])    # (per column, from the same values: the same scales)
         hp = dict(hat)
         hp.update(cs=cs_p, split=True, panel=True, live=count[0:1], data_ready=None, series_ready=None)
         keep = {k: self.info.get(k) for k in ("plain_flops", "plain_launches", "fused_flops", "fused_launches", "series_flops",

@@ -385,8 +385,28 @@ class FoldPhases:
             self.info["screen_switched_off"] = True
         if not over:
             return
-        logger.info("screening pass: %d of %d voxels undecided, the panel held %d: the range is scored again", found, V, cap)
         self.info["screen_overflows"] = self.info.get("screen_overflows", 0) + 1
+        args = st["hat"].get("refine_args")
+        if (args is not None and not st.get("_refined_again") and found <= self.opt.screen_second_panel_max * V
+                and self.opt.screen_panel_cols == 0):
+            # (round 6, later) a second panel that holds them all instead of three MFMAs for the whole range: the table still
+            # holds the screening scores (the first panel's columns their three-MFMA scores: they are found undecided again or
+            # not, and scored to the same bits either way); the count is exact, the margin covers the columns that change sides
+            logger.info("screening pass: %d of %d voxels undecided, the panel held %d: a second panel", found, V, cap)
+            st["_refined_again"] = True
+            self.info["undecided"] -= min(found, cap)      # (the second look at this step counts it again)
+            self.info["screened"] -= V
+            self._undecided_fracs.pop()
+            self._enter(st)
+            rs = st["hat"].get("refine_stream")
+            hat_ = st["hat"]
+            with torch.cuda.stream(rs if rs is not None else torch.cuda.current_stream()):
+                self._refine_undecided(hat_, st["Y"], st["scores"], *args, cap=int(1.1 * found) + 512)
+            st.pop("grouping", None)
+            st.pop("choose_done", None)
+            self.fold_choose(st, single_alpha)
+            return self._screen_check(st, single_alpha)
+        logger.info("screening pass: %d of %d voxels undecided, the panel held %d: the range is scored again", found, V, cap)
         hat = dict(st["hat"])
         hat["exact"] = True
         hat.pop("refine_stream", None)

@@ -529,8 +529,9 @@ def cast_f64_f32(src, dst, rows, cols):
     _lib.call("lc_cast_f64_f32", _p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, _s())
 
 
-def gather(src, ld_src, rows, n_rows, cols, n_cols, out):
-    _lib.call("lc_gather_f32", _p(src), ld_src, _p(rows), n_rows, _p(cols), n_cols, _p(out), out.stride(0), _s())
+def gather(src, ld_src, rows, n_rows, cols, n_cols, out, live=None):
+    """``live``: device int32 -- only the first ``*live`` columns (whole 256-column tiles) are touched (the refinement's panel)."""
+    _lib.call("lc_gather_f32", _p(src), ld_src, _p(rows), n_rows, _p(cols), n_cols, _p(out), out.stride(0), _p(live), _s())
     return out
 
 
@@ -944,11 +945,11 @@ def val_stats(y, V, va, M, n_val, ystat, yblk, yv):
     _lib.call("lc_val_stats", _p(y), y.stride(0), V, _p(va), M, n_val, _p(ystat), _p(yblk), _p(yv), _s())
 
 
-def val_stats_folds(y, V, va, F, M, n_vals, ystat, yblk, yv):
+def val_stats_folds(y, V, va, F, M, n_vals, ystat, yblk, yv, live=None):
     """All F inner folds of an outer fold in one launch: va (F, M), outputs (F, 3, V) / (F, M/32, V) / (F, M, V)."""
     import ctypes as ct
     nv = (ct.c_int32 * F)(*[int(n) for n in n_vals])
-    _lib.call("lc_val_stats_folds", _p(y), y.stride(0), V, _p(va), F, M, nv, _p(ystat), _p(yblk), _p(yv), _s())
+    _lib.call("lc_val_stats_folds", _p(y), y.stride(0), V, _p(va), F, M, nv, _p(ystat), _p(yblk), _p(yv), _p(live), _s())
 
 
 def alpha_sweep_scores(h, A, M, N, y, V, tr, yv, n_val, ystat, yblk, mode, part, scores, accumulate):
@@ -987,14 +988,14 @@ def mean_operator_image(mats, maps, scale, rows, K, tiled, rowscale_inv):
     _lib.call("lc_mean_operator_image_f16", m, ld, mp, n, float(scale), rows, K, _p(tiled), _p(rowscale_inv), _s())
 
 
-def col_scales_f16(y, T, V, want_flag=True, colflags=None):
+def col_scales_f16(y, T, V, want_flag=True, colflags=None, live=None):
     """(cs, flag): cs[:V] = 2^-e, cs[V:] = 2^e per column; flag (device int32) != 0 when some column's
     dynamic range is too wide for the fp16 hi/lo split (``want_flag=False``: the scales alone, one pass over y).
     ``colflags``: (V,) uint8 device vector that receives WHICH columns raised the flag."""
     cs = torch.empty(2 * V, dtype=torch.float32, device=y.device)
     flag = zeros(1, torch.int32, y.device) if want_flag else None
-    if colflags is not None:
-        _lib.call("lc_col_scales_f16_flags", _p(y), y.stride(0), T, V, _p(cs), _p(flag), _p(colflags), _s())
+    if colflags is not None or live is not None:
+        _lib.call("lc_col_scales_f16_flags", _p(y), y.stride(0), T, V, _p(cs), _p(flag), _p(colflags), _p(live), _s())
     else:
         _lib.call("lc_col_scales_f16", _p(y), y.stride(0), T, V, _p(cs), _p(flag), _s())
     return cs, flag
@@ -1022,8 +1023,8 @@ def gemv_cols(a, M, K, y, rows, ns, out, sel=None, want=0):
     return out
 
 
-def split_cols_f16(y, V, rows, K, cscale, tiled):
-    _lib.call("lc_split_cols_f16", _p(y), y.stride(0), V, _p(rows), K, _p(cscale), _p(tiled), _s())
+def split_cols_f16(y, V, rows, K, cscale, tiled, live=None):
+    _lib.call("lc_split_cols_f16", _p(y), y.stride(0), V, _p(rows), K, _p(cscale), _p(tiled), _p(live), _s())
 
 
 def permute_cols_f16(tiled, perm, Vs, K, out):
@@ -1122,20 +1123,20 @@ def series_sweep_scores_f16x3_folds(pt, rowscale_inv, M, n_vals, K, yt, cscale_i
               2 if accumulate == 2 else int(bool(accumulate)), b_rows, g0, gl, int(terms), _p(live), _s())
 
 
-def alpha_sweep_finalize_folds(part, ystat, yblk, A, M, n_vals, V, mode, scores, accumulate=False):
+def alpha_sweep_finalize_folds(part, ystat, yblk, A, M, n_vals, V, mode, scores, accumulate=False, live=None):
     """Scores of F folds whose fused contractions were launched with accumulate=2 (lc_alpha_sweep_finalize_folds)."""
     F = len(n_vals)
     nv = (ctypes.c_int32 * F)(*[int(n) for n in n_vals])
     _lib.call("lc_alpha_sweep_finalize_folds", _p(part), _p(ystat), _p(yblk), F, A, M, nv, V, mode, _p(scores),
-              int(bool(accumulate)), _s())
+              int(bool(accumulate)), _p(live), _s())
 
 
-def series_sweep_finalize_folds(part, ystat, yblk, M, n_vals, V, coef, aidx, scores, accumulate=False):
+def series_sweep_finalize_folds(part, ystat, yblk, M, n_vals, V, coef, aidx, scores, accumulate=False, live=None):
     """... and of the series-moments contractions (lc_series_sweep_finalize_folds)."""
     F = len(n_vals)
     nv = (ctypes.c_int32 * F)(*[int(n) for n in n_vals])
     _lib.call("lc_series_sweep_finalize_folds", _p(part), _p(ystat), _p(yblk), F, M, nv, V, _p(coef), _p(aidx), aidx.numel(),
-              _p(scores), int(bool(accumulate)), _s())
+              _p(scores), int(bool(accumulate)), _p(live), _s())
 
 
 def undecided_cols(scores, A, V, tau_sum, ystat, cap):
