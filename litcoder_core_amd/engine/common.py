@@ -130,6 +130,7 @@ class FitOptions:
     refine_on_side_stream: bool = True      # ... the undecided voxels' panel (a few column tiles: a quarter of the chip for ~1 ms
                                             # per step) and the alpha choice behind it on a stream of their own, beside the NEXT
                                             # step's full-width sweeps instead of in front of them (one GPU, no side panel)
+    refine_on_refit_stream: bool = True     # ... and that stream is the refit systems' (aux2), not one of its own (core.py)
     screen_series_tol: float = 1e-5         # ... and the LARGEST factorised alphas whose 4-term series is accurate to this (relative:
                                             # 1 / T_4(1 + 2 alpha^2); 2.5e-6 at alpha = 2.64, far below the screening arithmetic's
                                             # own ~2e-4) are screened from the shared series terms, not from their hat matrices:
@@ -146,10 +147,11 @@ class FitOptions:
                                             # scored on three MFMAs throughout (flat score curves -- pure-noise voxels on the
                                             # plateau of the large alphas, where neighbouring alphas agree to fp32 rounding --
                                             # cannot be decided by screening; scoring most voxels twice costs more than it saves)
-    screen_panel_first: float = 0.5         # ... share of a range the refinement's panel can hold (at least; twice the largest share
-                                            # of undecided voxels seen if that is more).  Generous since every pass over the panel
-                                            # reads the number of voxels it holds on the device: 1/16 until then, and two steps of
-                                            # a weak-signal fit overflowed before the host knew better (~8 ms each)
+    screen_panel_first: float = 0.5         # ... share of a range the refinement's panel can hold while no step of the fit has
+                                            # reported its undecided voxels (from then on: twice the largest share seen).  Generous,
+                                            # since every pass over the panel reads the number of voxels it holds on the device:
+                                            # 1/16 until then, and two steps of a weak-signal fit overflowed before the host knew
+                                            # better (~8 ms each)
     screen_second_panel_max: float = 0.6    # ... a panel that cannot hold a step's undecided voxels is followed by ONE that can (the
                                             # count is known by then) while they are at most this share of the range; beyond it
                                             # the range is scored again on three MFMAs (what every overflow cost before: ~15 ms
@@ -218,10 +220,26 @@ def _aux_stream(dev, which=0, priority=0):
     engine walks through torch's pool of 32 streams, and the FIRST cross-stream wait on a stream that has never run
     anything blocks the host for ~6 ms (its hardware queue is created there): every fit of a series paid that before
     its first fold was queued."""
+    which = _STREAM_ALIAS.get(which, which)
+    if which == "m":
+        return torch.cuda.default_stream(dev)
     key = (dev.type, dev.index, which)
     if key not in _AUX_STREAMS:
         _AUX_STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
     return _AUX_STREAMS[key]
+
+
+def _parse_stream_alias(text):
+    """LITCODER_AMD_STREAM_ALIAS="7=1,2=m": auxiliary stream 7 is stream 1, stream 2 the default stream (experiments with
+    which of the engine's streams share a queue: tools/stream_alias_ab.sh)."""
+    out = {}
+    for item in filter(None, (t.strip() for t in (text or "").split(","))):
+        a, b = item.split("=")
+        out[int(a)] = "m" if b.strip() == "m" else int(b)
+    return out
+
+
+_STREAM_ALIAS = _parse_stream_alias(os.environ.get("LITCODER_AMD_STREAM_ALIAS"))
 
 
 class _WideTargets(Exception):

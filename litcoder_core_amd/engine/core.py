@@ -161,7 +161,11 @@ class EngineCore:
         # sweeps' thousands (a HIGH-priority stream for it was measured: one spiked column then costs a cfg2 fit 12.6 %
         # instead of 5.1 % -- as with the fp64 chains, priorities only move the waiting around)
         self.side_stream = _aux_stream(self.dev, 6)
-        self.refine_stream = _aux_stream(self.dev, 7)   # the screening pass' undecided voxels + the alpha choice behind them (_after_screening)
+        # the screening pass' undecided voxels + the alpha choice behind them (_after_screening): beside the main stream's next
+        # sweeps, on the stream of the refit systems -- both feed the step's refit, and the panel's three-MFMA sweeps then do
+        # not run beside the refit's fp64 chains AND the main stream's sweeps at once (a stream of its own: resident cfg2 fit
+        # 83.8 -> 89.6 ms once every stream has its own hardware queue, tools/stream_alias_ab.sh)
+        self.refine_stream = self.aux2 if self.opt.refine_on_refit_stream else _aux_stream(self.dev, 7)
         # voxel shards: this rank's block is columns [lo[rank], lo[rank + 1]) of V_total; the statistics tail (BH-FDR
         # ranks ALL p-values) runs on the gathered vectors, on the device, on every rank; the driver sets alpha_fdr
         self.V_total = int(V_total) if V_total is not None else self.V_rank

@@ -503,9 +503,9 @@ class DualSweeps:
         self._refine_undecided(hat, Y, scores, ystat0, F, n_val_rows)
 
     def _refine_capacity(self, V):
-        """Columns of the refinement's panel for a voxel range of V columns: FitOptions.screen_panel_first of them (half), or
-        twice the largest share of undecided voxels a step of this fit has reported so far if that is more; whole 256-column
-        tiles."""
+        """Columns of the refinement's panel for a voxel range of V columns: FitOptions.screen_panel_first of them (half)
+        until a step of this fit has reported its share of undecided voxels, then twice the largest share reported so far;
+        whole 256-column tiles."""
         if self.opt.screen_panel_cols > 0:
             return int(min(ops.pad_to(self.opt.screen_panel_cols, 256), ops.pad_to(V, 256)))
         if self.shard.simulate:                          # (timing studies: the panel a real rank's ~1 % would get, _screen_check)
@@ -513,8 +513,14 @@ class DualSweeps:
         fracs = getattr(self, "_undecided_fracs", None)
         # (round 6, later: every pass over the panel costs what its voxels cost -- lc_gather_f32 / lc_col_scales_f16 /
         # lc_split_cols_f16 / lc_val_stats_folds / the sweeps all read the count on the device -- so the capacity is generous
-        # from the first step on: a panel that cannot hold a step's undecided voxels costs a second pass and a host round trip)
-        cap = max(int(self.opt.screen_panel_first * V), int(2.0 * max(fracs) * V) + 256 if fracs else 0, 2048)
+        # while no step has reported: a panel that cannot hold a step's undecided voxels costs a second pass and a host round
+        # trip.  Not free, though: the sweeps' launches cover the CAPACITY, and a workgroup that leaves at once still had to
+        # wait for a CU with 128 KB of LDS free -- 40 000 empty columns x 5 folds cost a cfg2 fit 1.5-2.5 ms
+        # (tools/panel_cap_queue_ab.sh) -- so from the first report on the capacity follows the shares seen)
+        if fracs:
+            cap = max(int(2.0 * max(fracs) * V) + 256, 2048)
+        else:
+            cap = max(int(self.opt.screen_panel_first * V), 2048)
         return int(min(ops.pad_to(max(cap, 256), 256), ops.pad_to(V, 256)))
 
     def _refine_undecided(self, hat, Y, scores, ystat0, F, n_val_rows, cap=None):

@@ -118,8 +118,10 @@ class FoldPhases:
             for g in groups:
                 X, K = self._fold_design(metas[g[0]]["tr"])                  # per-fold design only when len(g) == 1
                 split = False if self.moments else self._split_assumed()     # the targets' side belongs to the ranges
-                data_ready = torch.cuda.Event()
-                data_ready.record()
+                data_ready = None
+                if self.primal or X is not self.dX or os.environ.get("LITCODER_AMD_DATA_READY_EVENT") == "1":
+                    data_ready = torch.cuda.Event()
+                    data_ready.record()
                 # S[0]^2 of the inner train sets and of the whole outer-train block (refit penalty scale,
                 # independent of the alpha choice): precomputed for the whole fit, or one run for this fold
                 lmax_i, lmax_os = None, [None] * len(g)
