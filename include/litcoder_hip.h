@@ -535,6 +535,13 @@ int lc_split_rows_f16_groups(const float* d_h, int64_t ld, int groups, int64_t r
 int lc_mean_operator_image_f16(const float* const* h_mats, const int64_t* h_ld, const int32_t* const* h_maps, int n_folds,
                                float scale, int64_t rows, int64_t K, void* d_tiled, float* d_rowscale_inv,
                                lc_stream_t stream);
+/* The same for n_images alpha tuples in ONE launch.  d_table: DEVICE array of n_images x (n_folds + 1) int64 -- per image the
+ * n_folds device addresses of the folds' (rows, ld[f]) operators, then the slot of its image: image i is written at d_tiled +
+ * slot_i * pad256(rows) * K * 2 halves, its row scales at d_rowscale_inv + slot_i * pad256(rows).  h_ld / h_maps: as above
+ * (shared by all images).  Bit for bit what n_images calls of lc_mean_operator_image_f16 write. */
+int lc_mean_operator_images_f16(const int64_t* d_table, int n_images, const int64_t* h_ld, const int32_t* const* h_maps,
+                                int n_folds, float scale, int64_t rows, int64_t K, void* d_tiled, float* d_rowscale_inv,
+                                lc_stream_t stream);
 /* The A image of lc_alpha_sweep_scores_f16x3: per group (inner fold) the A hat matrices H_a (M x K each, stacked alpha by
  * alpha in d_h: rows a M + i), with the 32-row blocks taken in the order (validation block, alpha) -- image block s =
  * rows [32 (s / A), 32 (s / A) + 32) of alpha s %% A -- so that every 256-row tile of the sweep holds all alphas of the

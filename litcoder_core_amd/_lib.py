@@ -141,6 +141,8 @@ SIGNATURES = {
     "lc_split_rows_f16_groups": (c_int, [_ptr, c_int64, c_int, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_mean_operator_image_f16": (c_int, [POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), c_int, c_float, c_int64,
                                            c_int64, _ptr, _ptr, _ptr]),
+    "lc_mean_operator_images_f16": (c_int, [_ptr, c_int, POINTER(c_int64), POINTER(c_void_p), c_int, c_float, c_int64, c_int64,
+                                            _ptr, _ptr, _ptr]),
     "lc_split_rows_f16_alphas": (c_int, [_ptr, c_int64, c_int, c_int, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_split_rows_f16_alphas_sel": (c_int, [_ptr, c_int64, c_int, c_int, c_int, c_int64, c_int64, _ptr, _ptr, _ptr]),
     "lc_col_scales_f16": (c_int, [_ptr, c_int64, c_int64, c_int64, _ptr, _ptr, _ptr]),

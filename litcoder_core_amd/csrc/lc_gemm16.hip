@@ -94,8 +94,35 @@ extern "C" int lc_mean_operator_image_f16(const float* const* h_mats, const int6
     const long long rows_pad = lc::ceil_div<long long>(rows, TM) * TM;
     LC_REQUIRE(rows_pad < (1ll << 31), LC_E_SHAPE, "lc_mean_operator_image_f16: too many rows");
     lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
-    hipLaunchKernelGGL(k_mean_operator_image, dim3((unsigned)(rows_pad / 4)), dim3(256), 0, lc::as_stream(stream), a, (int)rows,
-                       (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad);
+    hipLaunchKernelGGL(k_mean_operator_image<false>, dim3((unsigned)(rows_pad / 4)), dim3(256), 0, lc::as_stream(stream), a,
+                       (const long long*)nullptr, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv, (int)rows_pad);
+    return lc::launched("k_mean_operator_image");
+}
+
+extern "C" int lc_mean_operator_images_f16(const int64_t* d_table, int n_images, const int64_t* h_ld,
+                                           const int32_t* const* h_maps, int n_folds, float scale, int64_t rows, int64_t K,
+                                           void* d_tiled, float* d_rowscale_inv, lc_stream_t stream) {
+    LC_REQUIRE(d_table && h_ld && h_maps && d_tiled && d_rowscale_inv, LC_E_BADARG, "lc_mean_operator_images_f16: null pointer");
+    LC_REQUIRE(n_folds >= 1 && n_folds <= MO_MAX_FOLDS, LC_E_SHAPE, "lc_mean_operator_images_f16: 1..%d folds", MO_MAX_FOLDS);
+    LC_REQUIRE(n_images >= 0 && n_images <= 65535, LC_E_SHAPE, "lc_mean_operator_images_f16: 0..65535 images per launch");
+    LC_REQUIRE(rows > 0 && K > 0 && K % TK == 0 && K <= 512 * MO_UNITS, LC_E_SHAPE,
+               "lc_mean_operator_images_f16: need K %% %d == 0 and K <= %d", TK, 512 * MO_UNITS);
+    if (n_images == 0) return LC_OK;
+    MeanOpArgs a{};
+    for (int f = 0; f < n_folds; ++f) {
+        LC_REQUIRE(h_maps[f] && (reinterpret_cast<uintptr_t>(h_maps[f]) & 15) == 0, LC_E_BADARG,
+                   "lc_mean_operator_images_f16: null or misaligned map");
+        a.ld[f] = (long long)h_ld[f];
+        a.map[f] = h_maps[f];
+    }
+    a.nf = n_folds;
+    a.scale = scale;
+    const long long rows_pad = lc::ceil_div<long long>(rows, TM) * TM;
+    LC_REQUIRE(rows_pad < (1ll << 31), LC_E_SHAPE, "lc_mean_operator_images_f16: too many rows");
+    lc::ScopedTimer timer_(lc::T_SPLIT16, lc::as_stream(stream));
+    hipLaunchKernelGGL(k_mean_operator_image<true>, dim3((unsigned)(rows_pad / 4), (unsigned)n_images), dim3(256), 0,
+                       lc::as_stream(stream), a, (const long long*)d_table, (int)rows, (int)K, (uint4*)d_tiled, d_rowscale_inv,
+                       (int)rows_pad);
     return lc::launched("k_mean_operator_image");
 }
 

@@ -113,11 +113,22 @@ struct MeanOpArgs {
     int nf;
     float scale;
 };
-__global__ void __launch_bounds__(256) k_mean_operator_image(const MeanOpArgs a, int rows, int K, uint4* __restrict__ out,
-                                                             float* __restrict__ rs_inv, int rows_pad) {
+// BATCH: the images of several alpha tuples in one launch (one launch per tuple was ~45 us of host time each: 1.8 ms at the
+// tail of a cfg2 fit, with the chip idle) -- blockIdx.y = entry of ``table``: n_folds device pointers (the folds'
+// operators for this tuple; ld / map / scale from ``a``) and the slot of the tuple's image in ``out`` / ``rs_inv``.
+template <bool BATCH>
+__global__ void __launch_bounds__(256) k_mean_operator_image(const MeanOpArgs a, const long long* __restrict__ table, int rows,
+                                                             int K, uint4* __restrict__ out, float* __restrict__ rs_inv,
+                                                             int rows_pad) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= rows_pad) return;
+    const long long* ent = BATCH ? table + (long long)blockIdx.y * (a.nf + 1) : nullptr;
+    if (BATCH) {
+        const long long slot = ent[a.nf];
+        out += slot * ((long long)rows_pad * K / 4);          // (rows_pad x K x 2 halves per image, 8 halves per uint4)
+        rs_inv += slot * rows_pad;
+    }
     const int KT = K / TK, units = K / 8;
     const bool live = r < rows;
     float x[MO_UNITS][8];
@@ -131,7 +142,7 @@ __global__ void __launch_bounds__(256) k_mean_operator_image(const MeanOpArgs a,
         for (int f = 0; f < a.nf; ++f) {
             const int4 m0 = *reinterpret_cast<const int4*>(a.map[f] + c * 8);
             const int4 m1 = *reinterpret_cast<const int4*>(a.map[f] + c * 8 + 4);
-            const float* src = a.m[f] + (long long)r * a.ld[f];
+            const float* src = (BATCH ? reinterpret_cast<const float*>(ent[f]) : a.m[f]) + (long long)r * a.ld[f];
             const int mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
             if (m0.x >= 0 && m1.w == m0.x + 7 && (m0.x & 3) == 0 && (a.ld[f] & 3) == 0) {       // an aligned run of 8 columns
                 const float4 v0 = *reinterpret_cast<const float4*>(src + m0.x);

@@ -55,6 +55,11 @@ class MeanOperatorRefit:
         if st.get("best_h") is None or not st["split"]:
             raise RuntimeError("mean-operator refit: a step without host alpha indices / on the f32 path in a fit set up for it")
         ent["best"][rg.c0:rg.c0 + rg.V] = st["best_h"][: rg.V]
+        # (the alphas the step's voxels chose, from its histogram: the tuple keys' digits without a pass over the indices)
+        if st.get("used") and ent.get("used") is not False:
+            ent.setdefault("used", set()).update(int(a) for a in st["used"])
+        else:
+            ent["used"] = False
         ent["images"][rg.key] = st["hat"].get("image")
         if side_job is not None:                       # the step's exact-f32 weights of the side panel's columns (_side_refit_begin)
             ent["side"].append((side_job, rg.c0))
@@ -139,41 +144,53 @@ class MeanOperatorRefit:
                 t.record_stream(main)
 
     @staticmethod
-    def _alpha_tuples(best, A):
+    def _alpha_tuples(best, A, used=None):
         """The voxels of a range grouped by the alpha TUPLE they chose over the folds.  ``best``: per fold an integer vector of
         alpha indices (0 <= index < A), all of the same length V.  Returns (order (V,) -- the voxels tuple after tuple, tuples in
         ascending order of their mixed-radix key (digit f = rank of the alpha among those fold f uses, fold 0 least significant),
         voxels ascending inside a tuple --, counts per tuple, the tuples as alpha-index tuples), or None when the key space
         overflows 62 bits.  Host side, numpy: a radix sort of 16-bit keys for the usual few alphas per fold."""
-        V = len(best[0])
-        key = np.zeros(V, dtype=np.int64)
-        stride, used = 1, []
-        for b in best:
-            b = np.asarray(b, dtype=np.int64)
-            u = np.nonzero(np.bincount(b, minlength=A))[0]
-            table = np.zeros(A, dtype=np.int64)
-            table[u] = np.arange(len(u))
-            if stride * max(len(u), 1) > (1 << 62):
+        best = [np.asarray(b) for b in best]
+        # ``used``: per fold the alphas that occur (or a superset: digits nobody has leave empty keys), sorted -- known from the
+        # folds' histograms; else counted here (0.2 ms per fold at cfg2, on the fit's critical path)
+        given = used is not None
+        used = ([np.asarray(sorted(u), dtype=np.int64) for u in used] if given
+                else [np.nonzero(np.bincount(b, minlength=A))[0] for b in best])
+        radix = [max(len(u), 1) for u in used]
+        if given and int(np.prod([float(r) for r in radix])) > 65535:
+            return MeanOperatorRefit._alpha_tuples(best, A)       # (a superset may cost the 16-bit keys: count, then)
+        stride = 1
+        for r in radix:
+            if stride * r > (1 << 62):
                 return None
-            key += table[b] * stride
-            used.append(u)
-            stride *= max(len(u), 1)
+            stride *= r
+        # (the host forms the tuples at the fit's tail, with nothing left to overlap them: one table look-up and one add per
+        # fold, in the narrowest key type -- 0.6 ms at cfg2 where the straightforward int64 version took 1.7)
+        kt = np.uint32 if stride <= 65535 else np.int64
+        key, st = None, 1
+        for b, u, r in zip(best, used, radix):
+            # (alphas that a GIVEN list does not name: a bit above every key -- caught below, never grouped silently)
+            table = np.full(A, (1 << 30) if given else 0, dtype=kt)
+            table[u] = (np.arange(len(u), dtype=np.int64) * st).astype(kt)          # digit x stride, per alpha
+            key = table[b] if key is None else key + table[b]
+            st *= r
+        if given and len(key) and int(key.max()) >= (1 << 30):
+            raise RuntimeError("mean-operator refit: a voxel chose an alpha its fold's histogram does not list")
         if stride <= 65535:
-            k16 = key.astype(np.uint16)
-            order = np.argsort(k16, kind="stable")         # (numpy radix-sorts 16-bit keys)
-            counts = np.bincount(k16, minlength=stride)
+            key = key.astype(np.uint16)
+            order = np.argsort(key, kind="stable")           # (numpy radix-sorts 16-bit keys)
+            counts = np.bincount(key, minlength=stride)
             live = np.nonzero(counts)[0]
             cnt = counts[live]
         else:
             order = np.argsort(key, kind="stable")
             live, cnt = np.unique(key, return_counts=True)
-        tuples = []
-        for kq in live:
-            q, tup = int(kq), []
-            for u in used:
-                tup.append(int(u[q % len(u)]))
-                q //= len(u)
-            tuples.append(tuple(tup))
+        q = np.asarray(live, dtype=np.int64)
+        cols = []
+        for u, r in zip(used, radix):
+            cols.append(u[q % r] if len(u) else np.zeros(len(q), dtype=np.int64))
+            q = q // r
+        tuples = [tuple(row) for row in np.stack(cols, axis=1).tolist()] if len(live) else []
         return order, np.asarray(cnt, dtype=np.int64), tuples
 
     @staticmethod
@@ -185,9 +202,9 @@ class MeanOperatorRefit:
         start = np.concatenate([[0], np.cumsum(tiles_g)]).astype(np.int64)
         perm = np.full(int(start[-1]) * 256, -1, dtype=np.int32)
         if len(order):
-            gi = np.repeat(np.arange(len(cnt)), cnt)
             first = np.concatenate([[0], np.cumsum(cnt)])[:-1]
-            perm[start[gi] * 256 + (np.arange(len(order)) - first[gi])] = np.asarray(order, dtype=np.int32)
+            # (position of voxel i of the sorted list: i + what the groups before its own were padded by)
+            perm[np.arange(len(order)) + np.repeat(start[:-1] * 256 - first, cnt)] = np.asarray(order, dtype=np.int32)
         return perm, start
 
     def _mean_operator_weights(self, rg):
@@ -214,7 +231,8 @@ class MeanOperatorRefit:
         n_o = [len(e["tr"]) for e in ents]
         scales = {e["scale"] for e in ents}
         pays = None
-        grouped = self._alpha_tuples(best, A) if len(scales) == 1 else None
+        known = [e.get("used") for e in ents]
+        grouped = (self._alpha_tuples(best, A, used=known if all(known) else None)) if len(scales) == 1 else None
         if grouped is not None:
             order, cnt, tuples = grouped
             # which tuples pay.  Costs in (column tile x depth row) units of the grouped contraction (3.7 ns at cfg2); one
@@ -258,7 +276,7 @@ class MeanOperatorRefit:
             At = torch.empty(G * rows_pad * Kd * 2, dtype=torch.float16, device=self.dev)
             rs_inv = torch.empty(G * rows_pad, dtype=torch.float32, device=self.dev)
             maps = [self._mo_map(f, e["tr"], Kd) for f, e in zip(folds, ents)]
-            new_imgs = 0
+            new_mats, new_slots = [], []
             for g, gq in enumerate(sel_groups):
                 tup = tuples[gq]
                 a_g, r_g = At[g * rows_pad * Kd * 2:(g + 1) * rows_pad * Kd * 2], rs_inv[g * rows_pad:(g + 1) * rows_pad]
@@ -267,9 +285,12 @@ class MeanOperatorRefit:
                     a_g.copy_(hit[0])
                     r_g.copy_(hit[1])
                     continue
-                ops.mean_operator_image([e["M"][a][:rows] for e, a in zip(ents, tup)], maps, ents[0]["scale"], rows, Kd, a_g, r_g)
+                new_mats.append([e["M"][a][:rows] for e, a in zip(ents, tup)])
+                new_slots.append(g)
                 mo["images"][tup] = (a_g, r_g)
-                new_imgs += 1
+            # (all new images in one launch: one per tuple was ~45 us of host time each, 1.8 ms at the tail of a cfg2 fit)
+            ops.mean_operator_images(new_mats, new_slots, maps, ents[0]["scale"], rows, Kd, At, rs_inv)
+            new_imgs = len(new_slots)
             C = torch.empty((rows, Vs), dtype=torch.float32, device=self.dev)
             ops.gemm_grouped_f16x3(At, rs_inv, rows, Yt, cs_s[1], C, Vs, Vs, Kd, [int(t) for t in start])
             n_comb = int(sel_sorted.sum())

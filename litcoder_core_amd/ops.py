@@ -988,6 +988,31 @@ def mean_operator_image(mats, maps, scale, rows, K, tiled, rowscale_inv):
     _lib.call("lc_mean_operator_image_f16", m, ld, mp, n, float(scale), rows, K, _p(tiled), _p(rowscale_inv), _s())
 
 
+def mean_operator_images(mats_per_image, slots, maps, scale, rows, K, tiled, rowscale_inv):
+    """The images of several alpha tuples in one launch (lc_mean_operator_images_f16): ``mats_per_image[i]`` = the folds'
+    operators of image i (all folds' operators of one fold share their row stride), written at slot ``slots[i]`` of ``tiled`` /
+    ``rowscale_inv`` (pad256(rows) * K * 2 halves / pad256(rows) floats per slot).  Bit for bit what mean_operator_image
+    writes, image by image."""
+    n_img = len(mats_per_image)
+    if n_img == 0:
+        return
+    n = len(maps)
+    ld = [int(x.stride(0)) for x in mats_per_image[0]]
+    table = np.empty((n_img, n + 1), dtype=np.int64)
+    for i, (mats, slot) in enumerate(zip(mats_per_image, slots)):
+        if len(mats) != n or any(int(x.stride(0)) != l for x, l in zip(mats, ld)):
+            raise ValueError("mean_operator_images: every image takes one operator per fold, with the fold's row stride")
+        table[i, :n] = [x.data_ptr() for x in mats]
+        table[i, n] = int(slot)
+    d_table = upload(table, tiled.device)
+    c_ld = (ctypes.c_int64 * n)(*ld)
+    mp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in maps])
+    for i0 in range(0, n_img, 65535):
+        k = min(65535, n_img - i0)
+        _lib.call("lc_mean_operator_images_f16", ctypes.c_void_p(d_table.data_ptr() + i0 * (n + 1) * 8), k, c_ld, mp, n,
+                  float(scale), rows, K, _p(tiled), _p(rowscale_inv), _s())
+
+
 def col_scales_f16(y, T, V, want_flag=True, colflags=None, live=None):
     """(cs, flag): cs[:V] = 2^-e, cs[V:] = 2^e per column; flag (device int32) != 0 when some column's
     dynamic range is too wide for the fp16 hi/lo split (``want_flag=False``: the scales alone, one pass over y).

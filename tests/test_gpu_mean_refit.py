@@ -75,6 +75,21 @@ def test_mean_operator_image_against_numpy(lc):
         ops.split_rows_f16(torch.from_numpy(ref).to(dev), rows, K, img2, rs2)
         assert torch.equal(rs[:rows], rs2[:rows])
         assert torch.equal(img, img2)
+        # several images in one launch (lc_mean_operator_images_f16): bit for bit the single launches', at the slots asked for
+        alt = [[m[:rows] for m in mats], [(m * 0.5)[:rows] for m in mats], [torch.flip(m, dims=(0,))[:rows].contiguous() for m in mats]]
+        singles = []
+        for ms in alt:
+            i1, r1 = torch.empty_like(img), torch.empty_like(rs)
+            ops.mean_operator_image(ms, maps, float(scale), rows, K, i1, r1)
+            singles.append((i1, r1))
+        slots = [2, 0, 3]
+        imgs = torch.zeros(4 * rows_pad * K * 2, dtype=torch.float16, device=dev)
+        rss = torch.zeros(4 * rows_pad, dtype=torch.float32, device=dev)
+        ops.mean_operator_images(alt, slots, maps, float(scale), rows, K, imgs, rss)
+        for (i1, r1), sl in zip(singles, slots):
+            assert torch.equal(imgs[sl * rows_pad * K * 2:(sl + 1) * rows_pad * K * 2], i1)
+            assert torch.equal(rss[sl * rows_pad:sl * rows_pad + rows], r1[:rows])
+        assert not imgs[rows_pad * K * 2:2 * rows_pad * K * 2].any()          # (slot 1: nobody's)
 
 
 @pytest.mark.parametrize("case", ["kfold", "chunked_norm_x", "single_alpha", "single_alpha_panels", "panels", "own_choice"])

@@ -368,6 +368,17 @@ def test_mean_operator_tuple_grouping_and_column_layout():
         for g, c in enumerate(cnt):
             blk = perm[int(start[g]) * 256:int(start[g + 1]) * 256]
             assert blk[:c].tolist() == want[tuples[g]] and (blk[c:] == -1).all()
+        # the folds' alphas handed in (from their histograms): exactly those that occur, or a superset -- the same grouping;
+        # a list that misses an alpha somebody chose is an error, never a silent regrouping
+        for extra in (0, 1):
+            known = [set(u.tolist()) | ({int(rng.integers(0, A))} if extra else set()) for u in used]
+            o2, c2, t2 = MO._alpha_tuples(best, A, used=known)
+            assert np.array_equal(o2, order) and np.array_equal(c2, cnt) and t2 == tuples
+        if V > 1 and len(used[0]) > 1 and np.prod([len(u) for u in used], dtype=np.float64) <= 65535:
+            short = [set(u.tolist()) for u in used]
+            short[0].discard(int(best[0][0]))
+            with pytest.raises(RuntimeError):
+                MO._alpha_tuples(best, A, used=short)
     # more key space than 16 bits: the sort-based path, same contract
     best = [rng.integers(0, 30, 400).astype(np.int64) for _ in range(5)]
     order, cnt, tuples = MO._alpha_tuples(best, 30)
