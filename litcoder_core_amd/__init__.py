@@ -13,16 +13,6 @@ All numerical work on the fit path is done by hand-written gfx950 HIP kernels in
 ``csrc/`` reached through the C ABI of ``include/litcoder_hip.h``; importing this package
 does not need a GPU, calling it does (there is no CPU fallback).
 """
-import os as _os
-
-# The HIP runtime gives a process four hardware queues unless told otherwise and deals its streams out over them: the engine
-# runs up to nine streams beside the upload's (hat-matrix chains, refit systems, column scales of arriving panels, weight
-# download, ...), so two of them share a queue and a small kernel on one waits for everything queued on its partner --
-# which pairs share depends on the order the streams were first used in.  Eight queues: every busy stream has its own
-# (host-to-host cfg2 fit 97.5 -> 95.4 ms, tools/hwq_ab.sh, tools/stream_alias_ab.sh).  The runtime reads the variable when
-# it initialises (the first HIP call of the process), so it is set here, at import, unless the caller has chosen a value.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 from .downsample import Downsampler
 from .fir import FIR
 from .folding import create_folds

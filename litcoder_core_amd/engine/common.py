@@ -130,7 +130,11 @@ class FitOptions:
     refine_on_side_stream: bool = True      # ... the undecided voxels' panel (a few column tiles: a quarter of the chip for ~1 ms
                                             # per step) and the alpha choice behind it on a stream of their own, beside the NEXT
                                             # step's full-width sweeps instead of in front of them (one GPU, no side panel)
-    refine_on_refit_stream: bool = True     # ... and that stream is the refit systems' (aux2), not one of its own (core.py)
+    refine_on_refit_stream: bool = False    # ... that stream = the refit systems' (aux2) instead of one of its own: level on cfg2,
+                                            # 8-12 % slower on cfg4 / cfg5 (the choice waits behind heavier refit chains)
+    results_on_refit_stream: bool = False   # one GPU: a fold's result unpack / BH-FDR / host copies on aux2 instead of the
+                                            # communication stream (experiments with the runtime's hardware queues:
+                                            # profiles/experiments/README.md, round 6; slower at cfg4's and cfg5's shapes)
     screen_series_tol: float = 1e-5         # ... and the LARGEST factorised alphas whose 4-term series is accurate to this (relative:
                                             # 1 / T_4(1 + 2 alpha^2); 2.5e-6 at alpha = 2.64, far below the screening arithmetic's
                                             # own ~2e-4) are screened from the shared series terms, not from their hat matrices:
@@ -148,10 +152,12 @@ class FitOptions:
                                             # plateau of the large alphas, where neighbouring alphas agree to fp32 rounding --
                                             # cannot be decided by screening; scoring most voxels twice costs more than it saves)
     screen_panel_first: float = 0.5         # ... share of a range the refinement's panel can hold while no step of the fit has
-                                            # reported its undecided voxels (from then on: twice the largest share seen).  Generous,
+                                            # reported its undecided voxels (from then on: screen_panel_margin).  Generous,
                                             # since every pass over the panel reads the number of voxels it holds on the device:
                                             # 1/16 until then, and two steps of a weak-signal fit overflowed before the host knew
                                             # better (~8 ms each)
+    screen_panel_margin: float = 1.25       # ... from the first report on: the largest share seen x this + 1024 columns (0: the first
+                                            # rule throughout)
     screen_second_panel_max: float = 0.6    # ... a panel that cannot hold a step's undecided voxels is followed by ONE that can (the
                                             # count is known by then) while they are at most this share of the range; beyond it
                                             # the range is scored again on three MFMAs (what every overflow cost before: ~15 ms

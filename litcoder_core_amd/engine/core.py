@@ -153,7 +153,9 @@ class EngineCore:
                                                    for a in ser_scr]).astype(np.float64), self.dev)
         self.aux = _aux_stream(self.dev)
         self.aux2 = _aux_stream(self.dev, 1)            # refit systems (see _refit_stream)
-        self.comm = _aux_stream(self.dev, 2)            # per-fold result exchange + global statistics
+        # per-fold result exchange + global statistics (FitOptions.results_on_refit_stream: an experiment, see there)
+        self.comm = (_aux_stream(self.dev, 2) if (self.shard.world > 1 or not self.opt.results_on_refit_stream)
+                     else self.aux2)
         self.aux3 = _aux_stream(self.dev, 3)            # voxel shards: what a fold's refit still needs after refit_ahead
         self.dl = _aux_stream(self.dev, 4)              # finished weight panels on their way to the host
         self.scales_stream = _aux_stream(self.dev, 5)   # column scales of target panels as they arrive (_target_scales)
@@ -162,9 +164,8 @@ class EngineCore:
         # instead of 5.1 % -- as with the fp64 chains, priorities only move the waiting around)
         self.side_stream = _aux_stream(self.dev, 6)
         # the screening pass' undecided voxels + the alpha choice behind them (_after_screening): beside the main stream's next
-        # sweeps, on the stream of the refit systems -- both feed the step's refit, and the panel's three-MFMA sweeps then do
-        # not run beside the refit's fp64 chains AND the main stream's sweeps at once (a stream of its own: resident cfg2 fit
-        # 83.8 -> 89.6 ms once every stream has its own hardware queue, tools/stream_alias_ab.sh)
+        # sweeps, on a stream of their own (on the refit systems' stream the choice waits behind the refit's fp64 chains:
+        # level on cfg2, 8-12 % slower at cfg4's and cfg5's shapes)
         self.refine_stream = self.aux2 if self.opt.refine_on_refit_stream else _aux_stream(self.dev, 7)
         # voxel shards: this rank's block is columns [lo[rank], lo[rank + 1]) of V_total; the statistics tail (BH-FDR
         # ranks ALL p-values) runs on the gathered vectors, on the device, on every rank; the driver sets alpha_fdr

@@ -504,8 +504,8 @@ class DualSweeps:
 
     def _refine_capacity(self, V):
         """Columns of the refinement's panel for a voxel range of V columns: FitOptions.screen_panel_first of them (half)
-        until a step of this fit has reported its share of undecided voxels, then twice the largest share reported so far;
-        whole 256-column tiles."""
+        until a step of this fit has reported its share of undecided voxels, then the largest share reported so far x
+        FitOptions.screen_panel_margin + 1024 columns; whole 256-column tiles."""
         if self.opt.screen_panel_cols > 0:
             return int(min(ops.pad_to(self.opt.screen_panel_cols, 256), ops.pad_to(V, 256)))
         if self.shard.simulate:                          # (timing studies: the panel a real rank's ~1 % would get, _screen_check)
@@ -516,9 +516,12 @@ class DualSweeps:
         # while no step has reported: a panel that cannot hold a step's undecided voxels costs a second pass and a host round
         # trip.  Not free, though: the sweeps' launches cover the CAPACITY, and a workgroup that leaves at once still had to
         # wait for a CU with 128 KB of LDS free -- 40 000 empty columns x 5 folds cost a cfg2 fit 1.5-2.5 ms
-        # (tools/panel_cap_queue_ab.sh) -- so from the first report on the capacity follows the shares seen)
-        if fracs:
-            cap = max(int(2.0 * max(fracs) * V) + 256, 2048)
+        # (tools/panel_cap_queue_ab.sh) -- so from the first report on the capacity follows the shares seen: the largest x
+        # FitOptions.screen_panel_margin + 1024 columns.  Measured on one box, margin 1.25 / 2 / capacity V/2 throughout: cfg2
+        # resident 80.7 / 80.9 / 82.3 ms, cfg5's shape 162 / 163 / 168, half the voxels pure noise 134 / 143 / 136, a tenth of
+        # the signal 172 / 175 / 177; a step beyond the margin costs a second panel, _screen_check)
+        if fracs and self.opt.screen_panel_margin > 0:
+            cap = max(int(self.opt.screen_panel_margin * max(fracs) * V) + 1024, 2048)
         else:
             cap = max(int(self.opt.screen_panel_first * V), 2048)
         return int(min(ops.pad_to(max(cap, 256), 256), ops.pad_to(V, 256)))
