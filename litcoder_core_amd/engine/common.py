@@ -88,10 +88,13 @@ class FitOptions:
                                             # shards keep the folds' own products: an operator image per alpha tuple costs what
                                             # ~3 column tiles do, and a rank of 10 000 voxels has no tuple that pays)
     mean_operator_max_tuples: int = 256     # ... and while a voxel range has at most this many distinct alpha tuples
-    mean_operator_min_share: float = 0.8    # ... and, judged from the first two folds' choices, at least this share of the voxels is
+    mean_operator_min_share: float = 0.25   # ... and, judged from the first two folds' choices, at least this share of the voxels is
                                             # expected in tuples that pay (weak-signal data: every fold another alpha -- the folds'
                                             # own products then stay where they were, beside the next fold's sweeps; deferring them
-                                            # to the range's end cost 2-7 % of such a fit)
+                                            # to the range's end cost 2-7 % of such a fit).  The estimate is pessimistic -- measured
+                                            # expected / actual share and fit with / without: cfg5's shape 0.76 / 0.83, 154 / 166 ms;
+                                            # half the voxels pure noise 0.32 / 0.55, 133.3 / 135.1; a tenth of the signal 0.13 /
+                                            # 0.06, 178.7 / 174.0 (0.8 until the round's last day: cfg5's shape lost 7 % to it)
     mean_operator_cost_ratio: float = 0.85  # ... and the grouped contraction + the operator images it needs are estimated at
                                             # no more than this share of the folds' own products (tests force the path: 1e9)
     panel_cols: int = 36864                 # voxel columns per panel of a host-to-host fit (_column_panels): 12 288 / 24 576 /

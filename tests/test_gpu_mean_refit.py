@@ -241,7 +241,7 @@ def test_mean_operator_is_dropped_when_the_first_two_folds_say_so(lc, layout):
     m1 = NestedCVModel("ridge_regression", precision="f16x3", options=FitOptions(mean_operator_min_cols=0), **mkw)
     out1 = m1.fit_predict(X, Y, **kw)
     mo = m1.last_fit["mean_operator"]
-    assert not mo["on"] and mo["expected_share"] < 0.5 and mo["ranges"] == 0, mo
+    assert not mo["on"] and mo["expected_share"] < FitOptions().mean_operator_min_share and mo["ranges"] == 0, mo
     np.testing.assert_array_equal(out1[2], out0[2])
     np.testing.assert_array_equal(np.asarray(out1[1]), np.asarray(out0[1]))
     np.testing.assert_array_equal(np.asarray(out1[0]["correlations"]), np.asarray(out0[0]["correlations"]))

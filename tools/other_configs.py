@@ -73,7 +73,9 @@ for name, args, alphas in (
     t = time.perf_counter(); m, W, a = fit(); torch.cuda.synchronize(); dt = time.perf_counter() - t
     name += f" [{model.last_form} form]"
     ok = bool(np.isfinite(np.asarray(m["correlations"])).all() and torch.isfinite(W).all() and np.isfinite(a).all())
-    print(f"{name}: resident {1e3 * dt:.0f} ms = {V / dt:.0f} voxels/s, median score {m['median_score']:.4f}, all finite: {ok}",
+    print(f"{name}: resident {1e3 * dt:.0f} ms = {V / dt:.0f} voxels/s, median score {m['median_score']:.4f}, all finite: {ok}; "
+          f"mean-operator refit {model.last_fit.get('mean_operator')}; screening undecided {model.last_fit.get('undecided')} of "
+          f"{model.last_fit.get('screened')}",
           flush=True)
     # ---- host to host: the reference's call
     r_res = np.asarray(m["correlations"])
