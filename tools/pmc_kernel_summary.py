@@ -2,7 +2,8 @@
 """Per-kernel summary of rocprofv3 --kernel-trace --pmc passes (counters only): launches, mean duration, the clock the chip
 held under the kernel (GRBM_GUI_ACTIVE / 8 XCDs / duration), the matrix pipe's busy share (SQ_VALU_MFMA_BUSY_CYCLES /
 (1024 SIMDs x cycles)) and the bytes leaving L2 per launch (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes; gfx950 corrections of
-/opt/skills/guides/MI355X_MICROARCH.md).  Launches of the LARGEST grid only (the full-width ones).
+/opt/skills/guides/MI355X_MICROARCH.md).  Launches of the (instantiation, grid size) that holds most of the kernel's time only:
+the fit's full-width ones.
 
     python tools/pmc_kernel_summary.py <dir> [<dir> ...] -- <kernel substring> [<kernel substring> ...]
 """
@@ -27,7 +28,16 @@ def main():
         if not sel:
             out[needle] = None
             continue
-        full = max(int(r["Grid_Size"]) for _, r in sel)
+        # the (instantiation, grid) group that holds most of the kernel's time: the full-width launches of the fit.  (Until the
+        # round's last refresh: the largest grid -- which became the undecided voxels' first panel of a fit, five inner folds
+        # in one launch over a capacity of V / 2 columns, nearly all of its workgroups leaving at once.)
+        weight = {}
+        for root, r in sel:
+            if r["Counter_Name"] == sel[0][1]["Counter_Name"]:
+                key = (r["Kernel_Name"], int(r["Grid_Size"]))
+                weight[key] = weight.get(key, 0.0) + float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        kname, full = max(weight, key=weight.get)
+        sel = [(root, r) for root, r in sel if r["Kernel_Name"] == kname]
         disp = {}
         for root, r in sel:
             if int(r["Grid_Size"]) != full:
