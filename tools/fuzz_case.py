@@ -109,3 +109,10 @@ for name, Wx in (("ours", W), ("oracle", W_o)):
     bad = np.abs(Wx - Wt) > tol
     print(f"{name}: {int(bad[:, same].sum())} elements beyond the test's tolerance of the float64 truth (voxels with the oracle's alphas)")
 print(f"alphas equal for {same.mean():.3f} of the voxels")
+if same.any():
+    eo, er = np.abs(W - Wt)[:, same], np.abs(W_o - Wt)[:, same]
+    print(f"voxels with the oracle's alphas: ours - truth max {eo.max():.3g} (rms {np.sqrt((eo ** 2).mean()):.3g}), "
+          f"oracle - truth max {er.max():.3g} (rms {np.sqrt((er ** 2).mean()):.3g}); max|W_true| {scale:.3g}")
+co, cr = np.asarray(m["correlations"], dtype=np.float64), np.asarray(m_o["correlations"], dtype=np.float64)
+print(f"correlations: ours - oracle max {np.nanmax(np.abs(co - cr)):.3g} over all voxels, "
+      f"{np.nanmax(np.abs(co - cr)[same]) if same.any() else float('nan'):.3g} over those with the oracle's alphas")

@@ -28,7 +28,35 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 large = len(sys.argv) > 3 and sys.argv[3] == "large"
 tall = len(sys.argv) > 3 and sys.argv[3] == "tall"
 rng = np.random.default_rng(seed)
-fails = skipped = 0
+fails = skipped = voids = 0
+
+
+def referee(X, Y, kw, detail, W, W_o):
+    """(the oracle misses the float64 result beyond the weight tolerance and ours are no further from it, our miss, the
+    oracle's -- both relative to max|W|): the reference's arithmetic in float64 at the oracle's alphas, over the voxels
+    whose alphas agree (tools/fuzz_case.py)."""
+    p, V = X.shape[1], Y.shape[1]
+    X32, Y32 = X.astype(np.float32).astype(np.float64), Y.astype(np.float32).astype(np.float64)
+    Wt = np.zeros((p, V))
+    for f, (tr, _te) in enumerate(detail["outer"]):
+        tr = np.asarray(tr)
+        Xtr, Ytr = X32[tr], Y32[tr]
+        if kw["normalize_features"]:
+            Xtr = (Xtr - Xtr.mean(0)) / (Xtr.std(0, ddof=1) + 1e-8)
+        if kw["normalize_targets"]:
+            Ytr = (Ytr - Ytr.mean(0)) / (Ytr.std(0, ddof=1) + 1e-8)
+        U, S, Vh = np.linalg.svd(Xtr, full_matrices=False)
+        al = np.asarray(detail["fold_alphas"][f], dtype=np.float64)
+        na = al * S[0] if kw["normalpha"] else al
+        UR = U.T @ Ytr
+        Wt += (Vh.T @ ((S[:, None] / (S[:, None] ** 2 + na[None, :] ** 2)) * UR)) / len(detail["outer"])
+    scale = max(float(np.abs(Wt).max()), 1e-30)
+    e_ours, e_oracle = float(np.abs(W - Wt).max()) / scale, float(np.abs(W_o - Wt).max()) / scale
+    tol = 2e-4 * np.abs(Wt) + 3e-6 * max(1.0, scale)       # (the comparison's own elementwise tolerance: assert_matches_oracle)
+    oracle_off = bool((np.abs(W_o - Wt) > tol).any())
+    return (oracle_off and e_ours <= e_oracle), e_ours, e_oracle
+
+
 forms = {}
 for case in range(n_cases):
     T = int(rng.integers(90, 420))
@@ -93,9 +121,27 @@ for case in range(n_cases):
         forms[key] = forms.get(key, 0) + 1
         print("ok  ", tag, "->", key, "side panel columns", model.last_fit.get("side_panel_cols"), flush=True)
     except Exception as e:                                   # noqa: BLE001
+        # a disagreement is only a failure where the oracle itself is right: the reference's arithmetic (fp32 normaliser, fp32
+        # SVD) carried out in float64 at the ORACLE's alphas is the referee -- when the oracle's own weights miss it by more
+        # than the comparison's tolerance (p > n with centred features and a tiny un-normalised alpha: the constant vector is
+        # a null direction of the Gram matrix, 1 / alpha^2 amplifies the fp32 residue of the centring) and ours are no
+        # further from it, the case says nothing about parity (tools/fuzz_case.py prints the details)
+        void = None
+        if isinstance(e, AssertionError) and not tt and "oracle" in locals() and "ours" in locals():
+            try:
+                void = referee(args[0], args[1], kw, detail, np.asarray(ours[1]), np.asarray(oracle[1]))
+            except Exception as e2:                          # noqa: BLE001
+                void = None
+                print("      (referee failed:", repr(e2)[:120], ")")
+        if void is not None and void[0]:
+            voids += 1
+            print("void", tag, f"-> the oracle misses the float64 result by {void[2]:.2g} of max|W| (beyond the comparison's tolerance), ours by "
+                  f"{void[1]:.2g}: ill-conditioned for the reference's fp32 arithmetic", flush=True)
+            continue
         fails += 1
         print("FAIL", tag, "\n     ", type(e).__name__, str(e)[:400], flush=True)
         if not isinstance(e, (AssertionError, ValueError)):
             traceback.print_exc()
-print(f"{n_cases - fails - skipped} of {n_cases - skipped} valid cases agree with the oracle ({skipped} rejected by both); forms: {forms}")
+print(f"{n_cases - fails - skipped - voids} of {n_cases - skipped - voids} valid cases agree with the oracle ({skipped} rejected by both"
+      + (f", {voids} void: the oracle itself misses the float64 result" if voids else "") + f"); forms: {forms}")
 sys.exit(1 if fails else 0)
