@@ -249,6 +249,25 @@ def _parse_stream_alias(text):
 
 
 _STREAM_ALIAS = _parse_stream_alias(os.environ.get("LITCODER_AMD_STREAM_ALIAS"))
+_STREAMS_TOUCHED = set()
+
+
+def _touch_streams(dev, order):
+    """Give the engine's streams their hardware queues in a FIXED order: the HIP runtime creates a stream's queue at its first
+    use and deals the process's four hardware queues out in that order, so which of the engine's streams share a queue --
+    and a resident cfg2 fit's 81 or 88 ms -- depended on whether the process's first fit had host or resident inputs
+    (tools/resident_after_host_ab.py).  ``order``: auxiliary stream numbers, "u" = the upload stream; once per device."""
+    key = (dev.type, dev.index)
+    if key in _STREAMS_TOUCHED or dev.type != "cuda":
+        return
+    _STREAMS_TOUCHED.add(key)
+    for item in order:
+        s = ops.upload_stream(dev) if item == "u" else _aux_stream(dev, int(item))
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(s):
+            ops.zeros((64,), torch.float32, dev)           # (a first command: the stream's queue exists from here on)
+            ev.record()
+        ev.synchronize()
 
 
 class _WideTargets(Exception):

@@ -13,7 +13,7 @@ import torch
 from .. import ops, series, stats
 from .._lib import COL_TILE, K_TILE, LC_MB, LC_NB, LC_SCORE_CORR, LC_SCORE_R2
 from ..dist import ShardContext, job_share
-from .common import (SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions, check_penalties, _PrimalUnsuitable, _WideTargets, _FoldResult, _aux_stream, _Range, _column_panels, _download_panels, _DeviceShapes, logger)
+from .common import (_touch_streams, SERIES_TERMS, SINGCUTOFF_REL, GROUPS_PER_LAUNCH, MAX_INNER_FOLDS, FitOptions, check_penalties, _PrimalUnsuitable, _WideTargets, _FoldResult, _aux_stream, _Range, _column_panels, _download_panels, _DeviceShapes, logger)
 
 
 class EngineCore:
@@ -151,6 +151,8 @@ class EngineCore:
             self.d_ser_scr = ops.upload(np.asarray(ser_scr, dtype=np.int32), self.dev)
             self.d_coef_scr = ops.upload(np.stack([series.minimax_inverse_coefficients(self.alphas[a], SERIES_TERMS)
                                                    for a in ser_scr]).astype(np.float64), self.dev)
+        if os.environ.get("LITCODER_AMD_STREAM_ORDER"):
+            _touch_streams(self.dev, [t.strip() for t in os.environ["LITCODER_AMD_STREAM_ORDER"].split(",") if t.strip()])
         self.aux = _aux_stream(self.dev)
         self.aux2 = _aux_stream(self.dev, 1)            # refit systems (see _refit_stream)
         # per-fold result exchange + global statistics (FitOptions.results_on_refit_stream: an experiment, see there)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What the bench's launch timers cost a host-to-host cfg2 fit: the same fits with the event timers of the two screening
-contractions on (as inside bench.py's timed region) and off, interleaved.   python tools/timer_overhead_ab.py [rounds]"""
+contractions on (as inside bench.py's timed region) and off, interleaved.   python tools/timer_overhead_ab.py [rounds] [resident]"""
 import os
 import sys
 import time
@@ -16,8 +16,10 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 V = 80000
 dev = ops.device(0)
 dX, dY, p = bench.synth_inputs(V, 0, dev)
-X, Y = bench.host_arrays(dX, dY, p, V)
-del dX, dY
+resident = "resident" in sys.argv[2:]
+if not resident:
+    X, Y = bench.host_arrays(dX, dY, p, V)
+    del dX, dY
 alphas = np.logspace(-1, 8, bench.A)
 model = NestedCVModel("ridge_regression")
 ts = {True: [], False: []}
@@ -27,7 +29,8 @@ for i in range(2 * rounds + 2):
     ops.timing_enable(on, only=["alpha_sweep_gemm", "series_sweep_gemm"] if on else None)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = model.fit_predict(X, Y, alphas=alphas, **bench.FIT_KW)
+    out = (model.fit_predict_device(dX, dY, p, V, alphas=alphas, **bench.FIT_KW) if resident
+           else model.fit_predict(X, Y, alphas=alphas, **bench.FIT_KW))
     torch.cuda.synchronize()
     dt = 1e3 * (time.perf_counter() - t0)
     ops.timing_enable(False)
