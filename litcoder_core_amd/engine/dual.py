@@ -273,7 +273,7 @@ class DualSweeps:
         part = torch.empty((max(Ad, 1) * M // LC_MB, 4, Vp_), dtype=torch.float32, device=self.dev)
         split, cs = hat["split"], hat["cs"]
         if hat.get("data_ready") is not None:
-            main.wait_event(hat["data_ready"])            # this fold's (normalised) targets and their column scales
+            main.wait_event(hat["data_ready"])            # a design of the fold's own (normalize_features), made on the auxiliary stream
         self.info.update(precision="f16x3" if split else "f32", fused_alphas=Ad,
                           series_terms=SERIES_TERMS if moments else 0, folds_per_launch=1)
         nbuf = F if moments else 1                        # two passes over the folds keep every fold's operands

@@ -119,7 +119,7 @@ class FoldPhases:
                 X, K = self._fold_design(metas[g[0]]["tr"])                  # per-fold design only when len(g) == 1
                 split = False if self.moments else self._split_assumed()     # the targets' side belongs to the ranges
                 data_ready = None
-                if self.primal or X is not self.dX or os.environ.get("LITCODER_AMD_DATA_READY_EVENT") == "1":
+                if self.primal or X is not self.dX:        # (a design of the fold's own was just made on this stream)
                     data_ready = torch.cuda.Event()
                     data_ready.record()
                 # S[0]^2 of the inner train sets and of the whole outer-train block (refit penalty scale,
