@@ -289,7 +289,13 @@ class MeanOperatorRefit:
                 new_slots.append(g)
                 mo["images"][tup] = (a_g, r_g)
             # (all new images in one launch: one per tuple was ~45 us of host time each, 1.8 ms at the tail of a cfg2 fit)
-            ops.mean_operator_images(new_mats, new_slots, maps, ents[0]["scale"], rows, Kd, At, rs_inv)
+            strides = {tuple(int(x.stride(0)) for x in ms) for ms in new_mats}
+            if len(strides) <= 1:
+                ops.mean_operator_images(new_mats, new_slots, maps, ents[0]["scale"], rows, Kd, At, rs_inv)
+            else:                                      # (a fold's operators with different row strides: image by image)
+                for ms, g in zip(new_mats, new_slots):
+                    ops.mean_operator_image(ms, maps, ents[0]["scale"], rows, Kd, At[g * rows_pad * Kd * 2:(g + 1) * rows_pad * Kd * 2],
+                                            rs_inv[g * rows_pad:(g + 1) * rows_pad])
             new_imgs = len(new_slots)
             C = torch.empty((rows, Vs), dtype=torch.float32, device=self.dev)
             ops.gemm_grouped_f16x3(At, rs_inv, rows, Yt, cs_s[1], C, Vs, Vs, Kd, [int(t) for t in start])
