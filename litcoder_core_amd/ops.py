@@ -415,7 +415,12 @@ class PanelUploader:
             _UPLOAD_LOCK.release()
             raise
         self.error = None
-        self.thread = threading.Thread(target=self._finish, name="lc-upload-finish", daemon=True)
+        # NOT a daemon thread: a process that ends while an upload is still in flight (an exception on the caller's way out,
+        # a script's last statement) must wait for it -- the interpreter joins this thread before it finalises.  As a daemon
+        # it came back from lc_upload_finish into a finalising interpreter, which ends such a thread with pthread_exit: a
+        # forced unwind through foreign frames, "terminate called without an active exception", SIGABRT at exit (seen once
+        # in some hundred fuzz-worker processes, round 6)
+        self.thread = threading.Thread(target=self._finish, name="lc-upload-finish", daemon=False)
         self.thread.start()
 
     def _finish(self):
